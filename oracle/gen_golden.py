@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Generate ``tests/golden/*.npz`` by running the REAL reference (``/root/reference/src``) on the case
+matrix of ``tests/cases.py``, and check ``oracle/allset_oracle.py`` against it.  TEST INFRASTRUCTURE.
+
+Container-only (needs /root/reference; uses ``oracle/ref_shim.py`` for the absent third-party
+wheels).  Usage:  ``python oracle/gen_golden.py``  -> rewrites tests/golden/ and
+tests/golden/REPORT.json (the oracle-vs-reference max-abs-diffs).
+
+Each fixture holds, for one case: the expected ``SetGNN`` logits, the raw outputs of
+``V2EConvs[0]`` / ``E2VConvs[0]``, d(loss)/dx and all parameter gradients for
+``loss = (logits * G).sum()`` (G = ``cases.cotangent``), eval mode with autograd on; the
+state_dict key/shape spec; input checksums; small cases also store the inputs themselves.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import cases  # noqa: E402
+from oracle import allset_oracle as oracle  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BIG_ROWS = 96           # rows of big per-row tensors kept in a fixture
+BIG_PARAM_NUMEL = 20000  # parameter grads above this size are stored as (sum, abs-sum, 64 samples)
+
+
+def sample_rows(n: int, name: str) -> np.ndarray:
+    rng = np.random.default_rng([cases.zlib.crc32(name.encode()) & 0x7FFFFFFF, 777])
+    return np.sort(rng.choice(n, size=min(BIG_ROWS, n), replace=False))
+
+
+def sample_flat(numel: int, key: str) -> np.ndarray:
+    rng = np.random.default_rng([cases.zlib.crc32(key.encode()) & 0x7FFFFFFF, 778])
+    return np.sort(rng.choice(numel, size=min(64, numel), replace=False))
+
+
+def run_reference(case: dict, ref_models):
+    args = case["args"]
+    x = torch.from_numpy(case["x"]).clone().requires_grad_(True)
+    ei = torch.from_numpy(case["edge_index"]).clone()      # SetGNN.forward mutates it (Q2)
+    norm = torch.from_numpy(case["norm"]).clone()
+    torch.manual_seed(0)
+    model = ref_models.SetGNN(args, norm=norm.to(torch.float32) if args.LearnMask else None)
+    spec = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    sd_np = cases.make_state_dict(spec, case["seed"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model.eval()
+    grabbed = {}
+    model.V2EConvs[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("v2e0", o))
+    model.E2VConvs[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("e2v0", o))
+    logits = model(SimpleNamespace(x=x, edge_index=ei, norm=norm))
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape))
+    (logits * G).sum().backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+    res = dict(logits=logits.detach(), v2e0=grabbed["v2e0"].detach(), e2v0=grabbed["e2v0"].detach(),
+               grad_x=x.grad.detach(), grads={k: g.detach() for k, g in grads.items()})
+    attn = None
+    if case["name"] == "rand50_pma_h4":
+        with torch.no_grad():
+            ei2 = torch.from_numpy(case["edge_index"]).clone()
+            ei2[1] -= ei2[1].min()
+            _, (_, attn) = model.V2EConvs[0].prop(torch.from_numpy(case["x"]), ei2, return_attention_weights=True)
+    return spec, sd_np, res, attn
+
+
+def run_oracle(case: dict, sd_np: dict):
+    args = case["args"]
+    sd = {k: torch.from_numpy(v).clone() for k, v in sd_np.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    x = torch.from_numpy(case["x"]).clone().requires_grad_(True)
+    ei = torch.from_numpy(case["edge_index"])
+    norm = torch.from_numpy(case["norm"])
+    collect = {}
+    logits = oracle.setgnn_forward(sd, args, x, ei, norm, collect)
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape))
+    (logits * G).sum().backward()
+    return dict(logits=logits.detach(), v2e0=collect["v2e0"].detach(), e2v0=collect["e2v0"].detach(),
+                grad_x=x.grad.detach(),
+                grads={k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()
+                       if v.requires_grad})
+
+
+def maxdiff(a: torch.Tensor, b: torch.Tensor) -> float:
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def main() -> None:
+    assert ref_shim.available(), "needs /root/reference"
+    _, ref_models = ref_shim.import_reference()
+    os.makedirs(GOLDEN, exist_ok=True)
+    report = {}
+    for name in cases.ALL_CASES:
+        case = cases.build_case(name)
+        spec, sd_np, ref, attn = run_reference(case, ref_models)
+        orc = run_oracle(case, sd_np)
+        diffs = {k: maxdiff(ref[k], orc[k]) for k in ("logits", "v2e0", "e2v0", "grad_x")}
+        scale = {k: float(ref[k].abs().max()) for k in ("logits", "v2e0", "e2v0", "grad_x")}
+        gd = 0.0
+        for k, g in ref["grads"].items():
+            if k in orc["grads"]:
+                gd = max(gd, maxdiff(g, orc["grads"][k]) / (1.0 + float(g.abs().max())))
+        worst = max(max(diffs[k] / (1.0 + scale[k]) for k in diffs), gd)
+        report[name] = dict(oracle_vs_reference_maxabs=diffs, param_grad_rel=gd, worst_rel=worst)
+        assert worst <= 1e-6 * (30 if case["big"] else 4), (name, diffs, gd)
+
+        out = {
+            "spec_keys": np.array([k for k, _ in spec]),
+            "spec_shapes": np.array([json.dumps(list(s)) for _, s in spec]),
+            "chk_x": np.int64(cases.checksum(case["x"])),
+            "chk_edge_index": np.int64(cases.checksum(case["edge_index"])),
+            "chk_norm": np.int64(cases.checksum(case["norm"])),
+            "n_rows_logits": np.int64(ref["logits"].shape[0]),
+            "n_rows_v2e0": np.int64(ref["v2e0"].shape[0]),
+            "n_rows_e2v0": np.int64(ref["e2v0"].shape[0]),
+        }
+        if not case["big"]:
+            out["in_x"], out["in_edge_index"], out["in_norm"] = case["x"], case["edge_index"], case["norm"]
+            for k in ("logits", "v2e0", "e2v0", "grad_x"):
+                out["out_" + k] = ref[k].numpy()
+            for k, g in ref["grads"].items():
+                out["grad_" + k] = g.numpy()
+        else:
+            for k in ("logits", "v2e0", "e2v0", "grad_x"):
+                rows = sample_rows(ref[k].shape[0], name + k)
+                out["rows_" + k] = rows
+                t = ref[k].numpy()[rows]
+                if t.shape[1] > 256:                      # grad_x of a 1433/3703-wide feature matrix
+                    t = t[:, :256]
+                out["out_" + k] = t
+                out["sum_" + k] = np.float64(ref[k].double().sum())
+                out["abs_" + k] = np.float64(ref[k].double().abs().sum())
+            for k, g in ref["grads"].items():
+                if g.numel() <= BIG_PARAM_NUMEL:
+                    out["grad_" + k] = g.numpy()
+                else:
+                    idx = sample_flat(g.numel(), name + k)
+                    out["gidx_" + k] = idx
+                    out["gval_" + k] = g.numpy().reshape(-1)[idx]
+                    out["gsum_" + k] = np.float64(g.double().sum())
+                    out["gabs_" + k] = np.float64(g.double().abs().sum())
+        if attn is not None:
+            out["attn_v2e0"] = attn.numpy()
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+        print(f"{name:28s} worst_rel={worst:.2e}  logits{tuple(ref['logits'].shape)} "
+              f"nnz={case['edge_index'].shape[1]}")
+    with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
+        json.dump(dict(generator="oracle/gen_golden.py", torch=torch.__version__, numpy=np.__version__,
+                       note="oracle (allset_oracle.py) vs reference (under ref_shim.py), max-abs diffs",
+                       cases=report), f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+"""Deterministic parity cases (pure numpy, seeded) shared by ``oracle/gen_golden.py`` (which runs the
+real reference on them in the build container) and by the tests (which re-create the same inputs on
+the GPU box, where the reference does not exist, and compare against ``tests/golden/*.npz``).
+
+Case matrix = SURVEY.md section 8(c3).  Small cases store their inputs inside the fixture as well; the two
+dataset-shaped cases (Cora-/Citeseer-shaped stand-ins, SURVEY F3: the real pickles are absent)
+store only input checksums + expected outputs to keep fixtures small.
+"""
+from __future__ import annotations
+
+import zlib
+from types import SimpleNamespace
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# mode -> SetGNN args
+# --------------------------------------------------------------------------------------
+
+MODES = {
+    "ds_add": dict(PMA=False, aggregate="add", heads=1),
+    "ds_mean": dict(PMA=False, aggregate="mean", heads=1),
+    "ds_max": dict(PMA=False, aggregate="max", heads=1),
+    "pma_h1": dict(PMA=True, aggregate="add", heads=1),
+    "pma_h4": dict(PMA=True, aggregate="add", heads=4),
+}
+
+
+def make_args(mode: str, num_features: int, hidden: int, num_classes: int, **over) -> SimpleNamespace:
+    a = dict(All_num_layers=1, dropout=0.5, aggregate="add", normalization="ln", deepset_input_norm=True,
+             GPR=False, LearnMask=False, num_features=num_features, MLP_hidden=hidden, MLP_num_layers=2,
+             heads=1, PMA=True, Classifier_hidden=64, Classifier_num_layers=1, num_classes=num_classes)
+    a.update(MODES[mode])
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+# --------------------------------------------------------------------------------------
+# hypergraph builders: return edge_index [2, nnz] int64, row0 = vertex ids, row1 = hyperedge ids
+# starting at n_v (the layout train.py hands to SetGNN), sorted by vertex id.
+# --------------------------------------------------------------------------------------
+
+
+def _finish(pairs: Sequence[Tuple[int, int]], n_v: int, self_loops: bool) -> np.ndarray:
+    v = np.array([p[0] for p in pairs], dtype=np.int64)
+    e = np.array([p[1] for p in pairs], dtype=np.int64)
+    n_e = int(e.max()) + 1 if e.size else 0
+    if self_loops:
+        # one new singleton hyperedge per vertex that is not already alone in some hyperedge
+        sizes = np.bincount(e, minlength=n_e)
+        alone = set(v[sizes[e] == 1].tolist())
+        extra_v = np.array([i for i in range(n_v) if i not in alone], dtype=np.int64)
+        extra_e = n_e + np.arange(extra_v.size, dtype=np.int64)
+        v = np.concatenate([v, extra_v])
+        e = np.concatenate([e, extra_e])
+    order = np.argsort(v, kind="stable")
+    return np.stack([v[order], e[order] + n_v])
+
+
+def doc_hypergraph(self_loops: bool) -> Tuple[np.ndarray, int]:
+    """{0,1,2},{1,2,3} (the docstring example at reference layers.py:332-343) + isolated vertex 4."""
+    pairs = [(0, 0), (1, 0), (2, 0), (1, 1), (2, 1), (3, 1)]
+    return _finish(pairs, 5, self_loops), 5
+
+
+def random_hypergraph(rng: np.random.Generator, n_v: int, n_e: int, nnz: int, self_loops: bool
+                      ) -> np.ndarray:
+    """nnz distinct (vertex, hyperedge) pairs, uniformly; every hyperedge id gets >= 1 member."""
+    chosen = set()
+    for e in range(n_e):
+        chosen.add((int(rng.integers(n_v)), e))
+    while len(chosen) < nnz:
+        chosen.add((int(rng.integers(n_v)), int(rng.integers(n_e))))
+    return _finish(sorted(chosen), n_v, self_loops)
+
+
+def edge_case_hypergraph(rng: np.random.Generator) -> Tuple[np.ndarray, int]:
+    """size-1 segment, an empty interior hyperedge id, an empty interior vertex, duplicated
+    incidences, one hyperedge of 4096 members."""
+    n_v = 5000
+    pairs: List[Tuple[int, int]] = []
+    pairs += [(7, 0)]                                     # hyperedge 0: size 1
+    pairs += [(1, 1), (2, 1), (2, 1), (2, 1), (9, 1)]     # hyperedge 1: duplicates
+    # hyperedge 2: empty (no incidence mentions it)
+    big = rng.choice(np.arange(10, n_v), size=4096, replace=False)
+    pairs += [(int(v), 3) for v in big]                   # hyperedge 3: 4096 members
+    for e in range(4, 40):                                # ragged small ones
+        k = int(rng.integers(1, 70))
+        for v in rng.choice(np.arange(10, n_v), size=k, replace=False):
+            pairs.append((int(v), e))
+    pairs += [(n_v - 1, 40), (0, 40)]                     # make the last vertex id present
+    # vertices 3..6 and 8 never appear -> empty interior vertex segments on the E->V side
+    return _finish(pairs, n_v, False), n_v
+
+
+def dataset_shaped(rng: np.random.Generator, n_v: int, n_e: int, mean_size: float) -> np.ndarray:
+    pairs = set()
+    for e in range(n_e):
+        k = max(1, int(rng.poisson(mean_size - 1)) + 1)
+        for v in rng.choice(n_v, size=min(k, n_v), replace=False):
+            pairs.add((int(v), e))
+    return _finish(sorted(pairs), n_v, True)
+
+
+def bow_features(rng: np.random.Generator, n: int, f: int, density: float = 0.012) -> np.ndarray:
+    """row-normalised sparse binary bag-of-words, the shape of the citation datasets' features."""
+    x = (rng.random((n, f)) < density).astype(np.float32)
+    x[np.arange(n), rng.integers(f, size=n)] = 1.0
+    return x / x.sum(axis=1, keepdims=True)
+
+
+# --------------------------------------------------------------------------------------
+# parameters: filled from a per-key seeded stream so any implementation with the reference's
+# state_dict layout can be loaded with identical values without storing them.
+# --------------------------------------------------------------------------------------
+
+
+def fill_param(key: str, shape: Sequence[int], seed: int, dtype: str = "float32") -> np.ndarray:
+    rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+    shape = tuple(int(s) for s in shape)
+    if key.endswith("num_batches_tracked"):
+        return np.zeros(shape, dtype=np.int64)
+    if key.endswith("running_var"):
+        return (0.5 + rng.random(shape)).astype(dtype)
+    if key.endswith("running_mean"):
+        return (0.1 * rng.standard_normal(shape)).astype(dtype)
+    if "normalizations" in key or ".ln0." in key or ".ln1." in key or key.startswith("bn"):
+        if key.endswith("weight"):
+            return (1.0 + 0.1 * rng.standard_normal(shape)).astype(dtype)
+        return (0.1 * rng.standard_normal(shape)).astype(dtype)
+    if key.endswith("att_r"):
+        return (0.5 * rng.standard_normal(shape)).astype(dtype)
+    if key == "Importance":
+        return (0.5 + rng.random(shape)).astype(dtype)
+    fan_in = shape[-1] if len(shape) >= 2 else max(shape[0], 1)
+    bound = 1.0 / np.sqrt(fan_in)
+    return rng.uniform(-bound, bound, size=shape).astype(dtype)
+
+
+def make_state_dict(spec: Sequence[Tuple[str, Sequence[int]]], seed: int) -> Dict[str, np.ndarray]:
+    return {k: fill_param(k, s, seed) for k, s in spec}
+
+
+# --------------------------------------------------------------------------------------
+# the case table
+# --------------------------------------------------------------------------------------
+
+
+def _norm_deg_half_sym(ei: np.ndarray) -> np.ndarray:
+    """D_v^-1/2 * D_e^-1/2 per incidence (reference preprocessing.py:456-463), float32."""
+    v, e = ei[0], ei[1] - ei[1].min()
+    dv = np.bincount(v).astype(np.float64)
+    de = np.bincount(e).astype(np.float64)
+    return (dv[v] ** -0.5 * de[e] ** -0.5).astype(np.float32)
+
+
+def build_case(name: str) -> dict:
+    """Return dict(name, args, x, edge_index, norm, seed, cotangent_seed, big)."""
+    seed = zlib.crc32(name.encode()) & 0x7FFFFFFF
+    rng = np.random.default_rng(seed)
+    big = False
+    over = {}
+    if name.startswith("doc_"):
+        _, sl, mode = name.split("_", 2)
+        ei, n_v = doc_hypergraph(sl == "self")
+        f, d, k = 8, 16, 3
+        x = rng.standard_normal((n_v, f)).astype(np.float32)
+    elif name.startswith("rand50_"):
+        mode = name[len("rand50_"):]
+        suffixes = {"_wnorm": ("_wnorm", True), "_L2": ("All_num_layers", 2),
+                    "_bn": ("normalization", "bn"), "_mask": ("LearnMask", True)}
+        stripped = True
+        while stripped:
+            stripped = False
+            for suf, (key, val) in suffixes.items():
+                if mode.endswith(suf):
+                    mode, stripped = mode[:-len(suf)], True
+                    over[key] = val
+        n_v, f, d, k = 50, 16, 64, 7
+        ei = random_hypergraph(rng, n_v, 20, 200, True)
+        x = rng.standard_normal((n_v, f)).astype(np.float32)
+    elif name.startswith("edge_"):
+        mode = name[len("edge_"):]
+        ei, n_v = edge_case_hypergraph(rng)
+        f, d, k = 12, 32, 4
+        x = rng.standard_normal((n_v, f)).astype(np.float32)
+    elif name == "cora_ds_add":          # BASELINE.json configs[0] shape (stand-in data)
+        mode, big = "ds_add", True
+        n_v, f, d, k = 2708, 1433, 64, 7
+        ei = dataset_shaped(rng, n_v, 1579, 3.03)
+        x = bow_features(rng, n_v, f)
+    elif name == "citeseer_pma_h4":      # BASELINE.json configs[1] shape (stand-in data)
+        mode, big = "pma_h4", True
+        n_v, f, d, k = 3312, 3703, 128, 6
+        ei = dataset_shaped(rng, n_v, 1079, 3.2)
+        x = bow_features(rng, n_v, f, 0.009)
+    else:
+        raise KeyError(name)
+    wnorm = over.pop("_wnorm", False)
+    args = make_args(mode, f, d, k, **over)
+    norm = _norm_deg_half_sym(ei) if wnorm else np.ones(ei.shape[1], dtype=np.int64)
+    return dict(name=name, args=args, x=x, edge_index=ei, norm=norm, seed=seed, big=big)
+
+
+def cotangent(name: str, shape: Sequence[int]) -> np.ndarray:
+    """Fixed random cotangent G for loss = (logits * G).sum() (transpose-sensitive, unlike ones)."""
+    rng = np.random.default_rng([zlib.crc32(name.encode()) & 0x7FFFFFFF, 12345])
+    return rng.standard_normal(tuple(shape)).astype(np.float32)
+
+
+SMALL_CASES: List[str] = (
+    [f"doc_{sl}_{m}" for sl in ("noself", "self") for m in MODES]
+    + [f"rand50_{m}" for m in MODES]
+    + ["rand50_ds_add_wnorm", "rand50_ds_mean_wnorm", "rand50_ds_add_L2", "rand50_pma_h4_L2",
+       "rand50_ds_add_bn", "rand50_ds_add_wnorm_mask"]
+    + [f"edge_{m}" for m in MODES]
+)
+BIG_CASES: List[str] = ["cora_ds_add", "citeseer_pma_h4"]
+ALL_CASES: List[str] = SMALL_CASES + BIG_CASES
+
+
+def checksum(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
