@@ -1,0 +1,101 @@
+"""ctypes binding of ``liballset_hip.so`` (C ABI: ``include/allset_hip.h``).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, this raises.
+``import torch`` must precede the ``CDLL`` so that the library's ``libamdhip64.so.7`` dependency
+binds to the HIP runtime torch has already mapped (one runtime per process: device pointers and
+streams are shared with torch).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+import torch  # noqa: F401  (must be imported before the CDLL below)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
+ABI_VERSION = 1
+
+SUM, MEAN, MAX, MIN = 0, 1, 2, 3
+F32, BF16 = 0, 1
+REDUCE_CODES = {"add": SUM, "sum": SUM, "mean": MEAN, "max": MAX, "min": MIN}
+
+# name -> argtypes, in the order of include/allset_hip.h.  Every function returns int except
+# allset_last_error.
+_P = c_void_p
+SIGNATURES = {
+    "allset_version": [],
+    "allset_csr_build_workspace_bytes": [c_int64, c_int64, POINTER(c_size_t)],
+    "allset_csr_build": [_P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P],
+    "allset_segreduce_fwd": [c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P],
+    "allset_segmax_bwd": [_P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_sddmm_rowdot": [c_int, _P, _P, _P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P],
+    "allset_pma_fwd": [c_int, _P, _P, _P, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_pma_attention": [_P, _P, _P, _P, _P, c_float, _P, c_int64, c_int64, _P],
+    "allset_pma_bwd_stats": [c_int, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, _P],
+    "allset_pma_bwd_src": [c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,
+                           c_int64, c_int64, c_int64, c_int64, _P],
+}
+EXPORTED_SYMBOLS = sorted(list(SIGNATURES) + ["allset_last_error"])
+
+
+class AllSetHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library; raises if it is absent or has the wrong ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AllSetHipError(
+            f"{LIB_PATH} not found: build it with `python -m allset_amd.build` "
+            "(allset_amd has no CPU / eager fallback for the aggregation path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.allset_last_error.argtypes = []
+    lib.allset_last_error.restype = c_char_p
+    got = lib.allset_version()
+    if got != ABI_VERSION:
+        raise AllSetHipError(f"liballset_hip.so ABI version {got}, python binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().allset_last_error().decode("utf-8", "replace")
+        raise AllSetHipError(f"{what} failed with status {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_of(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(*tensors) -> torch.device:
+    """All tensors must live on one ROCm device; CPU tensors are refused (no fallback)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AllSetHipError(
+                "allset_amd aggregation kernels need ROCm device tensors; got a CPU tensor "
+                "(there is no CPU fallback -- the CPU restatement lives in oracle/ and is test-only)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise AllSetHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev

@@ -1,0 +1,69 @@
+"""Compile ``allset_amd/csrc/*.hip`` for gfx950 into the in-tree ``allset_amd/liballset_hip.so``.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the built ``.so`` is
+git-ignored but travels to the GPU box with the gpurun snapshot.  ``python -m allset_amd.build``.
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+BUILD_DIR = os.path.join(PKG_DIR, "csrc", "build")
+LIB_PATH = os.path.join(PKG_DIR, "liballset_hip.so")
+ARCH = "gfx950"
+SOURCES = ["abi.hip", "csr_build.hip", "segreduce.hip", "pma.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "allset_hip.h")]
+CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
+            "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; cannot build liballset_hip.so")
+    return exe
+
+
+def _stale(target: str, deps: List[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(BUILD_DIR, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if force or _stale(obj, [path] + HEADERS):
+        cmd = [_hipcc()] + CXXFLAGS + ["-c", path, "-o", obj]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{res.stdout}\n{res.stderr}")
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Build (if stale) and return the path of liballset_hip.so."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    if force or _stale(LIB_PATH, objs):
+        # libamdhip64 is resolved at load time against the copy torch has already mapped (same SONAME)
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(f"built {LIB_PATH} ({os.path.getsize(LIB_PATH)} bytes)")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv, verbose=True)

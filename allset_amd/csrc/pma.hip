@@ -1,0 +1,400 @@
+// PMA (multi-head softmax-attention pooling with a source-only logit) for gfx950.
+// Replaces, per direction, the ~10 tensor ops of reference layers.py:145,168-194 (two index_select
+// lifts, leaky_relu, the 6-temporary segment softmax, the [nnz,H,C] product and the scatter-add)
+// with one gather pass forward and ONE gather pass backward:
+//
+//   forward  (target-major CSR):  per target row, each lane owns 16 B of one head's channels and
+//            runs its own online softmax over the incidences (running max m, running sum l,
+//            rescaled accumulator) -- the logit alpha[src,h] is a 4-byte load that rides along
+//            with the 16-byte V gather, so no cross-lane traffic is needed until the NS slots of
+//            the wave are merged at the end.  Saves m,l per (target, head).
+//   backward (source-major CSR):  p_j is recomputed from (alpha[s,h], m[t,h], l[t,h]); because p_j
+//            is identical in all lanes of a head, sum_j p_j*(<V_s,gO_t> - delta_t) commutes with the
+//            cross-lane dot product, so lanes accumulate partial dots over the whole row and the
+//            per-head reduction happens once per ROW, not once per incidence.  No [nnz,H] or
+//            [nnz,H,C] temporary exists anywhere (math: SURVEY.md A.5).
+//
+// Lane layout is the one of segreduce.hip: LPR lanes x VEC f32 cover a feature row, NS = 64/LPR
+// incidences are gathered per wave-wide load.  A lane's VEC channels never straddle a head (C % VEC == 0).
+#include <float.h>
+
+#include "common.h"
+
+namespace allset {
+
+constexpr int kPmaUnroll = 8;
+constexpr int kMaxHeads = 256;   // per-wave LDS accumulators for the per-head scalars of the backward
+constexpr float kSoftmaxEps = 1e-16f;   // torch_geometric.utils.softmax denominator guard [external]
+
+// Sum `val` over the lanes [grp_start, grp_end) of this lane's LPR-lane row group; valid in lane grp_start.
+template <int LPR>
+__device__ __forceinline__ float head_group_reduce(float val, int li, int grp_end) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) {
+    const float o = __shfl_down(val, off);
+    if (li + off < grp_end) val += o;
+  }
+  return val;
+}
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
+    const float* __restrict__ V, int64_t ldv, float slope, float* __restrict__ out, int64_t ldo,
+    float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C) {
+  constexpr int NS = kWave / LPR;
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_t) return;
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int start = rowptr[row], end = rowptr[row + 1];
+  const int d = H * C;
+
+  for (int cb = 0; cb < d; cb += LPR * VEC) {
+    const int c0 = cb + li * VEC;
+    const bool active = c0 < d;
+    const int h = active ? c0 / C : 0;
+    float m = -FLT_MAX, l = 0.f;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+
+    for (int base = start; base < end; base += kWave) {
+      const int n = min(kWave, end - base);
+      const int my_col = (lane < n) ? col[base + lane] : 0;
+      for (int j = 0; j < n; j += NS * kPmaUnroll) {
+        FVec<VEC> v[kPmaUnroll];
+        float a[kPmaUnroll];
+        bool ok[kPmaUnroll];
+#pragma unroll
+        for (int u = 0; u < kPmaUnroll; ++u) {
+          const int jj = j + u * NS + slot;
+          ok[u] = (jj < n) && active;
+          const int src = __shfl(my_col, jj & (kWave - 1));
+          if (ok[u]) {
+            a[u] = alpha[static_cast<int64_t>(src) * H + h];
+            v[u] = load_vec<VEC>(V + static_cast<int64_t>(src) * ldv + c0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kPmaUnroll; ++u) {
+          if (ok[u]) {
+            const float av = leaky_relu(a[u], slope);
+            const float m_new = fmaxf(m, av);
+            const float sc = __expf(m - m_new);       // 0 on the first incidence (m = -FLT_MAX)
+            const float pe = __expf(av - m_new);
+            l = fmaf(l, sc, pe);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(acc[k], sc, pe * v[u].v[k]);
+            m = m_new;
+          }
+        }
+      }
+    }
+
+    // merge the NS slots' (m, l, acc) triples
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+      const float mo = __shfl_xor(m, off);
+      const float lo = __shfl_xor(l, off);
+      const float m_new = fmaxf(m, mo);
+      const float s1 = __expf(m - m_new), s2 = __expf(mo - m_new);   // both -FLT_MAX -> exp(0) * (l = 0)
+      l = l * s1 + lo * s2;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float ao = __shfl_xor(acc[k], off);
+        acc[k] = acc[k] * s1 + ao * s2;
+      }
+      m = m_new;
+    }
+
+    if (slot == 0 && active) {
+      const float inv = l > 0.f ? 1.f / (l + kSoftmaxEps) : 0.f;   // empty row -> 0
+      FVec<VEC> r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r.v[k] = acc[k] * inv;
+      store_vec<VEC>(out + static_cast<int64_t>(row) * ldo + c0, r);
+      if (c0 % C == 0) {
+        m_out[static_cast<int64_t>(row) * H + h] = l > 0.f ? m : 0.f;
+        l_out[static_cast<int64_t>(row) * H + h] = l;
+      }
+    }
+  }
+}
+
+// p[j,h] in CSR order, for return_attention_weights
+__global__ __launch_bounds__(kBlock) void pma_attention_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
+    const float* __restrict__ m, const float* __restrict__ l, float slope, float* __restrict__ p, int n_t, int H) {
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_t) return;
+  const int lane = lane_id();
+  const int start = rowptr[row], end = rowptr[row + 1];
+  const int64_t items = static_cast<int64_t>(end - start) * H;
+  for (int64_t k = lane; k < items; k += kWave) {
+    const int inc = static_cast<int>(k / H), h = static_cast<int>(k % H);
+    const float a = leaky_relu(alpha[static_cast<int64_t>(col[start + inc]) * H + h], slope);
+    const int64_t th = static_cast<int64_t>(row) * H + h;
+    p[(static_cast<int64_t>(start) + inc) * H + h] = __expf(a - m[th]) / (l[th] + kSoftmaxEps);
+  }
+}
+
+// stats[t,h] = {m, 1/(l+eps), <out[t,h,:], gout[t,h,:]>, 0}
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
+    const float* __restrict__ out, int64_t ldo, const float* __restrict__ gout, int64_t ldg,
+    const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int n_t, int H, int C) {
+  __shared__ float red[kWavesPerBlock][kMaxHeads];
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int wave = threadIdx.x >> 6;
+  const int row = static_cast<int>(blk) * kWavesPerBlock + wave;
+  if (row >= n_t) return;
+  const int lane = lane_id();
+  const int li = lane % LPR, slot = lane / LPR;
+  const int d = H * C, G = C / VEC;
+  for (int h = lane; h < H; h += kWave) red[wave][h] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  for (int cb = 0; cb < d; cb += LPR * VEC) {
+    const int c0 = cb + li * VEC;
+    const bool active = (c0 < d) && slot == 0;
+    const int h = (c0 < d) ? c0 / C : 0;
+    const int q = (c0 < d) ? (c0 % C) / VEC : 0;
+    float part = 0.f;
+    if (active) {
+      const FVec<VEC> o = load_vec<VEC>(out + static_cast<int64_t>(row) * ldo + c0);
+      const FVec<VEC> g = load_vec<VEC>(gout + static_cast<int64_t>(row) * ldg + c0);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) part = fmaf(o.v[k], g.v[k], part);
+    }
+    const int n_act = min(LPR, (d - cb) / VEC);
+    const int grp_end = min(li - q + G, n_act);
+    part = head_group_reduce<LPR>(part, li, grp_end);
+    if (active && (q == 0 || li == 0)) atomicAdd(&red[wave][h], part);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  for (int h = lane; h < H; h += kWave) {
+    const int64_t th = static_cast<int64_t>(row) * H + h;
+    const float lv = l[th];
+    float4 s;
+    s.x = m[th];
+    s.y = lv > 0.f ? 1.f / (lv + kSoftmaxEps) : 0.f;
+    s.z = red[wave][h];
+    s.w = 0.f;
+    *reinterpret_cast<float4*>(stats + th * 4) = s;
+  }
+}
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
+    const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
+    const float* __restrict__ V, int64_t ldv, const float* __restrict__ gout, int64_t ldg,
+    const float* __restrict__ stats, float slope, float* __restrict__ gV, int64_t ldgv,
+    float* __restrict__ galpha, int n_s, int H, int C) {
+  constexpr int NS = kWave / LPR;
+  __shared__ float red[kWavesPerBlock][kMaxHeads];
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int wave = threadIdx.x >> 6;
+  const int row = static_cast<int>(blk) * kWavesPerBlock + wave;
+  if (row >= n_s) return;
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int start = rowptrT[row], end = rowptrT[row + 1];
+  const int d = H * C, G = C / VEC;
+  for (int h = lane; h < H; h += kWave) red[wave][h] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  for (int cb = 0; cb < d; cb += LPR * VEC) {
+    const int c0 = cb + li * VEC;
+    const bool active = c0 < d;
+    const int h = active ? c0 / C : 0;
+    const int q = active ? (c0 % C) / VEC : 0;
+    FVec<VEC> vown;
+    float a_s = 0.f;
+    if (active) {
+      vown = load_vec<VEC>(V + static_cast<int64_t>(row) * ldv + c0);
+      a_s = leaky_relu(alpha[static_cast<int64_t>(row) * H + h], slope);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) vown.v[k] = 0.f;
+    }
+    float gv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) gv[k] = 0.f;
+    float S = 0.f, D = 0.f;
+
+    for (int base = start; base < end; base += kWave) {
+      const int n = min(kWave, end - base);
+      const int my_col = (lane < n) ? colT[base + lane] : 0;
+      for (int j = 0; j < n; j += NS * kPmaUnroll) {
+        FVec<VEC> g[kPmaUnroll];
+        float4 st[kPmaUnroll];
+        bool ok[kPmaUnroll];
+#pragma unroll
+        for (int u = 0; u < kPmaUnroll; ++u) {
+          const int jj = j + u * NS + slot;
+          ok[u] = (jj < n) && active;
+          const int t = __shfl(my_col, jj & (kWave - 1));
+          if (ok[u]) {
+            g[u] = load_vec<VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
+            st[u] = *reinterpret_cast<const float4*>(stats + (static_cast<int64_t>(t) * H + h) * 4);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kPmaUnroll; ++u) {
+          if (ok[u]) {
+            const float p = __expf(a_s - st[u].x) * st[u].y;
+            float dotp = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+              gv[k] = fmaf(p, g[u].v[k], gv[k]);
+              dotp = fmaf(vown.v[k], g[u].v[k], dotp);
+            }
+            S = fmaf(p, dotp, S);
+            D = fmaf(p, st[u].z, D);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) gv[k] += __shfl_xor(gv[k], off);
+      S += __shfl_xor(S, off);
+      D += __shfl_xor(D, off);
+    }
+    if (slot == 0 && active) {
+      FVec<VEC> r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r.v[k] = gv[k];
+      store_vec<VEC>(gV + static_cast<int64_t>(row) * ldgv + c0, r);
+    }
+    // per-head: sum_lanes S  -  D (D is identical in every lane of the head; subtract it once)
+    const int n_act = min(LPR, (d - cb) / VEC);
+    const int grp_end = min(li - q + G, n_act);
+    float part = (slot == 0 && active) ? S : 0.f;
+    part = head_group_reduce<LPR>(part, li, grp_end);
+    if (slot == 0 && active && (q == 0 || li == 0)) atomicAdd(&red[wave][h], part - (q == 0 ? D : 0.f));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  for (int h = lane; h < H; h += kWave) {
+    const float av = alpha[static_cast<int64_t>(row) * H + h];
+    galpha[static_cast<int64_t>(row) * H + h] = (av > 0.f ? 1.f : slope) * red[wave][h];
+  }
+}
+
+static inline unsigned row_grid(int64_t rows) { return static_cast<unsigned>((rows + kWavesPerBlock - 1) / kWavesPerBlock); }
+
+static inline int pick_lpr(int64_t d) {
+  const int64_t need = (d + 3) / 4;
+  int lpr = 8;
+  while (lpr < need && lpr < 64) lpr <<= 1;
+  return lpr;
+}
+
+#define ALLSET_PMA_DISPATCH(KERNEL, GRID, ST, ...)                                       \
+  do {                                                                                   \
+    if (vec4) {                                                                          \
+      switch (pick_lpr(d)) {                                                             \
+        case 8:  KERNEL<4, 8><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;              \
+        case 16: KERNEL<4, 16><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;             \
+        case 32: KERNEL<4, 32><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;             \
+        default: KERNEL<4, 64><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;             \
+      }                                                                                  \
+    } else {                                                                             \
+      KERNEL<1, 64><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__);                               \
+    }                                                                                    \
+  } while (0)
+
+static int check_pma_dims(const char* who, int64_t n_a, int64_t n_b, int64_t H, int64_t C) {
+  ALLSET_REQUIRE(n_a >= 0 && n_b >= 0, "%s: negative size", who);
+  ALLSET_REQUIRE(H >= 1 && C >= 1, "%s: heads/channels must be >= 1", who);
+  ALLSET_REQUIRE(n_a < INT32_MAX && n_b < INT32_MAX && H * C < INT32_MAX, "%s: size exceeds int32", who);
+  if (H > kMaxHeads) {
+    set_error("%s: heads=%lld exceeds the built maximum %d", who, static_cast<long long>(H), kMaxHeads);
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  return ALLSET_OK;
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* col, const float* alpha,
+                              const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m, float* l,
+                              int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
+  clear_error();
+  int rc = check_pma_dims("pma_fwd", n_t, n_s, H, C);
+  if (rc != ALLSET_OK) return rc;
+  if (dtype != ALLSET_F32) { set_error("pma_fwd: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION); return ALLSET_ERR_UNSUPPORTED; }
+  if (n_t == 0) return ALLSET_OK;
+  const int64_t d = H * C;
+  ALLSET_REQUIRE(rowptr && out && m && l, "pma_fwd: null rowptr/out/m/l");
+  ALLSET_REQUIRE(n_s == 0 || (col && alpha && V), "pma_fwd: null col/alpha/V with n_s > 0");
+  ALLSET_REQUIRE(ldv >= d && ldo >= d, "pma_fwd: leading dimension smaller than H*C");
+  const bool vec4 = (C % 4 == 0) && (ldv % 4 == 0) && (ldo % 4 == 0) && aligned16(V) && aligned16(out);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  ALLSET_PMA_DISPATCH(pma_fwd_kernel, row_grid(n_t), st, rowptr, col, alpha, static_cast<const float*>(V), ldv, slope,
+                      static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_pma_attention(const int32_t* rowptr, const int32_t* col, const float* alpha, const float* m,
+                                    const float* l, float slope, float* p, int64_t n_t, int64_t H, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n_t >= 0 && H >= 1 && n_t < INT32_MAX && H < INT32_MAX, "pma_attention: bad size");
+  if (n_t == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rowptr && col && alpha && m && l && p, "pma_attention: null pointer");
+  pma_attention_kernel<<<row_grid(n_t), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      rowptr, col, alpha, m, l, slope, p, static_cast<int>(n_t), static_cast<int>(H));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg,
+                                    const float* m, const float* l, float* stats, int64_t n_t, int64_t H, int64_t C,
+                                    void* stream) {
+  clear_error();
+  int rc = check_pma_dims("pma_bwd_stats", n_t, 0, H, C);
+  if (rc != ALLSET_OK) return rc;
+  if (dtype != ALLSET_F32) { set_error("pma_bwd_stats: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION); return ALLSET_ERR_UNSUPPORTED; }
+  if (n_t == 0) return ALLSET_OK;
+  const int64_t d = H * C;
+  ALLSET_REQUIRE(out && gout && m && l && stats, "pma_bwd_stats: null pointer");
+  ALLSET_REQUIRE(ldo >= d && ldg >= d, "pma_bwd_stats: leading dimension smaller than H*C");
+  ALLSET_REQUIRE(aligned16(stats), "pma_bwd_stats: stats must be 16-byte aligned");
+  const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (ldg % 4 == 0) && aligned16(out) && aligned16(gout);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  ALLSET_PMA_DISPATCH(pma_bwd_stats_kernel, row_grid(n_t), st, static_cast<const float*>(out), ldo,
+                      static_cast<const float*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
+                      static_cast<int>(C));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT, const float* alpha,
+                                  const void* V, int64_t ldv, const void* gout, int64_t ldg, const float* stats,
+                                  float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t,
+                                  int64_t H, int64_t C, void* stream) {
+  clear_error();
+  int rc = check_pma_dims("pma_bwd_src", n_s, n_t, H, C);
+  if (rc != ALLSET_OK) return rc;
+  if (dtype != ALLSET_F32) { set_error("pma_bwd_src: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION); return ALLSET_ERR_UNSUPPORTED; }
+  if (n_s == 0) return ALLSET_OK;
+  const int64_t d = H * C;
+  ALLSET_REQUIRE(rowptrT && alpha && V && gV && galpha, "pma_bwd_src: null pointer");
+  ALLSET_REQUIRE(n_t == 0 || (colT && gout && stats), "pma_bwd_src: null colT/gout/stats with n_t > 0");
+  ALLSET_REQUIRE(ldv >= d && ldg >= d && ldgv >= d, "pma_bwd_src: leading dimension smaller than H*C");
+  ALLSET_REQUIRE(stats == nullptr || aligned16(stats), "pma_bwd_src: stats must be 16-byte aligned");
+  const bool vec4 = (C % 4 == 0) && (ldv % 4 == 0) && (ldg % 4 == 0) && (ldgv % 4 == 0) && aligned16(V) &&
+                    aligned16(gout) && aligned16(gV);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  ALLSET_PMA_DISPATCH(pma_bwd_src_kernel, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const float*>(V), ldv,
+                      static_cast<const float*>(gout), ldg, stats, slope, static_cast<float*>(gV), ldgv, galpha,
+                      static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

@@ -1,0 +1,330 @@
+// Deep Sets aggregation kernels for gfx950:  out[t,:] = reduce_j w[j] * x[col[j],:]  over CSR rows.
+// Replaces the index_select -> mul -> torch_scatter.scatter triple of reference layers.py:633-656
+// (three [nnz,d] temporaries + atomics) with ONE gather pass: rows are never materialised per
+// incidence, the segment is reduced in registers and written once, coalesced, without atomics.
+//
+// Mapping to the machine (CDNA4, wave = 64):
+//   * one wavefront per CSR row, 4 rows per 256-thread workgroup;
+//   * a feature row of d f32 is covered by LPR lanes x 16 B (VEC = 4); with d = 128 that is 32
+//     lanes = one 512-B row per half-wave, so a single global_load_dwordx4 gathers NS = 64/LPR
+//     different source rows at once (two for d = 128) -- every lane always moves 16 B;
+//   * the up-to-64 column ids of the row are fetched with ONE coalesced load (lane j holds id j)
+//     and broadcast with ds_bpermute, so the U*NS row gathers of an unrolled step are independent
+//     loads issued back-to-back (U = 8: 8 KiB in flight per wave, > 1 MiB per CU at full occupancy);
+//   * the NS partial sums are combined with log2(NS) xor-shuffles; slot 0 stores the row.
+// HBM-bound by construction: algorithmic bytes per launch are nnz*(4*d + 4) + (n_t+1)*4 + n_t*4*d
+// (SURVEY.md section 8(d3)); VALU work is one FMA per gathered element.
+#include "common.h"
+
+namespace allset {
+
+enum { kModeSum = 0, kModeExt = 1 };
+constexpr int kUnroll = 8;
+
+template <int VEC, int LPR, int MODE, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void segreduce_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    int32_t* __restrict__ argext, int n_t, int d, int mean, float sign) {
+  constexpr int NS = kWave / LPR;
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_t) return;  // whole wave exits together
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int start = rowptr[row], end = rowptr[row + 1];
+
+  for (int cb = 0; cb < d; cb += LPR * VEC) {
+    const int c0 = cb + li * VEC;
+    const bool active = c0 < d;
+    float acc[VEC];
+    int32_t arg[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { acc[k] = 0.f; arg[k] = -1; }
+
+    for (int base = start; base < end; base += kWave) {
+      const int n = min(kWave, end - base);
+      int my_col = 0;
+      float my_w = 0.f;
+      if (lane < n) {
+        my_col = col[base + lane];
+        if constexpr (WEIGHTED) my_w = w[base + lane];
+      }
+      for (int j = 0; j < n; j += NS * kUnroll) {
+        FVec<VEC> v[kUnroll];
+        float ww[kUnroll];
+        bool ok[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int jj = j + u * NS + slot;
+          ok[u] = (jj < n) && active;
+          const int src = __shfl(my_col, jj & (kWave - 1));
+          if constexpr (WEIGHTED) ww[u] = __shfl(my_w, jj & (kWave - 1)); else ww[u] = 1.f;
+          if (ok[u]) {
+            v[u] = load_vec<VEC>(x + static_cast<int64_t>(src) * ldx + c0);
+          } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[u].v[k] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          if constexpr (MODE == kModeSum) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(ww[u], v[u].v[k], acc[k]);   // ok==false -> v == 0
+          } else {
+            if (ok[u]) {
+              const int pos = base + j + u * NS + slot;
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) {
+                const float val = sign * (ww[u] * v[u].v[k]);
+                if (arg[k] < 0 || val > acc[k]) { acc[k] = val; arg[k] = pos; }
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // combine the NS slots (each reduced a disjoint subset of the row's incidences)
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float o = __shfl_xor(acc[k], off);
+        if constexpr (MODE == kModeSum) {
+          acc[k] += o;
+        } else {
+          const int oa = __shfl_xor(arg[k], off);
+          if (oa >= 0 && (arg[k] < 0 || o > acc[k] || (o == acc[k] && oa < arg[k]))) { acc[k] = o; arg[k] = oa; }
+        }
+      }
+    }
+
+    if (slot == 0 && active) {
+      FVec<VEC> r;
+      if constexpr (MODE == kModeSum) {
+        const float scale = mean ? 1.f / static_cast<float>(max(end - start, 1)) : 1.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r.v[k] = acc[k] * scale;
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r.v[k] = arg[k] >= 0 ? sign * acc[k] : 0.f;   // empty row -> 0
+        if (argext != nullptr) store_vec_i32<VEC>(argext + static_cast<int64_t>(row) * d + c0, arg);
+      }
+      store_vec<VEC>(out + static_cast<int64_t>(row) * ldo + c0, r);
+    }
+  }
+}
+
+// gx[s,c] = sum_{j in T-row s} [argext[colT[j],c] == posT[j]] * wT[j] * gout[colT[j],c]
+template <int VEC, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void segmax_bwd_kernel(
+    const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const int32_t* __restrict__ posT,
+    const float* __restrict__ wT, const int32_t* __restrict__ argext, const float* __restrict__ gout,
+    int64_t ldg, float* __restrict__ gx, int64_t ldx, int n_s, int d) {
+  constexpr int NS = kWave / LPR;
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_s) return;
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int start = rowptrT[row], end = rowptrT[row + 1];
+
+  for (int cb = 0; cb < d; cb += LPR * VEC) {
+    const int c0 = cb + li * VEC;
+    const bool active = c0 < d;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int base = start; base < end; base += kWave) {
+      const int n = min(kWave, end - base);
+      int my_col = 0, my_pos = -2;
+      float my_w = 1.f;
+      if (lane < n) {
+        my_col = colT[base + lane];
+        my_pos = posT[base + lane];
+        if constexpr (WEIGHTED) my_w = wT[base + lane];
+      }
+      for (int j = 0; j < n; j += NS) {
+        const int jj = j + slot;
+        const int t = __shfl(my_col, jj & (kWave - 1));
+        const int pos = __shfl(my_pos, jj & (kWave - 1));
+        const float ww = __shfl(my_w, jj & (kWave - 1));
+        if (jj < n && active) {
+          const FVec<VEC> g = load_vec<VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
+          const int32_t* ap = argext + static_cast<int64_t>(t) * d + c0;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k)
+            if (ap[k] == pos) acc[k] = fmaf(ww, g.v[k], acc[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+    if (slot == 0 && active) {
+      FVec<VEC> r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r.v[k] = acc[k];
+      store_vec<VEC>(gx + static_cast<int64_t>(row) * ldx + c0, r);
+    }
+  }
+}
+
+// gw[j] = scale(t) * sum_c m(j,c) * x[col[j],c] * gout[t,c]   (one wave per CSR row t; LearnMask path)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void sddmm_rowdot_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ x,
+    int64_t ldx, const float* __restrict__ gout, int64_t ldg, const int32_t* __restrict__ argext,
+    float* __restrict__ gw, int n_t, int d, int mean) {
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n_t) return;
+  const int lane = lane_id();
+  const int start = rowptr[row], end = rowptr[row + 1];
+  const float scale = mean ? 1.f / static_cast<float>(max(end - start, 1)) : 1.f;
+  const float* g = gout + static_cast<int64_t>(row) * ldg;
+  const int32_t* ap = argext ? argext + static_cast<int64_t>(row) * d : nullptr;
+  for (int j = start; j < end; ++j) {
+    const float* xr = x + static_cast<int64_t>(col[j]) * ldx;
+    float part = 0.f;
+    for (int c = lane; c < d; c += kWave) {
+      bool take = true;
+      if constexpr (MODE == kModeExt) take = (ap[c] == j);
+      if (take) part = fmaf(xr[c], g[c], part);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) gw[j] = part * scale;
+  }
+}
+
+// ---- host-side dispatch ------------------------------------------------------------------------
+
+static inline unsigned row_grid(int64_t rows) { return static_cast<unsigned>((rows + kWavesPerBlock - 1) / kWavesPerBlock); }
+
+// lanes-per-row for the 16-byte path: smallest power of two >= d/4, in [8, 64]
+static inline int pick_lpr(int64_t d) {
+  const int64_t need = (d + 3) / 4;
+  int lpr = 8;
+  while (lpr < need && lpr < 64) lpr <<= 1;
+  return lpr;
+}
+
+template <int VEC, int LPR>
+static void launch_segreduce(int mode_ext, bool weighted, unsigned grid, hipStream_t st,
+                             const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
+                             int64_t ldx, float* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean,
+                             float sign) {
+  if (!mode_ext) {
+    if (weighted) segreduce_kernel<VEC, LPR, kModeSum, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    else          segreduce_kernel<VEC, LPR, kModeSum, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+  } else {
+    if (weighted) segreduce_kernel<VEC, LPR, kModeExt, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    else          segreduce_kernel<VEC, LPR, kModeExt, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+  }
+}
+
+template <int VEC, int LPR>
+static void launch_segmax_bwd(bool weighted, unsigned grid, hipStream_t st, const int32_t* rowptrT,
+                              const int32_t* colT, const int32_t* posT, const float* wT, const int32_t* argext,
+                              const float* gout, int64_t ldg, float* gx, int64_t ldx, int n_s, int d) {
+  if (weighted) segmax_bwd_kernel<VEC, LPR, true><<<grid, kBlock, 0, st>>>(rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, n_s, d);
+  else          segmax_bwd_kernel<VEC, LPR, false><<<grid, kBlock, 0, st>>>(rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, n_s, d);
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_segreduce_fwd(int reduce, int dtype, const int32_t* rowptr, const int32_t* col,
+                                    const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
+                                    int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(reduce >= ALLSET_SUM && reduce <= ALLSET_MIN, "segreduce_fwd: bad reduce %d", reduce);
+  ALLSET_REQUIRE(n_t >= 0 && n_s >= 0 && d >= 0, "segreduce_fwd: negative size");
+  ALLSET_REQUIRE(n_t < INT32_MAX && n_s < INT32_MAX && d < INT32_MAX, "segreduce_fwd: size exceeds int32");
+  if (dtype != ALLSET_F32) {
+    set_error("segreduce_fwd: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION);
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (n_t == 0 || d == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rowptr && out, "segreduce_fwd: null rowptr/out");
+  ALLSET_REQUIRE(ldx >= d && ldo >= d, "segreduce_fwd: leading dimension smaller than d");
+  // col/x may only be null when there is nothing to gather; that cannot be known without a sync, so
+  // require them whenever a source table is declared.
+  ALLSET_REQUIRE(n_s == 0 || (col && x), "segreduce_fwd: null col/x with n_s > 0");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* xf = static_cast<const float*>(x);
+  float* of = static_cast<float*>(out);
+  const bool ext = (reduce == ALLSET_MAX || reduce == ALLSET_MIN);
+  const float sign = (reduce == ALLSET_MIN) ? -1.f : 1.f;
+  const int mean = (reduce == ALLSET_MEAN);
+  const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out) &&
+                    (argext == nullptr || aligned16(argext));
+  const unsigned grid = row_grid(n_t);
+  const int nt = static_cast<int>(n_t), di = static_cast<int>(d);
+  if (vec4) {
+    switch (pick_lpr(d)) {
+      case 8:  launch_segreduce<4, 8>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
+      case 16: launch_segreduce<4, 16>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
+      case 32: launch_segreduce<4, 32>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
+      default: launch_segreduce<4, 64>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
+    }
+  } else {
+    launch_segreduce<1, 64>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign);
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_segmax_bwd(const int32_t* rowptrT, const int32_t* colT, const int32_t* posT,
+                                 const float* wT, const int32_t* argext, const float* gout, int64_t ldg,
+                                 float* gx, int64_t ldx, int64_t n_s, int64_t n_t, int64_t d, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n_t >= 0 && n_s >= 0 && d >= 0, "segmax_bwd: negative size");
+  ALLSET_REQUIRE(n_t < INT32_MAX && n_s < INT32_MAX && d < INT32_MAX, "segmax_bwd: size exceeds int32");
+  if (n_s == 0 || d == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rowptrT && gx, "segmax_bwd: null rowptrT/gx");
+  ALLSET_REQUIRE(n_t == 0 || (colT && posT && argext && gout), "segmax_bwd: null input with n_t > 0");
+  ALLSET_REQUIRE(ldg >= d && ldx >= d, "segmax_bwd: leading dimension smaller than d");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec4 = (d % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) && aligned16(gout) && aligned16(gx);
+  const unsigned grid = row_grid(n_s);
+  const int ns = static_cast<int>(n_s), di = static_cast<int>(d);
+  if (vec4) {
+    switch (pick_lpr(d)) {
+      case 8:  launch_segmax_bwd<4, 8>(wT != nullptr, grid, st, rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, ns, di); break;
+      case 16: launch_segmax_bwd<4, 16>(wT != nullptr, grid, st, rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, ns, di); break;
+      case 32: launch_segmax_bwd<4, 32>(wT != nullptr, grid, st, rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, ns, di); break;
+      default: launch_segmax_bwd<4, 64>(wT != nullptr, grid, st, rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, ns, di); break;
+    }
+  } else {
+    launch_segmax_bwd<1, 64>(wT != nullptr, grid, st, rowptrT, colT, posT, wT, argext, gout, ldg, gx, ldx, ns, di);
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_sddmm_rowdot(int reduce, const int32_t* rowptr, const int32_t* col, const float* x,
+                                   int64_t ldx, const float* gout, int64_t ldg, const int32_t* argext,
+                                   float* gw, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(reduce >= ALLSET_SUM && reduce <= ALLSET_MIN, "sddmm_rowdot: bad reduce %d", reduce);
+  ALLSET_REQUIRE(n_t >= 0 && n_s >= 0 && d >= 0, "sddmm_rowdot: negative size");
+  ALLSET_REQUIRE(n_t < INT32_MAX && n_s < INT32_MAX && d < INT32_MAX, "sddmm_rowdot: size exceeds int32");
+  if (n_t == 0 || n_s == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rowptr && col && x && gout && gw, "sddmm_rowdot: null pointer");
+  ALLSET_REQUIRE(ldx >= d && ldg >= d, "sddmm_rowdot: leading dimension smaller than d");
+  const bool ext = (reduce == ALLSET_MAX || reduce == ALLSET_MIN);
+  ALLSET_REQUIRE(!ext || argext, "sddmm_rowdot: MAX/MIN need argext");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = row_grid(n_t);
+  const int mean = (reduce == ALLSET_MEAN);
+  if (ext) sddmm_rowdot_kernel<kModeExt><<<grid, kBlock, 0, st>>>(rowptr, col, x, ldx, gout, ldg, argext, gw, static_cast<int>(n_t), static_cast<int>(d), mean);
+  else     sddmm_rowdot_kernel<kModeSum><<<grid, kBlock, 0, st>>>(rowptr, col, x, ldx, gout, ldg, nullptr, gw, static_cast<int>(n_t), static_cast<int>(d), mean);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

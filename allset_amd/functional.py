@@ -1,0 +1,125 @@
+"""Differentiable aggregation operators backed by the HIP kernels (``torch.autograd.Function``
+wrappers over ``ops.py``).  These two functions are the whole "propagate" step of the reference:
+
+* ``deepsets_aggregate``  == ``HalfNLHconv.propagate`` -> ``message`` -> ``aggregate``  (layers.py:633-656)
+* ``pma_aggregate``       == ``PMA.propagate`` -> ``message`` -> ``aggregate``           (layers.py:145,168-194)
+
+Backward passes are kernels too (same segreduce kernel on the transposed CSR; one-gather-pass PMA
+backward) -- no autograd graph over per-incidence temporaries exists.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib, ops
+from ._lib import MAX, MEAN, MIN, REDUCE_CODES, SUM
+from .incidence import Incidence
+
+Tensor = torch.Tensor
+
+
+def _check_rows(x: Tensor, inc: Incidence) -> None:
+    """The gathered matrix must cover every source id (PyG's index_select would raise otherwise) and
+    may not have more rows than the transposed CSR (its backward produces one row per CSR row)."""
+    if not (inc.src_extent <= x.shape[0] <= inc.n_src):
+        raise ValueError(f"source matrix has {x.shape[0]} rows; incidence needs between {inc.src_extent} "
+                         f"and {inc.n_src}")
+
+
+class _SegReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w_dst: Optional[Tensor], w_src: Optional[Tensor], inc: Incidence, reduce: int):
+        csr = inc.by_dst
+        ext = reduce in (MAX, MIN)
+        out, arg = ops.segreduce(reduce, csr.rowptr, csr.col, w_dst, x, inc.n_dst, want_arg=ext)
+        need_gw = w_dst is not None and ctx.needs_input_grad[1]
+        ctx.inc, ctx.reduce, ctx.n_s, ctx.need_gw = inc, reduce, x.shape[0], need_gw
+        ctx.save_for_backward(x if need_gw else None, w_dst, w_src, arg)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout: Tensor):
+        x, w_dst, w_src, arg = ctx.saved_tensors
+        inc, reduce = ctx.inc, ctx.reduce
+        T = inc.by_src
+        gx = gw = None
+        gout = gout.contiguous()
+        if ctx.needs_input_grad[0]:
+            if w_dst is not None and w_src is None:       # differentiable weights: route on the fly
+                w_src = w_dst[inc.pos_dst_of_src().long()]
+            if reduce in (SUM, MEAN):
+                if reduce == MEAN:
+                    inv = inc.inv_count_by_src()
+                    w_src = inv if w_src is None else w_src * inv
+                gx, _ = ops.segreduce(SUM, T.rowptr, T.col, w_src, gout, ctx.n_s)
+            else:
+                gx = ops.segmax_bwd(T.rowptr, T.col, inc.pos_dst_of_src(), w_src, arg, gout, ctx.n_s)
+        if ctx.need_gw:
+            csr = inc.by_dst
+            gw = ops.sddmm_rowdot(reduce, csr.rowptr, csr.col, x, gout, arg)
+        return gx, gw, None, None, None
+
+
+def deepsets_aggregate(x: Tensor, inc: Incidence, norm: Optional[Tensor] = None, aggr: str = "add") -> Tensor:
+    """``out[t] = reduce_{i: dst_i = t} norm_i * x[src_i]`` for ``aggr`` in add|sum|mean|max|min.
+
+    ``norm`` is per incidence in the caller's edge-list order (int64 ones in the reference default,
+    preprocessing.py:454); ``None`` or all-ones skips the weight stream.  Output has ``inc.n_dst`` rows.
+    """
+    if aggr not in REDUCE_CODES:
+        raise ValueError(f"unknown aggr {aggr!r}")
+    _lib.require_device(x)
+    _check_rows(x, inc)
+    if norm is not None and norm.requires_grad:
+        w_dst = norm.reshape(-1).to(torch.float32)[inc.by_dst.perm.long()]     # differentiable routing
+        w_src = None
+    else:
+        w_dst, w_src = inc.weights(norm)
+    return _SegReduce.apply(x, w_dst, w_src, inc, REDUCE_CODES[aggr])
+
+
+class _PmaAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, V: Tensor, alpha: Tensor, inc: Incidence, heads: int, slope: float):
+        csr = inc.by_dst
+        out, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst)
+        ctx.inc, ctx.slope = inc, slope
+        ctx.save_for_backward(V, alpha, out, m, l)
+        ctx.mark_non_differentiable(m, l)
+        return out, m, l
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout: Tensor, _gm, _gl):
+        V, alpha, out, m, l = ctx.saved_tensors
+        T = ctx.inc.by_src
+        gout = gout.contiguous()
+        stats = ops.pma_bwd_stats(out, gout, m, l)
+        gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, ctx.slope)
+        return gV, galpha, None, None, None
+
+
+def pma_aggregate(V: Tensor, alpha: Tensor, inc: Incidence, heads: int, negative_slope: float = 0.2
+                  ) -> Tuple[Tensor, Tensor, Tensor]:
+    """Softmax-attention pooling: ``out[t,h,:] = sum_i softmax_i(leaky_relu(alpha[src_i,h])) * V[src_i,h,:]``.
+
+    ``V``: [n_src, heads*C], ``alpha``: [n_src, heads] (pre-activation).  Returns
+    ``(out [n_dst, heads*C], m [n_dst, heads], l [n_dst, heads])``; empty targets give 0.
+    """
+    _lib.require_device(V, alpha)
+    _check_rows(V, inc)
+    return _PmaAggregate.apply(V, alpha, inc, int(heads), float(negative_slope))
+
+
+def pma_attention_weights(alpha: Tensor, m: Tensor, l: Tensor, inc: Incidence, negative_slope: float = 0.2) -> Tensor:
+    """Per-incidence attention weights [nnz, heads] in the caller's edge-list order
+    (reference ``PMA.forward(..., return_attention_weights=True)``, layers.py:159-162)."""
+    csr = inc.by_dst
+    p_csr = ops.pma_attention(csr.rowptr, csr.col, alpha.detach(), m, l, float(negative_slope))
+    p = torch.empty_like(p_csr)
+    p[csr.perm.long()] = p_csr
+    return p

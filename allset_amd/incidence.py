@@ -1,0 +1,158 @@
+"""Incidence structure of a hypergraph in HBM: both CSR orientations of the bipartite V-E incidence,
+built ONCE on the device from the reference's ``[2, nnz]`` int64 ``edge_index``.
+
+The reference re-derives everything from ``edge_index`` on every forward: it re-bases the hyperedge
+ids in place and stacks a reversed copy (models.py:453-456), and each aggregate sizes its output from
+``index.max()+1`` (layers.py:174,656) -- three device->host syncs per layer.  Here sizes are fixed at
+construction; the only syncs are the one-time range checks below.
+
+Layout (all int32, device resident):
+  by_dst : CSR whose rows are the TARGETS of ``edge_index`` (row 1), cols the sources (row 0)
+  by_src : the transpose (rows = sources).  One orientation is the forward CSR of a direction and the
+           backward CSR of the opposite direction, so a V->E->V layer needs exactly these two.
+  perm   : CSR position -> position in the caller's edge list (routes ``norm`` / attention weights).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from .ops import CSR
+
+Tensor = torch.Tensor
+
+
+class Incidence:
+    """A directed bipartite incidence ``src -> dst`` with both CSR orientations.
+
+    ``n_dst`` follows the reference's sizing rule unless given: ``index.max()+1``.
+    ``n_src`` is the row count of the feature matrix that will be gathered from.
+    """
+
+    def __init__(self, by_dst: CSR, by_src: CSR, n_src: int, n_dst: int, src_extent: int, dst_extent: int):
+        self.by_dst, self.by_src = by_dst, by_src
+        self.n_src, self.n_dst = int(n_src), int(n_dst)
+        # (max id)+1 on each side: the fewest rows a gathered matrix may have / the reference's n_dst
+        self.src_extent, self.dst_extent = int(src_extent), int(dst_extent)
+        self.nnz = by_dst.nnz
+        self.device = by_dst.rowptr.device
+        self._pos_dst_of_src: Optional[Tensor] = None     # by_src position -> by_dst position
+        self._pos_src_of_dst: Optional[Tensor] = None
+        self._inv_cnt: Dict[str, Tensor] = {}
+        self._wcache: Dict[Tuple, Tuple[Optional[Tensor], Optional[Tensor]]] = {}
+        self._reversed: Optional["Incidence"] = None
+
+    # ---- construction ---------------------------------------------------------------------
+    @staticmethod
+    def from_edge_index(edge_index: Tensor, n_src: Optional[int] = None, n_dst: Optional[int] = None,
+                        src_base: int = 0, dst_base: int = 0) -> "Incidence":
+        """``edge_index``: int64 [2, nnz] on a ROCm device; row 0 = source ids, row 1 = target ids.
+        ids are taken relative to ``src_base`` / ``dst_base``."""
+        _lib.require_device(edge_index)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+            raise ValueError(f"edge_index must be int64 [2, nnz], got {edge_index.dtype} {tuple(edge_index.shape)}")
+        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+        nnz = src.numel()
+        if nnz > 0:   # one-time host syncs: id ranges (the kernels cannot report a bad id)
+            lo_s, hi_s = int(src.min()) - src_base, int(src.max()) - src_base
+            lo_d, hi_d = int(dst.min()) - dst_base, int(dst.max()) - dst_base
+        else:
+            lo_s = lo_d = 0
+            hi_s = hi_d = -1
+        if n_src is None:
+            n_src = hi_s + 1
+        if n_dst is None:
+            n_dst = hi_d + 1                      # the reference's index.max()+1
+        if lo_s < 0 or hi_s >= n_src:
+            raise ValueError(f"source ids span [{lo_s}, {hi_s}] but n_src = {n_src}")   # PyG: index_select error
+        if lo_d < 0 or hi_d >= n_dst:
+            raise ValueError(f"target ids span [{lo_d}, {hi_d}] but n_dst = {n_dst}")
+        by_dst = ops.csr_build(dst, src, dst_base, src_base, n_dst, n_src)
+        by_src = ops.csr_build(src, dst, src_base, dst_base, n_src, n_dst)
+        return Incidence(by_dst, by_src, n_src, n_dst, hi_s + 1, hi_d + 1)
+
+    def reversed(self, n_dst: Optional[int] = None) -> "Incidence":
+        """The opposite direction (dst -> src) sharing the same two CSRs.  ``n_dst`` of the reversed
+        direction defaults to the reference's rule: (max source id)+1, which may be smaller than
+        ``n_src`` when trailing rows are isolated (Q1: such vertices vanish from the E->V output)."""
+        if n_dst is not None:
+            return self._make_reversed(n_dst)
+        if self._reversed is None:
+            self._reversed = self._make_reversed(self.src_extent)
+        return self._reversed
+
+    def _make_reversed(self, n_dst: int) -> "Incidence":
+        if n_dst > self.by_src.n_rows:
+            raise ValueError("reversed(): n_dst exceeds the number of source rows")
+        rev = Incidence(self.by_src, self.by_dst, self.n_dst, n_dst, self.dst_extent, self.src_extent)
+        rev._pos_dst_of_src, rev._pos_src_of_dst = self._pos_src_of_dst, self._pos_dst_of_src
+        return rev
+
+    # ---- derived index maps (lazy, cached) -------------------------------------------------
+    def pos_dst_of_src(self) -> Tensor:
+        """int32[nnz]: for each position of ``by_src``, the position of the same incidence in ``by_dst``."""
+        if self._pos_dst_of_src is None:
+            inv = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+            inv[self.by_dst.perm.long()] = torch.arange(self.nnz, dtype=torch.int32, device=self.device)
+            self._pos_dst_of_src = inv[self.by_src.perm.long()].contiguous()
+        return self._pos_dst_of_src
+
+    def inv_count_by_src(self) -> Tensor:
+        """f32[nnz] in ``by_src`` order: 1 / max(|segment of the incidence's target|, 1) (mean backward)."""
+        if "src" not in self._inv_cnt:
+            rp = self.by_dst.rowptr
+            cnt = (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32)
+            self._inv_cnt["src"] = (1.0 / cnt)[self.by_src.col.long()].contiguous()
+        return self._inv_cnt["src"]
+
+    # ---- per-incidence weights ---------------------------------------------------------------
+    def weights(self, norm: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+        """Route the reference's per-incidence ``norm`` (edge-list order; int64 ones by default,
+        preprocessing.py:454) into (by_dst order, by_src order) f32 arrays.  All-ones -> (None, None):
+        the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms."""
+        if norm is None:
+            return None, None
+        if norm.numel() != self.nnz:
+            raise ValueError(f"norm has {norm.numel()} entries for {self.nnz} incidences")
+        if norm.requires_grad:
+            raise RuntimeError("weights(): differentiable norm goes through functional.route_weights")
+        key = (norm.data_ptr(), norm._version, norm.dtype, norm.numel())
+        hit = self._wcache.get(key)
+        if hit is None:
+            flat = norm.reshape(-1)
+            if bool((flat == 1).all()):          # one-time sync per norm tensor
+                hit = (None, None)
+            else:
+                f = flat.to(torch.float32)
+                hit = (f[self.by_dst.perm.long()].contiguous(), f[self.by_src.perm.long()].contiguous())
+            self._wcache.clear()
+            self._wcache[key] = hit
+        return hit
+
+
+# ---------------------------------------------------------------------------------------------
+# cache: edge_index tensor -> Incidence, keyed on storage identity + version (the reference hands the
+# same data.edge_index to every forward; models.py:450)
+# ---------------------------------------------------------------------------------------------
+
+_CACHE: Dict[Tuple, Tuple[weakref.ref, Incidence]] = {}
+_CACHE_LIMIT = 16
+
+
+def cached_incidence(edge_index: Tensor, n_src: Optional[int], n_dst: Optional[int] = None) -> Incidence:
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), n_src, n_dst)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0]() is not None:
+        return hit[1]
+    inc = Incidence.from_edge_index(edge_index, n_src=n_src, n_dst=n_dst)
+    if len(_CACHE) >= _CACHE_LIMIT:
+        _CACHE.pop(next(iter(_CACHE)))
+    try:
+        ref = weakref.ref(edge_index)
+    except TypeError:  # pragma: no cover
+        ref = lambda: edge_index  # noqa: E731
+    _CACHE[key] = (ref, inc)
+    return inc

@@ -1,0 +1,203 @@
+"""The reference's layer-level module surface for the AllSet path, on MI355X kernels.
+
+Same class names, constructor signatures, ``forward`` arguments and ``state_dict`` layout as
+reference ``src/layers.py`` (``MLP`` :496, ``PMA`` :42, ``HalfNLHconv`` :582), so a checkpoint or a
+``train.py``-style caller moves over unchanged.  What differs is underneath: ``propagate`` is not a
+PyG message-passing template over [nnz, d] temporaries but one call into ``functional.py`` (HIP
+kernels over a CSR built once).  The dense tail (Linear / LayerNorm / ReLU) stays on torch ops
+(hipBLASLt / MIOpen) in this round.
+
+``edge_index`` may be the reference's int64 ``[2, nnz]`` tensor (converted once and cached on tensor
+identity + version) or a prebuilt :class:`allset_amd.incidence.Incidence`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as AF
+from .incidence import Incidence, cached_incidence
+
+Tensor = torch.Tensor
+EdgeIndex = Union[Tensor, Incidence]
+
+
+def glorot(tensor: Optional[Tensor]) -> None:
+    """U(-a, a), a = sqrt(6 / (fan_in + fan_out))  -- reference layers.py:31-34."""
+    if tensor is not None:
+        bound = math.sqrt(6.0 / (tensor.size(-2) + tensor.size(-1)))
+        with torch.no_grad():
+            tensor.uniform_(-bound, bound)
+
+
+def zeros(tensor: Optional[Tensor]) -> None:
+    if tensor is not None:
+        with torch.no_grad():
+            tensor.zero_()
+
+
+def _as_incidence(edge_index: EdgeIndex, n_src: int) -> Incidence:
+    if isinstance(edge_index, Incidence):
+        return edge_index
+    return cached_incidence(edge_index, n_src=n_src)      # n_dst = index.max()+1, the reference's rule (Q1)
+
+
+def _make_norm(kind: str, width: int) -> nn.Module:
+    if kind == "bn":
+        return nn.BatchNorm1d(width)
+    if kind == "ln":
+        return nn.LayerNorm(width)
+    return nn.Identity()
+
+
+class MLP(nn.Module):
+    """``norm0 -> [Linear -> ReLU -> norm -> dropout] x (L-1) -> Linear``  (reference layers.py:496-579).
+
+    ``Normalization`` in {'bn','ln','None'}; ``InputNorm`` selects whether slot 0 normalises the input.
+    Parameter names: ``lins.{i}``, ``normalizations.{i}``.
+    """
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers,
+                 dropout=.5, Normalization='bn', InputNorm=False):
+        super().__init__()
+        assert Normalization in ['bn', 'ln', 'None']
+        self.InputNorm = InputNorm
+        self.dropout = dropout
+        widths = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        self.lins = nn.ModuleList(nn.Linear(widths[i], widths[i + 1]) for i in range(num_layers))
+        norms = [_make_norm(Normalization if InputNorm else 'None', in_channels)]
+        norms += [_make_norm(Normalization, hidden_channels) for _ in range(num_layers - 1)]
+        self.normalizations = nn.ModuleList(norms)
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+        for norm in self.normalizations:
+            if not isinstance(norm, nn.Identity):
+                norm.reset_parameters()
+
+    def forward(self, x):
+        x = self.normalizations[0](x)
+        for i, lin in enumerate(self.lins[:-1]):
+            x = F.relu(lin(x))
+            x = self.normalizations[i + 1](x)
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        return self.lins[-1](x)
+
+
+class PMA(nn.Module):
+    """Pooling by multi-head attention with a learned seed (reference layers.py:42-199).
+
+    ``K = lin_K(x)``, ``V = lin_V(x)``, ``alpha[s,h] = <K[s,h,:], att_r[h,:]>``; per target the softmax
+    of ``leaky_relu(alpha)`` over its incidences pools ``V``; then ``+att_r``, ``ln0``,
+    ``ln1(z + relu(rFF(z)))``.  ``concat``, ``dropout`` and ``bias`` are accepted and ignored exactly as
+    in the reference (attention dropout is hard-wired to 0 there, layers.py:63; bias is always None).
+
+    ``fold_alpha`` (default True): since ``alpha`` is linear in ``x``, it is computed as
+    ``x @ (att_r . W_K)^T + att_r . b_K`` -- an [in, H] mat-vec instead of the full [n, d] K projection
+    (SURVEY K6); gradients of ``att_r``/``lin_K`` follow by autograd through that contraction.
+    """
+
+    def __init__(self, in_channels, hid_dim, out_channels, num_layers, heads=1, concat=True,
+                 negative_slope=0.2, dropout=0.0, bias=False, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.hidden = hid_dim // heads
+        self.out_channels = out_channels
+        self.heads = heads
+        self.concat = concat
+        self.negative_slope = negative_slope
+        self.dropout = 0.
+        self.aggr = 'add'
+        self.fold_alpha = kwargs.pop("fold_alpha", True)
+        self.lin_K = nn.Linear(in_channels, self.heads * self.hidden)
+        self.lin_V = nn.Linear(in_channels, self.heads * self.hidden)
+        self.att_r = nn.Parameter(torch.empty(1, heads, self.hidden))
+        self.rFF = MLP(in_channels=self.heads * self.hidden, hidden_channels=self.heads * self.hidden,
+                       out_channels=out_channels, num_layers=num_layers, dropout=.0, Normalization='None')
+        self.ln0 = nn.LayerNorm(self.heads * self.hidden)
+        self.ln1 = nn.LayerNorm(self.heads * self.hidden)
+        self.register_parameter('bias', None)
+        self._alpha = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # weights only: the reference never re-initialises lin_K / lin_V biases
+        glorot(self.lin_K.weight)
+        glorot(self.lin_V.weight)
+        self.rFF.reset_parameters()
+        self.ln0.reset_parameters()
+        self.ln1.reset_parameters()
+        nn.init.xavier_uniform_(self.att_r)
+
+    def _logits(self, x: Tensor) -> Tensor:
+        H, C = self.heads, self.hidden
+        if self.fold_alpha:
+            w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
+            b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
+            return F.linear(x, w, b)
+        return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
+
+    def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None):
+        assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
+        H, C = self.heads, self.hidden
+        inc = _as_incidence(edge_index, x.shape[0])
+        x_V = self.lin_V(x)                                   # [n_s, H*C]
+        alpha_r = self._logits(x)                             # [n_s, H]
+        out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
+        out = out.view(-1, H, C) + self.att_r                 # seed + multihead (layers.py:153)
+        out = self.ln0(out.view(-1, H * C))
+        out = self.ln1(out + F.relu(self.rFF(out)))
+        if isinstance(return_attention_weights, bool):
+            alpha = AF.pma_attention_weights(alpha_r, m, l, inc, self.negative_slope)
+            return out, (edge_index, alpha)
+        return out
+
+    def __repr__(self):
+        return '{}({}, {}, heads={})'.format(self.__class__.__name__, self.in_channels, self.out_channels, self.heads)
+
+
+class HalfNLHconv(nn.Module):
+    """One direction (V->E or E->V) of an AllSet layer (reference layers.py:582-658).
+
+    ``attention=True``: delegate to :class:`PMA` (AllSetTransformer).  Otherwise Deep Sets:
+    ``relu(f_dec(aggregate(dropout(relu(f_enc(x))))))`` with ``aggr`` in add|sum|mean|max|min and
+    per-incidence ``norm`` weights.  ``num_layers == 0`` makes ``f_enc``/``f_dec`` identities.
+    """
+
+    def __init__(self, in_dim, hid_dim, out_dim, num_layers, dropout, Normalization='bn', InputNorm=False,
+                 heads=1, attention=True):
+        super().__init__()
+        self.attention = attention
+        self.dropout = dropout
+        if self.attention:
+            self.prop = PMA(in_dim, hid_dim, out_dim, num_layers, heads=heads)
+        elif num_layers > 0:
+            self.f_enc = MLP(in_dim, hid_dim, hid_dim, num_layers, dropout, Normalization, InputNorm)
+            self.f_dec = MLP(hid_dim, hid_dim, out_dim, num_layers, dropout, Normalization, InputNorm)
+        else:
+            self.f_enc = nn.Identity()
+            self.f_dec = nn.Identity()
+
+    def reset_parameters(self):
+        if self.attention:
+            self.prop.reset_parameters()
+        else:
+            for f in (self.f_enc, self.f_dec):
+                if not isinstance(f, nn.Identity):
+                    f.reset_parameters()
+
+    def forward(self, x, edge_index: EdgeIndex, norm, aggr='add'):
+        if self.attention:
+            return self.prop(x, edge_index)
+        if aggr is None:
+            raise ValueError("aggr was not passed!")
+        x = F.relu(self.f_enc(x))
+        x = F.dropout(x, p=self.dropout, training=self.training)
+        inc = _as_incidence(edge_index, x.shape[0])
+        x = AF.deepsets_aggregate(x, inc, norm, aggr)
+        return F.relu(self.f_dec(x))

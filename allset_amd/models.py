@@ -1,0 +1,132 @@
+"""``SetGNN`` -- the ``nn.Module`` surface ``train.py`` talks to (reference src/models.py:295-484).
+
+AllSetTransformer and AllDeepSets are both this class; ``args.PMA`` selects the attention path
+(reference train.py:30-42).  Constructor reads the same ``args`` attributes, registers the same
+sub-modules under the same names (including the never-applied ``bnV2Es`` / ``bnE2Vs`` BatchNorms, which
+still live in the ``state_dict``) and ``forward(data)`` takes the same ``data.x`` /
+``data.edge_index`` / ``data.norm``.
+
+What is different underneath: the bipartite incidence is converted once into two device CSRs
+(:mod:`allset_amd.incidence`) and cached on the identity of ``data.edge_index``; the per-forward
+``edge_index[1].min()`` host sync, the stacked reversed index and the ``index.max()+1`` syncs of the
+reference (models.py:453-456, layers.py:174,656) do not exist after the first call.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Linear, Parameter
+
+from .incidence import Incidence
+from .layers import MLP, HalfNLHconv
+
+
+class SetGNN(nn.Module):
+    def __init__(self, args, norm=None):
+        super().__init__()
+        self.All_num_layers = args.All_num_layers
+        self.dropout = args.dropout
+        self.aggr = args.aggregate
+        self.NormLayer = args.normalization
+        self.InputNorm = args.deepset_input_norm
+        self.GPR = args.GPR
+        self.LearnMask = args.LearnMask
+
+        self.V2EConvs = nn.ModuleList()
+        self.E2VConvs = nn.ModuleList()
+        self.bnV2Es = nn.ModuleList()
+        self.bnE2Vs = nn.ModuleList()
+
+        if self.LearnMask:
+            self.Importance = Parameter(torch.ones(norm.size()))
+
+        def conv(in_dim):
+            return HalfNLHconv(in_dim=in_dim, hid_dim=args.MLP_hidden, out_dim=args.MLP_hidden,
+                               num_layers=args.MLP_num_layers, dropout=self.dropout,
+                               Normalization=self.NormLayer, InputNorm=self.InputNorm,
+                               heads=args.heads, attention=args.PMA)
+
+        def head(in_dim):
+            return MLP(in_channels=in_dim, hidden_channels=args.Classifier_hidden, out_channels=args.num_classes,
+                       num_layers=args.Classifier_num_layers, dropout=self.dropout,
+                       Normalization=self.NormLayer, InputNorm=False)
+
+        if self.All_num_layers == 0:
+            self.classifier = head(args.num_features)
+        else:
+            for i in range(self.All_num_layers):
+                self.V2EConvs.append(conv(args.num_features if i == 0 else args.MLP_hidden))
+                self.bnV2Es.append(nn.BatchNorm1d(args.MLP_hidden))
+                self.E2VConvs.append(conv(args.MLP_hidden))
+                self.bnE2Vs.append(nn.BatchNorm1d(args.MLP_hidden))
+            if self.GPR:
+                self.MLP = MLP(in_channels=args.num_features, hidden_channels=args.MLP_hidden,
+                               out_channels=args.MLP_hidden, num_layers=args.MLP_num_layers,
+                               dropout=self.dropout, Normalization=self.NormLayer, InputNorm=False)
+                self.GPRweights = Linear(self.All_num_layers + 1, 1, bias=False)
+            self.classifier = head(args.MLP_hidden)
+
+        self._inc_cache: Dict[Tuple, Tuple[Incidence, Incidence]] = {}
+
+    def reset_parameters(self):
+        for group in (self.V2EConvs, self.E2VConvs, self.bnV2Es, self.bnE2Vs):
+            for layer in group:
+                layer.reset_parameters()
+        self.classifier.reset_parameters()
+        if self.GPR:
+            self.MLP.reset_parameters()
+            self.GPRweights.reset_parameters()
+        if self.LearnMask:
+            nn.init.ones_(self.Importance)
+
+    # ---- incidence handling ---------------------------------------------------------------------
+    def _incidences(self, edge_index: torch.Tensor, n_v: int) -> Tuple[Incidence, Incidence]:
+        """(V->E, E->V) incidences for ``data.edge_index``; built on first sight of the tensor.
+
+        Mirrors reference models.py:453-454: hyperedge ids are re-based IN PLACE so that they start at
+        0 (train.py hands them over starting at n_V; after the first call the tensor is unchanged, as in
+        the reference where subtracting min()==0 is a no-op).
+        """
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), n_v)
+        hit = self._inc_cache.get(key)
+        if hit is not None:
+            return hit
+        if edge_index.numel() > 0:
+            cidx = int(edge_index[1].min())          # one-time host sync (reference: every forward)
+            if cidx != 0:
+                edge_index[1] -= cidx                # reference side effect, kept
+        v2e = Incidence.from_edge_index(edge_index, n_src=n_v)    # n_E = max hyperedge id + 1 (Q1)
+        e2v = v2e.reversed()                                      # n_V' = max vertex id + 1 (Q1)
+        self._inc_cache.clear()
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), n_v)
+        self._inc_cache[key] = (v2e, e2v)
+        return v2e, e2v
+
+    def forward(self, data):
+        """``data.x`` [n_V, F] float32, ``data.edge_index`` int64 [2, nnz] (row 0 vertex ids, row 1
+        hyperedge ids), ``data.norm`` [nnz] per-incidence weights.  Returns vertex logits."""
+        x, edge_index, norm = data.x, data.edge_index, data.norm
+        if self.LearnMask:
+            norm = self.Importance * norm
+        v2e, e2v = self._incidences(edge_index, x.shape[0])
+        if self.GPR:
+            xs = [F.relu(self.MLP(x))]
+            for i in range(len(self.V2EConvs)):
+                x = F.relu(self.V2EConvs[i](x, v2e, norm, self.aggr))
+                x = F.dropout(x, p=self.dropout, training=self.training)
+                x = F.relu(self.E2VConvs[i](x, e2v, norm, self.aggr))
+                xs.append(x)
+                x = F.dropout(x, p=self.dropout, training=self.training)
+            x = torch.stack(xs, dim=-1)
+            x = self.GPRweights(x).squeeze()
+            return self.classifier(x)
+        x = F.dropout(x, p=0.2, training=self.training)      # hard-coded input dropout (models.py:473)
+        for i in range(len(self.V2EConvs)):
+            x = F.relu(self.V2EConvs[i](x, v2e, norm, self.aggr))
+            x = F.dropout(x, p=self.dropout, training=self.training)
+            x = F.relu(self.E2VConvs[i](x, e2v, norm, self.aggr))
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        return self.classifier(x)

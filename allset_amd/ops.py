@@ -1,0 +1,172 @@
+"""Thin tensor-level wrappers over the C ABI (one python function per entry point of
+``include/allset_hip.h``).  No autograd here -- see ``functional.py``.  All tensors are ROCm device
+tensors; outputs are allocated with torch (plumbing) and filled by the HIP kernels.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_size_t
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_device, stream_of
+
+Tensor = torch.Tensor
+
+
+class CSR(NamedTuple):
+    """rowptr int32[n_rows+1], col int32[nnz], perm int32[nnz] (CSR position -> edge-list position)."""
+    rowptr: Tensor
+    col: Tensor
+    perm: Tensor
+    n_rows: int
+    n_cols: int
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.numel())
+
+
+def _rowmajor(t: Tensor) -> Tensor:
+    """Kernels take row-major matrices with an explicit leading dimension (stride(1) == 1)."""
+    if t.dim() != 2:
+        raise _lib.AllSetHipError(f"expected a 2-D matrix, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        return t.contiguous()
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def _f32(t: Tensor, what: str) -> None:
+    if t.dtype != torch.float32:
+        raise _lib.AllSetHipError(f"{what}: float32 required (got {t.dtype}); bf16 storage is not built in ABI v1")
+
+
+def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_rows: int, n_cols: int) -> CSR:
+    dev = require_device(row_ids, col_ids)
+    if row_ids.dtype != torch.int64 or col_ids.dtype != torch.int64:
+        raise _lib.AllSetHipError("csr_build: int64 ids required (the reference's edge_index dtype)")
+    row_ids, col_ids = row_ids.contiguous(), col_ids.contiguous()
+    nnz = row_ids.numel()
+    lib = _lib.load()
+    need = c_size_t(0)
+    with torch.cuda.device(dev):
+        check(lib.allset_csr_build_workspace_bytes(nnz, n_rows, byref(need)), "allset_csr_build_workspace_bytes")
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(nnz, dtype=torch.int32, device=dev)
+        perm = torch.empty(nnz, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(need.value, 1), dtype=torch.uint8, device=dev)   # caching allocator: 512-B aligned
+        check(lib.allset_csr_build(ptr(row_ids), ptr(col_ids), nnz, row_base, col_base, n_rows,
+                                   ptr(rowptr), ptr(col), ptr(perm), ptr(ws), need.value, stream_of(dev)),
+              "allset_csr_build")
+    return CSR(rowptr, col, perm, n_rows, n_cols)
+
+
+def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: Tensor, n_t: int,
+              want_arg: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    dev = require_device(rowptr, col, w, x)
+    _f32(x, "segreduce")
+    x = _rowmajor(x)
+    n_s, d = x.shape
+    out = torch.empty((n_t, d), dtype=x.dtype, device=dev)
+    arg = torch.empty((n_t, d), dtype=torch.int32, device=dev) if want_arg else None
+    if w is not None:
+        _f32(w, "segreduce weights")
+        w = w.contiguous()
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_segreduce_fwd(reduce, _lib.F32, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
+                                               ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
+              "allset_segreduce_fwd")
+    return out, arg
+
+
+def segmax_bwd(rowptrT: Tensor, colT: Tensor, posT: Tensor, wT: Optional[Tensor], argext: Tensor, gout: Tensor,
+               n_s: int) -> Tensor:
+    dev = require_device(rowptrT, colT, posT, wT, argext, gout)
+    _f32(gout, "segmax_bwd")
+    gout = _rowmajor(gout)
+    n_t, d = gout.shape
+    gx = torch.empty((n_s, d), dtype=gout.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_segmax_bwd(ptr(rowptrT), ptr(colT), ptr(posT), ptr(wT), ptr(argext), ptr(gout),
+                                            _ld(gout), ptr(gx), max(d, 1), n_s, n_t, d, stream_of(dev)),
+              "allset_segmax_bwd")
+    return gx
+
+
+def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tensor, argext: Optional[Tensor]) -> Tensor:
+    dev = require_device(rowptr, col, x, gout, argext)
+    _f32(x, "sddmm_rowdot")
+    x, gout = _rowmajor(x), _rowmajor(gout)
+    n_s, d = x.shape
+    n_t = gout.shape[0]
+    gw = torch.empty(col.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_sddmm_rowdot(reduce, ptr(rowptr), ptr(col), ptr(x), _ld(x), ptr(gout), _ld(gout),
+                                              ptr(argext), ptr(gw), n_t, n_s, d, stream_of(dev)),
+              "allset_sddmm_rowdot")
+    return gw
+
+
+def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, slope: float, n_t: int
+            ) -> Tuple[Tensor, Tensor, Tensor]:
+    dev = require_device(rowptr, col, alpha, V)
+    _f32(V, "pma_fwd")
+    V = _rowmajor(V)
+    alpha = alpha.contiguous()
+    n_s, d = V.shape
+    if d % heads != 0 or alpha.shape != (n_s, heads):
+        raise _lib.AllSetHipError(f"pma_fwd: V {tuple(V.shape)} / alpha {tuple(alpha.shape)} inconsistent with heads={heads}")
+    out = torch.empty((n_t, d), dtype=V.dtype, device=dev)
+    m = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
+    l = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_pma_fwd(_lib.F32, ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V), slope, ptr(out),
+                                         max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads, stream_of(dev)),
+              "allset_pma_fwd")
+    return out, m, l
+
+
+def pma_attention(rowptr: Tensor, col: Tensor, alpha: Tensor, m: Tensor, l: Tensor, slope: float) -> Tensor:
+    dev = require_device(rowptr, col, alpha, m, l)
+    n_t, heads = m.shape
+    p = torch.empty((col.numel(), heads), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_pma_attention(ptr(rowptr), ptr(col), ptr(alpha.contiguous()), ptr(m), ptr(l), slope,
+                                               ptr(p), n_t, heads, stream_of(dev)), "allset_pma_attention")
+    return p
+
+
+def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
+    dev = require_device(out, gout, m, l)
+    out, gout = _rowmajor(out), _rowmajor(gout)
+    n_t, d = out.shape
+    heads = m.shape[1]
+    stats = torch.empty((n_t, heads, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_pma_bwd_stats(_lib.F32, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m), ptr(l),
+                                               ptr(stats), n_t, heads, d // heads, stream_of(dev)),
+              "allset_pma_bwd_stats")
+    return stats
+
+
+def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: Tensor, stats: Tensor, slope: float
+                ) -> Tuple[Tensor, Tensor]:
+    dev = require_device(rowptrT, colT, alpha, V, gout, stats)
+    V, gout = _rowmajor(V), _rowmajor(gout)
+    alpha = alpha.contiguous()
+    n_s, d = V.shape
+    n_t = gout.shape[0]
+    heads = alpha.shape[1]
+    gV = torch.empty((n_s, d), dtype=V.dtype, device=dev)
+    galpha = torch.empty((n_s, heads), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_pma_bwd_src(_lib.F32, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V), ptr(gout),
+                                             _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1), ptr(galpha),
+                                             n_s, n_t, heads, d // heads, stream_of(dev)),
+              "allset_pma_bwd_src")
+    return gV, galpha

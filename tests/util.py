@@ -1,0 +1,108 @@
+"""Helpers shared by the parity tests."""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict
+
+import numpy as np
+import torch
+
+import cases
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name: str) -> Dict[str, np.ndarray]:
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_spec(g: Dict[str, np.ndarray]):
+    return [(str(k), tuple(json.loads(str(s)))) for k, s in zip(g["spec_keys"], g["spec_shapes"])]
+
+
+def state_dict_for(case: dict, g: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    sd_np = cases.make_state_dict(golden_spec(g), case["seed"])
+    return {k: torch.from_numpy(v) for k, v in sd_np.items()}
+
+
+def run_oracle(case: dict, sd: Dict[str, torch.Tensor]):
+    """Oracle forward + backward of loss = (logits * G).sum(); returns dict like the fixtures."""
+    from oracle import allset_oracle as oracle
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    x = torch.from_numpy(case["x"]).clone().requires_grad_(True)
+    collect = {}
+    logits = oracle.setgnn_forward(sd, case["args"], x, torch.from_numpy(case["edge_index"]),
+                                   torch.from_numpy(case["norm"]), collect)
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape))
+    (logits * G).sum().backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
+    return dict(logits=logits.detach(), v2e0=collect["v2e0"].detach(), e2v0=collect["e2v0"].detach(),
+                grad_x=x.grad.detach(), grads=grads)
+
+
+def run_product(case: dict, sd: Dict[str, torch.Tensor], device):
+    """allset_amd.SetGNN forward + backward on `device` with the same loss."""
+    from allset_amd import SetGNN
+    args = case["args"]
+    norm_t = torch.from_numpy(case["norm"])
+    model = SetGNN(args, norm=norm_t.to(torch.float32) if args.LearnMask else None)
+    model.load_state_dict(sd)
+    model.eval().to(device)
+    grabbed = {}
+    model.V2EConvs[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("v2e0", o))
+    model.E2VConvs[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("e2v0", o))
+    x = torch.from_numpy(case["x"]).to(device).requires_grad_(True)
+    ei = torch.from_numpy(case["edge_index"]).to(device)
+    data = SimpleNamespace(x=x, edge_index=ei, norm=norm_t.to(device))
+    logits = model(data)
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape)).to(device)
+    (logits * G).sum().backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu()
+             for k, p in model.named_parameters()}
+    return dict(logits=logits.detach().cpu(), v2e0=grabbed["v2e0"].detach().cpu(), e2v0=grabbed["e2v0"].detach().cpu(),
+                grad_x=x.grad.detach().cpu(), grads=grads, model=model, data=data)
+
+
+def assert_matches_golden(res: dict, g: Dict[str, np.ndarray], big: bool, rtol: float, atol: float) -> None:
+    """Compare a result dict (from run_oracle / run_product) with a fixture.  atol is relative to the
+    max-abs of the expected tensor (so that it is a statement about significant digits)."""
+    def close(got: torch.Tensor, exp: np.ndarray, what: str):
+        exp_t = torch.from_numpy(np.asarray(exp))
+        scale = float(exp_t.abs().max()) if exp_t.numel() else 0.0
+        torch.testing.assert_close(got.to(exp_t.dtype), exp_t, rtol=rtol, atol=atol * max(scale, 1e-3),
+                                   msg=lambda m: f"{what}: {m}")
+
+    for k in ("logits", "v2e0", "e2v0"):
+        assert res[k].shape[0] == int(g["n_rows_" + k]), (k, res[k].shape)
+    if not big:
+        for k in ("logits", "v2e0", "e2v0", "grad_x"):
+            close(res[k], g["out_" + k], k)
+        for key in g:
+            if key.startswith("grad_") and key != "grad_x":
+                close(res["grads"][key[5:]], g[key], key)
+    else:
+        for k in ("logits", "v2e0", "e2v0", "grad_x"):
+            rows = torch.from_numpy(g["rows_" + k])
+            got = res[k][rows]
+            exp = g["out_" + k]
+            close(got[:, :exp.shape[1]], exp, k + "[rows]")
+            s, a = float(res[k].double().sum()), float(res[k].double().abs().sum())
+            tol = (rtol * 10) * float(g["abs_" + k]) + 1e-6
+            assert abs(s - float(g["sum_" + k])) <= tol, (k, s, float(g["sum_" + k]))
+            assert abs(a - float(g["abs_" + k])) <= tol, (k, a, float(g["abs_" + k]))
+        for key in g:
+            if key.startswith("grad_") and key != "grad_x":
+                close(res["grads"][key[5:]], g[key], key)
+            elif key.startswith("gidx_"):
+                name = key[5:]
+                got = res["grads"][name].reshape(-1)
+                close(got[torch.from_numpy(g[key])], g["gval_" + name], "gval_" + name)
+                tol = (rtol * 10) * float(g["gabs_" + name]) + 1e-6
+                assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= tol, name
+                assert abs(float(got.double().abs().sum()) - float(g["gabs_" + name])) <= tol, name
