@@ -1,0 +1,174 @@
+"""GPU: kernel-level parity of every C-ABI entry point against the oracle on seeded random incidences,
+across feature widths (vector and scalar paths, multi-chunk rows), degree shapes (empty, singleton,
+duplicates, > 64 and 4096-long segments) and head configurations (incl. heads that straddle chunks)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import allset_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+RTOL = ATOL = 1e-4
+
+
+def make_incidence(rng, n_s, n_t, nnz, long_row=0, sort=False):
+    src = rng.integers(0, n_s, size=nnz)
+    dst = rng.integers(0, n_t, size=nnz)
+    if n_t > 3:
+        dst[dst == 1] = 0                       # row 1 empty (interior empty segment)
+    if long_row:
+        src = np.concatenate([src, rng.integers(0, n_s, size=long_row)])
+        dst = np.concatenate([dst, np.full(long_row, min(2, n_t - 1))])
+    if sort:
+        o = np.argsort(src, kind="stable")
+        src, dst = src[o], dst[o]
+    return torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+
+
+def test_csr_build_matches_numpy(device):
+    from allset_amd import Incidence
+    rng = np.random.default_rng(0)
+    for n_s, n_t, nnz in ((1, 1, 1), (7, 5, 40), (1000, 300, 20000), (50, 70000, 300000)):
+        ei = make_incidence(rng, n_s, n_t, nnz)
+        inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+        for csr, keys, vals, nr in ((inc.by_dst, ei[1], ei[0], n_t), (inc.by_src, ei[0], ei[1], n_s)):
+            order = np.argsort(keys.numpy(), kind="stable")
+            np.testing.assert_array_equal(csr.perm.cpu().numpy(), order)          # stable: ties keep edge order
+            np.testing.assert_array_equal(csr.col.cpu().numpy(), vals.numpy()[order])
+            rp = np.concatenate([[0], np.cumsum(np.bincount(keys.numpy(), minlength=nr))])
+            np.testing.assert_array_equal(csr.rowptr.cpu().numpy(), rp)
+        pos = inc.pos_dst_of_src().cpu().numpy()
+        np.testing.assert_array_equal(inc.by_dst.perm.cpu().numpy()[pos], inc.by_src.perm.cpu().numpy())
+
+
+def test_csr_build_rejects_out_of_range_ids(device):
+    from allset_amd import Incidence
+    ei = torch.tensor([[0, 1, 5], [0, 1, 1]], dtype=torch.int64, device=device)
+    with pytest.raises(ValueError):
+        Incidence.from_edge_index(ei, n_src=3)
+    empty = Incidence.from_edge_index(torch.zeros((2, 0), dtype=torch.int64, device=device), n_src=4, n_dst=3)
+    assert empty.nnz == 0 and empty.by_dst.rowptr.cpu().tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("aggr", ["add", "mean", "max", "min"])
+@pytest.mark.parametrize("d", [1, 3, 4, 20, 64, 100, 128, 256, 516])
+def test_deepsets_aggregate_fwd_bwd(aggr, d, device):
+    from allset_amd import Incidence, deepsets_aggregate
+    rng = np.random.default_rng(d * 7 + len(aggr))
+    n_s, n_t = 300, 120
+    ei = make_incidence(rng, n_s, n_t, 1500, long_row=200 if d <= 128 else 70)
+    nnz = ei.shape[1]
+    for weighted in (False, True):
+        norm = torch.from_numpy(rng.uniform(0.2, 2.0, size=nnz).astype(np.float32)) if weighted \
+            else torch.ones(nnz, dtype=torch.int64)
+        x = torch.from_numpy(rng.standard_normal((n_s, d)).astype(np.float32))
+        G = torch.from_numpy(rng.standard_normal((n_t, d)).astype(np.float32))
+        xo = x.clone().requires_grad_(True)
+        no = norm.clone().requires_grad_(True) if weighted else norm
+        ref = oracle.deepsets_aggregate(xo, ei, no, aggr)
+        ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], d)])       # oracle sizes by max+1 (Q1)
+        (ref * G).sum().backward()
+
+        inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+        xg = x.to(device).requires_grad_(True)
+        ng = norm.to(device).requires_grad_(True) if weighted else norm.to(device)
+        out = deepsets_aggregate(xg, inc, ng, aggr)
+        (out * G.to(device)).sum().backward()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+        torch.testing.assert_close(xg.grad.cpu(), xo.grad, rtol=RTOL, atol=ATOL)
+        if weighted:
+            torch.testing.assert_close(ng.grad.cpu(), no.grad, rtol=RTOL, atol=ATOL * 10)
+        assert float(out[1].detach().abs().max()) == 0.0                             # empty segment -> exactly 0
+
+
+def test_fixed_float_norm_uses_cached_routing(device):
+    """Non-differentiable float norm (deg_half_sym, preprocessing.py:456-463): weights are routed once."""
+    from allset_amd import Incidence, deepsets_aggregate
+    rng = np.random.default_rng(5)
+    ei = make_incidence(rng, 64, 32, 500)
+    norm = torch.from_numpy(rng.uniform(0.1, 1.0, size=500).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((64, 32)).astype(np.float32))
+    inc = Incidence.from_edge_index(ei.to(device), n_src=64, n_dst=32)
+    ng = norm.to(device)
+    for aggr in ("add", "mean", "max"):
+        xo = x.clone().requires_grad_(True)
+        ref = oracle.deepsets_aggregate(xo, ei, norm, aggr)
+        ref = torch.cat([ref, ref.new_zeros(32 - ref.shape[0], 32)])
+        ref.square().sum().backward()
+        xg = x.to(device).requires_grad_(True)
+        out = deepsets_aggregate(xg, inc, ng, aggr)
+        out.square().sum().backward()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+        torch.testing.assert_close(xg.grad.cpu(), xo.grad, rtol=RTOL, atol=ATOL)
+    assert len(inc._wcache) == 1
+
+
+def test_max_ties_go_to_first_incidence(device):
+    """Documented tie rule: arg-extremum = smallest CSR position = first in edge order."""
+    from allset_amd import Incidence, ops
+    ei = torch.tensor([[0, 1, 2, 3, 4, 5], [0, 0, 0, 0, 1, 1]], dtype=torch.int64, device=device)
+    inc = Incidence.from_edge_index(ei, n_src=6, n_dst=3)
+    x = torch.tensor([[1.0], [5.0], [5.0], [2.0], [-3.0], [-3.0]], device=device).repeat(1, 4).contiguous()
+    out, arg = ops.segreduce(2, inc.by_dst.rowptr, inc.by_dst.col, None, x, 3, want_arg=True)
+    assert out.cpu().tolist() == [[5.0] * 4, [-3.0] * 4, [0.0] * 4]
+    assert arg.cpu().tolist() == [[1] * 4, [4] * 4, [-1] * 4]
+    out, arg = ops.segreduce(3, inc.by_dst.rowptr, inc.by_dst.col, None, x, 3, want_arg=True)
+    assert out.cpu().tolist() == [[1.0] * 4, [-3.0] * 4, [0.0] * 4] and arg.cpu().tolist()[0] == [0] * 4
+
+
+@pytest.mark.parametrize("H,C", [(1, 4), (1, 64), (4, 32), (8, 16), (4, 8), (3, 5), (2, 192), (1, 520), (16, 4), (5, 12)])
+def test_pma_aggregate_fwd_bwd(H, C, device):
+    from allset_amd import Incidence, pma_aggregate, pma_attention_weights
+    rng = np.random.default_rng(H * 100 + C)
+    n_s, n_t = 200, 90
+    ei = make_incidence(rng, n_s, n_t, 1200, long_row=300 if H * C <= 256 else 80, sort=True)
+    V = torch.from_numpy(rng.standard_normal((n_s, H, C)).astype(np.float32))
+    alpha = torch.from_numpy((3.0 * rng.standard_normal((n_s, H))).astype(np.float32))
+    alpha[3, 0] = 0.0                                            # leaky_relu'(0) = slope (PyTorch convention)
+    G = torch.from_numpy(rng.standard_normal((n_t, H, C)).astype(np.float32))
+    Vo, ao = V.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    ref, p_ref = oracle.pma_aggregate(Vo, ao, ei, 0.2)
+    ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], H, C)])
+    (ref * G).sum().backward()
+
+    inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    Vg = V.reshape(n_s, H * C).to(device).requires_grad_(True)
+    ag = alpha.to(device).requires_grad_(True)
+    out, m, l = pma_aggregate(Vg, ag, inc, H, 0.2)
+    (out * G.reshape(n_t, H * C).to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().view(n_t, H, C), ref.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(Vg.grad.cpu().view(n_s, H, C), Vo.grad, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(ag.grad.cpu(), ao.grad, rtol=RTOL, atol=ATOL)
+    p = pma_attention_weights(ag.detach(), m, l, inc, 0.2)
+    torch.testing.assert_close(p.cpu(), p_ref.detach(), rtol=RTOL, atol=1e-6)
+    assert float(out[1].abs().max()) == 0.0 and float(l[1].abs().max()) == 0.0    # empty target
+
+
+def test_pma_extreme_logits_are_stable(device):
+    """Online softmax must survive logits that overflow a naive exp (max-subtraction semantics)."""
+    from allset_amd import Incidence, pma_aggregate
+    ei = torch.tensor([[0, 1, 2, 3], [0, 0, 0, 1]], dtype=torch.int64)
+    V = torch.arange(16, dtype=torch.float32).view(4, 4)
+    alpha = torch.tensor([[200.0], [-500.0], [199.0], [-1e4]])
+    ref, _ = oracle.pma_aggregate(V.view(4, 1, 4), alpha, ei, 0.2)
+    inc = Incidence.from_edge_index(ei.to(device), n_src=4, n_dst=2)
+    out, _, _ = pma_aggregate(V.to(device), alpha.to(device), inc, 1, 0.2)
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out.cpu().view(2, 1, 4), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_strided_inputs_use_leading_dimension(device):
+    """Row-major matrices with ld > d are consumed in place (ABI takes an explicit leading dimension)."""
+    from allset_amd import Incidence, deepsets_aggregate
+    rng = np.random.default_rng(9)
+    ei = make_incidence(rng, 50, 20, 300)
+    big = torch.from_numpy(rng.standard_normal((50, 96)).astype(np.float32)).to(device)
+    x = big[:, 32:64]                                              # ld = 96, 16-byte aligned view
+    inc = Incidence.from_edge_index(ei.to(device), n_src=50, n_dst=20)
+    ref = oracle.deepsets_aggregate(x.cpu(), ei, torch.ones(300, dtype=torch.int64), "add")
+    out = deepsets_aggregate(x, inc, None, "add")
+    torch.testing.assert_close(out.cpu()[:ref.shape[0]], ref, rtol=RTOL, atol=ATOL)
+    x2 = big[:, 1:33]                                              # misaligned view -> scalar kernel path
+    ref2 = oracle.deepsets_aggregate(x2.cpu(), ei, torch.ones(300, dtype=torch.int64), "add")
+    out2 = deepsets_aggregate(x2, inc, None, "add")
+    torch.testing.assert_close(out2.cpu()[:ref2.shape[0]], ref2, rtol=RTOL, atol=ATOL)

@@ -1,0 +1,90 @@
+"""CPU: host-side logic that needs no kernel -- module surface / state_dict layout / init / alpha folding."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import util
+
+
+@pytest.mark.parametrize("name", ["rand50_ds_add", "rand50_pma_h4", "rand50_ds_add_bn", "rand50_pma_h4_L2",
+                                  "rand50_ds_add_wnorm_mask", "citeseer_pma_h4"])
+def test_state_dict_layout_equals_reference(name):
+    """Keys, order and shapes of allset_amd.SetGNN.state_dict() == the reference's (spec captured by
+    oracle/gen_golden.py from the real models.SetGNN)."""
+    from allset_amd import SetGNN
+    case, g = cases.build_case(name), util.load_golden(name)
+    norm = torch.from_numpy(case["norm"]).float() if case["args"].LearnMask else None
+    model = SetGNN(case["args"], norm=norm)
+    got = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert got == util.golden_spec(g)
+
+
+def test_setgnn_zero_layers_is_a_classifier_only():
+    from allset_amd import SetGNN
+    m = SetGNN(cases.make_args("ds_add", 8, 16, 3, All_num_layers=0))
+    assert len(m.V2EConvs) == 0 and m.classifier.lins[0].in_features == 8
+
+
+def test_pma_reset_keeps_linear_biases():
+    """reset_parameters() re-draws lin_K/lin_V weights but never their biases."""
+    from allset_amd import PMA
+    torch.manual_seed(0)
+    p = PMA(16, 32, 32, 2, heads=4)
+    b0, w0 = p.lin_K.bias.detach().clone(), p.lin_K.weight.detach().clone()
+    p.reset_parameters()
+    assert torch.equal(p.lin_K.bias, b0) and not torch.equal(p.lin_K.weight, w0)
+    bound = (6.0 / (16 + 32)) ** 0.5
+    assert float(p.lin_K.weight.abs().max()) <= bound
+    assert p.hidden == 8 and tuple(p.att_r.shape) == (1, 4, 8) and p.dropout == 0.0 and p.bias is None
+
+
+def test_alpha_fold_equals_unfolded_projection():
+    """alpha = <lin_K(x), att_r> computed through the folded [in,H] mat-vec."""
+    from allset_amd import PMA
+    torch.manual_seed(1)
+    p = PMA(24, 32, 32, 2, heads=4).double()
+    x = torch.randn(40, 24, dtype=torch.float64, requires_grad=True)
+    p.fold_alpha = True
+    a1 = p._logits(x)
+    g1 = torch.autograd.grad(a1.square().sum(), [x, p.att_r, p.lin_K.weight, p.lin_K.bias])
+    p.fold_alpha = False
+    a2 = p._logits(x)
+    g2 = torch.autograd.grad(a2.square().sum(), [x, p.att_r, p.lin_K.weight, p.lin_K.bias])
+    torch.testing.assert_close(a1, a2, rtol=1e-12, atol=1e-12)
+    for u, v in zip(g1, g2):
+        torch.testing.assert_close(u, v, rtol=1e-10, atol=1e-10)
+
+
+def test_mlp_matches_oracle_on_cpu():
+    """The dense tail is plain torch on both sides; check the module wiring (norm slots, ReLU order)."""
+    from allset_amd import MLP
+    from oracle import allset_oracle as oracle
+    torch.manual_seed(2)
+    for kind, inorm, layers in (("ln", True, 2), ("ln", False, 3), ("bn", True, 2), ("None", False, 1)):
+        m = MLP(12, 20, 7, layers, dropout=0.5, Normalization=kind, InputNorm=inorm).eval()
+        x = torch.randn(33, 12)
+        sd = {k: v for k, v in m.state_dict().items()}
+        torch.testing.assert_close(m(x), oracle.mlp_forward(sd, "", x, kind), rtol=1e-6, atol=1e-6)
+
+
+def test_halfnlhconv_zero_layers_has_identity_mlps():
+    from allset_amd import HalfNLHconv
+    h = HalfNLHconv(8, 8, 8, 0, 0.0, "ln", True, attention=False)
+    assert isinstance(h.f_enc, torch.nn.Identity) and len(list(h.parameters())) == 0
+
+
+def test_unknown_aggr_is_rejected_before_touching_the_device():
+    from allset_amd import functional as AF
+    with pytest.raises(ValueError):
+        AF.deepsets_aggregate(torch.zeros(2, 2), None, None, "median")
+
+
+def test_case_generators_are_deterministic():
+    a, b = cases.build_case("edge_pma_h4"), cases.build_case("edge_pma_h4")
+    np.testing.assert_array_equal(a["edge_index"], b["edge_index"])
+    ei = a["edge_index"]
+    assert (np.diff(ei[0]) >= 0).all()              # sorted by vertex id, like the reference's preprocessing
+    assert ei[1].min() == 5000                      # hyperedge ids start at n_V
+    sizes = np.bincount(ei[1] - 5000)
+    assert sizes.max() == 4096 and sizes[2] == 0 and sizes[0] == 1
