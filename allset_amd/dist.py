@@ -1,0 +1,230 @@
+"""Hyperedge-sharded execution of the AllSet layer across the GPUs of one node (one process per GPU,
+``torch.distributed``; backend ``nccl`` == RCCL over xGMI on ROCm).  The reference has no distributed
+code at all; this is new, and it is the one real exchange step of the path:
+
+* hyperedges are partitioned into P nnz-balanced shards; rank r owns its hyperedges' rows end to end;
+* vertices are partitioned into P equal blocks for the DENSE per-vertex work (owner computes);
+* V->E : owned vertex rows --all-gather--> full [n_V, d] table --local gather/reduce--> owned hyperedges;
+* E->V : owned hyperedges --local gather/reduce--> PARTIAL sums for all n_V vertices --reduce-scatter-->
+         owned vertex rows.   Backward mirrors: all-gather <-> reduce-scatter swap roles.
+
+So a layer forward is one all-gather + one reduce-scatter of [n_V, d] (and the same pair in backward),
+i.e. the "all-reduce of boundary-vertex embeddings" of the north star split into its two halves so the
+dense tail runs on n_V/P rows instead of n_V.  On a uniformly random hypergraph practically every vertex is
+a boundary vertex, so the exchange is dense.
+
+The local aggregation is pluggable (``aggregate=``): the product passes the HIP-backed functions of
+``functional.py``; the CPU (gloo) tests pass the oracle so the partition + exchange logic is testable
+without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ---------------------------------------------------------------------------------------------
+# partitioning (pure index arithmetic; runs on whatever device the ids live on)
+# ---------------------------------------------------------------------------------------------
+
+def vertex_block(n_v: int, world: int, rank: int) -> Tuple[int, int, int]:
+    """Equal vertex blocks of the padded vertex range.  Returns (lo, hi, n_v_padded)."""
+    per = (n_v + world - 1) // world
+    return rank * per, (rank + 1) * per, per * world
+
+
+def partition_hyperedges(sizes: Tensor, world: int, method: str = "contiguous") -> Tensor:
+    """Assign each hyperedge to a rank so that incidences (nnz), not hyperedge counts, are balanced.
+
+    ``contiguous``: split the id range where the running nnz crosses k/P of the total (keeps locality of
+    neighbouring ids; right for near-uniform sizes).  ``lpt``: longest-processing-time greedy over sizes
+    (right for power-law sizes, BASELINE.json configs[4]).  Returns int64[n_e] owner ranks."""
+    sizes = sizes.to(torch.int64)
+    n_e = sizes.numel()
+    if method == "contiguous":
+        csum = torch.cumsum(sizes, 0)
+        total = int(csum[-1]) if n_e else 0
+        # owner = number of split points strictly below the running midpoint of each hyperedge
+        mid = csum - sizes // 2
+        bounds = torch.tensor([total * (k + 1) // world for k in range(world - 1)], dtype=torch.int64, device=sizes.device)
+        return torch.bucketize(mid, bounds, right=False).clamp_(max=world - 1)
+    if method == "lpt":
+        order = torch.argsort(sizes, descending=True).tolist()
+        load = [0] * world
+        owner = torch.empty(n_e, dtype=torch.int64)
+        sz = sizes.tolist()
+        for e in order:
+            r = min(range(world), key=load.__getitem__)
+            owner[e] = r
+            load[r] += sz[e]
+        return owner.to(sizes.device)
+    raise ValueError(method)
+
+
+def local_shard(edge_index: Tensor, owner: Tensor, rank: int) -> Tuple[Tensor, Tensor]:
+    """Incidences of the hyperedges owned by ``rank`` with hyperedge ids renumbered 0..n_e_local-1 in
+    increasing global-id order.  ``edge_index``: [2, nnz] (row 0 global vertex ids, row 1 global 0-based
+    hyperedge ids).  Returns (local edge_index, int64[n_e_local] global ids of the local hyperedges)."""
+    mine = owner == rank
+    gids = mine.nonzero().reshape(-1)
+    new_id = torch.full_like(owner, -1)
+    new_id[gids] = torch.arange(gids.numel(), device=owner.device)
+    keep = mine[edge_index[1]]
+    loc = torch.stack([edge_index[0][keep], new_id[edge_index[1][keep]]], dim=0)
+    return loc.contiguous(), gids
+
+
+# ---------------------------------------------------------------------------------------------
+# collectives with autograd mirrors
+# ---------------------------------------------------------------------------------------------
+
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_gather_rows(x: Tensor, group=None) -> Tensor:
+    w = _world(group)
+    if w == 1:
+        return x
+    x = x.contiguous()
+    out = x.new_empty((w * x.shape[0],) + tuple(x.shape[1:]))
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
+def _reduce_scatter_rows(x: Tensor, group=None) -> Tensor:
+    w = _world(group)
+    if w == 1:
+        return x
+    x = x.contiguous()
+    per = x.shape[0] // w
+    if dist.get_backend(group) == "gloo":            # gloo has no reduce_scatter: all-reduce + slice (tests only)
+        buf = x.clone()
+        dist.all_reduce(buf, group=group)
+        r = dist.get_rank(group)
+        return buf[r * per:(r + 1) * per].contiguous()
+    out = x.new_empty((per,) + tuple(x.shape[1:]))
+    dist.reduce_scatter_tensor(out, x, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+class _AllGatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return _all_gather_rows(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _reduce_scatter_rows(g, ctx.group), None
+
+
+class _ReduceScatterRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return _reduce_scatter_rows(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _all_gather_rows(g, ctx.group), None
+
+
+def all_gather_rows(x: Tensor, group=None) -> Tensor:
+    """[n/P, ...] owned block -> [n, ...] full table; backward = sum-reduce-scatter of the gradient."""
+    return _AllGatherRows.apply(x, group)
+
+
+def reduce_scatter_rows(x: Tensor, group=None) -> Tensor:
+    """[n, ...] per-rank partial sums -> [n/P, ...] owned block of the total; backward = all-gather."""
+    return _ReduceScatterRows.apply(x, group)
+
+
+# ---------------------------------------------------------------------------------------------
+# the sharded layer
+# ---------------------------------------------------------------------------------------------
+
+class ShardedHypergraph:
+    """One rank's view: its hyperedges' incidences over the GLOBAL (padded) vertex range.
+
+    ``local_edge_index``: int64 [2, nnz_local], row 0 global vertex ids, row 1 local hyperedge ids.
+    ``v2e`` / ``e2v`` are whatever the ``aggregate`` callables accept as their incidence argument -- the
+    product builds :class:`allset_amd.incidence.Incidence` objects (``build_incidences``)."""
+
+    def __init__(self, local_edge_index: Tensor, n_v: int, n_e_local: int, world: int, rank: int,
+                 norm: Optional[Tensor] = None):
+        self.local_edge_index = local_edge_index
+        self.n_v, self.n_e_local, self.world, self.rank = int(n_v), int(n_e_local), int(world), int(rank)
+        self.v_lo, self.v_hi, self.n_v_pad = vertex_block(n_v, world, rank)
+        self.norm = norm
+        self.v2e = None
+        self.e2v = None
+        self._vdeg_owned: Optional[Tensor] = None
+
+    def build_incidences(self) -> "ShardedHypergraph":
+        from .incidence import Incidence
+        self.v2e = Incidence.from_edge_index(self.local_edge_index, n_src=self.n_v_pad, n_dst=self.n_e_local)
+        self.e2v = self.v2e.reversed(n_dst=self.n_v_pad)          # partial rows for EVERY vertex
+        return self
+
+    def owned_vertex_degree(self, group=None) -> Tensor:
+        """Global degree of the owned vertices (for E->V 'mean'); one reduce-scatter, cached."""
+        if self._vdeg_owned is None:
+            deg = torch.bincount(self.local_edge_index[0], minlength=self.n_v_pad).to(torch.float32)
+            self._vdeg_owned = _reduce_scatter_rows(deg.view(-1, 1), group).view(-1)
+        return self._vdeg_owned
+
+
+def _hip_deepsets(x, inc, norm, aggr):
+    from . import functional as AF
+    return AF.deepsets_aggregate(x, inc, norm, aggr)
+
+
+def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, aggr: str = "add",
+                           dropout: float = 0.0, training: bool = False, group=None,
+                           aggregate: Callable = _hip_deepsets) -> Tensor:
+    """One V->E->V AllDeepSets layer (reference models.py:475-481 with layers.py:630-634 inlined) on a
+    hyperedge shard.  ``x_owned``: this rank's block of vertex rows [n_v_pad/P, F].  Returns the owned block
+    of the layer output.  ``v2e_conv`` / ``e2v_conv`` are :class:`allset_amd.layers.HalfNLHconv` (Deep Sets
+    variant); their parameters are replicated, so parameter gradients must be all-reduced by the caller
+    (``allreduce_grads``) -- each rank sees only its rows."""
+    if aggr not in ("add", "sum", "mean"):
+        raise NotImplementedError("sharded E->V supports add/sum/mean (max needs an arg-owner exchange)")
+    # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
+    h = F.relu(v2e_conv.f_enc(x_owned))
+    h = F.dropout(h, p=v2e_conv.dropout, training=training)
+    h_full = all_gather_rows(h, group)
+    e = aggregate(h_full, hg.v2e, hg.norm, aggr)
+    e = F.relu(v2e_conv.f_dec(e))                               # conv's relu; SetGNN's outer relu is idempotent
+    e = F.dropout(e, p=dropout, training=training)
+    # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
+    g = F.relu(e2v_conv.f_enc(e))
+    g = F.dropout(g, p=e2v_conv.dropout, training=training)
+    partial = aggregate(g, hg.e2v, hg.norm, "add")
+    v = reduce_scatter_rows(partial, group)
+    if aggr == "mean":
+        v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
+    v = F.relu(e2v_conv.f_dec(v))
+    return F.dropout(v, p=dropout, training=training)
+
+
+def allreduce_grads(params, group=None) -> None:
+    """Sum replicated-parameter gradients over ranks with ONE flat all-reduce (the layer's parameters are a
+    few hundred KB; bucketing them into a single message keeps this off the per-link latency floor)."""
+    if _world(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

@@ -4,8 +4,10 @@ tensors; outputs are allocated with torch (plumbing) and filled by the HIP kerne
 """
 from __future__ import annotations
 
+from collections import defaultdict
+from contextlib import contextmanager
 from ctypes import byref, c_size_t
-from typing import NamedTuple, Optional, Tuple
+from typing import Dict, List, NamedTuple, Optional, Tuple
 
 import torch
 
@@ -13,6 +15,47 @@ from . import _lib
 from ._lib import check, ptr, require_device, stream_of
 
 Tensor = torch.Tensor
+
+
+class KernelTimer:
+    """Opt-in per-entry-point timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  ``bench.py`` installs one over its timed region; when none is installed
+    the wrappers below add no events.  ``algo_bytes`` is the ALGORITHMIC traffic of the call (SURVEY.md
+    section 8(d3) gather model: every incidence reads its d-vector once; int32 CSR)."""
+
+    def __init__(self):
+        self.events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event, int]]] = defaultdict(list)
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        """Call after a device synchronise.  name -> {calls, avg_ms, total_ms, algo_bytes (per call)}."""
+        out = {}
+        for name, evs in self.events.items():
+            ms = [s.elapsed_time(e) for s, e, _ in evs]
+            out[name] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                             algo_bytes=sum(b for _, _, b in evs) / len(evs))
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = timer
+
+
+@contextmanager
+def _timed(name: str, dev, algo_bytes: int):
+    t = _timer
+    if t is None:
+        yield
+        return
+    st = torch.cuda.current_stream(dev)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(st)
+    yield
+    e.record(st)
+    t.events[name].append((s, e, int(algo_bytes)))
 
 
 class CSR(NamedTuple):
@@ -77,7 +120,9 @@ def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: 
     if w is not None:
         _f32(w, "segreduce weights")
         w = w.contiguous()
-    with torch.cuda.device(dev):
+    nnz = col.numel()
+    algo = nnz * (4 * d + 4 + (4 if w is not None else 0)) + (n_t + 1) * 4 + n_t * d * 4
+    with torch.cuda.device(dev), _timed("segreduce_fwd", dev, algo):
         check(_lib.load().allset_segreduce_fwd(reduce, _lib.F32, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
                                                ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
               "allset_segreduce_fwd")
@@ -91,7 +136,8 @@ def segmax_bwd(rowptrT: Tensor, colT: Tensor, posT: Tensor, wT: Optional[Tensor]
     gout = _rowmajor(gout)
     n_t, d = gout.shape
     gx = torch.empty((n_s, d), dtype=gout.dtype, device=dev)
-    with torch.cuda.device(dev):
+    algo = colT.numel() * (4 * d + 4 * d + 8) + (n_s + 1) * 4 + n_s * d * 4
+    with torch.cuda.device(dev), _timed("segmax_bwd", dev, algo):
         check(_lib.load().allset_segmax_bwd(ptr(rowptrT), ptr(colT), ptr(posT), ptr(wT), ptr(argext), ptr(gout),
                                             _ld(gout), ptr(gx), max(d, 1), n_s, n_t, d, stream_of(dev)),
               "allset_segmax_bwd")
@@ -105,7 +151,8 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
     n_s, d = x.shape
     n_t = gout.shape[0]
     gw = torch.empty(col.numel(), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    algo = col.numel() * (4 * d + 8) + (n_t + 1) * 4 + n_t * d * 4
+    with torch.cuda.device(dev), _timed("sddmm_rowdot", dev, algo):
         check(_lib.load().allset_sddmm_rowdot(reduce, ptr(rowptr), ptr(col), ptr(x), _ld(x), ptr(gout), _ld(gout),
                                               ptr(argext), ptr(gw), n_t, n_s, d, stream_of(dev)),
               "allset_sddmm_rowdot")
@@ -124,7 +171,8 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
     out = torch.empty((n_t, d), dtype=V.dtype, device=dev)
     m = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
     l = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    algo = col.numel() * (4 * d + 4 + 4 * heads) + (n_t + 1) * 4 + n_t * (d * 4 + 8 * heads)
+    with torch.cuda.device(dev), _timed("pma_fwd", dev, algo):
         check(_lib.load().allset_pma_fwd(_lib.F32, ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V), slope, ptr(out),
                                          max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads, stream_of(dev)),
               "allset_pma_fwd")
@@ -147,7 +195,8 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
     n_t, d = out.shape
     heads = m.shape[1]
     stats = torch.empty((n_t, heads, 4), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    algo = n_t * (2 * d * 4 + 8 * heads + 16 * heads)
+    with torch.cuda.device(dev), _timed("pma_bwd_stats", dev, algo):
         check(_lib.load().allset_pma_bwd_stats(_lib.F32, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m), ptr(l),
                                                ptr(stats), n_t, heads, d // heads, stream_of(dev)),
               "allset_pma_bwd_stats")
@@ -164,7 +213,8 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     heads = alpha.shape[1]
     gV = torch.empty((n_s, d), dtype=V.dtype, device=dev)
     galpha = torch.empty((n_s, heads), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    algo = colT.numel() * (4 * d + 4 + 16 * heads) + (n_s + 1) * 4 + n_s * (2 * d * 4 + 8 * heads)
+    with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
         check(_lib.load().allset_pma_bwd_src(_lib.F32, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V), ptr(gout),
                                              _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1), ptr(galpha),
                                              n_s, n_t, heads, d // heads, stream_of(dev)),

@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- edges*d aggregated / sec for one V->E->V AllSet layer, forward + backward, on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched under
+``python -m torch.distributed.run --nproc-per-node N``, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+synthetic random hypergraph, |V| = |E| = 1M per GPU, every hyperedge has 16 distinct uniformly drawn members
+(nnz = 16M per GPU), d = 128, fp32, AllDeepSets (HalfNLHconv x2 with 2-layer LayerNorm MLPs, aggr = add,
+all-ones norm), weights from ``reset_parameters()`` under a fixed seed.  Weak scaling: rank r owns its own 1M
+hyperedges over the global N*1M vertex range; the exchange is one all-gather + one reduce-scatter of
+[n_V, d] per direction (allset_amd/dist.py).
+
+One STEP = zero_grad + full layer forward (dense tail included, dropout active as in train.py) + backward
+(gradients w.r.t. the input features and all parameters: four gather passes) + gradient all-reduce + Adam step.
+``value`` = N * nnz_local * d / (seconds per step), inputs resident in HBM.  Nothing on the path is skipped.
+
+Extra objects in the JSON line:
+  roofline      the dominant kernel (segreduce_fwd): algorithmic bytes per launch (SURVEY section 8(d3):
+                nnz*(4d+4) + (n_t+1)*4 + n_t*4d) / its mean launch time from HIP events recorded on the
+                launch stream INSIDE the timed region; peak = 8 TB/s HBM3E.
+  aggregation   the aggregation-only figure (all allset kernel time per step), which is what the
+                north star's "% of HBM roofline on the V->E->V aggregation" refers to.
+  cpu_baseline  the oracle (a restatement of the reference's CPU torch_scatter path) timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-per-gpu", type=int, default=1_000_000, help="|V| and |E| per GPU")
+    ap.add_argument("--degree", type=int, default=16)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--degree-dist", default="fixed", choices=["fixed", "poisson", "zipf"])
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=100_000, help="|V| = |E| of the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="host threads for the CPU baseline (32 is the fastest setting for torch's scatter_add_/"
+                         "index_select on the 2x128-thread GPU box: profiles/r01_cpu_threads_probe.txt)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, d, degree):
+    """Time the oracle (oracle/allset_oracle.py: index_select -> mul -> scatter_add_ + autograd, the ops
+    torch_scatter 2.0.4 dispatches to for reference layers.py:633-656) on the host cores, on a bounded
+    sample of the same workload.  Only this leg of bench.py touches oracle/."""
+    from oracle import allset_oracle as oracle
+    from allset_amd.synthetic import random_hypergraph
+    from allset_amd.layers import HalfNLHconv
+    n = args.cpu_sample_n
+    cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    hg = random_hypergraph(n, n, degree, seed=args.seed + 1, device="cpu", dist=args.degree_dist)
+    ei, norm = hg.edge_index, hg.norm                       # int64 all-ones norm: the reference default (Q3)
+    gen = torch.Generator().manual_seed(args.seed)
+    x = torch.randn(n, d, generator=gen)
+    # (a) aggregation only
+    agg = []
+    for it in range(args.cpu_iters + 1):
+        t0 = time.perf_counter()
+        oracle.v2e2v_aggregation_fwd_bwd(x, ei, norm, "add")
+        if it:
+            agg.append(time.perf_counter() - t0)
+    # (b) the full layer, same state_dict layout as the GPU step (eval-mode: the oracle has no dropout)
+    torch.manual_seed(args.seed)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, attention=False)
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, attention=False)
+    sd = {f"V2EConvs.0.{k}": v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in a.state_dict().items()}
+    sd.update({f"E2VConvs.0.{k}": v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in b.state_dict().items()})
+    rev = torch.stack([ei[1], ei[0]])
+    full = []
+    for it in range(args.cpu_iters + 1):
+        t0 = time.perf_counter()
+        xr = x.clone().requires_grad_(True)
+        e = torch.relu(oracle.halfnlhconv_forward(sd, "V2EConvs.0.", xr, ei, norm, "add", False, 1, "ln"))
+        v = torch.relu(oracle.halfnlhconv_forward(sd, "E2VConvs.0.", e, rev, norm, "add", False, 1, "ln"))
+        v.backward(torch.ones_like(v))
+        for t in sd.values():
+            t.grad = None
+        if it:
+            full.append(time.perf_counter() - t0)
+    unit = hg.nnz * d
+    return {
+        "value": unit / statistics.median(full), "unit": "edges*d/s", "cores": cores, "kind": "port",
+        "sample": f"|V|=|E|={n}, deg {degree} ({args.degree_dist}), d={d}, nnz={hg.nnz}, int64 all-ones norm; full "
+                  f"AllDeepSets layer fwd+bwd (eval-mode, no dropout), median of {args.cpu_iters} after 1 warm-up; "
+                  f"torch {torch.__version__} CPU, {cores} threads of {os.cpu_count()} logical CPUs",
+        "seconds_per_iter": statistics.median(full),
+        "aggregation_only": {"value": unit / statistics.median(agg), "seconds_per_iter": statistics.median(agg)},
+    }
+
+
+def hbm_traffic_from_profile():
+    """HBM bytes per segreduce launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get("segreduce_fwd_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE is 1)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from allset_amd import _lib, ops
+    from allset_amd import dist as adist
+    from allset_amd.layers import HalfNLHconv
+    from allset_amd.synthetic import random_hypergraph
+    _lib.load()                                                       # fail loudly if the HIP library is absent
+
+    d, n_loc = args.d, args.n_per_gpu
+    n_v = n_loc * world                                               # weak scaling: global vertex range grows with N
+    shard = random_hypergraph(n_v, n_loc, args.degree, seed=args.seed + 1 + rank, device=dev, dist=args.degree_dist)
+    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, rank, norm=shard.norm).build_incidences()
+    nnz_local = shard.nnz
+
+    torch.manual_seed(args.seed)                                       # identical replicated weights on every rank
+    v2e = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, attention=False)
+    e2v = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, attention=False)
+    v2e.reset_parameters(); e2v.reset_parameters()
+    v2e.to(dev).train(); e2v.to(dev).train()
+    params = list(v2e.parameters()) + list(e2v.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+
+    gen = torch.Generator(device=dev).manual_seed(args.seed + 100 + rank)
+    rows = hg.v_hi - hg.v_lo
+    x = torch.randn(rows, d, device=dev, generator=gen).requires_grad_(True)       # owned vertex block
+    G = torch.randn(rows, d, device=dev, generator=gen)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        x.grad = None
+        out = adist.sharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True)
+        out.backward(G)
+        adist.allreduce_grads(params)
+        opt.step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer()
+    fence()
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+
+    stats = torch.tensor([elapsed, float(nnz_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, nnz_total = float(tmax[0]), float(tsum[1])
+    else:
+        nnz_total = float(nnz_local)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = nnz_total * d / (elapsed / args.steps)
+        ks = timer.summary()
+        seg = ks.get("segreduce_fwd")
+        agg_ms = sum(v["total_ms"] for v in ks.values()) / args.steps
+        traffic = hbm_traffic_from_profile() if (world == 1 and args.n_per_gpu == 1_000_000 and d == 128) else None
+        roofline = None
+        if seg:
+            achieved = seg["algo_bytes"] / (seg["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "segreduce_kernel<4,32,sum> (allset_segreduce_fwd)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "algo_bytes_per_launch": seg["algo_bytes"], "avg_launch_ms": seg["avg_ms"],
+                        "launches": seg["calls"]}
+        line = {
+            "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": value, "unit": "edges*d/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: synthetic random hypergraph |V|=|E|={n_loc} per GPU, "
+                                   f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, "
+                                   f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), "
+                                   f"fwd+bwd+Adam", "n_v": n_v, "n_e": n_loc * world, "nnz": int(nnz_total), "d": d,
+                       "parallelism": f"hyperedge-shard x{world}" if world > 1 else "single GPU", "seed": args.seed},
+            "roofline": roofline,
+            "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if world == 1 else None,
+                            "unit": "edges*d/s", "note": "all allset_* kernel time per step (HIP events, rank 0): the "
+                            "aggregation-only V->E->V fwd+bwd", "kernels": {k: {"calls_per_step": v["calls"] / args.steps,
+                                                                          "avg_ms": v["avg_ms"]} for k, v in ks.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, d, args.degree)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
