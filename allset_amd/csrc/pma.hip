@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void pma_attention_kernel(
   }
 }
 
-// stats[t,h] = {m, 1/(l+eps), <out[t,h,:], gout[t,h,:]>, 0}
+// stats[t,h] = {M, delta}:  M = m + log(l + eps)  (so that p = exp(a - M)),  delta = <out[t,h,:], gout[t,h,:]>
 template <int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
     const float* __restrict__ out, int64_t ldo, const float* __restrict__ gout, int64_t ldg,
@@ -177,12 +177,10 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
   for (int h = lane; h < H; h += kWave) {
     const int64_t th = static_cast<int64_t>(row) * H + h;
     const float lv = l[th];
-    float4 s;
-    s.x = m[th];
-    s.y = lv > 0.f ? 1.f / (lv + kSoftmaxEps) : 0.f;
-    s.z = red[wave][h];
-    s.w = 0.f;
-    *reinterpret_cast<float4*>(stats + th * 4) = s;
+    float2 s;
+    s.x = lv > 0.f ? m[th] + __logf(lv + kSoftmaxEps) : FLT_MAX;   // empty target: never gathered; exp(a - FLT_MAX) = 0
+    s.y = red[wave][h];
+    *reinterpret_cast<float2*>(stats + th * 2) = s;
   }
 }
 
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
       const int my_col = (lane < n) ? colT[base + lane] : 0;
       for (int j = 0; j < n; j += NS * kPmaUnroll) {
         FVec<VEC> g[kPmaUnroll];
-        float4 st[kPmaUnroll];
+        float2 st[kPmaUnroll];
         bool ok[kPmaUnroll];
 #pragma unroll
         for (int u = 0; u < kPmaUnroll; ++u) {
@@ -238,13 +236,13 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
           const int t = __shfl(my_col, jj & (kWave - 1));
           if (ok[u]) {
             g[u] = load_vec<VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
-            st[u] = *reinterpret_cast<const float4*>(stats + (static_cast<int64_t>(t) * H + h) * 4);
+            st[u] = *reinterpret_cast<const float2*>(stats + (static_cast<int64_t>(t) * H + h) * 2);
           }
         }
 #pragma unroll
         for (int u = 0; u < kPmaUnroll; ++u) {
           if (ok[u]) {
-            const float p = __expf(a_s - st[u].x) * st[u].y;
+            const float p = __expf(a_s - st[u].x);
             float dotp = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -252,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
               dotp = fmaf(vown.v[k], g[u].v[k], dotp);
             }
             S = fmaf(p, dotp, S);
-            D = fmaf(p, st[u].z, D);
+            D = fmaf(p, st[u].y, D);
           }
         }
       }
@@ -365,7 +363,7 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
   const int64_t d = H * C;
   ALLSET_REQUIRE(out && gout && m && l && stats, "pma_bwd_stats: null pointer");
   ALLSET_REQUIRE(ldo >= d && ldg >= d, "pma_bwd_stats: leading dimension smaller than H*C");
-  ALLSET_REQUIRE(aligned16(stats), "pma_bwd_stats: stats must be 16-byte aligned");
+  ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "pma_bwd_stats: stats must be 8-byte aligned");
   const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (ldg % 4 == 0) && aligned16(out) && aligned16(gout);
   const hipStream_t st = static_cast<hipStream_t>(stream);
   ALLSET_PMA_DISPATCH(pma_bwd_stats_kernel, row_grid(n_t), st, static_cast<const float*>(out), ldo,
@@ -388,7 +386,7 @@ extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32
   ALLSET_REQUIRE(rowptrT && alpha && V && gV && galpha, "pma_bwd_src: null pointer");
   ALLSET_REQUIRE(n_t == 0 || (colT && gout && stats), "pma_bwd_src: null colT/gout/stats with n_t > 0");
   ALLSET_REQUIRE(ldv >= d && ldg >= d && ldgv >= d, "pma_bwd_src: leading dimension smaller than H*C");
-  ALLSET_REQUIRE(stats == nullptr || aligned16(stats), "pma_bwd_src: stats must be 16-byte aligned");
+  ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "pma_bwd_src: stats must be 8-byte aligned");
   const bool vec4 = (C % 4 == 0) && (ldv % 4 == 0) && (ldg % 4 == 0) && (ldgv % 4 == 0) && aligned16(V) &&
                     aligned16(gout) && aligned16(gV);
   const hipStream_t st = static_cast<hipStream_t>(stream);

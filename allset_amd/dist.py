@@ -19,6 +19,7 @@ without a GPU.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -87,10 +88,18 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _skip_collective(group=None) -> bool:
+    """World size 1 needs no exchange -- unless ALLSET_FORCE_COLLECTIVES=1, which runs the very same RCCL
+    calls on a 1-rank group (the only way to exercise them on a 1-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") != "1"
+
+
 def _all_gather_rows(x: Tensor, group=None) -> Tensor:
-    w = _world(group)
-    if w == 1:
+    if _skip_collective(group):
         return x
+    w = _world(group)
     x = x.contiguous()
     out = x.new_empty((w * x.shape[0],) + tuple(x.shape[1:]))
     dist.all_gather_into_tensor(out, x, group=group)
@@ -98,9 +107,9 @@ def _all_gather_rows(x: Tensor, group=None) -> Tensor:
 
 
 def _reduce_scatter_rows(x: Tensor, group=None) -> Tensor:
-    w = _world(group)
-    if w == 1:
+    if _skip_collective(group):
         return x
+    w = _world(group)
     x = x.contiguous()
     per = x.shape[0] // w
     if dist.get_backend(group) == "gloo":            # gloo has no reduce_scatter: all-reduce + slice (tests only)
@@ -216,7 +225,7 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
 def allreduce_grads(params, group=None) -> None:
     """Sum replicated-parameter gradients over ranks with ONE flat all-reduce (the layer's parameters are a
     few hundred KB; bucketing them into a single message keeps this off the per-link latency floor)."""
-    if _world(group) == 1:
+    if _skip_collective(group):
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

@@ -194,8 +194,8 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
     out, gout = _rowmajor(out), _rowmajor(gout)
     n_t, d = out.shape
     heads = m.shape[1]
-    stats = torch.empty((n_t, heads, 4), dtype=torch.float32, device=dev)
-    algo = n_t * (2 * d * 4 + 8 * heads + 16 * heads)
+    stats = torch.empty((n_t, heads, 2), dtype=torch.float32, device=dev)
+    algo = n_t * (2 * d * 4 + 8 * heads + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_stats", dev, algo):
         check(_lib.load().allset_pma_bwd_stats(_lib.F32, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m), ptr(l),
                                                ptr(stats), n_t, heads, d // heads, stream_of(dev)),
@@ -213,7 +213,7 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     heads = alpha.shape[1]
     gV = torch.empty((n_s, d), dtype=V.dtype, device=dev)
     galpha = torch.empty((n_s, heads), dtype=torch.float32, device=dev)
-    algo = colT.numel() * (4 * d + 4 + 16 * heads) + (n_s + 1) * 4 + n_s * (2 * d * 4 + 8 * heads)
+    algo = colT.numel() * (4 * d + 4 + 8 * heads) + (n_s + 1) * 4 + n_s * (2 * d * 4 + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
         check(_lib.load().allset_pma_bwd_src(_lib.F32, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V), ptr(gout),
                                              _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1), ptr(galpha),

@@ -136,7 +136,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force = os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") == "1"      # 1-rank RCCL group: API check on a 1-GPU box
+    if world > 1 or (force and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=dev)
 
     from allset_amd import _lib, ops
@@ -173,7 +174,7 @@ def main():
         opt.step()
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -186,14 +187,14 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
 
     stats = torch.tensor([elapsed, float(nnz_local)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, nnz_total = float(tmax[0]), float(tsum[1])
@@ -234,7 +235,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

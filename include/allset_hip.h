@@ -132,14 +132,14 @@ int allset_pma_attention(const int32_t* rowptr, const int32_t* col, const float*
                          const float* m, const float* l, float slope, float* p,
                          int64_t n_t, int64_t H, void* stream);
 
-/* Backward, step 1 (dense, target-major): stats[t,h] = { m, 1/(l+1e-16), delta, 0 } with
- * delta[t,h] = <out[t,h,:], gout[t,h,:]>.   stats: f32[n_t*H*4]. */
+/* Backward, step 1 (dense, target-major): stats[t,h] = { M, delta } with M = m + log(l + 1e-16) (so that
+ * p_j = exp(a_j - M)) and delta[t,h] = <out[t,h,:], gout[t,h,:]>.   stats: f32[n_t*H*2], 8-byte aligned. */
 int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg,
                          const float* m, const float* l, float* stats,
                          int64_t n_t, int64_t H, int64_t C, void* stream);
 
 /* Backward, step 2 (one gather pass, source-major, on the TRANSPOSED CSR; no [nnz,*] temporaries):
- *   p_j        = exp(lrelu(alpha[s,h]) - m[t_j,h]) / (l[t_j,h]+1e-16)
+ *   p_j        = exp(lrelu(alpha[s,h]) - M[t_j,h])
  *   gV[s,h,:]  = sum_j p_j * gout[t_j,h,:]
  *   galpha[s,h]= lrelu'(alpha[s,h]) * sum_j p_j * (<V[s,h,:], gout[t_j,h,:]> - delta[t_j,h])
  * with lrelu'(x) = 1 if x > 0 else slope (PyTorch's convention at 0). */
