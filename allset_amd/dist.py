@@ -194,6 +194,33 @@ def _hip_deepsets(x, inc, norm, aggr):
     return AF.deepsets_aggregate(x, inc, norm, aggr)
 
 
+class HipPmaKernels:
+    """The four local PMA primitives the sharded layer needs, on the HIP kernels.  The gloo tests swap in a
+    torch-CPU object with the same four methods."""
+
+    @staticmethod
+    def aggregate(V, alpha, inc, heads, slope):            # differentiable, complete targets (V->E)
+        from . import functional as AF
+        return AF.pma_aggregate(V, alpha, inc, heads, slope)[0]
+
+    @staticmethod
+    def fwd(V, alpha, inc, heads, slope):                   # raw: (out, m, l), local softmax statistics
+        from . import ops
+        csr = inc.by_dst
+        return ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst)
+
+    @staticmethod
+    def bwd_stats(out, gout, m, l):
+        from . import ops
+        return ops.pma_bwd_stats(out, gout, m, l)
+
+    @staticmethod
+    def bwd_src(inc, alpha, V, gout, stats, slope):
+        from . import ops
+        T = inc.by_src
+        return ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, slope)
+
+
 def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, aggr: str = "add",
                            dropout: float = 0.0, training: bool = False, group=None,
                            aggregate: Callable = _hip_deepsets) -> Tensor:
@@ -220,6 +247,85 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
         v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
     v = F.relu(e2v_conv.f_dec(v))
     return F.dropout(v, p=dropout, training=training)
+
+
+class _ShardedPmaE2V(torch.autograd.Function):
+    """E->V attention pooling when a vertex's hyperedges live on several ranks.
+
+    forward : local fused pass -> (o_loc, m_loc, l_loc) for every vertex; all-reduce(max) of m;
+              rescale w = l_loc * exp(m_loc - m_glob); reduce-scatter(sum) of [o_loc * w | w] -> owned rows;
+              out = numer / (l_glob + 1e-16).
+    backward: stats {M = m_glob + log l_glob, delta = <out, gO>} on owned rows; all-gather [gO | stats];
+              the ordinary one-pass source-major kernel with the GLOBAL stats gives exact gV / galpha for
+              the local hyperedges (p_j = exp(a_j - M_t) is the global softmax weight).
+    """
+
+    @staticmethod
+    def forward(ctx, V, alpha, hg, heads, slope, group, K):
+        inc = hg.e2v
+        o_loc, m_loc, l_loc = K.fwd(V, alpha, inc, heads, slope)          # [n_v_pad, d], [n_v_pad, H] x2
+        n, d = o_loc.shape
+        C = d // heads
+        has = l_loc > 0
+        neg_inf = torch.full_like(m_loc, float("-inf"))
+        m_eff = torch.where(has, m_loc, neg_inf)
+        m_g = m_eff.clone()
+        if not _skip_collective(group):
+            dist.all_reduce(m_g, op=dist.ReduceOp.MAX, group=group)
+        w = torch.where(has, l_loc * torch.exp(m_eff - torch.where(has, m_g, m_eff)), torch.zeros_like(l_loc))
+        packed = torch.cat([(o_loc.view(n, heads, C) * w.unsqueeze(-1)).view(n, d), w], dim=1)
+        red = _reduce_scatter_rows(packed, group)                           # owned rows
+        numer, l_g = red[:, :d], red[:, d:].contiguous()
+        inv = torch.where(l_g > 0, 1.0 / (l_g + 1e-16), torch.zeros_like(l_g))
+        out = (numer.reshape(-1, heads, C) * inv.unsqueeze(-1)).reshape(-1, d).contiguous()
+        lo, hi = hg.v_lo, hg.v_hi
+        m_g_owned = torch.where(l_g > 0, m_g[lo:hi], torch.zeros_like(l_g)).contiguous()
+        ctx.save_for_backward(V, alpha, out, m_g_owned, l_g)
+        ctx.hg, ctx.heads, ctx.slope, ctx.group, ctx.K = hg, heads, slope, group, K
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        V, alpha, out, m_g, l_g = ctx.saved_tensors
+        hg, H, K = ctx.hg, ctx.heads, ctx.K
+        gout = gout.contiguous()
+        stats = K.bwd_stats(out, gout, m_g, l_g)                            # [n_own, H, 2]
+        d = gout.shape[1]
+        packed = torch.cat([gout, stats.reshape(gout.shape[0], 2 * H)], dim=1)
+        full = _all_gather_rows(packed, ctx.group)
+        g_full = full[:, :d].contiguous()
+        stats_full = full[:, d:].contiguous().view(-1, H, 2)
+        gV, galpha = K.bwd_src(hg.e2v, alpha, V, g_full, stats_full, ctx.slope)
+        return gV, galpha, None, None, None, None, None
+
+
+def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, dropout: float = 0.0,
+                      training: bool = False, group=None, kernels=HipPmaKernels) -> Tensor:
+    """One V->E->V AllSetTransformer layer (reference models.py:475-481 with PMA.forward, layers.py:120-157,
+    inlined) on a hyperedge shard.  ``v2e_conv`` / ``e2v_conv``: :class:`allset_amd.layers.HalfNLHconv` with
+    ``attention=True``.  V->E targets (hyperedges) are complete on their owner, so that direction is the local
+    kernel behind an all-gather of [V | alpha]; E->V needs the cross-shard softmax merge above."""
+    K = kernels
+    # ---- V -> E
+    p = v2e_conv.prop
+    H, C = p.heads, p.hidden
+    packed = torch.cat([p.lin_V(x_owned), p._logits(x_owned)], dim=1)            # dense on owned vertices
+    full = all_gather_rows(packed, group)
+    V, alpha = full[:, :H * C], full[:, H * C:]
+    o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
+    o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
+    o = p.ln0(o)
+    e = p.ln1(o + F.relu(p.rFF(o)))
+    e = F.dropout(F.relu(e), p=dropout, training=training)
+    # ---- E -> V
+    p = e2v_conv.prop
+    H, C = p.heads, p.hidden
+    V, alpha = p.lin_V(e), p._logits(e)                                             # dense on owned hyperedges
+    o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
+    o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
+    o = p.ln0(o)
+    v = p.ln1(o + F.relu(p.rFF(o)))
+    return F.dropout(F.relu(v), p=dropout, training=training)
 
 
 def allreduce_grads(params, group=None) -> None:

@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--degree", type=int, default=16)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--degree-dist", default="fixed", choices=["fixed", "poisson", "zipf"])
+    ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
+                    help="deepsets = AllDeepSets (the headline, BASELINE configs[2]); pma = AllSetTransformer "
+                         "(configs[3] per-GPU shape), not the driver's default")
+    ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,8 +157,9 @@ def main():
     nnz_local = shard.nnz
 
     torch.manual_seed(args.seed)                                       # identical replicated weights on every rank
-    v2e = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, attention=False)
-    e2v = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, attention=False)
+    attn = args.model == "pma"
+    v2e = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, heads=args.heads, attention=attn)
+    e2v = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, heads=args.heads, attention=attn)
     v2e.reset_parameters(); e2v.reset_parameters()
     v2e.to(dev).train(); e2v.to(dev).train()
     params = list(v2e.parameters()) + list(e2v.parameters())
@@ -168,7 +173,10 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         x.grad = None
-        out = adist.sharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True)
+        if attn:
+            out = adist.sharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True)
+        else:
+            out = adist.sharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True)
         out.backward(G)
         adist.allreduce_grads(params)
         opt.step()
@@ -205,13 +213,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = nnz_total * d / (elapsed / args.steps)
         ks = timer.summary()
-        seg = ks.get("segreduce_fwd")
+        dom = max(ks, key=lambda k: ks[k]["total_ms"]) if ks else None          # dominant allset kernel
+        seg = ks.get(dom) if dom else None
         agg_ms = sum(v["total_ms"] for v in ks.values()) / args.steps
-        traffic = hbm_traffic_from_profile() if (world == 1 and args.n_per_gpu == 1_000_000 and d == 128) else None
+        traffic = hbm_traffic_from_profile() if (world == 1 and args.n_per_gpu == 1_000_000 and d == 128
+                                                 and dom == "segreduce_fwd") else None
         roofline = None
         if seg:
             achieved = seg["algo_bytes"] / (seg["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "segreduce_kernel<4,32,sum> (allset_segreduce_fwd)",
+            roofline = {"bound": "hbm", "kernel": f"allset_{dom}",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "algo_bytes_per_launch": seg["algo_bytes"], "avg_launch_ms": seg["avg_ms"],
                         "launches": seg["calls"]}
@@ -219,9 +229,10 @@ def main():
             "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": value, "unit": "edges*d/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic random hypergraph |V|=|E|={n_loc} per GPU, "
-                                   f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, "
-                                   f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), "
+            "config": {"workload": f"BASELINE configs[{3 if attn else 2}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph |V|=|E|={n_loc} per GPU, "
+                                   f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, " +
+                                   (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
+                                    f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), ") +
                                    f"fwd+bwd+Adam", "n_v": n_v, "n_e": n_loc * world, "nnz": int(nnz_total), "d": d,
                        "parallelism": f"hyperedge-shard x{world}" if world > 1 else "single GPU", "seed": args.seed},
             "roofline": roofline,
@@ -230,7 +241,7 @@ def main():
                             "aggregation-only V->E->V fwd+bwd", "kernels": {k: {"calls_per_step": v["calls"] / args.steps,
                                                                           "avg_ms": v["avg_ms"]} for k, v in ks.items()}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not attn:
             line["cpu_baseline"] = cpu_baseline(args, d, args.degree)
         else:
             line["cpu_baseline"] = None

@@ -137,3 +137,127 @@ def test_local_shard_renumbers_and_covers():
     assert g0.tolist() == [0, 2] and g1.tolist() == [1, 3]
     assert l0.tolist() == [[0, 1, 2, 3], [0, 0, 1, 1]] and l1.tolist() == [[2, 4], [0, 1]]
     assert l0.shape[1] + l1.shape[1] == ei.shape[1]
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded PMA (AllSetTransformer): cross-shard softmax merge
+# ---------------------------------------------------------------------------------------------
+
+class TorchPmaKernels:
+    """torch-CPU stand-ins for the four local PMA primitives (same contracts as the HIP kernels)."""
+
+    @staticmethod
+    def aggregate(V, alpha, inc, heads, slope):
+        from oracle import allset_oracle as oracle
+        ei, n_dst = inc
+        out, _ = oracle.pma_aggregate(V.view(V.shape[0], heads, -1), alpha, ei, slope)
+        out = out.reshape(out.shape[0], -1)
+        if out.shape[0] < n_dst:
+            out = torch.cat([out, out.new_zeros(n_dst - out.shape[0], out.shape[1])])
+        return out
+
+    @staticmethod
+    def fwd(V, alpha, inc, heads, slope):
+        ei, n_dst = inc
+        src, dst = ei[0], ei[1]
+        a = torch.nn.functional.leaky_relu(alpha[src], slope)
+        idx = dst.view(-1, 1).expand_as(a)
+        m = torch.full((n_dst, heads), float("-inf")).scatter_reduce(0, idx, a, "amax", include_self=True)
+        e = torch.exp(a - m[dst])
+        l = torch.zeros(n_dst, heads).index_add_(0, dst, e)
+        C = V.shape[1] // heads
+        num = torch.zeros(n_dst, heads, C).index_add_(0, dst, V.view(-1, heads, C)[src] * e.unsqueeze(-1))
+        out = torch.where(l.unsqueeze(-1) > 0, num / (l.unsqueeze(-1) + 1e-16), torch.zeros_like(num))
+        m = torch.where(l > 0, m, torch.zeros_like(m))
+        return out.reshape(n_dst, -1), m, l
+
+    @staticmethod
+    def bwd_stats(out, gout, m, l):
+        H = m.shape[1]
+        delta = (out * gout).view(out.shape[0], H, -1).sum(-1)
+        M = torch.where(l > 0, m + torch.log(l + 1e-16), torch.full_like(m, 3.0e38))
+        return torch.stack([M, delta], dim=-1)
+
+    @staticmethod
+    def bwd_src(inc, alpha, V, gout, stats, slope):
+        ei, n_dst = inc
+        src, dst = ei[0], ei[1]
+        H = alpha.shape[1]
+        C = V.shape[1] // H
+        a = torch.nn.functional.leaky_relu(alpha, slope)
+        p = torch.exp(a[src] - stats[dst, :, 0])                                   # [nnz, H]
+        g = gout.view(-1, H, C)[dst]
+        gV = torch.zeros(V.shape[0], H, C).index_add_(0, src, p.unsqueeze(-1) * g)
+        gp = (V.view(-1, H, C)[src] * g).sum(-1)
+        ga = torch.zeros_like(alpha).index_add_(0, src, p * (gp - stats[dst, :, 1]))
+        ga = ga * torch.where(alpha > 0, torch.ones_like(alpha), torch.full_like(alpha, slope))
+        return gV.reshape(V.shape[0], -1), ga
+
+
+def _pma_convs(d, H):
+    from allset_amd import HalfNLHconv
+    torch.manual_seed(5)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=True).eval()
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=True).eval()
+    return a, b
+
+
+def _pma_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
+        n_v, n_e, d, ei, _, x, G = _problem(world)
+        owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
+        loc, gids = adist.local_shard(ei, owner, rank)
+        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank)
+        hg.v2e = (loc, hg.n_e_local)
+        hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        a, b = _pma_convs(d, 4)
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+        Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - n_v, d)])
+        xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
+        out = adist.sharded_pma_layer(a, b, xo, hg, kernels=TorchPmaKernels)
+        (out * Gp[hg.v_lo:hg.v_hi]).sum().backward()
+        params = list(a.parameters()) + list(b.parameters())
+        adist.allreduce_grads(params)
+        q.put((rank, out.detach().numpy().copy(), xo.grad.numpy().copy(), [p.grad.numpy().copy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pma_layer_equals_unsharded():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pma_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    import torch.nn.functional as F
+    n_v, n_e, d, ei, _, x, G = _problem(world)
+    a, b = _pma_convs(d, 4)
+
+    def pma_module(p, xin, e_idx, n_dst):
+        H, C = p.heads, p.hidden
+        o = TorchPmaKernels.aggregate(p.lin_V(xin), p._logits(xin), (e_idx, n_dst), H, 0.2)
+        o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
+        o = p.ln0(o)
+        return p.ln1(o + F.relu(p.rFF(o)))
+
+    xr = x.clone().requires_grad_(True)
+    e = F.relu(pma_module(a.prop, xr, ei, n_e))
+    v = F.relu(pma_module(b.prop, e, torch.stack([ei[1], ei[0]]), n_v))
+    (v * G).sum().backward()
+    ref_pg = [p.grad for p in list(a.parameters()) + list(b.parameters())]
+    out = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    gx = torch.cat([torch.from_numpy(r[2]) for r in results])[:n_v]
+    torch.testing.assert_close(out, v.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=1e-5)
+    for got, exp in zip(results[0][3], ref_pg):
+        torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=2e-5)

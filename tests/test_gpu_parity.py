@@ -77,3 +77,40 @@ def test_training_mode_runs_and_is_finite(device):
             opt.step()
             losses.append(float(loss))
         assert all(map(lambda v: v == v and abs(v) < 1e6, losses))
+
+
+@pytest.mark.parametrize("attention", [False, True])
+def test_sharded_layer_world1_equals_module_composition(attention, device):
+    """allset_amd.dist layers with the HIP kernels (world size 1: collectives are identities) must equal the
+    plain HalfNLHconv composition SetGNN runs -- covers HipPmaKernels / the E->V merge Function on the GPU."""
+    import numpy as np
+    import torch.nn.functional as F
+    from allset_amd import HalfNLHconv, Incidence
+    from allset_amd import dist as adist
+    rng = np.random.default_rng(3)
+    n_v, n_e, d, H = 301, 157, 64, 4
+    pairs = sorted({(int(rng.integers(n_v)), int(rng.integers(n_e))) for _ in range(2500)})
+    ei = torch.tensor(pairs, dtype=torch.int64).t().contiguous().to(device)
+    torch.manual_seed(0)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=attention).to(device).eval()
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=attention).to(device).eval()
+    x = torch.randn(n_v, d, device=device)
+    G = torch.randn(n_v, d, device=device)
+    hg = adist.ShardedHypergraph(ei, n_v, n_e, 1, 0).build_incidences()
+    xs = x.clone().requires_grad_(True)
+    if attention:
+        out = adist.sharded_pma_layer(a, b, xs, hg)
+    else:
+        out = adist.sharded_deepsets_layer(a, b, xs, hg, aggr="add")
+    (out * G).sum().backward()
+    gs = [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+    for p in list(a.parameters()) + list(b.parameters()):
+        p.grad = None
+    inc = Incidence.from_edge_index(ei, n_src=n_v, n_dst=n_e)
+    xr = x.clone().requires_grad_(True)
+    ref = F.relu(b(F.relu(a(xr, inc, None, "add")), inc.reversed(n_dst=n_v), None, "add"))
+    (ref * G).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xs.grad, xr.grad, rtol=1e-4, atol=1e-4)
+    for g, p in zip(gs, list(a.parameters()) + list(b.parameters())):
+        torch.testing.assert_close(g, p.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(p.grad.abs().max())))
