@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p, POINTER
 
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
@@ -35,6 +35,14 @@ SIGNATURES = {
     "allset_pma_bwd_stats": [c_int, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_pma_bwd_src": [c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,
                            c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_ln_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64, c_int64, _P],
+    "allset_ln_bwd_partials": [c_int64, c_int64, POINTER(c_int64)],
+    "allset_ln_bwd": [_P, c_int64, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
+                      c_int64, c_int64, _P],
+    "allset_relu_dropout_fwd": [_P, c_float, c_uint64, _P, c_int64, _P],
+    "allset_relu_dropout_bwd": [_P, _P, c_float, _P, c_int64, _P],
+    "allset_wgrad_slices": [c_int64, c_int64, c_int64, POINTER(c_int64)],
+    "allset_wgrad": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
 }
 EXPORTED_SYMBOLS = sorted(list(SIGNATURES) + ["allset_last_error"])
 

@@ -1,0 +1,571 @@
+// Dense tail of the AllSet layer (reference MLP.forward, layers.py:571-579, and its autograd) for gfx950.
+//
+// The profile of round 1 (profiles/r01a_bench_kernel_stats.csv) showed the torch tail at [1M,128] fp32 spending
+// ~1 ms per LayerNorm pass (1 GB of traffic -> ~1 TB/s) and 1.8 ms per weight-gradient GEMM
+// (a [128 x 1M] x [1M x 128] product hipBLASLt tiles badly).  These kernels replace exactly those pieces:
+//
+//   ln_fwd_kernel      y = dropout( LayerNorm( relu?(x) ) )            1 read + 1 write, row statistics saved
+//   ln_bwd_kernel      gx, per-block partial (dgamma, dbeta)            2 reads + 1 write; mask regenerated
+//   relu_dropout_*     y = dropout(relu(x)) and its backward            elementwise, 16 B per lane
+//   wgrad_kernel       gW = ga^T @ u, gb = colsum(ga)                   split-K over rows, fp32 MFMA 32x32x2,
+//                                                                       per-slice partials (deterministic)
+//
+// The LayerNorm/elementwise kernels are HBM-bound streaming kernels; wgrad is the only MFMA user (exact fp32,
+// v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, MI355X_MICROARCH.md).  Dropout masks come from a counter-based
+// hash of (seed, element index), so the backward regenerates them instead of storing a mask tensor.
+#include "common.h"
+
+namespace allset {
+
+// ---- dropout mask: keep iff u(seed, idx) >= p, u uniform on [0,1) with 24 bits -----------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p, float inv_keep) {
+  uint32_t h = mix32(static_cast<uint32_t>(idx) ^ static_cast<uint32_t>(seed));
+  h = mix32(h + static_cast<uint32_t>(static_cast<uint64_t>(idx) >> 32) * 0x9E3779B9U + static_cast<uint32_t>(seed >> 32));
+  return (static_cast<float>(h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of W lanes (W power of two)
+#pragma unroll
+  for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr int kLnRowsPerGroup = 4;   // rows in flight per lane group (independent loads)
+
+// y = dropout(LN(relu?(x))).  LPR lanes x 16 B cover a row (d <= 4*LPR, d % 4 == 0); NS = 64/LPR rows per wave.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_fwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, int relu_in, float p, uint64_t seed, float* __restrict__ y, int64_t ldy,
+    float* __restrict__ stats, int64_t n, int d) {
+  constexpr int NS = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;            // row group inside the block
+  const int li = lane % LPR;
+  const int c0 = li * 4;
+  const bool active = c0 < d;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float4 g4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0);
+  if (active) {
+    g4 = *reinterpret_cast<const float4*>(gamma + c0);
+    b4 = *reinterpret_cast<const float4*>(beta + c0);
+  }
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + grp) * kLnRowsPerGroup;
+  float4 v[kLnRowsPerGroup];
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    const int64_t row = row0 + r;
+    v[r] = make_float4(0, 0, 0, 0);
+    if (active && row < n) v[r] = *reinterpret_cast<const float4*>(x + row * ldx + c0);
+  }
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    const int64_t row = row0 + r;
+    float4 t = v[r];
+    if (relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+    const float mean = group_sum<LPR>(t.x + t.y + t.z + t.w) * inv_d;
+    float4 c = make_float4(t.x - mean, t.y - mean, t.z - mean, t.w - mean);
+    if (!active) c = make_float4(0, 0, 0, 0);
+    const float var = group_sum<LPR>(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * inv_d;
+    const float rstd = rsqrtf(var + eps);
+    if (row < n) {
+      if (active) {
+        float4 o = make_float4(c.x * rstd * g4.x + b4.x, c.y * rstd * g4.y + b4.y, c.z * rstd * g4.z + b4.z,
+                               c.w * rstd * g4.w + b4.w);
+        if (p > 0.f) {
+          const int64_t e = row * d + c0;
+          o.x *= keep_scale(seed, e, p, inv_keep);     o.y *= keep_scale(seed, e + 1, p, inv_keep);
+          o.z *= keep_scale(seed, e + 2, p, inv_keep); o.w *= keep_scale(seed, e + 3, p, inv_keep);
+        }
+        *reinterpret_cast<float4*>(y + row * ldy + c0) = o;
+      }
+      if (li == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    }
+  }
+}
+
+// generic width: one wave per row, three passes over the row (L1/L2 resident), scalar accesses
+__global__ __launch_bounds__(kBlock) void ln_fwd_generic_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, int relu_in, float p, uint64_t seed, float* __restrict__ y, int64_t ldy,
+    float* __restrict__ stats, int64_t n, int d) {
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = lane_id();
+  const float* xr = x + row * ldx;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float s = 0.f;
+  for (int c = lane; c < d; c += kWave) s += relu_in ? fmaxf(xr[c], 0.f) : xr[c];
+  const float mean = group_sum<kWave>(s) / static_cast<float>(d);
+  float q = 0.f;
+  for (int c = lane; c < d; c += kWave) {
+    const float t = (relu_in ? fmaxf(xr[c], 0.f) : xr[c]) - mean;
+    q += t * t;
+  }
+  const float rstd = rsqrtf(group_sum<kWave>(q) / static_cast<float>(d) + eps);
+  for (int c = lane; c < d; c += kWave) {
+    float o = ((relu_in ? fmaxf(xr[c], 0.f) : xr[c]) - mean) * rstd * gamma[c] + beta[c];
+    if (p > 0.f) o *= keep_scale(seed, row * d + c, p, inv_keep);
+    y[row * ldy + c] = o;
+  }
+  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+
+// Backward of y = dropout(LN(relu?(x))).  Persistent grid-stride over rows; each lane keeps dgamma/dbeta
+// partials for its 4 columns, reduced over the block's row groups through LDS, one partial row per block:
+// part[blockIdx][0][c] = dgamma, part[blockIdx][1][c] = dbeta.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_bwd_kernel(
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ stats, const float* __restrict__ gamma, int relu_in, float p, uint64_t seed,
+    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d) {
+  constexpr int NS = kWave / LPR;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  __shared__ float red[kGroups][2][LPR * 4];
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 4;
+  const bool active = c0 < d;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float4 g4 = make_float4(0, 0, 0, 0);
+  if (active) g4 = *reinterpret_cast<const float4*>(gamma + c0);
+  float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0);
+
+  const int64_t rows_per_iter = static_cast<int64_t>(gridDim.x) * kGroups;
+  // lanes of one LPR-lane group share `row`, and the shuffles below never leave the group, so groups of a
+  // wave may run different trip counts
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + grp; row < n; row += rows_per_iter) {
+    const bool live = true;
+    float4 xv = make_float4(0, 0, 0, 0), gv = make_float4(0, 0, 0, 0);
+    float mean = 0.f, rstd = 0.f;
+    if (live && active) {
+      xv = *reinterpret_cast<const float4*>(x + row * ldx + c0);
+      gv = *reinterpret_cast<const float4*>(gy + row * ldg + c0);
+    }
+    if (live) { mean = stats[row * 2]; rstd = stats[row * 2 + 1]; }
+    float4 t = xv;
+    if (relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+    float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
+    if (!(live && active)) xh = make_float4(0, 0, 0, 0);
+    if (p > 0.f && live && active) {
+      const int64_t e = row * d + c0;
+      gv.x *= keep_scale(seed, e, p, inv_keep);     gv.y *= keep_scale(seed, e + 1, p, inv_keep);
+      gv.z *= keep_scale(seed, e + 2, p, inv_keep); gv.w *= keep_scale(seed, e + 3, p, inv_keep);
+    }
+    dg.x += gv.x * xh.x; dg.y += gv.y * xh.y; dg.z += gv.z * xh.z; dg.w += gv.w * xh.w;
+    db.x += gv.x; db.y += gv.y; db.z += gv.z; db.w += gv.w;
+    const float4 gh = make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w);
+    const float s1 = group_sum<LPR>(gh.x + gh.y + gh.z + gh.w) * inv_d;
+    const float s2 = group_sum<LPR>(gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w) * inv_d;
+    if (live && active) {
+      float4 o = make_float4(rstd * (gh.x - s1 - xh.x * s2), rstd * (gh.y - s1 - xh.y * s2),
+                             rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
+      if (relu_in) {
+        o.x = xv.x > 0.f ? o.x : 0.f; o.y = xv.y > 0.f ? o.y : 0.f;
+        o.z = xv.z > 0.f ? o.z : 0.f; o.w = xv.w > 0.f ? o.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(gx + row * ldgx + c0) = o;
+    }
+  }
+  *reinterpret_cast<float4*>(&red[grp][0][c0]) = dg;
+  *reinterpret_cast<float4*>(&red[grp][1][c0]) = db;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * LPR * 4; i += kBlock) {
+    const int which = i / (LPR * 4), c = i % (LPR * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) s += red[g][which][c];
+    if (c < d) part[(static_cast<int64_t>(blockIdx.x) * 2 + which) * d + c] = s;
+  }
+}
+
+// generic width backward: one wave per row per iteration, column partials via per-wave registers are not
+// possible for arbitrary d, so dgamma/dbeta partials are accumulated with float atomics into part[0] (d wide).
+__global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ stats, const float* __restrict__ gamma, int relu_in, float p, uint64_t seed,
+    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d) {
+  const int lane = lane_id();
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  // column c is always handled by lane c % 64 of some wave; accumulate per (wave, column-slot) over rows
+  for (int cb = 0; cb < d; cb += kWave * 8) {       // up to 8 column slots per lane per sweep
+    float dg[8], db[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dg[k] = 0.f; db[k] = 0.f; }
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+      const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+      const float* xr = x + row * ldx;
+      const float* gr = gy + row * ldg;
+      if (cb == 0) {   // first sweep also produces gx (needs the full-row sums)
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < d; c += kWave) {
+          const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
+          const float xh = (t - mean) * rstd;
+          const float gh = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, p, inv_keep) : 1.f) * gamma[c];
+          s1 += gh; s2 += gh * xh;
+        }
+        s1 = group_sum<kWave>(s1) / static_cast<float>(d);
+        s2 = group_sum<kWave>(s2) / static_cast<float>(d);
+        for (int c = lane; c < d; c += kWave) {
+          const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
+          const float xh = (t - mean) * rstd;
+          const float gh = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, p, inv_keep) : 1.f) * gamma[c];
+          float o = rstd * (gh - s1 - xh * s2);
+          if (relu_in && !(xr[c] > 0.f)) o = 0.f;
+          gx[row * ldgx + c] = o;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = cb + k * kWave + lane;
+        if (c < d) {
+          const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
+          const float g = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, p, inv_keep) : 1.f);
+          dg[k] += g * (t - mean) * rstd;
+          db[k] += g;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = cb + k * kWave + lane;
+      if (c < d) { atomicAdd(&part[c], dg[k]); atomicAdd(&part[d + c], db[k]); }
+    }
+  }
+}
+
+// y = dropout(relu(x)); backward gx = gy * inv_keep where y > 0 (y > 0 <=> kept and x > 0), else 0
+__global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(const float* __restrict__ x, float p, uint64_t seed,
+                                                                  float* __restrict__ y, int64_t n4) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (p > 0.f) {
+      const int64_t e = i * 4;
+      v.x *= keep_scale(seed, e, p, inv_keep);     v.y *= keep_scale(seed, e + 1, p, inv_keep);
+      v.z *= keep_scale(seed, e + 2, p, inv_keep); v.w *= keep_scale(seed, e + 3, p, inv_keep);
+    }
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                  float p, float* __restrict__ gx, int64_t n4) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const float4 g = reinterpret_cast<const float4*>(gy)[i];
+    const float4 o = reinterpret_cast<const float4*>(y)[i];
+    float4 r;
+    r.x = o.x > 0.f ? g.x * inv_keep : 0.f; r.y = o.y > 0.f ? g.y * inv_keep : 0.f;
+    r.z = o.z > 0.f ? g.z * inv_keep : 0.f; r.w = o.w > 0.f ? g.w * inv_keep : 0.f;
+    reinterpret_cast<float4*>(gx)[i] = r;
+  }
+}
+
+// scalar tail / unaligned variant (n elements)
+__global__ void relu_dropout_fwd_scalar_kernel(const float* __restrict__ x, float p, uint64_t seed, float* __restrict__ y,
+                                               int64_t n, int64_t offset) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const int64_t i = offset + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float v = fmaxf(x[i], 0.f);
+    if (p > 0.f) v *= keep_scale(seed, i, p, inv_keep);
+    y[i] = v;
+  }
+}
+
+__global__ void relu_dropout_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict__ y, float p,
+                                               float* __restrict__ gx, int64_t n, int64_t offset) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const int64_t i = offset + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) gx[i] = y[i] > 0.f ? gy[i] * inv_keep : 0.f;
+}
+
+// ---- weight gradient: gW[o][i] = sum_r ga[r][o] * u[r][i],  gb[o] = sum_r ga[r][o] -----------------------
+// Grid: x = 128x128 output macro-tile (o-block * tiles_i + i-block), y = split-K slice of the rows.
+// 4 waves; wave w owns o-rows [32w, 32w+32) x 128 i-columns = four 32x32 fp32 MFMA accumulators.
+// K (= rows) is consumed 32 rows per stage through LDS (row-major, unpadded: the A operand
+// ga[r0 + (l>>5)][o0 + (l&31)] and the B operand u[r0 + (l>>5)][i0 + (l&31)] are both unit-stride across lanes).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kWgTile = 128;
+constexpr int kWgRows = 32;
+
+__global__ __launch_bounds__(kBlock) void wgrad_kernel(
+    const float* __restrict__ ga, int64_t lda, const float* __restrict__ u, int64_t ldu,
+    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i,
+    int64_t rows_per_slice) {
+  __shared__ float sA[2][kWgRows][kWgTile];
+  __shared__ float sB[2][kWgRows][kWgTile];
+  const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
+  const int o_base = tile_o * kWgTile, i_base = tile_i * kWgTile;
+  const int slice = blockIdx.y;
+  const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
+  const int64_t r_end = min(n, r_begin + rows_per_slice);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // staging map: thread -> (row = tid / 32 + 8*k, 4 columns at (tid % 32)*4), k = 0..3
+  const int s_col = (tid & 31) * 4, s_row = tid >> 5;
+  const bool a_ok = (o_base + s_col) < O, b_ok = (i_base + s_col) < I;      // O, I are multiples of 4
+  float4 bsum = make_float4(0, 0, 0, 0);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+
+  float4 ra[4], rb[4];
+  auto load_stage = [&](int64_t r0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t r = r0 + s_row + 8 * k;
+      ra[k] = make_float4(0, 0, 0, 0);
+      rb[k] = make_float4(0, 0, 0, 0);
+      if (r < r_end) {
+        if (a_ok) ra[k] = *reinterpret_cast<const float4*>(ga + r * lda + o_base + s_col);
+        if (b_ok) rb[k] = *reinterpret_cast<const float4*>(u + r * ldu + i_base + s_col);
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      *reinterpret_cast<float4*>(&sA[buf][s_row + 8 * k][s_col]) = ra[k];
+      *reinterpret_cast<float4*>(&sB[buf][s_row + 8 * k][s_col]) = rb[k];
+      bsum.x += ra[k].x; bsum.y += ra[k].y; bsum.z += ra[k].z; bsum.w += ra[k].w;
+    }
+  };
+
+  int buf = 0;
+  if (r_begin < r_end) {
+    load_stage(r_begin);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+    const bool more = (r0 + kWgRows) < r_end;
+    if (more) load_stage(r0 + kWgRows);            // global loads in flight under the MFMAs below
+    const int ao = wave * 32 + (lane & 31);
+    const int kk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < kWgRows; ks += 2) {
+      const float a = sA[buf][ks + kk][ao];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float b = sB[buf][ks + kk][t * 32 + (lane & 31)];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: partial tile -> part_w[slice][O][I]
+  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = i_base + t * 32 + (lane & 31);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int o = o_base + wave * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+      if (o < O && i < I) pw[static_cast<int64_t>(o) * I + i] = acc[t][k];
+    }
+  }
+  // bias partial: reduce the 8 staging-row groups of each column quad through LDS (only i-tile 0 writes)
+  if (tile_i == 0 && part_b != nullptr) {
+    __syncthreads();
+    float* red = &sA[0][0][0];                     // [8][128]
+    *reinterpret_cast<float4*>(&red[s_row * kWgTile + s_col]) = bsum;
+    __syncthreads();
+    if (tid < kWgTile) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += red[g * kWgTile + tid];
+      if (o_base + tid < O) part_b[static_cast<int64_t>(slice) * O + o_base + tid] = s;
+    }
+  }
+}
+
+static inline int ln_lpr(int64_t d) {
+  int lpr = 8;
+  while (lpr * 4 < d && lpr < 64) lpr <<= 1;
+  return lpr;
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                             int relu_in, float p, uint64_t seed, float* y, int64_t ldy, float* stats,
+                             int64_t n, int64_t d, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "ln_fwd: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_fwd: dropout p must be in [0,1)");
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && gamma && beta && y && stats, "ln_fwd: null pointer");
+  ALLSET_REQUIRE(ldx >= d && ldy >= d, "ln_fwd: leading dimension smaller than d");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool fast = d <= 256 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) &&
+                    aligned16(gamma) && aligned16(beta);
+  const int di = static_cast<int>(d);
+  if (fast) {
+    const int lpr = ln_lpr(d);
+    const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
+    const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
+    switch (lpr) {
+      case 8:  ln_fwd_kernel<8><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
+      case 16: ln_fwd_kernel<16><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
+      case 32: ln_fwd_kernel<32><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
+      default: ln_fwd_kernel<64><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
+    }
+  } else {
+    const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    ln_fwd_generic_kernel<<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di);
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_bwd_partials(int64_t n, int64_t d, int64_t* n_partials) {
+  clear_error();
+  ALLSET_REQUIRE(n_partials != nullptr && n >= 0 && d >= 1, "ln_bwd_partials: bad argument");
+  const bool fast = d <= 256 && d % 4 == 0;
+  if (!fast) { *n_partials = 1; return ALLSET_OK; }
+  const int lpr = ln_lpr(d);
+  const int64_t groups = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const int64_t want = (n + groups - 1) / groups;
+  *n_partials = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* stats,
+                             const float* gamma, int relu_in, float p, uint64_t seed, float* gx, int64_t ldgx,
+                             float* partials, int64_t n_partials, int64_t n, int64_t d, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "ln_bwd: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_bwd: dropout p must be in [0,1)");
+  ALLSET_REQUIRE(partials != nullptr && n_partials >= 1, "ln_bwd: partials buffer required");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool shape_fast = d <= 256 && d % 4 == 0;
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * d * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && x && stats && gamma && gx, "ln_bwd: null pointer");
+  ALLSET_REQUIRE(ldg >= d && ldx >= d && ldgx >= d, "ln_bwd: leading dimension smaller than d");
+  const bool fast = shape_fast && ldg % 4 == 0 && ldx % 4 == 0 && ldgx % 4 == 0 && aligned16(gy) && aligned16(x) &&
+                    aligned16(gx) && aligned16(gamma);
+  const int di = static_cast<int>(d);
+  if (fast) {
+    const unsigned grid = static_cast<unsigned>(n_partials);
+    switch (ln_lpr(d)) {
+      case 8:  ln_bwd_kernel<8><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
+      case 16: ln_bwd_kernel<16><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
+      case 32: ln_bwd_kernel<32><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
+      default: ln_bwd_kernel<64><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
+    }
+  } else {
+    // generic path accumulates into partial row 0 with atomics; the other partial rows (if any) are zeroed
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * d * sizeof(float), st));
+    const int64_t want = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned grid = static_cast<unsigned>(want > 1024 ? 1024 : want);
+    ln_bwd_generic_kernel<<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di);
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, float* y, int64_t numel, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(numel >= 0, "relu_dropout_fwd: negative size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "relu_dropout_fwd: dropout p must be in [0,1)");
+  if (numel == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && y, "relu_dropout_fwd: null pointer");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t done = 0;
+  if (aligned16(x) && aligned16(y) && numel >= 4) {
+    const int64_t n4 = numel / 4;
+    const int64_t want = (n4 + kBlock - 1) / kBlock;
+    relu_dropout_fwd_kernel<<<static_cast<unsigned>(want > 8192 ? 8192 : want), kBlock, 0, st>>>(x, p, seed, y, n4);
+    done = n4 * 4;
+  }
+  if (done < numel) {
+    const int64_t rest = numel - done;
+    relu_dropout_fwd_scalar_kernel<<<static_cast<unsigned>((rest + kBlock - 1) / kBlock), kBlock, 0, st>>>(x, p, seed, y, numel, done);
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_relu_dropout_bwd(const float* gy, const float* y, float p, float* gx, int64_t numel, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(numel >= 0, "relu_dropout_bwd: negative size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "relu_dropout_bwd: dropout p must be in [0,1)");
+  if (numel == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(gy && y && gx, "relu_dropout_bwd: null pointer");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t done = 0;
+  if (aligned16(gy) && aligned16(y) && aligned16(gx) && numel >= 4) {
+    const int64_t n4 = numel / 4;
+    const int64_t want = (n4 + kBlock - 1) / kBlock;
+    relu_dropout_bwd_kernel<<<static_cast<unsigned>(want > 8192 ? 8192 : want), kBlock, 0, st>>>(gy, y, p, gx, n4);
+    done = n4 * 4;
+  }
+  if (done < numel) {
+    const int64_t rest = numel - done;
+    relu_dropout_bwd_scalar_kernel<<<static_cast<unsigned>((rest + kBlock - 1) / kBlock), kBlock, 0, st>>>(gy, y, p, gx, numel, done);
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices) {
+  clear_error();
+  ALLSET_REQUIRE(n_slices != nullptr && n >= 0 && O >= 1 && I >= 1, "wgrad_slices: bad argument");
+  const int64_t tiles = ((O + kWgTile - 1) / kWgTile) * ((I + kWgTile - 1) / kWgTile);
+  // aim at ~1024 workgroups in total, at least 256 rows (8 stages) per slice
+  int64_t s = 1024 / tiles;
+  const int64_t max_by_rows = (n + 255) / 256;
+  if (s > max_by_rows) s = max_by_rows;
+  if (s < 1) s = 1;
+  *n_slices = s;
+  return ALLSET_OK;
+}
+
+extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
+                            int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad: bad size");
+  ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad: bad slice count");
+  ALLSET_REQUIRE(part_w != nullptr, "wgrad: null partial buffer");
+  ALLSET_REQUIRE(n == 0 || (ga && u), "wgrad: null input");
+  if (O % 4 != 0 || I % 4 != 0 || lda % 4 != 0 || ldu % 4 != 0 || !aligned16(ga) || !aligned16(u)) {
+    set_error("wgrad: needs out/in features and leading dimensions that are multiples of 4 and 16-byte aligned inputs");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(lda >= O && ldu >= I, "wgrad: leading dimension smaller than the feature width");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int tiles_o = static_cast<int>((O + kWgTile - 1) / kWgTile), tiles_i = static_cast<int>((I + kWgTile - 1) / kWgTile);
+  int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
+  rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
+  if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
+  const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
+  wgrad_kernel<<<grid, kBlock, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I), tiles_i, rows_per_slice);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

@@ -1,0 +1,181 @@
+"""Dense tail on the HIP kernels of ``csrc/dense.hip``: LayerNorm (fused with the ReLU before it and the dropout
+after it), ReLU+dropout, and ``Linear`` whose weight gradient is the split-K fp32-MFMA kernel.  The two
+well-shaped GEMMs of a Linear (``x W^T`` and ``gy W``) stay on hipBLASLt through torch.
+
+These are ``torch.autograd.Function``s over ROCm fp32 tensors; ``layers.MLP`` routes here for device tensors.
+Dropout masks are a counter-based hash of (seed, element index): the seed is drawn from torch's CPU generator
+(so ``torch.manual_seed`` governs it, without a device sync) and the backward regenerates the mask.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_int64
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import check, ptr, require_device, stream_of
+from .ops import _ld, _rowmajor, _timed
+
+Tensor = torch.Tensor
+
+
+def _draw_seed() -> int:
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+def _check_f32(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.AllSetHipError(f"dense tail kernels are fp32 (got {t.dtype})")
+
+
+# ---- raw wrappers --------------------------------------------------------------------------------
+
+def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p: float, seed: int
+           ) -> Tuple[Tensor, Tensor]:
+    dev = require_device(x, gamma, beta)
+    _check_f32(x, gamma, beta)
+    x = _rowmajor(x)
+    n, d = x.shape
+    y = torch.empty((n, d), dtype=x.dtype, device=dev)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("ln_fwd", dev, 2 * n * d * 4):
+        check(_lib.load().allset_ln_fwd(ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
+                                        int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, stream_of(dev)),
+              "allset_ln_fwd")
+    return y, stats
+
+
+def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int
+           ) -> Tuple[Tensor, Tensor, Tensor]:
+    dev = require_device(gy, x, stats, gamma)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    n, d = x.shape
+    lib = _lib.load()
+    npart = c_int64(0)
+    check(lib.allset_ln_bwd_partials(n, d, byref(npart)), "allset_ln_bwd_partials")
+    partials = torch.empty((npart.value, 2, d), dtype=torch.float32, device=dev)
+    gx = torch.empty((n, d), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev), _timed("ln_bwd", dev, 3 * n * d * 4):
+        check(lib.allset_ln_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
+                                seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, stream_of(dev)),
+              "allset_ln_bwd")
+    red = partials.sum(dim=0)
+    return gx, red[0], red[1]
+
+
+def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """gW [O, I] = ga^T @ u,  gb [O] = ga.sum(0)  (ga: [n, O], u: [n, I])."""
+    dev = require_device(ga, u)
+    ga, u = _rowmajor(ga), _rowmajor(u)
+    n, O = ga.shape
+    I = u.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
+    part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
+    part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
+    with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * 4):
+        check(lib.allset_wgrad(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,
+                               stream_of(dev)), "allset_wgrad")
+    gw = part_w.sum(dim=0) if ns.value > 1 else part_w[0]
+    gb = (part_b.sum(dim=0) if ns.value > 1 else part_b[0]) if want_bias else None
+    return gw, gb
+
+
+def wgrad_supported(ga: Tensor, u: Tensor) -> bool:
+    return (ga.is_cuda and ga.dtype == torch.float32 and u.dtype == torch.float32 and ga.shape[1] % 4 == 0
+            and u.shape[1] % 4 == 0)
+
+
+# ---- autograd functions ------------------------------------------------------------------------------
+
+class _LayerNormFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu_in, p):
+        seed = _draw_seed() if p > 0.0 else 0
+        y, stats = ln_fwd(x, gamma, beta, eps, relu_in, p, seed)
+        ctx.save_for_backward(x, stats, gamma)
+        ctx.cfg = (bool(relu_in), float(p), seed)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, stats, gamma = ctx.saved_tensors
+        relu_in, p, seed = ctx.cfg
+        gx, dg, db = ln_bwd(gy.contiguous(), x, stats, gamma, relu_in, p, seed)
+        return gx, dg, db, None, None, None
+
+
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        dev = require_device(x)
+        _check_f32(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        seed = _draw_seed() if p > 0.0 else 0
+        n = x.numel()
+        with torch.cuda.device(dev), _timed("relu_dropout_fwd", dev, 2 * n * 4):
+            check(_lib.load().allset_relu_dropout_fwd(ptr(x), p, seed, ptr(y), n, stream_of(dev)), "allset_relu_dropout_fwd")
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        dev = y.device
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        n = y.numel()
+        with torch.cuda.device(dev), _timed("relu_dropout_bwd", dev, 3 * n * 4):
+            check(_lib.load().allset_relu_dropout_bwd(ptr(gy), ptr(y), ctx.p, ptr(gx), n, stream_of(dev)),
+                  "allset_relu_dropout_bwd")
+        return gx, None
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b.  Forward and grad-input are library GEMMs (hipBLASLt); grad-weight / grad-bias are the
+    split-K MFMA kernel (hipBLASLt's choice for the [O x n] x [n x I] shape is ~5x slower at n = 1M)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy @ weight
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            if wgrad_supported(gy, x):
+                gw, gb = wgrad(gy, x, want_bias=need_b)
+            else:                                           # odd widths (e.g. 1433 raw features): library GEMM
+                gw = gy.t() @ x
+                gb = gy.sum(dim=0) if need_b else None
+        return gx, gw, gb
+
+
+def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, relu_in: bool = False, p: float = 0.0) -> Tensor:
+    """``dropout_p(LayerNorm(relu(x) if relu_in else x))`` in one pass."""
+    return _LayerNormFused.apply(x, gamma, beta, float(eps), bool(relu_in), float(p))
+
+
+def relu_dropout(x: Tensor, p: float = 0.0) -> Tensor:
+    """``dropout_p(relu(x))`` in one pass."""
+    return _ReluDropout.apply(x, float(p))
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    return _Linear.apply(x, weight, bias)

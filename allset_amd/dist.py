@@ -232,21 +232,18 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     if aggr not in ("add", "sum", "mean"):
         raise NotImplementedError("sharded E->V supports add/sum/mean (max needs an arg-owner exchange)")
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
-    h = F.relu(v2e_conv.f_enc(x_owned))
-    h = F.dropout(h, p=v2e_conv.dropout, training=training)
+    from .layers import relu_dropout
+    h = relu_dropout(v2e_conv.f_enc(x_owned), v2e_conv.dropout, training)
     h_full = all_gather_rows(h, group)
     e = aggregate(h_full, hg.v2e, hg.norm, aggr)
-    e = F.relu(v2e_conv.f_dec(e))                               # conv's relu; SetGNN's outer relu is idempotent
-    e = F.dropout(e, p=dropout, training=training)
+    e = relu_dropout(v2e_conv.f_dec(e), dropout, training)      # conv's relu (SetGNN's outer relu is idempotent) + dropout
     # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
-    g = F.relu(e2v_conv.f_enc(e))
-    g = F.dropout(g, p=e2v_conv.dropout, training=training)
+    g = relu_dropout(e2v_conv.f_enc(e), e2v_conv.dropout, training)
     partial = aggregate(g, hg.e2v, hg.norm, "add")
     v = reduce_scatter_rows(partial, group)
     if aggr == "mean":
         v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
-    v = F.relu(e2v_conv.f_dec(v))
-    return F.dropout(v, p=dropout, training=training)
+    return relu_dropout(e2v_conv.f_dec(v), dropout, training)
 
 
 class _ShardedPmaE2V(torch.autograd.Function):
@@ -305,27 +302,22 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     inlined) on a hyperedge shard.  ``v2e_conv`` / ``e2v_conv``: :class:`allset_amd.layers.HalfNLHconv` with
     ``attention=True``.  V->E targets (hyperedges) are complete on their owner, so that direction is the local
     kernel behind an all-gather of [V | alpha]; E->V needs the cross-shard softmax merge above."""
+    from .layers import _linear, relu_dropout
     K = kernels
     # ---- V -> E
     p = v2e_conv.prop
     H, C = p.heads, p.hidden
-    packed = torch.cat([p.lin_V(x_owned), p._logits(x_owned)], dim=1)            # dense on owned vertices
+    packed = torch.cat([_linear(p.lin_V, x_owned), p._logits(x_owned)], dim=1)    # dense on owned vertices
     full = all_gather_rows(packed, group)
     V, alpha = full[:, :H * C], full[:, H * C:]
     o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
-    o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
-    o = p.ln0(o)
-    e = p.ln1(o + F.relu(p.rFF(o)))
-    e = F.dropout(F.relu(e), p=dropout, training=training)
+    e = relu_dropout(p.tail(o), dropout, training)
     # ---- E -> V
     p = e2v_conv.prop
     H, C = p.heads, p.hidden
-    V, alpha = p.lin_V(e), p._logits(e)                                             # dense on owned hyperedges
+    V, alpha = _linear(p.lin_V, e), p._logits(e)                                    # dense on owned hyperedges
     o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
-    o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
-    o = p.ln0(o)
-    v = p.ln1(o + F.relu(p.rFF(o)))
-    return F.dropout(F.relu(v), p=dropout, training=training)
+    return relu_dropout(p.tail(o), dropout, training)
 
 
 def allreduce_grads(params, group=None) -> None:

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dense
 from . import functional as AF
 from .incidence import Incidence, cached_incidence
 
@@ -44,6 +45,33 @@ def _as_incidence(edge_index: EdgeIndex, n_src: int) -> Incidence:
     if isinstance(edge_index, Incidence):
         return edge_index
     return cached_incidence(edge_index, n_src=n_src)      # n_dst = index.max()+1, the reference's rule (Q1)
+
+
+def _on_hip(x: Tensor) -> bool:
+    """Device fp32 tensors take the HIP dense-tail kernels (allset_amd/dense.py); anything else (CPU tensors in
+    unit tests / gloo tests, other dtypes) runs the same math as plain torch modules."""
+    return x.is_cuda and x.dtype == torch.float32
+
+
+def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    """``dropout(relu(x))`` -- one fused pass on the device."""
+    p = float(p) if training else 0.0
+    if _on_hip(x):
+        return dense.relu_dropout(x, p)
+    return F.dropout(F.relu(x), p=p, training=training)
+
+
+def _layer_norm(norm: nn.LayerNorm, x: Tensor, relu_in: bool = False, p: float = 0.0) -> Tensor:
+    if _on_hip(x) and norm.elementwise_affine and norm.bias is not None:
+        return dense.layer_norm(x, norm.weight, norm.bias, norm.eps, relu_in, p)
+    y = norm(F.relu(x) if relu_in else x)
+    return F.dropout(y, p=p, training=p > 0.0)
+
+
+def _linear(lin: nn.Linear, x: Tensor) -> Tensor:
+    if _on_hip(x):
+        return dense.linear(x, lin.weight, lin.bias)
+    return lin(x)
 
 
 def _make_norm(kind: str, width: int) -> nn.Module:
@@ -81,12 +109,19 @@ class MLP(nn.Module):
                 norm.reset_parameters()
 
     def forward(self, x):
-        x = self.normalizations[0](x)
+        p = float(self.dropout) if self.training else 0.0
+        n0 = self.normalizations[0]
+        x = _layer_norm(n0, x) if isinstance(n0, nn.LayerNorm) else n0(x)
         for i, lin in enumerate(self.lins[:-1]):
-            x = F.relu(lin(x))
-            x = self.normalizations[i + 1](x)
-            x = F.dropout(x, p=self.dropout, training=self.training)
-        return self.lins[-1](x)
+            a = _linear(lin, x)
+            nxt = self.normalizations[i + 1]
+            if isinstance(nxt, nn.LayerNorm):          # relu -> LayerNorm -> dropout: one kernel
+                x = _layer_norm(nxt, a, relu_in=True, p=p)
+            elif isinstance(nxt, nn.Identity):         # relu -> dropout: one kernel
+                x = relu_dropout(a, p, self.training)
+            else:                                      # BatchNorm1d: torch
+                x = F.dropout(nxt(F.relu(a)), p=p, training=self.training)
+        return _linear(self.lins[-1], x)
 
 
 class PMA(nn.Module):
@@ -142,16 +177,21 @@ class PMA(nn.Module):
             return F.linear(x, w, b)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
+    def tail(self, pooled: Tensor) -> Tensor:
+        """``+att_r -> ln0 -> ln1(z + relu(rFF(z)))`` (reference layers.py:153-157) on pooled [n_t, H*C]."""
+        H, C = self.heads, self.hidden
+        out = (pooled.view(-1, H, C) + self.att_r).view(-1, H * C)     # seed + multihead (layers.py:153)
+        out = _layer_norm(self.ln0, out)
+        return _layer_norm(self.ln1, out + F.relu(self.rFF(out)))
+
     def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
-        H, C = self.heads, self.hidden
+        H = self.heads
         inc = _as_incidence(edge_index, x.shape[0])
-        x_V = self.lin_V(x)                                   # [n_s, H*C]
+        x_V = _linear(self.lin_V, x)                          # [n_s, H*C]
         alpha_r = self._logits(x)                             # [n_s, H]
         out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
-        out = out.view(-1, H, C) + self.att_r                 # seed + multihead (layers.py:153)
-        out = self.ln0(out.view(-1, H * C))
-        out = self.ln1(out + F.relu(self.rFF(out)))
+        out = self.tail(out)
         if isinstance(return_attention_weights, bool):
             alpha = AF.pma_attention_weights(alpha_r, m, l, inc, self.negative_slope)
             return out, (edge_index, alpha)
@@ -191,13 +231,17 @@ class HalfNLHconv(nn.Module):
                 if not isinstance(f, nn.Identity):
                     f.reset_parameters()
 
-    def forward(self, x, edge_index: EdgeIndex, norm, aggr='add'):
+    def forward(self, x, edge_index: EdgeIndex, norm, aggr='add', _post_dropout: Optional[float] = None):
+        """``_post_dropout`` (internal, used by ``SetGNN``): also apply the ``relu -> dropout(p)`` that
+        ``SetGNN.forward`` wraps around every conv (models.py:475-481) inside the conv's last fused pass."""
+        post = _post_dropout is not None
         if self.attention:
-            return self.prop(x, edge_index)
+            x = self.prop(x, edge_index)
+            return relu_dropout(x, _post_dropout, self.training) if post else x
         if aggr is None:
             raise ValueError("aggr was not passed!")
-        x = F.relu(self.f_enc(x))
-        x = F.dropout(x, p=self.dropout, training=self.training)
+        x = relu_dropout(self.f_enc(x), self.dropout, self.training)
         inc = _as_incidence(edge_index, x.shape[0])
         x = AF.deepsets_aggregate(x, inc, norm, aggr)
-        return F.relu(self.f_dec(x))
+        # relu(f_dec(.)); SetGNN's outer relu is idempotent on it, so its dropout can ride in the same pass
+        return relu_dropout(self.f_dec(x), _post_dropout if post else 0.0, self.training)

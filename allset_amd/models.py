@@ -115,8 +115,7 @@ class SetGNN(nn.Module):
         if self.GPR:
             xs = [F.relu(self.MLP(x))]
             for i in range(len(self.V2EConvs)):
-                x = F.relu(self.V2EConvs[i](x, v2e, norm, self.aggr))
-                x = F.dropout(x, p=self.dropout, training=self.training)
+                x = self.V2EConvs[i](x, v2e, norm, self.aggr, _post_dropout=self.dropout)   # relu + dropout fused
                 x = F.relu(self.E2VConvs[i](x, e2v, norm, self.aggr))
                 xs.append(x)
                 x = F.dropout(x, p=self.dropout, training=self.training)
@@ -125,8 +124,7 @@ class SetGNN(nn.Module):
             return self.classifier(x)
         x = F.dropout(x, p=0.2, training=self.training)      # hard-coded input dropout (models.py:473)
         for i in range(len(self.V2EConvs)):
-            x = F.relu(self.V2EConvs[i](x, v2e, norm, self.aggr))
-            x = F.dropout(x, p=self.dropout, training=self.training)
-            x = F.relu(self.E2VConvs[i](x, e2v, norm, self.aggr))
-            x = F.dropout(x, p=self.dropout, training=self.training)
+            # x = dropout(relu(conv(x))) (models.py:475-481); relu + dropout ride in the conv's last fused pass
+            x = self.V2EConvs[i](x, v2e, norm, self.aggr, _post_dropout=self.dropout)
+            x = self.E2VConvs[i](x, e2v, norm, self.aggr, _post_dropout=self.dropout)
         return self.classifier(x)

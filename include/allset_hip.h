@@ -149,6 +149,39 @@ int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT,
                        void* gV, int64_t ldgv, float* galpha,
                        int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense tail (reference MLP.forward, layers.py:571-579: norm -> [Linear -> ReLU -> norm -> dropout]* -> Linear,
+ * and the relu/dropout that HalfNLHconv.forward / SetGNN.forward wrap around it, layers.py:631-634,
+ * models.py:473-481).  fp32, row-major.  The two well-shaped GEMMs (y = x W^T, gx = gy W) stay on hipBLASLt;
+ * these entry points cover what the torch ops do badly at [1M,128]: LayerNorm fwd/bwd (fused with the
+ * neighbouring ReLU / dropout) and the weight-gradient GEMM.
+ * Dropout: keep iff hash(seed, element index) >= p, kept values scaled by 1/(1-p); the backward regenerates the mask
+ * from the same seed.
+ * ------------------------------------------------------------------------------------------- */
+
+/* y = dropout_p( LayerNorm_{gamma,beta,eps}( relu_in ? relu(x) : x ) );  stats[row] = {mean, rstd} (f32[n*2]). */
+int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int relu_in,
+                  float p, uint64_t seed, float* y, int64_t ldy, float* stats, int64_t n, int64_t d, void* stream);
+
+/* Backward of allset_ln_fwd.  gx = d loss / d x;  partials: f32[n_partials*2*d], row k holds block k's
+ * (dgamma[d], dbeta[d]) partial sums -- the caller sums over k.  n_partials from allset_ln_bwd_partials. */
+int allset_ln_bwd_partials(int64_t n, int64_t d, int64_t* n_partials);
+int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* stats, const float* gamma,
+                  int relu_in, float p, uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials,
+                  int64_t n, int64_t d, void* stream);
+
+/* y = dropout_p(relu(x)) over numel contiguous elements, and its backward (gx = gy/(1-p) where y > 0, else 0). */
+int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, float* y, int64_t numel, void* stream);
+int allset_relu_dropout_bwd(const float* gy, const float* y, float p, float* gx, int64_t numel, void* stream);
+
+/* Weight gradient of y = u W^T + b:  gW[o][i] = sum_r ga[r][o] * u[r][i],  gb[o] = sum_r ga[r][o], as
+ * n_slices split-K partials (part_w: f32[n_slices*O*I], part_b: f32[n_slices*O] or NULL) that the caller
+ * sums -- deterministic, no atomics.  fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).  O, I, lda, ldu must be
+ * multiples of 4 and the inputs 16-byte aligned, else ALLSET_ERR_UNSUPPORTED. */
+int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
+int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
+                 int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,139 @@
+"""GPU: dense-tail kernels (csrc/dense.hip) against plain torch fp32/fp64 references of the same ops
+(floating-point kernels: the torch reference is the checker here, tolerance 1e-4 / 1e-5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,d", [(1, 4), (37, 128), (1000, 64), (513, 256), (300, 100), (129, 1433), (64, 7), (2050, 32)])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_layer_norm_fwd_bwd(n, d, relu_in, device):
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n * 1000 + d)
+    x = torch.randn(n, d, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(d, generator=g), 0.3 * torch.randn(d, generator=g)
+    G = torch.randn(n, d, generator=g)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    ref = F.layer_norm(F.relu(xr) if relu_in else xr, (d,), gr, br, 1e-5)
+    (ref * G.double()).sum().backward()
+    xg, gg, bg = (t.to(device).requires_grad_(True) for t in (x, gamma, beta))
+    out = dense.layer_norm(xg, gg, bg, 1e-5, relu_in, 0.0)
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5)
+    scale = max(1.0, float(gr.grad.abs().max()))
+    torch.testing.assert_close(gg.grad.cpu().double(), gr.grad, rtol=1e-4, atol=1e-4 * scale)
+    torch.testing.assert_close(bg.grad.cpu().double(), br.grad, rtol=1e-4, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize("d", [128, 100, 1433])
+def test_layer_norm_dropout_mask_is_consistent(d, device):
+    """y = mask/(1-p) * LN(x): the mask is Bernoulli(1-p), reproducible from the seed, and the backward uses
+    exactly the mask of the forward (checked against torch autograd with that mask)."""
+    from allset_amd import dense
+    n, p = 4000, 0.3
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=g).to(device)
+    gamma = (1 + 0.2 * torch.randn(d, generator=g)).to(device)
+    beta = (0.5 + 0.3 * torch.randn(d, generator=g)).to(device)
+    y0, st = dense.ln_fwd(x, gamma, beta, 1e-5, True, 0.0, 0)
+    y1, _ = dense.ln_fwd(x, gamma, beta, 1e-5, True, p, 1234567)
+    y2, _ = dense.ln_fwd(x, gamma, beta, 1e-5, True, p, 1234567)
+    y3, _ = dense.ln_fwd(x, gamma, beta, 1e-5, True, p, 7654321)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    kept = y1 != 0
+    torch.testing.assert_close(y1[kept], (y0 / (1 - p))[kept], rtol=1e-6, atol=1e-6)
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    per_col = kept.float().mean(0)
+    assert float((per_col - (1 - p)).abs().max()) < 0.06          # no column-structured bias
+    mask = kept.float() / (1 - p)
+    G = torch.randn(n, d, device=device)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    (F.layer_norm(F.relu(xr), (d,), gr, br, 1e-5) * mask * G).sum().backward()
+    gx, dg, db = dense.ln_bwd(G, x, st, gamma, True, p, 1234567)
+    torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dg, gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db, br.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(1000, 128), (7, 3), (513, 33), (1, 1)])
+def test_relu_dropout(shape, device):
+    from allset_amd import dense
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=device).requires_grad_(True)
+    y = dense.relu_dropout(x, 0.0)
+    torch.testing.assert_close(y, F.relu(x), rtol=0, atol=0)
+    G = torch.randn(*shape, device=device)
+    y.backward(G)
+    torch.testing.assert_close(x.grad, G * (x > 0), rtol=0, atol=0)
+    x.grad = None
+    p = 0.4
+    y = dense.relu_dropout(x, p)
+    y.backward(G)
+    kept = y != 0
+    torch.testing.assert_close(y[kept], (F.relu(x) / (1 - p))[kept], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(x.grad, torch.where(kept, G / (1 - p), torch.zeros_like(G)), rtol=1e-6, atol=1e-7)
+    if x.numel() > 10000:
+        pos = x > 0
+        assert abs(float(kept[pos].float().mean()) - (1 - p)) < 0.02
+
+
+@pytest.mark.parametrize("n,O,I", [(1000, 128, 128), (70001, 64, 256), (33, 4, 132), (5, 128, 128), (4096, 260, 128),
+                                   (300000, 128, 128), (1, 8, 8)])
+def test_wgrad_matches_matmul(n, O, I, device):
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n + O + I)
+    ga = torch.randn(n, O, generator=g)
+    u = torch.randn(n, I, generator=g)
+    gw, gb = dense.wgrad(ga.to(device), u.to(device))
+    ref_w = ga.double().t() @ u.double()
+    ref_b = ga.double().sum(0)
+    tol = 1e-5 * max(1.0, float(n) ** 0.5)
+    torch.testing.assert_close(gw.cpu().double(), ref_w, rtol=1e-4, atol=tol)
+    torch.testing.assert_close(gb.cpu().double(), ref_b, rtol=1e-4, atol=tol)
+    # transpose-sensitivity: an asymmetric pattern (a single one) lands where it should
+    ga2 = torch.zeros(n, O); u2 = torch.zeros(n, I)
+    ga2[n // 2, O - 1] = 1.0; u2[n // 2, 1 % I] = 2.0
+    gw2, _ = dense.wgrad(ga2.to(device), u2.to(device))
+    exp = torch.zeros(O, I); exp[O - 1, 1 % I] = 2.0
+    torch.testing.assert_close(gw2.cpu(), exp, rtol=0, atol=0)
+
+
+def test_linear_function_all_gradients(device):
+    from allset_amd import dense
+    torch.manual_seed(0)
+    for n, I, O in ((257, 128, 128), (50, 1433, 64), (64, 16, 7)):
+        x = torch.randn(n, I, device=device, requires_grad=True)
+        w = (0.1 * torch.randn(O, I, device=device)).requires_grad_(True)
+        b = torch.randn(O, device=device, requires_grad=True)
+        G = torch.randn(n, O, device=device)
+        dense.linear(x, w, b).backward(G)
+        got = [t.grad.clone() for t in (x, w, b)]
+        for t in (x, w, b):
+            t.grad = None
+        F.linear(x, w, b).backward(G)
+        for a, t in zip(got, (x, w, b)):
+            torch.testing.assert_close(a, t.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_mlp_train_mode_statistics(device):
+    """Full MLP in train mode (dropout active): gradients flow, are finite, and the expected output over masks
+    matches the eval output of the same weights (dropout is unbiased) to a loose statistical tolerance."""
+    from allset_amd import MLP
+    torch.manual_seed(1)
+    m = MLP(64, 64, 64, 2, dropout=0.5, Normalization="ln", InputNorm=True).to(device)
+    x = torch.randn(2048, 64, device=device, requires_grad=True)
+    m.eval()
+    ref = m(x).detach()
+    m.train()
+    acc = torch.zeros_like(ref)
+    for _ in range(64):
+        acc += m(x).detach()
+    err = float((acc / 64 - ref).abs().mean()) / float(ref.abs().mean())
+    assert err < 0.15, err
+    m(x).sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters()) and torch.isfinite(x.grad).all()

@@ -55,8 +55,13 @@ def run_product(case: dict, sd: Dict[str, torch.Tensor], device):
     model.load_state_dict(sd)
     model.eval().to(device)
     grabbed = {}
-    model.V2EConvs[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("v2e0", o))
-    model.E2VConvs[0].register_forward_hook(lambda m, i, o: grabbed.__setitem__("e2v0", o))
+    # the raw conv output as the reference's forward hook sees it: SetGNN fuses its outer relu(+dropout) into
+    # the conv's last pass, so for the attention variant hook the PMA module (pre-relu); for Deep Sets the conv
+    # output is relu'd in the reference too
+    def raw(conv):
+        return conv.prop if conv.attention else conv
+    raw(model.V2EConvs[0]).register_forward_hook(lambda m, i, o: grabbed.__setitem__("v2e0", o))
+    raw(model.E2VConvs[0]).register_forward_hook(lambda m, i, o: grabbed.__setitem__("e2v0", o))
     x = torch.from_numpy(case["x"]).to(device).requires_grad_(True)
     ei = torch.from_numpy(case["edge_index"]).to(device)
     data = SimpleNamespace(x=x, edge_index=ei, norm=norm_t.to(device))
