@@ -61,45 +61,91 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb
   return start + idx;
 }
 
-// VEC consecutive elements as float, 4*VEC (f32) or 2*VEC (bf16) bytes, one global_load per call.
+// Storage types: float, or bf16 carried as raw 16-bit words (fp32 accumulation everywhere).
+struct bf16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {            // round to nearest even
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;       // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// VEC consecutive elements, unpacked to float.
 template <int VEC>
 struct FVec {
   float v[VEC];
 };
 
-template <int VEC>
-__device__ __forceinline__ FVec<VEC> load_vec(const float* __restrict__ p) {
-  FVec<VEC> r;
-  if constexpr (VEC == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
-  } else if constexpr (VEC == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    r.v[0] = t.x; r.v[1] = t.y;
-  } else {
-    static_assert(VEC == 1, "VEC must be 1, 2 or 4 for f32");
-    r.v[0] = *p;
-  }
-  return r;
+// A lane's packet exactly as loaded (kept packed while the gather is in flight: 16 B = 4 VGPRs for both
+// f32 x 4 and bf16 x 8), unpacked to floats only when it is consumed.
+template <typename T, int VEC>
+struct Raw;
+
+template <>
+struct Raw<float, 4> { float4 r; };
+template <>
+struct Raw<float, 1> { float r; };
+template <>
+struct Raw<bf16_t, 8> { uint4 r; };
+template <>
+struct Raw<bf16_t, 1> { uint16_t r; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ Raw<T, VEC> load_raw(const T* __restrict__ p) {
+  Raw<T, VEC> t;
+  if constexpr (sizeof(T) == 4 && VEC == 4) t.r = *reinterpret_cast<const float4*>(p);
+  else if constexpr (sizeof(T) == 4 && VEC == 1) t.r = *reinterpret_cast<const float*>(p);
+  else if constexpr (sizeof(T) == 2 && VEC == 8) t.r = *reinterpret_cast<const uint4*>(p);
+  else t.r = *reinterpret_cast<const uint16_t*>(p);
+  return t;
 }
 
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* __restrict__ p, const FVec<VEC>& r) {
-  if constexpr (VEC == 4) {
-    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
-  } else if constexpr (VEC == 2) {
-    *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
-  } else {
-    *p = r.v[0];
-  }
+template <typename T, int VEC>
+__device__ __forceinline__ Raw<T, VEC> zero_raw() {
+  Raw<T, VEC> t;
+  if constexpr (sizeof(T) == 4 && VEC == 4) t.r = make_float4(0.f, 0.f, 0.f, 0.f);
+  else if constexpr (sizeof(T) == 4 && VEC == 1) t.r = 0.f;
+  else if constexpr (sizeof(T) == 2 && VEC == 8) t.r = make_uint4(0u, 0u, 0u, 0u);
+  else t.r = 0;
+  return t;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ FVec<VEC> unpack(const Raw<T, VEC>& t) {
+  FVec<VEC> f;
+  if constexpr (sizeof(T) == 4 && VEC == 4) { f.v[0] = t.r.x; f.v[1] = t.r.y; f.v[2] = t.r.z; f.v[3] = t.r.w; }
+  else if constexpr (sizeof(T) == 4 && VEC == 1) { f.v[0] = t.r; }
+  else if constexpr (sizeof(T) == 2 && VEC == 8) {
+    const uint32_t w[4] = {t.r.x, t.r.y, t.r.z, t.r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f.v[2 * k] = __uint_as_float(w[k] << 16); f.v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+  } else { f.v[0] = bf16_to_f32(t.r); }
+  return f;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ FVec<VEC> load_vec(const T* __restrict__ p) { return unpack<T, VEC>(load_raw<T, VEC>(p)); }
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, const FVec<VEC>& f) {
+  if constexpr (sizeof(T) == 4 && VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+  else if constexpr (sizeof(T) == 4 && VEC == 1) *reinterpret_cast<float*>(p) = f.v[0];
+  else if constexpr (sizeof(T) == 2 && VEC == 8) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = f32_to_bf16(f.v[2 * k]) | (f32_to_bf16(f.v[2 * k + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else *reinterpret_cast<uint16_t*>(p) = static_cast<uint16_t>(f32_to_bf16(f.v[0]));
 }
 
 template <int VEC>
 __device__ __forceinline__ void store_vec_i32(int32_t* __restrict__ p, const int32_t (&a)[VEC]) {
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 8) {
     *reinterpret_cast<int4*>(p) = make_int4(a[0], a[1], a[2], a[3]);
-  } else if constexpr (VEC == 2) {
-    *reinterpret_cast<int2*>(p) = make_int2(a[0], a[1]);
+    *reinterpret_cast<int4*>(p + 4) = make_int4(a[4], a[5], a[6], a[7]);
+  } else if constexpr (VEC == 4) {
+    *reinterpret_cast<int4*>(p) = make_int4(a[0], a[1], a[2], a[3]);
   } else {
     *p = a[0];
   }

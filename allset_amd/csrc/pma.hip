@@ -37,10 +37,10 @@ __device__ __forceinline__ float head_group_reduce(float val, int li, int grp_en
   return val;
 }
 
-template <int VEC, int LPR>
+template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
-    const float* __restrict__ V, int64_t ldv, float slope, float* __restrict__ out, int64_t ldo,
+    const T* __restrict__ V, int64_t ldv, float slope, T* __restrict__ out, int64_t ldo,
     float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C) {
   constexpr int NS = kWave / LPR;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
       const int n = min(kWave, end - base);
       const int my_col = (lane < n) ? col[base + lane] : 0;
       for (int j = 0; j < n; j += NS * kPmaUnroll) {
-        FVec<VEC> v[kPmaUnroll];
+        Raw<T, VEC> raw[kPmaUnroll];
         float a[kPmaUnroll];
         bool ok[kPmaUnroll];
 #pragma unroll
@@ -74,19 +74,20 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
           const int src = __shfl(my_col, jj & (kWave - 1));
           if (ok[u]) {
             a[u] = alpha[static_cast<int64_t>(src) * H + h];
-            v[u] = load_vec<VEC>(V + static_cast<int64_t>(src) * ldv + c0);
+            raw[u] = load_raw<T, VEC>(V + static_cast<int64_t>(src) * ldv + c0);
           }
         }
 #pragma unroll
         for (int u = 0; u < kPmaUnroll; ++u) {
           if (ok[u]) {
+            const FVec<VEC> vu = unpack<T, VEC>(raw[u]);
             const float av = leaky_relu(a[u], slope);
             const float m_new = fmaxf(m, av);
             const float sc = __expf(m - m_new);       // 0 on the first incidence (m = -FLT_MAX)
             const float pe = __expf(av - m_new);
             l = fmaf(l, sc, pe);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(acc[k], sc, pe * v[u].v[k]);
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(acc[k], sc, pe * vu.v[k]);
             m = m_new;
           }
         }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
       FVec<VEC> r;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r.v[k] = acc[k] * inv;
-      store_vec<VEC>(out + static_cast<int64_t>(row) * ldo + c0, r);
+      store_vec<T, VEC>(out + static_cast<int64_t>(row) * ldo + c0, r);
       if (c0 % C == 0) {
         m_out[static_cast<int64_t>(row) * H + h] = l > 0.f ? m : 0.f;
         l_out[static_cast<int64_t>(row) * H + h] = l;
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(kBlock) void pma_attention_kernel(
 }
 
 // stats[t,h] = {M, delta}:  M = m + log(l + eps)  (so that p = exp(a - M)),  delta = <out[t,h,:], gout[t,h,:]>
-template <int VEC, int LPR>
+template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
-    const float* __restrict__ out, int64_t ldo, const float* __restrict__ gout, int64_t ldg,
+    const T* __restrict__ out, int64_t ldo, const T* __restrict__ gout, int64_t ldg,
     const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int n_t, int H, int C) {
   __shared__ float red[kWavesPerBlock][kMaxHeads];
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
     const int q = (c0 < d) ? (c0 % C) / VEC : 0;
     float part = 0.f;
     if (active) {
-      const FVec<VEC> o = load_vec<VEC>(out + static_cast<int64_t>(row) * ldo + c0);
-      const FVec<VEC> g = load_vec<VEC>(gout + static_cast<int64_t>(row) * ldg + c0);
+      const FVec<VEC> o = load_vec<T, VEC>(out + static_cast<int64_t>(row) * ldo + c0);
+      const FVec<VEC> g = load_vec<T, VEC>(gout + static_cast<int64_t>(row) * ldg + c0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) part = fmaf(o.v[k], g.v[k], part);
     }
@@ -184,11 +185,11 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
   }
 }
 
-template <int VEC, int LPR>
+template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
-    const float* __restrict__ V, int64_t ldv, const float* __restrict__ gout, int64_t ldg,
-    const float* __restrict__ stats, float slope, float* __restrict__ gV, int64_t ldgv,
+    const T* __restrict__ V, int64_t ldv, const T* __restrict__ gout, int64_t ldg,
+    const float* __restrict__ stats, float slope, T* __restrict__ gV, int64_t ldgv,
     float* __restrict__ galpha, int n_s, int H, int C) {
   constexpr int NS = kWave / LPR;
   __shared__ float red[kWavesPerBlock][kMaxHeads];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     FVec<VEC> vown;
     float a_s = 0.f;
     if (active) {
-      vown = load_vec<VEC>(V + static_cast<int64_t>(row) * ldv + c0);
+      vown = load_vec<T, VEC>(V + static_cast<int64_t>(row) * ldv + c0);
       a_s = leaky_relu(alpha[static_cast<int64_t>(row) * H + h], slope);
     } else {
 #pragma unroll
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
       const int n = min(kWave, end - base);
       const int my_col = (lane < n) ? colT[base + lane] : 0;
       for (int j = 0; j < n; j += NS * kPmaUnroll) {
-        FVec<VEC> g[kPmaUnroll];
+        Raw<T, VEC> g[kPmaUnroll];
         float2 st[kPmaUnroll];
         bool ok[kPmaUnroll];
 #pragma unroll
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
           ok[u] = (jj < n) && active;
           const int t = __shfl(my_col, jj & (kWave - 1));
           if (ok[u]) {
-            g[u] = load_vec<VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
+            g[u] = load_raw<T, VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
             st[u] = *reinterpret_cast<const float2*>(stats + (static_cast<int64_t>(t) * H + h) * 2);
           }
         }
@@ -243,11 +244,12 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
         for (int u = 0; u < kPmaUnroll; ++u) {
           if (ok[u]) {
             const float p = __expf(a_s - st[u].x);
+            const FVec<VEC> gu = unpack<T, VEC>(g[u]);
             float dotp = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-              gv[k] = fmaf(p, g[u].v[k], gv[k]);
-              dotp = fmaf(vown.v[k], g[u].v[k], dotp);
+              gv[k] = fmaf(p, gu.v[k], gv[k]);
+              dotp = fmaf(vown.v[k], gu.v[k], dotp);
             }
             S = fmaf(p, dotp, S);
             D = fmaf(p, st[u].y, D);
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
       FVec<VEC> r;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r.v[k] = gv[k];
-      store_vec<VEC>(gV + static_cast<int64_t>(row) * ldgv + c0, r);
+      store_vec<T, VEC>(gV + static_cast<int64_t>(row) * ldgv + c0, r);
     }
     // per-head: sum_lanes S  -  D (D is identical in every lane of the head; subtract it once)
     const int n_act = min(LPR, (d - cb) / VEC);
@@ -284,25 +286,25 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
 
 static inline unsigned row_grid(int64_t rows) { return static_cast<unsigned>((rows + kWavesPerBlock - 1) / kWavesPerBlock); }
 
-static inline int pick_lpr(int64_t d) {
-  const int64_t need = (d + 3) / 4;
+static inline int pick_lpr(int64_t d, int vec) {
+  const int64_t need = (d + vec - 1) / vec;
   int lpr = 8;
   while (lpr < need && lpr < 64) lpr <<= 1;
   return lpr;
 }
 
-#define ALLSET_PMA_DISPATCH(KERNEL, GRID, ST, ...)                                       \
-  do {                                                                                   \
-    if (vec4) {                                                                          \
-      switch (pick_lpr(d)) {                                                             \
-        case 8:  KERNEL<4, 8><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;              \
-        case 16: KERNEL<4, 16><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;             \
-        case 32: KERNEL<4, 32><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;             \
-        default: KERNEL<4, 64><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;             \
-      }                                                                                  \
-    } else {                                                                             \
-      KERNEL<1, 64><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__);                               \
-    }                                                                                    \
+#define ALLSET_PMA_DISPATCH_T(KERNEL, T, WIDE, GRID, ST, ...)                                \
+  do {                                                                                       \
+    if (wide_ok) {                                                                           \
+      switch (pick_lpr(d, WIDE)) {                                                           \
+        case 8:  KERNEL<T, WIDE, 8><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;            \
+        case 16: KERNEL<T, WIDE, 16><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;           \
+        case 32: KERNEL<T, WIDE, 32><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;           \
+        default: KERNEL<T, WIDE, 64><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__); break;           \
+      }                                                                                      \
+    } else {                                                                                 \
+      KERNEL<T, 1, 64><<<GRID, kBlock, 0, ST>>>(__VA_ARGS__);                                \
+    }                                                                                        \
   } while (0)
 
 static int check_pma_dims(const char* who, int64_t n_a, int64_t n_b, int64_t H, int64_t C) {
@@ -326,16 +328,21 @@ extern "C" int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* c
   clear_error();
   int rc = check_pma_dims("pma_fwd", n_t, n_s, H, C);
   if (rc != ALLSET_OK) return rc;
-  if (dtype != ALLSET_F32) { set_error("pma_fwd: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_fwd: bad dtype %d", dtype);
   if (n_t == 0) return ALLSET_OK;
   const int64_t d = H * C;
   ALLSET_REQUIRE(rowptr && out && m && l, "pma_fwd: null rowptr/out/m/l");
   ALLSET_REQUIRE(n_s == 0 || (col && alpha && V), "pma_fwd: null col/alpha/V with n_s > 0");
   ALLSET_REQUIRE(ldv >= d && ldo >= d, "pma_fwd: leading dimension smaller than H*C");
-  const bool vec4 = (C % 4 == 0) && (ldv % 4 == 0) && (ldo % 4 == 0) && aligned16(V) && aligned16(out);
+  const int wide = dtype == ALLSET_F32 ? 4 : 8;
+  const bool wide_ok = (C % wide == 0) && (ldv % wide == 0) && (ldo % wide == 0) && aligned16(V) && aligned16(out);
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  ALLSET_PMA_DISPATCH(pma_fwd_kernel, row_grid(n_t), st, rowptr, col, alpha, static_cast<const float*>(V), ldv, slope,
-                      static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
+  if (dtype == ALLSET_F32)
+    ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, float, 4, row_grid(n_t), st, rowptr, col, alpha, static_cast<const float*>(V), ldv, slope,
+                          static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
+  else
+    ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, bf16_t, 8, row_grid(n_t), st, rowptr, col, alpha, static_cast<const bf16_t*>(V), ldv, slope,
+                          static_cast<bf16_t*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -358,17 +365,23 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
   clear_error();
   int rc = check_pma_dims("pma_bwd_stats", n_t, 0, H, C);
   if (rc != ALLSET_OK) return rc;
-  if (dtype != ALLSET_F32) { set_error("pma_bwd_stats: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_bwd_stats: bad dtype %d", dtype);
   if (n_t == 0) return ALLSET_OK;
   const int64_t d = H * C;
   ALLSET_REQUIRE(out && gout && m && l && stats, "pma_bwd_stats: null pointer");
   ALLSET_REQUIRE(ldo >= d && ldg >= d, "pma_bwd_stats: leading dimension smaller than H*C");
   ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "pma_bwd_stats: stats must be 8-byte aligned");
-  const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (ldg % 4 == 0) && aligned16(out) && aligned16(gout);
+  const int wide = dtype == ALLSET_F32 ? 4 : 8;
+  const bool wide_ok = (C % wide == 0) && (ldo % wide == 0) && (ldg % wide == 0) && aligned16(out) && aligned16(gout);
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  ALLSET_PMA_DISPATCH(pma_bwd_stats_kernel, row_grid(n_t), st, static_cast<const float*>(out), ldo,
-                      static_cast<const float*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
-                      static_cast<int>(C));
+  if (dtype == ALLSET_F32)
+    ALLSET_PMA_DISPATCH_T(pma_bwd_stats_kernel, float, 4, row_grid(n_t), st, static_cast<const float*>(out), ldo,
+                          static_cast<const float*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
+                          static_cast<int>(C));
+  else
+    ALLSET_PMA_DISPATCH_T(pma_bwd_stats_kernel, bf16_t, 8, row_grid(n_t), st, static_cast<const bf16_t*>(out), ldo,
+                          static_cast<const bf16_t*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
+                          static_cast<int>(C));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -380,19 +393,25 @@ extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32
   clear_error();
   int rc = check_pma_dims("pma_bwd_src", n_s, n_t, H, C);
   if (rc != ALLSET_OK) return rc;
-  if (dtype != ALLSET_F32) { set_error("pma_bwd_src: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_bwd_src: bad dtype %d", dtype);
   if (n_s == 0) return ALLSET_OK;
   const int64_t d = H * C;
   ALLSET_REQUIRE(rowptrT && alpha && V && gV && galpha, "pma_bwd_src: null pointer");
   ALLSET_REQUIRE(n_t == 0 || (colT && gout && stats), "pma_bwd_src: null colT/gout/stats with n_t > 0");
   ALLSET_REQUIRE(ldv >= d && ldg >= d && ldgv >= d, "pma_bwd_src: leading dimension smaller than H*C");
   ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "pma_bwd_src: stats must be 8-byte aligned");
-  const bool vec4 = (C % 4 == 0) && (ldv % 4 == 0) && (ldg % 4 == 0) && (ldgv % 4 == 0) && aligned16(V) &&
-                    aligned16(gout) && aligned16(gV);
+  const int wide = dtype == ALLSET_F32 ? 4 : 8;
+  const bool wide_ok = (C % wide == 0) && (ldv % wide == 0) && (ldg % wide == 0) && (ldgv % wide == 0) && aligned16(V) &&
+                       aligned16(gout) && aligned16(gV);
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  ALLSET_PMA_DISPATCH(pma_bwd_src_kernel, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const float*>(V), ldv,
-                      static_cast<const float*>(gout), ldg, stats, slope, static_cast<float*>(gV), ldgv, galpha,
-                      static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C));
+  if (dtype == ALLSET_F32)
+    ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, float, 4, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const float*>(V), ldv,
+                          static_cast<const float*>(gout), ldg, stats, slope, static_cast<float*>(gV), ldgv, galpha,
+                          static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C));
+  else
+    ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, bf16_t, 8, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const bf16_t*>(V), ldv,
+                          static_cast<const bf16_t*>(gout), ldg, stats, slope, static_cast<bf16_t*>(gV), ldgv, galpha,
+                          static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

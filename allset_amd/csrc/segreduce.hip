@@ -21,10 +21,10 @@ namespace allset {
 enum { kModeSum = 0, kModeExt = 1 };
 constexpr int kUnroll = 8;
 
-template <int VEC, int LPR, int MODE, bool WEIGHTED>
+template <typename T, int VEC, int LPR, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void segreduce_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
-    const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+    const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
     int32_t* __restrict__ argext, int n_t, int d, int mean, float sign) {
   constexpr int NS = kWave / LPR;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
         if constexpr (WEIGHTED) my_w = w[base + lane];
       }
       for (int j = 0; j < n; j += NS * kUnroll) {
-        FVec<VEC> v[kUnroll];
+        Raw<T, VEC> raw[kUnroll];        // kept packed while in flight (16 B per lane and load)
         float ww[kUnroll];
         bool ok[kUnroll];
 #pragma unroll
@@ -60,24 +60,21 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
           ok[u] = (jj < n) && active;
           const int src = __shfl(my_col, jj & (kWave - 1));
           if constexpr (WEIGHTED) ww[u] = __shfl(my_w, jj & (kWave - 1)); else ww[u] = 1.f;
-          if (ok[u]) {
-            v[u] = load_vec<VEC>(x + static_cast<int64_t>(src) * ldx + c0);
-          } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) v[u].v[k] = 0.f;
-          }
+          if (ok[u]) raw[u] = load_raw<T, VEC>(x + static_cast<int64_t>(src) * ldx + c0);
+          else raw[u] = zero_raw<T, VEC>();
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
+          const FVec<VEC> v = unpack<T, VEC>(raw[u]);
           if constexpr (MODE == kModeSum) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(ww[u], v[u].v[k], acc[k]);   // ok==false -> v == 0
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(ww[u], v.v[k], acc[k]);   // ok==false -> v == 0
           } else {
             if (ok[u]) {
               const int pos = base + j + u * NS + slot;
 #pragma unroll
               for (int k = 0; k < VEC; ++k) {
-                const float val = sign * (ww[u] * v[u].v[k]);
+                const float val = sign * (ww[u] * v.v[k]);
                 if (arg[k] < 0 || val > acc[k]) { acc[k] = val; arg[k] = pos; }
               }
             }
@@ -112,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
         for (int k = 0; k < VEC; ++k) r.v[k] = arg[k] >= 0 ? sign * acc[k] : 0.f;   // empty row -> 0
         if (argext != nullptr) store_vec_i32<VEC>(argext + static_cast<int64_t>(row) * d + c0, arg);
       }
-      store_vec<VEC>(out + static_cast<int64_t>(row) * ldo + c0, r);
+      store_vec<T, VEC>(out + static_cast<int64_t>(row) * ldo + c0, r);
     }
   }
 }
@@ -152,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void segmax_bwd_kernel(
         const int pos = __shfl(my_pos, jj & (kWave - 1));
         const float ww = __shfl(my_w, jj & (kWave - 1));
         if (jj < n && active) {
-          const FVec<VEC> g = load_vec<VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
+          const FVec<VEC> g = load_vec<float, VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
           const int32_t* ap = argext + static_cast<int64_t>(t) * d + c0;
 #pragma unroll
           for (int k = 0; k < VEC; ++k)
@@ -168,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void segmax_bwd_kernel(
       FVec<VEC> r;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r.v[k] = acc[k];
-      store_vec<VEC>(gx + static_cast<int64_t>(row) * ldx + c0, r);
+      store_vec<float, VEC>(gx + static_cast<int64_t>(row) * ldx + c0, r);
     }
   }
 }
@@ -205,25 +202,41 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowdot_kernel(
 
 static inline unsigned row_grid(int64_t rows) { return static_cast<unsigned>((rows + kWavesPerBlock - 1) / kWavesPerBlock); }
 
-// lanes-per-row for the 16-byte path: smallest power of two >= d/4, in [8, 64]
-static inline int pick_lpr(int64_t d) {
-  const int64_t need = (d + 3) / 4;
+// lanes-per-row for the 16-byte path: smallest power of two >= d/vec, in [8, 64]
+static inline int pick_lpr(int64_t d, int vec = 4) {
+  const int64_t need = (d + vec - 1) / vec;
   int lpr = 8;
   while (lpr < need && lpr < 64) lpr <<= 1;
   return lpr;
 }
 
-template <int VEC, int LPR>
+template <typename T, int VEC, int LPR>
 static void launch_segreduce(int mode_ext, bool weighted, unsigned grid, hipStream_t st,
-                             const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
-                             int64_t ldx, float* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean,
+                             const int32_t* rowptr, const int32_t* col, const float* w, const T* x,
+                             int64_t ldx, T* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean,
                              float sign) {
   if (!mode_ext) {
-    if (weighted) segreduce_kernel<VEC, LPR, kModeSum, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
-    else          segreduce_kernel<VEC, LPR, kModeSum, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    if (weighted) segreduce_kernel<T, VEC, LPR, kModeSum, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    else          segreduce_kernel<T, VEC, LPR, kModeSum, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
   } else {
-    if (weighted) segreduce_kernel<VEC, LPR, kModeExt, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
-    else          segreduce_kernel<VEC, LPR, kModeExt, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    if (weighted) segreduce_kernel<T, VEC, LPR, kModeExt, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    else          segreduce_kernel<T, VEC, LPR, kModeExt, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+  }
+}
+
+template <typename T, int WIDE>
+static void dispatch_segreduce(bool wide_ok, int mode_ext, bool weighted, unsigned grid, hipStream_t st,
+                               const int32_t* rowptr, const int32_t* col, const float* w, const T* x, int64_t ldx,
+                               T* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean, float sign) {
+  if (wide_ok) {
+    switch (pick_lpr(d, WIDE)) {
+      case 8:  launch_segreduce<T, WIDE, 8>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
+      case 16: launch_segreduce<T, WIDE, 16>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
+      case 32: launch_segreduce<T, WIDE, 32>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
+      default: launch_segreduce<T, WIDE, 64>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
+    }
+  } else {
+    launch_segreduce<T, 1, 64>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
   }
 }
 
@@ -246,10 +259,7 @@ extern "C" int allset_segreduce_fwd(int reduce, int dtype, const int32_t* rowptr
   ALLSET_REQUIRE(reduce >= ALLSET_SUM && reduce <= ALLSET_MIN, "segreduce_fwd: bad reduce %d", reduce);
   ALLSET_REQUIRE(n_t >= 0 && n_s >= 0 && d >= 0, "segreduce_fwd: negative size");
   ALLSET_REQUIRE(n_t < INT32_MAX && n_s < INT32_MAX && d < INT32_MAX, "segreduce_fwd: size exceeds int32");
-  if (dtype != ALLSET_F32) {
-    set_error("segreduce_fwd: dtype %d not built (f32 only in ABI v%d)", dtype, ALLSET_ABI_VERSION);
-    return ALLSET_ERR_UNSUPPORTED;
-  }
+  ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "segreduce_fwd: bad dtype %d", dtype);
   if (n_t == 0 || d == 0) return ALLSET_OK;
   ALLSET_REQUIRE(rowptr && out, "segreduce_fwd: null rowptr/out");
   ALLSET_REQUIRE(ldx >= d && ldo >= d, "segreduce_fwd: leading dimension smaller than d");
@@ -257,25 +267,20 @@ extern "C" int allset_segreduce_fwd(int reduce, int dtype, const int32_t* rowptr
   // require them whenever a source table is declared.
   ALLSET_REQUIRE(n_s == 0 || (col && x), "segreduce_fwd: null col/x with n_s > 0");
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  const float* xf = static_cast<const float*>(x);
-  float* of = static_cast<float*>(out);
   const bool ext = (reduce == ALLSET_MAX || reduce == ALLSET_MIN);
   const float sign = (reduce == ALLSET_MIN) ? -1.f : 1.f;
   const int mean = (reduce == ALLSET_MEAN);
-  const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out) &&
-                    (argext == nullptr || aligned16(argext));
+  const int wide = dtype == ALLSET_F32 ? 4 : 8;                       // elements in a 16-byte packet
+  const bool wide_ok = (d % wide == 0) && (ldx % wide == 0) && (ldo % wide == 0) && aligned16(x) && aligned16(out) &&
+                       (argext == nullptr || aligned16(argext));
   const unsigned grid = row_grid(n_t);
   const int nt = static_cast<int>(n_t), di = static_cast<int>(d);
-  if (vec4) {
-    switch (pick_lpr(d)) {
-      case 8:  launch_segreduce<4, 8>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
-      case 16: launch_segreduce<4, 16>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
-      case 32: launch_segreduce<4, 32>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
-      default: launch_segreduce<4, 64>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign); break;
-    }
-  } else {
-    launch_segreduce<1, 64>(ext, w != nullptr, grid, st, rowptr, col, w, xf, ldx, of, ldo, argext, nt, di, mean, sign);
-  }
+  if (dtype == ALLSET_F32)
+    dispatch_segreduce<float, 4>(wide_ok, ext, w != nullptr, grid, st, rowptr, col, w, static_cast<const float*>(x), ldx,
+                                 static_cast<float*>(out), ldo, argext, nt, di, mean, sign);
+  else
+    dispatch_segreduce<bf16_t, 8>(wide_ok, ext, w != nullptr, grid, st, rowptr, col, w, static_cast<const bf16_t*>(x), ldx,
+                                  static_cast<bf16_t*>(out), ldo, argext, nt, di, mean, sign);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -48,6 +48,10 @@ class _SegReduce(torch.autograd.Function):
         T = inc.by_src
         gx = gw = None
         gout = gout.contiguous()
+        if reduce in (MAX, MIN) or ctx.need_gw:
+            if gout.dtype != torch.float32:
+                raise _lib.AllSetHipError("max/min backward and weight gradients are fp32-only; bf16 storage covers "
+                                          "sum/mean and the PMA path")
         if ctx.needs_input_grad[0]:
             if w_dst is not None and w_src is None:       # differentiable weights: route on the fly
                 w_src = w_dst[inc.pos_dst_of_src().long()]
@@ -112,6 +116,8 @@ def pma_aggregate(V: Tensor, alpha: Tensor, inc: Incidence, heads: int, negative
     """
     _lib.require_device(V, alpha)
     _check_rows(V, inc)
+    if alpha.dtype != torch.float32:          # logits and softmax statistics are always fp32 (bf16 is storage only)
+        alpha = alpha.float()
     return _PmaAggregate.apply(V, alpha, inc, int(heads), float(negative_slope))
 
 

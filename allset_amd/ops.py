@@ -86,7 +86,16 @@ def _ld(t: Tensor) -> int:
 
 def _f32(t: Tensor, what: str) -> None:
     if t.dtype != torch.float32:
-        raise _lib.AllSetHipError(f"{what}: float32 required (got {t.dtype}); bf16 storage is not built in ABI v1")
+        raise _lib.AllSetHipError(f"{what}: float32 required (got {t.dtype})")
+
+
+def _dtype_code(t: Tensor, what: str) -> int:
+    """Storage dtype of a feature matrix: fp32, or bf16 (accumulation is fp32 in both cases)."""
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    raise _lib.AllSetHipError(f"{what}: float32 or bfloat16 storage required (got {t.dtype})")
 
 
 def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_rows: int, n_cols: int) -> CSR:
@@ -112,7 +121,8 @@ def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_
 def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: Tensor, n_t: int,
               want_arg: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     dev = require_device(rowptr, col, w, x)
-    _f32(x, "segreduce")
+    code = _dtype_code(x, "segreduce")
+    es = x.element_size()
     x = _rowmajor(x)
     n_s, d = x.shape
     out = torch.empty((n_t, d), dtype=x.dtype, device=dev)
@@ -121,9 +131,9 @@ def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: 
         _f32(w, "segreduce weights")
         w = w.contiguous()
     nnz = col.numel()
-    algo = nnz * (4 * d + 4 + (4 if w is not None else 0)) + (n_t + 1) * 4 + n_t * d * 4
+    algo = nnz * (es * d + 4 + (4 if w is not None else 0)) + (n_t + 1) * 4 + n_t * d * es
     with torch.cuda.device(dev), _timed("segreduce_fwd", dev, algo):
-        check(_lib.load().allset_segreduce_fwd(reduce, _lib.F32, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
+        check(_lib.load().allset_segreduce_fwd(reduce, code, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
                                                ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
               "allset_segreduce_fwd")
     return out, arg
@@ -162,7 +172,9 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
 def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, slope: float, n_t: int
             ) -> Tuple[Tensor, Tensor, Tensor]:
     dev = require_device(rowptr, col, alpha, V)
-    _f32(V, "pma_fwd")
+    code = _dtype_code(V, "pma_fwd")
+    es = V.element_size()
+    _f32(alpha, "pma_fwd logits")
     V = _rowmajor(V)
     alpha = alpha.contiguous()
     n_s, d = V.shape
@@ -171,9 +183,9 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
     out = torch.empty((n_t, d), dtype=V.dtype, device=dev)
     m = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
     l = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
-    algo = col.numel() * (4 * d + 4 + 4 * heads) + (n_t + 1) * 4 + n_t * (d * 4 + 8 * heads)
+    algo = col.numel() * (es * d + 4 + 4 * heads) + (n_t + 1) * 4 + n_t * (d * es + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_fwd", dev, algo):
-        check(_lib.load().allset_pma_fwd(_lib.F32, ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V), slope, ptr(out),
+        check(_lib.load().allset_pma_fwd(code, ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V), slope, ptr(out),
                                          max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads, stream_of(dev)),
               "allset_pma_fwd")
     return out, m, l
@@ -191,13 +203,17 @@ def pma_attention(rowptr: Tensor, col: Tensor, alpha: Tensor, m: Tensor, l: Tens
 
 def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
     dev = require_device(out, gout, m, l)
+    code = _dtype_code(out, "pma_bwd_stats")
+    if gout.dtype != out.dtype:
+        gout = gout.to(out.dtype)
+    es = out.element_size()
     out, gout = _rowmajor(out), _rowmajor(gout)
     n_t, d = out.shape
     heads = m.shape[1]
     stats = torch.empty((n_t, heads, 2), dtype=torch.float32, device=dev)
-    algo = n_t * (2 * d * 4 + 8 * heads + 8 * heads)
+    algo = n_t * (2 * d * es + 8 * heads + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_stats", dev, algo):
-        check(_lib.load().allset_pma_bwd_stats(_lib.F32, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m), ptr(l),
+        check(_lib.load().allset_pma_bwd_stats(code, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m), ptr(l),
                                                ptr(stats), n_t, heads, d // heads, stream_of(dev)),
               "allset_pma_bwd_stats")
     return stats
@@ -206,6 +222,11 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
 def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: Tensor, stats: Tensor, slope: float
                 ) -> Tuple[Tensor, Tensor]:
     dev = require_device(rowptrT, colT, alpha, V, gout, stats)
+    code = _dtype_code(V, "pma_bwd_src")
+    if gout.dtype != V.dtype:
+        gout = gout.to(V.dtype)
+    es = V.element_size()
+    _f32(alpha, "pma_bwd_src logits")
     V, gout = _rowmajor(V), _rowmajor(gout)
     alpha = alpha.contiguous()
     n_s, d = V.shape
@@ -213,9 +234,9 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     heads = alpha.shape[1]
     gV = torch.empty((n_s, d), dtype=V.dtype, device=dev)
     galpha = torch.empty((n_s, heads), dtype=torch.float32, device=dev)
-    algo = colT.numel() * (4 * d + 4 + 8 * heads) + (n_s + 1) * 4 + n_s * (2 * d * 4 + 8 * heads)
+    algo = colT.numel() * (es * d + 4 + 8 * heads) + (n_s + 1) * 4 + n_s * (2 * d * es + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
-        check(_lib.load().allset_pma_bwd_src(_lib.F32, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V), ptr(gout),
+        check(_lib.load().allset_pma_bwd_src(code, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V), ptr(gout),
                                              _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1), ptr(galpha),
                                              n_s, n_t, heads, d // heads, stream_of(dev)),
               "allset_pma_bwd_src")

@@ -50,8 +50,8 @@ def test_version_and_error_reporting():
     assert lib.allset_version() == _lib.ABI_VERSION == 1
     rc = lib.allset_segreduce_fwd(99, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)
     assert rc == -1 and b"bad reduce" in lib.allset_last_error()
-    rc = lib.allset_segreduce_fwd(0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)      # bf16: not built in ABI v1
-    assert rc == -3 and b"dtype" in lib.allset_last_error()
+    rc = lib.allset_segreduce_fwd(0, 7, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)      # dtype must be F32 (0) or BF16 (1)
+    assert rc == -1 and b"dtype" in lib.allset_last_error()
     rc = lib.allset_segreduce_fwd(0, 0, 0, 0, 0, 0, 4, 0, 4, 0, 5, 5, 4, 0)      # null pointers
     assert rc == -1 and b"null" in lib.allset_last_error()
     rc = lib.allset_segreduce_fwd(0, 0, 0, 0, 0, 0, 4, 0, 4, 0, 0, 5, 4, 0)      # n_t == 0: nothing to do

@@ -172,3 +172,50 @@ def test_strided_inputs_use_leading_dimension(device):
     ref2 = oracle.deepsets_aggregate(x2.cpu(), ei, torch.ones(300, dtype=torch.int64), "add")
     out2 = deepsets_aggregate(x2, inc, None, "add")
     torch.testing.assert_close(out2.cpu()[:ref2.shape[0]], ref2, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d,H", [(256, 8), (128, 4), (64, 1), (24, 3), (520, 1)])
+def test_bf16_storage_fp32_accumulate(d, H, device):
+    """BASELINE configs[4]: bf16 storage, fp32 accumulation.  Inputs are rounded to bf16 once; the oracle runs in
+    fp32 on those rounded values, so the only differences are the final bf16 rounding of the outputs
+    (rel 2^-8) -- tolerance 1e-2 relative to the tensor scale."""
+    from allset_amd import Incidence, deepsets_aggregate, pma_aggregate
+    rng = np.random.default_rng(d + H)
+    n_s, n_t = 250, 100
+    ei = make_incidence(rng, n_s, n_t, 1400, long_row=150)
+    x = torch.from_numpy(rng.standard_normal((n_s, d)).astype(np.float32)).bfloat16()
+    G = torch.from_numpy(rng.standard_normal((n_t, d)).astype(np.float32)).bfloat16()
+    inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+
+    def close(a, b):
+        scale = float(b.abs().max())
+        torch.testing.assert_close(a.float().cpu(), b, rtol=2e-2, atol=1e-2 * scale)
+
+    for aggr in ("add", "mean"):
+        xo = x.float().requires_grad_(True)
+        ref = oracle.deepsets_aggregate(xo, ei, torch.ones(ei.shape[1], dtype=torch.int64), aggr)
+        ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], d)])
+        (ref * G.float()).sum().backward()
+        xg = x.to(device).requires_grad_(True)
+        out = deepsets_aggregate(xg, inc, None, aggr)
+        assert out.dtype == torch.bfloat16
+        out.backward(G.to(device))
+        close(out.detach(), ref.detach())
+        close(xg.grad, xo.grad)
+    out_max = deepsets_aggregate(x.to(device), inc, None, "max")                 # forward-only in bf16
+    ref_max = oracle.deepsets_aggregate(x.float(), ei, torch.ones(ei.shape[1], dtype=torch.int64), "max")
+    close(out_max[:ref_max.shape[0]], ref_max)
+
+    C = d // H
+    alpha = torch.from_numpy((2.0 * rng.standard_normal((n_s, H))).astype(np.float32))
+    Vo, ao = x.float().view(n_s, H, C).clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    ref, _ = oracle.pma_aggregate(Vo, ao, ei, 0.2)
+    ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], H, C)])
+    (ref * G.float().view(n_t, H, C)).sum().backward()
+    Vg, ag = x.to(device).requires_grad_(True), alpha.to(device).requires_grad_(True)
+    out, m, l = pma_aggregate(Vg, ag, inc, H, 0.2)
+    assert out.dtype == torch.bfloat16 and m.dtype == torch.float32
+    out.backward(G.to(device))
+    close(out.detach().view(n_t, H, C), ref.detach())
+    close(Vg.grad.view(n_s, H, C), Vo.grad)
+    close(ag.grad, ao.grad)
