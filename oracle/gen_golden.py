@@ -162,5 +162,42 @@ def main() -> None:
                        cases=report), f, indent=1, sort_keys=True)
 
 
+def canon(ei: np.ndarray) -> np.ndarray:
+    """Order-free form of an edge list: columns sorted lexicographically (the reference's own sorts are unstable)."""
+    order = np.lexsort((ei[1], ei[0]))
+    return ei[:, order]
+
+
+def main_preprocessing() -> None:
+    """Golden vectors for allset_amd/preprocessing.py from the reference's own preprocessing.py functions."""
+    ref_pre = ref_shim.import_reference_preprocessing()
+    for name in cases.PREPROC_CASES:
+        c = cases.build_preproc_case(name)
+
+        def fresh():
+            return SimpleNamespace(edge_index=torch.from_numpy(c["edge_index"]).clone(), n_x=[c["n_v"]],
+                                   num_hyperedges=[c["n_e"]])
+        d = ref_pre.ExtractV2E(fresh())
+        out = {"in_edge_index": c["edge_index"], "n_v": np.int64(c["n_v"]), "n_e": np.int64(c["n_e"]),
+               "extract": canon(d.edge_index.numpy())}
+        d = ref_pre.Add_Self_Loops(d)
+        out["selfloop"] = canon(d.edge_index.numpy())
+        out["totedges"] = np.int64(d.totedges)
+        dn = ref_pre.norm_contruction(SimpleNamespace(edge_index=torch.from_numpy(out["selfloop"]).clone()), option="all_one")
+        out["norm_all_one"] = dn.norm.numpy()
+        dn = ref_pre.norm_contruction(SimpleNamespace(edge_index=torch.from_numpy(out["selfloop"]).clone()), option="deg_half_sym")
+        out["norm_deg_half_sym"] = dn.norm.numpy()
+        for th in (0, 4):
+            de = SimpleNamespace(edge_index=torch.from_numpy(out["selfloop"]).clone(), n_x=torch.tensor([c["n_v"]]),
+                                 num_hyperedges=[c["n_e"]], totedges=int(d.totedges))
+            de = ref_pre.expand_edge_index(de, edge_th=th)
+            out[f"expand_th{th}"] = canon(de.edge_index.numpy())
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+        print(f"{name:16s} extract nnz={out['extract'].shape[1]} selfloop nnz={out['selfloop'].shape[1]} "
+              f"expand nnz={out['expand_th0'].shape[1]}/{out['expand_th4'].shape[1]}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--preprocessing-only" not in sys.argv:
+        main()
+    main_preprocessing()

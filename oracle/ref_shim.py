@@ -146,11 +146,25 @@ def install() -> None:
     tg.nn = _module("torch_geometric.nn")
     tg.nn.conv = _module("torch_geometric.nn.conv", MessagePassing=_MessagePassing,
                          GCNConv=type("GCNConv", (), {}), GATConv=type("GATConv", (), {}))
+    _module("torch_geometric.nn.conv.gcn_conv", gcn_norm=None)      # imported (never called) by preprocessing.py:20
     tg.utils = _module("torch_geometric.utils", softmax=_pyg_softmax)
     tg.typing = _module("torch_geometric.typing", Adj=torch.Tensor, Size=Optional[Tuple[int, int]],
                         OptTensor=Optional[torch.Tensor])
     _module("ipdb")
     _installed = True
+
+
+def import_reference_preprocessing():
+    """The reference's ``preprocessing`` module (host-side edge-list surgery, preprocessing.py:394-469,22-144)."""
+    if not available():
+        raise RuntimeError("/root/reference is not present (this only works in the build container)")
+    install()
+    if REFERENCE_SRC not in sys.path:
+        sys.path.insert(0, REFERENCE_SRC)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import preprocessing as ref_pre   # noqa: E402
+    return ref_pre
 
 
 def import_reference():

@@ -222,3 +222,48 @@ ALL_CASES: List[str] = SMALL_CASES + BIG_CASES
 
 def checksum(a: np.ndarray) -> int:
     return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+# --------------------------------------------------------------------------------------
+# preprocessing cases: the [V|E ; E|V] block edge list the reference's loaders hand to ExtractV2E
+# (load_other_datasets.py:165-166), shuffled
+# --------------------------------------------------------------------------------------
+
+PREPROC_CASES: List[str] = ["pre_small", "pre_medium", "pre_singletons"]
+
+
+def build_preproc_case(name: str) -> dict:
+    seed = zlib.crc32(name.encode()) & 0x7FFFFFFF
+    rng = np.random.default_rng(seed)
+    if name == "pre_small":
+        n_v, n_e, nnz = 12, 5, 20
+    elif name == "pre_medium":
+        n_v, n_e, nnz = 400, 150, 1500
+    elif name == "pre_singletons":
+        n_v, n_e, nnz = 60, 40, 70          # many size-1 hyperedges -> skip list of Add_Self_Loops is exercised
+    else:
+        raise KeyError(name)
+    pairs = {(int(rng.integers(n_v)), e) for e in range(n_e)}
+    pairs |= {(n_v - 1, 0)}                                     # last vertex id present
+    if name == "pre_singletons":
+        # size-1 hyperedges must be owned by distinct vertices (the reference's Add_Self_Loops indexes out of
+        # bounds otherwise, preprocessing.py:428-440), so only hyperedges 0..9 receive extra members
+        taken = {}
+        pairs = set()
+        for e in range(n_e):
+            v = int(rng.integers(n_v))
+            while v in taken:
+                v = int(rng.integers(n_v))
+            taken[v] = e
+            pairs.add((v, e))
+        while len(pairs) < nnz:
+            pairs.add((int(rng.integers(n_v)), int(rng.integers(10))))
+    else:
+        while len(pairs) < nnz:
+            pairs.add((int(rng.integers(n_v)), int(rng.integers(n_e))))
+    pairs = sorted(pairs)
+    v = np.array([p[0] for p in pairs], dtype=np.int64)
+    e = np.array([p[1] for p in pairs], dtype=np.int64) + n_v
+    block = np.concatenate([np.stack([v, e]), np.stack([e, v])], axis=1)
+    block = block[:, rng.permutation(block.shape[1])]
+    return dict(name=name, n_v=n_v, n_e=n_e, edge_index=block, seed=seed)
