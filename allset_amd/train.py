@@ -1,0 +1,321 @@
+#!/usr/bin/env python
+"""``train.py``-compatible driver for AllSetTransformer / AllDeepSets on MI355X.
+
+Mirrors the surface of reference ``src/train.py`` for the two AllSet methods: same command-line flags, defaults
+and quirks (``--add_self_loop`` is ``store_false`` with default True, ``--PMA`` cannot be disabled except through
+``--method AllDeepSets``, ... : train.py:221-289), same preprocessing branch (:344-353), ``parse_method`` (:28-42),
+full-batch Adam loop with ``log_softmax`` + ``NLLLoss`` on the train split and an ``evaluate`` per epoch (:458-499),
+``Logger`` statistics (:106-150) and the CSV line appended under ``hyperparameter_tunning/`` (:504-520).
+
+Datasets: the reference's raw-data archive is not part of its repository.  This driver reads the
+HyperGCN on-disk format the reference's ``load_citation_dataset`` consumes (``features.pickle`` scipy-sparse,
+``labels.pickle`` list, ``hypergraph.pickle`` dict{hyperedge: [nodes]}; load_other_datasets.py:130-163) when
+``--raw_data_dir`` points at it, and otherwise generates ``--dname synthetic`` (a planted-partition hypergraph with
+noisy class-indicator features).  The baseline methods of the reference (HGNN, HCHA, HyperGCN, ...) are out of
+scope and rejected.
+
+    python -m allset_amd.train --method AllSetTransformer --dname synthetic --epochs 50 --runs 2 --heads 4 \\
+        --MLP_hidden 128 --All_num_layers 1
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import os.path as osp
+import pickle
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .models import SetGNN
+from .preprocessing import Add_Self_Loops, ExtractV2E, expand_edge_index, norm_contruction
+
+ALLSET_METHODS = ('AllSetTransformer', 'AllDeepSets')
+
+
+# --------------------------------------------------------------------------------------------------
+# data
+# --------------------------------------------------------------------------------------------------
+
+class HypergraphData(SimpleNamespace):
+    """The attributes train.py reads from its PyG ``Data`` object: x, edge_index, y, n_x, num_hyperedges, norm."""
+
+    def to(self, device):
+        for k, v in list(vars(self).items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        return self
+
+
+def block_edge_list(node_ids: np.ndarray, he_ids: np.ndarray, num_nodes: int) -> torch.Tensor:
+    """[[V | E], [E | V]] with hyperedge ids offset by ``num_nodes``, sorted and de-duplicated -- what the
+    reference's loaders produce (load_other_datasets.py:165-181, ``coalesce``)."""
+    v = np.asarray(node_ids, dtype=np.int64)
+    e = np.asarray(he_ids, dtype=np.int64) + num_nodes
+    ei = np.concatenate([np.stack([v, e]), np.stack([e, v])], axis=1)
+    span = int(ei.max()) + 1
+    key = np.unique(ei[0] * span + ei[1])
+    return torch.from_numpy(np.stack([key // span, key % span]))
+
+
+def load_hypergcn_dataset(path: str, dataset: str) -> HypergraphData:
+    """Read ``<path>/<dataset>/{features,labels,hypergraph}.pickle`` (reference load_other_datasets.py:121-196)."""
+    with open(osp.join(path, dataset, 'features.pickle'), 'rb') as f:
+        features = pickle.load(f)
+    features = np.asarray(features.todense() if hasattr(features, 'todense') else features, dtype=np.float32)
+    with open(osp.join(path, dataset, 'labels.pickle'), 'rb') as f:
+        labels = np.asarray(pickle.load(f), dtype=np.int64)
+    with open(osp.join(path, dataset, 'hypergraph.pickle'), 'rb') as f:
+        hypergraph = pickle.load(f)
+    num_nodes = features.shape[0]
+    assert num_nodes == len(labels)
+    nodes, hes = [], []
+    for idx, he in enumerate(hypergraph.keys()):
+        members = list(hypergraph[he])
+        nodes += members
+        hes += [idx] * len(members)
+    return HypergraphData(x=torch.from_numpy(features), y=torch.from_numpy(labels),
+                          edge_index=block_edge_list(np.array(nodes), np.array(hes), num_nodes),
+                          n_x=[num_nodes], num_hyperedges=[len(hypergraph)])
+
+
+def synthetic_dataset(n_v: int = 4000, n_e: int = 2000, num_classes: int = 5, num_features: int = 64,
+                      he_size: int = 6, purity: float = 0.8, feature_noise: float = 1.0, seed: int = 0) -> HypergraphData:
+    """Planted-partition hypergraph: each hyperedge draws a class and fills ``purity`` of its members from it;
+    features are a class indicator pattern plus N(0, feature_noise^2)."""
+    rng = np.random.default_rng(seed)
+    y = rng.integers(num_classes, size=n_v)
+    by_class = [np.flatnonzero(y == c) for c in range(num_classes)]
+    nodes, hes = [], []
+    for e in range(n_e):
+        c = int(rng.integers(num_classes))
+        k_in = max(1, int(round(purity * he_size)))
+        members = set(rng.choice(by_class[c], size=min(k_in, by_class[c].size), replace=False).tolist())
+        while len(members) < he_size:
+            members.add(int(rng.integers(n_v)))
+        nodes += sorted(members)
+        hes += [e] * len(members)
+    proto = rng.standard_normal((num_classes, num_features)).astype(np.float32)
+    x = proto[y] + feature_noise * rng.standard_normal((n_v, num_features)).astype(np.float32)
+    return HypergraphData(x=torch.from_numpy(x), y=torch.from_numpy(y.astype(np.int64)),
+                          edge_index=block_edge_list(np.array(nodes), np.array(hes), n_v),
+                          n_x=[n_v], num_hyperedges=[n_e])
+
+
+def rand_train_test_idx(label, train_prop=.5, valid_prop=.25, ignore_negative=True):
+    """Random train/valid/test split over labelled nodes (reference preprocessing.py:472-499, non-balanced)."""
+    labeled = torch.where(label != -1)[0] if ignore_negative else torch.arange(label.shape[0])
+    n = labeled.shape[0]
+    train_num, valid_num = int(n * train_prop), int(n * valid_prop)
+    perm = torch.as_tensor(np.random.permutation(n))
+    return {'train': labeled[perm[:train_num]], 'valid': labeled[perm[train_num:train_num + valid_num]],
+            'test': labeled[perm[train_num + valid_num:]]}
+
+
+# --------------------------------------------------------------------------------------------------
+# model / evaluation (reference train.py:28-42, 106-210)
+# --------------------------------------------------------------------------------------------------
+
+def parse_method(args, data):
+    if args.method == 'AllSetTransformer':
+        if args.LearnMask:
+            return SetGNN(args, data.norm)
+        return SetGNN(args)
+    if args.method == 'AllDeepSets':
+        args.PMA = False
+        args.aggregate = 'add'
+        if args.LearnMask:
+            return SetGNN(args, data.norm)
+        return SetGNN(args)
+    raise ValueError(f"method {args.method!r}: only {ALLSET_METHODS} are built (the reference's baselines are out of scope)")
+
+
+class Logger:
+    def __init__(self, runs, info=None):
+        self.info = info
+        self.results = [[] for _ in range(runs)]
+
+    def add_result(self, run, result):
+        assert len(result) == 3 and 0 <= run < len(self.results)
+        self.results[run].append(result)
+
+    def print_statistics(self, run=None):
+        if run is not None:
+            r = 100 * torch.tensor(self.results[run])
+            best = r[:, 1].argmax().item()
+            print(f'Run {run + 1:02d}:')
+            print(f'Highest Train: {r[:, 0].max():.2f}')
+            print(f'Highest Valid: {r[:, 1].max():.2f}')
+            print(f'  Final Train: {r[best, 0]:.2f}')
+            print(f'   Final Test: {r[best, 2]:.2f}')
+            return None
+        rows = []
+        for r in 100 * torch.tensor(self.results):
+            best = r[:, 1].argmax()
+            rows.append((r[:, 0].max().item(), r[:, 1].max().item(), r[best, 0].item(), r[best, 2].item()))
+        t = torch.tensor(rows)
+        print('All runs:')
+        for title, col in (('Highest Train', 0), ('Highest Valid', 1), ('  Final Train', 2), ('   Final Test', 3)):
+            print(f'{title}: {t[:, col].mean():.2f} ± {t[:, col].std():.2f}')
+        return t[:, 1], t[:, 3]
+
+
+def eval_acc(y_true, y_pred):
+    y_true = y_true.detach().cpu().numpy()
+    y_hat = y_pred.argmax(dim=-1).detach().cpu().numpy()
+    labeled = y_true == y_true
+    return float(np.sum(y_true[labeled] == y_hat[labeled])) / max(int(labeled.sum()), 1)
+
+
+@torch.no_grad()
+def evaluate(model, data, split_idx, eval_func, result=None):
+    if result is not None:
+        out = result
+    else:
+        model.eval()
+        out = F.log_softmax(model(data), dim=1)
+    accs = [eval_func(data.y[split_idx[k]], out[split_idx[k]]) for k in ('train', 'valid', 'test')]
+    losses = [F.nll_loss(out[split_idx[k]], data.y[split_idx[k]]) for k in ('train', 'valid', 'test')]
+    return (*accs, *losses, out)
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+# --------------------------------------------------------------------------------------------------
+# command line (reference train.py:221-289, flags of the AllSet methods; baseline-only flags are accepted and ignored)
+# --------------------------------------------------------------------------------------------------
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument('--train_prop', type=float, default=0.5)
+    p.add_argument('--valid_prop', type=float, default=0.25)
+    p.add_argument('--dname', default='synthetic')
+    p.add_argument('--method', default='AllSetTransformer')
+    p.add_argument('--epochs', default=500, type=int)
+    p.add_argument('--runs', default=20, type=int)
+    p.add_argument('--cuda', default=0, choices=[-1, 0, 1], type=int)
+    p.add_argument('--dropout', default=0.5, type=float)
+    p.add_argument('--lr', default=0.001, type=float)
+    p.add_argument('--wd', default=0.0, type=float)
+    p.add_argument('--All_num_layers', default=2, type=int)
+    p.add_argument('--MLP_num_layers', default=2, type=int)
+    p.add_argument('--MLP_hidden', default=64, type=int)
+    p.add_argument('--Classifier_num_layers', default=2, type=int)
+    p.add_argument('--Classifier_hidden', default=64, type=int)
+    p.add_argument('--display_step', type=int, default=-1)
+    p.add_argument('--aggregate', default='mean', choices=['sum', 'mean'])
+    p.add_argument('--normtype', default='all_one')
+    p.add_argument('--add_self_loop', action='store_false')
+    p.add_argument('--normalization', default='ln')
+    p.add_argument('--deepset_input_norm', default=True)
+    p.add_argument('--GPR', action='store_false')
+    p.add_argument('--LearnMask', action='store_false')
+    p.add_argument('--num_features', default=0, type=int)
+    p.add_argument('--num_classes', default=0, type=int)
+    p.add_argument('--feature_noise', default='1', type=str)
+    p.add_argument('--exclude_self', action='store_true')
+    p.add_argument('--PMA', action='store_true')
+    p.add_argument('--heads', default=1, type=int)
+    p.add_argument('--output_heads', default=1, type=int)
+    for flag in ('--HyperGCN_mediators', '--HyperGCN_fast', '--HCHA_symdegnorm', '--UniGNN_use-norm'):
+        p.add_argument(flag, action='store_true')
+    p.add_argument('--HNHN_alpha', default=-1.5, type=float)
+    p.add_argument('--HNHN_beta', default=-0.5, type=float)
+    p.add_argument('--HNHN_nonlinear_inbetween', default=True, type=bool)
+    p.add_argument('--UniGNN_degV', default=0)
+    p.add_argument('--UniGNN_degE', default=0)
+    # additions of this driver (absent from the reference)
+    p.add_argument('--raw_data_dir', default=None, help='directory holding <dname>/{features,labels,hypergraph}.pickle')
+    p.add_argument('--seed', default=None, type=int, help='seed numpy/torch (the reference fixes no seeds, README.md:60)')
+    p.add_argument('--res_root', default='hyperparameter_tunning')
+    p.set_defaults(PMA=True, add_self_loop=True, exclude_self=False, GPR=False, LearnMask=False)
+    return p
+
+
+def load_data(args) -> HypergraphData:
+    if args.raw_data_dir is not None:
+        data = load_hypergcn_dataset(args.raw_data_dir, args.dname)
+    elif args.dname == 'synthetic':
+        data = synthetic_dataset(feature_noise=float(args.feature_noise), seed=0 if args.seed is None else args.seed)
+    else:
+        raise FileNotFoundError(f"dataset {args.dname!r}: pass --raw_data_dir (the reference's raw-data archive is not "
+                                "distributed with its repository) or use --dname synthetic")
+    args.num_features = data.x.shape[1]
+    args.num_classes = len(data.y.unique())
+    return data
+
+
+def preprocess(args, data: HypergraphData) -> HypergraphData:
+    """The AllSet branch of reference train.py:344-353."""
+    data = ExtractV2E(data)
+    if args.add_self_loop:
+        data = Add_Self_Loops(data)
+    if args.exclude_self:
+        data = expand_edge_index(data)
+    return norm_contruction(data, option=args.normtype)
+
+
+def run(args) -> dict:
+    if args.method not in ALLSET_METHODS:
+        raise ValueError(f"method {args.method!r}: only {ALLSET_METHODS} are built")
+    if args.seed is not None:
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+    data = preprocess(args, load_data(args))
+    splits = [rand_train_test_idx(data.y, args.train_prop, args.valid_prop) for _ in range(args.runs)]
+    model = parse_method(args, data)
+    if args.cuda not in (0, 1) or not torch.cuda.is_available():
+        raise RuntimeError("allset_amd has no CPU path for the aggregation kernels: run with --cuda 0 on an MI355X")
+    device = torch.device(f'cuda:{args.cuda}')
+    model, data = model.to(device), data.to(device)
+    num_params = count_parameters(model)
+    logger = Logger(args.runs, args)
+    criterion = nn.NLLLoss()
+    runtimes = []
+    for r in range(args.runs):
+        t0 = time.time()
+        split_idx = {k: v.to(device) for k, v in splits[r].items()}
+        model.reset_parameters()
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+        for epoch in range(args.epochs):
+            model.train()
+            optimizer.zero_grad()
+            out = F.log_softmax(model(data), dim=1)
+            loss = criterion(out[split_idx['train']], data.y[split_idx['train']])
+            loss.backward()
+            optimizer.step()
+            result = evaluate(model, data, split_idx, eval_acc)
+            logger.add_result(r, result[:3])
+            if args.display_step > 0 and epoch % args.display_step == 0:
+                print(f'Epoch: {epoch:02d}, Train Loss: {loss:.4f}, Valid Loss: {result[4]:.4f}, Test  Loss: {result[5]:.4f}, '
+                      f'Train Acc: {100 * result[0]:.2f}%, Valid Acc: {100 * result[1]:.2f}%, Test  Acc: {100 * result[2]:.2f}%')
+        runtimes.append(time.time() - t0)
+    avg_time, std_time = float(np.mean(runtimes)), float(np.std(runtimes))
+    best_val, best_test = logger.print_statistics()
+    os.makedirs(args.res_root, exist_ok=True)
+    filename = f'{args.res_root}/{args.dname}_noise_{args.feature_noise}.csv'
+    print(f"Saving results to {filename}")
+    with open(filename, 'a+') as f:                                   # line format of reference train.py:512-518
+        f.write(f'{args.method}_{args.lr}_{args.wd}_{args.heads}'
+                f',{best_val.mean():.3f} ± {best_val.std():.3f}'
+                f',{best_test.mean():.3f} ± {best_test.std():.3f}'
+                f',{num_params}, {avg_time:.2f}s, {std_time:.2f}s'
+                f',{avg_time // 60}min{(avg_time % 60):.2f}s\n')
+    with open(f'{args.res_root}/all_args_{args.dname}_noise_{args.feature_noise}.csv', 'a+') as f:
+        f.write(str(args) + '\n')
+    return dict(best_val=best_val, best_test=best_test, num_params=num_params, avg_time=avg_time, csv=filename)
+
+
+def main(argv=None):
+    run(build_parser().parse_args(argv))
+    print('All done! Exit python code')
+
+
+if __name__ == '__main__':
+    main()
