@@ -153,6 +153,29 @@ __device__ __forceinline__ void store_vec_i32(int32_t* __restrict__ p, const int
 
 __device__ __forceinline__ float leaky_relu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
+// ---- dropout mask shared by every dense-tail kernel (forward kernels apply it, backward kernels regenerate it).
+// Counter-based: one 32-bit hash per PAIR of consecutive elements, 16 bits per element; keep iff u16 >= p * 65536.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, int64_t pair) {
+  uint32_t h = mix32(static_cast<uint32_t>(pair) ^ static_cast<uint32_t>(seed));
+  return mix32(h + static_cast<uint32_t>(static_cast<uint64_t>(pair) >> 32) * 0x9E3779B9U + static_cast<uint32_t>(seed >> 32));
+}
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return static_cast<uint32_t>(p * 65536.0f); }
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, uint32_t thr, float inv_keep) {
+  const uint32_t h = pair_hash(seed, idx >> 1);
+  const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return u >= thr ? inv_keep : 0.f;
+}
+// two consecutive elements starting at an EVEN index: one hash
+__device__ __forceinline__ void keep_scale2(uint64_t seed, int64_t idx_even, uint32_t thr, float inv_keep, float& s0, float& s1) {
+  const uint32_t h = pair_hash(seed, idx_even >> 1);
+  s0 = (h & 0xffffu) >= thr ? inv_keep : 0.f;
+  s1 = (h >> 16) >= thr ? inv_keep : 0.f;
+}
+
 #endif  // __HIPCC__
 
 }  // namespace allset

@@ -17,18 +17,6 @@
 
 namespace allset {
 
-// ---- dropout mask: keep iff u(seed, idx) >= p, u uniform on [0,1) with 24 bits -----------------
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-
-__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p, float inv_keep) {
-  uint32_t h = mix32(static_cast<uint32_t>(idx) ^ static_cast<uint32_t>(seed));
-  h = mix32(h + static_cast<uint32_t>(static_cast<uint64_t>(idx) >> 32) * 0x9E3779B9U + static_cast<uint32_t>(seed >> 32));
-  return (static_cast<float>(h >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
-}
-
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of W lanes (W power of two)
 #pragma unroll
@@ -53,6 +41,7 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(
   constexpr int kGroups = kWavesPerBlock * NS;
   const float inv_d = 1.f / static_cast<float>(d);
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   float4 g4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0);
   if (active) {
     g4 = *reinterpret_cast<const float4*>(gamma + c0);
@@ -82,8 +71,9 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(
                                c.w * rstd * g4.w + b4.w);
         if (p > 0.f) {
           const int64_t e = row * d + c0;
-          o.x *= keep_scale(seed, e, p, inv_keep);     o.y *= keep_scale(seed, e + 1, p, inv_keep);
-          o.z *= keep_scale(seed, e + 2, p, inv_keep); o.w *= keep_scale(seed, e + 3, p, inv_keep);
+          float k0, k1, k2, k3;
+          keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+          o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
         }
         *reinterpret_cast<float4*>(y + row * ldy + c0) = o;
       }
@@ -102,6 +92,7 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_generic_kernel(
   const int lane = lane_id();
   const float* xr = x + row * ldx;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   float s = 0.f;
   for (int c = lane; c < d; c += kWave) s += relu_in ? fmaxf(xr[c], 0.f) : xr[c];
   const float mean = group_sum<kWave>(s) / static_cast<float>(d);
@@ -113,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_generic_kernel(
   const float rstd = rsqrtf(group_sum<kWave>(q) / static_cast<float>(d) + eps);
   for (int c = lane; c < d; c += kWave) {
     float o = ((relu_in ? fmaxf(xr[c], 0.f) : xr[c]) - mean) * rstd * gamma[c] + beta[c];
-    if (p > 0.f) o *= keep_scale(seed, row * d + c, p, inv_keep);
+    if (p > 0.f) o *= keep_scale(seed, row * d + c, thr, inv_keep);
     y[row * ldy + c] = o;
   }
   if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
@@ -137,6 +128,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(
   const bool active = c0 < d;
   const float inv_d = 1.f / static_cast<float>(d);
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   float4 g4 = make_float4(0, 0, 0, 0);
   if (active) g4 = *reinterpret_cast<const float4*>(gamma + c0);
   float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0);
@@ -159,8 +151,9 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(
     if (!(live && active)) xh = make_float4(0, 0, 0, 0);
     if (p > 0.f && live && active) {
       const int64_t e = row * d + c0;
-      gv.x *= keep_scale(seed, e, p, inv_keep);     gv.y *= keep_scale(seed, e + 1, p, inv_keep);
-      gv.z *= keep_scale(seed, e + 2, p, inv_keep); gv.w *= keep_scale(seed, e + 3, p, inv_keep);
+      float k0, k1, k2, k3;
+      keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+      gv.x *= k0; gv.y *= k1; gv.z *= k2; gv.w *= k3;
     }
     dg.x += gv.x * xh.x; dg.y += gv.y * xh.y; dg.z += gv.z * xh.z; dg.w += gv.w * xh.w;
     db.x += gv.x; db.y += gv.y; db.z += gv.z; db.w += gv.w;
@@ -197,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
     float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d) {
   const int lane = lane_id();
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   // column c is always handled by lane c % 64 of some wave; accumulate per (wave, column-slot) over rows
   for (int cb = 0; cb < d; cb += kWave * 8) {       // up to 8 column slots per lane per sweep
@@ -212,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
         for (int c = lane; c < d; c += kWave) {
           const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
           const float xh = (t - mean) * rstd;
-          const float gh = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, p, inv_keep) : 1.f) * gamma[c];
+          const float gh = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, thr, inv_keep) : 1.f) * gamma[c];
           s1 += gh; s2 += gh * xh;
         }
         s1 = group_sum<kWave>(s1) / static_cast<float>(d);
@@ -220,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
         for (int c = lane; c < d; c += kWave) {
           const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
           const float xh = (t - mean) * rstd;
-          const float gh = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, p, inv_keep) : 1.f) * gamma[c];
+          const float gh = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, thr, inv_keep) : 1.f) * gamma[c];
           float o = rstd * (gh - s1 - xh * s2);
           if (relu_in && !(xr[c] > 0.f)) o = 0.f;
           gx[row * ldgx + c] = o;
@@ -231,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
         const int c = cb + k * kWave + lane;
         if (c < d) {
           const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
-          const float g = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, p, inv_keep) : 1.f);
+          const float g = gr[c] * (p > 0.f ? keep_scale(seed, row * d + c, thr, inv_keep) : 1.f);
           dg[k] += g * (t - mean) * rstd;
           db[k] += g;
         }
@@ -249,14 +243,16 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
 __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(const float* __restrict__ x, float p, uint64_t seed,
                                                                   float* __restrict__ y, int64_t n4) {
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
     float4 v = reinterpret_cast<const float4*>(x)[i];
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     if (p > 0.f) {
       const int64_t e = i * 4;
-      v.x *= keep_scale(seed, e, p, inv_keep);     v.y *= keep_scale(seed, e + 1, p, inv_keep);
-      v.z *= keep_scale(seed, e + 2, p, inv_keep); v.w *= keep_scale(seed, e + 3, p, inv_keep);
+      float k0, k1, k2, k3;
+      keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+      v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
     }
     reinterpret_cast<float4*>(y)[i] = v;
   }
@@ -265,6 +261,7 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(const float* _
 __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                   float p, float* __restrict__ gx, int64_t n4) {
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
     const float4 g = reinterpret_cast<const float4*>(gy)[i];
@@ -280,10 +277,11 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* _
 __global__ void relu_dropout_fwd_scalar_kernel(const float* __restrict__ x, float p, uint64_t seed, float* __restrict__ y,
                                                int64_t n, int64_t offset) {
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   const int64_t i = offset + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) {
     float v = fmaxf(x[i], 0.f);
-    if (p > 0.f) v *= keep_scale(seed, i, p, inv_keep);
+    if (p > 0.f) v *= keep_scale(seed, i, thr, inv_keep);
     y[i] = v;
   }
 }
@@ -291,6 +289,7 @@ __global__ void relu_dropout_fwd_scalar_kernel(const float* __restrict__ x, floa
 __global__ void relu_dropout_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict__ y, float p,
                                                float* __restrict__ gx, int64_t n, int64_t offset) {
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
   const int64_t i = offset + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) gx[i] = y[i] > 0.f ? gy[i] * inv_keep : 0.f;
 }

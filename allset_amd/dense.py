@@ -85,6 +85,32 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
     return gw, gb
 
 
+def fused_linear_supported(K: int, N: int) -> bool:
+    return bool(_lib.load().allset_fused_linear_supported(K, N))
+
+
+def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor] = None,
+                     beta: Optional[Tensor] = None, eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0,
+                     seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0, seed_out: int = 0
+                     ) -> Tuple[Tensor, Optional[Tensor]]:
+    """y = epi(pro(x) @ W^T + b) in one pass (csrc/fused_mlp.hip).  Returns (y, stats or None)."""
+    dev = require_device(x, weight, bias, gamma, beta)
+    _check_f32(x, weight, bias, gamma, beta)
+    x = _rowmajor(x)
+    n, K = x.shape
+    N = weight.shape[0]
+    weight = weight.contiguous()
+    y = torch.empty((n, N), dtype=x.dtype, device=dev)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev) if gamma is not None else None
+    with torch.cuda.device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
+        check(_lib.load().allset_fused_linear_fwd(
+            ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
+            ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
+            ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
+            ptr(stats), n, K, N, stream_of(dev)), "allset_fused_linear_fwd")
+    return y, stats
+
+
 def wgrad_supported(ga: Tensor, u: Tensor) -> bool:
     return (ga.is_cuda and ga.dtype == torch.float32 and u.dtype == torch.float32 and ga.shape[1] % 4 == 0
             and u.shape[1] % 4 == 0)

@@ -182,6 +182,17 @@ int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
+/* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
+ *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],
+ *                                 epi = [relu_out] -> [dropout p_out].
+ * One read + one write of the activation matrix; exact-fp32 MFMA.  stats (f32[n*2] = {mean, rstd}) is written
+ * when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0. */
+int allset_fused_linear_supported(int64_t K, int64_t N);
+int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                            int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
+                            int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats,
+                            int64_t n, int64_t K, int64_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,47 @@ def test_mlp_train_mode_statistics(device):
     assert err < 0.15, err
     m(x).sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters()) and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (64, 64), (128, 64), (64, 128)])
+@pytest.mark.parametrize("n", [1, 33, 1000, 70001])
+def test_fused_linear_fwd(K, N, n, device):
+    """y = epi(pro(x) W^T + b) with every prologue/epilogue combination, against torch ops in fp64."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(K + N + n)
+    x = torch.randn(n, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    xd, Wd, bd, gd, btd = (t.to(device) for t in (x, W, b, gamma, beta))
+    for has_ln in (False, True):
+        for relu_in in (False, True):
+            for relu_out in (False, True):
+                h = x.double()
+                if relu_in:
+                    h = F.relu(h)
+                if has_ln:
+                    h = F.layer_norm(h, (K,), gamma.double(), beta.double(), 1e-5)
+                ref = F.linear(h, W.double(), b.double())
+                if relu_out:
+                    ref = F.relu(ref)
+                y, st = dense.fused_linear_fwd(xd, Wd, bd, gd if has_ln else None, btd if has_ln else None, 1e-5,
+                                               relu_in, 0.0, 0, relu_out, 0.0, 0)
+                torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+                if has_ln:
+                    hh = F.relu(x.double()) if relu_in else x.double()
+                    torch.testing.assert_close(st[:, 0].cpu().double(), hh.mean(1), rtol=1e-4, atol=1e-5)
+                    torch.testing.assert_close(st[:, 1].cpu().double(), (hh.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+    # dropout masks: the prologue mask equals ln_fwd's mask for the same seed; the epilogue mask equals relu_dropout's
+    p = 0.3
+    u, _ = dense.ln_fwd(xd, gd, btd, 1e-5, True, p, 4242)
+    ref = F.linear(u, Wd, bd)
+    y, _ = dense.fused_linear_fwd(xd, Wd, bd, gd, btd, 1e-5, True, p, 4242, False, 0.0, 0)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    y0, _ = dense.fused_linear_fwd(xd, Wd, bd, None, None, 1e-5, False, 0.0, 0, True, 0.0, 0)
+    y1, _ = dense.fused_linear_fwd(xd, Wd, bd, None, None, 1e-5, False, 0.0, 0, True, p, 99)
+    kept = y1 != 0
+    torch.testing.assert_close(y1[kept], (y0 / (1 - p))[kept], rtol=1e-5, atol=1e-6)
+    if n >= 1000:
+        pos = y0 > 0
+        assert abs(float(kept[pos].float().mean()) - (1 - p)) < 0.03
