@@ -160,8 +160,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 __device__ __forceinline__ uint32_t pair_hash(uint64_t seed, int64_t pair) {
-  uint32_t h = mix32(static_cast<uint32_t>(pair) ^ static_cast<uint32_t>(seed));
-  return mix32(h + static_cast<uint32_t>(static_cast<uint64_t>(pair) >> 32) * 0x9E3779B9U + static_cast<uint32_t>(seed >> 32));
+  // one avalanche round over a Weyl-scrambled counter keyed by the 64-bit seed
+  const uint32_t lo = static_cast<uint32_t>(pair), hi = static_cast<uint32_t>(static_cast<uint64_t>(pair) >> 32);
+  return mix32((lo ^ static_cast<uint32_t>(seed)) * 0x9E3779B1U + hi * 0x85EBCA77U + static_cast<uint32_t>(seed >> 32));
 }
 __device__ __forceinline__ uint32_t drop_threshold(float p) { return static_cast<uint32_t>(p * 65536.0f); }
 __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, uint32_t thr, float inv_keep) {

@@ -303,10 +303,20 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kWgTile = 128;
 constexpr int kWgRows = 32;
 
+// Optional operand prologues (PRO = true): the two operands are recomputed on the fly from what the fused forward
+// (csrc/fused_mlp.hip) keeps, instead of being read from materialised tensors:
+//   A side: ga = gy * (y > 0 ? keep_out : 0)                       if y != nullptr   (relu/dropout epilogue)
+//   B side: u  = dropout_in( LN_{stats,gamma,beta}( relu_in(x) ) )   from x and the saved row statistics
+struct WgradPro {
+  const float* y; int64_t ldy; float keep_out;
+  const float* stats; const float* gamma; const float* beta; int has_ln; int relu_in; float p_in; uint64_t seed_in;
+};
+
+template <bool PRO>
 __global__ __launch_bounds__(kBlock) void wgrad_kernel(
     const float* __restrict__ ga, int64_t lda, const float* __restrict__ u, int64_t ldu,
     float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i,
-    int64_t rows_per_slice) {
+    int64_t rows_per_slice, WgradPro pro) {
   __shared__ float sA[2][kWgRows][kWgTile];
   __shared__ float sB[2][kWgRows][kWgTile];
   const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
@@ -327,21 +337,63 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
     for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
 
   float4 ra[4], rb[4];
-  auto load_stage = [&](int64_t r0) {
+  float4 g4 = make_float4(1, 1, 1, 1), be4 = make_float4(0, 0, 0, 0);
+  float keep_in = 1.f;
+  uint32_t thr_in = 0;
+  if constexpr (PRO) {
+    if (pro.has_ln && b_ok) {
+      g4 = *reinterpret_cast<const float4*>(pro.gamma + i_base + s_col);
+      be4 = *reinterpret_cast<const float4*>(pro.beta + i_base + s_col);
+    }
+    keep_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
+    thr_in = drop_threshold(pro.p_in);
+  }
+  float4 ry[4];
+  float2 rst[4];
+  int64_t rrow[4];
+  auto load_stage = [&](int64_t r0) {        // issue only: the loads stay in flight under the MFMAs of the current stage
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t r = r0 + s_row + 8 * k;
+      rrow[k] = r;
       ra[k] = make_float4(0, 0, 0, 0);
       rb[k] = make_float4(0, 0, 0, 0);
+      if constexpr (PRO) { ry[k] = make_float4(1, 1, 1, 1); rst[k] = make_float2(0.f, 1.f); }
       if (r < r_end) {
         if (a_ok) ra[k] = *reinterpret_cast<const float4*>(ga + r * lda + o_base + s_col);
         if (b_ok) rb[k] = *reinterpret_cast<const float4*>(u + r * ldu + i_base + s_col);
+        if constexpr (PRO) {
+          if (pro.y != nullptr && a_ok) ry[k] = *reinterpret_cast<const float4*>(pro.y + r * pro.ldy + o_base + s_col);
+          if (pro.has_ln) rst[k] = *reinterpret_cast<const float2*>(pro.stats + r * 2);
+        }
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf) {          // operand prologues (PRO) happen here, after the wait on the loads
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      if constexpr (PRO) {
+        const bool in_range = rrow[k] < r_end;
+        if (pro.y != nullptr) {
+          ra[k].x = ry[k].x > 0.f ? ra[k].x * pro.keep_out : 0.f; ra[k].y = ry[k].y > 0.f ? ra[k].y * pro.keep_out : 0.f;
+          ra[k].z = ry[k].z > 0.f ? ra[k].z * pro.keep_out : 0.f; ra[k].w = ry[k].w > 0.f ? ra[k].w * pro.keep_out : 0.f;
+        }
+        float4 t = rb[k];
+        if (pro.relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+        if (pro.has_ln) {
+          const float2 st = rst[k];
+          t.x = fmaf((t.x - st.x) * st.y, g4.x, be4.x); t.y = fmaf((t.y - st.x) * st.y, g4.y, be4.y);
+          t.z = fmaf((t.z - st.x) * st.y, g4.z, be4.z); t.w = fmaf((t.w - st.x) * st.y, g4.w, be4.w);
+        }
+        if (pro.p_in > 0.f) {
+          float k0, k1, k2, k3;
+          const int64_t e = rrow[k] * I + i_base + s_col;
+          keep_scale2(pro.seed_in, e, thr_in, keep_in, k0, k1); keep_scale2(pro.seed_in, e + 2, thr_in, keep_in, k2, k3);
+          t.x *= k0; t.y *= k1; t.z *= k2; t.w *= k3;
+        }
+        if (!(in_range && b_ok)) t = make_float4(0, 0, 0, 0);
+        rb[k] = t;
+      }
       *reinterpret_cast<float4*>(&sA[buf][s_row + 8 * k][s_col]) = ra[k];
       *reinterpret_cast<float4*>(&sB[buf][s_row + 8 * k][s_col]) = rb[k];
       bsum.x += ra[k].x; bsum.y += ra[k].y; bsum.z += ra[k].z; bsum.w += ra[k].w;
@@ -537,8 +589,9 @@ extern "C" int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_s
   clear_error();
   ALLSET_REQUIRE(n_slices != nullptr && n >= 0 && O >= 1 && I >= 1, "wgrad_slices: bad argument");
   const int64_t tiles = ((O + kWgTile - 1) / kWgTile) * ((I + kWgTile - 1) / kWgTile);
-  // aim at ~1024 workgroups in total, at least 256 rows (8 stages) per slice
-  int64_t s = 1024 / tiles;
+  // aim at ~512 workgroups in total (two 64-KiB-LDS workgroups per CU), at least 256 rows (8 stages) per slice;
+  // fewer slices also means fewer partial tiles for the caller to sum
+  int64_t s = 512 / tiles;
   const int64_t max_by_rows = (n + 255) / 256;
   if (s > max_by_rows) s = max_by_rows;
   if (s < 1) s = 1;
@@ -564,7 +617,42 @@ extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_
   rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
   if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
-  wgrad_kernel<<<grid, kBlock, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I), tiles_i, rows_per_slice);
+  wgrad_kernel<false><<<grid, kBlock, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
+                                               tiles_i, rows_per_slice, WgradPro{});
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
+                                  const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                                  int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
+                                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_fused: bad size");
+  ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_fused: bad slice count");
+  ALLSET_REQUIRE(part_w != nullptr, "wgrad_fused: null partial buffer");
+  ALLSET_REQUIRE(n == 0 || (gy && x), "wgrad_fused: null input");
+  ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "wgrad_fused: dropout p must be in [0,1)");
+  ALLSET_REQUIRE((stats == nullptr) == (gamma == nullptr) && (gamma == nullptr) == (beta == nullptr),
+                 "wgrad_fused: stats, gamma and beta must come together");
+  if (O % 4 != 0 || I % 4 != 0 || ldg % 4 != 0 || ldx % 4 != 0 || !aligned16(gy) || !aligned16(x) ||
+      (y != nullptr && (ldy % 4 != 0 || !aligned16(y))) || (gamma != nullptr && (!aligned16(gamma) || !aligned16(beta)))) {
+    set_error("wgrad_fused: needs feature widths / leading dimensions that are multiples of 4 and 16-byte aligned inputs");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(ldg >= O && ldx >= I && (y == nullptr || ldy >= O), "wgrad_fused: leading dimension too small");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int tiles_o = static_cast<int>((O + kWgTile - 1) / kWgTile), tiles_i = static_cast<int>((I + kWgTile - 1) / kWgTile);
+  int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
+  rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
+  if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
+  WgradPro pro;
+  pro.y = y; pro.ldy = ldy; pro.keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  pro.stats = stats; pro.gamma = gamma; pro.beta = beta; pro.has_ln = stats != nullptr;
+  pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in;
+  const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
+  wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
+                                              tiles_i, rows_per_slice, pro);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

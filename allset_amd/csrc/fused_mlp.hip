@@ -171,6 +171,169 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_fwd_kernel(
   }
 }
 
+
+// ---- backward w.r.t. the input of the fused Linear --------------------------------------------------------------
+//   ga = gy * (y > 0 ? keep_out : 0)   (if y != nullptr: relu/dropout epilogue of the forward)      [A operand, registers]
+//   gu = ga @ W                         (K = O out-features, N = I in-features; B operand = W rows, unit stride in LDS)
+//   gz = gu * dropout_in mask           (regenerated from seed_in)
+//   HAS_LN : gx = LayerNorm-backward(gz; x, stats, gamma) (through relu_in), dgamma/dbeta partials per wave
+//   else   : gx = gz (through relu_in)
+// One wave owns 32 complete rows, so the two row reductions of the LayerNorm backward (sum gh, sum gh*xhat) are
+// in-wave: 4 accumulator tiles per lane + a 32-lane xor butterfly.
+template <int OD, int IT, bool HAS_LN, bool DROP_IN>
+__global__ __launch_bounds__(kFusedBlock) void fused_linear_bwd_kernel(
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
+    const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
+    const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* __restrict__ gx,
+    int64_t ldgx, float* __restrict__ part, int64_t n) {
+  constexpr int I = 32 * IT;
+  constexpr int OH = OD / 2;
+  __shared__ __attribute__((aligned(16))) float sW[OD * I];          // W as stored: [o][i], unit stride in i
+  __shared__ float sG[I];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < OD * I / 4; idx += kFusedBlock)
+    reinterpret_cast<float4*>(sW)[idx] = reinterpret_cast<const float4*>(W)[idx];
+  for (int idx = tid; idx < I; idx += kFusedBlock) sG[idx] = HAS_LN ? gamma[idx] : 1.f;
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int rin = lane & 31, half = lane >> 5;
+  const float inv_i = 1.f / static_cast<float>(I);
+  const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
+  const uint32_t thr_in = drop_threshold(p_in);
+  const int64_t n_chunks = (n + 31) / 32;
+  if (wave >> 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  float dg[IT], db[IT];
+#pragma unroll
+  for (int t = 0; t < IT; ++t) { dg[t] = 0.f; db[t] = 0.f; }
+
+  for (int64_t chunk = static_cast<int64_t>(blockIdx.x) * kFusedWaves + wave; chunk < n_chunks;
+       chunk += static_cast<int64_t>(gridDim.x) * kFusedWaves) {
+    const int64_t row = chunk * 32 + rin;
+    const bool valid = row < n;
+    float a[OH];
+#pragma unroll
+    for (int jb = 0; jb < OH; jb += 16) {            // blocks of 16 columns: bounded landing registers
+      if (valid) {
+        const float4* gr = reinterpret_cast<const float4*>(gy + row * ldg + half * OH + jb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = gr[q];
+          a[jb + 4 * q] = v.x; a[jb + 4 * q + 1] = v.y; a[jb + 4 * q + 2] = v.z; a[jb + 4 * q + 3] = v.w;
+        }
+        if (y != nullptr) {
+          const float4* yr = reinterpret_cast<const float4*>(y + row * ldy + half * OH + jb);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = yr[q];
+            a[jb + 4 * q] = v.x > 0.f ? a[jb + 4 * q] * keep_out : 0.f;
+            a[jb + 4 * q + 1] = v.y > 0.f ? a[jb + 4 * q + 1] * keep_out : 0.f;
+            a[jb + 4 * q + 2] = v.z > 0.f ? a[jb + 4 * q + 2] * keep_out : 0.f;
+            a[jb + 4 * q + 3] = v.w > 0.f ? a[jb + 4 * q + 3] * keep_out : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = jb; j < jb + 16; ++j) a[j] = 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x16 acc[IT];
+#pragma unroll
+    for (int t = 0; t < IT; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    const float* wb = sW + (half * OH) * I + rin;
+#pragma unroll
+    for (int j = 0; j < OH; ++j) {
+#pragma unroll
+      for (int t = 0; t < IT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wb[j * I + t * 32], acc[t], 0, 0, 0);
+    }
+    // ---- epilogue: acc[t][k] is row (k&3) + 8*(k>>2) + 4*half, column t*32 + rin.
+    // All x values / row statistics of the chunk are requested in ONE batch (the A-operand registers are dead by
+    // now), so the epilogue pays one memory latency instead of one per row.
+    float xraw[16 * IT];
+    float2 st[16];
+    if (HAS_LN || relu_in) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int64_t r = chunk * 32 + (k & 3) + 8 * (k >> 2) + 4 * half;
+        const bool live = r < n;
+        if constexpr (HAS_LN) st[k] = live ? *reinterpret_cast<const float2*>(stats + r * 2) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < IT; ++t) xraw[k * IT + t] = live ? x[r * ldx + t * 32 + rin] : 1.f;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16 * IT; ++k) xraw[k] = 1.f;
+    }
+    float gam[IT];
+#pragma unroll
+    for (int t = 0; t < IT; ++t) gam[t] = sG[t * 32 + rin];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int rl = (k & 3) + 8 * (k >> 2) + 4 * half;
+      const int64_t r = chunk * 32 + rl;
+      const bool live = r < n;
+      float gz[IT], xh[IT];
+      float rstd = 0.f;
+#pragma unroll
+      for (int t = 0; t < IT; ++t) {
+        gz[t] = live ? acc[t][k] : 0.f;
+        if constexpr (DROP_IN) gz[t] *= keep_scale(seed_in, r * I + t * 32 + rin, thr_in, keep_in);
+        xh[t] = 0.f;
+        if constexpr (HAS_LN) {
+          rstd = st[k].y;
+          const float xr = relu_in ? fmaxf(xraw[k * IT + t], 0.f) : xraw[k * IT + t];
+          xh[t] = live ? (xr - st[k].x) * rstd : 0.f;
+          dg[t] = fmaf(gz[t], xh[t], dg[t]);
+          db[t] += gz[t];
+        }
+      }
+      if constexpr (HAS_LN) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+          const float gh = gz[t] * gam[t];
+          s1 += gh;
+          s2 = fmaf(gh, xh[t], s2);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        s1 *= inv_i; s2 *= inv_i;
+        if (live) {
+#pragma unroll
+          for (int t = 0; t < IT; ++t) {
+            float o = rstd * (gz[t] * gam[t] - s1 - xh[t] * s2);
+            if (relu_in && !(xraw[k * IT + t] > 0.f)) o = 0.f;
+            gx[r * ldgx + t * 32 + rin] = o;
+          }
+        }
+      } else {
+        if (live) {
+#pragma unroll
+          for (int t = 0; t < IT; ++t) {
+            float o = gz[t];
+            if (relu_in && !(xraw[k * IT + t] > 0.f)) o = 0.f;
+            gx[r * ldgx + t * 32 + rin] = o;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (HAS_LN) {     // per-wave partials of dgamma / dbeta: part[wave_global][0|1][I]
+    float* pw = part + (static_cast<int64_t>(blockIdx.x) * kFusedWaves + wave) * 2 * I;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      const float g = dg[t] + __shfl_xor(dg[t], 32);
+      const float b = db[t] + __shfl_xor(db[t], 32);
+      if (half == 0) { pw[t * 32 + rin] = g; pw[I + t * 32 + rin] = b; }
+    }
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -199,7 +362,7 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
   const int has_ln = gamma != nullptr;
   const int64_t chunks = (n + 31) / 32;
   int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
-  if (blocks > 512) blocks = 512;                         // persistent: up to two 8-wave workgroups per CU
+  if (blocks > 512) blocks = 512;                         // persistent workgroups
   const unsigned grid = static_cast<unsigned>(blocks);
 #define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                        \
   fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in,     \
@@ -225,6 +388,66 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
   else ALLSET_FUSED_FWD(64, 2);
 #undef ALLSET_FUSED_FWD_F
 #undef ALLSET_FUSED_FWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+static inline unsigned fused_grid(int64_t n) {
+  const int64_t chunks = (n + 31) / 32;
+  int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+extern "C" int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials) {
+  clear_error();
+  ALLSET_REQUIRE(n_partials != nullptr && n >= 0, "fused_linear_bwd_partials: bad argument");
+  *n_partials = static_cast<int64_t>(fused_grid(n)) * kFusedWaves;
+  return ALLSET_OK;
+}
+
+extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
+                                       const float* W, const float* x, int64_t ldx, const float* stats,
+                                       const float* gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
+                                       int64_t ldgx, float* partials, int64_t n_partials, int64_t n, int64_t O,
+                                       int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "fused_linear_bwd: negative size");
+  ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_bwd: dropout p must be in [0,1)");
+  if (!allset_fused_linear_supported(I, O)) {
+    set_error("fused_linear_bwd: in=%lld out=%lld not built (both in {64,128})", static_cast<long long>(I), static_cast<long long>(O));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  const bool has_ln = stats != nullptr;
+  ALLSET_REQUIRE(has_ln == (gamma != nullptr), "fused_linear_bwd: stats and gamma must come together");
+  const unsigned grid = fused_grid(n);
+  ALLSET_REQUIRE(!has_ln || (partials != nullptr && n_partials == static_cast<int64_t>(grid) * kFusedWaves),
+                 "fused_linear_bwd: partials buffer must hold allset_fused_linear_bwd_partials() rows");
+  if (n == 0) {
+    if (has_ln) ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * I * sizeof(float), static_cast<hipStream_t>(stream)));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && W && gx, "fused_linear_bwd: null pointer");
+  ALLSET_REQUIRE((has_ln || relu_in) ? x != nullptr : true, "fused_linear_bwd: x required for LayerNorm / relu backward");
+  ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && aligned16(gy) && aligned16(W), "fused_linear_bwd: gy/W must be 16-byte aligned rows");
+  ALLSET_REQUIRE(y == nullptr || (ldy >= O && ldy % 4 == 0 && aligned16(y)), "fused_linear_bwd: y must be 16-byte aligned rows");
+  ALLSET_REQUIRE(ldgx >= I && (x == nullptr || ldx >= I), "fused_linear_bwd: leading dimension too small");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+#define ALLSET_FUSED_BWD_F(OD, IT, LN, DI)                                                                                   \
+  fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma,     \
+                                                                        relu_in, p_in, seed_in, gx, ldgx, partials, n)
+#define ALLSET_FUSED_BWD(OD, IT)                                          \
+  do {                                                                    \
+    if (has_ln) { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, true, true); else ALLSET_FUSED_BWD_F(OD, IT, true, false); }     \
+    else        { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, false, true); else ALLSET_FUSED_BWD_F(OD, IT, false, false); }   \
+  } while (0)
+  if (O == 128 && I == 128) ALLSET_FUSED_BWD(128, 4);
+  else if (O == 128 && I == 64) ALLSET_FUSED_BWD(128, 2);
+  else if (O == 64 && I == 128) ALLSET_FUSED_BWD(64, 4);
+  else ALLSET_FUSED_BWD(64, 2);
+#undef ALLSET_FUSED_BWD
+#undef ALLSET_FUSED_BWD_F
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -111,6 +111,59 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
     return y, stats
 
 
+def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats: Optional[Tensor],
+                gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
+                want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """Weight/bias gradient of the fused Linear with both operands recomputed on the fly (csrc/dense.hip)."""
+    dev = require_device(gy, y, x, stats, gamma, beta)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    if y is not None:
+        y = _rowmajor(y)
+    n, O = gy.shape
+    I = x.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
+    part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
+    part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
+    with torch.cuda.device(dev), _timed("wgrad_fused", dev, n * (O * (2 if y is not None else 1) + I) * 4):
+        check(lib.allset_wgrad_fused(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),
+                                     ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
+                                     ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
+                                     ptr(part_w), ptr(part_b), ns.value, n, O, I, stream_of(dev)), "allset_wgrad_fused")
+    gw = part_w.sum(dim=0) if ns.value > 1 else part_w[0]
+    gb = (part_b.sum(dim=0) if ns.value > 1 else part_b[0]) if want_bias else None
+    return gw, gb
+
+
+def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
+                     gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int
+                     ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip)."""
+    dev = require_device(gy, y, weight, x, stats, gamma)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    if y is not None:
+        y = _rowmajor(y)
+    weight = weight.contiguous()
+    n, O = gy.shape
+    I = x.shape[1]
+    lib = _lib.load()
+    gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    partials, npart = None, c_int64(0)
+    if stats is not None:
+        check(lib.allset_fused_linear_bwd_partials(n, byref(npart)), "allset_fused_linear_bwd_partials")
+        partials = torch.empty((npart.value, 2, I), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("fused_linear_bwd", dev, n * (O * (2 if y is not None else 1) + 2 * I) * 4):
+        check(lib.allset_fused_linear_bwd(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(weight),
+                                          ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
+                                          int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(partials), npart.value,
+                                          n, O, I, stream_of(dev)), "allset_fused_linear_bwd")
+    if partials is None:
+        return gx, None, None
+    red = partials.sum(dim=0)
+    return gx, red[0], red[1]
+
+
 def wgrad_supported(ga: Tensor, u: Tensor) -> bool:
     return (ga.is_cuda and ga.dtype == torch.float32 and u.dtype == torch.float32 and ga.shape[1] % 4 == 0
             and u.shape[1] % 4 == 0)
@@ -191,6 +244,43 @@ class _Linear(torch.autograd.Function):
                 gw = gy.t() @ x
                 gb = gy.sum(dim=0) if need_b else None
         return gx, gw, gb
+
+
+class _FusedNormLinear(torch.autograd.Function):
+    """``y = epi( pro(x) @ W^T + b )`` with ``pro = [relu] -> [LayerNorm] -> [dropout p_in]`` and
+    ``epi = [relu] -> [dropout p_out]`` -- one kernel forward (fused_mlp.hip), two kernels backward
+    (wgrad_fused, fused_linear_bwd); nothing but x, the row statistics and (for the epilogue mask) y is kept."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out):
+        seed_in = _draw_seed() if p_in > 0.0 else 0
+        seed_out = _draw_seed() if p_out > 0.0 else 0
+        y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out)
+        keep_y = relu_out or p_out > 0.0
+        ctx.save_for_backward(x, stats, gamma, beta, weight, y if keep_y else None)
+        ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, stats, gamma, beta, weight, y = ctx.saved_tensors
+        relu_in, p_in, seed_in, p_out, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        gx = dg = db = gw = gb = None
+        need_b = has_bias and ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[3] or need_b:
+            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b)
+        if ctx.needs_input_grad[0] or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
+            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in)
+        return gx, dg, db, gw, gb, None, None, None, None, None
+
+
+def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
+                      eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0, relu_out: bool = False,
+                      p_out: float = 0.0) -> Tensor:
+    return _FusedNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out),
+                                  float(p_out))
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, relu_in: bool = False, p: float = 0.0) -> Tensor:

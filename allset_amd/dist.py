@@ -232,18 +232,18 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     if aggr not in ("add", "sum", "mean"):
         raise NotImplementedError("sharded E->V supports add/sum/mean (max needs an arg-owner exchange)")
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
-    from .layers import relu_dropout
-    h = relu_dropout(v2e_conv.f_enc(x_owned), v2e_conv.dropout, training)
+    # ``training`` must agree with the convs' own mode (the fused MLP kernels read conv.training)
+    h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
     h_full = all_gather_rows(h, group)
     e = aggregate(h_full, hg.v2e, hg.norm, aggr)
-    e = relu_dropout(v2e_conv.f_dec(e), dropout, training)      # conv's relu (SetGNN's outer relu is idempotent) + dropout
+    e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)           # conv's relu (SetGNN's outer relu is idempotent) + dropout
     # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
-    g = relu_dropout(e2v_conv.f_enc(e), e2v_conv.dropout, training)
+    g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
     partial = aggregate(g, hg.e2v, hg.norm, "add")
     v = reduce_scatter_rows(partial, group)
     if aggr == "mean":
         v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
-    return relu_dropout(e2v_conv.f_dec(v), dropout, training)
+    return e2v_conv._mlp_act(e2v_conv.f_dec, v, dropout)
 
 
 class _ShardedPmaE2V(torch.autograd.Function):

@@ -108,8 +108,32 @@ class MLP(nn.Module):
             if not isinstance(norm, nn.Identity):
                 norm.reset_parameters()
 
-    def forward(self, x):
+    def _fusable(self, x: Tensor) -> bool:
+        """Every Linear can take the fused kernel (norm -> Linear -> activation in one pass): device fp32, widths the
+        kernel is built for, LayerNorm/None normalisation (BatchNorm stays on torch)."""
+        if not _on_hip(x) or x.dim() != 2:
+            return False
+        for lin in self.lins:
+            if not dense.fused_linear_supported(lin.in_features, lin.out_features) or lin.bias is None:
+                return False
+        return all(isinstance(nm, (nn.LayerNorm, nn.Identity)) for nm in self.normalizations)
+
+    def forward(self, x, _post: Optional[float] = None):
+        """``_post`` (internal): also apply ``dropout_p(relu(.))`` to the output -- the activation its callers
+        (``HalfNLHconv``) put right after the MLP -- inside the last Linear's epilogue."""
         p = float(self.dropout) if self.training else 0.0
+        post_p = (float(_post) if self.training else 0.0) if _post is not None else None
+        if self._fusable(x):
+            last = len(self.lins) - 1
+            for i, lin in enumerate(self.lins):
+                nm = self.normalizations[i]
+                ln = nm if isinstance(nm, nn.LayerNorm) else None
+                is_last = i == last
+                x = dense.fused_norm_linear(
+                    x, ln.weight if ln is not None else None, ln.bias if ln is not None else None, lin.weight, lin.bias,
+                    ln.eps if ln is not None else 1e-5, relu_in=i > 0, p_in=p if i > 0 else 0.0,
+                    relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0)
+            return x
         n0 = self.normalizations[0]
         x = _layer_norm(n0, x) if isinstance(n0, nn.LayerNorm) else n0(x)
         for i, lin in enumerate(self.lins[:-1]):
@@ -121,7 +145,8 @@ class MLP(nn.Module):
                 x = relu_dropout(a, p, self.training)
             else:                                      # BatchNorm1d: torch
                 x = F.dropout(nxt(F.relu(a)), p=p, training=self.training)
-        return _linear(self.lins[-1], x)
+        x = _linear(self.lins[-1], x)
+        return x if post_p is None else relu_dropout(x, _post, self.training)
 
 
 class PMA(nn.Module):
@@ -240,8 +265,14 @@ class HalfNLHconv(nn.Module):
             return relu_dropout(x, _post_dropout, self.training) if post else x
         if aggr is None:
             raise ValueError("aggr was not passed!")
-        x = relu_dropout(self.f_enc(x), self.dropout, self.training)
+        x = self._mlp_act(self.f_enc, x, self.dropout)
         inc = _as_incidence(edge_index, x.shape[0])
         x = AF.deepsets_aggregate(x, inc, norm, aggr)
         # relu(f_dec(.)); SetGNN's outer relu is idempotent on it, so its dropout can ride in the same pass
-        return relu_dropout(self.f_dec(x), _post_dropout if post else 0.0, self.training)
+        return self._mlp_act(self.f_dec, x, _post_dropout if post else 0.0)
+
+    def _mlp_act(self, mlp, x, p):
+        """``dropout_p(relu(mlp(x)))``; the activation rides in the MLP's last fused kernel when there is one."""
+        if isinstance(mlp, MLP):
+            return mlp(x, _post=p)
+        return relu_dropout(mlp(x), p, self.training)

@@ -182,6 +182,14 @@ int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
+/* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
+ *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;
+ *   u  = dropout_{p_in,seed_in}( LayerNorm_{stats,gamma,beta}( relu_in ? relu(x) : x ) )  (LayerNorm iff stats != NULL). */
+int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
+                       const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                       int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
+                       int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+
 /* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
  *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],
  *                                 epi = [relu_out] -> [dropout p_out].
@@ -192,6 +200,17 @@ int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, con
                             int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                             int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats,
                             int64_t n, int64_t K, int64_t N, void* stream);
+
+/* Backward of allset_fused_linear_fwd w.r.t. x (O = out features, I = in features, both in {64,128}):
+ *   ga = gy * (y > 0 ? 1/(1-p_out) : 0) if y != NULL else gy;   gu = ga @ W;   gz = gu * dropout_{p_in,seed_in} mask;
+ *   gx = LayerNorm-backward(gz; x, stats, gamma) through relu_in   (stats != NULL), else gz through relu_in.
+ * partials (stats != NULL): f32[n_partials*2*I], row w = wave w's (dgamma[I], dbeta[I]); the caller sums over rows.
+ * n_partials from allset_fused_linear_bwd_partials(n). */
+int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials);
+int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out, const float* W,
+                            const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in,
+                            float p_in, uint64_t seed_in, float* gx, int64_t ldgx, float* partials,
+                            int64_t n_partials, int64_t n, int64_t O, int64_t I, void* stream);
 
 #ifdef __cplusplus
 }
