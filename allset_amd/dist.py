@@ -307,9 +307,9 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     # ---- V -> E
     p = v2e_conv.prop
     H, C = p.heads, p.hidden
-    packed = torch.cat([_linear(p.lin_V, x_owned), p._logits(x_owned)], dim=1)    # dense on owned vertices
-    full = all_gather_rows(packed, group)
-    V, alpha = full[:, :H * C], full[:, H * C:]
+    # dense on owned vertices, then two all-gathers (no concatenate / split copies of the [n_V, d] table)
+    V = all_gather_rows(_linear(p.lin_V, x_owned), group)
+    alpha = all_gather_rows(p._logits(x_owned), group)
     o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
     e = relu_dropout(p.tail(o), dropout, training)
     # ---- E -> V

@@ -199,7 +199,9 @@ class PMA(nn.Module):
         if self.fold_alpha:
             w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
             b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
-            return F.linear(x, w, b)
+            # [n,in] x [in,H]: the weight gradient of this skinny Linear is a [H x n] x [n x in] product that the
+            # library tiles badly (1.5 ms at n = 1M); dense.linear routes it to the split-K MFMA kernel
+            return dense.linear(x, w, b) if (_on_hip(x) and H % 4 == 0 and x.shape[1] % 4 == 0) else F.linear(x, w, b)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
     def tail(self, pooled: Tensor) -> Tensor:
@@ -207,7 +209,7 @@ class PMA(nn.Module):
         H, C = self.heads, self.hidden
         out = (pooled.view(-1, H, C) + self.att_r).view(-1, H * C)     # seed + multihead (layers.py:153)
         out = _layer_norm(self.ln0, out)
-        return _layer_norm(self.ln1, out + F.relu(self.rFF(out)))
+        return _layer_norm(self.ln1, out + self.rFF(out, _post=0.0))    # relu(rFF(.)) in rFF's last fused epilogue
 
     def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
