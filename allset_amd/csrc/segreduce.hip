@@ -114,6 +114,91 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
   }
 }
 
+
+// ---- short-row variant (sum / mean, single column chunk): several consecutive CSR rows per LPR-lane group ----------
+// One wave per row spends a wave launch and three dependent round trips (rowptr -> col -> gather) on every row; at
+// degree <= 4 that overhead, not bandwidth, sets the time (profiles: 4M rows take ~1.6 ms whether they hold 1 or 4
+// incidences).  Here each LPR-lane group ("slot") owns kFlatRows consecutive rows and walks their incidences as ONE
+// stream: the rows' rowptr entries arrive in one load (lane i holds rowptr[r0+i]), the column ids of consecutive rows
+// are contiguous in the CSR and arrive LPR at a time, the gathers of a batch are in flight together regardless of row
+// boundaries, and a row is flushed (one coalesced store) whenever the stream crosses its end.  Slots never combine.
+constexpr int kFlatRows = 7;       // rows per slot; kFlatRows + 1 rowptr entries must fit in the smallest slot (8 lanes)
+
+template <typename T, int VEC, int LPR, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void segreduce_flat_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+    const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo, int n_t, int d, int mean) {
+  constexpr int NS = kWave / LPR;
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int lane0 = slot * LPR;                                   // first lane of this slot
+  const int64_t slot_global = (static_cast<int64_t>(blk) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const int64_t r_begin64 = slot_global * kFlatRows;
+  if (r_begin64 - static_cast<int64_t>(slot) * kFlatRows >= n_t) return;      // whole wave beyond the last row
+  const int r_begin = static_cast<int>(min(r_begin64, static_cast<int64_t>(n_t)));
+  const int r_end = min(r_begin + kFlatRows, n_t);
+  const int c0 = li * VEC;
+  const bool active = c0 < d;
+  // lane i of the slot holds rowptr[r_begin + i], i = 0 .. r_end - r_begin
+  const int rp = (li <= r_end - r_begin) ? rowptr[r_begin + li] : 0;
+  const int q0 = __shfl(rp, lane0);
+  const int q_end = __shfl(rp, lane0 + (r_end - r_begin));
+
+  int cur_row = r_begin;
+  int cur_start = q0;
+  int cur_end = (r_begin < r_end) ? __shfl(rp, lane0 + 1) : q0;
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+
+  auto flush = [&]() {       // store the finished row and step to the next one (slot-uniform control flow)
+    if (active) {
+      const float scale = mean ? 1.f / static_cast<float>(max(cur_end - cur_start, 1)) : 1.f;
+      FVec<VEC> r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { r.v[k] = acc[k] * scale; acc[k] = 0.f; }
+      store_vec<T, VEC>(out + static_cast<int64_t>(cur_row) * ldo + c0, r);
+    }
+    ++cur_row;
+    cur_start = cur_end;
+    cur_end = __shfl(rp, lane0 + min(cur_row - r_begin + 1, LPR - 1));
+  };
+
+  for (int base = q0; base < q_end; base += LPR) {
+    const int n = min(LPR, q_end - base);
+    int my_col = 0;
+    float my_w = 0.f;
+    if (li < n) {
+      my_col = col[base + li];
+      if constexpr (WEIGHTED) my_w = w[base + li];
+    }
+    for (int j = 0; j < n; j += kUnroll) {
+      Raw<T, VEC> raw[kUnroll];
+      float ww[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int jj = j + u;
+        const int src = __shfl(my_col, lane0 + (jj & (LPR - 1)));
+        if constexpr (WEIGHTED) ww[u] = __shfl(my_w, lane0 + (jj & (LPR - 1))); else ww[u] = 1.f;
+        if (jj < n && active) raw[u] = load_raw<T, VEC>(x + static_cast<int64_t>(src) * ldx + c0);
+        else raw[u] = zero_raw<T, VEC>();
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int pos = base + j + u;
+        if (j + u < n) {
+          while (pos >= cur_end) flush();                          // also steps over empty rows
+          const FVec<VEC> v = unpack<T, VEC>(raw[u]);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] = fmaf(ww[u], v.v[k], acc[k]);
+        }
+      }
+    }
+  }
+  while (cur_row < r_end) flush();                                 // last row and trailing empty rows
+}
+
 // gx[s,c] = sum_{j in T-row s} [argext[colT[j],c] == posT[j]] * wT[j] * gout[colT[j],c]
 template <int VEC, int LPR, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void segmax_bwd_kernel(
@@ -224,6 +309,28 @@ static void launch_segreduce(int mode_ext, bool weighted, unsigned grid, hipStre
   }
 }
 
+template <typename T, int VEC, int LPR>
+static void launch_flat(bool weighted, hipStream_t st, const int32_t* rowptr, const int32_t* col, const float* w,
+                        const T* x, int64_t ldx, T* out, int64_t ldo, int n_t, int d, int mean) {
+  constexpr int NS = kWave / LPR;
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * NS * kFlatRows;
+  const unsigned grid = static_cast<unsigned>((n_t + rows_per_block - 1) / rows_per_block);
+  if (weighted) segreduce_flat_kernel<T, VEC, LPR, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, n_t, d, mean);
+  else          segreduce_flat_kernel<T, VEC, LPR, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, n_t, d, mean);
+}
+
+// short-row path: sum/mean, 16-byte packets, the whole row in one column chunk
+template <typename T, int WIDE>
+static void dispatch_flat(bool weighted, hipStream_t st, const int32_t* rowptr, const int32_t* col, const float* w,
+                          const T* x, int64_t ldx, T* out, int64_t ldo, int n_t, int d, int mean) {
+  switch (pick_lpr(d, WIDE)) {
+    case 8:  launch_flat<T, WIDE, 8>(weighted, st, rowptr, col, w, x, ldx, out, ldo, n_t, d, mean); break;
+    case 16: launch_flat<T, WIDE, 16>(weighted, st, rowptr, col, w, x, ldx, out, ldo, n_t, d, mean); break;
+    case 32: launch_flat<T, WIDE, 32>(weighted, st, rowptr, col, w, x, ldx, out, ldo, n_t, d, mean); break;
+    default: launch_flat<T, WIDE, 64>(weighted, st, rowptr, col, w, x, ldx, out, ldo, n_t, d, mean); break;
+  }
+}
+
 template <typename T, int WIDE>
 static void dispatch_segreduce(bool wide_ok, int mode_ext, bool weighted, unsigned grid, hipStream_t st,
                                const int32_t* rowptr, const int32_t* col, const float* w, const T* x, int64_t ldx,
@@ -252,10 +359,30 @@ static void launch_segmax_bwd(bool weighted, unsigned grid, hipStream_t st, cons
 
 using namespace allset;
 
+// mean degree below which the short-row kernel is used (AUTO); see allset_segreduce_fwd_ex
+constexpr double kFlatMaxMeanDegree = 6.0;
+
+static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
+                          const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
+                          int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream);
+
 extern "C" int allset_segreduce_fwd(int reduce, int dtype, const int32_t* rowptr, const int32_t* col,
                                     const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
                                     int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
+  return segreduce_impl(reduce, dtype, 0, -1, rowptr, col, w, x, ldx, out, ldo, argext, n_t, n_s, d, stream);
+}
+
+extern "C" int allset_segreduce_fwd_ex(int reduce, int dtype, int variant, int64_t nnz, const int32_t* rowptr,
+                                       const int32_t* col, const float* w, const void* x, int64_t ldx, void* out,
+                                       int64_t ldo, int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
+  return segreduce_impl(reduce, dtype, variant, nnz, rowptr, col, w, x, ldx, out, ldo, argext, n_t, n_s, d, stream);
+}
+
+static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
+                          const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
+                          int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
   clear_error();
+  ALLSET_REQUIRE(variant >= 0 && variant <= 2, "segreduce_fwd: bad variant %d", variant);
   ALLSET_REQUIRE(reduce >= ALLSET_SUM && reduce <= ALLSET_MIN, "segreduce_fwd: bad reduce %d", reduce);
   ALLSET_REQUIRE(n_t >= 0 && n_s >= 0 && d >= 0, "segreduce_fwd: negative size");
   ALLSET_REQUIRE(n_t < INT32_MAX && n_s < INT32_MAX && d < INT32_MAX, "segreduce_fwd: size exceeds int32");
@@ -275,6 +402,23 @@ extern "C" int allset_segreduce_fwd(int reduce, int dtype, const int32_t* rowptr
                        (argext == nullptr || aligned16(argext));
   const unsigned grid = row_grid(n_t);
   const int nt = static_cast<int>(n_t), di = static_cast<int>(d);
+  // variant: 0 = AUTO (short-row kernel when the caller's nnz says the mean degree is small), 1 = one wave per row,
+  // 2 = short-row kernel.  The short-row kernel needs sum/mean, 16-byte packets and d <= 64 packets.
+  const bool flat_ok = !ext && wide_ok && d <= 64 * wide;
+  const bool use_flat = flat_ok && (variant == 2 || (variant == 0 && nnz_hint >= 0 &&
+                                                     static_cast<double>(nnz_hint) < kFlatMaxMeanDegree * static_cast<double>(n_t)));
+  if (variant == 2 && !flat_ok) {
+    set_error("segreduce_fwd: the short-row variant needs sum/mean, 16-byte aligned rows and d <= %d", 64 * wide);
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (use_flat) {
+    if (dtype == ALLSET_F32)
+      dispatch_flat<float, 4>(w != nullptr, st, rowptr, col, w, static_cast<const float*>(x), ldx, static_cast<float*>(out), ldo, nt, di, mean);
+    else
+      dispatch_flat<bf16_t, 8>(w != nullptr, st, rowptr, col, w, static_cast<const bf16_t*>(x), ldx, static_cast<bf16_t*>(out), ldo, nt, di, mean);
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   if (dtype == ALLSET_F32)
     dispatch_segreduce<float, 4>(wide_ok, ext, w != nullptr, grid, st, rowptr, col, w, static_cast<const float*>(x), ldx,
                                  static_cast<float*>(out), ldo, argext, nt, di, mean, sign);

@@ -119,7 +119,8 @@ def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_
 
 
 def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: Tensor, n_t: int,
-              want_arg: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+              want_arg: bool = False, variant: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
+    """``variant``: 0 auto (short-row kernel when nnz / n_t < 6), 1 one wave per row, 2 short-row kernel."""
     dev = require_device(rowptr, col, w, x)
     code = _dtype_code(x, "segreduce")
     es = x.element_size()
@@ -133,9 +134,9 @@ def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: 
     nnz = col.numel()
     algo = nnz * (es * d + 4 + (4 if w is not None else 0)) + (n_t + 1) * 4 + n_t * d * es
     with torch.cuda.device(dev), _timed("segreduce_fwd", dev, algo):
-        check(_lib.load().allset_segreduce_fwd(reduce, code, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
-                                               ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
-              "allset_segreduce_fwd")
+        check(_lib.load().allset_segreduce_fwd_ex(reduce, code, variant, nnz, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
+                                                  ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
+              "allset_segreduce_fwd_ex")
     return out, arg
 
 

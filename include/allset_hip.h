@@ -98,6 +98,16 @@ int allset_segreduce_fwd(int reduce, int dtype,
                          const void* x, int64_t ldx, void* out, int64_t ldo, int32_t* argext,
                          int64_t n_t, int64_t n_s, int64_t d, void* stream);
 
+/* Same, with an explicit kernel choice.  variant: 0 = auto (uses nnz, the number of incidences -- known to the caller,
+ * unknowable to the library without a sync: mean degree nnz/n_t < 6 selects the short-row kernel), 1 = one wavefront
+ * per row, 2 = short-row kernel (several consecutive rows per half-wave walked as one incidence stream; sum/mean only,
+ * 16-byte aligned rows, d <= 256 f32 / 512 bf16; otherwise ALLSET_ERR_UNSUPPORTED).  Results are identical up to fp32
+ * summation order (the short-row kernel sums a row strictly in CSR order). */
+int allset_segreduce_fwd_ex(int reduce, int dtype, int variant, int64_t nnz,
+                            const int32_t* rowptr, const int32_t* col, const float* w,
+                            const void* x, int64_t ldx, void* out, int64_t ldo, int32_t* argext,
+                            int64_t n_t, int64_t n_s, int64_t d, void* stream);
+
 /* Backward of MAX/MIN w.r.t. x, deterministic (no atomics), on the TRANSPOSED CSR (rows = sources):
  *   gx[s, c] = sum_{j in T-row s} [argext[colT[j], c] == posT[j]] * wT[j] * gout[colT[j], c]
  * posT[j] = forward-CSR position of T-incidence j.  wT may be NULL. */

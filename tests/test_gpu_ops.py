@@ -219,3 +219,47 @@ def test_bf16_storage_fp32_accumulate(d, H, device):
     close(out.detach().view(n_t, H, C), ref.detach())
     close(Vg.grad.view(n_s, H, C), Vo.grad)
     close(ag.grad, ao.grad)
+
+
+@pytest.mark.parametrize("d", [4, 20, 64, 128, 256])
+@pytest.mark.parametrize("mean_deg", [0.7, 2.0, 12.0])
+def test_short_row_kernel_matches_row_per_wave_and_oracle(d, mean_deg, device):
+    """allset_segreduce_fwd_ex variant 2 (several consecutive rows per half-wave, one incidence stream) against
+    variant 1 and the oracle: empty rows, singletons, a 300-long row, weights, mean, bf16."""
+    from allset_amd import Incidence, ops
+    rng = np.random.default_rng(int(d * 10 + mean_deg * 3))
+    n_s, n_t = 500, 1003
+    ei = make_incidence(rng, n_s, n_t, int(n_t * mean_deg), long_row=300)
+    nnz = ei.shape[1]
+    inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    csr = inc.by_dst
+    x = torch.from_numpy(rng.standard_normal((n_s, d)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(0.5, 1.5, size=nnz).astype(np.float32))
+    w_csr = w.to(device)[csr.perm.long()].contiguous()
+    for reduce, aggr in ((0, "add"), (1, "mean")):
+        for weights in (None, w_csr):
+            ref = oracle.deepsets_aggregate(x, ei, w if weights is not None else torch.ones(nnz, dtype=torch.int64), aggr)
+            ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], d)])
+            a, _ = ops.segreduce(reduce, csr.rowptr, csr.col, weights, x.to(device), n_t, variant=1)
+            b, _ = ops.segreduce(reduce, csr.rowptr, csr.col, weights, x.to(device), n_t, variant=2)
+            torch.testing.assert_close(b.cpu(), ref, rtol=RTOL, atol=ATOL)
+            torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5)
+    xb = x.bfloat16().to(device)
+    if d % 8 == 0:
+        a, _ = ops.segreduce(0, csr.rowptr, csr.col, None, xb, n_t, variant=1)
+        b, _ = ops.segreduce(0, csr.rowptr, csr.col, None, xb, n_t, variant=2)
+        torch.testing.assert_close(b.float(), a.float(), rtol=2e-2, atol=2e-2)
+    auto, _ = ops.segreduce(0, csr.rowptr, csr.col, None, x.to(device), n_t)          # auto picks by nnz / n_t
+    expect, _ = ops.segreduce(0, csr.rowptr, csr.col, None, x.to(device), n_t, variant=2 if nnz < 6 * n_t else 1)
+    torch.testing.assert_close(auto, expect, rtol=0, atol=0)
+
+
+def test_short_row_kernel_rejects_what_it_cannot_do(device):
+    from allset_amd import Incidence, ops, _lib
+    ei = torch.tensor([[0, 1, 2], [0, 0, 1]], dtype=torch.int64, device=device)
+    inc = Incidence.from_edge_index(ei, n_src=3, n_dst=2)
+    x = torch.randn(3, 516, device=device)
+    with pytest.raises(_lib.AllSetHipError):
+        ops.segreduce(0, inc.by_dst.rowptr, inc.by_dst.col, None, x, 2, variant=2)       # d > 256: more than one chunk
+    with pytest.raises(_lib.AllSetHipError):
+        ops.segreduce(2, inc.by_dst.rowptr, inc.by_dst.col, None, x[:, :128].contiguous(), 2, variant=2)   # max

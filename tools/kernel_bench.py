@@ -14,6 +14,7 @@ ap.add_argument("--heads", type=int, default=4)
 ap.add_argument("--degree", type=int, default=16)
 ap.add_argument("--dists", default="fixed,poisson,zipf")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -33,6 +34,8 @@ def report(name, ms, nbytes):
 
 
 n, d, H = args.n, args.d, args.heads
+DT = torch.float32 if args.dtype == "f32" else torch.bfloat16
+ES = 4 if args.dtype == "f32" else 2
 for dist in args.dists.split(","):
     hg = random_hypergraph(n, n, args.degree, seed=11, device=dev, dist=dist)
     inc = Incidence.from_edge_index(hg.edge_index, n_src=n, n_dst=n)
@@ -40,25 +43,27 @@ for dist in args.dists.split(","):
     rp = inc.by_dst.rowptr
     deg = (rp[1:] - rp[:-1])
     print(f"[{dist}] nnz={nnz} max hyperedge size={int(deg.max())} max vertex degree={int((inc.by_src.rowptr[1:]-inc.by_src.rowptr[:-1]).max())}")
-    x = torch.randn(n, d, device=dev)
+    x = torch.randn(n, d, device=dev).to(DT)
     w = torch.rand(nnz, device=dev) + 0.5
     alpha = torch.randn(n, H, device=dev)
-    pass_bytes = nnz * (4 * d + 4) + (n + 1) * 4 + n * 4 * d
+    pass_bytes = nnz * (ES * d + 4) + (n + 1) * 4 + n * ES * d
     for label, csr in (("V->E (by hyperedge)", inc.by_dst), ("E->V (by vertex)", inc.by_src)):
-        report(f"segreduce sum {label}", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, None, x, n)), pass_bytes)
+        report(f"segreduce sum {label}", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, None, x, n, variant=1)), pass_bytes)
+        report(f"  .. short-row kernel", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, None, x, n, variant=2)), pass_bytes)
     csr, T = inc.by_dst, inc.by_src
     report("segreduce sum weighted", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, w, x, n)), pass_bytes + nnz * 4)
     report("segreduce mean", timeit(lambda: ops.segreduce(1, csr.rowptr, csr.col, None, x, n)), pass_bytes)
-    report("segreduce max (+argext)", timeit(lambda: ops.segreduce(2, csr.rowptr, csr.col, None, x, n, want_arg=True)), pass_bytes + n * 4 * d)
-    out, arg = ops.segreduce(2, csr.rowptr, csr.col, None, x, n, want_arg=True)
-    posT = inc.pos_dst_of_src()
-    report("segmax_bwd", timeit(lambda: ops.segmax_bwd(T.rowptr, T.col, posT, None, arg, x, n)), nnz * (8 * d + 8) + (n + 1) * 4 + n * 4 * d)
-    del out, arg
-    report("pma_fwd", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n)), nnz * (4 * d + 4 + 4 * H) + (n + 1) * 4 + n * (4 * d + 8 * H))
+    report("segreduce max (+argext)", timeit(lambda: ops.segreduce(2, csr.rowptr, csr.col, None, x, n, want_arg=True)), pass_bytes + n * 4 * d)  # + int32 argext
+    if args.dtype == "f32":
+        out, arg = ops.segreduce(2, csr.rowptr, csr.col, None, x, n, want_arg=True)
+        posT = inc.pos_dst_of_src()
+        report("segmax_bwd", timeit(lambda: ops.segmax_bwd(T.rowptr, T.col, posT, None, arg, x, n)), nnz * (8 * d + 8) + (n + 1) * 4 + n * 4 * d)
+        del out, arg
+    report("pma_fwd", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
     o, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n)
-    g = torch.randn(n, d, device=dev)
-    report("pma_bwd_stats", timeit(lambda: ops.pma_bwd_stats(o, g, m, l)), n * (8 * d + 24 * H))
+    g = torch.randn(n, d, device=dev).to(DT)
+    report("pma_bwd_stats", timeit(lambda: ops.pma_bwd_stats(o, g, m, l)), n * (2 * ES * d + 16 * H))
     st = ops.pma_bwd_stats(o, g, m, l)
-    report("pma_bwd_src", timeit(lambda: ops.pma_bwd_src(T.rowptr, T.col, alpha, x, g, st, 0.2)), nnz * (4 * d + 4 + 16 * H) + (n + 1) * 4 + n * (8 * d + 8 * H))
+    report("pma_bwd_src", timeit(lambda: ops.pma_bwd_src(T.rowptr, T.col, alpha, x, g, st, 0.2)), nnz * (ES * d + 4 + 8 * H) + (n + 1) * 4 + n * (2 * ES * d + 8 * H))
     del o, m, l, g, st, x, w, inc, hg
     torch.cuda.empty_cache()
