@@ -4,8 +4,9 @@ Same class names, constructor signatures, ``forward`` arguments and ``state_dict
 reference ``src/layers.py`` (``MLP`` :496, ``PMA`` :42, ``HalfNLHconv`` :582), so a checkpoint or a
 ``train.py``-style caller moves over unchanged.  What differs is underneath: ``propagate`` is not a
 PyG message-passing template over [nnz, d] temporaries but one call into ``functional.py`` (HIP
-kernels over a CSR built once).  The dense tail (Linear / LayerNorm / ReLU) stays on torch ops
-(hipBLASLt / MIOpen) in this round.
+kernels over a CSR built once), and the dense tail (LayerNorm / Linear / ReLU / dropout) runs on the
+fused fp32-MFMA kernels of ``dense.py`` for device fp32 tensors (plain torch modules otherwise: CPU
+tensors in host-side tests, bf16, BatchNorm).
 
 ``edge_index`` may be the reference's int64 ``[2, nnz]`` tensor (converted once and cached on tensor
 identity + version) or a prebuilt :class:`allset_amd.incidence.Incidence`.

@@ -114,3 +114,33 @@ def test_sharded_layer_world1_equals_module_composition(attention, device):
     torch.testing.assert_close(xs.grad, xr.grad, rtol=1e-4, atol=1e-4)
     for g, p in zip(gs, list(a.parameters()) + list(b.parameters())):
         torch.testing.assert_close(g, p.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(p.grad.abs().max())))
+
+
+def test_setgnn_bf16_storage_tracks_fp32(device):
+    """BASELINE configs[4] regime at model level: an AllSetTransformer in bfloat16 (bf16 feature storage through the
+    bf16 instantiations of the PMA kernels, fp32 softmax statistics / accumulation) stays within bf16 rounding of the
+    fp32 model.  The whole model is bf16 here (weights, LayerNorm, GEMMs through torch), so the bound is statistical:
+    mean abs error below 3 % of the mean magnitude, worst element below 20 % of the max magnitude (the kernel-level bf16
+    bound, 1e-2, is in test_gpu_ops.py::test_bf16_storage_fp32_accumulate)."""
+    from types import SimpleNamespace
+    from allset_amd import SetGNN
+    case = cases.build_case("edge_pma_h4")                      # includes the 4096-member hyperedge
+    g = util.load_golden("edge_pma_h4")
+    sd = util.state_dict_for(case, g)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = SetGNN(case["args"])
+        model.load_state_dict(sd)
+        model = model.eval().to(device).to(dt)
+        x = torch.from_numpy(case["x"]).to(device).to(dt).requires_grad_(True)
+        data = SimpleNamespace(x=x, edge_index=torch.from_numpy(case["edge_index"]).to(device),
+                               norm=torch.from_numpy(case["norm"]).to(device))
+        logits = model(data)
+        assert logits.dtype == dt
+        G = torch.from_numpy(cases.cotangent(case["name"], logits.shape)).to(device).to(dt)
+        (logits * G).sum().backward()
+        outs[dt] = (logits.detach().float(), x.grad.detach().float())
+    for a, b in zip(outs[torch.bfloat16], outs[torch.float32]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().mean()) <= 3e-2 * float(b.abs().mean()) + 1e-4
+        assert float((a - b).abs().max()) <= 0.2 * float(b.abs().max()) + 1e-3
