@@ -124,6 +124,99 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
   }
 }
 
+
+// ---- short-row variant of pma_fwd (see segreduce_flat_kernel): each LPR-lane slot owns kPmaFlatRows consecutive
+// target rows and walks their incidences as one stream, restarting its online-softmax state at every row end.
+// Needed where rows are short by construction: E->V under hyperedge sharding (each rank holds ~deg/P incidences of a
+// vertex) and graphs with self-loop hyperedges.  Whole row in one column chunk (d <= LPR*VEC).
+constexpr int kPmaFlatRows = 7;
+
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pma_fwd_flat_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
+    const T* __restrict__ V, int64_t ldv, float slope, T* __restrict__ out, int64_t ldo,
+    float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C) {
+  constexpr int NS = kWave / LPR;
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int lane0 = slot * LPR;
+  const int64_t slot_global = (static_cast<int64_t>(blk) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const int64_t r_begin64 = slot_global * kPmaFlatRows;
+  if (r_begin64 - static_cast<int64_t>(slot) * kPmaFlatRows >= n_t) return;
+  const int r_begin = static_cast<int>(min(r_begin64, static_cast<int64_t>(n_t)));
+  const int r_end = min(r_begin + kPmaFlatRows, n_t);
+  const int d = H * C;
+  const int c0 = li * VEC;
+  const bool active = c0 < d;
+  const int h = active ? c0 / C : 0;
+  const bool head_leader = active && (c0 % C == 0);
+  const int rp = (li <= r_end - r_begin) ? rowptr[r_begin + li] : 0;
+  const int q0 = __shfl(rp, lane0);
+  const int q_end = __shfl(rp, lane0 + (r_end - r_begin));
+
+  int cur_row = r_begin;
+  int cur_end = (r_begin < r_end) ? __shfl(rp, lane0 + 1) : q0;
+  float m = -FLT_MAX, l = 0.f;
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+
+  auto flush = [&]() {
+    if (active) {
+      const float inv = l > 0.f ? 1.f / (l + kSoftmaxEps) : 0.f;
+      FVec<VEC> r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { r.v[k] = acc[k] * inv; acc[k] = 0.f; }
+      store_vec<T, VEC>(out + static_cast<int64_t>(cur_row) * ldo + c0, r);
+      if (head_leader) {
+        m_out[static_cast<int64_t>(cur_row) * H + h] = l > 0.f ? m : 0.f;
+        l_out[static_cast<int64_t>(cur_row) * H + h] = l;
+      }
+    }
+    m = -FLT_MAX; l = 0.f;
+    ++cur_row;
+    cur_end = __shfl(rp, lane0 + min(cur_row - r_begin + 1, LPR - 1));
+  };
+
+  for (int base = q0; base < q_end; base += LPR) {
+    const int n = min(LPR, q_end - base);
+    const int my_col = (li < n) ? col[base + li] : 0;
+    for (int j = 0; j < n; j += kPmaUnroll) {
+      Raw<T, VEC> raw[kPmaUnroll];
+      float a[kPmaUnroll];
+#pragma unroll
+      for (int u = 0; u < kPmaUnroll; ++u) {
+        const int jj = j + u;
+        const int src = __shfl(my_col, lane0 + (jj & (LPR - 1)));
+        a[u] = 0.f;
+        raw[u] = zero_raw<T, VEC>();
+        if (jj < n && active) {
+          a[u] = alpha[static_cast<int64_t>(src) * H + h];
+          raw[u] = load_raw<T, VEC>(V + static_cast<int64_t>(src) * ldv + c0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPmaUnroll; ++u) {
+        const int pos = base + j + u;
+        if (j + u < n) {
+          while (pos >= cur_end) flush();
+          const FVec<VEC> vu = unpack<T, VEC>(raw[u]);
+          const float av = leaky_relu(a[u], slope);
+          const float m_new = fmaxf(m, av);
+          const float sc = __expf(m - m_new);
+          const float pe = __expf(av - m_new);
+          l = fmaf(l, sc, pe);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] = fmaf(acc[k], sc, pe * vu.v[k]);
+          m = m_new;
+        }
+      }
+    }
+  }
+  while (cur_row < r_end) flush();
+}
+
 // p[j,h] in CSR order, for return_attention_weights
 __global__ __launch_bounds__(kBlock) void pma_attention_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
@@ -245,13 +338,8 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
           if (ok[u]) {
             const float p = __expf(a_s - st[u].x);
             const FVec<VEC> gu = unpack<T, VEC>(g[u]);
-            float dotp = 0.f;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-              gv[k] = fmaf(p, gu.v[k], gv[k]);
-              dotp = fmaf(vown.v[k], gu.v[k], dotp);
-            }
-            S = fmaf(p, dotp, S);
+            for (int k = 0; k < VEC; ++k) gv[k] = fmaf(p, gu.v[k], gv[k]);
             D = fmaf(p, st[u].y, D);
           }
         }
@@ -261,9 +349,11 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     for (int off = LPR; off < kWave; off <<= 1) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) gv[k] += __shfl_xor(gv[k], off);
-      S += __shfl_xor(S, off);
       D += __shfl_xor(D, off);
     }
+    // sum_j p_j <V_s, gO_j> = <V_s, sum_j p_j gO_j> = <V_s, gV_s>: no per-incidence dot product is needed
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) S = fmaf(vown.v[k], gv[k], S);
     if (slot == 0 && active) {
       FVec<VEC> r;
 #pragma unroll
@@ -282,6 +372,111 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     const float av = alpha[static_cast<int64_t>(row) * H + h];
     galpha[static_cast<int64_t>(row) * H + h] = (av > 0.f ? 1.f : slope) * red[wave][h];
   }
+}
+
+
+// ---- short-row variant of pma_bwd_src: each slot owns kPmaFlatRows consecutive SOURCE rows (transposed CSR) and walks
+// their incidences as one stream.  The rows' own logits and V rows are requested up front (static shift registers keep
+// the indexing compile-time), so a row end costs VEC FMAs, one head-group reduction and two stores.
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
+    const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
+    const T* __restrict__ V, int64_t ldv, const T* __restrict__ gout, int64_t ldg,
+    const float* __restrict__ stats, float slope, T* __restrict__ gV, int64_t ldgv,
+    float* __restrict__ galpha, int n_s, int H, int C) {
+  constexpr int NS = kWave / LPR;
+  constexpr int R = kPmaFlatRows;
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int lane0 = slot * LPR;
+  const int64_t slot_global = (static_cast<int64_t>(blk) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const int64_t r_begin64 = slot_global * R;
+  if (r_begin64 - static_cast<int64_t>(slot) * R >= n_s) return;
+  const int r_begin = static_cast<int>(min(r_begin64, static_cast<int64_t>(n_s)));
+  const int r_end = min(r_begin + R, n_s);
+  const int d = H * C, G = C / VEC;
+  const int c0 = li * VEC;
+  const bool active = c0 < d;
+  const int h = active ? c0 / C : 0;
+  const int q = active ? (c0 % C) / VEC : 0;
+  const int n_act = min(LPR, d / VEC);
+  const int grp_end = min(li - q + G, n_act);
+  const int rp = (li <= r_end - r_begin) ? rowptrT[r_begin + li] : 0;
+  const int q0 = __shfl(rp, lane0);
+  const int q_end = __shfl(rp, lane0 + (r_end - r_begin));
+  // own-row data of the slot's rows, requested now, consumed at the row ends
+  float a_raw[R];
+  Raw<T, VEC> v_raw[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    a_raw[i] = 0.f;
+    v_raw[i] = zero_raw<T, VEC>();
+    if (active && r_begin + i < r_end) {
+      a_raw[i] = alpha[static_cast<int64_t>(r_begin + i) * H + h];
+      v_raw[i] = load_raw<T, VEC>(V + static_cast<int64_t>(r_begin + i) * ldv + c0);
+    }
+  }
+  int cur_row = r_begin;
+  int cur_end = (r_begin < r_end) ? __shfl(rp, lane0 + 1) : q0;
+  float a_s = leaky_relu(a_raw[0], slope);
+  float gv[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) gv[k] = 0.f;
+  float D = 0.f;
+
+  auto flush = [&]() {
+    const FVec<VEC> vown = unpack<T, VEC>(v_raw[0]);
+    float S = 0.f;
+    if (active) {
+      FVec<VEC> r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { r.v[k] = gv[k]; S = fmaf(vown.v[k], gv[k], S); gv[k] = 0.f; }
+      store_vec<T, VEC>(gV + static_cast<int64_t>(cur_row) * ldgv + c0, r);
+    }
+    S = head_group_reduce<LPR>(S, li, grp_end);
+    if (active && q == 0)
+      galpha[static_cast<int64_t>(cur_row) * H + h] = (a_raw[0] > 0.f ? 1.f : slope) * (S - D);
+    D = 0.f;
+#pragma unroll
+    for (int i = 0; i + 1 < R; ++i) { a_raw[i] = a_raw[i + 1]; v_raw[i] = v_raw[i + 1]; }
+    a_s = leaky_relu(a_raw[0], slope);
+    ++cur_row;
+    cur_end = __shfl(rp, lane0 + min(cur_row - r_begin + 1, LPR - 1));
+  };
+
+  for (int base = q0; base < q_end; base += LPR) {
+    const int n = min(LPR, q_end - base);
+    const int my_col = (li < n) ? colT[base + li] : 0;
+    for (int j = 0; j < n; j += kPmaUnroll) {
+      Raw<T, VEC> g[kPmaUnroll];
+      float2 st[kPmaUnroll];
+#pragma unroll
+      for (int u = 0; u < kPmaUnroll; ++u) {
+        const int jj = j + u;
+        const int t = __shfl(my_col, lane0 + (jj & (LPR - 1)));
+        g[u] = zero_raw<T, VEC>();
+        st[u] = make_float2(0.f, 0.f);
+        if (jj < n && active) {
+          g[u] = load_raw<T, VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
+          st[u] = *reinterpret_cast<const float2*>(stats + (static_cast<int64_t>(t) * H + h) * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPmaUnroll; ++u) {
+        const int pos = base + j + u;
+        if (j + u < n) {
+          while (pos >= cur_end) flush();
+          const float p = __expf(a_s - st[u].x);
+          const FVec<VEC> gu = unpack<T, VEC>(g[u]);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) gv[k] = fmaf(p, gu.v[k], gv[k]);
+          D = fmaf(p, st[u].y, D);
+        }
+      }
+    }
+  }
+  while (cur_row < r_end) flush();
 }
 
 static inline unsigned row_grid(int64_t rows) { return static_cast<unsigned>((rows + kWavesPerBlock - 1) / kWavesPerBlock); }
@@ -322,10 +517,27 @@ static int check_pma_dims(const char* who, int64_t n_a, int64_t n_b, int64_t H, 
 
 using namespace allset;
 
+static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
+                        const float* alpha, const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m,
+                        float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
+
 extern "C" int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* col, const float* alpha,
                               const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m, float* l,
                               int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
+  return pma_fwd_impl(dtype, 0, -1, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+}
+
+extern "C" int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                                 const float* alpha, const void* V, int64_t ldv, float slope, void* out, int64_t ldo,
+                                 float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
+  return pma_fwd_impl(dtype, variant, nnz, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+}
+
+static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
+                        const float* alpha, const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m,
+                        float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
   clear_error();
+  ALLSET_REQUIRE(variant >= 0 && variant <= 2, "pma_fwd: bad variant %d", variant);
   int rc = check_pma_dims("pma_fwd", n_t, n_s, H, C);
   if (rc != ALLSET_OK) return rc;
   ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_fwd: bad dtype %d", dtype);
@@ -337,6 +549,31 @@ extern "C" int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* c
   const int wide = dtype == ALLSET_F32 ? 4 : 8;
   const bool wide_ok = (C % wide == 0) && (ldv % wide == 0) && (ldo % wide == 0) && aligned16(V) && aligned16(out);
   const hipStream_t st = static_cast<hipStream_t>(stream);
+  // variant: 0 auto (short-row kernel when nnz / n_t < 6), 1 one wave per row, 2 short-row kernel
+  const bool flat_ok = wide_ok && d <= 64 * wide;
+  if (variant == 2 && !flat_ok) {
+    set_error("pma_fwd: the short-row variant needs 16-byte aligned rows, C %% %d == 0 and H*C <= %d", wide, 64 * wide);
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (flat_ok && (variant == 2 || (variant == 0 && nnz_hint >= 0 && static_cast<double>(nnz_hint) < 6.0 * static_cast<double>(n_t)))) {
+    const int lpr = pick_lpr(d, wide);
+    const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kPmaFlatRows;
+    const unsigned fgrid = static_cast<unsigned>((n_t + rows_per_block - 1) / rows_per_block);
+#define ALLSET_PMA_FLAT(T, WIDE, LPRV)                                                                              \
+  pma_fwd_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptr, col, alpha, static_cast<const T*>(V), ldv, slope, \
+                                                               static_cast<T*>(out), ldo, m, l, static_cast<int>(n_t),   \
+                                                               static_cast<int>(H), static_cast<int>(C))
+    if (dtype == ALLSET_F32) {
+      switch (lpr) { case 8: ALLSET_PMA_FLAT(float, 4, 8); break; case 16: ALLSET_PMA_FLAT(float, 4, 16); break;
+                     case 32: ALLSET_PMA_FLAT(float, 4, 32); break; default: ALLSET_PMA_FLAT(float, 4, 64); break; }
+    } else {
+      switch (lpr) { case 8: ALLSET_PMA_FLAT(bf16_t, 8, 8); break; case 16: ALLSET_PMA_FLAT(bf16_t, 8, 16); break;
+                     case 32: ALLSET_PMA_FLAT(bf16_t, 8, 32); break; default: ALLSET_PMA_FLAT(bf16_t, 8, 64); break; }
+    }
+#undef ALLSET_PMA_FLAT
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, float, 4, row_grid(n_t), st, rowptr, col, alpha, static_cast<const float*>(V), ldv, slope,
                           static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
@@ -386,11 +623,31 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
   return ALLSET_OK;
 }
 
+static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptrT, const int32_t* colT,
+                            const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
+                            const float* stats, float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s,
+                            int64_t n_t, int64_t H, int64_t C, void* stream);
+
 extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT, const float* alpha,
                                   const void* V, int64_t ldv, const void* gout, int64_t ldg, const float* stats,
                                   float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t,
                                   int64_t H, int64_t C, void* stream) {
+  return pma_bwd_src_impl(dtype, 0, -1, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+}
+
+extern "C" int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptrT, const int32_t* colT,
+                                     const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
+                                     const float* stats, float slope, void* gV, int64_t ldgv, float* galpha,
+                                     int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream) {
+  return pma_bwd_src_impl(dtype, variant, nnz, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+}
+
+static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptrT, const int32_t* colT,
+                            const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
+                            const float* stats, float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s,
+                            int64_t n_t, int64_t H, int64_t C, void* stream) {
   clear_error();
+  ALLSET_REQUIRE(variant >= 0 && variant <= 2, "pma_bwd_src: bad variant %d", variant);
   int rc = check_pma_dims("pma_bwd_src", n_s, n_t, H, C);
   if (rc != ALLSET_OK) return rc;
   ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_bwd_src: bad dtype %d", dtype);
@@ -404,6 +661,31 @@ extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32
   const bool wide_ok = (C % wide == 0) && (ldv % wide == 0) && (ldg % wide == 0) && (ldgv % wide == 0) && aligned16(V) &&
                        aligned16(gout) && aligned16(gV);
   const hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool flat_ok = wide_ok && d <= 64 * wide;
+  if (variant == 2 && !flat_ok) {
+    set_error("pma_bwd_src: the short-row variant needs 16-byte aligned rows, C %% %d == 0 and H*C <= %d", wide, 64 * wide);
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (flat_ok && (variant == 2 || (variant == 0 && nnz_hint >= 0 && static_cast<double>(nnz_hint) < 6.0 * static_cast<double>(n_s)))) {
+    const int lpr = pick_lpr(d, wide);
+    const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kPmaFlatRows;
+    const unsigned fgrid = static_cast<unsigned>((n_s + rows_per_block - 1) / rows_per_block);
+#define ALLSET_PMA_FLATB(T, WIDE, LPRV)                                                                                  \
+  pma_bwd_src_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptrT, colT, alpha, static_cast<const T*>(V), ldv,   \
+                                                                   static_cast<const T*>(gout), ldg, stats, slope,         \
+                                                                   static_cast<T*>(gV), ldgv, galpha, static_cast<int>(n_s), \
+                                                                   static_cast<int>(H), static_cast<int>(C))
+    if (dtype == ALLSET_F32) {
+      switch (lpr) { case 8: ALLSET_PMA_FLATB(float, 4, 8); break; case 16: ALLSET_PMA_FLATB(float, 4, 16); break;
+                     case 32: ALLSET_PMA_FLATB(float, 4, 32); break; default: ALLSET_PMA_FLATB(float, 4, 64); break; }
+    } else {
+      switch (lpr) { case 8: ALLSET_PMA_FLATB(bf16_t, 8, 8); break; case 16: ALLSET_PMA_FLATB(bf16_t, 8, 16); break;
+                     case 32: ALLSET_PMA_FLATB(bf16_t, 8, 32); break; default: ALLSET_PMA_FLATB(bf16_t, 8, 64); break; }
+    }
+#undef ALLSET_PMA_FLATB
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, float, 4, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const float*>(V), ldv,
                           static_cast<const float*>(gout), ldg, stats, slope, static_cast<float*>(gV), ldgv, galpha,

@@ -206,8 +206,10 @@ class HipPmaKernels:
     @staticmethod
     def fwd(V, alpha, inc, heads, slope):                   # raw: (out, m, l), local softmax statistics
         from . import ops
+        from .functional import _variant
         csr = inc.by_dst
-        return ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst)
+        return ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
+                           variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads))
 
     @staticmethod
     def bwd_stats(out, gout, m, l):
@@ -217,8 +219,10 @@ class HipPmaKernels:
     @staticmethod
     def bwd_src(inc, alpha, V, gout, stats, slope):
         from . import ops
+        from .functional import _variant
         T = inc.by_src
-        return ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, slope)
+        return ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, slope,
+                               variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]))
 
 
 def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, aggr: str = "add",

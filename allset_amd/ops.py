@@ -59,12 +59,23 @@ def _timed(name: str, dev, algo_bytes: int):
 
 
 class CSR(NamedTuple):
-    """rowptr int32[n_rows+1], col int32[nnz], perm int32[nnz] (CSR position -> edge-list position)."""
+    """rowptr int32[n_rows+1], col int32[nnz], perm int32[nnz] (CSR position -> edge-list position);
+    ``max_deg`` = longest row (read back once when the CSR is built; used to pick kernel variants)."""
     rowptr: Tensor
     col: Tensor
     perm: Tensor
     n_rows: int
     n_cols: int
+    max_deg: int = 0
+
+    def variant(self, kind: str, n_rows: Optional[int] = None) -> int:
+        """Kernel variant for this orientation: 2 = short-row kernel, 1 = one wavefront per row.  Thresholds from
+        profiles/r01_kernel_bench*.txt: the short-row kernels win below a mean degree of ~6 (segreduce, pma_fwd) and
+        up to ~24 for pma_bwd_src, as long as no row is long enough to serialise a half-wave."""
+        rows = max(int(self.n_rows if n_rows is None else n_rows), 1)
+        mean = self.col.numel() / rows
+        limit = 24.0 if kind == "pma_bwd_src" else 6.0
+        return 2 if (mean < limit and self.max_deg <= 512) else 1
 
     @property
     def nnz(self) -> int:
@@ -115,7 +126,8 @@ def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_
         check(lib.allset_csr_build(ptr(row_ids), ptr(col_ids), nnz, row_base, col_base, n_rows,
                                    ptr(rowptr), ptr(col), ptr(perm), ptr(ws), need.value, stream_of(dev)),
               "allset_csr_build")
-    return CSR(rowptr, col, perm, n_rows, n_cols)
+    max_deg = int((rowptr[1:] - rowptr[:-1]).max()) if n_rows > 0 and nnz > 0 else 0     # one-time sync at build
+    return CSR(rowptr, col, perm, n_rows, n_cols, max_deg)
 
 
 def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: Tensor, n_t: int,
@@ -170,8 +182,8 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
     return gw
 
 
-def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, slope: float, n_t: int
-            ) -> Tuple[Tensor, Tensor, Tensor]:
+def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, slope: float, n_t: int,
+            variant: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     dev = require_device(rowptr, col, alpha, V)
     code = _dtype_code(V, "pma_fwd")
     es = V.element_size()
@@ -186,9 +198,9 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
     l = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
     algo = col.numel() * (es * d + 4 + 4 * heads) + (n_t + 1) * 4 + n_t * (d * es + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_fwd", dev, algo):
-        check(_lib.load().allset_pma_fwd(code, ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V), slope, ptr(out),
-                                         max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads, stream_of(dev)),
-              "allset_pma_fwd")
+        check(_lib.load().allset_pma_fwd_ex(code, variant, col.numel(), ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V),
+                                            slope, ptr(out), max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads,
+                                            stream_of(dev)), "allset_pma_fwd_ex")
     return out, m, l
 
 
@@ -220,8 +232,8 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
     return stats
 
 
-def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: Tensor, stats: Tensor, slope: float
-                ) -> Tuple[Tensor, Tensor]:
+def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: Tensor, stats: Tensor, slope: float,
+                variant: int = 0) -> Tuple[Tensor, Tensor]:
     dev = require_device(rowptrT, colT, alpha, V, gout, stats)
     code = _dtype_code(V, "pma_bwd_src")
     if gout.dtype != V.dtype:
@@ -237,8 +249,8 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     galpha = torch.empty((n_s, heads), dtype=torch.float32, device=dev)
     algo = colT.numel() * (es * d + 4 + 8 * heads) + (n_s + 1) * 4 + n_s * (2 * d * es + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
-        check(_lib.load().allset_pma_bwd_src(code, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V), ptr(gout),
-                                             _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1), ptr(galpha),
-                                             n_s, n_t, heads, d // heads, stream_of(dev)),
-              "allset_pma_bwd_src")
+        check(_lib.load().allset_pma_bwd_src_ex(code, variant, colT.numel(), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
+                                                _ld(V), ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1),
+                                                ptr(galpha), n_s, n_t, heads, d // heads, stream_of(dev)),
+              "allset_pma_bwd_src_ex")
     return gV, galpha

@@ -136,6 +136,13 @@ int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* col,
                    void* out, int64_t ldo, float* m, float* l,
                    int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
 
+/* Same with an explicit kernel choice (see allset_segreduce_fwd_ex): variant 0 auto by nnz / n_t, 1 one wavefront per
+ * row, 2 short-row kernel (16-byte aligned rows, C a multiple of the packet width, H*C <= 256 f32 / 512 bf16). */
+int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                      const float* alpha, const void* V, int64_t ldv, float slope,
+                      void* out, int64_t ldo, float* m, float* l,
+                      int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
+
 /* Attention weights p[j,h] in CSR order (reference PMA.forward(..., return_attention_weights=True),
  * layers.py:159-162).  p: f32[nnz*H]. */
 int allset_pma_attention(const int32_t* rowptr, const int32_t* col, const float* alpha,
@@ -191,6 +198,13 @@ int allset_relu_dropout_bwd(const float* gy, const float* y, float p, float* gx,
 int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+
+/* Same with an explicit kernel choice (variant as in allset_pma_fwd_ex; nnz / n_s decides in auto mode). */
+int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptrT, const int32_t* colT,
+                          const float* alpha, const void* V, int64_t ldv,
+                          const void* gout, int64_t ldg, const float* stats, float slope,
+                          void* gV, int64_t ldgv, float* galpha,
+                          int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream);
 
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;

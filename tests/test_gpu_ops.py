@@ -263,3 +263,57 @@ def test_short_row_kernel_rejects_what_it_cannot_do(device):
         ops.segreduce(0, inc.by_dst.rowptr, inc.by_dst.col, None, x, 2, variant=2)       # d > 256: more than one chunk
     with pytest.raises(_lib.AllSetHipError):
         ops.segreduce(2, inc.by_dst.rowptr, inc.by_dst.col, None, x[:, :128].contiguous(), 2, variant=2)   # max
+
+
+@pytest.mark.parametrize("H,C", [(4, 32), (1, 64), (8, 16), (4, 8), (1, 256)])
+@pytest.mark.parametrize("mean_deg", [0.7, 2.5, 12.0])
+def test_pma_short_row_kernel(H, C, mean_deg, device):
+    """allset_pma_fwd_ex variant 2 against variant 1 and the oracle (out, m, l), incl. empty rows and a long row."""
+    from allset_amd import Incidence, ops
+    rng = np.random.default_rng(H * 1000 + C + int(mean_deg * 10))
+    n_s, n_t, d = 400, 900, H * C
+    ei = make_incidence(rng, n_s, n_t, int(n_t * mean_deg), long_row=200, sort=True)
+    inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    csr = inc.by_dst
+    V = torch.from_numpy(rng.standard_normal((n_s, d)).astype(np.float32))
+    alpha = torch.from_numpy((2.5 * rng.standard_normal((n_s, H))).astype(np.float32))
+    ref, _ = oracle.pma_aggregate(V.view(n_s, H, C), alpha, ei, 0.2)
+    ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], H, C)]).reshape(n_t, d)
+    o1, m1, l1 = ops.pma_fwd(csr.rowptr, csr.col, alpha.to(device), V.to(device), H, 0.2, n_t, variant=1)
+    o2, m2, l2 = ops.pma_fwd(csr.rowptr, csr.col, alpha.to(device), V.to(device), H, 0.2, n_t, variant=2)
+    torch.testing.assert_close(o2.cpu(), ref, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(o2, o1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(m2, m1, rtol=0, atol=0)
+    torch.testing.assert_close(l2, l1, rtol=1e-5, atol=1e-6)
+    ob, _, _ = ops.pma_fwd(csr.rowptr, csr.col, alpha.to(device), V.bfloat16().to(device), H, 0.2, n_t, variant=2) if C % 8 == 0 else (None, None, None)
+    if ob is not None:
+        torch.testing.assert_close(ob.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("H,C", [(4, 32), (1, 64), (8, 16), (4, 8), (3, 20)])
+@pytest.mark.parametrize("mean_deg", [0.7, 2.5, 12.0])
+def test_pma_bwd_short_row_kernel(H, C, mean_deg, device):
+    """allset_pma_bwd_src_ex variant 2 against variant 1 and against autograd of the oracle."""
+    from allset_amd import Incidence, ops
+    rng = np.random.default_rng(H * 77 + C + int(mean_deg * 10))
+    n_s, n_t, d = 700, 300, H * C
+    ei = make_incidence(rng, n_s, n_t, int(n_s * mean_deg), long_row=0, sort=True)
+    inc = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    csr, T = inc.by_dst, inc.by_src
+    V = torch.from_numpy(rng.standard_normal((n_s, d)).astype(np.float32))
+    alpha = torch.from_numpy((2.0 * rng.standard_normal((n_s, H))).astype(np.float32))
+    alpha[5, 0] = 0.0
+    G = torch.from_numpy(rng.standard_normal((n_t, d)).astype(np.float32))
+    Vo, ao = V.view(n_s, H, C).clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    ref, _ = oracle.pma_aggregate(Vo, ao, ei, 0.2)
+    ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], H, C)])
+    (ref * G.view(n_t, H, C)).sum().backward()
+    out, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha.to(device), V.to(device), H, 0.2, n_t)
+    stats = ops.pma_bwd_stats(out, G.to(device), m, l)
+    res = {}
+    for variant in (1, 2) if C % 4 == 0 else (1,):
+        res[variant] = ops.pma_bwd_src(T.rowptr, T.col, alpha.to(device), V.to(device), G.to(device), stats, 0.2, variant=variant)
+        torch.testing.assert_close(res[variant][0].cpu().view(n_s, H, C), Vo.grad, rtol=RTOL, atol=ATOL)
+        torch.testing.assert_close(res[variant][1].cpu(), ao.grad, rtol=RTOL, atol=ATOL)
+    if 2 in res:
+        torch.testing.assert_close(res[2][0], res[1][0], rtol=1e-5, atol=1e-5)

@@ -59,11 +59,13 @@ for dist in args.dists.split(","):
         posT = inc.pos_dst_of_src()
         report("segmax_bwd", timeit(lambda: ops.segmax_bwd(T.rowptr, T.col, posT, None, arg, x, n)), nnz * (8 * d + 8) + (n + 1) * 4 + n * 4 * d)
         del out, arg
-    report("pma_fwd", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
+    report("  .. pma_fwd short-row kernel", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=2)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
+    report("pma_fwd", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=1)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
     o, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n)
     g = torch.randn(n, d, device=dev).to(DT)
     report("pma_bwd_stats", timeit(lambda: ops.pma_bwd_stats(o, g, m, l)), n * (2 * ES * d + 16 * H))
     st = ops.pma_bwd_stats(o, g, m, l)
-    report("pma_bwd_src", timeit(lambda: ops.pma_bwd_src(T.rowptr, T.col, alpha, x, g, st, 0.2)), nnz * (ES * d + 4 + 8 * H) + (n + 1) * 4 + n * (2 * ES * d + 8 * H))
+    report("  .. pma_bwd_src short-row kernel", timeit(lambda: ops.pma_bwd_src(T.rowptr, T.col, alpha, x, g, st, 0.2, variant=2)), nnz * (ES * d + 4 + 8 * H) + (n + 1) * 4 + n * (2 * ES * d + 8 * H))
+    report("pma_bwd_src", timeit(lambda: ops.pma_bwd_src(T.rowptr, T.col, alpha, x, g, st, 0.2, variant=1)), nnz * (ES * d + 4 + 8 * H) + (n + 1) * 4 + n * (2 * ES * d + 8 * H))
     del o, m, l, g, st, x, w, inc, hg
     torch.cuda.empty_cache()

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Per-step wall time of a full training step (fwd + loss + bwd + Adam) and of an eval forward at dataset scale
+(Cora-/Citeseer-shaped parity cases): launch-bound regime."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.nn.functional as F
+from types import SimpleNamespace
+import cases
+from allset_amd import SetGNN
+dev = torch.device("cuda:0")
+for name in ("cora_ds_add", "citeseer_pma_h4"):
+    case = cases.build_case(name)
+    model = SetGNN(case["args"]).to(dev)
+    model.reset_parameters()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(dev), edge_index=torch.from_numpy(case["edge_index"]).to(dev),
+                           norm=torch.from_numpy(case["norm"]).to(dev))
+    n = data.x.shape[0]
+    y = torch.randint(0, case["args"].num_classes, (n,), device=dev)
+    def step():
+        model.train(); opt.zero_grad()
+        out = F.log_softmax(model(data), dim=1)
+        loss = F.nll_loss(out, y); loss.backward(); opt.step()
+    def evalf():
+        model.eval()
+        with torch.no_grad():
+            return model(data)
+    for fn, label in ((step, "train step"), (evalf, "eval forward")):
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): fn()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+        print(f"{name:18s} {label:13s} {dt*1e3:7.3f} ms")
