@@ -278,6 +278,54 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
   }
 }
 
+
+// Single-chunk variant of pma_bwd_stats (H*C <= LPR*VEC): every LPR-lane slot takes its own rows (4 in flight), the
+// head sums stay inside the slot (no LDS), so a d = 128 fp32 row uses 32 lanes instead of idling half the wave.
+constexpr int kStatsRows = 4;
+
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pma_bwd_stats_flat_kernel(
+    const T* __restrict__ out, int64_t ldo, const T* __restrict__ gout, int64_t ldg,
+    const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int n_t, int H, int C) {
+  constexpr int NS = kWave / LPR;
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR;
+  const int d = H * C, G = C / VEC;
+  const int c0 = li * VEC;
+  const bool active = c0 < d;
+  const int h = active ? c0 / C : 0;
+  const int q = active ? (c0 % C) / VEC : 0;
+  const int n_act = min(LPR, d / VEC);
+  const int grp_end = min(li - q + G, n_act);
+  const int64_t row0 = ((static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot) * kStatsRows;
+  Raw<T, VEC> o[kStatsRows], g[kStatsRows];
+#pragma unroll
+  for (int r = 0; r < kStatsRows; ++r) {
+    o[r] = zero_raw<T, VEC>();
+    g[r] = zero_raw<T, VEC>();
+    if (active && row0 + r < n_t) {
+      o[r] = load_raw<T, VEC>(out + (row0 + r) * ldo + c0);
+      g[r] = load_raw<T, VEC>(gout + (row0 + r) * ldg + c0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kStatsRows; ++r) {
+    const FVec<VEC> ov = unpack<T, VEC>(o[r]), gv = unpack<T, VEC>(g[r]);
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) part = fmaf(ov.v[k], gv.v[k], part);
+    part = head_group_reduce<LPR>(part, li, grp_end);
+    if (active && q == 0 && row0 + r < n_t) {
+      const int64_t th = (row0 + r) * H + h;
+      const float lv = l[th];
+      float2 st;
+      st.x = lv > 0.f ? m[th] + __logf(lv + kSoftmaxEps) : FLT_MAX;
+      st.y = part;
+      *reinterpret_cast<float2*>(stats + th * 2) = st;
+    }
+  }
+}
+
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
@@ -611,6 +659,26 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
   const int wide = dtype == ALLSET_F32 ? 4 : 8;
   const bool wide_ok = (C % wide == 0) && (ldo % wide == 0) && (ldg % wide == 0) && aligned16(out) && aligned16(gout);
   const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (wide_ok && d <= 64 * wide) {        // the whole row in one chunk: slot-per-row kernel, no LDS
+    const int lpr = pick_lpr(d, wide);
+    const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kStatsRows;
+    const unsigned fgrid = static_cast<unsigned>((n_t + rows_per_block - 1) / rows_per_block);
+#define ALLSET_PMA_STATS(T, WIDE, LPRV)                                                                               \
+  pma_bwd_stats_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(static_cast<const T*>(out), ldo,                   \
+                                                                     static_cast<const T*>(gout), ldg, m, l, stats,     \
+                                                                     static_cast<int>(n_t), static_cast<int>(H),        \
+                                                                     static_cast<int>(C))
+    if (dtype == ALLSET_F32) {
+      switch (lpr) { case 8: ALLSET_PMA_STATS(float, 4, 8); break; case 16: ALLSET_PMA_STATS(float, 4, 16); break;
+                     case 32: ALLSET_PMA_STATS(float, 4, 32); break; default: ALLSET_PMA_STATS(float, 4, 64); break; }
+    } else {
+      switch (lpr) { case 8: ALLSET_PMA_STATS(bf16_t, 8, 8); break; case 16: ALLSET_PMA_STATS(bf16_t, 8, 16); break;
+                     case 32: ALLSET_PMA_STATS(bf16_t, 8, 32); break; default: ALLSET_PMA_STATS(bf16_t, 8, 64); break; }
+    }
+#undef ALLSET_PMA_STATS
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_bwd_stats_kernel, float, 4, row_grid(n_t), st, static_cast<const float*>(out), ldo,
                           static_cast<const float*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
