@@ -28,18 +28,18 @@ SIGNATURES = {
     "allset_csr_build_workspace_bytes": [c_int64, c_int64, POINTER(c_size_t)],
     "allset_csr_build": [_P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P],
     "allset_segreduce_fwd": [c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P],
-    "allset_segreduce_fwd_ex": [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64,
+    "allset_segreduce_fwd_ex": [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64,
                                 c_int64, _P],
     "allset_segmax_bwd": [_P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_sddmm_rowdot": [c_int, _P, _P, _P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_pma_fwd": [c_int, _P, _P, _P, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
-    "allset_pma_fwd_ex": [c_int, c_int, c_int64, _P, _P, _P, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64, c_int64,
+    "allset_pma_fwd_ex": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64, c_int64,
                           c_int64, c_int64, _P],
     "allset_pma_attention": [_P, _P, _P, _P, _P, c_float, _P, c_int64, c_int64, _P],
     "allset_pma_bwd_stats": [c_int, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_pma_bwd_src": [c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,
                            c_int64, c_int64, c_int64, c_int64, _P],
-    "allset_pma_bwd_src_ex": [c_int, c_int, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,
+    "allset_pma_bwd_src_ex": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,
                               c_int64, c_int64, c_int64, c_int64, _P],
     "allset_ln_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64, c_int64, _P],
     "allset_ln_bwd_partials": [c_int64, c_int64, POINTER(c_int64)],

@@ -41,11 +41,12 @@ template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
     const T* __restrict__ V, int64_t ldv, float slope, T* __restrict__ out, int64_t ldo,
-    float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C) {
+    float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C, const int32_t* __restrict__ row_order) {
   constexpr int NS = kWave / LPR;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (row >= n_t) return;
+  const int slot_row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (slot_row >= n_t) return;
+  const int row = row_order ? row_order[slot_row] : slot_row;      // long rows first (see segreduce_kernel)
   const int lane = lane_id();
   const int slot = lane / LPR, li = lane % LPR;
   const int start = rowptr[row], end = rowptr[row + 1];
@@ -331,13 +332,14 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
     const T* __restrict__ V, int64_t ldv, const T* __restrict__ gout, int64_t ldg,
     const float* __restrict__ stats, float slope, T* __restrict__ gV, int64_t ldgv,
-    float* __restrict__ galpha, int n_s, int H, int C) {
+    float* __restrict__ galpha, int n_s, int H, int C, const int32_t* __restrict__ row_order) {
   constexpr int NS = kWave / LPR;
   __shared__ float red[kWavesPerBlock][kMaxHeads];
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int wave = threadIdx.x >> 6;
-  const int row = static_cast<int>(blk) * kWavesPerBlock + wave;
-  if (row >= n_s) return;
+  const int slot_row = static_cast<int>(blk) * kWavesPerBlock + wave;
+  if (slot_row >= n_s) return;
+  const int row = row_order ? row_order[slot_row] : slot_row;      // long rows first (see segreduce_kernel)
   const int lane = lane_id();
   const int slot = lane / LPR, li = lane % LPR;
   const int start = rowptrT[row], end = rowptrT[row + 1];
@@ -565,25 +567,26 @@ static int check_pma_dims(const char* who, int64_t n_a, int64_t n_b, int64_t H, 
 
 using namespace allset;
 
-static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
-                        const float* alpha, const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m,
-                        float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
+static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptr,
+                        const int32_t* col, const float* alpha, const void* V, int64_t ldv, float slope, void* out,
+                        int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
 
 extern "C" int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* col, const float* alpha,
                               const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m, float* l,
                               int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
-  return pma_fwd_impl(dtype, 0, -1, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+  return pma_fwd_impl(dtype, 0, -1, nullptr, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
 }
 
-extern "C" int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptr, const int32_t* col,
-                                 const float* alpha, const void* V, int64_t ldv, float slope, void* out, int64_t ldo,
-                                 float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
-  return pma_fwd_impl(dtype, variant, nnz, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+extern "C" int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptr,
+                                 const int32_t* col, const float* alpha, const void* V, int64_t ldv, float slope,
+                                 void* out, int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H,
+                                 int64_t C, void* stream) {
+  return pma_fwd_impl(dtype, variant, nnz, row_order, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
 }
 
-static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
-                        const float* alpha, const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m,
-                        float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
+static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptr,
+                        const int32_t* col, const float* alpha, const void* V, int64_t ldv, float slope, void* out,
+                        int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
   clear_error();
   ALLSET_REQUIRE(variant >= 0 && variant <= 2, "pma_fwd: bad variant %d", variant);
   int rc = check_pma_dims("pma_fwd", n_t, n_s, H, C);
@@ -624,10 +627,10 @@ static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t*
   }
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, float, 4, row_grid(n_t), st, rowptr, col, alpha, static_cast<const float*>(V), ldv, slope,
-                          static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
+                          static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C), row_order);
   else
     ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, bf16_t, 8, row_grid(n_t), st, rowptr, col, alpha, static_cast<const bf16_t*>(V), ldv, slope,
-                          static_cast<bf16_t*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C));
+                          static_cast<bf16_t*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C), row_order);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -691,29 +694,30 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
   return ALLSET_OK;
 }
 
-static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptrT, const int32_t* colT,
-                            const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
-                            const float* stats, float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s,
-                            int64_t n_t, int64_t H, int64_t C, void* stream);
+static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptrT,
+                            const int32_t* colT, const float* alpha, const void* V, int64_t ldv, const void* gout,
+                            int64_t ldg, const float* stats, float slope, void* gV, int64_t ldgv, float* galpha,
+                            int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream);
 
 extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT, const float* alpha,
                                   const void* V, int64_t ldv, const void* gout, int64_t ldg, const float* stats,
                                   float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t,
                                   int64_t H, int64_t C, void* stream) {
-  return pma_bwd_src_impl(dtype, 0, -1, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+  return pma_bwd_src_impl(dtype, 0, -1, nullptr, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
 }
 
-extern "C" int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptrT, const int32_t* colT,
-                                     const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
-                                     const float* stats, float slope, void* gV, int64_t ldgv, float* galpha,
-                                     int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream) {
-  return pma_bwd_src_impl(dtype, variant, nnz, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+extern "C" int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order,
+                                     const int32_t* rowptrT, const int32_t* colT, const float* alpha, const void* V,
+                                     int64_t ldv, const void* gout, int64_t ldg, const float* stats, float slope,
+                                     void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t, int64_t H,
+                                     int64_t C, void* stream) {
+  return pma_bwd_src_impl(dtype, variant, nnz, row_order, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
 }
 
-static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* rowptrT, const int32_t* colT,
-                            const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
-                            const float* stats, float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s,
-                            int64_t n_t, int64_t H, int64_t C, void* stream) {
+static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptrT,
+                            const int32_t* colT, const float* alpha, const void* V, int64_t ldv, const void* gout,
+                            int64_t ldg, const float* stats, float slope, void* gV, int64_t ldgv, float* galpha,
+                            int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream) {
   clear_error();
   ALLSET_REQUIRE(variant >= 0 && variant <= 2, "pma_bwd_src: bad variant %d", variant);
   int rc = check_pma_dims("pma_bwd_src", n_s, n_t, H, C);
@@ -757,11 +761,11 @@ static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int3
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, float, 4, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const float*>(V), ldv,
                           static_cast<const float*>(gout), ldg, stats, slope, static_cast<float*>(gV), ldgv, galpha,
-                          static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C));
+                          static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C), row_order);
   else
     ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, bf16_t, 8, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const bf16_t*>(V), ldv,
                           static_cast<const bf16_t*>(gout), ldg, stats, slope, static_cast<bf16_t*>(gV), ldgv, galpha,
-                          static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C));
+                          static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C), row_order);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -25,11 +25,14 @@ template <typename T, int VEC, int LPR, int MODE, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void segreduce_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
     const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
-    int32_t* __restrict__ argext, int n_t, int d, int mean, float sign) {
+    int32_t* __restrict__ argext, int n_t, int d, int mean, float sign, const int32_t* __restrict__ row_order) {
   constexpr int NS = kWave / LPR;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (row >= n_t) return;  // whole wave exits together
+  const int slot_row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (slot_row >= n_t) return;  // whole wave exits together
+  // optional processing order (skewed degree distributions): the long rows of each XCD's range come first, so that
+  // a 4096-member row, which keeps one wave busy for ~0.3 ms, starts at t = 0 instead of setting the kernel's tail
+  const int row = row_order ? row_order[slot_row] : slot_row;
   const int lane = lane_id();
   const int slot = lane / LPR, li = lane % LPR;
   const int start = rowptr[row], end = rowptr[row + 1];
@@ -299,13 +302,13 @@ template <typename T, int VEC, int LPR>
 static void launch_segreduce(int mode_ext, bool weighted, unsigned grid, hipStream_t st,
                              const int32_t* rowptr, const int32_t* col, const float* w, const T* x,
                              int64_t ldx, T* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean,
-                             float sign) {
+                             float sign, const int32_t* row_order) {
   if (!mode_ext) {
-    if (weighted) segreduce_kernel<T, VEC, LPR, kModeSum, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
-    else          segreduce_kernel<T, VEC, LPR, kModeSum, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    if (weighted) segreduce_kernel<T, VEC, LPR, kModeSum, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order);
+    else          segreduce_kernel<T, VEC, LPR, kModeSum, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order);
   } else {
-    if (weighted) segreduce_kernel<T, VEC, LPR, kModeExt, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
-    else          segreduce_kernel<T, VEC, LPR, kModeExt, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    if (weighted) segreduce_kernel<T, VEC, LPR, kModeExt, true><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order);
+    else          segreduce_kernel<T, VEC, LPR, kModeExt, false><<<grid, kBlock, 0, st>>>(rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order);
   }
 }
 
@@ -334,16 +337,17 @@ static void dispatch_flat(bool weighted, hipStream_t st, const int32_t* rowptr, 
 template <typename T, int WIDE>
 static void dispatch_segreduce(bool wide_ok, int mode_ext, bool weighted, unsigned grid, hipStream_t st,
                                const int32_t* rowptr, const int32_t* col, const float* w, const T* x, int64_t ldx,
-                               T* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean, float sign) {
+                               T* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean, float sign,
+                               const int32_t* row_order) {
   if (wide_ok) {
     switch (pick_lpr(d, WIDE)) {
-      case 8:  launch_segreduce<T, WIDE, 8>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
-      case 16: launch_segreduce<T, WIDE, 16>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
-      case 32: launch_segreduce<T, WIDE, 32>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
-      default: launch_segreduce<T, WIDE, 64>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign); break;
+      case 8:  launch_segreduce<T, WIDE, 8>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
+      case 16: launch_segreduce<T, WIDE, 16>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
+      case 32: launch_segreduce<T, WIDE, 32>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
+      default: launch_segreduce<T, WIDE, 64>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
     }
   } else {
-    launch_segreduce<T, 1, 64>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign);
+    launch_segreduce<T, 1, 64>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order);
   }
 }
 
@@ -362,23 +366,26 @@ using namespace allset;
 // mean degree below which the short-row kernel is used (AUTO); see allset_segreduce_fwd_ex
 constexpr double kFlatMaxMeanDegree = 6.0;
 
-static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
+static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, const int32_t* row_order,
+                          const int32_t* rowptr, const int32_t* col,
                           const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
                           int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream);
 
 extern "C" int allset_segreduce_fwd(int reduce, int dtype, const int32_t* rowptr, const int32_t* col,
                                     const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
                                     int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
-  return segreduce_impl(reduce, dtype, 0, -1, rowptr, col, w, x, ldx, out, ldo, argext, n_t, n_s, d, stream);
+  return segreduce_impl(reduce, dtype, 0, -1, nullptr, rowptr, col, w, x, ldx, out, ldo, argext, n_t, n_s, d, stream);
 }
 
-extern "C" int allset_segreduce_fwd_ex(int reduce, int dtype, int variant, int64_t nnz, const int32_t* rowptr,
-                                       const int32_t* col, const float* w, const void* x, int64_t ldx, void* out,
-                                       int64_t ldo, int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
-  return segreduce_impl(reduce, dtype, variant, nnz, rowptr, col, w, x, ldx, out, ldo, argext, n_t, n_s, d, stream);
+extern "C" int allset_segreduce_fwd_ex(int reduce, int dtype, int variant, int64_t nnz, const int32_t* row_order,
+                                       const int32_t* rowptr, const int32_t* col, const float* w, const void* x,
+                                       int64_t ldx, void* out, int64_t ldo, int32_t* argext, int64_t n_t, int64_t n_s,
+                                       int64_t d, void* stream) {
+  return segreduce_impl(reduce, dtype, variant, nnz, row_order, rowptr, col, w, x, ldx, out, ldo, argext, n_t, n_s, d, stream);
 }
 
-static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, const int32_t* rowptr, const int32_t* col,
+static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, const int32_t* row_order,
+                          const int32_t* rowptr, const int32_t* col,
                           const float* w, const void* x, int64_t ldx, void* out, int64_t ldo,
                           int32_t* argext, int64_t n_t, int64_t n_s, int64_t d, void* stream) {
   clear_error();
@@ -421,10 +428,10 @@ static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, 
   }
   if (dtype == ALLSET_F32)
     dispatch_segreduce<float, 4>(wide_ok, ext, w != nullptr, grid, st, rowptr, col, w, static_cast<const float*>(x), ldx,
-                                 static_cast<float*>(out), ldo, argext, nt, di, mean, sign);
+                                 static_cast<float*>(out), ldo, argext, nt, di, mean, sign, row_order);
   else
     dispatch_segreduce<bf16_t, 8>(wide_ok, ext, w != nullptr, grid, st, rowptr, col, w, static_cast<const bf16_t*>(x), ldx,
-                                  static_cast<bf16_t*>(out), ldo, argext, nt, di, mean, sign);
+                                  static_cast<bf16_t*>(out), ldo, argext, nt, di, mean, sign, row_order);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

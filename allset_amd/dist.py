@@ -209,7 +209,7 @@ class HipPmaKernels:
         from .functional import _variant
         csr = inc.by_dst
         return ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
-                           variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads))
+                           variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order)
 
     @staticmethod
     def bwd_stats(out, gout, m, l):
@@ -222,7 +222,7 @@ class HipPmaKernels:
         from .functional import _variant
         T = inc.by_src
         return ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, slope,
-                               variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]))
+                               variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]), row_order=T.row_order)
 
 
 def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, aggr: str = "add",

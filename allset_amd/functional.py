@@ -45,7 +45,7 @@ class _SegReduce(torch.autograd.Function):
         csr = inc.by_dst
         ext = reduce in (MAX, MIN)
         out, arg = ops.segreduce(reduce, csr.rowptr, csr.col, w_dst, x, inc.n_dst, want_arg=ext,
-                                 variant=1 if ext else _variant(csr, "segreduce", inc.n_dst, x))
+                                 variant=1 if ext else _variant(csr, "segreduce", inc.n_dst, x), row_order=csr.row_order)
         need_gw = w_dst is not None and ctx.needs_input_grad[1]
         ctx.inc, ctx.reduce, ctx.n_s, ctx.need_gw = inc, reduce, x.shape[0], need_gw
         ctx.save_for_backward(x if need_gw else None, w_dst, w_src, arg)
@@ -71,7 +71,7 @@ class _SegReduce(torch.autograd.Function):
                     inv = inc.inv_count_by_src()
                     w_src = inv if w_src is None else w_src * inv
                 gx, _ = ops.segreduce(SUM, T.rowptr, T.col, w_src, gout, ctx.n_s,
-                                      variant=_variant(T, "segreduce", ctx.n_s, gout))
+                                      variant=_variant(T, "segreduce", ctx.n_s, gout), row_order=T.row_order)
             else:
                 gx = ops.segmax_bwd(T.rowptr, T.col, inc.pos_dst_of_src(), w_src, arg, gout, ctx.n_s)
         if ctx.need_gw:
@@ -103,7 +103,7 @@ class _PmaAggregate(torch.autograd.Function):
     def forward(ctx, V: Tensor, alpha: Tensor, inc: Incidence, heads: int, slope: float):
         csr = inc.by_dst
         out, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
-                                variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads))
+                                variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order)
         ctx.inc, ctx.slope = inc, slope
         ctx.save_for_backward(V, alpha, out, m, l)
         ctx.mark_non_differentiable(m, l)
@@ -117,7 +117,8 @@ class _PmaAggregate(torch.autograd.Function):
         gout = gout.contiguous()
         stats = ops.pma_bwd_stats(out, gout, m, l)
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, ctx.slope,
-                                     variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]))
+                                     variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]),
+                                     row_order=T.row_order)
         return gV, galpha, None, None, None
 
 

@@ -102,8 +102,11 @@ int allset_segreduce_fwd(int reduce, int dtype,
  * unknowable to the library without a sync: mean degree nnz/n_t < 6 selects the short-row kernel), 1 = one wavefront
  * per row, 2 = short-row kernel (several consecutive rows per half-wave walked as one incidence stream; sum/mean only,
  * 16-byte aligned rows, d <= 256 f32 / 512 bf16; otherwise ALLSET_ERR_UNSUPPORTED).  Results are identical up to fp32
- * summation order (the short-row kernel sums a row strictly in CSR order). */
-int allset_segreduce_fwd_ex(int reduce, int dtype, int variant, int64_t nnz,
+ * summation order (the short-row kernel sums a row strictly in CSR order).
+ * row_order (int32[n_t], may be NULL; one-wavefront-per-row kernels only): a permutation giving the order in which rows
+ * are PROCESSED -- for skewed degree distributions the long rows of each XCD's row range are listed first so they do not
+ * set the tail of the launch (a 4096-incidence row occupies one wave for ~0.3 ms).  Results do not depend on it. */
+int allset_segreduce_fwd_ex(int reduce, int dtype, int variant, int64_t nnz, const int32_t* row_order,
                             const int32_t* rowptr, const int32_t* col, const float* w,
                             const void* x, int64_t ldx, void* out, int64_t ldo, int32_t* argext,
                             int64_t n_t, int64_t n_s, int64_t d, void* stream);
@@ -138,7 +141,7 @@ int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* col,
 
 /* Same with an explicit kernel choice (see allset_segreduce_fwd_ex): variant 0 auto by nnz / n_t, 1 one wavefront per
  * row, 2 short-row kernel (16-byte aligned rows, C a multiple of the packet width, H*C <= 256 f32 / 512 bf16). */
-int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptr, const int32_t* col,
                       const float* alpha, const void* V, int64_t ldv, float slope,
                       void* out, int64_t ldo, float* m, float* l,
                       int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
@@ -200,7 +203,7 @@ int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, floa
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* Same with an explicit kernel choice (variant as in allset_pma_fwd_ex; nnz / n_s decides in auto mode). */
-int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* rowptrT, const int32_t* colT,
+int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptrT, const int32_t* colT,
                           const float* alpha, const void* V, int64_t ldv,
                           const void* gout, int64_t ldg, const float* stats, float slope,
                           void* gV, int64_t ldgv, float* galpha,

@@ -317,3 +317,39 @@ def test_pma_bwd_short_row_kernel(H, C, mean_deg, device):
         torch.testing.assert_close(res[variant][1].cpu(), ao.grad, rtol=RTOL, atol=ATOL)
     if 2 in res:
         torch.testing.assert_close(res[2][0], res[1][0], rtol=1e-5, atol=1e-5)
+
+
+def test_long_rows_first_order_is_a_permutation_and_changes_nothing(device):
+    """Skewed degree distribution: the CSR carries a processing order (long rows first per XCD range); results of the
+    row-per-wave kernels must be bitwise identical with and without it."""
+    from allset_amd import Incidence, ops
+    from allset_amd.synthetic import random_hypergraph
+    hg = random_hypergraph(60000, 40000, 16, seed=2, device=device, dist="zipf", max_degree=4096)
+    inc = Incidence.from_edge_index(hg.edge_index, n_src=hg.n_v, n_dst=hg.n_e)
+    csr = inc.by_dst
+    assert csr.max_deg > 1000 and csr.row_order is not None
+    order = csr.row_order.long()
+    assert torch.equal(torch.sort(order).values, torch.arange(hg.n_e, device=device))
+    deg = csr.rowptr[1:] - csr.rowptr[:-1]
+    nb = (hg.n_e + 3) // 4
+    assert int(deg[order[0]]) >= int(deg[order[4 * (nb // 8 + (1 if nb % 8 else 0)) - 1]])       # long rows lead a range
+    assert inc.by_src.row_order is None                                                          # vertex side: not skewed
+    x = torch.randn(hg.n_v, 64, device=device)
+    a, _ = ops.segreduce(0, csr.rowptr, csr.col, None, x, hg.n_e, variant=1)
+    b, _ = ops.segreduce(0, csr.rowptr, csr.col, None, x, hg.n_e, variant=1, row_order=csr.row_order)
+    assert torch.equal(a, b)
+    alpha = torch.randn(hg.n_v, 4, device=device)
+    o1 = ops.pma_fwd(csr.rowptr, csr.col, alpha, x, 4, 0.2, hg.n_e, variant=1)
+    o2 = ops.pma_fwd(csr.rowptr, csr.col, alpha, x, 4, 0.2, hg.n_e, variant=1, row_order=csr.row_order)
+    assert all(torch.equal(u, v) for u, v in zip(o1, o2))
+    rev = inc.reversed(n_dst=hg.n_v)                   # E->V: its backward walks the hyperedge rows (long) as sources
+    g = torch.randn(hg.n_v, 64, device=device)
+    ev = torch.randn(hg.n_e, 64, device=device)
+    ae = torch.randn(hg.n_e, 4, device=device)
+    out, m, l = ops.pma_fwd(rev.by_dst.rowptr, rev.by_dst.col, ae, ev, 4, 0.2, hg.n_v)
+    st = ops.pma_bwd_stats(out, g, m, l)
+    T = rev.by_src
+    assert T.row_order is not None
+    r1 = ops.pma_bwd_src(T.rowptr, T.col, ae, ev, g, st, 0.2, variant=1)
+    r2 = ops.pma_bwd_src(T.rowptr, T.col, ae, ev, g, st, 0.2, variant=1, row_order=T.row_order)
+    assert all(torch.equal(u, v) for u, v in zip(r1, r2))

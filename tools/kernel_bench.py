@@ -49,6 +49,8 @@ for dist in args.dists.split(","):
     pass_bytes = nnz * (ES * d + 4) + (n + 1) * 4 + n * ES * d
     for label, csr in (("V->E (by hyperedge)", inc.by_dst), ("E->V (by vertex)", inc.by_src)):
         report(f"segreduce sum {label}", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, None, x, n, variant=1)), pass_bytes)
+        if csr.row_order is not None:
+            report(f"  .. long rows first", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, None, x, n, variant=1, row_order=csr.row_order)), pass_bytes)
         report(f"  .. short-row kernel", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, None, x, n, variant=2)), pass_bytes)
     csr, T = inc.by_dst, inc.by_src
     report("segreduce sum weighted", timeit(lambda: ops.segreduce(0, csr.rowptr, csr.col, w, x, n)), pass_bytes + nnz * 4)
@@ -60,6 +62,8 @@ for dist in args.dists.split(","):
         report("segmax_bwd", timeit(lambda: ops.segmax_bwd(T.rowptr, T.col, posT, None, arg, x, n)), nnz * (8 * d + 8) + (n + 1) * 4 + n * 4 * d)
         del out, arg
     report("  .. pma_fwd short-row kernel", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=2)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
+    if csr.row_order is not None:
+        report("  .. pma_fwd long rows first", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=1, row_order=csr.row_order)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
     report("pma_fwd", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=1)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
     o, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n)
     g = torch.randn(n, d, device=dev).to(DT)
