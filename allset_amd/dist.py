@@ -324,6 +324,37 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     return relu_dropout(p.tail(o), dropout, training)
 
 
+class ShardedSetGNN(torch.nn.Module):
+    """A :class:`allset_amd.SetGNN` executed on a hyperedge shard (reference models.py:450-484, non-GPR branch).
+
+    Holds the SAME module (same parameters / ``state_dict``); ``forward(x_owned)`` takes this rank's block of vertex
+    rows (``hg.v_lo:hg.v_hi`` of the padded vertex range) and returns the logits of those rows.  Every rank must call
+    it with its own block; replicated-parameter gradients are summed with :func:`allreduce_grads` after backward.
+    """
+
+    def __init__(self, model, hg: ShardedHypergraph, group=None, aggregate: Callable = _hip_deepsets, kernels=HipPmaKernels):
+        super().__init__()
+        if getattr(model, "GPR", False) or getattr(model, "LearnMask", False):
+            raise NotImplementedError("sharded execution covers the stock AllSetTransformer / AllDeepSets (no GPR / LearnMask)")
+        self.model, self.hg, self.group = model, hg, group
+        self._aggregate, self._kernels = aggregate, kernels
+
+    def forward(self, x_owned: Tensor) -> Tensor:
+        m = self.model
+        x = F.dropout(x_owned, p=0.2, training=m.training)                 # hard-coded input dropout (models.py:473)
+        for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):
+            if v2e.attention:
+                x = sharded_pma_layer(v2e, e2v, x, self.hg, dropout=m.dropout, training=m.training, group=self.group,
+                                      kernels=self._kernels)
+            else:
+                x = sharded_deepsets_layer(v2e, e2v, x, self.hg, aggr=m.aggr, dropout=m.dropout, training=m.training,
+                                           group=self.group, aggregate=self._aggregate)
+        return m.classifier(x)
+
+    def allreduce_grads(self) -> None:
+        allreduce_grads(list(self.model.parameters()), self.group)
+
+
 def allreduce_grads(params, group=None) -> None:
     """Sum replicated-parameter gradients over ranks with ONE flat all-reduce (the layer's parameters are a
     few hundred KB; bucketing them into a single message keeps this off the per-link latency floor)."""

@@ -40,7 +40,6 @@ class Incidence:
         self.nnz = by_dst.nnz
         self.device = by_dst.rowptr.device
         self._pos_dst_of_src: Optional[Tensor] = None     # by_src position -> by_dst position
-        self._pos_src_of_dst: Optional[Tensor] = None
         self._inv_cnt: Dict[str, Tensor] = {}
         self._wcache: Dict[Tuple, Tuple[Optional[Tensor], Optional[Tensor]]] = {}
         self._reversed: Optional["Incidence"] = None
@@ -87,9 +86,7 @@ class Incidence:
     def _make_reversed(self, n_dst: int) -> "Incidence":
         if n_dst > self.by_src.n_rows:
             raise ValueError("reversed(): n_dst exceeds the number of source rows")
-        rev = Incidence(self.by_src, self.by_dst, self.n_dst, n_dst, self.dst_extent, self.src_extent)
-        rev._pos_dst_of_src, rev._pos_src_of_dst = self._pos_src_of_dst, self._pos_dst_of_src
-        return rev
+        return Incidence(self.by_src, self.by_dst, self.n_dst, n_dst, self.dst_extent, self.src_extent)
 
     # ---- derived index maps (lazy, cached) -------------------------------------------------
     def pos_dst_of_src(self) -> Tensor:
@@ -118,7 +115,7 @@ class Incidence:
         if norm.numel() != self.nnz:
             raise ValueError(f"norm has {norm.numel()} entries for {self.nnz} incidences")
         if norm.requires_grad:
-            raise RuntimeError("weights(): differentiable norm goes through functional.route_weights")
+            raise RuntimeError("weights(): a norm that requires grad is routed inside functional.deepsets_aggregate")
         key = (norm.data_ptr(), norm._version, norm.dtype, norm.numel())
         hit = self._wcache.get(key)
         if hit is None:
@@ -150,9 +147,5 @@ def cached_incidence(edge_index: Tensor, n_src: Optional[int], n_dst: Optional[i
     inc = Incidence.from_edge_index(edge_index, n_src=n_src, n_dst=n_dst)
     if len(_CACHE) >= _CACHE_LIMIT:
         _CACHE.pop(next(iter(_CACHE)))
-    try:
-        ref = weakref.ref(edge_index)
-    except TypeError:  # pragma: no cover
-        ref = lambda: edge_index  # noqa: E731
-    _CACHE[key] = (ref, inc)
+    _CACHE[key] = (weakref.ref(edge_index), inc)
     return inc

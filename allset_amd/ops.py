@@ -158,15 +158,16 @@ def long_rows_first_order(rowptr: Tensor, n_rows: int, nnz: int, max_deg: int) -
     slot, taken = 0, 0
     for xcd in range(8):
         cnt = min(4 * (q + 1 if xcd < r else q), n_rows - slot)      # row slots of this XCD
-        mine = long_rows[xcd::8][:cnt]
+        mine = long_rows[xcd::8]
         k = int(mine.numel())
+        if k > cnt:
+            return None                                        # more long rows than slots: not a skew problem
         order[slot:slot + k] = mine
         order[slot + k:slot + cnt] = rest[taken:taken + cnt - k]
         taken += cnt - k
         slot += cnt
-    leftover = long_rows.numel() - sum(int(long_rows[x::8][:min(4 * (q + 1 if x < r else q), n_rows)].numel()) for x in range(8))
-    if slot != n_rows or taken != rest.numel() or leftover != 0:
-        return None                                            # degenerate split: keep natural order
+    if slot != n_rows or taken != rest.numel():
+        return None
     return order.to(torch.int32).contiguous()
 
 

@@ -261,3 +261,58 @@ def test_sharded_pma_layer_equals_unsharded():
     torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=1e-5)
     for got, exp in zip(results[0][3], ref_pg):
         torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# model level: ShardedSetGNN == SetGNN (oracle) on the owned vertex blocks
+# ---------------------------------------------------------------------------------------------
+
+def _model_worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import cases
+        from allset_amd import SetGNN, dist as adist
+        n_v, n_e, d, ei, _, x, G = _problem(world)
+        args = cases.make_args(mode, d, 32, 5, All_num_layers=2)
+        torch.manual_seed(11)
+        model = SetGNN(args).eval()
+        owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
+        loc, gids = adist.local_shard(ei, owner, rank)
+        keep = owner[ei[1]] == rank
+        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=torch.ones(int(keep.sum()), dtype=torch.int64))
+        hg.v2e = (loc, hg.n_e_local)
+        hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        sharded = adist.ShardedSetGNN(model, hg, aggregate=_oracle_aggregate, kernels=TorchPmaKernels)
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+        out = sharded(xp[hg.v_lo:hg.v_hi])
+        q.put((rank, out.detach().numpy().copy(), {k: v.numpy().copy() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ds_add", "pma_h4"])
+def test_sharded_setgnn_equals_oracle(mode):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cases
+    from oracle import allset_oracle as oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_v, n_e, d, ei, _, x, G = _problem(world)
+    args = cases.make_args(mode, d, 32, 5, All_num_layers=2)
+    sd = {k: torch.from_numpy(v) for k, v in results[0][2].items()}
+    ref = oracle.setgnn_forward(sd, args, x, ei, torch.ones(ei.shape[1], dtype=torch.int64))
+    got = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
