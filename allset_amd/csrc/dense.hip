@@ -451,6 +451,39 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
   }
 }
 
+
+// out[s][c] = sum of part[p][c] over the s-th slab of kRedRows rows (p < P, c < M): one level of the tree that
+// finishes every split-K / per-block partial scheme above.  2-D grid (column quads x row slabs), 8 row groups per
+// workgroup with 8 independent loads each, combined through LDS.  Two levels reduce 512 x 16K partials (32 MB).
+constexpr int kRedSplit = 8;                   // row groups per workgroup (256 threads = 32 column quads x 8 groups)
+constexpr int kRedRows = 64;                   // rows per slab
+
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ part, int64_t P, int64_t M,
+                                                                float* __restrict__ out) {
+  __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
+  const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
+  const int64_t c = (static_cast<int64_t>(blockIdx.x) * (kBlock / kRedSplit) + cq) * 4;
+  const int64_t p0 = static_cast<int64_t>(blockIdx.y) * kRedRows;
+  float4 acc = make_float4(0, 0, 0, 0);
+  if (c < M) {
+    float4 v[kRedRows / kRedSplit];
+#pragma unroll
+    for (int i = 0; i < kRedRows / kRedSplit; ++i) {
+      const int64_t p = p0 + rg + static_cast<int64_t>(i) * kRedSplit;
+      v[i] = p < P ? *reinterpret_cast<const float4*>(part + p * M + c) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kRedRows / kRedSplit; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+  }
+  red[rg][cq] = acc;
+  __syncthreads();
+  if (rg == 0 && c < M) {
+#pragma unroll
+    for (int g = 1; g < kRedSplit; ++g) { const float4 t = red[g][cq]; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+    *reinterpret_cast<float4*>(out + static_cast<int64_t>(blockIdx.y) * M + c) = acc;
+  }
+}
+
 static inline int ln_lpr(int64_t d) {
   int lpr = 8;
   while (lpr * 4 < d && lpr < 64) lpr <<= 1;
@@ -653,6 +686,30 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
                                               tiles_i, rows_per_slice, pro);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, float* scratch, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(P >= 1 && M >= 1, "reduce_partials: bad size");
+  ALLSET_REQUIRE(part && out, "reduce_partials: null pointer");
+  if (M % 4 != 0 || !aligned16(part) || !aligned16(out) || (scratch && !aligned16(scratch))) {
+    set_error("reduce_partials: M must be a multiple of 4 and the buffers 16-byte aligned");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  const int64_t slabs = (P + kRedRows - 1) / kRedRows;
+  ALLSET_REQUIRE(slabs == 1 || scratch != nullptr, "reduce_partials: P > %d needs a scratch buffer of ceil(P/%d)*M floats", kRedRows, kRedRows);
+  ALLSET_REQUIRE(slabs <= kRedRows, "reduce_partials: at most %d partial rows", kRedRows * kRedRows);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t quads = M / 4, per_block = kBlock / kRedSplit;
+  const unsigned gx = static_cast<unsigned>((quads + per_block - 1) / per_block);
+  if (slabs == 1) {
+    reduce_partials_kernel<<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out);
+  } else {
+    reduce_partials_kernel<<<dim3(gx, static_cast<unsigned>(slabs)), kBlock, 0, st>>>(part, P, M, scratch);
+    reduce_partials_kernel<<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out);
+  }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

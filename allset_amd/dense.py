@@ -8,6 +8,7 @@ Dropout masks are a counter-based hash of (seed, element index): the seed is dra
 """
 from __future__ import annotations
 
+import os
 from ctypes import byref, c_int64
 from typing import Optional, Tuple
 
@@ -32,6 +33,24 @@ def _check_f32(*ts: Tensor) -> None:
 
 
 # ---- raw wrappers --------------------------------------------------------------------------------
+
+def reduce_partials(part: Tensor) -> Tensor:
+    """Sum a partial buffer [P, ...] over its first axis with the dedicated kernel (the torch reduction runs at
+    ~1 TB/s on these shapes); returns a tensor shaped like ``part[0]``."""
+    P = part.shape[0]
+    if P == 1:
+        return part[0]
+    M = part[0].numel()
+    if M % 4 != 0 or P > 4096 or os.environ.get("ALLSET_TORCH_REDUCE", "0") == "1":
+        return part.sum(dim=0)
+    dev = part.device
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=dev)
+    scratch = torch.empty(((P + 63) // 64) * M, dtype=torch.float32, device=dev) if P > 64 else None
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_reduce_partials(ptr(part), P, M, ptr(out), ptr(scratch), stream_of(dev)),
+              "allset_reduce_partials")
+    return out
+
 
 def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p: float, seed: int
            ) -> Tuple[Tensor, Tensor]:
@@ -62,7 +81,7 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
         check(lib.allset_ln_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
                                 seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, stream_of(dev)),
               "allset_ln_bwd")
-    red = partials.sum(dim=0)
+    red = reduce_partials(partials)
     return gx, red[0], red[1]
 
 
@@ -80,8 +99,8 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
     with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * 4):
         check(lib.allset_wgrad(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,
                                stream_of(dev)), "allset_wgrad")
-    gw = part_w.sum(dim=0) if ns.value > 1 else part_w[0]
-    gb = (part_b.sum(dim=0) if ns.value > 1 else part_b[0]) if want_bias else None
+    gw = reduce_partials(part_w)
+    gb = reduce_partials(part_b) if want_bias else None
     return gw, gb
 
 
@@ -131,8 +150,8 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
                                      ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                      ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
                                      ptr(part_w), ptr(part_b), ns.value, n, O, I, stream_of(dev)), "allset_wgrad_fused")
-    gw = part_w.sum(dim=0) if ns.value > 1 else part_w[0]
-    gb = (part_b.sum(dim=0) if ns.value > 1 else part_b[0]) if want_bias else None
+    gw = reduce_partials(part_w)
+    gb = reduce_partials(part_b) if want_bias else None
     return gw, gb
 
 
@@ -160,7 +179,7 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
                                           n, O, I, stream_of(dev)), "allset_fused_linear_bwd")
     if partials is None:
         return gx, None, None
-    red = partials.sum(dim=0)
+    red = reduce_partials(partials)
     return gx, red[0], red[1]
 
 

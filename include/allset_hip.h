@@ -209,6 +209,10 @@ int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* ro
                           void* gV, int64_t ldgv, float* galpha,
                           int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream);
 
+/* out[c] = sum_p part[p*M + c], p < P <= 4096: sums the partial buffers the kernels above hand back (M % 4 == 0).
+ * scratch: f32[ceil(P/64) * M], required when P > 64 (two-level tree). */
+int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, float* scratch, void* stream);
+
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;
  *   u  = dropout_{p_in,seed_in}( LayerNorm_{stats,gamma,beta}( relu_in ? relu(x) : x ) )  (LayerNorm iff stats != NULL). */

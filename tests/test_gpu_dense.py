@@ -273,3 +273,14 @@ def test_mlp_fused_and_unfused_paths_agree(device):
         assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
         frac = float((out == 0).float().mean())
         assert 0.6 < frac < 0.9          # relu (~half) and dropout 0.5 -> ~75 % zeros
+
+
+@pytest.mark.parametrize("P,M", [(1, 8), (7, 128), (64, 16384), (65, 256), (512, 16384), (2048, 260)])
+def test_reduce_partials(P, M, device):
+    from allset_amd import dense
+    torch.manual_seed(P + M)
+    part = torch.randn(P, M, device=device)
+    got = dense.reduce_partials(part)
+    torch.testing.assert_close(got.double().cpu(), part.double().sum(0).cpu(), rtol=1e-5, atol=1e-4)
+    part3 = torch.randn(P, 2, M // 2, device=device)
+    torch.testing.assert_close(dense.reduce_partials(part3), part3.sum(0), rtol=1e-5, atol=1e-4)
