@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Per-rank COMPUTE time of an N-rank weak-scaling step, measured on one GPU: rank 0's shard of the N-rank job
+(N*1M vertices, 1M local hyperedges) with the two collectives replaced by local stand-ins of identical shapes
+(all-gather -> tile the owned block N times, reduce-scatter -> keep the owned slice).  What is left out is exactly the
+xGMI time; the output bounds the scaling the driver can measure:  efficiency <= t(1) / (t_compute(N) + t_comm(N))."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from allset_amd import dist as adist
+from allset_amd.layers import HalfNLHconv
+from allset_amd.synthetic import random_hypergraph
+dev = torch.device("cuda:0")
+d, n_loc = 128, 1_000_000
+model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
+for world in (1, 2, 4, 8):
+    adist._all_gather_rows = (lambda x, group=None, w=world: x if w == 1 else x.repeat((w,) + (1,) * (x.dim() - 1)))
+    adist._reduce_scatter_rows = (lambda x, group=None, w=world: x if w == 1 else x[: x.shape[0] // w].contiguous())
+    adist._skip_collective = lambda group=None: True
+    n_v = n_loc * world
+    shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev)
+    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm).build_incidences()
+    attn = model == "pma"
+    torch.manual_seed(0)
+    a = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).train()
+    b = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).train()
+    params = list(a.parameters()) + list(b.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+    x = torch.randn(n_loc, d, device=dev, requires_grad=True)
+    G = torch.randn(n_loc, d, device=dev)
+    def step():
+        opt.zero_grad(set_to_none=True); x.grad = None
+        out = adist.sharded_pma_layer(a, b, x, hg, dropout=0.5, training=True) if attn else \
+            adist.sharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
+        out.backward(G); opt.step()
+    for _ in range(3): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): step()
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+    exch = n_v * d * 4 * (world - 1) / world            # bytes a rank receives per collective
+    print(f"{model} world={world}: per-rank compute {ms:7.2f} ms   exchange per collective {exch/1e9:5.2f} GB x4 per step"
+          f"   (at 400 GB/s inbound: {4*exch/400e9*1e3:6.1f} ms)", flush=True)
+    del hg, shard, a, b, x, G, opt
+    torch.cuda.empty_cache()
