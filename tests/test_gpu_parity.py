@@ -144,3 +144,45 @@ def test_setgnn_bf16_storage_tracks_fp32(device):
         assert torch.isfinite(a).all()
         assert float((a - b).abs().mean()) <= 3e-2 * float(b.abs().mean()) + 1e-4
         assert float((a - b).abs().max()) <= 0.2 * float(b.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("layers", [1, 2, 3])
+@pytest.mark.parametrize("kind,inorm", [("ln", True), ("ln", False), ("None", False), ("bn", True)])
+@pytest.mark.parametrize("width", [64, 72])
+def test_mlp_depths_and_norms_match_oracle(layers, kind, inorm, width, device):
+    """MLP (reference layers.py:496-579) at depths 1-3 with every normalisation, on the fused (width 64) and unfused
+    (width 72) device paths, eval mode, against the oracle's functional MLP on the CPU."""
+    from allset_amd import MLP
+    from oracle import allset_oracle as oracle
+    torch.manual_seed(layers * 10 + width)
+    m = MLP(width, width, width, layers, dropout=0.5, Normalization=kind, InputNorm=inorm).eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(517, width)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    ref = oracle.mlp_forward(sd, "", xo, kind)
+    ref.square().sum().backward()
+    md = m.to(device)
+    xg = x.to(device).requires_grad_(True)
+    out = md(xg)
+    out.square().sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(xg.grad.cpu(), xo.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(xo.grad.abs().max())))
+
+
+@pytest.mark.parametrize("aggr", ["add", "mean", "max"])
+def test_halfnlhconv_identity_mlps(aggr, device):
+    """num_layers = 0 -> f_enc / f_dec are identities: relu -> aggregate -> relu only."""
+    import numpy as np
+    from allset_amd import HalfNLHconv
+    from oracle import allset_oracle as oracle
+    rng = np.random.default_rng(4)
+    ei = torch.from_numpy(np.stack([rng.integers(0, 40, 300), rng.integers(0, 25, 300)]).astype(np.int64))
+    ei[1, -1] = 24
+    x = torch.from_numpy(rng.standard_normal((40, 32)).astype(np.float32))
+    conv = HalfNLHconv(32, 32, 32, 0, 0.0, "ln", True, attention=False).to(device).eval()
+    out = conv(x.to(device), ei.to(device), torch.ones(300, dtype=torch.int64, device=device), aggr)
+    ref = oracle.halfnlhconv_forward({}, "", x, ei, torch.ones(300, dtype=torch.int64), aggr, False, 1, "ln")
+    torch.testing.assert_close(out.cpu(), ref, rtol=RTOL, atol=ATOL)
