@@ -41,23 +41,23 @@ SIGNATURES = {
                            c_int64, c_int64, c_int64, c_int64, _P],
     "allset_pma_bwd_src_ex": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,
                               c_int64, c_int64, c_int64, c_int64, _P],
-    "allset_ln_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64, c_int64, _P],
+    "allset_ln_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64, c_int64, _P, _P],
     "allset_ln_bwd_partials": [c_int64, c_int64, POINTER(c_int64)],
     "allset_ln_bwd": [_P, c_int64, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
-                      c_int64, c_int64, _P],
-    "allset_relu_dropout_fwd": [_P, c_float, c_uint64, _P, c_int64, _P],
+                      c_int64, c_int64, _P, _P],
+    "allset_relu_dropout_fwd": [_P, c_float, c_uint64, _P, c_int64, _P, _P],
     "allset_relu_dropout_bwd": [_P, _P, c_float, _P, c_int64, _P],
     "allset_wgrad_slices": [c_int64, c_int64, c_int64, POINTER(c_int64)],
     "allset_wgrad": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_reduce_partials": [_P, c_int64, c_int64, _P, _P, _P],
     "allset_wgrad_fused": [_P, c_int64, _P, c_int64, c_float, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, _P,
-                           c_int64, c_int64, c_int64, c_int64, _P],
+                           c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_fused_linear_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_partials": [c_int64, POINTER(c_int64)],
     "allset_fused_linear_bwd": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P,
-                                c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P],
+                                c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_fused_linear_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
-                                _P, c_int64, _P, c_int64, c_int64, c_int64, _P],
+                                _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P],
 }
 EXPORTED_SYMBOLS = sorted(list(SIGNATURES) + ["allset_last_error"])
 

@@ -164,6 +164,12 @@ __device__ __forceinline__ uint32_t pair_hash(uint64_t seed, int64_t pair) {
   const uint32_t lo = static_cast<uint32_t>(pair), hi = static_cast<uint32_t>(static_cast<uint64_t>(pair) >> 32);
   return mix32((lo ^ static_cast<uint32_t>(seed)) * 0x9E3779B1U + hi * 0x85EBCA77U + static_cast<uint32_t>(seed >> 32));
 }
+// Seeds: entry points take a host-side 64-bit seed by value and, optionally, `seed_base`, a DEVICE pointer to a 64-bit
+// counter.  With a counter the effective seed is counter * golden-ratio + seed, read at kernel start -- so a captured
+// hipGraph draws fresh masks on every replay (the host value is baked into the graph, the counter is not).
+__device__ __forceinline__ uint64_t resolve_seed(const uint64_t* base, uint64_t salt) {
+  return base ? (*base) * 0x9E3779B97F4A7C15ULL + salt : salt;
+}
 __device__ __forceinline__ uint32_t drop_threshold(float p) { return static_cast<uint32_t>(p * 65536.0f); }
 __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, uint32_t thr, float inv_keep) {
   const uint32_t h = pair_hash(seed, idx >> 1);

@@ -31,7 +31,8 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, int relu_in, float p, uint64_t seed, float* __restrict__ y, int64_t ldy,
-    float* __restrict__ stats, int64_t n, int d) {
+    float* __restrict__ stats, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
   const int lane = lane_id();
   const int grp = (threadIdx.x >> 6) * NS + lane / LPR;            // row group inside the block
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(
 __global__ __launch_bounds__(kBlock) void ln_fwd_generic_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, int relu_in, float p, uint64_t seed, float* __restrict__ y, int64_t ldy,
-    float* __restrict__ stats, int64_t n, int d) {
+    float* __restrict__ stats, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
   const int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = lane_id();
@@ -117,7 +119,8 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx,
     const float* __restrict__ stats, const float* __restrict__ gamma, int relu_in, float p, uint64_t seed,
-    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d) {
+    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
   constexpr int kGroups = kWavesPerBlock * NS;
   __shared__ float red[kGroups][2][LPR * 4];
@@ -182,16 +185,20 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(
   }
 }
 
-// generic width backward: one wave per row per iteration, column partials via per-wave registers are not
-// possible for arbitrary d, so dgamma/dbeta partials are accumulated with float atomics into part[0] (d wide).
+// generic width backward: one wave per row per iteration; each lane owns 8 column slots per sweep and accumulates
+// dgamma/dbeta over the block's rows in registers; the block's waves are combined through LDS in a fixed order and
+// written to the block's own partial row (no atomics: the result is run-to-run deterministic).
 __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx,
     const float* __restrict__ stats, const float* __restrict__ gamma, int relu_in, float p, uint64_t seed,
-    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d) {
+    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
   const int lane = lane_id();
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const uint32_t thr = drop_threshold(p);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  __shared__ float red[kWavesPerBlock][2][8 * kWave];
+  const int wave = threadIdx.x >> 6;
   // column c is always handled by lane c % 64 of some wave; accumulate per (wave, column-slot) over rows
   for (int cb = 0; cb < d; cb += kWave * 8) {       // up to 8 column slots per lane per sweep
     float dg[8], db[8];
@@ -232,16 +239,27 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = cb + k * kWave + lane;
-      if (c < d) { atomicAdd(&part[c], dg[k]); atomicAdd(&part[d + c], db[k]); }
+    for (int k = 0; k < 8; ++k) { red[wave][0][k * kWave + lane] = dg[k]; red[wave][1][k * kWave + lane] = db[k]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * 8 * kWave; t += kBlock) {
+      const int which = t / (8 * kWave), slot = t % (8 * kWave);
+      const int c = cb + slot;
+      if (c < d) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) sum += red[w][which][slot];
+        part[(static_cast<int64_t>(blockIdx.x) * 2 + which) * d + c] = sum;
+      }
     }
+    __syncthreads();
   }
 }
 
 // y = dropout(relu(x)); backward gx = gy * inv_keep where y > 0 (y > 0 <=> kept and x > 0), else 0
 __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(const float* __restrict__ x, float p, uint64_t seed,
-                                                                  float* __restrict__ y, int64_t n4) {
+                                                                  float* __restrict__ y, int64_t n4,
+                                                                  const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const uint32_t thr = drop_threshold(p);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4;
@@ -275,7 +293,8 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* _
 
 // scalar tail / unaligned variant (n elements)
 __global__ void relu_dropout_fwd_scalar_kernel(const float* __restrict__ x, float p, uint64_t seed, float* __restrict__ y,
-                                               int64_t n, int64_t offset) {
+                                               int64_t n, int64_t offset, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const uint32_t thr = drop_threshold(p);
   const int64_t i = offset + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -310,6 +329,7 @@ constexpr int kWgRows = 32;
 struct WgradPro {
   const float* y; int64_t ldy; float keep_out;
   const float* stats; const float* gamma; const float* beta; int has_ln; int relu_in; float p_in; uint64_t seed_in;
+  const uint64_t* seed_base;
 };
 
 template <bool PRO>
@@ -347,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
     }
     keep_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
     thr_in = drop_threshold(pro.p_in);
+    pro.seed_in = resolve_seed(pro.seed_base, pro.seed_in);
   }
   float4 ry[4];
   float2 rst[4];
@@ -496,7 +517,7 @@ using namespace allset;
 
 extern "C" int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                              int relu_in, float p, uint64_t seed, float* y, int64_t ldy, float* stats,
-                             int64_t n, int64_t d, void* stream) {
+                             int64_t n, int64_t d, const uint64_t* seed_base, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "ln_fwd: bad size");
   ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_fwd: dropout p must be in [0,1)");
@@ -512,14 +533,14 @@ extern "C" int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, co
     const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
     const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
     switch (lpr) {
-      case 8:  ln_fwd_kernel<8><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
-      case 16: ln_fwd_kernel<16><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
-      case 32: ln_fwd_kernel<32><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
-      default: ln_fwd_kernel<64><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di); break;
+      case 8:  ln_fwd_kernel<8><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base); break;
+      case 16: ln_fwd_kernel<16><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base); break;
+      case 32: ln_fwd_kernel<32><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base); break;
+      default: ln_fwd_kernel<64><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base); break;
     }
   } else {
     const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
-    ln_fwd_generic_kernel<<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di);
+    ln_fwd_generic_kernel<<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
@@ -529,7 +550,11 @@ extern "C" int allset_ln_bwd_partials(int64_t n, int64_t d, int64_t* n_partials)
   clear_error();
   ALLSET_REQUIRE(n_partials != nullptr && n >= 0 && d >= 1, "ln_bwd_partials: bad argument");
   const bool fast = d <= 256 && d % 4 == 0;
-  if (!fast) { *n_partials = 1; return ALLSET_OK; }
+  if (!fast) {      // generic kernel: one partial row per block, 4 rows per block-iteration, at most 512 blocks
+    const int64_t want = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    *n_partials = want < 1 ? 1 : (want > 512 ? 512 : want);
+    return ALLSET_OK;
+  }
   const int lpr = ln_lpr(d);
   const int64_t groups = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
   const int64_t want = (n + groups - 1) / groups;
@@ -539,7 +564,8 @@ extern "C" int allset_ln_bwd_partials(int64_t n, int64_t d, int64_t* n_partials)
 
 extern "C" int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* stats,
                              const float* gamma, int relu_in, float p, uint64_t seed, float* gx, int64_t ldgx,
-                             float* partials, int64_t n_partials, int64_t n, int64_t d, void* stream) {
+                             float* partials, int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base,
+                             void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "ln_bwd: bad size");
   ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_bwd: dropout p must be in [0,1)");
@@ -558,23 +584,27 @@ extern "C" int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64
   if (fast) {
     const unsigned grid = static_cast<unsigned>(n_partials);
     switch (ln_lpr(d)) {
-      case 8:  ln_bwd_kernel<8><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
-      case 16: ln_bwd_kernel<16><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
-      case 32: ln_bwd_kernel<32><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
-      default: ln_bwd_kernel<64><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di); break;
+      case 8:  ln_bwd_kernel<8><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base); break;
+      case 16: ln_bwd_kernel<16><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base); break;
+      case 32: ln_bwd_kernel<32><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base); break;
+      default: ln_bwd_kernel<64><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base); break;
     }
   } else {
-    // generic path accumulates into partial row 0 with atomics; the other partial rows (if any) are zeroed
-    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * d * sizeof(float), st));
+    // generic path: block b owns partial row b; rows past the grid (if the caller sized for the fast path) are zeroed
     const int64_t want = (n + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned grid = static_cast<unsigned>(want > 1024 ? 1024 : want);
-    ln_bwd_generic_kernel<<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di);
+    const int64_t cap = n_partials < 512 ? n_partials : 512;
+    const unsigned grid = static_cast<unsigned>(want > cap ? cap : want);
+    if (n_partials > grid)
+      ALLSET_HIP_CHECK(hipMemsetAsync(partials + static_cast<size_t>(grid) * 2 * d, 0,
+                                      static_cast<size_t>(n_partials - grid) * 2 * d * sizeof(float), st));
+    ln_bwd_generic_kernel<<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
 
-extern "C" int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, float* y, int64_t numel, void* stream) {
+extern "C" int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, float* y, int64_t numel,
+                                       const uint64_t* seed_base, void* stream) {
   clear_error();
   ALLSET_REQUIRE(numel >= 0, "relu_dropout_fwd: negative size");
   ALLSET_REQUIRE(p >= 0.f && p < 1.f, "relu_dropout_fwd: dropout p must be in [0,1)");
@@ -585,12 +615,12 @@ extern "C" int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, f
   if (aligned16(x) && aligned16(y) && numel >= 4) {
     const int64_t n4 = numel / 4;
     const int64_t want = (n4 + kBlock - 1) / kBlock;
-    relu_dropout_fwd_kernel<<<static_cast<unsigned>(want > 8192 ? 8192 : want), kBlock, 0, st>>>(x, p, seed, y, n4);
+    relu_dropout_fwd_kernel<<<static_cast<unsigned>(want > 8192 ? 8192 : want), kBlock, 0, st>>>(x, p, seed, y, n4, seed_base);
     done = n4 * 4;
   }
   if (done < numel) {
     const int64_t rest = numel - done;
-    relu_dropout_fwd_scalar_kernel<<<static_cast<unsigned>((rest + kBlock - 1) / kBlock), kBlock, 0, st>>>(x, p, seed, y, numel, done);
+    relu_dropout_fwd_scalar_kernel<<<static_cast<unsigned>((rest + kBlock - 1) / kBlock), kBlock, 0, st>>>(x, p, seed, y, numel, done, seed_base);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
@@ -659,7 +689,8 @@ extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_
 extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
                                   const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                                   int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
-                                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+                                  int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                                  void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_fused: bad size");
   ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_fused: bad slice count");
@@ -682,7 +713,7 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
   WgradPro pro;
   pro.y = y; pro.ldy = ldy; pro.keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   pro.stats = stats; pro.gamma = gamma; pro.beta = beta; pro.has_ln = stats != nullptr;
-  pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in;
+  pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in; pro.seed_base = seed_base;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
                                               tiles_i, rows_per_slice, pro);

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W,
     const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
-    int64_t ldy, float* __restrict__ stats, int64_t n) {
+    int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base) {
+  seed_in = resolve_seed(seed_base, seed_in);
+  seed_out = resolve_seed(seed_base, seed_out);
   constexpr int N = 32 * NT;
   constexpr int PITCH = KD + 1;
   constexpr int KH = KD / 2;                       // columns per lane
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_bwd_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
     const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
     const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* __restrict__ gx,
-    int64_t ldgx, float* __restrict__ part, int64_t n) {
+    int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base) {
+  seed_in = resolve_seed(seed_base, seed_in);
   constexpr int I = 32 * IT;
   constexpr int OH = OD / 2;
   __shared__ __attribute__((aligned(16))) float sW[OD * I];          // W as stored: [o][i], unit stride in i
@@ -345,7 +348,8 @@ extern "C" int allset_fused_linear_supported(int64_t K, int64_t N) {
 extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                        int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                                        int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
-                                       float* stats, int64_t n, int64_t K, int64_t N, void* stream) {
+                                       float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
+                                       void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_fwd: dropout p must be in [0,1)");
@@ -367,7 +371,7 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
 #define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                        \
   fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in,     \
                                                                             seed_in, W, bias, relu_out, p_out, seed_out, \
-                                                                            y, ldy, stats, n)
+                                                                            y, ldy, stats, n, seed_base)
 #define ALLSET_FUSED_FWD(KD, NT)                                                      \
   do {                                                                                \
     const int v = (has_ln ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);    \
@@ -411,7 +415,7 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
                                        const float* W, const float* x, int64_t ldx, const float* stats,
                                        const float* gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
                                        int64_t ldgx, float* partials, int64_t n_partials, int64_t n, int64_t O,
-                                       int64_t I, void* stream) {
+                                       int64_t I, const uint64_t* seed_base, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd: negative size");
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_bwd: dropout p must be in [0,1)");
@@ -436,7 +440,7 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
   const hipStream_t st = static_cast<hipStream_t>(stream);
 #define ALLSET_FUSED_BWD_F(OD, IT, LN, DI)                                                                                   \
   fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma,     \
-                                                                        relu_in, p_in, seed_in, gx, ldgx, partials, n)
+                                                                        relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base)
 #define ALLSET_FUSED_BWD(OD, IT)                                          \
   do {                                                                    \
     if (has_ln) { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, true, true); else ALLSET_FUSED_BWD_F(OD, IT, true, false); }     \

@@ -22,8 +22,42 @@ from .ops import _ld, _rowmajor, _timed
 Tensor = torch.Tensor
 
 
+class _SeedSource:
+    """Where dropout seeds come from.  Eager: a fresh 63-bit draw from torch's CPU generator per dropout site.
+    Under ``device_seed_counter`` (hipGraph capture, ``graphs.py``): the host value is only a per-site salt
+    (1, 2, 3, ...) and the randomness comes from a device-resident int64 counter the kernels read at start
+    (``seed_base`` in include/allset_hip.h), so replays of a captured graph draw fresh masks."""
+    base: Optional[Tensor] = None
+    salt: int = 0
+
+
 def _draw_seed() -> int:
+    if _SeedSource.base is not None:
+        _SeedSource.salt += 1
+        return _SeedSource.salt
     return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+def _seed_base() -> Optional[Tensor]:
+    return _SeedSource.base
+
+
+class device_seed_counter:
+    """Context manager: dropout sites inside draw their masks from ``counter`` (int64 device tensor, 1 element)."""
+
+    def __init__(self, counter: Tensor):
+        if counter.dtype != torch.int64 or counter.numel() != 1 or not counter.is_cuda:
+            raise _lib.AllSetHipError("device_seed_counter needs a 1-element int64 device tensor")
+        self.counter = counter
+
+    def __enter__(self):
+        self.prev = (_SeedSource.base, _SeedSource.salt)
+        _SeedSource.base, _SeedSource.salt = self.counter, 0
+        return self
+
+    def __exit__(self, *exc):
+        _SeedSource.base, _SeedSource.salt = self.prev
+        return False
 
 
 def _check_f32(*ts: Tensor) -> None:
@@ -52,8 +86,8 @@ def reduce_partials(part: Tensor) -> Tensor:
     return out
 
 
-def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p: float, seed: int
-           ) -> Tuple[Tensor, Tensor]:
+def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p: float, seed: int,
+           seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     dev = require_device(x, gamma, beta)
     _check_f32(x, gamma, beta)
     x = _rowmajor(x)
@@ -62,13 +96,14 @@ def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p:
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("ln_fwd", dev, 2 * n * d * 4):
         check(_lib.load().allset_ln_fwd(ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
-                                        int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, stream_of(dev)),
+                                        int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, ptr(seed_base),
+                                        stream_of(dev)),
               "allset_ln_fwd")
     return y, stats
 
 
-def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int
-           ) -> Tuple[Tensor, Tensor, Tensor]:
+def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
+           seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     dev = require_device(gy, x, stats, gamma)
     gy, x = _rowmajor(gy), _rowmajor(x)
     n, d = x.shape
@@ -79,7 +114,8 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
     gx = torch.empty((n, d), dtype=x.dtype, device=dev)
     with torch.cuda.device(dev), _timed("ln_bwd", dev, 3 * n * d * 4):
         check(lib.allset_ln_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
-                                seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, stream_of(dev)),
+                                seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
+                                stream_of(dev)),
               "allset_ln_bwd")
     red = reduce_partials(partials)
     return gx, red[0], red[1]
@@ -110,8 +146,8 @@ def fused_linear_supported(K: int, N: int) -> bool:
 
 def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor] = None,
                      beta: Optional[Tensor] = None, eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0,
-                     seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0, seed_out: int = 0
-                     ) -> Tuple[Tensor, Optional[Tensor]]:
+                     seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0, seed_out: int = 0,
+                     seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """y = epi(pro(x) @ W^T + b) in one pass (csrc/fused_mlp.hip).  Returns (y, stats or None)."""
     dev = require_device(x, weight, bias, gamma, beta)
     _check_f32(x, weight, bias, gamma, beta)
@@ -126,13 +162,13 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
             ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
             ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
             ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
-            ptr(stats), n, K, N, stream_of(dev)), "allset_fused_linear_fwd")
+            ptr(stats), n, K, N, ptr(seed_base), stream_of(dev)), "allset_fused_linear_fwd")
     return y, stats
 
 
 def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats: Optional[Tensor],
                 gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+                want_bias: bool = True, seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Weight/bias gradient of the fused Linear with both operands recomputed on the fly (csrc/dense.hip)."""
     dev = require_device(gy, y, x, stats, gamma, beta)
     gy, x = _rowmajor(gy), _rowmajor(x)
@@ -149,15 +185,16 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
         check(lib.allset_wgrad_fused(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),
                                      ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                      ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
-                                     ptr(part_w), ptr(part_b), ns.value, n, O, I, stream_of(dev)), "allset_wgrad_fused")
+                                     ptr(part_w), ptr(part_b), ns.value, n, O, I, ptr(seed_base), stream_of(dev)),
+              "allset_wgrad_fused")
     gw = reduce_partials(part_w)
     gb = reduce_partials(part_b) if want_bias else None
     return gw, gb
 
 
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
-                     gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int
-                     ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+                     gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
+                     seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
     """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip)."""
     dev = require_device(gy, y, weight, x, stats, gamma)
     gy, x = _rowmajor(gy), _rowmajor(x)
@@ -176,7 +213,7 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
         check(lib.allset_fused_linear_bwd(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(weight),
                                           ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                           int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(partials), npart.value,
-                                          n, O, I, stream_of(dev)), "allset_fused_linear_bwd")
+                                          n, O, I, ptr(seed_base), stream_of(dev)), "allset_fused_linear_bwd")
     if partials is None:
         return gx, None, None
     red = reduce_partials(partials)
@@ -194,17 +231,18 @@ class _LayerNormFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, relu_in, p):
         seed = _draw_seed() if p > 0.0 else 0
-        y, stats = ln_fwd(x, gamma, beta, eps, relu_in, p, seed)
+        base = _seed_base() if p > 0.0 else None
+        y, stats = ln_fwd(x, gamma, beta, eps, relu_in, p, seed, base)
         ctx.save_for_backward(x, stats, gamma)
-        ctx.cfg = (bool(relu_in), float(p), seed)
+        ctx.cfg = (bool(relu_in), float(p), seed, base)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         x, stats, gamma = ctx.saved_tensors
-        relu_in, p, seed = ctx.cfg
-        gx, dg, db = ln_bwd(gy.contiguous(), x, stats, gamma, relu_in, p, seed)
+        relu_in, p, seed, base = ctx.cfg
+        gx, dg, db = ln_bwd(gy.contiguous(), x, stats, gamma, relu_in, p, seed, base)
         return gx, dg, db, None, None, None
 
 
@@ -218,7 +256,8 @@ class _ReluDropout(torch.autograd.Function):
         seed = _draw_seed() if p > 0.0 else 0
         n = x.numel()
         with torch.cuda.device(dev), _timed("relu_dropout_fwd", dev, 2 * n * 4):
-            check(_lib.load().allset_relu_dropout_fwd(ptr(x), p, seed, ptr(y), n, stream_of(dev)), "allset_relu_dropout_fwd")
+            check(_lib.load().allset_relu_dropout_fwd(ptr(x), p, seed, ptr(y), n, ptr(_seed_base() if p > 0.0 else None),
+                                                      stream_of(dev)), "allset_relu_dropout_fwd")
         ctx.save_for_backward(y)
         ctx.p = float(p)
         return y
@@ -274,24 +313,27 @@ class _FusedNormLinear(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out):
         seed_in = _draw_seed() if p_in > 0.0 else 0
         seed_out = _draw_seed() if p_out > 0.0 else 0
-        y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out)
+        base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
+        y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out,
+                                    base)
         keep_y = relu_out or p_out > 0.0
         ctx.save_for_backward(x, stats, gamma, beta, weight, y if keep_y else None)
-        ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None)
+        ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         x, stats, gamma, beta, weight, y = ctx.saved_tensors
-        relu_in, p_in, seed_in, p_out, has_bias = ctx.cfg
+        relu_in, p_in, seed_in, p_out, has_bias, base = ctx.cfg
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3] or need_b:
-            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b)
+            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b,
+                                 seed_base=base)
         if ctx.needs_input_grad[0] or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
-            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in)
+            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in, base)
         return gx, dg, db, gw, gb, None, None, None, None, None
 
 

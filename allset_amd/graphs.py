@@ -1,0 +1,125 @@
+"""hipGraph capture of the launch-bound regime: at dataset scale (Cora: 2.7k vertices, 13k incidences) one
+``SetGNN`` training step is ~150 kernel launches of a few microseconds each, so the step time is the host's launch
+rate, not the GPU's.  Capturing the whole step once and replaying it removes the host from the loop.
+
+The reference has no counterpart (``src/train.py:480-560`` runs an eager PyTorch loop); this is the MI355X side of the
+same loop -- same arithmetic, one graph launch per epoch.
+
+What makes capture possible here:
+  * every kernel of the path is stream-ordered with no host read-back once the incidence is built
+    (``models.SetGNN._incidences`` caches the CSR pair on the first call, which must happen BEFORE capture);
+  * dropout masks come from a device-resident counter (``dense.device_seed_counter``): the graph bumps the counter
+    first, the kernels read it when they start, so every replay draws fresh masks although the host-side seeds were
+    frozen at capture;
+  * the optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``).
+
+Torch's ``CUDAGraph`` on ROCm records hipGraph nodes from whatever is launched on the capturing stream; the C-ABI
+takes the stream explicitly, so its launches are captured like torch's own.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import dense
+from ._lib import AllSetHipError
+
+Tensor = torch.Tensor
+
+
+def _side_stream_warmup(fn: Callable[[], None], iters: int) -> None:
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(iters):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+
+
+class GraphedForward:
+    """Eval-mode forward of ``model`` on a fixed ``data`` captured as one graph.
+
+    ``out = GraphedForward(model, data)()`` replays it; the result tensor is static (overwritten by the next
+    replay).  New features for the same hypergraph: ``gf(x_new)`` copies them into the captured input first.
+    Parameters are read at replay time, so the graph stays valid while training updates them in place.
+    """
+
+    def __init__(self, model: torch.nn.Module, data, warmup: int = 2):
+        if not data.x.is_cuda:
+            raise AllSetHipError("GraphedForward needs device tensors")
+        self.model, self.data = model, data
+        was_training = model.training
+        model.eval()
+        with torch.no_grad(), torch.cuda.device(data.x.device):
+            _side_stream_warmup(lambda: model(data), max(1, warmup))
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model(data)
+        model.train(was_training)
+
+    def __call__(self, x: Optional[Tensor] = None) -> Tensor:
+        if x is not None:
+            self.data.x.copy_(x)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedTrainStep:
+    """One full training step -- zero_grad, forward (train mode, dropout live), loss, backward, optimizer step --
+    captured as one graph.  ``loss = step()`` replays it and returns the static loss tensor (a device scalar; read
+    it with ``.item()`` only when you need it).
+
+    ``loss_fn(logits) -> scalar`` closes over static label / index tensors, e.g.
+    ``lambda out: F.nll_loss(F.log_softmax(out[train_idx], 1), y[train_idx])`` (``src/train.py:519-524``).
+
+    Capture needs a few real warm-up steps (allocator, autograd and optimizer state must exist before recording).
+    With ``restore=True`` (default) parameters and optimizer state are put back afterwards -- in place, the graph holds
+    their addresses -- so the first replay is step 1 of training, not step ``warmup + 1``: state the optimizer created
+    during warm-up is zeroed, which is Adam's initial state.
+    """
+
+    def __init__(self, model: torch.nn.Module, data, loss_fn: Callable[[Tensor], Tensor],
+                 optimizer: torch.optim.Optimizer, warmup: int = 3, train_mode: bool = True, restore: bool = True):
+        dev = data.x.device
+        if not data.x.is_cuda:
+            raise AllSetHipError("GraphedTrainStep needs device tensors")
+        for grp in optimizer.param_groups:
+            if not grp.get("capturable", False):
+                raise AllSetHipError("GraphedTrainStep needs a capturable optimizer (torch.optim.Adam(..., capturable=True))")
+        self.model, self.data, self.optimizer = model, data, optimizer
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.counter.fill_(int(torch.empty((), dtype=torch.int64).random_().item()) & 0x3FFFFFFFFFFFFFFF)
+        model.train(train_mode)           # False: a dropout-free (deterministic) step, e.g. for tests / fine-tuning
+
+        def one_step():
+            self.counter.add_(1)
+            optimizer.zero_grad(set_to_none=True)
+            loss = loss_fn(model(data))
+            loss.backward()
+            optimizer.step()
+            return loss
+
+        params = [p for grp in optimizer.param_groups for p in grp["params"]]
+        if restore:
+            with torch.no_grad():
+                p_snap = [p.detach().clone() for p in params]
+                s_snap = {p: {k: v.clone() for k, v in optimizer.state.get(p, {}).items() if torch.is_tensor(v)}
+                          for p in params}
+        with torch.cuda.device(dev), dense.device_seed_counter(self.counter):
+            _side_stream_warmup(one_step, max(1, warmup))
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = one_step()
+        if restore:
+            with torch.no_grad():
+                for p, snap in zip(params, p_snap):
+                    p.copy_(snap)
+                    for k, v in optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            v.copy_(s_snap[p][k]) if k in s_snap[p] else v.zero_()
+
+    def __call__(self) -> Tensor:
+        self.graph.replay()
+        return self.loss

@@ -234,6 +234,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--raw_data_dir', default=None, help='directory holding <dname>/{features,labels,hypergraph}.pickle')
     p.add_argument('--seed', default=None, type=int, help='seed numpy/torch (the reference fixes no seeds, README.md:60)')
     p.add_argument('--res_root', default='hyperparameter_tunning')
+    p.add_argument('--hip_graph', default=0, type=int, choices=[0, 1],
+                   help='1: capture the training step and the eval forward as hipGraphs (allset_amd/graphs.py)')
     p.set_defaults(PMA=True, add_self_loop=True, exclude_self=False, GPR=False, LearnMask=False)
     return p
 
@@ -282,15 +284,25 @@ def run(args) -> dict:
         t0 = time.time()
         split_idx = {k: v.to(device) for k, v in splits[r].items()}
         model.reset_parameters()
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd, capturable=bool(args.hip_graph))
+        if args.hip_graph:                     # same loop, two graph launches per epoch instead of ~400 kernel launches
+            from .graphs import GraphedForward, GraphedTrainStep
+            train_idx, y_train = split_idx['train'], data.y[split_idx['train']]
+            graphed_step = GraphedTrainStep(
+                model, data, lambda logits: criterion(F.log_softmax(logits, dim=1)[train_idx], y_train), optimizer)
+            graphed_eval = GraphedForward(model, data)
         for epoch in range(args.epochs):
-            model.train()
-            optimizer.zero_grad()
-            out = F.log_softmax(model(data), dim=1)
-            loss = criterion(out[split_idx['train']], data.y[split_idx['train']])
-            loss.backward()
-            optimizer.step()
-            result = evaluate(model, data, split_idx, eval_acc)
+            if args.hip_graph:
+                loss = graphed_step().detach()
+                result = evaluate(model, data, split_idx, eval_acc, result=F.log_softmax(graphed_eval(), dim=1))
+            else:
+                model.train()
+                optimizer.zero_grad()
+                out = F.log_softmax(model(data), dim=1)
+                loss = criterion(out[split_idx['train']], data.y[split_idx['train']])
+                loss.backward()
+                optimizer.step()
+                result = evaluate(model, data, split_idx, eval_acc)
             logger.add_result(r, result[:3])
             if args.display_step > 0 and epoch % args.display_step == 0:
                 print(f'Epoch: {epoch:02d}, Train Loss: {loss:.4f}, Valid Loss: {result[4]:.4f}, Test  Loss: {result[5]:.4f}, '

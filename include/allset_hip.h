@@ -176,22 +176,26 @@ int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT,
  * these entry points cover what the torch ops do badly at [1M,128]: LayerNorm fwd/bwd (fused with the
  * neighbouring ReLU / dropout) and the weight-gradient GEMM.
  * Dropout: keep iff hash(seed, element index) >= p, kept values scaled by 1/(1-p); the backward regenerates the mask
- * from the same seed.
+ * from the same seed.  Every dropout-bearing entry point also takes `seed_base` (may be NULL): a DEVICE pointer to a
+ * 64-bit counter; when given, the effective seed is counter * 0x9E3779B97F4A7C15 + seed, read when the kernel starts, so
+ * a captured hipGraph draws fresh masks on every replay (the caller bumps the counter inside the graph).
  * ------------------------------------------------------------------------------------------- */
 
 /* y = dropout_p( LayerNorm_{gamma,beta,eps}( relu_in ? relu(x) : x ) );  stats[row] = {mean, rstd} (f32[n*2]). */
 int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int relu_in,
-                  float p, uint64_t seed, float* y, int64_t ldy, float* stats, int64_t n, int64_t d, void* stream);
+                  float p, uint64_t seed, float* y, int64_t ldy, float* stats, int64_t n, int64_t d,
+                  const uint64_t* seed_base, void* stream);
 
 /* Backward of allset_ln_fwd.  gx = d loss / d x;  partials: f32[n_partials*2*d], row k holds block k's
  * (dgamma[d], dbeta[d]) partial sums -- the caller sums over k.  n_partials from allset_ln_bwd_partials. */
 int allset_ln_bwd_partials(int64_t n, int64_t d, int64_t* n_partials);
 int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* stats, const float* gamma,
                   int relu_in, float p, uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials,
-                  int64_t n, int64_t d, void* stream);
+                  int64_t n, int64_t d, const uint64_t* seed_base, void* stream);
 
 /* y = dropout_p(relu(x)) over numel contiguous elements, and its backward (gx = gy/(1-p) where y > 0, else 0). */
-int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, float* y, int64_t numel, void* stream);
+int allset_relu_dropout_fwd(const float* x, float p, uint64_t seed, float* y, int64_t numel,
+                            const uint64_t* seed_base, void* stream);
 int allset_relu_dropout_bwd(const float* gy, const float* y, float p, float* gx, int64_t numel, void* stream);
 
 /* Weight gradient of y = u W^T + b:  gW[o][i] = sum_r ga[r][o] * u[r][i],  gb[o] = sum_r ga[r][o], as
@@ -219,7 +223,7 @@ int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, 
 int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
                        const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                        int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
-                       int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+                       int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, void* stream);
 
 /* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
  *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],
@@ -230,7 +234,7 @@ int allset_fused_linear_supported(int64_t K, int64_t N);
 int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                             int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                             int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats,
-                            int64_t n, int64_t K, int64_t N, void* stream);
+                            int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, void* stream);
 
 /* Backward of allset_fused_linear_fwd w.r.t. x (O = out features, I = in features, both in {64,128}):
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0) if y != NULL else gy;   gu = ga @ W;   gz = gu * dropout_{p_in,seed_in} mask;
@@ -241,7 +245,7 @@ int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials);
 int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out, const float* W,
                             const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in,
                             float p_in, uint64_t seed_in, float* gx, int64_t ldgx, float* partials,
-                            int64_t n_partials, int64_t n, int64_t O, int64_t I, void* stream);
+                            int64_t n_partials, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, void* stream);
 
 #ifdef __cplusplus
 }

@@ -235,7 +235,7 @@ def test_fused_backward_kernels_match_unfused_chain_with_dropout(device):
     a = F.linear(u, W, b)
     y_ref = torch.empty_like(a)
     from allset_amd import _lib
-    _lib.check(_lib.load().allset_relu_dropout_fwd(a.data_ptr(), p_out, s_out, y_ref.data_ptr(), a.numel(),
+    _lib.check(_lib.load().allset_relu_dropout_fwd(a.data_ptr(), p_out, s_out, y_ref.data_ptr(), a.numel(), None,
                                                    torch.cuda.current_stream().cuda_stream), "relu_dropout_fwd")
     ga = torch.where(y_ref > 0, G / (1 - p_out), torch.zeros_like(G))
     gw_ref, gb_ref = ga.t() @ u, ga.sum(0)

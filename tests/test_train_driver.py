@@ -69,12 +69,13 @@ def test_synthetic_dataset_is_learnable_structure():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hip_graph", [0, 1])
 @pytest.mark.parametrize("method", ["AllSetTransformer", "AllDeepSets"])
-def test_training_run_improves_accuracy(method, device, tmp_path):
+def test_training_run_improves_accuracy(method, hip_graph, device, tmp_path):
     from allset_amd.train import build_parser, run
     args = build_parser().parse_args(['--method', method, '--dname', 'synthetic', '--epochs', '40', '--runs', '2',
                                       '--All_num_layers', '1', '--MLP_hidden', '64', '--heads', '4', '--lr', '0.01',
-                                      '--seed', '3', '--res_root', str(tmp_path)])
+                                      '--seed', '3', '--res_root', str(tmp_path), '--hip_graph', str(hip_graph)])
     res = run(args)
     assert float(res['best_test'].mean()) > 60.0          # 5 classes: chance = 20 %
     line = open(res['csv']).read().strip().split(',')

@@ -18,9 +18,9 @@ for name, flags in (("full", []), ("no-load", ["-DALLSET_ABLATE_NOLOAD"]), ("no-
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + flags + src, check=True)
     lib = ctypes.CDLL(so)
     fn = lib.allset_fused_linear_fwd
-    fn.argtypes = [P, I64, P, P, F, I, F, U64, P, P, I, F, U64, P, I64, P, I64, I64, I64, P]
+    fn.argtypes = [P, I64, P, P, F, I, F, U64, P, P, I, F, U64, P, I64, P, I64, I64, I64, P, P]
     def run():
-        rc = fn(x.data_ptr(), d, None, None, 1e-5, 0, 0.0, 0, W.data_ptr(), b.data_ptr(), 0, 0.0, 0, y.data_ptr(), d, None, n, d, d,
+        rc = fn(x.data_ptr(), d, None, None, 1e-5, 0, 0.0, 0, W.data_ptr(), b.data_ptr(), 0, 0.0, 0, y.data_ptr(), d, None, n, d, d, None,
                 torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     run(); torch.cuda.synchronize(); ts = []
