@@ -184,7 +184,7 @@ def halfnlhconv_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, edge_inde
 
 def setgnn_forward(sd: Dict[str, Tensor], args: SimpleNamespace, x: Tensor, edge_index: Tensor,
                    norm: Tensor, collect: Optional[dict] = None) -> Tensor:
-    """reference models.py:450-484, non-GPR branch, eval mode (dropouts are identities).
+    """reference models.py:450-484 (both the GPR branch :457-471 and the plain one), eval mode (dropouts are identities).
 
     Unlike the reference this does not mutate ``edge_index`` in place (Q2): the hyperedge ids are
     re-based on a copy.  ``collect`` (optional dict) receives the intermediate conv outputs.
@@ -198,8 +198,13 @@ def setgnn_forward(sd: Dict[str, Tensor], args: SimpleNamespace, x: Tensor, edge
     if getattr(args, "GPR", False):
         xs = [F.relu(mlp_forward(sd, "MLP.", x, nl))]
         for i in range(args.All_num_layers):
-            x = F.relu(halfnlhconv_forward(sd, f"V2EConvs.{i}.", x, ei, norm, args.aggregate, attention, args.heads, nl))
-            x = F.relu(halfnlhconv_forward(sd, f"E2VConvs.{i}.", x, rev, norm, args.aggregate, attention, args.heads, nl))
+            x = halfnlhconv_forward(sd, f"V2EConvs.{i}.", x, ei, norm, args.aggregate, attention, args.heads, nl)
+            if collect is not None:
+                collect[f"v2e{i}"] = x
+            x = halfnlhconv_forward(sd, f"E2VConvs.{i}.", F.relu(x), rev, norm, args.aggregate, attention, args.heads, nl)
+            if collect is not None:
+                collect[f"e2v{i}"] = x
+            x = F.relu(x)
             xs.append(x)
         x = torch.stack(xs, dim=-1)
         x = F.linear(x, sd["GPRweights.weight"]).squeeze()

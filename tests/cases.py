@@ -169,7 +169,7 @@ def build_case(name: str) -> dict:
     elif name.startswith("rand50_"):
         mode = name[len("rand50_"):]
         suffixes = {"_wnorm": ("_wnorm", True), "_L2": ("All_num_layers", 2),
-                    "_bn": ("normalization", "bn"), "_mask": ("LearnMask", True)}
+                    "_bn": ("normalization", "bn"), "_mask": ("LearnMask", True), "_gpr": ("GPR", True)}
         stripped = True
         while stripped:
             stripped = False
@@ -213,7 +213,8 @@ SMALL_CASES: List[str] = (
     [f"doc_{sl}_{m}" for sl in ("noself", "self") for m in MODES]
     + [f"rand50_{m}" for m in MODES]
     + ["rand50_ds_add_wnorm", "rand50_ds_mean_wnorm", "rand50_ds_add_L2", "rand50_pma_h4_L2",
-       "rand50_ds_add_bn", "rand50_ds_add_wnorm_mask"]
+       "rand50_ds_add_bn", "rand50_ds_add_wnorm_mask", "rand50_ds_add_L2_gpr", "rand50_pma_h4_L2_gpr",
+       "rand50_ds_mean_wnorm_mask_L2"]
     + [f"edge_{m}" for m in MODES]
 )
 BIG_CASES: List[str] = ["cora_ds_add", "citeseer_pma_h4"]

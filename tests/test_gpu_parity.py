@@ -75,7 +75,7 @@ def test_training_mode_runs_and_is_finite(device):
             loss = torch.nn.functional.nll_loss(torch.log_softmax(model(data), dim=1), y)
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         assert all(map(lambda v: v == v and abs(v) < 1e6, losses))
 
 
