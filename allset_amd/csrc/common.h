@@ -71,6 +71,26 @@ __device__ __forceinline__ uint32_t f32_to_bf16(float f) {            // round t
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// ---- fp32 on the bf16 matrix pipe ("bf16x6") --------------------------------------------------------------------
+// gfx950's fp32 MFMA runs at 1/16 of its bf16 MFMA (157 TF vs 2.5 PF dense).  An fp32 value splits EXACTLY into three
+// bf16 values x = h + m + l (round-to-nearest at each step: 8 + 8 + 8 significant bits cover fp32's 24), and
+//   x * w = hh' + hm' + mh' + hl' + lh' + mm'  + (ml' + lm' + ll')
+// where every kept product of two bf16 is exact in the fp32 accumulator and the dropped group is <= 2^-23 |x w|
+// (one fp32 rounding's worth).  Six bf16 MFMAs replace one fp32 MFMA: 16/6 = 2.7x the matrix throughput at fp32-level
+// accuracy, which is what turns the fused Linear kernels from matrix-pipe-bound into HBM-bound.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // {bf16(hi), bf16(lo)} packed, RNE
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void split3_bf16(float x0, float x1, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
+  ph = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
+  pm = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+  pl = cvt_pk_bf16(s0, s1);                                             // exact: s has <= 8 significant bits
+}
+
 // VEC consecutive elements, unpacked to float.
 template <int VEC>
 struct FVec {

@@ -19,6 +19,8 @@
 //     epilogue overlap the other wave's MFMAs on the same SIMD (2 waves / SIMD).
 // HBM traffic is 1 read + 1 write of the activation matrix per Linear instead of the 3 reads + 3 writes of the
 // unfused norm -> GEMM -> activation chain.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace allset {
@@ -173,6 +175,226 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_fwd_kernel(
   }
 }
 
+
+// ---- the same forward on the bf16 matrix pipe (bf16x6, see common.h) -----------------------------------------------
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] as 8 packed bf16 (4 VGPRs), B likewise for
+// column (l&15); C/D: column l&15, rows 4*(l>>4) + 0..3.  The k-order is free, so lane (i, g = l>>4) keeps the
+// CONTIGUOUS quarter g of row i in registers (K/4 floats -> three planes of K/8 dwords) and step t uses its local
+// columns 8t..8t+7.  One wave owns 16 complete rows at a time -- half the registers of the 32-row fp32 kernel, which
+// buys what that kernel could not afford at two waves per SIMD: the rows of the next TWO chunks are always in flight
+// into two register buffers (2 x 8 KiB per wave, 32 MiB chip-wide), so the activation stream never drains while a
+// wave splits, multiplies and stores.
+//   * W^T is split once per workgroup into three bf16 planes in LDS, laid out [k-quarter][column][K/8 dwords] with the
+//     16-byte piece index XOR-swizzled by the column, so a B fragment is one conflict-free ds_read_b128;
+//   * the accumulators (one column x 4 rows per lane) take one trip through the wave's LDS slab and leave as 16-byte
+//     stores of 4 consecutive columns (dword stores from the MFMA layout are issue-bound at ~5 B/clk/CU); bias / relu /
+//     dropout run on the row-major side, where one hash covers two neighbours.
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+union Frag8 { uint4 u; bf16x8 v; };
+constexpr int kX6Block = 512;
+constexpr int kX6Waves = kX6Block / kWave;
+
+// dword offset of 16-byte piece t of (k-quarter g, column j) inside a plane
+template <int KQD, int GS>
+__device__ __forceinline__ int plane_off(int g, int j, int t) {
+  constexpr int PIECES = KQD / 4, ROWS64 = 64 / KQD;
+  return g * GS + j * KQD + 4 * (t ^ ((j / ROWS64) % PIECES));
+}
+
+template <int KD, int ND, bool HAS_LN, bool DROP_IN, bool DROP_OUT>
+__global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W,
+    const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
+    int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base) {
+  seed_in = resolve_seed(seed_base, seed_in);
+  seed_out = resolve_seed(seed_base, seed_out);
+  constexpr int KQ = KD / 4;                       // columns per lane
+  constexpr int KQD = KQ / 2;                      // dwords per (quarter, column) row of a plane
+  constexpr int T = KQ / 8;                        // MFMA k-steps
+  constexpr int GS = ND * KQD;
+  constexpr int NTILE = ND / 16;
+  __shared__ __attribute__((aligned(16))) uint32_t sWh[4 * GS];
+  __shared__ __attribute__((aligned(16))) uint32_t sWm[4 * GS];
+  __shared__ __attribute__((aligned(16))) uint32_t sWl[4 * GS];
+  __shared__ __attribute__((aligned(16))) float sG[KD];
+  __shared__ __attribute__((aligned(16))) float sBeta[KD];
+  __shared__ __attribute__((aligned(16))) float sBias[ND];
+  __shared__ __attribute__((aligned(16))) float sTrans[kX6Waves * 16 * 64];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < ND * KD / 2; idx += kX6Block) {
+    const int j = idx / (KD / 2), k = 2 * (idx % (KD / 2));
+    const float2 w = *reinterpret_cast<const float2*>(W + j * KD + k);
+    uint32_t ph, pm, pl;
+    split3_bf16(w.x, w.y, ph, pm, pl);
+    const int e = k % KQ;
+    const int off = plane_off<KQD, GS>(k / KQ, j, e / 8) + (e % 8) / 2;
+    sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+  }
+  for (int idx = tid; idx < KD; idx += kX6Block) {
+    sG[idx] = HAS_LN ? gamma[idx] : 1.f;
+    sBeta[idx] = HAS_LN ? beta[idx] : 0.f;
+  }
+  for (int idx = tid; idx < ND; idx += kX6Block) sBias[idx] = bias ? bias[idx] : 0.f;
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ri = lane & 15, g = lane >> 4;
+  const float inv_k = 1.f / static_cast<float>(KD);
+  const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
+  const float keep_out = DROP_OUT ? 1.f / (1.f - p_out) : 1.f;
+  const uint32_t thr_in = drop_threshold(p_in), thr_out = drop_threshold(p_out);
+  const int64_t n_chunks = (n + 15) / 16;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kX6Waves;
+  float* sT = sTrans + wave * (16 * 64);
+
+  auto request_row = [&](float (&a)[KQ], int64_t chunk) {
+    const int64_t row = chunk * 16 + ri;
+#ifdef ALLSET_ABLATE_NOLOAD
+    if (chunk < n_chunks && row < n && p_in == 123.f) {
+#else
+    if (chunk < n_chunks && row < n) {
+#endif
+      const float4* xr = reinterpret_cast<const float4*>(x + row * ldx + g * KQ);
+#pragma unroll
+      for (int q = 0; q < KQ / 4; ++q) {
+        const float4 v = xr[q];
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) a[j] = 0.f;
+    }
+  };
+
+  auto process = [&](float (&a)[KQ], int64_t chunk) {
+    const int64_t row = chunk * 16 + ri;
+    const bool valid = row < n;
+    if (relu_in) {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) a[j] = fmaxf(a[j], 0.f);
+    }
+    if constexpr (HAS_LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) s += a[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv_k;
+      float q2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) { a[j] -= mean; q2 = fmaf(a[j], a[j], q2); }
+      q2 += __shfl_xor(q2, 16);
+      q2 += __shfl_xor(q2, 32);
+      const float rstd = rsqrtf(q2 * inv_k + eps);
+      if (valid && g == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+      for (int jb = 0; jb < KQ; jb += 4) {
+        const float4 g0 = *reinterpret_cast<const float4*>(&sG[g * KQ + jb]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&sBeta[g * KQ + jb]);
+        a[jb + 0] = fmaf(a[jb + 0] * rstd, g0.x, b0.x); a[jb + 1] = fmaf(a[jb + 1] * rstd, g0.y, b0.y);
+        a[jb + 2] = fmaf(a[jb + 2] * rstd, g0.z, b0.z); a[jb + 3] = fmaf(a[jb + 3] * rstd, g0.w, b0.w);
+      }
+    }
+    if constexpr (DROP_IN) {
+#pragma unroll
+      for (int j = 0; j < KQ; j += 2) {
+        float k0, k1;
+        keep_scale2(seed_in, row * KD + g * KQ + j, thr_in, keep_in, k0, k1);
+        a[j] *= k0; a[j + 1] *= k1;
+      }
+    }
+    uint32_t ah[KQD], am[KQD], al[KQD];
+#pragma unroll
+    for (int j = 0; j < KQD; ++j) split3_bf16(a[2 * j], a[2 * j + 1], ah[j], am[j], al[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    request_row(a, chunk + 2 * stride);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[NTILE];
+#pragma unroll
+    for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef ALLSET_ABLATE_NOMFMA
+    for (int t = 0; t < 1; ++t) {
+#else
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#endif
+      Frag8 fa_h, fa_m, fa_l;
+      fa_h.u = make_uint4(ah[4 * t], ah[4 * t + 1], ah[4 * t + 2], ah[4 * t + 3]);
+      fa_m.u = make_uint4(am[4 * t], am[4 * t + 1], am[4 * t + 2], am[4 * t + 3]);
+      fa_l.u = make_uint4(al[4 * t], al[4 * t + 1], al[4 * t + 2], al[4 * t + 3]);
+#pragma unroll
+      for (int tl = 0; tl < NTILE; tl += 2) {       // two column tiles: two independent accumulator chains
+        const int o0 = plane_off<KQD, GS>(g, tl * 16 + ri, t), o1 = plane_off<KQD, GS>(g, tl * 16 + 16 + ri, t);
+        Frag8 b0h, b0m, b0l, b1h, b1m, b1l;
+        b0h.u = *reinterpret_cast<const uint4*>(&sWh[o0]);
+        b0m.u = *reinterpret_cast<const uint4*>(&sWm[o0]);
+        b0l.u = *reinterpret_cast<const uint4*>(&sWl[o0]);
+        b1h.u = *reinterpret_cast<const uint4*>(&sWh[o1]);
+        b1m.u = *reinterpret_cast<const uint4*>(&sWm[o1]);
+        b1l.u = *reinterpret_cast<const uint4*>(&sWl[o1]);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l.v, b0h.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l.v, b1h.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b0l.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1l.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b0m.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b1m.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b0h.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b1h.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b0m.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1m.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b0h.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1h.v, acc[tl + 1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue, 64 columns (4 tiles) per trip through the slab
+    const int c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int hb = 0; hb < ND / 64; ++hb) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sT[(4 * g + r) * 64 + tt * 16 + ri] = acc[hb * 4 + tt][r];
+      // one wave, in-order LDS queue: no barrier needed, but the compiler must not move the vector reads above the
+      // scalar writes (different access types) nor the next trip's writes above these reads
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float4 bv = *reinterpret_cast<const float4*>(&sBias[hb * 64 + c4]);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int64_t r = chunk * 16 + rl;
+        float4 v = *reinterpret_cast<const float4*>(&sT[rl * 64 + c4]);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if constexpr (DROP_OUT) {
+          float k0, k1, k2, k3;
+          keep_scale2(seed_out, r * ND + hb * 64 + c4, thr_out, keep_out, k0, k1);
+          keep_scale2(seed_out, r * ND + hb * 64 + c4 + 2, thr_out, keep_out, k2, k3);
+          v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
+        }
+#ifdef ALLSET_ABLATE_NOSTORE
+        if (r < n && v.x == 123.456f) *reinterpret_cast<float4*>(y + r * ldy + hb * 64 + c4) = v;
+#else
+        if (r < n) *reinterpret_cast<float4*>(y + r * ldy + hb * 64 + c4) = v;
+#endif
+      }
+      __asm__ volatile("" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  float a0[KQ], a1[KQ];
+  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kX6Waves + wave;
+  request_row(a0, chunk);
+  request_row(a1, chunk + stride);
+  for (; chunk < n_chunks; chunk += 2 * stride) {
+    process(a0, chunk);
+    if (chunk + stride < n_chunks) process(a1, chunk + stride);
+  }
+}
 
 // ---- backward w.r.t. the input of the fused Linear --------------------------------------------------------------
 //   ga = gy * (y > 0 ? keep_out : 0)   (if y != nullptr: relu/dropout epilogue of the forward)      [A operand, registers]
@@ -341,6 +563,12 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_bwd_kernel(
 
 using namespace allset;
 
+// ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels (A/B comparisons, tools/dense_bench.py); default bf16x6.
+static bool dense_mfma_x6() {
+  const char* e = getenv("ALLSET_DENSE_MFMA");
+  return !(e && e[0] == 'f');
+}
+
 extern "C" int allset_fused_linear_supported(int64_t K, int64_t N) {
   return ((K == 64 || K == 128) && (N == 64 || N == 128)) ? 1 : 0;
 }
@@ -362,16 +590,28 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
   ALLSET_REQUIRE((gamma == nullptr) == (beta == nullptr), "fused_linear_fwd: gamma and beta must come together");
   ALLSET_REQUIRE(gamma == nullptr || stats != nullptr, "fused_linear_fwd: LayerNorm prologue needs a stats buffer");
   ALLSET_REQUIRE(ldx >= K && ldy >= N && ldx % 4 == 0 && aligned16(x), "fused_linear_fwd: x must be 16-byte aligned rows");
+  ALLSET_REQUIRE(ldy % 4 == 0 && aligned16(y), "fused_linear_fwd: y must be 16-byte aligned rows");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int has_ln = gamma != nullptr;
   const int64_t chunks = (n + 31) / 32;
   int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
   if (blocks > 512) blocks = 512;                         // persistent workgroups
   const unsigned grid = static_cast<unsigned>(blocks);
-#define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                        \
-  fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in,     \
-                                                                            seed_in, W, bias, relu_out, p_out, seed_out, \
-                                                                            y, ldy, stats, n, seed_base)
+  const bool x6 = dense_mfma_x6();
+  int64_t blocks_x6 = ((n + 15) / 16 + kX6Waves - 1) / kX6Waves;
+  if (blocks_x6 > 256) blocks_x6 = 256;                   // one persistent 8-wave workgroup per CU
+  const unsigned grid_x6 = static_cast<unsigned>(blocks_x6);
+#define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                           \
+  do {                                                                                                                   \
+    if (x6)                                                                                                              \
+      fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, kX6Block, 0, st>>>(                                      \
+          x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
+          seed_base);                                                                                                    \
+    else                                                                                                                 \
+      fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(                                         \
+          x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
+          seed_base);                                                                                                    \
+  } while (0)
 #define ALLSET_FUSED_FWD(KD, NT)                                                      \
   do {                                                                                \
     const int v = (has_ln ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);    \

@@ -284,3 +284,25 @@ def test_reduce_partials(P, M, device):
     torch.testing.assert_close(got.double().cpu(), part.double().sum(0).cpu(), rtol=1e-5, atol=1e-4)
     part3 = torch.randn(P, 2, M // 2, device=device)
     torch.testing.assert_close(dense.reduce_partials(part3), part3.sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (64, 128), (128, 64), (64, 64)])
+def test_fused_linear_bf16x6_is_fp32_accurate(K, N, device, monkeypatch):
+    """The fused Linear runs fp32 on the bf16 matrix pipe (exact 3-way split, 6 products; csrc/common.h).  It must be
+    as accurate as the native fp32 MFMA kernels (ALLSET_DENSE_MFMA=f32): error measured against float64 in units of
+    sum|terms|, on a wide-dynamic-range input where a plain bf16 (or bf16x3) product would be off by 1e-3 (1e-5)."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(K * 7 + N)
+    n = 20011
+    x = (torch.randn(n, K, generator=g) * torch.exp(3 * torch.randn(n, K, generator=g))).to(device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
+    b = torch.randn(N, generator=g).to(device)
+    ref = x.double() @ W.double().t() + b.double()
+    scale = x.double().abs() @ W.double().abs().t() + b.double().abs()
+    errs = {}
+    for mode in ("bf16x6", "f32"):
+        monkeypatch.setenv("ALLSET_DENSE_MFMA", mode)
+        y, _ = dense.fused_linear_fwd(x, W, b)
+        errs[mode] = float(((y.double() - ref).abs() / scale).max())
+    assert errs["bf16x6"] < 2e-6 and errs["f32"] < 2e-6, errs
+    assert errs["bf16x6"] < 2.0 * errs["f32"], errs

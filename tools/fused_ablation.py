@@ -13,7 +13,9 @@ y = torch.empty(n, d, device=dev); st = torch.empty(n, 2, device=dev)
 P, I64, F, U64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_int
 for name, flags in (("full", []), ("no-load", ["-DALLSET_ABLATE_NOLOAD"]), ("no-store", ["-DALLSET_ABLATE_NOSTORE"]),
                     ("no-load no-store", ["-DALLSET_ABLATE_NOLOAD", "-DALLSET_ABLATE_NOSTORE"]),
-                    ("no-mfma", ["-DALLSET_ABLATE_NOMFMA"])):
+                    ("no-mfma", ["-DALLSET_ABLATE_NOMFMA"]),
+                    ("no-mfma no-store", ["-DALLSET_ABLATE_NOMFMA", "-DALLSET_ABLATE_NOSTORE"]),
+                    ("no-mfma no-load", ["-DALLSET_ABLATE_NOMFMA", "-DALLSET_ABLATE_NOLOAD"])):
     so = f"/tmp/fused_{name.replace(' ', '_')}.so"
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + flags + src, check=True)
     lib = ctypes.CDLL(so)
