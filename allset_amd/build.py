@@ -21,7 +21,11 @@ ARCH = "gfx950"
 SOURCES = ["abi.hip", "csr_build.hip", "segreduce.hip", "pma.hip", "dense.hip", "fused_mlp.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "allset_hip.h")]
 CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
-            "-Wall", "-Wno-unused-function"]
+            "-Wall", "-Wno-unused-function",
+            # No SLP vectorisation: packed-f32 VALU (v_pk_fma_f32 & co.) beside MFMAs is slower on gfx950
+            # (MI355X_MICROARCH.md) and, in fused_linear_bwd_x6_kernel, hipcc 7.2's packed code produced wrong
+            # low halves nondeterministically (tools/x6_debug.py history; scalar code is bit-stable).
+            "-fno-slp-vectorize"] + os.environ.get("ALLSET_EXTRA_CXXFLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -249,28 +249,32 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kX6Waves;
   float* sT = sTrans + wave * (16 * 64);
 
+  // Loads are unconditional on a clamped row (no exec-mask branches around memory instructions, whose joins cost
+  // s_waitcnt vmcnt(0) and drain the prefetch); rows past n are zeroed when the operand is consumed.
   auto request_row = [&](float (&a)[KQ], int64_t chunk) {
-    const int64_t row = chunk * 16 + ri;
+    int64_t row = chunk * 16 + ri;
+    row = row < n ? row : n - 1;
 #ifdef ALLSET_ABLATE_NOLOAD
-    if (chunk < n_chunks && row < n && p_in == 123.f) {
-#else
-    if (chunk < n_chunks && row < n) {
+    if (p_in == 123.f) {
 #endif
-      const float4* xr = reinterpret_cast<const float4*>(x + row * ldx + g * KQ);
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx + g * KQ);
 #pragma unroll
-      for (int q = 0; q < KQ / 4; ++q) {
-        const float4 v = xr[q];
-        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < KQ; ++j) a[j] = 0.f;
+    for (int q = 0; q < KQ / 4; ++q) {
+      const float4 v = xr[q];
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
     }
+#ifdef ALLSET_ABLATE_NOLOAD
+    }
+#endif
   };
 
   auto process = [&](float (&a)[KQ], int64_t chunk) {
     const int64_t row = chunk * 16 + ri;
     const bool valid = row < n;
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) a[j] = 0.f;
+    }
     if (relu_in) {
 #pragma unroll
       for (int j = 0; j < KQ; ++j) a[j] = fmaxf(a[j], 0.f);
@@ -559,6 +563,264 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_bwd_kernel(
   }
 }
 
+// ---- backward-data on the bf16 matrix pipe (same scheme as fused_linear_fwd_x6_kernel) ---------------------------------
+//   ga = gy * (y > 0 ? keep_out : 0)     lane (i, g) holds quarter g of row i: O/4 values of gy and of y, 16-byte loads;
+//                                        the NEXT chunk's gy / y rows are in flight while this one is processed
+//   gu = ga @ W                          W is split into three bf16 planes in LDS, transposed on the way in
+//                                        ([o-quarter][in-column][O/8 dwords], swizzled as in the forward)
+//   epilogue on the ROW-MAJOR side of the LDS trip (lane = 4 consecutive columns of 4 rows): dropout-in mask,
+//   LayerNorm backward (row sums = 16-lane reductions), relu-in mask, 16-byte stores of gx; x and the row statistics
+//   for the epilogue are requested before the MFMAs.  dgamma/dbeta: per-lane column sums, one partial row per wave.
+template <int OD, int ID, bool HAS_LN, bool DROP_IN>
+__global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
+    const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
+    const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* __restrict__ gx,
+    int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base) {
+  seed_in = resolve_seed(seed_base, seed_in);
+  constexpr int OQ = OD / 4, OQD = OQ / 2, T = OQ / 8;
+  constexpr int GS = ID * OQD;
+  constexpr int NTILE = ID / 16, NH = ID / 64;
+  __shared__ __attribute__((aligned(16))) uint32_t sWh[4 * GS];
+  __shared__ __attribute__((aligned(16))) uint32_t sWm[4 * GS];
+  __shared__ __attribute__((aligned(16))) uint32_t sWl[4 * GS];
+  __shared__ __attribute__((aligned(16))) float sG[ID];
+  __shared__ __attribute__((aligned(16))) float sTrans[kX6Waves * 16 * 64];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < (OD / 2) * ID; idx += kX6Block) {
+    const int o = 2 * (idx / ID), i = idx % ID;                      // threads run along i: coalesced reads of W
+    uint32_t ph, pm, pl;
+    split3_bf16(W[o * ID + i], W[(o + 1) * ID + i], ph, pm, pl);
+    const int e = o % OQ;
+    const int off = plane_off<OQD, GS>(o / OQ, i, e / 8) + (e % 8) / 2;
+    sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+  }
+  for (int idx = tid; idx < ID; idx += kX6Block) sG[idx] = HAS_LN ? gamma[idx] : 1.f;
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ri = lane & 15, g = lane >> 4;
+  const int c4 = (lane & 15) * 4;
+  const float inv_i = 1.f / static_cast<float>(ID);
+  const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+  const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
+  const uint32_t thr_in = drop_threshold(p_in);
+  const bool has_y = y != nullptr;
+  const bool need_x = HAS_LN || relu_in;
+  const int64_t n_chunks = (n + 15) / 16;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kX6Waves;
+  float* sT = sTrans + wave * (16 * 64);
+  float4 gam[NH];
+#pragma unroll
+  for (int hb = 0; hb < NH; ++hb) gam[hb] = *reinterpret_cast<const float4*>(&sG[hb * 64 + c4]);
+  float4 dg[NH], db[NH];
+#pragma unroll
+  for (int hb = 0; hb < NH; ++hb) { dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+  float ag[OQ], ay[OQ];
+  auto request_rows = [&](int64_t chunk) {               // unconditional, clamped (see the forward kernel)
+    int64_t row = chunk * 16 + ri;
+    row = row < n ? row : n - 1;
+#ifdef ALLSET_ABLATE_NOLOAD
+    if (p_in == 123.f) {
+#endif
+    const float4* gr = reinterpret_cast<const float4*>(gy + row * ldg + g * OQ);
+#pragma unroll
+    for (int q = 0; q < OQ / 4; ++q) {
+      const float4 v = gr[q];
+      ag[4 * q] = v.x; ag[4 * q + 1] = v.y; ag[4 * q + 2] = v.z; ag[4 * q + 3] = v.w;
+    }
+    if (has_y) {
+      const float4* yr = reinterpret_cast<const float4*>(y + row * ldy + g * OQ);
+#pragma unroll
+      for (int q = 0; q < OQ / 4; ++q) {
+        const float4 v = yr[q];
+        ay[4 * q] = v.x; ay[4 * q + 1] = v.y; ay[4 * q + 2] = v.z; ay[4 * q + 3] = v.w;
+      }
+    }
+#ifdef ALLSET_ABLATE_NOLOAD
+    }
+#endif
+  };
+
+  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kX6Waves + wave;
+  request_rows(chunk);
+  for (; chunk < n_chunks; chunk += stride) {
+    // ---- A operand
+    const bool valid = chunk * 16 + ri < n;
+    if (has_y) {
+#pragma unroll
+      for (int j = 0; j < OQ; ++j) ag[j] = (valid && ay[j] > 0.f) ? ag[j] * keep_out : 0.f;
+    } else if (!valid) {
+#pragma unroll
+      for (int j = 0; j < OQ; ++j) ag[j] = 0.f;
+    }
+    uint32_t ah[OQD], am[OQD], al[OQD];
+#pragma unroll
+    for (int j = 0; j < OQD; ++j) split3_bf16(ag[2 * j], ag[2 * j + 1], ah[j], am[j], al[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    request_rows(chunk + stride);
+    // ---- epilogue inputs, row-major: lane = rows it*4 + (lane>>4), columns hb*64 + c4 .. +3
+    float4 xr[NH][4];
+    float2 st[4];
+    if (need_x) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int64_t r = chunk * 16 + it * 4 + (lane >> 4);
+        r = r < n ? r : n - 1;                          // clamped, unconditional; dead rows are masked where used
+#ifdef ALLSET_ABLATE_NOLOAD
+        if (p_in == 123.f) {
+#endif
+        if constexpr (HAS_LN) st[it] = *reinterpret_cast<const float2*>(stats + r * 2);
+#pragma unroll
+        for (int hb = 0; hb < NH; ++hb) xr[hb][it] = *reinterpret_cast<const float4*>(x + r * ldx + hb * 64 + c4);
+#ifdef ALLSET_ABLATE_NOLOAD
+        }
+#endif
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[NTILE];
+#pragma unroll
+    for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef ALLSET_ABLATE_NOMFMA
+    for (int t = 0; t < 1; ++t) {
+#else
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#endif
+      Frag8 fa_h, fa_m, fa_l;
+      fa_h.u = make_uint4(ah[4 * t], ah[4 * t + 1], ah[4 * t + 2], ah[4 * t + 3]);
+      fa_m.u = make_uint4(am[4 * t], am[4 * t + 1], am[4 * t + 2], am[4 * t + 3]);
+      fa_l.u = make_uint4(al[4 * t], al[4 * t + 1], al[4 * t + 2], al[4 * t + 3]);
+#pragma unroll
+      for (int tl = 0; tl < NTILE; tl += 2) {
+        const int o0 = plane_off<OQD, GS>(g, tl * 16 + ri, t), o1 = plane_off<OQD, GS>(g, tl * 16 + 16 + ri, t);
+        Frag8 b0h, b0m, b0l, b1h, b1m, b1l;
+        b0h.u = *reinterpret_cast<const uint4*>(&sWh[o0]);
+        b0m.u = *reinterpret_cast<const uint4*>(&sWm[o0]);
+        b0l.u = *reinterpret_cast<const uint4*>(&sWl[o0]);
+        b1h.u = *reinterpret_cast<const uint4*>(&sWh[o1]);
+        b1m.u = *reinterpret_cast<const uint4*>(&sWm[o1]);
+        b1l.u = *reinterpret_cast<const uint4*>(&sWl[o1]);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l.v, b0h.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_l.v, b1h.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b0l.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1l.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b0m.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b1m.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b0h.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_m.v, b1h.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b0m.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1m.v, acc[tl + 1], 0, 0, 0);
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b0h.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1h.v, acc[tl + 1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- to row-major through the wave's LDS slab
+    float4 gz[NH][4];
+#pragma unroll
+    for (int hb = 0; hb < NH; ++hb) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sT[(4 * g + r) * 64 + tt * 16 + ri] = acc[hb * 4 + tt][r];
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) gz[hb][it] = *reinterpret_cast<const float4*>(&sT[(it * 4 + (lane >> 4)) * 64 + c4]);
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- dropout-in mask, LayerNorm backward, relu-in mask
+#ifdef ALLSET_EXP_WAIT
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t r = chunk * 16 + it * 4 + (lane >> 4);
+      const bool live = r < n;
+      float s1 = 0.f, s2 = 0.f;
+      uint32_t pos = 0;                                  // x > 0 bits (relu-in mask), 4 per 64-column half
+#pragma unroll
+      for (int hb = 0; hb < NH; ++hb) {
+        float4 v = gz[hb][it];
+        if constexpr (DROP_IN) {
+          float k0, k1, k2, k3;
+          keep_scale2(seed_in, r * ID + hb * 64 + c4, thr_in, keep_in, k0, k1);
+          keep_scale2(seed_in, r * ID + hb * 64 + c4 + 2, thr_in, keep_in, k2, k3);
+          v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
+        }
+        if (need_x) {
+          const float4 xv = xr[hb][it];
+          pos |= ((xv.x > 0.f ? 1u : 0u) | (xv.y > 0.f ? 2u : 0u) | (xv.z > 0.f ? 4u : 0u) | (xv.w > 0.f ? 8u : 0u)) << (4 * hb);
+        }
+        if constexpr (HAS_LN) {
+          float4 t = xr[hb][it];
+          if (relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          const float mean = st[it].x, rstd = st[it].y;
+          float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
+          if (!live) xh = make_float4(0.f, 0.f, 0.f, 0.f);
+          dg[hb].x = fmaf(v.x, xh.x, dg[hb].x); dg[hb].y = fmaf(v.y, xh.y, dg[hb].y);
+          dg[hb].z = fmaf(v.z, xh.z, dg[hb].z); dg[hb].w = fmaf(v.w, xh.w, dg[hb].w);
+          db[hb].x += v.x; db[hb].y += v.y; db[hb].z += v.z; db[hb].w += v.w;
+          v.x *= gam[hb].x; v.y *= gam[hb].y; v.z *= gam[hb].z; v.w *= gam[hb].w;      // gh
+          s1 += (v.x + v.y) + (v.z + v.w);
+          s2 = fmaf(v.x, xh.x, s2); s2 = fmaf(v.y, xh.y, s2); s2 = fmaf(v.z, xh.z, s2); s2 = fmaf(v.w, xh.w, s2);
+          xr[hb][it] = xh;
+        }
+        gz[hb][it] = v;
+      }
+      if constexpr (HAS_LN) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        s1 *= inv_i; s2 *= inv_i;
+        const float rstd = st[it].y;
+#pragma unroll
+        for (int hb = 0; hb < NH; ++hb) {
+          const float4 gh = gz[hb][it], xh = xr[hb][it];
+          gz[hb][it] = make_float4(rstd * (gh.x - s1 - xh.x * s2), rstd * (gh.y - s1 - xh.y * s2),
+                                   rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int hb = 0; hb < NH; ++hb) {
+          float4 o = gz[hb][it];
+          if (relu_in) {
+            const uint32_t m = pos >> (4 * hb);
+            if (!(m & 1u)) o.x = 0.f;
+            if (!(m & 2u)) o.y = 0.f;
+            if (!(m & 4u)) o.z = 0.f;
+            if (!(m & 8u)) o.w = 0.f;
+          }
+#ifdef ALLSET_ABLATE_NOSTORE
+          if (o.x == 123.456f)
+#endif
+          *reinterpret_cast<float4*>(gx + r * ldgx + hb * 64 + c4) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (HAS_LN) {     // one partial row per wave: part[wave_global][0|1][I]; the 4 row groups of a lane column fold first
+    float* pw = part + (static_cast<int64_t>(blockIdx.x) * kX6Waves + wave) * 2 * ID;
+#pragma unroll
+    for (int hb = 0; hb < NH; ++hb) {
+      float4 a = dg[hb], b = db[hb];
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+        b.x += __shfl_xor(b.x, off); b.y += __shfl_xor(b.y, off); b.z += __shfl_xor(b.z, off); b.w += __shfl_xor(b.w, off);
+      }
+      if (lane < 16) {
+        *reinterpret_cast<float4*>(pw + hb * 64 + c4) = a;
+        *reinterpret_cast<float4*>(pw + ID + hb * 64 + c4) = b;
+      }
+    }
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -637,6 +899,10 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
 }
 
 static inline unsigned fused_grid(int64_t n) {
+  if (dense_mfma_x6()) {                                   // 16-row chunks, one persistent 8-wave workgroup per CU
+    int64_t blocks = ((n + 15) / 16 + kX6Waves - 1) / kX6Waves;
+    return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));
+  }
   const int64_t chunks = (n + 31) / 32;
   int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
   if (blocks > 512) blocks = 512;
@@ -678,9 +944,21 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
   ALLSET_REQUIRE(y == nullptr || (ldy >= O && ldy % 4 == 0 && aligned16(y)), "fused_linear_bwd: y must be 16-byte aligned rows");
   ALLSET_REQUIRE(ldgx >= I && (x == nullptr || ldx >= I), "fused_linear_bwd: leading dimension too small");
   const hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool x6 = dense_mfma_x6();
+  if (x6) {
+    ALLSET_REQUIRE(ldgx % 4 == 0 && aligned16(gx) && (x == nullptr || (ldx % 4 == 0 && aligned16(x))),
+                   "fused_linear_bwd: gx / x must be 16-byte aligned rows");
+    ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd: stats must be 8-byte aligned");
+  }
 #define ALLSET_FUSED_BWD_F(OD, IT, LN, DI)                                                                                   \
-  fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma,     \
-                                                                        relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base)
+  do {                                                                                                                       \
+    if (x6)                                                                                                                  \
+      fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI><<<grid, kX6Block, 0, st>>>(                                            \
+          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \
+    else                                                                                                                     \
+      fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(                                                 \
+          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \
+  } while (0)
 #define ALLSET_FUSED_BWD(OD, IT)                                          \
   do {                                                                    \
     if (has_ln) { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, true, true); else ALLSET_FUSED_BWD_F(OD, IT, true, false); }     \

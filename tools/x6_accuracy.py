@@ -36,3 +36,10 @@ def timeit(fn, it=20):
 print(f"[{mode}] plain fwd            {timeit(lambda: dense.fused_linear_fwd(x, W, b)):.3f} ms")
 print(f"[{mode}] LN + fwd             {timeit(lambda: dense.fused_linear_fwd(x, W, b, g, bt)):.3f} ms")
 print(f"[{mode}] relu LN drop fwd relu drop {timeit(lambda: dense.fused_linear_fwd(x, W, b, g, bt, 1e-5, True, 0.5, 1, True, 0.5, 2)):.3f} ms")
+G = torch.randn(n, 128, device=dev)
+y0, st0 = dense.fused_linear_fwd(x, W, b, g, bt)
+y1, st1 = dense.fused_linear_fwd(x, W, b, g, bt, 1e-5, True, 0.5, 1, True, 0.5, 2)
+print(f"[{mode}] bwd  LN                    {timeit(lambda: dense.fused_linear_bwd(G, None, 0.0, W, x, st0, g, False, 0.0, 0)):.3f} ms")
+print(f"[{mode}] bwd  relu LN drop | relu drop {timeit(lambda: dense.fused_linear_bwd(G, y1, 0.5, W, x, st1, g, True, 0.5, 1)):.3f} ms")
+print(f"[{mode}] wgrad LN                   {timeit(lambda: dense.wgrad_fused(G, None, 0.0, x, st0, g, bt, False, 0.0, 0)):.3f} ms")
+print(f"[{mode}] wgrad relu LN drop | relu drop {timeit(lambda: dense.wgrad_fused(G, y1, 0.5, x, st1, g, bt, True, 0.5, 1)):.3f} ms")
