@@ -13,6 +13,8 @@
 // The LayerNorm/elementwise kernels are HBM-bound streaming kernels; wgrad is the only MFMA user (exact fp32,
 // v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, MI355X_MICROARCH.md).  Dropout masks come from a counter-based
 // hash of (seed, element index), so the backward regenerates them instead of storing a mask tensor.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace allset {
@@ -511,9 +513,218 @@ static inline int ln_lpr(int64_t d) {
   return lpr;
 }
 
+
+// ---- the same weight gradient on the bf16 matrix pipe (bf16x6, see common.h) ------------------------------------------
+// gW[o][i] = sum_r ga[r][o] * u[r][i]: the reduction runs over ROWS, so an MFMA operand fragment is 8 consecutive rows of
+// one feature -- the transpose of how the tensors lie in memory.  The transpose happens on the way into LDS: a thread
+// loads the same 4 columns of two ADJACENT rows, applies the operand prologue, splits each (row r, row r+1) value pair
+// into three packed-bf16 dwords and writes them to plane[feature][row pair] (16 dwords = 32 rows per feature and stage,
+// the 16-byte piece index XOR-swizzled so both the dword writes and the ds_read_b128 fragment reads are conflict-free).
+// 8 waves per workgroup, wave tile 64 (o) x 32 (i) = 8 accumulators of 16x16; one v_mfma_f32_16x16x32_bf16 k-step per
+// 32-row stage: 18 fragment reads feed 48 MFMAs.  Two LDS buffers: the next stage's global loads are in flight under
+// this stage's MFMAs, and one wave's conversion overlaps the other wave's MFMAs on the same SIMD.
+constexpr int kWx6Block = 512;
+using bf16x8_t = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+union WFrag { uint4 u; bf16x8_t v; };
+
+__device__ __forceinline__ int wx6_swz(int feat) { return (((feat >> 2) & 3) >> 1) * 3; }
+
+template <bool PRO>
+__global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
+    const float* __restrict__ ga, int64_t lda, const float* __restrict__ u, int64_t ldu,
+    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i,
+    int64_t rows_per_slice, WgradPro pro) {
+  __shared__ __attribute__((aligned(16))) uint32_t sP[2][2][3][kWgTile * 16];     // [buffer][A|B][plane][feature*16 + ..]
+  const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
+  const int o_base = tile_o * kWgTile, i_base = tile_i * kWgTile;
+  const int slice = blockIdx.y;
+  const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
+  const int64_t r_end = min(n, r_begin + rows_per_slice);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // staging map: row pair rp of the 32-row stage, 4 columns at s_col
+  const int rp = lane & 15, s_col = (wave * 4 + (lane >> 4)) * 4;
+  const bool a_ok = (o_base + s_col) < O, b_ok = (i_base + s_col) < I;           // O, I are multiples of 4
+  const int a_col = a_ok ? o_base + s_col : 0, b_col = b_ok ? i_base + s_col : 0;
+  const int w_off = s_col * 16 + 4 * ((rp >> 2) ^ wx6_swz(s_col)) + (rp & 3);     // + c*16 for column s_col + c
+  float4 bsum = make_float4(0, 0, 0, 0);
+
+  float4 g4 = make_float4(1, 1, 1, 1), be4 = make_float4(0, 0, 0, 0);
+  float keep_in = 1.f;
+  uint32_t thr_in = 0;
+  if constexpr (PRO) {
+    if (pro.has_ln && b_ok) {
+      g4 = *reinterpret_cast<const float4*>(pro.gamma + i_base + s_col);
+      be4 = *reinterpret_cast<const float4*>(pro.beta + i_base + s_col);
+    }
+    keep_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
+    thr_in = drop_threshold(pro.p_in);
+    pro.seed_in = resolve_seed(pro.seed_base, pro.seed_in);
+  }
+  const bool has_y = PRO && pro.y != nullptr;
+  const bool has_ln = PRO && pro.has_ln;
+
+  // Two register sets: the global loads run TWO stages ahead of the MFMAs (one stage of 32-48 KiB per CU in flight is
+  // latency-bound at ~3 TB/s), the LDS conversion one stage ahead.
+  struct Stage { float4 ra[2], rb[2], ry[2]; float2 rst[2]; int64_t row0; };
+  // issue only; unconditional loads on clamped rows / columns (no branches around memory instructions)
+  auto load_stage = [&](Stage& sg, int64_t r0) {
+    sg.row0 = r0 + 2 * rp;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t r = sg.row0 + h;
+      r = r < r_end ? r : r_end - 1;
+      sg.ra[h] = *reinterpret_cast<const float4*>(ga + r * lda + a_col);
+      sg.rb[h] = *reinterpret_cast<const float4*>(u + r * ldu + b_col);
+      if constexpr (PRO) {
+        if (has_y) sg.ry[h] = *reinterpret_cast<const float4*>(pro.y + r * pro.ldy + a_col);
+        if (has_ln) sg.rst[h] = *reinterpret_cast<const float2*>(pro.stats + r * 2);
+      }
+    }
+  };
+  auto store_stage = [&](Stage& sg, int buf) {
+    float4 va[2], vb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool in_range = (sg.row0 + h) < r_end;
+      float4 a = sg.ra[h], t = sg.rb[h];
+      if constexpr (PRO) {
+        if (has_y) {
+          const float4 yv = sg.ry[h];
+          a.x = yv.x > 0.f ? a.x * pro.keep_out : 0.f; a.y = yv.y > 0.f ? a.y * pro.keep_out : 0.f;
+          a.z = yv.z > 0.f ? a.z * pro.keep_out : 0.f; a.w = yv.w > 0.f ? a.w * pro.keep_out : 0.f;
+        }
+        if (pro.relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+        if (has_ln) {
+          const float2 st = sg.rst[h];
+          t.x = fmaf((t.x - st.x) * st.y, g4.x, be4.x); t.y = fmaf((t.y - st.x) * st.y, g4.y, be4.y);
+          t.z = fmaf((t.z - st.x) * st.y, g4.z, be4.z); t.w = fmaf((t.w - st.x) * st.y, g4.w, be4.w);
+        }
+        if (pro.p_in > 0.f) {
+          float k0, k1, k2, k3;
+          const int64_t e = (sg.row0 + h) * I + i_base + s_col;
+          keep_scale2(pro.seed_in, e, thr_in, keep_in, k0, k1); keep_scale2(pro.seed_in, e + 2, thr_in, keep_in, k2, k3);
+          t.x *= k0; t.y *= k1; t.z *= k2; t.w *= k3;
+        }
+      }
+      if (!(in_range && a_ok)) a = make_float4(0, 0, 0, 0);
+      if (!(in_range && b_ok)) t = make_float4(0, 0, 0, 0);
+      va[h] = a; vb[h] = t;
+      bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w;
+    }
+    uint32_t* pa = &sP[buf][0][0][w_off];
+    uint32_t* pb = &sP[buf][1][0][w_off];
+    constexpr int PL = kWgTile * 16;                 // dwords per plane
+    uint32_t h0, m0, l0;
+    split3_bf16(va[0].x, va[1].x, h0, m0, l0); pa[0] = h0; pa[PL] = m0; pa[2 * PL] = l0;
+    split3_bf16(va[0].y, va[1].y, h0, m0, l0); pa[16] = h0; pa[PL + 16] = m0; pa[2 * PL + 16] = l0;
+    split3_bf16(va[0].z, va[1].z, h0, m0, l0); pa[32] = h0; pa[PL + 32] = m0; pa[2 * PL + 32] = l0;
+    split3_bf16(va[0].w, va[1].w, h0, m0, l0); pa[48] = h0; pa[PL + 48] = m0; pa[2 * PL + 48] = l0;
+    split3_bf16(vb[0].x, vb[1].x, h0, m0, l0); pb[0] = h0; pb[PL] = m0; pb[2 * PL] = l0;
+    split3_bf16(vb[0].y, vb[1].y, h0, m0, l0); pb[16] = h0; pb[PL + 16] = m0; pb[2 * PL + 16] = l0;
+    split3_bf16(vb[0].z, vb[1].z, h0, m0, l0); pb[32] = h0; pb[PL + 32] = m0; pb[2 * PL + 32] = l0;
+    split3_bf16(vb[0].w, vb[1].w, h0, m0, l0); pb[48] = h0; pb[PL + 48] = m0; pb[2 * PL + 48] = l0;
+  };
+
+  // MFMA side: wave tile 64 (o) x 32 (i); lane (j, g) reads piece g of feature row j of a 16-feature tile
+  const int fj = lane & 15, fg = lane >> 4;
+  const int ob = (wave >> 2) * 64, ib = (wave & 3) * 32;
+  f32x4_t acc[4][2];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) { acc[ot][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[ot][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  int a_off[4], b_off[2];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) { const int f = ob + ot * 16 + fj; a_off[ot] = f * 16 + 4 * (fg ^ wx6_swz(f)); }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) { const int f = ib + it * 16 + fj; b_off[it] = f * 16 + 4 * (fg ^ wx6_swz(f)); }
+  bool o_live[4];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) o_live[ot] = (o_base + ob + ot * 16) < O;
+  const bool i_live = (i_base + ib) < I;
+
+  auto mfma_stage = [&](int buf) {
+    if (i_live) {
+      WFrag b[2][3];
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[it][pl].u = *reinterpret_cast<const uint4*>(&sP[buf][1][pl][b_off[it]]);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) {
+        if (!o_live[ot]) continue;
+        WFrag a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl].u = *reinterpret_cast<const uint4*>(&sP[buf][0][pl][a_off[ot]]);
+        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, b[0][0].v, acc[ot][0], 0, 0, 0);
+        acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, b[1][0].v, acc[ot][1], 0, 0, 0);
+        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[0][2].v, acc[ot][0], 0, 0, 0);
+        acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[1][2].v, acc[ot][1], 0, 0, 0);
+        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, b[0][1].v, acc[ot][0], 0, 0, 0);
+        acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, b[1][1].v, acc[ot][1], 0, 0, 0);
+        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, b[0][0].v, acc[ot][0], 0, 0, 0);
+        acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, b[1][0].v, acc[ot][1], 0, 0, 0);
+        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[0][1].v, acc[ot][0], 0, 0, 0);
+        acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[1][1].v, acc[ot][1], 0, 0, 0);
+        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[0][0].v, acc[ot][0], 0, 0, 0);
+        acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, b[1][0].v, acc[ot][1], 0, 0, 0);
+      }
+    }
+  };
+  Stage s0, s1;
+  if (r_begin < r_end) {                       // stage 0 -> LDS buffer 0; stages 1 and 2 on their way
+    load_stage(s0, r_begin);
+    load_stage(s1, r_begin + kWgRows);
+    store_stage(s0, 0);
+    load_stage(s0, r_begin + 2 * kWgRows);
+  }
+  __syncthreads();
+  // stage k lives in LDS buffer k&1; register set s1 holds stage k+1, s0 stage k+2 (roles swap every iteration)
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kWgRows) {
+    mfma_stage(0);
+    if (r0 + kWgRows < r_end) store_stage(s1, 1);
+    load_stage(s1, r0 + 3 * kWgRows);
+    __syncthreads();
+    if (r0 + kWgRows < r_end) {
+      mfma_stage(1);
+      if (r0 + 2 * kWgRows < r_end) store_stage(s0, 0);
+      load_stage(s0, r0 + 4 * kWgRows);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: partial tile -> part_w[slice][O][I]; acc[ot][it][r] is (o = .. + 4*fg + r, i = .. + fj)
+  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = i_base + ib + it * 16 + fj;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o_base + ob + ot * 16 + 4 * fg + r;
+        if (o < O && i < I) pw[static_cast<int64_t>(o) * I + i] = acc[ot][it][r];
+      }
+    }
+  // bias partial: the 16 row-pair lanes of a column quad fold by shuffles (only i-tile 0 writes)
+  if (tile_i == 0 && part_b != nullptr) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      bsum.x += __shfl_xor(bsum.x, off); bsum.y += __shfl_xor(bsum.y, off);
+      bsum.z += __shfl_xor(bsum.z, off); bsum.w += __shfl_xor(bsum.w, off);
+    }
+    if (rp == 0 && a_ok) *reinterpret_cast<float4*>(part_b + static_cast<int64_t>(slice) * O + o_base + s_col) = bsum;
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
+
+// ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels (A/B comparisons); default: bf16x6 (common.h)
+static bool dense_mfma_x6() {
+  const char* e = getenv("ALLSET_DENSE_MFMA");
+  return !(e && e[0] == 'f');
+}
 
 extern "C" int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                              int relu_in, float p, uint64_t seed, float* y, int64_t ldy, float* stats,
@@ -680,8 +891,12 @@ extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_
   rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
   if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
-  wgrad_kernel<false><<<grid, kBlock, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
-                                               tiles_i, rows_per_slice, WgradPro{});
+  if (dense_mfma_x6())
+    wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O),
+                                                       static_cast<int>(I), tiles_i, rows_per_slice, WgradPro{});
+  else
+    wgrad_kernel<false><<<grid, kBlock, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
+                                                 tiles_i, rows_per_slice, WgradPro{});
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -715,8 +930,12 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
   pro.stats = stats; pro.gamma = gamma; pro.beta = beta; pro.has_ln = stats != nullptr;
   pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in; pro.seed_base = seed_base;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
-  wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
-                                              tiles_i, rows_per_slice, pro);
+  if (dense_mfma_x6())
+    wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
+                                                      static_cast<int>(I), tiles_i, rows_per_slice, pro);
+  else
+    wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
+                                                tiles_i, rows_per_slice, pro);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
