@@ -51,13 +51,14 @@ SIGNATURES = {
     "allset_wgrad": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_reduce_partials": [_P, c_int64, c_int64, _P, _P, _P],
     "allset_wgrad_fused": [_P, c_int64, _P, c_int64, c_float, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, _P,
-                           c_int64, c_int64, c_int64, c_int64, _P, _P],
+                           c_int64, c_int64, c_int64, c_int64, _P, _P, _P],
     "allset_fused_linear_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_partials": [c_int64, POINTER(c_int64)],
     "allset_fused_linear_bwd": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P,
-                                c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
+                                c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P],
     "allset_fused_linear_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
-                                _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P],
+                                _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P],
+    "allset_fused_linear_mask_words": [c_int64, c_int64],
 }
 EXPORTED_SYMBOLS = sorted(list(SIGNATURES) + ["allset_last_error"])
 
@@ -83,6 +84,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.allset_fused_linear_mask_words.restype = c_int64
     lib.allset_last_error.argtypes = []
     lib.allset_last_error.restype = c_char_p
     got = lib.allset_version()

@@ -332,6 +332,7 @@ struct WgradPro {
   const float* y; int64_t ldy; float keep_out;
   const float* stats; const float* gamma; const float* beta; int has_ln; int relu_in; float p_in; uint64_t seed_in;
   const uint64_t* seed_base;
+  const uint32_t* mask; int mask_nh;        // activation mask (replaces y; bf16x6 kernels only), O / 64
 };
 
 template <bool PRO>
@@ -561,12 +562,17 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
     thr_in = drop_threshold(pro.p_in);
     pro.seed_in = resolve_seed(pro.seed_base, pro.seed_in);
   }
-  const bool has_y = PRO && pro.y != nullptr;
+  const bool has_mask = PRO && pro.mask != nullptr;
+  const bool has_y = PRO && pro.y != nullptr && !has_mask;
+  // mask word of (row r, columns a_col..+3): block (r/16, a_col/64), dword (r%16/4)*8 + (r%4)*2 + ((a_col%64)/32),
+  // bits 8c + ((a_col%32)/4) for column a_col + c
+  const int m_col = ((a_col / 64) * 32) + ((a_col % 64) / 32);
+  const int m_bit = (a_col % 32) / 4;
   const bool has_ln = PRO && pro.has_ln;
 
   // Two register sets: the global loads run TWO stages ahead of the MFMAs (one stage of 32-48 KiB per CU in flight is
   // latency-bound at ~3 TB/s), the LDS conversion one stage ahead.
-  struct Stage { float4 ra[2], rb[2], ry[2]; float2 rst[2]; int64_t row0; };
+  struct Stage { float4 ra[2], rb[2], ry[2]; float2 rst[2]; uint32_t rm[2]; int64_t row0; };
   // issue only; unconditional loads on clamped rows / columns (no branches around memory instructions)
   auto load_stage = [&](Stage& sg, int64_t r0) {
     sg.row0 = r0 + 2 * rp;
@@ -578,6 +584,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
       sg.rb[h] = *reinterpret_cast<const float4*>(u + r * ldu + b_col);
       if constexpr (PRO) {
         if (has_y) sg.ry[h] = *reinterpret_cast<const float4*>(pro.y + r * pro.ldy + a_col);
+        if (has_mask) sg.rm[h] = pro.mask[(r >> 4) * (pro.mask_nh * 32) + m_col + ((r & 15) >> 2) * 8 + (r & 3) * 2];
         if (has_ln) sg.rst[h] = *reinterpret_cast<const float2*>(pro.stats + r * 2);
       }
     }
@@ -589,7 +596,11 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
       const bool in_range = (sg.row0 + h) < r_end;
       float4 a = sg.ra[h], t = sg.rb[h];
       if constexpr (PRO) {
-        if (has_y) {
+        if (has_mask) {
+          const uint32_t bits = sg.rm[h] >> m_bit;
+          a.x = (bits & 1u) ? a.x * pro.keep_out : 0.f; a.y = (bits & 0x100u) ? a.y * pro.keep_out : 0.f;
+          a.z = (bits & 0x10000u) ? a.z * pro.keep_out : 0.f; a.w = (bits & 0x1000000u) ? a.w * pro.keep_out : 0.f;
+        } else if (has_y) {
           const float4 yv = sg.ry[h];
           a.x = yv.x > 0.f ? a.x * pro.keep_out : 0.f; a.y = yv.y > 0.f ? a.y * pro.keep_out : 0.f;
           a.z = yv.z > 0.f ? a.z * pro.keep_out : 0.f; a.w = yv.w > 0.f ? a.w * pro.keep_out : 0.f;
@@ -905,9 +916,13 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
                                   const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                                   int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
                                   int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
-                                  void* stream) {
+                                  const uint32_t* mask, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_fused: bad size");
+  if (mask != nullptr && (!dense_mfma_x6() || O % 64 != 0)) {
+    set_error("wgrad_fused: the activation mask is consumed by the bf16x6 kernels only (out features % 64 == 0)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
   ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_fused: bad slice count");
   ALLSET_REQUIRE(part_w != nullptr, "wgrad_fused: null partial buffer");
   ALLSET_REQUIRE(n == 0 || (gy && x), "wgrad_fused: null input");
@@ -929,6 +944,7 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
   pro.y = y; pro.ldy = ldy; pro.keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   pro.stats = stats; pro.gamma = gamma; pro.beta = beta; pro.has_ln = stats != nullptr;
   pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in; pro.seed_base = seed_base;
+  pro.mask = mask; pro.mask_nh = static_cast<int>(O / 64);
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   if (dense_mfma_x6())
     wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),

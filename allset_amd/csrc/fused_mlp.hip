@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W,
     const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
-    int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base) {
+    int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base,
+    uint8_t* __restrict__ mask_out) {
   seed_in = resolve_seed(seed_base, seed_in);
   seed_out = resolve_seed(seed_base, seed_out);
   constexpr int KQ = KD / 4;                       // columns per lane
@@ -384,6 +385,15 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
 #else
         if (r < n) *reinterpret_cast<float4*>(y + r * ldy + hb * 64 + c4) = v;
 #endif
+        if (mask_out != nullptr) {
+          // activation mask for the backward kernels, 1 bit per element (include/allset_hip.h "mask layout"): four
+          // ballots (one per column-of-quad c), byte-transposed so that every consumer needs ONE dword: lane 8*idx'+..
+          const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+          const int c = lane & 3;
+          const uint64_t bsel = c == 0 ? b0 : (c == 1 ? b1 : (c == 2 ? b2 : b3));
+          if (lane < 32)
+            mask_out[(((chunk * (ND / 64) + hb) * 4 + it) * 8) * 4 + lane] = static_cast<uint8_t>(bsel >> (8 * (lane >> 2)));
+        }
       }
       __asm__ volatile("" ::: "memory");
     }
@@ -576,7 +586,8 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
     const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
     const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* __restrict__ gx,
-    int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base) {
+    int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base,
+    const uint32_t* __restrict__ mask) {
   seed_in = resolve_seed(seed_base, seed_in);
   constexpr int OQ = OD / 4, OQD = OQ / 2, T = OQ / 8;
   constexpr int GS = ID * OQD;
@@ -605,8 +616,14 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
   const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
   const uint32_t thr_in = drop_threshold(p_in);
-  const bool has_y = y != nullptr;
+  const bool has_mask = mask != nullptr;
+  const bool has_y = y != nullptr && !has_mask;
   const bool need_x = HAS_LN || relu_in;
+  // this lane's word of the activation mask: row ri of the chunk, columns g*OQ .. +OQ-1
+  constexpr int NHO = OD / 64;
+  const int m_l15 = ((g * OQ) % 64) / 4;
+  const int m_word = (((g * OQ) / 64) * 4 + (ri >> 2)) * 8 + (ri & 3) * 2 + (m_l15 >> 3);
+  const int m_shift = m_l15 & 7;
   const int64_t n_chunks = (n + 15) / 16;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kX6Waves;
   float* sT = sTrans + wave * (16 * 64);
@@ -618,9 +635,11 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
   for (int hb = 0; hb < NH; ++hb) { dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); }
 
   float ag[OQ], ay[OQ];
+  uint32_t am_bits = 0;
   auto request_rows = [&](int64_t chunk) {               // unconditional, clamped (see the forward kernel)
     int64_t row = chunk * 16 + ri;
     row = row < n ? row : n - 1;
+    if (has_mask) am_bits = mask[(row >> 4) * (NHO * 32) + m_word];
 #ifdef ALLSET_ABLATE_NOLOAD
     if (p_in == 123.f) {
 #endif
@@ -648,7 +667,11 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
   for (; chunk < n_chunks; chunk += stride) {
     // ---- A operand
     const bool valid = chunk * 16 + ri < n;
-    if (has_y) {
+    if (has_mask) {
+      const uint32_t bits = valid ? (am_bits >> m_shift) : 0u;
+#pragma unroll
+      for (int j = 0; j < OQ; ++j) ag[j] = (bits & (1u << (8 * (j & 3) + (j >> 2)))) ? ag[j] * keep_out : 0.f;
+    } else if (has_y) {
 #pragma unroll
       for (int j = 0; j < OQ; ++j) ag[j] = (valid && ay[j] > 0.f) ? ag[j] * keep_out : 0.f;
     } else if (!valid) {
@@ -831,6 +854,12 @@ static bool dense_mfma_x6() {
   return !(e && e[0] == 'f');
 }
 
+extern "C" int64_t allset_fused_linear_mask_words(int64_t n, int64_t N) {
+  // 1 bit per output element in 16-row x 64-column blocks of 32 dwords; 0 = this build/mode has no mask support
+  if (!dense_mfma_x6() || n <= 0 || N % 64 != 0) return 0;
+  return ((n + 15) / 16) * (N / 64) * 32;
+}
+
 extern "C" int allset_fused_linear_supported(int64_t K, int64_t N) {
   return ((K == 64 || K == 128) && (N == 64 || N == 128)) ? 1 : 0;
 }
@@ -839,9 +868,13 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
                                        int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                                        int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
                                        float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
-                                       void* stream) {
+                                       uint32_t* mask_out, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
+  if (mask_out != nullptr && !dense_mfma_x6()) {
+    set_error("fused_linear_fwd: the activation mask is produced by the bf16x6 kernels only (allset_fused_linear_mask_words)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_fwd: dropout p must be in [0,1)");
   if (!allset_fused_linear_supported(K, N)) {
     set_error("fused_linear_fwd: K=%lld N=%lld not built (K, N in {64,128})", static_cast<long long>(K), static_cast<long long>(N));
@@ -868,7 +901,7 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
     if (x6)                                                                                                              \
       fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, kX6Block, 0, st>>>(                                      \
           x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
-          seed_base);                                                                                                    \
+          seed_base, reinterpret_cast<uint8_t*>(mask_out));                                                              \
     else                                                                                                                 \
       fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(                                         \
           x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
@@ -921,9 +954,13 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
                                        const float* W, const float* x, int64_t ldx, const float* stats,
                                        const float* gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
                                        int64_t ldgx, float* partials, int64_t n_partials, int64_t n, int64_t O,
-                                       int64_t I, const uint64_t* seed_base, void* stream) {
+                                       int64_t I, const uint64_t* seed_base, const uint32_t* mask, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd: negative size");
+  if (mask != nullptr && !dense_mfma_x6()) {
+    set_error("fused_linear_bwd: the activation mask is consumed by the bf16x6 kernels only");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_bwd: dropout p must be in [0,1)");
   if (!allset_fused_linear_supported(I, O)) {
     set_error("fused_linear_bwd: in=%lld out=%lld not built (both in {64,128})", static_cast<long long>(I), static_cast<long long>(O));
@@ -954,7 +991,7 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
   do {                                                                                                                       \
     if (x6)                                                                                                                  \
       fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI><<<grid, kX6Block, 0, st>>>(                                            \
-          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \
+          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask);  \
     else                                                                                                                     \
       fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(                                                 \
           gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \

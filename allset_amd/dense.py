@@ -144,11 +144,18 @@ def fused_linear_supported(K: int, N: int) -> bool:
     return bool(_lib.load().allset_fused_linear_supported(K, N))
 
 
+def activation_mask_words(n: int, N: int) -> int:
+    """dwords of the 1-bit activation mask of an [n, N] output (0: not supported in this mode / for this width)."""
+    return int(_lib.load().allset_fused_linear_mask_words(n, N))
+
+
 def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor] = None,
                      beta: Optional[Tensor] = None, eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0,
                      seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0, seed_out: int = 0,
-                     seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-    """y = epi(pro(x) @ W^T + b) in one pass (csrc/fused_mlp.hip).  Returns (y, stats or None)."""
+                     seed_base: Optional[Tensor] = None, mask_out: Optional[Tensor] = None
+                     ) -> Tuple[Tensor, Optional[Tensor]]:
+    """y = epi(pro(x) @ W^T + b) in one pass (csrc/fused_mlp.hip).  Returns (y, stats or None).  ``mask_out`` (int32
+    tensor of ``activation_mask_words(n, N)`` elements) receives the 1-bit ``y > 0`` mask for the backward kernels."""
     dev = require_device(x, weight, bias, gamma, beta)
     _check_f32(x, weight, bias, gamma, beta)
     x = _rowmajor(x)
@@ -162,15 +169,17 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
             ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
             ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
             ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
-            ptr(stats), n, K, N, ptr(seed_base), stream_of(dev)), "allset_fused_linear_fwd")
+            ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), stream_of(dev)), "allset_fused_linear_fwd")
     return y, stats
 
 
 def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats: Optional[Tensor],
                 gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                want_bias: bool = True, seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-    """Weight/bias gradient of the fused Linear with both operands recomputed on the fly (csrc/dense.hip)."""
-    dev = require_device(gy, y, x, stats, gamma, beta)
+                want_bias: bool = True, seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None
+                ) -> Tuple[Tensor, Optional[Tensor]]:
+    """Weight/bias gradient of the fused Linear with both operands recomputed on the fly (csrc/dense.hip).
+    ``mask`` (from ``fused_linear_fwd(mask_out=...)``) replaces ``y`` as the source of the epilogue mask."""
+    dev = require_device(gy, y, x, stats, gamma, beta, mask)
     gy, x = _rowmajor(gy), _rowmajor(x)
     if y is not None:
         y = _rowmajor(y)
@@ -181,12 +190,12 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
     check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
     part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
     part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
-    with torch.cuda.device(dev), _timed("wgrad_fused", dev, n * (O * (2 if y is not None else 1) + I) * 4):
+    with torch.cuda.device(dev), _timed("wgrad_fused", dev, n * (O * (2 if (y is not None and mask is None) else 1) + I) * 4):
         check(lib.allset_wgrad_fused(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),
                                      ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                      ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
-                                     ptr(part_w), ptr(part_b), ns.value, n, O, I, ptr(seed_base), stream_of(dev)),
-              "allset_wgrad_fused")
+                                     ptr(part_w), ptr(part_b), ns.value, n, O, I, ptr(seed_base), ptr(mask),
+                                     stream_of(dev)), "allset_wgrad_fused")
     gw = reduce_partials(part_w)
     gb = reduce_partials(part_b) if want_bias else None
     return gw, gb
@@ -194,9 +203,11 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
 
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                      gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                     seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
-    """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip)."""
-    dev = require_device(gy, y, weight, x, stats, gamma)
+                     seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None
+                     ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip).
+    ``mask`` replaces ``y`` as the source of the relu/dropout epilogue mask."""
+    dev = require_device(gy, y, weight, x, stats, gamma, mask)
     gy, x = _rowmajor(gy), _rowmajor(x)
     if y is not None:
         y = _rowmajor(y)
@@ -209,11 +220,11 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
     if stats is not None:
         check(lib.allset_fused_linear_bwd_partials(n, byref(npart)), "allset_fused_linear_bwd_partials")
         partials = torch.empty((npart.value, 2, I), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("fused_linear_bwd", dev, n * (O * (2 if y is not None else 1) + 2 * I) * 4):
+    with torch.cuda.device(dev), _timed("fused_linear_bwd", dev, n * (O * (2 if (y is not None and mask is None) else 1) + 2 * I) * 4):
         check(lib.allset_fused_linear_bwd(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(weight),
                                           ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                           int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(partials), npart.value,
-                                          n, O, I, ptr(seed_base), stream_of(dev)), "allset_fused_linear_bwd")
+                                          n, O, I, ptr(seed_base), ptr(mask), stream_of(dev)), "allset_fused_linear_bwd")
     if partials is None:
         return gx, None, None
     red = reduce_partials(partials)
@@ -314,32 +325,39 @@ class _FusedNormLinear(torch.autograd.Function):
         seed_in = _draw_seed() if p_in > 0.0 else 0
         seed_out = _draw_seed() if p_out > 0.0 else 0
         base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
-        y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out,
-                                    base)
         keep_y = relu_out or p_out > 0.0
-        ctx.save_for_backward(x, stats, gamma, beta, weight, y if keep_y else None)
+        # the backward needs only the sign pattern of y: a 1-bit mask written by the forward kernel (1/32 of y's bytes)
+        words = activation_mask_words(x.shape[0], weight.shape[0]) if keep_y else 0
+        mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
+        y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out,
+                                    base, mask)
+        ctx.save_for_backward(x, stats, gamma, beta, weight, y if (keep_y and mask is None) else None, mask)
         ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, stats, gamma, beta, weight, y = ctx.saved_tensors
+        x, stats, gamma, beta, weight, y, mask = ctx.saved_tensors
         relu_in, p_in, seed_in, p_out, has_bias, base = ctx.cfg
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3] or need_b:
             gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b,
-                                 seed_base=base)
+                                 seed_base=base, mask=mask)
         if ctx.needs_input_grad[0] or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
-            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in, base)
+            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in, base, mask)
         return gx, dg, db, gw, gb, None, None, None, None, None
 
 
 def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
                       eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0, relu_out: bool = False,
                       p_out: float = 0.0) -> Tensor:
+    if p_out > 0.0 and not relu_out:
+        # the backward recovers the epilogue mask from the sign of y, which is only right behind a relu (MLP._post is
+        # always relu -> dropout, reference layers.py:575-577)
+        raise _lib.AllSetHipError("fused_norm_linear: an output dropout needs relu_out=True")
     return _FusedNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out),
                                   float(p_out))
 

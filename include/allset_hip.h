@@ -223,18 +223,30 @@ int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, 
 int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
                        const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                        int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
-                       int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, void* stream);
+                       int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                       const uint32_t* mask, void* stream);
 
 /* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
  *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],
  *                                 epi = [relu_out] -> [dropout p_out].
- * One read + one write of the activation matrix; exact-fp32 MFMA.  stats (f32[n*2] = {mean, rstd}) is written
- * when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0. */
+ * One read + one write of the activation matrix.  Arithmetic: fp32 on the bf16 matrix pipe -- every operand is split
+ * exactly into three bf16 values and six of the nine partial products are accumulated in fp32 ("bf16x6", dropped terms
+ * <= 2^-23 relative: as accurate as a native fp32 MFMA, 2.7x its rate on gfx950); the environment variable
+ * ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels instead (comparison builds).  stats (f32[n*2] =
+ * {mean, rstd}) is written when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0.
+ *
+ * Activation mask (optional, bf16x6 kernels): mask_out receives 1 bit per output element, "y > 0" after the epilogue,
+ * so the backward kernels need not re-read y.  Layout ("mask layout"): blocks of 16 rows x 64 columns, 32 dwords each,
+ * block index (row / 16) * (N / 64) + col / 64; inside a block, dword ((row % 16) / 4) * 8 + (row % 4) * 2 +
+ * (col % 64) / 32, bit 8 * (col % 4) + (col % 32) / 4.  Size: allset_fused_linear_mask_words(n, N) dwords (0 when the
+ * mask is not supported: N % 64 != 0 or ALLSET_DENSE_MFMA=f32).  Pass the same buffer as `mask` to
+ * allset_fused_linear_bwd / allset_wgrad_fused instead of y. */
 int allset_fused_linear_supported(int64_t K, int64_t N);
+int64_t allset_fused_linear_mask_words(int64_t n, int64_t N);
 int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                             int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                             int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats,
-                            int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, void* stream);
+                            int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, uint32_t* mask_out, void* stream);
 
 /* Backward of allset_fused_linear_fwd w.r.t. x (O = out features, I = in features, both in {64,128}):
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0) if y != NULL else gy;   gu = ga @ W;   gz = gu * dropout_{p_in,seed_in} mask;
@@ -245,7 +257,8 @@ int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials);
 int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out, const float* W,
                             const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in,
                             float p_in, uint64_t seed_in, float* gx, int64_t ldgx, float* partials,
-                            int64_t n_partials, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, void* stream);
+                            int64_t n_partials, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                            const uint32_t* mask, void* stream);
 
 #ifdef __cplusplus
 }

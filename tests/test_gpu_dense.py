@@ -306,3 +306,33 @@ def test_fused_linear_bf16x6_is_fp32_accurate(K, N, device, monkeypatch):
         errs[mode] = float(((y.double() - ref).abs() / scale).max())
     assert errs["bf16x6"] < 2e-6 and errs["f32"] < 2e-6, errs
     assert errs["bf16x6"] < 2.0 * errs["f32"], errs
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_activation_mask_layout_and_use(N, device):
+    """The forward kernel's 1-bit mask follows the documented layout (include/allset_hip.h) and the backward kernels
+    give the same results from the mask as from y."""
+    from allset_amd import dense
+    n, K, p = 1003, 128, 0.3
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(n, K, generator=g).to(device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
+    b = torch.randn(N, generator=g).to(device)
+    gamma, beta = (1 + 0.2 * torch.randn(K, generator=g)).to(device), (0.3 * torch.randn(K, generator=g)).to(device)
+    words = dense.activation_mask_words(n, N)
+    assert words == ((n + 15) // 16) * (N // 64) * 32
+    mask = torch.zeros(words, dtype=torch.int32, device=device)
+    y, st = dense.fused_linear_fwd(x, W, b, gamma, beta, 1e-5, True, p, 11, True, p, 22, None, mask)
+    m = mask.cpu().numpy().view(np.uint32)
+    rows, cols = np.meshgrid(np.arange(n), np.arange(N), indexing="ij")
+    dword = ((rows // 16) * (N // 64) + cols // 64) * 32 + ((rows % 16) // 4) * 8 + (rows % 4) * 2 + (cols % 64) // 32
+    bit = 8 * (cols % 4) + (cols % 32) // 4
+    decoded = (m[dword] >> bit) & 1
+    assert np.array_equal(decoded.astype(bool), (y > 0).cpu().numpy())
+    G = torch.randn(n, N, generator=g).to(device)
+    gx_y, dg_y, db_y = dense.fused_linear_bwd(G, y, p, W, x, st, gamma, True, p, 11)
+    gx_m, dg_m, db_m = dense.fused_linear_bwd(G, None, p, W, x, st, gamma, True, p, 11, None, mask)
+    assert torch.equal(gx_y, gx_m) and torch.equal(dg_y, dg_m) and torch.equal(db_y, db_m)
+    gw_y, gb_y = dense.wgrad_fused(G, y, p, x, st, gamma, beta, True, p, 11)
+    gw_m, gb_m = dense.wgrad_fused(G, None, p, x, st, gamma, beta, True, p, 11, mask=mask)
+    assert torch.equal(gw_y, gw_m) and torch.equal(gb_y, gb_m)
