@@ -245,8 +245,12 @@ def main():
                             "the aggregation-only V->E->V fwd+bwd", "kernels": {k: {"calls_per_step": v["calls"] / args.steps,
                                                                           "avg_ms": v["avg_ms"]} for k, v in agg_ks.items()}},
             "dense_tail": {"ms_per_step": dense_ms, "note": "HIP dense-tail kernels per step (fused norm+Linear fwd, "
-                           "backward-data with LayerNorm-backward epilogue, split-K weight gradient: fp32 MFMA, peak 157.3 TF)",
+                           "backward-data with LayerNorm-backward epilogue, split-K weight gradient). fp32 in, fp32 out, "
+                           "fp32-accurate arithmetic on the bf16 matrix pipe: operands split exactly into 3 bf16, 6 of 9 "
+                           "products accumulated in fp32 (error <= native fp32 MFMA, tests/test_gpu_dense.py); these "
+                           "kernels are HBM-bound: gbps = algorithmic activation bytes / time (peak 8000)",
                            "kernels": {k: {"calls_per_step": v["calls"] / args.steps, "avg_ms": v["avg_ms"],
+                                           "gbps": (v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9) if v.get("algo_bytes") else None,
                                            "tflops": (2.0 * rows * d * d / (v["avg_ms"] * 1e-3) / 1e12)
                                            if k in ("fused_linear_fwd", "fused_linear_bwd", "wgrad_fused", "wgrad") else None}
                                        for k, v in dense_ks.items()}},
