@@ -727,6 +727,147 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
   }
 }
 
+
+// ---- LayerNorm with a fused sum in front and a relu behind: the PMA tail (reference layers.py:153-157) --------------------
+//   y = dropout_p( relu_out?( LN_{gamma,beta}( x + colb + res ) ) )     colb [d] and res [n,d] optional
+// serves `ln0(pooled + att_r)` (colb = the seed vector), `ln1(out + relu(rFF(out)))` (res) and the relu -> dropout that
+// SetGNN puts behind every conv, each in ONE read-write pass instead of a torch add + LayerNorm (+ relu/dropout).
+// Backward: gs = d loss / d (x + colb + res) -- the same tensor is the gradient of x and of res, its column sums the
+// gradient of colb (third partial row); the relu mask is recomputed from the statistics (no y kept).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_res_fwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ colb, const float* __restrict__ res, int64_t ldr,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu_out, float p, uint64_t seed,
+    float* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n, int d,
+    const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  constexpr int NS = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 4;
+  const bool active = c0 < d;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  float4 g4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0), cb = make_float4(0, 0, 0, 0);
+  if (active) {
+    g4 = *reinterpret_cast<const float4*>(gamma + c0);
+    b4 = *reinterpret_cast<const float4*>(beta + c0);
+    if (colb) cb = *reinterpret_cast<const float4*>(colb + c0);
+  }
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + grp) * kLnRowsPerGroup;
+  float4 v[kLnRowsPerGroup], w[kLnRowsPerGroup];
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {          // unconditional loads on clamped rows
+    int64_t row = row0 + r;
+    row = row < n ? row : n - 1;
+    const int cc = active ? c0 : 0;
+    v[r] = *reinterpret_cast<const float4*>(x + row * ldx + cc);
+    w[r] = res ? *reinterpret_cast<const float4*>(res + row * ldr + cc) : make_float4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    const int64_t row = row0 + r;
+    float4 t = make_float4(v[r].x + w[r].x + cb.x, v[r].y + w[r].y + cb.y, v[r].z + w[r].z + cb.z, v[r].w + w[r].w + cb.w);
+    if (!active) t = make_float4(0, 0, 0, 0);
+    const float mean = group_sum<LPR>(t.x + t.y + t.z + t.w) * inv_d;
+    float4 c = make_float4(t.x - mean, t.y - mean, t.z - mean, t.w - mean);
+    if (!active) c = make_float4(0, 0, 0, 0);
+    const float var = group_sum<LPR>(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * inv_d;
+    const float rstd = rsqrtf(var + eps);
+    if (row < n) {
+      if (active) {
+        float4 o = make_float4(c.x * rstd * g4.x + b4.x, c.y * rstd * g4.y + b4.y, c.z * rstd * g4.z + b4.z,
+                               c.w * rstd * g4.w + b4.w);
+        if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (p > 0.f) {
+          const int64_t e = row * d + c0;
+          float k0, k1, k2, k3;
+          keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+          o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
+        }
+        *reinterpret_cast<float4*>(y + row * ldy + c0) = o;
+      }
+      if (li == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    }
+  }
+}
+
+// part[blockIdx][0|1|2][c] = dgamma, dbeta, dcolb (= column sums of gs)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ colb,
+    const float* __restrict__ res, int64_t ldr, const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int relu_out, float p, uint64_t seed, float* __restrict__ gs, int64_t ldgs,
+    float* __restrict__ part, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  constexpr int NS = kWave / LPR;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  __shared__ float red[kGroups][3][LPR * 4];
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 4;
+  const bool active = c0 < d;
+  const int cc = active ? c0 : 0;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  float4 g4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0), cb = make_float4(0, 0, 0, 0);
+  if (active) {
+    g4 = *reinterpret_cast<const float4*>(gamma + c0);
+    b4 = *reinterpret_cast<const float4*>(beta + c0);
+    if (colb) cb = *reinterpret_cast<const float4*>(colb + c0);
+  }
+  float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0), dc = make_float4(0, 0, 0, 0);
+  const int64_t rows_per_iter = static_cast<int64_t>(gridDim.x) * kGroups;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + grp; row < n; row += rows_per_iter) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + cc);
+    float4 gv = *reinterpret_cast<const float4*>(gy + row * ldg + cc);
+    const float4 rv = res ? *reinterpret_cast<const float4*>(res + row * ldr + cc) : make_float4(0, 0, 0, 0);
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float4 xh = make_float4((xv.x + rv.x + cb.x - mean) * rstd, (xv.y + rv.y + cb.y - mean) * rstd,
+                            (xv.z + rv.z + cb.z - mean) * rstd, (xv.w + rv.w + cb.w - mean) * rstd);
+    if (!active) { xh = make_float4(0, 0, 0, 0); gv = make_float4(0, 0, 0, 0); }
+    if (p > 0.f) {
+      const int64_t e = row * d + c0;
+      float k0, k1, k2, k3;
+      keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+      gv.x *= k0; gv.y *= k1; gv.z *= k2; gv.w *= k3;
+    }
+    if (relu_out) {                                      // relu mask from the recomputed LayerNorm output
+      if (!(fmaf(xh.x, g4.x, b4.x) > 0.f)) gv.x = 0.f;
+      if (!(fmaf(xh.y, g4.y, b4.y) > 0.f)) gv.y = 0.f;
+      if (!(fmaf(xh.z, g4.z, b4.z) > 0.f)) gv.z = 0.f;
+      if (!(fmaf(xh.w, g4.w, b4.w) > 0.f)) gv.w = 0.f;
+    }
+    dg.x += gv.x * xh.x; dg.y += gv.y * xh.y; dg.z += gv.z * xh.z; dg.w += gv.w * xh.w;
+    db.x += gv.x; db.y += gv.y; db.z += gv.z; db.w += gv.w;
+    const float4 gh = make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w);
+    const float s1 = group_sum<LPR>(gh.x + gh.y + gh.z + gh.w) * inv_d;
+    const float s2 = group_sum<LPR>(gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w) * inv_d;
+    if (active) {
+      const float4 o = make_float4(rstd * (gh.x - s1 - xh.x * s2), rstd * (gh.y - s1 - xh.y * s2),
+                                   rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
+      dc.x += o.x; dc.y += o.y; dc.z += o.z; dc.w += o.w;
+      *reinterpret_cast<float4*>(gs + row * ldgs + c0) = o;
+    }
+  }
+  *reinterpret_cast<float4*>(&red[grp][0][c0]) = dg;
+  *reinterpret_cast<float4*>(&red[grp][1][c0]) = db;
+  *reinterpret_cast<float4*>(&red[grp][2][c0]) = dc;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * LPR * 4; i += kBlock) {
+    const int which = i / (LPR * 4), c = i % (LPR * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) s += red[g][which][c];
+    if (c < d) part[(static_cast<int64_t>(blockIdx.x) * 3 + which) * d + c] = s;
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -976,6 +1117,81 @@ extern "C" int allset_reduce_partials(const float* part, int64_t P, int64_t M, f
     reduce_partials_kernel<<<dim3(gx, static_cast<unsigned>(slabs)), kBlock, 0, st>>>(part, P, M, scratch);
     reduce_partials_kernel<<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out);
   }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_res_supported(int64_t d) { return (d >= 4 && d <= 256 && d % 4 == 0) ? 1 : 0; }
+
+extern "C" int allset_ln_res_fwd(const float* x, int64_t ldx, const float* colb, const float* res, int64_t ldr,
+                                 const float* gamma, const float* beta, float eps, int relu_out, float p, uint64_t seed,
+                                 float* y, int64_t ldy, float* stats, int64_t n, int64_t d, const uint64_t* seed_base,
+                                 void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_fwd: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_fwd: dropout p must be in [0,1)");
+  if (!allset_ln_res_supported(d)) { set_error("ln_res_fwd: width %lld not built (d %% 4 == 0, d <= 256)", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && gamma && beta && y && stats, "ln_res_fwd: null pointer");
+  ALLSET_REQUIRE(ldx >= d && ldy >= d && (res == nullptr || ldr >= d), "ln_res_fwd: leading dimension smaller than d");
+  ALLSET_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
+                 (colb == nullptr || aligned16(colb)) && (res == nullptr || (ldr % 4 == 0 && aligned16(res))),
+                 "ln_res_fwd: rows and parameter vectors must be 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int di = static_cast<int>(d), lpr = ln_lpr(d);
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
+  const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
+#define ALLSET_LNRES_FWD(L) ln_res_fwd_kernel<L><<<grid, kBlock, 0, st>>>(x, ldx, colb, res, ldr, gamma, beta, eps, relu_out, p, seed, y, ldy, stats, n, di, seed_base)
+  switch (lpr) {
+    case 8: ALLSET_LNRES_FWD(8); break;
+    case 16: ALLSET_LNRES_FWD(16); break;
+    case 32: ALLSET_LNRES_FWD(32); break;
+    default: ALLSET_LNRES_FWD(64); break;
+  }
+#undef ALLSET_LNRES_FWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_res_bwd_partials(int64_t n, int64_t d, int64_t* n_partials) {
+  clear_error();
+  ALLSET_REQUIRE(n_partials != nullptr && n >= 0 && allset_ln_res_supported(d), "ln_res_bwd_partials: bad argument");
+  const int lpr = ln_lpr(d);
+  const int64_t groups = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const int64_t want = (n + groups - 1) / groups;
+  *n_partials = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb,
+                                 const float* res, int64_t ldr, const float* stats, const float* gamma, const float* beta,
+                                 int relu_out, float p, uint64_t seed, float* gs, int64_t ldgs, float* partials,
+                                 int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_bwd: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_bwd: dropout p must be in [0,1)");
+  if (!allset_ln_res_supported(d)) { set_error("ln_res_bwd: width %lld not built", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(partials != nullptr && n_partials >= 1, "ln_res_bwd: partials buffer required");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 3 * d * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && x && stats && gamma && beta && gs, "ln_res_bwd: null pointer");
+  ALLSET_REQUIRE(ldg >= d && ldx >= d && ldgs >= d && (res == nullptr || ldr >= d), "ln_res_bwd: leading dimension smaller than d");
+  ALLSET_REQUIRE(ldg % 4 == 0 && ldx % 4 == 0 && ldgs % 4 == 0 && aligned16(gy) && aligned16(x) && aligned16(gs) &&
+                 aligned16(gamma) && aligned16(beta) && (colb == nullptr || aligned16(colb)) &&
+                 (res == nullptr || (ldr % 4 == 0 && aligned16(res))), "ln_res_bwd: rows and parameter vectors must be 16-byte aligned");
+  const int di = static_cast<int>(d);
+  const unsigned grid = static_cast<unsigned>(n_partials);
+#define ALLSET_LNRES_BWD(L) ln_res_bwd_kernel<L><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n, di, seed_base)
+  switch (ln_lpr(d)) {
+    case 8: ALLSET_LNRES_BWD(8); break;
+    case 16: ALLSET_LNRES_BWD(16); break;
+    case 32: ALLSET_LNRES_BWD(32); break;
+    default: ALLSET_LNRES_BWD(64); break;
+  }
+#undef ALLSET_LNRES_BWD
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -362,6 +362,77 @@ def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor]
                                   float(p_out))
 
 
+def ln_res_supported(d: int) -> bool:
+    return bool(_lib.load().allset_ln_res_supported(d))
+
+
+def ln_res_fwd(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
+               relu_out: bool, p: float, seed: int, seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    dev = require_device(x, colb, res, gamma, beta)
+    _check_f32(x, colb, res, gamma, beta)
+    x = _rowmajor(x)
+    res = _rowmajor(res) if res is not None else None
+    n, d = x.shape
+    y = torch.empty((n, d), dtype=torch.float32, device=dev)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("ln_res_fwd", dev, (2 + (res is not None)) * n * d * 4):
+        check(_lib.load().allset_ln_res_fwd(
+            ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res), _ld(res) if res is not None else 0,
+            ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(relu_out), p, seed, ptr(y), max(d, 1), ptr(stats), n, d,
+            ptr(seed_base), stream_of(dev)), "allset_ln_res_fwd")
+    return y, stats
+
+
+def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], stats: Tensor, gamma: Tensor,
+               beta: Tensor, relu_out: bool, p: float, seed: int, seed_base: Optional[Tensor] = None
+               ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """(gs, dgamma, dbeta, dcolb); gs is the gradient of x and of res."""
+    dev = require_device(gy, x, colb, res, stats, gamma, beta)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    res = _rowmajor(res) if res is not None else None
+    n, d = x.shape
+    lib = _lib.load()
+    npart = c_int64(0)
+    check(lib.allset_ln_res_bwd_partials(n, d, byref(npart)), "allset_ln_res_bwd_partials")
+    partials = torch.empty((npart.value, 3, d), dtype=torch.float32, device=dev)
+    gs = torch.empty((n, d), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, (3 + (res is not None)) * n * d * 4):
+        check(lib.allset_ln_res_bwd(
+            ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res),
+            _ld(res) if res is not None else 0, ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), int(relu_out), p,
+            seed, ptr(gs), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base), stream_of(dev)), "allset_ln_res_bwd")
+    red = reduce_partials(partials)
+    return gs, red[0], red[1], red[2]
+
+
+class _LayerNormRes(torch.autograd.Function):
+    """``y = dropout_p(relu_out(LayerNorm(x + colb + res)))`` in one pass each way (csrc/dense.hip ``ln_res_*``)."""
+
+    @staticmethod
+    def forward(ctx, x, colb, res, gamma, beta, eps, relu_out, p):
+        seed = _draw_seed() if p > 0.0 else 0
+        base = _seed_base() if p > 0.0 else None
+        cb = colb.reshape(-1) if colb is not None else None
+        y, stats = ln_res_fwd(x, cb, res, gamma, beta, eps, relu_out, p, seed, base)
+        ctx.save_for_backward(x, cb, res, stats, gamma, beta)
+        ctx.cfg = (bool(relu_out), float(p), seed, base, colb.shape if colb is not None else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, cb, res, stats, gamma, beta = ctx.saved_tensors
+        relu_out, p, seed, base, cshape = ctx.cfg
+        gs, dg, db, dc = ln_res_bwd(gy.contiguous(), x, cb, res, stats, gamma, beta, relu_out, p, seed, base)
+        return gs, (dc.reshape(cshape) if cshape is not None else None), (gs if res is not None else None), dg, db, None, None, None
+
+
+def layer_norm_res(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gamma: Tensor, beta: Tensor,
+                   eps: float = 1e-5, relu_out: bool = False, p: float = 0.0) -> Tensor:
+    """``dropout_p(relu_out(LayerNorm(x + colb + res)))``; ``colb`` broadcasts over rows (any shape with d elements)."""
+    return _LayerNormRes.apply(x, colb, res, gamma, beta, float(eps), bool(relu_out), float(p))
+
+
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, relu_in: bool = False, p: float = 0.0) -> Tensor:
     """``dropout_p(LayerNorm(relu(x) if relu_in else x))`` in one pass."""
     return _LayerNormFused.apply(x, gamma, beta, float(eps), bool(relu_in), float(p))

@@ -306,22 +306,28 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     inlined) on a hyperedge shard.  ``v2e_conv`` / ``e2v_conv``: :class:`allset_amd.layers.HalfNLHconv` with
     ``attention=True``.  V->E targets (hyperedges) are complete on their owner, so that direction is the local
     kernel behind an all-gather of [V | alpha]; E->V needs the cross-shard softmax merge above."""
-    from .layers import _linear, relu_dropout
+    from .layers import _linear, _on_hip
+    from . import dense as _dense
+
+    def _lin_v(pma, t):
+        if _on_hip(t) and _dense.fused_linear_supported(pma.lin_V.in_features, pma.lin_V.out_features):
+            return _dense.fused_norm_linear(t, None, None, pma.lin_V.weight, pma.lin_V.bias)
+        return _linear(pma.lin_V, t)
     K = kernels
     # ---- V -> E
     p = v2e_conv.prop
     H, C = p.heads, p.hidden
     # dense on owned vertices, then two all-gathers (no concatenate / split copies of the [n_V, d] table)
-    V = all_gather_rows(_linear(p.lin_V, x_owned), group)
+    V = all_gather_rows(_lin_v(p, x_owned), group)
     alpha = all_gather_rows(p._logits(x_owned), group)
     o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
-    e = relu_dropout(p.tail(o), dropout, training)
+    e = p.tail(o, _post=dropout if training else 0.0)            # relu -> dropout inside ln1's pass
     # ---- E -> V
     p = e2v_conv.prop
     H, C = p.heads, p.hidden
-    V, alpha = _linear(p.lin_V, e), p._logits(e)                                    # dense on owned hyperedges
+    V, alpha = _lin_v(p, e), p._logits(e)                                           # dense on owned hyperedges
     o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
-    return relu_dropout(p.tail(o), dropout, training)
+    return p.tail(o, _post=dropout if training else 0.0)
 
 
 class ShardedSetGNN(torch.nn.Module):

@@ -205,21 +205,32 @@ class PMA(nn.Module):
             return dense.linear(x, w, b) if (_on_hip(x) and H % 4 == 0 and x.shape[1] % 4 == 0) else F.linear(x, w, b)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
-    def tail(self, pooled: Tensor) -> Tensor:
-        """``+att_r -> ln0 -> ln1(z + relu(rFF(z)))`` (reference layers.py:153-157) on pooled [n_t, H*C]."""
+    def tail(self, pooled: Tensor, _post: Optional[float] = None) -> Tensor:
+        """``+att_r -> ln0 -> ln1(z + relu(rFF(z)))`` (reference layers.py:153-157) on pooled [n_t, H*C].
+        ``_post`` (internal): also the ``relu -> dropout(p)`` SetGNN wraps around the conv, in ln1's pass."""
         H, C = self.heads, self.hidden
+        if _on_hip(pooled) and dense.ln_res_supported(H * C) and self.ln0.bias is not None and self.ln1.bias is not None:
+            # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
+            out = dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
+            z = self.rFF(out, _post=0.0)                                # relu(rFF(.)) in rFF's last fused epilogue
+            return dense.layer_norm_res(out, None, z, self.ln1.weight, self.ln1.bias, self.ln1.eps,
+                                        relu_out=_post is not None, p=float(_post or 0.0))
         out = (pooled.view(-1, H, C) + self.att_r).view(-1, H * C)     # seed + multihead (layers.py:153)
         out = _layer_norm(self.ln0, out)
-        return _layer_norm(self.ln1, out + self.rFF(out, _post=0.0))    # relu(rFF(.)) in rFF's last fused epilogue
+        out = _layer_norm(self.ln1, out + self.rFF(out, _post=0.0))
+        return out if _post is None else relu_dropout(out, _post, True)
 
-    def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None):
+    def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None, _post: Optional[float] = None):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         H = self.heads
         inc = _as_incidence(edge_index, x.shape[0])
-        x_V = _linear(self.lin_V, x)                          # [n_s, H*C]
+        if _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features):
+            x_V = dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias)    # bf16x6 kernels
+        else:
+            x_V = _linear(self.lin_V, x)                      # [n_s, H*C]
         alpha_r = self._logits(x)                             # [n_s, H]
         out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
-        out = self.tail(out)
+        out = self.tail(out, _post)
         if isinstance(return_attention_weights, bool):
             alpha = AF.pma_attention_weights(alpha_r, m, l, inc, self.negative_slope)
             return out, (edge_index, alpha)
@@ -264,7 +275,9 @@ class HalfNLHconv(nn.Module):
         ``SetGNN.forward`` wraps around every conv (models.py:475-481) inside the conv's last fused pass."""
         post = _post_dropout is not None
         if self.attention:
-            x = self.prop(x, edge_index)
+            if post and self.training:      # training: the conv's relu -> dropout rides in ln1's pass (PMA.tail)
+                return self.prop(x, edge_index, _post=float(_post_dropout))
+            x = self.prop(x, edge_index)    # eval: keep the raw PMA output observable (forward hooks), relu separately
             return relu_dropout(x, _post_dropout, self.training) if post else x
         if aggr is None:
             raise ValueError("aggr was not passed!")

@@ -226,6 +226,23 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                        const uint32_t* mask, void* stream);
 
+/* LayerNorm with a fused sum in front and a relu behind -- the PMA tail (reference layers.py:153-157) and the
+ * relu -> dropout SetGNN puts behind every conv (models.py:475-481):
+ *   y = dropout_{p,seed}( relu_out ? relu(.) : . )( LayerNorm_{gamma,beta,eps}( x + colb + res ) )
+ * colb f32[d] (may be NULL: e.g. PMA's seed vector att_r) and res f32[n*ldr] (may be NULL: the residual branch) are added
+ * in registers; stats f32[n*2] = {mean, rstd} of the sum.  Widths: allset_ln_res_supported(d) (d % 4 == 0, d <= 256).
+ * Backward: gs = d loss / d (x + colb + res) -- the gradient of x AND of res; partials f32[n_partials*3*d], row k holds
+ * block k's (dgamma[d], dbeta[d], dcolb[d]); the caller sums over k.  The relu mask is recomputed from the statistics. */
+int allset_ln_res_supported(int64_t d);
+int allset_ln_res_fwd(const float* x, int64_t ldx, const float* colb, const float* res, int64_t ldr, const float* gamma,
+                      const float* beta, float eps, int relu_out, float p, uint64_t seed, float* y, int64_t ldy,
+                      float* stats, int64_t n, int64_t d, const uint64_t* seed_base, void* stream);
+int allset_ln_res_bwd_partials(int64_t n, int64_t d, int64_t* n_partials);
+int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb, const float* res,
+                      int64_t ldr, const float* stats, const float* gamma, const float* beta, int relu_out, float p,
+                      uint64_t seed, float* gs, int64_t ldgs, float* partials, int64_t n_partials, int64_t n, int64_t d,
+                      const uint64_t* seed_base, void* stream);
+
 /* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
  *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],
  *                                 epi = [relu_out] -> [dropout p_out].

@@ -336,3 +336,60 @@ def test_activation_mask_layout_and_use(N, device):
     gw_y, gb_y = dense.wgrad_fused(G, y, p, x, st, gamma, beta, True, p, 11)
     gw_m, gb_m = dense.wgrad_fused(G, None, p, x, st, gamma, beta, True, p, 11, mask=mask)
     assert torch.equal(gw_y, gw_m) and torch.equal(gb_y, gb_m)
+
+
+@pytest.mark.parametrize("d", [128, 64, 100, 256])
+@pytest.mark.parametrize("with_colb,with_res,relu_out", [(True, False, False), (False, True, True), (True, True, True),
+                                                          (False, False, False)])
+def test_layer_norm_res_fwd_bwd(d, with_colb, with_res, relu_out, device):
+    """y = relu_out(LN(x + colb + res)) against torch autograd in float64: output and all five gradients."""
+    from allset_amd import dense
+    n = 1237
+    g = torch.Generator().manual_seed(d * 8 + with_colb * 4 + with_res * 2 + relu_out)
+    x, res = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+    colb = torch.randn(1, 4, d // 4, generator=g)                  # att_r-shaped: [1, H, C]
+    gamma, beta = 1 + 0.2 * torch.randn(d, generator=g), 0.3 * torch.randn(d, generator=g)
+    G = torch.randn(n, d, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (x, colb, res, gamma, beta)]
+    s = ref_in[0]
+    if with_colb:
+        s = s + ref_in[1].reshape(1, d)
+    if with_res:
+        s = s + ref_in[2]
+    ref = F.layer_norm(s, (d,), ref_in[3], ref_in[4], 1e-5)
+    if relu_out:
+        ref = F.relu(ref)
+    (ref * G.double()).sum().backward()
+    dev_in = [t.to(device).requires_grad_(True) for t in (x, colb, res, gamma, beta)]
+    y = dense.layer_norm_res(dev_in[0], dev_in[1] if with_colb else None, dev_in[2] if with_res else None, dev_in[3], dev_in[4],
+                             1e-5, relu_out, 0.0)
+    (y * G.to(device)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    for nm, a, r, used in zip(["x", "colb", "res", "gamma", "beta"], dev_in, ref_in, [True, with_colb, with_res, True, True]):
+        if not used:
+            assert a.grad is None
+            continue
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=2e-4, atol=1e-4 * scale, msg=lambda m: f"{nm}: {m}")
+
+
+def test_layer_norm_res_dropout_mask_consistent(device):
+    """relu -> dropout behind the LayerNorm: Bernoulli(1-p) mask on the positive part, backward uses the same mask."""
+    from allset_amd import dense
+    n, d, p = 3000, 128, 0.4
+    x = torch.randn(n, d, device=device)
+    res = torch.randn(n, d, device=device)
+    gamma, beta = torch.ones(d, device=device), torch.full((d,), 0.2, device=device)
+    y0, st = dense.ln_res_fwd(x, None, res, gamma, beta, 1e-5, True, 0.0, 0)
+    y1, _ = dense.ln_res_fwd(x, None, res, gamma, beta, 1e-5, True, p, 77)
+    pos = y0 > 0
+    kept = y1 != 0
+    assert not bool((kept & ~pos).any())
+    torch.testing.assert_close(y1[kept], (y0 / (1 - p))[kept], rtol=1e-6, atol=1e-6)
+    assert abs(float(kept[pos].float().mean()) - (1 - p)) < 0.01
+    G = torch.randn(n, d, device=device)
+    gs, dg, db, dc = dense.ln_res_bwd(G, x, None, res, st, gamma, beta, True, p, 77)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    (F.relu(F.layer_norm(xr + rr, (d,), gamma, beta, 1e-5)) * (kept.float() / (1 - p)) * G).sum().backward()
+    torch.testing.assert_close(gs, xr.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(gs, rr.grad, rtol=1e-4, atol=2e-5)

@@ -186,3 +186,31 @@ def test_halfnlhconv_identity_mlps(aggr, device):
     out = conv(x.to(device), ei.to(device), torch.ones(300, dtype=torch.int64, device=device), aggr)
     ref = oracle.halfnlhconv_forward({}, "", x, ei, torch.ones(300, dtype=torch.int64), aggr, False, 1, "ln")
     torch.testing.assert_close(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_pma_conv_training_path_fuses_relu_into_tail(device):
+    """HalfNLHconv(attention) in training mode hands SetGNN's relu -> dropout to PMA.tail (ln1's pass).  With p = 0
+    the fused training path must equal relu(eval-path raw output), values and gradients."""
+    from allset_amd import HalfNLHconv, Incidence
+    torch.manual_seed(5)
+    n_v, n_e, d = 300, 120, 128
+    ei = torch.stack([torch.randint(0, n_v, (2000,)), torch.randint(0, n_e, (2000,))]).to(device)
+    ei[1, 0], ei[0, 1] = n_e - 1, n_v - 1
+    conv = HalfNLHconv(d, d, d, 2, dropout=0.0, Normalization='ln', InputNorm=True, heads=4, attention=True).to(device)
+    inc = Incidence.from_edge_index(ei, n_src=n_v)
+    x = torch.randn(n_v, d, device=device)
+    G = torch.randn(n_e, d, device=device)
+    outs = []
+    for training in (False, True):
+        conv.train(training)
+        conv.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        y = conv(xx, inc, None, 'add', _post_dropout=0.0)
+        (y * G).sum().backward()
+        outs.append((y.detach(), xx.grad.clone(), {k: p.grad.clone() for k, p in conv.named_parameters() if p.grad is not None}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = outs
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx1, gx0, rtol=1e-4, atol=1e-5)
+    assert gp0.keys() == gp1.keys()
+    for k in gp0:
+        torch.testing.assert_close(gp1[k], gp0[k], rtol=1e-4, atol=1e-4 * max(1.0, float(gp0[k].abs().max())), msg=lambda m: f"{k}: {m}")
