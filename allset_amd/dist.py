@@ -326,7 +326,10 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     p = e2v_conv.prop
     H, C = p.heads, p.hidden
     V, alpha = _lin_v(p, e), p._logits(e)                                           # dense on owned hyperedges
-    o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
+    if _skip_collective(group):      # one rank owns every vertex: the local fused pooling IS the answer, no (m,l,o) merge
+        o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.e2v, H, p.negative_slope)[hg.v_lo:hg.v_hi]
+    else:
+        o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
     return p.tail(o, _post=dropout if training else 0.0)
 
 
