@@ -1,5 +1,9 @@
 // Fused tall-skinny Linear for the AllSet dense tail on gfx950 (reference MLP.forward, layers.py:571-579).
 //
+// Two kernel families live here.  The DEFAULT is the bf16x6 family further down (fused_linear_*_x6_kernel: fp32-accurate
+// arithmetic on the bf16 matrix pipe, HBM-bound); the native fp32-MFMA family that this header describes first is the
+// comparison arm (ALLSET_DENSE_MFMA=f32) and the documentation of the row-organised scheme both share.
+//
 //   y = epilogue( prologue(x) @ W^T + b )
 //     prologue : [relu] -> [LayerNorm(gamma, beta)] -> [dropout p_in]      applied to the A operand IN REGISTERS
 //     epilogue : [relu] -> [dropout p_out]                                   applied to the MFMA accumulators
