@@ -22,6 +22,14 @@
  *   src/models.py:453-456 edge_index re-basing + torch.stack of the reversed index,
  *   src/layers.py:174,656 index.max()+1 sizing (host syncs every forward)       ->  allset_csr_build (once)
  *
+ *   The dense tail either side of the aggregation -- torch modules in the reference:
+ *   src/layers.py:571-579 MLP.forward: norm -> (Linear -> ReLU -> norm -> dropout)* -> Linear, and the
+ *   relu -> dropout SetGNN puts behind every conv (src/models.py:475-481)        ->  allset_fused_linear_fwd / _bwd,
+ *                                                                                    allset_wgrad_fused (widths 64, 128);
+ *                                                                                    allset_ln_*, allset_relu_dropout_*,
+ *                                                                                    allset_wgrad (any width)
+ *   src/layers.py:153-157 PMA tail: + att_r, ln0, ln1(z + relu(rFF(z)))         ->  allset_ln_res_fwd / _bwd
+ *
  * Conventions
  *  - extern "C", plain pointers and sizes, no torch types.  Every function returns an int status:
  *    0 = ALLSET_OK, <0 = error (see enum); allset_last_error() gives a thread-local message.
