@@ -327,7 +327,9 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     H, C = p.heads, p.hidden
     V, alpha = _lin_v(p, e), p._logits(e)                                           # dense on owned hyperedges
     if _skip_collective(group):      # one rank owns every vertex: the local fused pooling IS the answer, no (m,l,o) merge
-        o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.e2v, H, p.negative_slope)[hg.v_lo:hg.v_hi]
+        o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.e2v, H, p.negative_slope)
+        if hg.v_lo != 0 or hg.v_hi != o.shape[0]:          # (a no-op slice would still cost a zero-fill + copy backward)
+            o = o[hg.v_lo:hg.v_hi]
     else:
         o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
     return p.tail(o, _post=dropout if training else 0.0)
