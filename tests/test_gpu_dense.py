@@ -309,10 +309,11 @@ def test_fused_linear_bf16x6_is_fp32_accurate(K, N, device, monkeypatch):
 
 
 @pytest.mark.parametrize("N", [64, 128])
-def test_activation_mask_layout_and_use(N, device):
+def test_activation_mask_layout_and_use(N, device, monkeypatch):
     """The forward kernel's 1-bit mask follows the documented layout (include/allset_hip.h) and the backward kernels
     give the same results from the mask as from y."""
     from allset_amd import dense
+    monkeypatch.setenv("ALLSET_DENSE_MFMA", "bf16x6")          # the mask belongs to the default kernel family
     n, K, p = 1003, 128, 0.3
     g = torch.Generator().manual_seed(N)
     x = torch.randn(n, K, generator=g).to(device)
