@@ -872,11 +872,6 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
 
 using namespace allset;
 
-// ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels (A/B comparisons); default: bf16x6 (common.h)
-static bool dense_mfma_x6() {
-  const char* e = getenv("ALLSET_DENSE_MFMA");
-  return !(e && e[0] == 'f');
-}
 
 extern "C" int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                              int relu_in, float p, uint64_t seed, float* y, int64_t ldy, float* stats,

@@ -852,11 +852,6 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
 
 using namespace allset;
 
-// ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels (A/B comparisons, tools/dense_bench.py); default bf16x6.
-static bool dense_mfma_x6() {
-  const char* e = getenv("ALLSET_DENSE_MFMA");
-  return !(e && e[0] == 'f');
-}
 
 extern "C" int64_t allset_fused_linear_mask_words(int64_t n, int64_t N) {
   // 1 bit per output element in 16-row x 64-column blocks of 32 dwords; 0 = this build/mode has no mask support
