@@ -181,12 +181,67 @@ class ShardedHypergraph:
         self.e2v = self.v2e.reversed(n_dst=self.n_v_pad)          # partial rows for EVERY vertex
         return self
 
+    def local_vertex_has_incidence(self) -> Tensor:
+        """[n_v_pad] bool: the vertex is a member of at least one of THIS rank's hyperedges (cached)."""
+        if getattr(self, "_vhas", None) is None:
+            self._vhas = torch.bincount(self.local_edge_index[0], minlength=self.n_v_pad) > 0
+        return self._vhas
+
     def owned_vertex_degree(self, group=None) -> Tensor:
         """Global degree of the owned vertices (for E->V 'mean'); one reduce-scatter, cached."""
         if self._vdeg_owned is None:
             deg = torch.bincount(self.local_edge_index[0], minlength=self.n_v_pad).to(torch.float32)
             self._vdeg_owned = _reduce_scatter_rows(deg.view(-1, 1), group).view(-1)
         return self._vdeg_owned
+
+
+def _ordered_key(v: Tensor) -> Tensor:
+    """fp32 -> int64 whose integer order is the float order (NaN excluded): flip the sign bit of non-negatives, all
+    bits of negatives."""
+    b = v.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return torch.where(b >= 0x80000000, 0xFFFFFFFF - b, b + 0x80000000)
+
+
+class _ShardedExtremeMerge(torch.autograd.Function):
+    """Cross-shard ``max`` / ``min`` of per-rank partial extremes ("max needs an all-reduce(max)",
+    bit-exact).  ``part`` [n_v_pad, d]: this rank's extreme over its local incidences (0 where a vertex has none),
+    ``has`` [n_v_pad] bool: the vertex has a local incidence.
+
+    forward : key = (order-preserving 32-bit image of the value) << 8 | (255 - rank) for rows with local incidences,
+              -1 otherwise; ONE max-collective over the int64 keys gives the global extreme AND a unique winner (lowest
+              rank among exact ties) for every (vertex, feature); owned rows are decoded, vertices without any
+              incidence give 0 as in torch_scatter.
+    backward: the all-gathered gradient, masked to the elements this rank won, continues into the local aggregation.
+    """
+
+    @staticmethod
+    def forward(ctx, part, has, hg, group, is_min):
+        w, r = (1, 0) if _skip_collective(group) else (_world(group), dist.get_rank(group))
+        v = -part if is_min else part
+        key = (_ordered_key(v) << 8) | (255 - r)
+        key = torch.where(has.view(-1, 1), key, torch.full_like(key, -1))
+        if _skip_collective(group):
+            best = key
+        else:
+            best = key.clone()
+            dist.all_reduce(best, op=dist.ReduceOp.MAX, group=group)     # [n_v_pad, d] int64: value and winner in one pass
+        won = (best == key) & has.view(-1, 1)
+        lo, hi = hg.v_lo, hg.v_hi
+        kb = best[lo:hi]
+        any_inc = kb >= 0
+        bits = (kb >> 8) & 0xFFFFFFFF
+        bits = torch.where(bits >= 0x80000000, bits - 0x80000000, 0xFFFFFFFF - bits)
+        val = torch.where(bits >= 0x80000000, bits - 0x100000000, bits).to(torch.int32).view(torch.float32)
+        out = torch.where(any_inc, -val if is_min else val, torch.zeros_like(val))
+        ctx.save_for_backward(won)
+        ctx.group = group
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (won,) = ctx.saved_tensors
+        g_full = _all_gather_rows(gout.contiguous(), ctx.group)
+        return torch.where(won, g_full, torch.zeros_like(g_full)), None, None, None, None
 
 
 def _hip_deepsets(x, inc, norm, aggr):
@@ -233,8 +288,8 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     of the layer output.  ``v2e_conv`` / ``e2v_conv`` are :class:`allset_amd.layers.HalfNLHconv` (Deep Sets
     variant); their parameters are replicated, so parameter gradients must be all-reduced by the caller
     (``allreduce_grads``) -- each rank sees only its rows."""
-    if aggr not in ("add", "sum", "mean"):
-        raise NotImplementedError("sharded E->V supports add/sum/mean (max needs an arg-owner exchange)")
+    if aggr not in ("add", "sum", "mean", "max", "min"):
+        raise ValueError(f"aggr {aggr!r}")
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
     # ``training`` must agree with the convs' own mode (the fused MLP kernels read conv.training)
     h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
@@ -243,8 +298,13 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)           # conv's relu (SetGNN's outer relu is idempotent) + dropout
     # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
     g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
-    partial = aggregate(g, hg.e2v, hg.norm, "add")
-    v = reduce_scatter_rows(partial, group)
+    if aggr in ("max", "min"):
+        # local extreme over this rank's hyperedges (autograd routes to the local arg-extreme), then the key merge
+        partial = aggregate(g, hg.e2v, hg.norm, aggr)
+        v = _ShardedExtremeMerge.apply(partial, hg.local_vertex_has_incidence(), hg, group, aggr == "min")
+    else:
+        partial = aggregate(g, hg.e2v, hg.norm, "add")
+        v = reduce_scatter_rows(partial, group)
     if aggr == "mean":
         v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
     return e2v_conv._mlp_act(e2v_conv.f_dec, v, dropout)

@@ -74,7 +74,7 @@ def _worker(rank, world, port, aggr, method, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("aggr,method", [("add", "contiguous"), ("mean", "lpt")])
+@pytest.mark.parametrize("aggr,method", [("add", "contiguous"), ("mean", "lpt"), ("max", "contiguous"), ("min", "lpt")])
 def test_sharded_layer_equals_unsharded(aggr, method):
     world = 2
     ctx = mp.get_context("spawn")
@@ -316,3 +316,50 @@ def test_sharded_setgnn_equals_oracle(mode):
     ref = oracle.setgnn_forward(sd, args, x, ei, torch.ones(ei.shape[1], dtype=torch.int64))
     got = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cross-shard max: one winner per (vertex, feature), lowest rank on exact ties, vertices without incidences give 0
+# ---------------------------------------------------------------------------------------------------------------
+
+def _merge_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
+        n_v, d = 6, 3
+        hg = adist.ShardedHypergraph(torch.zeros((2, 0), dtype=torch.int64), n_v, 0, world, rank)
+        # rows: 0 only rank 0 has it; 1 only rank 1; 2 both, rank 1 larger; 3 both, exact tie; 4 nobody; 5 both, negative values
+        part = torch.tensor([[[1., -2., 3.], [0., 0., 0.], [1., 1., 1.], [5., -0.5, 0.], [0., 0., 0.], [-4., -1., -9.]],
+                             [[0., 0., 0.], [-7., 8., 9.], [2., 0.5, 4.], [5., -0.5, 0.], [0., 0., 0.], [-3., -2., -9.]]])[rank]
+        has = torch.tensor([[True, False, True, True, False, True], [False, True, True, True, False, True]])[rank]
+        part = part.clone().requires_grad_(True)
+        out = adist._ShardedExtremeMerge.apply(part, has, hg, None, False)
+        G = torch.arange(1, 1 + out.numel(), dtype=torch.float32).view_as(out) + 100 * rank
+        (out * G).sum().backward()
+        q.put((rank, out.detach().numpy().copy(), part.grad.numpy().copy(), hg.v_lo, hg.v_hi))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_max_merge_picks_one_winner():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out = np.concatenate([res[0][1], res[1][1]])
+    expect = np.array([[1., -2., 3.], [-7., 8., 9.], [2., 1., 4.], [5., -0.5, 0.], [0., 0., 0.], [-3., -1., -9.]], dtype=np.float32)
+    assert np.array_equal(out, expect)
+    # cotangent of row v, feature c (as seen by the owner of v): rank 0 owns rows 0-2, rank 1 rows 3-5
+    G = np.concatenate([np.arange(1, 10, dtype=np.float32).reshape(3, 3), np.arange(1, 10, dtype=np.float32).reshape(3, 3) + 100])
+    g0, g1 = res[0][2], res[1][2]
+    win0 = np.array([[1, 1, 1], [0, 0, 0], [0, 1, 0], [1, 1, 1], [0, 0, 0], [0, 1, 1]], dtype=bool)     # ties -> rank 0
+    win1 = np.array([[0, 0, 0], [1, 1, 1], [1, 0, 1], [0, 0, 0], [0, 0, 0], [1, 0, 0]], dtype=bool)
+    assert np.array_equal(g0, np.where(win0, G, 0)) and np.array_equal(g1, np.where(win1, G, 0))
