@@ -589,9 +589,9 @@ template <int OD, int ID, bool HAS_LN, bool DROP_IN>
 __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
     const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
-    const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* __restrict__ gx,
+    const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
     int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base,
-    const uint32_t* __restrict__ mask) {
+    const uint32_t* __restrict__ mask, const float* acc_in, int64_t ldacc) {
   seed_in = resolve_seed(seed_base, seed_in);
   constexpr int OQ = OD / 4, OQD = OQ / 2, T = OQ / 8;
   constexpr int GS = ID * OQD;
@@ -821,6 +821,10 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
             if (!(m & 4u)) o.z = 0.f;
             if (!(m & 8u)) o.w = 0.f;
           }
+          if (acc_in != nullptr) {        // gx = acc_in + ...: a second gradient branch of the same tensor, summed here
+            const float4 ai = *reinterpret_cast<const float4*>(acc_in + r * ldacc + hb * 64 + c4);   // (may alias gx)
+            o.x += ai.x; o.y += ai.y; o.z += ai.z; o.w += ai.w;
+          }
 #ifdef ALLSET_ABLATE_NOSTORE
           if (o.x == 123.456f)
 #endif
@@ -953,9 +957,15 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
                                        const float* W, const float* x, int64_t ldx, const float* stats,
                                        const float* gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
                                        int64_t ldgx, float* partials, int64_t n_partials, int64_t n, int64_t O,
-                                       int64_t I, const uint64_t* seed_base, const uint32_t* mask, void* stream) {
+                                       int64_t I, const uint64_t* seed_base, const uint32_t* mask, const float* acc_in,
+                                       int64_t ldacc, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd: negative size");
+  if (acc_in != nullptr && !dense_mfma_x6()) {
+    set_error("fused_linear_bwd: acc_in is taken by the bf16x6 kernels only");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && aligned16(acc_in)), "fused_linear_bwd: acc_in must be 16-byte aligned rows");
   if (mask != nullptr && !dense_mfma_x6()) {
     set_error("fused_linear_bwd: the activation mask is consumed by the bf16x6 kernels only");
     return ALLSET_ERR_UNSUPPORTED;
@@ -990,7 +1000,8 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
   do {                                                                                                                       \
     if (x6)                                                                                                                  \
       fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI><<<grid, kX6Block, 0, st>>>(                                            \
-          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask);  \
+          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask,   \
+          acc_in, ldacc);                                                                                                    \
     else                                                                                                                     \
       fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(                                                 \
           gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \

@@ -203,11 +203,12 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
 
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                      gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                     seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None
+                     seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None, acc_in: Optional[Tensor] = None
                      ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
     """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip).
-    ``mask`` replaces ``y`` as the source of the relu/dropout epilogue mask."""
-    dev = require_device(gy, y, weight, x, stats, gamma, mask)
+    ``mask`` replaces ``y`` as the source of the relu/dropout epilogue mask.  ``acc_in`` [n, I]: another gradient
+    branch of the same input, summed in the kernel (``gx = acc_in + ...``; the buffer is reused for the result)."""
+    dev = require_device(gy, y, weight, x, stats, gamma, mask, acc_in)
     gy, x = _rowmajor(gy), _rowmajor(x)
     if y is not None:
         y = _rowmajor(y)
@@ -215,7 +216,11 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
     n, O = gy.shape
     I = x.shape[1]
     lib = _lib.load()
-    gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    if acc_in is not None:
+        acc_in = _rowmajor(acc_in)
+        gx = acc_in if acc_in.is_contiguous() else torch.empty((n, I), dtype=torch.float32, device=dev)
+    else:
+        gx = torch.empty((n, I), dtype=torch.float32, device=dev)
     partials, npart = None, c_int64(0)
     if stats is not None:
         check(lib.allset_fused_linear_bwd_partials(n, byref(npart)), "allset_fused_linear_bwd_partials")
@@ -224,7 +229,8 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
         check(lib.allset_fused_linear_bwd(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(weight),
                                           ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                           int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(partials), npart.value,
-                                          n, O, I, ptr(seed_base), ptr(mask), stream_of(dev)), "allset_fused_linear_bwd")
+                                          n, O, I, ptr(seed_base), ptr(mask), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0,
+                                          stream_of(dev)), "allset_fused_linear_bwd")
     if partials is None:
         return gx, None, None
     red = reduce_partials(partials)
@@ -431,6 +437,78 @@ def layer_norm_res(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gam
                    eps: float = 1e-5, relu_out: bool = False, p: float = 0.0) -> Tensor:
     """``dropout_p(relu_out(LayerNorm(x + colb + res)))``; ``colb`` broadcasts over rows (any shape with d elements)."""
     return _LayerNormRes.apply(x, colb, res, gamma, beta, float(eps), bool(relu_out), float(p))
+
+
+class _PmaProject(torch.autograd.Function):
+    """``x -> (x_V = x W_V^T + b_V,  alpha = x w_a^T + b_a)``: PMA's value projection and its folded logit mat-vec
+    (reference layers.py:126-131) as one autograd node, so that the two gradient branches of ``x`` are summed inside the
+    backward-data kernel (``acc_in``) instead of by a separate [n, d] add pass."""
+
+    @staticmethod
+    def forward(ctx, x, w_v, b_v, w_a, b_a):
+        x_v, _ = fused_linear_fwd(x, w_v, b_v)
+        alpha = torch.nn.functional.linear(x, w_a, b_a)
+        ctx.save_for_backward(x, w_v, w_a)
+        ctx.has_bias = (b_v is not None, b_a is not None)
+        return x_v, alpha
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_v, g_alpha):
+        x, w_v, w_a = ctx.saved_tensors
+        g_v, g_alpha = g_v.contiguous(), g_alpha.contiguous()
+        gx = gwv = gbv = gwa = gba = None
+        if ctx.needs_input_grad[0]:
+            gx, _, _ = fused_linear_bwd(g_v, None, 0.0, w_v, x, None, None, False, 0.0, 0, acc_in=g_alpha @ w_a)
+        if ctx.needs_input_grad[1] or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
+            gwv, gbv = wgrad(g_v, x, want_bias=ctx.has_bias[0])
+        if ctx.needs_input_grad[3] or (ctx.has_bias[1] and ctx.needs_input_grad[4]):
+            if wgrad_supported(g_alpha, x):
+                gwa, gba = wgrad(g_alpha, x, want_bias=ctx.has_bias[1])
+            else:
+                gwa, gba = g_alpha.t() @ x, (g_alpha.sum(0) if ctx.has_bias[1] else None)
+        return gx, gwv, gbv, gwa, gba
+
+
+def pma_project(x: Tensor, w_v: Tensor, b_v: Optional[Tensor], w_a: Tensor, b_a: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    return _PmaProject.apply(x, w_v, b_v, w_a, b_a)
+
+
+class _PmaResidualFF(torch.autograd.Function):
+    """``y = dropout_p(relu_post(LN(out + relu(W2 relu(W1 out + b1) + b2))))`` -- the second half of the PMA tail
+    (reference layers.py:156-157 with a 2-layer rFF) as one autograd node: three kernels forward, five backward, and the
+    two gradient branches of ``out`` (through the LayerNorm and through rFF) are summed by the last backward-data
+    kernel (``acc_in``) instead of an extra add pass."""
+
+    @staticmethod
+    def forward(ctx, out, w1, b1, w2, b2, gamma, beta, eps, relu_post, p):
+        y1, _ = fused_linear_fwd(out, w1, b1)
+        words = activation_mask_words(out.shape[0], w2.shape[0])
+        mask = torch.empty(words, dtype=torch.int32, device=out.device) if words > 0 else None
+        z, _ = fused_linear_fwd(y1, w2, b2, None, None, 1e-5, True, 0.0, 0, True, 0.0, 0, None, mask)
+        seed = _draw_seed() if p > 0.0 else 0
+        base = _seed_base() if p > 0.0 else None
+        y, stats = ln_res_fwd(out, None, z, gamma, beta, eps, relu_post, p, seed, base)
+        ctx.save_for_backward(out, y1, z, mask, stats, w1, w2, gamma, beta)
+        ctx.cfg = (bool(relu_post), float(p), seed, base, b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        out, y1, z, mask, stats, w1, w2, gamma, beta = ctx.saved_tensors
+        relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
+        gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
+        zy = None if mask is not None else z
+        gw2, gb2 = wgrad_fused(gs, zy, 0.0, y1, None, None, None, True, 0.0, 0, want_bias=has_b2, mask=mask)
+        g1, _, _ = fused_linear_bwd(gs, zy, 0.0, w2, y1, None, None, True, 0.0, 0, None, mask)
+        gw1, gb1 = wgrad(g1, out, want_bias=has_b1)
+        gout, _, _ = fused_linear_bwd(g1, None, 0.0, w1, out, None, None, False, 0.0, 0, acc_in=gs)   # gs + rFF branch
+        return gout, gw1, gb1, gw2, gb2, dg, db, None, None, None
+
+
+def pma_residual_ff(out: Tensor, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5, relu_post: bool = False, p: float = 0.0) -> Tensor:
+    return _PmaResidualFF.apply(out, w1, b1, w2, b2, gamma, beta, float(eps), bool(relu_post), float(p))
 
 
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, relu_in: bool = False, p: float = 0.0) -> Tensor:

@@ -378,14 +378,14 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     p = v2e_conv.prop
     H, C = p.heads, p.hidden
     # dense on owned vertices, then two all-gathers (no concatenate / split copies of the [n_V, d] table)
-    V = all_gather_rows(_lin_v(p, x_owned), group)
-    alpha = all_gather_rows(p._logits(x_owned), group)
+    V, alpha = p.project(x_owned)
+    V, alpha = all_gather_rows(V, group), all_gather_rows(alpha, group)
     o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
     e = p.tail(o, _post=dropout if training else 0.0)            # relu -> dropout inside ln1's pass
     # ---- E -> V
     p = e2v_conv.prop
     H, C = p.heads, p.hidden
-    V, alpha = _lin_v(p, e), p._logits(e)                                           # dense on owned hyperedges
+    V, alpha = p.project(e)                                                         # dense on owned hyperedges
     if _skip_collective(group):      # one rank owns every vertex: the local fused pooling IS the answer, no (m,l,o) merge
         o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.e2v, H, p.negative_slope)
         if hg.v_lo != 0 or hg.v_hi != o.shape[0]:          # (a no-op slice would still cost a zero-fill + copy backward)

@@ -14,7 +14,7 @@ identity + version) or a prebuilt :class:`allset_amd.incidence.Incidence`.
 from __future__ import annotations
 
 import math
-from typing import Optional, Union
+from typing import Tuple, Optional, Union
 
 import torch
 import torch.nn as nn
@@ -205,6 +205,19 @@ class PMA(nn.Module):
             return dense.linear(x, w, b) if (_on_hip(x) and H % 4 == 0 and x.shape[1] % 4 == 0) else F.linear(x, w, b)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
+    def project(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        """``(x_V, alpha_r)``: the value projection and the (folded) logits of ``x``."""
+        H, C = self.heads, self.hidden
+        fusable = _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features)
+        if fusable and self.fold_alpha and H % 4 == 0 and dense.activation_mask_words(16, 64) > 0:
+            # one autograd node for both consumers of x (bf16x6 kernels; the branches' gradients are summed in-kernel)
+            w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
+            b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
+            return dense.pma_project(x, self.lin_V.weight, self.lin_V.bias, w, b)
+        x_V = (dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias) if fusable
+               else _linear(self.lin_V, x))
+        return x_V, self._logits(x)
+
     def tail(self, pooled: Tensor, _post: Optional[float] = None) -> Tensor:
         """``+att_r -> ln0 -> ln1(z + relu(rFF(z)))`` (reference layers.py:153-157) on pooled [n_t, H*C].
         ``_post`` (internal): also the ``relu -> dropout(p)`` SetGNN wraps around the conv, in ln1's pass."""
@@ -212,7 +225,13 @@ class PMA(nn.Module):
         if _on_hip(pooled) and dense.ln_res_supported(H * C) and self.ln0.bias is not None and self.ln1.bias is not None:
             # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
             out = dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
-            z = self.rFF(out, _post=0.0)                                # relu(rFF(.)) in rFF's last fused epilogue
+            ff = self.rFF
+            if (len(ff.lins) == 2 and ff._fusable(out) and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
+                    and ff.lins[1].out_features == H * C):
+                # the whole residual block as one autograd node (gradient branches of `out` summed in a kernel)
+                return dense.pma_residual_ff(out, ff.lins[0].weight, ff.lins[0].bias, ff.lins[1].weight, ff.lins[1].bias,
+                                             self.ln1.weight, self.ln1.bias, self.ln1.eps, _post is not None, float(_post or 0.0))
+            z = ff(out, _post=0.0)                                      # relu(rFF(.)) in rFF's last fused epilogue
             return dense.layer_norm_res(out, None, z, self.ln1.weight, self.ln1.bias, self.ln1.eps,
                                         relu_out=_post is not None, p=float(_post or 0.0))
         out = (pooled.view(-1, H, C) + self.att_r).view(-1, H * C)     # seed + multihead (layers.py:153)
@@ -224,11 +243,7 @@ class PMA(nn.Module):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         H = self.heads
         inc = _as_incidence(edge_index, x.shape[0])
-        if _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features):
-            x_V = dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias)    # bf16x6 kernels
-        else:
-            x_V = _linear(self.lin_V, x)                      # [n_s, H*C]
-        alpha_r = self._logits(x)                             # [n_s, H]
+        x_V, alpha_r = self.project(x)                        # [n_s, H*C], [n_s, H]
         out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
         out = self.tail(out, _post)
         if isinstance(return_attention_weights, bool):

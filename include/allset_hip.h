@@ -277,13 +277,15 @@ int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, con
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0) if y != NULL else gy;   gu = ga @ W;   gz = gu * dropout_{p_in,seed_in} mask;
  *   gx = LayerNorm-backward(gz; x, stats, gamma) through relu_in   (stats != NULL), else gz through relu_in.
  * partials (stats != NULL): f32[n_partials*2*I], row w = wave w's (dgamma[I], dbeta[I]); the caller sums over rows.
- * n_partials from allset_fused_linear_bwd_partials(n). */
+ * n_partials from allset_fused_linear_bwd_partials(n).
+ * acc_in (may be NULL; f32[n*ldacc], may alias gx): added to the result, gx = acc_in + (this Linear's gradient) -- where
+ * a tensor feeds two branches the second branch's backward kernel does the sum instead of a separate add pass. */
 int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials);
 int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out, const float* W,
                             const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in,
                             float p_in, uint64_t seed_in, float* gx, int64_t ldgx, float* partials,
                             int64_t n_partials, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
-                            const uint32_t* mask, void* stream);
+                            const uint32_t* mask, const float* acc_in, int64_t ldacc, void* stream);
 
 #ifdef __cplusplus
 }
