@@ -55,9 +55,9 @@ SIGNATURES = {
     "allset_fused_linear_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_partials": [c_int64, POINTER(c_int64)],
     "allset_fused_linear_bwd": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P,
-                                c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P],
+                                c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, _P, _P],
     "allset_fused_linear_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
-                                _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P],
+                                _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "allset_fused_linear_mask_words": [c_int64, c_int64],
     "allset_ln_res_supported": [c_int64],
     "allset_ln_res_fwd": [_P, c_int64, _P, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
     float eps, int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W,
     const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
     int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base,
-    uint8_t* __restrict__ mask_out) {
+    uint8_t* __restrict__ mask_out, const float* __restrict__ aux_w, const float* __restrict__ aux_b,
+    float* __restrict__ aux_out) {
   seed_in = resolve_seed(seed_base, seed_in);
   seed_out = resolve_seed(seed_base, seed_out);
   constexpr int KQ = KD / 4;                       // columns per lane
@@ -227,7 +228,12 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
   __shared__ __attribute__((aligned(16))) float sBeta[KD];
   __shared__ __attribute__((aligned(16))) float sBias[ND];
   __shared__ __attribute__((aligned(16))) float sTrans[kX6Waves * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float sAux[4 * KD + 4];         // 4 auxiliary output columns: weights, bias
   const int tid = threadIdx.x;
+  if (aux_out != nullptr) {
+    for (int idx = tid; idx < 4 * KD; idx += kX6Block) sAux[idx] = aux_w[idx];
+    if (tid < 4) sAux[4 * KD + tid] = aux_b ? aux_b[tid] : 0.f;
+  }
   for (int idx = tid; idx < ND * KD / 2; idx += kX6Block) {
     const int j = idx / (KD / 2), k = 2 * (idx % (KD / 2));
     const float2 w = *reinterpret_cast<const float2*>(W + j * KD + k);
@@ -313,6 +319,27 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
         keep_scale2(seed_in, row * KD + g * KQ + j, thr_in, keep_in, k0, k1);
         a[j] *= k0; a[j + 1] *= k1;
       }
+    }
+    if (aux_out != nullptr) {
+      // four extra output columns in plain fp32 FMAs (PMA's folded attention logits ride along with the value
+      // projection: a [n,K] x [K,4] product is all bandwidth, and the rows are already in registers here)
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < KQ; j += 4) {
+        const float4 w0 = *reinterpret_cast<const float4*>(&sAux[0 * KD + g * KQ + j]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&sAux[1 * KD + g * KQ + j]);
+        const float4 w2 = *reinterpret_cast<const float4*>(&sAux[2 * KD + g * KQ + j]);
+        const float4 w3 = *reinterpret_cast<const float4*>(&sAux[3 * KD + g * KQ + j]);
+        s0 = fmaf(a[j], w0.x, fmaf(a[j + 1], w0.y, fmaf(a[j + 2], w0.z, fmaf(a[j + 3], w0.w, s0))));
+        s1 = fmaf(a[j], w1.x, fmaf(a[j + 1], w1.y, fmaf(a[j + 2], w1.z, fmaf(a[j + 3], w1.w, s1))));
+        s2 = fmaf(a[j], w2.x, fmaf(a[j + 1], w2.y, fmaf(a[j + 2], w2.z, fmaf(a[j + 3], w2.w, s2))));
+        s3 = fmaf(a[j], w3.x, fmaf(a[j + 1], w3.y, fmaf(a[j + 2], w3.z, fmaf(a[j + 3], w3.w, s3))));
+      }
+      s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16); s3 += __shfl_xor(s3, 16);
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+      if (valid && g == 0)
+        *reinterpret_cast<float4*>(aux_out + row * 4) =
+            make_float4(s0 + sAux[4 * KD], s1 + sAux[4 * KD + 1], s2 + sAux[4 * KD + 2], s3 + sAux[4 * KD + 3]);
     }
     uint32_t ah[KQD], am[KQD], al[KQD];
 #pragma unroll
@@ -591,7 +618,8 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
     const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
     const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
     int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base,
-    const uint32_t* __restrict__ mask, const float* acc_in, int64_t ldacc) {
+    const uint32_t* __restrict__ mask, const float* acc_in, int64_t ldacc, const float* __restrict__ aux_g,
+    const float* __restrict__ aux_w) {
   seed_in = resolve_seed(seed_base, seed_in);
   constexpr int OQ = OD / 4, OQD = OQ / 2, T = OQ / 8;
   constexpr int GS = ID * OQD;
@@ -637,6 +665,14 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
   float4 dg[NH], db[NH];
 #pragma unroll
   for (int hb = 0; hb < NH; ++hb) { dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  // rank-4 update gx += aux_g[n,4] @ aux_w[4,I] (the gradient of four auxiliary output columns of the forward)
+  float4 wa[NH][4];
+  if (aux_g != nullptr) {
+#pragma unroll
+    for (int hb = 0; hb < NH; ++hb)
+#pragma unroll
+      for (int h = 0; h < 4; ++h) wa[hb][h] = *reinterpret_cast<const float4*>(aux_w + h * ID + hb * 64 + c4);
+  }
 
   float ag[OQ], ay[OQ];
   uint32_t am_bits = 0;
@@ -825,6 +861,13 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
             const float4 ai = *reinterpret_cast<const float4*>(acc_in + r * ldacc + hb * 64 + c4);   // (may alias gx)
             o.x += ai.x; o.y += ai.y; o.z += ai.z; o.w += ai.w;
           }
+          if (aux_g != nullptr) {
+            const float4 q = *reinterpret_cast<const float4*>(aux_g + r * 4);
+            o.x = fmaf(q.x, wa[hb][0].x, fmaf(q.y, wa[hb][1].x, fmaf(q.z, wa[hb][2].x, fmaf(q.w, wa[hb][3].x, o.x))));
+            o.y = fmaf(q.x, wa[hb][0].y, fmaf(q.y, wa[hb][1].y, fmaf(q.z, wa[hb][2].y, fmaf(q.w, wa[hb][3].y, o.y))));
+            o.z = fmaf(q.x, wa[hb][0].z, fmaf(q.y, wa[hb][1].z, fmaf(q.z, wa[hb][2].z, fmaf(q.w, wa[hb][3].z, o.z))));
+            o.w = fmaf(q.x, wa[hb][0].w, fmaf(q.y, wa[hb][1].w, fmaf(q.z, wa[hb][2].w, fmaf(q.w, wa[hb][3].w, o.w))));
+          }
 #ifdef ALLSET_ABLATE_NOSTORE
           if (o.x == 123.456f)
 #endif
@@ -871,9 +914,15 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
                                        int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                                        int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
                                        float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
-                                       uint32_t* mask_out, void* stream) {
+                                       uint32_t* mask_out, const float* aux_w, const float* aux_b, float* aux_out,
+                                       void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
+  if (aux_out != nullptr && !dense_mfma_x6()) {
+    set_error("fused_linear_fwd: auxiliary output columns are computed by the bf16x6 kernels only");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(aux_out == nullptr || (aux_w != nullptr && aligned16(aux_out)), "fused_linear_fwd: aux_out needs aux_w and 16-byte alignment");
   if (mask_out != nullptr && !dense_mfma_x6()) {
     set_error("fused_linear_fwd: the activation mask is produced by the bf16x6 kernels only (allset_fused_linear_mask_words)");
     return ALLSET_ERR_UNSUPPORTED;
@@ -904,7 +953,7 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
     if (x6)                                                                                                              \
       fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, kX6Block, 0, st>>>(                                      \
           x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
-          seed_base, reinterpret_cast<uint8_t*>(mask_out));                                                              \
+          seed_base, reinterpret_cast<uint8_t*>(mask_out), aux_w, aux_b, aux_out);                                       \
     else                                                                                                                 \
       fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(                                         \
           x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
@@ -958,9 +1007,14 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
                                        const float* gamma, int relu_in, float p_in, uint64_t seed_in, float* gx,
                                        int64_t ldgx, float* partials, int64_t n_partials, int64_t n, int64_t O,
                                        int64_t I, const uint64_t* seed_base, const uint32_t* mask, const float* acc_in,
-                                       int64_t ldacc, void* stream) {
+                                       int64_t ldacc, const float* aux_g, const float* aux_w, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd: negative size");
+  if (aux_g != nullptr && !dense_mfma_x6()) {
+    set_error("fused_linear_bwd: the auxiliary rank-4 update is done by the bf16x6 kernels only");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(aux_g == nullptr || (aux_w != nullptr && aligned16(aux_g) && aligned16(aux_w)), "fused_linear_bwd: aux_g needs aux_w, both 16-byte aligned");
   if (acc_in != nullptr && !dense_mfma_x6()) {
     set_error("fused_linear_bwd: acc_in is taken by the bf16x6 kernels only");
     return ALLSET_ERR_UNSUPPORTED;
@@ -1001,7 +1055,7 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
     if (x6)                                                                                                                  \
       fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI><<<grid, kX6Block, 0, st>>>(                                            \
           gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask,   \
-          acc_in, ldacc);                                                                                                    \
+          acc_in, ldacc, aux_g, aux_w);                                                                                      \
     else                                                                                                                     \
       fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(                                                 \
           gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \

@@ -152,7 +152,8 @@ def activation_mask_words(n: int, N: int) -> int:
 def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor] = None,
                      beta: Optional[Tensor] = None, eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0,
                      seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0, seed_out: int = 0,
-                     seed_base: Optional[Tensor] = None, mask_out: Optional[Tensor] = None
+                     seed_base: Optional[Tensor] = None, mask_out: Optional[Tensor] = None,
+                     aux_w: Optional[Tensor] = None, aux_b: Optional[Tensor] = None, aux_out: Optional[Tensor] = None
                      ) -> Tuple[Tensor, Optional[Tensor]]:
     """y = epi(pro(x) @ W^T + b) in one pass (csrc/fused_mlp.hip).  Returns (y, stats or None).  ``mask_out`` (int32
     tensor of ``activation_mask_words(n, N)`` elements) receives the 1-bit ``y > 0`` mask for the backward kernels."""
@@ -169,7 +170,8 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
             ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
             ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
             ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
-            ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), stream_of(dev)), "allset_fused_linear_fwd")
+            ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), ptr(aux_w), ptr(aux_b), ptr(aux_out), stream_of(dev)),
+            "allset_fused_linear_fwd")
     return y, stats
 
 
@@ -203,7 +205,8 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
 
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                      gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                     seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None, acc_in: Optional[Tensor] = None
+                     seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None, acc_in: Optional[Tensor] = None,
+                     aux_g: Optional[Tensor] = None, aux_w: Optional[Tensor] = None
                      ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
     """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip).
     ``mask`` replaces ``y`` as the source of the relu/dropout epilogue mask.  ``acc_in`` [n, I]: another gradient
@@ -230,7 +233,7 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
                                           ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                           int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(partials), npart.value,
                                           n, O, I, ptr(seed_base), ptr(mask), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0,
-                                          stream_of(dev)), "allset_fused_linear_bwd")
+                                          ptr(aux_g), ptr(aux_w), stream_of(dev)), "allset_fused_linear_bwd")
     if partials is None:
         return gx, None, None
     red = reduce_partials(partials)
@@ -441,32 +444,50 @@ def layer_norm_res(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gam
 
 class _PmaProject(torch.autograd.Function):
     """``x -> (x_V = x W_V^T + b_V,  alpha = x w_a^T + b_a)``: PMA's value projection and its folded logit mat-vec
-    (reference layers.py:126-131) as one autograd node, so that the two gradient branches of ``x`` are summed inside the
-    backward-data kernel (``acc_in``) instead of by a separate [n, d] add pass."""
+    (reference layers.py:126-131) as one autograd node.  With up to 4 heads the logits are four auxiliary output
+    columns of the projection kernel and their input gradient a rank-4 update inside its backward-data kernel -- no
+    skinny GEMMs, no add pass for the two gradient branches of ``x``; with more heads the logits use the library GEMM and
+    the branches are summed through ``acc_in``."""
 
     @staticmethod
     def forward(ctx, x, w_v, b_v, w_a, b_a):
-        x_v, _ = fused_linear_fwd(x, w_v, b_v)
-        alpha = torch.nn.functional.linear(x, w_a, b_a)
-        ctx.save_for_backward(x, w_v, w_a)
-        ctx.has_bias = (b_v is not None, b_a is not None)
+        H = w_a.shape[0]
+        aux = H <= 4
+        if aux:
+            w4 = w_a if H == 4 else torch.cat([w_a, w_a.new_zeros(4 - H, w_a.shape[1])])
+            b4 = None if b_a is None else (b_a if H == 4 else torch.cat([b_a, b_a.new_zeros(4 - H)]))
+            a4 = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
+            x_v, _ = fused_linear_fwd(x, w_v, b_v, aux_w=w4.contiguous(), aux_b=b4, aux_out=a4)
+            alpha = a4 if H == 4 else a4[:, :H].contiguous()
+        else:
+            w4 = w_a
+            x_v, _ = fused_linear_fwd(x, w_v, b_v)
+            alpha = torch.nn.functional.linear(x, w_a, b_a)
+        ctx.save_for_backward(x, w_v, w4)
+        ctx.cfg = (b_v is not None, b_a is not None, aux, H)
         return x_v, alpha
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_v, g_alpha):
-        x, w_v, w_a = ctx.saved_tensors
+        x, w_v, w4 = ctx.saved_tensors
+        has_bv, has_ba, aux, H = ctx.cfg
         g_v, g_alpha = g_v.contiguous(), g_alpha.contiguous()
         gx = gwv = gbv = gwa = gba = None
         if ctx.needs_input_grad[0]:
-            gx, _, _ = fused_linear_bwd(g_v, None, 0.0, w_v, x, None, None, False, 0.0, 0, acc_in=g_alpha @ w_a)
-        if ctx.needs_input_grad[1] or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
-            gwv, gbv = wgrad(g_v, x, want_bias=ctx.has_bias[0])
-        if ctx.needs_input_grad[3] or (ctx.has_bias[1] and ctx.needs_input_grad[4]):
-            if wgrad_supported(g_alpha, x):
-                gwa, gba = wgrad(g_alpha, x, want_bias=ctx.has_bias[1])
+            if aux:
+                g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
+                gx, _, _ = fused_linear_bwd(g_v, None, 0.0, w_v, x, None, None, False, 0.0, 0, aux_g=g4.contiguous(),
+                                            aux_w=w4.contiguous())
             else:
-                gwa, gba = g_alpha.t() @ x, (g_alpha.sum(0) if ctx.has_bias[1] else None)
+                gx, _, _ = fused_linear_bwd(g_v, None, 0.0, w_v, x, None, None, False, 0.0, 0, acc_in=g_alpha @ w4)
+        if ctx.needs_input_grad[1] or (has_bv and ctx.needs_input_grad[2]):
+            gwv, gbv = wgrad(g_v, x, want_bias=has_bv)
+        if ctx.needs_input_grad[3] or (has_ba and ctx.needs_input_grad[4]):
+            if wgrad_supported(g_alpha, x):
+                gwa, gba = wgrad(g_alpha, x, want_bias=has_ba)
+            else:
+                gwa, gba = g_alpha.t() @ x, (g_alpha.sum(0) if has_ba else None)
         return gx, gwv, gbv, gwa, gba
 
 

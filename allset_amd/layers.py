@@ -209,7 +209,7 @@ class PMA(nn.Module):
         """``(x_V, alpha_r)``: the value projection and the (folded) logits of ``x``."""
         H, C = self.heads, self.hidden
         fusable = _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features)
-        if fusable and self.fold_alpha and H % 4 == 0 and dense.activation_mask_words(16, 64) > 0:
+        if fusable and self.fold_alpha and dense.activation_mask_words(16, 64) > 0:       # bf16x6 family active
             # one autograd node for both consumers of x (bf16x6 kernels; the branches' gradients are summed in-kernel)
             w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
             b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]

@@ -260,6 +260,11 @@ int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx,
  * ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels instead (comparison builds).  stats (f32[n*2] =
  * {mean, rstd}) is written when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0.
  *
+ * Auxiliary output columns (optional, bf16x6 kernels): aux_out f32[n*4] = pro(x) @ aux_w^T + aux_b with aux_w f32[4*K],
+ * aux_b f32[4] or NULL -- four extra output columns from the rows already in registers (PMA's folded attention logits
+ * next to its value projection, reference layers.py:126-131).  Their gradient w.r.t. x is the rank-4 update
+ * gx += aux_g[n,4] @ aux_w[4,I] of allset_fused_linear_bwd (aux_g, aux_w; NULL = none).
+ *
  * Activation mask (optional, bf16x6 kernels): mask_out receives 1 bit per output element, "y > 0" after the epilogue,
  * so the backward kernels need not re-read y.  Layout ("mask layout"): blocks of 16 rows x 64 columns, 32 dwords each,
  * block index (row / 16) * (N / 64) + col / 64; inside a block, dword ((row % 16) / 4) * 8 + (row % 4) * 2 +
@@ -271,7 +276,8 @@ int64_t allset_fused_linear_mask_words(int64_t n, int64_t N);
 int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                             int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                             int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats,
-                            int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, uint32_t* mask_out, void* stream);
+                            int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, uint32_t* mask_out,
+                            const float* aux_w, const float* aux_b, float* aux_out, void* stream);
 
 /* Backward of allset_fused_linear_fwd w.r.t. x (O = out features, I = in features, both in {64,128}):
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0) if y != NULL else gy;   gu = ga @ W;   gz = gu * dropout_{p_in,seed_in} mask;
@@ -285,7 +291,8 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
                             const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in,
                             float p_in, uint64_t seed_in, float* gx, int64_t ldgx, float* partials,
                             int64_t n_partials, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
-                            const uint32_t* mask, const float* acc_in, int64_t ldacc, void* stream);
+                            const uint32_t* mask, const float* acc_in, int64_t ldacc, const float* aux_g,
+                            const float* aux_w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,21 +20,21 @@ for name, flags in (("full", []), ("no-load", ["-DALLSET_ABLATE_NOLOAD"]), ("no-
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + flags + src, check=True)
     lib = ctypes.CDLL(so)
     fn = lib.allset_fused_linear_fwd
-    fn.argtypes = [P, I64, P, P, F, I, F, U64, P, P, I, F, U64, P, I64, P, I64, I64, I64, P, P, P]
+    fn.argtypes = [P, I64, P, P, F, I, F, U64, P, P, I, F, U64, P, I64, P, I64, I64, I64, P, P, P, P, P, P]
     fb = lib.allset_fused_linear_bwd
-    fb.argtypes = [P, I64, P, I64, F, P, P, I64, P, P, I, F, U64, P, I64, P, I64, I64, I64, I64, P, P, P, I64, P]
+    fb.argtypes = [P, I64, P, I64, F, P, P, I64, P, P, I, F, U64, P, I64, P, I64, I64, I64, I64, P, P, P, I64, P, P, P]
     npart = ctypes.c_int64(0)
     lib.allset_fused_linear_bwd_partials.argtypes = [I64, ctypes.POINTER(I64)]
     lib.allset_fused_linear_bwd_partials(n, ctypes.byref(npart))
     parts = torch.empty(npart.value * 2 * d, device=dev)
     gam = torch.ones(d, device=dev); gxo = torch.empty(n, d, device=dev)
     def run_fwd():
-        rc = fn(x.data_ptr(), d, None, None, 1e-5, 0, 0.0, 0, W.data_ptr(), b.data_ptr(), 0, 0.0, 0, y.data_ptr(), d, None, n, d, d, None, None,
+        rc = fn(x.data_ptr(), d, None, None, 1e-5, 0, 0.0, 0, W.data_ptr(), b.data_ptr(), 0, 0.0, 0, y.data_ptr(), d, None, n, d, d, None, None, None, None, None,
                 torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     def run_bwd():      # LayerNorm backward epilogue, no dropout, no y mask (the K1 shape of the bench)
         rc = fb(x.data_ptr(), d, None, 0, 0.0, W.data_ptr(), y.data_ptr(), d, st.data_ptr(), gam.data_ptr(), 0, 0.0, 0,
-                gxo.data_ptr(), d, parts.data_ptr(), npart.value, n, d, d, None, None, None, 0, torch.cuda.current_stream().cuda_stream)
+                gxo.data_ptr(), d, parts.data_ptr(), npart.value, n, d, d, None, None, None, 0, None, None, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.allset_last_error()
     lib.allset_last_error.restype = ctypes.c_char_p
     out = []
