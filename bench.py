@@ -232,7 +232,11 @@ def main():
         line = {
             "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": value, "unit": "edges*d/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: every fp32 operand split exactly "
+                          "into three bf16, six of the nine partial products formed on the bf16 matrix pipe and accumulated in "
+                          "fp32 -- measured error vs float64 <= that of the native fp32 MFMA / hipBLASLt (DESIGN.md section 6)",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if attn else 2}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph |V|=|E|={n_loc} per GPU, "
                                    f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, " +
                                    (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
