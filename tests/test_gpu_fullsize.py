@@ -76,3 +76,39 @@ def test_pma_is_a_convex_combination(big, device):
     from allset_amd import deepsets_aggregate
     assert bool((out <= deepsets_aggregate(V, v2e, None, "max") + 1e-4).all())
     assert bool((out >= deepsets_aggregate(V, v2e, None, "min") - 1e-4).all())
+
+
+def test_dense_tail_full_size_properties(device):
+    """The fused Linear kernels at the bench shape (n = 1M rows, 128 -> 128), checked through properties that need no
+    reference run: sampled rows against float64, additivity of the weight gradient over a row split, and the adjoint
+    identity <J x, g> = <x, J^T g> between forward and backward-data of the plain Linear."""
+    from allset_amd import dense
+    n, d = 1_000_003, 128                      # not a multiple of the 16 / 32-row tiles
+    g = torch.Generator(device=device).manual_seed(11)
+    x = torch.randn(n, d, device=device, generator=g)
+    W = torch.randn(d, d, device=device, generator=g) / d ** 0.5
+    b = torch.randn(d, device=device, generator=g)
+    gamma = 1 + 0.2 * torch.randn(d, device=device, generator=g)
+    beta = 0.3 * torch.randn(d, device=device, generator=g)
+    G = torch.randn(n, d, device=device, generator=g)
+    rows = torch.cat([torch.arange(0, 64, device=device), torch.randint(0, n, (4000,), device=device, generator=g),
+                      torch.arange(n - 64, n, device=device)])
+    # forward with the LayerNorm prologue and a relu epilogue, sampled rows in float64
+    y, st = dense.fused_linear_fwd(x, W, b, gamma, beta, 1e-5, False, 0.0, 0, True, 0.0, 0)
+    xs = x[rows].double()
+    ref = torch.relu(torch.nn.functional.layer_norm(xs, (d,), gamma.double(), beta.double(), 1e-5) @ W.double().t() + b.double())
+    torch.testing.assert_close(y[rows].double(), ref, rtol=1e-4, atol=1e-5)
+    # weight gradient is additive over a split of the rows
+    gw, gb = dense.wgrad(G, x)
+    h = 499_999
+    gw1, gb1 = dense.wgrad(G[:h], x[:h])
+    gw2, gb2 = dense.wgrad(G[h:], x[h:])
+    scale = float(gw.abs().max())
+    torch.testing.assert_close(gw1 + gw2, gw, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(gb1 + gb2, gb, rtol=1e-4, atol=1e-5 * float(gb.abs().max()))
+    # adjoint identity between the plain forward and its backward-data
+    yp, _ = dense.fused_linear_fwd(x, W, None)
+    gx, _, _ = dense.fused_linear_bwd(G, None, 0.0, W, x, None, None, False, 0.0, 0)
+    lhs = (yp.double() * G.double()).sum()
+    rhs = (x.double() * gx.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float(lhs.abs() + rhs.abs()) + 1e-2
