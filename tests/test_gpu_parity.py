@@ -214,3 +214,34 @@ def test_pma_conv_training_path_fuses_relu_into_tail(device):
     assert gp0.keys() == gp1.keys()
     for k in gp0:
         torch.testing.assert_close(gp1[k], gp0[k], rtol=1e-4, atol=1e-4 * max(1.0, float(gp0[k].abs().max())), msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("heads,hidden", [(8, 128), (2, 64), (1, 128), (16, 128)])
+def test_pma_layer_head_counts_match_oracle(heads, hidden, device):
+    """PMA with head counts either side of the 4-column auxiliary path (H <= 4: logits ride in the projection kernel,
+    H > 4: library GEMM + in-kernel accumulation of the two gradient branches) against the CPU oracle."""
+    from oracle import allset_oracle as oracle
+    from allset_amd import PMA, Incidence
+    torch.manual_seed(heads)
+    n_s, n_t, nnz = 700, 300, 5000
+    ei = torch.stack([torch.randint(0, n_s, (nnz,)), torch.randint(0, n_t, (nnz,))])
+    ei[0, 0], ei[1, 1] = n_s - 1, n_t - 1
+    pma = PMA(hidden, hidden, hidden, 2, heads=heads)
+    sd = {f"p.{k}": v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in pma.state_dict().items()}
+    x = torch.randn(n_s, hidden)
+    G = torch.randn(n_t, hidden)
+    xr = x.clone().requires_grad_(True)
+    ref = oracle.pma_forward(sd, "p.", xr, ei, heads)
+    (ref * G).sum().backward()
+    pd = pma.to(device)
+    xd = x.to(device).requires_grad_(True)
+    out = pd(xd, Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t))
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(xr.grad.abs().max())))
+    for k, p in pd.named_parameters():
+        r = sd[f"p.{k}"].grad
+        if r is None:
+            continue
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(p.grad.cpu(), r, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{k}: {m}")
