@@ -208,8 +208,9 @@ int allset_relu_dropout_bwd(const float* gy, const float* y, float p, float* gx,
 
 /* Weight gradient of y = u W^T + b:  gW[o][i] = sum_r ga[r][o] * u[r][i],  gb[o] = sum_r ga[r][o], as
  * n_slices split-K partials (part_w: f32[n_slices*O*I], part_b: f32[n_slices*O] or NULL) that the caller
- * sums -- deterministic, no atomics.  fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32).  O, I, lda, ldu must be
- * multiples of 4 and the inputs 16-byte aligned, else ALLSET_ERR_UNSUPPORTED. */
+ * sums -- deterministic, no atomics.  fp32-accurate arithmetic (bf16x6 on the bf16 matrix pipe, see
+ * allset_fused_linear_fwd; the native fp32 MFMA with ALLSET_DENSE_MFMA=f32).  O, I, lda, ldu must be multiples of 4 and
+ * the inputs 16-byte aligned, else ALLSET_ERR_UNSUPPORTED. */
 int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);

@@ -15,7 +15,8 @@ model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
 for world in (1, 2, 4, 8):
     adist._all_gather_rows = (lambda x, group=None, w=world: x if w == 1 else x.repeat((w,) + (1,) * (x.dim() - 1)))
     adist._reduce_scatter_rows = (lambda x, group=None, w=world: x if w == 1 else x[: x.shape[0] // w].contiguous())
-    adist._skip_collective = lambda group=None: True
+    adist._skip_collective = lambda group=None, w=world: w == 1      # world > 1: take the real merge paths ...
+    adist.dist.all_reduce = lambda *a, **k: None                      # ... with the small max-all-reduce stubbed out
     n_v = n_loc * world
     shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev)
     hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm).build_incidences()
