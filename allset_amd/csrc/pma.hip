@@ -595,7 +595,7 @@ static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t*
   if (n_t == 0) return ALLSET_OK;
   const int64_t d = H * C;
   ALLSET_REQUIRE(rowptr && out && m && l, "pma_fwd: null rowptr/out/m/l");
-  ALLSET_REQUIRE(n_s == 0 || (col && alpha && V), "pma_fwd: null col/alpha/V with n_s > 0");
+  ALLSET_REQUIRE(n_s == 0 || (alpha && V && (col || nnz_hint == 0)), "pma_fwd: null col/alpha/V with n_s > 0");
   ALLSET_REQUIRE(ldv >= d && ldo >= d, "pma_fwd: leading dimension smaller than H*C");
   const int wide = dtype == ALLSET_F32 ? 4 : 8;
   const bool wide_ok = (C % wide == 0) && (ldv % wide == 0) && (ldo % wide == 0) && aligned16(V) && aligned16(out);
@@ -726,7 +726,7 @@ static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int3
   if (n_s == 0) return ALLSET_OK;
   const int64_t d = H * C;
   ALLSET_REQUIRE(rowptrT && alpha && V && gV && galpha, "pma_bwd_src: null pointer");
-  ALLSET_REQUIRE(n_t == 0 || (colT && gout && stats), "pma_bwd_src: null colT/gout/stats with n_t > 0");
+  ALLSET_REQUIRE(n_t == 0 || (gout && stats && (colT || nnz_hint == 0)), "pma_bwd_src: null colT/gout/stats with n_t > 0");
   ALLSET_REQUIRE(ldv >= d && ldg >= d && ldgv >= d, "pma_bwd_src: leading dimension smaller than H*C");
   ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "pma_bwd_src: stats must be 8-byte aligned");
   const int wide = dtype == ALLSET_F32 ? 4 : 8;

@@ -397,9 +397,9 @@ static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, 
   if (n_t == 0 || d == 0) return ALLSET_OK;
   ALLSET_REQUIRE(rowptr && out, "segreduce_fwd: null rowptr/out");
   ALLSET_REQUIRE(ldx >= d && ldo >= d, "segreduce_fwd: leading dimension smaller than d");
-  // col/x may only be null when there is nothing to gather; that cannot be known without a sync, so
-  // require them whenever a source table is declared.
-  ALLSET_REQUIRE(n_s == 0 || (col && x), "segreduce_fwd: null col/x with n_s > 0");
+  // col/x may only be null when there is nothing to gather; without the caller's nnz that cannot be known (no sync
+  // here), so require them whenever a source table is declared -- unless nnz == 0 was stated (the _ex entry).
+  ALLSET_REQUIRE(n_s == 0 || nnz_hint == 0 || (col && x), "segreduce_fwd: null col/x with n_s > 0");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const bool ext = (reduce == ALLSET_MAX || reduce == ALLSET_MIN);
   const float sign = (reduce == ALLSET_MIN) ? -1.f : 1.f;

@@ -1,0 +1,138 @@
+"""GPU: randomised shapes (hypothesis, fixed seed): CSR build is bit-exact against numpy's stable sort, and the
+aggregation kernels agree with the oracle for arbitrary (n_src, n_dst, nnz, d, heads) incl. empty inputs, empty
+segments, duplicated incidences, single rows holding everything and widths that are not multiples of 4."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, seed, settings, strategies as st
+
+from oracle import allset_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+COMMON = dict(deadline=None, max_examples=40, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+
+
+@st.composite
+def incidences(draw, max_n=400, max_nnz=3000):
+    n_s = draw(st.integers(1, max_n))
+    n_t = draw(st.integers(1, max_n))
+    nnz = draw(st.integers(0, max_nnz))
+    shape = draw(st.sampled_from(["uniform", "one_row", "few_cols", "dups"]))
+    rs = np.random.default_rng(draw(st.integers(0, 2 ** 31 - 1)))
+    src = rs.integers(0, n_s, size=nnz)
+    dst = rs.integers(0, n_t, size=nnz)
+    if shape == "one_row":
+        dst[:] = rs.integers(0, n_t)
+    elif shape == "few_cols":
+        src = src % max(1, min(3, n_s))
+    elif shape == "dups" and nnz:
+        k = max(1, nnz // 4)
+        src, dst = np.tile(src[:k], 4)[:nnz], np.tile(dst[:k], 4)[:nnz]
+    return n_s, n_t, torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+
+
+@settings(**COMMON)
+@given(inc=incidences())
+def test_csr_build_bit_exact(inc, device):
+    from allset_amd import Incidence
+    n_s, n_t, ei = inc
+    I = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    for csr, keys, vals, nr in ((I.by_dst, ei[1].numpy(), ei[0].numpy(), n_t), (I.by_src, ei[0].numpy(), ei[1].numpy(), n_s)):
+        order = np.argsort(keys, kind="stable")
+        np.testing.assert_array_equal(csr.perm.cpu().numpy(), order)
+        np.testing.assert_array_equal(csr.col.cpu().numpy(), vals[order])
+        np.testing.assert_array_equal(csr.rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=nr))]))
+
+
+@settings(**COMMON)
+@given(inc=incidences(), d=st.sampled_from([1, 2, 4, 7, 16, 33, 64, 128, 200, 256]), aggr=st.sampled_from(["add", "mean", "max", "min"]),
+       weighted=st.booleans())
+def test_deepsets_aggregate_random(inc, d, aggr, weighted, device):
+    from allset_amd import Incidence, deepsets_aggregate
+    n_s, n_t, ei = inc
+    nnz = ei.shape[1]
+    g = torch.Generator().manual_seed(nnz * 131 + d)
+    x = torch.randn(n_s, d, generator=g)
+    norm = (0.5 + torch.rand(nnz, generator=g)) if weighted else torch.ones(nnz, dtype=torch.int64)
+    G = torch.randn(n_t, d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    if nnz == 0:                                               # (the reference cannot even size its output here)
+        ref = xr.new_zeros(n_t, d) + 0.0 * xr.sum()
+    else:
+        ref = oracle.deepsets_aggregate(xr, ei, norm, aggr)
+    if ref.shape[0] < n_t:                                     # the reference sizes by index.max()+1 (Q1)
+        ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], d)])
+    (ref * G).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    I = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    out = deepsets_aggregate(xd, I, norm.to(device), aggr)
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    if aggr in ("add", "mean"):                               # max/min ties may pick another (equal) argument
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    else:
+        torch.testing.assert_close(xd.grad.sum(0).cpu(), xr.grad.sum(0), rtol=1e-3, atol=1e-3)
+
+
+@settings(**COMMON)
+@given(inc=incidences(max_n=300, max_nnz=2000), heads=st.sampled_from([1, 2, 4, 8]), c=st.sampled_from([1, 4, 8, 16, 32]))
+def test_pma_aggregate_random(inc, heads, c, device):
+    from allset_amd import Incidence, pma_aggregate
+    n_s, n_t, ei = inc
+    d = heads * c
+    g = torch.Generator().manual_seed(ei.shape[1] * 17 + d)
+    V = torch.randn(n_s, d, generator=g)
+    alpha = 2.0 * torch.randn(n_s, heads, generator=g)
+    G = torch.randn(n_t, d, generator=g)
+    Vr, ar = V.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    if ei.shape[1] == 0:
+        ref = Vr.new_zeros(n_t, d) + 0.0 * (Vr.sum() + ar.sum())
+    else:
+        ref, _ = oracle.pma_aggregate(Vr.view(-1, heads, c), ar, ei, 0.2)
+        ref = ref.reshape(-1, d)
+    if ref.shape[0] < n_t:
+        ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], d)])
+    (ref * G).sum().backward()
+    Vd, ad = V.to(device).requires_grad_(True), alpha.to(device).requires_grad_(True)
+    I = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    out, m, l = pma_aggregate(Vd, ad, I, heads, 0.2)
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    if ei.shape[1]:
+        torch.testing.assert_close(Vd.grad.cpu(), Vr.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-3, atol=1e-4)
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 700), K=st.sampled_from([64, 128]), N=st.sampled_from([64, 128]), has_ln=st.booleans(),
+       relu_in=st.booleans(), relu_out=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, device):
+    """Any row count (tails of the 16-row chunks, n = 1) and every prologue / epilogue combination without dropout:
+    output and all gradients of the fused Linear against float64 torch."""
+    import torch.nn.functional as F
+    from allset_amd import dense
+    g = torch.Generator(device=device).manual_seed(sd)
+    x = torch.randn(n, K, device=device, generator=g)
+    W = torch.randn(N, K, device=device, generator=g) / K ** 0.5
+    b = torch.randn(N, device=device, generator=g)
+    gamma = 1 + 0.2 * torch.randn(K, device=device, generator=g)
+    beta = 0.3 * torch.randn(K, device=device, generator=g)
+    G = torch.randn(n, N, device=device, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (x, gamma, beta, W, b)]
+    h = F.relu(ref_in[0]) if relu_in else ref_in[0]
+    if has_ln:
+        h = F.layer_norm(h, (K,), ref_in[1], ref_in[2], 1e-5)
+    ref = F.linear(h, ref_in[3], ref_in[4])
+    if relu_out:
+        ref = F.relu(ref)
+    (ref * G.double()).sum().backward()
+    dev_in = [t.clone().requires_grad_(True) for t in (x, gamma, beta, W, b)]
+    y = dense.fused_norm_linear(dev_in[0], dev_in[1] if has_ln else None, dev_in[2] if has_ln else None, dev_in[3], dev_in[4],
+                                1e-5, relu_in, 0.0, relu_out, 0.0)
+    (y * G).sum().backward()
+    torch.testing.assert_close(y.detach().double(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for nm, a, r in zip(["x", "gamma", "beta", "W", "b"], dev_in, ref_in):
+        if nm in ("gamma", "beta") and not has_ln:
+            continue
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.double(), r.grad, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{nm}: {m}")
