@@ -136,3 +136,47 @@ def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, d
             continue
         scale = max(1.0, float(r.grad.abs().max()))
         torch.testing.assert_close(a.grad.double(), r.grad, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{nm}: {m}")
+
+
+@settings(deadline=None, max_examples=30, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+@given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64, 128]),
+       heads=st.sampled_from([1, 2, 4]), aggr=st.sampled_from(["add", "mean", "max"]), norm=st.sampled_from(["ln", "bn", "None"]),
+       input_norm=st.booleans(), mask=st.booleans(), gpr=st.booleans(), wnorm=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_setgnn_random_configurations_match_oracle(pma, layers, mlp_layers, hidden, heads, aggr, norm, input_norm, mask, gpr,
+                                                   wnorm, sd, device):
+    """Whole-model parity on random SetGNN configurations (depths, widths on and off the fused paths, heads,
+    aggregations, normalisations, LearnMask, GPR, weighted incidences): logits and d(loss)/dx against the oracle,
+    the same parameters on both sides."""
+    from types import SimpleNamespace
+    import cases
+    from oracle import allset_oracle as oracle
+    from allset_amd import SetGNN
+    rng = np.random.default_rng(sd)
+    n_v, n_e, f, k = 40, 17, 12, 5
+    ei = cases.random_hypergraph(rng, n_v, n_e, 150, True)
+    x = rng.standard_normal((n_v, f)).astype(np.float32)
+    args = cases.make_args("pma_h1" if pma else "ds_add", f, hidden, k, All_num_layers=layers, MLP_num_layers=mlp_layers,
+                           heads=heads if pma else 1, aggregate=aggr if not pma else "add", normalization=norm,
+                           deepset_input_norm=input_norm, LearnMask=mask, GPR=gpr, Classifier_num_layers=2)
+    nrm = cases._norm_deg_half_sym(ei) if (wnorm or mask) else np.ones(ei.shape[1], dtype=np.int64)
+    norm_t = torch.from_numpy(nrm)
+    torch.manual_seed(sd)
+    model = SetGNN(args, norm=norm_t.to(torch.float32) if mask else None)
+    model.reset_parameters()
+    model.eval()
+    sdict = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    for v in sdict.values():
+        if v.is_floating_point():
+            v.requires_grad_(False)
+    xr = torch.from_numpy(x).clone().requires_grad_(True)
+    ref = oracle.setgnn_forward(sdict, args, xr, torch.from_numpy(ei), norm_t)
+    G = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * G).sum().backward()
+    model.to(device)
+    xd = torch.from_numpy(x).to(device).requires_grad_(True)
+    out = model(SimpleNamespace(x=xd, edge_index=torch.from_numpy(ei).to(device), norm=norm_t.to(device)))
+    (out * G.to(device)).sum().backward()
+    scale = max(1.0, float(ref.detach().abs().max()))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=2e-4, atol=2e-4 * scale)
+    gs = max(1.0, float(xr.grad.abs().max()))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-3 * gs)
