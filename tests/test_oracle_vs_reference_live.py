@@ -1,0 +1,57 @@
+"""CPU, build container only (skipped where /root/reference is absent): the oracle against the LIVE reference
+(imported through oracle/ref_shim.py) on randomised SetGNN configurations -- the same generator the GPU-side
+random-configuration parity test uses, so that chain reads  reference == oracle (here)  and  oracle == product
+(tests/test_gpu_random_shapes.py).  Logits, d(loss)/dx and every parameter gradient."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+import cases
+from oracle import allset_oracle as oracle
+from oracle import ref_shim
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+
+
+@settings(deadline=None, max_examples=25, derandomize=True)
+@given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64]),
+       heads=st.sampled_from([1, 2, 4]), aggr=st.sampled_from(["add", "mean", "max"]), norm=st.sampled_from(["ln", "bn", "None"]),
+       input_norm=st.booleans(), mask=st.booleans(), gpr=st.booleans(), wnorm=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_oracle_equals_live_reference_on_random_configurations(pma, layers, mlp_layers, hidden, heads, aggr, norm, input_norm,
+                                                               mask, gpr, wnorm, sd):
+    _, ref_models = ref_shim.import_reference()
+    rng = np.random.default_rng(sd)
+    n_v, n_e, f, k = 40, 17, 12, 5
+    ei = cases.random_hypergraph(rng, n_v, n_e, 150, True)
+    x = rng.standard_normal((n_v, f)).astype(np.float32)
+    args = cases.make_args("pma_h1" if pma else "ds_add", f, hidden, k, All_num_layers=layers, MLP_num_layers=mlp_layers,
+                           heads=heads if pma else 1, aggregate=aggr if not pma else "add", normalization=norm,
+                           deepset_input_norm=input_norm, LearnMask=mask, GPR=gpr, Classifier_num_layers=2)
+    nrm = cases._norm_deg_half_sym(ei) if (wnorm or mask) else np.ones(ei.shape[1], dtype=np.int64)
+    norm_t = torch.from_numpy(nrm)
+    torch.manual_seed(sd)
+    model = ref_models.SetGNN(args, norm=norm_t.to(torch.float32) if mask else None)
+    model.reset_parameters()
+    model.eval()
+    xr = torch.from_numpy(x).clone().requires_grad_(True)
+    ref = model(SimpleNamespace(x=xr, edge_index=torch.from_numpy(ei).clone(), norm=norm_t))
+    G = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * G).sum().backward()
+    sdict = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    for kk, v in sdict.items():
+        if v.is_floating_point() and "running" not in kk:
+            v.requires_grad_(True)
+    xo = torch.from_numpy(x).clone().requires_grad_(True)
+    out = oracle.setgnn_forward(sdict, args, xo, torch.from_numpy(ei), norm_t)
+    (out * G).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xo.grad, xr.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(xr.grad.abs().max())))
+    for kk, p in model.named_parameters():
+        if p.grad is None or sdict[kk].grad is None:
+            assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and (sdict[kk].grad is None or float(sdict[kk].grad.abs().max()) == 0.0), kk
+            continue
+        torch.testing.assert_close(sdict[kk].grad, p.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(p.grad.abs().max())),
+                                   msg=lambda m: f"{kk}: {m}")
