@@ -59,6 +59,7 @@ SIGNATURES = {
     "allset_fused_linear_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                                 _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "allset_fused_linear_mask_words": [c_int64, c_int64],
+    "allset_pma_merge_pack": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_ln_res_supported": [c_int64],
     "allset_ln_res_fwd": [_P, c_int64, _P, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
                           c_int64, _P, _P],

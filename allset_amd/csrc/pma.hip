@@ -563,6 +563,41 @@ static int check_pma_dims(const char* who, int64_t n_a, int64_t n_b, int64_t H, 
   return ALLSET_OK;
 }
 
+
+// ---- cross-shard merge of partial PMA results (multi-GPU E->V) ----------------------------------
+// packed[r] = [ out_loc[r, h, :] * w[r, h]  for all h | w[r, 0..H-1] ],  w = l_loc > 0 ? l_loc * exp(m_loc - m_glob) : 0
+// -- the per-rank numerators and denominators relative to the GLOBAL row maximum, laid out as one row so that a single
+// sum-reduce-scatter merges the ranks.  One pass instead of torch's multiply + concatenate over [N*n, d].
+__global__ __launch_bounds__(kBlock) void pma_merge_pack_kernel(
+    const float* __restrict__ o, int64_t ldo, const float* __restrict__ m_loc, const float* __restrict__ l_loc,
+    const float* __restrict__ m_g, float* __restrict__ packed, int64_t ldp, int64_t n, int H, int C, int vec) {
+  const int d = H * C;
+  const int per_row = vec ? d / 4 + (H + 3) / 4 : d + H;          // work items per row
+  const int64_t total = n * per_row;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < total;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t r = idx / per_row;
+    const int j = static_cast<int>(idx % per_row);
+    auto weight = [&](int h) {
+      const float l = l_loc[r * H + h];
+      return l > 0.f ? l * __expf(m_loc[r * H + h] - m_g[r * H + h]) : 0.f;
+    };
+    if (vec) {
+      if (j < d / 4) {                                             // C % 4 == 0: the four columns share a head
+        const float w = weight((4 * j) / C);
+        float4 v = *reinterpret_cast<const float4*>(o + r * ldo + 4 * j);
+        v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+        *reinterpret_cast<float4*>(packed + r * ldp + 4 * j) = v;
+      } else {
+        const int h0 = 4 * (j - d / 4);
+        for (int h = h0; h < h0 + 4 && h < H; ++h) packed[r * ldp + d + h] = weight(h);
+      }
+    } else {
+      packed[r * ldp + j] = j < d ? o[r * ldo + j] * weight(j / C) : weight(j - d);
+    }
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -766,6 +801,26 @@ static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int3
     ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, bf16_t, 8, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const bf16_t*>(V), ldv,
                           static_cast<const bf16_t*>(gout), ldg, stats, slope, static_cast<bf16_t*>(gV), ldgv, galpha,
                           static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C), row_order);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_pma_merge_pack(const float* out_loc, int64_t ldo, const float* m_loc, const float* l_loc,
+                                     const float* m_glob, float* packed, int64_t ldp, int64_t n, int64_t H, int64_t C,
+                                     void* stream) {
+  clear_error();
+  int rc = check_pma_dims("pma_merge_pack", n, 0, H, C);
+  if (rc != ALLSET_OK) return rc;
+  if (n == 0) return ALLSET_OK;
+  const int64_t d = H * C;
+  ALLSET_REQUIRE(out_loc && m_loc && l_loc && m_glob && packed, "pma_merge_pack: null pointer");
+  ALLSET_REQUIRE(ldo >= d && ldp >= d + H, "pma_merge_pack: leading dimension too small");
+  const int vec = (C % 4 == 0 && ldo % 4 == 0 && ldp % 4 == 0 && aligned16(out_loc) && aligned16(packed)) ? 1 : 0;
+  const int64_t per_row = vec ? d / 4 + (H + 3) / 4 : d + H;
+  const int64_t want = (n * per_row + kBlock - 1) / kBlock;
+  const unsigned grid = static_cast<unsigned>(want > 65536 ? 65536 : want);
+  pma_merge_pack_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(out_loc, ldo, m_loc, l_loc, m_glob, packed, ldp,
+                                                                              n, static_cast<int>(H), static_cast<int>(C), vec);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -272,6 +272,11 @@ class HipPmaKernels:
         return ops.pma_bwd_stats(out, gout, m, l)
 
     @staticmethod
+    def merge_pack(o_loc, m_loc, l_loc, m_glob, heads):     # [o_loc * w | w], w = l_loc * exp(m_loc - m_glob)
+        from . import ops
+        return ops.pma_merge_pack(o_loc, m_loc, l_loc, m_glob, heads)
+
+    @staticmethod
     def bwd_src(inc, alpha, V, gout, stats, slope):
         from . import ops
         from .functional import _variant
@@ -333,8 +338,11 @@ class _ShardedPmaE2V(torch.autograd.Function):
         m_g = m_eff.clone()
         if not _skip_collective(group):
             dist.all_reduce(m_g, op=dist.ReduceOp.MAX, group=group)
-        w = torch.where(has, l_loc * torch.exp(m_eff - torch.where(has, m_g, m_eff)), torch.zeros_like(l_loc))
-        packed = torch.cat([(o_loc.view(n, heads, C) * w.unsqueeze(-1)).view(n, d), w], dim=1)
+        if hasattr(K, "merge_pack"):                 # one kernel; rows without local incidences have l_loc == 0 -> w = 0
+            packed = K.merge_pack(o_loc, m_loc, l_loc, torch.where(has, m_g, m_loc), heads)
+        else:
+            w = torch.where(has, l_loc * torch.exp(m_eff - torch.where(has, m_g, m_eff)), torch.zeros_like(l_loc))
+            packed = torch.cat([(o_loc.view(n, heads, C) * w.unsqueeze(-1)).view(n, d), w], dim=1)
         red = _reduce_scatter_rows(packed, group)                           # owned rows
         numer, l_g = red[:, :d], red[:, d:].contiguous()
         inv = torch.where(l_g > 0, 1.0 / (l_g + 1e-16), torch.zeros_like(l_g))
@@ -354,7 +362,7 @@ class _ShardedPmaE2V(torch.autograd.Function):
         d = gout.shape[1]
         packed = torch.cat([gout, stats.reshape(gout.shape[0], 2 * H)], dim=1)
         full = _all_gather_rows(packed, ctx.group)
-        g_full = full[:, :d].contiguous()
+        g_full = full[:, :d]                          # strided view: the kernels take a leading dimension, no copy
         stats_full = full[:, d:].contiguous().view(-1, H, 2)
         gV, galpha = K.bwd_src(hg.e2v, alpha, V, g_full, stats_full, ctx.slope)
         return gV, galpha, None, None, None, None, None

@@ -302,3 +302,20 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
                                                 ptr(galpha), n_s, n_t, heads, d // heads, stream_of(dev)),
               "allset_pma_bwd_src_ex")
     return gV, galpha
+
+
+def pma_merge_pack(out_loc: Tensor, m_loc: Tensor, l_loc: Tensor, m_glob: Tensor, heads: int) -> Tensor:
+    """[n, d + H] rows ``[out_loc * w | w]`` with ``w = l_loc * exp(m_loc - m_glob)`` (0 where ``l_loc == 0``): this rank's
+    numerators / denominators relative to the global row maximum, ready for a sum-reduce-scatter."""
+    dev = require_device(out_loc, m_loc, l_loc, m_glob)
+    _f32(out_loc, "pma_merge_pack")
+    out_loc = _rowmajor(out_loc)
+    n, d = out_loc.shape
+    width = d + heads
+    ldp = (width + 3) // 4 * 4
+    buf = torch.empty((n, ldp), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("pma_merge_pack", dev, n * (2 * d + 4 * heads) * 4):
+        check(_lib.load().allset_pma_merge_pack(ptr(out_loc), _ld(out_loc), ptr(m_loc.contiguous()), ptr(l_loc.contiguous()),
+                                                ptr(m_glob.contiguous()), ptr(buf), ldp, n, heads, d // heads, stream_of(dev)),
+              "allset_pma_merge_pack")
+    return buf if ldp == width else buf[:, :width]

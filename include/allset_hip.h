@@ -235,6 +235,13 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                        const uint32_t* mask, void* stream);
 
+/* Multi-GPU E->V attention pooling: pack this rank's partial result for the cross-rank merge.
+ *   packed[r] = [ out_loc[r,h,:] * w[r,h] for all h | w[r,0..H-1] ],  w = l_loc > 0 ? l_loc * exp(m_loc - m_glob) : 0
+ * (out_loc, m_loc, l_loc from allset_pma_fwd on the local incidences; m_glob = max over ranks of m_loc).  A sum over ranks of
+ * packed rows gives numerator and denominator of the global softmax pooling.  packed: f32[n*ldp], ldp >= H*C + H. */
+int allset_pma_merge_pack(const float* out_loc, int64_t ldo, const float* m_loc, const float* l_loc, const float* m_glob,
+                          float* packed, int64_t ldp, int64_t n, int64_t H, int64_t C, void* stream);
+
 /* LayerNorm with a fused sum in front and a relu behind -- the PMA tail (reference layers.py:153-157) and the
  * relu -> dropout SetGNN puts behind every conv (models.py:475-481):
  *   y = dropout_{p,seed}( relu_out ? relu(.) : . )( LayerNorm_{gamma,beta,eps}( x + colb + res ) )

@@ -245,3 +245,40 @@ def test_pma_layer_head_counts_match_oracle(heads, hidden, device):
             continue
         scale = max(1.0, float(r.abs().max()))
         torch.testing.assert_close(p.grad.cpu(), r, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{k}: {m}")
+
+
+def test_sharded_pma_merge_path_equals_single_rank_path(device, monkeypatch):
+    """The cross-rank (m,l,o) merge of sharded PMA -- merge_pack kernel, strided gradient views, global statistics in the
+    backward -- run on the GPU with the collectives stubbed to a 1-rank identity must equal the single-rank fast path."""
+    import numpy as np
+    from allset_amd import HalfNLHconv
+    from allset_amd import dist as adist
+    rng = np.random.default_rng(9)
+    n_v, n_e, d, H = 400, 211, 128, 4
+    pairs = sorted({(int(rng.integers(n_v)), int(rng.integers(n_e))) for _ in range(3000)} | {(n_v - 1, 0)})
+    pairs = [p for p in pairs if p[0] != 5]                      # vertex 5 has no incidence at all
+    ei = torch.tensor(pairs, dtype=torch.int64).t().contiguous().to(device)
+    torch.manual_seed(1)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=True).to(device).eval()
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=True).to(device).eval()
+    x = torch.randn(n_v, d, device=device)
+    G = torch.randn(n_v, d, device=device)
+    hg = adist.ShardedHypergraph(ei, n_v, n_e, 1, 0).build_incidences()
+    res = []
+    for merge in (False, True):
+        if merge:
+            monkeypatch.setattr(adist, "_skip_collective", lambda group=None: False)
+            monkeypatch.setattr(adist, "_all_gather_rows", lambda t, group=None: t)
+            monkeypatch.setattr(adist, "_reduce_scatter_rows", lambda t, group=None: t)
+            monkeypatch.setattr(adist.dist, "all_reduce", lambda *args, **kw: None)
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+        xs = x.clone().requires_grad_(True)
+        out = adist.sharded_pma_layer(a, b, xs, hg)
+        (out * G).sum().backward()
+        res.append((out.detach().clone(), xs.grad.clone(), [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]))
+    (o0, g0, p0), (o1, g1, p1) = res
+    torch.testing.assert_close(o1, o0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
+    for u, v in zip(p1, p0):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4 * max(1.0, float(v.abs().max())))
