@@ -612,7 +612,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_linear_bwd_kernel(
 //   epilogue on the ROW-MAJOR side of the LDS trip (lane = 4 consecutive columns of 4 rows): dropout-in mask,
 //   LayerNorm backward (row sums = 16-lane reductions), relu-in mask, 16-byte stores of gx; x and the row statistics
 //   for the epilogue are requested before the MFMAs.  dgamma/dbeta: per-lane column sums, one partial row per wave.
-template <int OD, int ID, bool HAS_LN, bool DROP_IN>
+template <int OD, int ID, bool HAS_LN, bool DROP_IN, bool HAS_AUX>
 __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
     const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
@@ -666,12 +666,11 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
 #pragma unroll
   for (int hb = 0; hb < NH; ++hb) { dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); }
   // rank-4 update gx += aux_g[n,4] @ aux_w[4,I] (the gradient of four auxiliary output columns of the forward)
-  float4 wa[NH][4];
-  if (aux_g != nullptr) {
-#pragma unroll
-    for (int hb = 0; hb < NH; ++hb)
-#pragma unroll
-      for (int h = 0; h < 4; ++h) wa[hb][h] = *reinterpret_cast<const float4*>(aux_w + h * ID + hb * 64 + c4);
+  // (a template flag, and aux_w read from LDS where it is used: its 32 registers must not weigh on the epilogue)
+  __shared__ __attribute__((aligned(16))) float sAuxW[HAS_AUX ? 4 * ID : 4];
+  if constexpr (HAS_AUX) {
+    for (int idx = tid; idx < 4 * ID; idx += kX6Block) sAuxW[idx] = aux_w[idx];
+    __syncthreads();
   }
 
   float ag[OQ], ay[OQ];
@@ -861,12 +860,16 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
             const float4 ai = *reinterpret_cast<const float4*>(acc_in + r * ldacc + hb * 64 + c4);   // (may alias gx)
             o.x += ai.x; o.y += ai.y; o.z += ai.z; o.w += ai.w;
           }
-          if (aux_g != nullptr) {
+          if constexpr (HAS_AUX) {
             const float4 q = *reinterpret_cast<const float4*>(aux_g + r * 4);
-            o.x = fmaf(q.x, wa[hb][0].x, fmaf(q.y, wa[hb][1].x, fmaf(q.z, wa[hb][2].x, fmaf(q.w, wa[hb][3].x, o.x))));
-            o.y = fmaf(q.x, wa[hb][0].y, fmaf(q.y, wa[hb][1].y, fmaf(q.z, wa[hb][2].y, fmaf(q.w, wa[hb][3].y, o.y))));
-            o.z = fmaf(q.x, wa[hb][0].z, fmaf(q.y, wa[hb][1].z, fmaf(q.z, wa[hb][2].z, fmaf(q.w, wa[hb][3].z, o.z))));
-            o.w = fmaf(q.x, wa[hb][0].w, fmaf(q.y, wa[hb][1].w, fmaf(q.z, wa[hb][2].w, fmaf(q.w, wa[hb][3].w, o.w))));
+            const float4 w0 = *reinterpret_cast<const float4*>(&sAuxW[0 * ID + hb * 64 + c4]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&sAuxW[1 * ID + hb * 64 + c4]);
+            const float4 w2 = *reinterpret_cast<const float4*>(&sAuxW[2 * ID + hb * 64 + c4]);
+            const float4 w3 = *reinterpret_cast<const float4*>(&sAuxW[3 * ID + hb * 64 + c4]);
+            o.x = fmaf(q.x, w0.x, fmaf(q.y, w1.x, fmaf(q.z, w2.x, fmaf(q.w, w3.x, o.x))));
+            o.y = fmaf(q.x, w0.y, fmaf(q.y, w1.y, fmaf(q.z, w2.y, fmaf(q.w, w3.y, o.y))));
+            o.z = fmaf(q.x, w0.z, fmaf(q.y, w1.z, fmaf(q.z, w2.z, fmaf(q.w, w3.z, o.z))));
+            o.w = fmaf(q.x, w0.w, fmaf(q.y, w1.w, fmaf(q.z, w2.w, fmaf(q.w, w3.w, o.w))));
           }
 #ifdef ALLSET_ABLATE_NOSTORE
           if (o.x == 123.456f)
@@ -1053,9 +1056,9 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
 #define ALLSET_FUSED_BWD_F(OD, IT, LN, DI)                                                                                   \
   do {                                                                                                                       \
     if (x6)                                                                                                                  \
-      fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI><<<grid, kX6Block, 0, st>>>(                                            \
+      fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI, false><<<grid, kX6Block, 0, st>>>(                                     \
           gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask,   \
-          acc_in, ldacc, aux_g, aux_w);                                                                                      \
+          acc_in, ldacc, nullptr, nullptr);                                                                                  \
     else                                                                                                                     \
       fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(                                                 \
           gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \
@@ -1065,6 +1068,23 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
     if (has_ln) { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, true, true); else ALLSET_FUSED_BWD_F(OD, IT, true, false); }     \
     else        { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, false, true); else ALLSET_FUSED_BWD_F(OD, IT, false, false); }   \
   } while (0)
+  if (aux_g != nullptr) {     // the rank-4 update exists for the plain Linear only (PMA's value projection)
+    if (has_ln || p_in > 0.f) {
+      set_error("fused_linear_bwd: aux_g is supported without LayerNorm / dropout prologue only");
+      return ALLSET_ERR_UNSUPPORTED;
+    }
+#define ALLSET_FUSED_BWD_AUX(OD, ID)                                                                                         \
+  fused_linear_bwd_x6_kernel<OD, ID, false, false, true><<<grid, kX6Block, 0, st>>>(                                         \
+      gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask,       \
+      acc_in, ldacc, aux_g, aux_w)
+    if (O == 128 && I == 128) ALLSET_FUSED_BWD_AUX(128, 128);
+    else if (O == 128 && I == 64) ALLSET_FUSED_BWD_AUX(128, 64);
+    else if (O == 64 && I == 128) ALLSET_FUSED_BWD_AUX(64, 128);
+    else ALLSET_FUSED_BWD_AUX(64, 64);
+#undef ALLSET_FUSED_BWD_AUX
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   if (O == 128 && I == 128) ALLSET_FUSED_BWD(128, 4);
   else if (O == 128 && I == 64) ALLSET_FUSED_BWD(128, 2);
   else if (O == 64 && I == 128) ALLSET_FUSED_BWD(64, 4);
