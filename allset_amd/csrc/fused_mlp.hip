@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
     __syncthreads();
   }
 
-  float ag[OQ], ay[OQ];
+  float ag[OQ];
   uint32_t am_bits = 0;
   auto request_rows = [&](int64_t chunk) {               // unconditional, clamped (see the forward kernel)
     int64_t row = chunk * 16 + ri;
@@ -687,14 +687,6 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
     for (int q = 0; q < OQ / 4; ++q) {
       const float4 v = gr[q];
       ag[4 * q] = v.x; ag[4 * q + 1] = v.y; ag[4 * q + 2] = v.z; ag[4 * q + 3] = v.w;
-    }
-    if (has_y) {
-      const float4* yr = reinterpret_cast<const float4*>(y + row * ldy + g * OQ);
-#pragma unroll
-      for (int q = 0; q < OQ / 4; ++q) {
-        const float4 v = yr[q];
-        ay[4 * q] = v.x; ay[4 * q + 1] = v.y; ay[4 * q + 2] = v.z; ay[4 * q + 3] = v.w;
-      }
     }
 #ifdef ALLSET_ABLATE_NOLOAD
     }
@@ -711,8 +703,18 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
 #pragma unroll
       for (int j = 0; j < OQ; ++j) ag[j] = (bits & (1u << (8 * (j & 3) + (j >> 2)))) ? ag[j] * keep_out : 0.f;
     } else if (has_y) {
+      // legacy source of the epilogue mask (callers without the 1-bit mask): y is read here, not prefetched, so that
+      // the mask path does not carry a second 32-register landing buffer
+      const int64_t yrow = valid ? chunk * 16 + ri : n - 1;
+      const float4* yr = reinterpret_cast<const float4*>(y + yrow * ldy + g * OQ);
 #pragma unroll
-      for (int j = 0; j < OQ; ++j) ag[j] = (valid && ay[j] > 0.f) ? ag[j] * keep_out : 0.f;
+      for (int q = 0; q < OQ / 4; ++q) {
+        const float4 v = yr[q];
+        ag[4 * q] = (valid && v.x > 0.f) ? ag[4 * q] * keep_out : 0.f;
+        ag[4 * q + 1] = (valid && v.y > 0.f) ? ag[4 * q + 1] * keep_out : 0.f;
+        ag[4 * q + 2] = (valid && v.z > 0.f) ? ag[4 * q + 2] * keep_out : 0.f;
+        ag[4 * q + 3] = (valid && v.w > 0.f) ? ag[4 * q + 3] * keep_out : 0.f;
+      }
     } else if (!valid) {
 #pragma unroll
       for (int j = 0; j < OQ; ++j) ag[j] = 0.f;
