@@ -398,6 +398,7 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
       // scalar writes (different access types) nor the next trip's writes above these reads
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const float4 bv = *reinterpret_cast<const float4*>(&sBias[hb * 64 + c4]);
+      uint64_t bal[4][4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int rl = it * 4 + (lane >> 4);
@@ -416,15 +417,23 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
 #else
         if (r < n) *reinterpret_cast<float4*>(y + r * ldy + hb * 64 + c4) = v;
 #endif
-        if (mask_out != nullptr) {
-          // activation mask for the backward kernels, 1 bit per element (include/allset_hip.h "mask layout"): four
-          // ballots (one per column-of-quad c), byte-transposed so that every consumer needs ONE dword: lane 8*idx'+..
-          const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
-          const int c = lane & 3;
-          const uint64_t bsel = c == 0 ? b0 : (c == 1 ? b1 : (c == 2 ? b2 : b3));
-          if (lane < 32)
-            mask_out[(((chunk * (ND / 64) + hb) * 4 + it) * 8) * 4 + lane] = static_cast<uint8_t>(bsel >> (8 * (lane >> 2)));
+        if (mask_out != nullptr) {     // four ballots per row group (one per column-of-quad c), combined below
+          bal[it][0] = __ballot(v.x > 0.f); bal[it][1] = __ballot(v.y > 0.f);
+          bal[it][2] = __ballot(v.z > 0.f); bal[it][3] = __ballot(v.w > 0.f);
         }
+      }
+      if (mask_out != nullptr) {
+        // activation mask for the backward kernels, 1 bit per element (include/allset_hip.h "mask layout"): the 16 ballots
+        // of this 16 x 64 block, byte-transposed so that every consumer needs ONE dword, leave as one 128-byte store:
+        // lane L < 32 builds dword it*8 + idx (it = L>>3, idx = L&7) = bytes idx of the four ballots of row group it
+        const int mit = (lane >> 3) & 3, sh = 8 * (lane & 7);
+        uint32_t word = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint64_t bsel = mit == 0 ? bal[0][c] : (mit == 1 ? bal[1][c] : (mit == 2 ? bal[2][c] : bal[3][c]));
+          word |= static_cast<uint32_t>((bsel >> sh) & 0xffu) << (8 * c);
+        }
+        if (lane < 32) reinterpret_cast<uint32_t*>(mask_out)[(chunk * (ND / 64) + hb) * 32 + lane] = word;
       }
       __asm__ volatile("" ::: "memory");
     }
