@@ -336,7 +336,8 @@ class _FusedNormLinear(torch.autograd.Function):
         base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
         keep_y = relu_out or p_out > 0.0
         # the backward needs only the sign pattern of y: a 1-bit mask written by the forward kernel (1/32 of y's bytes)
-        words = activation_mask_words(x.shape[0], weight.shape[0]) if keep_y else 0
+        # (no mask in inference: nothing will run backward)
+        words = activation_mask_words(x.shape[0], weight.shape[0]) if (keep_y and any(ctx.needs_input_grad)) else 0
         mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
         y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out,
                                     base, mask)
