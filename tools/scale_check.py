@@ -37,3 +37,27 @@ o2, _, _ = pma_aggregate(xr, alpha.clone().requires_grad_(True), v2e, 4, 0.2)
 o2.sum().backward()
 print("pma grad column sums (should equal n per column: each target row's weights sum to 1):", float(xr.grad.sum(0).mean()), n)
 print("peak memory GB:", torch.cuda.max_memory_allocated() / 2**30)
+
+# ---- dense tail at the same row count (8M x 128): sampled rows against float64, additivity of the weight gradient
+from allset_amd import dense
+n8 = 8_000_000 + 5
+g = torch.Generator(device=dev).manual_seed(3)
+xx = torch.randn(n8, 128, device=dev, generator=g)
+W = torch.randn(128, 128, device=dev, generator=g) / 128 ** 0.5
+bb = torch.randn(128, device=dev, generator=g)
+gam = 1 + 0.2 * torch.randn(128, device=dev, generator=g); bet = 0.3 * torch.randn(128, device=dev, generator=g)
+yy, st = dense.fused_linear_fwd(xx, W, bb, gam, bet, 1e-5, False, 0.0, 0, True, 0.0, 0)
+rows = torch.cat([torch.arange(0, 32, device=dev), torch.randint(0, n8, (2000,), device=dev, generator=g), torch.arange(n8 - 32, n8, device=dev)])
+ref = torch.relu(torch.nn.functional.layer_norm(xx[rows].double(), (128,), gam.double(), bet.double(), 1e-5) @ W.double().t() + bb.double())
+print("dense fwd @8M rows: max abs err on sampled rows", float((yy[rows].double() - ref).abs().max()))
+GG = torch.randn(n8, 128, device=dev, generator=g)
+gx, dg, db = dense.fused_linear_bwd(GG, yy, 0.0, W, xx, st, gam, False, 0.0, 0)
+xr = xx[rows].double().requires_grad_(True)
+r2 = torch.relu(torch.nn.functional.layer_norm(xr, (128,), gam.double(), bet.double(), 1e-5) @ W.double().t() + bb.double())
+(r2 * GG[rows].double()).sum().backward()
+print("dense bwd @8M rows: max abs err on sampled rows", float((gx[rows].double() - xr.grad).abs().max()))
+gw, gb = dense.wgrad(GG, xx)
+h = n8 // 2 + 7
+gw1, _ = dense.wgrad(GG[:h], xx[:h]); gw2, _ = dense.wgrad(GG[h:], xx[h:])
+print("wgrad additivity @8M rows: rel err", float((gw1 + gw2 - gw).abs().max() / gw.abs().max()))
+print("peak memory GB:", torch.cuda.max_memory_allocated() / 2 ** 30)
