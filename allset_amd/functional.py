@@ -31,6 +31,18 @@ def _variant(csr, kind: str, n_rows: int, x: Tensor, heads: int = 1) -> int:
     return csr.variant(kind, n_rows) if ok else 1
 
 
+def _split(csr, x: Tensor, heads: int = 1) -> int:
+    """``CSR.short_tail`` if the short-row kernel exists for this feature layout, else -1 (single launch)."""
+    if csr.short_tail <= 0:
+        return -1
+    es = x.element_size()
+    wide = 16 // es
+    d = x.shape[1]
+    ok = (d % wide == 0 and d <= 64 * wide and x.stride(0) % wide == 0 and x.data_ptr() % 16 == 0
+          and (d // max(heads, 1)) % wide == 0)
+    return csr.short_tail if ok else -1
+
+
 def _check_rows(x: Tensor, inc: Incidence) -> None:
     """The gathered matrix must cover every source id (PyG's index_select would raise otherwise) and
     may not have more rows than the transposed CSR (its backward produces one row per CSR row)."""
@@ -45,7 +57,8 @@ class _SegReduce(torch.autograd.Function):
         csr = inc.by_dst
         ext = reduce in (MAX, MIN)
         out, arg = ops.segreduce(reduce, csr.rowptr, csr.col, w_dst, x, inc.n_dst, want_arg=ext,
-                                 variant=1 if ext else _variant(csr, "segreduce", inc.n_dst, x), row_order=csr.row_order)
+                                 variant=1 if ext else _variant(csr, "segreduce", inc.n_dst, x), row_order=csr.row_order,
+                                 split=_split(csr, x))
         need_gw = w_dst is not None and ctx.needs_input_grad[1]
         ctx.inc, ctx.reduce, ctx.n_s, ctx.need_gw = inc, reduce, x.shape[0], need_gw
         ctx.save_for_backward(x if need_gw else None, w_dst, w_src, arg)
@@ -71,7 +84,8 @@ class _SegReduce(torch.autograd.Function):
                     inv = inc.inv_count_by_src()
                     w_src = inv if w_src is None else w_src * inv
                 gx, _ = ops.segreduce(SUM, T.rowptr, T.col, w_src, gout, ctx.n_s,
-                                      variant=_variant(T, "segreduce", ctx.n_s, gout), row_order=T.row_order)
+                                      variant=_variant(T, "segreduce", ctx.n_s, gout), row_order=T.row_order,
+                                      split=_split(T, gout) if ctx.n_s == T.n_rows else -1)
             else:
                 gx = ops.segmax_bwd(T.rowptr, T.col, inc.pos_dst_of_src(), w_src, arg, gout, ctx.n_s)
         if ctx.need_gw:
@@ -103,7 +117,8 @@ class _PmaAggregate(torch.autograd.Function):
     def forward(ctx, V: Tensor, alpha: Tensor, inc: Incidence, heads: int, slope: float):
         csr = inc.by_dst
         out, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
-                                variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order)
+                                variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order,
+                                split=_split(csr, V, heads))
         ctx.inc, ctx.slope = inc, slope
         ctx.save_for_backward(V, alpha, out, m, l)
         ctx.mark_non_differentiable(m, l)
@@ -118,7 +133,7 @@ class _PmaAggregate(torch.autograd.Function):
         stats = ops.pma_bwd_stats(out, gout, m, l)
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, ctx.slope,
                                      variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]),
-                                     row_order=T.row_order)
+                                     row_order=T.row_order, split=_split(T, V, alpha.shape[1]))
         return gV, galpha, None, None, None
 
 

@@ -68,6 +68,8 @@ class CSR(NamedTuple):
     n_cols: int
     max_deg: int = 0
     row_order: Optional[Tensor] = None      # int32[n_rows] processing order (long rows first per XCD range) or None
+    short_tail: int = -1                    # rows >= short_tail all have <= 2 incidences (Add_Self_Loops' singleton
+                                            # hyperedges sit at the end of the id range) and are worth their own launch
 
     def variant(self, kind: str, n_rows: Optional[int] = None) -> int:
         """Kernel variant for this orientation: 2 = short-row kernel, 1 = one wavefront per row.  Thresholds from
@@ -127,8 +129,18 @@ def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_
         check(lib.allset_csr_build(ptr(row_ids), ptr(col_ids), nnz, row_base, col_base, n_rows,
                                    ptr(rowptr), ptr(col), ptr(perm), ptr(ws), need.value, stream_of(dev)),
               "allset_csr_build")
-    max_deg = int((rowptr[1:] - rowptr[:-1]).max()) if n_rows > 0 and nnz > 0 else 0     # one-time sync at build
-    return CSR(rowptr, col, perm, n_rows, n_cols, max_deg, long_rows_first_order(rowptr, n_rows, nnz, max_deg))
+    max_deg, short_tail = 0, -1
+    if n_rows > 0 and nnz > 0:                                                            # one-time sync at build
+        deg = rowptr[1:] - rowptr[:-1]
+        big = (deg > 2).nonzero()
+        stats = torch.stack([deg.max().to(torch.int64), (big[-1, 0] + 1) if big.numel() else torch.zeros((), dtype=torch.int64, device=dev)])
+        max_deg, first_short = (int(v) for v in stats.tolist())
+        head_nnz = int(rowptr[first_short]) if first_short > 0 else 0
+        # a block of singleton rows behind regular rows (the reference's default Add_Self_Loops layout): one wave per
+        # row wastes the launch on them, the short-row kernel wastes the long rows -- give each block its kernel
+        if 0 < first_short < n_rows and (n_rows - first_short) * 16 >= n_rows and head_nnz >= 6 * first_short and max_deg <= 100000:
+            short_tail = first_short
+    return CSR(rowptr, col, perm, n_rows, n_cols, max_deg, long_rows_first_order(rowptr, n_rows, nnz, max_deg), short_tail)
 
 
 def long_rows_first_order(rowptr: Tensor, n_rows: int, nnz: int, max_deg: int) -> Optional[Tensor]:
@@ -172,9 +184,10 @@ def long_rows_first_order(rowptr: Tensor, n_rows: int, nnz: int, max_deg: int) -
 
 
 def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: Tensor, n_t: int,
-              want_arg: bool = False, variant: int = 0, row_order: Optional[Tensor] = None
+              want_arg: bool = False, variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1
               ) -> Tuple[Tensor, Optional[Tensor]]:
-    """``variant``: 0 auto (short-row kernel when nnz / n_t < 6), 1 one wave per row, 2 short-row kernel."""
+    """``variant``: 0 auto (short-row kernel when nnz / n_t < 6), 1 one wave per row, 2 short-row kernel.
+    ``split`` (``CSR.short_tail``): rows >= split go to the short-row kernel in a second launch."""
     dev = require_device(rowptr, col, w, x)
     code = _dtype_code(x, "segreduce")
     es = x.element_size()
@@ -190,9 +203,19 @@ def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: 
     with torch.cuda.device(dev), _timed("segreduce_fwd", dev, algo):
         if row_order is not None and row_order.numel() != n_t:
             row_order = None                       # order was built for a different row count (prefix views)
-        check(_lib.load().allset_segreduce_fwd_ex(reduce, code, variant, nnz, ptr(row_order), ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
-                                                  ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
-              "allset_segreduce_fwd_ex")
+        lib = _lib.load()
+        if 0 < split < n_t and not want_arg and rowptr.numel() == n_t + 1:
+            # regular rows: one wave per row; the singleton tail: short-row kernel (same rowptr / col / out buffers, the
+            # row pointers are absolute positions so an offset view is all the second launch needs)
+            check(lib.allset_segreduce_fwd_ex(reduce, code, 1, nnz, None, ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
+                                              ptr(out), max(d, 1), None, split, n_s, d, stream_of(dev)), "allset_segreduce_fwd_ex")
+            check(lib.allset_segreduce_fwd_ex(reduce, code, 2, nnz, None, ptr(rowptr[split:]), ptr(col), ptr(w), ptr(x), _ld(x),
+                                              ptr(out[split:]), max(d, 1), None, n_t - split, n_s, d, stream_of(dev)),
+                  "allset_segreduce_fwd_ex")
+        else:
+            check(lib.allset_segreduce_fwd_ex(reduce, code, variant, nnz, ptr(row_order), ptr(rowptr), ptr(col), ptr(w), ptr(x), _ld(x),
+                                              ptr(out), max(d, 1), ptr(arg), n_t, n_s, d, stream_of(dev)),
+                  "allset_segreduce_fwd_ex")
     return out, arg
 
 
@@ -227,7 +250,7 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
 
 
 def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, slope: float, n_t: int,
-            variant: int = 0, row_order: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+            variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1) -> Tuple[Tensor, Tensor, Tensor]:
     dev = require_device(rowptr, col, alpha, V)
     code = _dtype_code(V, "pma_fwd")
     es = V.element_size()
@@ -244,9 +267,18 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
     with torch.cuda.device(dev), _timed("pma_fwd", dev, algo):
         if row_order is not None and row_order.numel() != n_t:
             row_order = None
-        check(_lib.load().allset_pma_fwd_ex(code, variant, col.numel(), ptr(row_order), ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V),
-                                            slope, ptr(out), max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads,
-                                            stream_of(dev)), "allset_pma_fwd_ex")
+        lib = _lib.load()
+        if 0 < split < n_t and rowptr.numel() == n_t + 1:      # see segreduce: regular rows / singleton tail
+            check(lib.allset_pma_fwd_ex(code, 1, col.numel(), None, ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V), slope,
+                                        ptr(out), max(d, 1), ptr(m), ptr(l), split, n_s, heads, d // heads, stream_of(dev)),
+                  "allset_pma_fwd_ex")
+            check(lib.allset_pma_fwd_ex(code, 2, col.numel(), None, ptr(rowptr[split:]), ptr(col), ptr(alpha), ptr(V), _ld(V), slope,
+                                        ptr(out[split:]), max(d, 1), ptr(m[split:]), ptr(l[split:]), n_t - split, n_s, heads,
+                                        d // heads, stream_of(dev)), "allset_pma_fwd_ex")
+        else:
+            check(lib.allset_pma_fwd_ex(code, variant, col.numel(), ptr(row_order), ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V),
+                                        slope, ptr(out), max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads,
+                                        stream_of(dev)), "allset_pma_fwd_ex")
     return out, m, l
 
 
@@ -279,7 +311,7 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
 
 
 def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: Tensor, stats: Tensor, slope: float,
-                variant: int = 0, row_order: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1) -> Tuple[Tensor, Tensor]:
     dev = require_device(rowptrT, colT, alpha, V, gout, stats)
     code = _dtype_code(V, "pma_bwd_src")
     if gout.dtype != V.dtype:
@@ -297,10 +329,20 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
         if row_order is not None and row_order.numel() != n_s:
             row_order = None
-        check(_lib.load().allset_pma_bwd_src_ex(code, variant, colT.numel(), ptr(row_order), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
-                                                _ld(V), ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1),
-                                                ptr(galpha), n_s, n_t, heads, d // heads, stream_of(dev)),
-              "allset_pma_bwd_src_ex")
+        lib = _lib.load()
+        if 0 < split < n_s and rowptrT.numel() == n_s + 1:     # rows of this CSR are the SOURCES (alpha / V / gV rows)
+            check(lib.allset_pma_bwd_src_ex(code, 1, colT.numel(), None, ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V), _ld(V),
+                                            ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1), ptr(galpha), split, n_t,
+                                            heads, d // heads, stream_of(dev)), "allset_pma_bwd_src_ex")
+            check(lib.allset_pma_bwd_src_ex(code, 2, colT.numel(), None, ptr(rowptrT[split:]), ptr(colT), ptr(alpha[split:]),
+                                            ptr(V[split:]), _ld(V), ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV[split:]),
+                                            max(d, 1), ptr(galpha[split:]), n_s - split, n_t, heads, d // heads, stream_of(dev)),
+                  "allset_pma_bwd_src_ex")
+        else:
+            check(lib.allset_pma_bwd_src_ex(code, variant, colT.numel(), ptr(row_order), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
+                                            _ld(V), ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1),
+                                            ptr(galpha), n_s, n_t, heads, d // heads, stream_of(dev)),
+                  "allset_pma_bwd_src_ex")
     return gV, galpha
 
 

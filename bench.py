@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--degree", type=int, default=16)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--degree-dist", default="fixed", choices=["fixed", "poisson", "zipf"])
+    ap.add_argument("--self-loops", action="store_true",
+                    help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
                     help="deepsets = AllDeepSets (the headline, BASELINE configs[2]); pma = AllSetTransformer "
                          "(configs[3] per-GPU shape), not the driver's default")
@@ -153,7 +155,16 @@ def main():
     d, n_loc = args.d, args.n_per_gpu
     n_v = n_loc * world                                               # weak scaling: global vertex range grows with N
     shard = random_hypergraph(n_v, n_loc, args.degree, seed=args.seed + 1 + rank, device=dev, dist=args.degree_dist)
-    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, rank, norm=shard.norm).build_incidences()
+    n_e_loc = n_loc
+    if args.self_loops:
+        if world != 1:
+            raise SystemExit("--self-loops is a single-GPU variant")
+        vs = torch.arange(n_v, device=dev, dtype=torch.int64)
+        ei = torch.cat([shard.edge_index, torch.stack([vs, n_loc + vs])], dim=1)
+        ei = ei[:, torch.argsort(ei[0], stable=True)].contiguous()
+        shard.edge_index, shard.nnz, n_e_loc = ei, int(ei.shape[1]), n_loc + n_v
+        shard.norm = torch.ones(shard.nnz, dtype=torch.int64, device=dev)
+    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_e_loc, world, rank, norm=shard.norm).build_incidences()
     nnz_local = shard.nnz
 
     torch.manual_seed(args.seed)                                       # identical replicated weights on every rank
@@ -241,7 +252,8 @@ def main():
                                    f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, " +
                                    (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
                                     f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), ") +
-                                   f"fwd+bwd+Adam", "n_v": n_v, "n_e": n_loc * world, "nnz": int(nnz_total), "d": d,
+                                   f"fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
+                       "n_v": n_v, "n_e": n_e_loc * world, "nnz": int(nnz_total), "d": d,
                        "parallelism": f"hyperedge-shard x{world}" if world > 1 else "single GPU", "seed": args.seed},
             "roofline": roofline,
             "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if world == 1 else None,

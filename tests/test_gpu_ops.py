@@ -353,3 +353,59 @@ def test_long_rows_first_order_is_a_permutation_and_changes_nothing(device):
     r1 = ops.pma_bwd_src(T.rowptr, T.col, ae, ev, g, st, 0.2, variant=1)
     r2 = ops.pma_bwd_src(T.rowptr, T.col, ae, ev, g, st, 0.2, variant=1, row_order=T.row_order)
     assert all(torch.equal(u, v) for u, v in zip(r1, r2))
+
+
+@pytest.mark.parametrize("mode", ["add", "mean", "pma"])
+def test_self_loop_tail_split_dispatch(mode, device):
+    """Add_Self_Loops' layout -- regular hyperedges followed by a block of singleton hyperedges -- takes the two-launch
+    dispatch (CSR.short_tail: one wave per row for the regular rows, short-row kernel for the tail).  Results must equal
+    the oracle's, forward and backward, in both directions."""
+    from allset_amd import Incidence, deepsets_aggregate, pma_aggregate
+    rng = np.random.default_rng(11)
+    n_v, n_e, d, H = 900, 500, 64, 4
+    v = np.concatenate([rng.integers(0, n_v, size=n_e * 12), np.arange(n_v)])
+    e = np.concatenate([np.repeat(np.arange(n_e), 12), n_e + np.arange(n_v)])
+    ei = torch.from_numpy(np.stack([v, e]).astype(np.int64))
+    n_t = n_e + n_v
+    inc = Incidence.from_edge_index(ei.to(device), n_src=n_v, n_dst=n_t)
+    assert inc.by_dst.short_tail == n_e and inc.by_src.short_tail == -1        # hyperedge-major CSR has the tail
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n_v, d, generator=g)
+    G = torch.randn(n_t, d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    xd = x.to(device).requires_grad_(True)
+    if mode == "pma":
+        alpha = torch.randn(n_v, H, generator=g)
+        ar, ad = alpha.clone().requires_grad_(True), alpha.to(device).requires_grad_(True)
+        ref, _ = oracle.pma_aggregate(xr.view(-1, H, d // H), ar, ei, 0.2)
+        ref = ref.reshape(-1, d)
+        out, _, _ = pma_aggregate(xd, ad, inc, H, 0.2)
+    else:
+        norm = torch.ones(ei.shape[1], dtype=torch.int64)
+        ref = oracle.deepsets_aggregate(xr, ei, norm, mode)
+        out = deepsets_aggregate(xd, inc, norm.to(device), mode)
+    (ref * G).sum().backward()
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)
+    # the reverse direction (E -> V): its transposed CSR (rows = hyperedges) carries the tail in the backward pass
+    rev = inc.reversed()
+    y = torch.randn(n_t, d, generator=g)
+    Gv = torch.randn(n_v, d, generator=g)
+    yr, yd = y.clone().requires_grad_(True), y.to(device).requires_grad_(True)
+    rei = torch.stack([ei[1], ei[0]])
+    if mode == "pma":
+        al2 = torch.randn(n_t, H, generator=g)
+        a2r, a2d = al2.clone().requires_grad_(True), al2.to(device).requires_grad_(True)
+        ref2, _ = oracle.pma_aggregate(yr.view(-1, H, d // H), a2r, rei, 0.2)
+        ref2 = ref2.reshape(-1, d)
+        out2, _, _ = pma_aggregate(yd, a2d, rev, H, 0.2)
+    else:
+        ref2 = oracle.deepsets_aggregate(yr, rei, torch.ones(ei.shape[1], dtype=torch.int64), mode)
+        out2 = deepsets_aggregate(yd, rev, torch.ones(ei.shape[1], dtype=torch.int64, device=device), mode)
+    (ref2 * Gv).sum().backward()
+    (out2 * Gv.to(device)).sum().backward()
+    torch.testing.assert_close(out2.detach().cpu(), ref2.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(yd.grad.cpu(), yr.grad, rtol=RTOL, atol=ATOL)
+    if mode == "pma":
+        torch.testing.assert_close(a2d.grad.cpu(), a2r.grad, rtol=1e-3, atol=1e-4)
