@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 1
+#define ALLSET_ABI_VERSION 2   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack */
 
 enum allset_status {
   ALLSET_OK = 0,
