@@ -97,7 +97,7 @@ def test_graphed_train_step_draws_fresh_masks_and_trains(device):
     assert len(set(losses)) == 6, losses                                         # a fresh mask every replay
     # and with a real learning rate the captured loop optimises
     model2, data2, y2 = _setup("cora_ds_add", device, dropout=0.2)
-    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-2, capturable=True)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-2, capturable=True, fused=True)
     step2 = GraphedTrainStep(model2, data2, lambda out: F.nll_loss(F.log_softmax(out, dim=1), y2), opt2)
     first = sum(float(step2().detach()) for _ in range(3)) / 3
     for _ in range(60):

@@ -34,7 +34,7 @@ for name in ("cora_ds_add", "citeseer_pma_h4"):
         print(f"{name:18s} {label:13s} {dt*1e3:7.3f} ms")
     # the same two loops as hipGraph replays (allset_amd/graphs.py)
     from allset_amd.graphs import GraphedForward, GraphedTrainStep
-    opt_c = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    opt_c = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
     gstep = GraphedTrainStep(model, data, lambda out: F.nll_loss(F.log_softmax(out, dim=1), y), opt_c)
     gfwd = GraphedForward(model, data)
     for fn, label in ((gstep, "train step (graph)"), (gfwd, "eval forward (graph)")):
