@@ -284,9 +284,10 @@ def run(args) -> dict:
         t0 = time.time()
         split_idx = {k: v.to(device) for k, v in splits[r].items()}
         model.reset_parameters()
-        # graph mode: capturable + fused (the unfused capturable Adam spends ~2 tiny kernels per parameter on bias corrections)
+        # same Adam as the reference (train.py:469); fused: one multi-tensor kernel instead of ~15 (and, when capturable
+        # for graph mode, instead of ~2 tiny kernels per parameter for the bias corrections)
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd, capturable=bool(args.hip_graph),
-                                     fused=bool(args.hip_graph))
+                                     fused=True)
         if args.hip_graph:                     # same loop, two graph launches per epoch instead of ~400 kernel launches
             from .graphs import GraphedForward, GraphedTrainStep
             train_idx, y_train = split_idx['train'], data.y[split_idx['train']]
