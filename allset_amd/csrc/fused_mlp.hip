@@ -885,7 +885,7 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
 #ifdef ALLSET_ABLATE_NOSTORE
           if (o.x == 123.456f)
 #endif
-          *reinterpret_cast<float4*>(gx + r * ldgx + hb * 64 + c4) = o;
+          if (gx != nullptr) *reinterpret_cast<float4*>(gx + r * ldgx + hb * 64 + c4) = o;
         }
       }
     }
@@ -1052,7 +1052,9 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
     if (has_ln) ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * I * sizeof(float), static_cast<hipStream_t>(stream)));
     return ALLSET_OK;
   }
-  ALLSET_REQUIRE(gy && W && gx, "fused_linear_bwd: null pointer");
+  ALLSET_REQUIRE(gy && W, "fused_linear_bwd: null pointer");
+  ALLSET_REQUIRE(gx != nullptr || (dense_mfma_x6() && stats != nullptr),
+                 "fused_linear_bwd: gx may be NULL only to get the LayerNorm partials alone (bf16x6 kernels)");
   ALLSET_REQUIRE((has_ln || relu_in) ? x != nullptr : true, "fused_linear_bwd: x required for LayerNorm / relu backward");
   ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && aligned16(gy) && aligned16(W), "fused_linear_bwd: gy/W must be 16-byte aligned rows");
   ALLSET_REQUIRE(y == nullptr || (ldy >= O && ldy % 4 == 0 && aligned16(y)), "fused_linear_bwd: y must be 16-byte aligned rows");
@@ -1060,7 +1062,7 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const bool x6 = dense_mfma_x6();
   if (x6) {
-    ALLSET_REQUIRE(ldgx % 4 == 0 && aligned16(gx) && (x == nullptr || (ldx % 4 == 0 && aligned16(x))),
+    ALLSET_REQUIRE((gx == nullptr || (ldgx % 4 == 0 && aligned16(gx))) && (x == nullptr || (ldx % 4 == 0 && aligned16(x))),
                    "fused_linear_bwd: gx / x must be 16-byte aligned rows");
     ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd: stats must be 8-byte aligned");
   }

@@ -206,8 +206,8 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                      gamma: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
                      seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None, acc_in: Optional[Tensor] = None,
-                     aux_g: Optional[Tensor] = None, aux_w: Optional[Tensor] = None
-                     ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+                     aux_g: Optional[Tensor] = None, aux_w: Optional[Tensor] = None, want_gx: bool = True
+                     ) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
     """(gx, dgamma, dbeta) of the fused Linear w.r.t. its input and LayerNorm parameters (csrc/fused_mlp.hip).
     ``mask`` replaces ``y`` as the source of the relu/dropout epilogue mask.  ``acc_in`` [n, I]: another gradient
     branch of the same input, summed in the kernel (``gx = acc_in + ...``; the buffer is reused for the result)."""
@@ -222,8 +222,10 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
     if acc_in is not None:
         acc_in = _rowmajor(acc_in)
         gx = acc_in if acc_in.is_contiguous() else torch.empty((n, I), dtype=torch.float32, device=dev)
-    else:
+    elif want_gx or stats is None or activation_mask_words(16, 64) == 0:
         gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    else:
+        gx = None                                  # LayerNorm partials only (the input needs no gradient)
     partials, npart = None, c_int64(0)
     if stats is not None:
         check(lib.allset_fused_linear_bwd_partials(n, byref(npart)), "allset_fused_linear_bwd_partials")
@@ -357,7 +359,8 @@ class _FusedNormLinear(torch.autograd.Function):
             gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b,
                                  seed_base=base, mask=mask)
         if ctx.needs_input_grad[0] or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
-            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in, base, mask)
+            gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in, base, mask,
+                                          want_gx=ctx.needs_input_grad[0])
         return gx, dg, db, gw, gb, None, None, None, None, None
 
 

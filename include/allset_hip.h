@@ -292,6 +292,7 @@ int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, con
  *   gx = LayerNorm-backward(gz; x, stats, gamma) through relu_in   (stats != NULL), else gz through relu_in.
  * partials (stats != NULL): f32[n_partials*2*I], row w = wave w's (dgamma[I], dbeta[I]); the caller sums over rows.
  * n_partials from allset_fused_linear_bwd_partials(n).
+ * gx may be NULL when only the LayerNorm parameter partials are wanted (the input needs no gradient: a model's first layer).
  * acc_in (may be NULL; f32[n*ldacc], may alias gx): added to the result, gx = acc_in + (this Linear's gradient) -- where
  * a tensor feeds two branches the second branch's backward kernel does the sum instead of a separate add pass. */
 int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials);

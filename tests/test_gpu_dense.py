@@ -421,3 +421,26 @@ def test_fused_kernels_are_run_to_run_deterministic(device):
         else:
             for name, a, r in zip(("y", "stats", "gx", "dgamma", "dbeta", "gW", "gb"), cur, ref):
                 assert torch.equal(a, r), name
+
+
+def test_fused_backward_without_input_gradient(device):
+    """A model's first layer: the input needs no gradient, the LayerNorm parameters do -- the backward-data kernel then
+    runs for its dgamma / dbeta partials only (gx = NULL).  Parameter gradients must equal the full run's."""
+    from allset_amd import dense
+    n, d = 3001, 128
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, d, generator=g).to(device)
+    G = torch.randn(n, d, generator=g).to(device)
+    grads = []
+    for need_x in (True, False):
+        W = (torch.randn(d, d, generator=torch.Generator().manual_seed(1)) / d ** 0.5).to(device).requires_grad_(True)
+        b = torch.zeros(d, device=device, requires_grad=True)
+        gamma = torch.ones(d, device=device, requires_grad=True)
+        beta = torch.zeros(d, device=device, requires_grad=True)
+        xi = x.clone().requires_grad_(need_x)
+        y = dense.fused_norm_linear(xi, gamma, beta, W, b, 1e-5, True, 0.0, True, 0.0)
+        (y * G).sum().backward()
+        assert (xi.grad is not None) == need_x
+        grads.append([t.grad.clone() for t in (gamma, beta, W, b)])
+    for a, r in zip(grads[1], grads[0]):
+        assert torch.equal(a, r)
