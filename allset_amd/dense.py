@@ -144,6 +144,11 @@ def fused_linear_supported(K: int, N: int) -> bool:
     return bool(_lib.load().allset_fused_linear_supported(K, N))
 
 
+def x6_active() -> bool:
+    """The default bf16x6 kernel family is selected (ALLSET_DENSE_MFMA unset): mask / acc_in / aux features exist."""
+    return int(_lib.load().allset_fused_linear_mask_words(16, 64)) > 0
+
+
 def activation_mask_words(n: int, N: int) -> int:
     """dwords of the 1-bit activation mask of an [n, N] output (0: not supported in this mode / for this width)."""
     return int(_lib.load().allset_fused_linear_mask_words(n, N))
@@ -222,7 +227,7 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
     if acc_in is not None:
         acc_in = _rowmajor(acc_in)
         gx = acc_in if acc_in.is_contiguous() else torch.empty((n, I), dtype=torch.float32, device=dev)
-    elif want_gx or stats is None or activation_mask_words(16, 64) == 0:
+    elif want_gx or stats is None or not x6_active():
         gx = torch.empty((n, I), dtype=torch.float32, device=dev)
     else:
         gx = None                                  # LayerNorm partials only (the input needs no gradient)

@@ -209,7 +209,7 @@ class PMA(nn.Module):
         """``(x_V, alpha_r)``: the value projection and the (folded) logits of ``x``."""
         H, C = self.heads, self.hidden
         fusable = _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features)
-        if fusable and self.fold_alpha and dense.activation_mask_words(16, 64) > 0:       # bf16x6 family active
+        if fusable and self.fold_alpha and dense.x6_active():
             # one autograd node for both consumers of x (bf16x6 kernels; the branches' gradients are summed in-kernel)
             w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
             b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
@@ -226,7 +226,8 @@ class PMA(nn.Module):
             # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
             out = dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
             ff = self.rFF
-            if (len(ff.lins) == 2 and ff._fusable(out) and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
+            if (dense.x6_active() and len(ff.lins) == 2 and ff._fusable(out)
+                    and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
                     and ff.lins[1].out_features == H * C):
                 # the whole residual block as one autograd node (gradient branches of `out` summed in a kernel)
                 return dense.pma_residual_ff(out, ff.lins[0].weight, ff.lins[0].bias, ff.lins[1].weight, ff.lins[1].bias,
