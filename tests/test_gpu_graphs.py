@@ -88,15 +88,16 @@ def test_graphed_train_step_matches_eager_without_dropout(name, device):
         assert torch.equal(pa, pb)
 
 
-def test_graphed_train_step_draws_fresh_masks_and_trains(device):
+@pytest.mark.parametrize("name", ["cora_ds_add", "citeseer_pma_h4"])
+def test_graphed_train_step_draws_fresh_masks_and_trains(name, device):
     from allset_amd.graphs import GraphedTrainStep
-    model, data, y = _setup("cora_ds_add", device, dropout=0.5)
+    model, data, y = _setup(name, device, dropout=0.5)
     opt = torch.optim.Adam(model.parameters(), lr=0.0, capturable=True)          # lr 0: only the masks differ
     step = GraphedTrainStep(model, data, lambda out: F.nll_loss(F.log_softmax(out, dim=1), y), opt)
     losses = [float(step().detach()) for _ in range(6)]
     assert len(set(losses)) == 6, losses                                         # a fresh mask every replay
     # and with a real learning rate the captured loop optimises
-    model2, data2, y2 = _setup("cora_ds_add", device, dropout=0.2)
+    model2, data2, y2 = _setup(name, device, dropout=0.2)
     opt2 = torch.optim.Adam(model2.parameters(), lr=1e-2, capturable=True, fused=True)
     step2 = GraphedTrainStep(model2, data2, lambda out: F.nll_loss(F.log_softmax(out, dim=1), y2), opt2)
     first = sum(float(step2().detach()) for _ in range(3)) / 3
