@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_kernel(
         o.x = xv.x > 0.f ? o.x : 0.f; o.y = xv.y > 0.f ? o.y : 0.f;
         o.z = xv.z > 0.f ? o.z : 0.f; o.w = xv.w > 0.f ? o.w : 0.f;
       }
-      *reinterpret_cast<float4*>(gx + row * ldgx + c0) = o;
+      if (gx != nullptr) *reinterpret_cast<float4*>(gx + row * ldgx + c0) = o;
     }
   }
   *reinterpret_cast<float4*>(&red[grp][0][c0]) = dg;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_generic_kernel(
       const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
       const float* xr = x + row * ldx;
       const float* gr = gy + row * ldg;
-      if (cb == 0) {   // first sweep also produces gx (needs the full-row sums)
+      if (cb == 0 && gx != nullptr) {   // first sweep also produces gx (needs the full-row sums); NULL: partials only
         float s1 = 0.f, s2 = 0.f;
         for (int c = lane; c < d; c += kWave) {
           const float t = relu_in ? fmaxf(xr[c], 0.f) : xr[c];
@@ -934,10 +934,10 @@ extern "C" int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64
     ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * d * sizeof(float), st));
     return ALLSET_OK;
   }
-  ALLSET_REQUIRE(gy && x && stats && gamma && gx, "ln_bwd: null pointer");
-  ALLSET_REQUIRE(ldg >= d && ldx >= d && ldgx >= d, "ln_bwd: leading dimension smaller than d");
-  const bool fast = shape_fast && ldg % 4 == 0 && ldx % 4 == 0 && ldgx % 4 == 0 && aligned16(gy) && aligned16(x) &&
-                    aligned16(gx) && aligned16(gamma);
+  ALLSET_REQUIRE(gy && x && stats && gamma, "ln_bwd: null pointer");         // gx may be NULL: parameter partials only
+  ALLSET_REQUIRE(ldg >= d && ldx >= d && (gx == nullptr || ldgx >= d), "ln_bwd: leading dimension smaller than d");
+  const bool fast = shape_fast && ldg % 4 == 0 && ldx % 4 == 0 && (gx == nullptr || (ldgx % 4 == 0 && aligned16(gx))) &&
+                    aligned16(gy) && aligned16(x) && aligned16(gamma);
   const int di = static_cast<int>(d);
   if (fast) {
     const unsigned grid = static_cast<unsigned>(n_partials);

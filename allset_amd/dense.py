@@ -103,7 +103,7 @@ def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p:
 
 
 def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
-           seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+           seed_base: Optional[Tensor] = None, want_gx: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor]:
     dev = require_device(gy, x, stats, gamma)
     gy, x = _rowmajor(gy), _rowmajor(x)
     n, d = x.shape
@@ -111,8 +111,8 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
     npart = c_int64(0)
     check(lib.allset_ln_bwd_partials(n, d, byref(npart)), "allset_ln_bwd_partials")
     partials = torch.empty((npart.value, 2, d), dtype=torch.float32, device=dev)
-    gx = torch.empty((n, d), dtype=x.dtype, device=dev)
-    with torch.cuda.device(dev), _timed("ln_bwd", dev, 3 * n * d * 4):
+    gx = torch.empty((n, d), dtype=x.dtype, device=dev) if want_gx else None
+    with torch.cuda.device(dev), _timed("ln_bwd", dev, (3 if want_gx else 2) * n * d * 4):
         check(lib.allset_ln_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
                                 seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
                                 stream_of(dev)),
@@ -269,7 +269,7 @@ class _LayerNormFused(torch.autograd.Function):
     def backward(ctx, gy):
         x, stats, gamma = ctx.saved_tensors
         relu_in, p, seed, base = ctx.cfg
-        gx, dg, db = ln_bwd(gy.contiguous(), x, stats, gamma, relu_in, p, seed, base)
+        gx, dg, db = ln_bwd(gy.contiguous(), x, stats, gamma, relu_in, p, seed, base, want_gx=ctx.needs_input_grad[0])
         return gx, dg, db, None, None, None
 
 

@@ -194,7 +194,7 @@ int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, const float* 
                   float p, uint64_t seed, float* y, int64_t ldy, float* stats, int64_t n, int64_t d,
                   const uint64_t* seed_base, void* stream);
 
-/* Backward of allset_ln_fwd.  gx = d loss / d x;  partials: f32[n_partials*2*d], row k holds block k's
+/* Backward of allset_ln_fwd.  gx = d loss / d x (may be NULL when only the parameter partials are wanted);  partials: f32[n_partials*2*d], row k holds block k's
  * (dgamma[d], dbeta[d]) partial sums -- the caller sums over k.  n_partials from allset_ln_bwd_partials. */
 int allset_ln_bwd_partials(int64_t n, int64_t d, int64_t* n_partials);
 int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* stats, const float* gamma,

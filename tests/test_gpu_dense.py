@@ -444,3 +444,22 @@ def test_fused_backward_without_input_gradient(device):
         grads.append([t.grad.clone() for t in (gamma, beta, W, b)])
     for a, r in zip(grads[1], grads[0]):
         assert torch.equal(a, r)
+
+
+@pytest.mark.parametrize("d", [128, 1433])
+def test_layer_norm_backward_without_input_gradient(d, device):
+    """Input LayerNorm of a model's first layer (raw features need no gradient): gx = NULL, same dgamma / dbeta."""
+    from allset_amd import dense
+    n = 1500
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=g).to(device)
+    G = torch.randn(n, d, generator=g).to(device)
+    res = []
+    for need_x in (True, False):
+        gamma = torch.ones(d, device=device, requires_grad=True)
+        beta = torch.zeros(d, device=device, requires_grad=True)
+        xi = x.clone().requires_grad_(need_x)
+        (dense.layer_norm(xi, gamma, beta, 1e-5, False, 0.0) * G).sum().backward()
+        assert (xi.grad is not None) == need_x
+        res.append((gamma.grad.clone(), beta.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
