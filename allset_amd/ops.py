@@ -5,7 +5,6 @@ tensors; outputs are allocated with torch (plumbing) and filled by the HIP kerne
 from __future__ import annotations
 
 from collections import defaultdict
-from contextlib import contextmanager
 from ctypes import byref, c_size_t
 from typing import Dict, List, NamedTuple, Optional, Tuple
 
@@ -44,18 +43,42 @@ def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
     _timer = timer
 
 
-@contextmanager
+class _NoTimer:
+    """Shared do-nothing context: the common case (no KernelTimer installed) must cost nothing per launch."""
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
+class _Timed:
+    __slots__ = ("t", "name", "st", "s", "bytes")
+
+    def __init__(self, t, name, dev, algo_bytes):
+        self.t, self.name, self.bytes = t, name, int(algo_bytes)
+        self.st = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.s.record(self.st)
+        return None
+
+    def __exit__(self, *exc):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(self.st)
+        self.t.events[self.name].append((self.s, e, self.bytes))
+        return False
+
+
 def _timed(name: str, dev, algo_bytes: int):
     t = _timer
-    if t is None:
-        yield
-        return
-    st = torch.cuda.current_stream(dev)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record(st)
-    yield
-    e.record(st)
-    t.events[name].append((s, e, int(algo_bytes)))
+    return _NO_TIMER if t is None else _Timed(t, name, dev, algo_bytes)
 
 
 class CSR(NamedTuple):
