@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--degree", type=int, default=16)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--degree-dist", default="fixed", choices=["fixed", "poisson", "zipf"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: BASELINE configs[4] regime -- bf16 tensors end to end, bf16 instantiations of the gather kernels "
+                         "(fp32 accumulation / softmax statistics), dense tail through torch's bf16 modules")
     ap.add_argument("--self-loops", action="store_true",
                     help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
@@ -173,13 +176,16 @@ def main():
     e2v = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, heads=args.heads, attention=attn)
     v2e.reset_parameters(); e2v.reset_parameters()
     v2e.to(dev).train(); e2v.to(dev).train()
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if tdt != torch.float32:
+        v2e.to(tdt); e2v.to(tdt)
     params = list(v2e.parameters()) + list(e2v.parameters())
     opt = torch.optim.Adam(params, lr=1e-3, fused=True)     # same Adam math, one multi-tensor kernel for the 24 small parameters
 
     gen = torch.Generator(device=dev).manual_seed(args.seed + 100 + rank)
     rows = hg.v_hi - hg.v_lo
-    x = torch.randn(rows, d, device=dev, generator=gen).requires_grad_(True)       # owned vertex block
-    G = torch.randn(rows, d, device=dev, generator=gen)
+    x = torch.randn(rows, d, device=dev, generator=gen).to(tdt).requires_grad_(True)       # owned vertex block
+    G = torch.randn(rows, d, device=dev, generator=gen).to(tdt)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -243,10 +249,14 @@ def main():
         line = {
             "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": value, "unit": "edges*d/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: every fp32 operand split exactly "
-                          "into three bf16, six of the nine partial products formed on the bf16 matrix pipe and accumulated in "
-                          "fp32 -- measured error vs float64 <= that of the native fp32 MFMA / hipBLASLt (DESIGN.md section 6)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "dtype_note": ("fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: every fp32 operand split exactly "
+                           "into three bf16, six of the nine partial products formed on the bf16 matrix pipe and accumulated in "
+                           "fp32 -- measured error vs float64 <= that of the native fp32 MFMA / hipBLASLt (DESIGN.md section 6)")
+            if args.dtype == "f32" else
+            ("bf16 tensors end to end (BASELINE configs[4] regime): bf16 instantiations of the gather kernels with fp32 "
+             "accumulation and fp32 softmax statistics; the dense tail runs through torch's bf16 modules (no fused bf16 "
+             "dense kernels yet)"),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if attn else 2}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph |V|=|E|={n_loc} per GPU, "
                                    f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, " +
