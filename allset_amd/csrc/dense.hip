@@ -868,6 +868,125 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
   }
 }
 
+
+// ---- weight gradient for bf16 activations (BASELINE configs[4] regime) ----------------------------------------------
+// Same organisation as wgrad_x6_kernel (row-pair packed transposition into swizzled LDS planes, 64 x 32 wave tiles), but a
+// bf16 x bf16 product is exact in the fp32 accumulator, so there is ONE plane per operand and one MFMA per tile and
+// stage: the kernel is a pure stream over the two activation matrices (hipBLASLt tiles this [O x n] x [n x I] shape
+// badly: 0.5-0.7 ms at n = 250k, d = 256 against ~0.05 ms of traffic).
+template <int DUMMY>
+__global__ __launch_bounds__(kWx6Block) void wgrad_bf16_kernel(
+    const uint16_t* __restrict__ ga, int64_t lda, const uint16_t* __restrict__ u, int64_t ldu,
+    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i, int64_t rows_per_slice) {
+  __shared__ __attribute__((aligned(16))) uint32_t sP[2][2][kWgTile * 16];        // [buffer][A|B][feature*16 + ..]
+  const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
+  const int o_base = tile_o * kWgTile, i_base = tile_i * kWgTile;
+  const int slice = blockIdx.y;
+  const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
+  const int64_t r_end = min(n, r_begin + rows_per_slice);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rp = lane & 15, s_col = (wave * 4 + (lane >> 4)) * 4;
+  const bool a_ok = (o_base + s_col) < O, b_ok = (i_base + s_col) < I;           // O, I are multiples of 4
+  const int a_col = a_ok ? o_base + s_col : 0, b_col = b_ok ? i_base + s_col : 0;
+  const int w_off = s_col * 16 + 4 * ((rp >> 2) ^ wx6_swz(s_col)) + (rp & 3);
+  float4 bsum = make_float4(0, 0, 0, 0);
+
+  struct Stage { uint2 ra[2], rb[2]; int64_t row0; };
+  auto load_stage = [&](Stage& sg, int64_t r0) {            // unconditional loads on clamped rows / columns
+    sg.row0 = r0 + 2 * rp;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t r = sg.row0 + h;
+      r = r < r_end ? r : r_end - 1;
+      sg.ra[h] = *reinterpret_cast<const uint2*>(ga + r * lda + a_col);
+      sg.rb[h] = *reinterpret_cast<const uint2*>(u + r * ldu + b_col);
+    }
+  };
+  auto store_stage = [&](Stage& sg, int buf) {
+    uint2 a[2], b[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool in_range = (sg.row0 + h) < r_end;
+      a[h] = (in_range && a_ok) ? sg.ra[h] : make_uint2(0u, 0u);
+      b[h] = (in_range && b_ok) ? sg.rb[h] : make_uint2(0u, 0u);
+      bsum.x += __uint_as_float(a[h].x << 16); bsum.y += __uint_as_float(a[h].x & 0xffff0000u);
+      bsum.z += __uint_as_float(a[h].y << 16); bsum.w += __uint_as_float(a[h].y & 0xffff0000u);
+    }
+    uint32_t* pa = &sP[buf][0][w_off];
+    uint32_t* pb = &sP[buf][1][w_off];
+    // (row r, row r+1) of one column packed into a dword: low half = even row
+    pa[0] = (a[0].x & 0xffffu) | (a[1].x << 16);  pa[16] = (a[0].x >> 16) | (a[1].x & 0xffff0000u);
+    pa[32] = (a[0].y & 0xffffu) | (a[1].y << 16); pa[48] = (a[0].y >> 16) | (a[1].y & 0xffff0000u);
+    pb[0] = (b[0].x & 0xffffu) | (b[1].x << 16);  pb[16] = (b[0].x >> 16) | (b[1].x & 0xffff0000u);
+    pb[32] = (b[0].y & 0xffffu) | (b[1].y << 16); pb[48] = (b[0].y >> 16) | (b[1].y & 0xffff0000u);
+  };
+
+  const int fj = lane & 15, fg = lane >> 4;
+  const int ob = (wave >> 2) * 64, ib = (wave & 3) * 32;
+  f32x4_t acc[4][2];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) { acc[ot][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[ot][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  int a_off[4], b_off[2];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) { const int f = ob + ot * 16 + fj; a_off[ot] = f * 16 + 4 * (fg ^ wx6_swz(f)); }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) { const int f = ib + it * 16 + fj; b_off[it] = f * 16 + 4 * (fg ^ wx6_swz(f)); }
+  auto mfma_stage = [&](int buf) {
+    WFrag b0, b1;
+    b0.u = *reinterpret_cast<const uint4*>(&sP[buf][1][b_off[0]]);
+    b1.u = *reinterpret_cast<const uint4*>(&sP[buf][1][b_off[1]]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+      WFrag a;
+      a.u = *reinterpret_cast<const uint4*>(&sP[buf][0][a_off[ot]]);
+      acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0.v, acc[ot][0], 0, 0, 0);
+      acc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b1.v, acc[ot][1], 0, 0, 0);
+    }
+  };
+
+  Stage s0, s1;
+  if (r_begin < r_end) {
+    load_stage(s0, r_begin);
+    load_stage(s1, r_begin + kWgRows);
+    store_stage(s0, 0);
+    load_stage(s0, r_begin + 2 * kWgRows);
+  }
+  __syncthreads();
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kWgRows) {
+    mfma_stage(0);
+    if (r0 + kWgRows < r_end) store_stage(s1, 1);
+    load_stage(s1, r0 + 3 * kWgRows);
+    __syncthreads();
+    if (r0 + kWgRows < r_end) {
+      mfma_stage(1);
+      if (r0 + 2 * kWgRows < r_end) store_stage(s0, 0);
+      load_stage(s0, r0 + 4 * kWgRows);
+      __syncthreads();
+    }
+  }
+
+  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = i_base + ib + it * 16 + fj;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o_base + ob + ot * 16 + 4 * fg + r;
+        if (o < O && i < I) pw[static_cast<int64_t>(o) * I + i] = acc[ot][it][r];
+      }
+    }
+  if (tile_i == 0 && part_b != nullptr) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      bsum.x += __shfl_xor(bsum.x, off); bsum.y += __shfl_xor(bsum.y, off);
+      bsum.z += __shfl_xor(bsum.z, off); bsum.w += __shfl_xor(bsum.w, off);
+    }
+    if (rp == 0 && a_ok) *reinterpret_cast<float4*>(part_b + static_cast<int64_t>(slice) * O + o_base + s_col) = bsum;
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -1187,6 +1306,30 @@ extern "C" int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, i
     default: ALLSET_LNRES_BWD(64); break;
   }
 #undef ALLSET_LNRES_BWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
+                                 int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_bf16: bad size");
+  ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_bf16: bad slice count");
+  ALLSET_REQUIRE(part_w != nullptr, "wgrad_bf16: null partial buffer");
+  ALLSET_REQUIRE(n == 0 || (ga && u), "wgrad_bf16: null input");
+  if (O % 4 != 0 || I % 4 != 0 || lda % 4 != 0 || ldu % 4 != 0 || (reinterpret_cast<uintptr_t>(ga) & 7u) || (reinterpret_cast<uintptr_t>(u) & 7u)) {
+    set_error("wgrad_bf16: needs feature widths / leading dimensions that are multiples of 4 and 8-byte aligned inputs");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(lda >= O && ldu >= I, "wgrad_bf16: leading dimension smaller than the feature width");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int tiles_o = static_cast<int>((O + kWgTile - 1) / kWgTile), tiles_i = static_cast<int>((I + kWgTile - 1) / kWgTile);
+  int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
+  rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
+  if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
+  const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
+  wgrad_bf16_kernel<0><<<grid, kWx6Block, 0, st>>>(static_cast<const uint16_t*>(ga), lda, static_cast<const uint16_t*>(u), ldu,
+                                                   part_w, part_b, n, static_cast<int>(O), static_cast<int>(I), tiles_i, rows_per_slice);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -122,7 +122,8 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
 
 
 def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
-    """gW [O, I] = ga^T @ u,  gb [O] = ga.sum(0)  (ga: [n, O], u: [n, I])."""
+    """gW [O, I] = ga^T @ u,  gb [O] = ga.sum(0)  (ga: [n, O], u: [n, I]); fp32, or bf16 activations (fp32 accumulation,
+    result cast back to bf16)."""
     dev = require_device(ga, u)
     ga, u = _rowmajor(ga), _rowmajor(u)
     n, O = ga.shape
@@ -132,11 +133,18 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
     check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
     part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
     part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
-    with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * 4):
-        check(lib.allset_wgrad(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,
-                               stream_of(dev)), "allset_wgrad")
+    bf16 = ga.dtype == torch.bfloat16
+    with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
+        if bf16:
+            check(lib.allset_wgrad_bf16(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,
+                                        stream_of(dev)), "allset_wgrad_bf16")
+        else:
+            check(lib.allset_wgrad(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,
+                                   stream_of(dev)), "allset_wgrad")
     gw = reduce_partials(part_w)
     gb = reduce_partials(part_b) if want_bias else None
+    if bf16:
+        gw, gb = gw.to(torch.bfloat16), (gb.to(torch.bfloat16) if gb is not None else None)
     return gw, gb
 
 
@@ -248,7 +256,7 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
 
 
 def wgrad_supported(ga: Tensor, u: Tensor) -> bool:
-    return (ga.is_cuda and ga.dtype == torch.float32 and u.dtype == torch.float32 and ga.shape[1] % 4 == 0
+    return (ga.is_cuda and ga.dtype == u.dtype and ga.dtype in (torch.float32, torch.bfloat16) and ga.shape[1] % 4 == 0
             and u.shape[1] % 4 == 0)
 
 

@@ -70,8 +70,8 @@ def _layer_norm(norm: nn.LayerNorm, x: Tensor, relu_in: bool = False, p: float =
 
 
 def _linear(lin: nn.Linear, x: Tensor) -> Tensor:
-    if _on_hip(x):
-        return dense.linear(x, lin.weight, lin.bias)
+    if _on_hip(x) or (x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16):
+        return dense.linear(x, lin.weight, lin.bias)     # library GEMMs forward / backward-data, split-K MFMA weight gradient
     return lin(x)
 
 

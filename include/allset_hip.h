@@ -215,6 +215,11 @@ int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
+/* The same weight gradient for bf16 activations (ga, u: bf16 row-major; fp32 partials as above; bf16 x bf16 products are
+ * exact in the fp32 accumulator).  n_slices from allset_wgrad_slices. */
+int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
+                      int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+
 /* Same with an explicit kernel choice (variant as in allset_pma_fwd_ex; nnz / n_s decides in auto mode). */
 int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptrT, const int32_t* colT,
                           const float* alpha, const void* V, int64_t ldv,

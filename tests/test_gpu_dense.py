@@ -463,3 +463,31 @@ def test_layer_norm_backward_without_input_gradient(d, device):
         assert (xi.grad is not None) == need_x
         res.append((gamma.grad.clone(), beta.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("n,O,I", [(5000, 256, 256), (777, 128, 64), (33, 4, 260), (100003, 256, 128)])
+def test_wgrad_bf16_matches_float64(n, O, I, device):
+    """Weight gradient for bf16 activations: bf16 x bf16 products are exact in fp32, so the only error is the fp32
+    accumulation order -- compare with the float64 product of the SAME bf16 values."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n + O)
+    ga = torch.randn(n, O, generator=g).to(torch.bfloat16).to(device)
+    u = torch.randn(n, I, generator=g).to(torch.bfloat16).to(device)
+    gw, gb = dense.wgrad(ga, u)
+    assert gw.dtype == torch.bfloat16 and gw.shape == (O, I) and gb.shape == (O,)
+    ref_w = ga.double().t() @ u.double()
+    ref_b = ga.double().sum(0)
+    scale = float(ref_w.abs().max())
+    # the result is rounded to bf16 once at the end: 2^-8 relative
+    torch.testing.assert_close(gw.double(), ref_w, rtol=1e-2, atol=5e-3 * scale)
+    torch.testing.assert_close(gb.double(), ref_b, rtol=1e-2, atol=5e-3 * float(ref_b.abs().max()))
+    # fp32 partial sums before the final rounding: check them directly through the raw entry
+    from ctypes import byref, c_int64
+    from allset_amd import _lib
+    lib = _lib.load()
+    ns = c_int64(0)
+    _lib.check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "slices")
+    pw = torch.empty((ns.value, O, I), dtype=torch.float32, device=device)
+    _lib.check(lib.allset_wgrad_bf16(ga.data_ptr(), O, u.data_ptr(), I, pw.data_ptr(), None, ns.value, n, O, I,
+                                     torch.cuda.current_stream().cuda_stream), "wgrad_bf16")
+    torch.testing.assert_close(pw.double().sum(0), ref_w, rtol=1e-5, atol=1e-5 * scale)
