@@ -987,6 +987,154 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_kernel(
   }
 }
 
+
+// ---- LayerNorm for bf16 activations (fp32 statistics and arithmetic, bf16 in / out; gamma, beta bf16) -------------------
+// One lane = 8 consecutive columns (16 bytes), LPR = d / 8 lanes per row (d % 8 == 0, d <= 512), 64 / LPR rows per wave.
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 unpack8(uint4 q) {
+  F8 r;
+  r.v[0] = __uint_as_float(q.x << 16); r.v[1] = __uint_as_float(q.x & 0xffff0000u);
+  r.v[2] = __uint_as_float(q.y << 16); r.v[3] = __uint_as_float(q.y & 0xffff0000u);
+  r.v[4] = __uint_as_float(q.z << 16); r.v[5] = __uint_as_float(q.z & 0xffff0000u);
+  r.v[6] = __uint_as_float(q.w << 16); r.v[7] = __uint_as_float(q.w & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ uint4 pack8(const F8& f) {
+  return make_uint4(cvt_pk_bf16(f.v[0], f.v[1]), cvt_pk_bf16(f.v[2], f.v[3]), cvt_pk_bf16(f.v[4], f.v[5]), cvt_pk_bf16(f.v[6], f.v[7]));
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_fwd_bf16_kernel(
+    const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+    float eps, int relu_in, float p, uint64_t seed, uint16_t* __restrict__ y, int64_t ldy,
+    float* __restrict__ stats, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  constexpr int NS = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 8;
+  const bool active = c0 < d;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  const int cc = active ? c0 : 0;
+  const F8 g8 = unpack8(*reinterpret_cast<const uint4*>(gamma + cc)), b8 = unpack8(*reinterpret_cast<const uint4*>(beta + cc));
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + grp) * kLnRowsPerGroup;
+  uint4 raw[kLnRowsPerGroup];
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    int64_t row = row0 + r;
+    row = row < n ? row : n - 1;
+    raw[r] = *reinterpret_cast<const uint4*>(x + row * ldx + cc);
+  }
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    const int64_t row = row0 + r;
+    F8 t = unpack8(raw[r]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (relu_in) t.v[k] = fmaxf(t.v[k], 0.f); if (!active) t.v[k] = 0.f; s += t.v[k]; }
+    const float mean = group_sum<LPR>(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t.v[k] = active ? t.v[k] - mean : 0.f; q = fmaf(t.v[k], t.v[k], q); }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * inv_d + eps);
+    if (row < n) {
+      if (active) {
+        F8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.v[k] = fmaf(t.v[k] * rstd, g8.v[k], b8.v[k]);
+        if (p > 0.f) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            float k0, k1;
+            keep_scale2(seed, row * d + c0 + k, thr, inv_keep, k0, k1);
+            o.v[k] *= k0; o.v[k + 1] *= k1;
+          }
+        }
+        *reinterpret_cast<uint4*>(y + row * ldy + c0) = pack8(o);
+      }
+      if (li == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    }
+  }
+}
+
+// part[blockIdx][0|1][c] = dgamma, dbeta (fp32)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_bwd_bf16_kernel(
+    const uint16_t* __restrict__ gy, int64_t ldg, const uint16_t* __restrict__ x, int64_t ldx,
+    const float* __restrict__ stats, const uint16_t* __restrict__ gamma, int relu_in, float p, uint64_t seed,
+    uint16_t* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d,
+    const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  constexpr int NS = kWave / LPR;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  __shared__ float red[kGroups][2][LPR * 8];
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 8;
+  const bool active = c0 < d;
+  const int cc = active ? c0 : 0;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  const F8 g8 = unpack8(*reinterpret_cast<const uint4*>(gamma + cc));
+  F8 dg, db;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { dg.v[k] = 0.f; db.v[k] = 0.f; }
+  const int64_t rows_per_iter = static_cast<int64_t>(gridDim.x) * kGroups;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + grp; row < n; row += rows_per_iter) {
+    const F8 xv = unpack8(*reinterpret_cast<const uint4*>(x + row * ldx + cc));
+    F8 gv = unpack8(*reinterpret_cast<const uint4*>(gy + row * ldg + cc));
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    F8 xh, gh;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      if (p > 0.f) {
+        float k0, k1;
+        keep_scale2(seed, row * d + c0 + k, thr, inv_keep, k0, k1);
+        gv.v[k] *= k0; gv.v[k + 1] *= k1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t = relu_in ? fmaxf(xv.v[k], 0.f) : xv.v[k];
+      xh.v[k] = active ? (t - mean) * rstd : 0.f;
+      if (!active) gv.v[k] = 0.f;
+      dg.v[k] = fmaf(gv.v[k], xh.v[k], dg.v[k]);
+      db.v[k] += gv.v[k];
+      gh.v[k] = gv.v[k] * g8.v[k];
+      s1 += gh.v[k];
+      s2 = fmaf(gh.v[k], xh.v[k], s2);
+    }
+    s1 = group_sum<LPR>(s1) * inv_d;
+    s2 = group_sum<LPR>(s2) * inv_d;
+    if (active && gx != nullptr) {
+      F8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o.v[k] = rstd * (gh.v[k] - s1 - xh.v[k] * s2);
+        if (relu_in && !(xv.v[k] > 0.f)) o.v[k] = 0.f;
+      }
+      *reinterpret_cast<uint4*>(gx + row * ldgx + c0) = pack8(o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[grp][0][c0 + k] = dg.v[k]; red[grp][1][c0 + k] = db.v[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * LPR * 8; i += kBlock) {
+    const int which = i / (LPR * 8), c = i % (LPR * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) s += red[g][which][c];
+    if (c < d) part[(static_cast<int64_t>(blockIdx.x) * 2 + which) * d + c] = s;
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -1330,6 +1478,71 @@ extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   wgrad_bf16_kernel<0><<<grid, kWx6Block, 0, st>>>(static_cast<const uint16_t*>(ga), lda, static_cast<const uint16_t*>(u), ldu,
                                                    part_w, part_b, n, static_cast<int>(O), static_cast<int>(I), tiles_i, rows_per_slice);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+static inline int ln_bf16_lpr(int64_t d) { return d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 256 ? 32 : 64)); }
+
+extern "C" int allset_ln_bf16_supported(int64_t d) { return (d >= 8 && d <= 512 && d % 8 == 0) ? 1 : 0; }
+
+extern "C" int allset_ln_fwd_bf16(const void* x, int64_t ldx, const void* gamma, const void* beta, float eps, int relu_in,
+                                  float p, uint64_t seed, void* y, int64_t ldy, float* stats, int64_t n, int64_t d,
+                                  const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_fwd_bf16: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_fwd_bf16: dropout p must be in [0,1)");
+  if (!allset_ln_bf16_supported(d)) { set_error("ln_fwd_bf16: width %lld not built (d %% 8 == 0, d <= 512)", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && gamma && beta && y && stats, "ln_fwd_bf16: null pointer");
+  ALLSET_REQUIRE(ldx >= d && ldy >= d && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta),
+                 "ln_fwd_bf16: rows and parameter vectors must be 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int di = static_cast<int>(d), lpr = ln_bf16_lpr(d);
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
+  const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
+  const uint16_t *xx = static_cast<const uint16_t*>(x), *gg = static_cast<const uint16_t*>(gamma), *bb = static_cast<const uint16_t*>(beta);
+  uint16_t* yy = static_cast<uint16_t*>(y);
+#define ALLSET_LNB_FWD(L) ln_fwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>(xx, ldx, gg, bb, eps, relu_in, p, seed, yy, ldy, stats, n, di, seed_base)
+  switch (lpr) { case 8: ALLSET_LNB_FWD(8); break; case 16: ALLSET_LNB_FWD(16); break; case 32: ALLSET_LNB_FWD(32); break; default: ALLSET_LNB_FWD(64); break; }
+#undef ALLSET_LNB_FWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_bwd_bf16_partials(int64_t n, int64_t d, int64_t* n_partials) {
+  clear_error();
+  ALLSET_REQUIRE(n_partials != nullptr && n >= 0 && allset_ln_bf16_supported(d), "ln_bwd_bf16_partials: bad argument");
+  const int64_t groups = static_cast<int64_t>(kWavesPerBlock) * (kWave / ln_bf16_lpr(d));
+  const int64_t want = (n + groups - 1) / groups;
+  *n_partials = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const float* stats,
+                                  const void* gamma, int relu_in, float p, uint64_t seed, void* gx, int64_t ldgx,
+                                  float* partials, int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base,
+                                  void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_bwd_bf16: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_bwd_bf16: dropout p must be in [0,1)");
+  if (!allset_ln_bf16_supported(d)) { set_error("ln_bwd_bf16: width %lld not built", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(partials != nullptr && n_partials >= 1, "ln_bwd_bf16: partials buffer required");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * d * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && x && stats && gamma, "ln_bwd_bf16: null pointer");
+  ALLSET_REQUIRE(ldg >= d && ldx >= d && ldg % 8 == 0 && ldx % 8 == 0 && aligned16(gy) && aligned16(x) && aligned16(gamma) &&
+                 (gx == nullptr || (ldgx >= d && ldgx % 8 == 0 && aligned16(gx))), "ln_bwd_bf16: rows must be 16-byte aligned");
+  const int di = static_cast<int>(d);
+  const unsigned grid = static_cast<unsigned>(n_partials);
+  const uint16_t *gg = static_cast<const uint16_t*>(gy), *xx = static_cast<const uint16_t*>(x), *gm = static_cast<const uint16_t*>(gamma);
+  uint16_t* go = static_cast<uint16_t*>(gx);
+#define ALLSET_LNB_BWD(L) ln_bwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>(gg, ldg, xx, ldx, stats, gm, relu_in, p, seed, go, ldgx, partials, n, di, seed_base)
+  switch (ln_bf16_lpr(d)) { case 8: ALLSET_LNB_BWD(8); break; case 16: ALLSET_LNB_BWD(16); break; case 32: ALLSET_LNB_BWD(32); break; default: ALLSET_LNB_BWD(64); break; }
+#undef ALLSET_LNB_BWD
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

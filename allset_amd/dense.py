@@ -89,17 +89,29 @@ def reduce_partials(part: Tensor) -> Tensor:
 def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p: float, seed: int,
            seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     dev = require_device(x, gamma, beta)
-    _check_f32(x, gamma, beta)
     x = _rowmajor(x)
     n, d = x.shape
     y = torch.empty((n, d), dtype=x.dtype, device=dev)
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    if x.dtype == torch.bfloat16:                 # bf16 activations and parameters, fp32 arithmetic (configs[4] regime)
+        if gamma.dtype != torch.bfloat16 or beta.dtype != torch.bfloat16 or not ln_bf16_supported(d):
+            raise _lib.AllSetHipError("bf16 LayerNorm: bf16 gamma / beta and d % 8 == 0, d <= 512 required")
+        with torch.cuda.device(dev), _timed("ln_fwd", dev, 2 * n * d * 2):
+            check(_lib.load().allset_ln_fwd_bf16(ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
+                                                 int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, ptr(seed_base),
+                                                 stream_of(dev)), "allset_ln_fwd_bf16")
+        return y, stats
+    _check_f32(x, gamma, beta)
     with torch.cuda.device(dev), _timed("ln_fwd", dev, 2 * n * d * 4):
         check(_lib.load().allset_ln_fwd(ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
                                         int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, ptr(seed_base),
                                         stream_of(dev)),
               "allset_ln_fwd")
     return y, stats
+
+
+def ln_bf16_supported(d: int) -> bool:
+    return bool(_lib.load().allset_ln_bf16_supported(d))
 
 
 def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
@@ -109,6 +121,18 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
     n, d = x.shape
     lib = _lib.load()
     npart = c_int64(0)
+    if x.dtype == torch.bfloat16:
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        check(lib.allset_ln_bwd_bf16_partials(n, d, byref(npart)), "allset_ln_bwd_bf16_partials")
+        partials = torch.empty((npart.value, 2, d), dtype=torch.float32, device=dev)
+        gx = torch.empty((n, d), dtype=x.dtype, device=dev) if want_gx else None
+        with torch.cuda.device(dev), _timed("ln_bwd", dev, (3 if want_gx else 2) * n * d * 2):
+            check(lib.allset_ln_bwd_bf16(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
+                                         seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
+                                         stream_of(dev)), "allset_ln_bwd_bf16")
+        red = reduce_partials(partials)
+        return gx, red[0].to(torch.bfloat16), red[1].to(torch.bfloat16)
     check(lib.allset_ln_bwd_partials(n, d, byref(npart)), "allset_ln_bwd_partials")
     partials = torch.empty((npart.value, 2, d), dtype=torch.float32, device=dev)
     gx = torch.empty((n, d), dtype=x.dtype, device=dev) if want_gx else None

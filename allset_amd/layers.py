@@ -65,6 +65,9 @@ def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
 def _layer_norm(norm: nn.LayerNorm, x: Tensor, relu_in: bool = False, p: float = 0.0) -> Tensor:
     if _on_hip(x) and norm.elementwise_affine and norm.bias is not None:
         return dense.layer_norm(x, norm.weight, norm.bias, norm.eps, relu_in, p)
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and norm.elementwise_affine and norm.bias is not None
+            and norm.weight.dtype == torch.bfloat16 and dense.ln_bf16_supported(x.shape[1])):
+        return dense.layer_norm(x, norm.weight, norm.bias, norm.eps, relu_in, p)     # bf16 in / out, fp32 arithmetic
     y = norm(F.relu(x) if relu_in else x)
     return F.dropout(y, p=p, training=p > 0.0)
 

@@ -247,6 +247,18 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
 int allset_pma_merge_pack(const float* out_loc, int64_t ldo, const float* m_loc, const float* l_loc, const float* m_glob,
                           float* packed, int64_t ldp, int64_t n, int64_t H, int64_t C, void* stream);
 
+/* allset_ln_fwd / allset_ln_bwd for bf16 activations and bf16 gamma / beta (BASELINE configs[4] regime): fp32 statistics
+ * and arithmetic, bf16 in and out, stats and parameter partials fp32.  Widths: allset_ln_bf16_supported(d) (d % 8 == 0,
+ * d <= 512).  gx may be NULL (partials only). */
+int allset_ln_bf16_supported(int64_t d);
+int allset_ln_fwd_bf16(const void* x, int64_t ldx, const void* gamma, const void* beta, float eps, int relu_in, float p,
+                       uint64_t seed, void* y, int64_t ldy, float* stats, int64_t n, int64_t d, const uint64_t* seed_base,
+                       void* stream);
+int allset_ln_bwd_bf16_partials(int64_t n, int64_t d, int64_t* n_partials);
+int allset_ln_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const float* stats, const void* gamma,
+                       int relu_in, float p, uint64_t seed, void* gx, int64_t ldgx, float* partials, int64_t n_partials,
+                       int64_t n, int64_t d, const uint64_t* seed_base, void* stream);
+
 /* LayerNorm with a fused sum in front and a relu behind -- the PMA tail (reference layers.py:153-157) and the
  * relu -> dropout SetGNN puts behind every conv (models.py:475-481):
  *   y = dropout_{p,seed}( relu_out ? relu(.) : . )( LayerNorm_{gamma,beta,eps}( x + colb + res ) )

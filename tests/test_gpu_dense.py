@@ -491,3 +491,27 @@ def test_wgrad_bf16_matches_float64(n, O, I, device):
     _lib.check(lib.allset_wgrad_bf16(ga.data_ptr(), O, u.data_ptr(), I, pw.data_ptr(), None, ns.value, n, O, I,
                                      torch.cuda.current_stream().cuda_stream), "wgrad_bf16")
     torch.testing.assert_close(pw.double().sum(0), ref_w, rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("n,d", [(1000, 256), (37, 128), (4099, 64), (513, 512), (200, 8)])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_layer_norm_bf16_fwd_bwd(n, d, relu_in, device):
+    """bf16 LayerNorm kernels (bf16 in / out and parameters, fp32 arithmetic) against float64 torch on the same bf16
+    values: the output carries one bf16 rounding (2^-8), parameter gradients are fp32 sums rounded once."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n + d)
+    x = torch.randn(n, d, generator=g).to(torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(d, generator=g)).to(torch.bfloat16)
+    beta = (0.3 * torch.randn(d, generator=g)).to(torch.bfloat16)
+    G = torch.randn(n, d, generator=g).to(torch.bfloat16)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    ref = F.layer_norm(F.relu(xr) if relu_in else xr, (d,), gr, br, 1e-5)
+    (ref * G.double()).sum().backward()
+    xg, gg, bg = (t.to(device).requires_grad_(True) for t in (x, gamma, beta))
+    out = dense.layer_norm(xg, gg, bg, 1e-5, relu_in, 0.0)
+    assert out.dtype == torch.bfloat16
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=2e-2, atol=2e-2 * max(1.0, float(xr.grad.abs().max())))
+    for a, r in ((gg.grad, gr.grad), (bg.grad, br.grad)):
+        torch.testing.assert_close(a.cpu().double(), r, rtol=2e-2, atol=2e-2 * max(1.0, float(r.abs().max())))
