@@ -205,7 +205,8 @@ class PMA(nn.Module):
             b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
             # [n,in] x [in,H]: the weight gradient of this skinny Linear is a [H x n] x [n x in] product that the
             # library tiles badly (1.5 ms at n = 1M); dense.linear routes it to the split-K MFMA kernel
-            return dense.linear(x, w, b) if (_on_hip(x) and H % 4 == 0 and x.shape[1] % 4 == 0) else F.linear(x, w, b)
+            hip = _on_hip(x) or (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16)
+            return dense.linear(x, w, b) if (hip and H % 4 == 0 and x.shape[1] % 4 == 0) else F.linear(x, w, b)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
     def project(self, x: Tensor) -> Tuple[Tensor, Tensor]:
