@@ -66,6 +66,10 @@ SIGNATURES = {
     "allset_ln_bwd_bf16_partials": [c_int64, c_int64, POINTER(c_int64)],
     "allset_ln_bwd_bf16": [_P, c_int64, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
                            c_int64, c_int64, _P, _P],
+    "allset_ln_res_fwd_bf16": [_P, c_int64, _P, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
+                               c_int64, _P, _P],
+    "allset_ln_res_bwd_bf16": [_P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P,
+                               c_int64, c_int64, c_int64, _P, _P],
     "allset_ln_res_supported": [c_int64],
     "allset_ln_res_fwd": [_P, c_int64, _P, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
                           c_int64, _P, _P],

@@ -1135,6 +1135,147 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_bf16_kernel(
   }
 }
 
+
+// ---- ln_res_* for bf16 activations: y = dropout_p(relu_out(LN(x + colb + res))), bf16 in / out, fp32 arithmetic ------------
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_res_fwd_bf16_kernel(
+    const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ colb, const uint16_t* __restrict__ res,
+    int64_t ldr, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, float eps, int relu_out, float p,
+    uint64_t seed, uint16_t* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n, int d,
+    const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  constexpr int NS = kWave / LPR;
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 8;
+  const bool active = c0 < d;
+  const int cc = active ? c0 : 0;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  const F8 g8 = unpack8(*reinterpret_cast<const uint4*>(gamma + cc)), b8 = unpack8(*reinterpret_cast<const uint4*>(beta + cc));
+  F8 cb;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cb.v[k] = 0.f;
+  if (colb) cb = unpack8(*reinterpret_cast<const uint4*>(colb + cc));
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + grp) * kLnRowsPerGroup;
+  uint4 rx[kLnRowsPerGroup], rr[kLnRowsPerGroup];
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    int64_t row = row0 + r;
+    row = row < n ? row : n - 1;
+    rx[r] = *reinterpret_cast<const uint4*>(x + row * ldx + cc);
+    rr[r] = res ? *reinterpret_cast<const uint4*>(res + row * ldr + cc) : make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+    const int64_t row = row0 + r;
+    F8 t = unpack8(rx[r]);
+    const F8 w = unpack8(rr[r]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t.v[k] = active ? t.v[k] + w.v[k] + cb.v[k] : 0.f; s += t.v[k]; }
+    const float mean = group_sum<LPR>(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t.v[k] = active ? t.v[k] - mean : 0.f; q = fmaf(t.v[k], t.v[k], q); }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * inv_d + eps);
+    if (row < n) {
+      if (active) {
+        F8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o.v[k] = fmaf(t.v[k] * rstd, g8.v[k], b8.v[k]); if (relu_out) o.v[k] = fmaxf(o.v[k], 0.f); }
+        if (p > 0.f) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            float k0, k1;
+            keep_scale2(seed, row * d + c0 + k, thr, inv_keep, k0, k1);
+            o.v[k] *= k0; o.v[k + 1] *= k1;
+          }
+        }
+        *reinterpret_cast<uint4*>(y + row * ldy + c0) = pack8(o);
+      }
+      if (li == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    }
+  }
+}
+
+// part[blockIdx][0|1|2][c] = dgamma, dbeta, dcolb (fp32)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
+    const uint16_t* __restrict__ gy, int64_t ldg, const uint16_t* __restrict__ x, int64_t ldx,
+    const uint16_t* __restrict__ colb, const uint16_t* __restrict__ res, int64_t ldr, const float* __restrict__ stats,
+    const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, int relu_out, float p, uint64_t seed,
+    uint16_t* __restrict__ gs, int64_t ldgs, float* __restrict__ part, int64_t n, int d,
+    const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  constexpr int NS = kWave / LPR;
+  constexpr int kGroups = kWavesPerBlock * NS;
+  __shared__ float red[kGroups][3][LPR * 8];
+  const int lane = lane_id();
+  const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
+  const int li = lane % LPR;
+  const int c0 = li * 8;
+  const bool active = c0 < d;
+  const int cc = active ? c0 : 0;
+  const float inv_d = 1.f / static_cast<float>(d);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  const F8 g8 = unpack8(*reinterpret_cast<const uint4*>(gamma + cc)), b8 = unpack8(*reinterpret_cast<const uint4*>(beta + cc));
+  F8 cb, dg, db, dc;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { cb.v[k] = 0.f; dg.v[k] = 0.f; db.v[k] = 0.f; dc.v[k] = 0.f; }
+  if (colb) cb = unpack8(*reinterpret_cast<const uint4*>(colb + cc));
+  const int64_t rows_per_iter = static_cast<int64_t>(gridDim.x) * kGroups;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + grp; row < n; row += rows_per_iter) {
+    const F8 xv = unpack8(*reinterpret_cast<const uint4*>(x + row * ldx + cc));
+    F8 gv = unpack8(*reinterpret_cast<const uint4*>(gy + row * ldg + cc));
+    const F8 rv = unpack8(res ? *reinterpret_cast<const uint4*>(res + row * ldr + cc) : make_uint4(0u, 0u, 0u, 0u));
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    if (p > 0.f) {
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        float k0, k1;
+        keep_scale2(seed, row * d + c0 + k, thr, inv_keep, k0, k1);
+        gv.v[k] *= k0; gv.v[k + 1] *= k1;
+      }
+    }
+    F8 xh, gh;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      xh.v[k] = active ? (xv.v[k] + rv.v[k] + cb.v[k] - mean) * rstd : 0.f;
+      if (!active) gv.v[k] = 0.f;
+      if (relu_out && !(fmaf(xh.v[k], g8.v[k], b8.v[k]) > 0.f)) gv.v[k] = 0.f;
+      dg.v[k] = fmaf(gv.v[k], xh.v[k], dg.v[k]);
+      db.v[k] += gv.v[k];
+      gh.v[k] = gv.v[k] * g8.v[k];
+      s1 += gh.v[k];
+      s2 = fmaf(gh.v[k], xh.v[k], s2);
+    }
+    s1 = group_sum<LPR>(s1) * inv_d;
+    s2 = group_sum<LPR>(s2) * inv_d;
+    if (active) {
+      F8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { o.v[k] = rstd * (gh.v[k] - s1 - xh.v[k] * s2); dc.v[k] += o.v[k]; }
+      *reinterpret_cast<uint4*>(gs + row * ldgs + c0) = pack8(o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[grp][0][c0 + k] = dg.v[k]; red[grp][1][c0 + k] = db.v[k]; red[grp][2][c0 + k] = dc.v[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * LPR * 8; i += kBlock) {
+    const int which = i / (LPR * 8), c = i % (LPR * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) s += red[g][which][c];
+    if (c < d) part[(static_cast<int64_t>(blockIdx.x) * 3 + which) * d + c] = s;
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -1543,6 +1684,59 @@ extern "C" int allset_ln_bwd_bf16(const void* gy, int64_t ldg, const void* x, in
 #define ALLSET_LNB_BWD(L) ln_bwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>(gg, ldg, xx, ldx, stats, gm, relu_in, p, seed, go, ldgx, partials, n, di, seed_base)
   switch (ln_bf16_lpr(d)) { case 8: ALLSET_LNB_BWD(8); break; case 16: ALLSET_LNB_BWD(16); break; case 32: ALLSET_LNB_BWD(32); break; default: ALLSET_LNB_BWD(64); break; }
 #undef ALLSET_LNB_BWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_res_fwd_bf16(const void* x, int64_t ldx, const void* colb, const void* res, int64_t ldr,
+                                      const void* gamma, const void* beta, float eps, int relu_out, float p, uint64_t seed,
+                                      void* y, int64_t ldy, float* stats, int64_t n, int64_t d, const uint64_t* seed_base,
+                                      void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_fwd_bf16: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_fwd_bf16: dropout p must be in [0,1)");
+  if (!allset_ln_bf16_supported(d)) { set_error("ln_res_fwd_bf16: width %lld not built (d %% 8 == 0, d <= 512)", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && gamma && beta && y && stats, "ln_res_fwd_bf16: null pointer");
+  ALLSET_REQUIRE(ldx >= d && ldy >= d && ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) &&
+                 aligned16(beta) && (colb == nullptr || aligned16(colb)) && (res == nullptr || (ldr >= d && ldr % 8 == 0 && aligned16(res))),
+                 "ln_res_fwd_bf16: rows and parameter vectors must be 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int di = static_cast<int>(d), lpr = ln_bf16_lpr(d);
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
+  const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
+  typedef const uint16_t* CP;
+#define ALLSET_LNRB_FWD(L) ln_res_fwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>((CP)x, ldx, (CP)colb, (CP)res, ldr, (CP)gamma, (CP)beta, eps, relu_out, p, seed, (uint16_t*)y, ldy, stats, n, di, seed_base)
+  switch (lpr) { case 8: ALLSET_LNRB_FWD(8); break; case 16: ALLSET_LNRB_FWD(16); break; case 32: ALLSET_LNRB_FWD(32); break; default: ALLSET_LNRB_FWD(64); break; }
+#undef ALLSET_LNRB_FWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_ln_res_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb,
+                                      const void* res, int64_t ldr, const float* stats, const void* gamma, const void* beta,
+                                      int relu_out, float p, uint64_t seed, void* gs, int64_t ldgs, float* partials,
+                                      int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_bwd_bf16: bad size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_bwd_bf16: dropout p must be in [0,1)");
+  if (!allset_ln_bf16_supported(d)) { set_error("ln_res_bwd_bf16: width %lld not built", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(partials != nullptr && n_partials >= 1, "ln_res_bwd_bf16: partials buffer required");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 3 * d * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && x && stats && gamma && beta && gs, "ln_res_bwd_bf16: null pointer");
+  ALLSET_REQUIRE(ldg >= d && ldx >= d && ldgs >= d && ldg % 8 == 0 && ldx % 8 == 0 && ldgs % 8 == 0 && aligned16(gy) && aligned16(x) &&
+                 aligned16(gs) && aligned16(gamma) && aligned16(beta) && (colb == nullptr || aligned16(colb)) &&
+                 (res == nullptr || (ldr >= d && ldr % 8 == 0 && aligned16(res))), "ln_res_bwd_bf16: rows must be 16-byte aligned");
+  const int di = static_cast<int>(d);
+  const unsigned grid = static_cast<unsigned>(n_partials);
+  typedef const uint16_t* CP;
+#define ALLSET_LNRB_BWD(L) ln_res_bwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>((CP)gy, ldg, (CP)x, ldx, (CP)colb, (CP)res, ldr, stats, (CP)gamma, (CP)beta, relu_out, p, seed, (uint16_t*)gs, ldgs, partials, n, di, seed_base)
+  switch (ln_bf16_lpr(d)) { case 8: ALLSET_LNRB_BWD(8); break; case 16: ALLSET_LNRB_BWD(16); break; case 32: ALLSET_LNRB_BWD(32); break; default: ALLSET_LNRB_BWD(64); break; }
+#undef ALLSET_LNRB_BWD
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -66,6 +66,12 @@ def _check_f32(*ts: Tensor) -> None:
             raise _lib.AllSetHipError(f"dense tail kernels are fp32 (got {t.dtype})")
 
 
+def _check_dtype(dtype: torch.dtype, *ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and t.dtype != dtype:
+            raise _lib.AllSetHipError(f"expected {dtype} throughout (got {t.dtype})")
+
+
 # ---- raw wrappers --------------------------------------------------------------------------------
 
 def reduce_partials(part: Tensor) -> Tensor:
@@ -412,46 +418,63 @@ def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor]
                                   float(p_out))
 
 
-def ln_res_supported(d: int) -> bool:
-    return bool(_lib.load().allset_ln_res_supported(d))
+def ln_res_supported(d: int, dtype: torch.dtype = torch.float32) -> bool:
+    if dtype == torch.bfloat16:
+        return bool(_lib.load().allset_ln_bf16_supported(d))
+    return dtype == torch.float32 and bool(_lib.load().allset_ln_res_supported(d))
 
 
 def ln_res_fwd(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
                relu_out: bool, p: float, seed: int, seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """fp32, or bf16 activations and parameters (fp32 arithmetic and stats)."""
     dev = require_device(x, colb, res, gamma, beta)
-    _check_f32(x, colb, res, gamma, beta)
+    bf16 = x.dtype == torch.bfloat16
+    if bf16:
+        _check_dtype(torch.bfloat16, x, colb, res, gamma, beta)
+    else:
+        _check_f32(x, colb, res, gamma, beta)
     x = _rowmajor(x)
     res = _rowmajor(res) if res is not None else None
     n, d = x.shape
-    y = torch.empty((n, d), dtype=torch.float32, device=dev)
+    y = torch.empty((n, d), dtype=x.dtype, device=dev)
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("ln_res_fwd", dev, (2 + (res is not None)) * n * d * 4):
-        check(_lib.load().allset_ln_res_fwd(
-            ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res), _ld(res) if res is not None else 0,
-            ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(relu_out), p, seed, ptr(y), max(d, 1), ptr(stats), n, d,
-            ptr(seed_base), stream_of(dev)), "allset_ln_res_fwd")
+    lib = _lib.load()
+    fn, name = (lib.allset_ln_res_fwd_bf16, "allset_ln_res_fwd_bf16") if bf16 else (lib.allset_ln_res_fwd, "allset_ln_res_fwd")
+    with torch.cuda.device(dev), _timed("ln_res_fwd", dev, (2 + (res is not None)) * n * d * x.element_size()):
+        check(fn(ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res), _ld(res) if res is not None else 0,
+                 ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(relu_out), p, seed, ptr(y), max(d, 1), ptr(stats), n, d,
+                 ptr(seed_base), stream_of(dev)), name)
     return y, stats
 
 
 def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], stats: Tensor, gamma: Tensor,
                beta: Tensor, relu_out: bool, p: float, seed: int, seed_base: Optional[Tensor] = None
                ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """(gs, dgamma, dbeta, dcolb); gs is the gradient of x and of res."""
+    """(gs, dgamma, dbeta, dcolb); gs is the gradient of x and of res.  bf16 activations: the three parameter
+    gradients are accumulated in fp32 and cast back."""
     dev = require_device(gy, x, colb, res, stats, gamma, beta)
+    bf16 = x.dtype == torch.bfloat16
+    if bf16:
+        _check_dtype(torch.bfloat16, gy, x, colb, res, gamma, beta)
     gy, x = _rowmajor(gy), _rowmajor(x)
     res = _rowmajor(res) if res is not None else None
     n, d = x.shape
     lib = _lib.load()
     npart = c_int64(0)
-    check(lib.allset_ln_res_bwd_partials(n, d, byref(npart)), "allset_ln_res_bwd_partials")
+    if bf16:
+        check(lib.allset_ln_bwd_bf16_partials(n, d, byref(npart)), "allset_ln_bwd_bf16_partials")
+    else:
+        check(lib.allset_ln_res_bwd_partials(n, d, byref(npart)), "allset_ln_res_bwd_partials")
     partials = torch.empty((npart.value, 3, d), dtype=torch.float32, device=dev)
-    gs = torch.empty((n, d), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, (3 + (res is not None)) * n * d * 4):
-        check(lib.allset_ln_res_bwd(
-            ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res),
-            _ld(res) if res is not None else 0, ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), int(relu_out), p,
-            seed, ptr(gs), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base), stream_of(dev)), "allset_ln_res_bwd")
+    gs = torch.empty((n, d), dtype=x.dtype, device=dev)
+    fn, name = (lib.allset_ln_res_bwd_bf16, "allset_ln_res_bwd_bf16") if bf16 else (lib.allset_ln_res_bwd, "allset_ln_res_bwd")
+    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, (3 + (res is not None)) * n * d * x.element_size()):
+        check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res),
+                 _ld(res) if res is not None else 0, ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), int(relu_out), p,
+                 seed, ptr(gs), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base), stream_of(dev)), name)
     red = reduce_partials(partials)
+    if bf16:
+        red = red.to(torch.bfloat16)
     return gs, red[0], red[1], red[2]
 
 

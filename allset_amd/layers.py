@@ -226,7 +226,8 @@ class PMA(nn.Module):
         """``+att_r -> ln0 -> ln1(z + relu(rFF(z)))`` (reference layers.py:153-157) on pooled [n_t, H*C].
         ``_post`` (internal): also the ``relu -> dropout(p)`` SetGNN wraps around the conv, in ln1's pass."""
         H, C = self.heads, self.hidden
-        if _on_hip(pooled) and dense.ln_res_supported(H * C) and self.ln0.bias is not None and self.ln1.bias is not None:
+        hip = _on_hip(pooled) or (pooled.is_cuda and pooled.dtype == torch.bfloat16 and self.ln0.weight.dtype == torch.bfloat16)
+        if hip and dense.ln_res_supported(H * C, pooled.dtype) and self.ln0.bias is not None and self.ln1.bias is not None:
             # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
             out = dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
             ff = self.rFF

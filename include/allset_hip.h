@@ -259,6 +259,16 @@ int allset_ln_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, 
                        int relu_in, float p, uint64_t seed, void* gx, int64_t ldgx, float* partials, int64_t n_partials,
                        int64_t n, int64_t d, const uint64_t* seed_base, void* stream);
 
+/* allset_ln_res_fwd / _bwd (below) for bf16 activations and parameters: same semantics, fp32 arithmetic, fp32 stats and
+ * partials (n_partials from allset_ln_bwd_bf16_partials, 3 rows of d per block).  Widths: allset_ln_bf16_supported(d). */
+int allset_ln_res_fwd_bf16(const void* x, int64_t ldx, const void* colb, const void* res, int64_t ldr, const void* gamma,
+                           const void* beta, float eps, int relu_out, float p, uint64_t seed, void* y, int64_t ldy,
+                           float* stats, int64_t n, int64_t d, const uint64_t* seed_base, void* stream);
+int allset_ln_res_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb, const void* res,
+                           int64_t ldr, const float* stats, const void* gamma, const void* beta, int relu_out, float p,
+                           uint64_t seed, void* gs, int64_t ldgs, float* partials, int64_t n_partials, int64_t n, int64_t d,
+                           const uint64_t* seed_base, void* stream);
+
 /* LayerNorm with a fused sum in front and a relu behind -- the PMA tail (reference layers.py:153-157) and the
  * relu -> dropout SetGNN puts behind every conv (models.py:475-481):
  *   y = dropout_{p,seed}( relu_out ? relu(.) : . )( LayerNorm_{gamma,beta,eps}( x + colb + res ) )

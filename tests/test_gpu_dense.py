@@ -515,3 +515,46 @@ def test_layer_norm_bf16_fwd_bwd(n, d, relu_in, device):
     torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=2e-2, atol=2e-2 * max(1.0, float(xr.grad.abs().max())))
     for a, r in ((gg.grad, gr.grad), (bg.grad, br.grad)):
         torch.testing.assert_close(a.cpu().double(), r, rtol=2e-2, atol=2e-2 * max(1.0, float(r.abs().max())))
+
+
+@pytest.mark.parametrize("n,d", [(1000, 256), (37, 128), (4099, 64), (513, 512), (200, 8)])
+@pytest.mark.parametrize("with_colb,with_res,relu_out,p", [(True, False, False, 0.0), (False, True, True, 0.0),
+                                                            (True, True, True, 0.3), (False, False, False, 0.0)])
+def test_layer_norm_res_bf16_fwd_bwd(n, d, with_colb, with_res, relu_out, p, device):
+    """``dropout(relu_out(LN(x + colb + res)))`` for bf16 activations against float64 torch on the same bf16 values;
+    the dropout mask is read off the output (kept entries are non-zero except on the relu boundary)."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n * 3 + d)
+    x = torch.randn(n, d, generator=g).to(torch.bfloat16)
+    colb = (0.5 * torch.randn(d, generator=g)).to(torch.bfloat16) if with_colb else None
+    res = torch.randn(n, d, generator=g).to(torch.bfloat16) if with_res else None
+    gamma = (1 + 0.2 * torch.randn(d, generator=g)).to(torch.bfloat16)
+    beta = (0.3 * torch.randn(d, generator=g)).to(torch.bfloat16)
+    G = torch.randn(n, d, generator=g).to(torch.bfloat16)
+    dv = lambda t: None if t is None else t.to(device).requires_grad_(True)
+    xg, cg, rg, gg, bg = dv(x), dv(colb), dv(res), dv(gamma), dv(beta)
+    out = dense.layer_norm_res(xg, cg, rg, gg, bg, 1e-5, relu_out, p)
+    assert out.dtype == torch.bfloat16 and out.shape == (n, d)
+
+    dd = lambda t: None if t is None else t.double().requires_grad_(True)
+    xr, cr, rr, gr, br = dd(x), dd(colb), dd(res), dd(gamma), dd(beta)
+    s = xr + (cr if cr is not None else 0.0) + (rr if rr is not None else 0.0)
+    ref = F.layer_norm(s, (d,), gr, br, 1e-5)
+    if relu_out:
+        ref = F.relu(ref)
+    if p > 0.0:
+        kept = out.detach().cpu() != 0
+        unsure = ref.detach().abs() <= 1e-2          # a zero there is not mask evidence: take them out of the gradient
+        G = torch.where(unsure, torch.zeros_like(G), G)
+        ref = ref * (kept | unsure).double() / (1 - p)
+        assert abs(float(kept.float().mean()) - (1 - p) * (0.5 if relu_out else 1.0)) < 0.05
+    (out * G.to(device)).sum().backward()
+    (ref * G.double()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1.5e-2, atol=1.5e-2)
+    gmax = max(1.0, float(xr.grad.abs().max()))
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=2e-2, atol=2e-2 * gmax)
+    if with_res:
+        torch.testing.assert_close(rg.grad.cpu().double(), rr.grad, rtol=2e-2, atol=2e-2 * gmax)
+    pairs = [(gg.grad, gr.grad), (bg.grad, br.grad)] + ([(cg.grad, cr.grad)] if with_colb else [])
+    for a, r in pairs:
+        torch.testing.assert_close(a.cpu().double(), r, rtol=2e-2, atol=2e-2 * max(1.0, float(r.abs().max())))
