@@ -403,6 +403,193 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     return p.tail(o, _post=dropout if training else 0.0)
 
 
+# ---------------------------------------------------------------------------------------------
+# column-sharded aggregation: the exchange volume that does not grow with the number of ranks
+# ---------------------------------------------------------------------------------------------
+#
+# The hyperedge-sharded layer above moves the whole [n_V, d] table through every rank on every exchange
+# ((P-1)/P * n_V * d elements in, per rank): on a hypergraph without locality -- every vertex a boundary vertex,
+# SURVEY section 7 -- that volume grows linearly with P under weak scaling and dominates the step beyond 2 ranks
+# (DESIGN.md section 7).  The aggregation is independent per feature column, so the same layer can be cut the other
+# way: every rank holds the FULL incidence (a few bytes per incidence; trivial next to 288 GB) and d/P of the
+# columns of every row.  Dense work stays row-sharded (owner computes n/P rows, full d); around each aggregation the
+# activations change layout with one all-to-all,
+#       [n/P, d] (my rows, all columns)  <->  [n, d/P] (all rows, my columns),
+# which sends n/P * d/P elements to each peer: (P-1)/P * n/P * d per rank, 1/P of the all-gather's volume, and
+# constant per rank under weak scaling.  Every target row is complete on every rank, so max / min / mean and PMA's
+# segment softmax need no cross-rank merge: the ordinary differentiable local aggregates run on the column slice
+# (PMA: whole heads per rank while P <= H, a fraction of one head beyond -- the logits of that head are sent along).
+# Work per rank is identical by construction, so power-law hyperedge sizes (configs[4]) need no bin packing.
+# The price: gathers of d/P-wide rows; below 32 fp32 columns (128 B) a gathered row is less than a cache line and the
+# gather kernels lose efficiency (measured: profiles/r01_colshard_kernels.txt).
+
+def _rows_to_cols(x: Tensor, group=None) -> Tensor:
+    """[n/P, d] -> [n, d/P]: rank r ends with columns [r*d/P, (r+1)*d/P) of every rank's rows, in rank order."""
+    if _skip_collective(group):
+        return x
+    w = _world(group)
+    r, d = x.shape
+    if d % w:
+        raise ValueError(f"column sharding needs the width ({d}) to be a multiple of the world size ({w})")
+    send = x.view(r, w, d // w).permute(1, 0, 2).contiguous()              # [P, n/P, d/P]: chunk j goes to rank j
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.view(w * r, d // w)                                        # chunk i = rank i's rows: already row-major
+
+
+def _cols_to_rows(x: Tensor, group=None) -> Tensor:
+    """[n, d/P] -> [n/P, d]: the inverse layout change."""
+    if _skip_collective(group):
+        return x
+    w = _world(group)
+    n, dc = x.shape
+    if n % w:
+        raise ValueError(f"column sharding needs the (padded) row count ({n}) to be a multiple of the world size ({w})")
+    send = x.contiguous()                                                  # rows of block j (my columns) go to rank j
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.view(w, n // w, dc).permute(1, 0, 2).reshape(n // w, w * dc)
+
+
+class _RowsToCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return _rows_to_cols(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _cols_to_rows(g, ctx.group), None
+
+
+class _ColsToRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return _cols_to_rows(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rows_to_cols(g, ctx.group), None
+
+
+def rows_to_cols(x: Tensor, group=None) -> Tensor:
+    """Owned rows, all columns -> all rows, owned columns (one all-to-all); backward = :func:`cols_to_rows`."""
+    return _RowsToCols.apply(x, group)
+
+
+def cols_to_rows(x: Tensor, group=None) -> Tensor:
+    """All rows, owned columns -> owned rows, all columns (one all-to-all); backward = :func:`rows_to_cols`."""
+    return _ColsToRows.apply(x, group)
+
+
+class ColumnShardedHypergraph:
+    """One rank's view for column-sharded aggregation: the FULL incidence (``edge_index`` int64 [2, nnz], row 0 global
+    vertex ids, row 1 global 0-based hyperedge ids; identical on every rank) plus the row blocks this rank owns for the
+    dense work -- vertices ``v_lo:v_hi`` of the padded vertex range, hyperedges ``e_lo:e_hi`` of the padded hyperedge
+    range.  ``norm``: per-incidence weights in ``edge_index`` order, or None."""
+
+    def __init__(self, edge_index: Tensor, n_v: int, n_e: int, world: int, rank: int, norm: Optional[Tensor] = None):
+        self.edge_index = edge_index
+        self.n_v, self.n_e, self.world, self.rank = int(n_v), int(n_e), int(world), int(rank)
+        self.v_lo, self.v_hi, self.n_v_pad = vertex_block(n_v, world, rank)
+        self.e_lo, self.e_hi, self.n_e_pad = vertex_block(n_e, world, rank)
+        self.norm = norm
+        self.v2e = None
+        self.e2v = None
+
+    def build_incidences(self) -> "ColumnShardedHypergraph":
+        from .incidence import Incidence
+        self.v2e = Incidence.from_edge_index(self.edge_index, n_src=self.n_v_pad, n_dst=self.n_e_pad)
+        self.e2v = self.v2e.reversed(n_dst=self.n_v_pad)
+        return self
+
+
+def head_slots(heads: int, world: int) -> Tuple[int, list]:
+    """How PMA's heads fall on the column slices.  Returns (heads per rank, for every rank in order the global head
+    ids of its slice).  P <= H: H/P whole heads per rank; P > H: P/H ranks share one head, each holding C*H/P of its
+    columns (the softmax statistics of that head are then computed on each of them -- they only need the logits)."""
+    if heads % world == 0:
+        hl = heads // world
+        return hl, [r * hl + j for r in range(world) for j in range(hl)]
+    if world % heads == 0:
+        per = world // heads
+        return 1, [r // per for r in range(world)]
+    raise ValueError(f"column sharding of PMA needs heads ({heads}) and world size ({world}) to divide one another")
+
+
+def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, aggr: str = "add",
+                              dropout: float = 0.0, training: bool = False, group=None,
+                              aggregate: Callable = _hip_deepsets) -> Tensor:
+    """The layer of :func:`sharded_deepsets_layer` with column-sharded aggregation: four all-to-alls, no reduction
+    across ranks; every ``aggr`` of the reference (layers.py:641-656) is the plain local one on the column slice."""
+    if aggr not in ("add", "sum", "mean", "max", "min"):
+        raise ValueError(f"aggr {aggr!r}")
+    h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)               # [n_V/P, d]
+    e = cols_to_rows(aggregate(rows_to_cols(h, group), hg.v2e, hg.norm, aggr), group)      # [n_E/P, d]
+    e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)
+    g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
+    v = cols_to_rows(aggregate(rows_to_cols(g, group), hg.e2v, hg.norm, aggr), group)      # [n_V/P, d]
+    return e2v_conv._mlp_act(e2v_conv.f_dec, v, dropout)
+
+
+def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, dropout: float = 0.0,
+                         training: bool = False, group=None, kernels=HipPmaKernels) -> Tensor:
+    """The layer of :func:`sharded_pma_layer` with column-sharded pooling: per direction one all-to-all of the values,
+    one of the (few) logit columns each slice needs, the ordinary local fused pooling, one all-to-all back."""
+    w = 1 if _skip_collective(group) else _world(group)
+
+    def pool(p, t, inc):
+        H = p.heads
+        V, alpha = p.project(t)                                                    # [n/P, H*C], [n/P, H]: dense, owned rows
+        hl, slots = head_slots(H, w)
+        if slots != list(range(H)):
+            alpha = alpha[:, torch.tensor(slots, device=alpha.device)]             # a shared head's logits go to each sharer
+        o = kernels.aggregate(rows_to_cols(V, group).contiguous(), rows_to_cols(alpha.contiguous(), group).contiguous(),
+                              inc, hl, p.negative_slope)
+        return p.tail(cols_to_rows(o, group), _post=dropout if training else 0.0)
+
+    e = pool(v2e_conv.prop, x_owned, hg.v2e)
+    return pool(e2v_conv.prop, e, hg.e2v)
+
+
+def exchange_bytes_per_rank(mode: str, world: int, n_v: int, n_e: int, d: int, elem: int = 4) -> int:
+    """Bytes one rank RECEIVES per V->E->V layer, forward + backward (the dense case: every vertex a boundary vertex).
+    ``rows`` (hyperedge shards): all-gather + reduce-scatter of [n_V, d] each way; ``columns``: four all-to-alls each
+    way over [n_V, d] and [n_E, d] slices."""
+    if world <= 1:
+        return 0
+    f = (world - 1) / world
+    if mode == "rows":
+        return int(4 * f * n_v * d * elem)
+    if mode == "columns":
+        return int(4 * f * (n_v + n_e) / world * d * elem)
+    raise ValueError(mode)
+
+
+def choose_sharding(world: int, d: int, heads: Optional[int] = None, elem: int = 4) -> str:
+    """``"rows"`` or ``"columns"`` for a hypergraph WITHOUT locality (the synthetic benchmarks; every vertex a boundary
+    vertex).  Per link and step the row scheme moves 4*n_loc*d*elem bytes whatever P is, the column scheme 8/P of
+    that: equal at P = 2, half at P = 4, a quarter at P = 8; the column scheme pays for it with d/P-wide gathers
+    (no loss down to 128-byte rows, ~2.3x slower aggregation at 64-byte rows: profiles/r01_colshard_kernels.txt) and
+    two layout copies per exchange.  With the measured per-rank compute (profiles/r01_sim_rank.txt) the column scheme
+    wins from P = 4 on; at P = 2 the two tie and the row scheme (no repacking) is kept.  A hypergraph whose
+    partitions have few boundary vertices wants the row scheme regardless -- pass the mode explicitly there."""
+    if world < 4 or d % world:
+        return "rows"
+    dc = d // world
+    if dc * elem < 64 or dc % (16 // elem):            # below one 64-byte sector / not 16-byte packets: gather kernels degrade
+        return "rows"
+    if heads is not None:
+        try:
+            hl, _ = head_slots(heads, world)
+        except ValueError:
+            return "rows"
+        if dc % hl or (dc // hl) % (16 // elem):
+            return "rows"
+    return "columns"
+
+
 class ShardedSetGNN(torch.nn.Module):
     """A :class:`allset_amd.SetGNN` executed on a hyperedge shard (reference models.py:450-484, non-GPR branch).
 
@@ -411,7 +598,7 @@ class ShardedSetGNN(torch.nn.Module):
     it with its own block; replicated-parameter gradients are summed with :func:`allreduce_grads` after backward.
     """
 
-    def __init__(self, model, hg: ShardedHypergraph, group=None, aggregate: Callable = _hip_deepsets, kernels=HipPmaKernels):
+    def __init__(self, model, hg, group=None, aggregate: Callable = _hip_deepsets, kernels=HipPmaKernels):
         super().__init__()
         if getattr(model, "GPR", False) or getattr(model, "LearnMask", False):
             raise NotImplementedError("sharded execution covers the stock AllSetTransformer / AllDeepSets (no GPR / LearnMask)")
@@ -422,12 +609,14 @@ class ShardedSetGNN(torch.nn.Module):
         m = self.model
         x = F.dropout(x_owned, p=0.2, training=m.training)                 # hard-coded input dropout (models.py:473)
         for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):
+            cols = isinstance(self.hg, ColumnShardedHypergraph)
             if v2e.attention:
-                x = sharded_pma_layer(v2e, e2v, x, self.hg, dropout=m.dropout, training=m.training, group=self.group,
-                                      kernels=self._kernels)
+                layer = colsharded_pma_layer if cols else sharded_pma_layer
+                x = layer(v2e, e2v, x, self.hg, dropout=m.dropout, training=m.training, group=self.group, kernels=self._kernels)
             else:
-                x = sharded_deepsets_layer(v2e, e2v, x, self.hg, aggr=m.aggr, dropout=m.dropout, training=m.training,
-                                           group=self.group, aggregate=self._aggregate)
+                layer = colsharded_deepsets_layer if cols else sharded_deepsets_layer
+                x = layer(v2e, e2v, x, self.hg, aggr=m.aggr, dropout=m.dropout, training=m.training, group=self.group,
+                          aggregate=self._aggregate)
         return m.classifier(x)
 
     def allreduce_grads(self) -> None:

@@ -28,7 +28,13 @@ def _variant(csr, kind: str, n_rows: int, x: Tensor, heads: int = 1) -> int:
     d = x.shape[1]
     ok = (d % wide == 0 and d <= 64 * wide and x.stride(0) % wide == 0 and x.data_ptr() % 16 == 0
           and (d // max(heads, 1)) % wide == 0)
-    return csr.variant(kind, n_rows) if ok else 1
+    if not ok:
+        return 1
+    if d * es <= 128 and csr.max_deg <= 512:
+        # rows of at most one cache line (the column-sharded layer, dist.py): a wavefront per row leaves most lanes
+        # idle; the short-row kernel packs 64 / (d / wide) rows into each (profiles/r01_colshard_kernels.txt)
+        return 2
+    return csr.variant(kind, n_rows)
 
 
 def _split(csr, x: Tensor, heads: int = 1) -> int:

@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: BASELINE configs[4] regime -- bf16 tensors end to end, bf16 instantiations of the gather kernels "
                          "(fp32 accumulation / softmax statistics), dense tail through torch's bf16 modules")
+    ap.add_argument("--shard", default="auto", choices=["auto", "rows", "columns"],
+                    help="N > 1: 'rows' = hyperedge shards with all-gather / reduce-scatter of the vertex table; 'columns' = "
+                         "column-sharded aggregation with all-to-all layout changes (1/N of the exchange volume); 'auto' = "
+                         "allset_amd.dist.choose_sharding (DESIGN.md section 7)")
     ap.add_argument("--self-loops", action="store_true",
                     help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
@@ -157,6 +161,9 @@ def main():
 
     d, n_loc = args.d, args.n_per_gpu
     n_v = n_loc * world                                               # weak scaling: global vertex range grows with N
+    mode = args.shard if args.shard != "auto" else adist.choose_sharding(world, d, args.heads if args.model == "pma" else None)
+    if mode == "columns" and world == 1:
+        mode = "rows"                                                  # one rank: the two layouts coincide
     shard = random_hypergraph(n_v, n_loc, args.degree, seed=args.seed + 1 + rank, device=dev, dist=args.degree_dist)
     n_e_loc = n_loc
     if args.self_loops:
@@ -167,8 +174,19 @@ def main():
         ei = ei[:, torch.argsort(ei[0], stable=True)].contiguous()
         shard.edge_index, shard.nnz, n_e_loc = ei, int(ei.shape[1]), n_loc + n_v
         shard.norm = torch.ones(shard.nnz, dtype=torch.int64, device=dev)
-    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_e_loc, world, rank, norm=shard.norm).build_incidences()
-    nnz_local = shard.nnz
+    if mode == "columns":
+        # every rank holds the whole incidence: the same P blocks of hyperedges the row mode deals out one per rank
+        blocks = [shard if r == rank else random_hypergraph(n_v, n_loc, args.degree, seed=args.seed + 1 + r, device=dev,
+                                                            dist=args.degree_dist) for r in range(world)]
+        ei = torch.cat([torch.stack([b.edge_index[0], b.edge_index[1] + r * n_loc]) for r, b in enumerate(blocks)], dim=1)
+        nnz_global = int(ei.shape[1])
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, rank,
+                                           norm=torch.cat([b.norm for b in blocks])).build_incidences()
+        del blocks, ei
+        nnz_local = nnz_global / world                   # each rank aggregates every incidence over d/N of the columns
+    else:
+        hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_e_loc, world, rank, norm=shard.norm).build_incidences()
+        nnz_local = shard.nnz
 
     torch.manual_seed(args.seed)                                       # identical replicated weights on every rank
     attn = args.model == "pma"
@@ -190,7 +208,10 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         x.grad = None
-        if attn:
+        if mode == "columns":
+            out = (adist.colsharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True) if attn else
+                   adist.colsharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True))
+        elif attn:
             out = adist.sharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True)
         else:
             out = adist.sharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True)
@@ -264,7 +285,8 @@ def main():
                                     f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), ") +
                                    f"fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
                        "n_v": n_v, "n_e": n_e_loc * world, "nnz": int(nnz_total), "d": d,
-                       "parallelism": f"hyperedge-shard x{world}" if world > 1 else "single GPU", "seed": args.seed},
+                       "parallelism": ("single GPU" if world == 1 else f"hyperedge-shard x{world}" if mode == "rows"
+                                       else f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation)"), "seed": args.seed},
             "roofline": roofline,
             "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if world == 1 else None,
                             "unit": "edges*d/s", "note": "gather/segment-reduce kernel time per step (HIP events, rank 0): "

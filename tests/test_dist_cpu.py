@@ -363,3 +363,125 @@ def test_sharded_max_merge_picks_one_winner():
     win0 = np.array([[1, 1, 1], [0, 0, 0], [0, 1, 0], [1, 1, 1], [0, 0, 0], [0, 1, 1]], dtype=bool)     # ties -> rank 0
     win1 = np.array([[0, 0, 0], [1, 1, 1], [1, 0, 1], [0, 0, 0], [0, 0, 0], [1, 0, 0]], dtype=bool)
     assert np.array_equal(g0, np.where(win0, G, 0)) and np.array_equal(g1, np.where(win1, G, 0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# column-sharded aggregation: full incidence on every rank, d/P columns each, all-to-all layout changes
+# ---------------------------------------------------------------------------------------------------------------
+
+def _col_worker(rank, world, port, kind, arg, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
+        n_v, n_e, d, ei, norm, x, G = _problem(world)
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm if kind == "ds" else None)
+        hg.v2e = (ei, hg.n_e_pad)
+        hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+        Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - n_v, d)])
+        xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
+        if kind == "ds":
+            a, b = _convs(d)
+            out = adist.colsharded_deepsets_layer(a, b, xo, hg, aggr=arg, aggregate=_oracle_aggregate)
+        else:
+            a, b = _pma_convs(d, arg)
+            out = adist.colsharded_pma_layer(a, b, xo, hg, kernels=TorchPmaKernels)
+        (out * Gp[hg.v_lo:hg.v_hi]).sum().backward()
+        params = list(a.parameters()) + list(b.parameters())
+        adist.allreduce_grads(params)
+        q.put((rank, out.detach().numpy().copy(), xo.grad.numpy().copy(), [p.grad.numpy().copy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_col(kind, arg):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_col_worker, args=(r, world, port, kind, arg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("aggr", ["add", "mean", "max", "min"])
+def test_colsharded_deepsets_layer_equals_unsharded(aggr):
+    import torch.nn.functional as F
+    results = _run_col("ds", aggr)
+    n_v, n_e, d, ei, norm, x, G = _problem(2)
+    a, b = _convs(d)
+    xr = x.clone().requires_grad_(True)
+    h = F.relu(a.f_enc(xr))
+    e = F.relu(a.f_dec(_oracle_aggregate(h, (ei, n_e), norm, aggr)))
+    g = F.relu(b.f_enc(e))
+    v = F.relu(b.f_dec(_oracle_aggregate(g, (torch.stack([ei[1], ei[0]]), n_v), norm, aggr)))
+    (v * G).sum().backward()
+    ref_pg = [p.grad for p in list(a.parameters()) + list(b.parameters())]
+    out = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    gx = torch.cat([torch.from_numpy(r[2]) for r in results])[:n_v]
+    torch.testing.assert_close(out, v.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, xr.grad, rtol=1e-5, atol=1e-5)
+    # padded hyperedge rows (beyond n_e) run through the dense tail with zero cotangent AND are never gathered: their
+    # contribution to parameter gradients is exactly zero
+    for got, exp in zip(results[0][3], ref_pg):
+        torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=1e-5)
+    for got, got1 in zip(results[0][3], results[1][3]):
+        np.testing.assert_array_equal(got, got1)
+
+
+@pytest.mark.parametrize("H", [4, 1])        # 4: two whole heads per rank; 1: the two ranks share the one head
+def test_colsharded_pma_layer_equals_unsharded(H):
+    import torch.nn.functional as F
+    results = _run_col("pma", H)
+    n_v, n_e, d, ei, _, x, G = _problem(2)
+    a, b = _pma_convs(d, H)
+
+    def pma_module(p, xin, e_idx, n_dst):
+        C = p.hidden
+        o = TorchPmaKernels.aggregate(p.lin_V(xin), p._logits(xin), (e_idx, n_dst), H, 0.2)
+        o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
+        o = p.ln0(o)
+        return p.ln1(o + F.relu(p.rFF(o)))
+
+    xr = x.clone().requires_grad_(True)
+    e = F.relu(pma_module(a.prop, xr, ei, n_e))
+    v = F.relu(pma_module(b.prop, e, torch.stack([ei[1], ei[0]]), n_v))
+    (v * G).sum().backward()
+    ref_pg = [p.grad for p in list(a.parameters()) + list(b.parameters())]
+    out = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    gx = torch.cat([torch.from_numpy(r[2]) for r in results])[:n_v]
+    torch.testing.assert_close(out, v.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=1e-5)
+    for got, exp in zip(results[0][3], ref_pg):
+        torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=2e-5)
+
+
+def test_head_slots_and_exchange_volume():
+    from allset_amd import dist as adist
+    assert adist.head_slots(4, 2) == (2, [0, 1, 2, 3])
+    assert adist.head_slots(4, 4) == (1, [0, 1, 2, 3])
+    assert adist.head_slots(4, 8) == (1, [0, 0, 1, 1, 2, 2, 3, 3])
+    assert adist.head_slots(1, 2) == (1, [0, 0])
+    with pytest.raises(ValueError):
+        adist.head_slots(4, 3)
+    n, d = 8_000_000, 128
+    rows = adist.exchange_bytes_per_rank("rows", 8, n, n, d)
+    cols = adist.exchange_bytes_per_rank("columns", 8, n, n, d)
+    assert rows == 4 * cols                              # (n_V + n_E) / P vs n_V with n_E == n_V, P = 8
+    assert adist.exchange_bytes_per_rank("columns", 2, n, n, d) == adist.exchange_bytes_per_rank("rows", 2, n, n, d)
+    assert adist.exchange_bytes_per_rank("rows", 1, n, n, d) == 0
+
+
+def test_choose_sharding():
+    from allset_amd import dist as adist
+    assert adist.choose_sharding(1, 128) == "rows" and adist.choose_sharding(2, 128) == "rows"
+    assert adist.choose_sharding(4, 128) == "columns" and adist.choose_sharding(8, 128) == "columns"
+    assert adist.choose_sharding(8, 128, heads=4) == "columns" and adist.choose_sharding(8, 256, heads=4, elem=2) == "columns"
+    assert adist.choose_sharding(8, 64) == "rows"            # 8 fp32 columns = 32-byte rows
+    assert adist.choose_sharding(8, 100) == "rows" and adist.choose_sharding(4, 128, heads=3) == "rows"

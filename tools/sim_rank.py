@@ -2,7 +2,13 @@
 """Per-rank COMPUTE time of an N-rank weak-scaling step, measured on one GPU: rank 0's shard of the N-rank job
 (N*1M vertices, 1M local hyperedges) with the two collectives replaced by local stand-ins of identical shapes
 (all-gather -> tile the owned block N times, reduce-scatter -> keep the owned slice).  What is left out is exactly the
-xGMI time; the output bounds the scaling the driver can measure:  efficiency <= t(1) / (t_compute(N) + t_comm(N))."""
+xGMI time; the output bounds the scaling the driver can measure:  efficiency <= t(1) / (t_compute(N) + t_comm(N)).
+
+usage: sim_rank.py [deepsets|pma] [rows|columns]
+``columns``: the column-sharded layer (full incidence on the rank, d/N columns); the all-to-alls are replaced by their
+own pack / unpack copies, which produce tensors of exactly the exchanged shapes.
+The xGMI estimate printed beside it is per LINK: every pair of GPUs is joined by one link (~77 GB/s per direction peak,
+60 GB/s assumed achievable), and both schemes load all N-1 links of a rank evenly."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,14 +18,29 @@ from allset_amd.synthetic import random_hypergraph
 dev = torch.device("cuda:0")
 d, n_loc = 128, 1_000_000
 model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
+mode = sys.argv[2] if len(sys.argv) > 2 else "rows"
+LINK = 60e9
 for world in (1, 2, 4, 8):
+    adist._rows_to_cols = (lambda x, group=None, w=world: x if w == 1 else
+                           x.view(x.shape[0], w, x.shape[1] // w).permute(1, 0, 2).contiguous().view(w * x.shape[0], x.shape[1] // w))
+    adist._cols_to_rows = (lambda x, group=None, w=world: x if w == 1 else
+                           x.view(w, x.shape[0] // w, x.shape[1]).permute(1, 0, 2).reshape(x.shape[0] // w, w * x.shape[1]))
     adist._all_gather_rows = (lambda x, group=None, w=world: x if w == 1 else x.repeat((w,) + (1,) * (x.dim() - 1)))
     adist._reduce_scatter_rows = (lambda x, group=None, w=world: x if w == 1 else x[: x.shape[0] // w].contiguous())
+    adist._world = lambda group=None, w=world: w
     adist._skip_collective = lambda group=None, w=world: w == 1      # world > 1: take the real merge paths ...
     adist.dist.all_reduce = lambda *a, **k: None                      # ... with the small max-all-reduce stubbed out
     n_v = n_loc * world
-    shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev)
-    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm).build_incidences()
+    if mode == "columns":
+        blocks = [random_hypergraph(n_v, n_loc, 16, seed=5 + r, device=dev, e_offset=r * n_loc) for r in range(world)]
+        ei = torch.cat([b.edge_index for b in blocks], dim=1)
+        shard = blocks[0]
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, 0,
+                                           norm=torch.cat([b.norm for b in blocks])).build_incidences()
+        del blocks, ei
+    else:
+        shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev)
+        hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm).build_incidences()
     attn = model == "pma"
     torch.manual_seed(0)
     a = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).train()
@@ -30,15 +51,24 @@ for world in (1, 2, 4, 8):
     G = torch.randn(n_loc, d, device=dev)
     def step():
         opt.zero_grad(set_to_none=True); x.grad = None
-        out = adist.sharded_pma_layer(a, b, x, hg, dropout=0.5, training=True) if attn else \
-            adist.sharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
+        if mode == "columns":
+            out = adist.colsharded_pma_layer(a, b, x, hg, dropout=0.5, training=True) if attn else \
+                adist.colsharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
+        else:
+            out = adist.sharded_pma_layer(a, b, x, hg, dropout=0.5, training=True) if attn else \
+                adist.sharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
         out.backward(G); opt.step()
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
-    exch = n_v * d * 4 * (world - 1) / world            # bytes a rank receives per collective
-    print(f"{model} world={world}: per-rank compute {ms:7.2f} ms   exchange per collective {exch/1e9:5.2f} GB x4 per step"
-          f"   (at 400 GB/s inbound: {4*exch/400e9*1e3:6.1f} ms)", flush=True)
+    if world == 1:
+        t1 = ms
+    per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d)     # received per step (fwd + bwd)
+    per_link = per_rank / max(world - 1, 1)
+    comm = per_link / LINK * 1e3
+    print(f"{model} {mode} world={world}: per-rank compute {ms:7.2f} ms   exchange {per_rank/1e9:5.2f} GB per rank and step, "
+          f"{per_link/1e9:4.2f} GB per link -> {comm:5.1f} ms at 60 GB/s   speed-up if serial {world*t1/(ms+comm) if world > 1 else 1.0:4.2f}x, "
+          f"if fully overlapped {world*t1/max(ms, comm) if world > 1 else 1.0:4.2f}x", flush=True)
     del hg, shard, a, b, x, G, opt
     torch.cuda.empty_cache()
