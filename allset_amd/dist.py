@@ -487,13 +487,21 @@ class ColumnShardedHypergraph:
     """One rank's view for column-sharded aggregation: the FULL incidence (``edge_index`` int64 [2, nnz], row 0 global
     vertex ids, row 1 global 0-based hyperedge ids; identical on every rank) plus the row blocks this rank owns for the
     dense work -- vertices ``v_lo:v_hi`` of the padded vertex range, hyperedges ``e_lo:e_hi`` of the padded hyperedge
-    range.  ``norm``: per-incidence weights in ``edge_index`` order, or None."""
+    range (blocks padded to a multiple of ``chunks``, the chunk count of the overlapped exchange).  ``norm``:
+    per-incidence weights in ``edge_index`` order, or None."""
 
-    def __init__(self, edge_index: Tensor, n_v: int, n_e: int, world: int, rank: int, norm: Optional[Tensor] = None):
+    def __init__(self, edge_index: Tensor, n_v: int, n_e: int, world: int, rank: int, norm: Optional[Tensor] = None,
+                 chunks: int = 1):
         self.edge_index = edge_index
         self.n_v, self.n_e, self.world, self.rank = int(n_v), int(n_e), int(world), int(rank)
-        self.v_lo, self.v_hi, self.n_v_pad = vertex_block(n_v, world, rank)
-        self.e_lo, self.e_hi, self.n_e_pad = vertex_block(n_e, world, rank)
+        self.chunks = max(int(chunks), 1)         # owned blocks are padded to a multiple of this (overlapped exchange)
+
+        def block(n):
+            per = (n + world - 1) // world
+            per = (per + self.chunks - 1) // self.chunks * self.chunks
+            return rank * per, (rank + 1) * per, per * world
+        self.v_lo, self.v_hi, self.n_v_pad = block(self.n_v)
+        self.e_lo, self.e_hi, self.n_e_pad = block(self.n_e)
         self.norm = norm
         self.v2e = None
         self.e2v = None
@@ -518,39 +526,247 @@ def head_slots(heads: int, world: int) -> Tuple[int, list]:
     raise ValueError(f"column sharding of PMA needs heads ({heads}) and world size ({world}) to divide one another")
 
 
+def _chunking(hg, x_owned: Tensor, chunks: int, world: int, group, *convs) -> int:
+    """Chunk count for the overlapped exchange: divides both owned row counts; 1 (plain path) when there is no exchange
+    or with BatchNorm in a conv (its batch statistics are not row-wise)."""
+    if _skip_collective(group) or chunks <= 1 or _has_batchnorm(*convs):
+        return 1
+    import math
+    return pipeline_chunks(math.gcd(x_owned.shape[0], hg.n_e_pad // world), chunks)
+
+
 def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, aggr: str = "add",
                               dropout: float = 0.0, training: bool = False, group=None,
-                              aggregate: Callable = _hip_deepsets) -> Tensor:
+                              aggregate: Callable = _hip_deepsets, chunks: int = 1) -> Tensor:
     """The layer of :func:`sharded_deepsets_layer` with column-sharded aggregation: four all-to-alls, no reduction
-    across ranks; every ``aggr`` of the reference (layers.py:641-656) is the plain local one on the column slice."""
+    across ranks; every ``aggr`` of the reference (layers.py:641-656) is the plain local one on the column slice.
+    ``chunks`` > 1: the owned rows go through the MLPs in that many chunks, each chunk's exchange overlapping the
+    others' dense work (chunk k of rank i lands at rows i*n/P + k*rc of the column table: the natural row order)."""
     if aggr not in ("add", "sum", "mean", "max", "min"):
         raise ValueError(f"aggr {aggr!r}")
-    h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)               # [n_V/P, d]
-    e = cols_to_rows(aggregate(rows_to_cols(h, group), hg.v2e, hg.norm, aggr), group)      # [n_E/P, d]
-    e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)
-    g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
-    v = cols_to_rows(aggregate(rows_to_cols(g, group), hg.e2v, hg.norm, aggr), group)      # [n_V/P, d]
-    return e2v_conv._mlp_act(e2v_conv.f_dec, v, dropout)
+    w = 1 if _skip_collective(group) else _world(group)
+    K = _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
+    enc1 = lambda t: v2e_conv._mlp_act(v2e_conv.f_enc, t, v2e_conv.dropout)
+    mid = lambda t: e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, t, dropout), e2v_conv.dropout)
+    dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, dropout)
+    if K == 1:
+        e = cols_to_rows(aggregate(rows_to_cols(enc1(x_owned), group), hg.v2e, hg.norm, aggr), group)      # [n_E/P, d]
+        return dec2(cols_to_rows(aggregate(rows_to_cols(mid(e), group), hg.e2v, hg.norm, aggr), group))
+    (hc,) = _stage(torch.split(x_owned, x_owned.shape[0] // K), enc1, x_owned.shape[0] // K, K, w, group)
+    ec = aggregate(hc, hg.v2e, hg.norm, aggr)
+    (gc,) = _stage(_unstage(ec, K, w, group), lambda get: mid(get()), hg.n_e_pad // w // K, K, w, group)
+    vc = aggregate(gc, hg.e2v, hg.norm, aggr)
+    return torch.cat([dec2(get()) for get in _unstage(vc, K, w, group)])
 
 
 def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, dropout: float = 0.0,
-                         training: bool = False, group=None, kernels=HipPmaKernels) -> Tensor:
+                         training: bool = False, group=None, kernels=HipPmaKernels, chunks: int = 1) -> Tensor:
     """The layer of :func:`sharded_pma_layer` with column-sharded pooling: per direction one all-to-all of the values,
-    one of the (few) logit columns each slice needs, the ordinary local fused pooling, one all-to-all back."""
+    one of the (few) logit columns each slice needs, the ordinary local fused pooling, one all-to-all back.
+    ``chunks``: as in :func:`colsharded_deepsets_layer`."""
     w = 1 if _skip_collective(group) else _world(group)
+    K = _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
+    post = dropout if training else 0.0
 
-    def pool(p, t, inc):
-        H = p.heads
-        V, alpha = p.project(t)                                                    # [n/P, H*C], [n/P, H]: dense, owned rows
-        hl, slots = head_slots(H, w)
-        if slots != list(range(H)):
-            alpha = alpha[:, torch.tensor(slots, device=alpha.device)]             # a shared head's logits go to each sharer
-        o = kernels.aggregate(rows_to_cols(V, group).contiguous(), rows_to_cols(alpha.contiguous(), group).contiguous(),
-                              inc, hl, p.negative_slope)
-        return p.tail(cols_to_rows(o, group), _post=dropout if training else 0.0)
+    def project(p):
+        hl, slots = head_slots(p.heads, w)
+        idx = None if slots == list(range(p.heads)) else torch.tensor(slots, device=x_owned.device)
 
-    e = pool(v2e_conv.prop, x_owned, hg.v2e)
-    return pool(e2v_conv.prop, e, hg.e2v)
+        def f(t):
+            V, alpha = p.project(t)                                  # [rows, H*C], [rows, H]: dense, owned rows
+            return V, (alpha if idx is None else alpha[:, idx]).contiguous()   # a shared head's logits go to each sharer
+        return f, hl
+
+    p1, p2 = v2e_conv.prop, e2v_conv.prop
+    f1, hl1 = project(p1)
+    f2, hl2 = project(p2)
+    if K == 1:
+        def pool(p, f, hl, t, inc):
+            V, alpha = f(t)
+            o = kernels.aggregate(rows_to_cols(V, group).contiguous(), rows_to_cols(alpha, group).contiguous(), inc, hl,
+                                  p.negative_slope)
+            return p.tail(cols_to_rows(o, group), _post=post)
+        return pool(p2, f2, hl2, pool(p1, f1, hl1, x_owned, hg.v2e), hg.e2v)
+    rv, re = x_owned.shape[0] // K, hg.n_e_pad // w // K
+    Vc, ac = _stage(torch.split(x_owned, rv), f1, rv, K, w, group)
+    oc = kernels.aggregate(Vc, ac, hg.v2e, hl1, p1.negative_slope)
+    Vc, ac = _stage(_unstage(oc, K, w, group), lambda get: f2(p1.tail(get(), _post=post)), re, K, w, group)
+    oc = kernels.aggregate(Vc, ac, hg.e2v, hl2, p2.negative_slope)
+    return torch.cat([p2.tail(get(), _post=post) for get in _unstage(oc, K, w, group)])
+
+
+# ---- the same exchanges, chunked and overlapped with the row-sharded dense work ---------------------------------
+#
+# Both neighbours of an all-to-all are row-wise MLPs, so the owned rows are cut into K chunks and chunk k's exchange
+# runs (on RCCL's stream) while chunk k+1 is still in -- or chunk k-1 already past -- the MLP.  The autograd wiring
+# keeps that true in backward, where the engine would otherwise serialise "exchange k, MLP k, exchange k-1, ...":
+#   producer side   MLP chunk --_SendRowsChunk--> token  ... all tokens --_AssembleCols--> [n, d/P]
+#       forward : every chunk's all-to-all is issued as soon as the chunk exists; _AssembleCols waits for all of them.
+#       backward: _AssembleCols issues ALL K reverse all-to-alls at once; each _SendRowsChunk.backward only waits for its own.
+#   consumer side   [n, d/P] --_ScatterCols--> K tokens ... token --_RecvRowsChunk--> chunk for the MLP
+#       forward : all K all-to-alls issued at once, each chunk waits for its own; backward: each chunk issues its reverse
+#       exchange as soon as its MLP backward is done, _ScatterCols.backward waits for all.
+# Tokens are zero-size tensors that only carry the graph edges; the data moves through the shared ``_Pipe``.
+
+class _PendingCopy:
+    """gloo (tests) has no list all-to-all: exchange through a contiguous buffer, copy out after the wait."""
+
+    def __init__(self, work, tmp, views):
+        self.work, self.tmp, self.views = work, tmp, views
+
+    def wait(self):
+        self.work.wait()
+        for t, v in zip(self.tmp.unbind(0), self.views):
+            v.copy_(t)
+
+
+def _a2a_async(out_views, in_views, group):
+    """All-to-all of P equal contiguous pieces, asynchronous; ``wait()`` orders the current stream behind it."""
+    if dist.get_backend(group) == "nccl":
+        return dist.all_to_all(list(out_views), list(in_views), group=group, async_op=True)
+    send = torch.stack(list(in_views))
+    tmp = torch.empty_like(send)
+    return _PendingCopy(dist.all_to_all_single(tmp, send, group=group, async_op=True), tmp, list(out_views))
+
+
+class _Pipe:
+    def __init__(self, K: int, world: int, rc: int, group):
+        self.K, self.P, self.rc, self.group = K, world, rc, group
+        self.work = [None] * K
+        self.bwork = [None] * K
+        self.buf = [None] * K          # per-chunk [P, rc, dc] buffers (kept alive until their exchange was waited for)
+        self.bbuf = [None] * K
+        self.full = None               # [n, dc] assembled forward table / source of the scatter
+        self.bfull = None              # its gradient
+
+    def blocks(self, full: Tensor, k: int):
+        """The P contiguous [rc, dc] pieces of chunk k inside a [P*K*rc, dc] table (rank-major, chunk, row)."""
+        v = full.view(self.P, self.K, self.rc, full.shape[1])
+        return [v[i, k] for i in range(self.P)]
+
+
+class _SendRowsChunk(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, pipe, k):
+        rc, d = h.shape
+        dc = d // pipe.P
+        if pipe.full is None:
+            pipe.full = h.new_empty((pipe.P * pipe.K * rc, dc))
+        send = h.view(rc, pipe.P, dc).permute(1, 0, 2).contiguous()
+        pipe.buf[k] = send
+        pipe.work[k] = _a2a_async(pipe.blocks(pipe.full, k), send.unbind(0), pipe.group)
+        ctx.pipe, ctx.k, ctx.shape = pipe, k, (rc, d)
+        return h.new_empty(0)
+
+    @staticmethod
+    def backward(ctx, _g):
+        pipe, k = ctx.pipe, ctx.k
+        pipe.bwork[k].wait()
+        recv, pipe.bbuf[k], pipe.bwork[k] = pipe.bbuf[k], None, None
+        return recv.permute(1, 0, 2).reshape(ctx.shape), None, None
+
+
+class _AssembleCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pipe, *tokens):
+        for k in range(pipe.K):
+            pipe.work[k].wait()
+            pipe.work[k] = pipe.buf[k] = None
+        ctx.pipe = pipe
+        ctx.token_like = tokens[0]
+        full, pipe.full = pipe.full, None
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        pipe = ctx.pipe
+        g = g.contiguous()
+        pipe.bfull = g                                               # alive until the last chunk was received
+        for k in reversed(range(pipe.K)):                            # the engine runs the chunks last-created first
+            recv = g.new_empty((pipe.P, pipe.rc, g.shape[1]))
+            pipe.bbuf[k] = recv
+            pipe.bwork[k] = _a2a_async(recv.unbind(0), pipe.blocks(g, k), pipe.group)
+        return (None,) + tuple(ctx.token_like.new_zeros(0) for _ in range(pipe.K))
+
+
+class _ScatterCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, full, pipe):
+        full = full.contiguous()
+        pipe.full = full
+        for k in range(pipe.K):
+            recv = full.new_empty((pipe.P, pipe.rc, full.shape[1]))
+            pipe.buf[k] = recv
+            pipe.work[k] = _a2a_async(recv.unbind(0), pipe.blocks(full, k), pipe.group)
+        ctx.pipe = pipe
+        return tuple(full.new_empty(0) for _ in range(pipe.K))
+
+    @staticmethod
+    def backward(ctx, *_g):
+        pipe = ctx.pipe
+        for k in range(pipe.K):
+            pipe.bwork[k].wait()
+            pipe.bwork[k] = pipe.bbuf[k] = None
+        g, pipe.bfull, pipe.full = pipe.bfull, None, None
+        return g, None
+
+
+class _RecvRowsChunk(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, pipe, k):
+        pipe.work[k].wait()
+        recv, pipe.buf[k], pipe.work[k] = pipe.buf[k], None, None
+        ctx.pipe, ctx.k = pipe, k
+        ctx.token_like = token
+        return recv.permute(1, 0, 2).reshape(pipe.rc, pipe.P * recv.shape[2])
+
+    @staticmethod
+    def backward(ctx, g):
+        pipe, k = ctx.pipe, ctx.k
+        rc, d = g.shape
+        dc = d // pipe.P
+        if pipe.bfull is None:
+            pipe.bfull = g.new_empty((pipe.P * pipe.K * rc, dc))
+        send = g.view(rc, pipe.P, dc).permute(1, 0, 2).contiguous()
+        pipe.bbuf[k] = send
+        pipe.bwork[k] = _a2a_async(pipe.blocks(pipe.bfull, k), send.unbind(0), pipe.group)
+        return ctx.token_like.new_zeros(0), None, None
+
+
+def pipeline_chunks(rows: int, want: int) -> int:
+    """Largest chunk count <= ``want`` that divides the owned row count (1 = no pipelining)."""
+    for k in range(max(int(want), 1), 0, -1):
+        if rows % k == 0:
+            return k
+    return 1
+
+
+def _stage(items, fn, rc: int, K: int, world: int, group):
+    """``fn(item)`` (row-wise; one tensor or a tuple of tensors [rc, width] per chunk) for every chunk, each result handed
+    to its all-to-all at once.  Returns the assembled [P*K*rc, width/P] table(s), rows in global order."""
+    pipes, tokens = None, None
+    for k, item in enumerate(items):
+        ys = fn(item)
+        ys = ys if isinstance(ys, tuple) else (ys,)
+        if pipes is None:
+            pipes = [_Pipe(K, world, rc, group) for _ in ys]
+            tokens = [[] for _ in ys]
+        for pipe, toks, y in zip(pipes, tokens, ys):
+            toks.append(_SendRowsChunk.apply(y.contiguous(), pipe, k))
+    return tuple(_AssembleCols.apply(pipe, *toks) for pipe, toks in zip(pipes, tokens))
+
+
+def _unstage(table: Tensor, K: int, world: int, group):
+    """[P*K*rc, dc] -> K thunks; thunk k returns the owned row chunk [rc, P*dc] once its all-to-all (all K are already in
+    flight) has arrived."""
+    rc = table.shape[0] // (world * K)
+    pipe = _Pipe(K, world, rc, group)
+    tokens = _ScatterCols.apply(table, pipe)
+    return [(lambda tok=tok, k=k: _RecvRowsChunk.apply(tok, pipe, k)) for k, tok in enumerate(tokens)]
+
+
+def _has_batchnorm(*mods) -> bool:
+    return any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for mod in mods for m in mod.modules())
 
 
 def exchange_bytes_per_rank(mode: str, world: int, n_v: int, n_e: int, d: int, elem: int = 4) -> int:

@@ -59,6 +59,8 @@ def parse_args():
                     help="N > 1: 'rows' = hyperedge shards with all-gather / reduce-scatter of the vertex table; 'columns' = "
                          "column-sharded aggregation with all-to-all layout changes (1/N of the exchange volume); 'auto' = "
                          "allset_amd.dist.choose_sharding (DESIGN.md section 7)")
+    ap.add_argument("--pipeline-chunks", type=int, default=4,
+                    help="--shard columns: chunks of owned rows whose all-to-alls overlap the other chunks' dense work (1 = off)")
     ap.add_argument("--self-loops", action="store_true",
                     help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
@@ -180,8 +182,8 @@ def main():
                                                             dist=args.degree_dist) for r in range(world)]
         ei = torch.cat([torch.stack([b.edge_index[0], b.edge_index[1] + r * n_loc]) for r, b in enumerate(blocks)], dim=1)
         nnz_global = int(ei.shape[1])
-        hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, rank,
-                                           norm=torch.cat([b.norm for b in blocks])).build_incidences()
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, rank, norm=torch.cat([b.norm for b in blocks]),
+                                           chunks=args.pipeline_chunks).build_incidences()
         del blocks, ei
         nnz_local = nnz_global / world                   # each rank aggregates every incidence over d/N of the columns
     else:
@@ -209,8 +211,10 @@ def main():
         opt.zero_grad(set_to_none=True)
         x.grad = None
         if mode == "columns":
-            out = (adist.colsharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True) if attn else
-                   adist.colsharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True))
+            out = (adist.colsharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True, chunks=args.pipeline_chunks)
+                   if attn else
+                   adist.colsharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True,
+                                                   chunks=args.pipeline_chunks))
         elif attn:
             out = adist.sharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True)
         else:
@@ -286,7 +290,8 @@ def main():
                                    f"fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
                        "n_v": n_v, "n_e": n_e_loc * world, "nnz": int(nnz_total), "d": d,
                        "parallelism": ("single GPU" if world == 1 else f"hyperedge-shard x{world}" if mode == "rows"
-                                       else f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation)"), "seed": args.seed},
+                                       else f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; "
+                                            f"exchange in {args.pipeline_chunks} overlapped chunks)"), "seed": args.seed},
             "roofline": roofline,
             "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if world == 1 else None,
                             "unit": "edges*d/s", "note": "gather/segment-reduce kernel time per step (HIP events, rank 0): "

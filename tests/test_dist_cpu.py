@@ -369,13 +369,13 @@ def test_sharded_max_merge_picks_one_winner():
 # column-sharded aggregation: full incidence on every rank, d/P columns each, all-to-all layout changes
 # ---------------------------------------------------------------------------------------------------------------
 
-def _col_worker(rank, world, port, kind, arg, q):
+def _col_worker(rank, world, port, kind, arg, q, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from allset_amd import dist as adist
         n_v, n_e, d, ei, norm, x, G = _problem(world)
-        hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm if kind == "ds" else None)
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm if kind == "ds" else None, chunks=chunks)
         hg.v2e = (ei, hg.n_e_pad)
         hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
         xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
@@ -383,10 +383,10 @@ def _col_worker(rank, world, port, kind, arg, q):
         xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
         if kind == "ds":
             a, b = _convs(d)
-            out = adist.colsharded_deepsets_layer(a, b, xo, hg, aggr=arg, aggregate=_oracle_aggregate)
+            out = adist.colsharded_deepsets_layer(a, b, xo, hg, aggr=arg, aggregate=_oracle_aggregate, chunks=chunks)
         else:
             a, b = _pma_convs(d, arg)
-            out = adist.colsharded_pma_layer(a, b, xo, hg, kernels=TorchPmaKernels)
+            out = adist.colsharded_pma_layer(a, b, xo, hg, kernels=TorchPmaKernels, chunks=chunks)
         (out * Gp[hg.v_lo:hg.v_hi]).sum().backward()
         params = list(a.parameters()) + list(b.parameters())
         adist.allreduce_grads(params)
@@ -395,12 +395,12 @@ def _col_worker(rank, world, port, kind, arg, q):
         dist.destroy_process_group()
 
 
-def _run_col(kind, arg):
+def _run_col(kind, arg, chunks=1):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_col_worker, args=(r, world, port, kind, arg, q)) for r in range(world)]
+    procs = [ctx.Process(target=_col_worker, args=(r, world, port, kind, arg, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -410,10 +410,12 @@ def _run_col(kind, arg):
     return results
 
 
-@pytest.mark.parametrize("aggr", ["add", "mean", "max", "min"])
-def test_colsharded_deepsets_layer_equals_unsharded(aggr):
+@pytest.mark.parametrize("aggr,chunks", [("add", 1), ("mean", 1), ("max", 1), ("min", 1), ("add", 4), ("max", 3)])
+def test_colsharded_deepsets_layer_equals_unsharded(aggr, chunks):
+    """chunks > 1: the overlapped exchange (K all-to-alls in flight, tokens through autograd); the owned blocks are padded
+    to a multiple of the chunk count (37 vertices -> 2 x 20 rows for 4 chunks)."""
     import torch.nn.functional as F
-    results = _run_col("ds", aggr)
+    results = _run_col("ds", aggr, chunks)
     n_v, n_e, d, ei, norm, x, G = _problem(2)
     a, b = _convs(d)
     xr = x.clone().requires_grad_(True)
@@ -435,10 +437,10 @@ def test_colsharded_deepsets_layer_equals_unsharded(aggr):
         np.testing.assert_array_equal(got, got1)
 
 
-@pytest.mark.parametrize("H", [4, 1])        # 4: two whole heads per rank; 1: the two ranks share the one head
-def test_colsharded_pma_layer_equals_unsharded(H):
+@pytest.mark.parametrize("H,chunks", [(4, 1), (1, 1), (4, 4), (1, 2)])   # H=4: two whole heads per rank; 1: a shared head
+def test_colsharded_pma_layer_equals_unsharded(H, chunks):
     import torch.nn.functional as F
-    results = _run_col("pma", H)
+    results = _run_col("pma", H, chunks)
     n_v, n_e, d, ei, _, x, G = _problem(2)
     a, b = _pma_convs(d, H)
 

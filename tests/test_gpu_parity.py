@@ -282,3 +282,59 @@ def test_sharded_pma_merge_path_equals_single_rank_path(device, monkeypatch):
     torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
     for u, v in zip(p1, p0):
         torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4 * max(1.0, float(v.abs().max())))
+
+
+@pytest.fixture
+def one_rank_rccl(monkeypatch):
+    """A 1-rank nccl (= RCCL) process group with the collectives forced on: the only way to push the real all-to-all /
+    all-gather / reduce-scatter calls -- and the asynchronous, chunked exchange -- through RCCL on a 1-GPU box."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("ALLSET_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("attention", [False, True])
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_colsharded_layer_through_rccl_equals_module_composition(attention, chunks, device, one_rank_rccl):
+    """Column-sharded layers on the HIP kernels, exchanges through RCCL (1 rank), plain and with the overlapped chunked
+    exchange (asynchronous all-to-alls on RCCL's stream, waits on the compute stream): must equal the plain module
+    composition.  A missing stream dependency in the chunked path would show up here as stale rows."""
+    import numpy as np
+    import torch.nn.functional as F
+    from allset_amd import HalfNLHconv, Incidence
+    from allset_amd import dist as adist
+    rng = np.random.default_rng(13)
+    n_v, n_e, d, H = 40_000, 30_001, 128, 4
+    v = torch.from_numpy(rng.integers(0, n_v, size=400_000)); e = torch.from_numpy(rng.integers(0, n_e, size=400_000))
+    ei = torch.unique(torch.stack([v, e]), dim=1).to(device)
+    torch.manual_seed(0)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=attention).to(device).eval()
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=attention).to(device).eval()
+    hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, 1, 0, chunks=chunks).build_incidences()
+    assert hg.n_e_pad % chunks == 0 and hg.n_e_pad >= n_e
+    x = torch.randn(hg.n_v_pad, d, device=device)
+    G = torch.randn(hg.n_v_pad, d, device=device)
+    for rep in range(3):                                  # repeated: buffers are recycled by the caching allocator
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+        xs = x.clone().requires_grad_(True)
+        layer = adist.colsharded_pma_layer if attention else adist.colsharded_deepsets_layer
+        kw = {} if attention else {"aggr": "add"}
+        out = layer(a, b, xs, hg, chunks=chunks, **kw)
+        (out * G).sum().backward()
+    gs = [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+    for p in list(a.parameters()) + list(b.parameters()):
+        p.grad = None
+    inc = Incidence.from_edge_index(ei, n_src=hg.n_v_pad, n_dst=hg.n_e_pad)
+    xr = x.clone().requires_grad_(True)
+    ref = F.relu(b(F.relu(a(xr, inc, None, "add")), inc.reversed(n_dst=hg.n_v_pad), None, "add"))
+    (ref * G).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xs.grad, xr.grad, rtol=1e-4, atol=1e-4)
+    for g, p in zip(gs, list(a.parameters()) + list(b.parameters())):
+        torch.testing.assert_close(g, p.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(p.grad.abs().max())))
