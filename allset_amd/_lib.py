@@ -60,6 +60,7 @@ SIGNATURES = {
     "allset_fused_linear_fwd": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                                 _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "allset_fused_linear_mask_words": [c_int64, c_int64],
+    "allset_block_transpose": [_P, _P, c_int64, c_int64, c_int64, c_int64, c_int, _P],
     "allset_pma_merge_pack": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_ln_bf16_supported": [c_int64],
     "allset_ln_fwd_bf16": [_P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64, c_int64, _P, _P],

@@ -564,6 +564,25 @@ static int check_pma_dims(const char* who, int64_t n_a, int64_t n_b, int64_t H, 
 }
 
 
+// ---- layout change around the column-sharded layer's all-to-all (allset_amd/dist.py) ---------------------------------------
+// rows x (P blocks of q 16-byte packets)  <->  P blocks x rows x q packets.  to_blocks: dst[(j*rows + r)*q + t] = src[r*lds + j*q + t]
+// (pack: the per-destination column blocks become contiguous); else dst[r*ldd + j*q + t] = src[(j*rows + r)*q + t] (unpack).
+// Threads enumerate the ROW-MAJOR side in order, so a wavefront reads (writes) whole rows and touches, per block, the
+// consecutive rows of that block -- adjacent in memory -- and every cache line is completed by one wavefront.
+__global__ __launch_bounds__(kBlock) void block_transpose_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                                 int64_t rows, int P, int q, int64_t ld, int to_blocks) {
+  const int per_row = P * q;
+  const int64_t total = rows * per_row;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < total;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t r = idx / per_row;
+    const int c = static_cast<int>(idx - r * per_row);
+    const int j = c / q, t = c - j * q;
+    const int64_t rm = r * ld + c, bl = (static_cast<int64_t>(j) * rows + r) * q + t;
+    if (to_blocks) dst[bl] = src[rm]; else dst[rm] = src[bl];
+  }
+}
+
 // ---- cross-shard merge of partial PMA results (multi-GPU E->V) ----------------------------------
 // packed[r] = [ out_loc[r, h, :] * w[r, h]  for all h | w[r, 0..H-1] ],  w = l_loc > 0 ? l_loc * exp(m_loc - m_glob) : 0
 // -- the per-rank numerators and denominators relative to the GLOBAL row maximum, laid out as one row so that a single
@@ -821,6 +840,23 @@ extern "C" int allset_pma_merge_pack(const float* out_loc, int64_t ldo, const fl
   const unsigned grid = static_cast<unsigned>(want > 65536 ? 65536 : want);
   pma_merge_pack_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(out_loc, ldo, m_loc, l_loc, m_glob, packed, ldp,
                                                                               n, static_cast<int>(H), static_cast<int>(C), vec);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_block_transpose(const void* src, void* dst, int64_t rows, int64_t P, int64_t block_bytes, int64_t ld_bytes,
+                                      int to_blocks, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(rows >= 0 && P >= 1 && block_bytes >= 16 && block_bytes % 16 == 0, "block_transpose: blocks must be whole 16-byte packets");
+  ALLSET_REQUIRE(ld_bytes >= P * block_bytes && ld_bytes % 16 == 0, "block_transpose: bad leading dimension");
+  ALLSET_REQUIRE(P * (block_bytes / 16) < (1ll << 30), "block_transpose: row too wide");
+  if (rows == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(src && dst && aligned16(src) && aligned16(dst), "block_transpose: pointers must be 16-byte aligned");
+  const int q = static_cast<int>(block_bytes / 16);
+  const int64_t want = (rows * P * q + kBlock - 1) / kBlock;
+  const unsigned grid = static_cast<unsigned>(want > 65536 ? 65536 : want);
+  block_transpose_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint4*>(src), static_cast<uint4*>(dst), rows, static_cast<int>(P), q, ld_bytes / 16, to_blocks);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

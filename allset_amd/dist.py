@@ -423,6 +423,22 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
 # The price: gathers of d/P-wide rows; below 32 fp32 columns (128 B) a gathered row is less than a cache line and the
 # gather kernels lose efficiency (measured: profiles/r01_colshard_kernels.txt).
 
+def _pack(x: Tensor, w: int) -> Tensor:
+    """[rows, P*dc] -> [P, rows, dc] contiguous (what an all-to-all sends); one HIP copy kernel on the device."""
+    from . import ops
+    if ops.block_transpose_supported(x, w, True):
+        return ops.block_transpose(x, w, True)
+    return x.view(x.shape[0], w, x.shape[1] // w).permute(1, 0, 2).contiguous()
+
+
+def _unpack(x: Tensor) -> Tensor:
+    """[P, rows, dc] (what an all-to-all received) -> [rows, P*dc]."""
+    from . import ops
+    if ops.block_transpose_supported(x, x.shape[0], False):
+        return ops.block_transpose(x, x.shape[0], False)
+    return x.permute(1, 0, 2).reshape(x.shape[1], x.shape[0] * x.shape[2])
+
+
 def _rows_to_cols(x: Tensor, group=None) -> Tensor:
     """[n/P, d] -> [n, d/P]: rank r ends with columns [r*d/P, (r+1)*d/P) of every rank's rows, in rank order."""
     if _skip_collective(group):
@@ -431,7 +447,7 @@ def _rows_to_cols(x: Tensor, group=None) -> Tensor:
     r, d = x.shape
     if d % w:
         raise ValueError(f"column sharding needs the width ({d}) to be a multiple of the world size ({w})")
-    send = x.view(r, w, d // w).permute(1, 0, 2).contiguous()              # [P, n/P, d/P]: chunk j goes to rank j
+    send = _pack(x, w)                                                     # [P, n/P, d/P]: chunk j goes to rank j
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
     return recv.view(w * r, d // w)                                        # chunk i = rank i's rows: already row-major
@@ -448,7 +464,7 @@ def _cols_to_rows(x: Tensor, group=None) -> Tensor:
     send = x.contiguous()                                                  # rows of block j (my columns) go to rank j
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
-    return recv.view(w, n // w, dc).permute(1, 0, 2).reshape(n // w, w * dc)
+    return _unpack(recv.view(w, n // w, dc))
 
 
 class _RowsToCols(torch.autograd.Function):
@@ -652,7 +668,7 @@ class _SendRowsChunk(torch.autograd.Function):
         dc = d // pipe.P
         if pipe.full is None:
             pipe.full = h.new_empty((pipe.P * pipe.K * rc, dc))
-        send = h.view(rc, pipe.P, dc).permute(1, 0, 2).contiguous()
+        send = _pack(h, pipe.P)
         pipe.buf[k] = send
         pipe.work[k] = _a2a_async(pipe.blocks(pipe.full, k), send.unbind(0), pipe.group)
         ctx.pipe, ctx.k, ctx.shape = pipe, k, (rc, d)
@@ -663,7 +679,7 @@ class _SendRowsChunk(torch.autograd.Function):
         pipe, k = ctx.pipe, ctx.k
         pipe.bwork[k].wait()
         recv, pipe.bbuf[k], pipe.bwork[k] = pipe.bbuf[k], None, None
-        return recv.permute(1, 0, 2).reshape(ctx.shape), None, None
+        return _unpack(recv), None, None
 
 
 class _AssembleCols(torch.autograd.Function):
@@ -718,7 +734,7 @@ class _RecvRowsChunk(torch.autograd.Function):
         recv, pipe.buf[k], pipe.work[k] = pipe.buf[k], None, None
         ctx.pipe, ctx.k = pipe, k
         ctx.token_like = token
-        return recv.permute(1, 0, 2).reshape(pipe.rc, pipe.P * recv.shape[2])
+        return _unpack(recv)
 
     @staticmethod
     def backward(ctx, g):
@@ -727,7 +743,7 @@ class _RecvRowsChunk(torch.autograd.Function):
         dc = d // pipe.P
         if pipe.bfull is None:
             pipe.bfull = g.new_empty((pipe.P * pipe.K * rc, dc))
-        send = g.view(rc, pipe.P, dc).permute(1, 0, 2).contiguous()
+        send = _pack(g, pipe.P)
         pipe.bbuf[k] = send
         pipe.bwork[k] = _a2a_async(pipe.blocks(pipe.bfull, k), send.unbind(0), pipe.group)
         return ctx.token_like.new_zeros(0), None, None

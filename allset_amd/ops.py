@@ -369,6 +369,35 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     return gV, galpha
 
 
+def block_transpose(x: Tensor, world: int, to_blocks: bool) -> Tensor:
+    """The pack / unpack copy of the column-sharded layer's all-to-all.  ``to_blocks``: [rows, P*dc] row-major ->
+    [P, rows, dc]; else [P, rows, dc] -> [rows, P*dc].  Needs dc * element_size to be a multiple of 16."""
+    dev = require_device(x)
+    es = x.element_size()
+    if to_blocks:
+        x = _rowmajor(x)
+        rows, d = x.shape
+        dc = d // world
+        out = torch.empty((world, rows, dc), dtype=x.dtype, device=dev)
+        ld = _ld(x) * es
+    else:
+        x = x.contiguous()
+        _, rows, dc = x.shape
+        out = torch.empty((rows, world * dc), dtype=x.dtype, device=dev)
+        ld = world * dc * es
+    with torch.cuda.device(dev), _timed("block_transpose", dev, 2 * rows * world * dc * es):
+        check(_lib.load().allset_block_transpose(ptr(x), ptr(out), rows, world, dc * es, ld, int(to_blocks), stream_of(dev)),
+              "allset_block_transpose")
+    return out
+
+
+def block_transpose_supported(x: Tensor, world: int, to_blocks: bool) -> bool:
+    if not x.is_cuda:
+        return False
+    dc = (x.shape[1] // world) if to_blocks else x.shape[2]
+    return (dc * x.element_size()) % 16 == 0 and dc > 0 and (not to_blocks or x.shape[1] % world == 0)
+
+
 def pma_merge_pack(out_loc: Tensor, m_loc: Tensor, l_loc: Tensor, m_glob: Tensor, heads: int) -> Tensor:
     """[n, d + H] rows ``[out_loc * w | w]`` with ``w = l_loc * exp(m_loc - m_glob)`` (0 where ``l_loc == 0``): this rank's
     numerators / denominators relative to the global row maximum, ready for a sum-reduce-scatter."""

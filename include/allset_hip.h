@@ -240,6 +240,14 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                        const uint32_t* mask, void* stream);
 
+/* Layout change around the all-to-all of the column-sharded layer (allset_amd/dist.py; no reference counterpart -- the
+ * reference is single-device).  A row-major matrix of `rows` rows whose row holds P column blocks of
+ * `block_bytes` (a multiple of 16) each, leading dimension `ld_bytes`, and the block-major buffer [P][rows][block_bytes]
+ * an all-to-all sends / receives:   to_blocks != 0: src row-major -> dst block-major (pack);  0: src block-major -> dst
+ * row-major (unpack).  Any element type; all pointers 16-byte aligned. */
+int allset_block_transpose(const void* src, void* dst, int64_t rows, int64_t P, int64_t block_bytes, int64_t ld_bytes,
+                           int to_blocks, void* stream);
+
 /* Multi-GPU E->V attention pooling: pack this rank's partial result for the cross-rank merge.
  *   packed[r] = [ out_loc[r,h,:] * w[r,h] for all h | w[r,0..H-1] ],  w = l_loc > 0 ? l_loc * exp(m_loc - m_glob) : 0
  * (out_loc, m_loc, l_loc from allset_pma_fwd on the local incidences; m_glob = max over ranks of m_loc).  A sum over ranks of

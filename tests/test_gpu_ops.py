@@ -409,3 +409,19 @@ def test_self_loop_tail_split_dispatch(mode, device):
     torch.testing.assert_close(yd.grad.cpu(), yr.grad, rtol=RTOL, atol=ATOL)
     if mode == "pma":
         torch.testing.assert_close(a2d.grad.cpu(), a2r.grad, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,P,dc,dtype", [(1000, 8, 16, torch.float32), (777, 4, 32, torch.float32), (5, 2, 4, torch.float32),
+                                             (1234, 8, 32, torch.bfloat16), (64, 1, 128, torch.float32), (0, 4, 8, torch.float32)])
+def test_block_transpose_is_the_permute_copy(rows, P, dc, dtype, device):
+    """The all-to-all's pack / unpack kernel: bit-exact copies of torch's permute, both directions, strided source."""
+    from allset_amd import ops
+    wide = torch.randn(rows, P * dc + 8, device=device).to(dtype)
+    x = wide[:, :P * dc]                                                   # leading dimension > width
+    assert ops.block_transpose_supported(x, P, True)
+    packed = ops.block_transpose(x, P, True)
+    assert packed.shape == (P, rows, dc)
+    assert torch.equal(packed, x.reshape(rows, P, dc).permute(1, 0, 2).contiguous())
+    back = ops.block_transpose(packed, P, False)
+    assert torch.equal(back, x)
+    assert not ops.block_transpose_supported(torch.zeros(4, 6, device=device), 2, True)       # 12-byte blocks
