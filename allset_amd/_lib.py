@@ -35,6 +35,11 @@ SIGNATURES = {
     "allset_pma_fwd": [c_int, _P, _P, _P, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_pma_fwd_ex": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64, c_int64,
                           c_int64, c_int64, _P],
+    "allset_pma_fwd_ld": [c_int, c_int, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, c_float, _P, c_int64, _P, _P, c_int64,
+                          c_int64, c_int64, c_int64, _P],
+    "allset_pma_bwd_stats_ld": [c_int, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_pma_bwd_src_ld": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_float, _P, c_int64,
+                              _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_pma_attention": [_P, _P, _P, _P, _P, c_float, _P, c_int64, c_int64, _P],
     "allset_pma_bwd_stats": [c_int, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_pma_bwd_src": [c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_float, _P, c_int64, _P,

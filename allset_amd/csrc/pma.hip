@@ -39,7 +39,7 @@ __device__ __forceinline__ float head_group_reduce(float val, int li, int grp_en
 
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha, int64_t lda,
     const T* __restrict__ V, int64_t ldv, float slope, T* __restrict__ out, int64_t ldo,
     float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C, const int32_t* __restrict__ row_order) {
   constexpr int NS = kWave / LPR;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_kernel(
           ok[u] = (jj < n) && active;
           const int src = __shfl(my_col, jj & (kWave - 1));
           if (ok[u]) {
-            a[u] = alpha[static_cast<int64_t>(src) * H + h];
+            a[u] = alpha[static_cast<int64_t>(src) * lda + h];
             raw[u] = load_raw<T, VEC>(V + static_cast<int64_t>(src) * ldv + c0);
           }
         }
@@ -134,7 +134,7 @@ constexpr int kPmaFlatRows = 7;
 
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_fwd_flat_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha, int64_t lda,
     const T* __restrict__ V, int64_t ldv, float slope, T* __restrict__ out, int64_t ldo,
     float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C) {
   constexpr int NS = kWave / LPR;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_flat_kernel(
         a[u] = 0.f;
         raw[u] = zero_raw<T, VEC>();
         if (jj < n && active) {
-          a[u] = alpha[static_cast<int64_t>(src) * H + h];
+          a[u] = alpha[static_cast<int64_t>(src) * lda + h];
           raw[u] = load_raw<T, VEC>(V + static_cast<int64_t>(src) * ldv + c0);
         }
       }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void pma_attention_kernel(
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
     const T* __restrict__ out, int64_t ldo, const T* __restrict__ gout, int64_t ldg,
-    const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int n_t, int H, int C) {
+    const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int64_t lds, int n_t, int H, int C) {
   __shared__ float red[kWavesPerBlock][kMaxHeads];
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int wave = threadIdx.x >> 6;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_stats_kernel(
     float2 s;
     s.x = lv > 0.f ? m[th] + __logf(lv + kSoftmaxEps) : FLT_MAX;   // empty target: never gathered; exp(a - FLT_MAX) = 0
     s.y = red[wave][h];
-    *reinterpret_cast<float2*>(stats + th * 2) = s;
+    *reinterpret_cast<float2*>(stats + static_cast<int64_t>(row) * lds + h * 2) = s;
   }
 }
 
@@ -287,7 +287,7 @@ constexpr int kStatsRows = 4;
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_stats_flat_kernel(
     const T* __restrict__ out, int64_t ldo, const T* __restrict__ gout, int64_t ldg,
-    const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int n_t, int H, int C) {
+    const float* __restrict__ m, const float* __restrict__ l, float* __restrict__ stats, int64_t lds, int n_t, int H, int C) {
   constexpr int NS = kWave / LPR;
   const int lane = lane_id();
   const int slot = lane / LPR, li = lane % LPR;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_stats_flat_kernel(
       float2 st;
       st.x = lv > 0.f ? m[th] + __logf(lv + kSoftmaxEps) : FLT_MAX;
       st.y = part;
-      *reinterpret_cast<float2*>(stats + th * 2) = st;
+      *reinterpret_cast<float2*>(stats + (row0 + r) * lds + h * 2) = st;
     }
   }
 }
@@ -331,7 +331,7 @@ template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
     const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
     const T* __restrict__ V, int64_t ldv, const T* __restrict__ gout, int64_t ldg,
-    const float* __restrict__ stats, float slope, T* __restrict__ gV, int64_t ldgv,
+    const float* __restrict__ stats, int64_t lds, float slope, T* __restrict__ gV, int64_t ldgv,
     float* __restrict__ galpha, int n_s, int H, int C, const int32_t* __restrict__ row_order) {
   constexpr int NS = kWave / LPR;
   __shared__ float red[kWavesPerBlock][kMaxHeads];
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_kernel(
           const int t = __shfl(my_col, jj & (kWave - 1));
           if (ok[u]) {
             g[u] = load_raw<T, VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
-            st[u] = *reinterpret_cast<const float2*>(stats + (static_cast<int64_t>(t) * H + h) * 2);
+            st[u] = *reinterpret_cast<const float2*>(stats + static_cast<int64_t>(t) * lds + h * 2);
           }
         }
 #pragma unroll
@@ -432,7 +432,7 @@ template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
     const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
     const T* __restrict__ V, int64_t ldv, const T* __restrict__ gout, int64_t ldg,
-    const float* __restrict__ stats, float slope, T* __restrict__ gV, int64_t ldgv,
+    const float* __restrict__ stats, int64_t lds, float slope, T* __restrict__ gV, int64_t ldgv,
     float* __restrict__ galpha, int n_s, int H, int C) {
   constexpr int NS = kWave / LPR;
   constexpr int R = kPmaFlatRows;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
         st[u] = make_float2(0.f, 0.f);
         if (jj < n && active) {
           g[u] = load_raw<T, VEC>(gout + static_cast<int64_t>(t) * ldg + c0);
-          st[u] = *reinterpret_cast<const float2*>(stats + (static_cast<int64_t>(t) * H + h) * 2);
+          st[u] = *reinterpret_cast<const float2*>(stats + static_cast<int64_t>(t) * lds + h * 2);
         }
       }
 #pragma unroll
@@ -622,26 +622,34 @@ __global__ __launch_bounds__(kBlock) void pma_merge_pack_kernel(
 using namespace allset;
 
 static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptr,
-                        const int32_t* col, const float* alpha, const void* V, int64_t ldv, float slope, void* out,
+                        const int32_t* col, const float* alpha, int64_t lda, const void* V, int64_t ldv, float slope, void* out,
                         int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
 
 extern "C" int allset_pma_fwd(int dtype, const int32_t* rowptr, const int32_t* col, const float* alpha,
                               const void* V, int64_t ldv, float slope, void* out, int64_t ldo, float* m, float* l,
                               int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
-  return pma_fwd_impl(dtype, 0, -1, nullptr, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+  return pma_fwd_impl(dtype, 0, -1, nullptr, rowptr, col, alpha, H, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
 }
 
 extern "C" int allset_pma_fwd_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptr,
                                  const int32_t* col, const float* alpha, const void* V, int64_t ldv, float slope,
                                  void* out, int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H,
                                  int64_t C, void* stream) {
-  return pma_fwd_impl(dtype, variant, nnz, row_order, rowptr, col, alpha, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+  return pma_fwd_impl(dtype, variant, nnz, row_order, rowptr, col, alpha, H, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
+}
+
+extern "C" int allset_pma_fwd_ld(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptr,
+                                 const int32_t* col, const float* alpha, int64_t lda, const void* V, int64_t ldv, float slope,
+                                 void* out, int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H,
+                                 int64_t C, void* stream) {
+  return pma_fwd_impl(dtype, variant, nnz, row_order, rowptr, col, alpha, lda, V, ldv, slope, out, ldo, m, l, n_t, n_s, H, C, stream);
 }
 
 static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptr,
-                        const int32_t* col, const float* alpha, const void* V, int64_t ldv, float slope, void* out,
+                        const int32_t* col, const float* alpha, int64_t lda, const void* V, int64_t ldv, float slope, void* out,
                         int64_t ldo, float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream) {
   clear_error();
+  ALLSET_REQUIRE(lda >= H, "pma_fwd: logit leading dimension smaller than H");
   ALLSET_REQUIRE(variant >= 0 && variant <= 2, "pma_fwd: bad variant %d", variant);
   int rc = check_pma_dims("pma_fwd", n_t, n_s, H, C);
   if (rc != ALLSET_OK) return rc;
@@ -665,7 +673,7 @@ static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t*
     const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kPmaFlatRows;
     const unsigned fgrid = static_cast<unsigned>((n_t + rows_per_block - 1) / rows_per_block);
 #define ALLSET_PMA_FLAT(T, WIDE, LPRV)                                                                              \
-  pma_fwd_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptr, col, alpha, static_cast<const T*>(V), ldv, slope, \
+  pma_fwd_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptr, col, alpha, lda, static_cast<const T*>(V), ldv, slope, \
                                                                static_cast<T*>(out), ldo, m, l, static_cast<int>(n_t),   \
                                                                static_cast<int>(H), static_cast<int>(C))
     if (dtype == ALLSET_F32) {
@@ -680,10 +688,10 @@ static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t*
     return ALLSET_OK;
   }
   if (dtype == ALLSET_F32)
-    ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, float, 4, row_grid(n_t), st, rowptr, col, alpha, static_cast<const float*>(V), ldv, slope,
+    ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, float, 4, row_grid(n_t), st, rowptr, col, alpha, lda, static_cast<const float*>(V), ldv, slope,
                           static_cast<float*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C), row_order);
   else
-    ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, bf16_t, 8, row_grid(n_t), st, rowptr, col, alpha, static_cast<const bf16_t*>(V), ldv, slope,
+    ALLSET_PMA_DISPATCH_T(pma_fwd_kernel, bf16_t, 8, row_grid(n_t), st, rowptr, col, alpha, lda, static_cast<const bf16_t*>(V), ldv, slope,
                           static_cast<bf16_t*>(out), ldo, m, l, static_cast<int>(n_t), static_cast<int>(H), static_cast<int>(C), row_order);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
@@ -701,10 +709,25 @@ extern "C" int allset_pma_attention(const int32_t* rowptr, const int32_t* col, c
   return ALLSET_OK;
 }
 
+static int pma_bwd_stats_impl(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg, const float* m,
+                              const float* l, float* stats, int64_t lds, int64_t n_t, int64_t H, int64_t C, void* stream);
+
 extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg,
                                     const float* m, const float* l, float* stats, int64_t n_t, int64_t H, int64_t C,
                                     void* stream) {
+  return pma_bwd_stats_impl(dtype, out, ldo, gout, ldg, m, l, stats, 2 * H, n_t, H, C, stream);
+}
+
+extern "C" int allset_pma_bwd_stats_ld(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg,
+                                       const float* m, const float* l, float* stats, int64_t lds, int64_t n_t, int64_t H,
+                                       int64_t C, void* stream) {
+  return pma_bwd_stats_impl(dtype, out, ldo, gout, ldg, m, l, stats, lds, n_t, H, C, stream);
+}
+
+static int pma_bwd_stats_impl(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg, const float* m,
+                              const float* l, float* stats, int64_t lds, int64_t n_t, int64_t H, int64_t C, void* stream) {
   clear_error();
+  ALLSET_REQUIRE(lds >= 2 * H && lds % 2 == 0, "pma_bwd_stats: stats leading dimension must be even and >= 2H");
   int rc = check_pma_dims("pma_bwd_stats", n_t, 0, H, C);
   if (rc != ALLSET_OK) return rc;
   ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_bwd_stats: bad dtype %d", dtype);
@@ -722,7 +745,7 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
     const unsigned fgrid = static_cast<unsigned>((n_t + rows_per_block - 1) / rows_per_block);
 #define ALLSET_PMA_STATS(T, WIDE, LPRV)                                                                               \
   pma_bwd_stats_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(static_cast<const T*>(out), ldo,                   \
-                                                                     static_cast<const T*>(gout), ldg, m, l, stats,     \
+                                                                     static_cast<const T*>(gout), ldg, m, l, stats, lds, \
                                                                      static_cast<int>(n_t), static_cast<int>(H),        \
                                                                      static_cast<int>(C))
     if (dtype == ALLSET_F32) {
@@ -738,11 +761,11 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
   }
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_bwd_stats_kernel, float, 4, row_grid(n_t), st, static_cast<const float*>(out), ldo,
-                          static_cast<const float*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
+                          static_cast<const float*>(gout), ldg, m, l, stats, lds, static_cast<int>(n_t), static_cast<int>(H),
                           static_cast<int>(C));
   else
     ALLSET_PMA_DISPATCH_T(pma_bwd_stats_kernel, bf16_t, 8, row_grid(n_t), st, static_cast<const bf16_t*>(out), ldo,
-                          static_cast<const bf16_t*>(gout), ldg, m, l, stats, static_cast<int>(n_t), static_cast<int>(H),
+                          static_cast<const bf16_t*>(gout), ldg, m, l, stats, lds, static_cast<int>(n_t), static_cast<int>(H),
                           static_cast<int>(C));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
@@ -750,14 +773,14 @@ extern "C" int allset_pma_bwd_stats(int dtype, const void* out, int64_t ldo, con
 
 static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptrT,
                             const int32_t* colT, const float* alpha, const void* V, int64_t ldv, const void* gout,
-                            int64_t ldg, const float* stats, float slope, void* gV, int64_t ldgv, float* galpha,
+                            int64_t ldg, const float* stats, int64_t lds, float slope, void* gV, int64_t ldgv, float* galpha,
                             int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream);
 
 extern "C" int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT, const float* alpha,
                                   const void* V, int64_t ldv, const void* gout, int64_t ldg, const float* stats,
                                   float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t,
                                   int64_t H, int64_t C, void* stream) {
-  return pma_bwd_src_impl(dtype, 0, -1, nullptr, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+  return pma_bwd_src_impl(dtype, 0, -1, nullptr, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, 2 * H, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
 }
 
 extern "C" int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order,
@@ -765,15 +788,24 @@ extern "C" int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const 
                                      int64_t ldv, const void* gout, int64_t ldg, const float* stats, float slope,
                                      void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t, int64_t H,
                                      int64_t C, void* stream) {
-  return pma_bwd_src_impl(dtype, variant, nnz, row_order, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+  return pma_bwd_src_impl(dtype, variant, nnz, row_order, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, 2 * H, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
+}
+
+extern "C" int allset_pma_bwd_src_ld(int dtype, int variant, int64_t nnz, const int32_t* row_order,
+                                     const int32_t* rowptrT, const int32_t* colT, const float* alpha, const void* V,
+                                     int64_t ldv, const void* gout, int64_t ldg, const float* stats, int64_t lds, float slope,
+                                     void* gV, int64_t ldgv, float* galpha, int64_t n_s, int64_t n_t, int64_t H,
+                                     int64_t C, void* stream) {
+  return pma_bwd_src_impl(dtype, variant, nnz, row_order, rowptrT, colT, alpha, V, ldv, gout, ldg, stats, lds, slope, gV, ldgv, galpha, n_s, n_t, H, C, stream);
 }
 
 static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int32_t* row_order, const int32_t* rowptrT,
                             const int32_t* colT, const float* alpha, const void* V, int64_t ldv, const void* gout,
-                            int64_t ldg, const float* stats, float slope, void* gV, int64_t ldgv, float* galpha,
+                            int64_t ldg, const float* stats, int64_t lds, float slope, void* gV, int64_t ldgv, float* galpha,
                             int64_t n_s, int64_t n_t, int64_t H, int64_t C, void* stream) {
   clear_error();
   ALLSET_REQUIRE(variant >= 0 && variant <= 2, "pma_bwd_src: bad variant %d", variant);
+  ALLSET_REQUIRE(lds >= 2 * H && lds % 2 == 0, "pma_bwd_src: stats leading dimension must be even and >= 2H");
   int rc = check_pma_dims("pma_bwd_src", n_s, n_t, H, C);
   if (rc != ALLSET_OK) return rc;
   ALLSET_REQUIRE(dtype == ALLSET_F32 || dtype == ALLSET_BF16, "pma_bwd_src: bad dtype %d", dtype);
@@ -798,7 +830,7 @@ static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int3
     const unsigned fgrid = static_cast<unsigned>((n_s + rows_per_block - 1) / rows_per_block);
 #define ALLSET_PMA_FLATB(T, WIDE, LPRV)                                                                                  \
   pma_bwd_src_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptrT, colT, alpha, static_cast<const T*>(V), ldv,   \
-                                                                   static_cast<const T*>(gout), ldg, stats, slope,         \
+                                                                   static_cast<const T*>(gout), ldg, stats, lds, slope,    \
                                                                    static_cast<T*>(gV), ldgv, galpha, static_cast<int>(n_s), \
                                                                    static_cast<int>(H), static_cast<int>(C))
     if (dtype == ALLSET_F32) {
@@ -814,11 +846,11 @@ static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int3
   }
   if (dtype == ALLSET_F32)
     ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, float, 4, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const float*>(V), ldv,
-                          static_cast<const float*>(gout), ldg, stats, slope, static_cast<float*>(gV), ldgv, galpha,
+                          static_cast<const float*>(gout), ldg, stats, lds, slope, static_cast<float*>(gV), ldgv, galpha,
                           static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C), row_order);
   else
     ALLSET_PMA_DISPATCH_T(pma_bwd_src_kernel, bf16_t, 8, row_grid(n_s), st, rowptrT, colT, alpha, static_cast<const bf16_t*>(V), ldv,
-                          static_cast<const bf16_t*>(gout), ldg, stats, slope, static_cast<bf16_t*>(gV), ldgv, galpha,
+                          static_cast<const bf16_t*>(gout), ldg, stats, lds, slope, static_cast<bf16_t*>(gV), ldgv, galpha,
                           static_cast<int>(n_s), static_cast<int>(H), static_cast<int>(C), row_order);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;

@@ -118,13 +118,37 @@ def deepsets_aggregate(x: Tensor, inc: Incidence, norm: Optional[Tensor] = None,
     return _SegReduce.apply(x, w_dst, w_src, inc, REDUCE_CODES[aggr])
 
 
+def _colocate(V: Tensor, heads: int) -> bool:
+    """Feature rows of at most half a cache line (the column-sharded layer's d/P slices): put the per-row scalars the
+    kernels gather -- logits forward, (M, delta) backward -- into the same 128-byte line as the row, so an incidence
+    costs one cache-line request instead of two (profiles/r01_colshard_kernels.txt)."""
+    row = V.shape[1] * V.element_size()
+    return V.is_cuda and row % 16 == 0 and row + 8 * heads <= 128 and row <= 64 and V.shape[0] >= 4096
+
+
+def _beside(rows: Tensor, small_cols: int) -> Tuple[Tensor, Tensor]:
+    """A 128-byte-pitched buffer holding a copy of ``rows`` [n, d] and room for ``small_cols`` float32 per row behind it.
+    Returns (view of the row copy [n, d], float32 view [n, small_cols]) -- both row-strided views of the one buffer."""
+    n, d = rows.shape
+    rb = d * rows.element_size()
+    buf = torch.empty((n, 128), dtype=torch.uint8, device=rows.device)
+    rv = buf[:, :rb].view(rows.dtype)
+    rv.copy_(rows)
+    return rv, buf[:, rb:rb + 4 * small_cols].view(torch.float32)
+
+
 class _PmaAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, V: Tensor, alpha: Tensor, inc: Incidence, heads: int, slope: float):
         csr = inc.by_dst
-        out, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
+        split = _split(csr, V, heads)
+        Vg, ag = V, alpha
+        if _colocate(V, heads) and split <= 0:
+            Vg, ag = _beside(V, heads)
+            ag.copy_(alpha)
+        out, m, l = ops.pma_fwd(csr.rowptr, csr.col, ag, Vg, heads, slope, inc.n_dst,
                                 variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order,
-                                split=_split(csr, V, heads))
+                                split=split)
         ctx.inc, ctx.slope = inc, slope
         ctx.save_for_backward(V, alpha, out, m, l)
         ctx.mark_non_differentiable(m, l)
@@ -136,10 +160,16 @@ class _PmaAggregate(torch.autograd.Function):
         V, alpha, out, m, l = ctx.saved_tensors
         T = ctx.inc.by_src
         gout = gout.contiguous()
-        stats = ops.pma_bwd_stats(out, gout, m, l)
+        H = alpha.shape[1]
+        split = _split(T, V, H)
+        if _colocate(gout, H) and split <= 0:
+            gout, sv = _beside(gout, 2 * H)
+            stats = ops.pma_bwd_stats(out, gout, m, l, stats=sv.unflatten(1, (H, 2)))
+        else:
+            stats = ops.pma_bwd_stats(out, gout, m, l)
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, ctx.slope,
-                                     variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]),
-                                     row_order=T.row_order, split=_split(T, V, alpha.shape[1]))
+                                     variant=_variant(T, "pma_bwd_src", V.shape[0], V, H),
+                                     row_order=T.row_order, split=split)
         return gV, galpha, None, None, None
 
 

@@ -279,7 +279,8 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
     es = V.element_size()
     _f32(alpha, "pma_fwd logits")
     V = _rowmajor(V)
-    alpha = alpha.contiguous()
+    if alpha.dim() != 2 or (alpha.shape[1] > 1 and alpha.stride(1) != 1) or 0 < split:
+        alpha = alpha.contiguous()           # (a row-strided view is fine: the logits may sit beside the V rows)
     n_s, d = V.shape
     if d % heads != 0 or alpha.shape != (n_s, heads):
         raise _lib.AllSetHipError(f"pma_fwd: V {tuple(V.shape)} / alpha {tuple(alpha.shape)} inconsistent with heads={heads}")
@@ -299,9 +300,10 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
                                         ptr(out[split:]), max(d, 1), ptr(m[split:]), ptr(l[split:]), n_t - split, n_s, heads,
                                         d // heads, stream_of(dev)), "allset_pma_fwd_ex")
         else:
-            check(lib.allset_pma_fwd_ex(code, variant, col.numel(), ptr(row_order), ptr(rowptr), ptr(col), ptr(alpha), ptr(V), _ld(V),
-                                        slope, ptr(out), max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads,
-                                        stream_of(dev)), "allset_pma_fwd_ex")
+            lda = alpha.stride(0) if n_s > 1 else heads
+            check(lib.allset_pma_fwd_ld(code, variant, col.numel(), ptr(row_order), ptr(rowptr), ptr(col), ptr(alpha), lda, ptr(V),
+                                        _ld(V), slope, ptr(out), max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads,
+                                        stream_of(dev)), "allset_pma_fwd_ld")
     return out, m, l
 
 
@@ -315,7 +317,9 @@ def pma_attention(rowptr: Tensor, col: Tensor, alpha: Tensor, m: Tensor, l: Tens
     return p
 
 
-def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
+def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor, stats: Optional[Tensor] = None) -> Tensor:
+    """``stats`` (optional): a float32 [n_t, H, 2] destination, possibly a row-strided view (e.g. beside a copy of the
+    ``gout`` rows, see ``pma_bwd_src``)."""
     dev = require_device(out, gout, m, l)
     code = _dtype_code(out, "pma_bwd_stats")
     if gout.dtype != out.dtype:
@@ -324,12 +328,16 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor) -> Tensor:
     out, gout = _rowmajor(out), _rowmajor(gout)
     n_t, d = out.shape
     heads = m.shape[1]
-    stats = torch.empty((n_t, heads, 2), dtype=torch.float32, device=dev)
+    if stats is None:
+        stats = torch.empty((n_t, heads, 2), dtype=torch.float32, device=dev)
+    elif stats.shape != (n_t, heads, 2) or stats.dtype != torch.float32 or stats.stride(2) != 1 or stats.stride(1) != 2:
+        raise _lib.AllSetHipError("pma_bwd_stats: stats must be float32 [n_t, H, 2] with contiguous rows")
+    lds = stats.stride(0) if n_t > 1 else 2 * heads
     algo = n_t * (2 * d * es + 8 * heads + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_stats", dev, algo):
-        check(_lib.load().allset_pma_bwd_stats(code, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m), ptr(l),
-                                               ptr(stats), n_t, heads, d // heads, stream_of(dev)),
-              "allset_pma_bwd_stats")
+        check(_lib.load().allset_pma_bwd_stats_ld(code, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m.contiguous()),
+                                                  ptr(l.contiguous()), ptr(stats), lds, n_t, heads, d // heads, stream_of(dev)),
+              "allset_pma_bwd_stats_ld")
     return stats
 
 
@@ -348,6 +356,10 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
     heads = alpha.shape[1]
     gV = torch.empty((n_s, d), dtype=V.dtype, device=dev)
     galpha = torch.empty((n_s, heads), dtype=torch.float32, device=dev)
+    stats = stats.view(n_t, heads, 2) if stats.is_contiguous() else stats
+    if (stats.dim() != 3 or stats.stride(2) != 1 or stats.stride(1) != 2 or 0 < split < n_s):
+        stats = stats.contiguous().view(n_t, heads, 2)           # (a row-strided view is fine: stats may sit beside gout rows)
+    lds = stats.stride(0) if n_t > 1 else 2 * heads
     algo = colT.numel() * (es * d + 4 + 8 * heads) + (n_s + 1) * 4 + n_s * (2 * d * es + 8 * heads)
     with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
         if row_order is not None and row_order.numel() != n_s:
@@ -362,10 +374,10 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
                                             max(d, 1), ptr(galpha[split:]), n_s - split, n_t, heads, d // heads, stream_of(dev)),
                   "allset_pma_bwd_src_ex")
         else:
-            check(lib.allset_pma_bwd_src_ex(code, variant, colT.numel(), ptr(row_order), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
-                                            _ld(V), ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV), max(d, 1),
+            check(lib.allset_pma_bwd_src_ld(code, variant, colT.numel(), ptr(row_order), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
+                                            _ld(V), ptr(gout), _ld(gout), ptr(stats), lds, slope, ptr(gV), max(d, 1),
                                             ptr(galpha), n_s, n_t, heads, d // heads, stream_of(dev)),
-                  "allset_pma_bwd_src_ex")
+                  "allset_pma_bwd_src_ld")
     return gV, galpha
 
 

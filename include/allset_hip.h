@@ -240,6 +240,21 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                        const uint32_t* mask, void* stream);
 
+/* allset_pma_fwd_ex / allset_pma_bwd_stats / allset_pma_bwd_src_ex with explicit leading dimensions for the small per-row
+ * operands the kernels GATHER next to a feature row: the logits (`lda` floats between rows, >= H) and the backward
+ * statistics (`lds` floats between rows, even, >= 2H; stats 8-byte aligned).  A caller whose feature rows are narrower
+ * than a cache line (the column-sharded layer: d/P columns) interleaves [V row | logits] and [gout row | stats] in one
+ * 128-byte-pitched buffer and passes pointers into it, so each incidence costs one cache-line request instead of two. */
+int allset_pma_fwd_ld(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptr, const int32_t* col,
+                      const float* alpha, int64_t lda, const void* V, int64_t ldv, float slope, void* out, int64_t ldo,
+                      float* m, float* l, int64_t n_t, int64_t n_s, int64_t H, int64_t C, void* stream);
+int allset_pma_bwd_stats_ld(int dtype, const void* out, int64_t ldo, const void* gout, int64_t ldg, const float* m,
+                            const float* l, float* stats, int64_t lds, int64_t n_t, int64_t H, int64_t C, void* stream);
+int allset_pma_bwd_src_ld(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptrT,
+                          const int32_t* colT, const float* alpha, const void* V, int64_t ldv, const void* gout, int64_t ldg,
+                          const float* stats, int64_t lds, float slope, void* gV, int64_t ldgv, float* galpha, int64_t n_s,
+                          int64_t n_t, int64_t H, int64_t C, void* stream);
+
 /* Layout change around the all-to-all of the column-sharded layer (allset_amd/dist.py; no reference counterpart -- the
  * reference is single-device).  A row-major matrix of `rows` rows whose row holds P column blocks of
  * `block_bytes` (a multiple of 16) each, leading dimension `ld_bytes`, and the block-major buffer [P][rows][block_bytes]

@@ -425,3 +425,32 @@ def test_block_transpose_is_the_permute_copy(rows, P, dc, dtype, device):
     back = ops.block_transpose(packed, P, False)
     assert torch.equal(back, x)
     assert not ops.block_transpose_supported(torch.zeros(4, 6, device=device), 2, True)       # 12-byte blocks
+
+
+@pytest.mark.parametrize("d,H,dtype", [(16, 1, torch.float32), (8, 2, torch.float32), (16, 4, torch.float32), (32, 1, torch.bfloat16),
+                                       (4, 1, torch.float32)])
+def test_pma_colocated_operands_are_bitwise_the_plain_path(d, H, dtype, device, monkeypatch):
+    """Narrow feature rows (the column-sharded layer): logits / backward statistics interleaved with the rows in one
+    128-byte-pitched buffer (row-strided operands through the *_ld entry points) -- same kernels, same arithmetic: the
+    results must be bit-identical to the separate-table path, forward and backward."""
+    import numpy as np
+    from allset_amd import Incidence, functional as AF
+    rng = np.random.default_rng(d * 10 + H)
+    n_s, n_t, nnz = 6000, 5000, 60_000
+    ei = torch.unique(torch.stack([torch.from_numpy(rng.integers(0, n_s, nnz)), torch.from_numpy(rng.integers(0, n_t, nnz))]), dim=1).to(device)
+    inc = Incidence.from_edge_index(ei, n_src=n_s, n_dst=n_t)
+    V = torch.randn(n_s, d, device=device).to(dtype)
+    alpha = torch.randn(n_s, H, device=device)
+    G = torch.randn(n_t, d, device=device).to(dtype)
+    res = []
+    for colocate in (True, False):
+        if not colocate:
+            monkeypatch.setattr(AF, "_colocate", lambda V, heads: False)
+        else:
+            assert AF._colocate(V, H)
+        v, a = V.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+        out, m, l = AF.pma_aggregate(v, a, inc, H, 0.2)
+        (out.float() * G.float()).sum().backward()
+        res.append((out.detach(), m, l, v.grad, a.grad))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
