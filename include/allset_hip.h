@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 2   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack */
+#define ALLSET_ABI_VERSION 3   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose) */
 
 enum allset_status {
   ALLSET_OK = 0,
