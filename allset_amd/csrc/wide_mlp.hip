@@ -1,0 +1,388 @@
+// Linear layers wider than one LDS-resident weight (reference layers.py:571-579 with MLP_hidden 256 / 512, the widths of
+// src/run_AllSetTransformer.sh): a tiled GEMM on the bf16 matrix pipe with fp32-accurate arithmetic ("bf16x6", common.h).
+//
+//   out[r, n] = epi( sum_k pro(A)[r, k] * B[n, k] + bias[n] )          A: [rows, K] fp32,  B: [N, K] (weight, or its transpose)
+//
+// fused_mlp.hip keeps the three bf16 planes of a whole <=128 x 128 weight in LDS and streams rows past it; a 256 x 256
+// weight is 384 KB of planes, so here the weight streams too: a workgroup owns a 128-row x 256-column output tile (fp32
+// accumulators: 64 VGPRs per lane) and walks K in steps of 32, staging per step the A slab (split into planes on the fly,
+// with the prologue -- mask / relu / LayerNorm-apply / dropout -- applied per element as it passes) and the matching
+// 48 KB image of pre-split weight planes (allset_gemm_x6_planes lays them out exactly as the LDS wants them; 384 KB per
+// 256 x 256 weight, L2-resident).  Double-buffered: 144 KB of the 160 KB LDS, one workgroup of 8 waves per CU.
+// Per step and wave: 24 ds_read_b128 feed 96 MFMAs (16 accumulator tiles x 6 plane products) -- the kernel is meant to
+// be matrix-pipe-bound: 2*rows*N*K*6 flop at the bf16 rate is ~1.6x the HBM time of its operands at K = N = 256.
+#include "common.h"
+
+namespace allset {
+
+constexpr int kGxBM = 128, kGxBN = 256, kGxKS = 32, kGxThreads = 512;
+
+// LDS rows are 32 bf16 = four 16-byte pieces; an MFMA fragment read (ds_read_b128) has lane (fr = l & 15, fg = l >> 4) take
+// piece fg of row fr.  gfx950 services that instruction in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32 for
+// the upper half; MI355X_MICROARCH.md, LDS): per group 8 lanes of one piece on rows {0-3,12-15} and 8 lanes of the next
+// piece on rows {4-11}, and the 16 of them must land on the 16 distinct 16-byte slots of the 256-byte bank line.  Storing
+// piece p of row r at position p ^ h((r >> 2) & 3) with h = {0, 2, 3, 1} does exactly that (slot = 4 * (r & 3) + position).
+__host__ __device__ __forceinline__ int gx_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+using bf16x8_t = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+union GxFrag { uint4 u; bf16x8_t v; };
+
+// ---- weight planes: [n_tile][k_step][plane][256 n][32 k] bf16, zero-padded in n ------------------------------------------
+__global__ __launch_bounds__(kBlock) void gemm_x6_planes_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
+                                                                uint32_t* __restrict__ planes, int N, int K) {
+  const int n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
+  const int64_t pairs = static_cast<int64_t>(n_pad) * (K / 2);
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < pairs;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int n = static_cast<int>(idx / (K / 2));
+    const int k = 2 * static_cast<int>(idx - static_cast<int64_t>(n) * (K / 2));
+    float w0 = 0.f, w1 = 0.f;
+    if (n < N) {
+      if (transpose) { w0 = W[static_cast<int64_t>(k) * ldw + n]; w1 = W[static_cast<int64_t>(k + 1) * ldw + n]; }
+      else { w0 = W[static_cast<int64_t>(n) * ldw + k]; w1 = W[static_cast<int64_t>(n) * ldw + k + 1]; }
+    }
+    uint32_t ph, pm, pl;
+    split3_bf16(w0, w1, ph, pm, pl);
+    const int nt = n / kGxBN, nn = n % kGxBN, ks = k / kGxKS, kk = k % kGxKS;
+    const int64_t image = (static_cast<int64_t>(nt) * (K / kGxKS) + ks) * 3 * (kGxBN * kGxKS / 2);   // dwords
+    const int64_t at = image + nn * (kGxKS / 2) + (((kk >> 3) ^ gx_swz(nn)) << 2) + ((kk & 7) >> 1);   // swizzled piece
+    planes[at] = ph;
+    planes[at + kGxBN * kGxKS / 2] = pm;
+    planes[at + 2 * (kGxBN * kGxKS / 2)] = pl;
+  }
+}
+
+struct GxPro {
+  const float* y;          // backward: A = gy * (y > 0 ? 1/(1-p_mask) : 0), y [rows, K] (the forward's output); or NULL
+  int64_t ldy;
+  float p_mask;
+  int relu_in;
+  const float* stats;      // LayerNorm-apply: (a - mean) * rstd * gamma[k] + beta[k]; or NULL
+  const float* gamma;
+  const float* beta;
+  float p_in;              // dropout on the prologue's result, index r*K + k
+  uint64_t seed_in;
+};
+
+struct GxEpi {
+  const float* bias;       // [N] or NULL
+  int relu_out;
+  float p_out;             // dropout on the output, index r*N + n
+  uint64_t seed_out;
+};
+
+// Per-tile staging context of one thread: the row it stages (128 rows x 4 segments of 8 floats per K step).
+struct GxRow {
+  const float* a;          // A + row * lda + seg * 8 (row clamped: loads are unconditional)
+  const float* y;          // mask source, or NULL
+  int64_t g_row;
+  float mean, rstd;
+  bool ok;
+};
+
+template <bool HAS_Y>
+__global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
+    const float* __restrict__ A, int64_t lda, GxPro pro, const uint4* __restrict__ planes, GxEpi epi,
+    float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base) {
+  // one arena: A slabs [buffer][plane][row][32 bf16 = 4 x 16 B], B slabs likewise, and -- after the K loop -- the fp32
+  // output tile on its way from the MFMA layout to row-major 16-byte stores
+  constexpr int kASlab = 3 * kGxBM * 4, kBSlab = 3 * kGxBN * 4, kOutPitch = kGxBN + 4;
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * kASlab + 2 * kBSlab];
+  static_assert(sizeof(float) * kGxBM * kOutPitch <= sizeof(uint4) * (2 * kASlab + 2 * kBSlab), "output tile must fit the arena");
+  uint4 (*sA)[kASlab] = reinterpret_cast<uint4 (*)[kASlab]>(smem);
+  uint4 (*sB)[kBSlab] = reinterpret_cast<uint4 (*)[kBSlab]>(smem + 2 * kASlab);
+  float* sOut = reinterpret_cast<float*>(smem);
+  const int n_tiles = (N + kGxBN - 1) / kGxBN;
+  const int64_t total = (rows + kGxBM - 1) / kGxBM * n_tiles;           // tiles; a workgroup walks tiles b, b + grid, ...
+  const int ksteps = K / kGxKS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t seed_in = resolve_seed(seed_base, pro.seed_in), seed_out = resolve_seed(seed_base, epi.seed_out);
+  const float inv_mask = pro.p_mask > 0.f ? 1.f / (1.f - pro.p_mask) : 1.f;
+  const float inv_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
+  const uint32_t thr_in = drop_threshold(pro.p_in);
+  const float inv_out = epi.p_out > 0.f ? 1.f / (1.f - epi.p_out) : 1.f;
+  const uint32_t thr_out = drop_threshold(epi.p_out);
+
+  // ---- staging roles
+  const int s_row = tid >> 2, s_seg = tid & 3;
+  const int a_st = s_row * 4 + (s_seg ^ gx_swz(s_row));                 // swizzled 16-byte piece (gx_swz)
+  auto row_ctx = [&](int64_t tile) {
+    GxRow c;
+    const int64_t row0 = tile / n_tiles * kGxBM;
+    c.g_row = row0 + s_row;
+    c.ok = c.g_row < rows;
+    const int64_t cr = c.ok ? c.g_row : rows - 1;
+    c.a = A + cr * lda + s_seg * 8;
+    c.y = pro.y ? pro.y + cr * pro.ldy + s_seg * 8 : nullptr;
+    c.mean = 0.f; c.rstd = 1.f;
+    if (pro.stats) { c.mean = pro.stats[cr * 2]; c.rstd = pro.stats[cr * 2 + 1]; }
+    return c;
+  };
+
+  // One K step ahead of the MFMAs, in named registers -- not arrays: hipcc keeps indexed staging arrays in scratch, and a
+  // scratch store right behind the global load is a full wait, exactly the latency the prefetch hides.
+  float4 pa0, pa1, py0 = make_float4(1.f, 1.f, 1.f, 1.f), py1 = py0;
+  uint4 pb0, pb1, pb2, pb3, pb4, pb5;
+#define GX_LOAD(ctx_, img_base_, ks_)                                                           \
+  do {                                                                                          \
+    const int k0_ = (ks_) * kGxKS;                                                              \
+    pa0 = *reinterpret_cast<const float4*>((ctx_).a + k0_);                                     \
+    pa1 = *reinterpret_cast<const float4*>((ctx_).a + k0_ + 4);                                 \
+    if constexpr (HAS_Y) {                                                                      \
+      py0 = *reinterpret_cast<const float4*>((ctx_).y + k0_);                                   \
+      py1 = *reinterpret_cast<const float4*>((ctx_).y + k0_ + 4);                               \
+    }                                                                                           \
+    const uint4* img_ = (img_base_) + static_cast<int64_t>(ks_) * kBSlab + tid;                \
+    pb0 = img_[0]; pb1 = img_[kGxThreads]; pb2 = img_[2 * kGxThreads];                          \
+    pb3 = img_[3 * kGxThreads]; pb4 = img_[4 * kGxThreads]; pb5 = img_[5 * kGxThreads];         \
+  } while (0)
+
+  auto prologue2 = [&](const GxRow& c, float a0, float a1, float y0, float y1, int kk, float& o0, float& o1) {
+    if constexpr (HAS_Y) { a0 = y0 > 0.f ? a0 * inv_mask : 0.f; a1 = y1 > 0.f ? a1 * inv_mask : 0.f; }
+    if (pro.relu_in) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
+    if (pro.stats) {
+      const float2 g = *reinterpret_cast<const float2*>(pro.gamma + kk), b = *reinterpret_cast<const float2*>(pro.beta + kk);
+      a0 = fmaf((a0 - c.mean) * c.rstd, g.x, b.x);
+      a1 = fmaf((a1 - c.mean) * c.rstd, g.y, b.y);
+    }
+    if (pro.p_in > 0.f) {
+      float k0, k1;
+      keep_scale2(seed_in, c.g_row * K + kk, thr_in, inv_in, k0, k1);
+      a0 *= k0; a1 *= k1;
+    }
+    o0 = c.ok ? a0 : 0.f;
+    o1 = c.ok ? a1 : 0.f;
+  };
+#define GX_STORE(ctx_, ks_, buf_)                                                               \
+  do {                                                                                          \
+    const int kb_ = (ks_) * kGxKS + s_seg * 8;                                                  \
+    float e0, e1, e2, e3, e4, e5, e6, e7;                                                       \
+    prologue2(ctx_, pa0.x, pa0.y, py0.x, py0.y, kb_, e0, e1);                                   \
+    prologue2(ctx_, pa0.z, pa0.w, py0.z, py0.w, kb_ + 2, e2, e3);                               \
+    prologue2(ctx_, pa1.x, pa1.y, py1.x, py1.y, kb_ + 4, e4, e5);                               \
+    prologue2(ctx_, pa1.z, pa1.w, py1.z, py1.w, kb_ + 6, e6, e7);                               \
+    uint4 h_, m_, l_;                                                                           \
+    split3_bf16(e0, e1, h_.x, m_.x, l_.x);                                                      \
+    split3_bf16(e2, e3, h_.y, m_.y, l_.y);                                                      \
+    split3_bf16(e4, e5, h_.z, m_.z, l_.z);                                                      \
+    split3_bf16(e6, e7, h_.w, m_.w, l_.w);                                                      \
+    sA[buf_][a_st] = h_;                                                                        \
+    sA[buf_][kGxBM * 4 + a_st] = m_;                                                            \
+    sA[buf_][2 * kGxBM * 4 + a_st] = l_;                                                        \
+    sB[buf_][tid] = pb0; sB[buf_][tid + kGxThreads] = pb1; sB[buf_][tid + 2 * kGxThreads] = pb2; \
+    sB[buf_][tid + 3 * kGxThreads] = pb3; sB[buf_][tid + 4 * kGxThreads] = pb4;                 \
+    sB[buf_][tid + 5 * kGxThreads] = pb5;                                                       \
+  } while (0)
+
+  // ---- MFMA roles: wave (wr, wc) owns rows wr*64.., columns wc*64.. of the tile as 4 x 4 tiles of 16 x 16
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int sw = gx_swz(fr);                                           // tile rows start at multiples of 16
+  const int a_at = (wr * 64 + fr) * 4 + (fg ^ sw), b_at = (wc * 64 + fr) * 4 + (fg ^ sw);
+  // The two waves that share a SIMD (w and w + 4: waves are dealt to SIMDs cyclically) run a step's two halves in
+  // opposite order -- one multiplies out of the current buffers while the other splits and stores the next ones -- so the
+  // matrix pipe and the VALU / LDS-store path are busy at the same time instead of taking turns.
+  const bool mfma_first = wave < 4;
+  f32x4_t acc[4][4];
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {                                   // two row tiles at a time: 24 + 12 fragment registers
+      GxFrag a[2][3];
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[r2][p].u = sA[buf][p * kGxBM * 4 + a_at + (rh * 2 + r2) * 64];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        GxFrag b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p].u = sB[buf][p * kGxBN * 4 + b_at + ct * 64];
+        // smallest products first; consecutive MFMAs alternate between two accumulators
+#define GX_MFMA2(PA, PB)                                                                                                  \
+  acc[rh * 2][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][PA].v, b[PB].v, acc[rh * 2][ct], 0, 0, 0);               \
+  acc[rh * 2 + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][PA].v, b[PB].v, acc[rh * 2 + 1][ct], 0, 0, 0)
+        GX_MFMA2(1, 1); GX_MFMA2(2, 0); GX_MFMA2(0, 2); GX_MFMA2(1, 0); GX_MFMA2(0, 1); GX_MFMA2(0, 0);
+#undef GX_MFMA2
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  if (tile >= total) return;
+  GxRow cur = row_ctx(tile);
+  const uint4* img_cur = planes + static_cast<int64_t>(tile % n_tiles) * ksteps * kBSlab;
+  GX_LOAD(cur, img_cur, 0);
+  for (; tile < total; tile += gridDim.x) {
+    const int64_t next = tile + gridDim.x;
+    const bool has_next = next < total;
+    const GxRow nxt = row_ctx(has_next ? next : tile);                 // (stats of the next tile are in flight early)
+    const uint4* img_nxt = planes + static_cast<int64_t>((has_next ? next : tile) % n_tiles) * ksteps * kBSlab;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    GX_STORE(cur, 0, 0);                                               // step 0 of this tile (loaded during the previous one)
+    if (ksteps > 1) GX_LOAD(cur, img_cur, 1); else if (has_next) GX_LOAD(nxt, img_nxt, 0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+      // MFMAs out of buffer ks & 1; the registers (step ks + 1) go to the other buffer and reload with step ks + 2 --
+      // of the next tile when this one has no such step; the last step only multiplies (the arena turns into the output
+      // tile next, the registers keep the next tile's step 0).
+      const int buf = ks & 1;
+      const bool last = ks + 1 == ksteps;
+      if (mfma_first) compute(buf);
+      if (!last) {
+        GX_STORE(cur, ks + 1, buf ^ 1);
+        if (ks + 2 < ksteps) GX_LOAD(cur, img_cur, ks + 2); else if (has_next) GX_LOAD(nxt, img_nxt, 0);
+      }
+      if (!mfma_first) compute(buf);
+      // LDS traffic must have landed; the global loads just issued stay in flight ACROSS the barrier (__syncthreads()
+      // would drain them: s_waitcnt vmcnt(0), one exposed memory latency per step)
+      __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue.  lane holds acc[rt][ct][r] = tile[wr*64 + rt*16 + 4*fg + r][wc*64 + ct*16 + fr]: dword stores from
+    // that layout are issue-bound (~5 B/clk/CU), so the tile takes one trip through LDS (pitch 260 floats: the four row
+    // groups of a wave land on disjoint banks) and leaves as whole rows of 16-byte stores -- which then drain while the
+    // next tile's K loop runs; bias / relu / dropout on the row-major side.
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sOut[(wr * 64 + rt * 16 + 4 * fg + r) * kOutPitch + wc * 64 + ct * 16 + fr] = acc[rt][ct][r];
+    __syncthreads();
+    const int c4 = (tid & 63) * 4;
+    const int n = static_cast<int>(tile % n_tiles) * kGxBN + c4;
+    const int64_t row0 = tile / n_tiles * kGxBM;
+    if (n < N) {                                                       // N % 4 == 0: a packet is inside or outside
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (epi.bias) bv = *reinterpret_cast<const float4*>(epi.bias + n);
+      for (int rr = tid >> 6; rr < kGxBM; rr += kGxThreads / 64) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) break;
+        float4 v = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (epi.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (epi.p_out > 0.f) {
+          float k0, k1, k2, k3;
+          keep_scale2(seed_out, row * N + n, thr_out, inv_out, k0, k1);
+          keep_scale2(seed_out, row * N + n + 2, thr_out, inv_out, k2, k3);
+          v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
+        }
+        *reinterpret_cast<float4*>(out + row * ldo + n) = v;
+      }
+    }
+    __syncthreads();                                                   // the arena is free again
+    cur = nxt;
+    img_cur = img_nxt;
+  }
+#undef GX_LOAD
+#undef GX_STORE
+}
+
+// ---- row statistics for the LayerNorm-apply prologue: stats[r] = {mean, rstd} of relu_in ? relu(x[r]) : x[r] ----------------
+__global__ __launch_bounds__(kBlock) void row_stats_kernel(const float* __restrict__ x, int64_t ldx, int relu_in, float eps,
+                                                           float* __restrict__ stats, int64_t rows, int d) {
+  const int lane = lane_id();
+  const float inv_d = 1.f / static_cast<float>(d);
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6); row < rows;
+       row += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const float* p = x + row * ldx;
+    float4 v[2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = (lane + i * kWave) * 4;
+      v[i] = c < d ? *reinterpret_cast<const float4*>(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (relu_in) { v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f); }
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = (lane + i * kWave) * 4;
+      if (c < d) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+        q += a * a + b * b + cc * cc + e * e;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rsqrtf(q * inv_d + eps); }
+  }
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_gemm_x6_supported(int64_t N, int64_t K) {
+  return (N >= 1 && K >= kGxKS && K % kGxKS == 0 && K <= 4096 && N <= 4096 && N % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int64_t allset_gemm_x6_plane_bytes(int64_t N, int64_t K) {
+  if (!allset_gemm_x6_supported(N, K)) return -1;
+  return (N + kGxBN - 1) / kGxBN * kGxBN * K * 3 * 2;
+}
+
+extern "C" int allset_gemm_x6_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream) {
+  clear_error();
+  if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_x6_planes: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(W && planes && aligned16(planes), "gemm_x6_planes: null / misaligned pointer");
+  ALLSET_REQUIRE(ldw >= (transpose ? N : K), "gemm_x6_planes: leading dimension too small");
+  const int64_t pairs = (N + kGxBN - 1) / kGxBN * kGxBN * (K / 2);
+  const int64_t want = (pairs + kBlock - 1) / kBlock;
+  gemm_x6_planes_kernel<<<static_cast<unsigned>(want > 4096 ? 4096 : want), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      W, ldw, transpose, static_cast<uint32_t*>(planes), static_cast<int>(N), static_cast<int>(K));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_row_stats(const float* x, int64_t ldx, int relu_in, float eps, float* stats, int64_t rows, int64_t d,
+                                void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(rows >= 0 && d >= 4 && d <= 512 && d % 4 == 0, "row_stats: width must be a multiple of 4, <= 512");
+  if (rows == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && stats && ldx >= d && ldx % 4 == 0 && aligned16(x), "row_stats: bad pointer / leading dimension");
+  const int64_t want = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
+  row_stats_kernel<<<static_cast<unsigned>(want > 65536 ? 65536 : want), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      x, ldx, relu_in, eps, stats, rows, static_cast<int>(d));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
+                              const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                              const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
+                              float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base,
+                              void* stream) {
+  clear_error();
+  if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_x6: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(rows >= 0, "gemm_x6: bad row count");
+  ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f && p_mask >= 0.f && p_mask < 1.f, "gemm_x6: dropout p must be in [0,1)");
+  if (rows == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(A && planes && out, "gemm_x6: null pointer");
+  ALLSET_REQUIRE(lda >= K && lda % 4 == 0 && aligned16(A) && aligned16(planes), "gemm_x6: A rows / planes must be 16-byte aligned");
+  ALLSET_REQUIRE(ldo >= N && ldo % 4 == 0 && aligned16(out) && (bias == nullptr || aligned16(bias)),
+                 "gemm_x6: output rows / bias must be 16-byte aligned");
+  ALLSET_REQUIRE(mask_y == nullptr || (ldy >= K && ldy % 4 == 0 && aligned16(mask_y)), "gemm_x6: mask source rows must be 16-byte aligned");
+  ALLSET_REQUIRE(stats == nullptr || (gamma && beta && aligned16(gamma) && aligned16(beta)), "gemm_x6: LayerNorm-apply needs gamma and beta (16-byte aligned)");
+  GxPro pro{mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in};
+  GxEpi epi{bias, relu_out, p_out, seed_out};
+  const int64_t tiles = (rows + kGxBM - 1) / kGxBM * ((N + kGxBN - 1) / kGxBN);
+  const int64_t blocks = tiles < 256 ? tiles : 256;                     // one workgroup per CU (144 KB of LDS), walking its tiles
+  if (mask_y)
+    gemm_x6_kernel<true><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base);
+  else
+    gemm_x6_kernel<false><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

@@ -178,6 +178,62 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
     return gw, gb
 
 
+# ---- wide Linear layers (csrc/wide_mlp.hip): tiled GEMM, fp32-accurate on the bf16 matrix pipe --------------------------
+
+def gemm_x6_supported(N: int, K: int) -> bool:
+    return bool(_lib.load().allset_gemm_x6_supported(N, K))
+
+
+def gemm_x6_planes(W: Tensor, transpose: bool) -> Tensor:
+    """Pre-split bf16 planes of ``B`` for :func:`gemm_x6`: ``B = W`` ([N, K]) or, with ``transpose``, ``B = W^T``
+    (``W`` [K, N]).  Returns an opaque uint8 buffer."""
+    dev = require_device(W)
+    _check_f32(W)
+    W = _rowmajor(W)
+    N, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
+    lib = _lib.load()
+    nbytes = int(lib.allset_gemm_x6_plane_bytes(N, K))
+    if nbytes < 0:
+        raise _lib.AllSetHipError(f"gemm_x6: N={N}, K={K} not supported (K % 32 == 0, N % 4 == 0)")
+    planes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.allset_gemm_x6_planes(ptr(W), _ld(W), int(transpose), ptr(planes), N, K, stream_of(dev)), "allset_gemm_x6_planes")
+    return planes
+
+
+def row_stats(x: Tensor, relu_in: bool, eps: float) -> Tensor:
+    """[n, 2] {mean, rstd} of the rows of ``relu_in ? relu(x) : x`` -- the LayerNorm-apply prologue's input."""
+    dev = require_device(x)
+    _check_f32(x)
+    x = _rowmajor(x)
+    n, d = x.shape
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("row_stats", dev, n * d * 4):
+        check(_lib.load().allset_row_stats(ptr(x), _ld(x), int(relu_in), eps, ptr(stats), n, d, stream_of(dev)), "allset_row_stats")
+    return stats
+
+
+def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *, mask_y: Optional[Tensor] = None,
+            p_mask: float = 0.0, relu_in: bool = False, stats: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
+            beta: Optional[Tensor] = None, p_in: float = 0.0, seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0,
+            seed_out: int = 0, seed_base: Optional[Tensor] = None) -> Tensor:
+    """``out = epi(pro(A) @ B^T + bias)`` with ``B`` given as :func:`gemm_x6_planes` (include/allset_hip.h allset_gemm_x6)."""
+    dev = require_device(A, planes, bias, mask_y, stats, gamma, beta)
+    _check_f32(A, bias, mask_y, stats, gamma, beta)
+    A = _rowmajor(A)
+    n, K = A.shape
+    if mask_y is not None:
+        mask_y = _rowmajor(mask_y)
+    out = torch.empty((n, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("gemm_x6", dev, n * (K + N) * 4):
+        check(_lib.load().allset_gemm_x6(
+            ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, int(relu_in), ptr(stats),
+            ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None), p_in,
+            seed_in, ptr(planes), ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out,
+            ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_x6")
+    return out
+
+
 def fused_linear_supported(K: int, N: int) -> bool:
     return bool(_lib.load().allset_fused_linear_supported(K, N))
 
@@ -407,6 +463,62 @@ class _FusedNormLinear(torch.autograd.Function):
         return gx, dg, db, gw, gb, None, None, None, None, None
 
 
+class _WideNormLinear(torch.autograd.Function):
+    """The same layer as :class:`_FusedNormLinear` for widths beyond the LDS-resident-weight kernels (256, 512):
+    forward = row statistics + one tiled bf16x6 GEMM with the prologue applied as the A operand is staged and the epilogue
+    on the output tile (csrc/wide_mlp.hip); backward = the same GEMM against W^T with the epilogue mask applied to the
+    incoming gradient, the LayerNorm-backward kernel, and the split-K weight gradient with both operands recomputed."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out):
+        seed_in = _draw_seed() if p_in > 0.0 else 0
+        seed_out = _draw_seed() if p_out > 0.0 else 0
+        base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
+        stats = row_stats(x, relu_in, eps) if gamma is not None else None
+        y = gemm_x6(x, gemm_x6_planes(weight, False), weight.shape[0], bias, relu_in=relu_in, stats=stats, gamma=gamma,
+                    beta=beta, p_in=p_in, seed_in=seed_in, relu_out=relu_out, p_out=p_out, seed_out=seed_out, seed_base=base)
+        keep_y = relu_out or p_out > 0.0
+        ctx.save_for_backward(x, stats, gamma, beta, weight, y if keep_y else None)
+        ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, stats, gamma, beta, weight, y = ctx.saved_tensors
+        relu_in, p_in, seed_in, p_out, has_bias, base = ctx.cfg
+        gy = gy.contiguous()
+        gx = dg = db = gw = gb = None
+        need_b = has_bias and ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[3] or need_b:
+            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b, seed_base=base)
+        need_x = ctx.needs_input_grad[0]
+        if need_x or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
+            # gradient of the Linear's input u = dropout(LN(relu(x))): (gy * epilogue mask) @ W
+            gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out)
+            if gamma is not None:
+                gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x)
+            elif relu_in:                       # (p_in == 0 here, see wide_linear_supported): mask by the sign of x
+                gx = torch.empty_like(x)
+                with torch.cuda.device(x.device), _timed("relu_dropout_bwd", x.device, 3 * x.numel() * 4):
+                    check(_lib.load().allset_relu_dropout_bwd(ptr(gu), ptr(x.contiguous()), 0.0, ptr(gx), x.numel(),
+                                                              stream_of(x.device)), "allset_relu_dropout_bwd")
+            else:
+                gx = gu
+        return gx, dg, db, gw, gb, None, None, None, None, None
+
+
+def wide_linear_supported(K: int, N: int, has_ln: bool, relu_in: bool = False, p_in: float = 0.0) -> bool:
+    """The tiled bf16x6 GEMM path takes this layer: widths the LDS-resident kernels do not cover, K a multiple of 32,
+    LayerNorm rows of at most 512, and no input dropout without a LayerNorm (its mask is regenerated by the LayerNorm
+    backward kernel)."""
+    if fused_linear_supported(K, N) or not x6_active() or not gemm_x6_supported(N, K) or not gemm_x6_supported(K, N):
+        return False
+    if has_ln:
+        return K <= 512 and K % 4 == 0
+    return p_in == 0.0
+
+
 def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
                       eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0, relu_out: bool = False,
                       p_out: float = 0.0) -> Tensor:
@@ -414,8 +526,9 @@ def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor]
         # the backward recovers the epilogue mask from the sign of y, which is only right behind a relu (MLP._post is
         # always relu -> dropout, reference layers.py:575-577)
         raise _lib.AllSetHipError("fused_norm_linear: an output dropout needs relu_out=True")
-    return _FusedNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out),
-                                  float(p_out))
+    N, K = weight.shape
+    fn = _FusedNormLinear if fused_linear_supported(K, N) else _WideNormLinear
+    return fn.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out), float(p_out))
 
 
 def ln_res_supported(d: int, dtype: torch.dtype = torch.float32) -> bool:

@@ -117,10 +117,21 @@ class MLP(nn.Module):
         kernel is built for, LayerNorm/None normalisation (BatchNorm stays on torch)."""
         if not _on_hip(x) or x.dim() != 2:
             return False
-        for lin in self.lins:
-            if not dense.fused_linear_supported(lin.in_features, lin.out_features) or lin.bias is None:
+        if not all(isinstance(nm, (nn.LayerNorm, nn.Identity)) for nm in self.normalizations):
+            return False
+        p = float(self.dropout) if self.training else 0.0
+        for i, lin in enumerate(self.lins):
+            if lin.bias is None:
                 return False
-        return all(isinstance(nm, (nn.LayerNorm, nn.Identity)) for nm in self.normalizations)
+            if not (dense.fused_linear_supported(lin.in_features, lin.out_features) or
+                    dense.wide_linear_supported(lin.in_features, lin.out_features, isinstance(self.normalizations[i], nn.LayerNorm),
+                                                i > 0, p if i > 0 else 0.0)):
+                return False
+        return True
+
+    def _resident(self) -> bool:
+        """Every Linear fits the LDS-resident-weight kernels (widths <= 128): the joint PMA nodes build on those."""
+        return all(dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins)
 
     def forward(self, x, _post: Optional[float] = None):
         """``_post`` (internal): also apply ``dropout_p(relu(.))`` to the output -- the activation its callers
@@ -213,12 +224,14 @@ class PMA(nn.Module):
         """``(x_V, alpha_r)``: the value projection and the (folded) logits of ``x``."""
         H, C = self.heads, self.hidden
         fusable = _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features)
+        wide = _on_hip(x) and self.lin_V.bias is not None and dense.wide_linear_supported(
+            self.lin_V.in_features, self.lin_V.out_features, False)
         if fusable and self.fold_alpha and dense.x6_active():
             # one autograd node for both consumers of x (bf16x6 kernels; the branches' gradients are summed in-kernel)
             w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
             b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
             return dense.pma_project(x, self.lin_V.weight, self.lin_V.bias, w, b)
-        x_V = (dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias) if fusable
+        x_V = (dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias) if (fusable or wide)
                else _linear(self.lin_V, x))
         return x_V, self._logits(x)
 
@@ -231,7 +244,7 @@ class PMA(nn.Module):
             # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
             out = dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
             ff = self.rFF
-            if (dense.x6_active() and len(ff.lins) == 2 and ff._fusable(out)
+            if (dense.x6_active() and len(ff.lins) == 2 and ff._fusable(out) and ff._resident()
                     and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
                     and ff.lins[1].out_features == H * C):
                 # the whole residual block as one autograd node (gradient branches of `out` summed in a kernel)

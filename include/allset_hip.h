@@ -240,6 +240,29 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                        const uint32_t* mask, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Linear layers wider than 128 (reference layers.py:571-579 with MLP_hidden 256 / 512, src/run_AllSetTransformer.sh):
+ * a tiled GEMM with fp32-accurate arithmetic on the bf16 matrix pipe (csrc/wide_mlp.hip).
+ *   out[r, n] = epi( sum_k pro(A)[r, k] * B[n, k] + bias[n] ),   A: [rows, K] fp32,  B: [N, K]
+ *   pro(a)[r,k]: a *= (mask_y[r,k] > 0 ? 1/(1-p_mask) : 0) if mask_y;  a = relu(a) if relu_in;
+ *                a = (a - mean_r) * rstd_r * gamma[k] + beta[k] if stats ({mean, rstd} per row, allset_row_stats or
+ *                allset_ln_fwd);  a *= dropout_{p_in, seed_in}(r*K + k)
+ *   epi(v)[r,n]: v = relu(v) if relu_out;  v *= dropout_{p_out, seed_out}(r*N + n)
+ * (the same dropout hash as every other dense-tail entry, so allset_ln_bwd / allset_wgrad_fused regenerate the masks).
+ * B is passed as pre-split bf16 planes: allset_gemm_x6_planes(W, ldw, transpose, planes, N, K) with
+ *   transpose == 0: B = W [N, K] (forward: N = out features, K = in features);
+ *   transpose != 0: B[n, k] = W[k, n], W [K, N] (backward-data: N = in features, K = out features);
+ * planes: allset_gemm_x6_plane_bytes(N, K) bytes, 16-byte aligned.  Supported: K % 32 == 0, N % 4 == 0, both <= 4096.
+ * ------------------------------------------------------------------------------------------- */
+int allset_gemm_x6_supported(int64_t N, int64_t K);
+int64_t allset_gemm_x6_plane_bytes(int64_t N, int64_t K);
+int allset_gemm_x6_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream);
+int allset_row_stats(const float* x, int64_t ldx, int relu_in, float eps, float* stats, int64_t rows, int64_t d, void* stream);
+int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
+                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                   const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
+                   float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream);
+
 /* allset_pma_fwd_ex / allset_pma_bwd_stats / allset_pma_bwd_src_ex with explicit leading dimensions for the small per-row
  * operands the kernels GATHER next to a feature row: the logits (`lda` floats between rows, >= H) and the backward
  * statistics (`lds` floats between rows, even, >= 2H; stats 8-byte aligned).  A caller whose feature rows are narrower

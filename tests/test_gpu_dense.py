@@ -558,3 +558,109 @@ def test_layer_norm_res_bf16_fwd_bwd(n, d, with_colb, with_res, relu_out, p, dev
     pairs = [(gg.grad, gr.grad), (bg.grad, br.grad)] + ([(cg.grad, cr.grad)] if with_colb else [])
     for a, r in pairs:
         torch.testing.assert_close(a.cpu().double(), r, rtol=2e-2, atol=2e-2 * max(1.0, float(r.abs().max())))
+
+
+# ---- wide Linear layers (csrc/wide_mlp.hip: tiled bf16x6 GEMM; MLP_hidden 256 / 512 of the reference's scripts) ----------
+
+@pytest.mark.parametrize("K,N", [(256, 256), (512, 512), (256, 64), (96, 260), (512, 128)])
+@pytest.mark.parametrize("n", [1, 333, 4099])
+def test_gemm_x6_is_fp32_accurate(K, N, n, device):
+    """allset_gemm_x6 against float64: error relative to sum |terms| at fp32 rounding level, on inputs with a wide
+    dynamic range (a bf16 or bf16x3 product would be off by 1e-3 / 1e-5)."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(K + N + n)
+    x = (torch.randn(n, K, generator=g) * torch.exp(2 * torch.randn(n, 1, generator=g))).to(device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(device)
+    b = torch.randn(N, generator=g).to(device)
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), N, b)
+    ref = x.double() @ W.double().t() + b.double()
+    scale = x.double().abs() @ W.double().abs().t() + b.double().abs()
+    assert float(((y.double() - ref).abs() / scale).max()) < 1e-6
+    # the transposed planes: B = W^T
+    yt = dense.gemm_x6(x, dense.gemm_x6_planes(W.t().contiguous(), True), N, None)
+    assert float(((yt.double() - (ref - b.double())).abs() / scale).max()) < 1e-6
+
+
+@pytest.mark.parametrize("K,N", [(256, 256), (512, 256), (256, 512), (256, 64)])
+@pytest.mark.parametrize("has_ln,relu_in,relu_out", [(True, False, False), (True, True, True), (False, True, False),
+                                                     (False, False, True), (False, False, False)])
+def test_wide_norm_linear_gradients_no_dropout(K, N, has_ln, relu_in, relu_out, device):
+    """_WideNormLinear (row statistics + tiled GEMM forward; GEMM + LayerNorm-backward + split-K weight gradient backward)
+    against torch autograd of the same op chain in float64."""
+    from allset_amd import dense
+    assert dense.wide_linear_supported(K, N, has_ln, relu_in, 0.0)
+    n = 3001
+    g = torch.Generator().manual_seed(K * N + n)
+    x = torch.randn(n, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    G = torch.randn(n, N, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (x, gamma, beta, W, b)]
+    h = ref_in[0]
+    if relu_in:
+        h = F.relu(h)
+    if has_ln:
+        h = F.layer_norm(h, (K,), ref_in[1], ref_in[2], 1e-5)
+    ref = F.linear(h, ref_in[3], ref_in[4])
+    if relu_out:
+        ref = F.relu(ref)
+    (ref * G.double()).sum().backward()
+    dev_in = [t.to(device).requires_grad_(True) for t in (x, gamma, beta, W, b)]
+    y = dense.fused_norm_linear(dev_in[0], dev_in[1] if has_ln else None, dev_in[2] if has_ln else None, dev_in[3], dev_in[4],
+                                1e-5, relu_in, 0.0, relu_out, 0.0)
+    (y * G.to(device)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for nm, a, r in zip(["x", "gamma", "beta", "W", "b"], dev_in, ref_in):
+        if nm in ("gamma", "beta") and not has_ln:
+            continue
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{nm}: {m}")
+
+
+def test_wide_kernels_match_unfused_chain_with_dropout(device):
+    """With explicit seeds the tiled GEMM's prologue / epilogue draw the same masks as the unfused HIP chain."""
+    from allset_amd import dense, _lib
+    n, K, N, p_in, p_out = 5000, 256, 256, 0.3, 0.5
+    g = torch.Generator().manual_seed(19)
+    x, W, b = (torch.randn(n, K, generator=g).to(device), (torch.randn(N, K, generator=g) / K ** 0.5).to(device),
+               torch.randn(N, generator=g).to(device))
+    gamma, beta = (1 + 0.2 * torch.randn(K, generator=g)).to(device), (0.3 * torch.randn(K, generator=g)).to(device)
+    G = torch.randn(n, N, generator=g).to(device)
+    s_in, s_out = 1111, 2222
+    u, st_u = dense.ln_fwd(x, gamma, beta, 1e-5, True, p_in, s_in)
+    a = F.linear(u, W, b)
+    y_ref = torch.empty_like(a)
+    _lib.check(_lib.load().allset_relu_dropout_fwd(a.data_ptr(), p_out, s_out, y_ref.data_ptr(), a.numel(), None,
+                                                   torch.cuda.current_stream().cuda_stream), "relu_dropout_fwd")
+    ga = torch.where(y_ref > 0, G / (1 - p_out), torch.zeros_like(G))
+    st = dense.row_stats(x, True, 1e-5)
+    torch.testing.assert_close(st, st_u, rtol=1e-5, atol=1e-6)
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), N, b, relu_in=True, stats=st, gamma=gamma, beta=beta, p_in=p_in,
+                      seed_in=s_in, relu_out=True, p_out=p_out, seed_out=s_out)
+    torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
+    gu = dense.gemm_x6(G, dense.gemm_x6_planes(W, True), K, None, mask_y=y, p_mask=p_out)
+    torch.testing.assert_close(gu, ga @ W, rtol=1e-4, atol=1e-4)
+    gw, gb = dense.wgrad_fused(G, y, p_out, x, st, gamma, beta, True, p_in, s_in)
+    torch.testing.assert_close(gw, ga.t() @ u, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(gb, ga.sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_mlp_wide_path_is_taken_and_agrees(device):
+    """MLP.forward routes 256-wide layers to the tiled-GEMM path; eval-mode result equals the torch composition, the
+    train-mode step has finite gradients and the expected zero fraction."""
+    from allset_amd import MLP
+    torch.manual_seed(0)
+    for width in (256, 512):
+        m = MLP(width, width, width, 2, dropout=0.5, Normalization="ln", InputNorm=True).to(device).eval()
+        assert m._fusable(torch.empty(1, width, device=device)) and not m._resident()
+        x = torch.randn(999, width, device=device, requires_grad=True)
+        ref = m.lins[1](F.layer_norm(F.relu(m.lins[0](F.layer_norm(x, (width,), m.normalizations[0].weight,
+                        m.normalizations[0].bias))), (width,), m.normalizations[1].weight, m.normalizations[1].bias))
+        torch.testing.assert_close(m(x), ref, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(m(x, _post=0.5), F.relu(ref), rtol=1e-4, atol=1e-4)
+        m.train()
+        out = m(x, _post=0.5)
+        out.sum().backward()
+        assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+        assert 0.6 < float((out == 0).float().mean()) < 0.9
