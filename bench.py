@@ -280,8 +280,9 @@ def main():
                            "fp32 -- measured error vs float64 <= that of the native fp32 MFMA / hipBLASLt (DESIGN.md section 6)")
             if args.dtype == "f32" else
             ("bf16 tensors end to end (BASELINE configs[4] regime): bf16 instantiations of the gather kernels with fp32 "
-             "accumulation and fp32 softmax statistics; the dense tail runs through torch's bf16 modules (no fused bf16 "
-             "dense kernels yet)"),
+             "accumulation and fp32 softmax statistics; dense tail: this library's bf16 LayerNorm / add+LayerNorm+relu+dropout / "
+             "split-K weight-gradient kernels (fp32 arithmetic), Linear forward and backward-data through the library's bf16 "
+             "GEMMs"),
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{3 if attn else 2}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph |V|=|E|={n_loc} per GPU, "
                                    f"hyperedge size {args.degree} ({args.degree_dist}), nnz={int(nnz_total)}, d={d}, " +
