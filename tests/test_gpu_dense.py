@@ -664,3 +664,18 @@ def test_mlp_wide_path_is_taken_and_agrees(device):
         out.sum().backward()
         assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
         assert 0.6 < float((out == 0).float().mean()) < 0.9
+
+
+@pytest.mark.parametrize("n", [0, 1, 127, 129])
+def test_mlp_wide_path_tiny_and_empty_inputs(n, device):
+    """Row counts around the 128-row tile, and no rows at all, through the 256-wide MLP in train mode."""
+    from allset_amd import MLP
+    torch.manual_seed(0)
+    m = MLP(256, 256, 256, 2, dropout=0.5, Normalization="ln", InputNorm=True).to(device).train()
+    x = torch.randn(n, 256, device=device, requires_grad=True)
+    y = m(x, _post=0.5)
+    y.sum().backward()
+    assert y.shape == (n, 256) and x.grad.shape == x.shape
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    if n == 0:
+        assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters())
