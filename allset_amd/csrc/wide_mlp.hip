@@ -88,6 +88,9 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   // output tile on its way from the MFMA layout to row-major 16-byte stores
   constexpr int kASlab = 3 * kGxBM * 4, kBSlab = 3 * kGxBN * 4, kOutPitch = kGxBN + 4;
   __shared__ __attribute__((aligned(16))) uint4 smem[2 * kASlab + 2 * kBSlab];
+  // gamma / beta of the LayerNorm-apply prologue, once per workgroup: fetched from global memory inside the staging path
+  // they would sit behind an s_waitcnt vmcnt(0) -- which also drains the prefetch of the next A / B slabs -- four times a step
+  __shared__ __attribute__((aligned(16))) float sGB[2 * 512];
   static_assert(sizeof(float) * kGxBM * kOutPitch <= sizeof(uint4) * (2 * kASlab + 2 * kBSlab), "output tile must fit the arena");
   uint4 (*sA)[kASlab] = reinterpret_cast<uint4 (*)[kASlab]>(smem);
   uint4 (*sB)[kBSlab] = reinterpret_cast<uint4 (*)[kBSlab]>(smem + 2 * kASlab);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     if constexpr (HAS_Y) { a0 = y0 > 0.f ? a0 * inv_mask : 0.f; a1 = y1 > 0.f ? a1 * inv_mask : 0.f; }
     if (pro.relu_in) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
     if (pro.stats) {
-      const float2 g = *reinterpret_cast<const float2*>(pro.gamma + kk), b = *reinterpret_cast<const float2*>(pro.beta + kk);
+      const float2 g = *reinterpret_cast<const float2*>(sGB + kk), b = *reinterpret_cast<const float2*>(sGB + 512 + kk);
       a0 = fmaf((a0 - c.mean) * c.rstd, g.x, b.x);
       a1 = fmaf((a1 - c.mean) * c.rstd, g.y, b.y);
     }
@@ -210,6 +213,10 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
 
   int64_t tile = blockIdx.x;
   if (tile >= total) return;
+  if (pro.stats) {
+    for (int i = threadIdx.x; i < K; i += kGxThreads) { sGB[i] = pro.gamma[i]; sGB[512 + i] = pro.beta[i]; }
+    __syncthreads();
+  }
   GxRow cur = row_ctx(tile);
   const uint4* img_cur = planes + static_cast<int64_t>(tile % n_tiles) * ksteps * kBSlab;
   GX_LOAD(cur, img_cur, 0);
@@ -372,7 +379,7 @@ extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, 
   ALLSET_REQUIRE(ldo >= N && ldo % 4 == 0 && aligned16(out) && (bias == nullptr || aligned16(bias)),
                  "gemm_x6: output rows / bias must be 16-byte aligned");
   ALLSET_REQUIRE(mask_y == nullptr || (ldy >= K && ldy % 4 == 0 && aligned16(mask_y)), "gemm_x6: mask source rows must be 16-byte aligned");
-  ALLSET_REQUIRE(stats == nullptr || (gamma && beta && aligned16(gamma) && aligned16(beta)), "gemm_x6: LayerNorm-apply needs gamma and beta (16-byte aligned)");
+  ALLSET_REQUIRE(stats == nullptr || (gamma && beta && K <= 512), "gemm_x6: LayerNorm-apply needs gamma and beta, K <= 512");
   GxPro pro{mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in};
   GxEpi epi{bias, relu_out, p_out, seed_out};
   const int64_t tiles = (rows + kGxBM - 1) / kGxBM * ((N + kGxBN - 1) / kGxBN);
