@@ -805,9 +805,10 @@ def choose_sharding(world: int, d: int, heads: Optional[int] = None, elem: int =
     that: equal at P = 2, half at P = 4, a quarter at P = 8; the column scheme pays for it with d/P-wide gathers
     (no loss down to 128-byte rows, ~2.3x slower aggregation at 64-byte rows: profiles/r01_colshard_kernels.txt) and
     two layout copies per exchange.  With the measured per-rank compute (profiles/r01_sim_rank.txt) the column scheme
-    wins from P = 4 on; at P = 2 the two tie and the row scheme (no repacking) is kept.  A hypergraph whose
+    wins from P = 4 on; at P = 2 the two move the same bytes over the one link and the column scheme is taken for its
+    overlapped exchange (the row scheme's collectives run back to back with the compute).  A hypergraph whose
     partitions have few boundary vertices wants the row scheme regardless -- pass the mode explicitly there."""
-    if world < 4 or d % world:
+    if world < 2 or d % world:
         return "rows"
     dc = d // world
     if dc * elem < 64 or dc % (16 // elem):            # below one 64-byte sector / not 16-byte packets: gather kernels degrade

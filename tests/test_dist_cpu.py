@@ -482,7 +482,7 @@ def test_head_slots_and_exchange_volume():
 
 def test_choose_sharding():
     from allset_amd import dist as adist
-    assert adist.choose_sharding(1, 128) == "rows" and adist.choose_sharding(2, 128) == "rows"
+    assert adist.choose_sharding(1, 128) == "rows" and adist.choose_sharding(2, 128) == "columns"
     assert adist.choose_sharding(4, 128) == "columns" and adist.choose_sharding(8, 128) == "columns"
     assert adist.choose_sharding(8, 128, heads=4) == "columns" and adist.choose_sharding(8, 256, heads=4, elem=2) == "columns"
     assert adist.choose_sharding(8, 64) == "rows"            # 8 fp32 columns = 32-byte rows
