@@ -10,7 +10,7 @@ train.py passes, which ``SetGNN.forward`` re-bases).
 from __future__ import annotations
 
 from types import SimpleNamespace
-from typing import Optional
+
 
 import torch
 
