@@ -843,13 +843,15 @@ class ShardedSetGNN(torch.nn.Module):
         x = F.dropout(x_owned, p=0.2, training=m.training)                 # hard-coded input dropout (models.py:473)
         for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):
             cols = isinstance(self.hg, ColumnShardedHypergraph)
+            extra = {"chunks": self.hg.chunks} if cols else {}          # overlapped exchange: the chunking the blocks were padded for
             if v2e.attention:
                 layer = colsharded_pma_layer if cols else sharded_pma_layer
-                x = layer(v2e, e2v, x, self.hg, dropout=m.dropout, training=m.training, group=self.group, kernels=self._kernels)
+                x = layer(v2e, e2v, x, self.hg, dropout=m.dropout, training=m.training, group=self.group, kernels=self._kernels,
+                          **extra)
             else:
                 layer = colsharded_deepsets_layer if cols else sharded_deepsets_layer
                 x = layer(v2e, e2v, x, self.hg, aggr=m.aggr, dropout=m.dropout, training=m.training, group=self.group,
-                          aggregate=self._aggregate)
+                          aggregate=self._aggregate, **extra)
         return m.classifier(x)
 
     def allreduce_grads(self) -> None:

@@ -267,7 +267,7 @@ def test_sharded_pma_layer_equals_unsharded():
 # model level: ShardedSetGNN == SetGNN (oracle) on the owned vertex blocks
 # ---------------------------------------------------------------------------------------------
 
-def _model_worker(rank, world, port, mode, q):
+def _model_worker(rank, world, port, mode, q, columns=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -279,12 +279,18 @@ def _model_worker(rank, world, port, mode, q):
         args = cases.make_args(mode, d, 32, 5, All_num_layers=2)
         torch.manual_seed(11)
         model = SetGNN(args).eval()
-        owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
-        loc, gids = adist.local_shard(ei, owner, rank)
-        keep = owner[ei[1]] == rank
-        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=torch.ones(int(keep.sum()), dtype=torch.int64))
-        hg.v2e = (loc, hg.n_e_local)
-        hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        if columns:            # column-sharded aggregation, `columns` chunks in the overlapped exchange
+            hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=torch.ones(ei.shape[1], dtype=torch.int64),
+                                               chunks=columns)
+            hg.v2e = (ei, hg.n_e_pad)
+            hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
+        else:
+            owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
+            loc, gids = adist.local_shard(ei, owner, rank)
+            keep = owner[ei[1]] == rank
+            hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=torch.ones(int(keep.sum()), dtype=torch.int64))
+            hg.v2e = (loc, hg.n_e_local)
+            hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
         sharded = adist.ShardedSetGNN(model, hg, aggregate=_oracle_aggregate, kernels=TorchPmaKernels)
         xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
         out = sharded(xp[hg.v_lo:hg.v_hi])
@@ -293,8 +299,8 @@ def _model_worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ds_add", "pma_h4"])
-def test_sharded_setgnn_equals_oracle(mode):
+@pytest.mark.parametrize("mode,columns", [("ds_add", 0), ("pma_h4", 0), ("ds_add", 1), ("pma_h4", 2)])
+def test_sharded_setgnn_equals_oracle(mode, columns):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import cases
@@ -303,7 +309,7 @@ def test_sharded_setgnn_equals_oracle(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_model_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, mode, q, columns)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
