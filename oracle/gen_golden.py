@@ -3,8 +3,8 @@
 matrix of ``tests/cases.py``, and check ``oracle/allset_oracle.py`` against it.  TEST INFRASTRUCTURE.
 
 Container-only (needs /root/reference; uses ``oracle/ref_shim.py`` for the absent third-party
-wheels).  Usage:  ``python oracle/gen_golden.py``  -> rewrites tests/golden/ and
-tests/golden/REPORT.json (the oracle-vs-reference max-abs-diffs).
+wheels).  Usage:  ``python oracle/gen_golden.py [case ...]``  -> rewrites tests/golden/ (all cases, or only the named
+ones) and tests/golden/REPORT.json (the oracle-vs-reference max-abs-diffs).
 
 Each fixture holds, for one case: the expected ``SetGNN`` logits, the raw outputs of
 ``V2EConvs[0]`` / ``E2VConvs[0]``, d(loss)/dx and all parameter gradients for
@@ -102,7 +102,11 @@ def main() -> None:
     _, ref_models = ref_shim.import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     report = {}
-    for name in cases.ALL_CASES:
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]       # optional: regenerate just these cases
+    if only:
+        with open(os.path.join(GOLDEN, "REPORT.json")) as f:
+            report = json.load(f)["cases"]
+    for name in (only or cases.ALL_CASES):
         case = cases.build_case(name)
         spec, sd_np, ref, attn = run_reference(case, ref_models)
         orc = run_oracle(case, sd_np)

@@ -185,6 +185,11 @@ def build_case(name: str) -> dict:
         ei, n_v = edge_case_hypergraph(rng)
         f, d, k = 12, 32, 4
         x = rng.standard_normal((n_v, f)).astype(np.float32)
+    elif name.startswith("wide256_"):     # MLP_hidden 256 (src/run_AllSetTransformer.sh): the tiled-GEMM dense path
+        mode, big = name[len("wide256_"):], True       # (big: large parameter gradients are stored as samples + sums)
+        n_v, f, d, k = 300, 64, 256, 5
+        ei = random_hypergraph(rng, n_v, 150, 2000, True)
+        x = rng.standard_normal((n_v, f)).astype(np.float32)
     elif name == "cora_ds_add":          # BASELINE.json configs[0] shape (stand-in data)
         mode, big = "ds_add", True
         n_v, f, d, k = 2708, 1433, 64, 7
@@ -217,7 +222,7 @@ SMALL_CASES: List[str] = (
        "rand50_ds_mean_wnorm_mask_L2"]
     + [f"edge_{m}" for m in MODES]
 )
-BIG_CASES: List[str] = ["cora_ds_add", "citeseer_pma_h4"]
+BIG_CASES: List[str] = ["cora_ds_add", "citeseer_pma_h4", "wide256_ds_add", "wide256_pma_h4"]
 ALL_CASES: List[str] = SMALL_CASES + BIG_CASES
 
 
