@@ -29,7 +29,7 @@ def _setup(name, device, dropout=None):
     return model, data, y
 
 
-@pytest.mark.parametrize("name", ["cora_ds_add", "citeseer_pma_h4", "rand50_pma_h4"])
+@pytest.mark.parametrize("name", ["cora_ds_add", "citeseer_pma_h4", "rand50_pma_h4", "wide256_pma_h4"])
 def test_graphed_forward_is_bitwise_eager(name, device):
     from allset_amd.graphs import GraphedForward
     model, data, _ = _setup(name, device)
@@ -52,7 +52,7 @@ def test_graphed_forward_is_bitwise_eager(name, device):
     assert torch.equal(gf(x2), ref3)
 
 
-@pytest.mark.parametrize("name", ["cora_ds_add", "citeseer_pma_h4"])
+@pytest.mark.parametrize("name", ["cora_ds_add", "citeseer_pma_h4", "wide256_ds_add"])
 def test_graphed_train_step_matches_eager_without_dropout(name, device):
     """Without dropout (eval-mode step: SetGNN's input dropout p=0.2 is hard-coded, models.py:473) the step is
     deterministic: N graph replays == N eager steps from the same start, bit for bit."""
