@@ -329,7 +329,10 @@ class _ShardedPmaE2V(torch.autograd.Function):
     @staticmethod
     def forward(ctx, V, alpha, hg, heads, slope, group, K):
         inc = hg.e2v
+        in_dtype = V.dtype
+        alpha = alpha.float()                                             # logits / softmax statistics are fp32 throughout
         o_loc, m_loc, l_loc = K.fwd(V, alpha, inc, heads, slope)          # [n_v_pad, d], [n_v_pad, H] x2
+        o_loc = o_loc.float()                                             # (bf16 storage: the cross-rank merge runs in fp32)
         n, d = o_loc.shape
         C = d // heads
         has = l_loc > 0
@@ -351,21 +354,22 @@ class _ShardedPmaE2V(torch.autograd.Function):
         m_g_owned = torch.where(l_g > 0, m_g[lo:hi], torch.zeros_like(l_g)).contiguous()
         ctx.save_for_backward(V, alpha, out, m_g_owned, l_g)
         ctx.hg, ctx.heads, ctx.slope, ctx.group, ctx.K = hg, heads, slope, group, K
-        return out
+        ctx.in_dtype = in_dtype
+        return out.to(in_dtype)
 
     @staticmethod
     def backward(ctx, gout):
         V, alpha, out, m_g, l_g = ctx.saved_tensors
         hg, H, K = ctx.hg, ctx.heads, ctx.K
-        gout = gout.contiguous()
+        gout = gout.contiguous().float()
         stats = K.bwd_stats(out, gout, m_g, l_g)                            # [n_own, H, 2]
         d = gout.shape[1]
         packed = torch.cat([gout, stats.reshape(gout.shape[0], 2 * H)], dim=1)
         full = _all_gather_rows(packed, ctx.group)
         g_full = full[:, :d]                          # strided view: the kernels take a leading dimension, no copy
         stats_full = full[:, d:].contiguous().view(-1, H, 2)
-        gV, galpha = K.bwd_src(hg.e2v, alpha, V, g_full, stats_full, ctx.slope)
-        return gV, galpha, None, None, None, None, None
+        gV, galpha = K.bwd_src(hg.e2v, alpha, V, g_full.to(V.dtype) if g_full.dtype != V.dtype else g_full, stats_full, ctx.slope)
+        return gV, galpha.to(ctx.in_dtype) if galpha.dtype != ctx.in_dtype else galpha, None, None, None, None, None
 
 
 def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, dropout: float = 0.0,
@@ -747,6 +751,14 @@ class _RecvRowsChunk(torch.autograd.Function):
         pipe.bbuf[k] = send
         pipe.bwork[k] = _a2a_async(pipe.blocks(pipe.bfull, k), send.unbind(0), pipe.group)
         return ctx.token_like.new_zeros(0), None, None
+
+
+def auto_chunks(rows: int) -> int:
+    """Chunk count of the overlapped exchange for ``rows`` owned rows.  Every chunk repeats the layer's ~25 dense launches
+    and adds 2 collectives per exchange; measured on one GPU (1-rank RCCL group, profiles/r01_colshard_chunks.txt) that
+    costs 3.3 ms per step at 4 x 250k fp32 rows and 7 ms at 4 x 62k bf16 rows (launch-bound), against the dense time it
+    can hide an exchange behind (~7 ms per step at 1M x 128): worth it only while a chunk keeps >= 250k rows."""
+    return max(1, min(4, int(rows) // 250_000))
 
 
 def pipeline_chunks(rows: int, want: int) -> int:

@@ -50,7 +50,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n-per-gpu", type=int, default=1_000_000, help="|V| and |E| per GPU")
     ap.add_argument("--degree", type=int, default=16)
-    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--d", "--feature-dim", dest="d", type=int, default=128,
+                    help="feature width (under torch.distributed.run use --feature-dim: the launcher's argparse takes a bare "
+                         "'--d' for an abbreviation of its own --duplicate-* options)")
     ap.add_argument("--degree-dist", default="fixed", choices=["fixed", "poisson", "zipf"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: BASELINE configs[4] regime -- bf16 tensors end to end, bf16 instantiations of the gather kernels "
@@ -59,8 +61,9 @@ def parse_args():
                     help="N > 1: 'rows' = hyperedge shards with all-gather / reduce-scatter of the vertex table; 'columns' = "
                          "column-sharded aggregation with all-to-all layout changes (1/N of the exchange volume); 'auto' = "
                          "allset_amd.dist.choose_sharding (DESIGN.md section 7)")
-    ap.add_argument("--pipeline-chunks", type=int, default=4,
-                    help="--shard columns: chunks of owned rows whose all-to-alls overlap the other chunks' dense work (1 = off)")
+    ap.add_argument("--pipeline-chunks", type=int, default=0,
+                    help="--shard columns: chunks of owned rows whose all-to-alls overlap the other chunks' dense work "
+                         "(1 = off, 0 = allset_amd.dist.auto_chunks: 4 at 1M rows per GPU, 1 below 500k)")
     ap.add_argument("--self-loops", action="store_true",
                     help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
@@ -163,8 +166,10 @@ def main():
 
     d, n_loc = args.d, args.n_per_gpu
     n_v = n_loc * world                                               # weak scaling: global vertex range grows with N
+    if args.pipeline_chunks <= 0:
+        args.pipeline_chunks = adist.auto_chunks(args.n_per_gpu)
     mode = args.shard if args.shard != "auto" else adist.choose_sharding(world, d, args.heads if args.model == "pma" else None)
-    if mode == "columns" and world == 1:
+    if mode == "columns" and world == 1 and os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") != "1":
         mode = "rows"                                                  # one rank: the two layouts coincide
     shard = random_hypergraph(n_v, n_loc, args.degree, seed=args.seed + 1 + rank, device=dev, dist=args.degree_dist)
     n_e_loc = n_loc

@@ -338,3 +338,36 @@ def test_colsharded_layer_through_rccl_equals_module_composition(attention, chun
     torch.testing.assert_close(xs.grad, xr.grad, rtol=1e-4, atol=1e-4)
     for g, p in zip(gs, list(a.parameters()) + list(b.parameters())):
         torch.testing.assert_close(g, p.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(p.grad.abs().max())))
+
+
+def test_sharded_pma_merge_path_bf16(device, monkeypatch):
+    """The row scheme's cross-rank (m,l,o) merge with bf16 storage (BASELINE configs[4] regime): logits and the merge
+    arithmetic are fp32 inside, results return in bf16 -- must track the single-rank bf16 path within bf16 rounding."""
+    import numpy as np
+    from allset_amd import HalfNLHconv
+    from allset_amd import dist as adist
+    rng = np.random.default_rng(21)
+    n_v, n_e, d, H = 400, 211, 256, 4
+    pairs = sorted({(int(rng.integers(n_v)), int(rng.integers(n_e))) for _ in range(3000)} | {(n_v - 1, 0)})
+    ei = torch.tensor(pairs, dtype=torch.int64).t().contiguous().to(device)
+    torch.manual_seed(1)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=True).to(device).to(torch.bfloat16).eval()
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=True).to(device).to(torch.bfloat16).eval()
+    x = torch.randn(n_v, d, device=device).to(torch.bfloat16)
+    G = torch.randn(n_v, d, device=device).to(torch.bfloat16)
+    hg = adist.ShardedHypergraph(ei, n_v, n_e, 1, 0).build_incidences()
+    res = []
+    for merge in (False, True):
+        if merge:
+            monkeypatch.setattr(adist, "_skip_collective", lambda group=None: False)
+            monkeypatch.setattr(adist, "_all_gather_rows", lambda t, group=None: t)
+            monkeypatch.setattr(adist, "_reduce_scatter_rows", lambda t, group=None: t)
+            monkeypatch.setattr(adist.dist, "all_reduce", lambda *args, **kw: None)
+        xs = x.clone().requires_grad_(True)
+        out = adist.sharded_pma_layer(a, b, xs, hg)
+        assert out.dtype == torch.bfloat16
+        (out.float() * G.float()).sum().backward()
+        res.append((out.detach().float(), xs.grad.float()))
+    (o0, g0), (o1, g1) = res
+    assert float((o1 - o0).abs().mean()) < 0.03 * float(o0.abs().mean()) + 1e-3
+    assert float((g1 - g0).abs().mean()) < 0.05 * float(g0.abs().mean()) + 1e-3
