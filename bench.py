@@ -131,12 +131,13 @@ def cpu_baseline(args, d, degree):
     }
 
 
-def hbm_traffic_from_profile():
-    """HBM bytes per segreduce launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def hbm_traffic_from_profile(kernel="segreduce_fwd"):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    name = "hbm_traffic.json" if kernel == "segreduce_fwd" else "hbm_traffic_pma.json"
+    path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         try:
-            return json.load(open(path)).get("segreduce_fwd_bytes_per_launch")
+            return json.load(open(path)).get(f"{kernel}_bytes_per_launch")
         except Exception:
             return None
     return None
@@ -267,8 +268,10 @@ def main():
         seg = agg_ks.get(dom) if dom else None
         agg_ms = sum(v["total_ms"] for v in agg_ks.values()) / args.steps
         dense_ms = sum(v["total_ms"] for v in dense_ks.values()) / args.steps
-        traffic = hbm_traffic_from_profile() if (world == 1 and args.n_per_gpu == 1_000_000 and d == 128
-                                                 and dom == "segreduce_fwd") else None
+        # the PMC passes were taken at exactly this shape (tools/pmc_probe.py); any other shape reports null
+        traffic = (hbm_traffic_from_profile(dom) if (world == 1 and args.n_per_gpu == 1_000_000 and d == 128 and args.degree == 16
+                                                     and args.degree_dist == "fixed" and args.dtype == "f32" and not args.self_loops
+                                                     and (not attn or args.heads == 4)) else None)
         roofline = None
         if seg:
             achieved = seg["algo_bytes"] / (seg["avg_ms"] * 1e-3) / 1e9

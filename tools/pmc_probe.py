@@ -6,6 +6,7 @@ and measure HBM traffic of segreduce_kernel.  Launch order (each kernel launched
                  table): every gathered byte is compulsory     -> known nnz*512 B read, n_t*512 B write
   3. c3_v2e    : segreduce, V->E of the bench hypergraph (|V|=|E|=1M, deg 16, d=128)
   4. c3_e2v    : segreduce, E->V (the transposed CSR)
+  5. pma       : pma_fwd, pma_bwd_stats, pma_bwd_src on the same hypergraph (heads 4) -- the AllSetTransformer passes
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,5 +36,15 @@ for _ in range(R):
     ops.segreduce(0, inc.by_dst.rowptr, inc.by_dst.col, None, x, hg.n_e)
 for _ in range(R):
     ops.segreduce(0, inc.by_src.rowptr, inc.by_src.col, None, y, hg.n_v)
+torch.cuda.synchronize()
+H = 4
+alpha = torch.randn(hg.n_v, H, device=dev)
+gout = torch.randn(hg.n_e, d, device=dev)
+for _ in range(R):
+    out, m, l = ops.pma_fwd(inc.by_dst.rowptr, inc.by_dst.col, alpha, x, H, 0.2, hg.n_e, variant=1, row_order=inc.by_dst.row_order)
+for _ in range(R):
+    stats = ops.pma_bwd_stats(out, gout, m, l)
+for _ in range(R):
+    ops.pma_bwd_src(inc.by_src.rowptr, inc.by_src.col, alpha, x, gout, stats, 0.2, variant=1, row_order=inc.by_src.row_order)
 torch.cuda.synchronize()
 print("pmc_probe done")
