@@ -106,9 +106,44 @@ def test_dense_tail_full_size_properties(device):
     scale = float(gw.abs().max())
     torch.testing.assert_close(gw1 + gw2, gw, rtol=1e-4, atol=1e-5 * scale)
     torch.testing.assert_close(gb1 + gb2, gb, rtol=1e-4, atol=1e-5 * float(gb.abs().max()))
+    # the identity as weight returns the input bit for bit (bf16x6: x = h + m + l exactly, and they sum back exactly)
+    if dense.x6_active():
+        yi, _ = dense.fused_linear_fwd(x, torch.eye(d, device=device), None)
+        assert torch.equal(yi, x)
     # adjoint identity between the plain forward and its backward-data
     yp, _ = dense.fused_linear_fwd(x, W, None)
     gx, _, _ = dense.fused_linear_bwd(G, None, 0.0, W, x, None, None, False, 0.0, 0)
     lhs = (yp.double() * G.double()).sum()
     rhs = (x.double() * gx.double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-6 * float(lhs.abs() + rhs.abs()) + 1e-2
+
+
+def test_wide_gemm_full_size_properties(device):
+    """The tiled bf16x6 GEMM of the 256-wide layers at bench scale (n = 1M rows), through properties that need no
+    reference run: with the identity as weight it returns its input BIT FOR BIT (x = h + m + l exactly, and the six
+    products that survive a 0/1 weight sum back to x exactly in fp32); the transposed-planes GEMM is the adjoint of the
+    plain one; sampled rows of the LayerNorm-prologue / relu-epilogue form against float64."""
+    from allset_amd import dense
+    n, d = 1_000_003, 256                      # not a multiple of the 128-row tile
+    g = torch.Generator(device=device).manual_seed(13)
+    x = torch.randn(n, d, device=device, generator=g) * torch.exp(torch.randn(n, 1, device=device, generator=g))
+    eye = torch.eye(d, device=device)
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(eye, False), d, None)
+    assert torch.equal(y, x)
+    W = torch.randn(d, d, device=device, generator=g) / d ** 0.5
+    b = torch.randn(d, device=device, generator=g)
+    G = torch.randn(n, d, device=device, generator=g)
+    yp = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), d, None)              # x W^T
+    gx = dense.gemm_x6(G, dense.gemm_x6_planes(W, True), d, None)               # G W
+    lhs = (yp.double() * G.double()).sum()
+    rhs = (x.double() * gx.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float(lhs.abs() + rhs.abs()) + 1e-2
+    gamma = 1 + 0.2 * torch.randn(d, device=device, generator=g)
+    beta = 0.3 * torch.randn(d, device=device, generator=g)
+    rows = torch.cat([torch.arange(0, 64, device=device), torch.randint(0, n, (4000,), device=device, generator=g),
+                      torch.arange(n - 64, n, device=device)])
+    st = dense.row_stats(x, False, 1e-5)
+    yl = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), d, b, stats=st, gamma=gamma, beta=beta, relu_out=True)
+    ref = torch.relu(torch.nn.functional.layer_norm(x[rows].double(), (d,), gamma.double(), beta.double(), 1e-5)
+                     @ W.double().t() + b.double())
+    torch.testing.assert_close(yl[rows].double(), ref, rtol=1e-4, atol=1e-5)
