@@ -248,6 +248,8 @@ def segmax_bwd(rowptrT: Tensor, colT: Tensor, posT: Tensor, wT: Optional[Tensor]
     _f32(gout, "segmax_bwd")
     gout = _rowmajor(gout)
     n_t, d = gout.shape
+    if colT.numel() == 0:                       # no incidences: no row received anything (the ABI takes no null index arrays)
+        return torch.zeros((n_s, d), dtype=gout.dtype, device=dev)
     gx = torch.empty((n_s, d), dtype=gout.dtype, device=dev)
     algo = colT.numel() * (4 * d + 4 * d + 8) + (n_s + 1) * 4 + n_s * d * 4
     with torch.cuda.device(dev), _timed("segmax_bwd", dev, algo):
@@ -264,6 +266,8 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
     n_s, d = x.shape
     n_t = gout.shape[0]
     gw = torch.empty(col.numel(), dtype=torch.float32, device=dev)
+    if col.numel() == 0:
+        return gw
     algo = col.numel() * (4 * d + 8) + (n_t + 1) * 4 + n_t * d * 4
     with torch.cuda.device(dev), _timed("sddmm_rowdot", dev, algo):
         check(_lib.load().allset_sddmm_rowdot(reduce, ptr(rowptr), ptr(col), ptr(x), _ld(x), ptr(gout), _ld(gout),

@@ -454,3 +454,27 @@ def test_pma_colocated_operands_are_bitwise_the_plain_path(d, H, dtype, device, 
         res.append((out.detach(), m, l, v.grad, a.grad))
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("aggr", ["add", "mean", "max", "min"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_aggregate_without_any_incidence(aggr, weighted, device):
+    """An incidence with no entries at all (found by the randomised shapes with fresh seeds): every target is empty,
+    outputs and every gradient are zero -- forward and backward, including the arg-extreme backward of max / min and the
+    per-incidence weight gradient."""
+    from allset_amd import Incidence, functional as AF
+    ei = torch.zeros((2, 0), dtype=torch.int64, device=device)
+    inc = Incidence.from_edge_index(ei, n_src=3, n_dst=2)
+    x = torch.randn(3, 5, device=device, requires_grad=True)
+    w = torch.zeros(0, device=device, requires_grad=True) if weighted else None
+    out = AF.deepsets_aggregate(x, inc, w, aggr)
+    assert out.shape == (2, 5) and float(out.abs().max()) == 0.0
+    out.sum().backward()
+    assert x.grad.shape == x.shape and float(x.grad.abs().max()) == 0.0
+    if weighted:
+        assert w.grad is not None and w.grad.numel() == 0
+    V = torch.randn(3, 8, device=device, requires_grad=True)
+    alpha = torch.randn(3, 2, device=device, requires_grad=True)
+    o, m, l = AF.pma_aggregate(V, alpha, inc, 2, 0.2)
+    o.sum().backward()
+    assert float(o.abs().max()) == 0.0 and float(V.grad.abs().max()) == 0.0 and float(alpha.grad.abs().max()) == 0.0

@@ -4,12 +4,18 @@ segments, duplicated incidences, single rows holding everything and widths that 
 import numpy as np
 import pytest
 import torch
-from hypothesis import HealthCheck, given, seed, settings, strategies as st
+import os
+
+from hypothesis import HealthCheck, assume, given, seed, settings, strategies as st
 
 from oracle import allset_oracle as oracle
 
 pytestmark = pytest.mark.gpu
-COMMON = dict(deadline=None, max_examples=40, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+# ALLSET_HYPOTHESIS_EXAMPLES / ALLSET_HYPOTHESIS_RANDOM=1: bug-hunting runs (more examples, fresh seeds); the default is a fixed,
+# derandomized sample so that the suite is reproducible
+_N = int(os.environ.get("ALLSET_HYPOTHESIS_EXAMPLES", "40"))
+_DERAND = os.environ.get("ALLSET_HYPOTHESIS_RANDOM", "0") != "1"
+COMMON = dict(deadline=None, max_examples=_N, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.filter_too_much], derandomize=_DERAND)
 
 
 @st.composite
@@ -97,14 +103,18 @@ def test_pma_aggregate_random(inc, heads, c, device):
     I = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
     out, m, l = pma_aggregate(Vd, ad, I, heads, 0.2)
     (out * G.to(device)).sum().backward()
-    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    # a target that holds thousands of incidences sums thousands of fp32 terms (and its logit gradient cancels almost
+    # completely): the rounding scale grows with the longest row -- found by fresh-seed runs with 2000 duplicates of one pair
+    longest = int(max(torch.bincount(ei[1]).max(), torch.bincount(ei[0]).max())) if ei.shape[1] else 1      # target or source row
+    slack = max(1.0, longest / 256.0)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4 * slack)
     if ei.shape[1]:
-        torch.testing.assert_close(Vd.grad.cpu(), Vr.grad, rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(Vd.grad.cpu(), Vr.grad, rtol=1e-4, atol=1e-4 * slack)
+        torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-3, atol=1e-4 * slack)
 
 
 @settings(**COMMON)
-@given(n=st.integers(1, 700), K=st.sampled_from([64, 128]), N=st.sampled_from([64, 128]), has_ln=st.booleans(),
+@given(n=st.integers(1, 700), K=st.sampled_from([64, 128, 256]), N=st.sampled_from([64, 128, 256]), has_ln=st.booleans(),
        relu_in=st.booleans(), relu_out=st.booleans(), sd=st.integers(0, 10 ** 6))
 def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, device):
     """Any row count (tails of the 16-row chunks, n = 1) and every prologue / epilogue combination without dropout:
@@ -124,6 +134,9 @@ def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, d
         h = F.layer_norm(h, (K,), ref_in[1], ref_in[2], 1e-5)
     ref = F.linear(h, ref_in[3], ref_in[4])
     if relu_out:
+        # a pre-activation within rounding of the relu kink takes the other branch in fp32 (a fresh-seed run found
+        # -8.8e-8 in float64 against +5.2e-8 in the kernel): the gradient of that row then legitimately differs
+        assume(float(ref.detach().abs().min()) > 1e-5)
         ref = F.relu(ref)
     (ref * G.double()).sum().backward()
     dev_in = [t.clone().requires_grad_(True) for t in (x, gamma, beta, W, b)]
@@ -138,8 +151,9 @@ def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, d
         torch.testing.assert_close(a.grad.double(), r.grad, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{nm}: {m}")
 
 
-@settings(deadline=None, max_examples=30, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
-@given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64, 128]),
+@settings(deadline=None, max_examples=max(30, _N * 3 // 4), suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.filter_too_much],
+          derandomize=_DERAND)
+@given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64, 128, 256]),
        heads=st.sampled_from([1, 2, 4]), aggr=st.sampled_from(["add", "mean", "max"]), norm=st.sampled_from(["ln", "bn", "None"]),
        input_norm=st.booleans(), mask=st.booleans(), gpr=st.booleans(), wnorm=st.booleans(), sd=st.integers(0, 10 ** 6))
 def test_setgnn_random_configurations_match_oracle(pma, layers, mlp_layers, hidden, heads, aggr, norm, input_norm, mask, gpr,
@@ -176,7 +190,27 @@ def test_setgnn_random_configurations_match_oracle(pma, layers, mlp_layers, hidd
     xd = torch.from_numpy(x).to(device).requires_grad_(True)
     out = model(SimpleNamespace(x=xd, edge_index=torch.from_numpy(ei).to(device), norm=norm_t.to(device)))
     (out * G.to(device)).sum().backward()
-    scale = max(1.0, float(ref.detach().abs().max()))
-    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=2e-4, atol=2e-4 * scale)
-    gs = max(1.0, float(xr.grad.abs().max()))
-    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-3 * gs)
+    # The yardstick is the oracle in float64; the fp32 oracle's own distance from it sets the scale of what fp32 can
+    # deliver on this configuration (stacked LayerNorms over near-constant rows can be ill-conditioned: fresh-seed runs
+    # found cases where the fp32 ORACLE is 2e-3 of the gradient scale away from float64 and the product 5e-6).
+    sd64 = {kk: (v.double() if v.is_floating_point() else v) for kk, v in sdict.items()}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    ref64 = oracle.setgnn_forward(sd64, args, x64, torch.from_numpy(ei), norm_t.double() if norm_t.is_floating_point() else norm_t)
+    (ref64 * G.double()).sum().backward()
+    # parity is only meaningful where the model is stable: max / min aggregation routes gradients through arg-extremes, and a
+    # near-tie makes logits and gradients jump under a 1e-6 change of the input (fresh-seed runs found a 3-layer `max` model
+    # whose float64 gradient moves by 7 % of its scale) -- such examples are rejected, not asserted
+    xp = torch.from_numpy(x).double() + (1e-5 if aggr in ("max", "min") and not pma else 1e-6) * torch.from_numpy(rng.standard_normal(x.shape))
+    xp.requires_grad_(True)
+    refp = oracle.setgnn_forward(sd64, args, xp, torch.from_numpy(ei), norm_t.double() if norm_t.is_floating_point() else norm_t)
+    (refp * G.double()).sum().backward()
+    gs0 = max(1.0, float(x64.grad.abs().max()))
+    assume(float((xp.grad - x64.grad).abs().max()) <= 3e-4 * gs0 and
+           float((refp.detach() - ref64.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref64.detach().abs().max())))
+    scale = max(1.0, float(ref64.detach().abs().max()))
+    o_tol = max(2e-4 * scale, 3.0 * float((ref.detach().double() - ref64.detach()).abs().max()))
+    assert float((out.detach().cpu().double() - ref64.detach()).abs().max()) <= o_tol
+    gs = max(1.0, float(x64.grad.abs().max()))
+    depth = max(1.0, layers * mlp_layers / 2.0)             # rounding (and relu kinks inside it) accumulates with the stack's depth
+    g_tol = max(1e-3 * gs * depth, 3.0 * float((xr.grad.double() - x64.grad).abs().max()))
+    assert float((xd.grad.cpu().double() - x64.grad).abs().max()) <= g_tol
