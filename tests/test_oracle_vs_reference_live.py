@@ -2,6 +2,7 @@
 (imported through oracle/ref_shim.py) on randomised SetGNN configurations -- the same generator the GPU-side
 random-configuration parity test uses, so that chain reads  reference == oracle (here)  and  oracle == product
 (tests/test_gpu_random_shapes.py).  Logits, d(loss)/dx and every parameter gradient."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -16,8 +17,9 @@ from oracle import ref_shim
 pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
 
 
-@settings(deadline=None, max_examples=25, derandomize=True)
-@given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64]),
+@settings(deadline=None, max_examples=int(os.environ.get("ALLSET_HYPOTHESIS_EXAMPLES", "25")),
+          derandomize=os.environ.get("ALLSET_HYPOTHESIS_RANDOM", "0") != "1")
+@given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64, 256]),
        heads=st.sampled_from([1, 2, 4]), aggr=st.sampled_from(["add", "mean", "max"]), norm=st.sampled_from(["ln", "bn", "None"]),
        input_norm=st.booleans(), mask=st.booleans(), gpr=st.booleans(), wnorm=st.booleans(), sd=st.integers(0, 10 ** 6))
 def test_oracle_equals_live_reference_on_random_configurations(pma, layers, mlp_layers, hidden, heads, aggr, norm, input_norm,
