@@ -214,3 +214,55 @@ def test_setgnn_random_configurations_match_oracle(pma, layers, mlp_layers, hidd
     depth = max(1.0, layers * mlp_layers / 2.0)             # rounding (and relu kinks inside it) accumulates with the stack's depth
     g_tol = max(1e-3 * gs * depth, 3.0 * float((xr.grad.double() - x64.grad).abs().max()))
     assert float((xd.grad.cpu().double() - x64.grad).abs().max()) <= g_tol
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 900), d=st.sampled_from([1, 3, 4, 7, 8, 32, 60, 64, 100, 128, 200, 256, 260, 512, 1000]), relu_in=st.booleans(),
+       bf16=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_layer_norm_random(n, d, relu_in, bf16, sd, device):
+    """LayerNorm kernels (fp32: specialised widths and the generic path; bf16: d % 8 == 0, d <= 512) at random sizes against
+    float64 on the same values."""
+    import torch.nn.functional as F
+    from allset_amd import dense
+    if bf16:
+        assume(d % 8 == 0 and d <= 512)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator(device=device).manual_seed(sd)
+    x = torch.randn(n, d, device=device, generator=g).to(dt)
+    gamma = (1 + 0.2 * torch.randn(d, device=device, generator=g)).to(dt)
+    beta = (0.3 * torch.randn(d, device=device, generator=g)).to(dt)
+    G = torch.randn(n, d, device=device, generator=g).to(dt)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    hin = F.relu(xr) if relu_in else xr
+    assume(d > 1 or True)
+    ref = F.layer_norm(hin, (d,), gr, br, 1e-5)
+    (ref * G.double()).sum().backward()
+    xd, gd, bd = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    out = dense.layer_norm(xd, gd, bd, 1e-5, relu_in, 0.0)
+    (out * G).sum().backward()
+    tol = 1.5e-2 if bf16 else 1e-4
+    torch.testing.assert_close(out.detach().double(), ref.detach(), rtol=tol, atol=tol)
+    # rows whose variance is tiny amplify rounding by rstd (up to 1/sqrt(eps)): compare gradients at the scale of the largest
+    gsx = max(1.0, float(xr.grad.abs().max()))
+    torch.testing.assert_close(xd.grad.double(), xr.grad, rtol=tol * 2, atol=tol * 2 * gsx)
+    for a, r in ((gd.grad, gr.grad), (bd.grad, br.grad)):
+        torch.testing.assert_close(a.double(), r, rtol=tol * 2, atol=tol * 2 * max(1.0, float(r.abs().max())))
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 3000), O=st.sampled_from([4, 8, 64, 100, 128, 132, 256, 260]), I=st.sampled_from([4, 12, 64, 128, 200, 256]),
+       bf16=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_weight_gradient_random(n, O, I, bf16, sd, device):
+    """Split-K weight gradient (fp32 bf16x6 / bf16) at random sizes: ga^T u and the column sums against float64."""
+    from allset_amd import dense
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator(device=device).manual_seed(sd)
+    ga = torch.randn(n, O, device=device, generator=g).to(dt)
+    u = torch.randn(n, I, device=device, generator=g).to(dt)
+    gw, gb = dense.wgrad(ga, u, True)
+    ref = ga.double().t() @ u.double()
+    scale = float((ga.double().abs().t() @ u.double().abs()).max()) + 1e-30
+    tol = 1e-2 if bf16 else 2e-6                 # bf16: the result is rounded to bf16 once
+    assert float((gw.double() - ref).abs().max()) <= tol * scale
+    refb = ga.double().sum(0)
+    assert float((gb.double() - refb).abs().max()) <= tol * (float(ga.double().abs().sum(0).max()) + 1e-30)
