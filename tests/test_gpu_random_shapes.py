@@ -266,3 +266,75 @@ def test_weight_gradient_random(n, O, I, bf16, sd, device):
     assert float((gw.double() - ref).abs().max()) <= tol * scale
     refb = ga.double().sum(0)
     assert float((gb.double() - refb).abs().max()) <= tol * (float(ga.double().abs().sum(0).max()) + 1e-30)
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 700), K=st.sampled_from([32, 96, 160, 256, 512]), N=st.sampled_from([4, 12, 100, 256, 260, 512]),
+       use_mask=st.booleans(), relu_in=st.booleans(), has_ln=st.booleans(), relu_out=st.booleans(), bias=st.booleans(),
+       sd=st.integers(0, 10 ** 6))
+def test_gemm_x6_random(n, K, N, use_mask, relu_in, has_ln, relu_out, bias, sd, device):
+    """The tiled bf16x6 GEMM at random sizes (row tails of the 128-row tile, column tails of the 256-column tile, 1..16 K
+    steps) with every prologue / epilogue switch, against float64; the error is measured against sum |terms|."""
+    import torch.nn.functional as F
+    from allset_amd import dense
+    g = torch.Generator(device=device).manual_seed(sd)
+    x = torch.randn(n, K, device=device, generator=g)
+    W = torch.randn(N, K, device=device, generator=g) / K ** 0.5
+    b = torch.randn(N, device=device, generator=g) if bias else None
+    gamma = 1 + 0.2 * torch.randn(K, device=device, generator=g)
+    beta = 0.3 * torch.randn(K, device=device, generator=g)
+    ymask = torch.randn(n, K, device=device, generator=g) if use_mask else None
+    a = x.double()
+    if use_mask:
+        a = torch.where(ymask.double() > 0, a / (1 - 0.25), torch.zeros_like(a))
+    if relu_in:
+        a = F.relu(a)
+    stats = None
+    if has_ln:
+        src = x if not use_mask else torch.where(ymask > 0, x / (1 - 0.25), torch.zeros_like(x))
+        stats = dense.row_stats(src.contiguous(), relu_in, 1e-5)
+        a = F.layer_norm(a, (K,), gamma.double(), beta.double(), 1e-5)
+    pre = a @ W.double().t() + (b.double() if bias else 0.0)
+    if relu_out:
+        assume(float(pre.abs().min()) > 1e-6)
+    ref = F.relu(pre) if relu_out else pre
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), N, b, mask_y=ymask, p_mask=0.25 if use_mask else 0.0, relu_in=relu_in,
+                      stats=stats, gamma=gamma if has_ln else None, beta=beta if has_ln else None, relu_out=relu_out)
+    scale = a.abs() @ W.double().abs().t() + (b.double().abs() if bias else 0.0) + 1e-30
+    assert float(((y.double() - ref).abs() / scale).max()) < (2e-5 if has_ln else 2e-6)
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 900), d=st.sampled_from([4, 8, 32, 64, 100, 128, 200, 256]), with_colb=st.booleans(), with_res=st.booleans(),
+       relu_out=st.booleans(), bf16=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_layer_norm_res_random(n, d, with_colb, with_res, relu_out, bf16, sd, device):
+    """``relu_out(LN(x + colb + res))`` (PMA tail) at random sizes, fp32 and bf16, against float64 on the same values."""
+    import torch.nn.functional as F
+    from allset_amd import dense
+    if bf16:
+        assume(d % 8 == 0)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator(device=device).manual_seed(sd)
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, device=device, generator=g)).to(dt)
+    x, colb, res = mk(n, d), (mk(d, s=0.5) if with_colb else None), (mk(n, d) if with_res else None)
+    gamma, beta, G = (1 + mk(d, s=0.2)).to(dt), mk(d, s=0.3), mk(n, d)
+    dd = lambda t: None if t is None else t.double().requires_grad_(True)
+    xr, cr, rr, gr, br = dd(x), dd(colb), dd(res), dd(gamma), dd(beta)
+    pre = F.layer_norm(xr + (cr if cr is not None else 0.0) + (rr if rr is not None else 0.0), (d,), gr, br, 1e-5)
+    if relu_out:
+        assume(float(pre.detach().abs().min()) > (1e-2 if bf16 else 1e-5))
+    ref = F.relu(pre) if relu_out else pre
+    (ref * G.double()).sum().backward()
+    dv = lambda t: None if t is None else t.clone().requires_grad_(True)
+    xd, cd, rd, gd, bd = dv(x), dv(colb), dv(res), dv(gamma), dv(beta)
+    out = dense.layer_norm_res(xd, cd, rd, gd, bd, 1e-5, relu_out, 0.0)
+    (out * G).sum().backward()
+    tol = 1.5e-2 if bf16 else 1e-4
+    torch.testing.assert_close(out.detach().double(), ref.detach(), rtol=tol, atol=tol)
+    gsx = max(1.0, float(xr.grad.abs().max()))
+    torch.testing.assert_close(xd.grad.double(), xr.grad, rtol=2 * tol, atol=2 * tol * gsx)
+    if with_res:
+        torch.testing.assert_close(rd.grad.double(), rr.grad, rtol=2 * tol, atol=2 * tol * gsx)
+    pairs = [(gd.grad, gr.grad), (bd.grad, br.grad)] + ([(cd.grad, cr.grad)] if with_colb else [])
+    for a_, r_ in pairs:
+        torch.testing.assert_close(a_.double(), r_, rtol=2 * tol, atol=2 * tol * max(1.0, float(r_.abs().max())))
