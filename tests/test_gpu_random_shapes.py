@@ -135,8 +135,9 @@ def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, d
     ref = F.linear(h, ref_in[3], ref_in[4])
     if relu_out:
         # a pre-activation within rounding of the relu kink takes the other branch in fp32 (a fresh-seed run found
-        # -8.8e-8 in float64 against +5.2e-8 in the kernel): the gradient of that row then legitimately differs
-        assume(float(ref.detach().abs().min()) > 1e-5)
+        # -8.8e-8 in float64 against +5.2e-8 in the kernel): the gradient of that row then legitimately differs --
+        # such rows get a zero cotangent, so they contribute nothing to any gradient on either side
+        G = torch.where((ref.detach().abs() < 1e-5).any(1, keepdim=True).to(G.device), torch.zeros_like(G), G)
         ref = F.relu(ref)
     (ref * G.double()).sum().backward()
     dev_in = [t.clone().requires_grad_(True) for t in (x, gamma, beta, W, b)]
@@ -200,7 +201,9 @@ def test_setgnn_random_configurations_match_oracle(pma, layers, mlp_layers, hidd
     # parity is only meaningful where the model is stable: max / min aggregation routes gradients through arg-extremes, and a
     # near-tie makes logits and gradients jump under a 1e-6 change of the input (fresh-seed runs found a 3-layer `max` model
     # whose float64 gradient moves by 7 % of its scale) -- such examples are rejected, not asserted
-    xp = torch.from_numpy(x).double() + (1e-5 if aggr in ("max", "min") and not pma else 1e-6) * torch.from_numpy(rng.standard_normal(x.shape))
+    # (1e-5: a relu or arg-extreme kink closer than that can be crossed by fp32 rounding inside a 9-Linear stack -- a
+    # fresh-seed run found one that the bf16x6 arithmetic crossed and the native fp32 arithmetic did not)
+    xp = torch.from_numpy(x).double() + 1e-5 * torch.from_numpy(rng.standard_normal(x.shape))
     xp.requires_grad_(True)
     refp = oracle.setgnn_forward(sd64, args, xp, torch.from_numpy(ei), norm_t.double() if norm_t.is_floating_point() else norm_t)
     (refp * G.double()).sum().backward()
@@ -234,7 +237,6 @@ def test_layer_norm_random(n, d, relu_in, bf16, sd, device):
     G = torch.randn(n, d, device=device, generator=g).to(dt)
     xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
     hin = F.relu(xr) if relu_in else xr
-    assume(d > 1 or True)
     ref = F.layer_norm(hin, (d,), gr, br, 1e-5)
     (ref * G.double()).sum().backward()
     xd, gd, bd = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
@@ -295,8 +297,6 @@ def test_gemm_x6_random(n, K, N, use_mask, relu_in, has_ln, relu_out, bias, sd, 
         stats = dense.row_stats(src.contiguous(), relu_in, 1e-5)
         a = F.layer_norm(a, (K,), gamma.double(), beta.double(), 1e-5)
     pre = a @ W.double().t() + (b.double() if bias else 0.0)
-    if relu_out:
-        assume(float(pre.abs().min()) > 1e-6)
     ref = F.relu(pre) if relu_out else pre
     y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), N, b, mask_y=ymask, p_mask=0.25 if use_mask else 0.0, relu_in=relu_in,
                       stats=stats, gamma=gamma if has_ln else None, beta=beta if has_ln else None, relu_out=relu_out)
@@ -321,8 +321,8 @@ def test_layer_norm_res_random(n, d, with_colb, with_res, relu_out, bf16, sd, de
     dd = lambda t: None if t is None else t.double().requires_grad_(True)
     xr, cr, rr, gr, br = dd(x), dd(colb), dd(res), dd(gamma), dd(beta)
     pre = F.layer_norm(xr + (cr if cr is not None else 0.0) + (rr if rr is not None else 0.0), (d,), gr, br, 1e-5)
-    if relu_out:
-        assume(float(pre.detach().abs().min()) > (1e-2 if bf16 else 1e-5))
+    if relu_out:                                    # rows on the relu kink: zero cotangent (see test_fused_norm_linear_random_rows)
+        G = torch.where((pre.detach().abs() < (1e-4 if bf16 else 1e-5)).any(1, keepdim=True), torch.zeros_like(G), G)
     ref = F.relu(pre) if relu_out else pre
     (ref * G.double()).sum().backward()
     dv = lambda t: None if t is None else t.clone().requires_grad_(True)
@@ -338,3 +338,49 @@ def test_layer_norm_res_random(n, d, with_colb, with_res, relu_out, bf16, sd, de
     pairs = [(gd.grad, gr.grad), (bd.grad, br.grad)] + ([(cd.grad, cr.grad)] if with_colb else [])
     for a_, r_ in pairs:
         torch.testing.assert_close(a_.double(), r_, rtol=2 * tol, atol=2 * tol * max(1.0, float(r_.abs().max())))
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 900), K=st.sampled_from([64, 128, 256]), N=st.sampled_from([64, 128, 256]),
+       p_in=st.sampled_from([0.0, 0.2, 0.5]), p_out=st.sampled_from([0.0, 0.3, 0.5]), sd=st.integers(0, 10 ** 6))
+def test_dropout_masks_agree_between_fused_and_unfused_chains(n, K, N, p_in, p_out, sd, device):
+    """With explicit seeds the one-kernel Linear (LDS-resident weights for widths <= 128, tiled GEMM beyond) and the
+    unfused HIP chain LayerNorm -> library GEMM -> relu/dropout draw the SAME masks at any row count: forward output, the
+    gradient of the Linear's input, weight and bias gradients."""
+    import torch.nn.functional as F
+    from allset_amd import _lib, dense
+    g = torch.Generator(device=device).manual_seed(sd)
+    x = torch.randn(n, K, device=device, generator=g)
+    W = torch.randn(N, K, device=device, generator=g) / K ** 0.5
+    b = torch.randn(N, device=device, generator=g)
+    gamma = 1 + 0.2 * torch.randn(K, device=device, generator=g)
+    beta = 0.3 * torch.randn(K, device=device, generator=g)
+    G = torch.randn(n, N, device=device, generator=g)
+    s_in, s_out = sd + 11, sd + 29
+    u, st_u = dense.ln_fwd(x, gamma, beta, 1e-5, True, p_in, s_in)
+    a = F.linear(u, W, b)
+    G = torch.where((a.abs() < 1e-5).any(1, keepdim=True), torch.zeros_like(G), G)     # relu kink rows: zero cotangent
+    y_ref = torch.empty_like(a)
+    _lib.check(_lib.load().allset_relu_dropout_fwd(a.data_ptr(), p_out, s_out, y_ref.data_ptr(), a.numel(), None,
+                                                   torch.cuda.current_stream().cuda_stream), "relu_dropout_fwd")
+    ga = torch.where(y_ref > 0, G / (1 - p_out), torch.zeros_like(G))
+    gu_ref = ga @ W
+    if dense.fused_linear_supported(K, N):
+        y, st = dense.fused_linear_fwd(x, W, b, gamma, beta, 1e-5, True, p_in, s_in, True, p_out, s_out)
+        gx, dg, db = dense.fused_linear_bwd(G, y, p_out, W, x, st, gamma, True, p_in, s_in)
+        gx_ref, dg_ref, db_ref = dense.ln_bwd(gu_ref, x, st_u, gamma, True, p_in, s_in)
+        sc = max(1.0, float(gx_ref.abs().max()))
+        torch.testing.assert_close(gx, gx_ref, rtol=1e-4, atol=1e-4 * sc)
+        torch.testing.assert_close(dg, dg_ref, rtol=1e-4, atol=2e-3 * max(1.0, float(dg_ref.abs().max())))
+    else:
+        st = dense.row_stats(x, True, 1e-5)
+        y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), N, b, relu_in=True, stats=st, gamma=gamma, beta=beta, p_in=p_in,
+                          seed_in=s_in, relu_out=True, p_out=p_out, seed_out=s_out)
+        gu = dense.gemm_x6(G, dense.gemm_x6_planes(W, True), K, None, mask_y=y, p_mask=p_out)
+        torch.testing.assert_close(gu, gu_ref, rtol=1e-4, atol=1e-4 * max(1.0, float(gu_ref.abs().max())))
+    torch.testing.assert_close(st, st_u, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
+    gw, gb = dense.wgrad_fused(G, y, p_out, x, st, gamma, beta, True, p_in, s_in)
+    gw_ref = ga.t() @ u
+    torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-4 * max(1.0, float(gw_ref.abs().max())))
+    torch.testing.assert_close(gb, ga.sum(0), rtol=1e-4, atol=1e-4 * max(1.0, float(ga.sum(0).abs().max())))
