@@ -384,3 +384,35 @@ def test_dropout_masks_agree_between_fused_and_unfused_chains(n, K, N, p_in, p_o
     gw_ref = ga.t() @ u
     torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-4 * max(1.0, float(gw_ref.abs().max())))
     torch.testing.assert_close(gb, ga.sum(0), rtol=1e-4, atol=1e-4 * max(1.0, float(ga.sum(0).abs().max())))
+
+
+@settings(**COMMON)
+@given(inc=incidences(max_n=300, max_nnz=2000), d=st.sampled_from([8, 16, 32, 64, 128, 256]), aggr=st.sampled_from(["add", "mean"]),
+       weighted=st.booleans(), pma_heads=st.sampled_from([0, 1, 2, 4]))
+def test_bf16_storage_aggregate_random(inc, d, aggr, weighted, pma_heads, device):
+    """bf16 feature storage (BASELINE configs[4] regime) at random shapes: the sum / mean aggregation and the attention pooling
+    read bf16 rows, accumulate in fp32 and round once -- against the oracle in float64 on the same bf16 values."""
+    from allset_amd import Incidence, deepsets_aggregate, pma_aggregate
+    n_s, n_t, ei = inc
+    nnz = ei.shape[1]
+    assume(nnz > 0)
+    g = torch.Generator().manual_seed(nnz * 7 + d)
+    x = torch.randn(n_s, d, generator=g).to(torch.bfloat16)
+    I = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
+    longest = int(max(torch.bincount(ei[1]).max(), torch.bincount(ei[0]).max()))
+    if pma_heads == 0:
+        norm = (0.5 + torch.rand(nnz, generator=g)) if weighted else torch.ones(nnz, dtype=torch.int64)
+        ref = oracle.deepsets_aggregate(x.double(), ei, norm.double() if weighted else norm, aggr)
+        out = deepsets_aggregate(x.to(device), I, norm.to(device), aggr)
+    else:
+        assume(d % pma_heads == 0 and (d // pma_heads) % 8 == 0)
+        alpha = 2.0 * torch.randn(n_s, pma_heads, generator=g)
+        ref, _ = oracle.pma_aggregate(x.double().view(n_s, pma_heads, -1), alpha.double(), ei, 0.2)
+        ref = ref.reshape(-1, d)
+        out, _, _ = pma_aggregate(x.to(device), alpha.to(device), I, pma_heads, 0.2)
+    if ref.shape[0] < n_t:
+        ref = torch.cat([ref, ref.new_zeros(n_t - ref.shape[0], d)])
+    assert out.dtype == torch.bfloat16
+    # one bf16 rounding of the result (2^-9 relative) on top of fp32 accumulation
+    tol = 2.0 ** -8
+    torch.testing.assert_close(out.float().cpu().double(), ref, rtol=tol, atol=tol * max(1.0, longest / 64.0))
