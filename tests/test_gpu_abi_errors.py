@@ -1,0 +1,88 @@
+"""GPU: the C ABI refuses bad arguments with a status code and a message -- it never throws, crashes or launches.
+Called through ctypes with raw pointers, the way a foreign binding would (include/allset_hip.h: 0 ok, < 0 error,
+allset_last_error() for the text)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(lib, rc):
+    assert rc < 0, "a bad argument must not be accepted"
+    msg = lib.allset_last_error()
+    assert msg and len(msg) > 5
+    return msg.decode()
+
+
+def test_aggregation_entries_reject_bad_arguments(device):
+    from allset_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n, d, nnz = 64, 32, 200
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=device)
+    col = torch.zeros(nnz, dtype=torch.int32, device=device)
+    x = torch.randn(n, d, device=device)
+    out = torch.empty(n, d, device=device)
+    P = lambda t: t.data_ptr()
+    # segreduce: bad reduce code, bad dtype, null x with rows, leading dimension below the width, negative sizes
+    f = lib.allset_segreduce_fwd_ex
+    assert "reduce" in _err(lib, f(9, 0, 0, nnz, None, P(rowptr), P(col), None, P(x), d, P(out), d, None, n, n, d, st))
+    _err(lib, f(0, 7, 0, nnz, None, P(rowptr), P(col), None, P(x), d, P(out), d, None, n, n, d, st))
+    _err(lib, f(0, 0, 0, nnz, None, P(rowptr), P(col), None, None, d, P(out), d, None, n, n, d, st))
+    _err(lib, f(0, 0, 0, nnz, None, P(rowptr), P(col), None, P(x), d - 1, P(out), d, None, n, n, d, st))
+    _err(lib, f(0, 0, 0, nnz, None, P(rowptr), P(col), None, P(x), d, P(out), d, None, -1, n, d, st))
+    # the short-row variant refuses layouts it is not built for (rows not 16-byte aligned)
+    _err(lib, f(0, 0, 2, nnz, None, P(rowptr), P(col), None, P(x) + 4, d, P(out), d, None, n, n - 1, d, st))
+    # PMA: heads beyond the built maximum, C = 0, null logits
+    g = lib.allset_pma_fwd
+    alpha = torch.randn(n, 4, device=device)
+    m = torch.empty(n, 4, device=device); l = torch.empty(n, 4, device=device)
+    _err(lib, g(0, P(rowptr), P(col), P(alpha), P(x), d, 0.2, P(out), d, P(m), P(l), n, n, 4096, 1, st))
+    _err(lib, g(0, P(rowptr), P(col), None, P(x), d, 0.2, P(out), d, P(m), P(l), n, n, 4, 8, st))
+    _err(lib, g(0, P(rowptr), P(col), P(alpha), P(x), 4, 0.2, P(out), d, P(m), P(l), n, n, 4, 8, st))
+    # CSR build: negative counts
+    ws = ctypes.c_uint64(0)
+    _err(lib, lib.allset_csr_build_workspace_bytes(-5, 10, ctypes.byref(ws)))
+    torch.cuda.synchronize()                 # nothing was launched, nothing is pending
+
+
+def test_dense_entries_reject_bad_arguments(device):
+    from allset_amd import _lib, dense
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n, d = 100, 128
+    x = torch.randn(n, d + 4, device=device)[:, :d]                       # 16-byte aligned rows, ld = d + 4
+    y = torch.empty(n, d, device=device)
+    stats = torch.empty(n, 2, device=device)
+    g, b = torch.ones(d, device=device), torch.zeros(d, device=device)
+    P = lambda t: t.data_ptr()
+    # dropout probability outside [0, 1)
+    _err(lib, lib.allset_ln_fwd(P(x), d + 4, P(g), P(b), 1e-5, 0, 1.0, 0, P(y), d, P(stats), n, d, None, st))
+    _err(lib, lib.allset_ln_fwd(P(x), d + 4, P(g), P(b), 1e-5, 0, -0.1, 0, P(y), d, P(stats), n, d, None, st))
+    # null output, negative row count
+    _err(lib, lib.allset_ln_fwd(P(x), d + 4, P(g), P(b), 1e-5, 0, 0.0, 0, None, d, P(stats), n, d, None, st))
+    _err(lib, lib.allset_ln_fwd(P(x), d + 4, P(g), P(b), 1e-5, 0, 0.0, 0, P(y), d, P(stats), -3, d, None, st))
+    # widths the fused / tiled kernels are not built for report "unsupported", they do not guess
+    assert lib.allset_fused_linear_supported(100, 128) == 0 and lib.allset_gemm_x6_supported(256, 100) == 0
+    W = torch.randn(128, 100, device=device)
+    xb = torch.randn(n, 100, device=device)
+    rc = lib.allset_fused_linear_fwd(P(xb), 100, P(W), None, 1e-5, 0, 0.0, 0, None, None, 0, 0.0, 0, P(y), d, None, n, 100, 128,
+                                     None, None, None, None, None, st)
+    assert rc == -3 and b"fused_linear" in lib.allset_last_error()       # ALLSET_ERR_UNSUPPORTED
+    planes = torch.empty(int(lib.allset_gemm_x6_plane_bytes(256, 256)), dtype=torch.uint8, device=device)
+    xa = torch.randn(n, 256, device=device)
+    o = torch.empty(n, 256, device=device)
+    # misaligned A rows, LayerNorm-apply without gamma, dropout p = 1
+    _err(lib, lib.allset_gemm_x6(P(xa) + 4, 256, None, 0, 0.0, 0, None, None, None, 0.0, 0, P(planes), None, 0, 0.0, 0, P(o), 256, n - 1, 256,
+                                 256, None, st))
+    _err(lib, lib.allset_gemm_x6(P(xa), 256, None, 0, 0.0, 0, P(stats), None, None, 0.0, 0, P(planes), None, 0, 0.0, 0, P(o), 256, n, 256, 256,
+                                 None, st))
+    _err(lib, lib.allset_gemm_x6(P(xa), 256, None, 0, 0.0, 0, None, None, None, 1.0, 0, P(planes), None, 0, 0.0, 0, P(o), 256, n, 256, 256,
+                                 None, st))
+    assert lib.allset_gemm_x6_plane_bytes(256, 100) == -1
+    # the Python layer turns every one of these into AllSetHipError
+    with pytest.raises(_lib.AllSetHipError):
+        dense.gemm_x6_planes(torch.randn(256, 100, device=device), False)
+    torch.cuda.synchronize()
