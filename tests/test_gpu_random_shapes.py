@@ -114,7 +114,7 @@ def test_pma_aggregate_random(inc, heads, c, device):
 
 
 @settings(**COMMON)
-@given(n=st.integers(1, 700), K=st.sampled_from([64, 128, 256]), N=st.sampled_from([64, 128, 256]), has_ln=st.booleans(),
+@given(n=st.integers(1, 700), K=st.sampled_from([64, 128, 256, 512]), N=st.sampled_from([64, 128, 256, 512]), has_ln=st.booleans(),
        relu_in=st.booleans(), relu_out=st.booleans(), sd=st.integers(0, 10 ** 6))
 def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, device):
     """Any row count (tails of the 16-row chunks, n = 1) and every prologue / epilogue combination without dropout:
@@ -341,7 +341,7 @@ def test_layer_norm_res_random(n, d, with_colb, with_res, relu_out, bf16, sd, de
 
 
 @settings(**COMMON)
-@given(n=st.integers(1, 900), K=st.sampled_from([64, 128, 256]), N=st.sampled_from([64, 128, 256]),
+@given(n=st.integers(1, 900), K=st.sampled_from([64, 128, 256, 512]), N=st.sampled_from([64, 128, 256, 512]),
        p_in=st.sampled_from([0.0, 0.2, 0.5]), p_out=st.sampled_from([0.0, 0.3, 0.5]), sd=st.integers(0, 10 ** 6))
 def test_dropout_masks_agree_between_fused_and_unfused_chains(n, K, N, p_in, p_out, sd, device):
     """With explicit seeds the one-kernel Linear (LDS-resident weights for widths <= 128, tiled GEMM beyond) and the
