@@ -71,6 +71,9 @@ SIGNATURES = {
     "allset_row_stats": [_P, c_int64, c_int, c_float, _P, c_int64, c_int64, _P],
     "allset_gemm_x6": [_P, c_int64, _P, c_int64, c_float, c_int, _P, _P, _P, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                        _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
+    "allset_gemm_x6_lnb_partials": [c_int64],
+    "allset_gemm_x6_lnb": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P,
+                           c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_block_transpose": [_P, _P, c_int64, c_int64, c_int64, c_int64, c_int, _P],
     "allset_pma_merge_pack": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_ln_bf16_supported": [c_int64],
@@ -115,6 +118,7 @@ def load() -> ctypes.CDLL:
         fn.restype = c_int
     lib.allset_fused_linear_mask_words.restype = c_int64
     lib.allset_gemm_x6_plane_bytes.restype = c_int64
+    lib.allset_gemm_x6_lnb_partials.restype = c_int64
     lib.allset_last_error.argtypes = []
     lib.allset_last_error.restype = c_char_p
     got = lib.allset_version()

@@ -69,6 +69,17 @@ struct GxEpi {
   int relu_out;
   float p_out;             // dropout on the output, index r*N + n
   uint64_t seed_out;
+  // LayerNorm-backward epilogue (N <= 256: a tile holds whole rows): the GEMM's result is the gradient of
+  // u = dropout_p(LN(relu_in ? relu(x) : x)); what is stored is the gradient of x, and the workgroup's sums of
+  // dgamma / dbeta go to lnb_part[workgroup][0|1][N].  Active iff lnb_x != NULL (then bias / relu_out / p_out are unused).
+  const float* lnb_x;
+  int64_t lnb_ldx;
+  const float* lnb_stats;
+  const float* lnb_gamma;
+  int lnb_relu_in;
+  float lnb_p;
+  uint64_t lnb_seed;
+  float* lnb_part;
 };
 
 // Per-tile staging context of one thread: the row it stages (128 rows x 4 segments of 8 floats per K step).
@@ -80,7 +91,7 @@ struct GxRow {
   bool ok;
 };
 
-template <bool HAS_Y>
+template <bool HAS_Y, bool LNB>
 __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const float* __restrict__ A, int64_t lda, GxPro pro, const uint4* __restrict__ planes, GxEpi epi,
     float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base) {
@@ -211,8 +222,16 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     }
   };
 
+  const uint64_t lnb_seed = resolve_seed(seed_base, epi.lnb_seed);
+  const float lnb_inv = epi.lnb_p > 0.f ? 1.f / (1.f - epi.lnb_p) : 1.f;
+  const uint32_t lnb_thr = drop_threshold(epi.lnb_p);
+  float4 lnb_dg = make_float4(0.f, 0.f, 0.f, 0.f), lnb_db = lnb_dg;     // (LNB only: dead otherwise)
   int64_t tile = blockIdx.x;
-  if (tile >= total) return;
+  if (tile >= total) {
+    if constexpr (LNB)                                                 // an idle workgroup still owns a (zero) partial row
+      for (int i = threadIdx.x; i < 2 * N; i += kGxThreads) epi.lnb_part[static_cast<int64_t>(blockIdx.x) * 2 * N + i] = 0.f;
+    return;
+  }
   if (pro.stats) {
     for (int i = threadIdx.x; i < K; i += kGxThreads) { sGB[i] = pro.gamma[i]; sGB[512 + i] = pro.beta[i]; }
     __syncthreads();
@@ -264,7 +283,51 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const int c4 = (tid & 63) * 4;
     const int n = static_cast<int>(tile % n_tiles) * kGxBN + c4;
     const int64_t row0 = tile / n_tiles * kGxBM;
-    if (n < N) {                                                       // N % 4 == 0: a packet is inside or outside
+    if constexpr (LNB) {
+      // one wavefront per row (64 lanes x 4 columns = the whole row, N <= 256): the two row sums of the LayerNorm
+      // backward are wave reductions; dgamma / dbeta accumulate in registers over all rows this lane ever sees
+      const bool act = n < N;
+      const float inv_d = 1.f / static_cast<float>(N);
+      float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act) g4 = *reinterpret_cast<const float4*>(epi.lnb_gamma + n);
+      for (int rr = tid >> 6; rr < kGxBM; rr += kGxThreads / 64) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) break;                                        // (wave-uniform)
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
+        if (act) {
+          gv = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
+          xv = *reinterpret_cast<const float4*>(epi.lnb_x + row * epi.lnb_ldx + n);
+        }
+        const float mean = epi.lnb_stats[row * 2], rstd = epi.lnb_stats[row * 2 + 1];
+        float4 t = xv;
+        if (epi.lnb_relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+        float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
+        if (!act) xh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (epi.lnb_p > 0.f && act) {
+          float k0, k1, k2, k3;
+          keep_scale2(lnb_seed, row * N + n, lnb_thr, lnb_inv, k0, k1);
+          keep_scale2(lnb_seed, row * N + n + 2, lnb_thr, lnb_inv, k2, k3);
+          gv.x *= k0; gv.y *= k1; gv.z *= k2; gv.w *= k3;
+        }
+        lnb_dg.x += gv.x * xh.x; lnb_dg.y += gv.y * xh.y; lnb_dg.z += gv.z * xh.z; lnb_dg.w += gv.w * xh.w;
+        lnb_db.x += gv.x; lnb_db.y += gv.y; lnb_db.z += gv.z; lnb_db.w += gv.w;
+        const float4 gh = make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w);
+        float s1 = gh.x + gh.y + gh.z + gh.w, s2 = gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        s1 *= inv_d; s2 *= inv_d;
+        if (act) {
+          float4 o = make_float4(rstd * (gh.x - s1 - xh.x * s2), rstd * (gh.y - s1 - xh.y * s2),
+                                 rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
+          if (epi.lnb_relu_in) {
+            o.x = xv.x > 0.f ? o.x : 0.f; o.y = xv.y > 0.f ? o.y : 0.f;
+            o.z = xv.z > 0.f ? o.z : 0.f; o.w = xv.w > 0.f ? o.w : 0.f;
+          }
+          *reinterpret_cast<float4*>(out + row * ldo + n) = o;
+        }
+      }
+    }
+    if (!LNB && n < N) {                                               // N % 4 == 0: a packet is inside or outside
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (epi.bias) bv = *reinterpret_cast<const float4*>(epi.bias + n);
       for (int rr = tid >> 6; rr < kGxBM; rr += kGxThreads / 64) {
@@ -288,6 +351,21 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   }
 #undef GX_LOAD
 #undef GX_STORE
+  if constexpr (LNB) {
+    // lane l of every wave holds the sums of columns 4l..4l+3 over that wave's rows: add the 8 waves up through LDS
+    float* red = sOut;                                                 // [8 waves][2][256]
+    const int c4 = (tid & 63) * 4;
+    *reinterpret_cast<float4*>(red + (wave * 2 + 0) * kGxBN + c4) = lnb_dg;
+    *reinterpret_cast<float4*>(red + (wave * 2 + 1) * kGxBN + c4) = lnb_db;
+    __syncthreads();
+    for (int i = tid; i < 2 * N; i += kGxThreads) {
+      const int which = i / N, c = i - which * N;
+      float acc_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < kGxThreads / 64; ++w) acc_ += red[(w * 2 + which) * kGxBN + c];
+      epi.lnb_part[static_cast<int64_t>(blockIdx.x) * 2 * N + i] = acc_;
+    }
+  }
 }
 
 // ---- row statistics for the LayerNorm-apply prologue: stats[r] = {mean, rstd} of relu_in ? relu(x[r]) : x[r] ----------------
@@ -364,32 +442,67 @@ extern "C" int allset_row_stats(const float* x, int64_t ldx, int relu_in, float 
   return ALLSET_OK;
 }
 
+static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
+                        const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                        const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
+                        const uint64_t* seed_base, void* stream);
+
+extern "C" int64_t allset_gemm_x6_lnb_partials(int64_t rows) {
+  const int64_t tiles = (rows + kGxBM - 1) / kGxBM;
+  return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;
+}
+
+extern "C" int allset_gemm_x6_lnb(const float* G, int64_t ldg, const float* mask_y, int64_t ldy, float p_mask, const void* planes,
+                                  const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p,
+                                  uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows,
+                                  int64_t N, int64_t K, const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(N >= 4 && N <= kGxBN, "gemm_x6_lnb: the LayerNorm row (N) must fit one 256-column tile");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "gemm_x6_lnb: dropout p must be in [0,1)");
+  ALLSET_REQUIRE(partials != nullptr && n_partials == allset_gemm_x6_lnb_partials(rows), "gemm_x6_lnb: partials must hold allset_gemm_x6_lnb_partials(rows) x 2 x N floats");
+  if (rows == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * N * sizeof(float), static_cast<hipStream_t>(stream)));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(x && stats && gamma && gx, "gemm_x6_lnb: null pointer");
+  ALLSET_REQUIRE(ldx >= N && ldx % 4 == 0 && aligned16(x) && aligned16(gamma), "gemm_x6_lnb: x rows / gamma must be 16-byte aligned");
+  GxEpi epi{nullptr, 0, 0.f, 0, x, ldx, stats, gamma, relu_in, p, seed, partials};
+  return gemm_x6_impl(G, ldg, mask_y, ldy, p_mask, 0, nullptr, nullptr, nullptr, 0.f, 0, planes, epi, gx, ldgx, rows, N, K, seed_base, stream);
+}
+
 extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                               const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                               const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
                               float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base,
                               void* stream) {
   clear_error();
+  ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "gemm_x6: dropout p must be in [0,1)");
+  GxEpi epi{bias, relu_out, p_out, seed_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
+  ALLSET_REQUIRE(bias == nullptr || aligned16(bias), "gemm_x6: bias must be 16-byte aligned");
+  return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base, stream);
+}
+
+static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
+                        const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                        const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
+                        const uint64_t* seed_base, void* stream) {
   if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_x6: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(rows >= 0, "gemm_x6: bad row count");
-  ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f && p_mask >= 0.f && p_mask < 1.f, "gemm_x6: dropout p must be in [0,1)");
+  ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_mask >= 0.f && p_mask < 1.f, "gemm_x6: dropout p must be in [0,1)");
   if (rows == 0) return ALLSET_OK;
   ALLSET_REQUIRE(A && planes && out, "gemm_x6: null pointer");
   ALLSET_REQUIRE(lda >= K && lda % 4 == 0 && aligned16(A) && aligned16(planes), "gemm_x6: A rows / planes must be 16-byte aligned");
-  ALLSET_REQUIRE(ldo >= N && ldo % 4 == 0 && aligned16(out) && (bias == nullptr || aligned16(bias)),
-                 "gemm_x6: output rows / bias must be 16-byte aligned");
+  ALLSET_REQUIRE(ldo >= N && ldo % 4 == 0 && aligned16(out), "gemm_x6: output rows must be 16-byte aligned");
   ALLSET_REQUIRE(mask_y == nullptr || (ldy >= K && ldy % 4 == 0 && aligned16(mask_y)), "gemm_x6: mask source rows must be 16-byte aligned");
   ALLSET_REQUIRE(stats == nullptr || (gamma && beta && K <= 512), "gemm_x6: LayerNorm-apply needs gamma and beta, K <= 512");
   GxPro pro{mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in};
-  GxEpi epi{bias, relu_out, p_out, seed_out};
   const int64_t tiles = (rows + kGxBM - 1) / kGxBM * ((N + kGxBN - 1) / kGxBN);
   const int64_t blocks = tiles < 256 ? tiles : 256;                     // one workgroup per CU (144 KB of LDS), walking its tiles
-  if (mask_y)
-    gemm_x6_kernel<true><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>(
-        A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base);
-  else
-    gemm_x6_kernel<false><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>(
-        A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base);
+#define GX_LAUNCH(Y, L) gemm_x6_kernel<Y, L><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>( \
+      A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base)
+  if (epi.lnb_x != nullptr) { if (mask_y) GX_LAUNCH(true, true); else GX_LAUNCH(false, true); }
+  else { if (mask_y) GX_LAUNCH(true, false); else GX_LAUNCH(false, false); }
+#undef GX_LAUNCH
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

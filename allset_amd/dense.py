@@ -234,6 +234,30 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
     return out
 
 
+def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
+                mask_y: Optional[Tensor] = None, p_mask: float = 0.0, seed_base: Optional[Tensor] = None
+                ) -> Tuple[Tensor, Tensor, Tensor]:
+    """Backward-data of a wide Linear fused with the LayerNorm backward of its input (include/allset_hip.h
+    allset_gemm_x6_lnb): returns (gx, dgamma, dbeta).  ``planes_t``: ``gemm_x6_planes(weight, True)``; N = x.shape[1] <= 256."""
+    dev = require_device(G, planes_t, x, stats, gamma, mask_y)
+    _check_f32(G, x, stats, gamma, mask_y)
+    G, x = _rowmajor(G), _rowmajor(x)
+    n, K = G.shape
+    N = x.shape[1]
+    if mask_y is not None:
+        mask_y = _rowmajor(mask_y)
+    lib = _lib.load()
+    npart = int(lib.allset_gemm_x6_lnb_partials(n))
+    partials = torch.empty((npart, 2, N), dtype=torch.float32, device=dev)
+    gx = torch.empty((n, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("gemm_x6_lnb", dev, n * (K + 2 * N) * 4):
+        check(lib.allset_gemm_x6_lnb(ptr(G), _ld(G), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, ptr(planes_t),
+                                     ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
+                                     ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_x6_lnb")
+    red = reduce_partials(partials)
+    return gx, red[0], red[1]
+
+
 def fused_linear_supported(K: int, N: int) -> bool:
     return bool(_lib.load().allset_fused_linear_supported(K, N))
 
@@ -501,6 +525,11 @@ class _WideNormLinear(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         if need_x or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
             # gradient of the Linear's input u = dropout(LN(relu(x))): (gy * epilogue mask) @ W
+            if gamma is not None and weight.shape[1] <= 256:
+                # one kernel: the Linear's input gradient never leaves the chip, the LayerNorm backward is the GEMM's epilogue
+                gx, dg, db = gemm_x6_lnb(gy, gemm_x6_planes(weight, True), x, stats, gamma, relu_in, p_in, seed_in, mask_y=y,
+                                         p_mask=p_out, seed_base=base)
+                return gx, dg, db, gw, gb, None, None, None, None, None
             gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out)
             if gamma is not None:
                 gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x)

@@ -258,6 +258,17 @@ int allset_gemm_x6_supported(int64_t N, int64_t K);
 int64_t allset_gemm_x6_plane_bytes(int64_t N, int64_t K);
 int allset_gemm_x6_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream);
 int allset_row_stats(const float* x, int64_t ldx, int relu_in, float eps, float* stats, int64_t rows, int64_t d, void* stream);
+/* The same GEMM with a LayerNorm-BACKWARD epilogue, for N <= 256 (a tile holds whole rows): backward-data of a Linear whose
+ * input was u = dropout_p(LN(relu_in ? relu(x) : x)) in one kernel --
+ *   gu = (G * epilogue mask from mask_y / p_mask) @ B^T  stays on chip;  gx (stored) = LayerNorm backward of gu wrt x
+ *   (dropout mask regenerated from (seed, r*N + n), relu mask from the sign of x, {mean, rstd} from `stats`);
+ *   partials[w][0|1][N] = workgroup w's sums of dgamma = gu * xhat and dbeta = gu over its rows; the caller adds the
+ *   allset_gemm_x6_lnb_partials(rows) rows up (allset_reduce_partials).  Replaces allset_gemm_x6 + allset_ln_bwd. */
+int64_t allset_gemm_x6_lnb_partials(int64_t rows);
+int allset_gemm_x6_lnb(const float* G, int64_t ldg, const float* mask_y, int64_t ldy, float p_mask, const void* planes,
+                       const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p, uint64_t seed,
+                       float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows, int64_t N, int64_t K,
+                       const uint64_t* seed_base, void* stream);
 int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                    const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                    const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,

@@ -416,3 +416,27 @@ def test_bf16_storage_aggregate_random(inc, d, aggr, weighted, pma_heads, device
     # one bf16 rounding of the result (2^-9 relative) on top of fp32 accumulation
     tol = 2.0 ** -8
     torch.testing.assert_close(out.float().cpu().double(), ref, rtol=tol, atol=tol * max(1.0, longest / 64.0))
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 900), K=st.sampled_from([64, 128, 256, 512]), N=st.sampled_from([4, 64, 100, 128, 256]), relu_in=st.booleans(),
+       p=st.sampled_from([0.0, 0.3]), use_mask=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_gemm_with_layer_norm_backward_epilogue_random(n, K, N, relu_in, p, use_mask, sd, device):
+    """allset_gemm_x6_lnb (backward-data of a wide Linear with the LayerNorm backward as the GEMM's epilogue) against the two
+    kernels it replaces, allset_gemm_x6 + allset_ln_bwd, with the same seeds: identical masks, results to rounding."""
+    from allset_amd import dense
+    g = torch.Generator(device=device).manual_seed(sd)
+    G = torch.randn(n, K, device=device, generator=g)                 # gradient of the Linear's output [n, out = K of this GEMM]
+    W = torch.randn(K, N, device=device, generator=g) / K ** 0.5      # weight [out, in = N]
+    x = torch.randn(n, N, device=device, generator=g)                 # the Linear's (pre-LayerNorm) input
+    gamma = 1 + 0.2 * torch.randn(N, device=device, generator=g)
+    ymask = torch.randn(n, K, device=device, generator=g) if use_mask else None
+    stats = dense.row_stats(x, relu_in, 1e-5) if N <= 512 else None
+    planes_t = dense.gemm_x6_planes(W, True)
+    gu = dense.gemm_x6(G, planes_t, N, None, mask_y=ymask, p_mask=0.25 if use_mask else 0.0)
+    gx_ref, dg_ref, db_ref = dense.ln_bwd(gu, x, stats, gamma, relu_in, p, sd + 5)
+    gx, dg, db = dense.gemm_x6_lnb(G, planes_t, x, stats, gamma, relu_in, p, sd + 5, mask_y=ymask, p_mask=0.25 if use_mask else 0.0)
+    sc = max(1.0, float(gx_ref.abs().max()))
+    torch.testing.assert_close(gx, gx_ref, rtol=1e-4, atol=1e-4 * sc)
+    torch.testing.assert_close(dg, dg_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(dg_ref.abs().max())))
+    torch.testing.assert_close(db, db_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(db_ref.abs().max())))
