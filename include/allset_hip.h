@@ -258,7 +258,8 @@ int allset_gemm_x6_supported(int64_t N, int64_t K);
 int64_t allset_gemm_x6_plane_bytes(int64_t N, int64_t K);
 int allset_gemm_x6_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream);
 int allset_row_stats(const float* x, int64_t ldx, int relu_in, float eps, float* stats, int64_t rows, int64_t d, void* stream);
-/* The same GEMM with a LayerNorm-BACKWARD epilogue, for N <= 256 (a tile holds whole rows): backward-data of a Linear whose
+/* The same GEMM with a LayerNorm-BACKWARD epilogue, for N <= 256 (a tile holds whole rows) -- the autograd of one
+ * `norm -> Linear` stage of reference MLP.forward (layers.py:571-579) with respect to the stage's input: backward-data of a Linear whose
  * input was u = dropout_p(LN(relu_in ? relu(x) : x)) in one kernel --
  *   gu = (G * epilogue mask from mask_y / p_mask) @ B^T  stays on chip;  gx (stored) = LayerNorm backward of gu wrt x
  *   (dropout mask regenerated from (seed, r*N + n), relu mask from the sign of x, {mean, rstd} from `stats`);
