@@ -579,6 +579,17 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
     return torch.cat([dec2(get()) for get in _unstage(vc, K, w, group)])
 
 
+_SLOT_INDEX = {}
+
+
+def _slot_index(heads: int, world: int, device) -> Tensor:
+    """Device copy of ``head_slots(heads, world)[1]``, made once (a per-step host-to-device copy would also break capture)."""
+    key = (heads, world, str(device))
+    if key not in _SLOT_INDEX:
+        _SLOT_INDEX[key] = torch.tensor(head_slots(heads, world)[1], device=device)
+    return _SLOT_INDEX[key]
+
+
 def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, dropout: float = 0.0,
                          training: bool = False, group=None, kernels=HipPmaKernels, chunks: int = 1) -> Tensor:
     """The layer of :func:`sharded_pma_layer` with column-sharded pooling: per direction one all-to-all of the values,
@@ -590,7 +601,7 @@ def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedH
 
     def project(p):
         hl, slots = head_slots(p.heads, w)
-        idx = None if slots == list(range(p.heads)) else torch.tensor(slots, device=x_owned.device)
+        idx = None if slots == list(range(p.heads)) else _slot_index(p.heads, w, x_owned.device)
 
         def f(t):
             V, alpha = p.project(t)                                  # [rows, H*C], [rows, H]: dense, owned rows
