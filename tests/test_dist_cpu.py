@@ -493,3 +493,103 @@ def test_choose_sharding():
     assert adist.choose_sharding(8, 128, heads=4) == "columns" and adist.choose_sharding(8, 256, heads=4, elem=2) == "columns"
     assert adist.choose_sharding(8, 64) == "rows"            # 8 fp32 columns = 32-byte rows
     assert adist.choose_sharding(8, 100) == "rows" and adist.choose_sharding(4, 128, heads=3) == "rows"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# column scheme at random shapes, 2 ranks: one spawn, many configurations
+# ---------------------------------------------------------------------------------------------------------------
+
+def _rand_cfgs():
+    rng = np.random.default_rng(2026)
+    cfgs = []
+    for i in range(24):
+        pma = bool(i % 2)
+        H = int(rng.choice([1, 2, 4])) if pma else 1
+        cfgs.append(dict(n_v=int(rng.integers(5, 60)), n_e=int(rng.integers(3, 40)), nnz=int(rng.integers(20, 400)),
+                         d=int(rng.choice([8, 16, 32])), pma=pma, H=H, aggr=str(rng.choice(["add", "mean", "max", "min"])),
+                         chunks=int(rng.choice([1, 2, 3])), seed=int(rng.integers(1 << 30))))
+    return cfgs
+
+
+def _rand_problem(c):
+    rng = np.random.default_rng(c["seed"])
+    pairs = sorted({(int(rng.integers(c["n_v"])), int(rng.integers(c["n_e"]))) for _ in range(c["nnz"])})
+    ei = torch.tensor(pairs, dtype=torch.int64).t().contiguous()
+    x = torch.from_numpy(rng.standard_normal((c["n_v"], c["d"])).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((c["n_v"], c["d"])).astype(np.float32))
+    return ei, x, G
+
+
+def _rand_convs(c):
+    from allset_amd import HalfNLHconv
+    torch.manual_seed(c["seed"] % 1000)
+    d = c["d"]
+    return (HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=c["H"], attention=c["pma"]).eval(),
+            HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=c["H"], attention=c["pma"]).eval())
+
+
+def _col_random_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
+        res = []
+        for c in _rand_cfgs():
+            ei, x, G = _rand_problem(c)
+            hg = adist.ColumnShardedHypergraph(ei, c["n_v"], c["n_e"], world, rank, chunks=c["chunks"],
+                                               norm=torch.ones(ei.shape[1], dtype=torch.int64))
+            hg.v2e = (ei, hg.n_e_pad)
+            hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
+            a, b = _rand_convs(c)
+            xp = torch.cat([x, x.new_zeros(hg.n_v_pad - c["n_v"], c["d"])])
+            Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - c["n_v"], c["d"])])
+            xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
+            if c["pma"]:
+                out = adist.colsharded_pma_layer(a, b, xo, hg, kernels=TorchPmaKernels, chunks=c["chunks"])
+            else:
+                out = adist.colsharded_deepsets_layer(a, b, xo, hg, aggr=c["aggr"], aggregate=_oracle_aggregate, chunks=c["chunks"])
+            (out * Gp[hg.v_lo:hg.v_hi]).sum().backward()
+            res.append((out.detach().numpy().copy(), xo.grad.numpy().copy()))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_colsharded_layers_random_configurations_two_ranks():
+    """24 random (sizes, width, heads, aggregation, chunk count) configurations through the 2-rank column scheme in one spawn:
+    d/2 columns per rank, a head shared by both ranks when H = 1, padded owned blocks, chunked exchange."""
+    import torch.nn.functional as F
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_col_random_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i, c in enumerate(_rand_cfgs()):
+        ei, x, G = _rand_problem(c)
+        a, b = _rand_convs(c)
+        xr = x.clone().requires_grad_(True)
+        rev = torch.stack([ei[1], ei[0]])
+        if c["pma"]:
+            def pm(p, xin, e_idx, n_dst):
+                H, C = p.heads, p.hidden
+                o = TorchPmaKernels.aggregate(p.lin_V(xin), p._logits(xin), (e_idx, n_dst), H, 0.2)
+                o = p.ln0((o.view(-1, H, C) + p.att_r).view(-1, H * C))
+                return p.ln1(o + F.relu(p.rFF(o)))
+            v = F.relu(pm(b.prop, F.relu(pm(a.prop, xr, ei, c["n_e"])), rev, c["n_v"]))
+        else:
+            h = F.relu(a.f_enc(xr))
+            e = F.relu(a.f_dec(_oracle_aggregate(h, (ei, c["n_e"]), torch.ones(ei.shape[1], dtype=torch.int64), c["aggr"])))
+            g = F.relu(b.f_enc(e))
+            v = F.relu(b.f_dec(_oracle_aggregate(g, (rev, c["n_v"]), torch.ones(ei.shape[1], dtype=torch.int64), c["aggr"])))
+        (v * G).sum().backward()
+        out = torch.cat([torch.from_numpy(results[r][i][0]) for r in range(world)])[:c["n_v"]]
+        gx = torch.cat([torch.from_numpy(results[r][i][1]) for r in range(world)])[:c["n_v"]]
+        torch.testing.assert_close(out, v.detach(), rtol=1e-4, atol=1e-5, msg=lambda m: f"config {i} {c}: {m}")
+        if c["aggr"] in ("add", "mean") or c["pma"]:
+            torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=1e-4, msg=lambda m: f"config {i} {c}: {m}")
