@@ -251,22 +251,30 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     GX_STORE(cur, 0, 0);                                               // step 0 of this tile (loaded during the previous one)
     if (ksteps > 1) GX_LOAD(cur, img_cur, 1); else if (has_next) GX_LOAD(nxt, img_nxt, 0);
     __syncthreads();
-    for (int ks = 0; ks < ksteps; ++ks) {
-      // MFMAs out of buffer ks & 1; the registers (step ks + 1) go to the other buffer and reload with step ks + 2 --
-      // of the next tile when this one has no such step; the last step only multiplies (the arena turns into the output
-      // tile next, the registers keep the next tile's step 0).
-      const int buf = ks & 1;
-      const bool last = ks + 1 == ksteps;
-      if (mfma_first) compute(buf);
-      if (!last) {
-        GX_STORE(cur, ks + 1, buf ^ 1);
-        if (ks + 2 < ksteps) GX_LOAD(cur, img_cur, ks + 2); else if (has_next) GX_LOAD(nxt, img_nxt, 0);
-      }
-      if (!mfma_first) compute(buf);
-      // LDS traffic must have landed; the global loads just issued stay in flight ACROSS the barrier (__syncthreads()
-      // would drain them: s_waitcnt vmcnt(0), one exposed memory latency per step)
-      __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // MFMAs out of buffer ks & 1; the registers (step ks + 1) go to the other buffer and reload with step ks + 2 -- of the
+    // next tile when this one has no such step; the last step only multiplies (the arena turns into the output tile next, the
+    // registers keep the next tile's step 0).  Two steps per trip so that the buffer index is a compile-time constant: every
+    // LDS address of the fragments and of the staging stores is then an immediate offset instead of integer arithmetic
+    // (profiles/pmc_gemm_x6.json: a third of this kernel's VALU instructions were address arithmetic).
+#define GX_STEP(KS_, BUF_)                                                                      \
+  do {                                                                                          \
+    const int ks_ = (KS_);                                                                      \
+    const bool last_ = ks_ + 1 == ksteps;                                                       \
+    if (mfma_first) compute(BUF_);                                                              \
+    if (!last_) {                                                                               \
+      GX_STORE(cur, ks_ + 1, (BUF_) ^ 1);                                                       \
+      if (ks_ + 2 < ksteps) GX_LOAD(cur, img_cur, ks_ + 2); else if (has_next) GX_LOAD(nxt, img_nxt, 0); \
+    }                                                                                           \
+    if (!mfma_first) compute(BUF_);                                                             \
+    /* LDS traffic must have landed; the global loads just issued stay in flight ACROSS the barrier (__syncthreads()   \
+       would drain them: s_waitcnt vmcnt(0), one exposed memory latency per step) */                                   \
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
+  } while (0)
+    for (int ks = 0; ks < ksteps; ks += 2) {
+      GX_STEP(ks, 0);
+      if (ks + 1 < ksteps) GX_STEP(ks + 1, 1);
     }
+#undef GX_STEP
 
     // ---- epilogue.  lane holds acc[rt][ct][r] = tile[wr*64 + rt*16 + 4*fg + r][wc*64 + ct*16 + fr]: dword stores from
     // that layout are issue-bound (~5 B/clk/CU), so the tile takes one trip through LDS (pitch 260 floats: the four row
