@@ -7,8 +7,8 @@
 // weight is 384 KB of planes, so here the weight streams too: a workgroup owns a 128-row x 256-column output tile (fp32
 // accumulators: 64 VGPRs per lane) and walks K in steps of 32, staging per step the A slab (split into planes on the fly,
 // with the prologue -- mask / relu / LayerNorm-apply / dropout -- applied per element as it passes) and the matching
-// 48 KB image of pre-split weight planes (allset_gemm_x6_planes lays them out exactly as the LDS wants them; 384 KB per
-// 256 x 256 weight, L2-resident).  Double-buffered: 144 KB of the 160 KB LDS, one workgroup of 8 waves per CU.
+// 48 KB image of pre-split weight planes (allset_gemm_x6_planes lays them out as the LDS wants them, the six 1-KB pieces a
+// wave copies per step side by side: gx_image_at; 384 KB per 256 x 256 weight, L2-resident).  Double-buffered: 144 KB of the 160 KB LDS, one workgroup of 8 waves per CU.
 // Per step and wave: 24 ds_read_b128 feed 96 MFMAs (16 accumulator tiles x 6 plane products) -- the kernel is meant to
 // be matrix-pipe-bound: 2*rows*N*K*6 flop at the bf16 rate is ~1.6x the HBM time of its operands at K = N = 256.
 #include "common.h"
@@ -27,7 +27,15 @@ using bf16x8_t = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 union GxFrag { uint4 u; bf16x8_t v; };
 
-// ---- weight planes: [n_tile][k_step][plane][256 n][32 k] bf16, zero-padded in n ------------------------------------------
+// Where dword `at` of a K step's LDS slab of B (3 planes x 256 n x 32 k bf16 = 3072 pieces of 16 bytes; thread t of the
+// 512 copies pieces t, t + 512, ..., t + 2560) sits in the global image: the six pieces of one WAVE are adjacent (6 x 1 KB),
+// so one 64-bit address per K step reaches all six through the +-4 KB immediate of global_load, each load still 1 KB contiguous.
+__device__ __forceinline__ int gx_image_at(int at) {
+  const int j = at >> 2, piece = j >> 9, t = j & 511;
+  return (((t >> 6) * 6 + piece) * 64 + (t & 63)) * 4 + (at & 3);
+}
+
+// ---- weight planes: [n_tile][k_step] slabs of [plane][256 n][32 k] bf16 (zero-padded in n), pieces permuted by gx_image_at ------------------------------------------
 __global__ __launch_bounds__(kBlock) void gemm_x6_planes_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
                                                                 uint32_t* __restrict__ planes, int N, int K) {
   const int n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
@@ -45,10 +53,10 @@ __global__ __launch_bounds__(kBlock) void gemm_x6_planes_kernel(const float* __r
     split3_bf16(w0, w1, ph, pm, pl);
     const int nt = n / kGxBN, nn = n % kGxBN, ks = k / kGxKS, kk = k % kGxKS;
     const int64_t image = (static_cast<int64_t>(nt) * (K / kGxKS) + ks) * 3 * (kGxBN * kGxKS / 2);   // dwords
-    const int64_t at = image + nn * (kGxKS / 2) + (((kk >> 3) ^ gx_swz(nn)) << 2) + ((kk & 7) >> 1);   // swizzled piece
-    planes[at] = ph;
-    planes[at + kGxBN * kGxKS / 2] = pm;
-    planes[at + 2 * (kGxBN * kGxKS / 2)] = pl;
+    const int at = nn * (kGxKS / 2) + (((kk >> 3) ^ gx_swz(nn)) << 2) + ((kk & 7) >> 1);   // swizzled piece (dword of the LDS slab)
+    planes[image + gx_image_at(at)] = ph;
+    planes[image + gx_image_at(at + kGxBN * kGxKS / 2)] = pm;
+    planes[image + gx_image_at(at + 2 * (kGxBN * kGxKS / 2))] = pl;
   }
 }
 
@@ -120,6 +128,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   // ---- staging roles
   const int s_row = tid >> 2, s_seg = tid & 3;
   const int a_st = s_row * 4 + (s_seg ^ gx_swz(s_row));                 // swizzled 16-byte piece (gx_swz)
+  const int b_img = (tid >> 6) * 384 + (tid & 63) + 192;               // gx_image_at: this wave's six pieces, from the middle
   auto row_ctx = [&](int64_t tile) {
     GxRow c;
     const int64_t row0 = tile / n_tiles * kGxBM;
@@ -146,9 +155,9 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       py0 = *reinterpret_cast<const float4*>((ctx_).y + k0_);                                   \
       py1 = *reinterpret_cast<const float4*>((ctx_).y + k0_ + 4);                               \
     }                                                                                           \
-    const uint4* img_ = (img_base_) + static_cast<int64_t>(ks_) * kBSlab + tid;                \
-    pb0 = img_[0]; pb1 = img_[kGxThreads]; pb2 = img_[2 * kGxThreads];                          \
-    pb3 = img_[3 * kGxThreads]; pb4 = img_[4 * kGxThreads]; pb5 = img_[5 * kGxThreads];         \
+    const uint4* img_ = (img_base_) + static_cast<int64_t>(ks_) * kBSlab + b_img;               \
+    pb0 = img_[-192]; pb1 = img_[-128]; pb2 = img_[-64];                                        \
+    pb3 = img_[0]; pb4 = img_[64]; pb5 = img_[128];                                             \
   } while (0)
 
   auto prologue2 = [&](const GxRow& c, float a0, float a1, float y0, float y1, int kk, float& o0, float& o1) {
