@@ -28,11 +28,34 @@ CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
             "-fno-slp-vectorize"] + os.environ.get("ALLSET_EXTRA_CXXFLAGS", "").split()
 
 
+# The kernels were validated (bitwise run-to-run determinism of the LayerNorm-backward epilogue, tests/test_gpu_dense.py) with
+# this compiler and the -fno-slp-vectorize workaround above.  Another hipcc may miscompile differently -- or not need the
+# workaround: re-run the GPU suite, then extend this tuple (or set ALLSET_ALLOW_ANY_HIPCC=1 to build at your own risk).
+VALIDATED_HIPCC = ("7.2.26015",)
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found; cannot build liballset_hip.so")
     return exe
+
+
+def hipcc_version() -> str:
+    out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        if line.startswith("HIP version:"):
+            return line.split(":", 1)[1].strip()
+    return "unknown"
+
+
+def _check_compiler() -> None:
+    ver = hipcc_version()
+    if not any(ver.startswith(v) for v in VALIDATED_HIPCC) and os.environ.get("ALLSET_ALLOW_ANY_HIPCC", "0") != "1":
+        raise RuntimeError(
+            f"hipcc reports HIP version {ver}; liballset_hip.so was validated with {VALIDATED_HIPCC} only (the fused "
+            "dense kernels depend on a compiler workaround, see CXXFLAGS in allset_amd/build.py).  Re-run "
+            "`pytest -m gpu` with this compiler and add it to VALIDATED_HIPCC, or set ALLSET_ALLOW_ANY_HIPCC=1.")
 
 
 def _stale(target: str, deps: List[str]) -> bool:
@@ -56,6 +79,9 @@ def _compile(src: str, force: bool) -> str:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Build (if stale) and return the path of liballset_hip.so."""
     os.makedirs(BUILD_DIR, exist_ok=True)
+    if force or any(_stale(os.path.join(BUILD_DIR, os.path.splitext(src)[0] + ".o"), [os.path.join(CSRC, src)] + HEADERS)
+                    for src in SOURCES):
+        _check_compiler()                      # only when something is actually compiled
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or _stale(LIB_PATH, objs):

@@ -34,8 +34,16 @@ class _SeedSource:
 def _draw_seed() -> int:
     if _SeedSource.base is not None:
         _SeedSource.salt += 1
-        return _SeedSource.salt
-    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+        return _SeedSource.salt + (_rank() << 32)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    # Ranks of a sharded job seed torch identically (replicated initial weights), and a mask is a hash of (seed,
+    # LOCAL element index): without the rank in the seed every rank would drop the same positions of its row block.
+    return (seed ^ (_rank() * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
 def _seed_base() -> Optional[Tensor]:

@@ -166,8 +166,11 @@ class ShardedHypergraph:
     product builds :class:`allset_amd.incidence.Incidence` objects (``build_incidences``)."""
 
     def __init__(self, local_edge_index: Tensor, n_v: int, n_e_local: int, world: int, rank: int,
-                 norm: Optional[Tensor] = None):
+                 norm: Optional[Tensor] = None, inc_ids: Optional[Tensor] = None):
         self.local_edge_index = local_edge_index
+        # positions of the local incidences in the GLOBAL edge list (what a replicated per-incidence parameter such as
+        # SetGNN.Importance, reference models.py:336-337, is indexed by); only LearnMask needs them
+        self.inc_ids = inc_ids
         self.n_v, self.n_e_local, self.world, self.rank = int(n_v), int(n_e_local), int(world), int(rank)
         self.v_lo, self.v_hi, self.n_v_pad = vertex_block(n_v, world, rank)
         self.norm = norm
@@ -285,9 +288,19 @@ class HipPmaKernels:
                                variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]), row_order=T.row_order)
 
 
+def _no_batchnorm(*convs) -> None:
+    """Row-sharded BatchNorm would take its batch statistics over one rank's block (zero pad rows included) and let
+    the replicated running statistics drift apart silently; it needs a cross-rank (count, sum, sum of squares)
+    reduction that is not built.  Refuse instead of computing something else than the single-GPU model."""
+    if not _skip_collective(None) and _has_batchnorm(*convs):
+        raise NotImplementedError("sharded execution does not cover Normalization='bn' (per-rank batch statistics would "
+                                  "differ from the single-GPU model); use 'ln' or 'None'")
+
+
 def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, aggr: str = "add",
                            dropout: float = 0.0, training: bool = False, group=None,
-                           aggregate: Callable = _hip_deepsets) -> Tensor:
+                           aggregate: Callable = _hip_deepsets, norm: Optional[Tensor] = None,
+                           dropout_out: Optional[float] = None) -> Tensor:
     """One V->E->V AllDeepSets layer (reference models.py:475-481 with layers.py:630-634 inlined) on a
     hyperedge shard.  ``x_owned``: this rank's block of vertex rows [n_v_pad/P, F].  Returns the owned block
     of the layer output.  ``v2e_conv`` / ``e2v_conv`` are :class:`allset_amd.layers.HalfNLHconv` (Deep Sets
@@ -295,24 +308,27 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     (``allreduce_grads``) -- each rank sees only its rows."""
     if aggr not in ("add", "sum", "mean", "max", "min"):
         raise ValueError(f"aggr {aggr!r}")
+    _no_batchnorm(v2e_conv, e2v_conv)
+    norm = hg.norm if norm is None else norm                   # ``norm``: per-incidence weights of the LOCAL incidences
+    p_out = dropout if dropout_out is None else dropout_out    # GPR applies the last dropout itself (models.py:466-469)
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
     # ``training`` must agree with the convs' own mode (the fused MLP kernels read conv.training)
     h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
     h_full = all_gather_rows(h, group)
-    e = aggregate(h_full, hg.v2e, hg.norm, aggr)
+    e = aggregate(h_full, hg.v2e, norm, aggr)
     e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)           # conv's relu (SetGNN's outer relu is idempotent) + dropout
     # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
     g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
     if aggr in ("max", "min"):
         # local extreme over this rank's hyperedges (autograd routes to the local arg-extreme), then the key merge
-        partial = aggregate(g, hg.e2v, hg.norm, aggr)
+        partial = aggregate(g, hg.e2v, norm, aggr)
         v = _ShardedExtremeMerge.apply(partial, hg.local_vertex_has_incidence(), hg, group, aggr == "min")
     else:
-        partial = aggregate(g, hg.e2v, hg.norm, "add")
+        partial = aggregate(g, hg.e2v, norm, "add")
         v = reduce_scatter_rows(partial, group)
     if aggr == "mean":
         v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
-    return e2v_conv._mlp_act(e2v_conv.f_dec, v, dropout)
+    return e2v_conv._mlp_act(e2v_conv.f_dec, v, p_out)
 
 
 class _ShardedPmaE2V(torch.autograd.Function):
@@ -373,7 +389,8 @@ class _ShardedPmaE2V(torch.autograd.Function):
 
 
 def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, dropout: float = 0.0,
-                      training: bool = False, group=None, kernels=HipPmaKernels) -> Tensor:
+                      training: bool = False, group=None, kernels=HipPmaKernels,
+                      dropout_out: Optional[float] = None) -> Tensor:
     """One V->E->V AllSetTransformer layer (reference models.py:475-481 with PMA.forward, layers.py:120-157,
     inlined) on a hyperedge shard.  ``v2e_conv`` / ``e2v_conv``: :class:`allset_amd.layers.HalfNLHconv` with
     ``attention=True``.  V->E targets (hyperedges) are complete on their owner, so that direction is the local
@@ -404,7 +421,8 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
             o = o[hg.v_lo:hg.v_hi]
     else:
         o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
-    return p.tail(o, _post=dropout if training else 0.0)
+    p_out = dropout if dropout_out is None else dropout_out
+    return p.tail(o, _post=p_out if training else 0.0)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -557,25 +575,29 @@ def _chunking(hg, x_owned: Tensor, chunks: int, world: int, group, *convs) -> in
 
 def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, aggr: str = "add",
                               dropout: float = 0.0, training: bool = False, group=None,
-                              aggregate: Callable = _hip_deepsets, chunks: int = 1) -> Tensor:
+                              aggregate: Callable = _hip_deepsets, chunks: int = 1, norm: Optional[Tensor] = None,
+                              dropout_out: Optional[float] = None) -> Tensor:
     """The layer of :func:`sharded_deepsets_layer` with column-sharded aggregation: four all-to-alls, no reduction
     across ranks; every ``aggr`` of the reference (layers.py:641-656) is the plain local one on the column slice.
     ``chunks`` > 1: the owned rows go through the MLPs in that many chunks, each chunk's exchange overlapping the
     others' dense work (chunk k of rank i lands at rows i*n/P + k*rc of the column table: the natural row order)."""
     if aggr not in ("add", "sum", "mean", "max", "min"):
         raise ValueError(f"aggr {aggr!r}")
+    _no_batchnorm(v2e_conv, e2v_conv)
+    norm = hg.norm if norm is None else norm
+    p_out = dropout if dropout_out is None else dropout_out
     w = 1 if _skip_collective(group) else _world(group)
     K = _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
     enc1 = lambda t: v2e_conv._mlp_act(v2e_conv.f_enc, t, v2e_conv.dropout)
     mid = lambda t: e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, t, dropout), e2v_conv.dropout)
-    dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, dropout)
+    dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, p_out)
     if K == 1:
-        e = cols_to_rows(aggregate(rows_to_cols(enc1(x_owned), group), hg.v2e, hg.norm, aggr), group)      # [n_E/P, d]
-        return dec2(cols_to_rows(aggregate(rows_to_cols(mid(e), group), hg.e2v, hg.norm, aggr), group))
+        e = cols_to_rows(aggregate(rows_to_cols(enc1(x_owned), group), hg.v2e, norm, aggr), group)      # [n_E/P, d]
+        return dec2(cols_to_rows(aggregate(rows_to_cols(mid(e), group), hg.e2v, norm, aggr), group))
     (hc,) = _stage(torch.split(x_owned, x_owned.shape[0] // K), enc1, x_owned.shape[0] // K, K, w, group)
-    ec = aggregate(hc, hg.v2e, hg.norm, aggr)
+    ec = aggregate(hc, hg.v2e, norm, aggr)
     (gc,) = _stage(_unstage(ec, K, w, group), lambda get: mid(get()), hg.n_e_pad // w // K, K, w, group)
-    vc = aggregate(gc, hg.e2v, hg.norm, aggr)
+    vc = aggregate(gc, hg.e2v, norm, aggr)
     return torch.cat([dec2(get()) for get in _unstage(vc, K, w, group)])
 
 
@@ -591,13 +613,15 @@ def _slot_index(heads: int, world: int, device) -> Tensor:
 
 
 def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, dropout: float = 0.0,
-                         training: bool = False, group=None, kernels=HipPmaKernels, chunks: int = 1) -> Tensor:
+                         training: bool = False, group=None, kernels=HipPmaKernels, chunks: int = 1,
+                         dropout_out: Optional[float] = None) -> Tensor:
     """The layer of :func:`sharded_pma_layer` with column-sharded pooling: per direction one all-to-all of the values,
     one of the (few) logit columns each slice needs, the ordinary local fused pooling, one all-to-all back.
     ``chunks``: as in :func:`colsharded_deepsets_layer`."""
     w = 1 if _skip_collective(group) else _world(group)
     K = _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
     post = dropout if training else 0.0
+    post_out = (dropout if dropout_out is None else dropout_out) if training else 0.0
 
     def project(p):
         hl, slots = head_slots(p.heads, w)
@@ -612,18 +636,18 @@ def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedH
     f1, hl1 = project(p1)
     f2, hl2 = project(p2)
     if K == 1:
-        def pool(p, f, hl, t, inc):
+        def pool(p, f, hl, t, inc, pp):
             V, alpha = f(t)
             o = kernels.aggregate(rows_to_cols(V, group).contiguous(), rows_to_cols(alpha, group).contiguous(), inc, hl,
                                   p.negative_slope)
-            return p.tail(cols_to_rows(o, group), _post=post)
-        return pool(p2, f2, hl2, pool(p1, f1, hl1, x_owned, hg.v2e), hg.e2v)
+            return p.tail(cols_to_rows(o, group), _post=pp)
+        return pool(p2, f2, hl2, pool(p1, f1, hl1, x_owned, hg.v2e, post), hg.e2v, post_out)
     rv, re = x_owned.shape[0] // K, hg.n_e_pad // w // K
     Vc, ac = _stage(torch.split(x_owned, rv), f1, rv, K, w, group)
     oc = kernels.aggregate(Vc, ac, hg.v2e, hl1, p1.negative_slope)
     Vc, ac = _stage(_unstage(oc, K, w, group), lambda get: f2(p1.tail(get(), _post=post)), re, K, w, group)
     oc = kernels.aggregate(Vc, ac, hg.e2v, hl2, p2.negative_slope)
-    return torch.cat([p2.tail(get(), _post=post) for get in _unstage(oc, K, w, group)])
+    return torch.cat([p2.tail(get(), _post=post_out) for get in _unstage(oc, K, w, group)])
 
 
 # ---- the same exchanges, chunked and overlapped with the row-sharded dense work ---------------------------------
@@ -847,34 +871,62 @@ def choose_sharding(world: int, d: int, heads: Optional[int] = None, elem: int =
 
 
 class ShardedSetGNN(torch.nn.Module):
-    """A :class:`allset_amd.SetGNN` executed on a hyperedge shard (reference models.py:450-484, non-GPR branch).
+    """A :class:`allset_amd.SetGNN` executed on a hyperedge shard or with column-sharded aggregation (reference
+    models.py:450-484, both branches: stock and GPR; ``LearnMask`` included).
 
     Holds the SAME module (same parameters / ``state_dict``); ``forward(x_owned)`` takes this rank's block of vertex
     rows (``hg.v_lo:hg.v_hi`` of the padded vertex range) and returns the logits of those rows.  Every rank must call
     it with its own block; replicated-parameter gradients are summed with :func:`allreduce_grads` after backward.
-    """
+
+    ``LearnMask`` (models.py:336-337,451-452): ``Importance`` is a replicated [nnz] parameter in the caller's edge-list
+    order.  A hyperedge shard multiplies its own incidences' entries (``hg.inc_ids``) into its local ``norm``; every
+    incidence lives on exactly one rank, so the gradient all-reduce adds zeros from the others.  Column shards hold every
+    incidence and d/P of the columns: each rank's weight gradient is a partial sum over its columns and the same
+    all-reduce completes it.  ``Normalization='bn'`` is refused (see ``_no_batchnorm``)."""
 
     def __init__(self, model, hg, group=None, aggregate: Callable = _hip_deepsets, kernels=HipPmaKernels):
         super().__init__()
-        if getattr(model, "GPR", False) or getattr(model, "LearnMask", False):
-            raise NotImplementedError("sharded execution covers the stock AllSetTransformer / AllDeepSets (no GPR / LearnMask)")
+        if not _skip_collective(group) and _has_batchnorm(*model.V2EConvs, *model.E2VConvs, model.classifier,
+                                                          *([model.MLP] if getattr(model, "GPR", False) else [])):
+            raise NotImplementedError("sharded execution does not cover Normalization='bn' (per-rank batch statistics "
+                                      "would differ from the single-GPU model); use 'ln' or 'None'")
+        if getattr(model, "LearnMask", False) and isinstance(hg, ShardedHypergraph) and hg.inc_ids is None \
+                and model.Importance.numel() != hg.local_edge_index.shape[1]:
+            raise ValueError("LearnMask on a hyperedge shard needs ShardedHypergraph(inc_ids=...): the positions of the "
+                             "local incidences in the global edge list")
         self.model, self.hg, self.group = model, hg, group
         self._aggregate, self._kernels = aggregate, kernels
 
+    def _layer(self, v2e, e2v, x, norm, dropout_out=None):
+        m, hg = self.model, self.hg
+        cols = isinstance(hg, ColumnShardedHypergraph)
+        extra = {"chunks": hg.chunks} if cols else {}          # overlapped exchange: the chunking the blocks were padded for
+        if v2e.attention:                                      # PMA ignores norm (reference layers.py:628-629)
+            layer = colsharded_pma_layer if cols else sharded_pma_layer
+            return layer(v2e, e2v, x, hg, dropout=m.dropout, training=m.training, group=self.group, kernels=self._kernels,
+                         dropout_out=dropout_out, **extra)
+        layer = colsharded_deepsets_layer if cols else sharded_deepsets_layer
+        return layer(v2e, e2v, x, hg, aggr=m.aggr, dropout=m.dropout, training=m.training, group=self.group,
+                     aggregate=self._aggregate, norm=norm, dropout_out=dropout_out, **extra)
+
     def forward(self, x_owned: Tensor) -> Tensor:
-        m = self.model
+        m, hg = self.model, self.hg
+        norm = hg.norm
+        if getattr(m, "LearnMask", False):                     # norm = Importance * norm (models.py:451-452), local slice
+            ids = getattr(hg, "inc_ids", None)
+            norm = (m.Importance if ids is None else m.Importance[ids]) * norm
+        if getattr(m, "GPR", False):                           # models.py:457-471
+            x = x_owned
+            xs = [F.relu(m.MLP(x))]
+            for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):
+                x = self._layer(v2e, e2v, x, norm, dropout_out=0.0)      # relu(E2V(.)) -- the dropout comes after the tap
+                xs.append(x)
+                x = F.dropout(x, p=m.dropout, training=m.training)
+            x = m.GPRweights(torch.stack(xs, dim=-1)).squeeze(-1)
+            return m.classifier(x)
         x = F.dropout(x_owned, p=0.2, training=m.training)                 # hard-coded input dropout (models.py:473)
         for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):
-            cols = isinstance(self.hg, ColumnShardedHypergraph)
-            extra = {"chunks": self.hg.chunks} if cols else {}          # overlapped exchange: the chunking the blocks were padded for
-            if v2e.attention:
-                layer = colsharded_pma_layer if cols else sharded_pma_layer
-                x = layer(v2e, e2v, x, self.hg, dropout=m.dropout, training=m.training, group=self.group, kernels=self._kernels,
-                          **extra)
-            else:
-                layer = colsharded_deepsets_layer if cols else sharded_deepsets_layer
-                x = layer(v2e, e2v, x, self.hg, aggr=m.aggr, dropout=m.dropout, training=m.training, group=self.group,
-                          aggregate=self._aggregate, **extra)
+            x = self._layer(v2e, e2v, x, norm)
         return m.classifier(x)
 
     def allreduce_grads(self) -> None:
@@ -883,16 +935,25 @@ class ShardedSetGNN(torch.nn.Module):
 
 def allreduce_grads(params, group=None) -> None:
     """Sum replicated-parameter gradients over ranks with ONE flat all-reduce (the layer's parameters are a
-    few hundred KB; bucketing them into a single message keeps this off the per-link latency floor)."""
+    few hundred KB; bucketing them into a single message keeps this off the per-link latency floor).
+
+    The flat buffer covers EVERY parameter that requires grad, in list order, with zeros where a rank has no gradient
+    (a branch that saw no rows on this rank): the message size is then the same on every rank whatever each one's set
+    of ``None`` grads is -- a per-rank selection would hang or mix parameters up.  A parameter whose gradient is
+    ``None`` here but not on a peer receives the peers' sum."""
     if _skip_collective(group):
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, group=group)
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        piece = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = piece.clone()
+        else:
+            p.grad.copy_(piece)
         off += n

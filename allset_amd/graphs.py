@@ -108,6 +108,8 @@ class GraphedTrainStep:
                 p_snap = [p.detach().clone() for p in params]
                 s_snap = {p: {k: v.clone() for k, v in optimizer.state.get(p, {}).items() if torch.is_tensor(v)}
                           for p in params}
+                # module buffers move during warm-up too (BatchNorm running_mean / running_var / num_batches_tracked)
+                b_snap = [(b, b.detach().clone()) for b in model.buffers()]
         with torch.cuda.device(dev), dense.device_seed_counter(self.counter):
             _side_stream_warmup(one_step, max(1, warmup))
             self.graph = torch.cuda.CUDAGraph()
@@ -120,6 +122,8 @@ class GraphedTrainStep:
                     for k, v in optimizer.state.get(p, {}).items():
                         if torch.is_tensor(v):
                             v.copy_(s_snap[p][k]) if k in s_snap[p] else v.zero_()
+                for b, snap in b_snap:
+                    b.copy_(snap)
 
     def __call__(self) -> Tensor:
         self.graph.replay()

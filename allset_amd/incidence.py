@@ -41,7 +41,7 @@ class Incidence:
         self.device = by_dst.rowptr.device
         self._pos_dst_of_src: Optional[Tensor] = None     # by_src position -> by_dst position
         self._inv_cnt: Dict[str, Tensor] = {}
-        self._wcache: Dict[Tuple, Tuple[Optional[Tensor], Optional[Tensor]]] = {}
+        self._wcache: Dict[Tuple, Tuple[weakref.ref, Tuple[Optional[Tensor], Optional[Tensor]]]] = {}
         self._reversed: Optional["Incidence"] = None
 
     # ---- construction ---------------------------------------------------------------------
@@ -109,7 +109,10 @@ class Incidence:
     def weights(self, norm: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """Route the reference's per-incidence ``norm`` (edge-list order; int64 ones by default,
         preprocessing.py:454) into (by_dst order, by_src order) f32 arrays.  All-ones -> (None, None):
-        the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms."""
+        the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms, and only while
+        that very tensor object is alive: a temporary recomputed per forward (``Importance * norm`` under
+        ``no_grad``) is usually handed the previous temporary's address with ``_version`` 0 by the caching
+        allocator, so an address match alone would return the FIRST evaluation's weights for ever."""
         if norm is None:
             return None, None
         if norm.numel() != self.nnz:
@@ -117,7 +120,8 @@ class Incidence:
         if norm.requires_grad:
             raise RuntimeError("weights(): a norm that requires grad is routed inside functional.deepsets_aggregate")
         key = (norm.data_ptr(), norm._version, norm.dtype, norm.numel())
-        hit = self._wcache.get(key)
+        entry = self._wcache.get(key)
+        hit = entry[1] if (entry is not None and entry[0]() is norm) else None
         if hit is None:
             flat = norm.reshape(-1)
             if bool((flat == 1).all()):          # one-time sync per norm tensor
@@ -126,7 +130,7 @@ class Incidence:
                 f = flat.to(torch.float32)
                 hit = (f[self.by_dst.perm.long()].contiguous(), f[self.by_src.perm.long()].contiguous())
             self._wcache.clear()
-            self._wcache[key] = hit
+            self._wcache[key] = (weakref.ref(norm), hit)
         return hit
 
 
@@ -142,7 +146,7 @@ _CACHE_LIMIT = 16
 def cached_incidence(edge_index: Tensor, n_src: Optional[int], n_dst: Optional[int] = None) -> Incidence:
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), n_src, n_dst)
     hit = _CACHE.get(key)
-    if hit is not None and hit[0]() is not None:
+    if hit is not None and hit[0]() is edge_index:            # the live tensor itself, not a recycled address
         return hit[1]
     inc = Incidence.from_edge_index(edge_index, n_src=n_src, n_dst=n_dst)
     if len(_CACHE) >= _CACHE_LIMIT:

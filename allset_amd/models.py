@@ -13,6 +13,7 @@ reference (models.py:453-456, layers.py:174,656) do not exist after the first ca
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Tuple
 
 import torch
@@ -69,7 +70,7 @@ class SetGNN(nn.Module):
                 self.GPRweights = Linear(self.All_num_layers + 1, 1, bias=False)
             self.classifier = head(args.MLP_hidden)
 
-        self._inc_cache: Dict[Tuple, Tuple[Incidence, Incidence]] = {}
+        self._inc_cache: Dict[Tuple, Tuple[weakref.ref, Tuple[Incidence, Incidence]]] = {}
 
     def reset_parameters(self):
         for group in (self.V2EConvs, self.E2VConvs, self.bnV2Es, self.bnE2Vs):
@@ -92,8 +93,8 @@ class SetGNN(nn.Module):
         """
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), n_v)
         hit = self._inc_cache.get(key)
-        if hit is not None:
-            return hit
+        if hit is not None and hit[0]() is edge_index:        # same live tensor object, not merely a reused address
+            return hit[1]
         if edge_index.numel() > 0:
             cidx = int(edge_index[1].min())          # one-time host sync (reference: every forward)
             if cidx != 0:
@@ -102,7 +103,7 @@ class SetGNN(nn.Module):
         e2v = v2e.reversed()                                      # n_V' = max vertex id + 1 (Q1)
         self._inc_cache.clear()
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), n_v)
-        self._inc_cache[key] = (v2e, e2v)
+        self._inc_cache[key] = (weakref.ref(edge_index), (v2e, e2v))
         return v2e, e2v
 
     def forward(self, data):

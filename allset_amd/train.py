@@ -83,6 +83,85 @@ def load_hypergcn_dataset(path: str, dataset: str) -> HypergraphData:
                           n_x=[num_nodes], num_hyperedges=[len(hypergraph)])
 
 
+class _PygStandIn:
+    """What a pickled ``torch_geometric`` object unpickles into when that package is absent: a bag of attributes.
+    PyG 1.6.3 ``Data`` (the reference's pin, README.md:18-22) pickles as class reference + instance ``__dict__``
+    (x, edge_index, edge_attr, y, pos, normal, face and the loaders' extras); PyG 2.x keeps them in ``_store._mapping``."""
+
+    def __init__(self, *args, **kwargs):
+        self.__dict__.update(kwargs)
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple):                       # (dict, slots) protocol
+            state = {**(state[0] or {}), **(state[1] or {})}
+        self.__dict__.update(state)
+
+
+class _PygUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.split('.')[0] in ('torch_geometric', 'torch_sparse', 'torch_scatter'):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return _PygStandIn
+        return super().find_class(module, name)
+
+
+class _pyg_pickle:
+    """``pickle_module`` for ``torch.load``: the stock pickle with torch_geometric classes resolved to stand-ins."""
+    __name__ = 'pickle'
+    Unpickler = _PygUnpickler
+    load = staticmethod(lambda f, **kw: _PygUnpickler(f, **kw).load())
+    loads = staticmethod(pickle.loads)
+    dump, dumps, Pickler = staticmethod(pickle.dump), staticmethod(pickle.dumps), pickle.Pickler
+
+
+def _pyg_attrs(obj) -> dict:
+    d = dict(vars(obj))
+    store = d.get('_store')                                 # PyG 2.x: Data.__dict__ = {'_store': GlobalStorage{_mapping}}
+    if store is not None:
+        d = dict(getattr(store, '_mapping', None) or vars(store))
+    return {k: v for k, v in d.items() if v is not None and not k.startswith('__')}
+
+
+def load_pyg_processed(path: str) -> HypergraphData:
+    """Read the reference's processed dataset file ``<root>/<name>/processed/data.pt`` (or ``data_noise_<f>.pt``):
+    ``torch.save(self.collate([data]), ...)`` -- a ``(Data, slices)`` tuple (convert_datasets_to_pygDataset.py:170-175)
+    which ``dataset_Hypergraph.__init__`` reads back with ``torch.load`` (:78) and ``train.py`` uses as
+    ``dataset.data`` (train.py:327-339).  ``collate`` of a one-graph list keeps tensors as they are and turns the loaders'
+    scalar attributes (``n_x``, ``num_hyperedges``, ``train_percent``: load_other_datasets.py:112-117,190-194) into
+    1-element tensors.  torch_geometric is not needed: its classes unpickle into attribute bags.
+
+    Returns the attributes ``train.py`` consumes, with its two fall-backs applied (train.py:333-339): ``n_x`` defaults
+    to the feature row count, ``num_hyperedges`` to ``edge_index[0].max() - n_x + 1`` (consecutive hyperedge ids)."""
+    if osp.isdir(path):
+        path = osp.join(path, 'data.pt')
+    obj = torch.load(path, map_location='cpu', pickle_module=_pyg_pickle, weights_only=False)
+    if not (isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[1], dict)):
+        raise ValueError(f"{path}: expected the (data, slices) tuple InMemoryDataset.collate writes, got {type(obj).__name__}")
+    attrs, slices = _pyg_attrs(obj[0]), obj[1]
+    for key in ('x', 'edge_index', 'y'):
+        if not torch.is_tensor(attrs.get(key)):
+            raise ValueError(f"{path}: the stored Data has no tensor attribute {key!r}")
+    for key, sl in slices.items():                          # one graph per file: every slice is [0, size]
+        if torch.is_tensor(sl) and sl.numel() != 2:
+            raise ValueError(f"{path}: {sl.numel() - 1} graphs collated under {key!r}; the reference stores exactly one")
+    x, ei, y = attrs['x'], attrs['edge_index'], attrs['y']
+    if ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError(f"{path}: edge_index has shape {tuple(ei.shape)}")
+
+    def scalar(v):
+        return int(v.reshape(-1)[0]) if torch.is_tensor(v) else int(v[0] if isinstance(v, (list, tuple)) else v)
+    n_x = scalar(attrs['n_x']) if 'n_x' in attrs else int(x.shape[0])
+    n_he = scalar(attrs['num_hyperedges']) if 'num_hyperedges' in attrs else int(ei[0].max()) - n_x + 1
+    out = HypergraphData(x=x.to(torch.float32), y=y.to(torch.int64).reshape(-1), edge_index=ei.to(torch.int64).contiguous(),
+                         n_x=[n_x], num_hyperedges=[n_he])
+    if 'train_percent' in attrs:
+        tp = attrs['train_percent']
+        out.train_percent = float(tp.reshape(-1)[0]) if torch.is_tensor(tp) else float(tp)
+    return out
+
+
 def synthetic_dataset(n_v: int = 4000, n_e: int = 2000, num_classes: int = 5, num_features: int = 64,
                       he_size: int = 6, purity: float = 0.8, feature_noise: float = 1.0, seed: int = 0) -> HypergraphData:
     """Planted-partition hypergraph: each hyperedge draws a class and fills ``purity`` of its members from it;
@@ -232,6 +311,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--UniGNN_degE', default=0)
     # additions of this driver (absent from the reference)
     p.add_argument('--raw_data_dir', default=None, help='directory holding <dname>/{features,labels,hypergraph}.pickle')
+    p.add_argument('--processed_data', default=None,
+                   help="the reference's processed file <root>/<dname>/processed/data.pt (or its directory)")
     p.add_argument('--seed', default=None, type=int, help='seed numpy/torch (the reference fixes no seeds, README.md:60)')
     p.add_argument('--res_root', default='hyperparameter_tunning')
     p.add_argument('--hip_graph', default=0, type=int, choices=[0, 1],
@@ -241,7 +322,11 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def load_data(args) -> HypergraphData:
-    if args.raw_data_dir is not None:
+    if getattr(args, 'processed_data', None) is not None:
+        data = load_pyg_processed(args.processed_data)
+        if args.dname in ('yelp', 'walmart-trips', 'house-committees', 'walmart-trips-100', 'house-committees-100'):
+            data.y = data.y - data.y.min()                  # labels shifted to start at 0 (reference train.py:329-332)
+    elif args.raw_data_dir is not None:
         data = load_hypergcn_dataset(args.raw_data_dir, args.dname)
     elif args.dname == 'synthetic':
         data = synthetic_dataset(feature_noise=float(args.feature_noise), seed=0 if args.seed is None else args.seed)

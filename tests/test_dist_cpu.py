@@ -324,6 +324,124 @@ def test_sharded_setgnn_equals_oracle(mode, columns):
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
 
 
+def _gpr_mask_worker(rank, world, port, columns, q):
+    """GPR + LearnMask through ShardedSetGNN (reference models.py:451-452,457-471): logits of the owned rows and the
+    all-reduced gradient of the replicated per-incidence ``Importance``."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import cases
+        from allset_amd import SetGNN, dist as adist
+        n_v, n_e, d, ei, norm, x, G = _problem(world)
+        args = cases.make_args("ds_add", d, 32, 5, All_num_layers=2, GPR=True, LearnMask=True)
+        torch.manual_seed(11)
+        model = SetGNN(args, norm).eval()
+        with torch.no_grad():
+            model.Importance.copy_(torch.linspace(0.5, 1.5, ei.shape[1]))
+        if columns:
+            hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm, chunks=columns)
+            hg.v2e = (ei, hg.n_e_pad)
+            hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
+        else:
+            owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
+            loc, gids = adist.local_shard(ei, owner, rank)
+            keep = owner[ei[1]] == rank
+            hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=norm[keep], inc_ids=keep.nonzero().reshape(-1))
+            hg.v2e = (loc, hg.n_e_local)
+            hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        sharded = adist.ShardedSetGNN(model, hg, aggregate=_oracle_aggregate, kernels=TorchPmaKernels)
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+        out = sharded(xp[hg.v_lo:hg.v_hi])
+        live = max(0, min(hg.v_hi, n_v) - hg.v_lo)                 # pad rows carry no cotangent
+        cot = torch.linspace(-1.0, 1.0, n_v * out.shape[1]).view(n_v, -1)[hg.v_lo:hg.v_lo + live]
+        (out[:live] * cot).sum().backward()
+        sharded.allreduce_grads()
+        q.put((rank, out.detach().numpy().copy(), model.Importance.grad.numpy().copy(),
+               model.GPRweights.weight.grad.numpy().copy(), {k: v.numpy().copy() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("columns", [0, 1, 2])
+def test_sharded_gpr_learnmask_equals_oracle(columns):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cases
+    from oracle import allset_oracle as oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpr_mask_worker, args=(r, world, port, columns, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_v, n_e, d, ei, norm, x, G = _problem(world)
+    args = cases.make_args("ds_add", d, 32, 5, All_num_layers=2, GPR=True, LearnMask=True)
+    sd = {k: torch.from_numpy(v).requires_grad_(torch.from_numpy(v).is_floating_point()) for k, v in results[0][4].items()}
+    ref = oracle.setgnn_forward(sd, args, x, ei, norm)
+    cot = torch.linspace(-1.0, 1.0, n_v * ref.shape[1]).view(n_v, -1)
+    (ref * cot).sum().backward()
+    got = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    torch.testing.assert_close(got, ref.detach(), rtol=1e-4, atol=1e-5)
+    for r in results:                                  # after the all-reduce every rank holds the full gradient
+        torch.testing.assert_close(torch.from_numpy(r[2]), sd["Importance"].grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(torch.from_numpy(r[3]), sd["GPRweights.weight"].grad, rtol=1e-4, atol=1e-5)
+
+
+def _bn_refusal_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import cases
+        from allset_amd import SetGNN, HalfNLHconv, dist as adist
+        n_v, n_e, d, ei, norm, x, G = _problem(world)
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm)
+        msgs = []
+        try:
+            adist.ShardedSetGNN(SetGNN(cases.make_args("ds_add", d, 32, 5, normalization="bn")), hg)
+        except NotImplementedError as e:
+            msgs.append(str(e))
+        a = HalfNLHconv(d, d, d, 2, 0.0, "bn", True, attention=False)
+        try:
+            adist.colsharded_deepsets_layer(a, a, x[:hg.v_hi - hg.v_lo], hg, aggregate=_oracle_aggregate)
+        except NotImplementedError as e:
+            msgs.append(str(e))
+        # the zero-gradient substitution of allreduce_grads: rank 1 has no gradient for one parameter
+        p0, p1 = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+        p0.grad = torch.full((3,), float(rank + 1))
+        if rank == 0:
+            p1.grad = torch.full((2,), 5.0)
+        adist.allreduce_grads([p0, p1])
+        q.put((rank, msgs, p0.grad.tolist(), p1.grad.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_batchnorm_is_refused_and_missing_grads_are_zero_filled():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_refusal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msgs, g0, g1 in results:
+        assert len(msgs) == 2 and all("bn" in m for m in msgs)
+        assert g0 == [3.0, 3.0, 3.0] and g1 == [5.0, 5.0]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # cross-shard max: one winner per (vertex, feature), lowest rank on exact ties, vertices without incidences give 0
 # ---------------------------------------------------------------------------------------------------------------

@@ -56,6 +56,64 @@ def test_edge_index_is_rebased_in_place_like_the_reference(device):
     torch.testing.assert_close(again.cpu(), res["logits"], rtol=0, atol=0)    # deterministic kernels
 
 
+def test_learnmask_eval_follows_importance_between_no_grad_forwards(device):
+    """`norm = Importance * norm` is a fresh temporary on every forward (reference models.py:451-452); under no_grad
+    the caching allocator hands the next one the same address with _version 0, so a weight cache keyed on the address
+    alone served the FIRST evaluation's mask for ever.  Three evaluations with different Importance, each against the
+    oracle; the first one with Importance all ones (the cached '(None, None) = unweighted' case)."""
+    from oracle import allset_oracle as oracle
+    name = "rand50_ds_add_wnorm_mask"
+    case, g = cases.build_case(name), util.load_golden(name)
+    sd = util.state_dict_for(case, g)
+    res = util.run_product(case, sd, device)
+    model, data = res["model"], res["data"]
+    nnz = case["norm"].shape[0]
+    ones_norm = torch.ones(nnz, device=device)
+    data_ones = type(data)(x=data.x.detach(), edge_index=data.edge_index, norm=ones_norm)
+    gen = torch.Generator().manual_seed(5)
+    for step in range(3):
+        imp = torch.ones(nnz) if step == 0 else torch.rand(nnz, generator=gen) + 0.5
+        with torch.no_grad():
+            model.Importance.copy_(imp.to(device))
+            got = model(data_ones)
+        sd_o = dict(sd)
+        sd_o["Importance"] = imp
+        exp = oracle.setgnn_forward(sd_o, case["args"], torch.from_numpy(case["x"]), torch.from_numpy(case["edge_index"]),
+                                    torch.ones(nnz))
+        torch.testing.assert_close(got.cpu(), exp.detach(), rtol=RTOL, atol=ATOL * max(float(exp.abs().max()), 1e-3),
+                                   msg=lambda m: f"evaluation {step}: {m}")
+
+
+def test_incidence_cache_rebuilds_for_a_new_graph_at_a_recycled_address(device):
+    """A second hypergraph with the same number of incidences whose edge_index lands at the freed address of the first
+    must not be aggregated over the first one's CSR (SetGNN._inc_cache / cached_incidence keep a weakref)."""
+    from types import SimpleNamespace
+    from allset_amd import SetGNN
+    from oracle import allset_oracle as oracle
+    case = cases.build_case("rand50_ds_add")
+    g = util.load_golden("rand50_ds_add")
+    sd = util.state_dict_for(case, g)
+    model = SetGNN(case["args"])
+    model.load_state_dict(sd)
+    model.eval().to(device)
+    x = torch.from_numpy(case["x"]).to(device)
+    ei0 = torch.from_numpy(case["edge_index"])
+    perm = torch.randperm(50, generator=torch.Generator().manual_seed(1))
+    ei1 = torch.stack([perm[ei0[0]], ei0[1]])                  # same nnz, same hyperedge ids, vertices relabelled
+    ei1 = ei1[:, torch.argsort(ei1[0], stable=True)].contiguous()
+    norm = torch.from_numpy(case["norm"])
+    outs, ptrs = [], []
+    for ei in (ei0, ei1):
+        dev_ei = ei.clone().to(device)
+        ptrs.append(dev_ei.data_ptr())
+        with torch.no_grad():
+            outs.append(model(SimpleNamespace(x=x, edge_index=dev_ei, norm=norm.to(device))).cpu())
+        del dev_ei                                               # freed: the next clone usually reuses the block
+    exp1 = oracle.setgnn_forward(sd, case["args"], torch.from_numpy(case["x"]), ei1.clone(), norm)
+    torch.testing.assert_close(outs[1], exp1.detach(), rtol=RTOL, atol=ATOL * max(float(exp1.abs().max()), 1e-3))
+    assert not torch.allclose(outs[0], outs[1])
+
+
 def test_training_mode_runs_and_is_finite(device):
     """train() mode (dropout active, BatchNorm batch statistics) exercises the same kernels; only
     finiteness/shape can be asserted because dropout RNG streams differ between devices."""

@@ -36,6 +36,43 @@ def test_parse_method_sets_deepsets_flags():
         parse_method(a, None)
 
 
+GOLDEN_DATAPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datapt")
+
+
+@pytest.mark.parametrize("name", ["pyg163_legacy.pt", "pyg163_zip.pt", "pyg2_store.pt", "pyg163_no_counts.pt"])
+def test_processed_data_pt_reader(name):
+    """The reference's processed dataset file (convert_datasets_to_pygDataset.py:170-175: (Data, slices) written by
+    InMemoryDataset.collate) read WITHOUT torch_geometric, in both torch serialisation formats and both PyG attribute
+    layouts; fixtures and their provenance: oracle/gen_datapt_fixture.py.  The file without n_x / num_hyperedges takes
+    the fall-backs of reference train.py:333-339."""
+    import sys
+    from allset_amd.train import build_parser, load_data, load_pyg_processed, preprocess
+    assert "torch_geometric" not in sys.modules
+    exp = np.load(os.path.join(GOLDEN_DATAPT, "expected.npz"))
+    data = load_pyg_processed(os.path.join(GOLDEN_DATAPT, name))
+    assert np.array_equal(data.x.numpy(), exp["x"]) and data.x.dtype == torch.float32
+    assert np.array_equal(data.edge_index.numpy(), exp["edge_index"]) and data.edge_index.dtype == torch.int64
+    assert np.array_equal(data.y.numpy(), exp["y"])
+    assert data.n_x == [int(exp["n_x"])] and data.num_hyperedges == [int(exp["num_hyperedges"])]
+    if name != "pyg163_no_counts.pt":
+        assert abs(data.train_percent - 0.025) < 1e-9
+    # and through the driver: same preprocessing chain as the pickle reader's output
+    args = build_parser().parse_args(['--dname', 'cora', '--processed_data', os.path.join(GOLDEN_DATAPT, name)])
+    d2 = preprocess(args, load_data(args))
+    assert args.num_features == exp["x"].shape[1] and args.num_classes == len(np.unique(exp["y"]))
+    n_v = int(exp["n_x"])
+    v, e = d2.edge_index
+    assert v.tolist() == sorted(v.tolist()) and int(v.max()) < n_v and int(e.min()) == n_v
+    assert d2.edge_index.shape[1] == exp["edge_index"].shape[1] // 2 + n_v       # V->E half + one self loop per vertex
+
+
+def test_processed_data_pt_reader_rejects_other_payloads(tmp_path):
+    from allset_amd.train import load_pyg_processed
+    torch.save({"x": torch.zeros(2, 2)}, tmp_path / "data.pt")
+    with pytest.raises(ValueError):
+        load_pyg_processed(str(tmp_path))                     # a directory resolves to <dir>/data.pt
+
+
 def test_hypergcn_pickle_reader_and_preprocessing(tmp_path):
     """HyperGCN on-disk format (reference load_other_datasets.py:121-196): features scipy-sparse, labels list,
     hypergraph dict{he: [nodes]} -> [V|E;E|V] coalesced block list -> ExtractV2E/Add_Self_Loops/norm."""
