@@ -373,6 +373,53 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
     return gx, red[0], red[1]
 
 
+def fused_linear_bwd_all_supported(O: int, I: int, has_ln: bool, drop_in: bool, relu_in: bool, has_mask: bool,
+                                   has_acc: bool = False) -> bool:
+    """The one-pass backward kernel (csrc/fused_bwd.hip) is built for this Linear."""
+    if os.environ.get("ALLSET_BWD_SPLIT", "0") == "1":             # comparison arm: the two-kernel pair of round 1
+        return False
+    return bool(_lib.load().allset_fused_linear_bwd_all_supported(O, I, int(has_ln), int(drop_in), int(relu_in), int(has_mask),
+                                                                  int(has_acc)))
+
+
+def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
+                         gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
+                         seed_base: Optional[Tensor] = None, acc_in: Optional[Tensor] = None, want_bias: bool = True
+                         ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor, Optional[Tensor]]:
+    """(gx, dgamma, dbeta, gW, gb) of the fused Linear from ONE pass over gy and x (include/allset_hip.h
+    allset_fused_linear_bwd_all)."""
+    dev = require_device(gy, mask, weight, x, stats, gamma, beta, acc_in)
+    _check_f32(gy, weight, x, stats, gamma, beta, acc_in)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    weight = weight.contiguous()
+    n, O = gy.shape
+    I = x.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_fused_linear_bwd_all_slices(n, byref(ns)), "allset_fused_linear_bwd_all_slices")
+    P = ns.value
+    if acc_in is not None:
+        acc_in = _rowmajor(acc_in)
+        gx = acc_in if acc_in.is_contiguous() else torch.empty((n, I), dtype=torch.float32, device=dev)
+    else:
+        gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    part_w = torch.empty((P, O, I), dtype=torch.float32, device=dev)
+    part_b = torch.empty((P, O), dtype=torch.float32, device=dev) if want_bias else None
+    part_ln = torch.empty((P, 2, I), dtype=torch.float32, device=dev) if stats is not None else None
+    with torch.cuda.device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
+        check(lib.allset_fused_linear_bwd_all(
+            ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats),
+            ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
+            int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w), ptr(part_b), P, n, O, I,
+            ptr(seed_base), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0, stream_of(dev)), "allset_fused_linear_bwd_all")
+    gw = reduce_partials(part_w)
+    gb = reduce_partials(part_b) if want_bias else None
+    if part_ln is None:
+        return gx, None, None, gw, gb
+    red = reduce_partials(part_ln)
+    return gx, red[0], red[1], gw, gb
+
+
 def wgrad_supported(ga: Tensor, u: Tensor) -> bool:
     return (ga.is_cuda and ga.dtype == u.dtype and ga.dtype in (torch.float32, torch.bfloat16) and ga.shape[1] % 4 == 0
             and u.shape[1] % 4 == 0)
@@ -486,6 +533,13 @@ class _FusedNormLinear(torch.autograd.Function):
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
+        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and y is None and x.shape[0] > 0 and
+                fused_linear_bwd_all_supported(weight.shape[0], weight.shape[1], gamma is not None, p_in > 0.0, relu_in,
+                                               mask is not None)):
+            # everything from one read of gy and x
+            gx, dg, db, gw, gb = fused_linear_bwd_all(gy, mask, p_out, weight, x, stats, gamma, beta, relu_in, p_in, seed_in,
+                                                      base, want_bias=need_b)
+            return gx, dg, db, gw, gb, None, None, None, None, None
         if ctx.needs_input_grad[3] or need_b:
             gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b,
                                  seed_base=base, mask=mask)

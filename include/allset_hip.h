@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 3   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose) */
+#define ALLSET_ABI_VERSION 4   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -387,6 +387,27 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
                             int64_t n_partials, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                             const uint32_t* mask, const float* acc_in, int64_t ldacc, const float* aux_g,
                             const float* aux_w, void* stream);
+
+/* The WHOLE backward of allset_fused_linear_fwd in one pass over gy and x (bf16x6 kernel family): everything
+ * allset_fused_linear_bwd returns (gx, LayerNorm partials) AND the weight / bias gradient of allset_wgrad_fused,
+ *   gW[O][I] = ga^T @ u,   gb[O] = column sums of ga,    u = dropout_{p_in,seed_in}(LayerNorm(relu_in(x))) recomputed,
+ * from one read of gy, the activation mask, x and the row statistics (1.6 GB per [1M,128]x[128,128] Linear instead of 2.7 GB
+ * for the pair of kernels).  What torch autograd computes for reference MLP.forward, layers.py:571-579.
+ *   mask     the 1-bit activation mask of the forward ("mask layout" above) or NULL for a Linear without relu/dropout epilogue
+ *   x        always required (the weight gradient recomputes the Linear's input from it); stats/gamma/beta come together or NULL
+ *   gx       required (a Linear whose input needs no gradient keeps the two-kernel pair); acc_in as in allset_fused_linear_bwd
+ *   part_w   f32[n_slices*O*I], part_b f32[n_slices*O] or NULL, part_ln f32[n_slices*2*I] (stats != NULL): one partial per
+ *            wave, n_slices from allset_fused_linear_bwd_all_slices(n); the caller sums over slices (allset_reduce_partials).
+ * No atomics: bitwise reproducible run to run.  allset_fused_linear_bwd_all_supported(O, I, flags) -> 1/0: widths in
+ * {64,128} and the prologue / epilogue combinations the module surface produces (dropout_in only behind relu_in, acc_in only
+ * on the plain Linear); 0 under ALLSET_DENSE_MFMA=f32.  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
+int allset_fused_linear_bwd_all_supported(int64_t O, int64_t I, int has_ln, int drop_in, int relu_in, int has_mask, int has_acc);
+int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices);
+int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x,
+                                int64_t ldx, const float* stats, const float* gamma, const float* beta, int relu_in, float p_in,
+                                uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b,
+                                int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                                const float* acc_in, int64_t ldacc, void* stream);
 
 #ifdef __cplusplus
 }

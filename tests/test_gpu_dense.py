@@ -679,3 +679,94 @@ def test_mlp_wide_path_tiny_and_empty_inputs(n, device):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     if n == 0:
         assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters())
+
+
+@pytest.mark.parametrize("O,I", [(128, 128), (64, 64), (128, 64), (64, 128)])
+@pytest.mark.parametrize("has_ln,relu_in,p_in,with_mask", [(True, True, 0.3, True), (True, True, 0.0, False), (False, True, 0.25, True),
+                                                             (False, True, 0.0, True), (True, False, 0.0, True),
+                                                             (False, False, 0.0, False)])
+@pytest.mark.parametrize("n", [1, 17, 4099, 70001])
+def test_one_pass_backward_equals_the_two_kernel_pair(O, I, has_ln, relu_in, p_in, with_mask, n, device):
+    """allset_fused_linear_bwd_all (gx, LayerNorm partials, gW, gb from ONE pass over gy and x) against the round-1 pair
+    allset_fused_linear_bwd + allset_wgrad_fused on the same inputs, seeds and activation mask.  gx / dgamma / dbeta go
+    through the same arithmetic (bit-identical without LayerNorm; with it, up to the order of the two row sums); gW / gb accumulate
+    in a different order (per-wave 16-row MFMA steps instead of split-K slices): compared to fp32 rounding of the sum."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(O * 1000 + I + n)
+    x = torch.randn(n, I, generator=g).to(device)
+    W = (torch.randn(O, I, generator=g) / I ** 0.5).to(device)
+    b = torch.randn(O, generator=g).to(device)
+    gamma, beta = (1 + 0.2 * torch.randn(I, generator=g)).to(device), (0.3 * torch.randn(I, generator=g)).to(device)
+    G = torch.randn(n, O, generator=g).to(device)
+    ln = (gamma, beta) if has_ln else (None, None)
+    p_out, s_in, s_out = (0.4, 4242, 977) if with_mask else (0.0, 4242, 0)
+    assert dense.fused_linear_bwd_all_supported(O, I, has_ln, p_in > 0, relu_in, with_mask)
+    mask = None
+    if with_mask:
+        mask = torch.empty(dense.activation_mask_words(n, O), dtype=torch.int32, device=device)
+    y, st = dense.fused_linear_fwd(x, W, b, ln[0], ln[1], 1e-5, relu_in, p_in, s_in, with_mask, p_out, s_out, None, mask)
+    gw_ref, gb_ref = dense.wgrad_fused(G, None, p_out, x, st, ln[0], ln[1], relu_in, p_in, s_in, mask=mask)
+    gx_ref, dg_ref, db_ref = dense.fused_linear_bwd(G, None, p_out, W, x, st, ln[0], relu_in, p_in, s_in, None, mask)
+    gx, dg, db, gw, gb = dense.fused_linear_bwd_all(G, mask, p_out, W, x, st, ln[0], ln[1], relu_in, p_in, s_in)
+    if has_ln:      # the LayerNorm row sums are DPP row reductions here, xor-shuffle butterflies there: fp32 summation order differs
+        torch.testing.assert_close(gx, gx_ref, rtol=1e-5, atol=1e-6 * max(1.0, float(gx_ref.abs().max())))
+    else:
+        torch.testing.assert_close(gx, gx_ref, rtol=0, atol=0)
+    scale_w = float((G.abs().t() @ x.abs()).max()) if n < 5000 else float(gw_ref.abs().max()) * 30
+    torch.testing.assert_close(gw, gw_ref, rtol=1e-5, atol=2e-6 * max(scale_w, 1.0))
+    torch.testing.assert_close(gb, gb_ref, rtol=1e-5, atol=2e-6 * max(float(G.abs().sum(0).max()), 1.0))
+    if has_ln:
+        sc = max(1.0, float(dg_ref.abs().max()), float(db_ref.abs().max()))
+        torch.testing.assert_close(dg, dg_ref, rtol=1e-5, atol=1e-5 * sc)
+        torch.testing.assert_close(db, db_ref, rtol=1e-5, atol=1e-5 * sc)
+    # float64 yardstick for the weight gradient on one case per width pair (the pair above shares the kernel family)
+    if n == 4099:
+        xd = x.double()
+        u = torch.relu(xd) if relu_in else xd
+        if has_ln:
+            u = torch.nn.functional.layer_norm(u, (I,), gamma.double(), beta.double(), 1e-5)
+        if p_in == 0.0 and not with_mask:
+            ref = G.double().t() @ u
+            torch.testing.assert_close(gw.double(), ref, rtol=1e-5, atol=2e-6 * float((G.abs().double().t() @ u.abs()).max()))
+            torch.testing.assert_close(gb.double(), G.double().sum(0), rtol=1e-5, atol=1e-5 * float(G.abs().sum(0).max()))
+    # acc_in (plain Linear only): gx = acc_in + this Linear's gradient, in place
+    if not has_ln and not relu_in and p_in == 0.0 and not with_mask:
+        acc = torch.randn(n, I, generator=g).to(device)
+        want = acc + gx_ref
+        gx2, _, _, gw2, _ = dense.fused_linear_bwd_all(G, None, 0.0, W, x, None, None, None, False, 0.0, 0, acc_in=acc)
+        assert gx2.data_ptr() == acc.data_ptr()
+        torch.testing.assert_close(gx2, want, rtol=0, atol=0)
+        torch.testing.assert_close(gw2, gw, rtol=0, atol=0)                  # run-to-run bitwise stable
+
+
+def test_one_pass_backward_is_deterministic_and_used_by_the_mlp(device, monkeypatch):
+    """MLP backward takes the one-pass kernel by default; ALLSET_BWD_SPLIT=1 restores the two-kernel pair; both give the
+    same gradients, and the one-pass kernel is bitwise reproducible run to run (no atomics)."""
+    from allset_amd import ops
+    from allset_amd.layers import MLP
+    torch.manual_seed(5)
+    mlp = MLP(128, 128, 128, 2, 0.0, "ln", True).to(device).train()
+    x = torch.randn(20011, 128, device=device, requires_grad=True)
+    G = torch.randn(20011, 128, device=device)
+
+    def run():
+        for p in mlp.parameters():
+            p.grad = None
+        x.grad = None
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+        (mlp(x, _post=0.0) * G).sum().backward()
+        torch.cuda.synchronize()
+        ops.set_kernel_timer(None)
+        return [x.grad.clone()] + [p.grad.clone() for p in mlp.parameters()], set(timer.summary())
+
+    g1, k1 = run()
+    g2, _ = run()
+    assert "fused_linear_bwd_all" in k1 and "wgrad_fused" not in k1 and "fused_linear_bwd" not in k1
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("ALLSET_BWD_SPLIT", "1")
+    g3, k3 = run()
+    assert "fused_linear_bwd_all" not in k3 and "wgrad_fused" in k3
+    for a, b in zip(g1, g3):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())))
