@@ -170,6 +170,29 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
 #endif
   };
 
+  // epilogue inputs, row-major: lane = rows it*4 + (lane>>4), columns hb*64 + c4 .. +3.  Requested at the very top of the chunk:
+  // with one wave per SIMD the only latency hiding is distance, and a request from the previous chunk's weight-gradient phase
+  // (40 more registers live there) tips the allocator into spilling an accumulator.
+  float4 xr[NH][4];
+  float2 st[4];
+  auto request_x = [&](int64_t chunk, int lane) {
+    const int c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int64_t r = chunk * 16 + it * 4 + (lane >> 4);
+      r = r < n ? r : n - 1;                          // clamped, unconditional; dead rows are masked where used
+#ifdef ALLSET_ABL_NOLOAD
+      if (p_in == 123.f) {
+#endif
+      if constexpr (HAS_LN) st[it] = *reinterpret_cast<const float2*>(stats + r * 2);
+#pragma unroll
+      for (int hb = 0; hb < NH; ++hb) xr[hb][it] = *reinterpret_cast<const float4*>(x + r * ldx + hb * 64 + c4);
+#ifdef ALLSET_ABL_NOLOAD
+      }
+#endif
+    }
+  };
+
   int64_t chunk = static_cast<int64_t>(blockIdx.x) * kMWaves + wave;
   request_rows(chunk, lane0);
   for (; chunk < n_chunks; chunk += stride) {
@@ -181,6 +204,8 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
     const int wa_off = img_off<PA>(ri, g * OQ * 2);
     const int wb_base = g * GS + ri * OQD, wb_swz = (ri / (64 / OQD)) % (OQD / 4);      // W-plane fragments: see load_b below
     const bool valid = chunk * 16 + ri < n;
+    request_x(chunk, lane);                             // this chunk's x rows: the mask / split phase and the matrix phase cover them
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (HAS_MASK) {
       const uint32_t bits = valid ? (am_bits >> m_shift) : 0u;
 #pragma unroll
@@ -203,25 +228,6 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
     }
     __asm__ volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue inputs, row-major: lane = rows it*4 + (lane>>4), columns hb*64 + c4 .. +3
-    float4 xr[NH][4];
-    float2 st[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      int64_t r = chunk * 16 + it * 4 + (lane >> 4);
-      r = r < n ? r : n - 1;                          // clamped, unconditional; dead rows are masked where used
-#ifdef ALLSET_ABL_NOLOAD
-      if (p_in == 123.f) {
-#endif
-      if constexpr (HAS_LN) st[it] = *reinterpret_cast<const float2*>(stats + r * 2);
-#pragma unroll
-      for (int hb = 0; hb < NH; ++hb) xr[hb][it] = *reinterpret_cast<const float4*>(x + r * ldx + hb * 64 + c4);
-#ifdef ALLSET_ABL_NOLOAD
-      }
-#endif
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
     // ---- backward-data: gu = ga @ W on the bf16 matrix pipe (six of nine plane products)
     // B fragments (W planes, LDS) are fetched ONE block ahead by hand: two sets of six 16-byte fragments, so the matrix pipe
     // never waits on LDS and the register cost of the look-ahead is fixed (one wave per SIMD: nobody else hides it)
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
         gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][0], wb[0], gw[ot][it], 0, 0, 0);
         gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][0], wb[0], gw[ot + 1][it], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next chunk rewrites the image
     __builtin_amdgcn_sched_barrier(0);
