@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
         if constexpr (DROP_IN) { u.x *= kp[hb].x; u.y *= kp[hb].y; u.z *= kp[hb].z; u.w *= kp[hb].w; }
         xr[hb][it] = u;
       }
-      __builtin_amdgcn_sched_barrier(0);          // one row group at a time: interleaving the four multiplies the live set
+      __builtin_amdgcn_sched_barrier(0);          // one row group at a time (measured: letting the four interleave is 2.5 % slower)
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- weight-gradient A operands: ga^T fragments (32 columns of o x the chunk's 16 rows), three planes, by transpose-
@@ -448,25 +448,19 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
       bf16x8m wb[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) wb[pl] = tr_frag(reg + pl * PLB + tb_off[it], 4 * PB);
+      // the six plane products of an i-tile, each over ALL o-tiles before the next: OT independent accumulator chains between
+      // two MFMAs on the same accumulator (a 32x32x16 result is not ready for 16 passes; one wave per SIMD has no neighbour to
+      // fill the gap, so two interleaved chains -- enough at two waves per SIMD -- leave the pipe waiting)
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
 #ifdef ALLSET_ABL_NOWG
-      for (int ot = 0; ot < (it == 0 ? 2 : 0); ot += 2) {
+      for (int pr = 0; pr < (it == 0 ? 1 : 0); ++pr)
 #else
 #pragma unroll
-      for (int ot = 0; ot < OT; ot += 2) {                  // two o-tiles: two independent accumulator chains
+      for (int pr = 0; pr < 6; ++pr)
 #endif
-        gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][2], wb[0], gw[ot][it], 0, 0, 0);
-        gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][2], wb[0], gw[ot + 1][it], 0, 0, 0);
-        gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][0], wb[2], gw[ot][it], 0, 0, 0);
-        gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][0], wb[2], gw[ot + 1][it], 0, 0, 0);
-        gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][1], wb[1], gw[ot][it], 0, 0, 0);
-        gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][1], wb[1], gw[ot + 1][it], 0, 0, 0);
-        gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][1], wb[0], gw[ot][it], 0, 0, 0);
-        gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][1], wb[0], gw[ot + 1][it], 0, 0, 0);
-        gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][0], wb[1], gw[ot][it], 0, 0, 0);
-        gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][0], wb[1], gw[ot + 1][it], 0, 0, 0);
-        gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][0], wb[0], gw[ot][it], 0, 0, 0);
-        gw[ot + 1][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot + 1][0], wb[0], gw[ot + 1][it], 0, 0, 0);
-      }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+          gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][PA_[pr]], wb[PB_[pr]], gw[ot][it], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next chunk rewrites the image
@@ -554,7 +548,11 @@ static void launch_bwd_all(unsigned grid, hipStream_t st, bool ln, bool drop, bo
                                                                                    part_ln, part_w, part_b, n, seed_base,     \
                                                                                    acc_in, ldacc)
 #ifdef ALLSET_ABL_SINGLE       // ablation builds: one instantiation, whatever the flags say
+#ifdef ALLSET_ABL_LIGHT
+  ALLSET_BWD_ALL_K(true, false, false, false, false);
+#else
   ALLSET_BWD_ALL_K(true, true, true, true, false);
+#endif
   return;
 #else
   if (ha) { ALLSET_BWD_ALL_K(false, false, false, false, true); return; }

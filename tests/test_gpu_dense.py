@@ -442,8 +442,10 @@ def test_fused_backward_without_input_gradient(device):
         (y * G).sum().backward()
         assert (xi.grad is not None) == need_x
         grads.append([t.grad.clone() for t in (gamma, beta, W, b)])
+    # with an input gradient everything comes from the one-pass kernel, without it from the backward-data / weight-gradient
+    # pair (partials only): same arithmetic, different summation order of the row reductions
     for a, r in zip(grads[1], grads[0]):
-        assert torch.equal(a, r)
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-5 * max(1.0, float(r.abs().max())))
 
 
 @pytest.mark.parametrize("d", [128, 1433])

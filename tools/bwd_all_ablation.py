@@ -19,8 +19,13 @@ variants = [("full", []), ("no-load", ["-DALLSET_ABL_NOLOAD"]), ("no-store", ["-
             ("no-mfma", ["-DALLSET_ABL_NOWG", "-DALLSET_ABL_NOBD"]),
             ("no-mfma no-load no-store", ["-DALLSET_ABL_NOWG", "-DALLSET_ABL_NOBD", "-DALLSET_ABL_NOLOAD", "-DALLSET_ABL_NOSTORE"]),
             ("no-load no-store", ["-DALLSET_ABL_NOLOAD", "-DALLSET_ABL_NOSTORE"])]
+light = "--light" in sys.argv
+if light:
+    sys.argv.remove("--light")
+    variants = [(nm, fl + ["-DALLSET_ABL_LIGHT"]) for nm, fl in variants]
 if len(sys.argv) > 1:
-    variants = [v for v in variants if v[0] in sys.argv[1:]] + [(a, a.split()) for a in sys.argv[1:] if a.startswith("-D")]
+    variants = ([v for v in variants if v[0] in sys.argv[1:]] +
+                [(a, a.split() + (["-DALLSET_ABL_LIGHT"] if light else [])) for a in sys.argv[1:] if a.startswith("-D")])
 for name, flags in variants:
     so = f"/tmp/bwdall_{abs(hash(name))}.so"
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-shared", "-fPIC", "-DALLSET_ABL_SINGLE",
@@ -34,7 +39,8 @@ for name, flags in variants:
     pw = torch.empty(ns.value * d * d, device=dev); pb = torch.empty(ns.value * d, device=dev); pl = torch.empty(ns.value * 2 * d, device=dev)
     lib.allset_last_error.restype = ctypes.c_char_p
     def run():
-        rc = fn(gy.data_ptr(), d, mask.data_ptr(), 0.5, W.data_ptr(), x.data_ptr(), d, st.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 0.5, 77,
+        rc = fn(gy.data_ptr(), d, None if light else mask.data_ptr(), 0.0 if light else 0.5, W.data_ptr(), x.data_ptr(), d, st.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                0 if light else 1, 0.0 if light else 0.5, 77,
                 gx.data_ptr(), d, pl.data_ptr(), pw.data_ptr(), pb.data_ptr(), ns.value, n, d, d, None, None, 0, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.allset_last_error()
     run(); torch.cuda.synchronize(); ts = []
