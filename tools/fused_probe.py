@@ -13,4 +13,5 @@ for _ in range(3):
     y, st = dense.fused_linear_fwd(x, W, b, g, bt, 1e-5, True, p, 1, True, p, 2, None, mask)
     dense.fused_linear_bwd(G, None, p, W, x, st, g, True, p, 1, None, mask)
     dense.wgrad_fused(G, None, p, x, st, g, bt, True, p, 1, mask=mask)
+    dense.fused_linear_bwd_all(G, mask, p, W, x, st, g, bt, True, p, 1)         # round 2: the pair above as one pass
 torch.cuda.synchronize()
