@@ -204,6 +204,49 @@ def test_setgnn_bf16_storage_tracks_fp32(device):
         assert float((a - b).abs().max()) <= 0.2 * float(b.abs().max()) + 1e-3
 
 
+# (max error / max magnitude, mean error / mean magnitude) allowed for (logits, input gradient).  Measured: PMA logits 0.5 % /
+# 0.3 %, PMA input gradient 3-5 % / 2-4 %; the Deep Sets case amplifies bf16 rounding through the un-normalised segment sums
+# in front of a LayerNorm -- the ORACLE itself evaluated in bfloat16 on the CPU is 1.5 % / 1.3 % (logits) and 12 % / 16 %
+# (input gradient) away from its fp32 self on this case, the product 1.5 % / 1.3 % and 12 % / 16 %.
+BF16_TOL = {"pma": ((1e-2, 1e-2), (8e-2, 6e-2)), "ds": ((3e-2, 3e-2), (0.2, 0.25))}
+
+
+@pytest.mark.parametrize("name", ["rand50_pma_h4", "edge_pma_h4", "wide256_pma_h4", "rand50_ds_add"])
+def test_setgnn_bf16_matches_the_oracle_on_bf16_rounded_inputs(name, device):
+    """BASELINE configs[4] regime at model level, AGAINST THE ORACLE: parameters and features are rounded to bf16 once, the
+    product runs end to end in bfloat16 (bf16 storage, fp32 accumulation / softmax statistics), the oracle runs the same
+    rounded numbers in fp32 on the CPU.  What separates them is the bf16 rounding of every stored activation (2^-9
+    relative each, a handful of them in series): AllSetTransformer logits within 1e-2 of the expected scale (BF16_TOL)."""
+    from types import SimpleNamespace
+    from allset_amd import SetGNN
+    from oracle import allset_oracle as oracle
+    case = cases.build_case(name)
+    g = util.load_golden(name)
+    sd = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in util.state_dict_for(case, g).items()}
+    xb = torch.from_numpy(case["x"]).to(torch.bfloat16)
+    model = SetGNN(case["args"])
+    model.load_state_dict(sd)
+    model = model.eval().to(device).to(torch.bfloat16)
+    x = xb.to(device).requires_grad_(True)
+    data = SimpleNamespace(x=x, edge_index=torch.from_numpy(case["edge_index"]).to(device),
+                           norm=torch.from_numpy(case["norm"]).to(device))
+    logits = model(data)
+    assert logits.dtype == torch.bfloat16
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape)).to(torch.bfloat16)
+    (logits * G.to(device)).sum().backward()
+    xo = xb.float().requires_grad_(True)
+    lo = oracle.setgnn_forward(sd, case["args"], xo, torch.from_numpy(case["edge_index"]), torch.from_numpy(case["norm"]))
+    (lo * G.float()).sum().backward()
+    tol = BF16_TOL["pma" if "pma" in name else "ds"]
+    for (got, exp, what), (MAXTOL, MEANTOL) in zip(((logits.detach().float().cpu(), lo.detach(), "logits"),
+                                                    (x.grad.float().cpu(), xo.grad, "grad_x")), tol):
+        assert torch.isfinite(got).all()
+        scale = float(exp.abs().max())
+        emax, emean = float((got - exp).abs().max()), float((got - exp).abs().mean())
+        assert emax <= MAXTOL * scale + 1e-3, f"{name}/{what}: max error {emax:.3e} vs scale {scale:.3e}"
+        assert emean <= MEANTOL * float(exp.abs().mean()) + 1e-4, f"{name}/{what}: mean error {emean:.3e}"
+
+
 @pytest.mark.parametrize("layers", [1, 2, 3])
 @pytest.mark.parametrize("kind,inorm", [("ln", True), ("ln", False), ("None", False), ("bn", True)])
 @pytest.mark.parametrize("width", [64, 72])

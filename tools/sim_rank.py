@@ -23,6 +23,8 @@ LINK = 60e9
 for world in (1, 2, 4, 8):
     adist._rows_to_cols = (lambda x, group=None, w=world: x if w == 1 else adist._pack(x, w).view(w * x.shape[0], x.shape[1] // w))
     adist._cols_to_rows = (lambda x, group=None, w=world: x if w == 1 else adist._unpack(x.view(w, x.shape[0] // w, x.shape[1])))
+    adist._all_gather_rows = (lambda x, group=None, w=world: x if w == 1 else x.repeat(w, *([1] * (x.dim() - 1))))
+    adist._reduce_scatter_rows = (lambda x, group=None, w=world: x if w == 1 else x[:x.shape[0] // w].contiguous())
     adist._world = lambda group=None, w=world: w
     adist._skip_collective = lambda group=None, w=world: w == 1      # world > 1: take the real merge paths ...
     adist.dist.all_reduce = lambda *a, **k: None                      # ... with the small max-all-reduce stubbed out
