@@ -795,15 +795,8 @@ class _PmaResidualFF(torch.autograd.Function):
         relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
         gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
         zy = None if mask is not None else z
-        O2, I2 = w2.shape
-        O1, I1 = w1.shape
-        if (mask is not None and out.shape[0] > 0 and fused_linear_bwd_all_supported(O2, I2, False, False, True, True)
-                and fused_linear_bwd_all_supported(O1, I1, False, False, False, False, True)):
-            # one pass per Linear: input gradient and weight / bias gradient from a single read of the gradient and the input
-            g1, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
-            gout, _, _, gw1, gb1 = fused_linear_bwd_all(g1, None, 0.0, w1, out, None, None, None, False, 0.0, 0, acc_in=gs,
-                                                        want_bias=has_b1)                    # gs + rFF branch
-            return gout, gw1, gb1, gw2, gb2, dg, db, None, None, None
+        # (the one-pass backward kernel is not used here: without a LayerNorm to recompute, the plain weight-gradient kernel
+        # costs 0.19 ms and the pair 0.48-0.59 ms per Linear against 0.58 ms for the one-pass kernel -- measured, round 2)
         gw2, gb2 = wgrad_fused(gs, zy, 0.0, y1, None, None, None, True, 0.0, 0, want_bias=has_b2, mask=mask)
         g1, _, _ = fused_linear_bwd(gs, zy, 0.0, w2, y1, None, None, True, 0.0, 0, None, mask)
         gw1, gb1 = wgrad(g1, out, want_bias=has_b1)
