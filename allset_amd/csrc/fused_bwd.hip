@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
   }
   __syncthreads();
 
-  const int lane0 = tid & 63, wave = tid >> 6;
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: chunk bases live in scalar registers
   const float inv_i = 1.f / static_cast<float>(ID);
   const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
@@ -146,23 +147,32 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
 
   float ag[OQ];
   uint32_t am_bits = 0;
-  auto request_rows = [&](int64_t chunk, int lane) {     // unconditional loads on a clamped row (no branches around loads)
+  // Addresses: the chunk is wave-uniform, so a chunk's base pointers are scalar 64-bit values and a lane adds a 32-bit byte
+  // offset (global_load ... v_off, s[base] form).  Rows past n are clamped to the last valid row of the chunk (unconditional
+  // loads; dead rows are masked where used) -- on 32-bit local indices, not 64-bit row numbers.
+  auto rows_here = [&](int64_t chunk) -> int {            // valid rows of this chunk, 0..16 (0: the wave has run out of chunks)
+    const int64_t left = n - chunk * 16;
+    return left >= 16 ? 16 : (left > 0 ? static_cast<int>(left) : 0);
+  };
+  auto request_rows = [&](int64_t chunk, int lane) {
     const int ri = lane & 15, g = lane >> 4;
-    int64_t row = chunk * 16 + ri;
-    row = row < n ? row : n - 1;
+    const int nr = rows_here(chunk);
+    const int64_t c0 = nr > 0 ? chunk : n_chunks - 1;    // past the end: re-read the last chunk (never consumed)
+    const int lr = min(ri, max(nr, 1) - 1);
     if constexpr (HAS_MASK) {
       // this lane's word of the activation mask: row ri of the chunk, columns g*OQ .. +OQ-1 (include/allset_hip.h "mask layout")
       const int m_l15 = ((g * OQ) % 64) / 4;
-      const int m_word = (((g * OQ) / 64) * 4 + (ri >> 2)) * 8 + (ri & 3) * 2 + (m_l15 >> 3);
-      am_bits = mask[(row >> 4) * (NHO * 32) + m_word];
+      const int m_word = (((g * OQ) / 64) * 4 + (lr >> 2)) * 8 + (lr & 3) * 2 + (m_l15 >> 3);
+      am_bits = (mask + c0 * (NHO * 32))[m_word];
     }
 #ifdef ALLSET_ABL_NOLOAD       // ablation builds only (tools/bwd_all_ablation.py)
     if (p_in == 123.f) {
 #endif
-    const float4* gr = reinterpret_cast<const float4*>(gy + row * ldg + g * OQ);
+    const char* base = reinterpret_cast<const char*>(gy + c0 * 16 * ldg);
+    const uint32_t off = static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldg) * 4u + static_cast<uint32_t>(g * OQ * 4);
 #pragma unroll
     for (int q = 0; q < OQ / 4; ++q) {
-      const float4 v = gr[q];
+      const float4 v = *reinterpret_cast<const float4*>(base + off + 16 * q);
       ag[4 * q] = v.x; ag[4 * q + 1] = v.y; ag[4 * q + 2] = v.z; ag[4 * q + 3] = v.w;
     }
 #ifdef ALLSET_ABL_NOLOAD
@@ -177,16 +187,19 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
   float2 st[4];
   auto request_x = [&](int64_t chunk, int lane) {
     const int c4 = (lane & 15) * 4;
+    const int nr = rows_here(chunk);
+    const char* xb = reinterpret_cast<const char*>(x + chunk * 16 * ldx);
+    const char* sb = reinterpret_cast<const char*>(stats + chunk * 16 * 2);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      int64_t r = chunk * 16 + it * 4 + (lane >> 4);
-      r = r < n ? r : n - 1;                          // clamped, unconditional; dead rows are masked where used
+      const int lr = min(it * 4 + (lane >> 4), nr - 1);   // clamped, unconditional; dead rows are masked where used
+      const uint32_t off = static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldx) * 4u + static_cast<uint32_t>(c4 * 4);
 #ifdef ALLSET_ABL_NOLOAD
       if (p_in == 123.f) {
 #endif
-      if constexpr (HAS_LN) st[it] = *reinterpret_cast<const float2*>(stats + r * 2);
+      if constexpr (HAS_LN) st[it] = *reinterpret_cast<const float2*>(sb + lr * 8);
 #pragma unroll
-      for (int hb = 0; hb < NH; ++hb) xr[hb][it] = *reinterpret_cast<const float4*>(x + r * ldx + hb * 64 + c4);
+      for (int hb = 0; hb < NH; ++hb) xr[hb][it] = *reinterpret_cast<const float4*>(xb + off + hb * 256);
 #ifdef ALLSET_ABL_NOLOAD
       }
 #endif
@@ -203,7 +216,8 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
     // writer of ga (backward-data layout): row ri, columns g*OQ .. +OQ-1 = OQ*2 bytes inside one 64-byte chunk of the image
     const int wa_off = img_off<PA>(ri, g * OQ * 2);
     const int wb_base = g * GS + ri * OQD, wb_swz = (ri / (64 / OQD)) % (OQD / 4);      // W-plane fragments: see load_b below
-    const bool valid = chunk * 16 + ri < n;
+    const int nrows = rows_here(chunk);                 // 1..16 inside the loop
+    const bool valid = ri < nrows;
     request_x(chunk, lane);                             // this chunk's x rows: the mask / split phase and the matrix phase cover them
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HAS_MASK) {
@@ -324,8 +338,9 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int64_t r = chunk * 16 + it * 4 + (lane >> 4);
-      const bool live = r < n;
+      const int lrow = it * 4 + (lane >> 4);
+      const int64_t r = chunk * 16 + lrow;               // (the dropout hash is keyed by the global element index)
+      const bool live = lrow < nrows;
       float s1 = 0.f, s2 = 0.f;
       float4 xraw[NH], kp[NH];                           // the raw x (relu-in mask) and the dropout-in keep factors of this row group
 #pragma unroll
@@ -374,13 +389,16 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
             o.z = xraw[hb].z > 0.f ? o.z : 0.f; o.w = xraw[hb].w > 0.f ? o.w : 0.f;
           }
           if constexpr (HAS_ACC) {        // gx = acc_in + ...: a second gradient branch of the same tensor, summed here
-            const float4 ai = *reinterpret_cast<const float4*>(acc_in + r * ldacc + hb * 64 + c4);   // (may alias gx)
+            const float4 ai = *reinterpret_cast<const float4*>(
+                reinterpret_cast<const char*>(acc_in + chunk * 16 * ldacc) + static_cast<uint32_t>(lrow) * static_cast<uint32_t>(ldacc) * 4u +
+                (hb * 64 + c4) * 4);                                                            // (may alias gx)
             o.x += ai.x; o.y += ai.y; o.z += ai.z; o.w += ai.w;
           }
 #ifdef ALLSET_ABL_NOSTORE
           if (o.x == 123.456f)
 #endif
-          *reinterpret_cast<float4*>(gx + r * ldgx + hb * 64 + c4) = o;
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + chunk * 16 * ldgx) +
+                                     static_cast<uint32_t>(lrow) * static_cast<uint32_t>(ldgx) * 4u + (hb * 64 + c4) * 4) = o;
         }
       }
       // the Linear's input for the weight gradient, in place of x
@@ -602,6 +620,8 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && aligned16(acc_in)),
                  "fused_linear_bwd_all: acc_in must be 16-byte aligned rows");
   ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd_all: stats must be 8-byte aligned");
+  ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
+                 "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
 #define ALLSET_BWD_ALL_ARGS grid, st, has_ln, drop, relu, hm, ha, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in, \
                             gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc
