@@ -988,6 +988,162 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_kernel(
 }
 
 
+// ---- the same weight gradient, full width per workgroup, transposed by the LDS read (round 2) ---------------------------------
+// wgrad_bf16_kernel above tiles gW into 128 x 128 blocks, so at 256 x 256 (BASELINE configs[4]) four workgroups stream the same
+// rows and every operand is read twice: 0.10 ms where one pass over the two [250k, 256] bf16 matrices is 0.05 ms.  Here one
+// workgroup owns ALL of gW for its slice of rows: 8 waves x (O/4 x I/2) accumulators = 128 registers per lane at 256 x 256.
+// A 32-row stage of both operands is copied into LDS exactly as it lies in memory (16-byte pieces, row-major, 32-byte chunks
+// XOR-swizzled by the row) and the MFMA fragments -- 8 consecutive ROWS of one column -- come out of ds_read_b64_tr_b16
+// (hardware 4 x 4 transpose, see fused_bwd.hip): no row-pair packing, no VALU in the staging path at all.
+typedef short wv4s_t __attribute__((ext_vector_type(4)));
+typedef __bf16 wv2bf_t __attribute__((ext_vector_type(2)));
+union WTrFrag { uint4 u; bf16x8_t v; struct { wv4s_t lo, hi; } t; };
+
+template <int PITCH>
+__device__ __forceinline__ int wtr_off(int row, int cbyte) {
+  constexpr int NCH = PITCH / 32;                                  // 32-byte chunks per row
+  const int sw = ((row & 3) | (((row >> 3) & 1) << 2)) & (NCH - 1);
+  return row * PITCH + ((((cbyte >> 5) ^ sw)) << 5) + (cbyte & 31);
+}
+
+template <int OTN, int ITN>       // O = 64 OTN, I = 32 ITN; wave tile (16 OTN) x (16 ITN)
+__global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
+    const uint16_t* __restrict__ ga, int64_t lda, const uint16_t* __restrict__ u, int64_t ldu,
+    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int64_t rows_per_slice) {
+  constexpr int O = 64 * OTN, I = 32 * ITN;
+  constexpr int PA = O * 2, PB = I * 2;                            // row pitches (bytes)
+  constexpr int SA = 32 * PA, SB = 32 * PB;                        // bytes per stage and operand
+  constexpr int NPA = (32 * PA / 16 + kWx6Block - 1) / kWx6Block;  // 16-byte pieces per thread and stage
+  constexpr int NPB = (32 * PB / 16 + kWx6Block - 1) / kWx6Block;
+  __shared__ __attribute__((aligned(16))) uint8_t sS[2 * (SA + SB)];
+  const int slice = blockIdx.x;
+  const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
+  const int64_t r_end = min(n, r_begin + rows_per_slice);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  struct Stage { uint4 a[NPA], b[NPB]; };
+  auto load_stage = [&](Stage& sg, int64_t r0) {                 // unconditional loads on clamped rows; zeroed when stored
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+      const int p = tid + k * kWx6Block, row = p / (PA / 16), c16 = p % (PA / 16);
+      int64_t r = r0 + row;
+      r = r < r_end ? r : r_end - 1;
+      if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16) sg.a[k] = *reinterpret_cast<const uint4*>(ga + r * lda + c16 * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+      const int p = tid + k * kWx6Block, row = p / (PB / 16), c16 = p % (PB / 16);
+      int64_t r = r0 + row;
+      r = r < r_end ? r : r_end - 1;
+      if (32 * PB / 16 % kWx6Block == 0 || p < 32 * PB / 16) sg.b[k] = *reinterpret_cast<const uint4*>(u + r * ldu + c16 * 8);
+    }
+  };
+  auto store_stage = [&](const Stage& sg, int64_t r0, int buf) {
+    uint8_t* ba = sS + buf * (SA + SB);
+    uint8_t* bb = ba + SA;
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+      const int p = tid + k * kWx6Block, row = p / (PA / 16), c16 = p % (PA / 16);
+      if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16)
+        *reinterpret_cast<uint4*>(ba + wtr_off<PA>(row, c16 * 16)) = (r0 + row < r_end) ? sg.a[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+      const int p = tid + k * kWx6Block, row = p / (PB / 16), c16 = p % (PB / 16);
+      if (32 * PB / 16 % kWx6Block == 0 || p < 32 * PB / 16)
+        *reinterpret_cast<uint4*>(bb + wtr_off<PB>(row, c16 * 16)) = (r0 + row < r_end) ? sg.b[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+
+  // fragment addresses: lane (i = lane & 15, g = lane >> 4) of a 16 x 16 x 32 operand supplies rows 8 g + (i >> 2) [+4 for the
+  // second read], 4 columns at 4 (i & 3) of the tile's 16 columns (32 bytes = one swizzle chunk)
+  const int fi = lane & 15, fg = lane >> 4;
+  const int sw = (fi >> 2) | ((fg & 1) << 2);
+  const int ob = (wave >> 1) * (16 * OTN), ib = (wave & 1) * (16 * ITN);     // this wave's tile origin
+  const int rowoff_a = (8 * fg + (fi >> 2)) * PA + 8 * (fi & 3), rowoff_b = (8 * fg + (fi >> 2)) * PB + 8 * (fi & 3);
+  f32x4_t acc[OTN][ITN];
+#pragma unroll
+  for (int ot = 0; ot < OTN; ++ot)
+#pragma unroll
+    for (int it = 0; it < ITN; ++it) acc[ot][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float gbs[OTN];
+#pragma unroll
+  for (int ot = 0; ot < OTN; ++ot) gbs[ot] = 0.f;
+  const wv2bf_t ones = __builtin_bit_cast(wv2bf_t, 0x3f803f80u);
+
+  auto tr_frag = [&](const uint8_t* p, int half) {
+    WTrFrag f;
+    f.t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wv4s_t*)(p));
+    f.t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wv4s_t*)(p + half));
+    return f;
+  };
+  auto mfma_stage = [&](int buf) {
+    const uint8_t* ba = sS + buf * (SA + SB);
+    const uint8_t* bb = ba + SA;
+    WTrFrag a[OTN];
+#pragma unroll
+    for (int ot = 0; ot < OTN; ++ot) {
+      const int chunk = (ob + ot * 16) / 16;
+      a[ot] = tr_frag(ba + rowoff_a + (((chunk ^ sw) & (PA / 32 - 1)) << 5), 4 * PA);
+    }
+    if ((wave & 1) == 0 && part_b != nullptr) {
+#pragma unroll
+      for (int ot = 0; ot < OTN; ++ot) {
+        gbs[ot] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, a[ot].u.x), ones, gbs[ot], false);
+        gbs[ot] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, a[ot].u.y), ones, gbs[ot], false);
+        gbs[ot] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, a[ot].u.z), ones, gbs[ot], false);
+        gbs[ot] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, a[ot].u.w), ones, gbs[ot], false);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITN; ++it) {
+      const int chunk = (ib + it * 16) / 16;
+      const WTrFrag b = tr_frag(bb + rowoff_b + (((chunk ^ sw) & (PB / 32 - 1)) << 5), 4 * PB);
+#pragma unroll
+      for (int ot = 0; ot < OTN; ++ot) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ot].v, b.v, acc[ot][it], 0, 0, 0);
+    }
+  };
+
+  Stage s0, s1;
+  if (r_begin < r_end) {                       // stage 0 -> LDS buffer 0; stages 1 and 2 on their way
+    load_stage(s0, r_begin);
+    load_stage(s1, r_begin + 32);
+    store_stage(s0, r_begin, 0);
+    load_stage(s0, r_begin + 64);
+  }
+  __syncthreads();
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
+    mfma_stage(0);
+    if (r0 + 32 < r_end) store_stage(s1, r0 + 32, 1);
+    load_stage(s1, r0 + 96);
+    __syncthreads();
+    if (r0 + 32 < r_end) {
+      mfma_stage(1);
+      if (r0 + 64 < r_end) store_stage(s0, r0 + 64, 0);
+      load_stage(s0, r0 + 128);
+      __syncthreads();
+    }
+  }
+
+  // partial tile -> part_w[slice][O][I]; acc[ot][it][r] is (o = ob + 16 ot + 4 fg + r, i = ib + 16 it + fi)
+  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+#pragma unroll
+  for (int ot = 0; ot < OTN; ++ot)
+#pragma unroll
+    for (int it = 0; it < ITN; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[(ob + ot * 16 + 4 * fg + r) * I + ib + it * 16 + fi] = acc[ot][it][r];
+  if ((wave & 1) == 0 && part_b != nullptr) {  // lane (column fi, row group fg): fold the four row groups
+#pragma unroll
+    for (int ot = 0; ot < OTN; ++ot) {
+      float v = gbs[ot];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16) part_b[static_cast<int64_t>(slice) * O + ob + ot * 16 + fi] = v;
+    }
+  }
+}
+
 // ---- LayerNorm for bf16 activations (fp32 statistics and arithmetic, bf16 in / out; gamma, beta bf16) -------------------
 // One lane = 8 consecutive columns (16 bytes), LPR = d / 8 lanes per row (d % 8 == 0, d <= 512), 64 / LPR rows per wave.
 struct F8 { float v[8]; };
@@ -1599,6 +1755,23 @@ extern "C" int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, i
   return ALLSET_OK;
 }
 
+static inline bool wgrad_bf16_full_width(int64_t O, int64_t I) {
+  return (O == 64 || O == 128 || O == 256) && (I == 64 || I == 128 || I == 256);
+}
+
+extern "C" int allset_wgrad_bf16_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices) {
+  clear_error();
+  ALLSET_REQUIRE(n_slices != nullptr && n >= 0 && O >= 1 && I >= 1, "wgrad_bf16_slices: bad argument");
+  if (!wgrad_bf16_full_width(O, I)) return allset_wgrad_slices(n, O, I, n_slices);
+  // one workgroup owns the whole gW of its rows: two 64-KiB-LDS workgroups per CU at most, at least 256 rows per slice
+  int64_t s = (O == 256 && I == 256) ? 256 : 512;
+  const int64_t max_by_rows = (n + 255) / 256;
+  if (s > max_by_rows) s = max_by_rows;
+  if (s < 1) s = 1;
+  *n_slices = s;
+  return ALLSET_OK;
+}
+
 extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
                                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
   clear_error();
@@ -1612,6 +1785,30 @@ extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int
   }
   ALLSET_REQUIRE(lda >= O && ldu >= I, "wgrad_bf16: leading dimension smaller than the feature width");
   const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (wgrad_bf16_full_width(O, I) && lda % 8 == 0 && ldu % 8 == 0 && aligned16(ga) && aligned16(u) &&
+      getenv("ALLSET_WGRAD_BF16_TILED") == nullptr) {
+    // the full-width kernel: one read of each operand (the tiled one below re-reads them per 128 x 128 tile)
+    int64_t rps = (n + n_slices - 1) / n_slices;
+    rps = (rps + 31) / 32 * 32;
+    if (rps < 32) rps = 32;
+    const unsigned grid1 = static_cast<unsigned>(n_slices);
+    const uint16_t* a16 = static_cast<const uint16_t*>(ga);
+    const uint16_t* u16 = static_cast<const uint16_t*>(u);
+#define ALLSET_WGTR(OTN, ITN) wgrad_bf16_tr_kernel<OTN, ITN><<<grid1, kWx6Block, 0, st>>>(a16, lda, u16, ldu, part_w, part_b, n, rps)
+    const int otn = static_cast<int>(O / 64), itn = static_cast<int>(I / 32);
+    if (otn == 4 && itn == 8) ALLSET_WGTR(4, 8);
+    else if (otn == 4 && itn == 4) ALLSET_WGTR(4, 4);
+    else if (otn == 4 && itn == 2) ALLSET_WGTR(4, 2);
+    else if (otn == 2 && itn == 8) ALLSET_WGTR(2, 8);
+    else if (otn == 2 && itn == 4) ALLSET_WGTR(2, 4);
+    else if (otn == 2 && itn == 2) ALLSET_WGTR(2, 2);
+    else if (otn == 1 && itn == 8) ALLSET_WGTR(1, 8);
+    else if (otn == 1 && itn == 4) ALLSET_WGTR(1, 4);
+    else ALLSET_WGTR(1, 2);
+#undef ALLSET_WGTR
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   const int tiles_o = static_cast<int>((O + kWgTile - 1) / kWgTile), tiles_i = static_cast<int>((I + kWgTile - 1) / kWgTile);
   int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
   rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;

@@ -168,10 +168,13 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
     I = u.shape[1]
     lib = _lib.load()
     ns = c_int64(0)
-    check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
+    bf16 = ga.dtype == torch.bfloat16
+    if bf16:
+        check(lib.allset_wgrad_bf16_slices(n, O, I, byref(ns)), "allset_wgrad_bf16_slices")
+    else:
+        check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
     part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
     part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
-    bf16 = ga.dtype == torch.bfloat16
     with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
         if bf16:
             check(lib.allset_wgrad_bf16(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,

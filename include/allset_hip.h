@@ -216,7 +216,10 @@ int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, floa
                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* The same weight gradient for bf16 activations (ga, u: bf16 row-major; fp32 partials as above; bf16 x bf16 products are
- * exact in the fp32 accumulator).  n_slices from allset_wgrad_slices. */
+ * exact in the fp32 accumulator).  n_slices from allset_wgrad_bf16_slices (widths in {64,128,256} with 16-byte aligned rows take
+ * a full-width kernel -- one workgroup owns all of gW for its rows, each operand is read once, the transposes are LDS
+ * transpose-reads -- with its own slice count; other shapes fall back to the 128 x 128-tiled kernel and allset_wgrad_slices). */
+int allset_wgrad_bf16_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
                       int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
