@@ -69,7 +69,7 @@ SIGNATURES = {
     "allset_fused_linear_bwd_all_supported": [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int],
     "allset_fused_linear_bwd_all_slices": [c_int64, POINTER(c_int64)],
     "allset_fused_linear_bwd_all": [_P, c_int64, _P, c_float, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, c_int64,
-                                    _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int64, _P],
+                                    _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int64, c_int64, _P],
     "allset_gemm_x6_supported": [c_int64, c_int64],
     "allset_gemm_x6_plane_bytes": [c_int64, c_int64],
     "allset_gemm_x6_planes": [_P, c_int64, c_int, _P, c_int64, c_int64, _P],

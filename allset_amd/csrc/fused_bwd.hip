@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
-    const uint64_t* __restrict__ seed_base, const float* acc_in, int64_t ldacc) {
+    const uint64_t* __restrict__ seed_base, const float* acc_in, int64_t ldacc, int64_t pstride_w, int64_t pstride_b,
+    int64_t pstride_ln) {
   seed_in = resolve_seed(seed_base, seed_in);
   constexpr int OQ = OD / 4, OQD = OQ / 2, T = OQ / 8;
   constexpr int GS = ID * OQD;
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
   // ---- per-wave partials: gW [O][I], gb [O], LayerNorm (dgamma, dbeta) [2][I]
   const int64_t slice = static_cast<int64_t>(blockIdx.x) * kMWaves + wave;
   const int lane = lane0, c4 = (lane0 & 15) * 4;
-  float* pw = part_w + slice * OD * ID;
+  float* pw = part_w + slice * pstride_w;
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
@@ -502,11 +503,11 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const float sum = gbs[ot] + __shfl_xor(gbs[ot], 32);
-      if (lane < 32) part_b[slice * OD + ot * 32 + lane] = sum;
+      if (lane < 32) part_b[slice * pstride_b + ot * 32 + lane] = sum;
     }
   }
   if constexpr (HAS_LN) {     // the 4 row groups of a lane column fold first
-    float* pl = part_ln + slice * 2 * ID;
+    float* pl = part_ln + slice * pstride_ln;
 #pragma unroll
     for (int hb = 0; hb < NH; ++hb) {
       float4 a = dg[hb], b = db[hb];
@@ -559,12 +560,12 @@ static void launch_bwd_all(unsigned grid, hipStream_t st, bool ln, bool drop, bo
                            int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
                            const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in, float* gx,
                            int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n, const uint64_t* seed_base,
-                           const float* acc_in, int64_t ldacc) {
+                           const float* acc_in, int64_t ldacc, int64_t psw, int64_t psb, int64_t psl) {
 #define ALLSET_BWD_ALL_K(LN, DI, RI, HM, HA)                                                                                 \
   fused_linear_bwd_all_kernel<OD, ID, LN, DI, RI, HM, HA><<<grid, kMBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats,     \
                                                                                    gamma, beta, p_in, seed_in, gx, ldgx,      \
                                                                                    part_ln, part_w, part_b, n, seed_base,     \
-                                                                                   acc_in, ldacc)
+                                                                                   acc_in, ldacc, psw, psb, psl)
 #ifdef ALLSET_ABL_SINGLE       // ablation builds: one instantiation, whatever the flags say
 #ifdef ALLSET_ABL_LIGHT
   ALLSET_BWD_ALL_K(true, false, false, false, false);
@@ -589,9 +590,13 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
                                            const float* beta, int relu_in, float p_in, uint64_t seed_in, float* gx,
                                            int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
                                            int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, const float* acc_in,
-                                           int64_t ldacc, void* stream) {
+                                           int64_t ldacc, int64_t part_stride, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_all: negative size");
+  // part_stride = 0: three dense arrays [n_slices][O*I], [n_slices][O], [n_slices][2*I]; > 0: the three pointers address
+  // the sections of ONE [n_slices][part_stride] buffer (one reduction launch for all of them)
+  ALLSET_REQUIRE(part_stride == 0 || part_stride >= O * I, "fused_linear_bwd_all: part_stride smaller than a gW partial");
+  const int64_t psw = part_stride ? part_stride : O * I, psb = part_stride ? part_stride : O, psl = part_stride ? part_stride : 2 * I;
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_bwd_all: dropout p must be in [0,1)");
   const bool has_ln = stats != nullptr;
   ALLSET_REQUIRE(has_ln == (gamma != nullptr) && has_ln == (beta != nullptr), "fused_linear_bwd_all: stats, gamma and beta must come together");
@@ -607,6 +612,10 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   ALLSET_REQUIRE(!has_ln || part_ln != nullptr, "fused_linear_bwd_all: LayerNorm partials buffer missing");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   if (n == 0) {
+    if (part_stride) {
+      ALLSET_HIP_CHECK(hipMemsetAsync(part_w, 0, static_cast<size_t>(n_slices) * part_stride * sizeof(float), st));
+      return ALLSET_OK;
+    }
     ALLSET_HIP_CHECK(hipMemsetAsync(part_w, 0, static_cast<size_t>(n_slices) * O * I * sizeof(float), st));
     if (part_b) ALLSET_HIP_CHECK(hipMemsetAsync(part_b, 0, static_cast<size_t>(n_slices) * O * sizeof(float), st));
     if (has_ln) ALLSET_HIP_CHECK(hipMemsetAsync(part_ln, 0, static_cast<size_t>(n_slices) * 2 * I * sizeof(float), st));
@@ -624,7 +633,7 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
 #define ALLSET_BWD_ALL_ARGS grid, st, has_ln, drop, relu, hm, ha, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in, \
-                            gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc
+                            gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc, psw, psb, psl
 #ifdef ALLSET_ABL_SINGLE
   launch_bwd_all<128, 128>(ALLSET_BWD_ALL_ARGS);
 #else

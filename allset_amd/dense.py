@@ -406,21 +406,25 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
         gx = acc_in if acc_in.is_contiguous() else torch.empty((n, I), dtype=torch.float32, device=dev)
     else:
         gx = torch.empty((n, I), dtype=torch.float32, device=dev)
-    part_w = torch.empty((P, O, I), dtype=torch.float32, device=dev)
-    part_b = torch.empty((P, O), dtype=torch.float32, device=dev) if want_bias else None
-    part_ln = torch.empty((P, 2, I), dtype=torch.float32, device=dev) if stats is not None else None
+    # ONE partial buffer [P, O*I + O + 2*I]: gW, gb and the LayerNorm partials of a slice side by side, one reduction launch
+    M = O * I + O + (2 * I if stats is not None else 0)
+    M = (M + 3) // 4 * 4
+    part = torch.empty((P, M), dtype=torch.float32, device=dev)
+    flat = part.view(-1)
+    part_w, part_b = flat, flat[O * I:]
+    part_ln = flat[O * I + O:] if stats is not None else None
     with torch.cuda.device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
         check(lib.allset_fused_linear_bwd_all(
             ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
-            int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w), ptr(part_b), P, n, O, I,
-            ptr(seed_base), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0, stream_of(dev)), "allset_fused_linear_bwd_all")
-    gw = reduce_partials(part_w)
-    gb = reduce_partials(part_b) if want_bias else None
-    if part_ln is None:
+            int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w), ptr(part_b if want_bias else None), P, n, O, I,
+            ptr(seed_base), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0, M, stream_of(dev)), "allset_fused_linear_bwd_all")
+    red = reduce_partials(part)
+    gw = red[:O * I].view(O, I)
+    gb = red[O * I:O * I + O] if want_bias else None
+    if stats is None:
         return gx, None, None, gw, gb
-    red = reduce_partials(part_ln)
-    return gx, red[0], red[1], gw, gb
+    return gx, red[O * I + O:O * I + O + I], red[O * I + O + I:O * I + O + 2 * I], gw, gb
 
 
 def wgrad_supported(ga: Tensor, u: Tensor) -> bool:

@@ -401,6 +401,9 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  *   gx       required (a Linear whose input needs no gradient keeps the two-kernel pair); acc_in as in allset_fused_linear_bwd
  *   part_w   f32[n_slices*O*I], part_b f32[n_slices*O] or NULL, part_ln f32[n_slices*2*I] (stats != NULL): one partial per
  *            wave, n_slices from allset_fused_linear_bwd_all_slices(n); the caller sums over slices (allset_reduce_partials).
+ *   part_stride  0: part_w / part_b / part_ln are three dense arrays as sized above; > 0 (>= O*I + O + 2*I in practice): they
+ *            point into ONE f32[n_slices*part_stride] buffer, slice k's sections at k*part_stride from each pointer -- one
+ *            allset_reduce_partials launch then sums all of a Linear's parameter gradients.
  * No atomics: bitwise reproducible run to run.  allset_fused_linear_bwd_all_supported(O, I, flags) -> 1/0: widths in
  * {64,128} and the prologue / epilogue combinations the module surface produces (dropout_in only behind relu_in, acc_in only
  * on the plain Linear); 0 under ALLSET_DENSE_MFMA=f32.  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
@@ -410,7 +413,7 @@ int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* ma
                                 int64_t ldx, const float* stats, const float* gamma, const float* beta, int relu_in, float p_in,
                                 uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b,
                                 int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
-                                const float* acc_in, int64_t ldacc, void* stream);
+                                const float* acc_in, int64_t ldacc, int64_t part_stride, void* stream);
 
 #ifdef __cplusplus
 }

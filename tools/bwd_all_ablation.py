@@ -32,7 +32,7 @@ for name, flags in variants:
                     "-o", so] + flags + src, check=True)
     lib = ctypes.CDLL(so)
     fn = lib.allset_fused_linear_bwd_all
-    fn.argtypes = [P, I64, P, F, P, P, I64, P, P, P, I, F, U64, P, I64, P, P, P, I64, I64, I64, I64, P, P, I64, P]
+    fn.argtypes = [P, I64, P, F, P, P, I64, P, P, P, I, F, U64, P, I64, P, P, P, I64, I64, I64, I64, P, P, I64, I64, P]
     ns = ctypes.c_int64(0)
     lib.allset_fused_linear_bwd_all_slices.argtypes = [I64, ctypes.POINTER(I64)]
     lib.allset_fused_linear_bwd_all_slices(n, ctypes.byref(ns))
@@ -41,7 +41,7 @@ for name, flags in variants:
     def run():
         rc = fn(gy.data_ptr(), d, None if light else mask.data_ptr(), 0.0 if light else 0.5, W.data_ptr(), x.data_ptr(), d, st.data_ptr(), gam.data_ptr(), bet.data_ptr(),
                 0 if light else 1, 0.0 if light else 0.5, 77,
-                gx.data_ptr(), d, pl.data_ptr(), pw.data_ptr(), pb.data_ptr(), ns.value, n, d, d, None, None, 0, torch.cuda.current_stream().cuda_stream)
+                gx.data_ptr(), d, pl.data_ptr(), pw.data_ptr(), pb.data_ptr(), ns.value, n, d, d, None, None, 0, 0, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.allset_last_error()
     run(); torch.cuda.synchronize(); ts = []
     for _ in range(20):
