@@ -45,9 +45,9 @@ def test_processed_data_pt_reader(name):
     InMemoryDataset.collate) read WITHOUT torch_geometric, in both torch serialisation formats and both PyG attribute
     layouts; fixtures and their provenance: oracle/gen_datapt_fixture.py.  The file without n_x / num_hyperedges takes
     the fall-backs of reference train.py:333-339."""
-    import sys
+    import importlib.machinery
     from allset_amd.train import build_parser, load_data, load_pyg_processed, preprocess
-    assert "torch_geometric" not in sys.modules
+    assert importlib.machinery.PathFinder.find_spec("torch_geometric") is None      # the real package is not installed
     exp = np.load(os.path.join(GOLDEN_DATAPT, "expected.npz"))
     data = load_pyg_processed(os.path.join(GOLDEN_DATAPT, name))
     assert np.array_equal(data.x.numpy(), exp["x"]) and data.x.dtype == torch.float32
