@@ -94,6 +94,9 @@ SIGNATURES = {
     "allset_ln_res_fwd": [_P, c_int64, _P, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
                           c_int64, _P, _P],
     "allset_ln_res_bwd_partials": [c_int64, c_int64, POINTER(c_int64)],
+    "allset_ln_res_bwd_pma_supported": [c_int64, c_int64],
+    "allset_ln_res_bwd_pma": [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P,
+                              c_int64, _P],
     "allset_ln_res_bwd": [_P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P,
                           c_int64, c_int64, c_int64, _P, _P],
 }

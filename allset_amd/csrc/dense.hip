@@ -801,11 +801,16 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ colb,
     const float* __restrict__ res, int64_t ldr, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, int relu_out, float p, uint64_t seed, float* __restrict__ gs, int64_t ldgs,
-    float* __restrict__ part, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+    float* __restrict__ part, int64_t n, int d, const uint64_t* __restrict__ seed_base,
+    const float* __restrict__ pma_m, const float* __restrict__ pma_l, float* __restrict__ pma_stats, int pma_heads) {
   seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
   constexpr int kGroups = kWavesPerBlock * NS;
   __shared__ float red[kGroups][3][LPR * 4];
+  // optional epilogue for the PMA tail (x = the pooled output of allset_pma_fwd, gs = its gradient): the per-(row, head)
+  // backward statistics {M = m + log(l + eps), delta = <x_head, gs_head>} that allset_pma_bwd_src gathers, written here
+  // where both operands are in registers instead of by a separate pass over x and gs (allset_pma_bwd_stats)
+  const int pma_g = pma_stats ? (d / pma_heads) / 4 : 1;           // lanes per head (a power of two, checked by the host)
   const int lane = lane_id();
   const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
   const int li = lane % LPR;
@@ -853,6 +858,18 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
                                    rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
       dc.x += o.x; dc.y += o.y; dc.z += o.z; dc.w += o.w;
       *reinterpret_cast<float4*>(gs + row * ldgs + c0) = o;
+    }
+    if (pma_stats != nullptr) {                           // (uniform branch; inactive lanes contribute 0 to the shuffles)
+      float dot = active ? (xv.x * (rstd * (gh.x - s1 - xh.x * s2)) + xv.y * (rstd * (gh.y - s1 - xh.y * s2)) +
+                            xv.z * (rstd * (gh.z - s1 - xh.z * s2)) + xv.w * (rstd * (gh.w - s1 - xh.w * s2))) : 0.f;
+      for (int off = 1; off < pma_g; off <<= 1) dot += __shfl_xor(dot, off);
+      if (active && (li % pma_g) == 0) {
+        const int h = li / pma_g;
+        const float lv = pma_l[row * pma_heads + h];
+        // empty target: never gathered; exp(a - FLT_MAX) = 0 (same convention as pma_bwd_stats_kernel, csrc/pma.hip)
+        const float M = lv > 0.f ? pma_m[row * pma_heads + h] + __logf(lv + 1e-16f) : 3.402823466e+38f;
+        *reinterpret_cast<float2*>(pma_stats + (row * pma_heads + h) * 2) = make_float2(M, dot);
+      }
     }
   }
   *reinterpret_cast<float4*>(&red[grp][0][c0]) = dg;
@@ -1722,10 +1739,47 @@ extern "C" int allset_ln_res_bwd_partials(int64_t n, int64_t d, int64_t* n_parti
   return ALLSET_OK;
 }
 
+static int ln_res_bwd_impl(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb,
+                           const float* res, int64_t ldr, const float* stats, const float* gamma, const float* beta,
+                           int relu_out, float p, uint64_t seed, float* gs, int64_t ldgs, float* partials,
+                           int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, const float* pma_m,
+                           const float* pma_l, float* pma_stats, int64_t pma_heads, void* stream);
+
 extern "C" int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb,
                                  const float* res, int64_t ldr, const float* stats, const float* gamma, const float* beta,
                                  int relu_out, float p, uint64_t seed, float* gs, int64_t ldgs, float* partials,
                                  int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, void* stream) {
+  return ln_res_bwd_impl(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n_partials, n, d,
+                         seed_base, nullptr, nullptr, nullptr, 1, stream);
+}
+
+extern "C" int allset_ln_res_bwd_pma_supported(int64_t d, int64_t heads) {
+  if (!allset_ln_res_supported(d) || heads < 1 || d % heads != 0 || (d / heads) % 4 != 0) return 0;
+  const int64_t g = (d / heads) / 4;
+  return (g & (g - 1)) == 0 ? 1 : 0;
+}
+
+extern "C" int allset_ln_res_bwd_pma(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb,
+                                     const float* stats, const float* gamma, const float* beta, float* gs, int64_t ldgs,
+                                     float* partials, int64_t n_partials, int64_t n, int64_t d, const float* pma_m,
+                                     const float* pma_l, float* pma_stats, int64_t heads, void* stream) {
+  clear_error();
+  if (!allset_ln_res_bwd_pma_supported(d, heads)) {
+    set_error("ln_res_bwd_pma: d=%lld heads=%lld not built (channels per head must be 4 x a power of two)",
+              static_cast<long long>(d), static_cast<long long>(heads));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(n == 0 || (pma_m && pma_l && pma_stats), "ln_res_bwd_pma: null statistics pointer");
+  ALLSET_REQUIRE(pma_stats == nullptr || (reinterpret_cast<uintptr_t>(pma_stats) & 7u) == 0, "ln_res_bwd_pma: stats must be 8-byte aligned");
+  return ln_res_bwd_impl(gy, ldg, x, ldx, colb, nullptr, 0, stats, gamma, beta, 0, 0.f, 0, gs, ldgs, partials, n_partials, n, d, nullptr,
+                         pma_m, pma_l, pma_stats, heads, stream);
+}
+
+static int ln_res_bwd_impl(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb,
+                           const float* res, int64_t ldr, const float* stats, const float* gamma, const float* beta,
+                           int relu_out, float p, uint64_t seed, float* gs, int64_t ldgs, float* partials,
+                           int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, const float* pma_m,
+                           const float* pma_l, float* pma_stats, int64_t pma_heads, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_bwd: bad size");
   ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_bwd: dropout p must be in [0,1)");
@@ -1743,7 +1797,7 @@ extern "C" int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, i
                  (res == nullptr || (ldr % 4 == 0 && aligned16(res))), "ln_res_bwd: rows and parameter vectors must be 16-byte aligned");
   const int di = static_cast<int>(d);
   const unsigned grid = static_cast<unsigned>(n_partials);
-#define ALLSET_LNRES_BWD(L) ln_res_bwd_kernel<L><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n, di, seed_base)
+#define ALLSET_LNRES_BWD(L) ln_res_bwd_kernel<L><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n, di, seed_base, pma_m, pma_l, pma_stats, static_cast<int>(pma_heads))
   switch (ln_lpr(d)) {
     case 8: ALLSET_LNRES_BWD(8); break;
     case 16: ALLSET_LNRES_BWD(16); break;

@@ -697,6 +697,34 @@ def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tens
     return gs, red[0], red[1], red[2]
 
 
+def ln_res_bwd_pma_supported(d: int, heads: int) -> bool:
+    return bool(_lib.load().allset_ln_res_bwd_pma_supported(d, heads))
+
+
+def ln_res_bwd_pma(gy: Tensor, x: Tensor, colb: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, m: Tensor, l: Tensor
+                   ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """Backward of ``LayerNorm(x + colb)`` where ``x`` is PMA's pooled output, with the attention-backward statistics written by
+    the same pass: returns (gs, dgamma, dbeta, dcolb, pma_stats [n, H, 2]) -- include/allset_hip.h allset_ln_res_bwd_pma."""
+    dev = require_device(gy, x, colb, stats, gamma, beta, m, l)
+    _check_f32(gy, x, colb, stats, gamma, beta, m, l)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    n, d = x.shape
+    H = m.shape[1]
+    lib = _lib.load()
+    npart = c_int64(0)
+    check(lib.allset_ln_res_bwd_partials(n, d, byref(npart)), "allset_ln_res_bwd_partials")
+    partials = torch.empty((npart.value, 3, d), dtype=torch.float32, device=dev)
+    gs = torch.empty((n, d), dtype=torch.float32, device=dev)
+    pstats = torch.empty((n, H, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, 3 * n * d * 4 + n * H * 16):
+        check(lib.allset_ln_res_bwd_pma(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous()), ptr(stats), ptr(gamma.contiguous()),
+                                        ptr(beta.contiguous()), ptr(gs), max(d, 1), ptr(partials), npart.value, n, d,
+                                        ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, stream_of(dev)),
+              "allset_ln_res_bwd_pma")
+    red = reduce_partials(partials)
+    return gs, red[0], red[1], red[2], pstats
+
+
 class _LayerNormRes(torch.autograd.Function):
     """``y = dropout_p(relu_out(LayerNorm(x + colb + res)))`` in one pass each way (csrc/dense.hip ``ln_res_*``)."""
 

@@ -409,19 +409,24 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     # dense on owned vertices, then two all-gathers (no concatenate / split copies of the [n_V, d] table)
     V, alpha = p.project(x_owned)
     V, alpha = all_gather_rows(V, group), all_gather_rows(alpha, group)
-    o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
-    e = p.tail(o, _post=dropout if training else 0.0)            # relu -> dropout inside ln1's pass
+    if K is HipPmaKernels:      # targets complete on their owner: the module's own joint pooling + ln0 node applies
+        e = p.pool_tail(V.contiguous(), alpha.contiguous(), hg.v2e, dropout if training else 0.0)[0]
+    else:
+        o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
+        e = p.tail(o, _post=dropout if training else 0.0)            # relu -> dropout inside ln1's pass
     # ---- E -> V
     p = e2v_conv.prop
     H, C = p.heads, p.hidden
     V, alpha = p.project(e)                                                         # dense on owned hyperedges
+    p_out = dropout if dropout_out is None else dropout_out
+    if _skip_collective(group) and K is HipPmaKernels and hg.v_lo == 0 and hg.v_hi == hg.e2v.n_dst:
+        return p.pool_tail(V.contiguous(), alpha.contiguous(), hg.e2v, p_out if training else 0.0)[0]
     if _skip_collective(group):      # one rank owns every vertex: the local fused pooling IS the answer, no (m,l,o) merge
         o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.e2v, H, p.negative_slope)
         if hg.v_lo != 0 or hg.v_hi != o.shape[0]:          # (a no-op slice would still cost a zero-fill + copy backward)
             o = o[hg.v_lo:hg.v_hi]
     else:
         o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
-    p_out = dropout if dropout_out is None else dropout_out
     return p.tail(o, _post=p_out if training else 0.0)
 
 

@@ -235,14 +235,15 @@ class PMA(nn.Module):
                else _linear(self.lin_V, x))
         return x_V, self._logits(x)
 
-    def tail(self, pooled: Tensor, _post: Optional[float] = None) -> Tensor:
+    def tail(self, pooled: Tensor, _post: Optional[float] = None, _ln0_done: bool = False) -> Tensor:
         """``+att_r -> ln0 -> ln1(z + relu(rFF(z)))`` (reference layers.py:153-157) on pooled [n_t, H*C].
-        ``_post`` (internal): also the ``relu -> dropout(p)`` SetGNN wraps around the conv, in ln1's pass."""
+        ``_post`` (internal): also the ``relu -> dropout(p)`` SetGNN wraps around the conv, in ln1's pass.
+        ``_ln0_done`` (internal): ``pooled`` already is ``ln0(pooled + att_r)`` (the joint pooling + ln0 node of ``forward``)."""
         H, C = self.heads, self.hidden
         hip = _on_hip(pooled) or (pooled.is_cuda and pooled.dtype == torch.bfloat16 and self.ln0.weight.dtype == torch.bfloat16)
         if hip and dense.ln_res_supported(H * C, pooled.dtype) and self.ln0.bias is not None and self.ln1.bias is not None:
             # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
-            out = dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
+            out = pooled if _ln0_done else dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
             ff = self.rFF
             if (dense.x6_active() and len(ff.lins) == 2 and ff._fusable(out) and ff._resident()
                     and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
@@ -258,13 +259,24 @@ class PMA(nn.Module):
         out = _layer_norm(self.ln1, out + self.rFF(out, _post=0.0))
         return out if _post is None else relu_dropout(out, _post, True)
 
+    def pool_tail(self, x_V: Tensor, alpha_r: Tensor, inc: Incidence, _post: Optional[float] = None):
+        """``tail(pool(x_V, alpha_r))`` plus the softmax statistics: ``(out [n_t, H*C], m, l)`` (reference layers.py:145-157)."""
+        H = self.heads
+        if (_on_hip(x_V) and self.ln0.bias is not None and self.ln1.bias is not None and self.ln0.elementwise_affine
+                and AF.pma_pool_ln0_supported(x_V, H)):
+            # pooling + seed add + ln0 as one autograd node: the pooling's backward statistics come out of ln0's backward pass
+            out, m, l = AF.pma_pool_ln0(x_V, alpha_r, inc, H, self.negative_slope, self.att_r, self.ln0.weight, self.ln0.bias,
+                                        self.ln0.eps)
+            return self.tail(out, _post, _ln0_done=True), m, l
+        out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
+        return self.tail(out, _post), m, l
+
     def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None, _post: Optional[float] = None):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         H = self.heads
         inc = _as_incidence(edge_index, x.shape[0])
         x_V, alpha_r = self.project(x)                        # [n_s, H*C], [n_s, H]
-        out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
-        out = self.tail(out, _post)
+        out, m, l = self.pool_tail(x_V, alpha_r, inc, _post)
         if isinstance(return_attention_weights, bool):
             alpha = AF.pma_attention_weights(alpha_r, m, l, inc, self.negative_slope)
             return out, (edge_index, alpha)

@@ -346,6 +346,16 @@ int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx,
                       int64_t ldr, const float* stats, const float* gamma, const float* beta, int relu_out, float p,
                       uint64_t seed, float* gs, int64_t ldgs, float* partials, int64_t n_partials, int64_t n, int64_t d,
                       const uint64_t* seed_base, void* stream);
+/* The PMA tail's first LayerNorm, backward, with the statistics pass folded in: y = LayerNorm(x + colb) where x is the pooled
+ * output of allset_pma_fwd (reference layers.py:153-154).  Same results as allset_ln_res_bwd(res = NULL, relu_out = 0, p = 0)
+ * plus pma_stats f32[n*heads*2] = {m + log(l + 1e-16), <x[t,h,:], gs[t,h,:]>} -- exactly what allset_pma_bwd_stats(x, gs, m, l)
+ * would write, from the registers that hold x and gs (one pass over both saved).  allset_ln_res_bwd_pma_supported(d, heads):
+ * d / heads must be 4 x a power of two. */
+int allset_ln_res_bwd_pma_supported(int64_t d, int64_t heads);
+int allset_ln_res_bwd_pma(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb, const float* stats,
+                          const float* gamma, const float* beta, float* gs, int64_t ldgs, float* partials, int64_t n_partials,
+                          int64_t n, int64_t d, const float* pma_m, const float* pma_l, float* pma_stats, int64_t heads,
+                          void* stream);
 
 /* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
  *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],

@@ -472,3 +472,41 @@ def test_sharded_pma_merge_path_bf16(device, monkeypatch):
     (o0, g0), (o1, g1) = res
     assert float((o1 - o0).abs().mean()) < 0.03 * float(o0.abs().mean()) + 1e-3
     assert float((g1 - g0).abs().mean()) < 0.05 * float(g0.abs().mean()) + 1e-3
+
+
+@pytest.mark.parametrize("heads,hidden", [(4, 128), (1, 64), (8, 256)])
+def test_pma_pooling_and_ln0_as_one_node_equals_the_separate_nodes(heads, hidden, device, monkeypatch):
+    """The joint pooling + ln0 node (backward statistics written by ln0's backward kernel, allset_ln_res_bwd_pma) against
+    the two separate nodes (allset_pma_bwd_stats): same outputs, same gradients, targets without incidences included."""
+    from allset_amd import PMA, Incidence, ops
+    from allset_amd import functional as AF
+    torch.manual_seed(7 + heads)
+    n_s, n_t, nnz = 900, 400, 6000
+    ei = torch.stack([torch.randint(0, n_s, (nnz,)), torch.randint(0, n_t - 20, (nnz,))]).to(device)   # last 20 targets are empty
+    inc = Incidence.from_edge_index(ei, n_src=n_s, n_dst=n_t)
+    pma = PMA(hidden, hidden, hidden, 2, heads=heads).to(device)
+    x = torch.randn(n_s, hidden, device=device)
+    G = torch.randn(n_t, hidden, device=device)
+
+    def run():
+        for p in pma.parameters():
+            p.grad = None
+        xd = x.clone().requires_grad_(True)
+        out = pma(xd, inc)
+        (out * G).sum().backward()
+        return out.detach(), xd.grad, {k: p.grad.clone() for k, p in pma.named_parameters() if p.grad is not None}
+
+    calls = []
+    real = ops.pma_bwd_stats
+    monkeypatch.setattr(ops, "pma_bwd_stats", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    assert AF.pma_pool_ln0_supported(x, heads)
+    o1, g1, p1 = run()
+    assert not calls, "the joint node must not launch the separate statistics pass"
+    monkeypatch.setattr(AF, "pma_pool_ln0_supported", lambda *a, **k: False)
+    o0, g0, p0 = run()
+    assert calls
+    torch.testing.assert_close(o1, o0, rtol=0, atol=0)
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-5 * max(1.0, float(g0.abs().max())))
+    assert p0.keys() == p1.keys()
+    for k in p0:
+        torch.testing.assert_close(p1[k], p0[k], rtol=1e-5, atol=1e-5 * max(1.0, float(p0[k].abs().max())), msg=lambda m: f"{k}: {m}")
