@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 F32, BF16 = 0, 1
@@ -94,6 +94,10 @@ SIGNATURES = {
     "allset_ln_res_fwd": [_P, c_int64, _P, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, c_int64, _P, c_int64,
                           c_int64, _P, _P],
     "allset_ln_res_bwd_partials": [c_int64, c_int64, POINTER(c_int64)],
+    "allset_linear_bf16_supported": [c_int64, c_int64],
+    "allset_linear_bf16_fwd": [_P, c_int64, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_linear_bf16_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64,
+                               c_int64, _P],
     "allset_ln_res_bwd_pma_supported": [c_int64, c_int64],
     "allset_ln_res_bwd_pma": [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P,
                               c_int64, _P],

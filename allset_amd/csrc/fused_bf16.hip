@@ -1,0 +1,375 @@
+// The Linear of the bf16 regime (BASELINE configs[4]: bf16 activations and parameters, fp32 accumulation) with what
+// surrounds it in MLP.forward / PMA.forward (reference layers.py:571-579, 120-157) folded into ONE pass per direction:
+//
+//   forward        y = act(x W^T + b)                       act = relu or identity;            x, W, b, y: bf16
+//                  aux[n, 4] = x aux_w^T + aux_b            PMA's folded attention logits (fp32 out), optional
+//   backward-data  gx = (gy (.) [ymask > 0]) W  [+ acc_in]  [+ galpha aux_w]                    all bf16 except galpha (fp32)
+//                  ga_out = gy (.) [ymask > 0]              the masked gradient, kept for the weight-gradient kernel
+//
+// The library GEMM these replace already runs near the traffic floor (62 us for [250k, 256] x [256, 256]); what a fused
+// kernel removes is the element-wise traffic AROUND it -- relu forward, relu backward, the gradient-branch sums, the skinny
+// logits GEMM -- and their launches (the configs[4] per-GPU step is launch-bound).
+//
+// Organisation (both directions are the same kernel; backward-data stages W transposed):
+//   * the whole weight is resident in LDS as ONE bf16 image (128 KB at 256 x 256), laid out [k-quarter][column][K/8 dwords]
+//     with the 16-byte pieces XOR-swizzled by the column: a B fragment of v_mfma_f32_16x16x32_bf16 is one conflict-free
+//     ds_read_b128.  The k-order of an MFMA is free as long as both operands agree, so lane (i, g) of a wave owns the
+//     CONTIGUOUS quarter g of activation row i (128 B at K = 256: whole cache lines per lane) and k-step t multiplies its
+//     local columns 8t .. 8t+7 -- activation fragments are the registers exactly as loaded, no conversion, no LDS;
+//   * 8 waves per workgroup (two per SIMD), one persistent workgroup per CU, 16 rows per wave and step, the rows of the
+//     next two steps always in flight in registers;
+//   * operands are SWAPPED in the MFMA (A = weight fragment, B = activation fragment), so a lane's four accumulators of
+//     a tile are four CONSECUTIVE output columns of one row: bias / relu / the gradient-branch sum / the rank-4 logits
+//     term are applied there in fp32, the four values are packed to bf16 once, leave through a 16 x 64 per-wave LDS slab
+//     as one 8-byte write and reach memory as whole 128-byte row segments.
+#include "common.h"
+
+#include <stdint.h>
+
+namespace allset {
+
+using bf16x8_b = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using f32x4_b = __attribute__((ext_vector_type(4))) float;
+union FragB { uint4 u; bf16x8_b v; };
+
+constexpr int kBfBlock = 512;
+constexpr int kBfWaves = kBfBlock / kWave;
+constexpr int kSlabPitch = 36;                 // dwords per slab row: 32 of data (64 bf16) + 4 of padding (bank spread)
+
+// dword offset of 16-byte piece t of (k-quarter g, column j) inside the weight image
+template <int KQD, int GS>
+__device__ __forceinline__ int wimg_off(int g, int j, int t) {
+  constexpr int PIECES = KQD / 4, ROWS64 = (64 / KQD) > 0 ? (64 / KQD) : 1;
+  return g * GS + j * KQD + 4 * (t ^ ((j / ROWS64) % PIECES));
+}
+
+__device__ __forceinline__ uint32_t keep_where_positive(uint32_t v, uint32_t y) {
+  // per 16-bit half: keep v where the bf16 in y is > 0 (relu output: +0 or positive, so "magnitude bits set" is the test
+  // torch's threshold_backward applies to the saved bf16 activation)
+  const uint32_t lo = (y & 0x7fffu) != 0u && (y & 0x8000u) == 0u ? 0x0000ffffu : 0u;
+  const uint32_t hi = (y & 0x7fff0000u) != 0u && (y & 0x80000000u) == 0u ? 0xffff0000u : 0u;
+  return v & (lo | hi);
+}
+
+// KD: reduction width (columns of the activation rows), ND: output width.
+// TRANS_W: W is [KD, ND] row-major (backward-data: the layer's [out, in] weight, reduced over its rows);
+//          otherwise [ND, KD] (forward).
+template <int KD, int ND, bool TRANS_W, bool HAS_MASK, bool AUX_OUT>
+__global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
+    const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ ymask, int64_t ldm,
+    uint16_t* __restrict__ a_out, int64_t lda, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
+    int relu_out, const uint16_t* __restrict__ aux_w, const uint16_t* __restrict__ aux_b, float* __restrict__ aux_out,
+    const float* __restrict__ aux_in, const uint16_t* __restrict__ acc_in, int64_t ldacc, uint16_t* __restrict__ y,
+    int64_t ldy, int64_t n) {
+  constexpr int KQ = KD / 4;                       // bf16 columns per lane
+  constexpr int KQD = KQ / 2;                      // dwords per lane
+  constexpr int T = KQ / 8;                        // MFMA k-steps
+  constexpr int GS = ND * KQD;
+  constexpr int NTILE = ND / 16;
+  constexpr int AUXW = AUX_OUT ? KD : ND;          // width of the 4 auxiliary weight rows this instantiation keeps
+  __shared__ __attribute__((aligned(16))) uint32_t sW[4 * GS];
+  __shared__ __attribute__((aligned(16))) float sBias[ND];
+  __shared__ __attribute__((aligned(16))) float sAux[4 * AUXW + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t sSlab[kBfWaves * 16 * kSlabPitch];
+  const int tid = threadIdx.x;
+  const bool has_aux_in = !AUX_OUT && aux_in != nullptr;
+
+  if constexpr (!TRANS_W) {
+    // W[j][k]: 16-byte pieces copy straight into the image
+    for (int idx = tid; idx < ND * KD / 8; idx += kBfBlock) {
+      const int j = idx / (KD / 8), k0 = 8 * (idx % (KD / 8));
+      const uint4 w = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(j) * KD + k0);
+      *reinterpret_cast<uint4*>(&sW[wimg_off<KQD, GS>(k0 / KQ, j, (k0 % KQ) / 8)]) = w;
+    }
+  } else {
+    // W[o][i], reduction over o: the image row of column i holds o-pairs as dwords.  A thread takes 8 columns of two
+    // adjacent rows; lanes run along o, so the 64 dwords one instruction writes are 32 consecutive dwords of one image
+    // row per k-quarter (two-way bank conflict at worst).
+    for (int idx = tid; idx < (KD / 2) * (ND / 8); idx += kBfBlock) {
+      const int op = idx % (KD / 2), i0 = 8 * (idx / (KD / 2));
+      const int o = 2 * op;
+      const uint4 r0 = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o) * ND + i0);
+      const uint4 r1 = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o + 1) * ND + i0);
+      const uint32_t a0[4] = {r0.x, r0.y, r0.z, r0.w}, a1[4] = {r1.x, r1.y, r1.z, r1.w};
+      const int g = o / KQ, e = o % KQ;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int base0 = wimg_off<KQD, GS>(g, i0 + 2 * q, e / 8) + (e % 8) / 2;
+        const int base1 = wimg_off<KQD, GS>(g, i0 + 2 * q + 1, e / 8) + (e % 8) / 2;
+        sW[base0] = (a0[q] & 0xffffu) | (a1[q] << 16);
+        sW[base1] = (a0[q] >> 16) | (a1[q] & 0xffff0000u);
+      }
+    }
+  }
+  for (int idx = tid; idx < ND; idx += kBfBlock) sBias[idx] = bias ? bf16_to_f32(bias[idx]) : 0.f;
+  if (AUX_OUT || has_aux_in) {
+    for (int idx = tid; idx < 4 * AUXW; idx += kBfBlock) sAux[idx] = bf16_to_f32(aux_w[idx]);
+    if (tid < 4) sAux[4 * AUXW + tid] = (AUX_OUT && aux_b) ? bf16_to_f32(aux_b[tid]) : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: chunk indices and row bases stay scalar
+  const int ri = lane & 15, g = lane >> 4;
+  const int64_t n_chunks = (n + 15) / 16;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBfWaves;
+  uint32_t* slab = sSlab + wave * (16 * kSlabPitch);
+
+  // Addresses are a scalar row base per step (64-bit, in SGPRs) plus a 32-bit lane offset: 64-bit per-lane pointers for the
+  // six row-major operands cost ~20 VGPRs, which this kernel does not have.  Loads are unconditional on a clamped row
+  // (a branch around a load costs s_waitcnt vmcnt(0) at the join, which drains the prefetch); rows past n are zeroed when
+  // consumed.  `chunk` may run past the end (prefetch): clamped to the last step.
+  auto rows_here = [&](int64_t chunk) -> int {                 // rows of this step that exist (1..16); chunk < n_chunks
+    const int64_t left = n - chunk * 16;
+    return left < 16 ? static_cast<int>(left) : 16;
+  };
+  auto request = [&](uint32_t (&a)[KQD], const uint16_t* __restrict__ src, int64_t ld, int64_t chunk) {
+    const int64_t c = chunk < n_chunks ? chunk : n_chunks - 1;
+    const int rh = rows_here(c);
+    const uint32_t rr = ri < rh ? ri : rh - 1;
+    const uint16_t* base = src + c * 16 * ld;
+    const uint4* p = reinterpret_cast<const uint4*>(base + (rr * static_cast<uint32_t>(ld) + g * KQ));
+#pragma unroll
+    for (int q = 0; q < KQD / 4; ++q) {
+      const uint4 v = p[q];
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+  };
+
+  auto process = [&](uint32_t (&a)[KQD], uint32_t (&m)[HAS_MASK ? KQD : 1], int64_t chunk) {
+    const int rh = rows_here(chunk);
+    const bool valid = ri < rh;
+    const uint32_t rr = valid ? ri : rh - 1;                      // a row of this step that exists
+    if constexpr (HAS_MASK) {
+#pragma unroll
+      for (int j = 0; j < KQD; ++j) a[j] = keep_where_positive(a[j], m[j]);
+      if (a_out != nullptr && valid) {
+        uint4* p = reinterpret_cast<uint4*>(a_out + chunk * 16 * lda + (ri * static_cast<uint32_t>(lda) + g * KQ));
+#pragma unroll
+        for (int q = 0; q < KQD / 4; ++q) p[q] = make_uint4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+      }
+      // ONE mask buffer: the next step's rows are requested as soon as this step's are consumed and have the whole matrix
+      // phase and epilogue to arrive (the activation rows themselves are two steps ahead in two buffers)
+#ifndef ALLSET_BF16_LATE_MASK
+      __builtin_amdgcn_sched_barrier(0);
+      request(m, ymask, ldm, chunk + stride);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < KQD; ++j) a[j] = 0u;
+    }
+    if constexpr (AUX_OUT) {
+      if (aux_out != nullptr) {
+        // four extra output columns in plain fp32 FMAs from the rows already in registers ([n, K] x [K, 4] is all bandwidth)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < KQD; j += 2) {
+          const float v0 = __uint_as_float(a[j] << 16), v1 = __uint_as_float(a[j] & 0xffff0000u);
+          const float v2 = __uint_as_float(a[j + 1] << 16), v3 = __uint_as_float(a[j + 1] & 0xffff0000u);
+          const float4 w0 = *reinterpret_cast<const float4*>(&sAux[0 * KD + g * KQ + 2 * j]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&sAux[1 * KD + g * KQ + 2 * j]);
+          const float4 w2 = *reinterpret_cast<const float4*>(&sAux[2 * KD + g * KQ + 2 * j]);
+          const float4 w3 = *reinterpret_cast<const float4*>(&sAux[3 * KD + g * KQ + 2 * j]);
+          s0 = fmaf(v0, w0.x, fmaf(v1, w0.y, fmaf(v2, w0.z, fmaf(v3, w0.w, s0))));
+          s1 = fmaf(v0, w1.x, fmaf(v1, w1.y, fmaf(v2, w1.z, fmaf(v3, w1.w, s1))));
+          s2 = fmaf(v0, w2.x, fmaf(v1, w2.y, fmaf(v2, w2.z, fmaf(v3, w2.w, s2))));
+          s3 = fmaf(v0, w3.x, fmaf(v1, w3.y, fmaf(v2, w3.z, fmaf(v3, w3.w, s3))));
+        }
+        s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16); s3 += __shfl_xor(s3, 16);
+        s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+        if (valid && g == 0)
+          *reinterpret_cast<float4*>(aux_out + chunk * 64 + ri * 4) =
+              make_float4(s0 + sAux[4 * KD], s1 + sAux[4 * KD + 1], s2 + sAux[4 * KD + 2], s3 + sAux[4 * KD + 3]);
+      }
+    }
+    // the gradient-branch rows and the logits' gradient of this step, requested before the matrix phase
+    uint2 accv[NTILE];
+    if (acc_in != nullptr) {
+      const uint16_t* ap = acc_in + chunk * 16 * ldacc + (rr * static_cast<uint32_t>(ldacc) + 4 * g);
+#pragma unroll
+      for (int tl = 0; tl < NTILE; ++tl) accv[tl] = *reinterpret_cast<const uint2*>(ap + tl * 16);
+    }
+    float4 ga4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_aux_in) ga4 = *reinterpret_cast<const float4*>(aux_in + chunk * 64 + rr * 4);
+
+    f32x4_b acc[NTILE];
+#pragma unroll
+    for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4_b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      FragB fa;
+      fa.u = make_uint4(a[4 * t], a[4 * t + 1], a[4 * t + 2], a[4 * t + 3]);
+#pragma unroll
+      for (int tl = 0; tl < NTILE; tl += 2) {       // two column tiles: two independent accumulator chains
+        FragB b0, b1;
+        b0.u = *reinterpret_cast<const uint4*>(&sW[wimg_off<KQD, GS>(g, tl * 16 + ri, t)]);
+        b1.u = *reinterpret_cast<const uint4*>(&sW[wimg_off<KQD, GS>(g, tl * 16 + 16 + ri, t)]);
+        // swapped operands: D[i][j] = sum_k Wimg[col 16 tl + i][k] * x[row j][k]; lane holds row (lane & 15), columns 4 g .. +3
+        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0.v, fa.v, acc[tl], 0, 0, 0);
+        acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1.v, fa.v, acc[tl + 1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request(a, x, ldx, chunk + 2 * stride);
+#ifdef ALLSET_BF16_LATE_MASK
+    if constexpr (HAS_MASK) request(m, ymask, ldm, chunk + stride);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: 64 columns (4 tiles) per trip through the slab
+    const int srow = lane >> 2, sq = lane & 3;
+#pragma unroll
+    for (int hb = 0; hb < ND / 64; ++hb) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int tl = hb * 4 + tt;
+        const int c = tl * 16 + 4 * g;
+        const float4 bv = *reinterpret_cast<const float4*>(&sBias[c]);
+        float v0 = acc[tl][0] + bv.x, v1 = acc[tl][1] + bv.y, v2 = acc[tl][2] + bv.z, v3 = acc[tl][3] + bv.w;
+        if (has_aux_in) {
+          const float4 w0 = *reinterpret_cast<const float4*>(&sAux[0 * AUXW + c]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&sAux[1 * AUXW + c]);
+          const float4 w2 = *reinterpret_cast<const float4*>(&sAux[2 * AUXW + c]);
+          const float4 w3 = *reinterpret_cast<const float4*>(&sAux[3 * AUXW + c]);
+          v0 = fmaf(ga4.x, w0.x, fmaf(ga4.y, w1.x, fmaf(ga4.z, w2.x, fmaf(ga4.w, w3.x, v0))));
+          v1 = fmaf(ga4.x, w0.y, fmaf(ga4.y, w1.y, fmaf(ga4.z, w2.y, fmaf(ga4.w, w3.y, v1))));
+          v2 = fmaf(ga4.x, w0.z, fmaf(ga4.y, w1.z, fmaf(ga4.z, w2.z, fmaf(ga4.w, w3.z, v2))));
+          v3 = fmaf(ga4.x, w0.w, fmaf(ga4.y, w1.w, fmaf(ga4.z, w2.w, fmaf(ga4.w, w3.w, v3))));
+        }
+        if (acc_in != nullptr) {
+          v0 += __uint_as_float(accv[tl].x << 16); v1 += __uint_as_float(accv[tl].x & 0xffff0000u);
+          v2 += __uint_as_float(accv[tl].y << 16); v3 += __uint_as_float(accv[tl].y & 0xffff0000u);
+        }
+        if (relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        *reinterpret_cast<uint2*>(&slab[ri * kSlabPitch + tt * 8 + 2 * g]) = make_uint2(cvt_pk_bf16(v0, v1), cvt_pk_bf16(v2, v3));
+      }
+      // one wave, in-order LDS queue: no barrier needed, but the compiler must not move the reads above the writes nor the
+      // next trip's writes above these reads
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint4 o0 = *reinterpret_cast<const uint4*>(&slab[srow * kSlabPitch + sq * 8]);
+      const uint4 o1 = *reinterpret_cast<const uint4*>(&slab[srow * kSlabPitch + sq * 8 + 4]);
+      if (srow < rh) {
+        uint4* dst = reinterpret_cast<uint4*>(y + chunk * 16 * ldy + (srow * static_cast<uint32_t>(ldy) + sq * 16 + hb * 64));
+        dst[0] = o0;
+        dst[1] = o1;
+      }
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  uint32_t a0[KQD], a1[KQD];
+  uint32_t m0[HAS_MASK ? KQD : 1];
+  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kBfWaves + wave;
+  request(a0, x, ldx, chunk);
+  request(a1, x, ldx, chunk + stride);
+  if constexpr (HAS_MASK) request(m0, ymask, ldm, chunk);
+  for (; chunk < n_chunks; chunk += 2 * stride) {
+    process(a0, m0, chunk);
+    if (chunk + stride < n_chunks) process(a1, m0, chunk + stride);
+  }
+}
+
+static inline bool bf16_width(int64_t w) { return w == 128 || w == 256; }
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_linear_bf16_supported(int64_t in_features, int64_t out_features) {
+  return (bf16_width(in_features) && bf16_width(out_features)) ? 1 : 0;
+}
+
+template <int KD, int ND, bool TRANS_W>
+static void launch_bf16(bool has_mask, bool aux_out, unsigned grid, hipStream_t st, const uint16_t* x, int64_t ldx,
+                        const uint16_t* ymask, int64_t ldm, uint16_t* a_out, int64_t lda, const uint16_t* W,
+                        const uint16_t* bias, int relu_out, const uint16_t* aux_w, const uint16_t* aux_b, float* aux_o,
+                        const float* aux_in, const uint16_t* acc_in, int64_t ldacc, uint16_t* y, int64_t ldy, int64_t n) {
+#define ALLSET_BF16_GO(MASK, AUXO)                                                                                       \
+  linear_bf16_kernel<KD, ND, TRANS_W, MASK, AUXO><<<grid, kBfBlock, 0, st>>>(x, ldx, ymask, ldm, a_out, lda, W, bias,   \
+                                                                              relu_out, aux_w, aux_b, aux_o, aux_in,    \
+                                                                              acc_in, ldacc, y, ldy, n)
+  if constexpr (!TRANS_W) {
+    if (aux_out) ALLSET_BF16_GO(false, true);
+    else ALLSET_BF16_GO(false, false);
+  } else {
+    if (has_mask) ALLSET_BF16_GO(true, false);
+    else ALLSET_BF16_GO(false, false);
+  }
+#undef ALLSET_BF16_GO
+}
+
+static inline unsigned bf16_grid(int64_t n) {
+  int64_t blocks = ((n + 15) / 16 + kBfWaves - 1) / kBfWaves;
+  if (blocks > 256) blocks = 256;                    // one persistent 8-wave workgroup per CU
+  return static_cast<unsigned>(blocks < 1 ? 1 : blocks);
+}
+
+static inline bool rows_ok(const void* p, int64_t ld, int64_t w) {     // 32-bit lane offsets: 16 rows x ld must stay below 2^31
+  return p && aligned16(p) && ld >= w && ld % 8 == 0 && ld < (int64_t{1} << 26);
+}
+
+extern "C" int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void* bias, int relu_out,
+                                      const void* aux_w, const void* aux_b, float* aux_out, void* y, int64_t ldy,
+                                      int64_t n, int64_t K, int64_t N, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "linear_bf16_fwd: negative size");
+  if (!allset_linear_bf16_supported(K, N)) {
+    set_error("linear_bf16_fwd: K=%lld N=%lld not built (K, N in {128,256})", static_cast<long long>(K), static_cast<long long>(N));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rows_ok(x, ldx, K) && rows_ok(y, ldy, N), "linear_bf16_fwd: x and y must be 16-byte aligned rows (ld a multiple of 8)");
+  ALLSET_REQUIRE(W && aligned16(W), "linear_bf16_fwd: W must be 16-byte aligned");
+  ALLSET_REQUIRE(aux_out == nullptr || (aux_w != nullptr && aligned16(aux_out)), "linear_bf16_fwd: aux_out needs aux_w and 16-byte alignment");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = bf16_grid(n);
+  const uint16_t *xp = static_cast<const uint16_t*>(x), *Wp = static_cast<const uint16_t*>(W), *bp = static_cast<const uint16_t*>(bias);
+  const uint16_t *awp = static_cast<const uint16_t*>(aux_w), *abp = static_cast<const uint16_t*>(aux_b);
+  uint16_t* yp = static_cast<uint16_t*>(y);
+#define ALLSET_BF16_FWD(KD, ND) \
+  launch_bf16<KD, ND, false>(false, aux_out != nullptr, grid, st, xp, ldx, nullptr, 0, nullptr, 0, Wp, bp, relu_out, awp, abp, aux_out, nullptr, nullptr, 0, yp, ldy, n)
+  if (K == 256 && N == 256) ALLSET_BF16_FWD(256, 256);
+  else if (K == 256 && N == 128) ALLSET_BF16_FWD(256, 128);
+  else if (K == 128 && N == 256) ALLSET_BF16_FWD(128, 256);
+  else ALLSET_BF16_FWD(128, 128);
+#undef ALLSET_BF16_FWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out,
+                                      int64_t lda, const void* W, const float* galpha, const void* aux_w,
+                                      const void* acc_in, int64_t ldacc, void* gx, int64_t ldgx, int64_t n, int64_t O,
+                                      int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "linear_bf16_bwd: negative size");
+  if (!allset_linear_bf16_supported(I, O)) {
+    set_error("linear_bf16_bwd: O=%lld I=%lld not built (O, I in {128,256})", static_cast<long long>(O), static_cast<long long>(I));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rows_ok(gy, ldg, O) && rows_ok(gx, ldgx, I), "linear_bf16_bwd: gy and gx must be 16-byte aligned rows (ld a multiple of 8)");
+  ALLSET_REQUIRE(W && aligned16(W), "linear_bf16_bwd: W must be 16-byte aligned");
+  ALLSET_REQUIRE(ymask == nullptr || rows_ok(ymask, ldm, O), "linear_bf16_bwd: ymask must be 16-byte aligned rows");
+  ALLSET_REQUIRE(ga_out == nullptr || (ymask != nullptr && rows_ok(ga_out, lda, O)), "linear_bf16_bwd: ga_out needs ymask and 16-byte aligned rows");
+  ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && ldacc < (int64_t{1} << 26) && (reinterpret_cast<uintptr_t>(acc_in) & 7u) == 0),
+                 "linear_bf16_bwd: acc_in must be 8-byte aligned rows");
+  ALLSET_REQUIRE(galpha == nullptr || (aux_w != nullptr && aligned16(galpha)), "linear_bf16_bwd: galpha needs aux_w and 16-byte alignment");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = bf16_grid(n);
+  const uint16_t *gp = static_cast<const uint16_t*>(gy), *mp = static_cast<const uint16_t*>(ymask), *Wp = static_cast<const uint16_t*>(W);
+  const uint16_t *awp = static_cast<const uint16_t*>(aux_w), *ap = static_cast<const uint16_t*>(acc_in);
+  uint16_t *gap = static_cast<uint16_t*>(ga_out), *gxp = static_cast<uint16_t*>(gx);
+#define ALLSET_BF16_BWD(KD, ND) \
+  launch_bf16<KD, ND, true>(mp != nullptr, false, grid, st, gp, ldg, mp, ldm, gap, lda, Wp, nullptr, 0, awp, nullptr, nullptr, galpha, ap, ldacc, gxp, ldgx, n)
+  if (O == 256 && I == 256) ALLSET_BF16_BWD(256, 256);
+  else if (O == 256 && I == 128) ALLSET_BF16_BWD(256, 128);
+  else if (O == 128 && I == 256) ALLSET_BF16_BWD(128, 256);
+  else ALLSET_BF16_BWD(128, 128);
+#undef ALLSET_BF16_BWD
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

@@ -845,6 +845,163 @@ def pma_residual_ff(out: Tensor, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5,
     return _PmaResidualFF.apply(out, w1, b1, w2, b2, gamma, beta, float(eps), bool(relu_post), float(p))
 
 
+# ---- the bf16 regime (BASELINE configs[4]): csrc/fused_bf16.hip ---------------------------------------------------------
+def linear_bf16_supported(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> bool:
+    """bf16 rows on the device, bf16 parameters, in / out features in {128, 256}."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and (bias is None or bias.dtype == torch.bfloat16)
+            and bool(_lib.load().allset_linear_bf16_supported(weight.shape[1], weight.shape[0])))
+
+
+def linear_bf16_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu_out: bool = False, aux_w: Optional[Tensor] = None,
+                    aux_b: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """``y = act(x W^T + b)`` (bf16) and, with ``aux_w`` [4, K], the fp32 logits ``x aux_w^T + aux_b`` [n, 4]."""
+    dev = require_device(x, weight)
+    _check_dtype(torch.bfloat16, x, weight)
+    x = _rowmajor(x)
+    n, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((n, N), dtype=torch.bfloat16, device=dev)
+    aux = torch.empty((n, 4), dtype=torch.float32, device=dev) if aux_w is not None else None
+    with torch.cuda.device(dev), _timed("linear_bf16_fwd", dev, n * (K + N) * 2 + (n * 16 if aux is not None else 0)):
+        check(_lib.load().allset_linear_bf16_fwd(ptr(x), _ld(x), ptr(weight.contiguous()), ptr(bias.contiguous() if bias is not None else None),
+                                                 int(relu_out), ptr(aux_w.contiguous() if aux_w is not None else None),
+                                                 ptr(aux_b.contiguous() if aux_b is not None else None), ptr(aux), ptr(y), N, n, K, N,
+                                                 stream_of(dev)), "allset_linear_bf16_fwd")
+    return y, aux
+
+
+def linear_bf16_bwd(gy: Tensor, weight: Tensor, ymask: Optional[Tensor] = None, want_ga: bool = False,
+                    acc_in: Optional[Tensor] = None, galpha: Optional[Tensor] = None, aux_w: Optional[Tensor] = None
+                    ) -> Tuple[Tensor, Tensor]:
+    """``gx = (gy where ymask > 0) W [+ acc_in] [+ galpha aux_w]`` (one rounding), and the masked gradient ``ga`` (``gy``
+    itself without a mask) for the weight-gradient kernel."""
+    dev = require_device(gy, weight)
+    _check_dtype(torch.bfloat16, gy, weight)
+    gy = _rowmajor(gy)
+    n, O = gy.shape
+    I = weight.shape[1]
+    gx = torch.empty((n, I), dtype=torch.bfloat16, device=dev)
+    ga = torch.empty((n, O), dtype=torch.bfloat16, device=dev) if (ymask is not None and want_ga) else None
+    if ymask is not None:
+        ymask = _rowmajor(ymask)
+    if acc_in is not None:
+        acc_in = _rowmajor(acc_in)
+    nbytes = n * (O + I) * 2 + (n * O * 2 if ymask is not None else 0) + (n * O * 2 if ga is not None else 0) \
+        + (n * I * 2 if acc_in is not None else 0)
+    with torch.cuda.device(dev), _timed("linear_bf16_bwd", dev, nbytes):
+        check(_lib.load().allset_linear_bf16_bwd(ptr(gy), _ld(gy), ptr(ymask), _ld(ymask) if ymask is not None else 0, ptr(ga), O,
+                                                 ptr(weight.contiguous()), ptr(galpha.contiguous() if galpha is not None else None),
+                                                 ptr(aux_w.contiguous() if aux_w is not None else None), ptr(acc_in),
+                                                 _ld(acc_in) if acc_in is not None else 0, ptr(gx), I, n, O, I, stream_of(dev)),
+              "allset_linear_bf16_bwd")
+    return gx, (ga if ga is not None else gy)
+
+
+class _LinearBf16(torch.autograd.Function):
+    """``y = act(x W^T + b)`` in the bf16 regime: one kernel forward (relu in its epilogue), one backward-data kernel (relu
+    mask from the saved output in its prologue) and the full-width bf16 weight-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu_out):
+        y, _ = linear_bf16_fwd(x, weight, bias, relu_out)
+        ctx.save_for_backward(x, weight, y if relu_out else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        gx = gw = gb = None
+        ga = gy
+        if ctx.needs_input_grad[0]:
+            gx, ga = linear_bf16_bwd(gy, weight, y, want_ga=need_w)
+        elif y is not None and need_w:
+            ga = torch.where(y > 0, gy, torch.zeros_like(gy))
+        if need_w:
+            gw, gb = wgrad(ga, x, want_bias=ctx.has_bias)
+        return gx, gw, gb, None
+
+
+def linear_bf16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu_out: bool = False) -> Tensor:
+    return _LinearBf16.apply(x, weight, bias, bool(relu_out))
+
+
+class _PmaProjectBf16(torch.autograd.Function):
+    """:class:`_PmaProject` in the bf16 regime (H <= 4): the folded logits are four fp32 auxiliary output columns of the value
+    projection's kernel, and their input gradient a rank-4 term of its backward-data kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w_v, b_v, w_a, b_a):
+        H = w_a.shape[0]
+        w4 = w_a if H == 4 else torch.cat([w_a, w_a.new_zeros(4 - H, w_a.shape[1])])
+        b4 = None if b_a is None else (b_a if H == 4 else torch.cat([b_a, b_a.new_zeros(4 - H)]))
+        x_v, a4 = linear_bf16_fwd(x, w_v, b_v, False, w4, b4)
+        ctx.save_for_backward(x, w_v, w4)
+        ctx.cfg = (b_v is not None, b_a is not None, H)
+        return x_v, (a4 if H == 4 else a4[:, :H].contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_v, g_alpha):
+        x, w_v, w4 = ctx.saved_tensors
+        has_bv, has_ba, H = ctx.cfg
+        g_v, g_alpha = g_v.contiguous(), g_alpha.float().contiguous()
+        gx = gwv = gbv = gwa = gba = None
+        if ctx.needs_input_grad[0]:
+            g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
+            gx, _ = linear_bf16_bwd(g_v, w_v, galpha=g4, aux_w=w4)
+        if ctx.needs_input_grad[1] or (has_bv and ctx.needs_input_grad[2]):
+            gwv, gbv = wgrad(g_v, x, want_bias=has_bv)
+        if ctx.needs_input_grad[3] or (has_ba and ctx.needs_input_grad[4]):
+            ga16 = g_alpha.to(torch.bfloat16)
+            if wgrad_supported(ga16, x):
+                gwa, gba = wgrad(ga16, x, want_bias=has_ba)
+            else:
+                gwa, gba = ga16.t() @ x, (ga16.sum(0) if has_ba else None)
+        return gx, gwv, gbv, gwa, gba
+
+
+def pma_project_bf16(x: Tensor, w_v: Tensor, b_v: Optional[Tensor], w_a: Tensor, b_a: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    return _PmaProjectBf16.apply(x, w_v, b_v, w_a, b_a)
+
+
+class _PmaResidualFFBf16(torch.autograd.Function):
+    """:class:`_PmaResidualFF` in the bf16 regime: ``y = dropout_p(relu_post(LN(out + relu(W2 relu(W1 out + b1) + b2))))``;
+    both relus are Linear epilogues, their backward masks come from the saved outputs, and the two gradient branches of
+    ``out`` are summed in the last backward-data kernel."""
+
+    @staticmethod
+    def forward(ctx, out, w1, b1, w2, b2, gamma, beta, eps, relu_post, p):
+        h, _ = linear_bf16_fwd(out, w1, b1, True)
+        z, _ = linear_bf16_fwd(h, w2, b2, True)
+        seed = _draw_seed() if p > 0.0 else 0
+        base = _seed_base() if p > 0.0 else None
+        y, stats = ln_res_fwd(out, None, z, gamma, beta, eps, relu_post, p, seed, base)
+        ctx.save_for_backward(out, h, z, stats, w1, w2, gamma, beta)
+        ctx.cfg = (bool(relu_post), float(p), seed, base, b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        out, h, z, stats, w1, w2, gamma, beta = ctx.saved_tensors
+        relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
+        gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
+        gh, ga2 = linear_bf16_bwd(gs, w2, z, want_ga=True)
+        gw2, gb2 = wgrad(ga2, h, want_bias=has_b2)
+        gout, ga1 = linear_bf16_bwd(gh, w1, h, want_ga=True, acc_in=gs)         # gs + the rFF branch
+        gw1, gb1 = wgrad(ga1, out, want_bias=has_b1)
+        return gout, gw1, gb1, gw2, gb2, dg, db, None, None, None
+
+
+def pma_residual_ff_bf16(out: Tensor, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5, relu_post: bool = False, p: float = 0.0) -> Tensor:
+    return _PmaResidualFFBf16.apply(out, w1, b1, w2, b2, gamma, beta, float(eps), bool(relu_post), float(p))
+
+
 def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, relu_in: bool = False, p: float = 0.0) -> Tensor:
     """``dropout_p(LayerNorm(relu(x) if relu_in else x))`` in one pass."""
     return _LayerNormFused.apply(x, gamma, beta, float(eps), bool(relu_in), float(p))

@@ -72,7 +72,11 @@ def _layer_norm(norm: nn.LayerNorm, x: Tensor, relu_in: bool = False, p: float =
     return F.dropout(y, p=p, training=p > 0.0)
 
 
-def _linear(lin: nn.Linear, x: Tensor) -> Tensor:
+def _linear(lin: nn.Linear, x: Tensor, relu_out: bool = False) -> Tensor:
+    if dense.linear_bf16_supported(x, lin.weight, lin.bias):
+        return dense.linear_bf16(x, lin.weight, lin.bias, relu_out)     # bf16 regime: one kernel, relu in its epilogue
+    if relu_out:
+        return F.relu(_linear(lin, x))
     if _on_hip(x) or (x.is_cuda and x.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16):
         return dense.linear(x, lin.weight, lin.bias)     # library GEMMs forward / backward-data, split-K MFMA weight gradient
     return lin(x)
@@ -152,14 +156,19 @@ class MLP(nn.Module):
         n0 = self.normalizations[0]
         x = _layer_norm(n0, x) if isinstance(n0, nn.LayerNorm) else n0(x)
         for i, lin in enumerate(self.lins[:-1]):
-            a = _linear(lin, x)
             nxt = self.normalizations[i + 1]
+            if isinstance(nxt, nn.Identity) and p == 0.0 and dense.linear_bf16_supported(x, lin.weight, lin.bias):
+                x = _linear(lin, x, relu_out=True)     # bf16 regime: the relu is the Linear's epilogue
+                continue
+            a = _linear(lin, x)
             if isinstance(nxt, nn.LayerNorm):          # relu -> LayerNorm -> dropout: one kernel
                 x = _layer_norm(nxt, a, relu_in=True, p=p)
             elif isinstance(nxt, nn.Identity):         # relu -> dropout: one kernel
                 x = relu_dropout(a, p, self.training)
             else:                                      # BatchNorm1d: torch
                 x = F.dropout(nxt(F.relu(a)), p=p, training=self.training)
+        if post_p == 0.0 and dense.linear_bf16_supported(x, self.lins[-1].weight, self.lins[-1].bias):
+            return _linear(self.lins[-1], x, relu_out=True)
         x = _linear(self.lins[-1], x)
         return x if post_p is None else relu_dropout(x, _post, self.training)
 
@@ -231,6 +240,12 @@ class PMA(nn.Module):
             w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
             b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
             return dense.pma_project(x, self.lin_V.weight, self.lin_V.bias, w, b)
+        if (self.fold_alpha and H <= 4 and x.dim() == 2 and x.shape[1] % 8 == 0
+                and dense.linear_bf16_supported(x, self.lin_V.weight, self.lin_V.bias) and self.att_r.dtype == torch.bfloat16):
+            # bf16 regime: the logits are four fp32 auxiliary columns of the value projection's kernel
+            w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
+            b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
+            return dense.pma_project_bf16(x, self.lin_V.weight, self.lin_V.bias, w, b)
         x_V = (dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias) if (fusable or wide)
                else _linear(self.lin_V, x))
         return x_V, self._logits(x)
@@ -251,6 +266,12 @@ class PMA(nn.Module):
                 # the whole residual block as one autograd node (gradient branches of `out` summed in a kernel)
                 return dense.pma_residual_ff(out, ff.lins[0].weight, ff.lins[0].bias, ff.lins[1].weight, ff.lins[1].bias,
                                              self.ln1.weight, self.ln1.bias, self.ln1.eps, _post is not None, float(_post or 0.0))
+            if (len(ff.lins) == 2 and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
+                    and ff.lins[1].out_features == H * C and all(lin.bias is not None for lin in ff.lins)
+                    and all(dense.linear_bf16_supported(out, lin.weight, lin.bias) for lin in ff.lins)):
+                # bf16 regime: the same block as one autograd node on the bf16 Linear kernels
+                return dense.pma_residual_ff_bf16(out, ff.lins[0].weight, ff.lins[0].bias, ff.lins[1].weight, ff.lins[1].bias,
+                                                  self.ln1.weight, self.ln1.bias, self.ln1.eps, _post is not None, float(_post or 0.0))
             z = ff(out, _post=0.0)                                      # relu(rFF(.)) in rFF's last fused epilogue
             return dense.layer_norm_res(out, None, z, self.ln1.weight, self.ln1.bias, self.ln1.eps,
                                         relu_out=_post is not None, p=float(_post or 0.0))

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 4   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -222,6 +222,24 @@ int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, floa
 int allset_wgrad_bf16_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
                       int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+
+/* The Linear of the bf16 regime (BASELINE configs[4]; replaces MLP.forward's Linear + ReLU, reference layers.py:571-579, and
+ * PMA's value projection + folded logits, layers.py:120-145, with their autograd) -- bf16 activations and parameters, fp32
+ * accumulation, ONE pass per direction with the element-wise neighbours folded in.  in/out features in {128, 256}
+ * (allset_linear_bf16_supported); rows 16-byte aligned, leading dimensions multiples of 8 elements.
+ *   fwd:  y[n, N] = act(x[n, K] W[N, K]^T + bias[N])      act = relu if relu_out else identity; bias may be NULL
+ *         aux_out[n, 4] (fp32) = x aux_w[4, K]^T + aux_b[4]   when aux_out != NULL (aux_w, aux_b: bf16; aux_b may be NULL)
+ *   bwd:  ga = gy[n, O] where ymask[n, O] > 0 (ymask = the forward's relu output, or NULL: ga = gy);
+ *         ga_out (optional, needs ymask) receives ga for the weight-gradient kernel (allset_wgrad_bf16);
+ *         gx[n, I] = ga W[O, I]  [+ acc_in[n, I] (bf16: another gradient branch of x)]  [+ galpha[n, 4] (fp32) aux_w[4, I]]
+ *         -- all terms summed in fp32 and rounded to bf16 once. */
+int allset_linear_bf16_supported(int64_t in_features, int64_t out_features);
+int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void* bias, int relu_out, const void* aux_w,
+                           const void* aux_b, float* aux_out, void* y, int64_t ldy, int64_t n, int64_t K, int64_t N,
+                           void* stream);
+int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out, int64_t lda,
+                           const void* W, const float* galpha, const void* aux_w, const void* acc_in, int64_t ldacc,
+                           void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* Same with an explicit kernel choice (variant as in allset_pma_fwd_ex; nnz / n_s decides in auto mode). */
 int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptrT, const int32_t* colT,
