@@ -482,8 +482,9 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
 constexpr int kRedSplit = 8;                   // row groups per workgroup (256 threads = 32 column quads x 8 groups)
 constexpr int kRedRows = 64;                   // rows per slab
 
+template <bool OUT_BF16>
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ part, int64_t P, int64_t M,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, int64_t row_stride) {
   __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
   const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
   const int64_t c = (static_cast<int64_t>(blockIdx.x) * (kBlock / kRedSplit) + cq) * 4;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < kRedRows / kRedSplit; ++i) {
       const int64_t p = p0 + rg + static_cast<int64_t>(i) * kRedSplit;
-      v[i] = p < P ? *reinterpret_cast<const float4*>(part + p * M + c) : make_float4(0, 0, 0, 0);
+      v[i] = p < P ? *reinterpret_cast<const float4*>(part + p * row_stride + c) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < kRedRows / kRedSplit; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
@@ -504,7 +505,10 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __
   if (rg == 0 && c < M) {
 #pragma unroll
     for (int g = 1; g < kRedSplit; ++g) { const float4 t = red[g][cq]; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
-    *reinterpret_cast<float4*>(out + static_cast<int64_t>(blockIdx.y) * M + c) = acc;
+    if constexpr (OUT_BF16)      // single-slab launches only: `out` is a bf16 vector of M elements
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + c) = make_uint2(cvt_pk_bf16(acc.x, acc.y), cvt_pk_bf16(acc.z, acc.w));
+    else
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(blockIdx.y) * M + c) = acc;
   }
 }
 
@@ -894,7 +898,8 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
 template <int DUMMY>
 __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_kernel(
     const uint16_t* __restrict__ ga, int64_t lda, const uint16_t* __restrict__ u, int64_t ldu,
-    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i, int64_t rows_per_slice) {
+    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i, int64_t rows_per_slice,
+    int64_t pw_stride, int64_t pb_stride) {
   __shared__ __attribute__((aligned(16))) uint32_t sP[2][2][kWgTile * 16];        // [buffer][A|B][feature*16 + ..]
   const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
   const int o_base = tile_o * kWgTile, i_base = tile_i * kWgTile;
@@ -982,7 +987,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_kernel(
     }
   }
 
-  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+  float* pw = part_w + static_cast<int64_t>(slice) * pw_stride;
 #pragma unroll
   for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -1000,7 +1005,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_kernel(
       bsum.x += __shfl_xor(bsum.x, off); bsum.y += __shfl_xor(bsum.y, off);
       bsum.z += __shfl_xor(bsum.z, off); bsum.w += __shfl_xor(bsum.w, off);
     }
-    if (rp == 0 && a_ok) *reinterpret_cast<float4*>(part_b + static_cast<int64_t>(slice) * O + o_base + s_col) = bsum;
+    if (rp == 0 && a_ok) *reinterpret_cast<float4*>(part_b + static_cast<int64_t>(slice) * pb_stride + o_base + s_col) = bsum;
   }
 }
 
@@ -1026,7 +1031,8 @@ __device__ __forceinline__ int wtr_off(int row, int cbyte) {
 template <int OTN, int ITN>       // O = 64 OTN, I = 32 ITN; wave tile (16 OTN) x (16 ITN)
 __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
     const uint16_t* __restrict__ ga, int64_t lda, const uint16_t* __restrict__ u, int64_t ldu,
-    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int64_t rows_per_slice) {
+    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int64_t rows_per_slice, int64_t pw_stride,
+    int64_t pb_stride) {
   constexpr int O = 64 * OTN, I = 32 * ITN;
   constexpr int PA = O * 2, PB = I * 2;                            // row pitches (bytes)
   constexpr int SA = 32 * PA, SB = 32 * PB;                        // bytes per stage and operand
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
   }
 
   // partial tile -> part_w[slice][O][I]; acc[ot][it][r] is (o = ob + 16 ot + 4 fg + r, i = ib + 16 it + fi)
-  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+  float* pw = part_w + static_cast<int64_t>(slice) * pw_stride;
 #pragma unroll
   for (int ot = 0; ot < OTN; ++ot)
 #pragma unroll
@@ -1156,7 +1162,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
       float v = gbs[ot];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (lane < 16) part_b[static_cast<int64_t>(slice) * O + ob + ot * 16 + fi] = v;
+      if (lane < 16) part_b[static_cast<int64_t>(slice) * pb_stride + ob + ot * 16 + fi] = v;
     }
   }
 }
@@ -1673,11 +1679,28 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
   return ALLSET_OK;
 }
 
+static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride, int64_t M, void* out, int out_bf16, float* scratch,
+                                void* stream);
+
 extern "C" int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, float* scratch, void* stream) {
   clear_error();
+  return reduce_partials_impl(part, P, M, M, out, 0, scratch, stream);
+}
+
+extern "C" int allset_reduce_partials_ex(const float* part, int64_t P, int64_t row_stride, int64_t M, void* out, int out_dtype,
+                                         float* scratch, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(out_dtype == ALLSET_F32 || out_dtype == ALLSET_BF16, "reduce_partials_ex: out_dtype must be ALLSET_F32 or ALLSET_BF16");
+  ALLSET_REQUIRE(row_stride >= M && row_stride % 4 == 0, "reduce_partials_ex: row_stride must be >= M and a multiple of 4");
+  return reduce_partials_impl(part, P, row_stride, M, out, out_dtype == ALLSET_BF16, scratch, stream);
+}
+
+static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride, int64_t M, void* out_v, int out_bf16, float* scratch,
+                                void* stream) {
+  float* out = static_cast<float*>(out_v);
   ALLSET_REQUIRE(P >= 1 && M >= 1, "reduce_partials: bad size");
   ALLSET_REQUIRE(part && out, "reduce_partials: null pointer");
-  if (M % 4 != 0 || !aligned16(part) || !aligned16(out) || (scratch && !aligned16(scratch))) {
+  if (M % 4 != 0 || !aligned16(part) || (reinterpret_cast<uintptr_t>(out) & (out_bf16 ? 7u : 15u)) || (scratch && !aligned16(scratch))) {
     set_error("reduce_partials: M must be a multiple of 4 and the buffers 16-byte aligned");
     return ALLSET_ERR_UNSUPPORTED;
   }
@@ -1688,10 +1711,12 @@ extern "C" int allset_reduce_partials(const float* part, int64_t P, int64_t M, f
   const int64_t quads = M / 4, per_block = kBlock / kRedSplit;
   const unsigned gx = static_cast<unsigned>((quads + per_block - 1) / per_block);
   if (slabs == 1) {
-    reduce_partials_kernel<<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out);
+    if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride);
+    else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride);
   } else {
-    reduce_partials_kernel<<<dim3(gx, static_cast<unsigned>(slabs)), kBlock, 0, st>>>(part, P, M, scratch);
-    reduce_partials_kernel<<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out);
+    reduce_partials_kernel<false><<<dim3(gx, static_cast<unsigned>(slabs)), kBlock, 0, st>>>(part, P, M, scratch, row_stride);
+    if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M);
+    else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
@@ -1826,9 +1851,25 @@ extern "C" int allset_wgrad_bf16_slices(int64_t n, int64_t O, int64_t I, int64_t
   return ALLSET_OK;
 }
 
+static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
+                           int64_t pw_stride, int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+
 extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
                                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
   clear_error();
+  return wgrad_bf16_impl(ga, lda, u, ldu, part_w, part_b, O * I, O, n_slices, n, O, I, stream);
+}
+
+extern "C" int allset_wgrad_bf16_ex(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part, int64_t part_stride,
+                                    int want_bias, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(part != nullptr && part_stride >= O * I + (want_bias ? O : 0) && part_stride % 4 == 0 && aligned16(part),
+                 "wgrad_bf16_ex: part must be 16-byte aligned rows of at least O*I (+O) floats, stride a multiple of 4");
+  return wgrad_bf16_impl(ga, lda, u, ldu, part, want_bias ? part + O * I : nullptr, part_stride, part_stride, n_slices, n, O, I, stream);
+}
+
+static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
+                           int64_t pw_stride, int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
   ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_bf16: bad size");
   ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_bf16: bad slice count");
   ALLSET_REQUIRE(part_w != nullptr, "wgrad_bf16: null partial buffer");
@@ -1848,7 +1889,7 @@ extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int
     const unsigned grid1 = static_cast<unsigned>(n_slices);
     const uint16_t* a16 = static_cast<const uint16_t*>(ga);
     const uint16_t* u16 = static_cast<const uint16_t*>(u);
-#define ALLSET_WGTR(OTN, ITN) wgrad_bf16_tr_kernel<OTN, ITN><<<grid1, kWx6Block, 0, st>>>(a16, lda, u16, ldu, part_w, part_b, n, rps)
+#define ALLSET_WGTR(OTN, ITN) wgrad_bf16_tr_kernel<OTN, ITN><<<grid1, kWx6Block, 0, st>>>(a16, lda, u16, ldu, part_w, part_b, n, rps, pw_stride, pb_stride)
     const int otn = static_cast<int>(O / 64), itn = static_cast<int>(I / 32);
     if (otn == 4 && itn == 8) ALLSET_WGTR(4, 8);
     else if (otn == 4 && itn == 4) ALLSET_WGTR(4, 4);
@@ -1869,7 +1910,8 @@ extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int
   if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   wgrad_bf16_kernel<0><<<grid, kWx6Block, 0, st>>>(static_cast<const uint16_t*>(ga), lda, static_cast<const uint16_t*>(u), ldu,
-                                                   part_w, part_b, n, static_cast<int>(O), static_cast<int>(I), tiles_i, rows_per_slice);
+                                                   part_w, part_b, n, static_cast<int>(O), static_cast<int>(I), tiles_i, rows_per_slice,
+                                                   pw_stride, pb_stride);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -100,6 +100,18 @@ def reduce_partials(part: Tensor) -> Tensor:
     return out
 
 
+def reduce_partials_to(part: Tensor, M: int, dtype: torch.dtype) -> Tensor:
+    """Sum the first ``M`` columns of a partial buffer [P, stride] over its rows; ``dtype`` float32 or bfloat16 (rounded once)."""
+    P, stride = part.shape
+    dev = part.device
+    out = torch.empty(M, dtype=dtype, device=dev)
+    scratch = torch.empty(((P + 63) // 64) * M, dtype=torch.float32, device=dev) if P > 64 else None
+    with torch.cuda.device(dev):
+        check(_lib.load().allset_reduce_partials_ex(ptr(part), P, stride, M, ptr(out), 1 if dtype == torch.bfloat16 else 0,
+                                                    ptr(scratch), stream_of(dev)), "allset_reduce_partials_ex")
+    return out
+
+
 def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p: float, seed: int,
            seed_base: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     dev = require_device(x, gamma, beta)
@@ -145,6 +157,9 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
             check(lib.allset_ln_bwd_bf16(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
                                          seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
                                          stream_of(dev)), "allset_ln_bwd_bf16")
+        if (2 * d) % 4 == 0 and npart.value <= 4096:
+            red = reduce_partials_to(partials.view(npart.value, 2 * d), 2 * d, torch.bfloat16).view(2, d)
+            return gx, red[0], red[1]
         red = reduce_partials(partials)
         return gx, red[0].to(torch.bfloat16), red[1].to(torch.bfloat16)
     check(lib.allset_ln_bwd_partials(n, d, byref(npart)), "allset_ln_bwd_partials")
@@ -173,6 +188,16 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
         check(lib.allset_wgrad_bf16_slices(n, O, I, byref(ns)), "allset_wgrad_bf16_slices")
     else:
         check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
+    if bf16 and ns.value <= 4096:
+        # one partial buffer [slices, gW | gb], one reduction launch that also rounds to bf16 (this regime is launch-bound);
+        # O and I are multiples of 4 (checked by the kernel), so the row needs no padding
+        M = O * I + (O if want_bias else 0)
+        part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
+            check(lib.allset_wgrad_bf16_ex(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part), M, int(want_bias), ns.value, n, O, I,
+                                           stream_of(dev)), "allset_wgrad_bf16_ex")
+        red = reduce_partials_to(part, M, torch.bfloat16)
+        return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
     part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
     part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
     with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
@@ -691,9 +716,12 @@ def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tens
         check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res),
                  _ld(res) if res is not None else 0, ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), int(relu_out), p,
                  seed, ptr(gs), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base), stream_of(dev)), name)
-    red = reduce_partials(partials)
-    if bf16:
-        red = red.to(torch.bfloat16)
+    if bf16 and (3 * d) % 4 == 0 and npart.value <= 4096:
+        red = reduce_partials_to(partials.view(npart.value, 3 * d), 3 * d, torch.bfloat16).view(3, d)   # summed and rounded in one launch
+    else:
+        red = reduce_partials(partials)
+        if bf16:
+            red = red.to(torch.bfloat16)
     return gs, red[0], red[1], red[2]
 
 

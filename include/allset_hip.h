@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -222,6 +222,11 @@ int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, floa
 int allset_wgrad_bf16_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
                       int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+/* The same with ONE partial buffer: part: f32[n_slices][part_stride], row k = slice k's gW (O*I floats) followed, when
+ * want_bias, by its gb (O floats) -- so a single allset_reduce_partials_ex call sums every parameter gradient of the Linear
+ * and can write them as bf16.  part_stride >= O*I (+O), a multiple of 4. */
+int allset_wgrad_bf16_ex(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part, int64_t part_stride,
+                         int want_bias, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* The Linear of the bf16 regime (BASELINE configs[4]; replaces MLP.forward's Linear + ReLU, reference layers.py:571-579, and
  * PMA's value projection + folded logits, layers.py:120-145, with their autograd) -- bf16 activations and parameters, fp32
@@ -251,6 +256,10 @@ int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* ro
 /* out[c] = sum_p part[p*M + c], p < P <= 4096: sums the partial buffers the kernels above hand back (M % 4 == 0).
  * scratch: f32[ceil(P/64) * M], required when P > 64 (two-level tree). */
 int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, float* scratch, void* stream);
+/* The same with rows row_stride floats apart (only the first M of each row are summed) and a choice of output type
+ * (out_dtype: ALLSET_F32 -> f32[M], ALLSET_BF16 -> bf16[M], rounded once from the fp32 sum). */
+int allset_reduce_partials_ex(const float* part, int64_t P, int64_t row_stride, int64_t M, void* out, int out_dtype,
+                              float* scratch, void* stream);
 
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;

@@ -772,3 +772,20 @@ def test_one_pass_backward_is_deterministic_and_used_by_the_mlp(device, monkeypa
     assert "fused_linear_bwd_all" not in k3 and "wgrad_fused" in k3
     for a, b in zip(g1, g3):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("P,M,stride", [(1, 8, 8), (5, 260, 264), (64, 4096, 4096), (65, 132, 200), (700, 1028, 1028)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reduce_partials_with_a_row_stride_and_bf16_output(P, M, stride, dtype, device):
+    """allset_reduce_partials_ex: rows `stride` floats apart, the first M summed; bf16 output = the fp32 sum rounded once."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(P + M)
+    part = torch.randn(P, stride, generator=g).to(device)
+    got = dense.reduce_partials_to(part, M, dtype)
+    ref = part[:, :M].double().sum(0)
+    if dtype == torch.float32:
+        torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-5 * max(1.0, float(ref.abs().max())))
+    else:
+        assert got.dtype == torch.bfloat16
+        err = (got.double() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-4).all())
