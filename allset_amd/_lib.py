@@ -100,6 +100,9 @@ SIGNATURES = {
     "allset_linear_bf16_fwd": [_P, c_int64, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_linear_bf16_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                c_int64, _P],
+    "allset_ln_res_bwd_pma_bf16_supported": [c_int64, c_int64],
+    "allset_ln_res_bwd_pma_bf16": [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P,
+                                   c_int64, _P],
     "allset_ln_res_bwd_pma_supported": [c_int64, c_int64],
     "allset_ln_res_bwd_pma": [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P,
                               c_int64, _P],

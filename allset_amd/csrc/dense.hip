@@ -1388,10 +1388,12 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
     const uint16_t* __restrict__ colb, const uint16_t* __restrict__ res, int64_t ldr, const float* __restrict__ stats,
     const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, int relu_out, float p, uint64_t seed,
     uint16_t* __restrict__ gs, int64_t ldgs, float* __restrict__ part, int64_t n, int d,
-    const uint64_t* __restrict__ seed_base) {
+    const uint64_t* __restrict__ seed_base, const float* __restrict__ pma_m, const float* __restrict__ pma_l,
+    float* __restrict__ pma_stats, int pma_heads) {
   seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
   constexpr int kGroups = kWavesPerBlock * NS;
+  const int pma_g = pma_stats ? (d / pma_heads) / 8 : 1;           // lanes per head (a power of two, checked by the host)
   __shared__ float red[kGroups][3][LPR * 8];
   const int lane = lane_id();
   const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
@@ -1436,11 +1438,28 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
     }
     s1 = group_sum<LPR>(s1) * inv_d;
     s2 = group_sum<LPR>(s2) * inv_d;
+    float dot = 0.f;
     if (active) {
       F8 o;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { o.v[k] = rstd * (gh.v[k] - s1 - xh.v[k] * s2); dc.v[k] += o.v[k]; }
-      *reinterpret_cast<uint4*>(gs + row * ldgs + c0) = pack8(o);
+      const uint4 packed = pack8(o);
+      *reinterpret_cast<uint4*>(gs + row * ldgs + c0) = packed;
+      if (pma_stats != nullptr) {                         // <x, gs> of this lane's 8 columns, on the values as stored
+        const F8 r = unpack8(packed);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dot = fmaf(xv.v[k], r.v[k], dot);
+      }
+    }
+    if (pma_stats != nullptr) {                           // (uniform branch; inactive lanes contribute 0 to the shuffles)
+      for (int off = 1; off < pma_g; off <<= 1) dot += __shfl_xor(dot, off);
+      if (active && (li % pma_g) == 0) {
+        const int h = li / pma_g;
+        const float lv = pma_l[row * pma_heads + h];
+        // empty target: never gathered; exp(a - FLT_MAX) = 0 (same convention as pma_bwd_stats_kernel, csrc/pma.hip)
+        const float M = lv > 0.f ? pma_m[row * pma_heads + h] + __logf(lv + 1e-16f) : 3.402823466e+38f;
+        *reinterpret_cast<float2*>(pma_stats + (row * pma_heads + h) * 2) = make_float2(M, dot);
+      }
     }
   }
 #pragma unroll
@@ -2006,11 +2025,48 @@ extern "C" int allset_ln_res_fwd_bf16(const void* x, int64_t ldx, const void* co
   return ALLSET_OK;
 }
 
+static int ln_res_bwd_bf16_impl(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb,
+                                const void* res, int64_t ldr, const float* stats, const void* gamma, const void* beta,
+                                int relu_out, float p, uint64_t seed, void* gs, int64_t ldgs, float* partials,
+                                int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, const float* pma_m,
+                                const float* pma_l, float* pma_stats, int64_t pma_heads, void* stream);
+
 extern "C" int allset_ln_res_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb,
                                       const void* res, int64_t ldr, const float* stats, const void* gamma, const void* beta,
                                       int relu_out, float p, uint64_t seed, void* gs, int64_t ldgs, float* partials,
                                       int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, void* stream) {
   clear_error();
+  return ln_res_bwd_bf16_impl(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n_partials,
+                              n, d, seed_base, nullptr, nullptr, nullptr, 1, stream);
+}
+
+extern "C" int allset_ln_res_bwd_pma_bf16_supported(int64_t d, int64_t heads) {
+  if (!allset_ln_bf16_supported(d) || heads < 1 || d % heads != 0 || (d / heads) % 8 != 0) return 0;
+  const int64_t g = (d / heads) / 8;
+  return (g & (g - 1)) == 0 ? 1 : 0;
+}
+
+extern "C" int allset_ln_res_bwd_pma_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb,
+                                          const float* stats, const void* gamma, const void* beta, void* gs, int64_t ldgs,
+                                          float* partials, int64_t n_partials, int64_t n, int64_t d, const float* pma_m,
+                                          const float* pma_l, float* pma_stats, int64_t heads, void* stream) {
+  clear_error();
+  if (!allset_ln_res_bwd_pma_bf16_supported(d, heads)) {
+    set_error("ln_res_bwd_pma_bf16: d=%lld heads=%lld not built (channels per head must be 8 x a power of two)",
+              static_cast<long long>(d), static_cast<long long>(heads));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(n == 0 || (pma_m && pma_l && pma_stats), "ln_res_bwd_pma_bf16: null statistics pointer");
+  ALLSET_REQUIRE(pma_stats == nullptr || (reinterpret_cast<uintptr_t>(pma_stats) & 7u) == 0, "ln_res_bwd_pma_bf16: stats must be 8-byte aligned");
+  return ln_res_bwd_bf16_impl(gy, ldg, x, ldx, colb, nullptr, 0, stats, gamma, beta, 0, 0.f, 0, gs, ldgs, partials, n_partials, n, d,
+                              nullptr, pma_m, pma_l, pma_stats, heads, stream);
+}
+
+static int ln_res_bwd_bf16_impl(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb,
+                                const void* res, int64_t ldr, const float* stats, const void* gamma, const void* beta,
+                                int relu_out, float p, uint64_t seed, void* gs, int64_t ldgs, float* partials,
+                                int64_t n_partials, int64_t n, int64_t d, const uint64_t* seed_base, const float* pma_m,
+                                const float* pma_l, float* pma_stats, int64_t pma_heads, void* stream) {
   ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_bwd_bf16: bad size");
   ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_bwd_bf16: dropout p must be in [0,1)");
   if (!allset_ln_bf16_supported(d)) { set_error("ln_res_bwd_bf16: width %lld not built", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
@@ -2027,7 +2083,7 @@ extern "C" int allset_ln_res_bwd_bf16(const void* gy, int64_t ldg, const void* x
   const int di = static_cast<int>(d);
   const unsigned grid = static_cast<unsigned>(n_partials);
   typedef const uint16_t* CP;
-#define ALLSET_LNRB_BWD(L) ln_res_bwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>((CP)gy, ldg, (CP)x, ldx, (CP)colb, (CP)res, ldr, stats, (CP)gamma, (CP)beta, relu_out, p, seed, (uint16_t*)gs, ldgs, partials, n, di, seed_base)
+#define ALLSET_LNRB_BWD(L) ln_res_bwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>((CP)gy, ldg, (CP)x, ldx, (CP)colb, (CP)res, ldr, stats, (CP)gamma, (CP)beta, relu_out, p, seed, (uint16_t*)gs, ldgs, partials, n, di, seed_base, pma_m, pma_l, pma_stats, static_cast<int>(pma_heads))
   switch (ln_bf16_lpr(d)) { case 8: ALLSET_LNRB_BWD(8); break; case 16: ALLSET_LNRB_BWD(16); break; case 32: ALLSET_LNRB_BWD(32); break; default: ALLSET_LNRB_BWD(64); break; }
 #undef ALLSET_LNRB_BWD
   ALLSET_LAUNCH_CHECK();

@@ -725,31 +725,48 @@ def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tens
     return gs, red[0], red[1], red[2]
 
 
-def ln_res_bwd_pma_supported(d: int, heads: int) -> bool:
-    return bool(_lib.load().allset_ln_res_bwd_pma_supported(d, heads))
+def ln_res_bwd_pma_supported(d: int, heads: int, dtype: torch.dtype = torch.float32) -> bool:
+    if dtype == torch.bfloat16:
+        return bool(_lib.load().allset_ln_res_bwd_pma_bf16_supported(d, heads))
+    return dtype == torch.float32 and bool(_lib.load().allset_ln_res_bwd_pma_supported(d, heads))
 
 
 def ln_res_bwd_pma(gy: Tensor, x: Tensor, colb: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, m: Tensor, l: Tensor
                    ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """Backward of ``LayerNorm(x + colb)`` where ``x`` is PMA's pooled output, with the attention-backward statistics written by
-    the same pass: returns (gs, dgamma, dbeta, dcolb, pma_stats [n, H, 2]) -- include/allset_hip.h allset_ln_res_bwd_pma."""
+    the same pass: returns (gs, dgamma, dbeta, dcolb, pma_stats [n, H, 2]) -- include/allset_hip.h allset_ln_res_bwd_pma.
+    fp32, or bf16 activations and parameters (fp32 statistics)."""
     dev = require_device(gy, x, colb, stats, gamma, beta, m, l)
-    _check_f32(gy, x, colb, stats, gamma, beta, m, l)
+    bf16 = x.dtype == torch.bfloat16
+    if bf16:
+        _check_dtype(torch.bfloat16, gy, x, colb, gamma, beta)
+        _check_f32(stats, m, l)
+    else:
+        _check_f32(gy, x, colb, stats, gamma, beta, m, l)
     gy, x = _rowmajor(gy), _rowmajor(x)
     n, d = x.shape
     H = m.shape[1]
     lib = _lib.load()
     npart = c_int64(0)
-    check(lib.allset_ln_res_bwd_partials(n, d, byref(npart)), "allset_ln_res_bwd_partials")
+    if bf16:
+        check(lib.allset_ln_bwd_bf16_partials(n, d, byref(npart)), "allset_ln_bwd_bf16_partials")
+    else:
+        check(lib.allset_ln_res_bwd_partials(n, d, byref(npart)), "allset_ln_res_bwd_partials")
     partials = torch.empty((npart.value, 3, d), dtype=torch.float32, device=dev)
-    gs = torch.empty((n, d), dtype=torch.float32, device=dev)
+    gs = torch.empty((n, d), dtype=x.dtype, device=dev)
     pstats = torch.empty((n, H, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, 3 * n * d * 4 + n * H * 16):
-        check(lib.allset_ln_res_bwd_pma(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous()), ptr(stats), ptr(gamma.contiguous()),
-                                        ptr(beta.contiguous()), ptr(gs), max(d, 1), ptr(partials), npart.value, n, d,
-                                        ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, stream_of(dev)),
-              "allset_ln_res_bwd_pma")
-    red = reduce_partials(partials)
+    fn, name = ((lib.allset_ln_res_bwd_pma_bf16, "allset_ln_res_bwd_pma_bf16") if bf16
+                else (lib.allset_ln_res_bwd_pma, "allset_ln_res_bwd_pma"))
+    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, 3 * n * d * x.element_size() + n * H * 16):
+        check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous()), ptr(stats), ptr(gamma.contiguous()),
+                 ptr(beta.contiguous()), ptr(gs), max(d, 1), ptr(partials), npart.value, n, d,
+                 ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, stream_of(dev)), name)
+    if bf16 and (3 * d) % 4 == 0 and npart.value <= 4096:
+        red = reduce_partials_to(partials.view(npart.value, 3 * d), 3 * d, torch.bfloat16).view(3, d)
+    else:
+        red = reduce_partials(partials)
+        if bf16:
+            red = red.to(torch.bfloat16)
     return gs, red[0], red[1], red[2], pstats
 
 

@@ -210,8 +210,8 @@ class _PmaPoolLn0(torch.autograd.Function):
 def pma_pool_ln0_supported(V: Tensor, heads: int) -> bool:
     from . import dense
     d = V.shape[1]
-    return (V.is_cuda and V.dtype == torch.float32 and dense.ln_res_supported(d) and dense.ln_res_bwd_pma_supported(d, heads)
-            and not _colocate(V, heads))
+    return (V.is_cuda and V.dtype in (torch.float32, torch.bfloat16) and dense.ln_res_supported(d, V.dtype)
+            and dense.ln_res_bwd_pma_supported(d, heads, V.dtype) and not _colocate(V, heads))
 
 
 def pma_pool_ln0(V: Tensor, alpha: Tensor, inc: Incidence, heads: int, negative_slope: float, att_r: Tensor, gamma: Tensor,

@@ -283,7 +283,9 @@ class PMA(nn.Module):
     def pool_tail(self, x_V: Tensor, alpha_r: Tensor, inc: Incidence, _post: Optional[float] = None):
         """``tail(pool(x_V, alpha_r))`` plus the softmax statistics: ``(out [n_t, H*C], m, l)`` (reference layers.py:145-157)."""
         H = self.heads
-        if (_on_hip(x_V) and self.ln0.bias is not None and self.ln1.bias is not None and self.ln0.elementwise_affine
+        hip = _on_hip(x_V) or (x_V.is_cuda and x_V.dtype == torch.bfloat16 and self.ln0.weight.dtype == torch.bfloat16
+                               and self.att_r.dtype == torch.bfloat16)
+        if (hip and self.ln0.bias is not None and self.ln1.bias is not None and self.ln0.elementwise_affine
                 and AF.pma_pool_ln0_supported(x_V, H)):
             # pooling + seed add + ln0 as one autograd node: the pooling's backward statistics come out of ln0's backward pass
             out, m, l = AF.pma_pool_ln0(x_V, alpha_r, inc, H, self.negative_slope, self.att_r, self.ln0.weight, self.ln0.bias,

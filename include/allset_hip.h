@@ -383,6 +383,12 @@ int allset_ln_res_bwd_pma(const float* gy, int64_t ldg, const float* x, int64_t 
                           const float* gamma, const float* beta, float* gs, int64_t ldgs, float* partials, int64_t n_partials,
                           int64_t n, int64_t d, const float* pma_m, const float* pma_l, float* pma_stats, int64_t heads,
                           void* stream);
+/* The same for bf16 activations (channels per head = 8 x a power of two). */
+int allset_ln_res_bwd_pma_bf16_supported(int64_t d, int64_t heads);
+int allset_ln_res_bwd_pma_bf16(const void* gy, int64_t ldg, const void* x, int64_t ldx, const void* colb, const float* stats,
+                               const void* gamma, const void* beta, void* gs, int64_t ldgs, float* partials,
+                               int64_t n_partials, int64_t n, int64_t d, const float* pma_m, const float* pma_l,
+                               float* pma_stats, int64_t heads, void* stream);
 
 /* Fused tall-skinny Linear (K = in features, N = out features, both in {64, 128}; W row-major [N][K] contiguous):
  *   y = epi( pro(x) @ W^T + b ),  pro = [relu_in] -> [LayerNorm(gamma,beta,eps) if gamma != NULL] -> [dropout p_in],

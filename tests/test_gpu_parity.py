@@ -474,6 +474,45 @@ def test_sharded_pma_merge_path_bf16(device, monkeypatch):
     assert float((g1 - g0).abs().mean()) < 0.05 * float(g0.abs().mean()) + 1e-3
 
 
+@pytest.mark.parametrize("heads,hidden", [(4, 256), (1, 64), (4, 128)])
+def test_pma_pooling_and_ln0_as_one_node_equals_the_separate_nodes_bf16(heads, hidden, device, monkeypatch):
+    """The same in the bf16 regime (allset_ln_res_bwd_pma_bf16): the statistics are computed from the gradient rows as stored,
+    so outputs are identical and gradients agree to bf16 rounding of the parameter sums."""
+    from allset_amd import PMA, Incidence, ops
+    from allset_amd import functional as AF
+    torch.manual_seed(3 + heads)
+    n_s, n_t, nnz = 900, 400, 6000
+    ei = torch.stack([torch.randint(0, n_s, (nnz,)), torch.randint(0, n_t - 20, (nnz,))]).to(device)
+    inc = Incidence.from_edge_index(ei, n_src=n_s, n_dst=n_t)
+    pma = PMA(hidden, hidden, hidden, 2, heads=heads).to(device).to(torch.bfloat16)
+    x = torch.randn(n_s, hidden, device=device).to(torch.bfloat16)
+    G = torch.randn(n_t, hidden, device=device).to(torch.bfloat16)
+
+    def run():
+        for p in pma.parameters():
+            p.grad = None
+        xd = x.clone().requires_grad_(True)
+        out = pma(xd, inc)
+        out.backward(G)
+        return out.detach(), xd.grad, {k: p.grad.clone() for k, p in pma.named_parameters() if p.grad is not None}
+
+    calls = []
+    real = ops.pma_bwd_stats
+    monkeypatch.setattr(ops, "pma_bwd_stats", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    assert AF.pma_pool_ln0_supported(x, heads)
+    o1, g1, p1 = run()
+    assert not calls, "the joint node must not launch the separate statistics pass"
+    monkeypatch.setattr(AF, "pma_pool_ln0_supported", lambda *a, **k: False)
+    o0, g0, p0 = run()
+    assert calls
+    torch.testing.assert_close(o1, o0, rtol=0, atol=0)
+    torch.testing.assert_close(g1.float(), g0.float(), rtol=2e-2, atol=2e-2 * max(1e-3, float(g0.float().abs().max())))
+    assert p0.keys() == p1.keys()
+    for k in p0:
+        torch.testing.assert_close(p1[k].float(), p0[k].float(), rtol=2e-2, atol=2e-2 * max(1e-3, float(p0[k].float().abs().max())),
+                                   msg=lambda m: f"{k}: {m}")
+
+
 @pytest.mark.parametrize("heads,hidden", [(4, 128), (1, 64), (8, 256)])
 def test_pma_pooling_and_ln0_as_one_node_equals_the_separate_nodes(heads, hidden, device, monkeypatch):
     """The joint pooling + ln0 node (backward statistics written by ln0's backward kernel, allset_ln_res_bwd_pma) against
