@@ -85,6 +85,123 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(
   }
 }
 
+// Widths the 16-byte kernels do not take (d > 256 or d % 4 != 0, e.g. 1433 raw features) up to 64 * NS columns: one wave
+// per row, the whole row in NS registers per lane -- every load of the row is issued before the first is consumed, the
+// statistics come from the registers, one pass over memory (the scalar kernel below makes three dependent passes).
+template <int NS>
+__global__ __launch_bounds__(kBlock) void ln_fwd_rows_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, int relu_in, float p, uint64_t seed, float* __restrict__ y, int64_t ldy,
+    float* __restrict__ stats, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = lane_id();
+  const float* xr = x + row * ldx;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  float v[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int c = k * kWave + lane;
+    v[k] = c < d ? xr[c] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) { if (relu_in) v[k] = fmaxf(v[k], 0.f); s += v[k]; }
+  const float mean = group_sum<kWave>(s) / static_cast<float>(d);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int c = k * kWave + lane;
+    v[k] = c < d ? v[k] - mean : 0.f;
+    q = fmaf(v[k], v[k], q);
+  }
+  const float rstd = rsqrtf(group_sum<kWave>(q) / static_cast<float>(d) + eps);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int c = k * kWave + lane;
+    if (c < d) {
+      float o = fmaf(v[k] * rstd, gamma[c], beta[c]);
+      if (p > 0.f) o *= keep_scale(seed, row * d + c, thr, inv_keep);
+      y[row * ldy + c] = o;
+    }
+  }
+  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+
+// Its backward: persistent waves, one row per wave and trip, gy and x rows in registers, dgamma / dbeta accumulated per lane
+// over the wave's rows; the block's waves are combined through LDS in a fixed order (deterministic, no atomics).
+template <int NS>
+__global__ __launch_bounds__(kBlock) void ln_bwd_rows_kernel(
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ stats, const float* __restrict__ gamma, int relu_in, float p, uint64_t seed,
+    float* __restrict__ gx, int64_t ldgx, float* __restrict__ part, int64_t n, int d, const uint64_t* __restrict__ seed_base) {
+  seed = resolve_seed(seed_base, seed);
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t thr = drop_threshold(p);
+  const float inv_d = 1.f / static_cast<float>(d);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  __shared__ float red[kWavesPerBlock][2][NS * kWave];
+  float dg[NS], db[NS], gm[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int c = k * kWave + lane;
+    dg[k] = 0.f; db[k] = 0.f;
+    gm[k] = c < d ? gamma[c] : 0.f;
+  }
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; row < n; row += stride) {
+    const float* xr = x + row * ldx;
+    const float* gr = gy + row * ldg;
+    float xv[NS], gv[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int c = k * kWave + lane;
+      xv[k] = c < d ? xr[c] : 0.f;
+      gv[k] = c < d ? gr[c] : 0.f;
+    }
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int c = k * kWave + lane;
+      const bool pos = xv[k] > 0.f;
+      const float t = relu_in ? fmaxf(xv[k], 0.f) : xv[k];
+      const float xh = c < d ? (t - mean) * rstd : 0.f;
+      if (p > 0.f && c < d) gv[k] *= keep_scale(seed, row * d + c, thr, inv_keep);
+      dg[k] = fmaf(gv[k], xh, dg[k]);
+      db[k] += gv[k];
+      const float gh = gv[k] * gm[k];
+      s1 += gh;
+      s2 = fmaf(gh, xh, s2);
+      gv[k] = gh;
+      xv[k] = (relu_in && !pos) ? __int_as_float(0x7fc00000) : xh;      // NaN marks "relu closed": gx = 0 there
+    }
+    if (gx != nullptr) {
+      s1 = group_sum<kWave>(s1) * inv_d;
+      s2 = group_sum<kWave>(s2) * inv_d;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int c = k * kWave + lane;
+        if (c < d) gx[row * ldgx + c] = (xv[k] != xv[k]) ? 0.f : rstd * (gv[k] - s1 - xv[k] * s2);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) { red[wave][0][k * kWave + lane] = dg[k]; red[wave][1][k * kWave + lane] = db[k]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * NS * kWave; t += kBlock) {
+    const int which = t / (NS * kWave), c = t % (NS * kWave);
+    if (c < d) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWavesPerBlock; ++w) sum += red[w][which][c];
+      part[(static_cast<int64_t>(blockIdx.x) * 2 + which) * d + c] = sum;
+    }
+  }
+}
+
 // generic width: one wave per row, three passes over the row (L1/L2 resident), scalar accesses
 __global__ __launch_bounds__(kBlock) void ln_fwd_generic_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1504,7 +1621,11 @@ extern "C" int allset_ln_fwd(const float* x, int64_t ldx, const float* gamma, co
     }
   } else {
     const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
-    ln_fwd_generic_kernel<<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
+    if (d <= 8 * kWave) ln_fwd_rows_kernel<8><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
+    else if (d <= 16 * kWave) ln_fwd_rows_kernel<16><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
+    else if (d <= 24 * kWave) ln_fwd_rows_kernel<24><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
+    else if (d <= 32 * kWave) ln_fwd_rows_kernel<32><<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
+    else ln_fwd_generic_kernel<<<grid, kBlock, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p, seed, y, ldy, stats, n, di, seed_base);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
@@ -1561,7 +1682,10 @@ extern "C" int allset_ln_bwd(const float* gy, int64_t ldg, const float* x, int64
     if (n_partials > grid)
       ALLSET_HIP_CHECK(hipMemsetAsync(partials + static_cast<size_t>(grid) * 2 * d, 0,
                                       static_cast<size_t>(n_partials - grid) * 2 * d * sizeof(float), st));
-    ln_bwd_generic_kernel<<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base);
+    if (d <= 8 * kWave) ln_bwd_rows_kernel<8><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base);
+    else if (d <= 16 * kWave) ln_bwd_rows_kernel<16><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base);
+    else if (d <= 24 * kWave) ln_bwd_rows_kernel<24><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base);
+    else ln_bwd_generic_kernel<<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, stats, gamma, relu_in, p, seed, gx, ldgx, partials, n, di, seed_base);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
