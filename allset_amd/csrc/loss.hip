@@ -1,0 +1,102 @@
+// The loss of the reference's training loop (train.py:479-480: log_softmax over classes, NLLLoss over the train split) as two
+// small kernels -- at dataset scale (Cora: 2708 x 7 logits) the torch composition is ~8 launches of 5-16 us each, a tenth of
+// the whole graphed training step.  Rows are selected by a 0/1 weight per row (the train split as a mask), so the gradient
+// kernel writes every row of d loss / d logits (zeros outside the split) and nothing needs a scatter.
+//   loss = inv_count * sum_r w[r] * (logsumexp(logits[r, :]) - logits[r, y[r]])
+#include "common.h"
+
+#include <float.h>
+
+namespace allset {
+
+constexpr int kLossBlock = 256;
+
+__device__ __forceinline__ float row_lse(const float* __restrict__ row, int C) {
+  float m = -FLT_MAX;
+  for (int c = 0; c < C; ++c) m = fmaxf(m, row[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += __expf(row[c] - m);
+  return m + __logf(s);
+}
+
+__global__ __launch_bounds__(kLossBlock) void nll_fwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ y, const float* __restrict__ w,
+                                                            float inv_count, float* __restrict__ partials, int64_t n, int C) {
+  __shared__ float red[kLossBlock / kWave];
+  float acc = 0.f;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kLossBlock + threadIdx.x; r < n; r += static_cast<int64_t>(gridDim.x) * kLossBlock) {
+    const float wr = w ? w[r] : 1.f;
+    if (wr != 0.f) {
+      const float* row = logits + r * ld;
+      acc += wr * (row_lse(row, C) - row[y[r]]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLossBlock / kWave; ++k) s += red[k];
+    partials[blockIdx.x] = s * inv_count;
+  }
+}
+
+__global__ __launch_bounds__(kLossBlock) void nll_bwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                            const int64_t* __restrict__ y, const float* __restrict__ w,
+                                                            float inv_count, const float* __restrict__ gout,
+                                                            float* __restrict__ glogits, int64_t ldg, int64_t n, int C) {
+  const float scale = inv_count * (gout ? gout[0] : 1.f);
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kLossBlock + threadIdx.x; r < n; r += static_cast<int64_t>(gridDim.x) * kLossBlock) {
+    const float wr = (w ? w[r] : 1.f) * scale;
+    float* g = glogits + r * ldg;
+    if (wr == 0.f) {
+      for (int c = 0; c < C; ++c) g[c] = 0.f;
+      continue;
+    }
+    const float* row = logits + r * ld;
+    const float lse = row_lse(row, C);
+    const int64_t t = y[r];
+    for (int c = 0; c < C; ++c) g[c] = wr * (__expf(row[c] - lse) - (c == t ? 1.f : 0.f));
+  }
+}
+
+static inline unsigned loss_grid(int64_t n) {
+  int64_t b = (n + kLossBlock - 1) / kLossBlock;
+  if (b > 256) b = 256;
+  return static_cast<unsigned>(b < 1 ? 1 : b);
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_nll_partials(int64_t n, int64_t* n_partials) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && n_partials != nullptr, "nll_partials: bad argument");
+  *n_partials = loss_grid(n);
+  return ALLSET_OK;
+}
+
+extern "C" int allset_nll_logsoftmax_fwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
+                                         float* partials, int64_t n_partials, int64_t n, int64_t C, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && C >= 1 && C < INT32_MAX && ld >= C, "nll_logsoftmax_fwd: bad size");
+  ALLSET_REQUIRE(partials != nullptr && n_partials == loss_grid(n), "nll_logsoftmax_fwd: partials must hold allset_nll_partials(n) floats");
+  ALLSET_REQUIRE(n == 0 || (logits && y), "nll_logsoftmax_fwd: null pointer");
+  nll_fwd_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, w, inv_count, partials, n, static_cast<int>(C));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_nll_logsoftmax_bwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
+                                         const float* gout, float* glogits, int64_t ldg, int64_t n, int64_t C, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && C >= 1 && C < INT32_MAX && ld >= C && ldg >= C, "nll_logsoftmax_bwd: bad size");
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(logits && y && glogits, "nll_logsoftmax_bwd: null pointer");
+  nll_bwd_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, w, inv_count, gout, glogits, ldg, n, static_cast<int>(C));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

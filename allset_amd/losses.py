@@ -1,0 +1,67 @@
+"""The loss of the reference's training loop -- ``NLLLoss()(F.log_softmax(out, dim=1)[train_idx], y[train_idx])``
+(``/root/reference/src/train.py:479-480``) -- as one forward and one backward kernel (``csrc/loss.hip``).
+
+At dataset scale the torch composition (log_softmax, two index kernels, nll forward / backward, a reduction, softmax
+backward) is ~8 launches of 5-16 us, a tenth of a hipGraph-replayed Cora step.  The split is passed as a 0/1 weight per row
+(:func:`split_mask`), so the gradient kernel writes every row of ``d loss / d logits`` and no scatter is needed.
+Device fp32 logits only; anything else (CPU tensors in unit tests) runs the reference composition.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_int64
+
+import torch
+import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import check, ptr, stream_of
+
+Tensor = torch.Tensor
+
+
+def split_mask(idx: Tensor, n: int) -> Tensor:
+    """float32 [n] with 1 at the rows of ``idx`` (unique row ids, as the reference's splits are)."""
+    w = torch.zeros(n, dtype=torch.float32, device=idx.device)
+    w[idx] = 1.0
+    return w
+
+
+class _NllLogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y, w, inv_count):
+        dev = logits.device
+        n, C = logits.shape
+        lib = _lib.load()
+        npart = c_int64(0)
+        check(lib.allset_nll_partials(n, byref(npart)), "allset_nll_partials")
+        partials = torch.empty(npart.value, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.allset_nll_logsoftmax_fwd(ptr(logits), logits.stride(0), ptr(y), ptr(w), inv_count, ptr(partials), npart.value,
+                                                n, C, stream_of(dev)), "allset_nll_logsoftmax_fwd")
+        ctx.save_for_backward(logits, y, w)
+        ctx.inv_count = inv_count
+        return partials.sum() if npart.value > 1 else partials[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        logits, y, w = ctx.saved_tensors
+        dev = logits.device
+        n, C = logits.shape
+        g = torch.empty((n, C), dtype=torch.float32, device=dev)
+        gout = gout.reshape(1).float().contiguous()
+        with torch.cuda.device(dev):
+            check(_lib.load().allset_nll_logsoftmax_bwd(ptr(logits), logits.stride(0), ptr(y), ptr(w), ctx.inv_count, ptr(gout), ptr(g), C,
+                                                        n, C, stream_of(dev)), "allset_nll_logsoftmax_bwd")
+        return g, None, None, None
+
+
+def nll_log_softmax(logits: Tensor, y: Tensor, mask: Tensor, count: float) -> Tensor:
+    """``mean over the rows with mask == 1 of -log_softmax(logits)[r, y[r]]`` -- ``count`` = number of such rows (a host
+    number, known when the split is made: no device read-back per step).  ``y``: int64 class per row, for all rows."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1:
+        return _NllLogSoftmax.apply(logits, y.contiguous(), mask.contiguous(), 1.0 / float(count))
+    out = F.log_softmax(logits.float(), dim=1)
+    picked = out.gather(1, y.view(-1, 1)).squeeze(1)
+    return -(picked * mask).sum() / float(count)

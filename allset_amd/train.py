@@ -363,7 +363,6 @@ def run(args) -> dict:
     model, data = model.to(device), data.to(device)
     num_params = count_parameters(model)
     logger = Logger(args.runs, args)
-    criterion = nn.NLLLoss()
     runtimes = []
     for r in range(args.runs):
         t0 = time.time()
@@ -373,11 +372,14 @@ def run(args) -> dict:
         # for graph mode, instead of ~2 tiny kernels per parameter for the bias corrections)
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd, capturable=bool(args.hip_graph),
                                      fused=True)
+        # the train-split loss as one forward and one backward kernel (allset_amd/losses.py): same value as
+        # criterion(F.log_softmax(out, dim=1)[train_idx], y[train_idx]), the split as a 0/1 row mask made once per run
+        from .losses import nll_log_softmax, split_mask
+        train_mask, n_train = split_mask(split_idx['train'], data.y.shape[0]), int(split_idx['train'].numel())
+        y_all = data.y.long()
         if args.hip_graph:                     # same loop, two graph launches per epoch instead of ~400 kernel launches
             from .graphs import GraphedForward, GraphedTrainStep
-            train_idx, y_train = split_idx['train'], data.y[split_idx['train']]
-            graphed_step = GraphedTrainStep(
-                model, data, lambda logits: criterion(F.log_softmax(logits, dim=1)[train_idx], y_train), optimizer)
+            graphed_step = GraphedTrainStep(model, data, lambda logits: nll_log_softmax(logits, y_all, train_mask, n_train), optimizer)
             graphed_eval = GraphedForward(model, data)
         for epoch in range(args.epochs):
             if args.hip_graph:
@@ -386,8 +388,7 @@ def run(args) -> dict:
             else:
                 model.train()
                 optimizer.zero_grad()
-                out = F.log_softmax(model(data), dim=1)
-                loss = criterion(out[split_idx['train']], data.y[split_idx['train']])
+                loss = nll_log_softmax(model(data), y_all, train_mask, n_train)
                 loss.backward()
                 optimizer.step()
                 result = evaluate(model, data, split_idx, eval_acc)

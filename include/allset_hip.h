@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -245,6 +245,16 @@ int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void
 int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out, int64_t lda,
                            const void* W, const float* galpha, const void* aux_w, const void* acc_in, int64_t ldacc,
                            void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream);
+
+/* The training loop's loss (reference train.py:479-480: F.log_softmax over the classes, NLLLoss over the train split):
+ *   loss = inv_count * sum_r w[r] * (logsumexp(logits[r, :]) - logits[r, y[r]])       w: 0/1 per row (NULL = all rows)
+ * fwd writes allset_nll_partials(n) partial sums (the caller adds them); bwd writes d loss / d logits for EVERY row (zeros
+ * where w is 0), scaled by gout[0] (a device scalar, NULL = 1).  y: int64 class per row (read only where w != 0). */
+int allset_nll_partials(int64_t n, int64_t* n_partials);
+int allset_nll_logsoftmax_fwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
+                              float* partials, int64_t n_partials, int64_t n, int64_t C, void* stream);
+int allset_nll_logsoftmax_bwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
+                              const float* gout, float* glogits, int64_t ldg, int64_t n, int64_t C, void* stream);
 
 /* Same with an explicit kernel choice (variant as in allset_pma_fwd_ex; nnz / n_s decides in auto mode). */
 int allset_pma_bwd_src_ex(int dtype, int variant, int64_t nnz, const int32_t* row_order, const int32_t* rowptrT, const int32_t* colT,

@@ -789,3 +789,23 @@ def test_reduce_partials_with_a_row_stride_and_bf16_output(P, M, stride, dtype, 
         assert got.dtype == torch.bfloat16
         err = (got.double() - ref).abs()
         assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-4).all())
+
+
+@pytest.mark.parametrize("n,C,frac", [(1, 2, 1.0), (2708, 7, 0.5), (3327, 6, 0.3), (70000, 40, 0.1), (300, 67, 1.0)])
+def test_fused_nll_log_softmax_matches_the_reference_composition(n, C, frac, device):
+    """allset_nll_logsoftmax_* against NLLLoss()(F.log_softmax(out, 1)[idx], y[idx]) (reference train.py:479-480): value and
+    the gradient of every row (zeros outside the split), with a non-unit upstream gradient."""
+    from allset_amd.losses import nll_log_softmax, split_mask
+    g = torch.Generator().manual_seed(n + C)
+    logits = (3 * torch.randn(n, C, generator=g)).to(device)
+    y = torch.randint(0, C, (n,), generator=g).to(device)
+    k = max(1, int(n * frac))
+    idx = torch.randperm(n, generator=g)[:k].to(device)
+    a = logits.clone().requires_grad_(True)
+    loss = nll_log_softmax(a, y, split_mask(idx, n), k)
+    (loss * 1.7).backward()
+    b = logits.double().requires_grad_(True)
+    ref = F.nll_loss(F.log_softmax(b, dim=1)[idx], y[idx])
+    (ref * 1.7).backward()
+    torch.testing.assert_close(loss.double(), ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad.double(), b.grad, rtol=1e-5, atol=1e-7)

@@ -19,7 +19,9 @@ data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(dev), edge_index=torch.f
                        norm=torch.from_numpy(case["norm"]).to(dev))
 y = torch.randint(0, case["args"].num_classes, (data.x.shape[0],), device=dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
-g = GraphedTrainStep(model, data, lambda out: F.nll_loss(F.log_softmax(out, dim=1), y), opt)
+from allset_amd.losses import nll_log_softmax
+ones = torch.ones(data.x.shape[0], device=dev)
+g = GraphedTrainStep(model, data, lambda out: nll_log_softmax(out, y, ones, data.x.shape[0]), opt)
 torch.cuda.synchronize()
 for _ in range(REPLAYS):
     g()

@@ -35,7 +35,9 @@ for name in ("cora_ds_add", "citeseer_pma_h4"):
     # the same two loops as hipGraph replays (allset_amd/graphs.py)
     from allset_amd.graphs import GraphedForward, GraphedTrainStep
     opt_c = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
-    gstep = GraphedTrainStep(model, data, lambda out: F.nll_loss(F.log_softmax(out, dim=1), y), opt_c)
+    from allset_amd.losses import nll_log_softmax
+    ones = torch.ones(n, device=dev)
+    gstep = GraphedTrainStep(model, data, lambda out: nll_log_softmax(out, y, ones, n), opt_c)   # the driver's loss (allset_amd/train.py)
     gfwd = GraphedForward(model, data)
     for fn, label in ((gstep, "train step (graph)"), (gfwd, "eval forward (graph)")):
         for _ in range(5): fn()
