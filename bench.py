@@ -389,11 +389,15 @@ def main(argv=None, hooks=None):
     primary, other = resolve_modes(args, world)
 
     res = run_partition(args, primary, world, rank, dev, hooks)
-    res2 = None
+    res2, res2_error = None, None
     if other is not None:
         if not cpu_mode:
             torch.cuda.empty_cache()
-        res2 = run_partition(args, other, world, rank, dev, hooks)
+        try:                                    # the secondary partition must not cost the primary its line
+            res2 = run_partition(args, other, world, rank, dev, hooks)
+        except Exception as exc:                # noqa: BLE001 -- reported in the line, the primary result stands
+            res2_error = f"{type(exc).__name__}: {exc}"
+            print(f"[bench] partition {other!r} failed on rank {rank}: {res2_error}", file=sys.stderr, flush=True)
 
     line = None
     if rank == 0:
@@ -450,11 +454,15 @@ def main(argv=None, hooks=None):
                             "unit": "edges*d/s", "note": "gather/segment-reduce kernel time per step (HIP events, rank 0): "
                             "the aggregation-only V->E->V fwd+bwd",
                             "kernels": {k: kernel_entry(v, args.steps) for k, v in agg_ks.items()}},
-            "dense_tail": {"ms_per_step": dense_ms, "note": "HIP dense-tail kernels per step (fused norm+Linear forward; ONE backward "
+            "dense_tail": {"ms_per_step": dense_ms, "note": ("HIP dense-tail kernels per step (fused norm+Linear forward; ONE backward "
                            "kernel per Linear producing input gradient, LayerNorm parameter gradients and the weight / bias "
                            "gradient from a single read of gy and x). fp32 in, fp32 out, fp32-accurate arithmetic on the bf16 "
                            "matrix pipe: operands split exactly into 3 bf16, 6 of 9 products accumulated in fp32 (error <= "
-                           "native fp32 MFMA, tests/test_gpu_dense.py); HBM-bound: gbps = algorithmic activation bytes / time",
+                           "native fp32 MFMA, tests/test_gpu_dense.py); HBM-bound: gbps = algorithmic activation bytes / time")
+                           if args.dtype == "f32" else
+                           ("HIP dense-tail kernels per step, bf16 in / out with fp32 accumulation: Linear forward / backward-data "
+                            "with relu, folded logits, relu mask and gradient-branch sums in the same pass (csrc/fused_bf16.hip), "
+                            "full-width weight gradient, add+LayerNorm kernels; gbps = algorithmic activation bytes / time"),
                            "kernels": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in dense_ks.items()}},
         }
         if world > 1 or res2 is not None:
@@ -463,6 +471,8 @@ def main(argv=None, hooks=None):
             if res2 is not None:
                 parts[other] = {"ms_per_step": res2["ms_per_step"], "value": res2["value"],
                                 "parallelism": parallelism_label(args, other, world), "is_value": False}
+            elif res2_error is not None:
+                parts[other] = {"error": res2_error, "parallelism": parallelism_label(args, other, world), "is_value": False}
             parts["note"] = ("`rows` = hyperedge shards, the partition BASELINE.json's north star names; `columns` = column-sharded "
                              "aggregation (DESIGN.md section 7.2). Same global hypergraph, same K steps, separate timed regions; "
                              "`value` / `ms_per_step` of the line are those of the entry with is_value = true")
