@@ -606,17 +606,6 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
     return torch.cat([dec2(get()) for get in _unstage(vc, K, w, group)])
 
 
-_SLOT_INDEX = {}
-
-
-def _slot_index(heads: int, world: int, device) -> Tensor:
-    """Device copy of ``head_slots(heads, world)[1]``, made once (a per-step host-to-device copy would also break capture)."""
-    key = (heads, world, str(device))
-    if key not in _SLOT_INDEX:
-        _SLOT_INDEX[key] = torch.tensor(head_slots(heads, world)[1], device=device)
-    return _SLOT_INDEX[key]
-
-
 def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, dropout: float = 0.0,
                          training: bool = False, group=None, kernels=HipPmaKernels, chunks: int = 1,
                          dropout_out: Optional[float] = None) -> Tensor:
@@ -630,11 +619,16 @@ def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedH
 
     def project(p):
         hl, slots = head_slots(p.heads, w)
-        idx = None if slots == list(range(p.heads)) else _slot_index(p.heads, w, x_owned.device)
+        per = 1 if slots == list(range(p.heads)) else w // p.heads          # ranks sharing one head (P > H)
 
         def f(t):
             V, alpha = p.project(t)                                  # [rows, H*C], [rows, H]: dense, owned rows
-            return V, (alpha if idx is None else alpha[:, idx]).contiguous()   # a shared head's logits go to each sharer
+            if per > 1:
+                # a shared head's logits go to each sharer: every column `per` times in a row.  As expand + reshape, whose
+                # backward is a sum over the copies -- `alpha[:, idx]` with an index tensor costs a sort-based index_put in
+                # backward (2.8 ms per direction at 1M rows, the third-largest kernel of the N = 8 step)
+                alpha = alpha.unsqueeze(2).expand(-1, p.heads, per).reshape(alpha.shape[0], p.heads * per)
+            return V, alpha.contiguous()
         return f, hl
 
     p1, p2 = v2e_conv.prop, e2v_conv.prop

@@ -20,7 +20,7 @@ d, n_loc = 128, 1_000_000
 model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
 mode = sys.argv[2] if len(sys.argv) > 2 else "rows"
 LINK = 60e9
-for world in (1, 2, 4, 8):
+for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split(",")):
     adist._rows_to_cols = (lambda x, group=None, w=world: x if w == 1 else adist._pack(x, w).view(w * x.shape[0], x.shape[1] // w))
     adist._cols_to_rows = (lambda x, group=None, w=world: x if w == 1 else adist._unpack(x.view(w, x.shape[0] // w, x.shape[1])))
     adist._all_gather_rows = (lambda x, group=None, w=world: x if w == 1 else x.repeat(w, *([1] * (x.dim() - 1))))
@@ -57,11 +57,17 @@ for world in (1, 2, 4, 8):
                 adist.sharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
         out.backward(G); opt.step()
     for _ in range(3): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    from allset_amd import ops as _ops
+    timer = _ops.KernelTimer() if os.environ.get("SIM_KERNELS") else None     # per-kernel HIP-event times of the 10 steps
+    torch.cuda.synchronize(); _ops.set_kernel_timer(timer); t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
-    if world == 1:
-        t1 = ms
+    _ops.set_kernel_timer(None)
+    if timer is not None:
+        for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
+            print(f"      {k:22s} {v['calls'] / 10:5.1f} calls/step  {v['avg_ms']:7.3f} ms avg  {v['total_ms'] / 10:7.3f} ms/step")
+    if world == 1 or "t1" not in globals():
+        t1 = ms if world == 1 else float(os.environ.get("SIM_T1_MS", "nan"))
     per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d)     # received per step (fwd + bwd)
     per_link = per_rank / max(world - 1, 1)
     comm = per_link / LINK * 1e3
