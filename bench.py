@@ -77,9 +77,12 @@ def parse_args(argv=None):
                     help="N > 1: which partition is timed as `value` ('auto' = allset_amd.dist.choose_sharding)")
     ap.add_argument("--partitions", default="both", choices=["both", "primary"],
                     help="N > 1: 'both' also times the other partition in a second region and reports it under `partitions`")
-    ap.add_argument("--pipeline-chunks", type=int, default=0,
+    ap.add_argument("--pipeline-chunks", type=int, default=1,
                     help="--shard columns: chunks of owned rows whose all-to-alls overlap the other chunks' dense work "
-                         "(1 = off, 0 = allset_amd.dist.auto_chunks: 4 at 1M rows per GPU, 1 below 500k)")
+                         "(1 = off, the default: blocking all-to-alls; 0 = allset_amd.dist.auto_chunks: 4 at 1M rows per GPU, "
+                         "1 below 500k).  Off by default since round 2: on one GPU the 4-chunk machinery costs +4.8 ms per step "
+                         "(AllDeepSets) and turns the AllSetTransformer step host-bound (profiles/r02_colshard_chunks.txt) against "
+                         "<= 6 ms of exchange it can hide at N = 8, and it has never run on more than one rank")
     ap.add_argument("--self-loops", action="store_true",
                     help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
@@ -341,8 +344,8 @@ def parallelism_label(args, mode, world):
         return "single GPU"
     if mode == "rows":
         return f"hyperedge-shard x{world} (all-gather + reduce-scatter of the [n_V, d] vertex table per direction)"
-    return (f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; all-to-all exchange in "
-            f"{args.pipeline_chunks} overlapped chunks)")
+    how = f"in {args.pipeline_chunks} overlapped chunks" if args.pipeline_chunks > 1 else "blocking"
+    return f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; all-to-all exchange {how})"
 
 
 def kernel_entry(v, steps, rows=None, d=None, name=None):
