@@ -444,3 +444,68 @@ def test_gemm_with_layer_norm_backward_epilogue_random(n, K, N, relu_in, p, use_
     torch.testing.assert_close(gx, gx_ref, rtol=1e-4, atol=1e-4 * sc)
     torch.testing.assert_close(dg, dg_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(dg_ref.abs().max())))
     torch.testing.assert_close(db, db_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(db_ref.abs().max())))
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 5000), K=st.sampled_from([128, 256]), N=st.sampled_from([128, 256]), relu=st.booleans(), aux=st.booleans(),
+       bias=st.booleans(), pad=st.sampled_from([0, 8, 64]), sd=st.integers(0, 2 ** 31 - 1))
+def test_linear_bf16_forward_random(n, K, N, relu, aux, bias, pad, sd, device):
+    """csrc/fused_bf16.hip forward: random row counts, row-strided inputs, every fold; bound = one bf16 rounding of the fp32
+    reference on the same bf16 inputs."""
+    from allset_amd import dense
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sd)
+    big = torch.randn(n, K + pad, generator=g).to(torch.bfloat16).to(device)
+    x = big[:, pad:] if pad else big
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(device)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(device) if bias else None
+    aw = torch.randn(4, K, generator=g).to(torch.bfloat16).to(device) if aux else None
+    y, a = dense.linear_bf16_fwd(x, W, b, relu, aw, None)
+    ref = x.float() @ W.float().t() + (b.float() if bias else 0.0)
+    ref = F.relu(ref) if relu else ref
+    tol = ref.abs() * 2.0 ** -8 + 1e-3 * float(ref.abs().max()) * 2.0 ** -8 + 1e-30
+    assert bool(((y.float() - ref).abs() <= tol).all())
+    if aux:
+        torch.testing.assert_close(a, x.float() @ aw.float().t(), rtol=1e-5, atol=1e-5)
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 5000), O=st.sampled_from([128, 256]), I=st.sampled_from([128, 256]), mask=st.booleans(), acc=st.booleans(),
+       aux=st.booleans(), want_ga=st.booleans(), sd=st.integers(0, 2 ** 31 - 1))
+def test_linear_bf16_backward_random(n, O, I, mask, acc, aux, want_ga, sd, device):
+    from allset_amd import dense
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sd)
+    gy = torch.randn(n, O, generator=g).to(torch.bfloat16).to(device)
+    W = (torch.randn(O, I, generator=g) / O ** 0.5).to(torch.bfloat16).to(device)
+    y = F.relu(torch.randn(n, O, generator=g)).to(torch.bfloat16).to(device) if mask else None
+    a = torch.randn(n, I, generator=g).to(torch.bfloat16).to(device) if acc else None
+    ga4 = torch.randn(n, 4, generator=g).to(device) if aux else None
+    aw = torch.randn(4, I, generator=g).to(torch.bfloat16).to(device) if aux else None
+    gx, ga = dense.linear_bf16_bwd(gy, W, y, want_ga=want_ga and mask, acc_in=a, galpha=ga4, aux_w=aw)
+    ga_ref = torch.where(y.float() > 0, gy.float(), torch.zeros((), device=device)) if mask else gy.float()
+    if (want_ga and mask) or not mask:
+        assert torch.equal(ga.float(), ga_ref)
+    ref = ga_ref @ W.float() + (a.float() if acc else 0.0) + ((ga4 @ aw.float()) if aux else 0.0)
+    tol = ref.abs() * 2.0 ** -8 + 1e-3 * float(ref.abs().max()) * 2.0 ** -8 + 1e-30
+    assert bool(((gx.float() - ref).abs() <= tol).all())
+
+
+@settings(**COMMON)
+@given(n=st.integers(1, 4000), C=st.integers(1, 80), frac=st.floats(0.0, 1.0), sd=st.integers(0, 2 ** 31 - 1))
+def test_fused_loss_random(n, C, frac, sd, device):
+    from allset_amd.losses import nll_log_softmax
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sd)
+    logits = (4 * torch.randn(n, C, generator=g)).to(device)
+    yv = torch.randint(0, C, (n,), generator=g).to(device)
+    w = (torch.rand(n, generator=g) < frac).float().to(device)
+    cnt = max(1.0, float(w.sum()))
+    a = logits.clone().requires_grad_(True)
+    loss = nll_log_softmax(a, yv, w, cnt)
+    loss.backward()
+    b = logits.double().requires_grad_(True)
+    ref = -(F.log_softmax(b, dim=1).gather(1, yv.view(-1, 1)).squeeze(1) * w.double()).sum() / cnt
+    ref.backward()
+    torch.testing.assert_close(loss.double(), ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad.double(), b.grad, rtol=1e-5, atol=1e-7)
