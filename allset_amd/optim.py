@@ -1,0 +1,77 @@
+"""``torch.optim.Adam`` (what the reference trains with, ``/root/reference/src/train.py:469``) as ONE kernel launch per step
+(``csrc/optim.hip``) plus one ``_foreach_add_`` on the step counters.
+
+At dataset scale the parameter set is ~20 small tensors; torch's fused multi-tensor Adam in capturable mode spends ~40 us on
+them -- a tenth of a hipGraph-replayed Cora step.  Same arithmetic (non-amsgrad, L2 ``weight_decay``, bias corrections from a
+per-parameter step counter kept on the device, so the optimizer is capturable by construction); parameters that are not fp32
+device tensors fall back to ``torch.optim.Adam``'s functional form.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable
+
+import torch
+
+from . import _lib
+from ._lib import check, stream_of
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` on fp32 device parameters."""
+
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        # `capturable` is what allset_amd.graphs.GraphedTrainStep checks: this optimizer keeps its step counters on the device
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        cap = int(lib.allset_adam_max_tensors())
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            live = [p for p in group["params"] if p.grad is not None]
+            fast = [p for p in live if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                    and p.grad.dtype == torch.float32 and not p.grad.is_sparse]
+            slow = [p for p in live if all(p is not q for q in fast)]
+            if slow:     # anything else: torch's own functional Adam on the same state layout
+                sts = [self._state(p) for p in slow]
+                torch.optim.adam.adam(slow, [p.grad for p in slow], [s["exp_avg"] for s in sts], [s["exp_avg_sq"] for s in sts], [],
+                                      [s["step"] for s in sts], amsgrad=False, beta1=b1, beta2=b2, lr=group["lr"],
+                                      weight_decay=group["weight_decay"], eps=group["eps"], maximize=False, capturable=True,
+                                      foreach=None, fused=None)
+            if not fast:
+                continue
+            sts = [self._state(p) for p in fast]
+            torch._foreach_add_([s["step"] for s in sts], 1.0)
+            by_dev = {}
+            for p, s in zip(fast, sts):
+                by_dev.setdefault(p.device, []).append((p, s))
+            for dev, items in by_dev.items():
+                for k0 in range(0, len(items), cap):
+                    part = items[k0:k0 + cap]
+                    n = len(part)
+                    arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+                    with torch.cuda.device(dev):
+                        check(lib.allset_adam_step(arr([p.data_ptr() for p, _ in part]), arr([p.grad.data_ptr() for p, _ in part]),
+                                                   arr([s["exp_avg"].data_ptr() for _, s in part]),
+                                                   arr([s["exp_avg_sq"].data_ptr() for _, s in part]),
+                                                   arr([s["step"].data_ptr() for _, s in part]),
+                                                   (ctypes.c_int64 * n)(*[p.numel() for p, _ in part]), n, float(group["lr"]),
+                                                   float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                   stream_of(dev)), "allset_adam_step")
+        return loss

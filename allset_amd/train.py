@@ -368,10 +368,10 @@ def run(args) -> dict:
         t0 = time.time()
         split_idx = {k: v.to(device) for k, v in splits[r].items()}
         model.reset_parameters()
-        # same Adam as the reference (train.py:469); fused: one multi-tensor kernel instead of ~15 (and, when capturable
-        # for graph mode, instead of ~2 tiny kernels per parameter for the bias corrections)
-        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd, capturable=bool(args.hip_graph),
-                                     fused=True)
+        # same Adam as the reference (train.py:469) as one kernel launch over all parameters (allset_amd/optim.py: torch's fused
+        # capturable Adam takes ~40 us for the ~20 small tensors of a Cora-sized model, a tenth of a replayed step)
+        from .optim import FusedAdam
+        optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
         # the train-split loss as one forward and one backward kernel (allset_amd/losses.py): same value as
         # criterion(F.log_softmax(out, dim=1)[train_idx], y[train_idx]), the split as a 0/1 row mask made once per run
         from .losses import nll_log_softmax, split_mask

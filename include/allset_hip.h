@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, adam_step) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -245,6 +245,15 @@ int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void
 int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out, int64_t lda,
                            const void* W, const float* galpha, const void* aux_w, const void* acc_in, int64_t ldacc,
                            void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream);
+
+/* torch.optim.Adam's update (reference train.py:469; non-amsgrad, L2 weight decay) for up to allset_adam_max_tensors() fp32
+ * tensors in ONE launch.  params / grads / exp_avg / exp_avg_sq / numel: HOST arrays of `count` device pointers / sizes (read
+ * during the call); steps: one DEVICE float per tensor holding its t >= 1, which the caller increments before each call (so a
+ * captured graph advances the bias corrections on replay).  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). */
+int allset_adam_max_tensors(void);
+int allset_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     const float* const* steps, const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, void* stream);
 
 /* The training loop's loss (reference train.py:479-480: F.log_softmax over the classes, NLLLoss over the train split):
  *   loss = inv_count * sum_r w[r] * (logsumexp(logits[r, :]) - logits[r, y[r]])       w: 0/1 per row (NULL = all rows)

@@ -809,3 +809,65 @@ def test_fused_nll_log_softmax_matches_the_reference_composition(n, C, frac, dev
     (ref * 1.7).backward()
     torch.testing.assert_close(loss.double(), ref, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a.grad.double(), b.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(wd, device):
+    """allset_amd.optim.FusedAdam against torch.optim.Adam (reference train.py:469): same trajectories over 6 steps, 60 tensors of
+    mixed sizes (more than one kernel table), one parameter without a gradient on alternate steps (its own step counter)."""
+    from allset_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 1433), (64,), (7, 64), (1,), (128, 128), (5000,)] * 10
+    pa = [torch.randn(*s, generator=g).to(device).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedAdam(pa, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    for it in range(6):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == 3 and it % 2 == 1:
+                a.grad, b.grad = None, None
+                continue
+            gr = torch.randn(a.shape, generator=g).to(device)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_fused_adam_in_a_captured_training_step(device):
+    """FusedAdam is capturable by construction: replays of a GraphedTrainStep over it are bit-identical to eager steps with the
+    same optimizer (step counters live on the device, the kernel's pointer table is static under capture).  (Against
+    torch.optim.Adam the per-step update agrees to rounding -- the test above -- but whole trajectories do not stay close:
+    Adam turns 1e-7 differences in near-zero gradients of the 1433-wide input layer into +-lr updates.)"""
+    import cases
+    from types import SimpleNamespace
+    from allset_amd import SetGNN
+    from allset_amd.graphs import GraphedTrainStep
+    from allset_amd.optim import FusedAdam
+    from allset_amd.losses import nll_log_softmax
+    case = cases.build_case("cora_ds_add")
+    torch.manual_seed(0)
+    m1 = SetGNN(case["args"]).to(device)
+    m1.reset_parameters()
+    import copy
+    m2 = copy.deepcopy(m1)
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(device), edge_index=torch.from_numpy(case["edge_index"]).to(device),
+                           norm=torch.from_numpy(case["norm"]).to(device))
+    n = data.x.shape[0]
+    y = torch.randint(0, case["args"].num_classes, (n,), device=device)
+    ones = torch.ones(n, device=device)
+    loss_fn = lambda out: nll_log_softmax(out, y, ones, n)
+    o1 = FusedAdam(m1.parameters(), lr=1e-3)
+    o2 = FusedAdam(m2.parameters(), lr=1e-3)
+    gstep = GraphedTrainStep(m1, data, loss_fn, o1, train_mode=False)     # dropout off: deterministic
+    m2.train(False)
+    d2 = SimpleNamespace(x=data.x, edge_index=data.edge_index.clone(), norm=data.norm)
+    for _ in range(4):
+        l1 = gstep()
+        o2.zero_grad()
+        l2 = loss_fn(m2(d2))
+        l2.backward()
+        o2.step()
+        assert torch.equal(l1, l2.detach())
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k

@@ -18,7 +18,8 @@ model.reset_parameters()
 data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(dev), edge_index=torch.from_numpy(case["edge_index"]).to(dev),
                        norm=torch.from_numpy(case["norm"]).to(dev))
 y = torch.randint(0, case["args"].num_classes, (data.x.shape[0],), device=dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
+from allset_amd.optim import FusedAdam
+opt = FusedAdam(model.parameters(), lr=1e-3)
 from allset_amd.losses import nll_log_softmax
 ones = torch.ones(data.x.shape[0], device=dev)
 g = GraphedTrainStep(model, data, lambda out: nll_log_softmax(out, y, ones, data.x.shape[0]), opt)

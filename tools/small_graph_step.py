@@ -34,7 +34,8 @@ for name in ("cora_ds_add", "citeseer_pma_h4"):
         print(f"{name:18s} {label:13s} {dt*1e3:7.3f} ms")
     # the same two loops as hipGraph replays (allset_amd/graphs.py)
     from allset_amd.graphs import GraphedForward, GraphedTrainStep
-    opt_c = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
+    from allset_amd.optim import FusedAdam
+    opt_c = FusedAdam(model.parameters(), lr=1e-3)
     from allset_amd.losses import nll_log_softmax
     ones = torch.ones(n, device=dev)
     gstep = GraphedTrainStep(model, data, lambda out: nll_log_softmax(out, y, ones, n), opt_c)   # the driver's loss (allset_amd/train.py)
