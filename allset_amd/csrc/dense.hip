@@ -599,23 +599,26 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
 constexpr int kRedSplit = 8;                   // row groups per workgroup (256 threads = 32 column quads x 8 groups)
 constexpr int kRedRows = 64;                   // rows per slab
 
+// `slabs_here` > 1: one workgroup walks that many slabs itself (small reductions: one launch instead of two levels).
 template <bool OUT_BF16>
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ part, int64_t P, int64_t M,
-                                                                float* __restrict__ out, int64_t row_stride) {
+                                                                float* __restrict__ out, int64_t row_stride, int slabs_here) {
   __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
   const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
   const int64_t c = (static_cast<int64_t>(blockIdx.x) * (kBlock / kRedSplit) + cq) * 4;
-  const int64_t p0 = static_cast<int64_t>(blockIdx.y) * kRedRows;
   float4 acc = make_float4(0, 0, 0, 0);
   if (c < M) {
-    float4 v[kRedRows / kRedSplit];
+    for (int sl = 0; sl < slabs_here; ++sl) {
+      const int64_t p0 = (static_cast<int64_t>(blockIdx.y) + sl) * kRedRows;
+      float4 v[kRedRows / kRedSplit];
 #pragma unroll
-    for (int i = 0; i < kRedRows / kRedSplit; ++i) {
-      const int64_t p = p0 + rg + static_cast<int64_t>(i) * kRedSplit;
-      v[i] = p < P ? *reinterpret_cast<const float4*>(part + p * row_stride + c) : make_float4(0, 0, 0, 0);
+      for (int i = 0; i < kRedRows / kRedSplit; ++i) {
+        const int64_t p = p0 + rg + static_cast<int64_t>(i) * kRedSplit;
+        v[i] = p < P ? *reinterpret_cast<const float4*>(part + p * row_stride + c) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < kRedRows / kRedSplit; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
     }
-#pragma unroll
-    for (int i = 0; i < kRedRows / kRedSplit; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
   }
   red[rg][cq] = acc;
   __syncthreads();
@@ -1848,18 +1851,22 @@ static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride
     return ALLSET_ERR_UNSUPPORTED;
   }
   const int64_t slabs = (P + kRedRows - 1) / kRedRows;
-  ALLSET_REQUIRE(slabs == 1 || scratch != nullptr, "reduce_partials: P > %d needs a scratch buffer of ceil(P/%d)*M floats", kRedRows, kRedRows);
+  ALLSET_REQUIRE(slabs == 1 || scratch != nullptr, "reduce_partials: P > %d needs a scratch buffer of ceil(P/%d)*M floats", kRedRows, kRedRows);   // (not touched by the one-launch path)
   ALLSET_REQUIRE(slabs <= kRedRows, "reduce_partials: at most %d partial rows", kRedRows * kRedRows);
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t quads = M / 4, per_block = kBlock / kRedSplit;
   const unsigned gx = static_cast<unsigned>((quads + per_block - 1) / per_block);
-  if (slabs == 1) {
-    if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride);
-    else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride);
+  // small reductions (dataset-scale steps are launch-bound: 16 of a Cora step's 63 kernels were these): one launch, each
+  // workgroup walks all slabs; large ones keep the two-level tree (1024 x 16.5k partials want every CU)
+  const bool one_launch = slabs == 1 || (slabs <= 8 && P * M <= (int64_t{1} << 21));
+  if (one_launch) {
+    const int sh = static_cast<int>(slabs);
+    if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride, sh);
+    else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride, sh);
   } else {
-    reduce_partials_kernel<false><<<dim3(gx, static_cast<unsigned>(slabs)), kBlock, 0, st>>>(part, P, M, scratch, row_stride);
-    if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M);
-    else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M);
+    reduce_partials_kernel<false><<<dim3(gx, static_cast<unsigned>(slabs)), kBlock, 0, st>>>(part, P, M, scratch, row_stride, 1);
+    if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M, 1);
+    else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M, 1);
   }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
