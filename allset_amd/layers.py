@@ -226,7 +226,7 @@ class PMA(nn.Module):
             # [n,in] x [in,H]: the weight gradient of this skinny Linear is a [H x n] x [n x in] product that the
             # library tiles badly (1.5 ms at n = 1M); dense.linear routes it to the split-K MFMA kernel
             hip = _on_hip(x) or (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16)
-            return dense.linear(x, w, b) if (hip and H % 4 == 0 and x.shape[1] % 4 == 0) else F.linear(x, w, b)
+            return dense.linear(x, w, b) if hip else F.linear(x, w, b)      # (odd H / widths: the padded weight gradient)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
     def project(self, x: Tensor) -> Tuple[Tensor, Tensor]:
