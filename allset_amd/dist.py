@@ -921,7 +921,10 @@ class ShardedSetGNN(torch.nn.Module):
                 x = self._layer(v2e, e2v, x, norm, dropout_out=0.0)      # relu(E2V(.)) -- the dropout comes after the tap
                 xs.append(x)
                 x = F.dropout(x, p=m.dropout, training=m.training)
-            x = m.GPRweights(torch.stack(xs, dim=-1)).squeeze(-1)
+            w = m.GPRweights.weight            # the weighted sum of the layer outputs (models.SetGNN.forward says why not a matmul)
+            x = xs[0] * w[0, 0]
+            for k in range(1, len(xs)):
+                x = x + xs[k] * w[0, k]
             return m.classifier(x)
         x = F.dropout(x_owned, p=0.2, training=m.training)                 # hard-coded input dropout (models.py:473)
         for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):

@@ -57,6 +57,23 @@ def _check_rows(x: Tensor, inc: Incidence) -> None:
                          f"and {inc.n_src}")
 
 
+class _RouteWeights(torch.autograd.Function):
+    """``w[perm]`` for a PERMUTATION ``perm`` (edge-list order -> CSR order of a trainable per-incidence weight, LearnMask):
+    the backward of a permutation is the gather by its inverse -- torch's advanced-indexing backward is a sort-based
+    ``index_put`` (several radix-sort passes over nnz keys per call, ~1 ms at nnz = 16M)."""
+
+    @staticmethod
+    def forward(ctx, w, perm, inv_perm):
+        ctx.save_for_backward(inv_perm)
+        return w.index_select(0, perm)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (inv_perm,) = ctx.saved_tensors
+        return g.index_select(0, inv_perm), None, None
+
+
 class _SegReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, w_dst: Optional[Tensor], w_src: Optional[Tensor], inc: Incidence, reduce: int):
@@ -111,7 +128,7 @@ def deepsets_aggregate(x: Tensor, inc: Incidence, norm: Optional[Tensor] = None,
     _lib.require_device(x)
     _check_rows(x, inc)
     if norm is not None and norm.requires_grad:
-        w_dst = norm.reshape(-1).to(torch.float32)[inc.by_dst.perm.long()]     # differentiable routing
+        w_dst = _RouteWeights.apply(norm.reshape(-1).to(torch.float32), inc.perm_dst_long(), inc.inv_perm_dst())   # differentiable routing
         w_src = None
     else:
         w_dst, w_src = inc.weights(norm)

@@ -97,6 +97,20 @@ class Incidence:
             self._pos_dst_of_src = inv[self.by_src.perm.long()].contiguous()
         return self._pos_dst_of_src
 
+    def perm_dst_long(self) -> Tensor:
+        """``by_dst.perm`` as int64 (what ``index_select`` takes), made once."""
+        if getattr(self, "_perm_dst_long", None) is None:
+            self._perm_dst_long = self.by_dst.perm.long()
+        return self._perm_dst_long
+
+    def inv_perm_dst(self) -> Tensor:
+        """int64[nnz]: position in ``by_dst`` of each incidence of the caller's edge list (the inverse of ``by_dst.perm``)."""
+        if getattr(self, "_inv_perm_dst", None) is None:
+            inv = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
+            inv[self.perm_dst_long()] = torch.arange(self.nnz, dtype=torch.int64, device=self.device)
+            self._inv_perm_dst = inv
+        return self._inv_perm_dst
+
     def inv_count_by_src(self) -> Tensor:
         """f32[nnz] in ``by_src`` order: 1 / max(|segment of the incidence's target|, 1) (mean backward)."""
         if "src" not in self._inv_cnt:

@@ -120,8 +120,14 @@ class SetGNN(nn.Module):
                 x = F.relu(self.E2VConvs[i](x, e2v, norm, self.aggr))
                 xs.append(x)
                 x = F.dropout(x, p=self.dropout, training=self.training)
-            x = torch.stack(xs, dim=-1)
-            x = self.GPRweights(x).squeeze()
+            # reference models.py:468-470: x = GPRweights(stack(xs, -1)).squeeze() -- a Linear(L+1 -> 1) over the stacked layer
+            # outputs, i.e. a weighted sum of them.  Written as that sum: as a matmul it is an [n*d, L+1] x [L+1, 1] product,
+            # which the library runs as a strided-batched GEMM with K = L+1 -- 19 SECONDS per step at n = 1M, d = 128
+            # (tools/model_step_profile.py with MODEL_ARGS=All_num_layers=2,GPR=1); same arithmetic, same parameter.
+            w = self.GPRweights.weight                          # [1, L+1]
+            x = xs[0] * w[0, 0]
+            for k in range(1, len(xs)):
+                x = x + xs[k] * w[0, k]
             return self.classifier(x)
         x = F.dropout(x, p=0.2, training=self.training)      # hard-coded input dropout (models.py:473)
         for i in range(len(self.V2EConvs)):

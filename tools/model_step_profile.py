@@ -16,13 +16,20 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 f = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 dev = torch.device("cuda:0")
-args = cases.make_args("pma_h4" if mode == "pma" else "ds_add", f, 128, 10)
+over = {}
+for kv in os.environ.get("MODEL_ARGS", "").split(","):        # e.g. MODEL_ARGS=All_num_layers=2,GPR=1,LearnMask=1
+    if "=" in kv:
+        k, v = kv.split("=")
+        over[k] = int(v) if v.lstrip("-").isdigit() else v
+        if k in ("GPR", "LearnMask"):
+            over[k] = bool(int(v))
+args = cases.make_args("pma_h4" if mode == "pma" else "ds_add", f, 128, 10, **over)
 hg = random_hypergraph(n, n, 16, seed=3, device=dev)
 ei = hg.edge_index.clone()
 ei[1] += n                                                     # the reference's layout: hyperedge ids follow the vertex ids
 data = SimpleNamespace(x=torch.randn(n, f, device=dev), edge_index=ei, norm=torch.ones(ei.shape[1], device=dev),
                        y=torch.randint(0, 10, (n,), device=dev))
-model = SetGNN(args).to(dev)
+model = (SetGNN(args, data.norm) if getattr(args, "LearnMask", False) else SetGNN(args)).to(dev)
 model.reset_parameters()
 opt = FusedAdam(model.parameters(), lr=1e-3)
 idx = torch.randperm(n, device=dev)[: n // 2]
