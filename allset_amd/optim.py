@@ -50,9 +50,11 @@ class FusedAdam(torch.optim.Optimizer):
             slow = [p for p in live if all(p is not q for q in fast)]
             if slow:     # anything else: torch's own functional Adam on the same state layout
                 sts = [self._state(p) for p in slow]
-                torch.optim.adam.adam(slow, [p.grad for p in slow], [s["exp_avg"] for s in sts], [s["exp_avg_sq"] for s in sts], [],
+                import importlib
+                importlib.import_module("torch.optim.adam").adam(slow, [p.grad for p in slow], [s["exp_avg"] for s in sts], [s["exp_avg_sq"] for s in sts], [],
                                       [s["step"] for s in sts], amsgrad=False, beta1=b1, beta2=b2, lr=group["lr"],
-                                      weight_decay=group["weight_decay"], eps=group["eps"], maximize=False, capturable=True,
+                                      weight_decay=group["weight_decay"], eps=group["eps"], maximize=False,
+                                      capturable=all(p.is_cuda for p in slow),
                                       foreach=None, fused=None)
             if not fast:
                 continue

@@ -88,3 +88,20 @@ def test_case_generators_are_deterministic():
     assert ei[1].min() == 5000                      # hyperedge ids start at n_V
     sizes = np.bincount(ei[1] - 5000)
     assert sizes.max() == 4096 and sizes[2] == 0 and sizes[0] == 1
+
+
+def test_fused_adam_falls_back_to_torch_adam_for_tensors_it_does_not_take():
+    """allset_amd.optim.FusedAdam on CPU parameters (and, on the device, bf16 ones) runs torch's functional Adam on the same state."""
+    import torch
+    from allset_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    pa = [torch.randn(5, 3, generator=g).requires_grad_(True), torch.randn(7, generator=g).requires_grad_(True)]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = FusedAdam(pa, lr=1e-2, weight_decay=0.01), torch.optim.Adam(pb, lr=1e-2, weight_decay=0.01)
+    for _ in range(4):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)

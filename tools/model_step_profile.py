@@ -30,6 +30,9 @@ ei[1] += n                                                     # the reference's
 data = SimpleNamespace(x=torch.randn(n, f, device=dev), edge_index=ei, norm=torch.ones(ei.shape[1], device=dev),
                        y=torch.randint(0, 10, (n,), device=dev))
 model = (SetGNN(args, data.norm) if getattr(args, "LearnMask", False) else SetGNN(args)).to(dev)
+if os.environ.get("MODEL_DTYPE") == "bf16":                    # bf16 storage end to end (BASELINE configs[4] regime)
+    model = model.to(torch.bfloat16)
+    data.x = data.x.to(torch.bfloat16)
 model.reset_parameters()
 opt = FusedAdam(model.parameters(), lr=1e-3)
 idx = torch.randperm(n, device=dev)[: n // 2]
