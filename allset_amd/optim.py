@@ -3,8 +3,8 @@
 
 At dataset scale the parameter set is ~20 small tensors; torch's fused multi-tensor Adam in capturable mode spends ~40 us on
 them -- a tenth of a hipGraph-replayed Cora step.  Same arithmetic (non-amsgrad, L2 ``weight_decay``, bias corrections from a
-per-parameter step counter kept on the device, so the optimizer is capturable by construction); parameters that are not fp32
-device tensors fall back to ``torch.optim.Adam``'s functional form.
+per-parameter step counter kept on the device, so the optimizer is capturable by construction); fp32 and bf16 device
+parameters (bf16: moments in bf16 as torch keeps them, fp32 arithmetic); anything else falls back to ``torch.optim.Adam``'s functional form.
 """
 from __future__ import annotations
 
@@ -45,8 +45,8 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             live = [p for p in group["params"] if p.grad is not None]
-            fast = [p for p in live if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
-                    and p.grad.dtype == torch.float32 and not p.grad.is_sparse]
+            fast = [p for p in live if p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and p.is_contiguous()
+                    and p.grad.is_contiguous() and p.grad.dtype == p.dtype and not p.grad.is_sparse]
             slow = [p for p in live if all(p is not q for q in fast)]
             if slow:     # anything else: torch's own functional Adam on the same state layout
                 sts = [self._state(p) for p in slow]
@@ -62,18 +62,18 @@ class FusedAdam(torch.optim.Optimizer):
             torch._foreach_add_([s["step"] for s in sts], 1.0)
             by_dev = {}
             for p, s in zip(fast, sts):
-                by_dev.setdefault(p.device, []).append((p, s))
-            for dev, items in by_dev.items():
+                by_dev.setdefault((p.device, p.dtype), []).append((p, s))
+            for (dev, dt), items in by_dev.items():
                 for k0 in range(0, len(items), cap):
                     part = items[k0:k0 + cap]
                     n = len(part)
                     arr = lambda vals: (ctypes.c_void_p * n)(*vals)
                     with torch.cuda.device(dev):
-                        check(lib.allset_adam_step(arr([p.data_ptr() for p, _ in part]), arr([p.grad.data_ptr() for p, _ in part]),
+                        check(lib.allset_adam_step_dtype(1 if dt == torch.bfloat16 else 0, arr([p.data_ptr() for p, _ in part]), arr([p.grad.data_ptr() for p, _ in part]),
                                                    arr([s["exp_avg"].data_ptr() for _, s in part]),
                                                    arr([s["exp_avg_sq"].data_ptr() for _, s in part]),
                                                    arr([s["step"].data_ptr() for _, s in part]),
                                                    (ctypes.c_int64 * n)(*[p.numel() for p, _ in part]), n, float(group["lr"]),
                                                    float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                   stream_of(dev)), "allset_adam_step")
+                                                   stream_of(dev)), "allset_adam_step_dtype")
         return loss

@@ -254,6 +254,11 @@ int allset_adam_max_tensors(void);
 int allset_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                      const float* const* steps, const int64_t* numel, int64_t count, float lr, float beta1, float beta2, float eps,
                      float weight_decay, void* stream);
+/* The same for tensors of one storage type (ALLSET_F32 or ALLSET_BF16: parameter, gradient and both moments in that type, as torch
+ * keeps them; fp32 arithmetic, each stored value rounded once). */
+int allset_adam_step_dtype(int dtype, void* const* params, const void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                           const float* const* steps, const int64_t* numel, int64_t count, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, void* stream);
 
 /* The training loop's loss (reference train.py:479-480: F.log_softmax over the classes, NLLLoss over the train split):
  *   loss = inv_count * sum_r w[r] * (logsumexp(logits[r, :]) - logits[r, y[r]])       w: 0/1 per row (NULL = all rows)

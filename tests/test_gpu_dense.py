@@ -888,3 +888,22 @@ def test_linear_with_widths_that_are_not_multiples_of_four(n, I, O, device):
     for got, ref in ((xd.grad, xr.grad), (Wd.grad, Wr.grad), (bd.grad, br.grad)):
         torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-4, atol=1e-4 * max(1.0, float(ref.abs().max())))
     assert Wd.grad.shape == (O, I)
+
+
+def test_fused_adam_bf16_parameters(device):
+    """bf16 parameters (moments in bf16, fp32 arithmetic, one rounding per stored value) against torch.optim.Adam on the same bf16
+    tensors: one step agrees to a bf16 ulp of the parameter; the fallback list is empty (one launch)."""
+    from allset_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    pa = [torch.randn(256, 256, generator=g).to(torch.bfloat16).to(device).requires_grad_(True),
+          torch.randn(256, generator=g).to(torch.bfloat16).to(device).requires_grad_(True)]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = FusedAdam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)
+    for _ in range(3):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(torch.bfloat16).to(device)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.float(), b.float(), rtol=2 ** -6, atol=2e-2)
+        assert oa.state[a]["exp_avg"].dtype == torch.bfloat16
