@@ -62,6 +62,49 @@ __global__ __launch_bounds__(kLossBlock) void nll_bwd_kernel(const float* __rest
   }
 }
 
+// Per-split accuracy and loss of the reference's evaluate() (train.py:169-199: eval_acc = mean(argmax == y), NLLLoss of
+// log_softmax, each over the train / valid / test rows) in ONE pass over the logits: partials[block][6] = {correct_0..2, nll_0..2}
+// summed over the block's rows of each split (split[r] in {0, 1, 2}, anything else = in no split).  The driver keeps the six
+// numbers of every epoch on the device and reads them back once per run -- the reference's per-epoch .cpu() calls are host
+// round trips that dwarf a 0.4 ms training step at dataset scale.
+__global__ __launch_bounds__(kLossBlock) void split_metrics_kernel(const float* __restrict__ logits, int64_t ld,
+                                                                  const int64_t* __restrict__ y, const int8_t* __restrict__ split,
+                                                                  float* __restrict__ partials, int64_t n, int C) {
+  __shared__ float red[kLossBlock / kWave][6];
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kLossBlock + threadIdx.x; r < n; r += static_cast<int64_t>(gridDim.x) * kLossBlock) {
+    const int sp = split[r];
+    if (sp < 0 || sp > 2) continue;
+    const float* row = logits + r * ld;
+    float m = row[0];
+    int am = 0;
+    for (int c = 1; c < C; ++c) if (row[c] > m) { m = row[c]; am = c; }      // first maximum, as torch.argmax
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += __expf(row[c] - m);
+    const int64_t t = y[r];
+    const float nll = (m + __logf(s)) - row[t];
+    const float ok = am == t ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { acc[k] += sp == k ? ok : 0.f; acc[3 + k] += sp == k ? nll : 0.f; }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kLossBlock / kWave; ++w) s += red[w][threadIdx.x];
+    partials[blockIdx.x * 6 + threadIdx.x] = s;
+  }
+}
+
 static inline unsigned loss_grid(int64_t n) {
   int64_t b = (n + kLossBlock - 1) / kLossBlock;
   if (b > 256) b = 256;
@@ -97,6 +140,17 @@ extern "C" int allset_nll_logsoftmax_bwd(const float* logits, int64_t ld, const 
   if (n == 0) return ALLSET_OK;
   ALLSET_REQUIRE(logits && y && glogits, "nll_logsoftmax_bwd: null pointer");
   nll_bwd_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, w, inv_count, gout, glogits, ldg, n, static_cast<int>(C));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_split_metrics(const float* logits, int64_t ld, const int64_t* y, const int8_t* split, float* partials,
+                                    int64_t n_partials, int64_t n, int64_t C, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && C >= 1 && C < INT32_MAX && ld >= C, "split_metrics: bad size");
+  ALLSET_REQUIRE(partials != nullptr && n_partials == loss_grid(n), "split_metrics: partials must hold 6 x allset_nll_partials(n) floats");
+  ALLSET_REQUIRE(n == 0 || (logits && y && split), "split_metrics: null pointer");
+  split_metrics_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, split, partials, n, static_cast<int>(C));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

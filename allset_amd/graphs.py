@@ -67,6 +67,24 @@ class GraphedForward:
         return self.out
 
 
+class GraphedCallable:
+    """A no-grad callable over STATIC device tensors (closed over by ``fn``) captured as one graph: ``out = gc()`` replays it and
+    returns ``fn``'s result tensor (static, overwritten by the next replay).  For the small per-epoch tails of a training loop
+    (metrics of a replayed forward, copies into a history buffer) whose 5-10 eager launches cost more host time than the
+    replayed step takes on the device."""
+
+    def __init__(self, fn: Callable[[], Tensor], device, warmup: int = 2):
+        with torch.no_grad(), torch.cuda.device(device):
+            _side_stream_warmup(lambda: fn(), max(1, warmup))
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+
+    def __call__(self) -> Tensor:
+        self.graph.replay()
+        return self.out
+
+
 class GraphedTrainStep:
     """One full training step -- zero_grad, forward (train mode, dropout live), loss, backward, optimizer step --
     captured as one graph.  ``loss = step()`` replays it and returns the static loss tensor (a device scalar; read

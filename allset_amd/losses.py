@@ -65,3 +65,35 @@ def nll_log_softmax(logits: Tensor, y: Tensor, mask: Tensor, count: float) -> Te
     out = F.log_softmax(logits.float(), dim=1)
     picked = out.gather(1, y.view(-1, 1)).squeeze(1)
     return -(picked * mask).sum() / float(count)
+
+
+def split_ids(split_idx: dict, n: int, device) -> Tensor:
+    """int8 [n]: 0 / 1 / 2 for the rows of ``split_idx['train' | 'valid' | 'test']``, -1 elsewhere."""
+    sp = torch.full((n,), -1, dtype=torch.int8, device=device)
+    for k, name in enumerate(("train", "valid", "test")):
+        sp[split_idx[name].to(device)] = k
+    return sp
+
+
+def split_metrics(logits: Tensor, y: Tensor, split: Tensor, counts: Tensor) -> Tensor:
+    """float32 [6] ON THE DEVICE: accuracy of the train / valid / test rows and their mean NLL of ``log_softmax(logits)`` -- what the
+    reference's ``evaluate`` returns (train.py:169-199), without its host round trips.  ``split``: :func:`split_ids`;
+    ``counts``: float32 [3] set sizes (device)."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1:
+        dev = logits.device
+        n, C = logits.shape
+        lib = _lib.load()
+        npart = c_int64(0)
+        check(lib.allset_nll_partials(n, byref(npart)), "allset_nll_partials")
+        partials = torch.empty((npart.value, 6), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.allset_split_metrics(ptr(logits), logits.stride(0), ptr(y.contiguous()), ptr(split), ptr(partials), npart.value, n, C,
+                                           stream_of(dev)), "allset_split_metrics")
+        sums = partials.sum(0) if npart.value > 1 else partials[0]
+    else:
+        out = F.log_softmax(logits.float(), dim=1)
+        ok = (out.argmax(dim=1) == y).float()
+        nll = -out.gather(1, y.view(-1, 1)).squeeze(1)
+        sel = torch.stack([(split == k).float() for k in range(3)])
+        sums = torch.cat([sel @ ok, sel @ nll])
+    return sums / torch.cat([counts, counts]).clamp(min=1.0)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, adam_step) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -267,6 +267,11 @@ int allset_adam_step_dtype(int dtype, void* const* params, const void* const* gr
 int allset_nll_partials(int64_t n, int64_t* n_partials);
 int allset_nll_logsoftmax_fwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
                               float* partials, int64_t n_partials, int64_t n, int64_t C, void* stream);
+/* Accuracy and loss of the reference's evaluate() (train.py:169-199) for three row sets in one pass: split[r] in {0, 1, 2} names the
+ * row's set (anything else: none); partials: f32[allset_nll_partials(n)][6] = per-block sums {correct_0, correct_1, correct_2,
+ * nll_0, nll_1, nll_2}; the caller adds the blocks and divides by the set sizes. */
+int allset_split_metrics(const float* logits, int64_t ld, const int64_t* y, const int8_t* split, float* partials,
+                         int64_t n_partials, int64_t n, int64_t C, void* stream);
 int allset_nll_logsoftmax_bwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
                               const float* gout, float* glogits, int64_t ldg, int64_t n, int64_t C, void* stream);
 

@@ -907,3 +907,30 @@ def test_fused_adam_bf16_parameters(device):
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a.float(), b.float(), rtol=2 ** -6, atol=2e-2)
         assert oa.state[a]["exp_avg"].dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("n,C", [(1, 3), (2708, 7), (50000, 40), (300, 67)])
+def test_split_metrics_match_the_reference_evaluate(n, C, device):
+    """allset_split_metrics against the reference's evaluate() (train.py:169-199): eval_acc and NLLLoss(log_softmax) per split,
+    including rows in no split and an exact tie (first maximum wins, as torch.argmax)."""
+    from allset_amd.losses import split_ids, split_metrics
+    g = torch.Generator().manual_seed(n * 3 + C)
+    logits = (3 * torch.randn(n, C, generator=g)).to(device)
+    if n > 2 and C > 2:
+        logits[2, 1] = logits[2, 0] = logits[2].max() + 1.0
+    y = torch.randint(0, C, (n,), generator=g).to(device)
+    perm = torch.randperm(n, generator=g)
+    a, b = n // 2, (3 * n) // 4
+    idx = {"train": perm[:a].to(device), "valid": perm[a:b].to(device), "test": perm[b:max(b, n - 5)].to(device)}
+    counts = torch.tensor([float(idx[k].numel()) for k in ("train", "valid", "test")], device=device)
+    got = split_metrics(logits, y, split_ids(idx, n, device), counts).cpu()
+    out = F.log_softmax(logits.double(), dim=1)
+    for k, name in enumerate(("train", "valid", "test")):
+        ii = idx[name]
+        if ii.numel() == 0:
+            assert got[k] == 0 and got[3 + k] == 0
+            continue
+        acc = float((out[ii].argmax(dim=-1) == y[ii]).double().mean())
+        nll = float(F.nll_loss(out[ii], y[ii]))
+        assert abs(float(got[k]) - acc) < 1e-6
+        assert abs(float(got[3 + k]) - nll) < 1e-4 * max(1.0, abs(nll))
