@@ -315,8 +315,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="the reference's processed file <root>/<dname>/processed/data.pt (or its directory)")
     p.add_argument('--seed', default=None, type=int, help='seed numpy/torch (the reference fixes no seeds, README.md:60)')
     p.add_argument('--res_root', default='hyperparameter_tunning')
-    p.add_argument('--hip_graph', default=0, type=int, choices=[0, 1],
-                   help='1: capture the training step and the eval forward as hipGraphs (allset_amd/graphs.py)')
+    p.add_argument('--hip_graph', default=-1, type=int, choices=[-1, 0, 1],
+                   help='1: capture the training step, the eval forward and the metrics as hipGraphs (allset_amd/graphs.py); '
+                        '0: eager launches; -1 (default): graphs where the loop is launch-bound (at most 200k vertices), eager '
+                        'above; a failed capture falls back to eager launches with a warning')
     p.set_defaults(PMA=True, add_self_loop=True, exclude_self=False, GPR=False, LearnMask=False)
     return p
 
@@ -377,10 +379,19 @@ def run(args) -> dict:
         from .losses import nll_log_softmax, split_mask
         train_mask, n_train = split_mask(split_idx['train'], data.y.shape[0]), int(split_idx['train'].numel())
         y_all = data.y.long()
-        if args.hip_graph:                     # same loop, two graph launches per epoch instead of ~400 kernel launches
+        use_graph = args.hip_graph == 1 or (args.hip_graph == -1 and data.y.shape[0] <= 200_000)
+        if use_graph:                          # same loop, three graph launches per epoch instead of ~400 kernel launches
             from .graphs import GraphedForward, GraphedTrainStep
-            graphed_step = GraphedTrainStep(model, data, lambda logits: nll_log_softmax(logits, y_all, train_mask, n_train), optimizer)
-            graphed_eval = GraphedForward(model, data)
+            try:
+                graphed_step = GraphedTrainStep(model, data, lambda logits: nll_log_softmax(logits, y_all, train_mask, n_train), optimizer)
+                graphed_eval = GraphedForward(model, data)
+            except Exception as exc:           # noqa: BLE001 -- the eager loop below is the same arithmetic on the same kernels
+                if args.hip_graph == 1:
+                    raise
+                print(f"[allset_amd.train] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager launches")
+                use_graph = False
+                model.reset_parameters()
+                optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
         # evaluate() of the reference (train.py:483: three accuracies + three losses per epoch, each through .cpu()) as one kernel
         # whose six numbers stay on the device: they are read back once per run (and every display_step epochs for the progress
         # line) -- at dataset scale the per-epoch host round trips cost several times the 0.4 ms training step
@@ -388,12 +399,12 @@ def run(args) -> dict:
         sp = split_ids(split_idx, data.y.shape[0], device)
         counts = torch.tensor([float(split_idx[k].numel()) for k in ('train', 'valid', 'test')], device=device)
         hist = torch.zeros((args.epochs, 7), dtype=torch.float32, device=device)       # [acc x 3, loss x 3, train-step loss]
-        if args.hip_graph:                     # the metrics of the replayed forward and the step's loss as a third small graph
+        if use_graph:                          # the metrics of the replayed forward and the step's loss as a third small graph
             from .graphs import GraphedCallable
             graphed_metrics = GraphedCallable(
                 lambda: torch.cat([split_metrics(graphed_eval.out, y_all, sp, counts), graphed_step.loss.detach().reshape(1)]), device)
         for epoch in range(args.epochs):
-            if args.hip_graph:
+            if use_graph:
                 graphed_step()
                 graphed_eval()
                 hist[epoch] = graphed_metrics()

@@ -106,7 +106,7 @@ def test_synthetic_dataset_is_learnable_structure():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hip_graph", [0, 1])
+@pytest.mark.parametrize("hip_graph", [0, 1, -1])
 @pytest.mark.parametrize("method", ["AllSetTransformer", "AllDeepSets"])
 def test_training_run_improves_accuracy(method, hip_graph, device, tmp_path):
     from allset_amd.train import build_parser, run
