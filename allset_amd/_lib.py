@@ -99,6 +99,8 @@ SIGNATURES = {
     "allset_adam_max_tensors": [],
     "allset_adam_step_dtype": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P],
     "allset_adam_step": [_P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, _P],
+    "allset_pma_fold_fwd": [_P, _P, _P, _P, _P, c_int64, c_int64, c_int64, _P],
+    "allset_pma_fold_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_split_metrics": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_nll_partials": [c_int64, POINTER(c_int64)],
     "allset_nll_logsoftmax_fwd": [_P, c_int64, _P, _P, c_float, _P, c_int64, c_int64, c_int64, _P],

@@ -154,3 +154,79 @@ extern "C" int allset_split_metrics(const float* logits, int64_t ld, const int64
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
+
+// ---- PMA's folded attention logits: alpha = K . att_r is linear in x, so the layer multiplies x by
+//   w[h, k] = sum_c W_K[h C + c, k] att_r[h, c],   b[h] = sum_c b_K[h C + c] att_r[h, c]
+// instead of forming K (reference layers.py:126-131 computes the full [n, H C] projection).  As torch ops the fold and its
+// backward are ~10 tiny launches per direction; at dataset scale that is a tenth of a replayed AllSetTransformer step.
+namespace allset {
+
+__global__ __launch_bounds__(256) void pma_fold_fwd_kernel(const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                          const float* __restrict__ att, float* __restrict__ w,
+                                                          float* __restrict__ b, int H, int C, int K) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // (h, k) pairs, then H bias entries
+  if (idx < H * K) {
+    const int h = idx / K, k = idx % K;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(Wk[static_cast<int64_t>(h * C + c) * K + k], att[h * C + c], s);
+    w[idx] = s;
+  } else if (idx < H * K + H) {
+    const int h = idx - H * K;
+    float s = 0.f;
+    if (bk != nullptr)
+      for (int c = 0; c < C; ++c) s = fmaf(bk[h * C + c], att[h * C + c], s);
+    b[h] = s;
+  }
+}
+
+// gWk[h C + c, k] = gw[h, k] att[h, c];  gbk[h C + c] = gb[h] att[h, c];  gatt[h, c] = sum_k gw[h, k] Wk[h C + c, k] + gb[h] bk[h C + c]
+__global__ __launch_bounds__(256) void pma_fold_bwd_kernel(const float* __restrict__ Wk, const float* __restrict__ bk,
+                                                          const float* __restrict__ att, const float* __restrict__ gw,
+                                                          const float* __restrict__ gb, float* __restrict__ gWk,
+                                                          float* __restrict__ gbk, float* __restrict__ gatt, int H, int C, int K) {
+  // one workgroup per row (h, c) of W_K: writes its gWk row and reduces its gatt entry
+  const int row = blockIdx.x, h = row / C;
+  const float a = att[row];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float g = gw[h * K + k];
+    gWk[static_cast<int64_t>(row) * K + k] = g * a;
+    s = fmaf(g, Wk[static_cast<int64_t>(row) * K + k], s);
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0] + red[1] + red[2] + red[3];
+    const float g = gb ? gb[h] : 0.f;
+    if (bk != nullptr) { t = fmaf(g, bk[row], t); gbk[row] = g * a; }
+    gatt[row] = t;
+  }
+}
+
+}  // namespace allset
+
+extern "C" int allset_pma_fold_fwd(const float* Wk, const float* bk, const float* att, float* w, float* b, int64_t H, int64_t C,
+                                   int64_t K, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(H >= 1 && C >= 1 && K >= 1 && H * K < (int64_t{1} << 30), "pma_fold_fwd: bad size");
+  ALLSET_REQUIRE(Wk && att && w && b, "pma_fold_fwd: null pointer");
+  const unsigned grid = static_cast<unsigned>((H * K + H + 255) / 256);
+  allset::pma_fold_fwd_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(Wk, bk, att, w, b, static_cast<int>(H), static_cast<int>(C),
+                                                                            static_cast<int>(K));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_pma_fold_bwd(const float* Wk, const float* bk, const float* att, const float* gw, const float* gb, float* gWk,
+                                   float* gbk, float* gatt, int64_t H, int64_t C, int64_t K, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(H >= 1 && C >= 1 && K >= 1 && H * C < (int64_t{1} << 30), "pma_fold_bwd: bad size");
+  ALLSET_REQUIRE(Wk && att && gw && gWk && gatt && (bk == nullptr || gbk != nullptr), "pma_fold_bwd: null pointer");
+  allset::pma_fold_bwd_kernel<<<static_cast<unsigned>(H * C), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      Wk, bk, att, gw, gb, gWk, gbk, gatt, static_cast<int>(H), static_cast<int>(C), static_cast<int>(K));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

@@ -915,6 +915,49 @@ def pma_residual_ff(out: Tensor, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5,
     return _PmaResidualFF.apply(out, w1, b1, w2, b2, gamma, beta, float(eps), bool(relu_post), float(p))
 
 
+class _PmaFold(torch.autograd.Function):
+    """``(w [H, K], b [H]) = fold(W_K [H C, K], b_K [H C], att_r [.., H, C])``: the weight of PMA's folded logits as ONE kernel each
+    way (as torch ops: mul, sum, mul, sum forward and six more backward -- ~80 us per replayed dataset-scale step)."""
+
+    @staticmethod
+    def forward(ctx, Wk, bk, att):
+        dev = require_device(Wk, att)
+        HC, K = Wk.shape
+        H = att.shape[-2]
+        C = HC // H
+        Wk_c, att_c = Wk.contiguous(), att.contiguous()
+        w = torch.empty((H, K), dtype=torch.float32, device=dev)
+        b = torch.empty((H,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.load().allset_pma_fold_fwd(ptr(Wk_c), ptr(bk.contiguous() if bk is not None else None), ptr(att_c), ptr(w), ptr(b),
+                                                  H, C, K, stream_of(dev)), "allset_pma_fold_fwd")
+        ctx.save_for_backward(Wk_c, bk, att_c)
+        ctx.att_shape = att.shape
+        return w, b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gw, gb):
+        Wk, bk, att = ctx.saved_tensors
+        dev = Wk.device
+        HC, K = Wk.shape
+        H = att.shape[-2]
+        C = HC // H
+        gWk = torch.empty_like(Wk)
+        gbk = torch.empty((HC,), dtype=torch.float32, device=dev) if bk is not None else None
+        gatt = torch.empty((HC,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.load().allset_pma_fold_bwd(ptr(Wk), ptr(bk.contiguous() if bk is not None else None), ptr(att), ptr(gw.contiguous()),
+                                                  ptr(gb.contiguous() if gb is not None else None), ptr(gWk), ptr(gbk), ptr(gatt), H, C, K,
+                                                  stream_of(dev)), "allset_pma_fold_bwd")
+        return gWk, gbk, gatt.view(ctx.att_shape)
+
+
+def pma_fold(Wk: Tensor, bk: Optional[Tensor], att: Tensor) -> Tuple[Tensor, Tensor]:
+    """fp32 device parameters only (callers keep the torch expression for anything else)."""
+    return _PmaFold.apply(Wk, bk, att)
+
+
 # ---- the bf16 regime (BASELINE configs[4]): csrc/fused_bf16.hip ---------------------------------------------------------
 def linear_bf16_supported(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> bool:
     """bf16 rows on the device, bf16 parameters, in / out features in {128, 256}."""

@@ -218,11 +218,20 @@ class PMA(nn.Module):
         self.ln1.reset_parameters()
         nn.init.xavier_uniform_(self.att_r)
 
+    def _fold(self) -> Tuple[Tensor, Tensor]:
+        """``(w [H, in], b [H])`` with ``alpha = x w^T + b``: one kernel each way for fp32 device parameters."""
+        H, C = self.heads, self.hidden
+        Wk, bk = self.lin_K.weight, self.lin_K.bias
+        if Wk.is_cuda and Wk.dtype == torch.float32 and self.att_r.dtype == torch.float32 and (bk is None or bk.dtype == torch.float32):
+            return dense.pma_fold(Wk, bk, self.att_r)
+        w = (Wk.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
+        b = (bk.view(H, C) * self.att_r.view(H, C)).sum(dim=1)           # [H]
+        return w, b
+
     def _logits(self, x: Tensor) -> Tensor:
         H, C = self.heads, self.hidden
         if self.fold_alpha:
-            w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
-            b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
+            w, b = self._fold()
             # [n,in] x [in,H]: the weight gradient of this skinny Linear is a [H x n] x [n x in] product that the
             # library tiles badly (1.5 ms at n = 1M); dense.linear routes it to the split-K MFMA kernel
             hip = _on_hip(x) or (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16)
@@ -237,14 +246,12 @@ class PMA(nn.Module):
             self.lin_V.in_features, self.lin_V.out_features, False)
         if fusable and self.fold_alpha and dense.x6_active():
             # one autograd node for both consumers of x (bf16x6 kernels; the branches' gradients are summed in-kernel)
-            w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
-            b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
+            w, b = self._fold()
             return dense.pma_project(x, self.lin_V.weight, self.lin_V.bias, w, b)
         if (self.fold_alpha and H <= 4 and x.dim() == 2 and x.shape[1] % 8 == 0
                 and dense.linear_bf16_supported(x, self.lin_V.weight, self.lin_V.bias) and self.att_r.dtype == torch.bfloat16):
             # bf16 regime: the logits are four fp32 auxiliary columns of the value projection's kernel
-            w = (self.lin_K.weight.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
-            b = (self.lin_K.bias.view(H, C) * self.att_r.view(H, C)).sum(dim=1)              # [H]
+            w, b = self._fold()
             return dense.pma_project_bf16(x, self.lin_V.weight, self.lin_V.bias, w, b)
         x_V = (dense.fused_norm_linear(x, None, None, self.lin_V.weight, self.lin_V.bias) if (fusable or wide)
                else _linear(self.lin_V, x))

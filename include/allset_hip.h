@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -267,6 +267,14 @@ int allset_adam_step_dtype(int dtype, void* const* params, const void* const* gr
 int allset_nll_partials(int64_t n, int64_t* n_partials);
 int allset_nll_logsoftmax_fwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
                               float* partials, int64_t n_partials, int64_t n, int64_t C, void* stream);
+/* PMA's folded attention logits (reference layers.py:126-131 forms K = lin_K(x) and contracts it with att_r; alpha is linear in
+ * x, so the layer multiplies x by the folded weight instead):  w[h, k] = sum_c W_K[h C + c, k] att_r[h, c]  (f32 [H, K]),
+ * b[h] = sum_c b_K[h C + c] att_r[h, c] (bk may be NULL: b = 0), and the backward of that fold. */
+int allset_pma_fold_fwd(const float* Wk, const float* bk, const float* att, float* w, float* b, int64_t H, int64_t C, int64_t K,
+                        void* stream);
+int allset_pma_fold_bwd(const float* Wk, const float* bk, const float* att, const float* gw, const float* gb, float* gWk,
+                        float* gbk, float* gatt, int64_t H, int64_t C, int64_t K, void* stream);
+
 /* Accuracy and loss of the reference's evaluate() (train.py:169-199) for three row sets in one pass: split[r] in {0, 1, 2} names the
  * row's set (anything else: none); partials: f32[allset_nll_partials(n)][6] = per-block sums {correct_0, correct_1, correct_2,
  * nll_0, nll_1, nll_2}; the caller adds the blocks and divides by the set sizes. */

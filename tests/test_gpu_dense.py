@@ -934,3 +934,23 @@ def test_split_metrics_match_the_reference_evaluate(n, C, device):
         nll = float(F.nll_loss(out[ii], y[ii]))
         assert abs(float(got[k]) - acc) < 1e-6
         assert abs(float(got[3 + k]) - nll) < 1e-4 * max(1.0, abs(nll))
+
+
+@pytest.mark.parametrize("H,C,K,bias", [(4, 32, 128, True), (1, 128, 3703, True), (8, 16, 100, False), (2, 5, 7, True)])
+def test_pma_logit_fold_kernels(H, C, K, bias, device):
+    """allset_pma_fold_fwd/_bwd against the torch expression of the fold (layers.PMA._fold): values and the three gradients."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(H * 100 + C + K)
+    Wk, bk, att = torch.randn(H * C, K, generator=g), torch.randn(H * C, generator=g), torch.randn(1, H, C, generator=g)
+    Gw, Gb = torch.randn(H, K, generator=g), torch.randn(H, generator=g)
+    r = [t.double().requires_grad_(True) for t in (Wk, bk, att)]
+    wr = (r[0].view(H, C, -1) * r[2].view(H, C, 1)).sum(dim=1)
+    br = (r[1].view(H, C) * r[2].view(H, C)).sum(dim=1) if bias else torch.zeros(H, dtype=torch.float64)
+    ((wr * Gw.double()).sum() + (br * Gb.double()).sum()).backward()
+    d = [t.to(device).requires_grad_(True) for t in (Wk, bk, att)]
+    w, b = dense.pma_fold(d[0], d[1] if bias else None, d[2])
+    ((w * Gw.to(device)).sum() + (b * Gb.to(device)).sum()).backward()
+    torch.testing.assert_close(w.detach().cpu().double(), wr.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(b.detach().cpu().double(), br.detach(), rtol=1e-5, atol=1e-5)
+    for k in ((0, 1, 2) if bias else (0, 2)):
+        torch.testing.assert_close(d[k].grad.cpu().double(), r[k].grad, rtol=1e-5, atol=1e-5 * max(1.0, float(r[k].grad.abs().max())))
