@@ -450,6 +450,7 @@ struct WgradPro {
   const float* stats; const float* gamma; const float* beta; int has_ln; int relu_in; float p_in; uint64_t seed_in;
   const uint64_t* seed_base;
   const uint32_t* mask; int mask_nh;        // activation mask (replaces y; bf16x6 kernels only), O / 64
+  int64_t pw_stride = 0, pb_stride = 0;     // floats between consecutive slices of part_w / part_b (0: O*I and O)
 };
 
 template <bool PRO>
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
   }
 
   // epilogue: partial tile -> part_w[slice][O][I]
-  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+  float* pw = part_w + static_cast<int64_t>(slice) * (pro.pw_stride ? pro.pw_stride : static_cast<int64_t>(O) * I);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int i = i_base + t * 32 + (lane & 31);
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_kernel(
       float s = 0.f;
 #pragma unroll
       for (int g = 0; g < 8; ++g) s += red[g * kWgTile + tid];
-      if (o_base + tid < O) part_b[static_cast<int64_t>(slice) * O + o_base + tid] = s;
+      if (o_base + tid < O) part_b[static_cast<int64_t>(slice) * (pro.pb_stride ? pro.pb_stride : O) + o_base + tid] = s;
     }
   }
 }
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
   }
 
   // epilogue: partial tile -> part_w[slice][O][I]; acc[ot][it][r] is (o = .. + 4*fg + r, i = .. + fj)
-  float* pw = part_w + static_cast<int64_t>(slice) * O * I;
+  float* pw = part_w + static_cast<int64_t>(slice) * (pro.pw_stride ? pro.pw_stride : static_cast<int64_t>(O) * I);
 #pragma unroll
   for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
       bsum.x += __shfl_xor(bsum.x, off); bsum.y += __shfl_xor(bsum.y, off);
       bsum.z += __shfl_xor(bsum.z, off); bsum.w += __shfl_xor(bsum.w, off);
     }
-    if (rp == 0 && a_ok) *reinterpret_cast<float4*>(part_b + static_cast<int64_t>(slice) * O + o_base + s_col) = bsum;
+    if (rp == 0 && a_ok) *reinterpret_cast<float4*>(part_b + static_cast<int64_t>(slice) * (pro.pb_stride ? pro.pb_stride : O) + o_base + s_col) = bsum;
   }
 }
 
@@ -1781,12 +1782,39 @@ extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_
   return ALLSET_OK;
 }
 
+static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
+                            const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                            int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b, int64_t pw_stride,
+                            int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                            const uint32_t* mask, void* stream);
+
 extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
                                   const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                                   int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
                                   int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                                   const uint32_t* mask, void* stream) {
   clear_error();
+  return wgrad_fused_impl(gy, ldg, y, ldy, p_out, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, part_w, part_b, 0, 0, n_slices, n,
+                          O, I, seed_base, mask, stream);
+}
+
+extern "C" int allset_wgrad_fused_ex(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
+                                     const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                                     int relu_in, float p_in, uint64_t seed_in, float* part, int64_t part_stride, int want_bias,
+                                     int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                                     const uint32_t* mask, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(part != nullptr && part_stride >= O * I + (want_bias ? O : 0) && part_stride % 4 == 0 && aligned16(part),
+                 "wgrad_fused_ex: part must be 16-byte aligned rows of at least O*I (+O) floats, stride a multiple of 4");
+  return wgrad_fused_impl(gy, ldg, y, ldy, p_out, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, part,
+                          want_bias ? part + O * I : nullptr, part_stride, part_stride, n_slices, n, O, I, seed_base, mask, stream);
+}
+
+static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out,
+                            const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                            int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b, int64_t pw_stride,
+                            int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                            const uint32_t* mask, void* stream) {
   ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_fused: bad size");
   if (mask != nullptr && (!dense_mfma_x6() || O % 64 != 0)) {
     set_error("wgrad_fused: the activation mask is consumed by the bf16x6 kernels only (out features % 64 == 0)");
@@ -1814,6 +1842,7 @@ extern "C" int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, 
   pro.stats = stats; pro.gamma = gamma; pro.beta = beta; pro.has_ln = stats != nullptr;
   pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in; pro.seed_base = seed_base;
   pro.mask = mask; pro.mask_nh = static_cast<int>(O / 64);
+  pro.pw_stride = pw_stride; pro.pb_stride = pb_stride;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   if (dense_mfma_x6())
     wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),

@@ -198,6 +198,14 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
                                            stream_of(dev)), "allset_wgrad_bf16_ex")
         red = reduce_partials_to(part, M, torch.bfloat16)
         return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
+    if not bf16 and O % 4 == 0 and I % 4 == 0:
+        M = O * I + (O if want_bias else 0)                # one partial buffer [slices, gW | gb], one reduction launch
+        part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * 4):
+            check(lib.allset_wgrad_fused_ex(ptr(ga), _ld(ga), None, 0, 0.0, ptr(u), _ld(u), None, None, None, 0, 0.0, 0, ptr(part), M,
+                                            int(want_bias), ns.value, n, O, I, None, None, stream_of(dev)), "allset_wgrad_fused_ex")
+        red = reduce_partials(part)
+        return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
     part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
     part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
     with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
@@ -349,17 +357,17 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
     lib = _lib.load()
     ns = c_int64(0)
     check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
-    part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
-    part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
+    # one partial buffer [slices, gW | gb] and one reduction launch (O and I are multiples of 4, checked by the kernel)
+    M = O * I + (O if want_bias else 0)
+    part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("wgrad_fused", dev, n * (O * (2 if (y is not None and mask is None) else 1) + I) * 4):
-        check(lib.allset_wgrad_fused(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),
-                                     ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
-                                     ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
-                                     ptr(part_w), ptr(part_b), ns.value, n, O, I, ptr(seed_base), ptr(mask),
-                                     stream_of(dev)), "allset_wgrad_fused")
-    gw = reduce_partials(part_w)
-    gb = reduce_partials(part_b) if want_bias else None
-    return gw, gb
+        check(lib.allset_wgrad_fused_ex(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),
+                                        ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
+                                        ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
+                                        ptr(part), M, int(want_bias), ns.value, n, O, I, ptr(seed_base), ptr(mask),
+                                        stream_of(dev)), "allset_wgrad_fused_ex")
+    red = reduce_partials(part)
+    return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
 
 
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*) */
+#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -306,6 +306,13 @@ int allset_wgrad_fused(const float* gy, int64_t ldg, const float* y, int64_t ldy
                        int relu_in, float p_in, uint64_t seed_in, float* part_w, float* part_b,
                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                        const uint32_t* mask, void* stream);
+/* The same with ONE partial buffer (part: f32[n_slices][part_stride]: a slice's gW, then -- when want_bias -- its gb), so that a
+ * single allset_reduce_partials_ex call sums both.  With y, mask, stats, gamma, beta NULL and relu_in = 0, p_in = p_out = 0 this is
+ * allset_wgrad. */
+int allset_wgrad_fused_ex(const float* gy, int64_t ldg, const float* y, int64_t ldy, float p_out, const float* x, int64_t ldx,
+                          const float* stats, const float* gamma, const float* beta, int relu_in, float p_in, uint64_t seed_in,
+                          float* part, int64_t part_stride, int want_bias, int64_t n_slices, int64_t n, int64_t O, int64_t I,
+                          const uint64_t* seed_base, const uint32_t* mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Linear layers wider than 128 (reference layers.py:571-579 with MLP_hidden 256 / 512, src/run_AllSetTransformer.sh):
