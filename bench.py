@@ -311,6 +311,13 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
         if on_gpu:
             torch.cuda.synchronize(dev)
 
+    # Python's cyclic collector: a generation-2 pass walks every object the process holds (torch alone is ~10^6) and is triggered by
+    # allocation counts, i.e. by the autograd nodes of the steps themselves -- tens of milliseconds landing at random inside a timed
+    # region (measured on the dataset-scale loop: 4x on an eager step).  Freeze what exists (set-up state never becomes garbage)
+    # so the passes that still run only look at the steps' own objects.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     timer = ops.KernelTimer() if on_gpu else None

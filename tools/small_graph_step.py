@@ -9,6 +9,7 @@ from types import SimpleNamespace
 import cases
 from allset_amd import SetGNN
 dev = torch.device("cuda:0")
+import gc
 for name in ("cora_ds_add", "citeseer_pma_h4"):
     case = cases.build_case(name)
     model = SetGNN(case["args"]).to(dev)
@@ -18,6 +19,7 @@ for name in ("cora_ds_add", "citeseer_pma_h4"):
                            norm=torch.from_numpy(case["norm"]).to(dev))
     n = data.x.shape[0]
     y = torch.randint(0, case["args"].num_classes, (n,), device=dev)
+    gc.collect(); gc.freeze()      # (generation-2 passes over the test fixtures' object graph otherwise land in the eager loops: 4x)
     def step():
         model.train(); opt.zero_grad()
         out = F.log_softmax(model(data), dim=1)
