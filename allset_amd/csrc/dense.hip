@@ -1844,12 +1844,22 @@ static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_
   pro.mask = mask; pro.mask_nh = static_cast<int>(O / 64);
   pro.pw_stride = pw_stride; pro.pb_stride = pb_stride;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
-  if (dense_mfma_x6())
-    wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
-                                                      static_cast<int>(I), tiles_i, rows_per_slice, pro);
-  else
+  // no operand prologue at all (allset_wgrad through the one-buffer entry): the plain instantiation, 12 % faster
+  const bool plain = y == nullptr && mask == nullptr && stats == nullptr && !relu_in && p_in == 0.f && p_out == 0.f;
+  if (dense_mfma_x6()) {
+    if (plain)
+      wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
+                                                         static_cast<int>(I), tiles_i, rows_per_slice, pro);
+    else
+      wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
+                                                        static_cast<int>(I), tiles_i, rows_per_slice, pro);
+  } else if (plain) {
+    wgrad_kernel<false><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
+                                                 tiles_i, rows_per_slice, pro);
+  } else {
     wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
                                                 tiles_i, rows_per_slice, pro);
+  }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
