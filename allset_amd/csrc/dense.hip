@@ -1949,7 +1949,11 @@ extern "C" int allset_ln_res_bwd_partials(int64_t n, int64_t d, int64_t* n_parti
   const int lpr = ln_lpr(d);
   const int64_t groups = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
   const int64_t want = (n + groups - 1) / groups;
-  *n_partials = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  // persistent grid: 78 VGPRs = 6 waves per SIMD = 6 workgroups of 4 waves per CU -> 1536 resident workgroups; with 2048 the last
+  // quarter runs as a second, third-full round (0.315 -> see profiles/r02_ln_res_bench.txt)
+  int64_t cap = 1536;
+  if (const char* e = getenv("ALLSET_LNRES_CAP")) cap = atoll(e);        // (tuning knob, read per call like ALLSET_DENSE_MFMA)
+  *n_partials = want < 1 ? 1 : (want > cap ? cap : want);
   return ALLSET_OK;
 }
 
@@ -2138,7 +2142,7 @@ extern "C" int allset_ln_bwd_bf16_partials(int64_t n, int64_t d, int64_t* n_part
   ALLSET_REQUIRE(n_partials != nullptr && n >= 0 && allset_ln_bf16_supported(d), "ln_bwd_bf16_partials: bad argument");
   const int64_t groups = static_cast<int64_t>(kWavesPerBlock) * (kWave / ln_bf16_lpr(d));
   const int64_t want = (n + groups - 1) / groups;
-  *n_partials = want < 1 ? 1 : (want > 2048 ? 2048 : want);
+  *n_partials = want < 1 ? 1 : (want > 2048 ? 2048 : want);     // (1024 = the resident count at 117 VGPRs measured the same at [250k, 256])
   return ALLSET_OK;
 }
 
