@@ -16,7 +16,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import check, ptr, require_device, stream_of
+from ._lib import check, ptr, require_device, stream_of, on_device
 from .ops import _ld, _rowmajor, _timed
 
 Tensor = torch.Tensor
@@ -94,7 +94,7 @@ def reduce_partials(part: Tensor) -> Tensor:
     dev = part.device
     out = torch.empty(part.shape[1:], dtype=torch.float32, device=dev)
     scratch = torch.empty(((P + 63) // 64) * M, dtype=torch.float32, device=dev) if P > 64 else None
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_lib.load().allset_reduce_partials(ptr(part), P, M, ptr(out), ptr(scratch), stream_of(dev)),
               "allset_reduce_partials")
     return out
@@ -106,7 +106,7 @@ def reduce_partials_to(part: Tensor, M: int, dtype: torch.dtype) -> Tensor:
     dev = part.device
     out = torch.empty(M, dtype=dtype, device=dev)
     scratch = torch.empty(((P + 63) // 64) * M, dtype=torch.float32, device=dev) if P > 64 else None
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_lib.load().allset_reduce_partials_ex(ptr(part), P, stride, M, ptr(out), 1 if dtype == torch.bfloat16 else 0,
                                                     ptr(scratch), stream_of(dev)), "allset_reduce_partials_ex")
     return out
@@ -122,13 +122,13 @@ def ln_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu_in: bool, p:
     if x.dtype == torch.bfloat16:                 # bf16 activations and parameters, fp32 arithmetic (configs[4] regime)
         if gamma.dtype != torch.bfloat16 or beta.dtype != torch.bfloat16 or not ln_bf16_supported(d):
             raise _lib.AllSetHipError("bf16 LayerNorm: bf16 gamma / beta and d % 8 == 0, d <= 512 required")
-        with torch.cuda.device(dev), _timed("ln_fwd", dev, 2 * n * d * 2):
+        with on_device(dev), _timed("ln_fwd", dev, 2 * n * d * 2):
             check(_lib.load().allset_ln_fwd_bf16(ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
                                                  int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, ptr(seed_base),
                                                  stream_of(dev)), "allset_ln_fwd_bf16")
         return y, stats
     _check_f32(x, gamma, beta)
-    with torch.cuda.device(dev), _timed("ln_fwd", dev, 2 * n * d * 4):
+    with on_device(dev), _timed("ln_fwd", dev, 2 * n * d * 4):
         check(_lib.load().allset_ln_fwd(ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
                                         int(relu_in), p, seed, ptr(y), max(d, 1), ptr(stats), n, d, ptr(seed_base),
                                         stream_of(dev)),
@@ -153,7 +153,7 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
         check(lib.allset_ln_bwd_bf16_partials(n, d, byref(npart)), "allset_ln_bwd_bf16_partials")
         partials = torch.empty((npart.value, 2, d), dtype=torch.float32, device=dev)
         gx = torch.empty((n, d), dtype=x.dtype, device=dev) if want_gx else None
-        with torch.cuda.device(dev), _timed("ln_bwd", dev, (3 if want_gx else 2) * n * d * 2):
+        with on_device(dev), _timed("ln_bwd", dev, (3 if want_gx else 2) * n * d * 2):
             check(lib.allset_ln_bwd_bf16(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
                                          seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
                                          stream_of(dev)), "allset_ln_bwd_bf16")
@@ -165,7 +165,7 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
     check(lib.allset_ln_bwd_partials(n, d, byref(npart)), "allset_ln_bwd_partials")
     partials = torch.empty((npart.value, 2, d), dtype=torch.float32, device=dev)
     gx = torch.empty((n, d), dtype=x.dtype, device=dev) if want_gx else None
-    with torch.cuda.device(dev), _timed("ln_bwd", dev, (3 if want_gx else 2) * n * d * 4):
+    with on_device(dev), _timed("ln_bwd", dev, (3 if want_gx else 2) * n * d * 4):
         check(lib.allset_ln_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p,
                                 seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
                                 stream_of(dev)),
@@ -193,7 +193,7 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
         # O and I are multiples of 4 (checked by the kernel), so the row needs no padding
         M = O * I + (O if want_bias else 0)
         part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
+        with on_device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
             check(lib.allset_wgrad_bf16_ex(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part), M, int(want_bias), ns.value, n, O, I,
                                            stream_of(dev)), "allset_wgrad_bf16_ex")
         red = reduce_partials_to(part, M, torch.bfloat16)
@@ -201,14 +201,14 @@ def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Option
     if not bf16 and O % 4 == 0 and I % 4 == 0:
         M = O * I + (O if want_bias else 0)                # one partial buffer [slices, gW | gb], one reduction launch
         part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * 4):
+        with on_device(dev), _timed("wgrad", dev, n * (O + I) * 4):
             check(lib.allset_wgrad_fused_ex(ptr(ga), _ld(ga), None, 0, 0.0, ptr(u), _ld(u), None, None, None, 0, 0.0, 0, ptr(part), M,
                                             int(want_bias), ns.value, n, O, I, None, None, stream_of(dev)), "allset_wgrad_fused_ex")
         red = reduce_partials(part)
         return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
     part_w = torch.empty((ns.value, O, I), dtype=torch.float32, device=dev)
     part_b = torch.empty((ns.value, O), dtype=torch.float32, device=dev) if want_bias else None
-    with torch.cuda.device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
+    with on_device(dev), _timed("wgrad", dev, n * (O + I) * ga.element_size()):
         if bf16:
             check(lib.allset_wgrad_bf16(ptr(ga), _ld(ga), ptr(u), _ld(u), ptr(part_w), ptr(part_b), ns.value, n, O, I,
                                         stream_of(dev)), "allset_wgrad_bf16")
@@ -240,7 +240,7 @@ def gemm_x6_planes(W: Tensor, transpose: bool) -> Tensor:
     if nbytes < 0:
         raise _lib.AllSetHipError(f"gemm_x6: N={N}, K={K} not supported (K % 32 == 0, N % 4 == 0)")
     planes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.allset_gemm_x6_planes(ptr(W), _ld(W), int(transpose), ptr(planes), N, K, stream_of(dev)), "allset_gemm_x6_planes")
     return planes
 
@@ -252,7 +252,7 @@ def row_stats(x: Tensor, relu_in: bool, eps: float) -> Tensor:
     x = _rowmajor(x)
     n, d = x.shape
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("row_stats", dev, n * d * 4):
+    with on_device(dev), _timed("row_stats", dev, n * d * 4):
         check(_lib.load().allset_row_stats(ptr(x), _ld(x), int(relu_in), eps, ptr(stats), n, d, stream_of(dev)), "allset_row_stats")
     return stats
 
@@ -269,7 +269,7 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
     if mask_y is not None:
         mask_y = _rowmajor(mask_y)
     out = torch.empty((n, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("gemm_x6", dev, n * (K + N) * 4):
+    with on_device(dev), _timed("gemm_x6", dev, n * (K + N) * 4):
         check(_lib.load().allset_gemm_x6(
             ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, int(relu_in), ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None), p_in,
@@ -294,7 +294,7 @@ def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Te
     npart = int(lib.allset_gemm_x6_lnb_partials(n))
     partials = torch.empty((npart, 2, N), dtype=torch.float32, device=dev)
     gx = torch.empty((n, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("gemm_x6_lnb", dev, n * (K + 2 * N) * 4):
+    with on_device(dev), _timed("gemm_x6_lnb", dev, n * (K + 2 * N) * 4):
         check(lib.allset_gemm_x6_lnb(ptr(G), _ld(G), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, ptr(planes_t),
                                      ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
                                      ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_x6_lnb")
@@ -332,7 +332,7 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
     weight = weight.contiguous()
     y = torch.empty((n, N), dtype=x.dtype, device=dev)
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev) if gamma is not None else None
-    with torch.cuda.device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
+    with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
         check(_lib.load().allset_fused_linear_fwd(
             ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
             ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
@@ -360,7 +360,7 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
     # one partial buffer [slices, gW | gb] and one reduction launch (O and I are multiples of 4, checked by the kernel)
     M = O * I + (O if want_bias else 0)
     part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("wgrad_fused", dev, n * (O * (2 if (y is not None and mask is None) else 1) + I) * 4):
+    with on_device(dev), _timed("wgrad_fused", dev, n * (O * (2 if (y is not None and mask is None) else 1) + I) * 4):
         check(lib.allset_wgrad_fused_ex(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),
                                         ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                         ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
@@ -397,7 +397,7 @@ def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tens
     if stats is not None:
         check(lib.allset_fused_linear_bwd_partials(n, byref(npart)), "allset_fused_linear_bwd_partials")
         partials = torch.empty((npart.value, 2, I), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("fused_linear_bwd", dev, n * (O * (2 if (y is not None and mask is None) else 1) + 2 * I) * 4):
+    with on_device(dev), _timed("fused_linear_bwd", dev, n * (O * (2 if (y is not None and mask is None) else 1) + 2 * I) * 4):
         check(lib.allset_fused_linear_bwd(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(weight),
                                           ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous() if gamma is not None else None),
                                           int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(partials), npart.value,
@@ -446,7 +446,7 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
     flat = part.view(-1)
     part_w, part_b = flat, flat[O * I:]
     part_ln = flat[O * I + O:] if stats is not None else None
-    with torch.cuda.device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
+    with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
         check(lib.allset_fused_linear_bwd_all(
             ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
@@ -515,7 +515,7 @@ class _ReluDropout(torch.autograd.Function):
         y = torch.empty_like(x)
         seed = _draw_seed() if p > 0.0 else 0
         n = x.numel()
-        with torch.cuda.device(dev), _timed("relu_dropout_fwd", dev, 2 * n * 4):
+        with on_device(dev), _timed("relu_dropout_fwd", dev, 2 * n * 4):
             check(_lib.load().allset_relu_dropout_fwd(ptr(x), p, seed, ptr(y), n, ptr(_seed_base() if p > 0.0 else None),
                                                       stream_of(dev)), "allset_relu_dropout_fwd")
         ctx.save_for_backward(y)
@@ -530,7 +530,7 @@ class _ReluDropout(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(y)
         n = y.numel()
-        with torch.cuda.device(dev), _timed("relu_dropout_bwd", dev, 3 * n * 4):
+        with on_device(dev), _timed("relu_dropout_bwd", dev, 3 * n * 4):
             check(_lib.load().allset_relu_dropout_bwd(ptr(gy), ptr(y), ctx.p, ptr(gx), n, stream_of(dev)),
                   "allset_relu_dropout_bwd")
         return gx, None
@@ -717,7 +717,7 @@ def ln_res_fwd(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gamma: 
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
     lib = _lib.load()
     fn, name = (lib.allset_ln_res_fwd_bf16, "allset_ln_res_fwd_bf16") if bf16 else (lib.allset_ln_res_fwd, "allset_ln_res_fwd")
-    with torch.cuda.device(dev), _timed("ln_res_fwd", dev, (2 + (res is not None)) * n * d * x.element_size()):
+    with on_device(dev), _timed("ln_res_fwd", dev, (2 + (res is not None)) * n * d * x.element_size()):
         check(fn(ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res), _ld(res) if res is not None else 0,
                  ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(relu_out), p, seed, ptr(y), max(d, 1), ptr(stats), n, d,
                  ptr(seed_base), stream_of(dev)), name)
@@ -745,7 +745,7 @@ def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tens
     partials = torch.empty((npart.value, 3, d), dtype=torch.float32, device=dev)
     gs = torch.empty((n, d), dtype=x.dtype, device=dev)
     fn, name = (lib.allset_ln_res_bwd_bf16, "allset_ln_res_bwd_bf16") if bf16 else (lib.allset_ln_res_bwd, "allset_ln_res_bwd")
-    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, (3 + (res is not None)) * n * d * x.element_size()):
+    with on_device(dev), _timed("ln_res_bwd", dev, (3 + (res is not None)) * n * d * x.element_size()):
         check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res),
                  _ld(res) if res is not None else 0, ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), int(relu_out), p,
                  seed, ptr(gs), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base), stream_of(dev)), name)
@@ -790,7 +790,7 @@ def ln_res_bwd_pma(gy: Tensor, x: Tensor, colb: Tensor, stats: Tensor, gamma: Te
     pstats = torch.empty((n, H, 2), dtype=torch.float32, device=dev)
     fn, name = ((lib.allset_ln_res_bwd_pma_bf16, "allset_ln_res_bwd_pma_bf16") if bf16
                 else (lib.allset_ln_res_bwd_pma, "allset_ln_res_bwd_pma"))
-    with torch.cuda.device(dev), _timed("ln_res_bwd", dev, 3 * n * d * x.element_size() + n * H * 16):
+    with on_device(dev), _timed("ln_res_bwd", dev, 3 * n * d * x.element_size() + n * H * 16):
         check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous()), ptr(stats), ptr(gamma.contiguous()),
                  ptr(beta.contiguous()), ptr(gs), max(d, 1), ptr(partials), npart.value, n, d,
                  ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, stream_of(dev)), name)
@@ -936,7 +936,7 @@ class _PmaFold(torch.autograd.Function):
         Wk_c, att_c = Wk.contiguous(), att.contiguous()
         w = torch.empty((H, K), dtype=torch.float32, device=dev)
         b = torch.empty((H,), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(_lib.load().allset_pma_fold_fwd(ptr(Wk_c), ptr(bk.contiguous() if bk is not None else None), ptr(att_c), ptr(w), ptr(b),
                                                   H, C, K, stream_of(dev)), "allset_pma_fold_fwd")
         ctx.save_for_backward(Wk_c, bk, att_c)
@@ -954,7 +954,7 @@ class _PmaFold(torch.autograd.Function):
         gWk = torch.empty_like(Wk)
         gbk = torch.empty((HC,), dtype=torch.float32, device=dev) if bk is not None else None
         gatt = torch.empty((HC,), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(_lib.load().allset_pma_fold_bwd(ptr(Wk), ptr(bk.contiguous() if bk is not None else None), ptr(att), ptr(gw.contiguous()),
                                                   ptr(gb.contiguous() if gb is not None else None), ptr(gWk), ptr(gbk), ptr(gatt), H, C, K,
                                                   stream_of(dev)), "allset_pma_fold_bwd")
@@ -984,7 +984,7 @@ def linear_bf16_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu_out:
     N = weight.shape[0]
     y = torch.empty((n, N), dtype=torch.bfloat16, device=dev)
     aux = torch.empty((n, 4), dtype=torch.float32, device=dev) if aux_w is not None else None
-    with torch.cuda.device(dev), _timed("linear_bf16_fwd", dev, n * (K + N) * 2 + (n * 16 if aux is not None else 0)):
+    with on_device(dev), _timed("linear_bf16_fwd", dev, n * (K + N) * 2 + (n * 16 if aux is not None else 0)):
         check(_lib.load().allset_linear_bf16_fwd(ptr(x), _ld(x), ptr(weight.contiguous()), ptr(bias.contiguous() if bias is not None else None),
                                                  int(relu_out), ptr(aux_w.contiguous() if aux_w is not None else None),
                                                  ptr(aux_b.contiguous() if aux_b is not None else None), ptr(aux), ptr(y), N, n, K, N,
@@ -1010,7 +1010,7 @@ def linear_bf16_bwd(gy: Tensor, weight: Tensor, ymask: Optional[Tensor] = None, 
         acc_in = _rowmajor(acc_in)
     nbytes = n * (O + I) * 2 + (n * O * 2 if ymask is not None else 0) + (n * O * 2 if ga is not None else 0) \
         + (n * I * 2 if acc_in is not None else 0)
-    with torch.cuda.device(dev), _timed("linear_bf16_bwd", dev, nbytes):
+    with on_device(dev), _timed("linear_bf16_bwd", dev, nbytes):
         check(_lib.load().allset_linear_bf16_bwd(ptr(gy), _ld(gy), ptr(ymask), _ld(ymask) if ymask is not None else 0, ptr(ga), O,
                                                  ptr(weight.contiguous()), ptr(galpha.contiguous() if galpha is not None else None),
                                                  ptr(aux_w.contiguous() if aux_w is not None else None), ptr(acc_in),

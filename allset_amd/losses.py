@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import check, ptr, stream_of
+from ._lib import check, ptr, stream_of, on_device
 
 Tensor = torch.Tensor
 
@@ -36,7 +36,7 @@ class _NllLogSoftmax(torch.autograd.Function):
         npart = c_int64(0)
         check(lib.allset_nll_partials(n, byref(npart)), "allset_nll_partials")
         partials = torch.empty(npart.value, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.allset_nll_logsoftmax_fwd(ptr(logits), logits.stride(0), ptr(y), ptr(w), inv_count, ptr(partials), npart.value,
                                                 n, C, stream_of(dev)), "allset_nll_logsoftmax_fwd")
         ctx.save_for_backward(logits, y, w)
@@ -51,7 +51,7 @@ class _NllLogSoftmax(torch.autograd.Function):
         n, C = logits.shape
         g = torch.empty((n, C), dtype=torch.float32, device=dev)
         gout = gout.reshape(1).float().contiguous()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(_lib.load().allset_nll_logsoftmax_bwd(ptr(logits), logits.stride(0), ptr(y), ptr(w), ctx.inv_count, ptr(gout), ptr(g), C,
                                                         n, C, stream_of(dev)), "allset_nll_logsoftmax_bwd")
         return g, None, None, None
@@ -86,7 +86,7 @@ def split_metrics(logits: Tensor, y: Tensor, split: Tensor, counts: Tensor) -> T
         npart = c_int64(0)
         check(lib.allset_nll_partials(n, byref(npart)), "allset_nll_partials")
         partials = torch.empty((npart.value, 6), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.allset_split_metrics(ptr(logits), logits.stride(0), ptr(y.contiguous()), ptr(split), ptr(partials), npart.value, n, C,
                                            stream_of(dev)), "allset_split_metrics")
         sums = partials.sum(0) if npart.value > 1 else partials[0]

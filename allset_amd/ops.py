@@ -11,7 +11,7 @@ from typing import Dict, List, NamedTuple, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import check, ptr, require_device, stream_of
+from ._lib import check, ptr, require_device, stream_of, on_device
 
 Tensor = torch.Tensor
 
@@ -143,7 +143,7 @@ def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_
     nnz = row_ids.numel()
     lib = _lib.load()
     need = c_size_t(0)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.allset_csr_build_workspace_bytes(nnz, n_rows, byref(need)), "allset_csr_build_workspace_bytes")
         rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
         col = torch.empty(nnz, dtype=torch.int32, device=dev)
@@ -223,7 +223,7 @@ def segreduce(reduce: int, rowptr: Tensor, col: Tensor, w: Optional[Tensor], x: 
         w = w.contiguous()
     nnz = col.numel()
     algo = nnz * (es * d + 4 + (4 if w is not None else 0)) + (n_t + 1) * 4 + n_t * d * es
-    with torch.cuda.device(dev), _timed("segreduce_fwd", dev, algo):
+    with on_device(dev), _timed("segreduce_fwd", dev, algo):
         if row_order is not None and row_order.numel() != n_t:
             row_order = None                       # order was built for a different row count (prefix views)
         lib = _lib.load()
@@ -252,7 +252,7 @@ def segmax_bwd(rowptrT: Tensor, colT: Tensor, posT: Tensor, wT: Optional[Tensor]
         return torch.zeros((n_s, d), dtype=gout.dtype, device=dev)
     gx = torch.empty((n_s, d), dtype=gout.dtype, device=dev)
     algo = colT.numel() * (4 * d + 4 * d + 8) + (n_s + 1) * 4 + n_s * d * 4
-    with torch.cuda.device(dev), _timed("segmax_bwd", dev, algo):
+    with on_device(dev), _timed("segmax_bwd", dev, algo):
         check(_lib.load().allset_segmax_bwd(ptr(rowptrT), ptr(colT), ptr(posT), ptr(wT), ptr(argext), ptr(gout),
                                             _ld(gout), ptr(gx), max(d, 1), n_s, n_t, d, stream_of(dev)),
               "allset_segmax_bwd")
@@ -269,7 +269,7 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
     if col.numel() == 0:
         return gw
     algo = col.numel() * (4 * d + 8) + (n_t + 1) * 4 + n_t * d * 4
-    with torch.cuda.device(dev), _timed("sddmm_rowdot", dev, algo):
+    with on_device(dev), _timed("sddmm_rowdot", dev, algo):
         check(_lib.load().allset_sddmm_rowdot(reduce, ptr(rowptr), ptr(col), ptr(x), _ld(x), ptr(gout), _ld(gout),
                                               ptr(argext), ptr(gw), n_t, n_s, d, stream_of(dev)),
               "allset_sddmm_rowdot")
@@ -292,7 +292,7 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
     m = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
     l = torch.empty((n_t, heads), dtype=torch.float32, device=dev)
     algo = col.numel() * (es * d + 4 + 4 * heads) + (n_t + 1) * 4 + n_t * (d * es + 8 * heads)
-    with torch.cuda.device(dev), _timed("pma_fwd", dev, algo):
+    with on_device(dev), _timed("pma_fwd", dev, algo):
         if row_order is not None and row_order.numel() != n_t:
             row_order = None
         lib = _lib.load()
@@ -315,7 +315,7 @@ def pma_attention(rowptr: Tensor, col: Tensor, alpha: Tensor, m: Tensor, l: Tens
     dev = require_device(rowptr, col, alpha, m, l)
     n_t, heads = m.shape
     p = torch.empty((col.numel(), heads), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_lib.load().allset_pma_attention(ptr(rowptr), ptr(col), ptr(alpha.contiguous()), ptr(m), ptr(l), slope,
                                                ptr(p), n_t, heads, stream_of(dev)), "allset_pma_attention")
     return p
@@ -338,7 +338,7 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor, stats: Option
         raise _lib.AllSetHipError("pma_bwd_stats: stats must be float32 [n_t, H, 2] with contiguous rows")
     lds = stats.stride(0) if n_t > 1 else 2 * heads
     algo = n_t * (2 * d * es + 8 * heads + 8 * heads)
-    with torch.cuda.device(dev), _timed("pma_bwd_stats", dev, algo):
+    with on_device(dev), _timed("pma_bwd_stats", dev, algo):
         check(_lib.load().allset_pma_bwd_stats_ld(code, ptr(out), _ld(out), ptr(gout), _ld(gout), ptr(m.contiguous()),
                                                   ptr(l.contiguous()), ptr(stats), lds, n_t, heads, d // heads, stream_of(dev)),
               "allset_pma_bwd_stats_ld")
@@ -365,7 +365,7 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
         stats = stats.contiguous().view(n_t, heads, 2)           # (a row-strided view is fine: stats may sit beside gout rows)
     lds = stats.stride(0) if n_t > 1 else 2 * heads
     algo = colT.numel() * (es * d + 4 + 8 * heads) + (n_s + 1) * 4 + n_s * (2 * d * es + 8 * heads)
-    with torch.cuda.device(dev), _timed("pma_bwd_src", dev, algo):
+    with on_device(dev), _timed("pma_bwd_src", dev, algo):
         if row_order is not None and row_order.numel() != n_s:
             row_order = None
         lib = _lib.load()
@@ -401,7 +401,7 @@ def block_transpose(x: Tensor, world: int, to_blocks: bool) -> Tensor:
         _, rows, dc = x.shape
         out = torch.empty((rows, world * dc), dtype=x.dtype, device=dev)
         ld = world * dc * es
-    with torch.cuda.device(dev), _timed("block_transpose", dev, 2 * rows * world * dc * es):
+    with on_device(dev), _timed("block_transpose", dev, 2 * rows * world * dc * es):
         check(_lib.load().allset_block_transpose(ptr(x), ptr(out), rows, world, dc * es, ld, int(to_blocks), stream_of(dev)),
               "allset_block_transpose")
     return out
@@ -424,7 +424,7 @@ def pma_merge_pack(out_loc: Tensor, m_loc: Tensor, l_loc: Tensor, m_glob: Tensor
     width = d + heads
     ldp = (width + 3) // 4 * 4
     buf = torch.empty((n, ldp), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("pma_merge_pack", dev, n * (2 * d + 4 * heads) * 4):
+    with on_device(dev), _timed("pma_merge_pack", dev, n * (2 * d + 4 * heads) * 4):
         check(_lib.load().allset_pma_merge_pack(ptr(out_loc), _ld(out_loc), ptr(m_loc.contiguous()), ptr(l_loc.contiguous()),
                                                 ptr(m_glob.contiguous()), ptr(buf), ldp, n, heads, d // heads, stream_of(dev)),
               "allset_pma_merge_pack")

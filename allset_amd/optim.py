@@ -14,7 +14,7 @@ from typing import Iterable
 import torch
 
 from . import _lib
-from ._lib import check, stream_of
+from ._lib import check, stream_of, on_device
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -68,7 +68,7 @@ class FusedAdam(torch.optim.Optimizer):
                     part = items[k0:k0 + cap]
                     n = len(part)
                     arr = lambda vals: (ctypes.c_void_p * n)(*vals)
-                    with torch.cuda.device(dev):
+                    with on_device(dev):
                         check(lib.allset_adam_step_dtype(1 if dt == torch.bfloat16 else 0, arr([p.data_ptr() for p, _ in part]), arr([p.grad.data_ptr() for p, _ in part]),
                                                    arr([s["exp_avg"].data_ptr() for _, s in part]),
                                                    arr([s["exp_avg_sq"].data_ptr() for _, s in part]),
