@@ -16,7 +16,9 @@ from allset_amd import dist as adist
 from allset_amd.layers import HalfNLHconv
 from allset_amd.synthetic import random_hypergraph
 dev = torch.device("cuda:0")
-d, n_loc = 128, 1_000_000
+d, n_loc = int(os.environ.get("SIM_D", "128")), int(os.environ.get("SIM_N", "1000000"))
+DT = torch.bfloat16 if os.environ.get("SIM_DTYPE") == "bf16" else torch.float32
+DIST = os.environ.get("SIM_DIST", "fixed")          # fixed | zipf (BASELINE configs[4]: SIM_D=256 SIM_N=250000 SIM_DTYPE=bf16 SIM_DIST=zipf)
 model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
 mode = sys.argv[2] if len(sys.argv) > 2 else "rows"
 LINK = 60e9
@@ -30,23 +32,23 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     adist.dist.all_reduce = lambda *a, **k: None                      # ... with the small max-all-reduce stubbed out
     n_v = n_loc * world
     if mode == "columns":
-        blocks = [random_hypergraph(n_v, n_loc, 16, seed=5 + r, device=dev, e_offset=r * n_loc) for r in range(world)]
+        blocks = [random_hypergraph(n_v, n_loc, 16, seed=5 + r, device=dev, e_offset=r * n_loc, dist=DIST) for r in range(world)]
         ei = torch.cat([b.edge_index for b in blocks], dim=1)
         shard = blocks[0]
         hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, 0,
                                            norm=torch.cat([b.norm for b in blocks])).build_incidences()
         del blocks, ei
     else:
-        shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev)
+        shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev, dist=DIST)
         hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm).build_incidences()
     attn = model == "pma"
     torch.manual_seed(0)
-    a = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).train()
-    b = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).train()
+    a = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).to(DT).train()
+    b = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).to(DT).train()
     params = list(a.parameters()) + list(b.parameters())
     opt = torch.optim.Adam(params, lr=1e-3, fused=True)
-    x = torch.randn(n_loc, d, device=dev, requires_grad=True)
-    G = torch.randn(n_loc, d, device=dev)
+    x = torch.randn(n_loc, d, device=dev).to(DT).requires_grad_(True)
+    G = torch.randn(n_loc, d, device=dev).to(DT)
     def step():
         opt.zero_grad(set_to_none=True); x.grad = None
         if mode == "columns":
@@ -68,7 +70,7 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
             print(f"      {k:22s} {v['calls'] / 10:5.1f} calls/step  {v['avg_ms']:7.3f} ms avg  {v['total_ms'] / 10:7.3f} ms/step")
     if world == 1 or "t1" not in globals():
         t1 = ms if world == 1 else float(os.environ.get("SIM_T1_MS", "nan"))
-    per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d)     # received per step (fwd + bwd)
+    per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d, 2 if DT == torch.bfloat16 else 4)     # received per step (fwd + bwd)
     per_link = per_rank / max(world - 1, 1)
     comm = per_link / LINK * 1e3
     print(f"{model} {mode} world={world}: per-rank compute {ms:7.2f} ms   exchange {per_rank/1e9:5.2f} GB per rank and step, "
