@@ -180,6 +180,17 @@ __device__ __forceinline__ void store_vec_i32(int32_t* __restrict__ p, const int
   }
 }
 
+template <int VEC>
+__device__ __forceinline__ void load_vec_i32(const int32_t* __restrict__ p, int32_t (&a)[VEC]) {
+  if constexpr (VEC == 4) {
+    const int4 t = *reinterpret_cast<const int4*>(p);
+    a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a[k] = p[k];
+  }
+}
+
 __device__ __forceinline__ float leaky_relu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
 // ---- dropout mask shared by every dense-tail kernel (forward kernels apply it, backward kernels regenerate it).

@@ -528,6 +528,14 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
 
 using namespace allset;
 
+// fused_bwd2.hip: the same pass at two waves per SIMD (pairs of waves share a chunk); O = I = 128 without acc_in
+int fused_linear_bwd_pair_supported(int64_t O, int64_t I, int has_acc);
+int launch_fused_linear_bwd_pair(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy,
+                                 int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
+                                 const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                                 float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
+                                 const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl);
+
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
   return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
@@ -632,6 +640,12 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
+  if (fused_linear_bwd_pair_supported(O, I, ha)) {        // same grid, same slices: one partial per pair of waves
+    launch_fused_linear_bwd_pair(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
+                                 seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl);
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
 #define ALLSET_BWD_ALL_ARGS grid, st, has_ln, drop, relu, hm, ha, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in, \
                             gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc, psw, psb, psl
 #ifdef ALLSET_ABL_SINGLE

@@ -96,13 +96,47 @@ def _skip_collective(group=None) -> bool:
     return dist.get_world_size(group) == 1 and os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") != "1"
 
 
+def _host_staged(group, *tensors) -> bool:
+    """gloo moves host memory only: device tensors are staged through the host around the call.  That is how two real
+    ranks run the HIP path on ONE GPU (tests/test_gpu_two_ranks.py: RCCL refuses two ranks on the same device) -- the
+    autograd Functions, the kernels and the exchange wiring are the product's, only the wire is the host's."""
+    return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
+
+
+def _all_reduce_(t: Tensor, op=None, group=None) -> Tensor:
+    """In-place all-reduce of ``t`` (sum by default) on whatever backend the group has."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(group, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def _all_to_all_single(recv: Tensor, send: Tensor, group=None) -> None:
+    if _host_staged(group, recv, send):
+        hs = send.cpu()
+        hr = torch.empty_like(hs)
+        dist.all_to_all_single(hr, hs, group=group)
+        recv.copy_(hr)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+
+
 def _all_gather_rows(x: Tensor, group=None) -> Tensor:
     if _skip_collective(group):
         return x
     w = _world(group)
     x = x.contiguous()
     out = x.new_empty((w * x.shape[0],) + tuple(x.shape[1:]))
-    dist.all_gather_into_tensor(out, x, group=group)
+    if _host_staged(group, x):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, x.cpu(), group=group)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
     return out
 
 
@@ -113,8 +147,7 @@ def _reduce_scatter_rows(x: Tensor, group=None) -> Tensor:
     x = x.contiguous()
     per = x.shape[0] // w
     if dist.get_backend(group) == "gloo":            # gloo has no reduce_scatter: all-reduce + slice (tests only)
-        buf = x.clone()
-        dist.all_reduce(buf, group=group)
+        buf = _all_reduce_(x.clone(), group=group)
         r = dist.get_rank(group)
         return buf[r * per:(r + 1) * per].contiguous()
     out = x.new_empty((per,) + tuple(x.shape[1:]))
@@ -226,8 +259,7 @@ class _ShardedExtremeMerge(torch.autograd.Function):
         if _skip_collective(group):
             best = key
         else:
-            best = key.clone()
-            dist.all_reduce(best, op=dist.ReduceOp.MAX, group=group)     # [n_v_pad, d] int64: value and winner in one pass
+            best = _all_reduce_(key.clone(), dist.ReduceOp.MAX, group)   # [n_v_pad, d] int64: value and winner in one pass
         won = (best == key) & has.view(-1, 1)
         lo, hi = hg.v_lo, hg.v_hi
         kb = best[lo:hi]
@@ -356,7 +388,7 @@ class _ShardedPmaE2V(torch.autograd.Function):
         m_eff = torch.where(has, m_loc, neg_inf)
         m_g = m_eff.clone()
         if not _skip_collective(group):
-            dist.all_reduce(m_g, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce_(m_g, dist.ReduceOp.MAX, group)
         if hasattr(K, "merge_pack"):                 # one kernel; rows without local incidences have l_loc == 0 -> w = 0
             packed = K.merge_pack(o_loc, m_loc, l_loc, torch.where(has, m_g, m_loc), heads)
         else:
@@ -380,10 +412,14 @@ class _ShardedPmaE2V(torch.autograd.Function):
         gout = gout.contiguous().float()
         stats = K.bwd_stats(out, gout, m_g, l_g)                            # [n_own, H, 2]
         d = gout.shape[1]
-        packed = torch.cat([gout, stats.reshape(gout.shape[0], 2 * H)], dim=1)
-        full = _all_gather_rows(packed, ctx.group)
+        # [gout | stats | pad]: the gradient rows are gathered through a strided view of the packed table, so its row pitch
+        # must keep them 16-byte aligned (d + 2H floats is not a multiple of 4 for odd head counts: H = 1 gives 66 -- found by
+        # the two-rank GPU test, a 1-rank group never packs)
+        pad = (-(d + 2 * H)) % 4
+        parts = [gout, stats.reshape(gout.shape[0], 2 * H)] + ([gout.new_zeros(gout.shape[0], pad)] if pad else [])
+        full = _all_gather_rows(torch.cat(parts, dim=1), ctx.group)
         g_full = full[:, :d]                          # strided view: the kernels take a leading dimension, no copy
-        stats_full = full[:, d:].contiguous().view(-1, H, 2)
+        stats_full = full[:, d:d + 2 * H].contiguous().view(-1, H, 2)
         gV, galpha = K.bwd_src(hg.e2v, alpha, V, g_full.to(V.dtype) if g_full.dtype != V.dtype else g_full, stats_full, ctx.slope)
         return gV, galpha.to(ctx.in_dtype) if galpha.dtype != ctx.in_dtype else galpha, None, None, None, None, None
 
@@ -476,7 +512,7 @@ def _rows_to_cols(x: Tensor, group=None) -> Tensor:
         raise ValueError(f"column sharding needs the width ({d}) to be a multiple of the world size ({w})")
     send = _pack(x, w)                                                     # [P, n/P, d/P]: chunk j goes to rank j
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    _all_to_all_single(recv, send, group)
     return recv.view(w * r, d // w)                                        # chunk i = rank i's rows: already row-major
 
 
@@ -490,7 +526,7 @@ def _cols_to_rows(x: Tensor, group=None) -> Tensor:
         raise ValueError(f"column sharding needs the (padded) row count ({n}) to be a multiple of the world size ({w})")
     send = x.contiguous()                                                  # rows of block j (my columns) go to rank j
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    _all_to_all_single(recv, send, group)
     return _unpack(recv.view(w, n // w, dc))
 
 
@@ -679,6 +715,8 @@ def _a2a_async(out_views, in_views, group):
     if dist.get_backend(group) == "nccl":
         return dist.all_to_all(list(out_views), list(in_views), group=group, async_op=True)
     send = torch.stack(list(in_views))
+    if send.is_cuda:                      # host-staged (two ranks on one GPU): the exchange itself runs on host memory
+        send = send.cpu()
     tmp = torch.empty_like(send)
     return _PendingCopy(dist.all_to_all_single(tmp, send, group=group, async_op=True), tmp, list(out_views))
 
@@ -949,7 +987,7 @@ def allreduce_grads(params, group=None) -> None:
     if not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, group=group)
+    _all_reduce_(flat, group=group)
     off = 0
     for p in params:
         n = p.numel()

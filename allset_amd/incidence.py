@@ -103,6 +103,12 @@ class Incidence:
             self._perm_dst_long = self.by_dst.perm.long()
         return self._perm_dst_long
 
+    def perm_src_long(self) -> Tensor:
+        """``by_src.perm`` as int64, made once."""
+        if getattr(self, "_perm_src_long", None) is None:
+            self._perm_src_long = self.by_src.perm.long()
+        return self._perm_src_long
+
     def inv_perm_dst(self) -> Tensor:
         """int64[nnz]: position in ``by_dst`` of each incidence of the caller's edge list (the inverse of ``by_dst.perm``)."""
         if getattr(self, "_inv_perm_dst", None) is None:
@@ -123,7 +129,7 @@ class Incidence:
     def weights(self, norm: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """Route the reference's per-incidence ``norm`` (edge-list order; int64 ones by default,
         preprocessing.py:454) into (by_dst order, by_src order) f32 arrays.  All-ones -> (None, None):
-        the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms, and only while
+        (integer norms only, see below) the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms, and only while
         that very tensor object is alive: a temporary recomputed per forward (``Importance * norm`` under
         ``no_grad``) is usually handed the previous temporary's address with ``_version`` 0 by the caching
         allocator, so an address match alone would return the FIRST evaluation's weights for ever."""
@@ -138,11 +144,15 @@ class Incidence:
         hit = entry[1] if (entry is not None and entry[0]() is norm) else None
         if hit is None:
             flat = norm.reshape(-1)
-            if bool((flat == 1).all()):          # one-time sync per norm tensor
+            # The all-ones probe (a host sync) is for the reference's DEFAULT norm only: int64 ones (preprocessing.py:454),
+            # a persistent tensor probed once.  A floating-point norm is routed without looking at its values: under
+            # LearnMask the eval forward hands over a fresh ``Importance * norm`` temporary every call (models.py:451-452), so
+            # a probe would synchronise on every forward and is illegal inside a hipGraph capture (graphs.GraphedForward).
+            if not norm.dtype.is_floating_point and bool((flat == 1).all()):
                 hit = (None, None)
             else:
                 f = flat.to(torch.float32)
-                hit = (f[self.by_dst.perm.long()].contiguous(), f[self.by_src.perm.long()].contiguous())
+                hit = (f.index_select(0, self.perm_dst_long()), f.index_select(0, self.perm_src_long()))
             self._wcache.clear()
             self._wcache[key] = (weakref.ref(norm), hit)
         return hit

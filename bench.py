@@ -332,8 +332,8 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
 
     stats = torch.tensor([elapsed, float(nnz_local)], dtype=torch.float64, device=dev)
     if dist.is_initialized():
-        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        tmax = adist._all_reduce_(stats.clone(), dist.ReduceOp.MAX)     # (host-staged when the group is gloo, see main())
+        tsum = adist._all_reduce_(stats.clone(), dist.ReduceOp.SUM)
         elapsed, nnz_total = float(tmax[0]), float(tsum[1])
     else:
         nnz_total = float(nnz_local)
@@ -381,11 +381,19 @@ def main(argv=None, hooks=None):
         dev = torch.device("cpu")
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU"
+        # ALLSET_DIST_BACKEND=gloo: the ranks exchange through host memory and may SHARE a device (local rank modulo the
+        # device count) -- how the N = 2 control flow runs the HIP path with a real peer on a 1-GPU box
+        # (tests/test_gpu_two_ranks.py); RCCL itself refuses two ranks on one device.  Never the driver's mode.
+        backend = os.environ.get("ALLSET_DIST_BACKEND", "nccl")
+        if backend == "gloo":
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     force = os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") == "1"      # 1-rank RCCL group: API check on a 1-GPU box
     if (world > 1 or (force and "RANK" in os.environ)) and not dist.is_initialized():
         if cpu_mode:
+            dist.init_process_group("gloo")
+        elif backend == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -475,6 +483,10 @@ def main(argv=None, hooks=None):
                             "full-width weight gradient, add+LayerNorm kernels; gbps = algorithmic activation bytes / time"),
                            "kernels": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in dense_ks.items()}},
         }
+        if dist.is_initialized():
+            line["config"]["collectives"] = ("gloo, device tensors staged through the host, ranks may share a device (test mode)"
+                                             if dist.get_backend() == "gloo" and not cpu_mode else
+                                             ("gloo (CPU test)" if cpu_mode else "RCCL (torch.distributed nccl backend)"))
         if world > 1 or res2 is not None:
             parts = {primary: {"ms_per_step": res["ms_per_step"], "value": res["value"],
                                "parallelism": parallelism_label(args, primary, world), "is_value": True}}

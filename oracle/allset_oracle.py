@@ -22,8 +22,11 @@ reference-owned artefact: the published semantics of the two absent wheels, whic
 softmax denominator +1e-16).  For that seam: **parity unpinned** (see DESIGN.md "Oracle").
 
 The arithmetic is fp32 unless the caller passes fp64 tensors; eval-mode semantics (dropout is the
-identity; BatchNorm uses running statistics).  Autograd is plain torch autograd over these ops, which
-is what the reference relies on as well.
+identity; BatchNorm uses running statistics) unless a ``drop`` callable is passed: then every
+``F.dropout(..., training=True)`` site of the reference is visited in the reference's order and
+``drop(x, p)`` stands for it (``ExplicitDropout``: keep masks given by the caller, so a product run
+whose masks are known can be checked in TRAINING mode).  Autograd is plain torch autograd over these
+ops, which is what the reference relies on as well.
 """
 from __future__ import annotations
 
@@ -120,27 +123,57 @@ def pma_aggregate(x_v: Tensor, alpha_r: Tensor, edge_index: Tensor, negative_slo
 # --------------------------------------------------------------------------------------
 
 
-def _norm_apply(sd: Dict[str, Tensor], key: str, x: Tensor, kind: str) -> Tensor:
+class ExplicitDropout:
+    """``F.dropout(x, p, training=True)`` with the keep mask SUPPLIED: ``y = x * keep / (1 - p)`` (torch's scaling).
+
+    ``masks``: bool tensors in the order the reference's training forward meets its dropout sites (models.py:473,477,481;
+    layers.py:577,632).  Sites with p == 0 draw nothing and consume nothing, as in torch.  ``used`` counts consumed masks
+    so a caller can assert that product and oracle agree on the NUMBER of sites too."""
+
+    def __init__(self, masks):
+        self.masks = list(masks)
+        self.used = 0
+
+    def __call__(self, x: Tensor, p: float) -> Tensor:
+        if p <= 0.0:
+            return x
+        if self.used >= len(self.masks):
+            raise IndexError(f"dropout site {self.used}: no mask left (shape {tuple(x.shape)}, p = {p})")
+        keep = self.masks[self.used]
+        if tuple(keep.shape) != tuple(x.shape):
+            raise ValueError(f"dropout site {self.used}: mask {tuple(keep.shape)} for a tensor {tuple(x.shape)}")
+        self.used += 1
+        return x * keep.to(x.dtype) / (1.0 - p)
+
+
+
+def _norm_apply(sd: Dict[str, Tensor], key: str, x: Tensor, kind: str, training: bool = False) -> Tensor:
     if key + ".weight" not in sd:
         return x  # nn.Identity slot
     if kind == "ln":
         return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], 1e-5)
-    if kind == "bn":  # eval mode: running statistics
+    if kind == "bn":  # eval mode: running statistics; training mode: batch statistics (running buffers not updated here)
+        if training:
+            return F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], True, 0.0, 1e-5)
         return F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"],
                             sd[key + ".weight"], sd[key + ".bias"], False, 0.0, 1e-5)
     raise ValueError(kind)
 
 
-def mlp_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, normalization: str = "ln") -> Tensor:
-    """reference layers.py:571-579: norm0 -> [Linear -> ReLU -> norm -> dropout] x (L-1) -> Linear."""
+def mlp_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, normalization: str = "ln", drop=None, p: float = 0.0) -> Tensor:
+    """reference layers.py:571-579: norm0 -> [Linear -> ReLU -> norm -> dropout] x (L-1) -> Linear.
+    ``drop`` / ``p``: training mode, the MLP's own dropout rate (layers.py:577)."""
     n_lin = 0
     while f"{prefix}lins.{n_lin}.weight" in sd:
         n_lin += 1
-    x = _norm_apply(sd, f"{prefix}normalizations.0", x, normalization)
+    training = drop is not None
+    x = _norm_apply(sd, f"{prefix}normalizations.0", x, normalization, training)
     for i in range(n_lin - 1):
         x = F.linear(x, sd[f"{prefix}lins.{i}.weight"], sd[f"{prefix}lins.{i}.bias"])
         x = F.relu(x)
-        x = _norm_apply(sd, f"{prefix}normalizations.{i + 1}", x, normalization)
+        x = _norm_apply(sd, f"{prefix}normalizations.{i + 1}", x, normalization, training)
+        if training:
+            x = drop(x, p)
     last = n_lin - 1
     return F.linear(x, sd[f"{prefix}lins.{last}.weight"], sd[f"{prefix}lins.{last}.bias"])
 
@@ -168,23 +201,29 @@ def pma_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, edge_index: Tenso
 
 
 def halfnlhconv_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, edge_index: Tensor, norm: Tensor,
-                        aggr: str, attention: bool, heads: int, normalization: str) -> Tensor:
-    """reference layers.py:623-636 (HalfNLHconv.forward), eval mode."""
+                        aggr: str, attention: bool, heads: int, normalization: str, drop=None, p: float = 0.0) -> Tensor:
+    """reference layers.py:623-636 (HalfNLHconv.forward); eval mode unless ``drop`` is given (``p`` = the conv's
+    ``dropout``, which is also its MLPs' rate, layers.py:603-604; PMA has no dropout site, layers.py:63,76-80)."""
     if attention:
         return pma_forward(sd, prefix + "prop.", x, edge_index, heads)
     has_mlp = (prefix + "f_enc.lins.0.weight") in sd           # num_layers == 0 -> nn.Identity (Q8)
     if has_mlp:
-        x = mlp_forward(sd, prefix + "f_enc.", x, normalization)
+        x = mlp_forward(sd, prefix + "f_enc.", x, normalization, drop, p)
     x = F.relu(x)
+    if drop is not None:
+        x = drop(x, p)                                         # layers.py:632
     x = deepsets_aggregate(x, edge_index, norm, aggr)
     if has_mlp:
-        x = mlp_forward(sd, prefix + "f_dec.", x, normalization)
+        x = mlp_forward(sd, prefix + "f_dec.", x, normalization, drop, p)
     return F.relu(x)
 
 
 def setgnn_forward(sd: Dict[str, Tensor], args: SimpleNamespace, x: Tensor, edge_index: Tensor,
-                   norm: Tensor, collect: Optional[dict] = None) -> Tensor:
-    """reference models.py:450-484 (both the GPR branch :457-471 and the plain one), eval mode (dropouts are identities).
+                   norm: Tensor, collect: Optional[dict] = None, drop=None) -> Tensor:
+    """reference models.py:450-484 (both the GPR branch :457-471 and the plain one); eval mode (dropouts are identities)
+    unless ``drop`` is given: then training mode with ``drop(x, p)`` at every dropout site, in the reference's order
+    (input dropout 0.2 :473; per conv the MLPs' inner sites and the conv's own, layers.py:577,632; after every relu(conv)
+    :477,481 / :461,466; the classifier's inner sites).
 
     Unlike the reference this does not mutate ``edge_index`` in place (Q2): the hyperedge ids are
     re-based on a copy.  ``collect`` (optional dict) receives the intermediate conv outputs.
@@ -195,30 +234,35 @@ def setgnn_forward(sd: Dict[str, Tensor], args: SimpleNamespace, x: Tensor, edge
     rev = torch.stack([ei[1], ei[0]], dim=0)
     attention = bool(args.PMA)
     nl = args.normalization
+    p = float(args.dropout)
+    d_ = (lambda t, q: t) if drop is None else drop
     if getattr(args, "GPR", False):
-        xs = [F.relu(mlp_forward(sd, "MLP.", x, nl))]
+        xs = [F.relu(mlp_forward(sd, "MLP.", x, nl, drop, p))]
         for i in range(args.All_num_layers):
-            x = halfnlhconv_forward(sd, f"V2EConvs.{i}.", x, ei, norm, args.aggregate, attention, args.heads, nl)
+            x = halfnlhconv_forward(sd, f"V2EConvs.{i}.", x, ei, norm, args.aggregate, attention, args.heads, nl, drop, p)
             if collect is not None:
                 collect[f"v2e{i}"] = x
-            x = halfnlhconv_forward(sd, f"E2VConvs.{i}.", F.relu(x), rev, norm, args.aggregate, attention, args.heads, nl)
+            x = d_(F.relu(x), p)
+            x = halfnlhconv_forward(sd, f"E2VConvs.{i}.", x, rev, norm, args.aggregate, attention, args.heads, nl, drop, p)
             if collect is not None:
                 collect[f"e2v{i}"] = x
             x = F.relu(x)
             xs.append(x)
+            x = d_(x, p)
         x = torch.stack(xs, dim=-1)
         x = F.linear(x, sd["GPRweights.weight"]).squeeze()
-        return mlp_forward(sd, "classifier.", x, nl)
+        return mlp_forward(sd, "classifier.", x, nl, drop, p)
+    x = d_(x, 0.2)                                                           # models.py:473
     for i in range(args.All_num_layers):
-        x = halfnlhconv_forward(sd, f"V2EConvs.{i}.", x, ei, norm, args.aggregate, attention, args.heads, nl)
+        x = halfnlhconv_forward(sd, f"V2EConvs.{i}.", x, ei, norm, args.aggregate, attention, args.heads, nl, drop, p)
         if collect is not None:
             collect[f"v2e{i}"] = x          # raw conv output (what a forward hook on the conv sees)
-        x = F.relu(x)
-        x = halfnlhconv_forward(sd, f"E2VConvs.{i}.", x, rev, norm, args.aggregate, attention, args.heads, nl)
+        x = d_(F.relu(x), p)
+        x = halfnlhconv_forward(sd, f"E2VConvs.{i}.", x, rev, norm, args.aggregate, attention, args.heads, nl, drop, p)
         if collect is not None:
             collect[f"e2v{i}"] = x
-        x = F.relu(x)
-    return mlp_forward(sd, "classifier.", x, nl)
+        x = d_(F.relu(x), p)
+    return mlp_forward(sd, "classifier.", x, nl, drop, p)
 
 
 # --------------------------------------------------------------------------------------

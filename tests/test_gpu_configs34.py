@@ -169,3 +169,95 @@ def test_configs4_load_balanced_hyperedge_bins(c4, device):
         nnz += loc.shape[1]
         assert int(loc[1].max()) == gids.numel() - 1 and loc.shape[1] == int(load[r])
     assert nnz == int(load[0] + load[7])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole LAYER at the two configurations' sizes (round 3): both partitions' layer functions on one rank, train-free
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _float64_layer_rows(v2e_conv, e2v_conv, x, by_dst_v2e, by_src_v2e, sample_v, heads, in_dtype=torch.float64):
+    """Rows ``sample_v`` of ``relu(E2V(relu(V2E(x))))`` (AllSetTransformer layer, eval mode) in float64 through the CPU oracle
+    on the induced sub-hypergraph: all hyperedges incident to the sampled vertices, all members of those hyperedges."""
+    from oracle import allset_oracle as oracle
+    rp_s, col_s = by_src_v2e.rowptr, by_src_v2e.col            # vertex -> its hyperedges
+    rp_d, col_d = by_dst_v2e.rowptr, by_dst_v2e.col            # hyperedge -> its members
+    es = torch.unique(torch.cat([col_s[int(rp_s[v]):int(rp_s[v + 1])].long() for v in sample_v.tolist()]))
+    mem = [col_d[int(rp_d[e]):int(rp_d[e + 1])].long() for e in es.tolist()]
+    vs = torch.unique(torch.cat(mem + [sample_v]))
+    vid = {int(v): i for i, v in enumerate(vs.tolist())}
+    src = torch.tensor([vid[int(v)] for m in mem for v in m.tolist()], dtype=torch.int64)
+    dst = torch.repeat_interleave(torch.arange(len(mem)), torch.tensor([m.numel() for m in mem]))
+    ei = torch.stack([src, dst])
+    sd = {f"V2EConvs.0.{k}": v.detach().to("cpu", torch.float64) for k, v in v2e_conv.state_dict().items()}
+    sd.update({f"E2VConvs.0.{k}": v.detach().to("cpu", torch.float64) for k, v in e2v_conv.state_dict().items()})
+    xs = x[vs.to(x.device)].to("cpu", torch.float64)
+    ones = torch.ones(ei.shape[1], dtype=torch.float64)
+    e = torch.relu(oracle.halfnlhconv_forward(sd, "V2EConvs.0.", xs, ei, ones, "add", True, heads, "ln"))
+    # E -> V restricted to the sampled vertices: incidences (hyperedge e, vertex v in the sample)
+    sv = {int(v): i for i, v in enumerate(sample_v.tolist())}
+    keep = torch.tensor([int(vs[s]) in sv for s in src.tolist()])
+    rev = torch.stack([dst[keep], torch.tensor([sv[int(vs[s])] for s in src[keep].tolist()], dtype=torch.int64)])
+    v = torch.relu(oracle.halfnlhconv_forward(sd, "E2VConvs.0.", e, rev, ones[:rev.shape[1]], "add", True, heads, "ln"))
+    return v            # row i = vertex sample_v[i]   (every sampled vertex has >= 1 hyperedge in these generators)
+
+
+def _layer_both_partitions(n, hg, d, heads, dtype, device, seed):
+    from allset_amd import HalfNLHconv
+    from allset_amd import dist as adist
+    torch.manual_seed(seed)
+    a = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=heads, attention=True).to(device).to(dtype).eval()
+    b = HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=heads, attention=True).to(device).to(dtype).eval()
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(n, d, device=device, generator=g).to(dtype)
+    G = torch.randn(n, d, device=device, generator=g).to(dtype)
+    rows = adist.ShardedHypergraph(hg.edge_index, n, n, 1, 0).build_incidences()
+    cols = adist.ColumnShardedHypergraph(hg.edge_index, n, n, 1, 0).build_incidences()
+    res = {}
+    for name, fn, h in (("rows", adist.sharded_pma_layer, rows), ("columns", adist.colsharded_pma_layer, cols)):
+        outs = []
+        for rep in range(2):
+            xs = x.clone().requires_grad_(True)
+            out = fn(a, b, xs, h)
+            out.backward(G)
+            outs.append((out.detach(), xs.grad.detach(), [p.grad.detach().clone() for p in list(a.parameters()) + list(b.parameters())]))
+            for p in list(a.parameters()) + list(b.parameters()):
+                p.grad = None
+        o0, o1 = outs
+        assert torch.equal(o0[0], o1[0]) and torch.equal(o0[1], o1[1])                    # no atomics anywhere: bitwise repeatable
+        assert all(torch.equal(p0, p1) for p0, p1 in zip(o0[2], o1[2]))
+        assert bool(torch.isfinite(o0[0]).all()) and bool(torch.isfinite(o0[1]).all())
+        res[name] = o0
+        del outs, o1
+    return a, b, x, rows, res
+
+
+def test_configs3_full_layer_both_partitions(c3, device):
+    """One AllSetTransformer layer step (forward + backward, eval mode) at |V| = |E| = 8M, nnz = 128M, d = 128, 4 heads through
+    BOTH partitions' layer functions on one rank: finite, bitwise repeatable, the two partitions agree, sampled output rows
+    match a float64 recomputation of the layer (CPU oracle on the induced sub-hypergraph)."""
+    n, hg, v2e = c3
+    a, b, x, rows, res = _layer_both_partitions(n, hg, 128, 4, torch.float32, device, 31)
+    (o_r, gx_r, pg_r), (o_c, gx_c, pg_c) = res["rows"], res["columns"]
+    torch.testing.assert_close(o_c, o_r, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gx_c, gx_r, rtol=1e-4, atol=1e-4 * float(gx_r.abs().max()))
+    for p_c, p_r in zip(pg_c, pg_r):
+        torch.testing.assert_close(p_c, p_r, rtol=1e-3, atol=1e-3 * max(float(p_r.abs().max()), 1e-3))
+    sample = torch.tensor([0, 1_234_567, 4_194_305, n - 1])
+    ref = _float64_layer_rows(a, b, x, rows.v2e.by_dst, rows.v2e.by_src, sample, 4)
+    torch.testing.assert_close(o_r[sample.to(device)].double().cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_configs4_full_layer_both_partitions_bf16(c4, device):
+    """The same at configs[4]: |V| = |E| = 2M, truncated-Zipf sizes <= 4096, d = 256, bf16 end to end (fp32 accumulation)."""
+    n, hg, v2e = c4
+    a, b, x, rows, res = _layer_both_partitions(n, hg, 256, 4, torch.bfloat16, device, 41)
+    (o_r, gx_r, pg_r), (o_c, gx_c, pg_c) = res["rows"], res["columns"]
+    # bf16 storage: one rounding of O(1) LayerNorm outputs is 2^-8 relative; the two code paths round at different places
+    torch.testing.assert_close(o_c.float(), o_r.float(), rtol=4e-2, atol=4e-2)
+    assert float((gx_c.float() - gx_r.float()).abs().mean()) <= 2e-2 * float(gx_r.float().abs().mean()) + 1e-6
+    deg = rows.v2e.by_src.rowptr[1:] - rows.v2e.by_src.rowptr[:-1]
+    cand = torch.nonzero((deg > 0) & (deg < 40)).reshape(-1)
+    sample = cand[torch.tensor([0, cand.numel() // 3, cand.numel() - 1])].cpu()
+    ref = _float64_layer_rows(a, b, x, rows.v2e.by_dst, rows.v2e.by_src, sample, 4)
+    got = o_r[sample.to(device)].double().cpu()
+    assert float((got - ref).abs().max()) <= 6e-2 * max(1.0, float(ref.abs().max()))

@@ -134,3 +134,32 @@ def test_device_seed_counter_changes_mask(device):
     u = torch.relu(F.linear(y3, W, b))
     kept = f1 != 0
     torch.testing.assert_close(f1[kept], (u / (1 - p))[kept], rtol=1e-4, atol=1e-4)
+
+
+def test_graphed_forward_with_learnmask_routes_weights_inside_the_graph(device):
+    """LearnMask (reference models.py:336-337,451-452): the eval forward multiplies ``Importance * norm`` into a fresh
+    temporary every call; routing it to CSR order must neither synchronise with the host (illegal in a capture) nor be
+    frozen at capture time -- a replay after an in-place change of ``Importance`` follows the eager result."""
+    from allset_amd import SetGNN
+    from allset_amd.graphs import GraphedForward
+    case = cases.build_case("rand50_ds_add_wnorm")
+    args = copy.copy(case["args"])
+    args.LearnMask = True
+    norm = torch.from_numpy(case["norm"]).float()
+    torch.manual_seed(0)
+    model = SetGNN(args, norm).to(device)
+    model.reset_parameters()
+    with torch.no_grad():
+        model.Importance.copy_(torch.linspace(0.5, 1.5, norm.numel()))
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(device), edge_index=torch.from_numpy(case["edge_index"]).to(device),
+                           norm=norm.to(device))
+    model.eval()
+    with torch.no_grad():
+        ref = model(data).clone()
+    gf = GraphedForward(model, data)            # raised before round 3: the all-ones probe of the temporary synchronised
+    assert torch.equal(gf(), ref)
+    with torch.no_grad():
+        model.Importance.mul_(0.5).add_(0.1)
+        ref2 = model(data).clone()
+    assert not torch.equal(ref2, ref)
+    assert torch.equal(gf(), ref2)

@@ -1,0 +1,140 @@
+"""GPU: one TRAINING-mode step of ``SetGNN`` (dropout 0.5 inside the convs, input dropout 0.2 -- the configuration
+bench.py times and train.py runs) against the oracle's explicit-mask training mode (``oracle.ExplicitDropout``, itself pinned
+against the live reference in ``.train()`` mode by tests/test_oracle_vs_reference_live.py).
+
+The product's dropout masks are a counter hash of (seed, element index) evaluated inside whichever kernel carries the site
+(fused Linear prologue / epilogue, LayerNorm pass, add+LayerNorm pass, relu-dropout pass).  The test records the seeds the
+product draws during the forward (one per site, in forward order), re-evaluates each site's keep mask with the library's
+stand-alone relu-dropout kernel on a tensor of ones of the site's shape (same hash, same element indexing -- which is exactly
+what this test then proves for every fused site), takes the input dropout's mask from torch's generator, and hands the masks
+to the oracle in the reference's site order (models.py:473,477,481; layers.py:577,632).  Logits, input gradient and every
+parameter gradient must agree within fp32 tolerance: the dropped positions, the 1/(1-p) scaling, the 1-bit activation masks
+of the backward and the dropout applied to the gradients are all on the compared path."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _keep_mask(seed: int, shape, p: float, device) -> torch.Tensor:
+    """Keep mask of a dropout site with host seed ``seed`` over a row-major tensor of ``shape``: the library's own
+    ``allset_relu_dropout_fwd`` on ones (kept elements come out as 1 / (1 - p), dropped ones as 0)."""
+    from allset_amd import _lib
+    from allset_amd._lib import check, ptr, stream_of, on_device
+    ones = torch.ones(shape, device=device)
+    y = torch.empty_like(ones)
+    with on_device(device):
+        check(_lib.load().allset_relu_dropout_fwd(ptr(ones), float(p), int(seed), ptr(y), ones.numel(), ptr(None), stream_of(device)),
+              "allset_relu_dropout_fwd")
+    keep = y != 0
+    kept = y[keep]
+    assert kept.numel() == 0 or torch.allclose(kept, torch.full_like(kept, 1.0 / (1.0 - p)), rtol=1e-6)
+    return keep.cpu()
+
+
+class _ShapeProbe:
+    """A ``drop`` callable for the oracle that only records (shape, p) of every site it meets (values pass through)."""
+
+    def __init__(self):
+        self.sites = []
+
+    def __call__(self, x, p):
+        if p > 0.0:
+            self.sites.append((tuple(x.shape), float(p)))
+        return x
+
+
+CASES = [("rand50_ds_add", {}), ("rand50_pma_h4", {}), ("cora_ds_add", {}), ("citeseer_pma_h4", {}),
+         ("rand50_ds_add", dict(MLP_num_layers=3, Classifier_num_layers=2, All_num_layers=2)),
+         ("rand50_ds_mean", dict(dropout=0.2, Classifier_num_layers=2)),
+         ("rand50_pma_h4", dict(All_num_layers=2, Classifier_num_layers=2, MLP_hidden=128))]
+
+
+@pytest.mark.parametrize("name,over", CASES, ids=lambda v: v if isinstance(v, str) else ("-".join(f"{k}{w}" for k, w in v.items()) or "stock"))
+def test_training_step_matches_oracle_with_the_products_masks(name, over, device, monkeypatch):
+    from allset_amd import SetGNN, dense
+    from oracle import allset_oracle as oracle
+    case = cases.build_case(name)
+    args = SimpleNamespace(**{**vars(case["args"]), **over})
+    assert args.dropout > 0.0
+    torch.manual_seed(case["seed"])
+    model = SetGNN(args)
+    model.reset_parameters()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.train().to(device)
+
+    x_np, ei_np, norm_np = case["x"], case["edge_index"], case["norm"]
+    x = torch.from_numpy(x_np).to(device).requires_grad_(True)
+    data = SimpleNamespace(x=x, edge_index=torch.from_numpy(ei_np).clone().to(device), norm=torch.from_numpy(norm_np).to(device))
+
+    seeds = []
+    real_draw = dense._draw_seed
+
+    def recording_draw():
+        s = real_draw()
+        seeds.append(s)
+        return s
+    monkeypatch.setattr(dense, "_draw_seed", recording_draw)
+
+    torch.manual_seed(1234)                               # governs torch's device generator (input dropout) and the host seeds
+    logits = model(data)
+    n_fwd_seeds = len(seeds)
+    G = torch.from_numpy(cases.cotangent(name, logits.shape)).to(device)
+    (logits * G).sum().backward()
+    assert len(seeds) == n_fwd_seeds                      # the backward re-uses the forward's seeds, it draws none
+
+    # ---- the sites in the reference's order, by a dry run of the oracle
+    probe = _ShapeProbe()
+    xo = torch.from_numpy(x_np)
+    oracle.setgnn_forward(sd, args, xo, torch.from_numpy(ei_np), torch.from_numpy(norm_np), drop=probe)
+    sites = probe.sites
+    assert sites[0] == (tuple(x_np.shape), 0.2)
+    assert len(sites) == 1 + n_fwd_seeds, (sites, n_fwd_seeds)     # one hash seed per site after the (torch) input dropout
+
+    # ---- the product's masks
+    torch.manual_seed(1234)
+    masks = [(F.dropout(torch.ones_like(x), p=0.2, training=True) != 0).cpu()]
+    masks += [_keep_mask(s, shape, p, device) for s, (shape, p) in zip(seeds, sites[1:])]
+    for m, (shape, p) in zip(masks, sites):               # sanity: the masks drop about p of the positions
+        if m.numel() >= 2000:
+            assert abs(1.0 - float(m.float().mean()) - p) < 0.05, (shape, p, float(m.float().mean()))
+
+    # ---- oracle, training mode, same masks
+    sdo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    xo = torch.from_numpy(x_np).clone().requires_grad_(True)
+    drop = oracle.ExplicitDropout(masks)
+    ref = oracle.setgnn_forward(sdo, args, xo, torch.from_numpy(ei_np), torch.from_numpy(norm_np), drop=drop)
+    assert drop.used == len(masks)
+    (ref * G.cpu()).sum().backward()
+
+    def close(got, exp, what, scale_floor=1e-3):
+        scale = max(float(exp.abs().max()), scale_floor)
+        torch.testing.assert_close(got, exp, rtol=1e-4, atol=1e-4 * scale, msg=lambda m: f"{name} {what}: {m}")
+
+    close(logits.detach().cpu(), ref.detach(), "logits")
+    close(x.grad.cpu(), xo.grad, "grad_x")
+    gscale = max(float(t.grad.abs().max()) for t in sdo.values() if t.requires_grad and t.grad is not None)
+    for k, p in model.named_parameters():
+        exp = sdo[k].grad
+        if exp is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        close(p.grad.cpu(), exp, f"grad {k}", scale_floor=1e-2 * gscale)     # (analytically-zero gradients: tests/util.py)
+
+
+def test_eval_mode_draws_no_seed(device, monkeypatch):
+    from allset_amd import SetGNN, dense
+    case = cases.build_case("rand50_ds_add")
+    model = SetGNN(case["args"]).eval().to(device)
+    calls = []
+    monkeypatch.setattr(dense, "_draw_seed", lambda: calls.append(1) or 1)
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(device), edge_index=torch.from_numpy(case["edge_index"]).clone().to(device),
+                           norm=torch.from_numpy(case["norm"]).to(device))
+    model(data)
+    assert not calls

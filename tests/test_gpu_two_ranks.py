@@ -1,0 +1,267 @@
+"""GPU, world_size 2 on ONE device: two real ranks run the product's sharded layers -- the HIP kernels behind the real
+``torch.autograd.Function``s of ``allset_amd/dist.py`` -- and exchange through gloo, device tensors staged through the host
+(``dist._host_staged``; RCCL refuses two ranks on one GPU, and the driver's box has one).  What this covers that neither the
+2-rank gloo tests on CPU (oracle as the local aggregate) nor the 1-rank RCCL tests (no peer) do: partial sums, (m, l, o)
+merges, extreme-key merges, column slices and the asynchronous chunked exchange computed by the HIP path and combined with a
+peer's.  Both ranks run every configuration in one spawn; the parent compares with the unsharded HIP layer and with the CPU
+oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+N_V, N_E, NNZ = 301, 187, 2600            # odd counts: padded owned blocks
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# kind, scheme, aggr / heads, partition method, chunks, width
+LAYER_CFGS = [
+    ("ds", "rows", "add", "contiguous", 1, 64), ("ds", "rows", "mean", "lpt", 1, 64), ("ds", "rows", "max", "contiguous", 1, 64),
+    ("ds", "rows", "min", "lpt", 1, 32),
+    ("ds", "cols", "add", None, 1, 64), ("ds", "cols", "mean", None, 4, 64), ("ds", "cols", "max", None, 1, 128),
+    ("ds", "cols", "add", None, 4, 128),
+    ("pma", "rows", 4, "contiguous", 1, 64), ("pma", "rows", 1, "lpt", 1, 64),
+    ("pma", "cols", 4, None, 1, 64), ("pma", "cols", 1, None, 1, 64), ("pma", "cols", 4, None, 4, 128), ("pma", "cols", 1, None, 4, 64),
+]
+# mode, scheme, chunks, model kwargs
+MODEL_CFGS = [
+    ("ds_add", "rows", 1, dict(GPR=True, LearnMask=True)), ("ds_add", "cols", 1, dict(GPR=True, LearnMask=True)),
+    ("ds_add", "cols", 4, dict(GPR=True, LearnMask=True)), ("pma_h4", "rows", 1, {}), ("pma_h4", "cols", 4, {}),
+    ("ds_mean", "cols", 1, {}),
+]
+
+
+def _problem(d, seed=42):
+    rng = np.random.default_rng(seed)
+    pairs = sorted({(int(rng.integers(N_V)), int(rng.integers(N_E))) for _ in range(NNZ)} | {(0, e) for e in range(N_E)})
+    ei = torch.tensor(pairs, dtype=torch.int64).t().contiguous()
+    norm = torch.from_numpy(rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((N_V, d)).astype(np.float32))
+    G = torch.from_numpy(rng.standard_normal((N_V, d)).astype(np.float32))
+    return ei, norm, x, G
+
+
+def _convs(kind, arg, d):
+    from allset_amd import HalfNLHconv
+    torch.manual_seed(3)
+    attn = kind == "pma"
+    H = arg if attn else 1
+    return (HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=attn).eval(),
+            HalfNLHconv(d, d, d, 2, 0.0, "ln", True, heads=H, attention=attn).eval())
+
+
+def _shard(adist, scheme, ei, norm, world, rank, method, chunks, dev):
+    if scheme == "cols":
+        return adist.ColumnShardedHypergraph(ei.to(dev), N_V, N_E, world, rank, norm=None if norm is None else norm.to(dev),
+                                             chunks=chunks).build_incidences()
+    owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=N_E), world, method)
+    loc, gids = adist.local_shard(ei, owner, rank)
+    keep = owner[ei[1]] == rank
+    return adist.ShardedHypergraph(loc.to(dev), N_V, gids.numel(), world, rank, norm=None if norm is None else norm[keep].to(dev),
+                                   inc_ids=keep.nonzero().reshape(-1).to(dev)).build_incidences()
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (os.path.dirname(HERE), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _run_configs(rank, world, dev, q)
+    except BaseException:                       # report instead of leaving the parent waiting for a result that never comes
+        import traceback
+        q.put((rank, "ERROR\n" + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_configs(rank, world, dev, q):
+    if True:
+        import cases
+        from allset_amd import SetGNN, dist as adist
+        res = {}
+        for cfg in LAYER_CFGS:
+            kind, scheme, arg, method, chunks, d = cfg
+            ei, norm, x, G = _problem(d)
+            hg = _shard(adist, scheme, ei, norm if kind == "ds" else None, world, rank, method, chunks, dev)
+            a, b = _convs(kind, arg, d)
+            a.to(dev); b.to(dev)
+            xp = torch.cat([x, x.new_zeros(hg.n_v_pad - N_V, d)])
+            Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - N_V, d)])
+            xo = xp[hg.v_lo:hg.v_hi].to(dev).requires_grad_(True)
+            if kind == "ds":
+                layer = adist.colsharded_deepsets_layer if scheme == "cols" else adist.sharded_deepsets_layer
+                out = layer(a, b, xo, hg, aggr=arg, **({"chunks": chunks} if scheme == "cols" else {}))
+            else:
+                layer = adist.colsharded_pma_layer if scheme == "cols" else adist.sharded_pma_layer
+                out = layer(a, b, xo, hg, **({"chunks": chunks} if scheme == "cols" else {}))
+            (out * Gp[hg.v_lo:hg.v_hi].to(dev)).sum().backward()
+            params = list(a.parameters()) + list(b.parameters())
+            adist.allreduce_grads(params)
+            res[("layer",) + cfg] = (out.detach().cpu().numpy(), xo.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in params])
+        for cfg in MODEL_CFGS:
+            mode, scheme, chunks, kw = cfg
+            d = 64
+            ei, norm, x, G = _problem(d, seed=7)
+            args = cases.make_args(mode, d, 64, 5, All_num_layers=2, **kw)
+            torch.manual_seed(11)
+            model = SetGNN(args, norm if kw.get("LearnMask") else None).eval()
+            if kw.get("LearnMask"):
+                with torch.no_grad():
+                    model.Importance.copy_(torch.linspace(0.5, 1.5, ei.shape[1]))
+            model.to(dev)
+            nrm = norm if kw.get("LearnMask") else torch.ones(ei.shape[1], dtype=torch.int64)
+            hg = _shard(adist, scheme, ei, nrm, world, rank, "contiguous", chunks, dev)
+            sharded = adist.ShardedSetGNN(model, hg)
+            xp = torch.cat([x, x.new_zeros(hg.n_v_pad - N_V, d)])
+            out = sharded(xp[hg.v_lo:hg.v_hi].to(dev))
+            live = max(0, min(hg.v_hi, N_V) - hg.v_lo)
+            cot = torch.linspace(-1.0, 1.0, N_V * out.shape[1]).view(N_V, -1)[hg.v_lo:hg.v_lo + live].to(dev)
+            (out[:live] * cot).sum().backward()
+            sharded.allreduce_grads()
+            grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+            res[("model", mode, scheme, chunks, tuple(sorted(kw)))] = (
+                out.detach().cpu().numpy(), grads, {k: v.cpu().numpy() for k, v in model.state_dict().items()})
+        q.put((rank, res))
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            r, payload = q.get(timeout=420)
+            assert not isinstance(payload, str), f"rank {r}: {payload}"
+            results[r] = payload
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return results
+
+
+@pytest.mark.parametrize("cfg", LAYER_CFGS, ids=lambda c: "-".join(str(t) for t in c))
+def test_two_rank_hip_layer_equals_unsharded_hip_layer_and_oracle(cfg, two_ranks, device):
+    import torch.nn.functional as F
+    from allset_amd import Incidence
+    from oracle import allset_oracle as oracle
+    kind, scheme, arg, method, chunks, d = cfg
+    ei, norm, x, G = _problem(d)
+    key = ("layer",) + cfg
+    out = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(2)])[:N_V]
+    gx = torch.cat([torch.from_numpy(two_ranks[r][key][1]) for r in range(2)])[:N_V]
+    pg = [torch.from_numpy(t) for t in two_ranks[0][key][2]]
+    for g0, g1 in zip(two_ranks[0][key][2], two_ranks[1][key][2]):
+        np.testing.assert_array_equal(g0, g1)                      # after the all-reduce both ranks hold the same gradients
+
+    # (a) the unsharded layer on the HIP kernels
+    a, b = _convs(kind, arg, d)
+    a.to(device); b.to(device)
+    inc = Incidence.from_edge_index(ei.to(device), n_src=N_V, n_dst=N_E)
+    xr = x.to(device).requires_grad_(True)
+    ag = arg if kind == "ds" else "add"
+    nrm = norm.to(device) if kind == "ds" else None
+    ref = F.relu(b(F.relu(a(xr, inc, nrm, ag)), inc.reversed(n_dst=N_V), nrm, ag))
+    (ref * G.to(device)).sum().backward()
+    torch.testing.assert_close(out, ref.detach().cpu(), rtol=1e-4, atol=1e-4)
+    ties = kind == "ds" and arg in ("max", "min")                  # exact ties may route a gradient to another incidence
+    if not ties:
+        torch.testing.assert_close(gx, xr.grad.cpu(), rtol=1e-4, atol=1e-4 * max(1.0, float(xr.grad.abs().max())))
+        for got, p in zip(pg, list(a.parameters()) + list(b.parameters())):
+            torch.testing.assert_close(got, p.grad.cpu(), rtol=1e-3, atol=1e-3 * max(1.0, float(p.grad.abs().max())))
+
+    # (b) the CPU oracle (restatement of the reference's layer) with the same parameters
+    a, b = _convs(kind, arg, d)
+    sd = {f"V2EConvs.0.{k}": v.detach().clone() for k, v in a.state_dict().items()}
+    sd.update({f"E2VConvs.0.{k}": v.detach().clone() for k, v in b.state_dict().items()})
+    H = arg if kind == "pma" else 1
+    onorm = norm if kind == "ds" else torch.ones(ei.shape[1])
+    xo = x.clone().requires_grad_(True)
+    e = oracle.halfnlhconv_forward(sd, "V2EConvs.0.", xo, ei, onorm, ag, kind == "pma", H, "ln")
+    if e.shape[0] < N_E:
+        e = torch.cat([e, e.new_zeros(N_E - e.shape[0], d)])
+    v = oracle.halfnlhconv_forward(sd, "E2VConvs.0.", F.relu(e), torch.stack([ei[1], ei[0]]), onorm, ag, kind == "pma", H, "ln")
+    v = F.relu(v)
+    (v * G[:v.shape[0]]).sum().backward()
+    torch.testing.assert_close(out[:v.shape[0]], v.detach(), rtol=1e-4, atol=1e-4)
+    if not ties:
+        torch.testing.assert_close(gx, xo.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(xo.grad.abs().max())))
+
+
+@pytest.mark.parametrize("cfg", MODEL_CFGS, ids=lambda c: "-".join(str(t) for t in c[:3]) + ("-gpr-mask" if c[3] else ""))
+def test_two_rank_sharded_setgnn_equals_oracle(cfg, two_ranks):
+    import cases
+    from oracle import allset_oracle as oracle
+    mode, scheme, chunks, kw = cfg
+    key = ("model", mode, scheme, chunks, tuple(sorted(kw)))
+    d = 64
+    ei, norm, x, G = _problem(d, seed=7)
+    args = cases.make_args(mode, d, 64, 5, All_num_layers=2, **kw)
+    sd = {k: torch.from_numpy(v).clone() for k, v in two_ranks[0][key][2].items()}
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    nrm = norm if kw.get("LearnMask") else torch.ones(ei.shape[1], dtype=torch.int64)
+    ref = oracle.setgnn_forward(sd, args, x, ei, nrm)
+    cot = torch.linspace(-1.0, 1.0, N_V * ref.shape[1]).view(N_V, -1)
+    (ref * cot).sum().backward()
+    got = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(2)])[:N_V]
+    torch.testing.assert_close(got, ref.detach(), rtol=1e-4, atol=1e-4)
+    scale = max(float(t.grad.abs().max()) for t in sd.values() if t.requires_grad and t.grad is not None)
+    for r in range(2):
+        grads = two_ranks[r][key][1]
+        for k, t in sd.items():
+            if t.requires_grad and t.grad is not None and k in grads:
+                torch.testing.assert_close(torch.from_numpy(grads[k]), t.grad, rtol=1e-3, atol=1e-4 * max(scale, 1.0),
+                                           msg=lambda m, k=k: f"{k} (rank {r}): {m}")
+
+
+def test_bench_two_ranks_one_gpu_gloo():
+    """bench.py --gpus 2 as the driver launches it, except for the wire: ALLSET_DIST_BACKEND=gloo (host-staged collectives, both
+    ranks on the one device).  Both partitions, blocking and chunked (asynchronous) column exchange."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    for model, chunks in (("deepsets", 1), ("deepsets", 2), ("pma", 2)):
+        env = dict(os.environ, ALLSET_DIST_BACKEND="gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--n-per-gpu", "20000", "--model", model, "--pipeline-chunks", str(chunks)]
+        res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and "gloo" in line["config"]["collectives"]
+        parts = line["partitions"]
+        assert {"rows", "columns"} <= set(parts) and all("error" not in parts[k] for k in ("rows", "columns")), parts
+        assert line["config"]["nnz"] == 2 * 20000 * 16
+        for k in ("rows", "columns"):
+            assert abs(parts[k]["value"] - line["config"]["nnz"] * 128 / (parts[k]["ms_per_step"] * 1e-3)) <= 1e-6 * parts[k]["value"]

@@ -57,3 +57,74 @@ def test_oracle_equals_live_reference_on_random_configurations(pma, layers, mlp_
             continue
         torch.testing.assert_close(sdict[kk].grad, p.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(p.grad.abs().max())),
                                    msg=lambda m: f"{kk}: {m}")
+
+
+class _RecordDropout:
+    """Wraps torch's own ``F.dropout`` while the LIVE reference runs in training mode: calls the real function and reads
+    the keep mask off its output (``out != 0``; where the input itself is 0 -- behind a relu -- the mask is immaterial
+    for the value and the gradient is cut by the relu, so those positions count as kept)."""
+
+    def __init__(self):
+        import torch.nn.functional as F
+        self.F, self.orig, self.masks = F, F.dropout, []
+
+    def __enter__(self):
+        def dropout(x, p=0.5, training=True, inplace=False):
+            out = self.orig(x, p=p, training=training, inplace=False)
+            if training and p > 0.0:
+                self.masks.append(((out != 0) | (x == 0)).detach().clone())
+            return out
+        self.F.dropout = dropout
+        return self
+
+    def __exit__(self, *exc):
+        self.F.dropout = self.orig
+        return False
+
+
+@settings(deadline=None, max_examples=int(os.environ.get("ALLSET_HYPOTHESIS_EXAMPLES", "25")),
+          derandomize=os.environ.get("ALLSET_HYPOTHESIS_RANDOM", "0") != "1")
+@given(pma=st.booleans(), layers=st.integers(1, 2), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64]),
+       heads=st.sampled_from([1, 4]), aggr=st.sampled_from(["add", "mean", "max"]), norm=st.sampled_from(["ln", "None"]),
+       gpr=st.booleans(), p=st.sampled_from([0.5, 0.2]), sd=st.integers(0, 10 ** 6))
+def test_oracle_training_mode_with_explicit_masks_equals_live_reference(pma, layers, mlp_layers, hidden, heads, aggr, norm, gpr, p, sd):
+    """The explicit-mask training mode of the oracle (``setgnn_forward(..., drop=ExplicitDropout(masks))``) against the live
+    reference in ``.train()`` mode: same dropout sites in the same order (every recorded mask is consumed, shapes agree),
+    same logits and gradients.  Both sides run in float64 (dropout in front of stacked LayerNorms over 16 columns amplifies
+    fp32 rounding differences between the two implementations to ~3e-5; in float64 the comparison is about semantics).  This pins the oracle that tests/test_gpu_train_parity.py checks the product's training step
+    against."""
+    _, ref_models = ref_shim.import_reference()
+    rng = np.random.default_rng(sd)
+    n_v, n_e, f, k = 40, 17, 12, 5
+    ei = cases.random_hypergraph(rng, n_v, n_e, 150, True)
+    x = rng.standard_normal((n_v, f)).astype(np.float32)
+    args = cases.make_args("pma_h1" if pma else "ds_add", f, hidden, k, All_num_layers=layers, MLP_num_layers=mlp_layers,
+                           heads=heads if pma else 1, aggregate=aggr if not pma else "add", normalization=norm, GPR=gpr,
+                           Classifier_num_layers=2, dropout=p)
+    norm_t = torch.ones(ei.shape[1], dtype=torch.int64)
+    torch.manual_seed(sd)
+    model = ref_models.SetGNN(args)
+    model.reset_parameters()
+    model.double().train()
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    with _RecordDropout() as rec:
+        ref = model(SimpleNamespace(x=xr, edge_index=torch.from_numpy(ei).clone(), norm=norm_t))
+    G = torch.from_numpy(rng.standard_normal(tuple(ref.shape)))
+    (ref * G).sum().backward()
+    sdict = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    for kk, v in sdict.items():
+        if v.is_floating_point() and "running" not in kk:
+            v.requires_grad_(True)
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    drop = oracle.ExplicitDropout(rec.masks)
+    out = oracle.setgnn_forward(sdict, args, xo, torch.from_numpy(ei), norm_t, drop=drop)
+    assert drop.used == len(rec.masks) and len(rec.masks) >= 2
+    (out * G).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(xo.grad, xr.grad, rtol=1e-8, atol=1e-9 * max(1.0, float(xr.grad.abs().max())))
+    for kk, pp in model.named_parameters():
+        if pp.grad is None or sdict[kk].grad is None:
+            assert (pp.grad is None or float(pp.grad.abs().max()) == 0.0) and (sdict[kk].grad is None or float(sdict[kk].grad.abs().max()) == 0.0), kk
+            continue
+        torch.testing.assert_close(sdict[kk].grad, pp.grad, rtol=1e-8, atol=1e-9 * max(1.0, float(pp.grad.abs().max())),
+                                   msg=lambda m: f"{kk}: {m}")

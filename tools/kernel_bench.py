@@ -60,7 +60,10 @@ for dist in args.dists.split(","):
         out, arg = ops.segreduce(2, csr.rowptr, csr.col, None, x, n, want_arg=True)
         posT = inc.pos_dst_of_src()
         report("segmax_bwd", timeit(lambda: ops.segmax_bwd(T.rowptr, T.col, posT, None, arg, x, n)), nnz * (8 * d + 8) + (n + 1) * 4 + n * 4 * d)
-        del out, arg
+        gO = torch.randn(n, d, device=dev)
+        report("sddmm_rowdot sum", timeit(lambda: ops.sddmm_rowdot(0, csr.rowptr, csr.col, x, gO, None)), nnz * (4 * d + 8) + (n + 1) * 4 + n * 4 * d)
+        report("sddmm_rowdot max", timeit(lambda: ops.sddmm_rowdot(2, csr.rowptr, csr.col, x, gO, arg)), nnz * (4 * d + 8) + (n + 1) * 4 + n * 8 * d)
+        del out, arg, gO
     report("  .. pma_fwd short-row kernel", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=2)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
     if csr.row_order is not None:
         report("  .. pma_fwd long rows first", timeit(lambda: ops.pma_fwd(csr.rowptr, csr.col, alpha, x, H, 0.2, n, variant=1, row_order=csr.row_order)), nnz * (ES * d + 4 + 4 * H) + (n + 1) * 4 + n * (ES * d + 8 * H))
