@@ -13,11 +13,11 @@
 // read all of it -- row-major 16-byte fragments for backward-data, ds_read_b64_tr_b16 transposes for the weight gradient.
 // u is private: wave h stores its half of the u planes in the very bytes its ga half occupied.  The LayerNorm backward's two
 // row sums run over all I columns: each wave reduces its 64 and the pair swaps the partial sums through LDS.
-// Three workgroup barriers per chunk (lgkmcnt-only waits: the global prefetch stays in flight across them):
+// Three hand-offs per chunk, PAIR-local (LDS sequence numbers, see pair_signal / pair_wait; no workgroup barrier in the loop):
 //     B1  ga image complete                      -> backward-data MFMAs, slab trips, partial row sums
 //     B2  partial sums posted                    -> LayerNorm backward -> gx, u; transposed ga fragments into registers
 //     B3  both waves are done with the ga image  -> u planes over it, weight-gradient MFMAs
-// LDS: 96 KB W planes + 4 x 12 KB pair images + 8 x 2 KB slabs = 160 KB exactly (gamma / beta live in registers).
+// LDS: 96 KB W planes + 4 x 12 KB pair images + 8 x 1.25 KB slabs + gamma / beta + 8 sequence words = 155 KB.
 #include <stdlib.h>
 
 #include "common.h"
@@ -56,7 +56,23 @@ __device__ __forceinline__ int img_off_p(int row, int colbyte) {
 }
 __device__ __forceinline__ uint32_t hash_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; return x; }   // pair_hash's finaliser
 // LDS-only barrier: global loads / stores stay in flight (s_barrier does not need them drained)
-#define ALLSET_PAIR_BARRIER() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// One s_barrier per TICK.  A chunk is four segments of alternating kind,
+//     S0 (vector)  ga: mask + bf16 planes into the pair's image
+//     S1 (matrix)  backward-data MFMAs, slab trips, this wave's share of the LayerNorm row sums
+//     S2 (vector)  LayerNorm backward -> gx, u recomputed, transposed ga fragments into registers
+//     S3 (matrix)  u planes over the image, weight-gradient MFMAs
+// and the two waves of a SIMD (waves w and w + 4 of the workgroup: pairs 0-1 and pairs 2-3) run the SAME program ONE TICK
+// APART: while one is in a matrix segment its SIMD-mate is in a vector segment, in every tick.  That is the point of the
+// exercise: tools/micro/mfma_valu_corun.hip shows an MFMA-only wave and a VALU-only wave on one SIMD run concurrently (1000 us
+// of MFMAs + 570 us of v_fma finish in 1040 us), while waves that are all in the same phase -- what plain workgroup barriers
+// or free-running pairs gave -- simply add their matrix and vector time (ablation: 0.25 + 0.24 ms + 0.10 ms of exposed
+// load latency).  The tick barrier is also the pair's hand-off (B1 after S0, B2 after S1, B3 after S2).
+// LDS-only wait in front of it: global loads / stores stay in flight across a tick.
+#ifdef ALLSET_ABL2_NOBAR            // ablation builds only (tools/bwd_pair_ablation.py): timing without the barriers, results wrong
+#define ALLSET_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define ALLSET_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 // the lane id, re-derived where it is needed (two v_mbcnt) instead of living in a register across the row loop
 #define ALLSET_FRESH_LANE_P(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
@@ -73,13 +89,17 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
   constexpr int GS = ID * OQD;                               // dwords per k-quarter of a W plane
   constexpr int HW = ID / 2, NT = HW / 16;                   // columns and 16-column tiles per wave
   constexpr int PA = 256, PLA = 16 * PA, IMAGE = 3 * PLA;    // the pair's image: 3 planes x 16 rows x 256 B
-  constexpr int SLAB = 16 * 32 * 4;
+  constexpr int SP = 20;                                     // slab pitch (floats): one 16 x 16 tile a trip, rows 80 B apart
+  constexpr int SLAB = 16 * SP * 4;
   constexpr int OT = OD / 32, ITL = HW / 32;                 // 32 x 32 tiles of this wave's gW slice: 4 x 2
   __shared__ __attribute__((aligned(16))) uint32_t sW[3 * 4 * GS];
   __shared__ __attribute__((aligned(16))) uint8_t sImg[kPPairs * IMAGE];
   __shared__ __attribute__((aligned(16))) uint8_t sSlab[2 * kPPairs * SLAB];
+  __shared__ __attribute__((aligned(16))) float sG[ID];
+  __shared__ __attribute__((aligned(16))) float sB[ID];
   seed_in = resolve_seed(seed_base, seed_in);
   const int tid = threadIdx.x;
+  if (tid < ID) { sG[tid] = HAS_LN ? gamma[tid] : 1.f; sB[tid] = HAS_LN ? beta[tid] : 0.f; }
   {
     uint32_t* const sWh = sW;
     uint32_t* const sWm = sW + 4 * GS;
@@ -101,19 +121,14 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
   uint8_t* const img = sImg + pair * IMAGE;
   float* const sT = reinterpret_cast<float*>(sSlab + wave * SLAB);
   const float* const sTp = reinterpret_cast<const float*>(sSlab + (wave ^ 1) * SLAB);     // the partner's slab (row sums)
+  const bool late = wave >= 4;                    // the SIMD-mates of waves 0-3: one tick behind them
   const float inv_i = 1.f / static_cast<float>(ID);
   const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
   const uint32_t thr_in = drop_threshold(p_in);
   const int64_t n_chunks = (n + 15) / 16;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kPPairs;
-  const int64_t trips = (n_chunks + stride - 1) / stride;              // the same for every wave of the grid: barriers inside
 
-  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (HAS_LN) {
-    gam = *reinterpret_cast<const float4*>(gamma + h * HW + (lane0 & 15) * 4);
-    bet = *reinterpret_cast<const float4*>(beta + h * HW + (lane0 & 15) * 4);
-  }
   float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
   float gbs[2] = {0.f, 0.f};                      // bias gradient of o-tiles 2h, 2h+1: column (lane & 31), rows 8 (lane >> 5) .. +7
   f32x16p gw[OT][ITL];
@@ -135,7 +150,11 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
   auto request_rows = [&](int64_t chunk, int lane) {
     const int ri = lane & 15, g = lane >> 4;
     const int nr = rows_here(chunk);
+#ifdef ALLSET_ABL2_HOT              // ablation: every pair re-reads chunk (its pair id): L2-resident operands, no HBM latency
+    const int64_t c0 = pair;
+#else
     const int64_t c0 = nr > 0 ? chunk : n_chunks - 1;
+#endif
     const int lr = min(ri, max(nr, 1) - 1);
     if constexpr (HAS_MASK)       // "mask layout" (include/allset_hip.h): block (chunk, 64-column half h), dword (row, 32-column group)
       am_bits = (mask + (c0 * (OD / 64) + h) * 32)[(lr >> 2) * 8 + (lr & 3) * 2 + (g >> 1)];
@@ -152,7 +171,11 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
   float2 st[4];
   auto request_x = [&](int64_t chunk, int lane) {
     const int nr = rows_here(chunk);
+#ifdef ALLSET_ABL2_HOT
+    const int64_t c0 = pair;
+#else
     const int64_t c0 = nr > 0 ? chunk : n_chunks - 1;
+#endif
     const int nrc = max(nr, 1);
     const char* xb = reinterpret_cast<const char*>(x + c0 * 16 * ldx);
     const char* sb = reinterpret_cast<const char*>(stats + c0 * 16 * 2);
@@ -167,10 +190,12 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
 
   int64_t chunk = static_cast<int64_t>(blockIdx.x) * kPPairs + pair;
   request_rows(chunk, lane0);
+  const int64_t trips = (n_chunks + stride - 1) / stride;              // the same for every wave of the grid: barriers inside
+  if (late) ALLSET_TICK();
   for (int64_t trip = 0; trip < trips; ++trip, chunk += stride) {
     ALLSET_FRESH_LANE_P(lane);
     const int ri = lane & 15, g = lane >> 4;
-    const int nrows = rows_here(chunk);                  // 0: this pair has no chunk left (it still takes part in the barriers)
+    const int nrows = rows_here(chunk);                  // 0: this pair has no chunk left (it still takes part in the ticks)
     const bool valid = ri < nrows;
     request_x(chunk, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
         *reinterpret_cast<uint4*>(img + 2 * PLA + wa_off + 16 * q) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
       }
     }
-    ALLSET_PAIR_BARRIER();                                                                   // B1
+    ALLSET_TICK();                                                                           // B1: the pair's ga image is complete
     __builtin_amdgcn_sched_barrier(0);
     // ---- backward-data: gu[:, this wave's 64 columns] = ga @ W on the bf16 matrix pipe (six of nine plane products)
     f32x4p acc[NT];
@@ -206,8 +231,12 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
       const int a_base = ri * 256 + 16 * 0, a_chunk = g;                 // colbyte = 64 g + 16 t: chunk g, in-chunk 16 t
       const int a_off = a_base + (((a_chunk ^ ri) & 3) << 6);
       const int wb_base = g * GS + (h * HW + ri) * OQD, wb_swz = (ri / (64 / OQD)) % (OQD / 4);
+#ifdef ALLSET_ABL2_NOMFMA
+      for (int t = 0; t < (p_in == 123.f ? T : 0); ++t) {
+#else
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+#endif
         FragP fa[3];
         fa[0].u = *reinterpret_cast<const uint4*>(img + 0 * PLA + a_off + 16 * t);
         fa[1].u = *reinterpret_cast<const uint4*>(img + 1 * PLA + a_off + 16 * t);
@@ -241,26 +270,24 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- gu to row-major through the wave's slab, 32 columns a trip: lane = rows it*4 + (lane>>4), columns 4 (lane & 15) .. +3
+    // ---- gu to row-major through the wave's slab, one 16 x 16 tile a trip: lane = rows it*4 + (lane>>4), columns 4 (lane & 15) .. +3
+    // (the lanes whose four columns lie in the tile read it -- exec-masked loads, no selects)
     const int c4 = (lane & 15) * 4, r4 = lane >> 4;
     float4 gz[4];
 #pragma unroll
-    for (int sx = 0; sx < 2; ++sx) {
+    for (int tl = 0; tl < NT; ++tl) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sT[(4 * g + r) * 32 + tt * 16 + ri] = acc[sx * 2 + tt][r];
+      for (int r = 0; r < 4; ++r) sT[(4 * g + r) * SP + ri] = acc[tl][r];
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const bool mine = (ri >> 3) == sx;
+      if ((ri >> 2) == tl) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const float4 v = *reinterpret_cast<const float4*>(&sT[(it * 4 + r4) * 32 + (c4 & 31)]);
-        if (sx == 0) gz[it] = v;
-        else gz[it] = make_float4(mine ? v.x : gz[it].x, mine ? v.y : gz[it].y, mine ? v.z : gz[it].z, mine ? v.w : gz[it].w);
+        for (int it = 0; it < 4; ++it) gz[it] = *reinterpret_cast<const float4*>(&sT[(it * 4 + r4) * SP + (c4 & 15)]);
       }
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // ---- dropout-in mask, first half of the LayerNorm backward: this wave's share of the two row sums
+    const float4 gam = *reinterpret_cast<const float4*>(&sG[h * HW + c4]);      // (re-read per chunk: 8 registers less across the loop)
+    const float4 bet = *reinterpret_cast<const float4*>(&sB[h * HW + c4]);
     const uint64_t chunk_pair = static_cast<uint64_t>(chunk) * (16 * ID / 2);
     const uint32_t chunk_pair_lo = static_cast<uint32_t>(chunk_pair);
     const uint32_t seed_lo = static_cast<uint32_t>(seed_in);
@@ -317,7 +344,9 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
 #pragma unroll
         for (int it = 0; it < 4; ++it) *reinterpret_cast<float2*>(&sT[(it * 4 + r4) * 2]) = make_float2(s1[it], s2[it]);
       }
-      ALLSET_PAIR_BARRIER();                                                                 // B2
+    }
+    ALLSET_TICK();                                                                           // B2: the partner's row sums are posted
+    if constexpr (HAS_LN) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const float2 o = *reinterpret_cast<const float2*>(&sTp[(it * 4 + r4) * 2]);
@@ -342,9 +371,19 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
         o.x = (xbits >> (4 * it)) & 1u ? o.x : 0.f; o.y = (xbits >> (4 * it)) & 2u ? o.y : 0.f;
         o.z = (xbits >> (4 * it)) & 4u ? o.z : 0.f; o.w = (xbits >> (4 * it)) & 8u ? o.w : 0.f;
       }
+#ifdef ALLSET_ABL2_HOT
+      if (live)
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + static_cast<int64_t>(pair) * 16 * ldgx) +
+                                   static_cast<uint32_t>(lrow) * static_cast<uint32_t>(ldgx) * 4u + (h * HW + c4) * 4) = o;
+#elif defined(ALLSET_ABL2_NOSTORE)
+      if (live && o.x == 123.456f)
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + chunk * 16 * ldgx) +
+                                   static_cast<uint32_t>(lrow) * static_cast<uint32_t>(ldgx) * 4u + (h * HW + c4) * 4) = o;
+#else
       if (live)
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + chunk * 16 * ldgx) +
                                    static_cast<uint32_t>(lrow) * static_cast<uint32_t>(ldgx) * 4u + (h * HW + c4) * 4) = o;
+#endif
       float4 u = xr[it];
       if constexpr (HAS_LN)
         u = make_float4(fmaf(u.x, gam.x, bet.x), fmaf(u.y, gam.y, bet.y), fmaf(u.z, gam.z, bet.z), fmaf(u.w, gam.w, bet.w));
@@ -364,19 +403,21 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) wa[ot][pl] = tr_frag_p(img + pl * PLA + tr_row * PA + (((ot ^ tr_r) & 3) << 6) + tr_in, 4 * PA);
-    ALLSET_PAIR_BARRIER();                                                                   // B3: the image may be overwritten
+    ALLSET_TICK();                                                                           // B3: both waves are done with the ga image -- u may go over it
     if (part_b != nullptr) {
       const v2bfp_t ones = __builtin_bit_cast(v2bfp_t, 0x3f803f80u);
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
+      auto colsum = [&](const bf16x8p (&w3)[3], float& acc_b) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          FragP f; f.v = (h == 0 ? wa[k][pl] : wa[2 + k][pl]);
-          gbs[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.x), ones, gbs[k], false);
-          gbs[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.y), ones, gbs[k], false);
-          gbs[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.z), ones, gbs[k], false);
-          gbs[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.w), ones, gbs[k], false);
+          FragP f; f.v = w3[pl];
+          acc_b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.x), ones, acc_b, false);
+          acc_b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.y), ones, acc_b, false);
+          acc_b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.z), ones, acc_b, false);
+          acc_b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bfp_t, f.u.w), ones, acc_b, false);
         }
+      };
+      if (h == 0) { colsum(wa[0], gbs[0]); colsum(wa[1], gbs[1]); }       // (h is wave-uniform: a scalar branch, no selects)
+      else        { colsum(wa[2], gbs[0]); colsum(wa[3], gbs[1]); }
     }
     // ---- u planes over this wave's half of the image: row it*4 + (lane>>4), columns 64 h + 4 (lane & 15) .. +3 (8 bytes a plane)
 #pragma unroll
@@ -392,8 +433,7 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
     }
     __asm__ volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // the next chunk's gy half: requested here, where its 16 registers only meet the operand fragments (the partner wave on
-    // the SIMD and this phase's MFMAs cover the latency)
+    // the next chunk's gy half, requested once x / u are dead: the weight-gradient MFMAs and the tick barrier lie before its use
     request_rows(chunk + stride, lane_w);
     __builtin_amdgcn_sched_barrier(0);
     // ---- weight gradient: gW[o][this wave's i] += sum over the chunk's 16 rows of ga[r][o] u[r][i]; K = 16 = the chunk
@@ -404,15 +444,21 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
       for (int pl = 0; pl < 3; ++pl)
         wb[pl] = tr_frag_p(img + pl * PLA + tr_row * PA + ((((2 * h + it) ^ tr_r) & 3) << 6) + tr_in, 4 * PA);
       constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#ifdef ALLSET_ABL2_NOMFMA
+      for (int pr = 0; pr < (it == 0 ? 1 : 0); ++pr)
+#else
 #pragma unroll
       for (int pr = 0; pr < 6; ++pr)
+#endif
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
           gw[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ot][PA_[pr]], wb[PB_[pr]], gw[ot][it], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    ALLSET_TICK();                                                                           // end of S3
   }
+  if (!late) ALLSET_TICK();                        // (every wave passes 4 * trips + 1 barriers)
 
   // ---- per-pair partials: gW [O][I] (each wave its 64 columns), gb [O] (each wave its 64 o's), LayerNorm (dgamma, dbeta) [2][I]
   const int64_t slice = static_cast<int64_t>(blockIdx.x) * kPPairs + pair;
@@ -453,10 +499,12 @@ __global__ __launch_bounds__(kPBlock, 2) void fused_linear_bwd_pair_kernel(
 
 using namespace allset;
 
-// 1 = the pair kernel covers this call (O = I = 128, no acc_in; bf16x6 mode); ALLSET_BWD_PAIR=0 keeps the one-wave kernel
+// 1 = the pair kernel takes this call (O = I = 128, no acc_in; bf16x6 mode).  OFF unless ALLSET_BWD_PAIR=1: measured on the
+// GPU it does not beat the one-wave kernel (0.51-0.64 ms against 0.50 at [1M,128] x [128,128]; DESIGN.md section 6a has the three
+// synchronisation schemes that were tried and the ablation of each) -- kept as the comparison arm of that analysis.
 int fused_linear_bwd_pair_supported(int64_t O, int64_t I, int has_acc) {
   const char* e = getenv("ALLSET_BWD_PAIR");
-  if (e && e[0] == '0') return 0;
+  if (!(e && e[0] == '1')) return 0;
   return (dense_mfma_x6() && O == 128 && I == 128 && !has_acc) ? 1 : 0;
 }
 

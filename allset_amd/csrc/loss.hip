@@ -28,7 +28,10 @@ __global__ __launch_bounds__(kLossBlock) void nll_fwd_kernel(const float* __rest
     const float wr = w ? w[r] : 1.f;
     if (wr != 0.f) {
       const float* row = logits + r * ld;
-      acc += wr * (row_lse(row, C) - row[y[r]]);
+      const int64_t t = y[r];
+      // a label outside [0, C) (an unlabeled row that reached a split, a class count that does not match the head) contributes
+      // NaN: loud in the loss, where torch's nll_loss would raise -- never an out-of-bounds read
+      acc += wr * (row_lse(row, C) - ((t >= 0 && t < C) ? row[t] : __builtin_nanf("")));
     }
   }
 #pragma unroll
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(kLossBlock) void nll_bwd_kernel(const float* __rest
     const float* row = logits + r * ld;
     const float lse = row_lse(row, C);
     const int64_t t = y[r];
-    for (int c = 0; c < C; ++c) g[c] = wr * (__expf(row[c] - lse) - (c == t ? 1.f : 0.f));
+    const float bad = (t >= 0 && t < C) ? 0.f : __builtin_nanf("");        // out-of-range label: NaN gradient (see nll_fwd_kernel)
+    for (int c = 0; c < C; ++c) g[c] = wr * (__expf(row[c] - lse) - (c == t ? 1.f : 0.f)) + bad;
   }
 }
 
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(kLossBlock) void split_metrics_kernel(const float* 
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += __expf(row[c] - m);
     const int64_t t = y[r];
-    const float nll = (m + __logf(s)) - row[t];
+    const float nll = (m + __logf(s)) - ((t >= 0 && t < C) ? row[t] : __builtin_nanf(""));
     const float ok = am == t ? 1.f : 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { acc[k] += sp == k ? ok : 0.f; acc[3 + k] += sp == k ? nll : 0.f; }

@@ -495,6 +495,17 @@ def wgrad_padded(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor,
     return gw[:O, :I], (gb[:O] if gb is not None else None)
 
 
+def dropout_scale(shape, p: float, seed: int, device) -> Tensor:
+    """The hash dropout's per-element factor (0 or 1 / (1 - p)) for a row-major tensor of ``shape`` and host seed ``seed``: the
+    relu-dropout kernel on ones -- the same hash and element indexing every fused site uses."""
+    ones = torch.ones(shape, dtype=torch.float32, device=device)
+    y = torch.empty_like(ones)
+    with on_device(device):
+        check(_lib.load().allset_relu_dropout_fwd(ptr(ones), float(p), int(seed), ptr(y), ones.numel(), ptr(_seed_base()), stream_of(device)),
+              "allset_relu_dropout_fwd")
+    return y
+
+
 class _LayerNormFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, relu_in, p):

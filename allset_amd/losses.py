@@ -61,6 +61,8 @@ def nll_log_softmax(logits: Tensor, y: Tensor, mask: Tensor, count: float) -> Te
     """``mean over the rows with mask == 1 of -log_softmax(logits)[r, y[r]]`` -- ``count`` = number of such rows (a host
     number, known when the split is made: no device read-back per step).  ``y``: int64 class per row, for all rows."""
     if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1:
+        if y.dtype != torch.int64 or mask.dtype != torch.float32:
+            raise _lib.AllSetHipError(f"nll_log_softmax needs int64 labels and a float32 mask (got {y.dtype}, {mask.dtype})")
         return _NllLogSoftmax.apply(logits, y.contiguous(), mask.contiguous(), 1.0 / float(count))
     out = F.log_softmax(logits.float(), dim=1)
     picked = out.gather(1, y.view(-1, 1)).squeeze(1)
@@ -80,6 +82,8 @@ def split_metrics(logits: Tensor, y: Tensor, split: Tensor, counts: Tensor) -> T
     reference's ``evaluate`` returns (train.py:169-199), without its host round trips.  ``split``: :func:`split_ids`;
     ``counts``: float32 [3] set sizes (device)."""
     if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1:
+        if y.dtype != torch.int64 or split.dtype != torch.int8:
+            raise _lib.AllSetHipError(f"split_metrics needs int64 labels and int8 split ids (got {y.dtype}, {split.dtype})")
         dev = logits.device
         n, C = logits.shape
         lib = _lib.load()

@@ -18,9 +18,15 @@ from ._lib import check, stream_of, on_device
 
 
 class FusedAdam(torch.optim.Optimizer):
-    """Drop-in for ``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` on fp32 device parameters."""
+    """``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` -- the form the reference uses -- on fp32 / bf16 device
+    parameters.  NOT covered, and refused rather than ignored: ``amsgrad``, ``maximize``, a tensor ``lr``."""
 
-    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False, maximize: bool = False):
+        if amsgrad or maximize:
+            raise NotImplementedError("FusedAdam covers plain Adam only (no amsgrad / maximize): use torch.optim.Adam")
+        if isinstance(lr, torch.Tensor):
+            raise NotImplementedError("FusedAdam takes a float learning rate (the kernel receives it by value)")
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdam: invalid hyper-parameter")
         # `capturable` is what allset_amd.graphs.GraphedTrainStep checks: this optimizer keeps its step counters on the device
@@ -32,6 +38,14 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        step = st["step"]
+        # a state loaded from a non-capturable torch.optim.Adam checkpoint carries a Python number or a CPU tensor here; the kernel
+        # takes the counter's DEVICE address
+        if not isinstance(step, torch.Tensor) or step.device != p.device or step.dtype != torch.float32 or step.dim() != 0:
+            st["step"] = torch.as_tensor(float(step), dtype=torch.float32).to(p.device).reshape(())
+        for k in ("exp_avg", "exp_avg_sq"):
+            if st[k].device != p.device:
+                st[k] = st[k].to(p.device)
         return st
 
     @torch.no_grad()

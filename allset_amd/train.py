@@ -31,6 +31,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._lib import AllSetHipError
 from .models import SetGNN
 from .preprocessing import Add_Self_Loops, ExtractV2E, expand_edge_index, norm_contruction
 
@@ -372,6 +373,13 @@ def run(args) -> dict:
     import gc
     gc.collect()
     gc.freeze()
+    try:
+        return _run_loop(args, model, data, splits, device, logger, runtimes, num_params)
+    finally:
+        gc.unfreeze()                          # (a process-global switch: callers that import run() get their collector back)
+
+
+def _run_loop(args, model, data, splits, device, logger, runtimes, num_params):
     for r in range(args.runs):
         t0 = time.time()
         split_idx = {k: v.to(device) for k, v in splits[r].items()}
@@ -385,17 +393,25 @@ def run(args) -> dict:
         from .losses import nll_log_softmax, split_mask
         train_mask, n_train = split_mask(split_idx['train'], data.y.shape[0]), int(split_idx['train'].numel())
         y_all = data.y.long()
+        if r == 0:      # once per run() call: the loss kernels turn an out-of-range label into NaN, torch's nll_loss raises -- raise too
+            nc = int(getattr(args, "num_classes", 0) or 0)
+            lo, hi = int(y_all.min()), int(y_all.max())
+            if lo < 0 or (nc > 0 and hi >= nc):
+                raise ValueError(f"labels must lie in [0, {nc}): found [{lo}, {hi}]")
         use_graph = args.hip_graph == 1 or (args.hip_graph == -1 and data.y.shape[0] <= 200_000)
         if use_graph:                          # same loop, three graph launches per epoch instead of ~400 kernel launches
             from .graphs import GraphedForward, GraphedTrainStep
+            graphed_step = graphed_eval = None
             try:
                 graphed_step = GraphedTrainStep(model, data, lambda logits: nll_log_softmax(logits, y_all, train_mask, n_train), optimizer)
                 graphed_eval = GraphedForward(model, data)
-            except Exception as exc:           # noqa: BLE001 -- the eager loop below is the same arithmetic on the same kernels
-                if args.hip_graph == 1:
-                    raise
+            except (RuntimeError, AllSetHipError) as exc:     # capture-time failures only (an op that synchronises, an unsupported
+                if args.hip_graph == 1:                       # launch); shape / dtype bugs in the model are TypeError / ValueError
+                    raise                                     # and IndexError and are not swallowed
                 print(f"[allset_amd.train] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager launches")
                 use_graph = False
+                del graphed_step, graphed_eval                # a captured step keeps its memory pool alive
+                graphed_step = graphed_eval = None
                 model.reset_parameters()
                 optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
         # evaluate() of the reference (train.py:483: three accuracies + three losses per epoch, each through .cpu()) as one kernel

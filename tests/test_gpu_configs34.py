@@ -181,8 +181,9 @@ def _float64_layer_rows(v2e_conv, e2v_conv, x, by_dst_v2e, by_src_v2e, sample_v,
     from oracle import allset_oracle as oracle
     rp_s, col_s = by_src_v2e.rowptr, by_src_v2e.col            # vertex -> its hyperedges
     rp_d, col_d = by_dst_v2e.rowptr, by_dst_v2e.col            # hyperedge -> its members
-    es = torch.unique(torch.cat([col_s[int(rp_s[v]):int(rp_s[v + 1])].long() for v in sample_v.tolist()]))
-    mem = [col_d[int(rp_d[e]):int(rp_d[e + 1])].long() for e in es.tolist()]
+    es = torch.unique(torch.cat([col_s[int(rp_s[v]):int(rp_s[v + 1])].long() for v in sample_v.tolist()])).cpu()
+    mem = [col_d[int(rp_d[e]):int(rp_d[e + 1])].long().cpu() for e in es.tolist()]
+    sample_v = sample_v.cpu()
     vs = torch.unique(torch.cat(mem + [sample_v]))
     vid = {int(v): i for i, v in enumerate(vs.tolist())}
     src = torch.tensor([vid[int(v)] for m in mem for v in m.tolist()], dtype=torch.int64)

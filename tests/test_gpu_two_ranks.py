@@ -224,22 +224,25 @@ def test_two_rank_sharded_setgnn_equals_oracle(cfg, two_ranks):
     d = 64
     ei, norm, x, G = _problem(d, seed=7)
     args = cases.make_args(mode, d, 64, 5, All_num_layers=2, **kw)
-    sd = {k: torch.from_numpy(v).clone() for k, v in two_ranks[0][key][2].items()}
+    # the yardstick is the oracle in float64: two layers of stacked LayerNorms put the fp32 oracle itself ~1e-3 of the gradient
+    # scale away from it, which is no statement about the sharding
+    sd = {k: (torch.from_numpy(v).double() if torch.from_numpy(v).is_floating_point() else torch.from_numpy(v).clone())
+          for k, v in two_ranks[0][key][2].items()}
     for t in sd.values():
         if t.is_floating_point():
             t.requires_grad_(True)
-    nrm = norm if kw.get("LearnMask") else torch.ones(ei.shape[1], dtype=torch.int64)
-    ref = oracle.setgnn_forward(sd, args, x, ei, nrm)
+    nrm = norm.double() if kw.get("LearnMask") else torch.ones(ei.shape[1], dtype=torch.int64)
+    ref = oracle.setgnn_forward(sd, args, x.double(), ei, nrm)
     cot = torch.linspace(-1.0, 1.0, N_V * ref.shape[1]).view(N_V, -1)
-    (ref * cot).sum().backward()
+    (ref * cot.double()).sum().backward()
     got = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(2)])[:N_V]
-    torch.testing.assert_close(got, ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got.double(), ref.detach(), rtol=1e-4, atol=1e-4)
     scale = max(float(t.grad.abs().max()) for t in sd.values() if t.requires_grad and t.grad is not None)
     for r in range(2):
         grads = two_ranks[r][key][1]
         for k, t in sd.items():
             if t.requires_grad and t.grad is not None and k in grads:
-                torch.testing.assert_close(torch.from_numpy(grads[k]), t.grad, rtol=1e-3, atol=1e-4 * max(scale, 1.0),
+                torch.testing.assert_close(torch.from_numpy(grads[k]).double(), t.grad, rtol=1e-3, atol=1e-4 * max(scale, 1.0),
                                            msg=lambda m, k=k: f"{k} (rank {r}): {m}")
 
 
