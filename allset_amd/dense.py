@@ -440,7 +440,7 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
     I = x.shape[1]
     lib = _lib.load()
     ns = c_int64(0)
-    check(lib.allset_fused_linear_bwd_all_slices(n, byref(ns)), "allset_fused_linear_bwd_all_slices")
+    check(lib.allset_fused_linear_bwd_all_slices_for(n, O, I, int(acc_in is not None), byref(ns)), "allset_fused_linear_bwd_all_slices_for")
     P = ns.value
     if acc_in is not None:
         acc_in = _rowmajor(acc_in)

@@ -96,6 +96,28 @@ def _skip_collective(group=None) -> bool:
     return dist.get_world_size(group) == 1 and os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") != "1"
 
 
+# ---- opt-in reduced-precision WIRE format (SURVEY section 7 mitigation (b)) -----------------------------------------------
+# fp32 activations are rounded to this dtype for the exchange only and widened again on arrival; every sum -- including the
+# cross-rank sum of the row scheme's reduce-scatter, which becomes an all-to-all of pieces + a local fp32 sum -- stays fp32.
+# Halves the bytes per link.  NOT the default and never the headline: it changes results (one bf16 rounding, 2^-9 relative, per
+# exchanged activation; tests/test_dist_cpu.py states the tolerance) -- bench.py reports it as its own `partitions` entry.
+# Covers the blocking exchanges; the chunked asynchronous exchange keeps fp32.
+_WIRE_DTYPE: Optional[torch.dtype] = torch.bfloat16 if os.environ.get("ALLSET_WIRE_DTYPE", "") == "bf16" else None
+
+
+def set_wire_dtype(dtype: Optional[torch.dtype]) -> Optional[torch.dtype]:
+    """``torch.bfloat16`` (or ``None`` = exact fp32 wire, the default).  Returns the previous setting."""
+    global _WIRE_DTYPE
+    if dtype not in (None, torch.bfloat16, torch.float16):
+        raise ValueError(f"wire dtype {dtype}")
+    prev, _WIRE_DTYPE = _WIRE_DTYPE, dtype
+    return prev
+
+
+def _narrow(t: Tensor) -> Tensor:
+    return t.to(_WIRE_DTYPE) if (_WIRE_DTYPE is not None and t.dtype == torch.float32) else t
+
+
 def _host_staged(group, *tensors) -> bool:
     """gloo moves host memory only: device tensors are staged through the host around the call.  That is how two real
     ranks run the HIP path on ONE GPU (tests/test_gpu_two_ranks.py: RCCL refuses two ranks on the same device) -- the
@@ -130,6 +152,16 @@ def _all_gather_rows(x: Tensor, group=None) -> Tensor:
         return x
     w = _world(group)
     x = x.contiguous()
+    if _narrow(x) is not x:                       # reduced-precision wire: gather the narrow rows, widen on arrival
+        xn = _narrow(x)
+        outn = xn.new_empty((w * x.shape[0],) + tuple(x.shape[1:]))
+        if _host_staged(group, xn):
+            ho = torch.empty(outn.shape, dtype=outn.dtype)
+            dist.all_gather_into_tensor(ho, xn.cpu(), group=group)
+            outn.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(outn, xn, group=group)
+        return outn.to(x.dtype)
     out = x.new_empty((w * x.shape[0],) + tuple(x.shape[1:]))
     if _host_staged(group, x):
         ho = torch.empty(out.shape, dtype=out.dtype)
@@ -146,6 +178,11 @@ def _reduce_scatter_rows(x: Tensor, group=None) -> Tensor:
     w = _world(group)
     x = x.contiguous()
     per = x.shape[0] // w
+    if _narrow(x) is not x:                       # reduced-precision wire: the P pieces travel narrow, the sum over ranks is fp32 here
+        send = _narrow(x).view((w, per) + tuple(x.shape[1:]))
+        recv = torch.empty_like(send)
+        _all_to_all_single(recv, send, group)
+        return recv.to(x.dtype).sum(dim=0)
     if dist.get_backend(group) == "gloo":            # gloo has no reduce_scatter: all-reduce + slice (tests only)
         buf = _all_reduce_(x.clone(), group=group)
         r = dist.get_rank(group)
@@ -510,10 +547,10 @@ def _rows_to_cols(x: Tensor, group=None) -> Tensor:
     r, d = x.shape
     if d % w:
         raise ValueError(f"column sharding needs the width ({d}) to be a multiple of the world size ({w})")
-    send = _pack(x, w)                                                     # [P, n/P, d/P]: chunk j goes to rank j
+    send = _narrow(_pack(x, w))                                            # [P, n/P, d/P]: chunk j goes to rank j
     recv = torch.empty_like(send)
     _all_to_all_single(recv, send, group)
-    return recv.view(w * r, d // w)                                        # chunk i = rank i's rows: already row-major
+    return recv.view(w * r, d // w).to(x.dtype)                            # chunk i = rank i's rows: already row-major
 
 
 def _cols_to_rows(x: Tensor, group=None) -> Tensor:
@@ -524,10 +561,10 @@ def _cols_to_rows(x: Tensor, group=None) -> Tensor:
     n, dc = x.shape
     if n % w:
         raise ValueError(f"column sharding needs the (padded) row count ({n}) to be a multiple of the world size ({w})")
-    send = x.contiguous()                                                  # rows of block j (my columns) go to rank j
+    send = _narrow(x.contiguous())                                         # rows of block j (my columns) go to rank j
     recv = torch.empty_like(send)
     _all_to_all_single(recv, send, group)
-    return _unpack(recv.view(w, n // w, dc))
+    return _unpack(recv.view(w, n // w, dc).to(x.dtype))
 
 
 class _RowsToCols(torch.autograd.Function):

@@ -83,6 +83,8 @@ def parse_args(argv=None):
                          "1 below 500k).  Off by default since round 2: on one GPU the 4-chunk machinery costs +4.8 ms per step "
                          "(AllDeepSets) and turns the AllSetTransformer step host-bound (profiles/r02_colshard_chunks.txt) against "
                          "<= 6 ms of exchange it can hide at N = 8, and it has never run on more than one rank")
+    ap.add_argument("--no-wire-entry", dest="wire_entry", action="store_false",
+                    help="N > 1: skip the extra timed region of the primary partition with the opt-in bf16 wire format")
     ap.add_argument("--self-loops", action="store_true",
                     help="variant (SURVEY 8(d1)): add one singleton hyperedge per vertex as Add_Self_Loops does (single GPU only)")
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
@@ -346,6 +348,14 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
     return res
 
 
+def cfg_index(args) -> int:
+    """Which BASELINE.json configuration the flags describe: [2] AllDeepSets d = 128 fp32 (the headline), [3] AllSetTransformer
+    d = 128 fp32, [4] the PMA path on power-law sizes at d = 256 in bf16."""
+    if args.model != "pma":
+        return 2
+    return 4 if (args.dtype == "bf16" and args.degree_dist == "zipf") else 3
+
+
 def parallelism_label(args, mode, world):
     if world == 1:
         return "single GPU"
@@ -417,6 +427,21 @@ def main(argv=None, hooks=None):
             res2_error = f"{type(exc).__name__}: {exc}"
             print(f"[bench] partition {other!r} failed on rank {rank}: {res2_error}", file=sys.stderr, flush=True)
 
+    # N > 1: the primary partition once more with the opt-in bf16 WIRE format (allset_amd.dist.set_wire_dtype: fp32 tensors and
+    # fp32 sums, every exchanged activation rounded once to bf16 -- half the bytes per link, results changed within the tolerance
+    # tests/test_dist_cpu.py restates).  Its own `partitions` entry, never `value`.
+    res_wire, res_wire_error = None, None
+    if world > 1 and args.dtype == "f32" and args.wire_entry and args.pipeline_chunks <= 1:
+        prev = adist.set_wire_dtype(torch.bfloat16)
+        try:
+            if not cpu_mode:
+                torch.cuda.empty_cache()
+            res_wire = run_partition(args, primary, world, rank, dev, hooks)
+        except Exception as exc:                # noqa: BLE001
+            res_wire_error = f"{type(exc).__name__}: {exc}"
+        finally:
+            adist.set_wire_dtype(prev)
+
     line = None
     if rank == 0:
         d, attn = args.d, args.model == "pma"
@@ -458,7 +483,7 @@ def main(argv=None, hooks=None):
              "accumulation and fp32 softmax statistics; dense tail: this library's bf16 kernels (fp32 arithmetic and "
              "accumulation, bf16 in / out)"),
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{3 if attn else 2}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph "
+            "config": {"workload": f"BASELINE configs[{cfg_index(args)}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph "
                                    f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}), "
                                    f"nnz={int(nnz_total)}, d={d}, " +
                                    (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
@@ -495,6 +520,12 @@ def main(argv=None, hooks=None):
                                 "parallelism": parallelism_label(args, other, world), "is_value": False}
             elif res2_error is not None:
                 parts[other] = {"error": res2_error, "parallelism": parallelism_label(args, other, world), "is_value": False}
+            if res_wire is not None:
+                parts[primary + "+bf16wire"] = {"ms_per_step": res_wire["ms_per_step"], "value": res_wire["value"], "is_value": False,
+                                                "parallelism": parallelism_label(args, primary, world) + "; bf16 wire format (opt-in, "
+                                                "results within the restated tolerance of tests/test_dist_cpu.py, not bit-comparable)"}
+            elif res_wire_error is not None:
+                parts[primary + "+bf16wire"] = {"error": res_wire_error, "is_value": False}
             parts["note"] = ("`rows` = hyperedge shards, the partition BASELINE.json's north star names; `columns` = column-sharded "
                              "aggregation (DESIGN.md section 7.2). Same global hypergraph, same K steps, separate timed regions; "
                              "`value` / `ms_per_step` of the line are those of the entry with is_value = true")

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 5   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex) */
+#define ALLSET_ABI_VERSION 6   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -487,7 +487,7 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  *   x        always required (the weight gradient recomputes the Linear's input from it); stats/gamma/beta come together or NULL
  *   gx       required (a Linear whose input needs no gradient keeps the two-kernel pair); acc_in as in allset_fused_linear_bwd
  *   part_w   f32[n_slices*O*I], part_b f32[n_slices*O] or NULL, part_ln f32[n_slices*2*I] (stats != NULL): one partial per
- *            wave, n_slices from allset_fused_linear_bwd_all_slices(n); the caller sums over slices (allset_reduce_partials).
+ *            wave or workgroup, n_slices from allset_fused_linear_bwd_all_slices_for(n, O, I, acc_in != NULL); the caller sums over slices (allset_reduce_partials).
  *   part_stride  0: part_w / part_b / part_ln are three dense arrays as sized above; > 0 (>= O*I + O + 2*I in practice): they
  *            point into ONE f32[n_slices*part_stride] buffer, slice k's sections at k*part_stride from each pointer -- one
  *            allset_reduce_partials launch then sums all of a Linear's parameter gradients.
@@ -495,7 +495,10 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  * {64,128} and the prologue / epilogue combinations the module surface produces (dropout_in only behind relu_in, acc_in only
  * on the plain Linear); 0 under ALLSET_DENSE_MFMA=f32.  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
 int allset_fused_linear_bwd_all_supported(int64_t O, int64_t I, int has_ln, int drop_in, int relu_in, int has_mask, int has_acc);
-int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices);
+int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices);      /* the one-wave-per-SIMD kernel's count (ABI 4-5 callers) */
+/* The slice count allset_fused_linear_bwd_all expects for these widths (ABI 6): the O = I = 128 kernel keeps ONE weight-gradient
+ * accumulator per workgroup (n_slices = number of workgroups), the other widths one per wave. */
+int allset_fused_linear_bwd_all_slices_for(int64_t n, int64_t O, int64_t I, int has_acc, int64_t* n_slices);
 int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x,
                                 int64_t ldx, const float* stats, const float* gamma, const float* beta, int relu_in, float p_in,
                                 uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b,

@@ -738,7 +738,10 @@ def test_one_pass_backward_equals_the_two_kernel_pair(O, I, has_ln, relu_in, p_i
         gx2, _, _, gw2, _ = dense.fused_linear_bwd_all(G, None, 0.0, W, x, None, None, None, False, 0.0, 0, acc_in=acc)
         assert gx2.data_ptr() == acc.data_ptr()
         torch.testing.assert_close(gx2, want, rtol=0, atol=0)
-        torch.testing.assert_close(gw2, gw, rtol=0, atol=0)                  # run-to-run bitwise stable
+        # (acc_in keeps the one-wave kernel, the plain call may take another kernel at 128 x 128: another summation order)
+        torch.testing.assert_close(gw2, gw, rtol=1e-5, atol=2e-6 * max(scale_w, 1.0))
+        gx3, _, _, gw3, _ = dense.fused_linear_bwd_all(G, None, 0.0, W, x, None, None, None, False, 0.0, 0)
+        assert torch.equal(gw3, gw) and torch.equal(gx3, gx)               # run-to-run bitwise stable
 
 
 def test_one_pass_backward_is_deterministic_and_used_by_the_mlp(device, monkeypatch):
