@@ -552,7 +552,8 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
-                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl);
+                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
+                                  int64_t ldacc);
 
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
@@ -673,7 +674,7 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
-                                  seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl);
+                                  seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }

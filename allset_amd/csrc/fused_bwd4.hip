@@ -67,13 +67,14 @@ __device__ __forceinline__ uint32_t hash_mix_r(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_R(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK>
+template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC>
 __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     const float* __restrict__ gy, int64_t ldg, const uint32_t* __restrict__ mask, float p_out, const float* __restrict__ W,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
-    const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln) {
+    const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, const float* acc_in,
+    int64_t ldacc) {
   constexpr int OD = 128, ID = 128;
   constexpr int R = kRRows;
   constexpr int PLANE = R * 256;                 // bytes per bf16 plane of an image
@@ -272,6 +273,20 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
       float4 gam[2];
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
+      // gx = acc_in + ...: a second gradient branch of the same tensor, summed here (may alias gx: each element is read and
+      // written by the same lane).  Requested first, consumed last.
+      float4 acc[2][2];
+      if constexpr (HAS_ACC) {
+        const int nrc = max(nrows, 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int lrc = min(8 * wave + rg + 4 * j, nrc - 1);
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb)
+            acc[j][hb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(acc_in + stage * R * ldacc) +
+                                                          static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldacc) * 4u + 256 * hb + 16 * c);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {            // (the two rows are independent chains: left to the scheduler to interleave)
         const int lr = 8 * wave + rg + 4 * j;
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
             const uint32_t xb = xbK >> (8 * j + 4 * hb);
             o.x = (xb & 1u) ? o.x : 0.f; o.y = (xb & 2u) ? o.y : 0.f; o.z = (xb & 4u) ? o.z : 0.f; o.w = (xb & 8u) ? o.w : 0.f;
           }
+          if constexpr (HAS_ACC) { o.x += acc[j][hb].x; o.y += acc[j][hb].y; o.z += acc[j][hb].z; o.w += acc[j][hb].w; }
 #ifdef ALLSET_ABL4_NOSTORE
           if (live && o.x == 123.456f)
 #else
@@ -565,9 +581,10 @@ using namespace allset;
 
 // 1 = the split-role kernel takes this call (O = I = 128, no acc_in; bf16x6 mode); ALLSET_BWD_ROLES=0 falls through to the next one
 int fused_linear_bwd_roles_supported(int64_t O, int64_t I, int has_acc) {
+  (void)has_acc;                         // (acc_in is built for the plain Linear, the one combination the one-wave kernel has it for too)
   const char* e = getenv("ALLSET_BWD_ROLES");
   if (e && e[0] == '0') return 0;
-  return (dense_mfma_x6() && O == 128 && I == 128 && !has_acc) ? 1 : 0;
+  return (dense_mfma_x6() && O == 128 && I == 128) ? 1 : 0;
 }
 
 unsigned fused_linear_bwd_roles_grid(int64_t n) {
@@ -580,12 +597,14 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
-                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl) {
-#define ALLSET_ROLES_K(LN, DI, RI, HM)                                                                                         \
-  fused_linear_bwd_roles_kernel<LN, DI, RI, HM><<<grid, kRBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta,   \
-                                                                         p_in, seed_in, gx, ldgx, part_ln, part_w, part_b, n,   \
-                                                                         seed_base, psw, psb, psl)
-#define ALLSET_ROLES_M(LN, DI, RI) do { if (hm) ALLSET_ROLES_K(LN, DI, RI, true); else ALLSET_ROLES_K(LN, DI, RI, false); } while (0)
+                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
+                                  int64_t ldacc) {
+#define ALLSET_ROLES_K(LN, DI, RI, HM, HA)                                                                                     \
+  fused_linear_bwd_roles_kernel<LN, DI, RI, HM, HA><<<grid, kRBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma,     \
+                                                                             beta, p_in, seed_in, gx, ldgx, part_ln, part_w,    \
+                                                                             part_b, n, seed_base, psw, psb, psl, acc_in, ldacc)
+  if (acc_in != nullptr) { ALLSET_ROLES_K(false, false, false, false, true); return 0; }     // (bwd_all_combo: plain Linear only)
+#define ALLSET_ROLES_M(LN, DI, RI) do { if (hm) ALLSET_ROLES_K(LN, DI, RI, true, false); else ALLSET_ROLES_K(LN, DI, RI, false, false); } while (0)
   if (!relu) { if (ln) ALLSET_ROLES_M(true, false, false); else ALLSET_ROLES_M(false, false, false); }
   else if (ln) { if (drop) ALLSET_ROLES_M(true, true, true); else ALLSET_ROLES_M(true, false, true); }
   else { if (drop) ALLSET_ROLES_M(false, true, true); else ALLSET_ROLES_M(false, false, true); }

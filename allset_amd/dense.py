@@ -426,6 +426,24 @@ def fused_linear_bwd_all_supported(O: int, I: int, has_ln: bool, drop_in: bool, 
                                                                   int(has_acc)))
 
 
+_ONE_PASS_PREFERRED = {}
+
+
+def one_pass_preferred(O: int, I: int) -> bool:
+    """True when ``allset_fused_linear_bwd_all`` launches one of the two-waves-per-SIMD kernels for these widths (round 3:
+    O = I = 128; one partial slice per workgroup instead of one per wave).  Those beat the backward-data + weight-gradient pair
+    also for a Linear WITHOUT a LayerNorm prologue (0.35-0.4 ms against 0.21 + 0.32); the one-wave kernel did not."""
+    key = (int(O), int(I), os.environ.get("ALLSET_BWD_ROLES", ""), os.environ.get("ALLSET_BWD_STAGE", ""), os.environ.get("ALLSET_DENSE_MFMA", ""))
+    hit = _ONE_PASS_PREFERRED.get(key)
+    if hit is None:
+        lib = _lib.load()
+        a, b = c_int64(0), c_int64(0)
+        check(lib.allset_fused_linear_bwd_all_slices_for(1 << 20, int(O), int(I), 0, byref(a)), "allset_fused_linear_bwd_all_slices_for")
+        check(lib.allset_fused_linear_bwd_all_slices(1 << 20, byref(b)), "allset_fused_linear_bwd_all_slices")
+        hit = _ONE_PASS_PREFERRED[key] = bool(lib.allset_fused_linear_bwd_all_supported(int(O), int(I), 0, 0, 0, 0, 0)) and a.value < b.value
+    return hit
+
+
 def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                          gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
                          seed_base: Optional[Tensor] = None, acc_in: Optional[Tensor] = None, want_bias: bool = True
@@ -619,7 +637,8 @@ class _FusedNormLinear(torch.autograd.Function):
         need_b = has_bias and ctx.needs_input_grad[4]
         # one-pass kernel where a LayerNorm prologue makes both halves of the pair recompute the same operand (0.49-0.55 ms
         # against 0.62-0.63); without one the plain weight-gradient kernel is cheap and the pair wins (0.48 vs 0.58 ms)
-        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and y is None and x.shape[0] > 0 and gamma is not None and
+        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and y is None and x.shape[0] > 0 and
+                (gamma is not None or one_pass_preferred(weight.shape[0], weight.shape[1])) and
                 fused_linear_bwd_all_supported(weight.shape[0], weight.shape[1], gamma is not None, p_in > 0.0, relu_in,
                                                mask is not None)):
             # everything from one read of gy and x
@@ -929,8 +948,14 @@ class _PmaResidualFF(torch.autograd.Function):
         relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
         gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
         zy = None if mask is not None else z
-        # (the one-pass backward kernel is not used here: without a LayerNorm to recompute, the plain weight-gradient kernel
-        # costs 0.19 ms and the pair 0.48-0.59 ms per Linear against 0.58 ms for the one-pass kernel -- measured, round 2)
+        if mask is not None and gs.shape[0] > 0 and one_pass_preferred(w2.shape[0], w2.shape[1]) and one_pass_preferred(w1.shape[0], w1.shape[1]):
+            # round 3: the split-role one-pass kernel covers both Linears (relu prologue + mask; plain + acc_in): two launches
+            # instead of four, each reading its gradient and its input once
+            g1, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
+            gout, _, _, gw1, gb1 = fused_linear_bwd_all(g1, None, 0.0, w1, out, None, None, None, False, 0.0, 0, acc_in=gs, want_bias=has_b1)
+            return gout, gw1, gb1, gw2, gb2, dg, db, None, None, None
+        # (the one-wave one-pass kernel is not used here: without a LayerNorm to recompute, the plain weight-gradient kernel
+        # costs 0.19 ms and the pair 0.48-0.59 ms per Linear against 0.58 ms for that kernel -- measured, round 2)
         gw2, gb2 = wgrad_fused(gs, zy, 0.0, y1, None, None, None, True, 0.0, 0, want_bias=has_b2, mask=mask)
         g1, _, _ = fused_linear_bwd(gs, zy, 0.0, w2, y1, None, None, True, 0.0, 0, None, mask)
         gw1, gb1 = wgrad(g1, out, want_bias=has_b1)

@@ -122,6 +122,8 @@ def _host_staged(group, *tensors) -> bool:
     """gloo moves host memory only: device tensors are staged through the host around the call.  That is how two real
     ranks run the HIP path on ONE GPU (tests/test_gpu_two_ranks.py: RCCL refuses two ranks on the same device) -- the
     autograd Functions, the kernels and the exchange wiring are the product's, only the wire is the host's."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
     return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
 
 

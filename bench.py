@@ -83,6 +83,10 @@ def parse_args(argv=None):
                          "1 below 500k).  Off by default since round 2: on one GPU the 4-chunk machinery costs +4.8 ms per step "
                          "(AllDeepSets) and turns the AllSetTransformer step host-bound (profiles/r02_colshard_chunks.txt) against "
                          "<= 6 ms of exchange it can hide at N = 8, and it has never run on more than one rank")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="single GPU: capture the step (zero_grad + forward + backward + Adam, dropout seeds from a device counter) "
+                         "as one hipGraph and time K replays -- the same kernels on the same data, without the ~100 host launches "
+                         "per step that are ~10 %% of a step in the bf16 regime (configs[4] per-GPU shape)")
     ap.add_argument("--no-wire-entry", dest="wire_entry", action="store_false",
                     help="N > 1: skip the extra timed region of the primary partition with the opt-in bf16 wire format")
     ap.add_argument("--self-loops", action="store_true",
@@ -277,7 +281,9 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
     if tdt != torch.float32:
         v2e.to(tdt); e2v.to(tdt)
     params = list(v2e.parameters()) + list(e2v.parameters())
-    opt = torch.optim.Adam(params, lr=1e-3, fused=on_gpu)   # same Adam math, one multi-tensor kernel for the 24 small parameters
+    graph_mode = bool(getattr(args, "hip_graph", False)) and on_gpu and world == 1
+    # same Adam math, one multi-tensor kernel for the 24 small parameters (capturable: its step counters live on the device)
+    opt = torch.optim.Adam(params, lr=1e-3, fused=on_gpu, capturable=graph_mode)
 
     gen = torch.Generator(device=dev).manual_seed(args.seed + 100 + rank)
     rows = hg.v_hi - hg.v_lo
@@ -305,6 +311,22 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
         adist.allreduce_grads(params)
         opt.step()
 
+    if graph_mode:            # one hipGraph per step (allset_amd/graphs.py explains what makes the path capturable)
+        from allset_amd import dense as _dense
+        from allset_amd.graphs import _side_stream_warmup
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        eager_step = step
+
+        def counted_step():
+            counter.add_(1)                        # every replay draws fresh dropout masks: the kernels read the counter
+            eager_step()
+        with torch.cuda.device(dev), _dense.device_seed_counter(counter):
+            _side_stream_warmup(counted_step, 3)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                counted_step()
+        step = graph.replay
+
     def fence():
         if on_gpu:
             torch.cuda.synchronize(dev)
@@ -322,7 +344,7 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
     gc.freeze()
     for _ in range(args.warmup):
         step()
-    timer = ops.KernelTimer() if on_gpu else None
+    timer = ops.KernelTimer() if (on_gpu and not graph_mode) else None      # (HIP events per kernel are host calls: eager mode only)
     fence()
     ops.set_kernel_timer(timer)
     t0 = time.perf_counter()
@@ -491,7 +513,7 @@ def main(argv=None, hooks=None):
                                    "fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
                        "n_v": res["n_v"], "n_e": res["n_e"], "nnz": int(nnz_total), "d": d,
                        "parallelism": parallelism_label(args, primary, world), "partition": primary if world > 1 else None,
-                       "seed": args.seed},
+                       "seed": args.seed, "launch": "one hipGraph replay per step" if (args.hip_graph and world == 1) else "eager launches"},
             "roofline": roofline,
             "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if (world == 1 and agg_ms > 0) else None,
                             "unit": "edges*d/s", "note": "gather/segment-reduce kernel time per step (HIP events, rank 0): "
