@@ -266,10 +266,13 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
   request(a0, x, ldx, chunk);
   request(a1, x, ldx, chunk + stride);
   if constexpr (HAS_MASK) request(m0, ymask, ldm, chunk);
-  for (; chunk < n_chunks; chunk += 2 * stride) {
+  // (two chunks per trip, the odd last chunk peeled: a conditional second half makes the compiler wait vmcnt(0) at the loop
+  // header -- see fused_mlp.hip)
+  for (; chunk + stride < n_chunks; chunk += 2 * stride) {
     process(a0, m0, chunk);
-    if (chunk + stride < n_chunks) process(a1, m0, chunk + stride);
+    process(a1, m0, chunk + stride);
   }
+  if (chunk < n_chunks) process(a0, m0, chunk);
 }
 
 static inline bool bf16_width(int64_t w) { return w == 128 || w == 256; }

@@ -444,10 +444,15 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
   int64_t chunk = static_cast<int64_t>(blockIdx.x) * kX6Waves + wave;
   request_row(a0, chunk);
   request_row(a1, chunk + stride);
-  for (; chunk < n_chunks; chunk += 2 * stride) {
+  // Two chunks per trip, the odd last chunk PEELED: with "if (chunk + stride < n_chunks) process(a1, ...)" inside the loop the
+  // compiler's s_waitcnt insertion follows the path that skips the second half and puts s_waitcnt vmcnt(0) at the loop header --
+  // every trip then waited for the buffer it had just re-requested, i.e. the two-deep prefetch covered one chunk of latency
+  // instead of two (found in round 3 with the same construct in fused_bwd4.hip).
+  for (; chunk + stride < n_chunks; chunk += 2 * stride) {
     process(a0, chunk);
-    if (chunk + stride < n_chunks) process(a1, chunk + stride);
+    process(a1, chunk + stride);
   }
+  if (chunk < n_chunks) process(a0, chunk);
 }
 
 // ---- backward w.r.t. the input of the fused Linear --------------------------------------------------------------
