@@ -206,8 +206,21 @@ __device__ __forceinline__ int plane_off(int g, int j, int t) {
   return g * GS + j * KQD + 4 * (t ^ ((j / ROWS64) % PIECES));
 }
 
+// Waves per workgroup (round 3): 12 = three per SIMD for the variants with a LayerNorm prologue -- their vector work (statistics,
+// normalisation, dropout hash, three-plane split, epilogue) is 7x the matrix pipe's issue slots, and a third wave per SIMD fills
+// what two leave idle when both sit in the same kind of phase (same box: 0.251 -> 0.241 ms at [1M,128]); at 168 registers per
+// wave there is room for ONE chunk of prefetch, requested after the matrix phase.  The plain variants keep 8 waves and two
+// chunks in flight: with little vector work they are bound by bytes in flight (8 -> 12 waves measured 0.217 -> 0.228 there).
+template <bool HAS_LN>
+constexpr int fwd_x6_waves() {
+#ifdef ALLSET_FWD_WAVES
+  return ALLSET_FWD_WAVES;
+#else
+  return HAS_LN ? 12 : 8;
+#endif
+}
 template <int KD, int ND, bool HAS_LN, bool DROP_IN, bool DROP_OUT>
-__global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
+__global__ __launch_bounds__(fwd_x6_waves<HAS_LN>() * kWave) void fused_linear_fwd_x6_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W,
     const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
@@ -216,6 +229,9 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
     float* __restrict__ aux_out) {
   seed_in = resolve_seed(seed_base, seed_in);
   seed_out = resolve_seed(seed_base, seed_out);
+  constexpr int kF6Waves = fwd_x6_waves<HAS_LN>();
+  constexpr int kF6Block = kF6Waves * kWave;
+  constexpr int kF6Depth = kF6Waves > 8 ? 1 : 2;   // chunks in flight per wave
   constexpr int KQ = KD / 4;                       // columns per lane
   constexpr int KQD = KQ / 2;                      // dwords per (quarter, column) row of a plane
   constexpr int T = KQ / 8;                        // MFMA k-steps
@@ -227,14 +243,14 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
   __shared__ __attribute__((aligned(16))) float sG[KD];
   __shared__ __attribute__((aligned(16))) float sBeta[KD];
   __shared__ __attribute__((aligned(16))) float sBias[ND];
-  __shared__ __attribute__((aligned(16))) float sTrans[kX6Waves * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float sTrans[kF6Waves * 16 * 64];
   __shared__ __attribute__((aligned(16))) float sAux[4 * KD + 4];         // 4 auxiliary output columns: weights, bias
   const int tid = threadIdx.x;
   if (aux_out != nullptr) {
-    for (int idx = tid; idx < 4 * KD; idx += kX6Block) sAux[idx] = aux_w[idx];
+    for (int idx = tid; idx < 4 * KD; idx += kF6Block) sAux[idx] = aux_w[idx];
     if (tid < 4) sAux[4 * KD + tid] = aux_b ? aux_b[tid] : 0.f;
   }
-  for (int idx = tid; idx < ND * KD / 2; idx += kX6Block) {
+  for (int idx = tid; idx < ND * KD / 2; idx += kF6Block) {
     const int j = idx / (KD / 2), k = 2 * (idx % (KD / 2));
     const float2 w = *reinterpret_cast<const float2*>(W + j * KD + k);
     uint32_t ph, pm, pl;
@@ -243,11 +259,11 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
     const int off = plane_off<KQD, GS>(k / KQ, j, e / 8) + (e % 8) / 2;
     sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
   }
-  for (int idx = tid; idx < KD; idx += kX6Block) {
+  for (int idx = tid; idx < KD; idx += kF6Block) {
     sG[idx] = HAS_LN ? gamma[idx] : 1.f;
     sBeta[idx] = HAS_LN ? beta[idx] : 0.f;
   }
-  for (int idx = tid; idx < ND; idx += kX6Block) sBias[idx] = bias ? bias[idx] : 0.f;
+  for (int idx = tid; idx < ND; idx += kF6Block) sBias[idx] = bias ? bias[idx] : 0.f;
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6;
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
   const float keep_out = DROP_OUT ? 1.f / (1.f - p_out) : 1.f;
   const uint32_t thr_in = drop_threshold(p_in), thr_out = drop_threshold(p_out);
   const int64_t n_chunks = (n + 15) / 16;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kX6Waves;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kF6Waves;
   float* sT = sTrans + wave * (16 * 64);
 
   // Loads are unconditional on a clamped row (no exec-mask branches around memory instructions, whose joins cost
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
 #pragma unroll
     for (int j = 0; j < KQD; ++j) split3_bf16(a[2 * j], a[2 * j + 1], ah[j], am[j], al[j]);
     __builtin_amdgcn_sched_barrier(0);
-    request_row(a, chunk + 2 * stride);
+    if constexpr (kF6Depth == 2) request_row(a, chunk + 2 * stride);
     __builtin_amdgcn_sched_barrier(0);
 
     f32x4 acc[NTILE];
@@ -385,6 +401,8 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
         acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_h.v, b1h.v, acc[tl + 1], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kF6Depth == 1) request_row(a, chunk + stride);     // (no registers for it during the matrix phase at 168)
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue, 64 columns (4 tiles) per trip through the slab
     const int c4 = (lane & 15) * 4;
@@ -440,9 +458,14 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_fwd_x6_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  float a0[KQ], a1[KQ];
-  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kX6Waves + wave;
+  float a0[KQ];
+  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kF6Waves + wave;
   request_row(a0, chunk);
+  if constexpr (kF6Depth == 1) {              // three waves per SIMD: one chunk ahead (168 registers per wave)
+    for (; chunk < n_chunks; chunk += stride) process(a0, chunk);
+    return;
+  }
+  float a1[KQ];
   request_row(a1, chunk + stride);
   // Two chunks per trip, the odd last chunk PEELED: with "if (chunk + stride < n_chunks) process(a1, ...)" inside the loop the
   // compiler's s_waitcnt insertion follows the path that skips the second half and puts s_waitcnt vmcnt(0) at the loop header --
@@ -964,13 +987,14 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
   if (blocks > 512) blocks = 512;                         // persistent workgroups
   const unsigned grid = static_cast<unsigned>(blocks);
   const bool x6 = dense_mfma_x6();
-  int64_t blocks_x6 = ((n + 15) / 16 + kX6Waves - 1) / kX6Waves;
-  if (blocks_x6 > 256) blocks_x6 = 256;                   // one persistent 8-wave workgroup per CU
+  const int waves_x6 = has_ln ? fwd_x6_waves<true>() : fwd_x6_waves<false>();
+  int64_t blocks_x6 = ((n + 15) / 16 + waves_x6 - 1) / waves_x6;
+  if (blocks_x6 > 256) blocks_x6 = 256;                   // one persistent workgroup per CU
   const unsigned grid_x6 = static_cast<unsigned>(blocks_x6);
 #define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                           \
   do {                                                                                                                   \
     if (x6)                                                                                                              \
-      fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, kX6Block, 0, st>>>(                                      \
+      fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, fwd_x6_waves<LN>() * kWave, 0, st>>>(                                      \
           x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
           seed_base, reinterpret_cast<uint8_t*>(mask_out), aux_w, aux_b, aux_out);                                       \
     else                                                                                                                 \

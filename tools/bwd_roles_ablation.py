@@ -34,7 +34,7 @@ for name, flags in variants + others:
         os.environ["ALLSET_BWD_STAGE"] = "0"
         flags = []
     so = f"/tmp/bwdroles_{abs(hash(name))}.so"
-    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-shared", "-fPIC",
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950"] + ([] if "-DSLP" in flags else ["-fno-slp-vectorize"]) + ["-shared", "-fPIC",
                     "-I", os.path.join(ROOT, "include"), "-o", so] + flags + src, check=True)
     lib = ctypes.CDLL(so)
     fn = lib.allset_fused_linear_bwd_all
