@@ -553,7 +553,7 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                  int64_t ldacc);
+                                  int64_t ldacc, const float* aux_g, const float* aux_w);
 
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
@@ -674,7 +674,8 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
-                                  seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc);
+                                  seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc,
+                                  nullptr, nullptr);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }
@@ -701,6 +702,46 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   else launch_bwd_all<64, 64>(ALLSET_BWD_ALL_ARGS);
 #endif
 #undef ALLSET_BWD_ALL_ARGS
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+// ---- the plain Linear with four auxiliary output columns (PMA's value projection + folded logits, fused_mlp.hip aux_out) ----
+// gx = gy W + aux_g aux_w;  gW = gy^T x, gb = colsum(gy);  gaux_w = aux_g^T x [4, I], gaux_b = colsum(aux_g) [4] -- ONE pass over gy
+// and x (the split-role kernel of fused_bwd4.hip) where the two-kernel path reads x three times.
+extern "C" int allset_fused_linear_bwd_all_aux_supported(int64_t O, int64_t I) {
+  return fused_linear_bwd_roles_supported(O, I, 0);
+}
+
+extern "C" int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, const float* W, const float* x, int64_t ldx,
+                                               const float* aux_g, const float* aux_w, float* gx, int64_t ldgx, float* part,
+                                               int64_t part_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I,
+                                               void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_all_aux: negative size");
+  if (!allset_fused_linear_bwd_all_aux_supported(O, I)) {
+    set_error("fused_linear_bwd_all_aux: out=%lld in=%lld is not built (allset_fused_linear_bwd_all_aux_supported)",
+              static_cast<long long>(O), static_cast<long long>(I));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  // part: [n_slices][part_stride], sections gW [O*I] | gb [O] | gaux_w [4*I] | gaux_b [4]
+  ALLSET_REQUIRE(part != nullptr && part_stride >= O * I + O + 4 * I + 4, "fused_linear_bwd_all_aux: part_stride smaller than O*I + O + 4*I + 4");
+  const unsigned grid = fused_linear_bwd_roles_grid(n);
+  ALLSET_REQUIRE(n_slices == static_cast<int64_t>(grid), "fused_linear_bwd_all_aux: part must hold allset_fused_linear_bwd_all_slices_for() slices");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(part, 0, static_cast<size_t>(n_slices) * part_stride * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && W && x && gx && aux_g && aux_w, "fused_linear_bwd_all_aux: null pointer");
+  ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && aligned16(gy) && aligned16(W), "fused_linear_bwd_all_aux: gy / W must be 16-byte aligned rows");
+  ALLSET_REQUIRE(ldx >= I && ldx % 4 == 0 && aligned16(x), "fused_linear_bwd_all_aux: x must be 16-byte aligned rows");
+  ALLSET_REQUIRE(ldgx >= I && ldgx % 4 == 0 && aligned16(gx), "fused_linear_bwd_all_aux: gx must be 16-byte aligned rows");
+  ALLSET_REQUIRE(aligned16(aux_g) && aligned16(aux_w), "fused_linear_bwd_all_aux: aux_g [n,4] / aux_w [4,I] must be 16-byte aligned and dense");
+  ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24), "fused_linear_bwd_all_aux: leading dimensions must stay below 2^24 elements");
+  launch_fused_linear_bwd_roles(grid, st, false, false, false, false, gy, ldg, nullptr, 0.f, W, x, ldx, nullptr, nullptr, nullptr, 0.f, 0,
+                                gx, ldgx, part + O * I + O, part, part + O * I, n, nullptr, part_stride, part_stride, part_stride,
+                                nullptr, 0, aux_g, aux_w);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

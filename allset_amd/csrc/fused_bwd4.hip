@@ -67,14 +67,19 @@ __device__ __forceinline__ uint32_t hash_mix_r(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_R(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC>
+template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC, bool HAS_AUX>
 __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     const float* __restrict__ gy, int64_t ldg, const uint32_t* __restrict__ mask, float p_out, const float* __restrict__ W,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, const float* acc_in,
-    int64_t ldacc) {
+    int64_t ldacc, const float* __restrict__ aux_g, const float* __restrict__ aux_w) {
+  // HAS_AUX (plain Linear only): four auxiliary output columns rode along in the forward (PMA's folded logits, fused_mlp.hip
+  // aux_out = x aux_w^T + aux_b); here gx += aux_g[n,4] @ aux_w[4,I] as four FMAs per element in S2b, and the columns' own
+  // weight / bias gradient (aux_g^T x [4,I], column sums of aux_g) accumulate in the vector waves' registers next to the bias
+  // gradient -- partials go to part_ln[slice][4 I + 4], which a LayerNorm-free Linear does not use.
+  static_assert(!HAS_AUX || (!HAS_LN && !DROP_IN && !RELU_IN && !HAS_MASK && !HAS_ACC), "aux columns: plain Linear only");
   constexpr int OD = 128, ID = 128;
   constexpr int R = kRRows;
   constexpr int PLANE = R * 256;                 // bytes per bf16 plane of an image
@@ -128,6 +133,18 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     // ahead doubles the bytes in flight (the waves have the registers: no accumulators here).
     float4 agS[2][2][2]; uint32_t amS[2][2][2];      // [set][j][hb]: gy rows / mask words
     float4 xrS[2][2][2]; float2 stS[2][2];           // [set][j][hb]: x rows; [set][j]: statistics
+    float4 g4S[2][2];                                // [set][j]: the row's four auxiliary-column gradients (HAS_AUX)
+    float4 w4r[4][2], ga4[4][2], g4K[2];             // aux_w slice of this lane's columns; aux weight-gradient accumulators; stage k's g4
+    float4 gb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (HAS_AUX) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          w4r[q][hb] = *reinterpret_cast<const float4*>(aux_w + q * ID + 64 * hb + 4 * (lane0 & 15));
+          ga4[q][hb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     auto request_gy = [&](int64_t k, int lane, float4 (&ag)[2][2], uint32_t (&am)[2][2]) {
       const int c = lane & 15, rg = lane >> 4;
       const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);           // past the end: re-read the last stage (never consumed)
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         }
       }
     };
-    auto request_x = [&](int64_t k, int lane, float4 (&xr)[2][2], float2 (&st)[2]) {
+    auto request_x = [&](int64_t k, int lane, float4 (&xr)[2][2], float2 (&st)[2], float4 (&g4)[2]) {
       const int c = lane & 15, rg = lane >> 4;
       const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);
       const int nrc = max(rows_left(s0), 1);
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         for (int hb = 0; hb < 2; ++hb)
           xr[j][hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldx) * 4u + 256 * hb + 16 * c);
         if constexpr (HAS_LN) st[j] = *reinterpret_cast<const float2*>(sb + lr * 8);
+        if constexpr (HAS_AUX) g4[j] = *reinterpret_cast<const float4*>(aux_g + (s0 * R + lr) * 4);
       }
     };
     // ---- S0(k): ga = gy under the forward's epilogue mask, three bf16 planes into ga[k % 3]; then the request for gy(k + 1)
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     float4 kpK[2][2];          // dropout-in keep factors (keep_in or 0)
     uint32_t xbK = 0;          // "raw x > 0" flags, bit 8 j + 4 hb + q
     float rstdK[2];
-    auto S2a = [&](int64_t k, float4 (&xr)[2][2], float2 (&st)[2]) {
+    auto S2a = [&](int64_t k, float4 (&xr)[2][2], float2 (&st)[2], float4 (&g4)[2]) {
       const int lane = lane0;
       const int c = lane & 15, rg = lane >> 4;
       const int64_t stage = stage_of(k);
@@ -221,6 +239,12 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         const int lr = 8 * wave + rg + 4 * j;
         const bool live = lr < nrows;
         rstdK[j] = HAS_LN ? st[j].y : 1.f;
+        if constexpr (HAS_AUX) {          // (a dead row's clamped re-read is a live row's gradient: zero it)
+          float4 g = g4[j];
+          g.x = live ? g.x : 0.f; g.y = live ? g.y : 0.f; g.z = live ? g.z : 0.f; g.w = live ? g.w : 0.f;
+          g4K[j] = g;
+          gb4.x += g.x; gb4.y += g.y; gb4.z += g.z; gb4.w += g.w;
+        }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
           float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -248,6 +272,13 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
                             fmaf(xh.w, gam[hb].w, bet[hb].w));
           }
           xhK[j][hb] = t;
+          if constexpr (HAS_AUX) {        // aux_g^T x: this lane's four columns of the four auxiliary rows
+            const float4 g = g4K[j];
+            ga4[0][hb].x = fmaf(g.x, t.x, ga4[0][hb].x); ga4[0][hb].y = fmaf(g.x, t.y, ga4[0][hb].y); ga4[0][hb].z = fmaf(g.x, t.z, ga4[0][hb].z); ga4[0][hb].w = fmaf(g.x, t.w, ga4[0][hb].w);
+            ga4[1][hb].x = fmaf(g.y, t.x, ga4[1][hb].x); ga4[1][hb].y = fmaf(g.y, t.y, ga4[1][hb].y); ga4[1][hb].z = fmaf(g.y, t.z, ga4[1][hb].z); ga4[1][hb].w = fmaf(g.y, t.w, ga4[1][hb].w);
+            ga4[2][hb].x = fmaf(g.z, t.x, ga4[2][hb].x); ga4[2][hb].y = fmaf(g.z, t.y, ga4[2][hb].y); ga4[2][hb].z = fmaf(g.z, t.z, ga4[2][hb].z); ga4[2][hb].w = fmaf(g.z, t.w, ga4[2][hb].w);
+            ga4[3][hb].x = fmaf(g.w, t.x, ga4[3][hb].x); ga4[3][hb].y = fmaf(g.w, t.y, ga4[3][hb].y); ga4[3][hb].z = fmaf(g.w, t.z, ga4[3][hb].z); ga4[3][hb].w = fmaf(g.w, t.w, ga4[3][hb].w);
+          }
           if (j == 0) {         // row 0's planes here, row 1's in S2b: the split that balances the two ticks against the matrix waves
             if constexpr (DROP_IN) { u.x *= kp.x; u.y *= kp.y; u.z *= kp.z; u.w *= kp.w; }
             uint32_t h0, m0, l0, h1, m1, l1;
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
       }
       if constexpr (RELU_IN) __asm__ volatile("" : "+v"(xbK));     // (packed here, not at its use)
       __builtin_amdgcn_sched_barrier(0);
-      request_x(k + 2, lane, xr, st);             // x is consumed: the request for two stages ahead goes out a tick earlier
+      request_x(k + 2, lane, xr, st, g4);         // x is consumed: the request for two stages ahead goes out a tick earlier
       __builtin_amdgcn_sched_barrier(0);
     };
     auto S2b = [&](int64_t k) {
@@ -325,6 +356,13 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
             o.x = (xb & 1u) ? o.x : 0.f; o.y = (xb & 2u) ? o.y : 0.f; o.z = (xb & 4u) ? o.z : 0.f; o.w = (xb & 8u) ? o.w : 0.f;
           }
           if constexpr (HAS_ACC) { o.x += acc[j][hb].x; o.y += acc[j][hb].y; o.z += acc[j][hb].z; o.w += acc[j][hb].w; }
+          if constexpr (HAS_AUX) {        // + aux_g @ aux_w, added in the order q = 0..3 (the two-kernel path's order)
+            const float4 g = g4K[j];
+            o.x = fmaf(g.w, w4r[3][hb].x, fmaf(g.z, w4r[2][hb].x, fmaf(g.y, w4r[1][hb].x, fmaf(g.x, w4r[0][hb].x, o.x))));
+            o.y = fmaf(g.w, w4r[3][hb].y, fmaf(g.z, w4r[2][hb].y, fmaf(g.y, w4r[1][hb].y, fmaf(g.x, w4r[0][hb].y, o.y))));
+            o.z = fmaf(g.w, w4r[3][hb].z, fmaf(g.z, w4r[2][hb].z, fmaf(g.y, w4r[1][hb].z, fmaf(g.x, w4r[0][hb].z, o.z))));
+            o.w = fmaf(g.w, w4r[3][hb].w, fmaf(g.z, w4r[2][hb].w, fmaf(g.y, w4r[1][hb].w, fmaf(g.x, w4r[0][hb].w, o.w))));
+          }
 #ifdef ALLSET_ABL4_NOSTORE
           if (live && o.x == 123.456f)
 #else
@@ -353,9 +391,9 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     };
 
     request_gy(0, lane0, agS[0], amS[0]);
-    request_x(0, lane0, xrS[0], stS[0]);
+    request_x(0, lane0, xrS[0], stS[0], g4S[0]);
     request_gy(1, lane0, agS[1], amS[1]);
-    request_x(1, lane0, xrS[1], stS[1]);
+    request_x(1, lane0, xrS[1], stS[1], g4S[1]);
     S0(0, agS[0], amS[0]);
     ALLSET_ROLE_TICK();
     ALLSET_RMARK(3);
@@ -366,7 +404,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     int64_t k = 0;
     for (; k + 1 < T; k += 2) {
       S0(k + 1, agS[1], amS[1]);
-      S2a(k, xrS[0], stS[0]);
+      S2a(k, xrS[0], stS[0], g4S[0]);
       ALLSET_RMARK(0);
       ALLSET_ROLE_TICK();
       ALLSET_RMARK(1);
@@ -375,7 +413,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
       ALLSET_ROLE_TICK();
       ALLSET_RMARK(3);
       if (k + 2 < T) S0(k + 2, agS[0], amS[0]);
-      S2a(k + 1, xrS[1], stS[1]);
+      S2a(k + 1, xrS[1], stS[1], g4S[1]);
       ALLSET_RMARK(0);
       ALLSET_ROLE_TICK();
       ALLSET_RMARK(1);
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
       ALLSET_RMARK(3);
     }
     if (k < T) {                            // odd stage count: the last stage, in set 0
-      S2a(k, xrS[0], stS[0]);
+      S2a(k, xrS[0], stS[0], g4S[0]);
       ALLSET_ROLE_TICK();
       S2b(k);
       ALLSET_ROLE_TICK();
@@ -409,6 +447,26 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
           *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + ID + 64 * hb + 4 * lane]) = b;
           *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + 2 * ID + 64 * hb + 4 * lane]) = g3;
         }
+      }
+      if constexpr (HAS_AUX) {                  // behind the four waves' 3 I column sums: per wave [4][I] + 4
+        float* sa = sGU + 4 * 3 * ID + wave * (4 * ID + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            float4 a = ga4[q][hb];
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+              a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+            }
+            if (lane < 16) *reinterpret_cast<float4*>(&sa[q * ID + 64 * hb + 4 * lane]) = a;
+          }
+        float4 b = gb4;                         // (the 16 lanes of a row group hold the same sums: lane 0 of each group counts)
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+          b.x += __shfl_xor(b.x, off); b.y += __shfl_xor(b.y, off); b.z += __shfl_xor(b.z, off); b.w += __shfl_xor(b.w, off);
+        }
+        if (lane == 0) *reinterpret_cast<float4*>(&sa[4 * ID]) = b;
       }
     }
   } else {
@@ -573,6 +631,14 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     if (tid < 2 * ID) { if constexpr (HAS_LN) part_ln[slice * pstride_ln + tid] = s; }
     else if (part_b != nullptr) part_b[slice * pstride_b + (tid - 2 * ID)] = s;
   }
+  if constexpr (HAS_AUX) {
+    for (int idx = tid; idx < 4 * ID + 4; idx += kRBlock) {
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s += sGU[4 * 3 * ID + v * (4 * ID + 4) + idx];
+      part_ln[static_cast<int64_t>(blockIdx.x) * pstride_ln + idx] = s;
+    }
+  }
 }
 
 }  // namespace allset
@@ -598,11 +664,14 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                  int64_t ldacc) {
-#define ALLSET_ROLES_K(LN, DI, RI, HM, HA)                                                                                     \
-  fused_linear_bwd_roles_kernel<LN, DI, RI, HM, HA><<<grid, kRBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma,     \
+                                  int64_t ldacc, const float* aux_g, const float* aux_w) {
+#define ALLSET_ROLES_KA(LN, DI, RI, HM, HA, AX)                                                                                \
+  fused_linear_bwd_roles_kernel<LN, DI, RI, HM, HA, AX><<<grid, kRBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, \
                                                                              beta, p_in, seed_in, gx, ldgx, part_ln, part_w,    \
-                                                                             part_b, n, seed_base, psw, psb, psl, acc_in, ldacc)
+                                                                             part_b, n, seed_base, psw, psb, psl, acc_in, ldacc, \
+                                                                             aux_g, aux_w)
+#define ALLSET_ROLES_K(LN, DI, RI, HM, HA) ALLSET_ROLES_KA(LN, DI, RI, HM, HA, false)
+  if (aux_g != nullptr) { ALLSET_ROLES_KA(false, false, false, false, false, true); return 0; }   // (plain Linear + four aux columns)
   if (acc_in != nullptr) { ALLSET_ROLES_K(false, false, false, false, true); return 0; }     // (bwd_all_combo: plain Linear only)
 #define ALLSET_ROLES_M(LN, DI, RI) do { if (hm) ALLSET_ROLES_K(LN, DI, RI, true, false); else ALLSET_ROLES_K(LN, DI, RI, false, false); } while (0)
   if (!relu) { if (ln) ALLSET_ROLES_M(true, false, false); else ALLSET_ROLES_M(false, false, false); }
@@ -610,5 +679,6 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
   else { if (drop) ALLSET_ROLES_M(false, true, true); else ALLSET_ROLES_M(false, false, true); }
 #undef ALLSET_ROLES_M
 #undef ALLSET_ROLES_K
+#undef ALLSET_ROLES_KA
   return 0;
 }

@@ -486,6 +486,36 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
     return gx, red[O * I + O:O * I + O + I], red[O * I + O + I:O * I + O + 2 * I], gw, gb
 
 
+def fused_linear_bwd_all_aux_supported(O: int, I: int) -> bool:
+    return bool(_lib.load().allset_fused_linear_bwd_all_aux_supported(int(O), int(I)))
+
+
+def fused_linear_bwd_all_aux(gy: Tensor, weight: Tensor, x: Tensor, aux_g: Tensor, aux_w: Tensor
+                             ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """(gx, gW, gb, gaux_w [4, I], gaux_b [4]) of the plain Linear with four auxiliary output columns, from ONE pass over gy and x
+    (include/allset_hip.h allset_fused_linear_bwd_all_aux)."""
+    dev = require_device(gy, weight, x, aux_g, aux_w)
+    _check_f32(gy, weight, x, aux_g, aux_w)
+    gy, x = _rowmajor(gy), _rowmajor(x)
+    weight, aux_g, aux_w = weight.contiguous(), aux_g.contiguous(), aux_w.contiguous()
+    n, O = gy.shape
+    I = x.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_fused_linear_bwd_all_slices_for(n, O, I, 0, byref(ns)), "allset_fused_linear_bwd_all_slices_for")
+    P = ns.value
+    gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    M = (O * I + O + 4 * I + 4 + 3) // 4 * 4
+    part = torch.empty((P, M), dtype=torch.float32, device=dev)
+    with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I + 4) * 4):
+        check(lib.allset_fused_linear_bwd_all_aux(ptr(gy), _ld(gy), ptr(weight), ptr(x), _ld(x), ptr(aux_g), ptr(aux_w), ptr(gx),
+                                                  max(I, 1), ptr(part), M, P, n, O, I, stream_of(dev)),
+              "allset_fused_linear_bwd_all_aux")
+    red = reduce_partials(part)
+    o = O * I
+    return gx, red[:o].view(O, I), red[o:o + O], red[o + O:o + O + 4 * I].view(4, I), red[o + O + 4 * I:o + O + 4 * I + 4]
+
+
 def wgrad_supported(ga: Tensor, u: Tensor) -> bool:
     return (ga.is_cuda and ga.dtype == u.dtype and ga.dtype in (torch.float32, torch.bfloat16) and ga.shape[1] % 4 == 0
             and u.shape[1] % 4 == 0)
@@ -901,6 +931,13 @@ class _PmaProject(torch.autograd.Function):
         has_bv, has_ba, aux, H = ctx.cfg
         g_v, g_alpha = g_v.contiguous(), g_alpha.contiguous()
         gx = gwv = gbv = gwa = gba = None
+        if (aux and ctx.needs_input_grad[0] and g_v.is_cuda and g_v.dtype == torch.float32
+                and fused_linear_bwd_all_aux_supported(w_v.shape[0], w_v.shape[1])):
+            # one pass: both gradient branches of x, the projection's weight / bias gradient and the logit columns' own
+            g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
+            gx, gwv, gbv, gwa4, gba4 = fused_linear_bwd_all_aux(g_v, w_v, x, g4, w4)
+            return (gx, gwv, gbv if has_bv else None, gwa4[:H] if H < 4 else gwa4,
+                    (gba4[:H] if H < 4 else gba4) if has_ba else None)
         if ctx.needs_input_grad[0]:
             if aux:
                 g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 6   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for) */
+#define ALLSET_ABI_VERSION 7   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -504,6 +504,17 @@ int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* ma
                                 uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b,
                                 int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                                 const float* acc_in, int64_t ldacc, int64_t part_stride, void* stream);
+/* The same single pass for the plain Linear that carried four auxiliary output columns in the forward (allset_fused_linear_fwd's
+ * aux_w / aux_out: PMA's folded attention logits, reference layers.py:126-131 `x_K = self.lin_K(x); alpha = (x_K * self.att_r).sum(-1)`
+ * restated as x @ w_a^T):  gx = gy W + aux_g aux_w,  gW = gy^T x,  gb = colsum(gy),  gaux_w = aux_g^T x [4, I],  gaux_b = colsum(aux_g).
+ * aux_g [n,4] and aux_w [4,I] dense fp32, 16-byte aligned.  part: [n_slices][part_stride] with sections gW [O*I] | gb [O] | gaux_w
+ * [4*I] | gaux_b [4] (part_stride >= O*I + O + 4*I + 4; n_slices = allset_fused_linear_bwd_all_slices_for(n, O, I, 0)); the caller
+ * sums over slices (allset_reduce_partials).  Built where _aux_supported(O, I) returns 1 (O = I = 128, default kernel family);
+ * otherwise ALLSET_ERR_UNSUPPORTED and the caller keeps allset_fused_linear_bwd (aux_g / aux_w) + allset_wgrad. */
+int allset_fused_linear_bwd_all_aux_supported(int64_t O, int64_t I);
+int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, const float* W, const float* x, int64_t ldx, const float* aux_g,
+                                    const float* aux_w, float* gx, int64_t ldgx, float* part, int64_t part_stride, int64_t n_slices,
+                                    int64_t n, int64_t O, int64_t I, void* stream);
 
 #ifdef __cplusplus
 }

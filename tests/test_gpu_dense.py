@@ -957,3 +957,44 @@ def test_pma_logit_fold_kernels(H, C, K, bias, device):
     torch.testing.assert_close(b.detach().cpu().double(), br.detach(), rtol=1e-5, atol=1e-5)
     for k in ((0, 1, 2) if bias else (0, 2)):
         torch.testing.assert_close(d[k].grad.cpu().double(), r[k].grad, rtol=1e-5, atol=1e-5 * max(1.0, float(r[k].grad.abs().max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [4, 1, 2])
+@pytest.mark.parametrize("n", [1, 17, 33, 4099, 70001])
+def test_one_pass_backward_with_aux_columns(H, n, device):
+    """PMA's value projection + folded logit columns (reference layers.py:126-131): the single-pass backward
+    (allset_fused_linear_bwd_all_aux) against float64, against the two-kernel path it replaces, and run to run."""
+    from allset_amd import dense
+    if not dense.fused_linear_bwd_all_aux_supported(128, 128):
+        pytest.skip("default kernel family not selected")
+    g = torch.Generator(device="cpu").manual_seed(100 * H + n)
+    x = torch.randn(n, 128, generator=g).to(device).requires_grad_(True)
+    w_v = (torch.randn(128, 128, generator=g) / 11).to(device).requires_grad_(True)
+    b_v = torch.randn(128, generator=g).to(device).requires_grad_(True)
+    w_a = (torch.randn(H, 128, generator=g) / 11).to(device).requires_grad_(True)
+    b_a = torch.randn(H, generator=g).to(device).requires_grad_(True)
+    cv, ca = torch.randn(n, 128, generator=g).to(device), torch.randn(n, H, generator=g).to(device)
+    leaves = (x, w_v, b_v, w_a, b_a)
+
+    def run():
+        for t in leaves:
+            t.grad = None
+        xv, al = dense.pma_project(x, w_v, b_v, w_a, b_a)
+        ((xv * cv).sum() + (al * ca).sum()).backward()
+        return [t.grad.clone() for t in leaves]
+
+    got = run()
+    again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    x64, wv64, wa64 = x.detach().double(), w_v.detach().double(), w_a.detach().double()
+    ref = [cv.double() @ wv64 + ca.double() @ wa64, cv.double().t() @ x64, cv.double().sum(0), ca.double().t() @ x64, ca.double().sum(0)]
+    for a, r in zip(got, ref):
+        scale = float(r.abs().max()) + 1e-30
+        assert float((a.double() - r).abs().max()) <= 2e-5 * scale + 1e-6, (a.shape, float((a.double() - r).abs().max()), scale)
+    # the two-kernel path on the same operands
+    g4 = ca if H == 4 else torch.cat([ca, ca.new_zeros(n, 4 - H)], dim=1)
+    w4 = w_a.detach() if H == 4 else torch.cat([w_a.detach(), w_a.new_zeros(4 - H, 128)])
+    gx2, _, _ = dense.fused_linear_bwd(cv, None, 0.0, w_v.detach(), x.detach(), None, None, False, 0.0, 0, aux_g=g4.contiguous(), aux_w=w4.contiguous())
+    torch.testing.assert_close(got[0], gx2, rtol=1e-5, atol=1e-5 * float(gx2.abs().max()))
