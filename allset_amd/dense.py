@@ -1216,3 +1216,97 @@ def relu_dropout(x: Tensor, p: float = 0.0) -> Tensor:
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     return _Linear.apply(x, weight, bias)
+
+
+# ---- BatchNorm over a row-sharded batch (reference layers.py:499-562: MLP's default Normalization='bn') ----------------------------
+# A sharded layer holds a block of the batch's rows per rank (plus zero pad rows).  torch's BatchNorm1d would take its statistics
+# over that block alone -- a different model than the single-GPU one, and replicated running statistics that drift apart.  Inside
+# `sync_bn_rows(valid_rows, group)` the BatchNorm1d modules of an MLP compute (count, sum) and then the centred sum of squares over
+# the VALID rows of ALL ranks (two [d]-sized all-reduces: the two-pass form, no cancellation), normalise every local row with them
+# and update the running statistics exactly as torch does (biased variance to normalise, unbiased into running_var).
+import contextlib
+import threading
+
+_sync_bn_state = threading.local()
+
+
+@contextlib.contextmanager
+def sync_bn_rows(valid_rows: int, group=None):
+    """BatchNorm1d modules called inside see a batch = the first ``valid_rows`` local rows of every rank of ``group``."""
+    prev = getattr(_sync_bn_state, "scope", None)
+    _sync_bn_state.scope = (int(valid_rows), group)
+    try:
+        yield
+    finally:
+        _sync_bn_state.scope = prev
+
+
+def _host_all_reduce_sum(t: Tensor, group) -> Tensor:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":          # (tests: two ranks on one GPU; a [d]-sized message)
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group)
+    return t
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, valid, group, eps):
+        xs = x[:valid].float()
+        d = x.shape[1]
+        head = torch.cat([xs.sum(0), xs.new_full((1,), float(valid))])
+        head = _host_all_reduce_sum(head, group)
+        count = head[d].clamp(min=1.0)
+        mean = head[:d] / count
+        m2 = _host_all_reduce_sum(((xs - mean) ** 2).sum(0), group)
+        var = m2 / count                                             # biased: what normalises (torch.nn.BatchNorm1d)
+        rstd = torch.rsqrt(var + eps)
+        xhat = (x.float() - mean) * rstd
+        y = xhat * weight.float() + bias.float() if weight is not None else xhat
+        ctx.save_for_backward(xhat, weight, rstd, count)
+        ctx.cfg = (int(valid), group, bias is not None)
+        ctx.mark_non_differentiable(mean, var, count)
+        return y.to(x.dtype), mean, var, count
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gm, _gv, _gc):
+        xhat, weight, rstd, count = ctx.saved_tensors
+        valid, group, has_bias = ctx.cfg
+        g = gy.float()
+        gs, xs = g[:valid], xhat[:valid]
+        loc = torch.cat([gs.sum(0), (gs * xs).sum(0)])               # this rank's share of (dbeta, dgamma)
+        d = g.shape[1]
+        glob = _host_all_reduce_sum(loc.clone(), group)
+        w = weight.float() if weight is not None else torch.ones_like(rstd)
+        gx = torch.zeros_like(g)
+        gx[:valid] = (gs - glob[:d] / count - xs * (glob[d:] / count)) * (w * rstd)
+        if valid < g.shape[0]:                                       # pad rows: constants of the batch as far as they are concerned
+            gx[valid:] = g[valid:] * (w * rstd)
+        # parameter gradients stay LOCAL partial sums: the caller's gradient all-reduce (dist.allreduce_grads) completes them
+        gw = loc[d:].to(weight.dtype) if weight is not None else None
+        gb = loc[:d].to(weight.dtype) if (weight is not None and has_bias) else None
+        return gx.to(gy.dtype), gw, gb, None, None, None
+
+
+def batch_norm(bn: torch.nn.modules.batchnorm._BatchNorm, x: Tensor) -> Tensor:
+    """``bn(x)``; inside :func:`sync_bn_rows` with batch statistics in use, the cross-rank form above."""
+    scope = getattr(_sync_bn_state, "scope", None)
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    if scope is None or not use_batch:
+        return bn(x)                      # eval with running statistics is row-wise: nothing to synchronise
+    valid, group = scope
+    valid = max(0, min(valid, x.shape[0]))
+    y, mean, var, count = _SyncBatchNorm.apply(x, bn.weight, bn.bias, valid, group, float(bn.eps))
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            unbiased = var * (count / (count - 1.0).clamp(min=1.0))
+            bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+    return y

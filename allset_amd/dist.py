@@ -359,13 +359,18 @@ class HipPmaKernels:
                                variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]), row_order=T.row_order)
 
 
-def _no_batchnorm(*convs) -> None:
-    """Row-sharded BatchNorm would take its batch statistics over one rank's block (zero pad rows included) and let
-    the replicated running statistics drift apart silently; it needs a cross-rank (count, sum, sum of squares)
-    reduction that is not built.  Refuse instead of computing something else than the single-GPU model."""
-    if not _skip_collective(None) and _has_batchnorm(*convs):
-        raise NotImplementedError("sharded execution does not cover Normalization='bn' (per-rank batch statistics would "
-                                  "differ from the single-GPU model); use 'ln' or 'None'")
+def _bn_scope(valid_rows: int, group):
+    """Row-sharded BatchNorm (the reference MLP's default ``Normalization='bn'``, layers.py:499-562): per-rank batch statistics
+    (zero pad rows included) would be a different model than the single-GPU one and let the replicated running statistics drift
+    apart.  Inside this scope the MLP's BatchNorm1d modules reduce (count, sum, centred sum of squares) over the VALID rows of all
+    ranks (``dense.sync_bn_rows``); round 3 -- rounds 1-2 refused 'bn' in sharded mode."""
+    import contextlib
+    from . import dense
+    return contextlib.nullcontext() if _skip_collective(group) else dense.sync_bn_rows(valid_rows, group)
+
+
+def _valid_rows(lo: int, hi: int, n: int) -> int:
+    return max(0, min(int(hi), int(n)) - int(lo))
 
 
 def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, aggr: str = "add",
@@ -379,17 +384,19 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     (``allreduce_grads``) -- each rank sees only its rows."""
     if aggr not in ("add", "sum", "mean", "max", "min"):
         raise ValueError(f"aggr {aggr!r}")
-    _no_batchnorm(v2e_conv, e2v_conv)
+    vv = _valid_rows(hg.v_lo, hg.v_hi, hg.n_v)                 # real (not pad) rows of this rank's vertex block; every local hyperedge is real
     norm = hg.norm if norm is None else norm                   # ``norm``: per-incidence weights of the LOCAL incidences
     p_out = dropout if dropout_out is None else dropout_out    # GPR applies the last dropout itself (models.py:466-469)
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
     # ``training`` must agree with the convs' own mode (the fused MLP kernels read conv.training)
-    h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
+    with _bn_scope(vv, group):
+        h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
     h_full = all_gather_rows(h, group)
     e = aggregate(h_full, hg.v2e, norm, aggr)
-    e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)           # conv's relu (SetGNN's outer relu is idempotent) + dropout
-    # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
-    g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
+    with _bn_scope(e.shape[0], group):
+        e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)       # conv's relu (SetGNN's outer relu is idempotent) + dropout
+        # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
+        g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
     if aggr in ("max", "min"):
         # local extreme over this rank's hyperedges (autograd routes to the local arg-extreme), then the key merge
         partial = aggregate(g, hg.e2v, norm, aggr)
@@ -399,7 +406,8 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
         v = reduce_scatter_rows(partial, group)
     if aggr == "mean":
         v = v / hg.owned_vertex_degree(group).clamp(min=1).view(-1, 1)
-    return e2v_conv._mlp_act(e2v_conv.f_dec, v, p_out)
+    with _bn_scope(vv, group):
+        return e2v_conv._mlp_act(e2v_conv.f_dec, v, p_out)
 
 
 class _ShardedPmaE2V(torch.autograd.Function):
@@ -663,7 +671,6 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
     others' dense work (chunk k of rank i lands at rows i*n/P + k*rc of the column table: the natural row order)."""
     if aggr not in ("add", "sum", "mean", "max", "min"):
         raise ValueError(f"aggr {aggr!r}")
-    _no_batchnorm(v2e_conv, e2v_conv)
     norm = hg.norm if norm is None else norm
     p_out = dropout if dropout_out is None else dropout_out
     w = 1 if _skip_collective(group) else _world(group)
@@ -672,8 +679,15 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
     mid = lambda t: e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, t, dropout), e2v_conv.dropout)
     dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, p_out)
     if K == 1:
-        e = cols_to_rows(aggregate(rows_to_cols(enc1(x_owned), group), hg.v2e, norm, aggr), group)      # [n_E/P, d]
-        return dec2(cols_to_rows(aggregate(rows_to_cols(mid(e), group), hg.e2v, norm, aggr), group))
+        vv, ve = _valid_rows(hg.v_lo, hg.v_hi, hg.n_v), _valid_rows(hg.e_lo, hg.e_hi, hg.n_e)     # real rows of the two owned blocks
+        with _bn_scope(vv, group):
+            h = enc1(x_owned)
+        e = cols_to_rows(aggregate(rows_to_cols(h, group), hg.v2e, norm, aggr), group)      # [n_E/P, d]
+        with _bn_scope(ve, group):
+            g = mid(e)
+        v = cols_to_rows(aggregate(rows_to_cols(g, group), hg.e2v, norm, aggr), group)
+        with _bn_scope(vv, group):
+            return dec2(v)
     (hc,) = _stage(torch.split(x_owned, x_owned.shape[0] // K), enc1, x_owned.shape[0] // K, K, w, group)
     ec = aggregate(hc, hg.v2e, norm, aggr)
     (gc,) = _stage(_unstage(ec, K, w, group), lambda get: mid(get()), hg.n_e_pad // w // K, K, w, group)
@@ -991,14 +1005,10 @@ class ShardedSetGNN(torch.nn.Module):
     order.  A hyperedge shard multiplies its own incidences' entries (``hg.inc_ids``) into its local ``norm``; every
     incidence lives on exactly one rank, so the gradient all-reduce adds zeros from the others.  Column shards hold every
     incidence and d/P of the columns: each rank's weight gradient is a partial sum over its columns and the same
-    all-reduce completes it.  ``Normalization='bn'`` is refused (see ``_no_batchnorm``)."""
+    all-reduce completes it.  ``Normalization='bn'``: cross-rank batch statistics (``_bn_scope``)."""
 
     def __init__(self, model, hg, group=None, aggregate: Callable = _hip_deepsets, kernels=HipPmaKernels):
         super().__init__()
-        if not _skip_collective(group) and _has_batchnorm(*model.V2EConvs, *model.E2VConvs, model.classifier,
-                                                          *([model.MLP] if getattr(model, "GPR", False) else [])):
-            raise NotImplementedError("sharded execution does not cover Normalization='bn' (per-rank batch statistics "
-                                      "would differ from the single-GPU model); use 'ln' or 'None'")
         if getattr(model, "LearnMask", False) and isinstance(hg, ShardedHypergraph) and hg.inc_ids is None \
                 and model.Importance.numel() != hg.local_edge_index.shape[1]:
             raise ValueError("LearnMask on a hyperedge shard needs ShardedHypergraph(inc_ids=...): the positions of the "
@@ -1019,6 +1029,12 @@ class ShardedSetGNN(torch.nn.Module):
                      aggregate=self._aggregate, norm=norm, dropout_out=dropout_out, **extra)
 
     def forward(self, x_owned: Tensor) -> Tensor:
+        # BatchNorm1d in the classifier / GPR MLP: statistics over the real vertex rows of all ranks (the convs' own MLPs set
+        # their scopes inside the layer functions)
+        with _bn_scope(_valid_rows(self.hg.v_lo, self.hg.v_hi, self.hg.n_v), self.group):
+            return self._forward(x_owned)
+
+    def _forward(self, x_owned: Tensor) -> Tensor:
         m, hg = self.model, self.hg
         norm = hg.norm
         if getattr(m, "LearnMask", False):                     # norm = Importance * norm (models.py:451-452), local slice

@@ -72,6 +72,14 @@ def _layer_norm(norm: nn.LayerNorm, x: Tensor, relu_in: bool = False, p: float =
     return F.dropout(y, p=p, training=p > 0.0)
 
 
+def _norm_module(nm: nn.Module, x: Tensor) -> Tensor:
+    """Identity / BatchNorm1d slot of an MLP; BatchNorm goes through ``dense.batch_norm`` so that a sharded layer
+    (``dist.py``) can give it the statistics of the whole batch instead of one rank's block of rows."""
+    if isinstance(nm, nn.modules.batchnorm._BatchNorm):
+        return dense.batch_norm(nm, x)
+    return nm(x)
+
+
 def _linear(lin: nn.Linear, x: Tensor, relu_out: bool = False) -> Tensor:
     if dense.linear_bf16_supported(x, lin.weight, lin.bias):
         return dense.linear_bf16(x, lin.weight, lin.bias, relu_out)     # bf16 regime: one kernel, relu in its epilogue
@@ -154,7 +162,7 @@ class MLP(nn.Module):
                     relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0)
             return x
         n0 = self.normalizations[0]
-        x = _layer_norm(n0, x) if isinstance(n0, nn.LayerNorm) else n0(x)
+        x = _layer_norm(n0, x) if isinstance(n0, nn.LayerNorm) else _norm_module(n0, x)
         for i, lin in enumerate(self.lins[:-1]):
             nxt = self.normalizations[i + 1]
             if isinstance(nxt, nn.Identity) and p == 0.0 and dense.linear_bf16_supported(x, lin.weight, lin.bias):
@@ -166,7 +174,7 @@ class MLP(nn.Module):
             elif isinstance(nxt, nn.Identity):         # relu -> dropout: one kernel
                 x = relu_dropout(a, p, self.training)
             else:                                      # BatchNorm1d: torch
-                x = F.dropout(nxt(F.relu(a)), p=p, training=self.training)
+                x = F.dropout(_norm_module(nxt, F.relu(a)), p=p, training=self.training)
         if post_p == 0.0 and dense.linear_bf16_supported(x, self.lins[-1].weight, self.lins[-1].bias):
             return _linear(self.lins[-1], x, relu_out=True)
         x = _linear(self.lins[-1], x)

@@ -394,51 +394,120 @@ def test_sharded_gpr_learnmask_equals_oracle(columns):
         torch.testing.assert_close(torch.from_numpy(r[3]), sd["GPRweights.weight"].grad, rtol=1e-4, atol=1e-5)
 
 
-def _bn_refusal_worker(rank, world, port, q):
+def _bn_worker(rank, world, port, columns, q):
+    """``Normalization='bn'`` (the reference MLP's default, layers.py:499-562) through ShardedSetGNN in TRAINING mode: batch
+    statistics over the real rows of both ranks; dropouts off so that the oracle's training mode is comparable."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import cases
-        from allset_amd import SetGNN, HalfNLHconv, dist as adist
-        n_v, n_e, d, ei, norm, x, G = _problem(world)
-        hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm)
-        msgs = []
-        try:
-            adist.ShardedSetGNN(SetGNN(cases.make_args("ds_add", d, 32, 5, normalization="bn")), hg)
-        except NotImplementedError as e:
-            msgs.append(str(e))
-        a = HalfNLHconv(d, d, d, 2, 0.0, "bn", True, attention=False)
-        try:
-            adist.colsharded_deepsets_layer(a, a, x[:hg.v_hi - hg.v_lo], hg, aggregate=_oracle_aggregate)
-        except NotImplementedError as e:
-            msgs.append(str(e))
+        from allset_amd import SetGNN, dist as adist
+        n_v, n_e, d, ei, _, x, G = _problem(world)
+        args = cases.make_args("ds_add", d, 32, 5, All_num_layers=2, normalization="bn", dropout=0.0, Classifier_num_layers=2)
+        torch.manual_seed(11)
+        model = SetGNN(args).train()
+        sd0 = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+        adist._rank_dropout = lambda t, p, training: t            # the hard-wired input dropout (models.py:473) off
+        ones = torch.ones(ei.shape[1], dtype=torch.int64)
+        if columns:
+            hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=ones, chunks=columns)
+            hg.v2e = (ei, hg.n_e_pad)
+            hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
+        else:
+            owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
+            loc, gids = adist.local_shard(ei, owner, rank)
+            keep = owner[ei[1]] == rank
+            hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=torch.ones(int(keep.sum()), dtype=torch.int64))
+            hg.v2e = (loc, hg.n_e_local)
+            hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        sharded = adist.ShardedSetGNN(model, hg, aggregate=_oracle_aggregate, kernels=TorchPmaKernels)
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+        out = sharded(xp[hg.v_lo:hg.v_hi])
+        cot = torch.linspace(-1.0, 1.0, hg.n_v_pad * out.shape[1]).view(hg.n_v_pad, -1)[hg.v_lo:hg.v_hi].clone()
+        cot[max(0, n_v - hg.v_lo):] = 0.0                         # pad rows carry no loss
+        (out * cot).sum().backward()
+        sharded.allreduce_grads()
+        grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+        q.put((rank, out.detach().numpy().copy(), sd0, grads, {k: v.numpy().copy() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("columns", [0, 1])
+def test_sharded_batchnorm_uses_the_statistics_of_the_whole_batch(columns):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cases
+    from oracle import allset_oracle as oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, world, port, columns, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_v, n_e, d, ei, _, x, G = _problem(world)
+    args = cases.make_args("ds_add", d, 32, 5, All_num_layers=2, normalization="bn", dropout=0.0, Classifier_num_layers=2)
+    sd = {k: torch.from_numpy(v).clone() for k, v in results[0][2].items()}
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    ref = oracle.setgnn_forward(sd, args, x, ei, torch.ones(ei.shape[1], dtype=torch.int64), drop=lambda t, p: t)   # training mode, no dropout
+    got = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    torch.testing.assert_close(got, ref.detach(), rtol=1e-4, atol=1e-4 * float(ref.detach().abs().max()))    # (atol relative to the tensor's scale: tests/util.py)
+    n_pad = sum(r[1].shape[0] for r in results)
+    cot = torch.linspace(-1.0, 1.0, n_pad * ref.shape[1]).view(n_pad, -1)[:n_v]
+    (ref * cot).sum().backward()
+    for r in results:                                              # all-reduced: every rank holds the full gradient
+        for k, g in r[3].items():
+            exp = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])      # (never-applied modules: zero-filled by allreduce_grads)
+            torch.testing.assert_close(torch.from_numpy(g), exp, rtol=1e-3, atol=1e-4 * max(1.0, float(exp.abs().max())), msg=lambda m, k=k: f"{k}: {m}")
+    # running statistics: identical on both ranks, moved towards the whole batch's statistics exactly as torch moves them
+    for k in results[0][4]:
+        np.testing.assert_array_equal(results[0][4][k], results[1][4][k])
+    key = "V2EConvs.0.f_enc.normalizations.0"
+    rm = torch.from_numpy(results[0][4][key + ".running_mean"])
+    torch.testing.assert_close(rm, 0.1 * x.mean(0), rtol=1e-4, atol=1e-6)                      # InputNorm slot sees x itself
+    rv = torch.from_numpy(results[0][4][key + ".running_var"])
+    torch.testing.assert_close(rv, 0.9 + 0.1 * x.var(0, unbiased=True), rtol=1e-4, atol=1e-6)
+    assert int(results[0][4][key + ".num_batches_tracked"]) == 1
+
+
+def _zero_fill_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
         # the zero-gradient substitution of allreduce_grads: rank 1 has no gradient for one parameter
         p0, p1 = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
         p0.grad = torch.full((3,), float(rank + 1))
         if rank == 0:
             p1.grad = torch.full((2,), 5.0)
         adist.allreduce_grads([p0, p1])
-        q.put((rank, msgs, p0.grad.tolist(), p1.grad.tolist()))
+        q.put((rank, p0.grad.tolist(), p1.grad.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_batchnorm_is_refused_and_missing_grads_are_zero_filled():
+def test_missing_grads_are_zero_filled():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_bn_refusal_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_zero_fill_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, msgs, g0, g1 in results:
-        assert len(msgs) == 2 and all("bn" in m for m in msgs)
+    for rank, g0, g1 in results:
         assert g0 == [3.0, 3.0, 3.0] and g1 == [5.0, 5.0]
 
 

@@ -41,6 +41,8 @@ MODEL_CFGS = [
     ("ds_add", "rows", 1, dict(GPR=True, LearnMask=True)), ("ds_add", "cols", 1, dict(GPR=True, LearnMask=True)),
     ("ds_add", "cols", 4, dict(GPR=True, LearnMask=True)), ("pma_h4", "rows", 1, {}), ("pma_h4", "cols", 4, {}),
     ("ds_mean", "cols", 1, {}),
+    # the reference MLP's default normalisation, TRAINING mode (batch statistics over both ranks' real rows), dropouts off
+    ("ds_add", "rows", 1, dict(normalization="bn", dropout=0.0)), ("ds_add", "cols", 1, dict(normalization="bn", dropout=0.0)),
 ]
 
 
@@ -123,6 +125,10 @@ def _run_configs(rank, world, dev, q):
             args = cases.make_args(mode, d, 64, 5, All_num_layers=2, **kw)
             torch.manual_seed(11)
             model = SetGNN(args, norm if kw.get("LearnMask") else None).eval()
+            keep_rank_dropout = adist._rank_dropout
+            if kw.get("normalization") == "bn":
+                model.train()
+                adist._rank_dropout = lambda t, p, training: t        # the hard-wired input dropout (models.py:473) off
             if kw.get("LearnMask"):
                 with torch.no_grad():
                     model.Importance.copy_(torch.linspace(0.5, 1.5, ei.shape[1]))
@@ -136,6 +142,7 @@ def _run_configs(rank, world, dev, q):
             cot = torch.linspace(-1.0, 1.0, N_V * out.shape[1]).view(N_V, -1)[hg.v_lo:hg.v_lo + live].to(dev)
             (out[:live] * cot).sum().backward()
             sharded.allreduce_grads()
+            adist._rank_dropout = keep_rank_dropout
             grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
             res[("model", mode, scheme, chunks, tuple(sorted(kw)))] = (
                 out.detach().cpu().numpy(), grads, {k: v.cpu().numpy() for k, v in model.state_dict().items()})
@@ -215,7 +222,8 @@ def test_two_rank_hip_layer_equals_unsharded_hip_layer_and_oracle(cfg, two_ranks
         torch.testing.assert_close(gx, xo.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(xo.grad.abs().max())))
 
 
-@pytest.mark.parametrize("cfg", MODEL_CFGS, ids=lambda c: "-".join(str(t) for t in c[:3]) + ("-gpr-mask" if c[3] else ""))
+@pytest.mark.parametrize("cfg", MODEL_CFGS, ids=lambda c: "-".join(str(t) for t in c[:3]) + ("-gpr-mask" if c[3].get("GPR") else "") +
+                         ("-bn-train" if c[3].get("normalization") == "bn" else ""))
 def test_two_rank_sharded_setgnn_equals_oracle(cfg, two_ranks):
     import cases
     from oracle import allset_oracle as oracle
@@ -232,7 +240,8 @@ def test_two_rank_sharded_setgnn_equals_oracle(cfg, two_ranks):
         if t.is_floating_point():
             t.requires_grad_(True)
     nrm = norm.double() if kw.get("LearnMask") else torch.ones(ei.shape[1], dtype=torch.int64)
-    ref = oracle.setgnn_forward(sd, args, x.double(), ei, nrm)
+    bn_train = kw.get("normalization") == "bn"                 # training mode without dropouts: batch statistics
+    ref = oracle.setgnn_forward(sd, args, x.double(), ei, nrm, drop=(lambda t, p: t) if bn_train else None)
     cot = torch.linspace(-1.0, 1.0, N_V * ref.shape[1]).view(N_V, -1)
     (ref * cot.double()).sum().backward()
     got = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(2)])[:N_V]
