@@ -56,6 +56,14 @@ def _problem(d, seed=42):
     return ei, norm, x, G
 
 
+def _model_seed(kw):
+    """Data seed of a model configuration.  BatchNorm in training mode couples all rows, so ONE relu input within fp32 rounding
+    of zero moves every parameter gradient by percents (a kink: either side's gradient is right) -- and with ~250k relu inputs
+    most random examples have one: of the seeds 7..19, a 1e-6 perturbation of x moves the float64 oracle's own gradient by
+    0.5-4 % for all but 11 and 17.  The bn-train configurations use 11, and the test below asserts that the example is stable."""
+    return 11 if kw.get("normalization") == "bn" else 7
+
+
 def _convs(kind, arg, d):
     from allset_amd import HalfNLHconv
     torch.manual_seed(3)
@@ -121,7 +129,7 @@ def _run_configs(rank, world, dev, q):
         for cfg in MODEL_CFGS:
             mode, scheme, chunks, kw = cfg
             d = 64
-            ei, norm, x, G = _problem(d, seed=7)
+            ei, norm, x, G = _problem(d, seed=_model_seed(kw))
             args = cases.make_args(mode, d, 64, 5, All_num_layers=2, **kw)
             torch.manual_seed(11)
             model = SetGNN(args, norm if kw.get("LearnMask") else None).eval()
@@ -230,7 +238,7 @@ def test_two_rank_sharded_setgnn_equals_oracle(cfg, two_ranks):
     mode, scheme, chunks, kw = cfg
     key = ("model", mode, scheme, chunks, tuple(sorted(kw)))
     d = 64
-    ei, norm, x, G = _problem(d, seed=7)
+    ei, norm, x, G = _problem(d, seed=_model_seed(kw))
     args = cases.make_args(mode, d, 64, 5, All_num_layers=2, **kw)
     # the yardstick is the oracle in float64: two layers of stacked LayerNorms put the fp32 oracle itself ~1e-3 of the gradient
     # scale away from it, which is no statement about the sharding
@@ -242,6 +250,18 @@ def test_two_rank_sharded_setgnn_equals_oracle(cfg, two_ranks):
     nrm = norm.double() if kw.get("LearnMask") else torch.ones(ei.shape[1], dtype=torch.int64)
     bn_train = kw.get("normalization") == "bn"                 # training mode without dropouts: batch statistics
     ref = oracle.setgnn_forward(sd, args, x.double(), ei, nrm, drop=(lambda t, p: t) if bn_train else None)
+    if bn_train:                                               # the example is not on a relu kink at fp32 rounding (see _model_seed)
+        def oracle_grads(xin):
+            sd2 = {k: (t.detach().clone().requires_grad_(True) if t.is_floating_point() else t.clone()) for k, t in sd.items()}
+            r2 = oracle.setgnn_forward(sd2, args, xin, ei, nrm, drop=lambda t, p: t)
+            (r2 * torch.linspace(-1.0, 1.0, N_V * r2.shape[1]).view(N_V, -1).double()).sum().backward()
+            return {k: t.grad for k, t in sd2.items() if t.is_floating_point() and t.grad is not None}
+        g0 = oracle_grads(x.double())
+        gen = torch.Generator().manual_seed(0)
+        for _ in range(3):
+            g1 = oracle_grads(x.double() + 1e-6 * torch.randn(x.shape, generator=gen, dtype=torch.float64))
+            gscale = max(float(v.abs().max()) for v in g0.values())
+            assert max(float((g0[k] - g1[k]).abs().max()) for k in g0) <= 1e-4 * gscale, "the example sits on a relu kink"
     cot = torch.linspace(-1.0, 1.0, N_V * ref.shape[1]).view(N_V, -1)
     (ref * cot.double()).sum().backward()
     got = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(2)])[:N_V]
