@@ -235,16 +235,17 @@ def cpu_baseline(args, d, degree, edge_index=None, x=None):
     }
 
 
-def hbm_traffic_from_profile(kernel="segreduce_fwd"):
-    """(HBM bytes per launch of ``kernel``, source) from the committed rocprofv3 --pmc passes (profiles/), or (None, None)."""
-    name = "hbm_traffic.json" if kernel == "segreduce_fwd" else "hbm_traffic_pma.json"
+def hbm_traffic_from_profile(kernel="segreduce_fwd", shape="c3"):
+    """(HBM bytes per launch of ``kernel``, source) from the committed rocprofv3 --pmc passes (profiles/), or (None, None).
+    ``shape``: "c3" = the headline shape (tools/pmc_probe.py), "c5" = the configs[4] per-GPU shape (tools/pmc_probe_c5.py)."""
+    name = "hbm_traffic_c5.json" if shape == "c5" else ("hbm_traffic.json" if kernel == "segreduce_fwd" else "hbm_traffic_pma.json")
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         try:
             val = json.load(open(path)).get(f"{kernel}_bytes_per_launch")
             if val is not None:
                 return val, (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (gfx950 corrections of "
-                             "MI355X_MICROARCH.md) of this kernel at exactly this shape, taken with tools/pmc_probe.py; "
+                             "MI355X_MICROARCH.md) of this kernel at exactly this shape, taken with tools/pmc_probe" + ("_c5" if shape == "c5" else "") + ".py; "
                              "not a counter of this run")
         except Exception:
             pass
@@ -478,7 +479,10 @@ def main(argv=None, hooks=None):
         at_profiled_shape = (world == 1 and args.n_per_gpu == 1_000_000 and d == 128 and args.degree == 16
                              and args.degree_dist == "fixed" and args.dtype == "f32" and not args.self_loops
                              and (not attn or args.heads == 4))
-        traffic, traffic_source = hbm_traffic_from_profile(dom) if (at_profiled_shape and dom) else (None, None)
+        at_c5_shape = (world == 1 and args.n_per_gpu == 250_000 and d == 256 and args.degree == 16 and args.degree_dist == "zipf"
+                       and args.dtype == "bf16" and not args.self_loops and attn and args.heads == 4 and args.seed == 20260928)
+        traffic, traffic_source = hbm_traffic_from_profile(dom) if (at_profiled_shape and dom) else (
+            hbm_traffic_from_profile(dom, "c5") if (at_c5_shape and dom) else (None, None))
         roofline = None
         if seg:
             achieved = seg["algo_bytes"] / (seg["avg_ms"] * 1e-3) / 1e9
