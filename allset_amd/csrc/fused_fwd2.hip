@@ -1,0 +1,370 @@
+// The fused Linear forward (math: fused_mlp.hip fused_linear_fwd_x6_kernel) for K = N = 128 with the CU's waves SPLIT BY ROLE, the
+// organisation of the one-pass backward (fused_bwd4.hip) carried over -- and with what that kernel could not afford: TWO vector
+// waves per SIMD.  768 threads: waves 0-7 do all the vector work, waves 8-11 all the matrix work; wave w runs on SIMD w % 4, so
+// every SIMD holds two vector waves and one matrix wave (168 registers each).
+//
+// Why: the symmetric kernel spends, per 16-row chunk and wave, 1390 VALU instructions next to 192 MFMAs; on a SIMD with two (or
+// three) such waves vector phases collide with vector phases and matrix phases with matrix phases, so the two kinds of time add
+// (DESIGN.md 6a''').  With the roles split a SIMD's matrix pipe belongs to one wave that does nothing else (W slice in 96
+// registers, no W in LDS), and its vector issue port alternates between two waves whose dependent chains (LayerNorm row sums,
+// hashes, three-plane splits) hide each other's latency -- which a lone vector wave per SIMD could not (fused_bwd4.hip: 7.6 cycles
+// per instruction).
+//
+// Stage = 32 rows, one workgroup barrier per stage:
+//     tick t   vector waves: S0(t+1): x(t+1) -> LayerNorm / relu / dropout -> three bf16 planes -> img[(t+1) % 2]
+//                            E(t-1) : ytile[(t-1) % 2] + bias -> relu / dropout / 1-bit mask -> y
+//              matrix waves: S1(t)  : img[t % 2] @ W^T -> ytile[t % 2]            (96 x v_mfma_f32_16x16x32_bf16 per wave)
+// Two operand images and two output tiles make every hand-off a tick boundary.  Vector wave v owns rows 4 v .. 4 v + 3 of a stage,
+// one row per DPP row of 16 lanes (row sums = four DPP adds), 8 elements per lane and stage; the rows of the next TWO stages are in
+// flight in two register sets.  Same k-order and product order as fused_linear_fwd_x6_kernel: given the same LayerNorm statistics
+// the outputs are bit-identical to that kernel's; the statistics themselves differ in the last bits (DPP row sums vs per-lane
+// partial sums + two shuffles).
+// LDS: 2 x 24 KB images + 2 x 16.5 KB tiles + gamma / beta / bias = 83 KB.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace allset {
+
+using bf16x8f = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using f32x4f = __attribute__((ext_vector_type(4))) float;
+union FragF { uint4 u; bf16x8f v; };
+constexpr int kF2Block = 768;
+constexpr int kF2Rows = 32;                    // rows per stage
+constexpr int kF2VWaves = 8;
+constexpr int kF2Sets = 4;                     // register sets of prefetched rows per vector wave
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_ff(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum_f(float v) {     // sum over the 16 lanes of a DPP row, result in every lane of it
+  v += dpp_ff<0xB1>(v);
+  v += dpp_ff<0x4E>(v);
+  v += dpp_ff<0x141>(v);
+  v += dpp_ff<0x140>(v);
+  return v;
+}
+// byte offset of (row, column byte) in a [rows][256 B] bf16 plane (fused_bwd4.hip img_off_r: conflict-free 16-byte fragment reads)
+__device__ __forceinline__ int img_off_f(int row, int colbyte) {
+  return row * 256 + ((((colbyte >> 6) ^ row) & 3) << 6) + (((((colbyte >> 4) & 3) ^ (row >> 2)) & 3) << 4) + (colbyte & 15);
+}
+__device__ __forceinline__ uint32_t hash_mix_f(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; return x; }
+#ifdef ALLSET_ABL5_NOBAR            // ablation builds only (tools/fwd_roles_ablation.py): timing without the barriers, results wrong
+#define ALLSET_F2_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define ALLSET_F2_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+#define ALLSET_FRESH_LANE_F(name) \
+  int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
+
+template <bool HAS_LN, bool DROP_IN, bool DROP_OUT>
+__global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
+    float p_out, uint64_t seed_out, float* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n,
+    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out) {
+  constexpr int KD = 128, ND = 128;
+  constexpr int R = kF2Rows;
+  constexpr int PLANE = R * 256;                 // bytes per bf16 plane of an image
+  constexpr int IMG = 3 * PLANE;
+  constexpr int SPY = 132;                       // pitch (floats) of an output tile
+  __shared__ __attribute__((aligned(16))) uint8_t sX[2 * IMG];
+  __shared__ __attribute__((aligned(16))) float sY[2 * R * SPY];
+  __shared__ __attribute__((aligned(16))) float sG[KD];
+  __shared__ __attribute__((aligned(16))) float sB[KD];
+  __shared__ __attribute__((aligned(16))) float sBias[ND];
+  seed_in = resolve_seed(seed_base, seed_in);
+  seed_out = resolve_seed(seed_base, seed_out);
+  const int tid = threadIdx.x;
+  if (tid < KD) { sG[tid] = HAS_LN ? gamma[tid] : 1.f; sB[tid] = HAS_LN ? beta[tid] : 0.f; sBias[tid] = bias ? bias[tid] : 0.f; }
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n_stages = (n + R - 1) / R;
+  // this workgroup's stages: blockIdx.x + k * gridDim.x, k = 0 .. T - 1 (T >= 1: the grid never exceeds the stage count)
+  const int64_t T = (n_stages - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  auto stage_of = [&](int64_t k) -> int64_t { return blockIdx.x + (k < T ? k : T - 1) * static_cast<int64_t>(gridDim.x); };
+  auto rows_left = [&](int64_t stage) -> int {
+    const int64_t left = n - stage * R;
+    return left >= R ? R : (left > 0 ? static_cast<int>(left) : 0);
+  };
+  __syncthreads();
+#ifdef ALLSET_ABL5_TIMING          // diagnostic builds only: cycles per segment of waves 0 (vector) and 8 (matrix) of workgroup 0
+  uint64_t tph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define ALLSET_FMARK(k) do { const uint64_t tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define ALLSET_FMARK(k) do {} while (0)
+#endif
+
+  if (wave < kF2VWaves) {
+    // =================================================== vector waves ===================================================
+    const float inv_k = 1.f / static_cast<float>(KD);
+    const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
+    const float keep_out = DROP_OUT ? 1.f / (1.f - p_out) : 1.f;
+    const uint32_t thr_in = drop_threshold(p_in), thr_out = drop_threshold(p_out);
+    const int c = lane0 & 15, rg = lane0 >> 4;
+    const int lr = 4 * wave + rg;                // this lane's row of a stage; columns 64 hb + 4 c .. + 3, hb = 0, 1
+    float4 gam[2], bet[2], bia[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
+      bet[hb] = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
+      bia[hb] = *reinterpret_cast<const float4*>(&sBias[64 * hb + 4 * c]);
+    }
+    // [set][hb]: the rows of the next kF2Sets stages.  Bytes in flight bound these kernels (~2 us of loaded latency, DESIGN.md 6a'''):
+    // a vector wave's share of a stage is 2 KB, so four sets = 64 KB per CU, 16 MB chip-wide -- at 8 registers per set
+    float4 xrS[kF2Sets][2];
+    // Loads are unconditional on a clamped row / stage (no exec-mask branch around a memory instruction: its join costs
+    // s_waitcnt vmcnt(0) and drains the prefetch); what was read for a row past n is never stored.
+    auto request_x = [&](int64_t k, float4 (&xr)[2]) {
+      const int64_t s0 = stage_of(k);
+      const int nrc = max(rows_left(s0), 1);
+      const int lrc = min(lr, nrc - 1);
+      const char* xb = reinterpret_cast<const char*>(x + s0 * R * ldx);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+        xr[hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + 256 * hb + 16 * c);
+    };
+    // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
+    auto keep4 = [&](uint64_t seed, int64_t stage, int hb, uint32_t thr, float keep) -> float4 {
+      const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * KD / 2);
+      const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_pair >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed >> 32);
+      const uint32_t lo = static_cast<uint32_t>(stage_pair) | static_cast<uint32_t>((lr * KD + 64 * hb + 4 * c) >> 1);
+      const uint32_t sl = static_cast<uint32_t>(seed);
+      const uint32_t h0 = hash_mix_f((lo ^ sl) * 0x9E3779B1U + hi_term);
+      const uint32_t h1 = hash_mix_f(((lo + 1u) ^ sl) * 0x9E3779B1U + hi_term);
+      return make_float4((h0 & 0xffffu) >= thr ? keep : 0.f, (h0 >> 16) >= thr ? keep : 0.f,
+                         (h1 & 0xffffu) >= thr ? keep : 0.f, (h1 >> 16) >= thr ? keep : 0.f);
+    };
+    // ---- S0(k): the prologue of stage k -> three bf16 planes into img[k % 2]; then the request for x(k + 2)
+    auto S0 = [&](int64_t k, float4 (&xr)[2]) {
+      const int64_t stage = stage_of(k);
+      const bool live = lr < rows_left(stage);
+      uint8_t* img = sX + (k & 1) * IMG;
+      float4 t[2] = {xr[0], xr[1]};
+      if (relu_in) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          t[hb].x = fmaxf(t[hb].x, 0.f); t[hb].y = fmaxf(t[hb].y, 0.f); t[hb].z = fmaxf(t[hb].z, 0.f); t[hb].w = fmaxf(t[hb].w, 0.f);
+        }
+      }
+      if constexpr (HAS_LN) {
+        const float s = row16_sum_f(((t[0].x + t[0].y) + (t[0].z + t[0].w)) + ((t[1].x + t[1].y) + (t[1].z + t[1].w)));
+        const float mean = s * inv_k;
+        float q2 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          t[hb].x -= mean; t[hb].y -= mean; t[hb].z -= mean; t[hb].w -= mean;
+          q2 = fmaf(t[hb].x, t[hb].x, fmaf(t[hb].y, t[hb].y, fmaf(t[hb].z, t[hb].z, fmaf(t[hb].w, t[hb].w, q2))));
+        }
+        const float rstd = rsqrtf(row16_sum_f(q2) * inv_k + eps);
+        if (live && c == 0) *reinterpret_cast<float2*>(stats + (stage * R + lr) * 2) = make_float2(mean, rstd);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          t[hb].x = fmaf(t[hb].x * rstd, gam[hb].x, bet[hb].x); t[hb].y = fmaf(t[hb].y * rstd, gam[hb].y, bet[hb].y);
+          t[hb].z = fmaf(t[hb].z * rstd, gam[hb].z, bet[hb].z); t[hb].w = fmaf(t[hb].w * rstd, gam[hb].w, bet[hb].w);
+        }
+      }
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        if constexpr (DROP_IN) {
+          const float4 kp = keep4(seed_in, stage, hb, thr_in, keep_in);
+          t[hb].x *= kp.x; t[hb].y *= kp.y; t[hb].z *= kp.z; t[hb].w *= kp.w;
+        }
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3_bf16(t[hb].x, t[hb].y, h0, m0, l0);
+        split3_bf16(t[hb].z, t[hb].w, h1, m1, l1);
+        const int wo = img_off_f(lr, 128 * hb + 8 * c);
+        *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(img + 2 * PLANE + wo) = make_uint2(l0, l1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_x(k + kF2Sets, xr);                // into the set just consumed: kF2Sets stages ahead
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- E(k): the epilogue of stage k from ytile[k % 2]
+    auto E = [&](int64_t k) {
+      const int64_t stage = stage_of(k);
+      const int nrows = rows_left(stage);
+      const bool live = lr < nrows;
+      const float* ty = sY + (k & 1) * (R * SPY);
+      char* yb = reinterpret_cast<char*>(y + stage * R * ldy) + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldy) * 4u + 16 * c;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        float4 v = *reinterpret_cast<const float4*>(&ty[lr * SPY + 64 * hb + 4 * c]);
+        v.x += bia[hb].x; v.y += bia[hb].y; v.z += bia[hb].z; v.w += bia[hb].w;
+        if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if constexpr (DROP_OUT) {
+          const float4 kp = keep4(seed_out, stage, hb, thr_out, keep_out);
+          v.x *= kp.x; v.y *= kp.y; v.z *= kp.z; v.w *= kp.w;
+        }
+#ifdef ALLSET_ABL5_NOSTORE
+        if (live && v.x == 123.456f)
+#else
+        if (live)
+#endif
+          *reinterpret_cast<float4*>(yb + 256 * hb) = v;
+        if (mask_out != nullptr) {
+          // activation mask, 1 bit per element (include/allset_hip.h "mask layout"): block (row / 16, column / 64), dword
+          // (row % 16, 32-column half h8), bit 8 q + (c % 8) for column 4 c + q.  A ballot's bit 16 rg + c is lane (c, rg): byte
+          // (2 rg + h8) of the ballot for q is byte q of the dword of row rg, half h8 -- lane L < 8 assembles dword (rg = L >> 1,
+          // h8 = L & 1); the wave's rows 4 v .. 4 v + 3 are 8 consecutive dwords of the block: one 32-byte store
+          const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+          const int sh = 8 * (lane0 & 7);
+          const uint32_t word = static_cast<uint32_t>((b0 >> sh) & 0xffu) | (static_cast<uint32_t>((b1 >> sh) & 0xffu) << 8) |
+                                (static_cast<uint32_t>((b2 >> sh) & 0xffu) << 16) | (static_cast<uint32_t>((b3 >> sh) & 0xffu) << 24);
+          if (lane0 < 8 && 16 * (wave >> 2) < nrows)         // (a 16-row block entirely past n has no words in the buffer)
+            mask_out[((stage * (R / 16) + (wave >> 2)) * (ND / 64) + hb) * 32 + (wave & 3) * 8 + lane0] = word;
+        }
+      }
+    };
+
+    static_assert(kF2Sets == 4, "the trip below is written for four register sets");
+#pragma unroll
+    for (int q = 0; q < kF2Sets; ++q) request_x(q, xrS[q]);
+    S0(0, xrS[0]);
+    ALLSET_F2_TICK();
+    S0(1, xrS[1]);                               // tick 0 (stage 1 may be a re-run of the last stage: never consumed)
+    ALLSET_F2_TICK();
+    // ticks 1 .. T - 1, four per trip (stage t + 1 lives in register set (t + 1) % 4); the last 1..3 ticks are peeled off: a
+    // conditional part inside the trip makes hipcc wait vmcnt(0) at the loop header (DESIGN.md 6a''')
+#define ALLSET_F2_FULL_TICK(tt, set) do { ALLSET_FMARK(3); S0((tt) + 1, xrS[set]); ALLSET_FMARK(0); E((tt) - 1); ALLSET_FMARK(1); ALLSET_F2_TICK(); ALLSET_FMARK(2); } while (0)
+    int64_t t = 1;
+    for (; t + 3 < T; t += 4) {
+      ALLSET_F2_FULL_TICK(t, 2);
+      ALLSET_F2_FULL_TICK(t + 1, 3);
+      ALLSET_F2_FULL_TICK(t + 2, 0);
+      ALLSET_F2_FULL_TICK(t + 3, 1);
+    }
+    if (t < T) ALLSET_F2_FULL_TICK(t, 2);
+    if (t + 1 < T) ALLSET_F2_FULL_TICK(t + 1, 3);
+    if (t + 2 < T) ALLSET_F2_FULL_TICK(t + 2, 0);
+#undef ALLSET_F2_FULL_TICK
+    E(T - 1);                                    // tick T
+  } else {
+    // =================================================== matrix waves ===================================================
+    const int m = wave - kF2VWaves;
+    // this wave's slice of W^T as MFMA B fragments: output columns 32 m + 16 ct + nn, k-step t, plane pl; lane (nn = lane & 15,
+    // kg = lane >> 4) holds W[column][k = 32 kg + 8 t + j], j = 0..7 (the k-order of fused_linear_fwd_x6_kernel)
+    FragF wq[2][4][3];
+    {
+      const int nn = lane0 & 15, kg = lane0 >> 4;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const float4* wr = reinterpret_cast<const float4*>(W + (32 * m + 16 * ct + nn) * KD + 32 * kg + 8 * tt);
+          const float4 a = wr[0], b = wr[1];
+          uint32_t ph[4], pm[4], pl[4];
+          split3_bf16(a.x, a.y, ph[0], pm[0], pl[0]);
+          split3_bf16(a.z, a.w, ph[1], pm[1], pl[1]);
+          split3_bf16(b.x, b.y, ph[2], pm[2], pl[2]);
+          split3_bf16(b.z, b.w, ph[3], pm[3], pl[3]);
+          wq[ct][tt][0].u = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          wq[ct][tt][1].u = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+          wq[ct][tt][2].u = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+    }
+    auto S1 = [&](int64_t k) {
+      ALLSET_FRESH_LANE_F(lane);
+      const int ri = lane & 15, kg = lane >> 4;
+      const uint8_t* img = sX + (k & 1) * IMG;
+      float* ty = sY + (k & 1) * (R * SPY);
+      auto load_a = [&](FragF (&f0)[3], FragF (&f1)[3], int tt) {
+        const int o0 = img_off_f(ri, 64 * kg + 16 * tt), o1 = img_off_f(16 + ri, 64 * kg + 16 * tt);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          f0[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o0);
+          f1[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o1);
+        }
+      };
+      FragF fa0[2][3], fa1[2][3];
+      f32x4f acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4f{0.f, 0.f, 0.f, 0.f};
+      load_a(fa0[0], fa1[0], 0);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        if (tt + 1 < 4) load_a(fa0[(tt + 1) & 1], fa1[(tt + 1) & 1], tt + 1);
+        const FragF (&a0)[3] = fa0[tt & 1];
+        const FragF (&a1)[3] = fa1[tt & 1];
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};     // l.h, h.l, m.m, m.h, h.m, h.h
+#ifdef ALLSET_ABL5_NOMFMA
+        acc[0][0][0] += __builtin_bit_cast(float, a0[0].u.x ^ a0[1].u.y ^ a0[2].u.z); acc[1][0][0] += __builtin_bit_cast(float, a1[0].u.x ^ a1[1].u.y ^ a1[2].u.z);
+        for (int pr = 0; pr < 0; ++pr) {
+#else
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+#endif
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[PA_[pr]].v, wq[0][tt][PB_[pr]].v, acc[0][0], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[PA_[pr]].v, wq[0][tt][PB_[pr]].v, acc[1][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[PA_[pr]].v, wq[1][tt][PB_[pr]].v, acc[0][1], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[PA_[pr]].v, wq[1][tt][PB_[pr]].v, acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // acc[rt][ct][r] = y[row 16 rt + 4 kg + r][column 32 m + 16 ct + ri]
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ty[(16 * rt + 4 * kg + r) * SPY + 32 * m + 16 * ct + ri] = acc[rt][ct][r];
+    };
+    ALLSET_F2_TICK();
+    for (int64_t k = 0; k < T; ++k) {
+      ALLSET_FMARK(3);
+      S1(k);
+      ALLSET_FMARK(0);
+      ALLSET_F2_TICK();
+      ALLSET_FMARK(2);
+    }
+  }
+#ifdef ALLSET_ABL5_TIMING
+  // vector wave 0: [0] S0, [1] E, [2] barrier wait; matrix wave 8: [4] S1, [6] wait  (cycles, all stages) -> the first floats of y
+  __syncthreads();
+  if (blockIdx.x == 0 && (tid == 0 || tid == 512)) {
+    float* dbg = y + (tid == 0 ? 0 : 4);
+    for (int k = 0; k < 4; ++k) dbg[k] = static_cast<float>(tph[k]);
+  }
+#endif
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+// 1 = the split-role forward takes this call (K = N = 128, no auxiliary columns; bf16x6 mode); ALLSET_FWD_ROLES=0 keeps the symmetric kernel
+int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux) {
+  const char* e = getenv("ALLSET_FWD_ROLES");
+  if (e && e[0] == '0') return 0;
+  return (dense_mfma_x6() && K == 128 && N == 128 && !has_aux) ? 1 : 0;
+}
+
+int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                  int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
+                                  float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
+                                  const uint64_t* seed_base, uint32_t* mask_out) {
+  const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
+  const unsigned grid = static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
+#define ALLSET_F2_K(LN, DI, DO)                                                                                               \
+  fused_linear_fwd_roles_kernel<LN, DI, DO><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
+                                                                       relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
+                                                                       mask_out)
+  const int v = (gamma != nullptr ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);
+  switch (v) {
+    case 0: ALLSET_F2_K(false, false, false); break;
+    case 1: ALLSET_F2_K(false, false, true); break;
+    case 2: ALLSET_F2_K(false, true, false); break;
+    case 3: ALLSET_F2_K(false, true, true); break;
+    case 4: ALLSET_F2_K(true, false, false); break;
+    case 5: ALLSET_F2_K(true, false, true); break;
+    case 6: ALLSET_F2_K(true, true, false); break;
+    default: ALLSET_F2_K(true, true, true); break;
+  }
+#undef ALLSET_F2_K
+  return 0;
+}

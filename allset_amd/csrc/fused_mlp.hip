@@ -952,6 +952,13 @@ extern "C" int allset_fused_linear_supported(int64_t K, int64_t N) {
   return ((K == 64 || K == 128) && (N == 64 || N == 128)) ? 1 : 0;
 }
 
+// fused_fwd2.hip: the forward with the waves split by role (eight vector waves, four matrix waves; K = N = 128)
+int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux);
+int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                  int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
+                                  float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
+                                  const uint64_t* seed_base, uint32_t* mask_out);
+
 extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                        int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
                                        int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
@@ -982,6 +989,13 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
   ALLSET_REQUIRE(ldy % 4 == 0 && aligned16(y), "fused_linear_fwd: y must be 16-byte aligned rows");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int has_ln = gamma != nullptr;
+  if (fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
+      (reinterpret_cast<uintptr_t>(stats) & 7u) == 0) {                   // K = N = 128: the split-role kernel (fused_fwd2.hip)
+    launch_fused_linear_fwd_roles(st, x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy,
+                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out));
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   const int64_t chunks = (n + 31) / 32;
   int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
   if (blocks > 512) blocks = 512;                         // persistent workgroups
