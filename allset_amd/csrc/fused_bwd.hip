@@ -555,6 +555,16 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
                                   int64_t ldacc, const float* aux_g, const float* aux_w);
 
+// fused_bwd5.hip: the role split at THREE waves per SIMD (eight vector waves that also carry the weight gradient, four matrix
+// waves for backward-data); same grid and slice layout as fused_bwd4.hip
+int fused_linear_bwd_roles3_supported(int64_t O, int64_t I);
+int launch_fused_linear_bwd_roles3(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy,
+                                   int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
+                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
+                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
+                                   int64_t ldacc);
+
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
   return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
@@ -672,6 +682,12 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
+  if (roles_kernel && fused_linear_bwd_roles3_supported(O, I)) {  // one partial per workgroup; three waves per SIMD
+    launch_fused_linear_bwd_roles3(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
+                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc);
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc,
