@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 F32, BF16 = 0, 1
@@ -76,6 +76,12 @@ SIGNATURES = {
     "allset_fused_linear_bwd_all_aux_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, _P],
+    "allset_fused_linear_blocked_supported": [c_int64, c_int64],
+    "allset_fused_linear_fwd_blocked": [_P, c_int64, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
+                                        _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P],
+    "allset_fused_linear_bwd_all_blocked": [_P, c_int64, c_int64, _P, c_float, _P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_float,
+                                            c_uint64, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64,
+                                            _P],
     "allset_gemm_x6_supported": [c_int64, c_int64],
     "allset_gemm_x6_plane_bytes": [c_int64, c_int64],
     "allset_gemm_x6_planes": [_P, c_int64, c_int, _P, c_int64, c_int64, _P],

@@ -553,7 +553,7 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                  int64_t ldacc, const float* aux_g, const float* aux_w);
+                                  int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb);
 
 // fused_bwd5.hip: the role split at THREE waves per SIMD (eight vector waves that also carry the weight gradient, four matrix
 // waves for backward-data); same grid and slice layout as fused_bwd4.hip
@@ -633,12 +633,16 @@ static void launch_bwd_all(unsigned grid, hipStream_t st, bool ln, bool drop, bo
 #undef ALLSET_BWD_ALL_K
 }
 
-extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W,
-                                           const float* x, int64_t ldx, const float* stats, const float* gamma,
-                                           const float* beta, int relu_in, float p_in, uint64_t seed_in, float* gx,
-                                           int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
-                                           int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, const float* acc_in,
-                                           int64_t ldacc, int64_t part_stride, void* stream) {
+static bool bwd_block_cols_ok(int64_t cb, int64_t K, int64_t ld) {
+  return cb >= 4 && cb <= K / 2 && (cb & (cb - 1)) == 0 && K % cb == 0 && ld == cb;
+}
+
+static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W,
+                                     const float* x, int64_t ldx, const float* stats, const float* gamma,
+                                     const float* beta, int relu_in, float p_in, uint64_t seed_in, float* gx,
+                                     int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
+                                     int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, const float* acc_in,
+                                     int64_t ldacc, int64_t part_stride, void* stream, int64_t gcb, int64_t xcb, int64_t gxcb) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_all: negative size");
   // part_stride = 0: three dense arrays [n_slices][O*I], [n_slices][O], [n_slices][2*I]; > 0: the three pointers address
@@ -655,6 +659,12 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
     return ALLSET_ERR_UNSUPPORTED;
   }
   const bool roles_kernel = fused_linear_bwd_roles_supported(O, I, acc_in != nullptr) != 0;
+  const bool blocked = gcb != 0 || xcb != 0 || gxcb != 0;
+  if (blocked && (!roles_kernel || acc_in != nullptr)) {
+    set_error("fused_linear_bwd_all_blocked: column-blocked operands are read / written by the O = I = 128 split-role kernel only "
+              "(allset_fused_linear_blocked_supported), without acc_in");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
   const bool stage_kernel = !roles_kernel && fused_linear_bwd_stage_supported(O, I, acc_in != nullptr) != 0;
   const unsigned grid = roles_kernel ? fused_linear_bwd_roles_grid(n) : (stage_kernel ? fused_linear_bwd_stage_grid(n) : bwd_all_grid(n));
   ALLSET_REQUIRE(part_w != nullptr && n_slices == static_cast<int64_t>(grid) * ((roles_kernel || stage_kernel) ? 1 : kMWaves),
@@ -673,16 +683,17 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   }
   ALLSET_REQUIRE(gy && W && x && gx, "fused_linear_bwd_all: null pointer (x is always needed: the weight gradient recomputes the "
                                      "Linear's input; a Linear whose input needs no gradient keeps the two-kernel path)");
-  ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && aligned16(gy) && aligned16(W), "fused_linear_bwd_all: gy / W must be 16-byte aligned rows");
-  ALLSET_REQUIRE(ldx >= I && ldx % 4 == 0 && aligned16(x), "fused_linear_bwd_all: x must be 16-byte aligned rows");
-  ALLSET_REQUIRE(ldgx >= I && ldgx % 4 == 0 && aligned16(gx), "fused_linear_bwd_all: gx must be 16-byte aligned rows");
+  ALLSET_REQUIRE(aligned16(gy) && aligned16(W) && aligned16(x) && aligned16(gx), "fused_linear_bwd_all: gy / W / x / gx must be 16-byte aligned");
+  ALLSET_REQUIRE(gcb ? bwd_block_cols_ok(gcb, O, ldg) : (ldg >= O && ldg % 4 == 0), "fused_linear_bwd_all: gy must be 16-byte aligned rows (or a valid block width with ldg == it)");
+  ALLSET_REQUIRE(xcb ? bwd_block_cols_ok(xcb, I, ldx) : (ldx >= I && ldx % 4 == 0), "fused_linear_bwd_all: x must be 16-byte aligned rows (or a valid block width with ldx == it)");
+  ALLSET_REQUIRE(gxcb ? bwd_block_cols_ok(gxcb, I, ldgx) : (ldgx >= I && ldgx % 4 == 0), "fused_linear_bwd_all: gx must be 16-byte aligned rows (or a valid block width with ldgx == it)");
   ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && aligned16(acc_in)),
                  "fused_linear_bwd_all: acc_in must be 16-byte aligned rows");
   ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd_all: stats must be 8-byte aligned");
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
-  if (roles_kernel && fused_linear_bwd_roles3_supported(O, I)) {  // one partial per workgroup; three waves per SIMD
+  if (roles_kernel && !blocked && fused_linear_bwd_roles3_supported(O, I)) {  // one partial per workgroup; three waves per SIMD
     launch_fused_linear_bwd_roles3(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
                                    seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc);
     ALLSET_LAUNCH_CHECK();
@@ -691,7 +702,7 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc,
-                                  nullptr, nullptr);
+                                  nullptr, nullptr, gcb, xcb, gxcb);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }
@@ -757,7 +768,30 @@ extern "C" int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, con
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24), "fused_linear_bwd_all_aux: leading dimensions must stay below 2^24 elements");
   launch_fused_linear_bwd_roles(grid, st, false, false, false, false, gy, ldg, nullptr, 0.f, W, x, ldx, nullptr, nullptr, nullptr, 0.f, 0,
                                 gx, ldgx, part + O * I + O, part, part + O * I, n, nullptr, part_stride, part_stride, part_stride,
-                                nullptr, 0, aux_g, aux_w);
+                                nullptr, 0, aux_g, aux_w, 0, 0, 0);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
+}
+
+extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W,
+                                           const float* x, int64_t ldx, const float* stats, const float* gamma,
+                                           const float* beta, int relu_in, float p_in, uint64_t seed_in, float* gx,
+                                           int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
+                                           int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, const float* acc_in,
+                                           int64_t ldacc, int64_t part_stride, void* stream) {
+  return fused_linear_bwd_all_impl(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, gx, ldgx, part_ln,
+                                   part_w, part_b, n_slices, n, O, I, seed_base, acc_in, ldacc, part_stride, stream, 0, 0, 0);
+}
+
+// The same pass with gy / x / gx COLUMN-BLOCKED ([cols / cb][n][cb], ld == cb; 0 = row-major): see allset_fused_linear_fwd_blocked.
+extern "C" int allset_fused_linear_bwd_all_blocked(const float* gy, int64_t ldg, int64_t gy_block_cols, const uint32_t* mask,
+                                                   float p_out, const float* W, const float* x, int64_t ldx, int64_t x_block_cols,
+                                                   const float* stats, const float* gamma, const float* beta, int relu_in,
+                                                   float p_in, uint64_t seed_in, float* gx, int64_t ldgx, int64_t gx_block_cols,
+                                                   float* part_ln, float* part_w, float* part_b, int64_t n_slices, int64_t n,
+                                                   int64_t O, int64_t I, const uint64_t* seed_base, int64_t part_stride,
+                                                   void* stream) {
+  return fused_linear_bwd_all_impl(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, gx, ldgx, part_ln,
+                                   part_w, part_b, n_slices, n, O, I, seed_base, nullptr, 0, part_stride, stream, gy_block_cols,
+                                   x_block_cols, gx_block_cols);
 }

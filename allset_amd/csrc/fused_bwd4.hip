@@ -74,7 +74,9 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, const float* acc_in,
-    int64_t ldacc, const float* __restrict__ aux_g, const float* __restrict__ aux_w) {
+    int64_t ldacc, const float* __restrict__ aux_g, const float* __restrict__ aux_w, int64_t gcb, int64_t xcb, int64_t gxcb) {
+  // gcb / xcb / gxcb: 0 = row-major with the operand's leading dimension; cb > 0 = COLUMN-BLOCKED [128 / cb][n][cb] (ld == cb) for gy /
+  // x / gx: the layout of the column-sharded layer's exchange buffers (fused_fwd2.hip has the forward side).
   // HAS_AUX (plain Linear only): four auxiliary output columns rode along in the forward (PMA's folded logits, fused_mlp.hip
   // aux_out = x aux_w^T + aux_b); here gx += aux_g[n,4] @ aux_w[4,I] as four FMAs per element in S2b, and the columns' own
   // weight / bias gradient (aux_g^T x [4,I], column sums of aux_g) accumulate in the vector waves' registers next to the bias
@@ -119,8 +121,13 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     const uint32_t thr_in = drop_threshold(p_in);
     const uint32_t seed_lo = static_cast<uint32_t>(seed_in);
     float4 dg[2], db[2], gbv[2];
+    int64_t cog[2], cox[2], cogx[2];             // byte offset of this lane's columns inside a row (plain) / row of blocks
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
+      const int col = 64 * hb + 4 * (lane0 & 15);
+      cog[hb] = gcb ? ((col / gcb) * n * gcb + col % gcb) * 4 : col * 4;
+      cox[hb] = xcb ? ((col / xcb) * n * xcb + col % xcb) * 4 : col * 4;
+      cogx[hb] = gxcb ? ((col / gxcb) * n * gxcb + col % gxcb) * 4 : col * 4;
       dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); gbv[hb] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // lane (c = lane & 15, rg = lane >> 4) owns rows 8 wave + rg + 4 j (j = 0, 1) of a stage, columns 64 hb + 4 c .. + 3 (hb = 0, 1):
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         const int lr = min(8 * wave + rg + 4 * j, nrc - 1);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-          ag[j][hb] = *reinterpret_cast<const float4*>(base + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldg) * 4u + 256 * hb + 16 * c);
+          ag[j][hb] = *reinterpret_cast<const float4*>(base + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldg) * 4u + cog[hb]);
           if constexpr (HAS_MASK)   // "mask layout" (include/allset_hip.h): block (row / 16, column / 64), dword (row % 16, 32-column group)
             am[j][hb] = (mask + ((s0 * (R / 16) + (lr >> 4)) * (OD / 64) + hb) * 32)[((lr & 15) >> 2) * 8 + (lr & 3) * 2 + (c >> 3)];
         }
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         const int lr = min(8 * wave + rg + 4 * j, nrc - 1);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
-          xr[j][hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldx) * 4u + 256 * hb + 16 * c);
+          xr[j][hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldx) * 4u + cox[hb]);
         if constexpr (HAS_LN) st[j] = *reinterpret_cast<const float2*>(sb + lr * 8);
         if constexpr (HAS_AUX) g4[j] = *reinterpret_cast<const float4*>(aux_g + (s0 * R + lr) * 4);
       }
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
           if (live)
 #endif
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + stage * R * ldgx) +
-                                       static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + 256 * hb + 16 * c) = o;
+                                       static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx[hb]) = o;
           if (j == 1) {         // the u planes of row 1 (from the kept xhat: see S2a)
             float4 u = xhK[j][hb];
             if constexpr (HAS_LN) {
@@ -664,12 +671,12 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                  int64_t ldacc, const float* aux_g, const float* aux_w) {
+                                  int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb) {
 #define ALLSET_ROLES_KA(LN, DI, RI, HM, HA, AX)                                                                                \
   fused_linear_bwd_roles_kernel<LN, DI, RI, HM, HA, AX><<<grid, kRBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, \
                                                                              beta, p_in, seed_in, gx, ldgx, part_ln, part_w,    \
                                                                              part_b, n, seed_base, psw, psb, psl, acc_in, ldacc, \
-                                                                             aux_g, aux_w)
+                                                                             aux_g, aux_w, gcb, xcb, gxcb)
 #define ALLSET_ROLES_K(LN, DI, RI, HM, HA) ALLSET_ROLES_KA(LN, DI, RI, HM, HA, false)
   if (aux_g != nullptr) { ALLSET_ROLES_KA(false, false, false, false, false, true); return 0; }   // (plain Linear + four aux columns)
   if (acc_in != nullptr) { ALLSET_ROLES_K(false, false, false, false, true); return 0; }     // (bwd_all_combo: plain Linear only)

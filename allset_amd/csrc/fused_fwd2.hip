@@ -63,7 +63,10 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
     float p_out, uint64_t seed_out, float* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n,
-    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out) {
+    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out, int64_t xcb, int64_t ycb) {
+  // xcb / ycb: 0 = row-major [n][128] with leading dimension ldx / ldy; cb > 0 = COLUMN-BLOCKED [128 / cb][n][cb] (ld == cb): the
+  // layout the column-sharded layer's all-to-all sends and receives (allset_amd/dist.py) -- reading / writing it here removes the
+  // pack / unpack passes around the exchange.  A lane's 16 bytes stay inside one block (cb >= 4).
   constexpr int KD = 128, ND = 128;
   constexpr int R = kF2Rows;
   constexpr int PLANE = R * 256;                 // bytes per bf16 plane of an image
@@ -105,8 +108,12 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const int c = lane0 & 15, rg = lane0 >> 4;
     const int lr = 4 * wave + rg;                // this lane's row of a stage; columns 64 hb + 4 c .. + 3, hb = 0, 1
     float4 gam[2], bet[2], bia[2];
+    int64_t cox[2], coy[2];                      // byte offset of this lane's columns inside a row (plain) / row of blocks
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
+      const int col = 64 * hb + 4 * c;
+      cox[hb] = xcb ? ((col / xcb) * n * xcb + col % xcb) * 4 : col * 4;
+      coy[hb] = ycb ? ((col / ycb) * n * ycb + col % ycb) * 4 : col * 4;
       gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
       bet[hb] = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
       bia[hb] = *reinterpret_cast<const float4*>(&sBias[64 * hb + 4 * c]);
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       const char* xb = reinterpret_cast<const char*>(x + s0 * R * ldx);
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb)
-        xr[hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + 256 * hb + 16 * c);
+        xr[hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + cox[hb]);
     };
     // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
     auto keep4 = [&](uint64_t seed, int64_t stage, int hb, uint32_t thr, float keep) -> float4 {
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       const int nrows = rows_left(stage);
       const bool live = lr < nrows;
       const float* ty = sY + (k & 1) * (R * SPY);
-      char* yb = reinterpret_cast<char*>(y + stage * R * ldy) + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldy) * 4u + 16 * c;
+      char* yb = reinterpret_cast<char*>(y + stage * R * ldy) + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldy) * 4u;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         float4 v = *reinterpret_cast<const float4*>(&ty[lr * SPY + 64 * hb + 4 * c]);
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
 #else
         if (live)
 #endif
-          *reinterpret_cast<float4*>(yb + 256 * hb) = v;
+          *reinterpret_cast<float4*>(yb + coy[hb]) = v;
         if (mask_out != nullptr) {
           // activation mask, 1 bit per element (include/allset_hip.h "mask layout"): block (row / 16, column / 64), dword
           // (row % 16, 32-column half h8), bit 8 q + (c % 8) for column 4 c + q.  A ballot's bit 16 rg + c is lane (c, rg): byte
@@ -347,13 +354,13 @@ int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux) {
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
-                                  const uint64_t* seed_base, uint32_t* mask_out) {
+                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb) {
   const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
   const unsigned grid = static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
 #define ALLSET_F2_K(LN, DI, DO)                                                                                               \
   fused_linear_fwd_roles_kernel<LN, DI, DO><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
                                                                        relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
-                                                                       mask_out)
+                                                                       mask_out, xcb, ycb)
   const int v = (gamma != nullptr ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);
   switch (v) {
     case 0: ALLSET_F2_K(false, false, false); break;

@@ -957,14 +957,19 @@ int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux);
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
-                                  const uint64_t* seed_base, uint32_t* mask_out);
+                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb);
 
-extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
-                                       int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
-                                       int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
-                                       float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
-                                       uint32_t* mask_out, const float* aux_w, const float* aux_b, float* aux_out,
-                                       void* stream) {
+// 1 = cb is a usable column-block width for a K-column operand (a power of two, 4 <= cb <= K / 2, the operand's ld == cb)
+static bool block_cols_ok(int64_t cb, int64_t K, int64_t ld) {
+  return cb >= 4 && cb <= K / 2 && (cb & (cb - 1)) == 0 && K % cb == 0 && ld == cb;
+}
+
+static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                 int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
+                                 int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
+                                 float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
+                                 uint32_t* mask_out, const float* aux_w, const float* aux_b, float* aux_out,
+                                 void* stream, int64_t xcb, int64_t ycb) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
   if (aux_out != nullptr && !dense_mfma_x6()) {
@@ -985,16 +990,24 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
   ALLSET_REQUIRE(x && W && y, "fused_linear_fwd: null pointer");
   ALLSET_REQUIRE((gamma == nullptr) == (beta == nullptr), "fused_linear_fwd: gamma and beta must come together");
   ALLSET_REQUIRE(gamma == nullptr || stats != nullptr, "fused_linear_fwd: LayerNorm prologue needs a stats buffer");
-  ALLSET_REQUIRE(ldx >= K && ldy >= N && ldx % 4 == 0 && aligned16(x), "fused_linear_fwd: x must be 16-byte aligned rows");
-  ALLSET_REQUIRE(ldy % 4 == 0 && aligned16(y), "fused_linear_fwd: y must be 16-byte aligned rows");
+  ALLSET_REQUIRE(aligned16(x) && aligned16(y), "fused_linear_fwd: x / y must be 16-byte aligned");
+  ALLSET_REQUIRE(xcb != 0 || (ldx >= K && ldx % 4 == 0), "fused_linear_fwd: x must be 16-byte aligned rows");
+  ALLSET_REQUIRE(ycb != 0 || (ldy >= N && ldy % 4 == 0), "fused_linear_fwd: y must be 16-byte aligned rows");
+  ALLSET_REQUIRE(xcb == 0 || block_cols_ok(xcb, K, ldx), "fused_linear_fwd_blocked: x_block_cols must be a power of two in [4, K/2] and ldx == x_block_cols");
+  ALLSET_REQUIRE(ycb == 0 || block_cols_ok(ycb, N, ldy), "fused_linear_fwd_blocked: y_block_cols must be a power of two in [4, N/2] and ldy == y_block_cols");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int has_ln = gamma != nullptr;
   if (fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
       (reinterpret_cast<uintptr_t>(stats) & 7u) == 0) {                   // K = N = 128: the split-role kernel (fused_fwd2.hip)
     launch_fused_linear_fwd_roles(st, x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy,
-                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out));
+                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out), xcb, ycb);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
+  }
+  if (xcb != 0 || ycb != 0) {
+    set_error("fused_linear_fwd_blocked: column-blocked operands are read / written by the K = N = 128 split-role kernel only "
+              "(allset_fused_linear_blocked_supported)");
+    return ALLSET_ERR_UNSUPPORTED;
   }
   const int64_t chunks = (n + 31) / 32;
   int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
@@ -1149,4 +1162,31 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
 #undef ALLSET_FUSED_BWD_F
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
+}
+
+extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                       int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
+                                       int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
+                                       float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
+                                       uint32_t* mask_out, const float* aux_w, const float* aux_b, float* aux_out,
+                                       void* stream) {
+  return fused_linear_fwd_impl(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,
+                               K, N, seed_base, mask_out, aux_w, aux_b, aux_out, stream, 0, 0);
+}
+
+// 1 = allset_fused_linear_fwd_blocked / allset_fused_linear_bwd_all_blocked take column-blocked operands at these widths
+extern "C" int allset_fused_linear_blocked_supported(int64_t K, int64_t N) {
+  return fused_linear_fwd_roles_supported(K, N, 0);
+}
+
+// The same forward with x and / or y COLUMN-BLOCKED: an operand with block width cb is stored [cols / cb][n][cb] (ld == cb) -- the
+// send / receive layout of the column-sharded layer's all-to-all (allset_amd/dist.py _rows_to_cols / _cols_to_rows), so that no
+// pack / unpack pass stands between the Linear and the exchange.  x_block_cols / y_block_cols = 0: that operand is row-major.
+extern "C" int allset_fused_linear_fwd_blocked(const float* x, int64_t ldx, int64_t x_block_cols, const float* gamma,
+                                               const float* beta, float eps, int relu_in, float p_in, uint64_t seed_in,
+                                               const float* W, const float* bias, int relu_out, float p_out, uint64_t seed_out,
+                                               float* y, int64_t ldy, int64_t y_block_cols, float* stats, int64_t n, int64_t K,
+                                               int64_t N, const uint64_t* seed_base, uint32_t* mask_out, void* stream) {
+  return fused_linear_fwd_impl(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,
+                               K, N, seed_base, mask_out, nullptr, nullptr, nullptr, stream, x_block_cols, y_block_cols);
 }

@@ -350,6 +350,73 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
     return y, stats
 
 
+def blocked_linear_supported(K: int, N: int) -> bool:
+    """The fused Linear can read / write COLUMN-BLOCKED operands at these widths (include/allset_hip.h, ABI 8)."""
+    return bool(_lib.load().allset_fused_linear_blocked_supported(int(K), int(N)))
+
+
+def fused_linear_fwd_blocked(x: Tensor, x_cb: int, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor],
+                             beta: Optional[Tensor], eps: float, relu_in: bool, p_in: float, seed_in: int, relu_out: bool,
+                             p_out: float, seed_out: int, seed_base: Optional[Tensor], mask_out: Optional[Tensor], y_cb: int
+                             ) -> Tuple[Tensor, Optional[Tensor]]:
+    """:func:`fused_linear_fwd` with ``x`` and / or ``y`` column-blocked: a blocked [n, C] operand with block width cb is the 2-D
+    tensor [(C / cb) * n, cb] (``x_cb`` / ``y_cb`` = 0: plain [n, C])."""
+    dev = require_device(x, weight, bias, gamma, beta)
+    _check_f32(x, weight, bias, gamma, beta)
+    N, K = weight.shape
+    x = x.contiguous() if x_cb else _rowmajor(x)
+    n = x.shape[0] // (K // x_cb) if x_cb else x.shape[0]
+    if x_cb and (x.shape[1] != x_cb or x.shape[0] != (K // x_cb) * n):
+        raise _lib.AllSetHipError(f"fused_linear_fwd_blocked: x of shape {tuple(x.shape)} is not [{K} / {x_cb} blocks x n, {x_cb}]")
+    weight = weight.contiguous()
+    y = torch.empty(((N // y_cb) * n, y_cb) if y_cb else (n, N), dtype=x.dtype, device=dev)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev) if gamma is not None else None
+    with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
+        check(_lib.load().allset_fused_linear_fwd_blocked(
+            ptr(x), x_cb if x_cb else _ld(x), x_cb, ptr(gamma.contiguous() if gamma is not None else None),
+            ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
+            ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), y_cb if y_cb else max(N, 1),
+            y_cb, ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), stream_of(dev)), "allset_fused_linear_fwd_blocked")
+    return y, stats
+
+
+def fused_linear_bwd_all_blocked(gy: Tensor, gy_cb: int, mask: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, x_cb: int,
+                                 stats: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float,
+                                 seed_in: int, seed_base: Optional[Tensor], want_bias: bool = True
+                                 ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor, Optional[Tensor]]:
+    """:func:`fused_linear_bwd_all` with ``gy`` blocked by ``gy_cb`` and ``x`` (hence ``gx``) by ``x_cb`` (0 = plain)."""
+    dev = require_device(gy, mask, weight, x, stats, gamma, beta)
+    _check_f32(gy, weight, x, stats, gamma, beta)
+    O, I = weight.shape
+    gy = gy.contiguous() if gy_cb else _rowmajor(gy)
+    x = x.contiguous() if x_cb else _rowmajor(x)
+    n = x.shape[0] // (I // x_cb) if x_cb else x.shape[0]
+    weight = weight.contiguous()
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_fused_linear_bwd_all_slices_for(n, O, I, 0, byref(ns)), "allset_fused_linear_bwd_all_slices_for")
+    P = ns.value
+    gx = torch.empty_like(x)
+    M = O * I + O + (2 * I if stats is not None else 0)
+    M = (M + 3) // 4 * 4
+    part = torch.empty((P, M), dtype=torch.float32, device=dev)
+    flat = part.view(-1)
+    part_w, part_b = flat, flat[O * I:]
+    part_ln = flat[O * I + O:] if stats is not None else None
+    with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
+        check(lib.allset_fused_linear_bwd_all_blocked(
+            ptr(gy), gy_cb if gy_cb else _ld(gy), gy_cb, ptr(mask), p_out, ptr(weight), ptr(x), x_cb if x_cb else _ld(x), x_cb, ptr(stats),
+            ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
+            int(relu_in), p_in, seed_in, ptr(gx), x_cb if x_cb else max(I, 1), x_cb, ptr(part_ln), ptr(part_w),
+            ptr(part_b if want_bias else None), P, n, O, I, ptr(seed_base), M, stream_of(dev)), "allset_fused_linear_bwd_all_blocked")
+    red = reduce_partials(part)
+    gw = red[:O * I].view(O, I)
+    gb = red[O * I:O * I + O] if want_bias else None
+    if stats is None:
+        return gx, None, None, gw, gb
+    return gx, red[O * I + O:O * I + O + I], red[O * I + O + I:O * I + O + 2 * I], gw, gb
+
+
 def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats: Optional[Tensor],
                 gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
                 want_bias: bool = True, seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None
@@ -638,11 +705,13 @@ class _Linear(torch.autograd.Function):
 
 class _FusedNormLinear(torch.autograd.Function):
     """``y = epi( pro(x) @ W^T + b )`` with ``pro = [relu] -> [LayerNorm] -> [dropout p_in]`` and
-    ``epi = [relu] -> [dropout p_out]`` -- one kernel forward (fused_mlp.hip), two kernels backward
-    (wgrad_fused, fused_linear_bwd); nothing but x, the row statistics and (for the epilogue mask) y is kept."""
+    ``epi = [relu] -> [dropout p_out]`` -- one kernel forward (fused_mlp.hip / fused_fwd2.hip), one kernel backward
+    (the one-pass ``fused_linear_bwd_all``; the two-kernel pair where that is not built); nothing but x, the row statistics and
+    the 1-bit epilogue mask is kept.  ``in_cb`` / ``out_cb`` > 0: x / y (and their gradients) are COLUMN-BLOCKED 2-D tensors
+    [(C / cb) * n, cb] -- the exchange layout of the column-sharded layer (dist.py)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out):
+    def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out, in_cb=0, out_cb=0):
         seed_in = _draw_seed() if p_in > 0.0 else 0
         seed_out = _draw_seed() if p_out > 0.0 else 0
         base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
@@ -651,10 +720,18 @@ class _FusedNormLinear(torch.autograd.Function):
         # (no mask in inference: nothing will run backward)
         words = activation_mask_words(x.shape[0], weight.shape[0]) if (keep_y and any(ctx.needs_input_grad)) else 0
         mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
-        y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out,
-                                    base, mask)
+        if in_cb or out_cb:
+            n_rows = x.shape[0] // (weight.shape[1] // in_cb) if in_cb else x.shape[0]
+            words = activation_mask_words(n_rows, weight.shape[0]) if (keep_y and any(ctx.needs_input_grad)) else 0
+            mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
+            y, stats = fused_linear_fwd_blocked(x, in_cb, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out,
+                                                seed_out, base, mask, out_cb)
+        else:
+            y, stats = fused_linear_fwd(x, weight, bias, gamma, beta, eps, relu_in, p_in, seed_in, relu_out, p_out, seed_out,
+                                        base, mask)
         ctx.save_for_backward(x, stats, gamma, beta, weight, y if (keep_y and mask is None) else None, mask)
         ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
+        ctx.layout = (int(in_cb), int(out_cb))
         return y
 
     @staticmethod
@@ -665,6 +742,11 @@ class _FusedNormLinear(torch.autograd.Function):
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
+        in_cb, out_cb = ctx.layout
+        if in_cb or out_cb:                       # blocked operands: the one-pass kernel reads / writes them in place
+            gx, dg, db, gw, gb = fused_linear_bwd_all_blocked(gy, out_cb, mask, p_out, weight, x, in_cb, stats, gamma, beta, relu_in,
+                                                              p_in, seed_in, base, want_bias=need_b)
+            return gx, dg, db, gw, gb, None, None, None, None, None, None, None
         # one-pass kernel where a LayerNorm prologue makes both halves of the pair recompute the same operand (0.49-0.55 ms
         # against 0.62-0.63); without one the plain weight-gradient kernel is cheap and the pair wins (0.48 vs 0.58 ms)
         if (ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and y is None and x.shape[0] > 0 and
@@ -674,14 +756,14 @@ class _FusedNormLinear(torch.autograd.Function):
             # everything from one read of gy and x
             gx, dg, db, gw, gb = fused_linear_bwd_all(gy, mask, p_out, weight, x, stats, gamma, beta, relu_in, p_in, seed_in,
                                                       base, want_bias=need_b)
-            return gx, dg, db, gw, gb, None, None, None, None, None
+            return gx, dg, db, gw, gb, None, None, None, None, None, None, None
         if ctx.needs_input_grad[3] or need_b:
             gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b,
                                  seed_base=base, mask=mask)
         if ctx.needs_input_grad[0] or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
             gx, dg, db = fused_linear_bwd(gy, y, p_out, weight, x, stats, gamma, relu_in, p_in, seed_in, base, mask,
                                           want_gx=ctx.needs_input_grad[0])
-        return gx, dg, db, gw, gb, None, None, None, None, None
+        return gx, dg, db, gw, gb, None, None, None, None, None, None, None
 
 
 class _WideNormLinear(torch.autograd.Function):
@@ -753,12 +835,17 @@ def wide_linear_supported(K: int, N: int, has_ln: bool, relu_in: bool = False, p
 
 def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
                       eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0, relu_out: bool = False,
-                      p_out: float = 0.0) -> Tensor:
+                      p_out: float = 0.0, in_cb: int = 0, out_cb: int = 0) -> Tensor:
     if p_out > 0.0 and not relu_out:
         # the backward recovers the epilogue mask from the sign of y, which is only right behind a relu (MLP._post is
         # always relu -> dropout, reference layers.py:575-577)
         raise _lib.AllSetHipError("fused_norm_linear: an output dropout needs relu_out=True")
     N, K = weight.shape
+    if in_cb or out_cb:
+        if not blocked_linear_supported(K, N):
+            raise _lib.AllSetHipError(f"fused_norm_linear: column-blocked operands are not built for a [{N}, {K}] weight")
+        return _FusedNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out),
+                                      float(p_out), int(in_cb), int(out_cb))
     fn = _FusedNormLinear if fused_linear_supported(K, N) else _WideNormLinear
     return fn.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out), float(p_out))
 

@@ -577,6 +577,51 @@ def _cols_to_rows(x: Tensor, group=None) -> Tensor:
     return _unpack(recv.view(w, n // w, dc).to(x.dtype))
 
 
+def _exchange_blocks(x: Tensor, group=None) -> Tensor:
+    """The all-to-all of :func:`_rows_to_cols` / :func:`_cols_to_rows` on a tensor that is ALREADY in the exchange layout: ``x``
+    [P * r, c] is P blocks of r rows, block j goes to rank j, block i of the result came from rank i.  Row block -> column slice:
+    ``x`` is column-blocked (block j = columns [j c, (j+1) c) of my r rows, what a fused Linear writes with ``out_cb = c``) and
+    the result is the row-major [n, c] table of my column slice.  Column slice -> row block: ``x`` is that table and the result is
+    my rows column-blocked (what a fused Linear reads with ``in_cb = c``).  No pack / unpack pass on either side."""
+    if _skip_collective(group):
+        return x
+    send = _narrow(x.contiguous())
+    recv = torch.empty_like(send)
+    _all_to_all_single(recv, send, group)
+    return recv.to(x.dtype)
+
+
+class _ExchangeBlocks(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return _exchange_blocks(x, group)
+
+    @staticmethod
+    def backward(ctx, g):                          # the exchange is its own transpose: block (i <- j) back along (j <- i)
+        return _exchange_blocks(g, ctx.group), None
+
+
+def exchange_blocks(x: Tensor, group=None) -> Tensor:
+    return _ExchangeBlocks.apply(x, group)
+
+
+def _blocked_exchange_width(x_owned: Tensor, w: int, *mlps) -> int:
+    """Column-block width d / P if every MLP around the two exchanges of the column-sharded layer can read / write the exchange
+    layout directly (fused Linear kernels of csrc/fused_fwd2.hip / fused_bwd4.hip: fp32, width 128); 0 = pack / unpack path.
+    ``ALLSET_BLOCKED_EXCHANGE=0`` forces the pack / unpack path."""
+    if os.environ.get("ALLSET_BLOCKED_EXCHANGE", "1") == "0" or w <= 1:
+        return 0
+    from .layers import MLP
+    if not all(isinstance(m, MLP) for m in mlps):
+        return 0
+    d = mlps[0].lins[-1].out_features
+    if d % w or any(m.lins[0].in_features != d or m.lins[-1].out_features != d for m in mlps[1:]):
+        return 0
+    cb = d // w
+    return cb if all(m.blockable(x_owned, cb) for m in mlps) else 0
+
+
 class _RowsToCols(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
@@ -678,6 +723,14 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
     enc1 = lambda t: v2e_conv._mlp_act(v2e_conv.f_enc, t, v2e_conv.dropout)
     mid = lambda t: e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, t, dropout), e2v_conv.dropout)
     dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, p_out)
+    cb = _blocked_exchange_width(x_owned, w, v2e_conv.f_enc, v2e_conv.f_dec, e2v_conv.f_enc, e2v_conv.f_dec) if K == 1 else 0
+    if cb:
+        # repack-free: the MLPs on either side of each all-to-all write / read its buffer layout themselves
+        h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout, out_cb=cb)                   # [P * n_V/P, d/P] blocked
+        e = exchange_blocks(aggregate(exchange_blocks(h, group), hg.v2e, norm, aggr), group)          # [P * n_E/P, d/P] blocked
+        g = e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout, in_cb=cb), e2v_conv.dropout, out_cb=cb)
+        v = exchange_blocks(aggregate(exchange_blocks(g, group), hg.e2v, norm, aggr), group)
+        return e2v_conv._mlp_act(e2v_conv.f_dec, v, p_out, in_cb=cb)
     if K == 1:
         vv, ve = _valid_rows(hg.v_lo, hg.v_hi, hg.n_v), _valid_rows(hg.e_lo, hg.e_hi, hg.n_e)     # real rows of the two owned blocks
         with _bn_scope(vv, group):

@@ -145,11 +145,35 @@ class MLP(nn.Module):
         """Every Linear fits the LDS-resident-weight kernels (widths <= 128): the joint PMA nodes build on those."""
         return all(dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins)
 
-    def forward(self, x, _post: Optional[float] = None):
+    def blockable(self, x: Tensor, cb: int) -> bool:
+        """The first / last Linear can read / write a COLUMN-BLOCKED tensor of block width ``cb`` (dist.py's exchange layout)."""
+        if cb < 4 or (cb & (cb - 1)) or not (_on_hip(x) and x.dtype == torch.float32):
+            return False
+        first, last = self.lins[0], self.lins[-1]
+        return (all(isinstance(nm, (nn.LayerNorm, nn.Identity)) for nm in self.normalizations) and
+                all(lin.bias is not None for lin in self.lins) and
+                all(dense.blocked_linear_supported(lin.in_features, lin.out_features) for lin in (first, last)) and
+                all(dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins) and
+                cb <= first.in_features // 2 and cb <= last.out_features // 2)
+
+    def forward(self, x, _post: Optional[float] = None, _in_cb: int = 0, _out_cb: int = 0):
         """``_post`` (internal): also apply ``dropout_p(relu(.))`` to the output -- the activation its callers
-        (``HalfNLHconv``) put right after the MLP -- inside the last Linear's epilogue."""
+        (``HalfNLHconv``) put right after the MLP -- inside the last Linear's epilogue.  ``_in_cb`` / ``_out_cb`` (internal, only
+        after ``blockable``): the input / output is column-blocked [(C / cb) * n, cb]."""
         p = float(self.dropout) if self.training else 0.0
         post_p = (float(_post) if self.training else 0.0) if _post is not None else None
+        if _in_cb or _out_cb:
+            last = len(self.lins) - 1
+            for i, lin in enumerate(self.lins):
+                nm = self.normalizations[i]
+                ln = nm if isinstance(nm, nn.LayerNorm) else None
+                is_last = i == last
+                x = dense.fused_norm_linear(
+                    x, ln.weight if ln is not None else None, ln.bias if ln is not None else None, lin.weight, lin.bias,
+                    ln.eps if ln is not None else 1e-5, relu_in=i > 0, p_in=p if i > 0 else 0.0,
+                    relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0,
+                    in_cb=_in_cb if i == 0 else 0, out_cb=_out_cb if is_last else 0)
+            return x
         if self._fusable(x):
             last = len(self.lins) - 1
             for i, lin in enumerate(self.lins):
@@ -371,8 +395,9 @@ class HalfNLHconv(nn.Module):
         # relu(f_dec(.)); SetGNN's outer relu is idempotent on it, so its dropout can ride in the same pass
         return self._mlp_act(self.f_dec, x, _post_dropout if post else 0.0)
 
-    def _mlp_act(self, mlp, x, p):
-        """``dropout_p(relu(mlp(x)))``; the activation rides in the MLP's last fused kernel when there is one."""
+    def _mlp_act(self, mlp, x, p, in_cb: int = 0, out_cb: int = 0):
+        """``dropout_p(relu(mlp(x)))``; the activation rides in the MLP's last fused kernel when there is one.
+        ``in_cb`` / ``out_cb``: column-blocked input / output (only after ``mlp.blockable``; dist.py)."""
         if isinstance(mlp, MLP):
-            return mlp(x, _post=p)
+            return mlp(x, _post=p, _in_cb=in_cb, _out_cb=out_cb)
         return relu_dropout(mlp(x), p, self.training)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 7   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported) */
+#define ALLSET_ABI_VERSION 8   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -515,6 +515,25 @@ int allset_fused_linear_bwd_all_aux_supported(int64_t O, int64_t I);
 int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, const float* W, const float* x, int64_t ldx, const float* aux_g,
                                     const float* aux_w, float* gx, int64_t ldgx, float* part, int64_t part_stride, int64_t n_slices,
                                     int64_t n, int64_t O, int64_t I, void* stream);
+
+/* Column-blocked operands (ABI 8).  An [n, C] operand with block width cb is stored [C / cb][n][cb] (its ld argument == cb):
+ * exactly the send / receive buffer of an equal-split all-to-all that turns a row block of all C columns into all rows of a
+ * C / P column slice (allset_amd/dist.py _rows_to_cols and back).  The fused Linear reading / writing that layout removes the
+ * pack / unpack pass on either side of the exchange (no reference counterpart: the reference is single-device; the layer these
+ * serve is reference layers.py:623-656 sharded by feature columns).  *_block_cols = 0: that operand is plain row-major.
+ * cb must be a power of two with 4 <= cb <= C / 2.  Built where allset_fused_linear_blocked_supported(K, N) returns 1 (K = N = 128,
+ * default kernel family); no auxiliary columns, no acc_in.  Everything else as in the un-blocked entry points. */
+int allset_fused_linear_blocked_supported(int64_t K, int64_t N);
+int allset_fused_linear_fwd_blocked(const float* x, int64_t ldx, int64_t x_block_cols, const float* gamma, const float* beta, float eps,
+                                    int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
+                                    float p_out, uint64_t seed_out, float* y, int64_t ldy, int64_t y_block_cols, float* stats,
+                                    int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, uint32_t* mask_out, void* stream);
+int allset_fused_linear_bwd_all_blocked(const float* gy, int64_t ldg, int64_t gy_block_cols, const uint32_t* mask, float p_out,
+                                        const float* W, const float* x, int64_t ldx, int64_t x_block_cols, const float* stats,
+                                        const float* gamma, const float* beta, int relu_in, float p_in, uint64_t seed_in, float* gx,
+                                        int64_t ldgx, int64_t gx_block_cols, float* part_ln, float* part_w, float* part_b,
+                                        int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
+                                        int64_t part_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1032,3 +1032,42 @@ def test_one_pass_backward_three_waves_per_simd_variant(has_ln, relu_in, p_in, w
             assert torch.equal(a, r)                                # same fragment layouts, same accumulation order
         else:                                                       # column sums: eight vector waves instead of four fold in another order
             torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-5 * float(r.abs().max()) + 1e-30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cb", [16, 32, 64, 4])
+@pytest.mark.parametrize("has_ln,relu_in,p_in,post", [(True, False, 0.0, None), (True, True, 0.3, 0.4), (False, True, 0.0, 0.0), (False, False, 0.0, None)])
+@pytest.mark.parametrize("n", [1, 37, 4099])
+def test_fused_linear_with_column_blocked_operands(cb, has_ln, relu_in, p_in, post, n, device):
+    """ABI 8: the fused Linear reading / writing the column-sharded layer's exchange layout [C / cb][n][cb] (dist.py
+    _exchange_blocks) equals the same Linear on row-major operands with the pack / unpack done by torch -- outputs, input gradient
+    and every parameter gradient, bit for bit (same kernel, same seeds; only addresses differ)."""
+    from allset_amd import dense
+    if not dense.blocked_linear_supported(128, 128):
+        pytest.skip("default kernel family not selected")
+    C, nb = 128, 128 // cb
+    g = torch.Generator(device="cpu").manual_seed(n + cb)
+    x = torch.randn(n, C, generator=g).to(device)
+    W = (torch.randn(C, C, generator=g) / 11).to(device)
+    b = torch.randn(C, generator=g).to(device)
+    gam = (torch.rand(C, generator=g) + 0.5).to(device) if has_ln else None
+    bet = torch.randn(C, generator=g).to(device) if has_ln else None
+    cot = torch.randn(n, C, generator=g).to(device)
+    pack = lambda t: t.view(n, nb, cb).permute(1, 0, 2).reshape(nb * n, cb).contiguous()         # [n, C] -> blocked 2-D
+    unpack = lambda t: t.view(nb, n, cb).permute(1, 0, 2).reshape(n, C)
+    relu_out, p_out = post is not None, (post or 0.0)
+
+    def run(in_cb, out_cb):
+        leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x, gam, bet, W, b)]
+        xi = pack(leaves[0]) if in_cb else leaves[0]
+        torch.manual_seed(1234)                      # same dropout seeds in every run (dense._draw_seed)
+        y = dense.fused_norm_linear(xi, leaves[1], leaves[2], leaves[3], leaves[4], 1e-5, relu_in, p_in, relu_out, p_out, in_cb=in_cb, out_cb=out_cb)
+        yp = unpack(y) if out_cb else y
+        (yp * cot).sum().backward()
+        return [yp.detach()] + [t.grad for t in leaves if t is not None]
+
+    ref = run(0, 0)
+    for in_cb, out_cb in ((cb, 0), (0, cb), (cb, cb)):
+        got = run(in_cb, out_cb)
+        for a, r in zip(got, ref):
+            assert torch.equal(a, r), (in_cb, out_cb, float((a - r).abs().max()))

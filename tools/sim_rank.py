@@ -25,6 +25,7 @@ LINK = 60e9
 for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split(",")):
     adist._rows_to_cols = (lambda x, group=None, w=world: x if w == 1 else adist._pack(x, w).view(w * x.shape[0], x.shape[1] // w))
     adist._cols_to_rows = (lambda x, group=None, w=world: x if w == 1 else adist._unpack(x.view(w, x.shape[0] // w, x.shape[1])))
+    adist._exchange_blocks = (lambda x, group=None: x)                # repack-free exchange: the buffer IS the layout on both sides
     adist._all_gather_rows = (lambda x, group=None, w=world: x if w == 1 else x.repeat(w, *([1] * (x.dim() - 1))))
     adist._reduce_scatter_rows = (lambda x, group=None, w=world: x if w == 1 else x[:x.shape[0] // w].contiguous())
     adist._world = lambda group=None, w=world: w
