@@ -121,13 +121,15 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     const uint32_t thr_in = drop_threshold(p_in);
     const uint32_t seed_lo = static_cast<uint32_t>(seed_in);
     float4 dg[2], db[2], gbv[2];
-    int64_t cog[2], cox[2], cogx[2];             // byte offset of this lane's columns inside a row (plain) / row of blocks
+    // A lane's columns 64 hb + 4 c: byte offset of columns 4 c (one 32-bit VGPR per operand) + hb x a wave-uniform step --
+    // 256 bytes in a row-major row, 64 columns' worth of blocks (256 n bytes) in the blocked layout (cb <= 64 divides 64)
+    const int c40 = 4 * (lane0 & 15);
+    const uint32_t cog0 = gcb ? static_cast<uint32_t>(((c40 / gcb) * n * gcb + c40 % gcb) * 4) : 4u * c40;
+    const uint32_t cox0 = xcb ? static_cast<uint32_t>(((c40 / xcb) * n * xcb + c40 % xcb) * 4) : 4u * c40;
+    const uint32_t cogx0 = gxcb ? static_cast<uint32_t>(((c40 / gxcb) * n * gxcb + c40 % gxcb) * 4) : 4u * c40;
+    const int64_t dhg = gcb ? 256 * n : 256, dhx = xcb ? 256 * n : 256, dhgx = gxcb ? 256 * n : 256;
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      const int col = 64 * hb + 4 * (lane0 & 15);
-      cog[hb] = gcb ? ((col / gcb) * n * gcb + col % gcb) * 4 : col * 4;
-      cox[hb] = xcb ? ((col / xcb) * n * xcb + col % xcb) * 4 : col * 4;
-      cogx[hb] = gxcb ? ((col / gxcb) * n * gxcb + col % gxcb) * 4 : col * 4;
       dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); gbv[hb] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // lane (c = lane & 15, rg = lane >> 4) owns rows 8 wave + rg + 4 j (j = 0, 1) of a stage, columns 64 hb + 4 c .. + 3 (hb = 0, 1):
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         const int lr = min(8 * wave + rg + 4 * j, nrc - 1);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-          ag[j][hb] = *reinterpret_cast<const float4*>(base + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldg) * 4u + cog[hb]);
+          ag[j][hb] = *reinterpret_cast<const float4*>(base + hb * dhg + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldg) * 4u + cog0));
           if constexpr (HAS_MASK)   // "mask layout" (include/allset_hip.h): block (row / 16, column / 64), dword (row % 16, 32-column group)
             am[j][hb] = (mask + ((s0 * (R / 16) + (lr >> 4)) * (OD / 64) + hb) * 32)[((lr & 15) >> 2) * 8 + (lr & 3) * 2 + (c >> 3)];
         }
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
         const int lr = min(8 * wave + rg + 4 * j, nrc - 1);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
-          xr[j][hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldx) * 4u + cox[hb]);
+          xr[j][hb] = *reinterpret_cast<const float4*>(xb + hb * dhx + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldx) * 4u + cox0));
         if constexpr (HAS_LN) st[j] = *reinterpret_cast<const float2*>(sb + lr * 8);
         if constexpr (HAS_AUX) g4[j] = *reinterpret_cast<const float4*>(aux_g + (s0 * R + lr) * 4);
       }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
           if (live)
 #endif
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + stage * R * ldgx) +
-                                       static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx[hb]) = o;
+                                       hb * dhgx + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx0)) = o;
           if (j == 1) {         // the u planes of row 1 (from the kept xhat: see S2a)
             float4 u = xhK[j][hb];
             if constexpr (HAS_LN) {

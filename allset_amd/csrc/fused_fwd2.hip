@@ -108,12 +108,13 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const int c = lane0 & 15, rg = lane0 >> 4;
     const int lr = 4 * wave + rg;                // this lane's row of a stage; columns 64 hb + 4 c .. + 3, hb = 0, 1
     float4 gam[2], bet[2], bia[2];
-    int64_t cox[2], coy[2];                      // byte offset of this lane's columns inside a row (plain) / row of blocks
+    // A lane's columns 64 hb + 4 c: byte offset of columns 4 c (one 32-bit VGPR per operand) + hb x a wave-uniform step --
+    // 256 bytes in a row-major row, 64 columns' worth of blocks (256 n bytes) in the blocked layout (cb <= 64 divides 64)
+    const uint32_t cox0 = xcb ? static_cast<uint32_t>((((4 * c) / xcb) * n * xcb + (4 * c) % xcb) * 4) : 16u * c;
+    const uint32_t coy0 = ycb ? static_cast<uint32_t>((((4 * c) / ycb) * n * ycb + (4 * c) % ycb) * 4) : 16u * c;
+    const int64_t dhx = xcb ? 256 * n : 256, dhy = ycb ? 256 * n : 256;
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      const int col = 64 * hb + 4 * c;
-      cox[hb] = xcb ? ((col / xcb) * n * xcb + col % xcb) * 4 : col * 4;
-      coy[hb] = ycb ? ((col / ycb) * n * ycb + col % ycb) * 4 : col * 4;
       gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
       bet[hb] = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
       bia[hb] = *reinterpret_cast<const float4*>(&sBias[64 * hb + 4 * c]);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       const char* xb = reinterpret_cast<const char*>(x + s0 * R * ldx);
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb)
-        xr[hb] = *reinterpret_cast<const float4*>(xb + static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + cox[hb]);
+        xr[hb] = *reinterpret_cast<const float4*>(xb + hb * dhx + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + cox0));
     };
     // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
     auto keep4 = [&](uint64_t seed, int64_t stage, int hb, uint32_t thr, float keep) -> float4 {
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       const int nrows = rows_left(stage);
       const bool live = lr < nrows;
       const float* ty = sY + (k & 1) * (R * SPY);
-      char* yb = reinterpret_cast<char*>(y + stage * R * ldy) + static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldy) * 4u;
+      char* yb = reinterpret_cast<char*>(y + stage * R * ldy);
+      const uint32_t yo = static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldy) * 4u + coy0;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         float4 v = *reinterpret_cast<const float4*>(&ty[lr * SPY + 64 * hb + 4 * c]);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
 #else
         if (live)
 #endif
-          *reinterpret_cast<float4*>(yb + coy[hb]) = v;
+          *reinterpret_cast<float4*>(yb + hb * dhy + yo) = v;
         if (mask_out != nullptr) {
           // activation mask, 1 bit per element (include/allset_hip.h "mask layout"): block (row / 16, column / 64), dword
           // (row % 16, 32-column half h8), bit 8 q + (c % 8) for column 4 c + q.  A ballot's bit 16 rg + c is lane (c, rg): byte
