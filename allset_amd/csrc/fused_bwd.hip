@@ -687,6 +687,7 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
   ALLSET_REQUIRE(gcb ? bwd_block_cols_ok(gcb, O, ldg) : (ldg >= O && ldg % 4 == 0), "fused_linear_bwd_all: gy must be 16-byte aligned rows (or a valid block width with ldg == it)");
   ALLSET_REQUIRE(xcb ? bwd_block_cols_ok(xcb, I, ldx) : (ldx >= I && ldx % 4 == 0), "fused_linear_bwd_all: x must be 16-byte aligned rows (or a valid block width with ldx == it)");
   ALLSET_REQUIRE(gxcb ? bwd_block_cols_ok(gxcb, I, ldgx) : (ldgx >= I && ldgx % 4 == 0), "fused_linear_bwd_all: gx must be 16-byte aligned rows (or a valid block width with ldgx == it)");
+  ALLSET_REQUIRE(!blocked || n * 128 * 4 < (int64_t{1} << 32), "fused_linear_bwd_all_blocked: a blocked operand must stay below 4 GiB (32-bit lane offsets)");
   ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && aligned16(acc_in)),
                  "fused_linear_bwd_all: acc_in must be 16-byte aligned rows");
   ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd_all: stats must be 8-byte aligned");

@@ -995,6 +995,7 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
   ALLSET_REQUIRE(ycb != 0 || (ldy >= N && ldy % 4 == 0), "fused_linear_fwd: y must be 16-byte aligned rows");
   ALLSET_REQUIRE(xcb == 0 || block_cols_ok(xcb, K, ldx), "fused_linear_fwd_blocked: x_block_cols must be a power of two in [4, K/2] and ldx == x_block_cols");
   ALLSET_REQUIRE(ycb == 0 || block_cols_ok(ycb, N, ldy), "fused_linear_fwd_blocked: y_block_cols must be a power of two in [4, N/2] and ldy == y_block_cols");
+  ALLSET_REQUIRE((xcb == 0 && ycb == 0) || n * 128 * 4 < (int64_t{1} << 32), "fused_linear_fwd_blocked: a blocked operand must stay below 4 GiB (32-bit lane offsets)");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int has_ln = gamma != nullptr;
   if (fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
