@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 os.environ["ALLSET_BWD_ROLES"] = "0"
-src = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bwd.hip", "fused_bwd2.hip", "fused_bwd3.hip", "fused_bwd4.hip", "abi.hip")]
+src = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bwd.hip", "fused_bwd2.hip", "fused_bwd3.hip", "fused_bwd4.hip", "fused_bwd5.hip", "abi.hip")]
 dev = torch.device("cuda:0")
 n, d = 1_000_000, 128
 x = torch.randn(n, d, device=dev); W = torch.randn(d, d, device=dev) / d ** 0.5
