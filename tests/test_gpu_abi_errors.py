@@ -86,3 +86,38 @@ def test_dense_entries_reject_bad_arguments(device):
     with pytest.raises(_lib.AllSetHipError):
         dense.gemm_x6_planes(torch.randn(256, 100, device=device), False)
     torch.cuda.synchronize()
+
+
+def test_blocked_and_aux_entries_reject_bad_arguments(device):
+    """ABI 7 / 8 entry points: a block width that is not a power of two in [4, C / 2], a leading dimension that is not the block
+    width, widths the split-role kernels are not built for, a partial buffer too small for the aux sections."""
+    from allset_amd import _lib
+    lib = _lib.load()
+    if not lib.allset_fused_linear_blocked_supported(128, 128):
+        pytest.skip("default kernel family not selected")
+    st = torch.cuda.current_stream().cuda_stream
+    n, d = 64, 128
+    x = torch.randn(n, d, device=device); y = torch.empty(n, d, device=device); W = torch.randn(d, d, device=device)
+    P = lambda t: t.data_ptr()
+    f = lib.allset_fused_linear_fwd_blocked
+    ok = f(P(x), 16, 16, None, None, 1e-5, 0, 0.0, 0, P(W), None, 0, 0.0, 0, P(y), 32, 32, None, n, d, d, None, None, st)
+    assert ok == 0
+    _err(lib, f(P(x), 16, 24, None, None, 1e-5, 0, 0.0, 0, P(W), None, 0, 0.0, 0, P(y), d, 0, None, n, d, d, None, None, st))     # 24: not a power of two
+    _err(lib, f(P(x), d, 16, None, None, 1e-5, 0, 0.0, 0, P(W), None, 0, 0.0, 0, P(y), d, 0, None, n, d, d, None, None, st))      # ldx != block width
+    _err(lib, f(P(x), 128, 128, None, None, 1e-5, 0, 0.0, 0, P(W), None, 0, 0.0, 0, P(y), d, 0, None, n, d, d, None, None, st))   # block = whole row
+    assert lib.allset_fused_linear_blocked_supported(64, 64) == 0
+    W64 = torch.randn(64, 64, device=device)
+    _err(lib, f(P(x), 16, 16, None, None, 1e-5, 0, 0.0, 0, P(W64), None, 0, 0.0, 0, P(y), 64, 0, None, n, 64, 64, None, None, st))
+    # the aux one-pass backward: partial stride below O*I + O + 4*I + 4, wrong slice count
+    ns = ctypes.c_int64(0)
+    assert lib.allset_fused_linear_bwd_all_slices_for(n, d, d, 0, ctypes.byref(ns)) == 0
+    M = d * d + d + 4 * d + 4
+    part = torch.empty(ns.value * M, device=device); g4 = torch.randn(n, 4, device=device); w4 = torch.randn(4, d, device=device)
+    gx = torch.empty(n, d, device=device)
+    h = lib.allset_fused_linear_bwd_all_aux
+    assert h(P(y), d, P(W), P(x), d, P(g4), P(w4), P(gx), d, P(part), M, ns.value, n, d, d, st) == 0
+    _err(lib, h(P(y), d, P(W), P(x), d, P(g4), P(w4), P(gx), d, P(part), M - 8, ns.value, n, d, d, st))
+    _err(lib, h(P(y), d, P(W), P(x), d, P(g4), P(w4), P(gx), d, P(part), M, ns.value + 1, n, d, d, st))
+    _err(lib, h(P(y), d, P(W), P(x), d, None, P(w4), P(gx), d, P(part), M, ns.value, n, d, d, st))
+    assert lib.allset_fused_linear_bwd_all_aux_supported(64, 128) == 0
+    torch.cuda.synchronize()
