@@ -136,7 +136,9 @@ template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void pma_fwd_flat_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ alpha, int64_t lda,
     const T* __restrict__ V, int64_t ldv, float slope, T* __restrict__ out, int64_t ldo,
-    float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C) {
+    float* __restrict__ m_out, float* __restrict__ l_out, int n_t, int H, int C, const int32_t* __restrict__ row_ids) {
+  // row_ids (optional): the CSR handed in is a COMPACTED one -- row i of it is row row_ids[i] of the outputs (the short rows of a
+  // skewed incidence; the long ones go to the one-wave-per-row kernel with their own list: ops.CSR.split)
   constexpr int NS = kWave / LPR;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int lane = lane_id();
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_flat_kernel(
   const int h = active ? c0 / C : 0;
   const bool head_leader = active && (c0 % C == 0);
   const int rp = (li <= r_end - r_begin) ? rowptr[r_begin + li] : 0;
+  const int rid = (li < r_end - r_begin) ? (row_ids ? row_ids[r_begin + li] : r_begin + li) : 0;      // output row of slot row li
   const int q0 = __shfl(rp, lane0);
   const int q_end = __shfl(rp, lane0 + (r_end - r_begin));
 
@@ -164,15 +167,16 @@ __global__ __launch_bounds__(kBlock) void pma_fwd_flat_kernel(
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
 
   auto flush = [&]() {
+    const int orow = __shfl(rid, lane0 + min(cur_row - r_begin, LPR - 1));
     if (active) {
       const float inv = l > 0.f ? 1.f / (l + kSoftmaxEps) : 0.f;
       FVec<VEC> r;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) { r.v[k] = acc[k] * inv; acc[k] = 0.f; }
-      store_vec<T, VEC>(out + static_cast<int64_t>(cur_row) * ldo + c0, r);
+      store_vec<T, VEC>(out + static_cast<int64_t>(orow) * ldo + c0, r);
       if (head_leader) {
-        m_out[static_cast<int64_t>(cur_row) * H + h] = l > 0.f ? m : 0.f;
-        l_out[static_cast<int64_t>(cur_row) * H + h] = l;
+        m_out[static_cast<int64_t>(orow) * H + h] = l > 0.f ? m : 0.f;
+        l_out[static_cast<int64_t>(orow) * H + h] = l;
       }
     }
     m = -FLT_MAX; l = 0.f;
@@ -433,7 +437,8 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
     const int32_t* __restrict__ rowptrT, const int32_t* __restrict__ colT, const float* __restrict__ alpha,
     const T* __restrict__ V, int64_t ldv, const T* __restrict__ gout, int64_t ldg,
     const float* __restrict__ stats, int64_t lds, float slope, T* __restrict__ gV, int64_t ldgv,
-    float* __restrict__ galpha, int n_s, int H, int C) {
+    float* __restrict__ galpha, int n_s, int H, int C, const int32_t* __restrict__ row_ids) {
+  // row_ids (optional): compacted transposed CSR -- its row i is source row row_ids[i] (see pma_fwd_flat_kernel)
   constexpr int NS = kWave / LPR;
   constexpr int R = kPmaFlatRows;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -453,6 +458,7 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
   const int n_act = min(LPR, d / VEC);
   const int grp_end = min(li - q + G, n_act);
   const int rp = (li <= r_end - r_begin) ? rowptrT[r_begin + li] : 0;
+  const int rid = (li < r_end - r_begin) ? (row_ids ? row_ids[r_begin + li] : r_begin + li) : 0;      // source row of slot row li
   const int q0 = __shfl(rp, lane0);
   const int q_end = __shfl(rp, lane0 + (r_end - r_begin));
   // own-row data of the slot's rows, requested now, consumed at the row ends
@@ -462,9 +468,10 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
   for (int i = 0; i < R; ++i) {
     a_raw[i] = 0.f;
     v_raw[i] = zero_raw<T, VEC>();
+    const int srow = __shfl(rid, lane0 + i);
     if (active && r_begin + i < r_end) {
-      a_raw[i] = alpha[static_cast<int64_t>(r_begin + i) * H + h];
-      v_raw[i] = load_raw<T, VEC>(V + static_cast<int64_t>(r_begin + i) * ldv + c0);
+      a_raw[i] = alpha[static_cast<int64_t>(srow) * H + h];
+      v_raw[i] = load_raw<T, VEC>(V + static_cast<int64_t>(srow) * ldv + c0);
     }
   }
   int cur_row = r_begin;
@@ -477,16 +484,17 @@ __global__ __launch_bounds__(kBlock) void pma_bwd_src_flat_kernel(
 
   auto flush = [&]() {
     const FVec<VEC> vown = unpack<T, VEC>(v_raw[0]);
+    const int orow = __shfl(rid, lane0 + min(cur_row - r_begin, LPR - 1));
     float S = 0.f;
     if (active) {
       FVec<VEC> r;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) { r.v[k] = gv[k]; S = fmaf(vown.v[k], gv[k], S); gv[k] = 0.f; }
-      store_vec<T, VEC>(gV + static_cast<int64_t>(cur_row) * ldgv + c0, r);
+      store_vec<T, VEC>(gV + static_cast<int64_t>(orow) * ldgv + c0, r);
     }
     S = head_group_reduce<LPR>(S, li, grp_end);
     if (active && q == 0)
-      galpha[static_cast<int64_t>(cur_row) * H + h] = (a_raw[0] > 0.f ? 1.f : slope) * (S - D);
+      galpha[static_cast<int64_t>(orow) * H + h] = (a_raw[0] > 0.f ? 1.f : slope) * (S - D);
     D = 0.f;
 #pragma unroll
     for (int i = 0; i + 1 < R; ++i) { a_raw[i] = a_raw[i + 1]; v_raw[i] = v_raw[i + 1]; }
@@ -675,7 +683,7 @@ static int pma_fwd_impl(int dtype, int variant, int64_t nnz_hint, const int32_t*
 #define ALLSET_PMA_FLAT(T, WIDE, LPRV)                                                                              \
   pma_fwd_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptr, col, alpha, lda, static_cast<const T*>(V), ldv, slope, \
                                                                static_cast<T*>(out), ldo, m, l, static_cast<int>(n_t),   \
-                                                               static_cast<int>(H), static_cast<int>(C))
+                                                               static_cast<int>(H), static_cast<int>(C), variant == 2 ? row_order : nullptr)
     if (dtype == ALLSET_F32) {
       switch (lpr) { case 8: ALLSET_PMA_FLAT(float, 4, 8); break; case 16: ALLSET_PMA_FLAT(float, 4, 16); break;
                      case 32: ALLSET_PMA_FLAT(float, 4, 32); break; default: ALLSET_PMA_FLAT(float, 4, 64); break; }
@@ -832,7 +840,7 @@ static int pma_bwd_src_impl(int dtype, int variant, int64_t nnz_hint, const int3
   pma_bwd_src_flat_kernel<T, WIDE, LPRV><<<fgrid, kBlock, 0, st>>>(rowptrT, colT, alpha, static_cast<const T*>(V), ldv,   \
                                                                    static_cast<const T*>(gout), ldg, stats, lds, slope,    \
                                                                    static_cast<T*>(gV), ldgv, galpha, static_cast<int>(n_s), \
-                                                                   static_cast<int>(H), static_cast<int>(C))
+                                                                   static_cast<int>(H), static_cast<int>(C), variant == 2 ? row_order : nullptr)
     if (dtype == ALLSET_F32) {
       switch (lpr) { case 8: ALLSET_PMA_FLATB(float, 4, 8); break; case 16: ALLSET_PMA_FLATB(float, 4, 16); break;
                      case 32: ALLSET_PMA_FLATB(float, 4, 32); break; default: ALLSET_PMA_FLATB(float, 4, 64); break; }

@@ -335,10 +335,10 @@ class HipPmaKernels:
     @staticmethod
     def fwd(V, alpha, inc, heads, slope):                   # raw: (out, m, l), local softmax statistics
         from . import ops
-        from .functional import _variant
+        from .functional import _variant, _sizes
         csr = inc.by_dst
         return ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
-                           variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order)
+                           variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order, sizes=_sizes(csr, V, heads))
 
     @staticmethod
     def bwd_stats(out, gout, m, l):
@@ -353,10 +353,11 @@ class HipPmaKernels:
     @staticmethod
     def bwd_src(inc, alpha, V, gout, stats, slope):
         from . import ops
-        from .functional import _variant
+        from .functional import _variant, _sizes
         T = inc.by_src
         return ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, slope,
-                               variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]), row_order=T.row_order)
+                               variant=_variant(T, "pma_bwd_src", V.shape[0], V, alpha.shape[1]), row_order=T.row_order,
+                               sizes=_sizes(T, V, alpha.shape[1]))
 
 
 def _bn_scope(valid_rows: int, group):

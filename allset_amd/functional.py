@@ -37,6 +37,19 @@ def _variant(csr, kind: str, n_rows: int, x: Tensor, heads: int = 1) -> int:
     return csr.variant(kind, n_rows)
 
 
+def _sizes(csr, x: Tensor, heads: int = 1):
+    """``CSR.sizes`` (long-row list + compacted short rows, ops.SizeSplit) where it pays and the short-row kernel exists: rows of
+    at most one cache line.  ``ALLSET_SIZE_SPLIT=0`` turns it off."""
+    import os
+    if getattr(csr, "sizes", None) is None or os.environ.get("ALLSET_SIZE_SPLIT", "1") == "0":
+        return None
+    es = x.element_size()
+    wide = 16 // es
+    d = x.shape[1]
+    ok = (d % wide == 0 and d * es <= 128 and x.stride(0) % wide == 0 and x.data_ptr() % 16 == 0 and (d // max(heads, 1)) % wide == 0)
+    return csr.sizes if ok else None
+
+
 def _split(csr, x: Tensor, heads: int = 1) -> int:
     """``CSR.short_tail`` if the short-row kernel exists for this feature layout, else -1 (single launch)."""
     if csr.short_tail <= 0:
@@ -165,7 +178,7 @@ class _PmaAggregate(torch.autograd.Function):
             ag.copy_(alpha)
         out, m, l = ops.pma_fwd(csr.rowptr, csr.col, ag, Vg, heads, slope, inc.n_dst,
                                 variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order,
-                                split=split)
+                                split=split, sizes=_sizes(csr, V, heads) if split <= 0 else None)
         ctx.inc, ctx.slope = inc, slope
         ctx.save_for_backward(V, alpha, out, m, l)
         ctx.mark_non_differentiable(m, l)
@@ -186,7 +199,7 @@ class _PmaAggregate(torch.autograd.Function):
             stats = ops.pma_bwd_stats(out, gout, m, l)
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, gout, stats, ctx.slope,
                                      variant=_variant(T, "pma_bwd_src", V.shape[0], V, H),
-                                     row_order=T.row_order, split=split)
+                                     row_order=T.row_order, split=split, sizes=_sizes(T, V, H) if split <= 0 else None)
         return gV, galpha, None, None, None
 
 
@@ -202,7 +215,7 @@ class _PmaPoolLn0(torch.autograd.Function):
         csr = inc.by_dst
         pooled, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
                                    variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order,
-                                   split=_split(csr, V, heads))
+                                   split=_split(csr, V, heads), sizes=_sizes(csr, V, heads))
         cb = att_r.reshape(-1)
         y, stats = dense.ln_res_fwd(pooled, cb, None, gamma, beta, eps, False, 0.0, 0, None)
         ctx.inc, ctx.slope, ctx.cshape = inc, slope, att_r.shape
@@ -220,7 +233,7 @@ class _PmaPoolLn0(torch.autograd.Function):
         H = alpha.shape[1]
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, g_pooled, pstats, ctx.slope,
                                      variant=_variant(T, "pma_bwd_src", V.shape[0], V, H), row_order=T.row_order,
-                                     split=_split(T, V, H))
+                                     split=_split(T, V, H), sizes=_sizes(T, V, H))
         return gV, galpha, None, None, None, dc.reshape(ctx.cshape), dg, db, None
 
 

@@ -81,6 +81,40 @@ def _timed(name: str, dev, algo_bytes: int):
     return _NO_TIMER if t is None else _Timed(t, name, dev, algo_bytes)
 
 
+class SizeSplit(NamedTuple):
+    """A skewed CSR cut by row length (round 3): the few LONG rows (> ``threshold`` incidences) as a list for
+    the one-wave-per-row kernels, the many SHORT rows as a compacted CSR (+ their ids) for the short-row kernels, which pack
+    64 / LPR rows into a wave.  Pays where a row is at most one cache line (the column-sharded PMA layer: d / P columns): one wave
+    per row leaves most lanes idle there, and the short-row kernels alone would serialise a 4096-member row in one lane group."""
+    long_ids: Tensor          # int32[n_long]
+    short_ids: Tensor         # int32[n_short]
+    rowptr_short: Tensor      # int32[n_short + 1] into col_short
+    col_short: Tensor         # int32[nnz_short]
+    threshold: int
+
+
+SIZE_SPLIT_THRESHOLD = 32
+
+
+def size_split(rowptr: Tensor, col: Tensor, n_rows: int, max_deg: int, threshold: int = SIZE_SPLIT_THRESHOLD) -> Optional[SizeSplit]:
+    """Built once per CSR (one host sync), only for skewed row lengths: some row longer than ``threshold`` and at most 1/8 of the
+    rows long."""
+    if n_rows <= 0 or max_deg <= threshold or col.numel() == 0:
+        return None
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    is_long = deg > threshold
+    n_long = int(is_long.sum())
+    if n_long == 0 or n_long * 8 > n_rows:
+        return None
+    long_ids = is_long.nonzero().reshape(-1).to(torch.int32)
+    short_ids64 = (~is_long).nonzero().reshape(-1)
+    deg_s = deg[short_ids64]
+    rowptr_short = torch.zeros(short_ids64.numel() + 1, dtype=torch.int32, device=rowptr.device)
+    rowptr_short[1:] = torch.cumsum(deg_s, 0).to(torch.int32)
+    keep = ~torch.repeat_interleave(is_long, deg)                  # per incidence: its row is short
+    return SizeSplit(long_ids, short_ids64.to(torch.int32), rowptr_short, col[keep].contiguous(), threshold)
+
+
 class CSR(NamedTuple):
     """rowptr int32[n_rows+1], col int32[nnz], perm int32[nnz] (CSR position -> edge-list position);
     ``max_deg`` = longest row (read back once when the CSR is built; used to pick kernel variants)."""
@@ -93,6 +127,7 @@ class CSR(NamedTuple):
     row_order: Optional[Tensor] = None      # int32[n_rows] processing order (long rows first per XCD range) or None
     short_tail: int = -1                    # rows >= short_tail all have <= 2 incidences (Add_Self_Loops' singleton
                                             # hyperedges sit at the end of the id range) and are worth their own launch
+    sizes: Optional[SizeSplit] = None       # skewed row lengths: long-row list + compacted short rows (narrow-row PMA kernels)
 
     def variant(self, kind: str, n_rows: Optional[int] = None) -> int:
         """Kernel variant for this orientation: 2 = short-row kernel, 1 = one wavefront per row.  Thresholds from
@@ -163,7 +198,8 @@ def csr_build(row_ids: Tensor, col_ids: Tensor, row_base: int, col_base: int, n_
         # row wastes the launch on them, the short-row kernel wastes the long rows -- give each block its kernel
         if 0 < first_short < n_rows and (n_rows - first_short) * 16 >= n_rows and head_nnz >= 6 * first_short and max_deg <= 100000:
             short_tail = first_short
-    return CSR(rowptr, col, perm, n_rows, n_cols, max_deg, long_rows_first_order(rowptr, n_rows, nnz, max_deg), short_tail)
+    return CSR(rowptr, col, perm, n_rows, n_cols, max_deg, long_rows_first_order(rowptr, n_rows, nnz, max_deg), short_tail,
+               size_split(rowptr, col, n_rows, max_deg) if short_tail < 0 else None)
 
 
 def long_rows_first_order(rowptr: Tensor, n_rows: int, nnz: int, max_deg: int) -> Optional[Tensor]:
@@ -277,7 +313,10 @@ def sddmm_rowdot(reduce: int, rowptr: Tensor, col: Tensor, x: Tensor, gout: Tens
 
 
 def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, slope: float, n_t: int,
-            variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1) -> Tuple[Tensor, Tensor, Tensor]:
+            variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1, sizes: Optional[SizeSplit] = None
+            ) -> Tuple[Tensor, Tensor, Tensor]:
+    """``sizes`` (``CSR.sizes``): two launches -- the long rows one wave each, the short rows through the short-row kernel on their
+    compacted CSR -- instead of ``variant``."""
     dev = require_device(rowptr, col, alpha, V)
     code = _dtype_code(V, "pma_fwd")
     es = V.element_size()
@@ -303,8 +342,18 @@ def pma_fwd(rowptr: Tensor, col: Tensor, alpha: Tensor, V: Tensor, heads: int, s
             check(lib.allset_pma_fwd_ex(code, 2, col.numel(), None, ptr(rowptr[split:]), ptr(col), ptr(alpha), ptr(V), _ld(V), slope,
                                         ptr(out[split:]), max(d, 1), ptr(m[split:]), ptr(l[split:]), n_t - split, n_s, heads,
                                         d // heads, stream_of(dev)), "allset_pma_fwd_ex")
+        elif sizes is not None and rowptr.numel() == n_t + 1:
+            lda = alpha.stride(0) if n_s > 1 else heads
+            check(lib.allset_pma_fwd_ld(code, 1, col.numel(), ptr(sizes.long_ids), ptr(rowptr), ptr(col), ptr(alpha), lda, ptr(V),
+                                        _ld(V), slope, ptr(out), max(d, 1), ptr(m), ptr(l), sizes.long_ids.numel(), n_s, heads,
+                                        d // heads, stream_of(dev)), "allset_pma_fwd_ld")
+            check(lib.allset_pma_fwd_ld(code, 2, sizes.col_short.numel(), ptr(sizes.short_ids), ptr(sizes.rowptr_short),
+                                        ptr(sizes.col_short), ptr(alpha), lda, ptr(V), _ld(V), slope, ptr(out), max(d, 1), ptr(m),
+                                        ptr(l), sizes.short_ids.numel(), n_s, heads, d // heads, stream_of(dev)), "allset_pma_fwd_ld")
         else:
             lda = alpha.stride(0) if n_s > 1 else heads
+            if variant == 2:
+                row_order = None             # (the short-row kernel reads a row list as the ids of a COMPACTED CSR: see ``sizes``)
             check(lib.allset_pma_fwd_ld(code, variant, col.numel(), ptr(row_order), ptr(rowptr), ptr(col), ptr(alpha), lda, ptr(V),
                                         _ld(V), slope, ptr(out), max(d, 1), ptr(m), ptr(l), n_t, n_s, heads, d // heads,
                                         stream_of(dev)), "allset_pma_fwd_ld")
@@ -346,7 +395,8 @@ def pma_bwd_stats(out: Tensor, gout: Tensor, m: Tensor, l: Tensor, stats: Option
 
 
 def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: Tensor, stats: Tensor, slope: float,
-                variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1) -> Tuple[Tensor, Tensor]:
+                variant: int = 0, row_order: Optional[Tensor] = None, split: int = -1, sizes: Optional[SizeSplit] = None
+                ) -> Tuple[Tensor, Tensor]:
     dev = require_device(rowptrT, colT, alpha, V, gout, stats)
     code = _dtype_code(V, "pma_bwd_src")
     if gout.dtype != V.dtype:
@@ -377,7 +427,18 @@ def pma_bwd_src(rowptrT: Tensor, colT: Tensor, alpha: Tensor, V: Tensor, gout: T
                                             ptr(V[split:]), _ld(V), ptr(gout), _ld(gout), ptr(stats), slope, ptr(gV[split:]),
                                             max(d, 1), ptr(galpha[split:]), n_s - split, n_t, heads, d // heads, stream_of(dev)),
                   "allset_pma_bwd_src_ex")
+        elif sizes is not None and rowptrT.numel() == n_s + 1:
+            check(lib.allset_pma_bwd_src_ld(code, 1, colT.numel(), ptr(sizes.long_ids), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
+                                            _ld(V), ptr(gout), _ld(gout), ptr(stats), lds, slope, ptr(gV), max(d, 1),
+                                            ptr(galpha), sizes.long_ids.numel(), n_t, heads, d // heads, stream_of(dev)),
+                  "allset_pma_bwd_src_ld")
+            check(lib.allset_pma_bwd_src_ld(code, 2, sizes.col_short.numel(), ptr(sizes.short_ids), ptr(sizes.rowptr_short),
+                                            ptr(sizes.col_short), ptr(alpha), ptr(V), _ld(V), ptr(gout), _ld(gout), ptr(stats), lds,
+                                            slope, ptr(gV), max(d, 1), ptr(galpha), sizes.short_ids.numel(), n_t, heads, d // heads,
+                                            stream_of(dev)), "allset_pma_bwd_src_ld")
         else:
+            if variant == 2:
+                row_order = None
             check(lib.allset_pma_bwd_src_ld(code, variant, colT.numel(), ptr(row_order), ptr(rowptrT), ptr(colT), ptr(alpha), ptr(V),
                                             _ld(V), ptr(gout), _ld(gout), ptr(stats), lds, slope, ptr(gV), max(d, 1),
                                             ptr(galpha), n_s, n_t, heads, d // heads, stream_of(dev)),

@@ -478,3 +478,47 @@ def test_aggregate_without_any_incidence(aggr, weighted, device):
     o, m, l = AF.pma_aggregate(V, alpha, inc, 2, 0.2)
     o.sum().backward()
     assert float(o.abs().max()) == 0.0 and float(V.grad.abs().max()) == 0.0 and float(alpha.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,d", [(1, 16), (4, 32), (1, 8)])
+def test_pma_kernels_with_size_split_dispatch(heads, d, dtype, device, monkeypatch):
+    """Skewed row lengths and rows of at most one cache line (the column-sharded PMA layer at P = 8): ``CSR.sizes`` sends the long
+    rows to the one-wave-per-row kernel and the compacted short rows to the short-row kernel (ops.SizeSplit).  Same results as the
+    single-kernel dispatch, forward and backward, including rows without incidences."""
+    from allset_amd import Incidence, ops
+    from allset_amd.functional import _variant, _sizes
+    from allset_amd.synthetic import random_hypergraph
+    if dtype == torch.bfloat16 and d * 2 % 16:
+        pytest.skip("bf16 rows must be 16-byte packets")
+    hg = random_hypergraph(3000, 2500, 12, seed=5, device=device, dist="zipf", max_degree=700)
+    ei = hg.edge_index.clone()
+    ei = ei[:, ei[1] % 17 != 3]                                  # some hyperedges lose all members
+    inc = Incidence.from_edge_index(ei, n_src=3000, n_dst=2500)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    V = torch.randn(3000, d, generator=g).to(device).to(dtype)
+    alpha = torch.randn(3000, heads, generator=g).to(device)
+    gout = torch.randn(2500, d, generator=g).to(device).to(dtype)
+    for csr, n_rows in ((inc.by_dst, 2500),):
+        assert csr.sizes is not None and csr.sizes.long_ids.numel() > 0 and _sizes(csr, V, heads) is csr.sizes
+        ref = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, 0.2, n_rows, variant=1, row_order=csr.row_order)
+        got = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, 0.2, n_rows, variant=_variant(csr, "pma_fwd", n_rows, V, heads),
+                          row_order=csr.row_order, sizes=csr.sizes)
+        tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+        for a, r in zip(got, ref):
+            torch.testing.assert_close(a.float(), r.float(), **tol)
+    # backward: rows of the TRANSPOSED incidence are the sources; use the hyperedges as sources so that its rows are the skewed ones
+    rev = inc.reversed(n_dst=3000)
+    T = rev.by_src                                               # rows = hyperedges (Zipf sizes)
+    assert T.sizes is not None
+    Ve = torch.randn(2500, d, generator=g).to(device).to(dtype)
+    ae = torch.randn(2500, heads, generator=g).to(device)
+    gv = torch.randn(3000, d, generator=g).to(device).to(dtype)
+    out, m, l = ops.pma_fwd(rev.by_dst.rowptr, rev.by_dst.col, ae, Ve, heads, 0.2, 3000, variant=1)
+    stats = ops.pma_bwd_stats(out, gv, m, l)
+    ref = ops.pma_bwd_src(T.rowptr, T.col, ae, Ve, gv, stats, 0.2, variant=1, row_order=T.row_order)
+    got = ops.pma_bwd_src(T.rowptr, T.col, ae, Ve, gv, stats, 0.2, variant=1, row_order=T.row_order, sizes=T.sizes)
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    for a, r in zip(got, ref):
+        torch.testing.assert_close(a.float(), r.float(), **tol)

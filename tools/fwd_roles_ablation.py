@@ -16,9 +16,11 @@ y = torch.empty(n, d, device=dev); st = torch.empty(n, 2, device=dev)
 mask = torch.empty((n + 15) // 16 * 2 * 32, dtype=torch.int32, device=dev)
 P, I64, F, U64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_int
 light = "--light" in sys.argv
-variants = [("roles: full", []), ("roles: no barriers", ["-DALLSET_ABL5_NOBAR"]), ("roles: no MFMA", ["-DALLSET_ABL5_NOMFMA"]),
+# --combo ln,din,dout,mask (each 0/1): which prologue / epilogue pieces the timed call has (default 1,1,1,1; --light = 1,0,0,0)
+combo = [int(v) for v in sys.argv[sys.argv.index("--combo") + 1].split(",")] if "--combo" in sys.argv else ([1, 0, 0, 0] if light else [1, 1, 1, 1])
+variants = [("roles: full", [])] if "--combo" in sys.argv else [("roles: full", []), ("roles: no barriers", ["-DALLSET_ABL5_NOBAR"]), ("roles: no MFMA", ["-DALLSET_ABL5_NOMFMA"]),
             ("roles: no stores", ["-DALLSET_ABL5_NOSTORE"]), ("roles: no MFMA, no stores", ["-DALLSET_ABL5_NOMFMA", "-DALLSET_ABL5_NOSTORE"]),
-            ("roles: segment timing", ["-DALLSET_ABL5_TIMING"]), ("symmetric kernel (fused_mlp.hip)", None)]
+            ("roles: segment timing", ["-DALLSET_ABL5_TIMING"]), ("symmetric kernel (fused_mlp.hip)", None)][:7 if "--combo" not in sys.argv else 0]
 variants += [(a, a.split()) for a in sys.argv[1:] if a.startswith("-D")]
 for name, flags in variants:
     os.environ["ALLSET_FWD_ROLES"] = "1"
@@ -32,9 +34,10 @@ for name, flags in variants:
     fn.argtypes = [P, I64, P, P, F, I, F, U64, P, P, I, F, U64, P, I64, P, I64, I64, I64, P, P, P, P, P, P]
     lib.allset_last_error.restype = ctypes.c_char_p
     def run():
-        rc = fn(x.data_ptr(), d, None if light else gam.data_ptr(), None if light else bet.data_ptr(), 1e-5, 0, 0.0 if light else 0.5, 11,
-                W.data_ptr(), b.data_ptr(), 0 if light else 1, 0.0 if light else 0.5, 12, y.data_ptr(), d, st.data_ptr(), n, d, d, None,
-                None if light else mask.data_ptr(), None, None, None, torch.cuda.current_stream().cuda_stream)
+        ln, din, dout, mk = combo
+        rc = fn(x.data_ptr(), d, gam.data_ptr() if ln else None, bet.data_ptr() if ln else None, 1e-5, 0, 0.5 if din else 0.0, 11,
+                W.data_ptr(), b.data_ptr(), 1 if (dout or mk) else 0, 0.5 if dout else 0.0, 12, y.data_ptr(), d, st.data_ptr(), n, d, d, None,
+                mask.data_ptr() if mk else None, None, None, None, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.allset_last_error()
     run(); torch.cuda.synchronize(); ts = []
     for _ in range(20):
