@@ -93,7 +93,7 @@ class SizeSplit(NamedTuple):
     threshold: int
 
 
-SIZE_SPLIT_THRESHOLD = 32
+SIZE_SPLIT_THRESHOLD = int(__import__('os').environ.get('ALLSET_SIZE_SPLIT_T', '32'))      # (env: tuning sweeps only)
 
 
 def size_split(rowptr: Tensor, col: Tensor, n_rows: int, max_deg: int, threshold: int = SIZE_SPLIT_THRESHOLD) -> Optional[SizeSplit]:
