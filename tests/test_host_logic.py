@@ -105,3 +105,26 @@ def test_fused_adam_falls_back_to_torch_adam_for_tensors_it_does_not_take():
         oa.step(); ob.step()
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_size_split_compacts_the_short_rows_and_lists_the_long_ones():
+    """ops.size_split (host logic of the size-split dispatch): long-row list, short-row ids, compacted rowptr / col in row order;
+    None when nothing is long or too many rows are."""
+    import numpy as np
+    import torch
+    from allset_amd import ops
+    rng = np.random.default_rng(0)
+    deg = rng.integers(0, 6, size=200)
+    deg[[5, 77, 150]] = [40, 33, 400]                          # three long rows (> 32)
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int32))
+    col = torch.arange(int(rowptr[-1]), dtype=torch.int32)     # col = incidence position: makes the compaction checkable
+    sp = ops.size_split(rowptr, col, 200, int(deg.max()))
+    assert sp is not None and sp.long_ids.tolist() == [5, 77, 150] and sp.threshold == 32
+    short = [r for r in range(200) if r not in (5, 77, 150)]
+    assert sp.short_ids.tolist() == short
+    assert sp.rowptr_short.tolist() == np.concatenate([[0], np.cumsum(deg[short])]).tolist()
+    expect = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in short])
+    assert sp.col_short.tolist() == expect.tolist()
+    assert ops.size_split(rowptr, col, 200, 32) is None                                  # nothing longer than the threshold
+    many = torch.from_numpy(np.concatenate([[0], np.cumsum(np.full(16, 40))]).astype(np.int32))
+    assert ops.size_split(many, torch.zeros(640, dtype=torch.int32), 16, 40) is None     # every row is long: not a skewed CSR
