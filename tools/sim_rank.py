@@ -62,10 +62,17 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     for _ in range(3): step()
     from allset_amd import ops as _ops
     timer = _ops.KernelTimer() if os.environ.get("SIM_KERNELS") else None     # per-kernel HIP-event times of the 10 steps
+    import gc
+    gc.collect(); gc.freeze()            # (as bench.py does: a full collection inside the timed steps costs milliseconds once the process holds several worlds' objects)
     torch.cuda.synchronize(); _ops.set_kernel_timer(timer); t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+    if os.environ.get("SIM_ALLOC_STATS"):
+        st = torch.cuda.memory_stats()
+        print(f"      allocator: device mallocs {st.get('num_device_alloc')}, frees {st.get('num_device_free')}, retries {st.get('num_alloc_retries')}, "
+              f"reserved {st.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB, gc counts {__import__('gc').get_count()}")
     _ops.set_kernel_timer(None)
+    gc.unfreeze()
     if timer is not None:
         for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
             print(f"      {k:22s} {v['calls'] / 10:5.1f} calls/step  {v['avg_ms']:7.3f} ms avg  {v['total_ms'] / 10:7.3f} ms/step")
