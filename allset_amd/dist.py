@@ -1101,10 +1101,8 @@ class ShardedSetGNN(torch.nn.Module):
                 x = self._layer(v2e, e2v, x, norm, dropout_out=0.0)      # relu(E2V(.)) -- the dropout comes after the tap
                 xs.append(x)
                 x = _rank_dropout(x, m.dropout, m.training)
-            w = m.GPRweights.weight            # the weighted sum of the layer outputs (models.SetGNN.forward says why not a matmul)
-            x = xs[0] * w[0, 0]
-            for k in range(1, len(xs)):
-                x = x + xs[k] * w[0, k]
+            from .models import _WeightedSum   # the weighted sum of the layer outputs (models.SetGNN.forward says why not a matmul)
+            x = _WeightedSum.apply(m.GPRweights.weight, *xs)
             return m.classifier(x)
         x = _rank_dropout(x_owned, 0.2, m.training)                        # hard-coded input dropout (models.py:473)
         for v2e, e2v in zip(m.V2EConvs, m.E2VConvs):

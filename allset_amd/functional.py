@@ -87,6 +87,18 @@ class _RouteWeights(torch.autograd.Function):
         return g.index_select(0, inv_perm), None, None
 
 
+def _routed(norm: Tensor, inc: Incidence, dst: bool) -> Tensor:
+    """``norm`` (edge-list order, requires grad) in the order of ``inc.by_dst`` / ``inc.by_src``; cached ON the norm tensor per CSR
+    object, so the cache lives exactly as long as that forward's norm (autograd sums the gradients of all its uses)."""
+    cache = norm.__dict__.setdefault("_allset_routed", {})
+    csr = inc.by_dst if dst else inc.by_src
+    hit = cache.get(id(csr))
+    if hit is None:
+        perm, inv = (inc.perm_dst_long(), inc.inv_perm_dst()) if dst else (inc.perm_src_long(), inc.inv_perm_src())
+        hit = cache[id(csr)] = _RouteWeights.apply(norm.reshape(-1).to(torch.float32), perm, inv)
+    return hit
+
+
 class _SegReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, w_dst: Optional[Tensor], w_src: Optional[Tensor], inc: Incidence, reduce: int):
@@ -141,8 +153,11 @@ def deepsets_aggregate(x: Tensor, inc: Incidence, norm: Optional[Tensor] = None,
     _lib.require_device(x)
     _check_rows(x, inc)
     if norm is not None and norm.requires_grad:
-        w_dst = _RouteWeights.apply(norm.reshape(-1).to(torch.float32), inc.perm_dst_long(), inc.inv_perm_dst())   # differentiable routing
-        w_src = None
+        # differentiable routing (LearnMask): edge-list order -> the two CSR orders, ONCE per norm tensor and CSR -- every conv of a
+        # forward gets the same ``Importance * norm`` object (models.py:451-452) and V->E / E->V share the two CSRs, so a two-layer
+        # model routes twice per forward and twice per backward instead of three gathers per aggregation
+        w_dst = _routed(norm, inc, True)
+        w_src = _routed(norm, inc, False).detach()        # (only the input gradient reads it; the weight gradient flows through w_dst)
     else:
         w_dst, w_src = inc.weights(norm)
     return _SegReduce.apply(x, w_dst, w_src, inc, REDUCE_CODES[aggr])

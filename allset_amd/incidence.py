@@ -117,6 +117,14 @@ class Incidence:
             self._inv_perm_dst = inv
         return self._inv_perm_dst
 
+    def inv_perm_src(self) -> Tensor:
+        """int64[nnz]: position in ``by_src`` of each incidence of the caller's edge list (the inverse of ``by_src.perm``)."""
+        if getattr(self, "_inv_perm_src", None) is None:
+            inv = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
+            inv[self.perm_src_long()] = torch.arange(self.nnz, dtype=torch.int64, device=self.device)
+            self._inv_perm_src = inv
+        return self._inv_perm_src
+
     def inv_count_by_src(self) -> Tensor:
         """f32[nnz] in ``by_src`` order: 1 / max(|segment of the incidence's target|, 1) (mean backward)."""
         if "src" not in self._inv_cnt:

@@ -25,6 +25,31 @@ from .incidence import Incidence
 from .layers import MLP, HalfNLHconv
 
 
+class _WeightedSum(torch.autograd.Function):
+    """``sum_k w[0, k] * xs[k]`` -- the GPR readout (reference models.py:468-470) as one autograd node: L + 1 element-wise passes
+    forward (``mul`` then ``addcmul``), and backward one scaled copy per term plus one dot product per weight, where the chain
+    ``x = x + xs[k] * w[0, k]`` cost two passes per term forward and three + a reduction per term backward."""
+
+    @staticmethod
+    def forward(ctx, w, *xs):
+        ctx.save_for_backward(w, *xs)
+        out = xs[0] * w[0, 0]
+        for k in range(1, len(xs)):
+            out = torch.addcmul(out, xs[k], w[0, k])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, *xs = ctx.saved_tensors
+        g = g.contiguous()
+        gw = None
+        if ctx.needs_input_grad[0]:
+            gf = g.reshape(-1)
+            gw = torch.stack([torch.dot(gf, x.reshape(-1).to(gf.dtype)) for x in xs]).reshape(1, -1).to(w.dtype)
+        gxs = [g * w[0, k] if ctx.needs_input_grad[1 + k] else None for k in range(len(xs))]
+        return (gw, *gxs)
+
+
 class SetGNN(nn.Module):
     def __init__(self, args, norm=None):
         super().__init__()
@@ -124,11 +149,7 @@ class SetGNN(nn.Module):
             # outputs, i.e. a weighted sum of them.  Written as that sum: as a matmul it is an [n*d, L+1] x [L+1, 1] product,
             # which the library runs as a strided-batched GEMM with K = L+1 -- 19 SECONDS per step at n = 1M, d = 128
             # (tools/model_step_profile.py with MODEL_ARGS=All_num_layers=2,GPR=1); same arithmetic, same parameter.
-            w = self.GPRweights.weight                          # [1, L+1]
-            x = xs[0] * w[0, 0]
-            for k in range(1, len(xs)):
-                x = x + xs[k] * w[0, k]
-            return self.classifier(x)
+            return self.classifier(_WeightedSum.apply(self.GPRweights.weight, *xs))
         x = F.dropout(x, p=0.2, training=self.training)      # hard-coded input dropout (models.py:473)
         for i in range(len(self.V2EConvs)):
             # x = dropout(relu(conv(x))) (models.py:475-481); relu + dropout ride in the conv's last fused pass
