@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch.nn import Linear, Parameter
 
 from .incidence import Incidence
-from .layers import MLP, HalfNLHconv
+from .layers import MLP, HalfNLHconv, relu_dropout
 
 
 class _WeightedSum(torch.autograd.Function):
@@ -142,9 +142,11 @@ class SetGNN(nn.Module):
             xs = [F.relu(self.MLP(x))]
             for i in range(len(self.V2EConvs)):
                 x = self.V2EConvs[i](x, v2e, norm, self.aggr, _post_dropout=self.dropout)   # relu + dropout fused
-                x = F.relu(self.E2VConvs[i](x, e2v, norm, self.aggr))
+                x = self.E2VConvs[i](x, e2v, norm, self.aggr)
+                if self.E2VConvs[i].attention:     # (the Deep Sets conv ends in relu(f_dec(.)) already: layers.py, reference layers.py:634)
+                    x = F.relu(x)
                 xs.append(x)
-                x = F.dropout(x, p=self.dropout, training=self.training)
+                x = relu_dropout(x, self.dropout, self.training)     # x >= 0 already: the dropout alone, from the counter hash (no mask tensor)
             # reference models.py:468-470: x = GPRweights(stack(xs, -1)).squeeze() -- a Linear(L+1 -> 1) over the stacked layer
             # outputs, i.e. a weighted sum of them.  Written as that sum: as a matmul it is an [n*d, L+1] x [L+1, 1] product,
             # which the library runs as a strided-batched GEMM with K = L+1 -- 19 SECONDS per step at n = 1M, d = 128
