@@ -141,6 +141,25 @@ class MLP(nn.Module):
                 return False
         return True
 
+    def _bn_foldable(self, x: Tensor) -> bool:
+        """BatchNorm1d slots in EVAL mode (running statistics) are per-column affine maps ``x * a + b`` -- in MLP.forward's order
+        (norm0 -> Linear; Linear -> relu -> norm -> dropout -> Linear, reference layers.py:571-579) each one sits directly in front
+        of a Linear and folds into its weight and bias.  The whole MLP then takes the fused Linear kernels with no normalisation
+        prologue at all (round 3; training mode needs batch statistics and their backward and stays on torch)."""
+        if self.training or not _on_hip(x) or x.dim() != 2 or x.dtype != torch.float32:
+            return False
+        bns = [nm for nm in self.normalizations if not isinstance(nm, nn.Identity)]
+        if not bns or not all(isinstance(nm, nn.modules.batchnorm._BatchNorm) and nm.running_mean is not None and nm.affine for nm in bns):
+            return False
+        return all(lin.bias is not None and dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins)
+
+    @staticmethod
+    def _fold_bn(bn, lin) -> Tuple[Tensor, Tensor]:
+        """(W', b') with ``lin(bn(x)) == x @ W'^T + b'`` for an eval-mode BatchNorm (differentiable w.r.t. W, b, gamma, beta)."""
+        a = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * a
+        return lin.weight * a.unsqueeze(0), lin.bias + lin.weight @ shift
+
     def _resident(self) -> bool:
         """Every Linear fits the LDS-resident-weight kernels (widths <= 128): the joint PMA nodes build on those."""
         return all(dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins)
@@ -173,6 +192,15 @@ class MLP(nn.Module):
                     ln.eps if ln is not None else 1e-5, relu_in=i > 0, p_in=p if i > 0 else 0.0,
                     relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0,
                     in_cb=_in_cb if i == 0 else 0, out_cb=_out_cb if is_last else 0)
+            return x
+        if self._bn_foldable(x):
+            last = len(self.lins) - 1
+            for i, lin in enumerate(self.lins):
+                nm = self.normalizations[i]
+                w, b = (lin.weight, lin.bias) if isinstance(nm, nn.Identity) else self._fold_bn(nm, lin)
+                is_last = i == last
+                x = dense.fused_norm_linear(x, None, None, w, b, 1e-5, relu_in=i > 0, p_in=0.0,
+                                            relu_out=is_last and post_p is not None, p_out=0.0)
             return x
         if self._fusable(x):
             last = len(self.lins) - 1

@@ -1071,3 +1071,36 @@ def test_fused_linear_with_column_blocked_operands(cb, has_ln, relu_in, p_in, po
         got = run(in_cb, out_cb)
         for a, r in zip(got, ref):
             assert torch.equal(a, r), (in_cb, out_cb, float((a - r).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,input_norm", [(2, True), (3, False), (1, True)])
+def test_eval_mode_batchnorm_mlp_folds_into_the_fused_linear(layers, input_norm, device, monkeypatch):
+    """``Normalization='bn'`` (the reference MLP's default, layers.py:499-562) in EVAL mode: every BatchNorm1d is a per-column
+    affine map in front of a Linear and folds into its weight and bias, so the MLP runs on the fused Linear kernels alone
+    (layers.MLP._bn_foldable).  Same outputs and gradients (input, Linear and BatchNorm parameters) as the torch modules on the CPU."""
+    from allset_amd import dense
+    from allset_amd.layers import MLP
+    torch.manual_seed(layers)
+    ref = MLP(128, 128, 128, layers, dropout=0.5, Normalization="bn", InputNorm=input_norm)
+    with torch.no_grad():
+        for nm in ref.normalizations:
+            if isinstance(nm, torch.nn.BatchNorm1d):
+                nm.running_mean.normal_(); nm.running_var.uniform_(0.5, 2.0); nm.weight.uniform_(0.5, 1.5); nm.bias.normal_()
+    ref.eval()
+    import copy
+    dut = copy.deepcopy(ref).to(device).eval()
+    calls = []
+    real = dense.fused_norm_linear
+    monkeypatch.setattr(dense, "fused_norm_linear", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = torch.randn(1000, 128)
+    xr, xd = x.clone().requires_grad_(True), x.clone().to(device).requires_grad_(True)
+    cot = torch.randn(1000, 128)
+    yr = ref(xr, _post=0.5); (yr * cot).sum().backward()
+    yd = dut(xd, _post=0.5); (yd * cot.to(device)).sum().backward()
+    assert len(calls) == layers                                   # every Linear went through the fused kernel, nothing else ran
+    torch.testing.assert_close(yd.cpu(), yr, rtol=1e-4, atol=1e-4 * float(yr.abs().max()))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()))
+    for (k, pr), (_, pd) in zip(ref.named_parameters(), dut.named_parameters()):
+        if pr.grad is not None:
+            torch.testing.assert_close(pd.grad.cpu(), pr.grad, rtol=1e-3, atol=2e-4 * max(1.0, float(pr.grad.abs().max())), msg=lambda m, k=k: f"{k}: {m}")
