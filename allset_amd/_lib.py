@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 F32, BF16 = 0, 1

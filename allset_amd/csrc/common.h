@@ -46,14 +46,6 @@ void clear_error();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Kernel family of the dense tail: default "bf16x6" (fp32-accurate arithmetic on the bf16 matrix pipe, see split3_bf16);
-// the environment variable ALLSET_DENSE_MFMA=f32 selects the native fp32-MFMA kernels (comparison arm).  Read per call:
-// the library keeps no state.
-inline bool dense_mfma_x6() {
-  const char* e = getenv("ALLSET_DENSE_MFMA");
-  return !(e && e[0] == 'f');
-}
-
 // ---- device helpers ---------------------------------------------------------------------------
 #ifdef __HIPCC__
 

@@ -7,11 +7,10 @@
 //   ln_fwd_kernel      y = dropout( LayerNorm( relu?(x) ) )            1 read + 1 write, row statistics saved
 //   ln_bwd_kernel      gx, per-block partial (dgamma, dbeta)            2 reads + 1 write; mask regenerated
 //   relu_dropout_*     y = dropout(relu(x)) and its backward            elementwise, 16 B per lane
-//   wgrad_kernel       gW = ga^T @ u, gb = colsum(ga)                   split-K over rows, fp32 MFMA 32x32x2,
-//                                                                       per-slice partials (deterministic)
+//   wgrad_x6_kernel    gW = ga^T @ u, gb = colsum(ga)                   split-K over rows on the bf16 matrix pipe (bf16x6,
+//                                                                       fp32-accurate), per-slice partials (deterministic)
 //
-// The LayerNorm/elementwise kernels are HBM-bound streaming kernels; wgrad is the only MFMA user (exact fp32,
-// v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, MI355X_MICROARCH.md).  Dropout masks come from a counter-based
+// The LayerNorm/elementwise kernels are HBM-bound streaming kernels; wgrad is the only MFMA user.  Dropout masks come from a counter-based
 // hash of (seed, element index), so the backward regenerates them instead of storing a mask tensor.
 #include <stdlib.h>
 
@@ -433,10 +432,8 @@ __global__ void relu_dropout_bwd_scalar_kernel(const float* __restrict__ gy, con
 }
 
 // ---- weight gradient: gW[o][i] = sum_r ga[r][o] * u[r][i],  gb[o] = sum_r ga[r][o] -----------------------
-// Grid: x = 128x128 output macro-tile (o-block * tiles_i + i-block), y = split-K slice of the rows.
-// 4 waves; wave w owns o-rows [32w, 32w+32) x 128 i-columns = four 32x32 fp32 MFMA accumulators.
-// K (= rows) is consumed 32 rows per stage through LDS (row-major, unpadded: the A operand
-// ga[r0 + (l>>5)][o0 + (l&31)] and the B operand u[r0 + (l>>5)][i0 + (l&31)] are both unit-stride across lanes).
+// Weight gradient.  Grid: x = 128x128 output macro-tile (o-block * tiles_i + i-block), y = split-K slice of the rows;
+// K (= rows) is consumed 32 rows per stage through LDS (wgrad_x6_kernel below).
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kWgTile = 128;
 constexpr int kWgRows = 32;
@@ -452,147 +449,6 @@ struct WgradPro {
   const uint32_t* mask; int mask_nh;        // activation mask (replaces y; bf16x6 kernels only), O / 64
   int64_t pw_stride = 0, pb_stride = 0;     // floats between consecutive slices of part_w / part_b (0: O*I and O)
 };
-
-template <bool PRO>
-__global__ __launch_bounds__(kBlock) void wgrad_kernel(
-    const float* __restrict__ ga, int64_t lda, const float* __restrict__ u, int64_t ldu,
-    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i,
-    int64_t rows_per_slice, WgradPro pro) {
-  __shared__ float sA[2][kWgRows][kWgTile];
-  __shared__ float sB[2][kWgRows][kWgTile];
-  const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
-  const int o_base = tile_o * kWgTile, i_base = tile_i * kWgTile;
-  const int slice = blockIdx.y;
-  const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
-  const int64_t r_end = min(n, r_begin + rows_per_slice);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // staging map: thread -> (row = tid / 32 + 8*k, 4 columns at (tid % 32)*4), k = 0..3
-  const int s_col = (tid & 31) * 4, s_row = tid >> 5;
-  const bool a_ok = (o_base + s_col) < O, b_ok = (i_base + s_col) < I;      // O, I are multiples of 4
-  float4 bsum = make_float4(0, 0, 0, 0);
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-
-  float4 ra[4], rb[4];
-  float4 g4 = make_float4(1, 1, 1, 1), be4 = make_float4(0, 0, 0, 0);
-  float keep_in = 1.f;
-  uint32_t thr_in = 0;
-  if constexpr (PRO) {
-    if (pro.has_ln && b_ok) {
-      g4 = *reinterpret_cast<const float4*>(pro.gamma + i_base + s_col);
-      be4 = *reinterpret_cast<const float4*>(pro.beta + i_base + s_col);
-    }
-    keep_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
-    thr_in = drop_threshold(pro.p_in);
-    pro.seed_in = resolve_seed(pro.seed_base, pro.seed_in);
-  }
-  float4 ry[4];
-  float2 rst[4];
-  int64_t rrow[4];
-  auto load_stage = [&](int64_t r0) {        // issue only: the loads stay in flight under the MFMAs of the current stage
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t r = r0 + s_row + 8 * k;
-      rrow[k] = r;
-      ra[k] = make_float4(0, 0, 0, 0);
-      rb[k] = make_float4(0, 0, 0, 0);
-      if constexpr (PRO) { ry[k] = make_float4(1, 1, 1, 1); rst[k] = make_float2(0.f, 1.f); }
-      if (r < r_end) {
-        if (a_ok) ra[k] = *reinterpret_cast<const float4*>(ga + r * lda + o_base + s_col);
-        if (b_ok) rb[k] = *reinterpret_cast<const float4*>(u + r * ldu + i_base + s_col);
-        if constexpr (PRO) {
-          if (pro.y != nullptr && a_ok) ry[k] = *reinterpret_cast<const float4*>(pro.y + r * pro.ldy + o_base + s_col);
-          if (pro.has_ln) rst[k] = *reinterpret_cast<const float2*>(pro.stats + r * 2);
-        }
-      }
-    }
-  };
-  auto store_stage = [&](int buf) {          // operand prologues (PRO) happen here, after the wait on the loads
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if constexpr (PRO) {
-        const bool in_range = rrow[k] < r_end;
-        if (pro.y != nullptr) {
-          ra[k].x = ry[k].x > 0.f ? ra[k].x * pro.keep_out : 0.f; ra[k].y = ry[k].y > 0.f ? ra[k].y * pro.keep_out : 0.f;
-          ra[k].z = ry[k].z > 0.f ? ra[k].z * pro.keep_out : 0.f; ra[k].w = ry[k].w > 0.f ? ra[k].w * pro.keep_out : 0.f;
-        }
-        float4 t = rb[k];
-        if (pro.relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-        if (pro.has_ln) {
-          const float2 st = rst[k];
-          t.x = fmaf((t.x - st.x) * st.y, g4.x, be4.x); t.y = fmaf((t.y - st.x) * st.y, g4.y, be4.y);
-          t.z = fmaf((t.z - st.x) * st.y, g4.z, be4.z); t.w = fmaf((t.w - st.x) * st.y, g4.w, be4.w);
-        }
-        if (pro.p_in > 0.f) {
-          float k0, k1, k2, k3;
-          const int64_t e = rrow[k] * I + i_base + s_col;
-          keep_scale2(pro.seed_in, e, thr_in, keep_in, k0, k1); keep_scale2(pro.seed_in, e + 2, thr_in, keep_in, k2, k3);
-          t.x *= k0; t.y *= k1; t.z *= k2; t.w *= k3;
-        }
-        if (!(in_range && b_ok)) t = make_float4(0, 0, 0, 0);
-        rb[k] = t;
-      }
-      *reinterpret_cast<float4*>(&sA[buf][s_row + 8 * k][s_col]) = ra[k];
-      *reinterpret_cast<float4*>(&sB[buf][s_row + 8 * k][s_col]) = rb[k];
-      bsum.x += ra[k].x; bsum.y += ra[k].y; bsum.z += ra[k].z; bsum.w += ra[k].w;
-    }
-  };
-
-  int buf = 0;
-  if (r_begin < r_end) {
-    load_stage(r_begin);
-    store_stage(0);
-  }
-  __syncthreads();
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
-    const bool more = (r0 + kWgRows) < r_end;
-    if (more) load_stage(r0 + kWgRows);            // global loads in flight under the MFMAs below
-    const int ao = wave * 32 + (lane & 31);
-    const int kk = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < kWgRows; ks += 2) {
-      const float a = sA[buf][ks + kk][ao];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float b = sB[buf][ks + kk][t * 32 + (lane & 31)];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-      }
-    }
-    if (more) store_stage(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  // epilogue: partial tile -> part_w[slice][O][I]
-  float* pw = part_w + static_cast<int64_t>(slice) * (pro.pw_stride ? pro.pw_stride : static_cast<int64_t>(O) * I);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = i_base + t * 32 + (lane & 31);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int o = o_base + wave * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
-      if (o < O && i < I) pw[static_cast<int64_t>(o) * I + i] = acc[t][k];
-    }
-  }
-  // bias partial: reduce the 8 staging-row groups of each column quad through LDS (only i-tile 0 writes)
-  if (tile_i == 0 && part_b != nullptr) {
-    __syncthreads();
-    float* red = &sA[0][0][0];                     // [8][128]
-    *reinterpret_cast<float4*>(&red[s_row * kWgTile + s_col]) = bsum;
-    __syncthreads();
-    if (tid < kWgTile) {
-      float s = 0.f;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) s += red[g * kWgTile + tid];
-      if (o_base + tid < O) part_b[static_cast<int64_t>(slice) * (pro.pb_stride ? pro.pb_stride : O) + o_base + tid] = s;
-    }
-  }
-}
-
 
 // out[s][c] = sum of part[p][c] over the s-th slab of kRedRows rows (p < P, c < M): one level of the tree that
 // finishes every split-K / per-block partial scheme above.  2-D grid (column quads x row slabs), 8 row groups per
@@ -1772,12 +1628,8 @@ extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_
   rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
   if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
-  if (dense_mfma_x6())
-    wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O),
-                                                       static_cast<int>(I), tiles_i, rows_per_slice, WgradPro{});
-  else
-    wgrad_kernel<false><<<grid, kBlock, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
-                                                 tiles_i, rows_per_slice, WgradPro{});
+  wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O),
+                                                     static_cast<int>(I), tiles_i, rows_per_slice, WgradPro{});
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -1816,8 +1668,8 @@ static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_
                             int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, const uint64_t* seed_base,
                             const uint32_t* mask, void* stream) {
   ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_fused: bad size");
-  if (mask != nullptr && (!dense_mfma_x6() || O % 64 != 0)) {
-    set_error("wgrad_fused: the activation mask is consumed by the bf16x6 kernels only (out features % 64 == 0)");
+  if (mask != nullptr && O % 64 != 0) {
+    set_error("wgrad_fused: the activation mask needs out features % 64 == 0");
     return ALLSET_ERR_UNSUPPORTED;
   }
   ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_fused: bad slice count");
@@ -1846,20 +1698,12 @@ static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_
   const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
   // no operand prologue at all (allset_wgrad through the one-buffer entry): the plain instantiation, 12 % faster
   const bool plain = y == nullptr && mask == nullptr && stats == nullptr && !relu_in && p_in == 0.f && p_out == 0.f;
-  if (dense_mfma_x6()) {
-    if (plain)
-      wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
-                                                         static_cast<int>(I), tiles_i, rows_per_slice, pro);
-    else
-      wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
-                                                        static_cast<int>(I), tiles_i, rows_per_slice, pro);
-  } else if (plain) {
-    wgrad_kernel<false><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
-                                                 tiles_i, rows_per_slice, pro);
-  } else {
-    wgrad_kernel<true><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), static_cast<int>(I),
-                                                tiles_i, rows_per_slice, pro);
-  }
+  if (plain)
+    wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
+                                                       static_cast<int>(I), tiles_i, rows_per_slice, pro);
+  else
+    wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
+                                                      static_cast<int>(I), tiles_i, rows_per_slice, pro);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -1951,8 +1795,7 @@ extern "C" int allset_ln_res_bwd_partials(int64_t n, int64_t d, int64_t* n_parti
   const int64_t want = (n + groups - 1) / groups;
   // persistent grid: 78 VGPRs = 6 waves per SIMD = 6 workgroups of 4 waves per CU -> 1536 resident workgroups; with 2048 the last
   // quarter runs as a second, third-full round (0.315 -> see profiles/r02_ln_res_bench.txt)
-  int64_t cap = 1536;
-  if (const char* e = getenv("ALLSET_LNRES_CAP")) cap = atoll(e);        // (tuning knob, read per call like ALLSET_DENSE_MFMA)
+  const int64_t cap = 1536;
   *n_partials = want < 1 ? 1 : (want > cap ? cap : want);
   return ALLSET_OK;
 }
@@ -2073,8 +1916,7 @@ static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t l
   }
   ALLSET_REQUIRE(lda >= O && ldu >= I, "wgrad_bf16: leading dimension smaller than the feature width");
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  if (wgrad_bf16_full_width(O, I) && lda % 8 == 0 && ldu % 8 == 0 && aligned16(ga) && aligned16(u) &&
-      getenv("ALLSET_WGRAD_BF16_TILED") == nullptr) {
+  if (wgrad_bf16_full_width(O, I) && lda % 8 == 0 && ldu % 8 == 0 && aligned16(ga) && aligned16(u)) {
     // the full-width kernel: one read of each operand (the tiled one below re-reads them per 128 x 128 tile)
     int64_t rps = (n + n_slices - 1) / n_slices;
     rps = (rps + 31) / 32 * 32;

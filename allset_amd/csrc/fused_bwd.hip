@@ -528,23 +528,6 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
 
 using namespace allset;
 
-// fused_bwd2.hip: the same pass at two waves per SIMD (pairs of waves share a chunk); O = I = 128 without acc_in
-int fused_linear_bwd_pair_supported(int64_t O, int64_t I, int has_acc);
-int launch_fused_linear_bwd_pair(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy,
-                                 int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
-                                 const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
-                                 float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
-                                 const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl);
-
-// fused_bwd3.hip: the same pass with one gW per workgroup, W in registers, 8 cooperating waves (two per SIMD)
-int fused_linear_bwd_stage_supported(int64_t O, int64_t I, int has_acc);
-unsigned fused_linear_bwd_stage_grid(int64_t n);
-int launch_fused_linear_bwd_stage(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy,
-                                  int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
-                                  const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
-                                  float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
-                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl);
-
 // fused_bwd4.hip: the same pass with the waves split by role (four vector waves, four matrix waves, one of each per SIMD)
 int fused_linear_bwd_roles_supported(int64_t O, int64_t I, int has_acc);
 unsigned fused_linear_bwd_roles_grid(int64_t n);
@@ -554,16 +537,6 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
                                   int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb);
-
-// fused_bwd5.hip: the role split at THREE waves per SIMD (eight vector waves that also carry the weight gradient, four matrix
-// waves for backward-data); same grid and slice layout as fused_bwd4.hip
-int fused_linear_bwd_roles3_supported(int64_t O, int64_t I);
-int launch_fused_linear_bwd_roles3(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy,
-                                   int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
-                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
-                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
-                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                   int64_t ldacc);
 
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
@@ -581,7 +554,7 @@ static inline bool bwd_all_combo(bool ln, bool drop, bool relu, bool mask, bool 
 
 extern "C" int allset_fused_linear_bwd_all_supported(int64_t O, int64_t I, int has_ln, int drop_in, int relu_in, int has_mask,
                                                      int has_acc) {
-  return (dense_mfma_x6() && (O == 64 || O == 128) && (I == 64 || I == 128) &&
+  return ((O == 64 || O == 128) && (I == 64 || I == 128) &&
           bwd_all_combo(has_ln != 0, drop_in != 0, relu_in != 0, has_mask != 0, has_acc != 0)) ? 1 : 0;
 }
 
@@ -592,13 +565,12 @@ extern "C" int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices) 
   return ALLSET_OK;
 }
 
-// The slice count of the kernel allset_fused_linear_bwd_all will actually launch for these widths: one per WORKGROUP for the
-// stage kernel (fused_bwd3.hip: a single gW accumulator per CU), one per wave / pair of waves for the others.
+// The slice count of the kernel allset_fused_linear_bwd_all launches for these widths -- a pure function of its arguments: one
+// per WORKGROUP for the split-role kernel (fused_bwd4.hip, O = I = 128: a single gW accumulator per CU), one per wave otherwise.
 extern "C" int allset_fused_linear_bwd_all_slices_for(int64_t n, int64_t O, int64_t I, int has_acc, int64_t* n_slices) {
   clear_error();
   ALLSET_REQUIRE(n_slices != nullptr && n >= 0, "fused_linear_bwd_all_slices_for: bad argument");
   if (fused_linear_bwd_roles_supported(O, I, has_acc)) *n_slices = static_cast<int64_t>(fused_linear_bwd_roles_grid(n));
-  else if (fused_linear_bwd_stage_supported(O, I, has_acc)) *n_slices = static_cast<int64_t>(fused_linear_bwd_stage_grid(n));
   else *n_slices = static_cast<int64_t>(bwd_all_grid(n)) * kMWaves;
   return ALLSET_OK;
 }
@@ -665,9 +637,8 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
               "(allset_fused_linear_blocked_supported), without acc_in");
     return ALLSET_ERR_UNSUPPORTED;
   }
-  const bool stage_kernel = !roles_kernel && fused_linear_bwd_stage_supported(O, I, acc_in != nullptr) != 0;
-  const unsigned grid = roles_kernel ? fused_linear_bwd_roles_grid(n) : (stage_kernel ? fused_linear_bwd_stage_grid(n) : bwd_all_grid(n));
-  ALLSET_REQUIRE(part_w != nullptr && n_slices == static_cast<int64_t>(grid) * ((roles_kernel || stage_kernel) ? 1 : kMWaves),
+  const unsigned grid = roles_kernel ? fused_linear_bwd_roles_grid(n) : bwd_all_grid(n);
+  ALLSET_REQUIRE(part_w != nullptr && n_slices == static_cast<int64_t>(grid) * (roles_kernel ? 1 : kMWaves),
                  "fused_linear_bwd_all: part_w must hold allset_fused_linear_bwd_all_slices_for() slices of [O][I]");
   ALLSET_REQUIRE(!has_ln || part_ln != nullptr, "fused_linear_bwd_all: LayerNorm partials buffer missing");
   const hipStream_t st = static_cast<hipStream_t>(stream);
@@ -694,28 +665,10 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
-  if (roles_kernel && !blocked && fused_linear_bwd_roles3_supported(O, I)) {  // one partial per workgroup; three waves per SIMD
-    launch_fused_linear_bwd_roles3(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
-                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc);
-    ALLSET_LAUNCH_CHECK();
-    return ALLSET_OK;
-  }
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc,
                                   nullptr, nullptr, gcb, xcb, gxcb);
-    ALLSET_LAUNCH_CHECK();
-    return ALLSET_OK;
-  }
-  if (stage_kernel) {                                            // one partial per workgroup
-    launch_fused_linear_bwd_stage(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
-                                  seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl);
-    ALLSET_LAUNCH_CHECK();
-    return ALLSET_OK;
-  }
-  if (fused_linear_bwd_pair_supported(O, I, ha)) {        // same grid, same slices: one partial per pair of waves
-    launch_fused_linear_bwd_pair(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
-                                 seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }

@@ -654,12 +654,10 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
 
 using namespace allset;
 
-// 1 = the split-role kernel takes this call (O = I = 128, no acc_in; bf16x6 mode); ALLSET_BWD_ROLES=0 falls through to the next one
+// 1 = the split-role kernel takes this call (O = I = 128): a pure function of the widths
 int fused_linear_bwd_roles_supported(int64_t O, int64_t I, int has_acc) {
   (void)has_acc;                         // (acc_in is built for the plain Linear, the one combination the one-wave kernel has it for too)
-  const char* e = getenv("ALLSET_BWD_ROLES");
-  if (e && e[0] == '0') return 0;
-  return (dense_mfma_x6() && O == 128 && I == 128) ? 1 : 0;
+  return (O == 128 && I == 128) ? 1 : 0;
 }
 
 unsigned fused_linear_bwd_roles_grid(int64_t n) {

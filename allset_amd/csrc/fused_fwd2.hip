@@ -346,11 +346,9 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
 
 using namespace allset;
 
-// 1 = the split-role forward takes this call (K = N = 128, no auxiliary columns; bf16x6 mode); ALLSET_FWD_ROLES=0 keeps the symmetric kernel
+// 1 = the split-role forward takes this call (K = N = 128, no auxiliary columns): a pure function of its arguments
 int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux) {
-  const char* e = getenv("ALLSET_FWD_ROLES");
-  if (e && e[0] == '0') return 0;
-  return (dense_mfma_x6() && K == 128 && N == 128 && !has_aux) ? 1 : 0;
+  return (K == 128 && N == 128 && !has_aux) ? 1 : 0;
 }
 
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,

@@ -33,153 +33,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kFusedBlock = 512;
 constexpr int kFusedWaves = kFusedBlock / kWave;
 
-template <int KD, int NT, bool HAS_LN, bool DROP_IN, bool DROP_OUT>
-__global__ __launch_bounds__(kFusedBlock) void fused_linear_fwd_kernel(
-    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float eps, int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W,
-    const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
-    int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base) {
-  seed_in = resolve_seed(seed_base, seed_in);
-  seed_out = resolve_seed(seed_base, seed_out);
-  constexpr int N = 32 * NT;
-  constexpr int PITCH = KD + 1;
-  constexpr int KH = KD / 2;                       // columns per lane
-  __shared__ float sW[N * PITCH];
-  __shared__ __attribute__((aligned(16))) float sG[KD];
-  __shared__ __attribute__((aligned(16))) float sBeta[KD];
-  __shared__ float sBias[N];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < N * KD; idx += kFusedBlock) sW[(idx / KD) * PITCH + (idx % KD)] = W[idx];
-  for (int idx = tid; idx < KD; idx += kFusedBlock) {
-    sG[idx] = HAS_LN ? gamma[idx] : 1.f;
-    sBeta[idx] = HAS_LN ? beta[idx] : 0.f;
-  }
-  for (int idx = tid; idx < N; idx += kFusedBlock) sBias[idx] = bias ? bias[idx] : 0.f;
-  __syncthreads();
-
-  const int lane = tid & 63, wave = tid >> 6;
-  const int rin = lane & 31, half = lane >> 5;
-  const float inv_k = 1.f / static_cast<float>(KD);
-  const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
-  const float keep_out = DROP_OUT ? 1.f / (1.f - p_out) : 1.f;
-  const uint32_t thr_in = drop_threshold(p_in), thr_out = drop_threshold(p_out);
-  const int64_t n_chunks = (n + 31) / 32;
-  // The two waves that share a SIMD run identical load -> MFMA -> store phases; a static priority split keeps
-  // them from settling into lockstep.
-  if (wave >> 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-
-  for (int64_t chunk = static_cast<int64_t>(blockIdx.x) * kFusedWaves + wave; chunk < n_chunks;
-       chunk += static_cast<int64_t>(gridDim.x) * kFusedWaves) {
-    const int64_t row = chunk * 32 + rin;
-    const bool valid = row < n;
-    // ---- A operand: this lane's row, columns half*K/2 + j, straight into the operand registers
-    float a[KH];
-#ifdef ALLSET_ABLATE_NOLOAD       // ablation builds only (tools/fused_ablation.py): operand from registers
-    if (false) {
-#else
-    if (valid) {
-#endif
-      const float4* xr = reinterpret_cast<const float4*>(x + row * ldx + half * KH);
-#pragma unroll
-      for (int q = 0; q < KH / 4; ++q) {
-        const float4 v = xr[q];
-        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < KH; ++j) a[j] = static_cast<float>(j + rin) * 1e-3f;
-    }
-    if (relu_in) {
-#pragma unroll
-      for (int j = 0; j < KH; ++j) a[j] = fmaxf(a[j], 0.f);
-    }
-    if constexpr (HAS_LN) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < KH; ++j) s += a[j];
-      s += __shfl_xor(s, 32);
-      const float mean = s * inv_k;
-      float q2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < KH; ++j) { a[j] -= mean; q2 = fmaf(a[j], a[j], q2); }
-      q2 += __shfl_xor(q2, 32);
-      const float rstd = rsqrtf(q2 * inv_k + eps);
-      if (valid && half == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
-      // affine in blocks of 8 columns; the scheduling barrier keeps the compiler from hoisting every gamma/beta
-      // LDS read (2*K/2 registers) above the arithmetic
-#pragma unroll
-      for (int jb = 0; jb < KH; jb += 8) {
-        const float4 g0 = *reinterpret_cast<const float4*>(&sG[half * KH + jb]);
-        const float4 g1 = *reinterpret_cast<const float4*>(&sG[half * KH + jb + 4]);
-        const float4 b0 = *reinterpret_cast<const float4*>(&sBeta[half * KH + jb]);
-        const float4 b1 = *reinterpret_cast<const float4*>(&sBeta[half * KH + jb + 4]);
-        a[jb + 0] = fmaf(a[jb + 0] * rstd, g0.x, b0.x); a[jb + 1] = fmaf(a[jb + 1] * rstd, g0.y, b0.y);
-        a[jb + 2] = fmaf(a[jb + 2] * rstd, g0.z, b0.z); a[jb + 3] = fmaf(a[jb + 3] * rstd, g0.w, b0.w);
-        a[jb + 4] = fmaf(a[jb + 4] * rstd, g1.x, b1.x); a[jb + 5] = fmaf(a[jb + 5] * rstd, g1.y, b1.y);
-        a[jb + 6] = fmaf(a[jb + 6] * rstd, g1.z, b1.z); a[jb + 7] = fmaf(a[jb + 7] * rstd, g1.w, b1.w);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if constexpr (DROP_IN) {
-#pragma unroll
-      for (int jb = 0; jb < KH; jb += 8) {
-#pragma unroll
-        for (int j = jb; j < jb + 8; j += 2) {       // columns half*K/2 + j, +1: one hash per pair
-          float k0, k1;
-          keep_scale2(seed_in, row * KD + half * KH + j, thr_in, keep_in, k0, k1);
-          a[j] *= k0; a[j + 1] *= k1;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // ---- MFMA + epilogue, two 32-column tiles at a time (32 accumulator registers live)
-#pragma unroll
-    for (int tp = 0; tp < NT; tp += 2) {
-      f32x16 acc0, acc1;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
-      const float* w0 = sW + ((tp + 0) * 32 + rin) * PITCH + half * KH;
-      const float* w1 = sW + ((tp + 1) * 32 + rin) * PITCH + half * KH;
-#ifndef ALLSET_ABLATE_NOMFMA
-#pragma unroll
-      for (int j = 0; j < KH; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w1[j], acc1, 0, 0, 0);
-      }
-#else
-#pragma unroll
-      for (int j = 0; j < KH; ++j) { acc0[j & 15] += a[j] * w0[j & 3]; acc1[j & 15] += a[j] * w1[j & 3]; }
-#endif
-      // acc[k] is row (k&3) + 8*(k>>2) + 4*half, column tile*32 + rin
-      const int c0 = (tp + 0) * 32 + rin, c1 = (tp + 1) * 32 + rin;
-      const float bias0 = sBias[c0], bias1 = sBias[c1];
-      float* ybase = y + (chunk * 32 + 4 * half) * ldy;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int rl = (k & 3) + 8 * (k >> 2);
-        const int64_t r = chunk * 32 + 4 * half + rl;
-        if (r < n) {
-          float v0 = acc0[k] + bias0, v1 = acc1[k] + bias1;
-          if (relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          if constexpr (DROP_OUT) {
-            v0 *= keep_scale(seed_out, r * N + c0, thr_out, keep_out);
-            v1 *= keep_scale(seed_out, r * N + c1, thr_out, keep_out);
-          }
-          float* yr = ybase + rl * ldy;
-#ifdef ALLSET_ABLATE_NOSTORE
-          if (v0 == 123.456f && v1 == 654.321f) { yr[c0] = v0; yr[c1] = v1; }     // keeps the values live
-#else
-          yr[c0] = v0;
-          yr[c1] = v1;
-#endif
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-
 // ---- the same forward on the bf16 matrix pipe (bf16x6, see common.h) -----------------------------------------------
 // v_mfma_f32_16x16x32_bf16: lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] as 8 packed bf16 (4 VGPRs), B likewise for
 // column (l&15); C/D: column l&15, rows 4*(l>>4) + 0..3.  The k-order is free, so lane (i, g = l>>4) keeps the
@@ -476,169 +329,6 @@ __global__ __launch_bounds__(fwd_x6_waves<HAS_LN>() * kWave) void fused_linear_f
     process(a1, chunk + stride);
   }
   if (chunk < n_chunks) process(a0, chunk);
-}
-
-// ---- backward w.r.t. the input of the fused Linear --------------------------------------------------------------
-//   ga = gy * (y > 0 ? keep_out : 0)   (if y != nullptr: relu/dropout epilogue of the forward)      [A operand, registers]
-//   gu = ga @ W                         (K = O out-features, N = I in-features; B operand = W rows, unit stride in LDS)
-//   gz = gu * dropout_in mask           (regenerated from seed_in)
-//   HAS_LN : gx = LayerNorm-backward(gz; x, stats, gamma) (through relu_in), dgamma/dbeta partials per wave
-//   else   : gx = gz (through relu_in)
-// One wave owns 32 complete rows, so the two row reductions of the LayerNorm backward (sum gh, sum gh*xhat) are
-// in-wave: 4 accumulator tiles per lane + a 32-lane xor butterfly.
-template <int OD, int IT, bool HAS_LN, bool DROP_IN>
-__global__ __launch_bounds__(kFusedBlock) void fused_linear_bwd_kernel(
-    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ y, int64_t ldy, float p_out,
-    const float* __restrict__ W, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats,
-    const float* __restrict__ gamma, int relu_in, float p_in, uint64_t seed_in, float* __restrict__ gx,
-    int64_t ldgx, float* __restrict__ part, int64_t n, const uint64_t* __restrict__ seed_base) {
-  seed_in = resolve_seed(seed_base, seed_in);
-  constexpr int I = 32 * IT;
-  constexpr int OH = OD / 2;
-  __shared__ __attribute__((aligned(16))) float sW[OD * I];          // W as stored: [o][i], unit stride in i
-  __shared__ float sG[I];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < OD * I / 4; idx += kFusedBlock)
-    reinterpret_cast<float4*>(sW)[idx] = reinterpret_cast<const float4*>(W)[idx];
-  for (int idx = tid; idx < I; idx += kFusedBlock) sG[idx] = HAS_LN ? gamma[idx] : 1.f;
-  __syncthreads();
-
-  const int lane = tid & 63, wave = tid >> 6;
-  const int rin = lane & 31, half = lane >> 5;
-  const float inv_i = 1.f / static_cast<float>(I);
-  const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
-  const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
-  const uint32_t thr_in = drop_threshold(p_in);
-  const int64_t n_chunks = (n + 31) / 32;
-  if (wave >> 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-  float dg[IT], db[IT];
-#pragma unroll
-  for (int t = 0; t < IT; ++t) { dg[t] = 0.f; db[t] = 0.f; }
-
-  for (int64_t chunk = static_cast<int64_t>(blockIdx.x) * kFusedWaves + wave; chunk < n_chunks;
-       chunk += static_cast<int64_t>(gridDim.x) * kFusedWaves) {
-    const int64_t row = chunk * 32 + rin;
-    const bool valid = row < n;
-    float a[OH];
-#pragma unroll
-    for (int jb = 0; jb < OH; jb += 16) {            // blocks of 16 columns: bounded landing registers
-      if (valid) {
-        const float4* gr = reinterpret_cast<const float4*>(gy + row * ldg + half * OH + jb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = gr[q];
-          a[jb + 4 * q] = v.x; a[jb + 4 * q + 1] = v.y; a[jb + 4 * q + 2] = v.z; a[jb + 4 * q + 3] = v.w;
-        }
-        if (y != nullptr) {
-          const float4* yr = reinterpret_cast<const float4*>(y + row * ldy + half * OH + jb);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = yr[q];
-            a[jb + 4 * q] = v.x > 0.f ? a[jb + 4 * q] * keep_out : 0.f;
-            a[jb + 4 * q + 1] = v.y > 0.f ? a[jb + 4 * q + 1] * keep_out : 0.f;
-            a[jb + 4 * q + 2] = v.z > 0.f ? a[jb + 4 * q + 2] * keep_out : 0.f;
-            a[jb + 4 * q + 3] = v.w > 0.f ? a[jb + 4 * q + 3] * keep_out : 0.f;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = jb; j < jb + 16; ++j) a[j] = 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    f32x16 acc[IT];
-#pragma unroll
-    for (int t = 0; t < IT; ++t)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    const float* wb = sW + (half * OH) * I + rin;
-#pragma unroll
-    for (int j = 0; j < OH; ++j) {
-#pragma unroll
-      for (int t = 0; t < IT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wb[j * I + t * 32], acc[t], 0, 0, 0);
-    }
-    // ---- epilogue: acc[t][k] is row (k&3) + 8*(k>>2) + 4*half, column t*32 + rin.
-    // All x values / row statistics of the chunk are requested in ONE batch (the A-operand registers are dead by
-    // now), so the epilogue pays one memory latency instead of one per row.
-    float xraw[16 * IT];
-    float2 st[16];
-    if (HAS_LN || relu_in) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int64_t r = chunk * 32 + (k & 3) + 8 * (k >> 2) + 4 * half;
-        const bool live = r < n;
-        if constexpr (HAS_LN) st[k] = live ? *reinterpret_cast<const float2*>(stats + r * 2) : make_float2(0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < IT; ++t) xraw[k * IT + t] = live ? x[r * ldx + t * 32 + rin] : 1.f;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16 * IT; ++k) xraw[k] = 1.f;
-    }
-    float gam[IT];
-#pragma unroll
-    for (int t = 0; t < IT; ++t) gam[t] = sG[t * 32 + rin];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int rl = (k & 3) + 8 * (k >> 2) + 4 * half;
-      const int64_t r = chunk * 32 + rl;
-      const bool live = r < n;
-      float gz[IT], xh[IT];
-      float rstd = 0.f;
-#pragma unroll
-      for (int t = 0; t < IT; ++t) {
-        gz[t] = live ? acc[t][k] : 0.f;
-        if constexpr (DROP_IN) gz[t] *= keep_scale(seed_in, r * I + t * 32 + rin, thr_in, keep_in);
-        xh[t] = 0.f;
-        if constexpr (HAS_LN) {
-          rstd = st[k].y;
-          const float xr = relu_in ? fmaxf(xraw[k * IT + t], 0.f) : xraw[k * IT + t];
-          xh[t] = live ? (xr - st[k].x) * rstd : 0.f;
-          dg[t] = fmaf(gz[t], xh[t], dg[t]);
-          db[t] += gz[t];
-        }
-      }
-      if constexpr (HAS_LN) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int t = 0; t < IT; ++t) {
-          const float gh = gz[t] * gam[t];
-          s1 += gh;
-          s2 = fmaf(gh, xh[t], s2);
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-        s1 *= inv_i; s2 *= inv_i;
-        if (live) {
-#pragma unroll
-          for (int t = 0; t < IT; ++t) {
-            float o = rstd * (gz[t] * gam[t] - s1 - xh[t] * s2);
-            if (relu_in && !(xraw[k * IT + t] > 0.f)) o = 0.f;
-            gx[r * ldgx + t * 32 + rin] = o;
-          }
-        }
-      } else {
-        if (live) {
-#pragma unroll
-          for (int t = 0; t < IT; ++t) {
-            float o = gz[t];
-            if (relu_in && !(xraw[k * IT + t] > 0.f)) o = 0.f;
-            gx[r * ldgx + t * 32 + rin] = o;
-          }
-        }
-      }
-    }
-  }
-  if constexpr (HAS_LN) {     // per-wave partials of dgamma / dbeta: part[wave_global][0|1][I]
-    float* pw = part + (static_cast<int64_t>(blockIdx.x) * kFusedWaves + wave) * 2 * I;
-#pragma unroll
-    for (int t = 0; t < IT; ++t) {
-      const float g = dg[t] + __shfl_xor(dg[t], 32);
-      const float b = db[t] + __shfl_xor(db[t], 32);
-      if (half == 0) { pw[t * 32 + rin] = g; pw[I + t * 32 + rin] = b; }
-    }
-  }
 }
 
 // ---- backward-data on the bf16 matrix pipe (same scheme as fused_linear_fwd_x6_kernel) ---------------------------------
@@ -944,7 +634,7 @@ using namespace allset;
 
 extern "C" int64_t allset_fused_linear_mask_words(int64_t n, int64_t N) {
   // 1 bit per output element in 16-row x 64-column blocks of 32 dwords; 0 = this build/mode has no mask support
-  if (!dense_mfma_x6() || n <= 0 || N % 64 != 0) return 0;
+  if (n <= 0 || N % 64 != 0) return 0;
   return ((n + 15) / 16) * (N / 64) * 32;
 }
 
@@ -972,15 +662,7 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
                                  void* stream, int64_t xcb, int64_t ycb) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
-  if (aux_out != nullptr && !dense_mfma_x6()) {
-    set_error("fused_linear_fwd: auxiliary output columns are computed by the bf16x6 kernels only");
-    return ALLSET_ERR_UNSUPPORTED;
-  }
   ALLSET_REQUIRE(aux_out == nullptr || (aux_w != nullptr && aligned16(aux_out)), "fused_linear_fwd: aux_out needs aux_w and 16-byte alignment");
-  if (mask_out != nullptr && !dense_mfma_x6()) {
-    set_error("fused_linear_fwd: the activation mask is produced by the bf16x6 kernels only (allset_fused_linear_mask_words)");
-    return ALLSET_ERR_UNSUPPORTED;
-  }
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_fwd: dropout p must be in [0,1)");
   if (!allset_fused_linear_supported(K, N)) {
     set_error("fused_linear_fwd: K=%lld N=%lld not built (K, N in {64,128})", static_cast<long long>(K), static_cast<long long>(N));
@@ -1010,26 +692,14 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
               "(allset_fused_linear_blocked_supported)");
     return ALLSET_ERR_UNSUPPORTED;
   }
-  const int64_t chunks = (n + 31) / 32;
-  int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
-  if (blocks > 512) blocks = 512;                         // persistent workgroups
-  const unsigned grid = static_cast<unsigned>(blocks);
-  const bool x6 = dense_mfma_x6();
   const int waves_x6 = has_ln ? fwd_x6_waves<true>() : fwd_x6_waves<false>();
   int64_t blocks_x6 = ((n + 15) / 16 + waves_x6 - 1) / waves_x6;
   if (blocks_x6 > 256) blocks_x6 = 256;                   // one persistent workgroup per CU
   const unsigned grid_x6 = static_cast<unsigned>(blocks_x6);
 #define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                           \
-  do {                                                                                                                   \
-    if (x6)                                                                                                              \
-      fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, fwd_x6_waves<LN>() * kWave, 0, st>>>(                                      \
-          x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
-          seed_base, reinterpret_cast<uint8_t*>(mask_out), aux_w, aux_b, aux_out);                                       \
-    else                                                                                                                 \
-      fused_linear_fwd_kernel<KD, NT, LN, DI, DO><<<grid, kFusedBlock, 0, st>>>(                                         \
-          x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,        \
-          seed_base);                                                                                                    \
-  } while (0)
+  fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, fwd_x6_waves<LN>() * kWave, 0, st>>>(                     \
+      x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,            \
+      seed_base, reinterpret_cast<uint8_t*>(mask_out), aux_w, aux_b, aux_out)
 #define ALLSET_FUSED_FWD(KD, NT)                                                      \
   do {                                                                                \
     const int v = (has_ln ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);    \
@@ -1054,16 +724,9 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
   return ALLSET_OK;
 }
 
-static inline unsigned fused_grid(int64_t n) {
-  if (dense_mfma_x6()) {                                   // 16-row chunks, one persistent 8-wave workgroup per CU
-    int64_t blocks = ((n + 15) / 16 + kX6Waves - 1) / kX6Waves;
-    return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));
-  }
-  const int64_t chunks = (n + 31) / 32;
-  int64_t blocks = (chunks + kFusedWaves - 1) / kFusedWaves;
-  if (blocks > 512) blocks = 512;
-  if (blocks < 1) blocks = 1;
-  return static_cast<unsigned>(blocks);
+static inline unsigned fused_grid(int64_t n) {                 // 16-row chunks, one persistent 8-wave workgroup per CU
+  int64_t blocks = ((n + 15) / 16 + kX6Waves - 1) / kX6Waves;
+  return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));
 }
 
 extern "C" int allset_fused_linear_bwd_partials(int64_t n, int64_t* n_partials) {
@@ -1081,20 +744,8 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
                                        int64_t ldacc, const float* aux_g, const float* aux_w, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd: negative size");
-  if (aux_g != nullptr && !dense_mfma_x6()) {
-    set_error("fused_linear_bwd: the auxiliary rank-4 update is done by the bf16x6 kernels only");
-    return ALLSET_ERR_UNSUPPORTED;
-  }
   ALLSET_REQUIRE(aux_g == nullptr || (aux_w != nullptr && aligned16(aux_g) && aligned16(aux_w)), "fused_linear_bwd: aux_g needs aux_w, both 16-byte aligned");
-  if (acc_in != nullptr && !dense_mfma_x6()) {
-    set_error("fused_linear_bwd: acc_in is taken by the bf16x6 kernels only");
-    return ALLSET_ERR_UNSUPPORTED;
-  }
   ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && aligned16(acc_in)), "fused_linear_bwd: acc_in must be 16-byte aligned rows");
-  if (mask != nullptr && !dense_mfma_x6()) {
-    set_error("fused_linear_bwd: the activation mask is consumed by the bf16x6 kernels only");
-    return ALLSET_ERR_UNSUPPORTED;
-  }
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_bwd: dropout p must be in [0,1)");
   if (!allset_fused_linear_supported(I, O)) {
     set_error("fused_linear_bwd: in=%lld out=%lld not built (both in {64,128})", static_cast<long long>(I), static_cast<long long>(O));
@@ -1110,29 +761,19 @@ extern "C" int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float
     return ALLSET_OK;
   }
   ALLSET_REQUIRE(gy && W, "fused_linear_bwd: null pointer");
-  ALLSET_REQUIRE(gx != nullptr || (dense_mfma_x6() && stats != nullptr),
-                 "fused_linear_bwd: gx may be NULL only to get the LayerNorm partials alone (bf16x6 kernels)");
+  ALLSET_REQUIRE(gx != nullptr || stats != nullptr, "fused_linear_bwd: gx may be NULL only to get the LayerNorm partials alone");
   ALLSET_REQUIRE((has_ln || relu_in) ? x != nullptr : true, "fused_linear_bwd: x required for LayerNorm / relu backward");
   ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && aligned16(gy) && aligned16(W), "fused_linear_bwd: gy/W must be 16-byte aligned rows");
   ALLSET_REQUIRE(y == nullptr || (ldy >= O && ldy % 4 == 0 && aligned16(y)), "fused_linear_bwd: y must be 16-byte aligned rows");
   ALLSET_REQUIRE(ldgx >= I && (x == nullptr || ldx >= I), "fused_linear_bwd: leading dimension too small");
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool x6 = dense_mfma_x6();
-  if (x6) {
-    ALLSET_REQUIRE((gx == nullptr || (ldgx % 4 == 0 && aligned16(gx))) && (x == nullptr || (ldx % 4 == 0 && aligned16(x))),
-                   "fused_linear_bwd: gx / x must be 16-byte aligned rows");
-    ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd: stats must be 8-byte aligned");
-  }
+  ALLSET_REQUIRE((gx == nullptr || (ldgx % 4 == 0 && aligned16(gx))) && (x == nullptr || (ldx % 4 == 0 && aligned16(x))),
+                 "fused_linear_bwd: gx / x must be 16-byte aligned rows");
+  ALLSET_REQUIRE(stats == nullptr || (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "fused_linear_bwd: stats must be 8-byte aligned");
 #define ALLSET_FUSED_BWD_F(OD, IT, LN, DI)                                                                                   \
-  do {                                                                                                                       \
-    if (x6)                                                                                                                  \
-      fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI, false><<<grid, kX6Block, 0, st>>>(                                     \
-          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask,   \
-          acc_in, ldacc, nullptr, nullptr);                                                                                  \
-    else                                                                                                                     \
-      fused_linear_bwd_kernel<OD, IT, LN, DI><<<grid, kFusedBlock, 0, st>>>(                                                 \
-          gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base);        \
-  } while (0)
+  fused_linear_bwd_x6_kernel<OD, 32 * IT, LN, DI, false><<<grid, kX6Block, 0, st>>>(                                         \
+      gy, ldg, y, ldy, p_out, W, x, ldx, stats, gamma, relu_in, p_in, seed_in, gx, ldgx, partials, n, seed_base, mask,       \
+      acc_in, ldacc, nullptr, nullptr)
 #define ALLSET_FUSED_BWD(OD, IT)                                          \
   do {                                                                    \
     if (has_ln) { if (p_in > 0.f) ALLSET_FUSED_BWD_F(OD, IT, true, true); else ALLSET_FUSED_BWD_F(OD, IT, true, false); }     \

@@ -315,7 +315,7 @@ def fused_linear_supported(K: int, N: int) -> bool:
 
 
 def x6_active() -> bool:
-    """The default bf16x6 kernel family is selected (ALLSET_DENSE_MFMA unset): mask / acc_in / aux features exist."""
+    """Always true since ABI 9 (one kernel family: fp32-accurate arithmetic on the bf16 matrix pipe); kept for callers."""
     return int(_lib.load().allset_fused_linear_mask_words(16, 64)) > 0
 
 
@@ -500,7 +500,7 @@ def one_pass_preferred(O: int, I: int) -> bool:
     """True when ``allset_fused_linear_bwd_all`` launches one of the two-waves-per-SIMD kernels for these widths (round 3:
     O = I = 128; one partial slice per workgroup instead of one per wave).  Those beat the backward-data + weight-gradient pair
     also for a Linear WITHOUT a LayerNorm prologue (0.35-0.4 ms against 0.21 + 0.32); the one-wave kernel did not."""
-    key = (int(O), int(I), os.environ.get("ALLSET_BWD_ROLES", ""), os.environ.get("ALLSET_BWD_STAGE", ""), os.environ.get("ALLSET_DENSE_MFMA", ""))
+    key = (int(O), int(I))                                          # the dispatch is a pure function of the widths (ABI 9)
     hit = _ONE_PASS_PREFERRED.get(key)
     if hit is None:
         lib = _lib.load()

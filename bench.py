@@ -2,7 +2,14 @@
 """bench.py -- edges*d aggregated / sec for one V->E->V AllSet layer, forward + backward, on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched under
-``python -m torch.distributed.run --nproc-per-node N``, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+``python -m torch.distributed.run --nproc-per-node N``, one rank per GPU, RCCL -- or bare: without RANK in the environment
+``--gpus N`` spawns that launcher itself).  Prints ONE JSON line on rank 0's stdout, always:
+  * N > 1 runs its timed regions in the order rows -> (link preflight) -> columns -> primary with the bf16 wire; every region
+    runs under a watchdog deadline (``--region-timeout``).  A region that raises is recorded under ``partitions`` and skipped; a
+    region that HANGS (a collective that never completes) makes the watchdog print the line assembled from the regions that did
+    finish and end the process with exit code 0 -- the first region's result is never lost to a later one.
+  * after the first region rank 0 also writes that region's line to STDERR (``[bench] early line ...``), for a log reader;
+    stdout carries exactly one line.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
 synthetic random hypergraph, |V| = |E| = 1M per GPU, every hyperedge has 16 distinct uniformly drawn members
@@ -20,9 +27,10 @@ N > 1 -- two partitions of the same job (allset_amd/dist.py, DESIGN.md section 7
            one reduce-scatter of the [n_V, d] vertex table per direction;
   columns  column-sharded aggregation: every rank holds the whole incidence and d/N feature columns of every row;
            four all-to-alls per direction-pair, 1/N of the row scheme's bytes at N = 8, overlapped with the dense work.
-``--shard auto`` (default) times the one ``allset_amd.dist.choose_sharding`` picks as ``value`` / ``ms_per_step``
-(reported in ``config.parallelism``) and then, in a second timed region of the same K steps, the other one; both
-appear under ``partitions`` so a scaling record always carries the north-star partition too.
+``--shard auto`` (default) reports the one ``allset_amd.dist.choose_sharding`` picks as ``value`` / ``ms_per_step``
+(``config.parallelism`` says which); both are timed, each in its own region of the same K steps, and appear under
+``partitions``, so a scaling record always carries the north-star partition too.  ``preflight`` = the layer's four
+collectives timed alone at this job's message sizes (GB/s per rank and per xGMI link).
 
 Extra objects in the JSON line:
   roofline      the dominant gather kernel: algorithmic bytes per launch (SURVEY section 8(d3):
@@ -30,13 +38,15 @@ Extra objects in the JSON line:
                 stream INSIDE the timed region; peak = 8 TB/s HBM3E.  ``frac_of_copy_ceiling`` = the same rate over the
                 6.3 TB/s streaming-copy ceiling of MI355X_MICROARCH.md; ``traffic`` = HBM bytes per launch from the
                 committed rocprofv3 --pmc passes at exactly this shape (``traffic_source`` says which file; null at
-                any other shape -- it is a profile of the same kernel and shape, not a counter of this run);
+                any other shape, and null when the gather kernels' sources / flags differ from the ones the passes
+                were taken with -- it is a profile of the same kernel and shape, not a counter of this run);
+                ``layer_frac`` = the aggregation's algorithmic bytes per step / the WHOLE step time / peak;
                 ``per_kernel`` = the same arithmetic for every timed kernel that states its algorithmic bytes.
   aggregation   the aggregation-only figure (all gather-kernel time per step): the north star's
                 "% of HBM roofline on the V->E->V aggregation".
   cpu_baseline  the oracle (a restatement of the reference's CPU torch_scatter path) timed on this box's host cores
-                on the SAME hypergraph and features the GPU ran (copied back), one iteration at full size after a
-                warm-up on a 1/10 sample (rank 0, N = 1 only).
+                on the SAME hypergraph and features the GPU ran (copied back), median of ``--cpu-iters`` (3) iterations at
+                full size after a warm-up on a 1/10 sample (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -100,7 +110,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0,
                     help="|V| = |E| of the CPU-baseline sample (0 = the GPU workload itself, copied back to the host)")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU iterations (median reported; BASELINE.md section 3: >= 3)")
+    ap.add_argument("--region-timeout", type=float, default=300.0,
+                    help="N > 1: seconds a timed region (or the preflight) may take before bench.py's watchdog prints the line from "
+                         "the regions that finished and ends the process (the first region gets 3x)")
+    ap.add_argument("--preflight", default="auto", choices=["auto", "on", "off"],
+                    help="time the layer's four collectives at this job's message sizes after the first region and report GB/s per "
+                         "link under `preflight` (auto = when N > 1)")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 is the fastest setting for torch's scatter_add_/"
                          "index_select on the 2x128-thread GPU box: profiles/r01_cpu_threads_probe.txt)")
@@ -242,7 +258,13 @@ def hbm_traffic_from_profile(kernel="segreduce_fwd", shape="c3"):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         try:
-            val = json.load(open(path)).get(f"{kernel}_bytes_per_launch")
+            prof = json.load(open(path))
+            val = prof.get(f"{kernel}_bytes_per_launch")
+            if prof.get("kernel_source_sha") != kernel_source_sha():
+                # the gather kernels (or their flags) changed since the PMC passes were taken: a stale profile is not reported
+                return None, (f"profiles/{name} was taken with other kernel sources (its kernel_source_sha "
+                              f"{prof.get('kernel_source_sha')!r} != {kernel_source_sha()!r}): re-run tools/pmc_probe"
+                              + ("_c5" if shape == "c5" else "") + ".py under rocprofv3 --pmc and tools/pmc_sum.py --stamp")
             if val is not None:
                 return val, (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (gfx950 corrections of "
                              "MI355X_MICROARCH.md) of this kernel at exactly this shape, taken with tools/pmc_probe" + ("_c5" if shape == "c5" else "") + ".py; "
@@ -399,15 +421,275 @@ def kernel_entry(v, steps, rows=None, d=None, name=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launching, hang protection, link preflight
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv=None) -> int:
+    """``python bench.py --gpus N`` OUTSIDE ``torch.distributed.run`` (no RANK in the environment): spawn the N ranks here --
+    the same launcher command the driver documents, rendezvous on 127.0.0.1 and a free port -- and hand its exit code back.
+    Rank 0's stdout (the ONE JSON line) is inherited, so the bare command prints what the launched one prints."""
+    import subprocess
+    out = []
+    for t in list(sys.argv[1:] if argv is None else argv):      # the launcher's own argparse would eat a bare `--d` (see parse_args)
+        out.append("--feature-dim" if t == "--d" else ("--feature-dim=" + t[4:] if t.startswith("--d=") else t))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + out
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL between processes needs it on this host driver
+    print(f"[bench] --gpus {args.gpus} without a launcher: spawning {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+class Watchdog:
+    """One deadline at a time, watched from a daemon thread.  A collective that never completes blocks the main thread inside
+    RCCL / a device synchronise (both release the GIL) for ever -- ``try/except`` sees nothing, and the process group's own
+    watchdog would abort the process and lose everything measured so far.  When a deadline passes, ``on_expire(label)`` runs on
+    this thread; bench.py's handler prints the line assembled from the regions that DID finish and ends the process."""
+
+    def __init__(self, on_expire):
+        import threading
+        self._cv = threading.Condition()
+        self._deadline, self._label, self._on_expire = None, None, on_expire
+        threading.Thread(target=self._run, daemon=True, name="bench-watchdog").start()
+
+    def arm(self, seconds: float, label: str) -> None:
+        with self._cv:
+            self._deadline, self._label = time.monotonic() + seconds, label
+            self._cv.notify()
+
+    def disarm(self) -> None:
+        with self._cv:
+            self._deadline = None
+            self._cv.notify()
+
+    def _run(self):
+        while True:
+            with self._cv:
+                if self._deadline is None:
+                    self._cv.wait()
+                    continue
+                left = self._deadline - time.monotonic()
+                if left > 0:
+                    self._cv.wait(left)
+                    continue
+                label, self._deadline = self._label, None
+            self._on_expire(label)
+
+
+def _test_hang(label: str, rank: int) -> None:
+    """Test hook (tests/test_gpu_two_ranks.py, tests/test_bench_setup.py): ALLSET_BENCH_TEST_HANG="<region>:<rank>" parks that
+    rank at the start of that region, so its peers block in the region's first collective exactly as behind a dead link."""
+    spec = os.environ.get("ALLSET_BENCH_TEST_HANG", "")
+    if spec and spec == f"{label}:{rank}":
+        time.sleep(10 ** 6)
+
+
+def preflight_collectives(args, world: int, rank: int, dev, iters: int = 5):
+    """The four collectives the sharded layers issue (allset_amd/dist.py), through the same wrappers and at THIS job's message
+    sizes, timed one by one (max over ranks, median of ``iters``): the measured per-link rate that DESIGN.md section 7.3's
+    projection needs.  ``sent`` = bytes one rank sends per call; per_link = sent / (N - 1) / time on the fully connected xGMI mesh."""
+    from allset_amd import dist as adist
+    n, d = args.n_per_gpu, args.d
+    on_gpu = dev.type == "cuda"
+
+    def timed(fn):
+        ts = []
+        for it in range(iters + 1):
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            fn()
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            adist._all_reduce_(t, dist.ReduceOp.MAX)
+            if it:                                                    # first call: communicator / buffer set-up
+                ts.append(float(t[0]))
+        return statistics.median(ts)
+
+    f = (world - 1) / world
+    out = {}
+
+    def entry(name, sent, sec):
+        links = max(world - 1, 1)
+        out[name] = {"sent_bytes_per_rank": int(sent), "ms": sec * 1e3, "gbps_per_rank": sent / sec / 1e9,
+                     "gbps_per_link": sent / links / sec / 1e9}
+
+    for wire, dt, es in (("f32", torch.float32, 4), ("bf16", torch.bfloat16, 2)):
+        own = torch.randn(n, d, device=dev).to(dt)                    # this rank's owned rows, all columns
+        part = torch.randn(world * n, d, device=dev).to(dt)           # per-rank partial sums for every vertex
+        entry(f"{wire} all_gather [n,d]->[N*n,d] (rows scheme, one per direction)", n * d * es * (world - 1),
+              timed(lambda: adist._all_gather_rows(own)))
+        if wire == "f32" or dist.get_backend() != "gloo":             # (gloo reduces fp32 only; the bf16 wire never reduce-scatters)
+            entry(f"{wire} reduce_scatter [N*n,d]->[n,d] (rows scheme)", world * n * d * es * f,
+                  timed(lambda: adist._reduce_scatter_rows(part)))
+        if d % world == 0:
+            send = own.view(n, world, d // world).transpose(0, 1).contiguous()
+            recv = torch.empty_like(send)
+            entry(f"{wire} all_to_all [n,d]<->[N*n,d/N] (column scheme, eight per step)", n * d * es * f,
+                  timed(lambda: adist._all_to_all_single(recv, send)))
+        del own, part
+    flat = torch.randn(200_000, device=dev)
+    entry("f32 all_reduce of the flat parameter gradient (0.8 MB)", flat.numel() * 4 * 2 * f, timed(lambda: adist._all_reduce_(flat)))
+    return {"collectives": out, "iters": iters, "backend": dist.get_backend(),
+            "note": "each call timed alone between barriers, max over ranks, median; per_link = sent / (N-1) links / time"}
+
+
+def kernel_source_sha() -> str:
+    """Hash of what determines segreduce_kernel's code object: its source, the shared header and the compiler flags.  Stored
+    beside profiles/hbm_traffic*.json when the PMC passes are taken (tools/pmc_sum.py --stamp); ``roofline.traffic`` is null
+    when the library in use was built from anything else."""
+    import hashlib
+    from allset_amd import build as _build
+    h = hashlib.sha256()
+    for name in ("segreduce.hip", "pma.hip", "common.h"):
+        with open(os.path.join(_build.CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(_build.CXXFLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the JSON line
+# ---------------------------------------------------------------------------------------------------------------------
+
+def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
+    """The ONE JSON line from whatever regions have finished (``state['results']``: partition name -> run_partition result).
+    ``value`` is the primary partition's if it finished, otherwise the first finished region's (labelled).  None if nothing has."""
+    results, errors = state["results"], state["errors"]
+    value_key = primary if primary in results else next((k for k in state["order"] if k in results and "+" not in k), None)
+    if value_key is None:
+        return None
+    res = results[value_key]
+    d, attn = args.d, args.model == "pma"
+    ks = res["kernels"]
+    agg_ks = {k: v for k, v in ks.items() if k in AGG_KERNELS}                   # HBM-bound gather kernels
+    dense_ks = {k: v for k, v in ks.items() if k not in AGG_KERNELS}             # dense tail (MFMA / streaming)
+    dom = max(agg_ks, key=lambda k: agg_ks[k]["total_ms"]) if agg_ks else None   # dominant aggregation kernel
+    seg = agg_ks.get(dom) if dom else None
+    agg_ms = sum(v["total_ms"] for v in agg_ks.values()) / args.steps
+    dense_ms = sum(v["total_ms"] for v in dense_ks.values()) / args.steps
+    agg_bytes = sum(v["algo_bytes"] * v["calls"] for v in agg_ks.values() if v.get("algo_bytes")) / args.steps
+    all_bytes = sum(v["algo_bytes"] * v["calls"] for v in ks.values() if v.get("algo_bytes")) / args.steps
+    # the PMC passes were taken at exactly this shape (tools/pmc_probe.py); any other shape reports null
+    at_profiled_shape = (world == 1 and args.n_per_gpu == 1_000_000 and d == 128 and args.degree == 16
+                         and args.degree_dist == "fixed" and args.dtype == "f32" and not args.self_loops
+                         and (not attn or args.heads == 4))
+    at_c5_shape = (world == 1 and args.n_per_gpu == 250_000 and d == 256 and args.degree == 16 and args.degree_dist == "zipf"
+                   and args.dtype == "bf16" and not args.self_loops and attn and args.heads == 4 and args.seed == 20260928)
+    traffic, traffic_source = hbm_traffic_from_profile(dom) if (at_profiled_shape and dom) else (
+        hbm_traffic_from_profile(dom, "c5") if (at_c5_shape and dom) else (None, None))
+    roofline = None
+    if seg:
+        achieved = seg["algo_bytes"] / (seg["avg_ms"] * 1e-3) / 1e9
+        step_s = res["ms_per_step"] * 1e-3
+        roofline = {"bound": "hbm", "kernel": f"allset_{dom}",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "frac_of_copy_ceiling": achieved / COPY_CEILING_GBS,
+                    "layer_frac": agg_bytes / step_s / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
+                    "layer_frac_all_bytes": all_bytes / step_s / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
+                    "layer_note": "layer_frac = the aggregation's algorithmic bytes per step (all gather passes, SURVEY 8(d3)) / the WHOLE "
+                                  "step time (dense tail and Adam included) / peak: the north star's '>= 40 % of HBM roofline on the "
+                                  "V->E->V aggregation' held against the full step; layer_frac_all_bytes also counts the dense "
+                                  "tail's algorithmic activation bytes",
+                    "note": "achieved = SURVEY 8(d3) gather-model bytes / HIP-event launch time; the rate can exceed the 6.3 TB/s "
+                            "streaming-copy ceiling because each source row is gathered `degree` times and part of the table is "
+                            "served by the 256 MiB Infinity Cache (FETCH_SIZE counts at the L2's fabric side, cache hits "
+                            "included); DRAM-only bytes are not exposed by rocprofv3 on gfx950",
+                    "algo_bytes_per_launch": seg["algo_bytes"], "avg_launch_ms": seg["avg_ms"], "launches": seg["calls"],
+                    "per_kernel": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in ks.items() if v.get("algo_bytes")}}
+    nnz_total = res["nnz_total"]
+    line = {
+        "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": res["value"], "unit": "edges*d/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "dtype_note": ("fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: every fp32 operand split exactly "
+                       "into three bf16, six of the nine partial products formed on the bf16 matrix pipe and accumulated in "
+                       "fp32 -- measured error vs float64 <= that of the native fp32 MFMA / hipBLASLt (DESIGN.md section 6)")
+        if args.dtype == "f32" else
+        ("bf16 tensors end to end (BASELINE configs[4] regime): bf16 instantiations of the gather kernels with fp32 "
+         "accumulation and fp32 softmax statistics; dense tail: this library's bf16 kernels (fp32 arithmetic and "
+         "accumulation, bf16 in / out)"),
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{cfg_index(args)}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph "
+                               f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}), "
+                               f"nnz={int(nnz_total)}, d={d}, " +
+                               (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
+                                f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), ") +
+                               "fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
+                   "n_v": res["n_v"], "n_e": res["n_e"], "nnz": int(nnz_total), "d": d,
+                   "parallelism": parallelism_label(args, value_key, world), "partition": value_key if world > 1 else None,
+                   "seed": args.seed, "launch": "one hipGraph replay per step" if (args.hip_graph and world == 1) else "eager launches"},
+        "roofline": roofline,
+        "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if (world == 1 and agg_ms > 0) else None,
+                        "unit": "edges*d/s", "note": "gather/segment-reduce kernel time per step (HIP events, rank 0): "
+                        "the aggregation-only V->E->V fwd+bwd",
+                        "kernels": {k: kernel_entry(v, args.steps) for k, v in agg_ks.items()}},
+        "dense_tail": {"ms_per_step": dense_ms, "note": ("HIP dense-tail kernels per step (fused norm+Linear forward; ONE backward "
+                       "kernel per Linear producing input gradient, LayerNorm parameter gradients and the weight / bias "
+                       "gradient from a single read of gy and x). fp32 in, fp32 out, fp32-accurate arithmetic on the bf16 "
+                       "matrix pipe: operands split exactly into 3 bf16, 6 of 9 products accumulated in fp32 (error <= "
+                       "native fp32 MFMA, tests/test_gpu_dense.py); HBM-bound: gbps = algorithmic activation bytes / time")
+                       if args.dtype == "f32" else
+                       ("HIP dense-tail kernels per step, bf16 in / out with fp32 accumulation: Linear forward / backward-data "
+                        "with relu, folded logits, relu mask and gradient-branch sums in the same pass (csrc/fused_bf16.hip), "
+                        "full-width weight gradient, add+LayerNorm kernels; gbps = algorithmic activation bytes / time"),
+                       "kernels": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in dense_ks.items()}},
+    }
+    if dist.is_initialized():
+        line["config"]["collectives"] = ("gloo, device tensors staged through the host, ranks may share a device (test mode)"
+                                         if dist.get_backend() == "gloo" and not cpu_mode else
+                                         ("gloo (CPU test)" if cpu_mode else "RCCL (torch.distributed nccl backend)"))
+    if world > 1 or len(state["order"]) > 1:
+        parts = {}
+        for key in state["order"]:
+            base = key.split("+")[0]
+            label = parallelism_label(args, base, world)
+            if "+bf16wire" in key:
+                label += ("; bf16 wire format (opt-in, results within the restated tolerance of tests/test_dist_cpu.py, not "
+                          "bit-comparable)")
+            if key in results:
+                parts[key] = {"ms_per_step": results[key]["ms_per_step"], "value": results[key]["value"], "parallelism": label,
+                              "is_value": key == value_key}
+            elif key in errors:
+                parts[key] = {"error": errors[key], "parallelism": label, "is_value": False}
+            elif not final:
+                parts[key] = {"pending": True, "parallelism": label, "is_value": False}
+        if value_key != primary:
+            parts["value_note"] = (f"`value` is partition {value_key!r}: the partition this run would report ({primary!r}) did not "
+                                   "finish (see its entry)")
+        parts["note"] = ("`rows` = hyperedge shards, the partition BASELINE.json's north star names; `columns` = column-sharded "
+                         "aggregation (DESIGN.md section 7.2). Same global hypergraph, same K steps, separate timed regions (rows first: "
+                         "its all-gather / reduce-scatter are the plainest collectives, so a scaling record exists before the "
+                         "all-to-all paths run); `value` / `ms_per_step` of the line are those of the entry with is_value = true")
+        line["partitions"] = parts
+    if state.get("preflight") is not None or "preflight" in errors:
+        line["preflight"] = state.get("preflight") or {"error": errors["preflight"]}
+    line["cpu_baseline"] = state.get("cpu_baseline")
+    return line
+
+
 def main(argv=None, hooks=None):
     args = parse_args(argv)
     hooks = hooks or {}
+    if "RANK" not in os.environ and args.gpus > 1 and hooks.get("device") != "cpu":
+        raise SystemExit(self_launch(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE is 1)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cpu_mode = hooks.get("device") == "cpu"
     if cpu_mode:
@@ -424,12 +706,13 @@ def main(argv=None, hooks=None):
         dev = torch.device("cuda", local_rank)
     force = os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") == "1"      # 1-rank RCCL group: API check on a 1-GPU box
     if (world > 1 or (force and "RANK" in os.environ)) and not dist.is_initialized():
-        if cpu_mode:
-            dist.init_process_group("gloo")
-        elif backend == "gloo":
-            dist.init_process_group("gloo")
+        import datetime
+        # the group's own watchdog must never fire before bench.py's (it aborts the process and the line with it)
+        pg_timeout = datetime.timedelta(seconds=max(3600.0, 4 * args.region_timeout))
+        if cpu_mode or backend == "gloo":
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
 
     from allset_amd import dist as adist
     if not cpu_mode:
@@ -439,130 +722,88 @@ def main(argv=None, hooks=None):
         args.pipeline_chunks = adist.auto_chunks(args.n_per_gpu)
     primary, other = resolve_modes(args, world)
 
-    res = run_partition(args, primary, world, rank, dev, hooks)
-    res2, res2_error = None, None
-    if other is not None:
-        if not cpu_mode:
-            torch.cuda.empty_cache()
-        try:                                    # the secondary partition must not cost the primary its line
-            res2 = run_partition(args, other, world, rank, dev, hooks)
-        except Exception as exc:                # noqa: BLE001 -- reported in the line, the primary result stands
-            res2_error = f"{type(exc).__name__}: {exc}"
-            print(f"[bench] partition {other!r} failed on rank {rank}: {res2_error}", file=sys.stderr, flush=True)
+    # Region order.  N > 1 with both partitions: `rows` first whatever the primary is -- the north-star partition, on the
+    # plainest collectives (one all-gather, one reduce-scatter) -- so that a scaling record exists before any all-to-all runs.
+    order = [primary] + ([other] if other is not None else [])
+    if other is not None and "rows" in order:
+        order = ["rows"] + [m for m in order if m != "rows"]
+    wire_key = primary + "+bf16wire"
+    want_wire = world > 1 and args.dtype == "f32" and args.wire_entry and args.pipeline_chunks <= 1
+    want_preflight = dist.is_initialized() and (args.preflight == "on" or (args.preflight == "auto" and world > 1))
+    state = {"results": {}, "errors": {}, "order": order + ([wire_key] if want_wire else []), "preflight": None, "cpu_baseline": None}
+    exit_fn = hooks.get("exit", os._exit)
 
+    def on_expire(label):
+        state["errors"][label] = (f"timeout: region did not finish within its deadline ({args.region_timeout:.0f} s; first region "
+                                  f"{3 * args.region_timeout:.0f} s) -- a collective that never completed; bench.py's watchdog printed the "
+                                  "line from the regions that had finished and ended the process")
+        print(f"[bench] rank {rank}: region {label!r} timed out; ending the process", file=sys.stderr, flush=True)
+        if state.get("printed"):                                      # (teardown: the line is out already)
+            exit_fn(0)
+        line = assemble_line(args, world, primary, state, cpu_mode) if rank == 0 else None
+        if line is not None:
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+        exit_fn(0 if (rank != 0 or line is not None) else 3)
+
+    dog = Watchdog(on_expire) if dist.is_initialized() else None
+
+    def region(label, fn, first=False):
+        """Run ``fn`` under the watchdog.  The first region may raise (nothing to salvage); later ones are recorded and skipped."""
+        if dog is not None:
+            dog.arm(args.region_timeout * (3 if first else 1), label)
+        try:
+            _test_hang(label, rank)
+            return fn()
+        except Exception as exc:                                     # noqa: BLE001 -- reported in the line, earlier results stand
+            if first:
+                raise
+            state["errors"][label] = f"{type(exc).__name__}: {exc}"
+            print(f"[bench] region {label!r} failed on rank {rank}: {state['errors'][label]}", file=sys.stderr, flush=True)
+            return None
+        finally:
+            if dog is not None:
+                dog.disarm()
+
+    def partition_region(key, mode, first=False):
+        if not cpu_mode and not first:
+            torch.cuda.empty_cache()
+        res = region(key, lambda: run_partition(args, mode, world, rank, dev, hooks), first)
+        if res is not None:
+            state["results"][key] = res
+
+    partition_region(order[0], order[0], first=True)
+    if rank == 0:                                   # the early line: stderr only -- stdout carries exactly ONE JSON line, the final one
+        early = assemble_line(args, world, primary, state, cpu_mode, final=False)
+        print("[bench] early line (first region fenced): " + json.dumps(early), file=sys.stderr, flush=True)
+    if want_preflight:
+        state["preflight"] = region("preflight", lambda: preflight_collectives(args, world, rank, dev))
+    for mode in order[1:]:
+        partition_region(mode, mode)
     # N > 1: the primary partition once more with the opt-in bf16 WIRE format (allset_amd.dist.set_wire_dtype: fp32 tensors and
     # fp32 sums, every exchanged activation rounded once to bf16 -- half the bytes per link, results changed within the tolerance
     # tests/test_dist_cpu.py restates).  Its own `partitions` entry, never `value`.
-    res_wire, res_wire_error = None, None
-    if world > 1 and args.dtype == "f32" and args.wire_entry and args.pipeline_chunks <= 1:
+    if want_wire:
         prev = adist.set_wire_dtype(torch.bfloat16)
         try:
-            if not cpu_mode:
-                torch.cuda.empty_cache()
-            res_wire = run_partition(args, primary, world, rank, dev, hooks)
-        except Exception as exc:                # noqa: BLE001
-            res_wire_error = f"{type(exc).__name__}: {exc}"
+            partition_region(wire_key, primary)
         finally:
             adist.set_wire_dtype(prev)
 
     line = None
     if rank == 0:
-        d, attn = args.d, args.model == "pma"
-        ks = res["kernels"]
-        agg_ks = {k: v for k, v in ks.items() if k in AGG_KERNELS}                   # HBM-bound gather kernels
-        dense_ks = {k: v for k, v in ks.items() if k not in AGG_KERNELS}             # dense tail (MFMA / streaming)
-        dom = max(agg_ks, key=lambda k: agg_ks[k]["total_ms"]) if agg_ks else None   # dominant aggregation kernel
-        seg = agg_ks.get(dom) if dom else None
-        agg_ms = sum(v["total_ms"] for v in agg_ks.values()) / args.steps
-        dense_ms = sum(v["total_ms"] for v in dense_ks.values()) / args.steps
-        # the PMC passes were taken at exactly this shape (tools/pmc_probe.py); any other shape reports null
-        at_profiled_shape = (world == 1 and args.n_per_gpu == 1_000_000 and d == 128 and args.degree == 16
-                             and args.degree_dist == "fixed" and args.dtype == "f32" and not args.self_loops
-                             and (not attn or args.heads == 4))
-        at_c5_shape = (world == 1 and args.n_per_gpu == 250_000 and d == 256 and args.degree == 16 and args.degree_dist == "zipf"
-                       and args.dtype == "bf16" and not args.self_loops and attn and args.heads == 4 and args.seed == 20260928)
-        traffic, traffic_source = hbm_traffic_from_profile(dom) if (at_profiled_shape and dom) else (
-            hbm_traffic_from_profile(dom, "c5") if (at_c5_shape and dom) else (None, None))
-        roofline = None
-        if seg:
-            achieved = seg["algo_bytes"] / (seg["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": f"allset_{dom}",
-                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "traffic_source": traffic_source,
-                        "frac_of_copy_ceiling": achieved / COPY_CEILING_GBS,
-                        "note": "achieved = SURVEY 8(d3) gather-model bytes / HIP-event launch time; the rate can exceed the 6.3 TB/s "
-                                "streaming-copy ceiling because each source row is gathered `degree` times and part of the table is "
-                                "served by the 256 MiB Infinity Cache (FETCH_SIZE counts at the L2's fabric side, cache hits "
-                                "included); DRAM-only bytes are not exposed by rocprofv3 on gfx950",
-                        "algo_bytes_per_launch": seg["algo_bytes"], "avg_launch_ms": seg["avg_ms"], "launches": seg["calls"],
-                        "per_kernel": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in ks.items() if v.get("algo_bytes")}}
-        nnz_total = res["nnz_total"]
-        line = {
-            "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": res["value"], "unit": "edges*d/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "dtype_note": ("fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: every fp32 operand split exactly "
-                           "into three bf16, six of the nine partial products formed on the bf16 matrix pipe and accumulated in "
-                           "fp32 -- measured error vs float64 <= that of the native fp32 MFMA / hipBLASLt (DESIGN.md section 6)")
-            if args.dtype == "f32" else
-            ("bf16 tensors end to end (BASELINE configs[4] regime): bf16 instantiations of the gather kernels with fp32 "
-             "accumulation and fp32 softmax statistics; dense tail: this library's bf16 kernels (fp32 arithmetic and "
-             "accumulation, bf16 in / out)"),
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{cfg_index(args)}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph "
-                                   f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}), "
-                                   f"nnz={int(nnz_total)}, d={d}, " +
-                                   (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
-                                    f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), ") +
-                                   "fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
-                       "n_v": res["n_v"], "n_e": res["n_e"], "nnz": int(nnz_total), "d": d,
-                       "parallelism": parallelism_label(args, primary, world), "partition": primary if world > 1 else None,
-                       "seed": args.seed, "launch": "one hipGraph replay per step" if (args.hip_graph and world == 1) else "eager launches"},
-            "roofline": roofline,
-            "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if (world == 1 and agg_ms > 0) else None,
-                            "unit": "edges*d/s", "note": "gather/segment-reduce kernel time per step (HIP events, rank 0): "
-                            "the aggregation-only V->E->V fwd+bwd",
-                            "kernels": {k: kernel_entry(v, args.steps) for k, v in agg_ks.items()}},
-            "dense_tail": {"ms_per_step": dense_ms, "note": ("HIP dense-tail kernels per step (fused norm+Linear forward; ONE backward "
-                           "kernel per Linear producing input gradient, LayerNorm parameter gradients and the weight / bias "
-                           "gradient from a single read of gy and x). fp32 in, fp32 out, fp32-accurate arithmetic on the bf16 "
-                           "matrix pipe: operands split exactly into 3 bf16, 6 of 9 products accumulated in fp32 (error <= "
-                           "native fp32 MFMA, tests/test_gpu_dense.py); HBM-bound: gbps = algorithmic activation bytes / time")
-                           if args.dtype == "f32" else
-                           ("HIP dense-tail kernels per step, bf16 in / out with fp32 accumulation: Linear forward / backward-data "
-                            "with relu, folded logits, relu mask and gradient-branch sums in the same pass (csrc/fused_bf16.hip), "
-                            "full-width weight gradient, add+LayerNorm kernels; gbps = algorithmic activation bytes / time"),
-                           "kernels": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in dense_ks.items()}},
-        }
-        if dist.is_initialized():
-            line["config"]["collectives"] = ("gloo, device tensors staged through the host, ranks may share a device (test mode)"
-                                             if dist.get_backend() == "gloo" and not cpu_mode else
-                                             ("gloo (CPU test)" if cpu_mode else "RCCL (torch.distributed nccl backend)"))
-        if world > 1 or res2 is not None:
-            parts = {primary: {"ms_per_step": res["ms_per_step"], "value": res["value"],
-                               "parallelism": parallelism_label(args, primary, world), "is_value": True}}
-            if res2 is not None:
-                parts[other] = {"ms_per_step": res2["ms_per_step"], "value": res2["value"],
-                                "parallelism": parallelism_label(args, other, world), "is_value": False}
-            elif res2_error is not None:
-                parts[other] = {"error": res2_error, "parallelism": parallelism_label(args, other, world), "is_value": False}
-            if res_wire is not None:
-                parts[primary + "+bf16wire"] = {"ms_per_step": res_wire["ms_per_step"], "value": res_wire["value"], "is_value": False,
-                                                "parallelism": parallelism_label(args, primary, world) + "; bf16 wire format (opt-in, "
-                                                "results within the restated tolerance of tests/test_dist_cpu.py, not bit-comparable)"}
-            elif res_wire_error is not None:
-                parts[primary + "+bf16wire"] = {"error": res_wire_error, "is_value": False}
-            parts["note"] = ("`rows` = hyperedge shards, the partition BASELINE.json's north star names; `columns` = column-sharded "
-                             "aggregation (DESIGN.md section 7.2). Same global hypergraph, same K steps, separate timed regions; "
-                             "`value` / `ms_per_step` of the line are those of the entry with is_value = true")
-            line["partitions"] = parts
-        if world == 1 and not args.no_cpu_baseline and not attn and not cpu_mode:
-            line["cpu_baseline"] = cpu_baseline(args, d, args.degree, res.get("edge_index_cpu"), res.get("x_cpu"))
-        else:
-            line["cpu_baseline"] = None
+        res = state["results"].get(primary) or next(iter(state["results"].values()))
+        if world == 1 and not args.no_cpu_baseline and args.model != "pma" and not cpu_mode:
+            state["cpu_baseline"] = cpu_baseline(args, args.d, args.degree, res.get("edge_index_cpu"), res.get("x_cpu"))
+        line = assemble_line(args, world, primary, state, cpu_mode)
         print(json.dumps(line), flush=True)
+    state["printed"] = True
     if dist.is_initialized() and not hooks.get("keep_group"):
+        if dog is not None:
+            dog.arm(args.region_timeout, "teardown")                  # a peer that died in a later region must not hang the exit
         dist.destroy_process_group()
+        if dog is not None:
+            dog.disarm()
     return line
 
 

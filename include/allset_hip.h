@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 8   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked) */
+#define ALLSET_ABI_VERSION 9   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); no entry point added or removed.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only" */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -209,7 +209,7 @@ int allset_relu_dropout_bwd(const float* gy, const float* y, float p, float* gx,
 /* Weight gradient of y = u W^T + b:  gW[o][i] = sum_r ga[r][o] * u[r][i],  gb[o] = sum_r ga[r][o], as
  * n_slices split-K partials (part_w: f32[n_slices*O*I], part_b: f32[n_slices*O] or NULL) that the caller
  * sums -- deterministic, no atomics.  fp32-accurate arithmetic (bf16x6 on the bf16 matrix pipe, see
- * allset_fused_linear_fwd; the native fp32 MFMA with ALLSET_DENSE_MFMA=f32).  O, I, lda, ldu must be multiples of 4 and
+ * allset_fused_linear_fwd).  O, I, lda, ldu must be multiples of 4 and
  * the inputs 16-byte aligned, else ALLSET_ERR_UNSUPPORTED. */
 int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
 int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_t ldu, float* part_w, float* part_b,
@@ -439,8 +439,8 @@ int allset_ln_res_bwd_pma_bf16(const void* gy, int64_t ldg, const void* x, int64
  *                                 epi = [relu_out] -> [dropout p_out].
  * One read + one write of the activation matrix.  Arithmetic: fp32 on the bf16 matrix pipe -- every operand is split
  * exactly into three bf16 values and six of the nine partial products are accumulated in fp32 ("bf16x6", dropped terms
- * <= 2^-23 relative: as accurate as a native fp32 MFMA, 2.7x its rate on gfx950); the environment variable
- * ALLSET_DENSE_MFMA=f32 selects the native fp32 MFMA kernels instead (comparison builds).  stats (f32[n*2] =
+ * <= 2^-23 relative: as accurate as a native fp32 MFMA, 2.7x its rate on gfx950; the only
+ * kernel family since ABI 9).  stats (f32[n*2] =
  * {mean, rstd}) is written when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0.
  *
  * Auxiliary output columns (optional, bf16x6 kernels): aux_out f32[n*4] = pro(x) @ aux_w^T + aux_b with aux_w f32[4*K],
@@ -452,7 +452,7 @@ int allset_ln_res_bwd_pma_bf16(const void* gy, int64_t ldg, const void* x, int64
  * so the backward kernels need not re-read y.  Layout ("mask layout"): blocks of 16 rows x 64 columns, 32 dwords each,
  * block index (row / 16) * (N / 64) + col / 64; inside a block, dword ((row % 16) / 4) * 8 + (row % 4) * 2 +
  * (col % 64) / 32, bit 8 * (col % 4) + (col % 32) / 4.  Size: allset_fused_linear_mask_words(n, N) dwords (0 when the
- * mask is not supported: N % 64 != 0 or ALLSET_DENSE_MFMA=f32).  Pass the same buffer as `mask` to
+ * mask is not supported: N % 64 != 0).  Pass the same buffer as `mask` to
  * allset_fused_linear_bwd / allset_wgrad_fused instead of y. */
 int allset_fused_linear_supported(int64_t K, int64_t N);
 int64_t allset_fused_linear_mask_words(int64_t n, int64_t N);
@@ -493,9 +493,9 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  *            allset_reduce_partials launch then sums all of a Linear's parameter gradients.
  * No atomics: bitwise reproducible run to run.  allset_fused_linear_bwd_all_supported(O, I, flags) -> 1/0: widths in
  * {64,128} and the prologue / epilogue combinations the module surface produces (dropout_in only behind relu_in, acc_in only
- * on the plain Linear); 0 under ALLSET_DENSE_MFMA=f32.  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
+ * on the plain Linear).  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
 int allset_fused_linear_bwd_all_supported(int64_t O, int64_t I, int has_ln, int drop_in, int relu_in, int has_mask, int has_acc);
-int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices);      /* the one-wave-per-SIMD kernel's count (ABI 4-5 callers) */
+int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices);      /* DEPRECATED: the one-wave-per-SIMD kernel's count (widths other than O = I = 128); size buffers with _slices_for */
 /* The slice count allset_fused_linear_bwd_all expects for these widths (ABI 6): the O = I = 128 kernel keeps ONE weight-gradient
  * accumulator per workgroup (n_slices = number of workgroups), the other widths one per wave. */
 int allset_fused_linear_bwd_all_slices_for(int64_t n, int64_t O, int64_t I, int has_acc, int64_t* n_slices);

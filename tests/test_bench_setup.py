@@ -124,3 +124,64 @@ def test_bench_two_ranks_runs_both_partitions_and_reports_one_line(model):
         assert p["ms_per_step"] > 0 and abs(p["value"] - nnz * 32 / (p["ms_per_step"] * 1e-3)) <= 1e-6 * p["value"]
     assert line["value"] == parts["columns"]["value"] and line["ms_per_step"] == parts["columns"]["ms_per_step"]
     assert line["cpu_baseline"] is None and line["vs_baseline"] is None and line["higher_is_better"] is True
+    # regions run rows first (the plainest collectives), then the all-to-all partition, then the bf16 wire; the link preflight ran
+    assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+bf16wire"]
+    pf = line["preflight"]["collectives"]
+    assert any("all_gather" in k for k in pf) and any("reduce_scatter" in k for k in pf) and any("all_to_all" in k for k in pf)
+    assert all(v["ms"] > 0 and v["gbps_per_link"] > 0 for v in pf.values())
+
+
+def _hang_worker(rank, world, port, label, q):
+    """bench.main with rank 1 parked at the start of region ``label``: rank 0 blocks in that region's first collective; the watchdog
+    must print the line assembled from the regions that DID finish and end the process (here: hand it to the test, then exit)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      ALLSET_BENCH_TEST_HANG=f"{label}:1")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import contextlib
+    import io
+    import bench
+    from test_dist_cpu import TorchPmaKernels
+    buf = io.StringIO()
+
+    def exit_fn(code):
+        import time
+        q.put((rank, code, buf.getvalue()))
+        time.sleep(0.5)                                 # let the queue's feeder thread flush before the hard exit
+        os._exit(0)
+    hooks = {"device": "cpu", "aggregate": _oracle_aggregate, "kernels": TorchPmaKernels, "incidences": _tuple_incidences, "exit": exit_fn}
+    argv = ["--gpus", str(world), "--n-per-gpu", "120", "--degree", "4", "--feature-dim", "32", "--steps", "2", "--warmup", "1",
+            "--dropout", "0.0", "--region-timeout", "8"]
+    real_stdout = sys.stdout
+    sys.stdout = buf                                   # (the watchdog thread prints through sys.stdout too)
+    try:
+        bench.main(argv, hooks)
+    finally:
+        sys.stdout = real_stdout
+    q.put((rank, "returned", buf.getvalue()))
+
+
+@pytest.mark.parametrize("label", ["columns", "preflight"])
+def test_bench_hung_later_region_still_yields_the_first_regions_line(label):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hang_worker, args=(r, world, port, label, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, code, out = q.get(timeout=300)
+        got[r] = (code, out)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    code0, out0 = got[0]
+    assert code0 == 0 and got[1][0] == 0 and got[1][1].strip() == ""           # both ended by their watchdogs; rank 1 printed nothing
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                      # ONE JSON line
+    line = json.loads(lines[0])
+    parts = line["partitions"]
+    assert parts["rows"]["is_value"] and line["value"] == parts["rows"]["value"] and line["config"]["partition"] == "rows"
+    assert "timeout" in (parts["columns"]["error"] if label == "columns" else line["preflight"]["error"])
+    assert "value_note" in parts and "columns" in parts["value_note"]

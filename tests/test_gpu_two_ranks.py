@@ -297,3 +297,47 @@ def test_bench_two_ranks_one_gpu_gloo():
         assert line["config"]["nnz"] == 2 * 20000 * 16
         for k in ("rows", "columns"):
             assert abs(parts[k]["value"] - line["config"]["nnz"] * 128 / (parts[k]["ms_per_step"] * 1e-3)) <= 1e-6 * parts[k]["value"]
+
+
+def test_bench_bare_command_spawns_its_own_ranks():
+    """``python bench.py --gpus 2`` with NO launcher around it (no RANK / WORLD_SIZE): bench.py re-launches itself under
+    torch.distributed.run and the bare command prints the one line."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ALLSET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000", "--d", "128"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["nnz"] == 2 * 20000 * 16
+    parts = line["partitions"]
+    assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+bf16wire"]
+    assert all("error" not in parts[k] for k in ("rows", "columns", "columns+bf16wire")), parts
+    assert parts["columns"]["is_value"] and line["value"] == parts["columns"]["value"]
+    assert any("all_to_all" in k for k in line["preflight"]["collectives"])
+    early = [l for l in res.stderr.splitlines() if l.startswith("[bench] early line")]
+    assert len(early) == 1 and json.loads(early[0].split(": ", 1)[1])["partitions"]["rows"]["is_value"]
+
+
+def test_bench_hung_second_region_keeps_the_first_regions_line():
+    """Rank 1 parks at the start of the column partition: rank 0 blocks in its first exchange.  The watchdog prints the line with
+    the row partition's result and both ranks exit 0."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ALLSET_DIST_BACKEND="gloo", ALLSET_BENCH_TEST_HANG="columns:1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000",
+           "--region-timeout", "20", "--preflight", "off"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    parts = line["partitions"]
+    assert parts["rows"]["is_value"] and line["value"] == parts["rows"]["value"] and "timeout" in parts["columns"]["error"]
+    assert line["roofline"]["launches"] > 0 and line["config"]["partition"] == "rows"

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
-"""(stage kernel) Ablation of fused_linear_bwd_roles_kernel (csrc/fused_bwd4.hip): variants with L2-hot operands (every pair re-reads one
-chunk: no HBM latency), without the workgroup barriers (results wrong, timing only), without the MFMAs, without the gx stores,
-each timed at [1M,128] x [128,128] next to the one-wave kernel (ALLSET_BWD_PAIR=0).  Run on the GPU box:
-python tools/bwd_pair_ablation.py [--light]"""
+"""Ablation of fused_linear_bwd_roles_kernel (csrc/fused_bwd4.hip): variants without the workgroup barriers (results wrong,
+timing only), without the MFMAs, without the gx stores, with per-segment cycle counters, each timed at [1M,128] x [128,128].
+Run on the GPU box: python tools/bwd_roles_ablation.py [--light] [--only <substring>] [-DFLAG ...]
+(the comparison arms of rounds 2-3 -- the pair / stage / three-waves kernels and their ablation scripts -- live in
+tools/micro/retired/ as they were when they lost their A/B; the library no longer builds them.)"""
 import ctypes, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-src = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bwd.hip", "fused_bwd2.hip", "fused_bwd3.hip", "fused_bwd4.hip", "fused_bwd5.hip", "abi.hip")]
+src = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bwd.hip", "fused_bwd4.hip", "abi.hip")]
 dev = torch.device("cuda:0")
 n, d = 1_000_000, 128
 x = torch.randn(n, d, device=dev); W = torch.randn(d, d, device=dev) / d ** 0.5
@@ -23,16 +24,7 @@ light = "--light" in sys.argv
 if "--only" in sys.argv:
     key = sys.argv[sys.argv.index("--only") + 1]
     variants = [v for v in variants if key in v[0]]
-os.environ["ALLSET_BWD_ROLES"] = "1"
-others = [] if "--only" in sys.argv else [("eight waves in lock-step phases (fused_bwd3.hip)", "stage"), ("one wave per SIMD (fused_bwd.hip)", None)]
-for name, flags in variants + others:
-    if flags == "stage":
-        os.environ["ALLSET_BWD_ROLES"] = "0"
-        flags = []
-    elif flags is None:
-        os.environ["ALLSET_BWD_ROLES"] = "0"
-        os.environ["ALLSET_BWD_STAGE"] = "0"
-        flags = []
+for name, flags in variants:
     so = f"/tmp/bwdroles_{abs(hash(name))}.so"
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950"] + ([] if "-DSLP" in flags else ["-fno-slp-vectorize"]) + ["-shared", "-fPIC",
                     "-I", os.path.join(ROOT, "include"), "-o", so] + flags + src, check=True)

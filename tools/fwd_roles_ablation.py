@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Ablation of fused_linear_fwd_roles_kernel (csrc/fused_fwd2.hip) at [1M,128] x [128,128], LayerNorm + dropout in + relu/dropout
-out + mask: without the barriers (timing only), without the MFMAs, without the y stores, with segment timing; beside the symmetric
-kernel (ALLSET_FWD_ROLES=0).  Run on the GPU box: python tools/fwd_roles_ablation.py [--light]"""
+out + mask: without the barriers (timing only), without the MFMAs, without the y stores, with segment timing (the symmetric
+kernel it replaced at K = N = 128 is no longer reachable there since ABI 9: no getenv dispatch).  Run on the GPU box: python tools/fwd_roles_ablation.py [--light]"""
 import ctypes, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,12 +20,9 @@ light = "--light" in sys.argv
 combo = [int(v) for v in sys.argv[sys.argv.index("--combo") + 1].split(",")] if "--combo" in sys.argv else ([1, 0, 0, 0] if light else [1, 1, 1, 1])
 variants = [("roles: full", [])] if "--combo" in sys.argv else [("roles: full", []), ("roles: no barriers", ["-DALLSET_ABL5_NOBAR"]), ("roles: no MFMA", ["-DALLSET_ABL5_NOMFMA"]),
             ("roles: no stores", ["-DALLSET_ABL5_NOSTORE"]), ("roles: no MFMA, no stores", ["-DALLSET_ABL5_NOMFMA", "-DALLSET_ABL5_NOSTORE"]),
-            ("roles: segment timing", ["-DALLSET_ABL5_TIMING"]), ("symmetric kernel (fused_mlp.hip)", None)][:7 if "--combo" not in sys.argv else 0]
+            ("roles: segment timing", ["-DALLSET_ABL5_TIMING"])]
 variants += [(a, a.split()) for a in sys.argv[1:] if a.startswith("-D")]
 for name, flags in variants:
-    os.environ["ALLSET_FWD_ROLES"] = "1"
-    if flags is None:
-        os.environ["ALLSET_FWD_ROLES"] = "0"; flags = []
     so = f"/tmp/fwdroles_{abs(hash(name))}.so"
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-shared", "-fPIC",
                     "-I", os.path.join(ROOT, "include"), "-o", so] + flags + src, check=True)
