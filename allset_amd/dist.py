@@ -365,9 +365,11 @@ def _bn_scope(valid_rows: int, group):
     (zero pad rows included) would be a different model than the single-GPU one and let the replicated running statistics drift
     apart.  Inside this scope the MLP's BatchNorm1d modules reduce (count, sum, centred sum of squares) over the VALID rows of all
     ranks (``dense.sync_bn_rows``); round 3 -- rounds 1-2 refused 'bn' in sharded mode."""
-    import contextlib
     from . import dense
-    return contextlib.nullcontext() if _skip_collective(group) else dense.sync_bn_rows(valid_rows, group)
+    # Entered at world 1 too: the owned blocks may carry zero PAD rows there as well (ColumnShardedHypergraph pads them to a
+    # multiple of `chunks`), and only the valid-row mask keeps those out of the batch and running statistics; the all-reduces
+    # inside are no-ops on one rank.
+    return dense.sync_bn_rows(valid_rows, group)
 
 
 def _valid_rows(lo: int, hi: int, n: int) -> int:

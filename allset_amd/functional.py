@@ -88,14 +88,22 @@ class _RouteWeights(torch.autograd.Function):
 
 
 def _routed(norm: Tensor, inc: Incidence, dst: bool) -> Tensor:
-    """``norm`` (edge-list order, requires grad) in the order of ``inc.by_dst`` / ``inc.by_src``; cached ON the norm tensor per CSR
-    object, so the cache lives exactly as long as that forward's norm (autograd sums the gradients of all its uses)."""
-    cache = norm.__dict__.setdefault("_allset_routed", {})
+    """``norm`` (edge-list order, requires grad) in the order of ``inc.by_dst`` / ``inc.by_src``.
+
+    A NON-LEAF norm (SetGNN's ``Importance * norm``, a fresh tensor per forward) caches the routed copy on itself per
+    (CSR object, version, grad mode): the V->E and E->V convs of a layer share one routing and autograd sums their gradients; the
+    cache dies with that forward's tensor.  A LEAF (an ``nn.Parameter`` handed straight to ``deepsets_aggregate``) is never
+    cached: it outlives the forward, the optimizer updates it in place, a hit would replay the first call's values and graph
+    (and keep it alive through AccumulateGrad -> tensor -> cache).  Routing is one gather, 0.2 ms at nnz = 16M."""
     csr = inc.by_dst if dst else inc.by_src
-    hit = cache.get(id(csr))
+    perm, inv = (inc.perm_dst_long(), inc.inv_perm_dst()) if dst else (inc.perm_src_long(), inc.inv_perm_src())
+    if norm.grad_fn is None:
+        return _RouteWeights.apply(norm.reshape(-1).to(torch.float32), perm, inv)
+    cache = norm.__dict__.setdefault("_allset_routed", {})
+    key = (id(csr), norm._version, torch.is_grad_enabled())
+    hit = cache.get(key)
     if hit is None:
-        perm, inv = (inc.perm_dst_long(), inc.inv_perm_dst()) if dst else (inc.perm_src_long(), inc.inv_perm_src())
-        hit = cache[id(csr)] = _RouteWeights.apply(norm.reshape(-1).to(torch.float32), perm, inv)
+        hit = cache[key] = _RouteWeights.apply(norm.reshape(-1).to(torch.float32), perm, inv)
     return hit
 
 

@@ -137,7 +137,7 @@ class Incidence:
     def weights(self, norm: Optional[Tensor]) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """Route the reference's per-incidence ``norm`` (edge-list order; int64 ones by default,
         preprocessing.py:454) into (by_dst order, by_src order) f32 arrays.  All-ones -> (None, None):
-        (integer norms only, see below) the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms, and only while
+        (integer norms on first sight, a persistent floating-point tensor from its second use on) the kernels then skip the weight stream.  Cached per (storage, version) for non-grad norms, and only while
         that very tensor object is alive: a temporary recomputed per forward (``Importance * norm`` under
         ``no_grad``) is usually handed the previous temporary's address with ``_version`` 0 by the caching
         allocator, so an address match alone would return the FIRST evaluation's weights for ever."""
@@ -150,19 +150,27 @@ class Incidence:
         key = (norm.data_ptr(), norm._version, norm.dtype, norm.numel())
         entry = self._wcache.get(key)
         hit = entry[1] if (entry is not None and entry[0]() is norm) else None
+        if hit is not None and not entry[2] and not _capturing(norm):
+            # A floating-point norm seen a SECOND time as the very same live tensor is persistent (``torch.ones(nnz)`` kept by the
+            # caller), not a per-forward temporary: probe it once now.  All ones -> the weight stream is skipped from here on.
+            if bool((norm.reshape(-1) == 1).all()):
+                hit = (None, None)
+            self._wcache[key] = (entry[0], hit, True)
         if hit is None:
             flat = norm.reshape(-1)
-            # The all-ones probe (a host sync) is for the reference's DEFAULT norm only: int64 ones (preprocessing.py:454),
-            # a persistent tensor probed once.  A floating-point norm is routed without looking at its values: under
-            # LearnMask the eval forward hands over a fresh ``Importance * norm`` temporary every call (models.py:451-452), so
-            # a probe would synchronise on every forward and is illegal inside a hipGraph capture (graphs.GraphedForward).
-            if not norm.dtype.is_floating_point and bool((flat == 1).all()):
+            # The all-ones probe (a host sync) on FIRST sight is for the reference's DEFAULT norm only: int64 ones
+            # (preprocessing.py:454), a persistent tensor probed once.  A floating-point norm is routed without looking at its
+            # values the first time: under LearnMask the eval forward hands over a fresh ``Importance * norm`` temporary every call
+            # (models.py:451-452), so a probe would synchronise on every forward and is illegal inside a hipGraph capture
+            # (graphs.GraphedForward); a persistent float norm is probed on its second use (above).
+            probed = not norm.dtype.is_floating_point
+            if probed and bool((flat == 1).all()):
                 hit = (None, None)
             else:
                 f = flat.to(torch.float32)
                 hit = (f.index_select(0, self.perm_dst_long()), f.index_select(0, self.perm_src_long()))
             self._wcache.clear()
-            self._wcache[key] = (weakref.ref(norm), hit)
+            self._wcache[key] = (weakref.ref(norm), hit, probed)
         return hit
 
 
@@ -170,6 +178,10 @@ class Incidence:
 # cache: edge_index tensor -> Incidence, keyed on storage identity + version (the reference hands the
 # same data.edge_index to every forward; models.py:450)
 # ---------------------------------------------------------------------------------------------
+
+def _capturing(t: Tensor) -> bool:
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
 
 _CACHE: Dict[Tuple, Tuple[weakref.ref, Incidence]] = {}
 _CACHE_LIMIT = 16

@@ -25,6 +25,7 @@ import os.path as osp
 import pickle
 import time
 from types import SimpleNamespace
+from typing import Optional
 
 import numpy as np
 import torch
@@ -82,6 +83,91 @@ def load_hypergcn_dataset(path: str, dataset: str) -> HypergraphData:
     return HypergraphData(x=torch.from_numpy(features), y=torch.from_numpy(labels),
                           edge_index=block_edge_list(np.array(nodes), np.array(hes), num_nodes),
                           n_x=[num_nodes], num_hyperedges=[len(hypergraph)])
+
+
+def load_le_dataset(path: str, dataset: str = "ModelNet40", train_percent: float = 0.025) -> HypergraphData:
+    """``<path>/<dataset>/<dataset>.content`` (one line per id: id, features..., label) and ``<dataset>.edges`` (pairs
+    ``node_id he_id``) -- the "LE" format of ModelNet40 / NTU2012 / Mushroom / zoo / 20newsW100 (reference
+    load_other_datasets.py:32-119).  Same conventions: ids are remapped through the order of the .content file, hyperedge ids must
+    follow the node ids without a gap, ``x`` / ``y`` keep the node rows only."""
+    content = np.genfromtxt(osp.join(path, dataset, f'{dataset}.content'), dtype=np.dtype(str))
+    if content.ndim == 1:
+        content = content[None, :]
+    features = content[:, 1:-1].astype(np.float32)
+    labels = content[:, -1].astype(float).astype(np.int64)
+    idx_map = {j: i for i, j in enumerate(content[:, 0].astype(np.int32))}
+    raw = np.genfromtxt(osp.join(path, dataset, f'{dataset}.edges'), dtype=np.int32)
+    if raw.ndim == 1:
+        raw = raw[None, :]
+    pairs = np.array([idx_map[int(v)] for v in raw.flatten()], dtype=np.int64).reshape(raw.shape).T      # [2, nnz]: nodes | hyperedges
+    if int(pairs[0].max()) != int(pairs[1].min()) - 1:
+        raise ValueError(f"{dataset}: hyperedge ids must start right behind the node ids (reference load_other_datasets.py:69)")
+    if len(np.unique(pairs)) != int(pairs.max()) + 1:
+        raise ValueError(f"{dataset}: node / hyperedge ids are not consecutive (reference load_other_datasets.py:72)")
+    num_nodes = int(pairs[0].max()) + 1
+    num_he = int(pairs[1].max()) - num_nodes + 1
+    return HypergraphData(x=torch.from_numpy(features[:num_nodes].copy()), y=torch.from_numpy(labels[:num_nodes].copy()),
+                          edge_index=block_edge_list(pairs[0], pairs[1] - num_nodes, num_nodes),
+                          n_x=[num_nodes], num_hyperedges=[num_he], train_percent=train_percent)
+
+
+def load_cornell_dataset(path: str, dataset: str = "amazon", feature_noise: float = 0.1, feature_dim: Optional[int] = None,
+                         train_percent: float = 0.025, rng: Optional[np.random.Generator] = None) -> HypergraphData:
+    """``<path>/<dataset>/node-labels-<dataset>.txt`` (one label per line, from 1) and ``hyperedges-<dataset>.txt`` (one hyperedge
+    per line, comma-separated node ids) -- walmart-trips / house-committees / amazon-reviews (reference
+    load_other_datasets.py:293-391).  Features are the one-hot label (zero-padded to ``feature_dim``) plus N(0, feature_noise)
+    noise; the reference draws it from numpy's GLOBAL generator (unseeded: README.md:60), here ``rng`` (default: that same
+    global state, so a caller that seeds numpy gets the reference's very numbers)."""
+    labels = np.loadtxt(osp.join(path, dataset, f'node-labels-{dataset}.txt'), dtype=np.int64, ndmin=1)
+    num_nodes = labels.shape[0]
+    features = np.zeros((num_nodes, int(labels.max())))
+    features[np.arange(num_nodes), labels - 1] = 1
+    if feature_dim is not None:
+        features = np.hstack((features, np.zeros((num_nodes, feature_dim - features.shape[1]), dtype=features.dtype)))
+    features = (rng.normal(features, feature_noise, features.shape) if rng is not None
+                else np.random.normal(features, feature_noise, features.shape))
+    nodes, hes = [], []
+    he_id = 0
+    with open(osp.join(path, dataset, f'hyperedges-{dataset}.txt')) as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            members = [int(v) for v in line.split(',')]
+            nodes += members
+            hes += [he_id] * len(members)
+            he_id += 1
+    nodes = np.asarray(nodes, dtype=np.int64)
+    nodes = nodes - nodes.min()                                     # node ids shifted to start at 0 (reference :351-352)
+    return HypergraphData(x=torch.from_numpy(features.astype(np.float32)), y=torch.from_numpy(labels),
+                          edge_index=block_edge_list(nodes, np.asarray(hes, dtype=np.int64), num_nodes),
+                          n_x=[num_nodes], num_hyperedges=[he_id], train_percent=train_percent)
+
+
+def load_yelp_dataset(path: str, name_dictionary_size: int = 1000, train_percent: float = 0.025) -> HypergraphData:
+    """The five csv files of the yelp restaurant hypergraph (reference load_other_datasets.py:198-291): features =
+    [lat, long | one-hot state | one-hot city | bag-of-words of the name (sklearn CountVectorizer, english stop words, ascii
+    accents, ``name_dictionary_size`` terms)], labels = binned stars, incidence csv with 1-based ``node`` / ``he`` columns."""
+    import pandas as pd
+    from sklearn.feature_extraction.text import CountVectorizer
+    latlong = pd.read_csv(osp.join(path, 'yelp_restaurant_latlong.csv')).values
+    loc = pd.read_csv(osp.join(path, 'yelp_restaurant_locations.csv'))
+    state_int, city_int = loc.state_int.values, loc.city_int.values
+    num_nodes = loc.shape[0]
+    state_1hot = np.zeros((num_nodes, state_int.max()))
+    state_1hot[np.arange(num_nodes), state_int - 1] = 1
+    city_1hot = np.zeros((num_nodes, city_int.max()))
+    city_1hot[np.arange(num_nodes), city_int - 1] = 1
+    vectorizer = CountVectorizer(max_features=name_dictionary_size, stop_words='english', strip_accents='ascii')
+    names = pd.read_csv(osp.join(path, 'yelp_restaurant_name.csv')).values.flatten()
+    name_bow = np.asarray(vectorizer.fit_transform(names).todense())
+    features = np.hstack([latlong, state_1hot, city_1hot, name_bow]).astype(np.float32)
+    labels = pd.read_csv(osp.join(path, 'yelp_restaurant_business_stars.csv')).values.flatten().astype(np.int64)
+    assert features.shape[0] == len(labels)
+    H = pd.read_csv(osp.join(path, 'yelp_restaurant_incidence_H.csv'))
+    return HypergraphData(x=torch.from_numpy(features), y=torch.from_numpy(labels),
+                          edge_index=block_edge_list(H.node.values - 1, H.he.values - 1, num_nodes),
+                          n_x=[num_nodes], num_hyperedges=[int(H.he.values.max())], train_percent=train_percent)
 
 
 class _PygStandIn:
@@ -324,13 +410,31 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
+CORNELL_DATASETS = ('amazon-reviews', 'walmart-trips', 'house-committees', 'walmart-trips-100', 'house-committees-100')
+HYPERGCN_DATASETS = ('cora', 'citeseer', 'pubmed', 'coauthor_cora', 'coauthor_dblp')
+
+
 def load_data(args) -> HypergraphData:
     if getattr(args, 'processed_data', None) is not None:
         data = load_pyg_processed(args.processed_data)
         if args.dname in ('yelp', 'walmart-trips', 'house-committees', 'walmart-trips-100', 'house-committees-100'):
             data.y = data.y - data.y.min()                  # labels shifted to start at 0 (reference train.py:329-332)
     elif args.raw_data_dir is not None:
-        data = load_hypergcn_dataset(args.raw_data_dir, args.dname)
+        # the reader per dataset name: reference convert_datasets_to_pygDataset.py:122-163
+        if args.dname in CORNELL_DATASETS:
+            base = args.dname[:-4] if args.dname.endswith('-100') else args.dname
+            data = load_cornell_dataset(args.raw_data_dir, base, feature_noise=float(args.feature_noise),
+                                        feature_dim=100 if args.dname.endswith('-100') else None)
+            data.y = data.y - data.y.min()                  # labels shifted to start at 0 (reference train.py:329-332)
+        elif args.dname == 'yelp':
+            data = load_yelp_dataset(osp.join(args.raw_data_dir, 'yelp') if osp.isdir(osp.join(args.raw_data_dir, 'yelp')) else args.raw_data_dir)
+            data.y = data.y - data.y.min()
+        elif args.dname in HYPERGCN_DATASETS:
+            data = load_hypergcn_dataset(args.raw_data_dir, args.dname)
+        elif osp.exists(osp.join(args.raw_data_dir, args.dname, f'{args.dname}.content')):
+            data = load_le_dataset(args.raw_data_dir, args.dname)
+        else:
+            data = load_hypergcn_dataset(args.raw_data_dir, args.dname)
     elif args.dname == 'synthetic':
         data = synthetic_dataset(feature_noise=float(args.feature_noise), seed=0 if args.seed is None else args.seed)
     else:

@@ -167,6 +167,39 @@ def import_reference_preprocessing():
     return ref_pre
 
 
+class _Data:
+    """torch_geometric.data.Data as the reference's loaders use it (load_other_datasets.py:81-85,113-117): an attribute bag
+    constructed from keyword tensors."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _coalesce(index, value, m, n, op="add"):
+    """torch_sparse.coalesce (pinned torch-sparse 0.6.x, reference README.md:18-22) for ``value=None``: the edge list sorted
+    by (row, col) with duplicates removed.  [external: restated from the library's documented behaviour]"""
+    assert value is None
+    key = torch.unique(index[0] * int(n) + index[1])                     # sorted
+    return torch.stack([key // int(n), key % int(n)]), None
+
+
+def import_reference_loaders():
+    """The reference's ``load_other_datasets`` module (raw-file readers, load_other_datasets.py:32-391)."""
+    if not available():
+        raise RuntimeError("/root/reference is not present (this only works in the build container)")
+    install()
+    tg = sys.modules["torch_geometric"]
+    tg.data = _module("torch_geometric.data", Data=_Data)
+    _module("torch_sparse", coalesce=_coalesce)
+    if REFERENCE_SRC not in sys.path:
+        sys.path.insert(0, REFERENCE_SRC)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import load_other_datasets as ref_load   # noqa: E402
+    return ref_load
+
+
 def import_reference():
     """Return the reference's ``(layers, models)`` modules, imported from /root/reference/src."""
     if not available():

@@ -103,6 +103,58 @@ def test_fixed_float_norm_uses_cached_routing(device):
     assert len(inc._wcache) == 1
 
 
+def test_leaf_norm_parameter_two_optimizer_steps(device):
+    """a persistent LEAF norm that requires grad (an nn.Parameter handed straight to deepsets_aggregate)
+    must be re-routed on every call -- the optimizer updates it in place between calls, and the routed copy of the first call
+    carries that call's graph.  Two SGD steps against the oracle's own two steps; also under no_grad first (a cached no-grad hit
+    would drop the weight gradient)."""
+    from allset_amd import Incidence, deepsets_aggregate
+    rng = np.random.default_rng(17)
+    ei = make_incidence(rng, 64, 32, 500)
+    x = torch.from_numpy(rng.standard_normal((64, 32)).astype(np.float32))
+    w0 = torch.from_numpy(rng.uniform(0.5, 1.5, size=500).astype(np.float32))
+    inc = Incidence.from_edge_index(ei.to(device), n_src=64, n_dst=32)
+    wg = torch.nn.Parameter(w0.clone().to(device))
+    wo = torch.nn.Parameter(w0.clone())
+    xg = x.to(device)
+    with torch.no_grad():
+        deepsets_aggregate(xg, inc, wg, "add")                     # must not poison the later differentiable calls
+    og, oo = torch.optim.SGD([wg], lr=0.05), torch.optim.SGD([wo], lr=0.05)
+    for step in range(3):
+        og.zero_grad(); oo.zero_grad()
+        out = deepsets_aggregate(xg, inc, wg, "add")
+        ref = oracle.deepsets_aggregate(x, ei, wo, "add")
+        ref = torch.cat([ref, ref.new_zeros(32 - ref.shape[0], 32)])
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL, msg=lambda m: f"step {step}: {m}")
+        out.square().sum().backward()
+        ref.square().sum().backward()
+        torch.testing.assert_close(wg.grad.cpu(), wo.grad, rtol=RTOL, atol=ATOL, msg=lambda m: f"step {step} grad: {m}")
+        og.step(); oo.step()
+    assert "_allset_routed" not in wg.__dict__                    # nothing cached on a leaf
+    assert float((wg.detach().cpu() - w0).abs().max()) > 1e-3       # the steps did move it
+
+
+def test_persistent_float_ones_norm_skips_the_weight_stream_from_its_second_use(device):
+    """``torch.ones(nnz)`` kept by the caller is probed on its SECOND use (a per-forward temporary never is):
+    from then on the kernels skip the weight stream like for the reference's int64 ones."""
+    from allset_amd import Incidence
+    rng = np.random.default_rng(3)
+    ei = make_incidence(rng, 64, 32, 500)
+    inc = Incidence.from_edge_index(ei.to(device), n_src=64, n_dst=32)
+    ones = torch.ones(500, device=device)
+    first = inc.weights(ones)
+    assert first[0] is not None and first[1] is not None            # first sight: routed unseen (no host sync)
+    assert inc.weights(ones) == (None, None)                         # second use of the same live tensor: probed
+    assert inc.weights(ones) == (None, None)
+    other = torch.full((500,), 0.5, device=device)
+    inc.weights(other)
+    w = inc.weights(other)
+    assert w[0] is not None and float(w[0][0]) == 0.5
+    ones.mul_(2.0)                                                   # in-place update: a new version, routed again
+    w2 = inc.weights(ones); w2 = inc.weights(ones)
+    assert w2[0] is not None and float(w2[0][0]) == 2.0
+
+
 def test_max_ties_go_to_first_incidence(device):
     """Documented tie rule: arg-extremum = smallest CSR position = first in edge order."""
     from allset_amd import Incidence, ops

@@ -66,6 +66,64 @@ def test_processed_data_pt_reader(name):
     assert d2.edge_index.shape[1] == exp["edge_index"].shape[1] // 2 + n_v       # V->E half + one self loop per vertex
 
 
+GOLDEN_RAW = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raw")
+
+
+def _same_dataset(data, exp, prefix, exact_x=True):
+    assert data.x.dtype == torch.float32 and data.edge_index.dtype == torch.int64
+    if exact_x:
+        assert np.array_equal(data.x.numpy(), exp[f"{prefix}_x"])
+    else:
+        np.testing.assert_allclose(data.x.numpy(), exp[f"{prefix}_x"], rtol=0, atol=1e-6)
+    assert np.array_equal(data.y.numpy(), exp[f"{prefix}_y"])
+    assert np.array_equal(data.edge_index.numpy(), exp[f"{prefix}_edge_index"])
+    assert data.n_x == [int(exp[f"{prefix}_n_x"])] and data.num_hyperedges == [int(exp[f"{prefix}_num_hyperedges"])]
+
+
+def test_raw_readers_equal_the_reference_loaders_outputs():
+    """The LE (.content / .edges), Cornell (node-labels / hyperedges txt) and yelp (csv set) readers against what the REFERENCE's
+    own load_LE_dataset / load_cornell_dataset / load_yelp_dataset returned for the same files (tests/golden/raw/expected.npz,
+    written by oracle/gen_raw_fixture.py from the imported reference; load_other_datasets.py:32,293,198)."""
+    from allset_amd.train import load_cornell_dataset, load_le_dataset, load_yelp_dataset
+    exp = np.load(os.path.join(GOLDEN_RAW, "expected.npz"))
+    _same_dataset(load_le_dataset(GOLDEN_RAW, "toyLE"), exp, "le")
+    seed = int(exp["cornell_seed"])
+    np.random.seed(seed)                                   # the reference draws the noise from numpy's global generator
+    _same_dataset(load_cornell_dataset(GOLDEN_RAW, "toy-trips", feature_noise=0.6), exp, "cornell")
+    np.random.seed(seed)
+    _same_dataset(load_cornell_dataset(GOLDEN_RAW, "toy-trips", feature_noise=1.0, feature_dim=100), exp, "cornell100")
+    _same_dataset(load_yelp_dataset(os.path.join(GOLDEN_RAW, "yelp")), exp, "yelp")
+    # an explicit generator gives other noise, same everything else
+    d = load_cornell_dataset(GOLDEN_RAW, "toy-trips", feature_noise=0.6, rng=np.random.default_rng(0))
+    assert np.array_equal(d.edge_index.numpy(), exp["cornell_edge_index"]) and not np.array_equal(d.x.numpy(), exp["cornell_x"])
+
+
+def test_raw_readers_through_the_driver(tmp_path):
+    """load_data picks the reader by dataset name as reference convert_datasets_to_pygDataset.py:122-163 does, shifts the labels
+    of the Cornell / yelp sets to start at 0 (reference train.py:329-332) and feeds the same preprocessing chain."""
+    import shutil
+    from allset_amd.train import build_parser, load_data, preprocess
+    exp = np.load(os.path.join(GOLDEN_RAW, "expected.npz"))
+    shutil.copytree(os.path.join(GOLDEN_RAW, "toy-trips"), tmp_path / "walmart-trips")
+    for f in os.listdir(tmp_path / "walmart-trips"):
+        os.rename(tmp_path / "walmart-trips" / f, tmp_path / "walmart-trips" / f.replace("toy-trips", "walmart-trips"))
+    args = build_parser().parse_args(['--dname', 'walmart-trips-100', '--raw_data_dir', str(tmp_path), '--feature_noise', '1'])
+    np.random.seed(int(exp["cornell_seed"]))
+    data = load_data(args)
+    assert np.array_equal(data.x.numpy(), exp["cornell100_x"]) and int(data.y.min()) == 0
+    assert np.array_equal(data.y.numpy(), exp["cornell100_y"] - exp["cornell100_y"].min())
+    assert args.num_features == 100 and args.num_classes == len(np.unique(exp["cornell100_y"]))
+    d2 = preprocess(args, data)
+    n_v = int(exp["cornell100_n_x"])
+    assert int(d2.edge_index[0].max()) < n_v and int(d2.edge_index[1].min()) == n_v
+    args = build_parser().parse_args(['--dname', 'toyLE', '--raw_data_dir', GOLDEN_RAW])
+    data = load_data(args)
+    assert np.array_equal(data.edge_index.numpy(), exp["le_edge_index"]) and args.num_features == 6
+    args = build_parser().parse_args(['--dname', 'yelp', '--raw_data_dir', GOLDEN_RAW])
+    data = load_data(args)
+    assert np.array_equal(data.edge_index.numpy(), exp["yelp_edge_index"]) and int(data.y.min()) == 0
+
+
 def test_processed_data_pt_reader_rejects_other_payloads(tmp_path):
     from allset_amd.train import load_pyg_processed
     torch.save({"x": torch.zeros(2, 2)}, tmp_path / "data.pt")
