@@ -744,11 +744,20 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
         v = cols_to_rows(aggregate(rows_to_cols(g, group), hg.e2v, norm, aggr), group)
         with _bn_scope(vv, group):
             return dec2(v)
-    (hc,) = _stage(torch.split(x_owned, x_owned.shape[0] // K), enc1, x_owned.shape[0] // K, K, w, group)
+    rc_v, rc_e = x_owned.shape[0] // K, hg.n_e_pad // w // K
+    cbk = _blocked_exchange_width(x_owned[:rc_v], w, v2e_conv.f_enc, v2e_conv.f_dec, e2v_conv.f_enc, e2v_conv.f_dec)
+    if cbk:
+        # chunked AND repack-free: every chunk's MLPs write / read the [P][rc][d/P] buffers of its own all-to-all
+        enc1 = lambda t: v2e_conv._mlp_act(v2e_conv.f_enc, t, v2e_conv.dropout, out_cb=cbk)
+        mid = lambda t: e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, t, dropout, in_cb=cbk), e2v_conv.dropout,
+                                          out_cb=cbk)
+        dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, p_out, in_cb=cbk)
+    bl = bool(cbk)
+    (hc,) = _stage(torch.split(x_owned, rc_v), enc1, rc_v, K, w, group, bl)
     ec = aggregate(hc, hg.v2e, norm, aggr)
-    (gc,) = _stage(_unstage(ec, K, w, group), lambda get: mid(get()), hg.n_e_pad // w // K, K, w, group)
+    (gc,) = _stage(_unstage(ec, K, w, group, bl), lambda get: mid(get()), rc_e, K, w, group, bl)
     vc = aggregate(gc, hg.e2v, norm, aggr)
-    return torch.cat([dec2(get()) for get in _unstage(vc, K, w, group)])
+    return torch.cat([dec2(get()) for get in _unstage(vc, K, w, group, bl)])
 
 
 def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedHypergraph, dropout: float = 0.0,
@@ -831,8 +840,11 @@ def _a2a_async(out_views, in_views, group):
 
 
 class _Pipe:
-    def __init__(self, K: int, world: int, rc: int, group):
+    def __init__(self, K: int, world: int, rc: int, group, blocked: bool = False):
         self.K, self.P, self.rc, self.group = K, world, rc, group
+        # blocked: the row-side tensors of a chunk are ALREADY in the exchange layout [P][rc][dc] (column-blocked operands of
+        # the fused Linear kernels, ``_blocked_exchange_width``): no pack before a send, no unpack after a receive
+        self.blocked = blocked
         self.work = [None] * K
         self.bwork = [None] * K
         self.buf = [None] * K          # per-chunk [P, rc, dc] buffers (kept alive until their exchange was waited for)
@@ -849,14 +861,18 @@ class _Pipe:
 class _SendRowsChunk(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, pipe, k):
-        rc, d = h.shape
-        dc = d // pipe.P
+        if pipe.blocked:                                   # [P * rc, dc]: block j = columns of slice j of my rc rows
+            rc, dc = h.shape[0] // pipe.P, h.shape[1]
+            send = h.view(pipe.P, rc, dc)
+        else:
+            rc, d = h.shape
+            dc = d // pipe.P
+            send = _pack(h, pipe.P)
         if pipe.full is None:
             pipe.full = h.new_empty((pipe.P * pipe.K * rc, dc))
-        send = _pack(h, pipe.P)
         pipe.buf[k] = send
         pipe.work[k] = _a2a_async(pipe.blocks(pipe.full, k), send.unbind(0), pipe.group)
-        ctx.pipe, ctx.k, ctx.shape = pipe, k, (rc, d)
+        ctx.pipe, ctx.k = pipe, k
         return h.new_empty(0)
 
     @staticmethod
@@ -864,7 +880,7 @@ class _SendRowsChunk(torch.autograd.Function):
         pipe, k = ctx.pipe, ctx.k
         pipe.bwork[k].wait()
         recv, pipe.bbuf[k], pipe.bwork[k] = pipe.bbuf[k], None, None
-        return _unpack(recv), None, None
+        return (recv.view(pipe.P * pipe.rc, recv.shape[2]) if pipe.blocked else _unpack(recv)), None, None
 
 
 class _AssembleCols(torch.autograd.Function):
@@ -919,16 +935,21 @@ class _RecvRowsChunk(torch.autograd.Function):
         recv, pipe.buf[k], pipe.work[k] = pipe.buf[k], None, None
         ctx.pipe, ctx.k = pipe, k
         ctx.token_like = token
-        return _unpack(recv)
+        return recv.view(pipe.P * pipe.rc, recv.shape[2]) if pipe.blocked else _unpack(recv)
 
     @staticmethod
     def backward(ctx, g):
         pipe, k = ctx.pipe, ctx.k
-        rc, d = g.shape
-        dc = d // pipe.P
+        if pipe.blocked:
+            g = g.contiguous()
+            rc, dc = g.shape[0] // pipe.P, g.shape[1]
+            send = g.view(pipe.P, rc, dc)
+        else:
+            rc, d = g.shape
+            dc = d // pipe.P
+            send = _pack(g, pipe.P)
         if pipe.bfull is None:
             pipe.bfull = g.new_empty((pipe.P * pipe.K * rc, dc))
-        send = _pack(g, pipe.P)
         pipe.bbuf[k] = send
         pipe.bwork[k] = _a2a_async(pipe.blocks(pipe.bfull, k), send.unbind(0), pipe.group)
         return ctx.token_like.new_zeros(0), None, None
@@ -950,26 +971,27 @@ def pipeline_chunks(rows: int, want: int) -> int:
     return 1
 
 
-def _stage(items, fn, rc: int, K: int, world: int, group):
-    """``fn(item)`` (row-wise; one tensor or a tuple of tensors [rc, width] per chunk) for every chunk, each result handed
-    to its all-to-all at once.  Returns the assembled [P*K*rc, width/P] table(s), rows in global order."""
+def _stage(items, fn, rc: int, K: int, world: int, group, blocked: bool = False):
+    """``fn(item)`` (row-wise; one tensor or a tuple of tensors [rc, width] per chunk -- or, ``blocked``, [P*rc, width/P] in the
+    exchange layout) for every chunk, each result handed to its all-to-all at once.  Returns the assembled [P*K*rc, width/P]
+    table(s), rows in global order."""
     pipes, tokens = None, None
     for k, item in enumerate(items):
         ys = fn(item)
         ys = ys if isinstance(ys, tuple) else (ys,)
         if pipes is None:
-            pipes = [_Pipe(K, world, rc, group) for _ in ys]
+            pipes = [_Pipe(K, world, rc, group, blocked) for _ in ys]
             tokens = [[] for _ in ys]
         for pipe, toks, y in zip(pipes, tokens, ys):
             toks.append(_SendRowsChunk.apply(y.contiguous(), pipe, k))
     return tuple(_AssembleCols.apply(pipe, *toks) for pipe, toks in zip(pipes, tokens))
 
 
-def _unstage(table: Tensor, K: int, world: int, group):
-    """[P*K*rc, dc] -> K thunks; thunk k returns the owned row chunk [rc, P*dc] once its all-to-all (all K are already in
-    flight) has arrived."""
+def _unstage(table: Tensor, K: int, world: int, group, blocked: bool = False):
+    """[P*K*rc, dc] -> K thunks; thunk k returns the owned row chunk [rc, P*dc] (``blocked``: [P*rc, dc], the exchange layout
+    as it arrived) once its all-to-all (all K are already in flight) has arrived."""
     rc = table.shape[0] // (world * K)
-    pipe = _Pipe(K, world, rc, group)
+    pipe = _Pipe(K, world, rc, group, blocked)
     tokens = _ScatterCols.apply(table, pipe)
     return [(lambda tok=tok, k=k: _RecvRowsChunk.apply(tok, pipe, k)) for k, tok in enumerate(tokens)]
 

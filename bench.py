@@ -97,6 +97,9 @@ def parse_args(argv=None):
                     help="single GPU: capture the step (zero_grad + forward + backward + Adam, dropout seeds from a device counter) "
                          "as one hipGraph and time K replays -- the same kernels on the same data, without the ~100 host launches "
                          "per step that are ~10 %% of a step in the bf16 regime (configs[4] per-GPU shape)")
+    ap.add_argument("--chunk-entry", type=int, default=-1,
+                    help="N > 1: chunk count of the extra timed region of the column partition with the chunked, overlapped exchange "
+                         "(-1 = allset_amd.dist.auto_chunks: 4 at 1M rows per GPU, none below 500k; 0 = skip)")
     ap.add_argument("--no-wire-entry", dest="wire_entry", action="store_false",
                     help="N > 1: skip the extra timed region of the primary partition with the opt-in bf16 wire format")
     ap.add_argument("--self-loops", action="store_true",
@@ -657,6 +660,10 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         for key in state["order"]:
             base = key.split("+")[0]
             label = parallelism_label(args, base, world)
+            if "+chunks" in key:
+                kk = key.split("+chunks")[1]
+                label = label.replace("blocking", f"in {kk} overlapped chunks (the Linear kernels write / read each chunk's exchange "
+                                                  "buffers, asynchronous all-to-alls)")
             if "+bf16wire" in key:
                 label += ("; bf16 wire format (opt-in, results within the restated tolerance of tests/test_dist_cpu.py, not "
                           "bit-comparable)")
@@ -729,8 +736,14 @@ def main(argv=None, hooks=None):
         order = ["rows"] + [m for m in order if m != "rows"]
     wire_key = primary + "+bf16wire"
     want_wire = world > 1 and args.dtype == "f32" and args.wire_entry and args.pipeline_chunks <= 1
+    # N > 1: the column partition once more with the chunked, overlapped exchange (off by default: it has never run over xGMI;
+    # its own `partitions` entry so that the first multi-GPU lease measures what the overlap is worth -- never `value`)
+    kc = adist.auto_chunks(args.n_per_gpu) if args.chunk_entry < 0 else args.chunk_entry
+    chunk_key = f"columns+chunks{kc}"
+    want_chunks = world > 1 and "columns" in order and args.pipeline_chunks <= 1 and kc > 1
     want_preflight = dist.is_initialized() and (args.preflight == "on" or (args.preflight == "auto" and world > 1))
-    state = {"results": {}, "errors": {}, "order": order + ([wire_key] if want_wire else []), "preflight": None, "cpu_baseline": None}
+    state = {"results": {}, "errors": {}, "order": order + ([chunk_key] if want_chunks else []) + ([wire_key] if want_wire else []),
+             "preflight": None, "cpu_baseline": None}
     exit_fn = hooks.get("exit", os._exit)
 
     def on_expire(label):
@@ -780,6 +793,12 @@ def main(argv=None, hooks=None):
         state["preflight"] = region("preflight", lambda: preflight_collectives(args, world, rank, dev))
     for mode in order[1:]:
         partition_region(mode, mode)
+    if want_chunks:
+        args.pipeline_chunks = kc
+        try:
+            partition_region(chunk_key, "columns")
+        finally:
+            args.pipeline_chunks = 1
     # N > 1: the primary partition once more with the opt-in bf16 WIRE format (allset_amd.dist.set_wire_dtype: fp32 tensors and
     # fp32 sums, every exchanged activation rounded once to bf16 -- half the bytes per link, results changed within the tolerance
     # tests/test_dist_cpu.py restates).  Its own `partitions` entry, never `value`.

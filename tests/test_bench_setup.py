@@ -88,7 +88,7 @@ def _bench_worker(rank, world, port, model, q):
     from test_dist_cpu import TorchPmaKernels
     hooks = {"device": "cpu", "aggregate": _oracle_aggregate, "kernels": TorchPmaKernels, "incidences": _tuple_incidences}
     argv = ["--gpus", str(world), "--n-per-gpu", "120", "--degree", "4", "--feature-dim", "32", "--steps", "2", "--warmup", "1",
-            "--model", model, "--heads", "2", "--dropout", "0.0"]
+            "--model", model, "--heads", "2", "--dropout", "0.0", "--chunk-entry", "2"]
     import contextlib
     import io
     buf = io.StringIO()
@@ -125,7 +125,8 @@ def test_bench_two_ranks_runs_both_partitions_and_reports_one_line(model):
     assert line["value"] == parts["columns"]["value"] and line["ms_per_step"] == parts["columns"]["ms_per_step"]
     assert line["cpu_baseline"] is None and line["vs_baseline"] is None and line["higher_is_better"] is True
     # regions run rows first (the plainest collectives), then the all-to-all partition, then the bf16 wire; the link preflight ran
-    assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+bf16wire"]
+    assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+chunks2", "columns+bf16wire"]
+    assert "2 overlapped chunks" in parts["columns+chunks2"]["parallelism"] and not parts["columns+chunks2"]["is_value"]
     pf = line["preflight"]["collectives"]
     assert any("all_gather" in k for k in pf) and any("reduce_scatter" in k for k in pf) and any("all_to_all" in k for k in pf)
     assert all(v["ms"] > 0 and v["gbps_per_link"] > 0 for v in pf.values())

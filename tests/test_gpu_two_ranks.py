@@ -307,7 +307,8 @@ def test_bench_bare_command_spawns_its_own_ranks():
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["ALLSET_DIST_BACKEND"] = "gloo"
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000", "--d", "128"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000", "--d", "128",
+           "--chunk-entry", "2"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -315,8 +316,8 @@ def test_bench_bare_command_spawns_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["nnz"] == 2 * 20000 * 16
     parts = line["partitions"]
-    assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+bf16wire"]
-    assert all("error" not in parts[k] for k in ("rows", "columns", "columns+bf16wire")), parts
+    assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+chunks2", "columns+bf16wire"]
+    assert all("error" not in parts[k] for k in ("rows", "columns", "columns+chunks2", "columns+bf16wire")), parts
     assert parts["columns"]["is_value"] and line["value"] == parts["columns"]["value"]
     assert any("all_to_all" in k for k in line["preflight"]["collectives"])
     early = [l for l in res.stderr.splitlines() if l.startswith("[bench] early line")]

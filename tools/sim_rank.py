@@ -22,6 +22,28 @@ DIST = os.environ.get("SIM_DIST", "fixed")          # fixed | zipf (BASELINE con
 model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
 mode = sys.argv[2] if len(sys.argv) > 2 else "rows"
 LINK = 60e9
+CHUNKS = int(os.environ.get("SIM_CHUNKS", "1"))     # columns: chunks of owned rows (the overlapped exchange's machinery; its all-to-alls become local copies)
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
+def _a2a_local(out_views, in_views, group):
+    # SIM_A2A_COPY=1: move the pieces with device copies (correct data, but 2 x 4 GB of copy traffic per step that a real
+    # all-to-all does on the links, not in HBM time -- the K = 1 path's stand-in moves nothing either); default: move nothing,
+    # the received buffers keep whatever they held (timing only: every kernel runs on the same shapes)
+    if os.environ.get("SIM_A2A_COPY") == "1":
+        for o, i in zip(out_views, in_views):
+            o.copy_(i)
+    else:
+        for o in out_views[:1]:
+            o.zero_()                       # (keeps NaN garbage of a fresh allocation out of the LayerNorms)
+    return _Done()
+
+
+adist._a2a_async = _a2a_local
 for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split(",")):
     adist._rows_to_cols = (lambda x, group=None, w=world: x if w == 1 else adist._pack(x, w).view(w * x.shape[0], x.shape[1] // w))
     adist._cols_to_rows = (lambda x, group=None, w=world: x if w == 1 else adist._unpack(x.view(w, x.shape[0] // w, x.shape[1])))
@@ -53,8 +75,8 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     def step():
         opt.zero_grad(set_to_none=True); x.grad = None
         if mode == "columns":
-            out = adist.colsharded_pma_layer(a, b, x, hg, dropout=0.5, training=True) if attn else \
-                adist.colsharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
+            out = adist.colsharded_pma_layer(a, b, x, hg, dropout=0.5, training=True, chunks=CHUNKS) if attn else \
+                adist.colsharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True, chunks=CHUNKS)
         else:
             out = adist.sharded_pma_layer(a, b, x, hg, dropout=0.5, training=True) if attn else \
                 adist.sharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True)
@@ -81,7 +103,7 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d, 2 if DT == torch.bfloat16 else 4)     # received per step (fwd + bwd)
     per_link = per_rank / max(world - 1, 1)
     comm = per_link / LINK * 1e3
-    print(f"{model} {mode} world={world}: per-rank compute {ms:7.2f} ms   exchange {per_rank/1e9:5.2f} GB per rank and step, "
+    print(f"{model} {mode}{f' chunks={CHUNKS}' if CHUNKS > 1 else ''} world={world}: per-rank compute {ms:7.2f} ms   exchange {per_rank/1e9:5.2f} GB per rank and step, "
           f"{per_link/1e9:4.2f} GB per link -> {comm:5.1f} ms at 60 GB/s   speed-up if serial {world*t1/(ms+comm) if world > 1 else 1.0:4.2f}x, "
           f"if fully overlapped {world*t1/max(ms, comm) if world > 1 else 1.0:4.2f}x", flush=True)
     del hg, shard, a, b, x, G, opt
