@@ -28,18 +28,20 @@ def state_dict_for(case: dict, g: Dict[str, np.ndarray]) -> Dict[str, torch.Tens
     return {k: torch.from_numpy(v) for k, v in sd_np.items()}
 
 
-def run_oracle(case: dict, sd: Dict[str, torch.Tensor]):
-    """Oracle forward + backward of loss = (logits * G).sum(); returns dict like the fixtures."""
+def run_oracle(case: dict, sd: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32):
+    """Oracle forward + backward of loss = (logits * G).sum(); returns dict like the fixtures.  ``dtype=torch.float64``: the
+    same oracle in double precision (the yardstick where fp32 rounding of the ORACLE itself exceeds the tolerance)."""
     from oracle import allset_oracle as oracle
-    sd = {k: v.clone() for k, v in sd.items()}
+    sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
-    x = torch.from_numpy(case["x"]).clone().requires_grad_(True)
+    x = torch.from_numpy(case["x"]).clone().to(dtype).requires_grad_(True)
     collect = {}
+    norm = torch.from_numpy(case["norm"])
     logits = oracle.setgnn_forward(sd, case["args"], x, torch.from_numpy(case["edge_index"]),
-                                   torch.from_numpy(case["norm"]), collect)
-    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape))
+                                   norm.to(dtype) if norm.is_floating_point() else norm, collect)
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape)).to(dtype)
     (logits * G).sum().backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
     return dict(logits=logits.detach(), v2e0=collect["v2e0"].detach(), e2v0=collect["e2v0"].detach(),
