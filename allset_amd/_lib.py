@@ -73,6 +73,14 @@ SIGNATURES = {
     "allset_fused_linear_bwd_all_slices_for": [c_int64, c_int64, c_int64, c_int, POINTER(c_int64)],
     "allset_fused_linear_bwd_all": [_P, c_int64, _P, c_float, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, c_int64,
                                     _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int64, c_int64, _P],
+    "allset_fused_linear_bwd_all_nm": [_P, c_int64, _P, c_float, _P, _P, c_int64, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, c_int64,
+                                       _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P],
+    "allset_fused_linear_fwd_nm": [_P, c_int64, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64, _P,
+                                   c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P],
+    "allset_col_moments_supported": [c_int64],
+    "allset_col_moments_slices": [c_int64, POINTER(c_int64)],
+    "allset_col_moments": [_P, c_int64, c_int64, c_int64, c_int, _P, _P, c_int64, _P],
+    "allset_col_affine_add": [_P, c_int64, _P, c_int64, _P, _P, c_int, c_int64, c_int64, _P],
     "allset_fused_linear_bwd_all_aux_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, _P],

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, const float* acc_in, int64_t ldacc, int64_t pstride_w, int64_t pstride_b,
-    int64_t pstride_ln) {
+    int64_t pstride_ln, float ln_inv) {                  // ln_inv: 1 / I (LayerNorm) or 0 (column affine): fused_bwd4.hip
   seed_in = resolve_seed(seed_base, seed_in);
   constexpr int OQ = OD / 4, OQD = OQ / 2, T = OQ / 8;
   constexpr int GS = ID * OQD;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
 
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: chunk bases live in scalar registers
-  const float inv_i = 1.f / static_cast<float>(ID);
+  const float inv_i = ln_inv;
   const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
   const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
   const uint32_t thr_in = drop_threshold(p_in);
@@ -536,7 +536,8 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                  int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb);
+                                  int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb,
+                                  float ln_inv);
 
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
@@ -580,12 +581,12 @@ static void launch_bwd_all(unsigned grid, hipStream_t st, bool ln, bool drop, bo
                            int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
                            const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in, float* gx,
                            int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n, const uint64_t* seed_base,
-                           const float* acc_in, int64_t ldacc, int64_t psw, int64_t psb, int64_t psl) {
+                           const float* acc_in, int64_t ldacc, int64_t psw, int64_t psb, int64_t psl, float ln_inv) {
 #define ALLSET_BWD_ALL_K(LN, DI, RI, HM, HA)                                                                                 \
   fused_linear_bwd_all_kernel<OD, ID, LN, DI, RI, HM, HA><<<grid, kMBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats,     \
                                                                                    gamma, beta, p_in, seed_in, gx, ldgx,      \
                                                                                    part_ln, part_w, part_b, n, seed_base,     \
-                                                                                   acc_in, ldacc, psw, psb, psl)
+                                                                                   acc_in, ldacc, psw, psb, psl, ln_inv)
 #ifdef ALLSET_ABL_SINGLE       // ablation builds: one instantiation, whatever the flags say
 #ifdef ALLSET_ABL_LIGHT
   ALLSET_BWD_ALL_K(true, false, false, false, false);
@@ -614,9 +615,13 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
                                      const float* beta, int relu_in, float p_in, uint64_t seed_in, float* gx,
                                      int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
                                      int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, const float* acc_in,
-                                     int64_t ldacc, int64_t part_stride, void* stream, int64_t gcb, int64_t xcb, int64_t gxcb) {
+                                     int64_t ldacc, int64_t part_stride, void* stream, int64_t gcb, int64_t xcb, int64_t gxcb,
+                                     int norm_mode = ALLSET_NORM_LAYER) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_all: negative size");
+  ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || norm_mode == ALLSET_NORM_COLUMN_AFFINE, "fused_linear_bwd_all: norm_mode must be ALLSET_NORM_LAYER or ALLSET_NORM_COLUMN_AFFINE");
+  ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || stats != nullptr, "fused_linear_bwd_all: the column-affine prologue needs the {0, 1} row statistics its forward wrote, gamma (scale) and beta (shift)");
+  const float ln_inv = norm_mode == ALLSET_NORM_COLUMN_AFFINE ? 0.f : 1.f / static_cast<float>(I);
   // part_stride = 0: three dense arrays [n_slices][O*I], [n_slices][O], [n_slices][2*I]; > 0: the three pointers address
   // the sections of ONE [n_slices][part_stride] buffer (one reduction launch for all of them)
   ALLSET_REQUIRE(part_stride == 0 || part_stride >= O * I, "fused_linear_bwd_all: part_stride smaller than a gW partial");
@@ -668,12 +673,12 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc,
-                                  nullptr, nullptr, gcb, xcb, gxcb);
+                                  nullptr, nullptr, gcb, xcb, gxcb, ln_inv);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }
 #define ALLSET_BWD_ALL_ARGS grid, st, has_ln, drop, relu, hm, ha, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in, \
-                            gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc, psw, psb, psl
+                            gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc, psw, psb, psl, ln_inv
 #ifdef ALLSET_ABL_SINGLE
   launch_bwd_all<128, 128>(ALLSET_BWD_ALL_ARGS);
 #else
@@ -722,7 +727,7 @@ extern "C" int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, con
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24), "fused_linear_bwd_all_aux: leading dimensions must stay below 2^24 elements");
   launch_fused_linear_bwd_roles(grid, st, false, false, false, false, gy, ldg, nullptr, 0.f, W, x, ldx, nullptr, nullptr, nullptr, 0.f, 0,
                                 gx, ldgx, part + O * I + O, part, part + O * I, n, nullptr, part_stride, part_stride, part_stride,
-                                nullptr, 0, aux_g, aux_w, 0, 0, 0);
+                                nullptr, 0, aux_g, aux_w, 0, 0, 0, 1.f / static_cast<float>(I));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -736,6 +741,20 @@ extern "C" int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const u
   return fused_linear_bwd_all_impl(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, gx, ldgx, part_ln,
                                    part_w, part_b, n_slices, n, O, I, seed_base, acc_in, ldacc, part_stride, stream, 0, 0, 0);
 }
+
+// allset_fused_linear_bwd_all with a choice of what the (stats, gamma, beta) prologue was in the forward (allset_fused_linear_fwd_nm):
+// ALLSET_NORM_COLUMN_AFFINE -> gx = (gy W) * gamma through the relu / dropout masks, no row-mean terms; part_ln = per-slice column
+// sums of gu * x and gu (the gradients of the caller's per-column scale and shift).
+extern "C" int allset_fused_linear_bwd_all_nm(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W,
+                                              const float* x, int64_t ldx, const float* stats, const float* gamma,
+                                              const float* beta, int norm_mode, int relu_in, float p_in, uint64_t seed_in, float* gx,
+                                              int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
+                                              int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, int64_t part_stride,
+                                              void* stream) {
+  return fused_linear_bwd_all_impl(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, gx, ldgx, part_ln,
+                                   part_w, part_b, n_slices, n, O, I, seed_base, nullptr, 0, part_stride, stream, 0, 0, 0, norm_mode);
+}
+
 
 // The same pass with gy / x / gx COLUMN-BLOCKED ([cols / cb][n][cb], ld == cb; 0 = row-major): see allset_fused_linear_fwd_blocked.
 extern "C" int allset_fused_linear_bwd_all_blocked(const float* gy, int64_t ldg, int64_t gy_block_cols, const uint32_t* mask,

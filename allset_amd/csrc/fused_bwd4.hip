@@ -74,7 +74,11 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, const float* acc_in,
-    int64_t ldacc, const float* __restrict__ aux_g, const float* __restrict__ aux_w, int64_t gcb, int64_t xcb, int64_t gxcb) {
+    int64_t ldacc, const float* __restrict__ aux_g, const float* __restrict__ aux_w, int64_t gcb, int64_t xcb, int64_t gxcb,
+    float ln_inv) {
+  // ln_inv: 1 / 128 for the LayerNorm backward; 0 drops its two row-mean terms -- with the {0, 1} row statistics the forward wrote
+  // in that mode, gx = gu * gamma: the backward of the per-column affine prologue (ALLSET_NORM_COLUMN_AFFINE, fused_fwd2.hip);
+  // part_ln then holds sum_r gu * x and sum_r gu per column.
   // gcb / xcb / gxcb: 0 = row-major with the operand's leading dimension; cb > 0 = COLUMN-BLOCKED [128 / cb][n][cb] (ld == cb) for gy /
   // x / gx: the layout of the column-sharded layer's exchange buffers (fused_fwd2.hip has the forward side).
   // HAS_AUX (plain Linear only): four auxiliary output columns rode along in the forward (PMA's folded logits, fused_mlp.hip
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
 
   if (wave < 4) {
     // =================================================== vector waves ===================================================
-    const float inv_i = 1.f / static_cast<float>(ID);
+    const float inv_i = ln_inv;
     const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
     const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
     const uint32_t thr_in = drop_threshold(p_in);
@@ -671,12 +675,13 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, const float* acc_in,
-                                  int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb) {
+                                  int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb,
+                                  float ln_inv) {
 #define ALLSET_ROLES_KA(LN, DI, RI, HM, HA, AX)                                                                                \
   fused_linear_bwd_roles_kernel<LN, DI, RI, HM, HA, AX><<<grid, kRBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, \
                                                                              beta, p_in, seed_in, gx, ldgx, part_ln, part_w,    \
                                                                              part_b, n, seed_base, psw, psb, psl, acc_in, ldacc, \
-                                                                             aux_g, aux_w, gcb, xcb, gxcb)
+                                                                             aux_g, aux_w, gcb, xcb, gxcb, ln_inv)
 #define ALLSET_ROLES_K(LN, DI, RI, HM, HA) ALLSET_ROLES_KA(LN, DI, RI, HM, HA, false)
   if (aux_g != nullptr) { ALLSET_ROLES_KA(false, false, false, false, false, true); return 0; }   // (plain Linear + four aux columns)
   if (acc_in != nullptr) { ALLSET_ROLES_K(false, false, false, false, true); return 0; }     // (bwd_all_combo: plain Linear only)

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
     float p_out, uint64_t seed_out, float* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n,
-    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out, int64_t xcb, int64_t ycb) {
+    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out, int64_t xcb, int64_t ycb, float ln_inv) {
+  // ln_inv: 1 / 128 for the LayerNorm prologue; 0 (with eps = 1) switches the row statistics off -- mean = 0, rstd = 1, which is
+  // what gets written to `stats` -- and leaves the per-column affine map x * gamma + beta: BatchNorm with batch statistics
+  // folded into (gamma, beta) by the caller (ALLSET_NORM_COLUMN_AFFINE, csrc/batchnorm.hip).
   // xcb / ycb: 0 = row-major [n][128] with leading dimension ldx / ldy; cb > 0 = COLUMN-BLOCKED [128 / cb][n][cb] (ld == cb): the
   // layout the column-sharded layer's all-to-all sends and receives (allset_amd/dist.py) -- reading / writing it here removes the
   // pack / unpack passes around the exchange.  A lane's 16 bytes stay inside one block (cb >= 4).
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
 
   if (wave < kF2VWaves) {
     // =================================================== vector waves ===================================================
-    const float inv_k = 1.f / static_cast<float>(KD);
+    const float inv_k = ln_inv;
     const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
     const float keep_out = DROP_OUT ? 1.f / (1.f - p_out) : 1.f;
     const uint32_t thr_in = drop_threshold(p_in), thr_out = drop_threshold(p_out);
@@ -354,13 +357,13 @@ int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux) {
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
-                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb) {
+                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv) {
   const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
   const unsigned grid = static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
 #define ALLSET_F2_K(LN, DI, DO)                                                                                               \
   fused_linear_fwd_roles_kernel<LN, DI, DO><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
                                                                        relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
-                                                                       mask_out, xcb, ycb)
+                                                                       mask_out, xcb, ycb, ln_inv)
   const int v = (gamma != nullptr ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);
   switch (v) {
     case 0: ALLSET_F2_K(false, false, false); break;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(fwd_x6_waves<HAS_LN>() * kWave) void fused_linear_f
     const float* __restrict__ bias, int relu_out, float p_out, uint64_t seed_out, float* __restrict__ y,
     int64_t ldy, float* __restrict__ stats, int64_t n, const uint64_t* __restrict__ seed_base,
     uint8_t* __restrict__ mask_out, const float* __restrict__ aux_w, const float* __restrict__ aux_b,
-    float* __restrict__ aux_out) {
+    float* __restrict__ aux_out, float ln_inv) {          // ln_inv: 1 / K (LayerNorm) or 0 (column affine, eps = 1): fused_fwd2.hip
   seed_in = resolve_seed(seed_base, seed_in);
   seed_out = resolve_seed(seed_base, seed_out);
   constexpr int kF6Waves = fwd_x6_waves<HAS_LN>();
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(fwd_x6_waves<HAS_LN>() * kWave) void fused_linear_f
 
   const int lane = tid & 63, wave = tid >> 6;
   const int ri = lane & 15, g = lane >> 4;
-  const float inv_k = 1.f / static_cast<float>(KD);
+  const float inv_k = ln_inv;
   const float keep_in = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
   const float keep_out = DROP_OUT ? 1.f / (1.f - p_out) : 1.f;
   const uint32_t thr_in = drop_threshold(p_in), thr_out = drop_threshold(p_out);
@@ -647,7 +647,7 @@ int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux);
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
-                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb);
+                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv);
 
 // 1 = cb is a usable column-block width for a K-column operand (a power of two, 4 <= cb <= K / 2, the operand's ld == cb)
 static bool block_cols_ok(int64_t cb, int64_t K, int64_t ld) {
@@ -659,9 +659,14 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
                                  int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
                                  float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
                                  uint32_t* mask_out, const float* aux_w, const float* aux_b, float* aux_out,
-                                 void* stream, int64_t xcb, int64_t ycb) {
+                                 void* stream, int64_t xcb, int64_t ycb, int norm_mode = ALLSET_NORM_LAYER) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
+  ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || norm_mode == ALLSET_NORM_COLUMN_AFFINE, "fused_linear_fwd: norm_mode must be ALLSET_NORM_LAYER or ALLSET_NORM_COLUMN_AFFINE");
+  ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || gamma != nullptr, "fused_linear_fwd: the column-affine prologue needs gamma (scale) and beta (shift)");
+  // column affine = the LayerNorm prologue with the row statistics switched off: mean = s * 0, rstd = rsqrt(q * 0 + 1)
+  const float ln_inv = norm_mode == ALLSET_NORM_COLUMN_AFFINE ? 0.f : 1.f / static_cast<float>(K);
+  if (norm_mode == ALLSET_NORM_COLUMN_AFFINE) eps = 1.f;
   ALLSET_REQUIRE(aux_out == nullptr || (aux_w != nullptr && aligned16(aux_out)), "fused_linear_fwd: aux_out needs aux_w and 16-byte alignment");
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_out >= 0.f && p_out < 1.f, "fused_linear_fwd: dropout p must be in [0,1)");
   if (!allset_fused_linear_supported(K, N)) {
@@ -683,7 +688,7 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
   if (fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
       (reinterpret_cast<uintptr_t>(stats) & 7u) == 0) {                   // K = N = 128: the split-role kernel (fused_fwd2.hip)
     launch_fused_linear_fwd_roles(st, x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy,
-                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out), xcb, ycb);
+                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out), xcb, ycb, ln_inv);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }
@@ -699,7 +704,7 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
 #define ALLSET_FUSED_FWD_F(KD, NT, LN, DI, DO)                                                                           \
   fused_linear_fwd_x6_kernel<KD, 32 * NT, LN, DI, DO><<<grid_x6, fwd_x6_waves<LN>() * kWave, 0, st>>>(                     \
       x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,            \
-      seed_base, reinterpret_cast<uint8_t*>(mask_out), aux_w, aux_b, aux_out)
+      seed_base, reinterpret_cast<uint8_t*>(mask_out), aux_w, aux_b, aux_out, ln_inv)
 #define ALLSET_FUSED_FWD(KD, NT)                                                      \
   do {                                                                                \
     const int v = (has_ln ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);    \
@@ -814,6 +819,19 @@ extern "C" int allset_fused_linear_fwd(const float* x, int64_t ldx, const float*
                                        void* stream) {
   return fused_linear_fwd_impl(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,
                                K, N, seed_base, mask_out, aux_w, aux_b, aux_out, stream, 0, 0);
+}
+
+// The same forward with a choice of what the (gamma, beta) prologue means: ALLSET_NORM_LAYER = LayerNorm (row statistics computed
+// here and written to `stats`), ALLSET_NORM_COLUMN_AFFINE = relu?(x) * gamma + beta per column, no row statistics (`stats` is
+// filled with {0, 1} so that the backward entries read what they expect) -- training-mode BatchNorm1d with the batch statistics
+// folded into (gamma, beta) by the caller (csrc/batchnorm.hip).
+extern "C" int allset_fused_linear_fwd_nm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int norm_mode,
+                                          int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias,
+                                          int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats,
+                                          int64_t n, int64_t K, int64_t N, const uint64_t* seed_base, uint32_t* mask_out,
+                                          void* stream) {
+  return fused_linear_fwd_impl(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,
+                               K, N, seed_base, mask_out, nullptr, nullptr, nullptr, stream, 0, 0, norm_mode);
 }
 
 // 1 = allset_fused_linear_fwd_blocked / allset_fused_linear_bwd_all_blocked take column-blocked operands at these widths

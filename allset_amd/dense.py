@@ -328,10 +328,11 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
                      beta: Optional[Tensor] = None, eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0,
                      seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0, seed_out: int = 0,
                      seed_base: Optional[Tensor] = None, mask_out: Optional[Tensor] = None,
-                     aux_w: Optional[Tensor] = None, aux_b: Optional[Tensor] = None, aux_out: Optional[Tensor] = None
-                     ) -> Tuple[Tensor, Optional[Tensor]]:
+                     aux_w: Optional[Tensor] = None, aux_b: Optional[Tensor] = None, aux_out: Optional[Tensor] = None,
+                     norm_mode: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
     """y = epi(pro(x) @ W^T + b) in one pass (csrc/fused_mlp.hip).  Returns (y, stats or None).  ``mask_out`` (int32
-    tensor of ``activation_mask_words(n, N)`` elements) receives the 1-bit ``y > 0`` mask for the backward kernels."""
+    tensor of ``activation_mask_words(n, N)`` elements) receives the 1-bit ``y > 0`` mask for the backward kernels.
+    ``norm_mode`` 1 (ALLSET_NORM_COLUMN_AFFINE): (gamma, beta) are a per-column scale / shift, no row statistics."""
     dev = require_device(x, weight, bias, gamma, beta)
     _check_f32(x, weight, bias, gamma, beta)
     x = _rowmajor(x)
@@ -340,6 +341,15 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
     weight = weight.contiguous()
     y = torch.empty((n, N), dtype=x.dtype, device=dev)
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev) if gamma is not None else None
+    if norm_mode:
+        if aux_out is not None or gamma is None:
+            raise _lib.AllSetHipError("fused_linear_fwd: the column-affine prologue takes gamma / beta and no auxiliary columns")
+        with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
+            check(_lib.load().allset_fused_linear_fwd_nm(
+                ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(norm_mode), int(relu_in), p_in, seed_in,
+                ptr(weight), ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
+                ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), stream_of(dev)), "allset_fused_linear_fwd_nm")
+        return y, stats
     with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
         check(_lib.load().allset_fused_linear_fwd(
             ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
@@ -513,8 +523,8 @@ def one_pass_preferred(O: int, I: int) -> bool:
 
 def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                          gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                         seed_base: Optional[Tensor] = None, acc_in: Optional[Tensor] = None, want_bias: bool = True
-                         ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor, Optional[Tensor]]:
+                         seed_base: Optional[Tensor] = None, acc_in: Optional[Tensor] = None, want_bias: bool = True,
+                         norm_mode: int = 0) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor, Optional[Tensor]]:
     """(gx, dgamma, dbeta, gW, gb) of the fused Linear from ONE pass over gy and x (include/allset_hip.h
     allset_fused_linear_bwd_all)."""
     dev = require_device(gy, mask, weight, x, stats, gamma, beta, acc_in)
@@ -539,6 +549,17 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
     flat = part.view(-1)
     part_w, part_b = flat, flat[O * I:]
     part_ln = flat[O * I + O:] if stats is not None else None
+    if norm_mode:
+        if acc_in is not None or stats is None:
+            raise _lib.AllSetHipError("fused_linear_bwd_all: the column-affine prologue takes stats / gamma / beta and no acc_in")
+        with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
+            check(lib.allset_fused_linear_bwd_all_nm(
+                ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()),
+                ptr(beta.contiguous()), int(norm_mode), int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w),
+                ptr(part_b if want_bias else None), P, n, O, I, ptr(seed_base), M, stream_of(dev)), "allset_fused_linear_bwd_all_nm")
+        red = reduce_partials(part)
+        return (gx, red[O * I + O:O * I + O + I], red[O * I + O + I:O * I + O + 2 * I], red[:O * I].view(O, I),
+                red[O * I:O * I + O] if want_bias else None)
     with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
         check(lib.allset_fused_linear_bwd_all(
             ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats),
@@ -619,6 +640,32 @@ def dropout_scale(shape, p: float, seed: int, device) -> Tensor:
         check(_lib.load().allset_relu_dropout_fwd(ptr(ones), float(p), int(seed), ptr(y), ones.numel(), ptr(_seed_base()), stream_of(device)),
               "allset_relu_dropout_fwd")
     return y
+
+
+class _HashDropout(torch.autograd.Function):
+    """``x * keep / (1 - p)`` with the library's counter-hash mask (a dropout site that is not the prologue / epilogue of a fused
+    kernel -- behind a torch BatchNorm, say -- still draws its mask the way every other site does: reproducible from the seed)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        scale = dropout_scale(x.shape, p, _draw_seed(), x.device)
+        ctx.save_for_backward(scale)
+        return x * scale
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return g * scale, None
+
+
+def hash_dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    """``F.dropout`` for device fp32 tensors through the hash mask; anything else through torch's generator."""
+    if not training or p <= 0.0:
+        return x
+    if x.is_cuda and x.dtype == torch.float32:
+        return _HashDropout.apply(x.contiguous(), float(p))
+    return torch.nn.functional.dropout(x, p=p, training=True)
 
 
 class _LayerNormFused(torch.autograd.Function):
@@ -1378,6 +1425,125 @@ class _SyncBatchNorm(torch.autograd.Function):
         gw = loc[d:].to(weight.dtype) if weight is not None else None
         gb = loc[:d].to(weight.dtype) if (weight is not None and has_bias) else None
         return gx.to(gy.dtype), gw, gb, None, None, None
+
+
+# ---- training-mode BatchNorm1d in front of a fused Linear (csrc/batchnorm.hip) ----------------------------------------------------
+
+def col_moments_supported(d: int) -> bool:
+    return bool(_lib.load().allset_col_moments_supported(int(d)))
+
+
+def col_moments(x: Tensor, relu_in: bool = False, center: Optional[Tensor] = None) -> Tensor:
+    """[d] column sums of ``f(x)`` (``center`` None) or of ``(f(x) - center)^2``; f = relu if ``relu_in``."""
+    dev = require_device(x, center)
+    _check_f32(x, center)
+    x = _rowmajor(x)
+    n, d = x.shape
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_col_moments_slices(n, byref(ns)), "allset_col_moments_slices")
+    part = torch.empty((ns.value, d), dtype=torch.float32, device=dev)
+    with on_device(dev), _timed("col_moments", dev, n * d * 4):
+        check(lib.allset_col_moments(ptr(x), _ld(x), n, d, int(relu_in), ptr(center.contiguous() if center is not None else None),
+                                     ptr(part), ns.value, stream_of(dev)), "allset_col_moments")
+    return reduce_partials(part) if ns.value > 1 else part[0]
+
+
+def col_affine_add_(gx: Tensor, x: Tensor, s: Tensor, t: Tensor, relu_mask: bool) -> Tensor:
+    """``gx += [x > 0 if relu_mask] * (f(x) * s + t)`` in place (the gradient of the batch statistics)."""
+    dev = require_device(gx, x, s, t)
+    _check_f32(gx, x, s, t)
+    n, d = x.shape
+    with on_device(dev), _timed("col_affine_add", dev, 3 * n * d * 4):
+        check(_lib.load().allset_col_affine_add(ptr(gx), _ld(gx), ptr(x), _ld(x), ptr(s.contiguous()), ptr(t.contiguous()),
+                                                int(relu_mask), n, d, stream_of(dev)), "allset_col_affine_add")
+    return gx
+
+
+def bn_linear_supported(bn, lin, x: Optional[Tensor] = None) -> bool:
+    """The HIP BatchNorm -> [dropout] -> Linear path takes this pair: affine fp32 BatchNorm1d of the Linear's input width, a width
+    the fused Linear kernels and the one-pass backward are built for; ``x`` (optional): also the operand itself (device fp32
+    16-byte aligned rows, at least two of them)."""
+    ok = (bn.affine and bn.weight is not None and bn.weight.dtype == torch.float32 and lin.weight.dtype == torch.float32 and
+          lin.bias is not None and lin.in_features == bn.num_features and
+          fused_linear_supported(lin.in_features, lin.out_features) and
+          bool(_lib.load().allset_fused_linear_bwd_all_supported(lin.out_features, lin.in_features, 1, 1, 1, 1, 0)) and
+          col_moments_supported(lin.in_features))
+    if ok and x is not None:
+        ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 2 and x.shape[1] == lin.in_features and
+              x.data_ptr() % 16 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0)
+    return ok
+
+
+class _BatchNormLinear(torch.autograd.Function):
+    """``y = epi( dropout_p_in( BatchNorm_train( f(x) ) ) @ W^T + b )``, f = relu if ``relu_in`` -- reference MLP.forward with
+    ``Normalization='bn'`` (layers.py:571-579: ``x = lin(dropout(bn(relu(x))))``), batch statistics.
+
+    Forward: two column reductions (mean, centred biased variance), then the fused Linear with the per-column affine prologue
+    ``f(x) * a + b`` (a = gamma * rstd, b = beta - mean * a): no normalised tensor is written.  Backward: the one-pass kernel gives
+    the direct input gradient, the weight / bias gradient and the column sums G_a = sum gu * f(x), G_b = sum gu; then
+        dgamma = rstd * (G_a - mean * G_b),  dbeta = G_b,
+        dmean = -a * G_b,  dvar = -1/2 * rstd^3 * gamma * (G_a - mean * G_b),
+        gx += mask * (f(x) * s + t),  s = 2 dvar / n,  t = dmean / n - s * mean          (one in-place pass)
+    Returns (y, mean, biased var) -- the caller updates the running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, bn_weight, bn_bias, weight, bias, eps, relu_in, p_in, relu_out, p_out):
+        n, d = x.shape
+        mean = col_moments(x, relu_in) / n
+        var = col_moments(x, relu_in, mean) / n
+        rstd = torch.rsqrt(var + eps)
+        a = bn_weight.float() * rstd
+        b = bn_bias.float() - mean * a
+        seed_in = _draw_seed() if p_in > 0.0 else 0
+        seed_out = _draw_seed() if p_out > 0.0 else 0
+        base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
+        keep_y = relu_out or p_out > 0.0
+        words = activation_mask_words(n, weight.shape[0]) if (keep_y and any(ctx.needs_input_grad)) else 0
+        mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
+        y, stats = fused_linear_fwd(x, weight, bias, a, b, 1.0, relu_in, p_in, seed_in, relu_out, p_out, seed_out, base, mask,
+                                    norm_mode=1)
+        ctx.save_for_backward(x, stats, a, b, weight, mask, mean, rstd, bn_weight)
+        ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), base, keep_y)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gm, _gv):
+        x, stats, a, b, weight, mask, mean, rstd, bn_weight = ctx.saved_tensors
+        relu_in, p_in, seed_in, p_out, base, keep_y = ctx.cfg
+        if keep_y and mask is None:
+            raise _lib.AllSetHipError("_BatchNormLinear: the forward ran without gradients enabled (no activation mask was kept)")
+        n = x.shape[0]
+        gx, g_a, g_b, gw, gb = fused_linear_bwd_all(gy.contiguous(), mask, p_out, weight, x, stats, a, b, relu_in, p_in, seed_in, base,
+                                                    want_bias=True, norm_mode=1)
+        core = g_a - mean * g_b                                    # sum_r gu * (f(x) - mean)
+        dgamma = rstd * core
+        dvar = -0.5 * rstd * rstd * rstd * bn_weight.float() * core
+        dmean = -a * g_b
+        s = dvar * (2.0 / n)
+        t = dmean / n - s * mean
+        if ctx.needs_input_grad[0]:
+            col_affine_add_(gx, x, s, t, relu_in)
+        else:
+            gx = None
+        return gx, dgamma.to(bn_weight.dtype), g_b.to(bn_weight.dtype), gw, gb, None, None, None, None, None
+
+
+def bn_linear(bn, lin, x: Tensor, relu_in: bool, p_in: float, relu_out: bool = False, p_out: float = 0.0) -> Tensor:
+    """``lin(dropout(bn(relu?(x))))`` (+ relu / dropout epilogue) in training mode on the HIP kernels, with torch's bookkeeping of
+    the running statistics (biased variance normalises, unbiased goes into ``running_var``)."""
+    y, mean, var = _BatchNormLinear.apply(x, bn.weight, bn.bias, lin.weight, lin.bias, float(bn.eps), bool(relu_in), float(p_in),
+                                          bool(relu_out), float(p_out))
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            n = x.shape[0]
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(bn.running_var.dtype), alpha=mom)
+    return y
 
 
 def batch_norm(bn: torch.nn.modules.batchnorm._BatchNorm, x: Tensor) -> Tensor:

@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from typing import Tuple, Optional, Union
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -153,6 +155,35 @@ class MLP(nn.Module):
             return False
         return all(lin.bias is not None and dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins)
 
+    def _bn_trainable(self, x: Tensor) -> bool:
+        """BatchNorm1d slots with BATCH statistics (training mode; round 4): each one, with the relu before it and the dropout
+        behind it, is the operand prologue of the Linear that follows -- two column reductions + a per-column affine map inside the
+        fused Linear kernel, and one extra in-place pass in the backward for the statistics' own gradient (``dense.bn_linear``,
+        csrc/batchnorm.hip).  Not inside a sharded scope (cross-rank / padded-row statistics keep ``dense.batch_norm``)."""
+        if not _on_hip(x) or x.dim() != 2 or x.dtype != torch.float32:
+            return False
+        scope = getattr(dense._sync_bn_state, "scope", None)
+        if scope is not None:             # a sharded layer's scope: only the trivial one (one rank, every local row a real row)
+            import torch.distributed as dist
+            valid, group = scope
+            if valid < x.shape[0] or (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+                return False
+        if os.environ.get("ALLSET_BN_TORCH", "0") == "1":           # comparison arm (tools, bench variants): torch's BatchNorm kernels
+            return False
+        bns = [nm for nm in self.normalizations if not isinstance(nm, nn.Identity)]
+        if not bns or not all(isinstance(nm, nn.BatchNorm1d) for nm in bns):
+            return False
+        if not all(nm.training or (nm.running_mean is None and nm.running_var is None) for nm in bns):
+            return False
+        if x.shape[0] < 2:
+            return False
+        for nm, lin in zip(self.normalizations, self.lins):
+            if lin.bias is None or not dense.fused_linear_supported(lin.in_features, lin.out_features):
+                return False
+            if not isinstance(nm, nn.Identity) and not dense.bn_linear_supported(nm, lin, x if lin is self.lins[0] else None):
+                return False
+        return True
+
     @staticmethod
     def _fold_bn(bn, lin) -> Tuple[Tensor, Tensor]:
         """(W', b') with ``lin(bn(x)) == x @ W'^T + b'`` for an eval-mode BatchNorm (differentiable w.r.t. W, b, gamma, beta)."""
@@ -213,6 +244,18 @@ class MLP(nn.Module):
                     ln.eps if ln is not None else 1e-5, relu_in=i > 0, p_in=p if i > 0 else 0.0,
                     relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0)
             return x
+        if self._bn_trainable(x):
+            last = len(self.lins) - 1
+            for i, lin in enumerate(self.lins):
+                nm = self.normalizations[i]
+                ro = i == last and post_p is not None
+                po = post_p if ro else 0.0
+                if isinstance(nm, nn.Identity):
+                    x = dense.fused_norm_linear(x, None, None, lin.weight, lin.bias, 1e-5, relu_in=i > 0, p_in=p if i > 0 else 0.0,
+                                                relu_out=ro, p_out=po)
+                else:               # relu -> BatchNorm (batch statistics) -> dropout -> Linear: one column-affine prologue
+                    x = dense.bn_linear(nm, lin, x, relu_in=i > 0, p_in=p if i > 0 else 0.0, relu_out=ro, p_out=po)
+            return x
         n0 = self.normalizations[0]
         x = _layer_norm(n0, x) if isinstance(n0, nn.LayerNorm) else _norm_module(n0, x)
         for i, lin in enumerate(self.lins[:-1]):
@@ -226,7 +269,7 @@ class MLP(nn.Module):
             elif isinstance(nxt, nn.Identity):         # relu -> dropout: one kernel
                 x = relu_dropout(a, p, self.training)
             else:                                      # BatchNorm1d: torch
-                x = F.dropout(_norm_module(nxt, F.relu(a)), p=p, training=self.training)
+                x = dense.hash_dropout(_norm_module(nxt, F.relu(a)), p, self.training)
         if post_p == 0.0 and dense.linear_bf16_supported(x, self.lins[-1].weight, self.lins[-1].bias):
             return _linear(self.lins[-1], x, relu_out=True)
         x = _linear(self.lins[-1], x)

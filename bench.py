@@ -107,6 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--model", default="deepsets", choices=["deepsets", "pma"],
                     help="deepsets = AllDeepSets (the headline, BASELINE configs[2]); pma = AllSetTransformer "
                          "(configs[3] per-GPU shape), not the driver's default")
+    ap.add_argument("--norm", default="ln", choices=["ln", "bn"],
+                    help="normalisation inside the MLPs: ln = LayerNorm (the stock train.py setting and the headline), bn = BatchNorm1d "
+                         "with batch statistics (the reference MLP's class default), a variant line")
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=20260928)
@@ -299,8 +302,8 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
 
     torch.manual_seed(args.seed)                                       # identical replicated weights on every rank
     attn = args.model == "pma"
-    v2e = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, heads=args.heads, attention=attn)
-    e2v = HalfNLHconv(d, d, d, 2, args.dropout, "ln", True, heads=args.heads, attention=attn)
+    v2e = HalfNLHconv(d, d, d, 2, args.dropout, args.norm, True, heads=args.heads, attention=attn)
+    e2v = HalfNLHconv(d, d, d, 2, args.dropout, args.norm, True, heads=args.heads, attention=attn)
     v2e.reset_parameters(); e2v.reset_parameters()
     v2e.to(dev).train(); e2v.to(dev).train()
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -630,7 +633,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
                                f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}), "
                                f"nnz={int(nnz_total)}, d={d}, " +
                                (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
-                                f"AllDeepSets layer (HalfNLHconv x2, 2-layer LN MLPs, aggr=add, dropout {args.dropout}), ") +
+                                f"AllDeepSets layer (HalfNLHconv x2, 2-layer {args.norm.upper()} MLPs, aggr=add, dropout {args.dropout}), ") +
                                "fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
                    "n_v": res["n_v"], "n_e": res["n_e"], "nnz": int(nnz_total), "d": d,
                    "parallelism": parallelism_label(args, value_key, world), "partition": value_key if world > 1 else None,

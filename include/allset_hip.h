@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 9   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); no entry point added or removed.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only" */
+#define ALLSET_ABI_VERSION 9   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only" */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -499,6 +499,38 @@ int allset_fused_linear_bwd_all_slices(int64_t n, int64_t* n_slices);      /* DE
 /* The slice count allset_fused_linear_bwd_all expects for these widths (ABI 6): the O = I = 128 kernel keeps ONE weight-gradient
  * accumulator per workgroup (n_slices = number of workgroups), the other widths one per wave. */
 int allset_fused_linear_bwd_all_slices_for(int64_t n, int64_t O, int64_t I, int has_acc, int64_t* n_slices);
+
+/* ---- training-mode BatchNorm1d of the reference MLP (`Normalization='bn'`, the constructor default: layers.py:499-517, 571-579) ----
+ * BatchNorm(f(x)) with batch statistics is a per-column affine map f(x) * a + b (a = gamma * rsqrt(var + eps), b = beta - mean * a):
+ * the caller takes the two column moments with allset_col_moments (+ allset_reduce_partials), hands (a, b) to the fused Linear
+ * as its prologue (norm_mode = ALLSET_NORM_COLUMN_AFFINE) and adds the statistics' own dependence on x to the input gradient
+ * with allset_col_affine_add.  No normalised tensor is written.  csrc/batchnorm.hip; allset_amd/dense.py _BatchNormLinear. */
+#define ALLSET_NORM_LAYER 0            /* (gamma, beta) = LayerNorm weight / bias; row statistics computed in the kernel */
+#define ALLSET_NORM_COLUMN_AFFINE 1    /* (gamma, beta) = per-column scale / shift; `stats` is filled with {0, 1} per row */
+/* allset_fused_linear_fwd without auxiliary columns + norm_mode (ALLSET_NORM_LAYER reproduces allset_fused_linear_fwd). */
+int allset_fused_linear_fwd_nm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int norm_mode,
+                               int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
+                               float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n, int64_t K,
+                               int64_t N, const uint64_t* seed_base, uint32_t* mask_out, void* stream);
+/* allset_fused_linear_bwd_all without acc_in + norm_mode.  ALLSET_NORM_COLUMN_AFFINE: stats = the {0, 1} rows the forward wrote;
+ * gx = (gy W) * gamma through the relu / dropout masks (no row-mean terms); part_ln[slice] = {sum_r gu * f(x), sum_r gu} per column
+ * = the gradients of the column scale and shift. */
+int allset_fused_linear_bwd_all_nm(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x,
+                                   int64_t ldx, const float* stats, const float* gamma, const float* beta, int norm_mode,
+                                   int relu_in, float p_in, uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln,
+                                   float* part_w, float* part_b, int64_t n_slices, int64_t n, int64_t O, int64_t I,
+                                   const uint64_t* seed_base, int64_t part_stride, void* stream);
+/* part[slice][c] = sum over the slice's rows of f(x)[r,c] (center == NULL) or of (f(x)[r,c] - center[c])^2, f = relu if relu_in
+ * else identity; x: f32 rows of d (4 <= d <= 1024, d % 4 == 0), 16-byte aligned; n_slices from allset_col_moments_slices(n); the
+ * caller sums the slices (allset_reduce_partials) and divides by n.  Two calls give mean and the centred (biased) variance. */
+int allset_col_moments_supported(int64_t d);
+int allset_col_moments_slices(int64_t n, int64_t* n_slices);
+int allset_col_moments(const float* x, int64_t ldx, int64_t n, int64_t d, int relu_in, const float* center, float* part,
+                       int64_t n_slices, void* stream);
+/* gx[r,c] += m * (f(x)[r,c] * s[c] + t[c]) in place, m = (x[r,c] > 0) if relu_mask else 1: the gradient of the batch statistics
+ * (s = 2 dvar / n, t = dmean / n - s * mean). */
+int allset_col_affine_add(float* gx, int64_t ldgx, const float* x, int64_t ldx, const float* s, const float* t, int relu_mask,
+                          int64_t n, int64_t d, void* stream);
 int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x,
                                 int64_t ldx, const float* stats, const float* gamma, const float* beta, int relu_in, float p_in,
                                 uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b,

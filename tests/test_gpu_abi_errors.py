@@ -121,3 +121,52 @@ def test_blocked_and_aux_entries_reject_bad_arguments(device):
     _err(lib, h(P(y), d, P(W), P(x), d, None, P(w4), P(gx), d, P(part), M, ns.value, n, d, d, st))
     assert lib.allset_fused_linear_bwd_all_aux_supported(64, 128) == 0
     torch.cuda.synchronize()
+
+
+def test_batchnorm_entries_reject_bad_arguments(device):
+    """ABI 9 additions (csrc/batchnorm.hip, norm_mode of the fused Linear): status codes, not launches."""
+    from allset_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n, d = 100, 128
+    x = torch.randn(n, d, device=device)
+    P = lambda t: t.data_ptr()
+    ns = ctypes.c_int64(0)
+    assert lib.allset_col_moments_slices(n, ctypes.byref(ns)) == 0 and ns.value >= 1
+    part = torch.empty(ns.value, d, device=device)
+    f = lib.allset_col_moments
+    assert f(P(x), d, n, d, 0, None, P(part), ns.value, st) == 0
+    assert "width" in _err(lib, f(P(x), d, n, 6, 0, None, P(part), ns.value, st))            # width not a multiple of 4
+    _err(lib, f(P(x), d, n, d, 0, None, P(part), ns.value + 1, st))                            # wrong slice count
+    _err(lib, f(P(x), d - 4, n, d, 0, None, P(part), ns.value, st))                            # leading dimension below the width
+    _err(lib, f(P(x) + 4, d, n, d, 0, None, P(part), ns.value, st))                            # rows not 16-byte aligned
+    _err(lib, f(None, d, n, d, 0, None, P(part), ns.value, st))
+    _err(lib, lib.allset_col_moments_slices(-1, ctypes.byref(ns)))
+    gx, s = torch.zeros(n, d, device=device), torch.ones(d, device=device)
+    h = lib.allset_col_affine_add
+    assert h(P(gx), d, P(x), d, P(s), P(s), 1, n, d, st) == 0
+    _err(lib, h(P(gx), d, P(x), d, None, P(s), 1, n, d, st))
+    _err(lib, h(P(gx), d, P(x), d, P(s), P(s), 1, -3, d, st))
+    _err(lib, h(P(gx), d, P(x), d, P(s), P(s), 1, n, 2048, st))
+    # norm_mode: unknown value, column affine without scale / shift, column affine backward without the row statistics
+    W, b = torch.randn(d, d, device=device), torch.zeros(d, device=device)
+    y, stats = torch.empty(n, d, device=device), torch.empty(n, 2, device=device)
+    fw = lib.allset_fused_linear_fwd_nm
+    assert fw(P(x), d, P(s), P(b), 1e-5, 1, 0, 0.0, 0, P(W), P(b), 0, 0.0, 0, P(y), d, P(stats), n, d, d, None, None, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(stats.cpu(), torch.tensor([0.0, 1.0]).repeat(n, 1))                     # what the backward entries expect
+    assert "norm_mode" in _err(lib, fw(P(x), d, P(s), P(b), 1e-5, 7, 0, 0.0, 0, P(W), P(b), 0, 0.0, 0, P(y), d, P(stats), n, d, d, None, None, st))
+    _err(lib, fw(P(x), d, None, None, 1e-5, 1, 0, 0.0, 0, P(W), P(b), 0, 0.0, 0, P(y), d, P(stats), n, d, d, None, None, st))
+    sl = ctypes.c_int64(0)
+    lib.allset_fused_linear_bwd_all_slices_for(n, d, d, 0, ctypes.byref(sl))
+    M = d * d + d + 2 * d
+    partb = torch.empty(sl.value, M, device=device)
+    gy, gxb = torch.randn(n, d, device=device), torch.empty(n, d, device=device)
+    bw = lib.allset_fused_linear_bwd_all_nm
+    flat = partb.view(-1)
+    args = lambda stats_p, mode: (P(gy), d, None, 0.0, P(W), P(x), d, stats_p, P(s), P(b), mode, 0, 0.0, 0, P(gxb), d,
+                                  flat[d * d + d:].data_ptr(), P(flat), flat[d * d:].data_ptr(), sl.value, n, d, d, None, M, st)
+    assert bw(*args(P(stats), 1)) == 0
+    _err(lib, bw(*args(None, 1)))
+    _err(lib, bw(*args(P(stats), 5)))
+    torch.cuda.synchronize()

@@ -53,7 +53,11 @@ class _ShapeProbe:
 CASES = [("rand50_ds_add", {}), ("rand50_pma_h4", {}), ("cora_ds_add", {}), ("citeseer_pma_h4", {}),
          ("rand50_ds_add", dict(MLP_num_layers=3, Classifier_num_layers=2, All_num_layers=2)),
          ("rand50_ds_mean", dict(dropout=0.2, Classifier_num_layers=2)),
-         ("rand50_pma_h4", dict(All_num_layers=2, Classifier_num_layers=2, MLP_hidden=128))]
+         ("rand50_pma_h4", dict(All_num_layers=2, Classifier_num_layers=2, MLP_hidden=128)),
+         # Normalization='bn' (the reference MLP's class default) in TRAINING mode: batch statistics; the 64 -> 64 MLPs take the HIP
+         # BatchNorm path (column moments + column-affine Linear prologue, csrc/batchnorm.hip), the 16 -> 64 one torch's
+         ("rand50_ds_add", dict(normalization="bn")),
+         ("rand50_ds_add", dict(normalization="bn", All_num_layers=2, MLP_num_layers=3))]
 
 
 @pytest.mark.parametrize("name,over", CASES, ids=lambda v: v if isinstance(v, str) else ("-".join(f"{k}{w}" for k, w in v.items()) or "stock"))
