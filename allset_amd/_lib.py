@@ -80,6 +80,7 @@ SIGNATURES = {
     "allset_col_moments_supported": [c_int64],
     "allset_col_moments_slices": [c_int64, POINTER(c_int64)],
     "allset_col_moments": [_P, c_int64, c_int64, c_int64, c_int, _P, _P, c_int64, _P],
+    "allset_col_moments2": [_P, c_int64, c_int64, c_int64, c_int, _P, c_int64, _P],
     "allset_col_affine_add": [_P, c_int64, _P, c_int64, _P, _P, c_int, c_int64, c_int64, _P],
     "allset_fused_linear_bwd_all_aux_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,

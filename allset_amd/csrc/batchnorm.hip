@@ -1,5 +1,5 @@
 // Training-mode BatchNorm1d of the reference MLP (`Normalization='bn'`, the constructor default: layers.py:499-517, applied at
-// layers.py:571-579) as TWO column reductions + a column-affine prologue of the fused Linear kernels:
+// layers.py:571-579) as ONE column-moment pass + a column-affine prologue of the fused Linear kernels:
 //
 //   mean_c = sum_r f(x)[r,c] / n,   var_c = sum_r (f(x)[r,c] - mean_c)^2 / n      f = relu (behind a Linear) or identity
 //   BatchNorm(f(x)) = f(x) * a_c + b_c,   a_c = gamma_c * rsqrt(var_c + eps),  b_c = beta_c - mean_c * a_c
@@ -12,11 +12,11 @@
 //
 // (allset_amd/dense.py `_BatchNormLinear` has the closed forms of dmean / dvar from the kernels' column sums).
 //
-//   col_moments_kernel      per-slice partial column sums of f(x) or of (f(x) - center)^2     1 read, HBM-bound streaming
-//   col_affine_add_kernel   gx += mask * (f(x) * s + t), in place                              2 reads + 1 write, HBM-bound
+//   col_moments2_kernel     per-slice fp64 sums of f(x) and f(x)^2: both moments from ONE read    1 read, HBM-bound streaming
+//   col_moments_kernel      per-slice fp32 sums of f(x) or of (f(x) - center)^2 (two-pass form)   1 read each
+//   col_affine_add_kernel   gx += mask * (f(x) * s + t), in place                                 2 reads + 1 write, HBM-bound
 //
-// Two passes over x for the statistics (the centred second moment: no cancellation), each a plain streaming read; partials are
-// summed by allset_reduce_partials in a fixed order -- no atomics, bitwise reproducible.
+// Partials are summed in a fixed order -- no atomics, bitwise reproducible.
 #include "common.h"
 
 namespace allset {
@@ -80,6 +80,62 @@ __global__ __launch_bounds__(kBlock) void col_moments_kernel(const float* __rest
   }
 }
 
+// Both raw moments in ONE read: per-slice sums of f(x) and f(x)^2 accumulated in fp64 (the kernel is a streaming read; the fp64
+// adds ride under it), so that var = E[f^2] - mean^2 is taken in double precision by the caller -- cancellation costs
+// (mean^2 / var) * 2^-53 there, nothing at any realistic scale.  part: f64 [slice][2][d].
+__global__ __launch_bounds__(kBlock) void col_moments2_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int d,
+                                                              int relu_in, double* __restrict__ part, int64_t rows_per_slice) {
+  __shared__ double red[2][kBlock][4];
+  const int Q = d >> 2;
+  const int RG = kBlock / Q;
+  const int t = threadIdx.x;
+  const int q = t % Q, rg = t / Q;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_slice;
+  const int64_t r1 = min(r0 + rows_per_slice, n);
+  double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+  if (rg < RG) {
+    const float* xp = x + 4 * q;
+    int64_t r = r0 + rg;
+    for (; r + 3 * RG < r1; r += 4 * RG) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (r + u * RG) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double a = static_cast<double>(relu_in ? fmaxf(w[k], 0.f) : w[k]);
+          s1[k] += a; s2[k] = fma(a, a, s2[k]);
+        }
+      }
+    }
+    for (; r < r1; r += RG) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + r * ldx);
+      float w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double a = static_cast<double>(relu_in ? fmaxf(w[k], 0.f) : w[k]);
+        s1[k] += a; s2[k] = fma(a, a, s2[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][t][k] = s1[k]; red[1][t][k] = s2[k]; }
+  __syncthreads();
+  if (t < Q) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      double a[4] = {red[m][t][0], red[m][t][1], red[m][t][2], red[m][t][3]};
+      for (int g = 1; g < RG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += red[m][g * Q + t][k];
+      double* o = part + (static_cast<int64_t>(blockIdx.x) * 2 + m) * d + 4 * t;
+      o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void col_affine_add_kernel(float* __restrict__ gx, int64_t ldgx, const float* __restrict__ x,
                                                                 int64_t ldx, const float* __restrict__ s,
                                                                 const float* __restrict__ tt, int relu_mask, int64_t n, int d) {
@@ -138,6 +194,30 @@ extern "C" int allset_col_moments(const float* x, int64_t ldx, int64_t n, int64_
   const int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
   col_moments_kernel<<<static_cast<unsigned>(n_slices), kBlock, 0, st>>>(x, ldx, n, static_cast<int>(d), relu_in, center, part,
                                                                          rows_per_slice);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_col_moments2(const float* x, int64_t ldx, int64_t n, int64_t d, int relu_in, double* part, int64_t n_slices,
+                                   void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "col_moments2: negative size");
+  if (!allset_col_moments_supported(d)) {
+    set_error("col_moments2: width %lld not built (4 <= d <= 1024, d %% 4 == 0)", static_cast<long long>(d));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  int64_t want = 0;
+  allset_col_moments_slices(n, &want);
+  ALLSET_REQUIRE(part != nullptr && n_slices == want, "col_moments2: part must hold allset_col_moments_slices(n) x 2 rows of d doubles");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(part, 0, static_cast<size_t>(n_slices) * 2 * d * sizeof(double), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(x != nullptr && ldx >= d && ldx % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(part) & 7u) == 0,
+                 "col_moments2: x rows must be 16-byte aligned, part 8-byte aligned");
+  const int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
+  col_moments2_kernel<<<static_cast<unsigned>(n_slices), kBlock, 0, st>>>(x, ldx, n, static_cast<int>(d), relu_in, part, rows_per_slice);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

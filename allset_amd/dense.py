@@ -1449,6 +1449,25 @@ def col_moments(x: Tensor, relu_in: bool = False, center: Optional[Tensor] = Non
     return reduce_partials(part) if ns.value > 1 else part[0]
 
 
+def col_mean_var(x: Tensor, relu_in: bool = False) -> Tuple[Tensor, Tensor]:
+    """(mean, biased variance) per column of ``f(x)`` from ONE read: fp64 sums of f and f^2 (``allset_col_moments2``), combined in
+    fp64, returned as fp32."""
+    dev = require_device(x)
+    _check_f32(x)
+    x = _rowmajor(x)
+    n, d = x.shape
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_col_moments_slices(n, byref(ns)), "allset_col_moments_slices")
+    part = torch.empty((ns.value, 2, d), dtype=torch.float64, device=dev)
+    with on_device(dev), _timed("col_moments", dev, n * d * 4):
+        check(lib.allset_col_moments2(ptr(x), _ld(x), n, d, int(relu_in), ptr(part), ns.value, stream_of(dev)), "allset_col_moments2")
+    tot = part.sum(0) if ns.value > 1 else part[0]
+    mean = tot[0] / n
+    var = (tot[1] / n - mean * mean).clamp_(min=0.0)
+    return mean.float(), var.float()
+
+
 def col_affine_add_(gx: Tensor, x: Tensor, s: Tensor, t: Tensor, relu_mask: bool) -> Tensor:
     """``gx += [x > 0 if relu_mask] * (f(x) * s + t)`` in place (the gradient of the batch statistics)."""
     dev = require_device(gx, x, s, t)
@@ -1490,8 +1509,7 @@ class _BatchNormLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bn_weight, bn_bias, weight, bias, eps, relu_in, p_in, relu_out, p_out):
         n, d = x.shape
-        mean = col_moments(x, relu_in) / n
-        var = col_moments(x, relu_in, mean) / n
+        mean, var = col_mean_var(x, relu_in)
         rstd = torch.rsqrt(var + eps)
         a = bn_weight.float() * rstd
         b = bn_bias.float() - mean * a

@@ -23,6 +23,9 @@ def test_col_moments_and_affine_add(n, d, relu_in, device):
     s2 = dense.col_moments(x, relu_in, mean)
     ref2 = ((f - mean.double()) ** 2).sum(0)
     torch.testing.assert_close(s2.double(), ref2, rtol=2e-5, atol=1e-6 * float(ref2.max()))
+    m1, v1 = dense.col_mean_var(x, relu_in)                      # one read, fp64 raw moments
+    torch.testing.assert_close(m1.double(), f.mean(0), rtol=1e-6, atol=1e-6 * float(f.abs().max()))
+    torch.testing.assert_close(v1.double(), f.var(0, unbiased=False), rtol=1e-5, atol=1e-7 * float(f.var(0, unbiased=False).max()))
     gx = torch.randn(n, d, generator=g).to(device)
     s, t = torch.randn(d, generator=g).to(device), torch.randn(d, generator=g).to(device)
     want = gx.double() + ((x > 0).double() if relu_in else 1.0) * (f * s.double() + t.double())

@@ -62,21 +62,7 @@ CASES = [("rand50_ds_add", {}), ("rand50_pma_h4", {}), ("cora_ds_add", {}), ("ci
 
 @pytest.mark.parametrize("name,over", CASES, ids=lambda v: v if isinstance(v, str) else ("-".join(f"{k}{w}" for k, w in v.items()) or "stock"))
 def test_training_step_matches_oracle_with_the_products_masks(name, over, device, monkeypatch):
-    from allset_amd import SetGNN, dense
-    from oracle import allset_oracle as oracle
-    case = cases.build_case(name)
-    args = SimpleNamespace(**{**vars(case["args"]), **over})
-    assert args.dropout > 0.0
-    torch.manual_seed(case["seed"])
-    model = SetGNN(args)
-    model.reset_parameters()
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model.train().to(device)
-
-    x_np, ei_np, norm_np = case["x"], case["edge_index"], case["norm"]
-    x = torch.from_numpy(x_np).to(device).requires_grad_(True)
-    data = SimpleNamespace(x=x, edge_index=torch.from_numpy(ei_np).clone().to(device), norm=torch.from_numpy(norm_np).to(device))
-
+    from allset_amd import dense
     seeds = []
     real_draw = dense._draw_seed
 
@@ -85,6 +71,33 @@ def test_training_step_matches_oracle_with_the_products_masks(name, over, device
         seeds.append(s)
         return s
     monkeypatch.setattr(dense, "_draw_seed", recording_draw)
+    # BatchNorm with batch statistics couples every row to every other: ONE relu input within fp32 rounding of zero moves all
+    # gradients by percents (either side's value is a correct subgradient; tests/test_gpu_two_ranks.py::_model_seed has the same
+    # remark).  Those configurations are evaluated on the first parameter draw whose float64 oracle gradient is stable under a
+    # 2e-6 perturbation of x; the LayerNorm configurations (row-local: a kink moves one row) keep their single fixed draw.
+    bn = over.get("normalization") == "bn"
+    for attempt in range(12 if bn else 1):
+        seeds.clear()
+        if _one_training_step(name, over, device, seeds, attempt, need_stable=bn):
+            return
+    pytest.skip("no kink-free parameter draw in twelve attempts")
+
+
+def _one_training_step(name, over, device, seeds, attempt, need_stable):
+    from allset_amd import SetGNN
+    from oracle import allset_oracle as oracle
+    case = cases.build_case(name)
+    args = SimpleNamespace(**{**vars(case["args"]), **over})
+    assert args.dropout > 0.0
+    torch.manual_seed(case["seed"] + attempt)
+    model = SetGNN(args)
+    model.reset_parameters()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.train().to(device)
+
+    x_np, ei_np, norm_np = case["x"], case["edge_index"], case["norm"]
+    x = torch.from_numpy(x_np).to(device).requires_grad_(True)
+    data = SimpleNamespace(x=x, edge_index=torch.from_numpy(ei_np).clone().to(device), norm=torch.from_numpy(norm_np).to(device))
 
     torch.manual_seed(1234)                               # governs torch's device generator (input dropout) and the host seeds
     logits = model(data)
@@ -109,6 +122,19 @@ def test_training_step_matches_oracle_with_the_products_masks(name, over, device
         if m.numel() >= 2000:
             assert abs(1.0 - float(m.float().mean()) - p) < 0.05, (shape, p, float(m.float().mean()))
 
+    if need_stable:                                       # float64 oracle with the same masks at x and at x +- 2e-6 * direction
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        dirn = torch.from_numpy(np.random.default_rng(attempt).standard_normal(x_np.shape))
+        grads = []
+        for sgn in (0.0, 1.0, -1.0):
+            xp = (torch.from_numpy(x_np).double() + sgn * 2e-6 * dirn).requires_grad_(True)
+            lp = oracle.setgnn_forward(sd64, args, xp, torch.from_numpy(ei_np), torch.from_numpy(norm_np), drop=oracle.ExplicitDropout(masks))
+            (lp * G.cpu().double()).sum().backward()
+            grads.append(xp.grad)
+        gs = max(1.0, float(grads[0].abs().max()))
+        if max(float((g - grads[0]).abs().max()) for g in grads[1:]) > 3e-4 * gs:
+            return False
+
     # ---- oracle, training mode, same masks
     sdo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     xo = torch.from_numpy(x_np).clone().requires_grad_(True)
@@ -130,6 +156,7 @@ def test_training_step_matches_oracle_with_the_products_masks(name, over, device
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         close(p.grad.cpu(), exp, f"grad {k}", scale_floor=1e-2 * gscale)     # (analytically-zero gradients: tests/util.py)
+    return True
 
 
 def test_eval_mode_draws_no_seed(device, monkeypatch):
