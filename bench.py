@@ -27,9 +27,10 @@ N > 1 -- two partitions of the same job (allset_amd/dist.py, DESIGN.md section 7
            one reduce-scatter of the [n_V, d] vertex table per direction;
   columns  column-sharded aggregation: every rank holds the whole incidence and d/N feature columns of every row;
            four all-to-alls per direction-pair, 1/N of the row scheme's bytes at N = 8, overlapped with the dense work.
-``--shard auto`` (default) reports the one ``allset_amd.dist.choose_sharding`` picks as ``value`` / ``ms_per_step``
-(``config.parallelism`` says which); both are timed, each in its own region of the same K steps, and appear under
-``partitions``, so a scaling record always carries the north-star partition too.  ``preflight`` = the layer's four
+Both are timed in every N > 1 run, each in its own region of the same K steps (plus the column partition with the chunked
+overlapped exchange), and appear under ``partitions``, so a scaling record always carries the north-star partition.
+``--shard auto`` (default) reports the FASTEST of these exact (fp32-wire) executions as ``value`` / ``ms_per_step``
+(``config.partition`` / ``config.parallelism`` say which); ``--shard rows`` / ``columns`` pin it.  ``preflight`` = the layer's four
 collectives timed alone at this job's message sizes (GB/s per rank and per xGMI link).
 
 Extra objects in the JSON line:
@@ -416,6 +417,18 @@ def parallelism_label(args, mode, world):
     return f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; all-to-all exchange {how})"
 
 
+def region_label(args, key, world):
+    """parallelism_label for a region key: a partition name plus '+chunksK' / '+bf16wire'."""
+    label = parallelism_label(args, key.split("+")[0], world)
+    if "+chunks" in key:
+        kk = key.split("+chunks")[1].split("+")[0]
+        label = label.replace("blocking", f"in {kk} overlapped chunks (the Linear kernels write / read each chunk's exchange buffers, "
+                                          "asynchronous all-to-alls)")
+    if "+bf16wire" in key:
+        label += "; bf16 wire format (opt-in, results within the restated tolerance of tests/test_dist_cpu.py, not bit-comparable)"
+    return label
+
+
 def kernel_entry(v, steps, rows=None, d=None, name=None):
     gbps = (v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9) if v.get("algo_bytes") else None
     out = {"calls_per_step": v["calls"] / steps, "avg_ms": v["avg_ms"], "algo_bytes_per_launch": v.get("algo_bytes") or None,
@@ -574,7 +587,15 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
     """The ONE JSON line from whatever regions have finished (``state['results']``: partition name -> run_partition result).
     ``value`` is the primary partition's if it finished, otherwise the first finished region's (labelled).  None if nothing has."""
     results, errors = state["results"], state["errors"]
-    value_key = primary if primary in results else next((k for k in state["order"] if k in results and "+" not in k), None)
+    # `value`: --shard rows / columns = that partition (or, if it did not finish, the first one that did, labelled);
+    # --shard auto at N > 1 = the FASTEST of the exact (fp32-wire) executions of the job this run timed -- rows, columns, columns
+    # with the chunked overlapped exchange: same global hypergraph, same K steps each, same results up to summation order -- i.e.
+    # the partition an autotuning deployment would keep.  The bf16-wire entry changes results and is never `value`.
+    exact = [k for k in state["order"] if k in results and "bf16wire" not in k]
+    if args.shard == "auto" and world > 1 and exact:
+        value_key = min(exact, key=lambda k: results[k]["ms_per_step"])
+    else:
+        value_key = primary if primary in results else (exact[0] if exact else None)
     if value_key is None:
         return None
     res = results[value_key]
@@ -636,7 +657,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
                                 f"AllDeepSets layer (HalfNLHconv x2, 2-layer {args.norm.upper()} MLPs, aggr=add, dropout {args.dropout}), ") +
                                "fwd+bwd+Adam" + (" + one singleton self-loop hyperedge per vertex" if args.self_loops else ""),
                    "n_v": res["n_v"], "n_e": res["n_e"], "nnz": int(nnz_total), "d": d,
-                   "parallelism": parallelism_label(args, value_key, world), "partition": value_key if world > 1 else None,
+                   "parallelism": region_label(args, value_key, world), "partition": value_key if world > 1 else None,
                    "seed": args.seed, "launch": "one hipGraph replay per step" if (args.hip_graph and world == 1) else "eager launches"},
         "roofline": roofline,
         "aggregation": {"ms_per_step": agg_ms, "value": nnz_total * d / (agg_ms * 1e-3) if (world == 1 and agg_ms > 0) else None,
@@ -661,15 +682,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
     if world > 1 or len(state["order"]) > 1:
         parts = {}
         for key in state["order"]:
-            base = key.split("+")[0]
-            label = parallelism_label(args, base, world)
-            if "+chunks" in key:
-                kk = key.split("+chunks")[1]
-                label = label.replace("blocking", f"in {kk} overlapped chunks (the Linear kernels write / read each chunk's exchange "
-                                                  "buffers, asynchronous all-to-alls)")
-            if "+bf16wire" in key:
-                label += ("; bf16 wire format (opt-in, results within the restated tolerance of tests/test_dist_cpu.py, not "
-                          "bit-comparable)")
+            label = region_label(args, key, world)
             if key in results:
                 parts[key] = {"ms_per_step": results[key]["ms_per_step"], "value": results[key]["value"], "parallelism": label,
                               "is_value": key == value_key}
@@ -677,7 +690,11 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
                 parts[key] = {"error": errors[key], "parallelism": label, "is_value": False}
             elif not final:
                 parts[key] = {"pending": True, "parallelism": label, "is_value": False}
-        if value_key != primary:
+        if args.shard == "auto" and world > 1:
+            parts["value_note"] = (f"--shard auto: `value` is the fastest exact (fp32-wire) execution this run timed, {value_key!r} "
+                                   f"(allset_amd.dist.choose_sharding's a-priori pick was {primary!r}"
+                                   + ("" if primary in results else ", which did not finish: see its entry") + ")")
+        elif value_key != primary:
             parts["value_note"] = (f"`value` is partition {value_key!r}: the partition this run would report ({primary!r}) did not "
                                    "finish (see its entry)")
         parts["note"] = ("`rows` = hyperedge shards, the partition BASELINE.json's north star names; `columns` = column-sharded "

@@ -318,7 +318,9 @@ def test_bench_bare_command_spawns_its_own_ranks():
     parts = line["partitions"]
     assert [k for k in parts if k not in ("note", "value_note")] == ["rows", "columns", "columns+chunks2", "columns+bf16wire"]
     assert all("error" not in parts[k] for k in ("rows", "columns", "columns+chunks2", "columns+bf16wire")), parts
-    assert parts["columns"]["is_value"] and line["value"] == parts["columns"]["value"]
+    exact = ["rows", "columns", "columns+chunks2"]
+    best = min(exact, key=lambda k: parts[k]["ms_per_step"])                 # --shard auto: the fastest exact execution is `value`
+    assert parts[best]["is_value"] and line["value"] == parts[best]["value"] and line["config"]["partition"] == best
     assert any("all_to_all" in k for k in line["preflight"]["collectives"])
     early = [l for l in res.stderr.splitlines() if l.startswith("[bench] early line")]
     assert len(early) == 1 and json.loads(early[0].split(": ", 1)[1])["partitions"]["rows"]["is_value"]
