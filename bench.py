@@ -693,7 +693,8 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         if args.shard == "auto" and world > 1:
             parts["value_note"] = (f"--shard auto: `value` is the fastest exact (fp32-wire) execution this run timed, {value_key!r} "
                                    f"(allset_amd.dist.choose_sharding's a-priori pick was {primary!r}"
-                                   + ("" if primary in results else ", which did not finish: see its entry") + ")")
+                                   + ("" if primary in results else (", which did not finish: see its entry" if final else
+                                                                     ", not run yet") ) + ")")
         elif value_key != primary:
             parts["value_note"] = (f"`value` is partition {value_key!r}: the partition this run would report ({primary!r}) did not "
                                    "finish (see its entry)")

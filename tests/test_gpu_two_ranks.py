@@ -344,3 +344,30 @@ def test_bench_hung_second_region_keeps_the_first_regions_line():
     parts = line["partitions"]
     assert parts["rows"]["is_value"] and line["value"] == parts["rows"]["value"] and "timeout" in parts["columns"]["error"]
     assert line["roofline"]["launches"] > 0 and line["config"]["partition"] == "rows"
+
+
+@pytest.mark.parametrize("model", ["deepsets", "pma"])
+def test_bench_eight_ranks_one_gpu_gloo(model):
+    """The N = 8 shapes of the job with eight real ranks (one device, gloo): d / P = 16 columns per rank -- 64-byte gather rows, the
+    short-row kernels, PMA with two ranks sharing a head (P > H) and its logits riding in the row's line, column-blocked Linear
+    operands of width 16, the chunked exchange with 8 pieces per all-to-all.  Every region must finish and the exact partitions must
+    describe the same job."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ALLSET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n-per-gpu", "8000",
+           "--model", model, "--chunk-entry", "2", "--region-timeout", "300"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    parts = line["partitions"]
+    keys = ["rows", "columns", "columns+chunks2", "columns+bf16wire"]
+    assert [k for k in parts if k not in ("note", "value_note")] == keys
+    assert all("error" not in parts[k] and parts[k]["ms_per_step"] > 0 for k in keys), parts
+    assert line["n_gpus"] == 8 and line["config"]["nnz"] == 8 * 8000 * 16 and line["config"]["n_v"] == 64000
+    assert "column-shard x8" in parts["columns"]["parallelism"] and "d/8 columns" in parts["columns"]["parallelism"]
+    assert len(line["preflight"]["collectives"]) >= 6
