@@ -84,7 +84,7 @@ def _shard(adist, scheme, ei, norm, world, rank, method, chunks, dev):
                                    inc_ids=keep.nonzero().reshape(-1).to(dev)).build_incidences()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, which="two"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for p in (os.path.dirname(HERE), HERE):
@@ -94,7 +94,7 @@ def _worker(rank, world, port, q):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _run_configs(rank, world, dev, q)
+        _run_configs(rank, world, dev, q, *((LAYER_CFGS, MODEL_CFGS) if which == "two" else (LAYER_CFGS_8, [])))
     except BaseException:                       # report instead of leaving the parent waiting for a result that never comes
         import traceback
         q.put((rank, "ERROR\n" + traceback.format_exc()))
@@ -102,12 +102,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run_configs(rank, world, dev, q):
+def _run_configs(rank, world, dev, q, layer_cfgs, model_cfgs):
     if True:
         import cases
         from allset_amd import SetGNN, dist as adist
         res = {}
-        for cfg in LAYER_CFGS:
+        for cfg in layer_cfgs:
             kind, scheme, arg, method, chunks, d = cfg
             ei, norm, x, G = _problem(d)
             hg = _shard(adist, scheme, ei, norm if kind == "ds" else None, world, rank, method, chunks, dev)
@@ -126,7 +126,7 @@ def _run_configs(rank, world, dev, q):
             params = list(a.parameters()) + list(b.parameters())
             adist.allreduce_grads(params)
             res[("layer",) + cfg] = (out.detach().cpu().numpy(), xo.grad.cpu().numpy(), [p.grad.cpu().numpy() for p in params])
-        for cfg in MODEL_CFGS:
+        for cfg in model_cfgs:
             mode, scheme, chunks, kw = cfg
             d = 64
             ei, norm, x, G = _problem(d, seed=_model_seed(kw))
@@ -157,6 +157,43 @@ def _run_configs(rank, world, dev, q):
         q.put((rank, res))
 
 
+# The N = 8 shapes with eight real ranks: d / P = 16 columns per rank (64-byte gather rows, column blocks of 16 in the Linear kernels),
+# PMA with two ranks sharing each of 4 heads and its logits riding in the gathered row's line, 8 pieces per all-to-all, chunks.
+LAYER_CFGS_8 = [
+    ("ds", "cols", "add", None, 1, 128), ("ds", "cols", "mean", None, 2, 128), ("ds", "cols", "max", None, 1, 128),
+    ("pma", "cols", 4, None, 1, 128), ("pma", "cols", 4, None, 2, 128), ("pma", "cols", 1, None, 1, 128),
+    ("ds", "rows", "add", "lpt", 1, 64), ("ds", "rows", "max", "contiguous", 1, 64), ("pma", "rows", 4, "contiguous", 1, 64),
+]
+
+
+def _spawn_ranks(world, which):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, which)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            r, payload = q.get(timeout=600)
+            assert not isinstance(payload, str), f"rank {r}: {payload}"
+            results[r] = payload
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return results
+
+
+@pytest.fixture(scope="module")
+def eight_ranks():
+    return _spawn_ranks(8, "eight")
+
+
 @pytest.fixture(scope="module")
 def two_ranks():
     import torch.multiprocessing as mp
@@ -182,19 +219,29 @@ def two_ranks():
     return results
 
 
+@pytest.mark.parametrize("cfg", LAYER_CFGS_8, ids=lambda c: "-".join(str(t) for t in c))
+def test_eight_rank_hip_layer_equals_unsharded_hip_layer_and_oracle(cfg, eight_ranks, device):
+    _check_layer(cfg, eight_ranks, 8, device)
+
+
 @pytest.mark.parametrize("cfg", LAYER_CFGS, ids=lambda c: "-".join(str(t) for t in c))
 def test_two_rank_hip_layer_equals_unsharded_hip_layer_and_oracle(cfg, two_ranks, device):
+    _check_layer(cfg, two_ranks, 2, device)
+
+
+def _check_layer(cfg, two_ranks, world, device):
     import torch.nn.functional as F
     from allset_amd import Incidence
     from oracle import allset_oracle as oracle
     kind, scheme, arg, method, chunks, d = cfg
     ei, norm, x, G = _problem(d)
     key = ("layer",) + cfg
-    out = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(2)])[:N_V]
-    gx = torch.cat([torch.from_numpy(two_ranks[r][key][1]) for r in range(2)])[:N_V]
+    out = torch.cat([torch.from_numpy(two_ranks[r][key][0]) for r in range(world)])[:N_V]
+    gx = torch.cat([torch.from_numpy(two_ranks[r][key][1]) for r in range(world)])[:N_V]
     pg = [torch.from_numpy(t) for t in two_ranks[0][key][2]]
-    for g0, g1 in zip(two_ranks[0][key][2], two_ranks[1][key][2]):
-        np.testing.assert_array_equal(g0, g1)                      # after the all-reduce both ranks hold the same gradients
+    for r in range(1, world):
+        for g0, g1 in zip(two_ranks[0][key][2], two_ranks[r][key][2]):
+            np.testing.assert_array_equal(g0, g1)                  # after the all-reduce every rank holds the same gradients
 
     # (a) the unsharded layer on the HIP kernels
     a, b = _convs(kind, arg, d)
