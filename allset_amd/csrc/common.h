@@ -186,7 +186,8 @@ __device__ __forceinline__ void load_vec_i32(const int32_t* __restrict__ p, int3
 __device__ __forceinline__ float leaky_relu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
 // ---- dropout mask shared by every dense-tail kernel (forward kernels apply it, backward kernels regenerate it).
-// Counter-based: one 32-bit hash per PAIR of consecutive elements, 16 bits per element; keep iff u16 >= p * 65536.
+// Counter-based: one 32-bit hash per PAIR (16 bits per element) or per QUAD (8 bits per element) of consecutive elements -- see
+// drop_threshold below for which.
 __device__ __forceinline__ uint32_t pair_hash(uint64_t seed, int64_t pair) {
   // A Weyl-scrambled counter keyed by the 64-bit seed, then one xorshift-multiply-xorshift round.  32-bit integer multiplies run
   // at a quarter of the vector rate on gfx950 and a dropout-bearing kernel hashes once per element pair, so the count matters:
@@ -206,17 +207,55 @@ __device__ __forceinline__ uint32_t pair_hash(uint64_t seed, int64_t pair) {
 __device__ __forceinline__ uint64_t resolve_seed(const uint64_t* base, uint64_t salt) {
   return base ? (*base) * 0x9E3779B97F4A7C15ULL + salt : salt;
 }
-__device__ __forceinline__ uint32_t drop_threshold(float p) { return static_cast<uint32_t>(p * 65536.0f); }
+// Two resolutions, chosen by p alone (so that every kernel agrees without being told):
+//   p * 256 an integer (0.5, 0.25, 0.125, ... -- the reference scripts' dropout 0.5 among them): 8 bits per element, ONE hash per
+//   FOUR consecutive elements (counter = idx >> 2, field = idx & 3), keep iff u8 >= p * 256 -- exact, and half the hashes of
+//   the 16-bit form below (a dropout-bearing fused kernel spends 10-17 % of its vector cycles hashing);
+//   any other p: 16 bits per element, one hash per PAIR (counter = idx >> 1), keep iff u16 >= p * 65536.
+// drop_threshold() returns the threshold with the resolution in bit 16 (kDrop8).
+constexpr uint32_t kDrop8 = 0x10000u;
+__device__ __forceinline__ uint32_t drop_threshold(float p) {
+#ifndef ALLSET_ABL_DROP16          // (ablation builds: the 16-bit form for every p)
+  const float t8 = p * 256.0f;
+  if (t8 == floorf(t8)) return kDrop8 | static_cast<uint32_t>(t8);
+#endif
+  return static_cast<uint32_t>(p * 65536.0f);
+}
 __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, uint32_t thr, float inv_keep) {
+  if (thr & kDrop8) {
+    const uint32_t h = pair_hash(seed, idx >> 2);
+    return ((h >> (8 * static_cast<uint32_t>(idx & 3))) & 0xffu) >= (thr & 0xffu) ? inv_keep : 0.f;
+  }
   const uint32_t h = pair_hash(seed, idx >> 1);
   const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return u >= thr ? inv_keep : 0.f;
 }
-// two consecutive elements starting at an EVEN index: one hash
+// two consecutive elements starting at an EVEN index: one hash (in the 8-bit form the pair (idx, idx + 1) and the pair
+// (idx + 2, idx + 3) of an aligned quad evaluate the SAME hash: two calls on one float4 cost one hash after CSE)
 __device__ __forceinline__ void keep_scale2(uint64_t seed, int64_t idx_even, uint32_t thr, float inv_keep, float& s0, float& s1) {
+  if (thr & kDrop8) {
+    const uint32_t h = pair_hash(seed, idx_even >> 2);
+    const uint32_t sh = (static_cast<uint32_t>(idx_even) & 2u) << 3, t8 = thr & 0xffu;
+    s0 = ((h >> sh) & 0xffu) >= t8 ? inv_keep : 0.f;
+    s1 = ((h >> (sh + 8u)) & 0xffu) >= t8 ? inv_keep : 0.f;
+    return;
+  }
   const uint32_t h = pair_hash(seed, idx_even >> 1);
   s0 = (h & 0xffffu) >= thr ? inv_keep : 0.f;
   s1 = (h >> 16) >= thr ? inv_keep : 0.f;
+}
+// four consecutive elements starting at a multiple of FOUR: one hash (8-bit form) or two (16-bit form)
+__device__ __forceinline__ float4 keep_scale4(uint64_t seed, int64_t idx4, uint32_t thr, float inv_keep) {
+  float4 k;
+  if (thr & kDrop8) {
+    const uint32_t h = pair_hash(seed, idx4 >> 2), t8 = thr & 0xffu;
+    k.x = (h & 0xffu) >= t8 ? inv_keep : 0.f; k.y = ((h >> 8) & 0xffu) >= t8 ? inv_keep : 0.f;
+    k.z = ((h >> 16) & 0xffu) >= t8 ? inv_keep : 0.f; k.w = (h >> 24) >= t8 ? inv_keep : 0.f;
+    return k;
+  }
+  keep_scale2(seed, idx4, thr, inv_keep, k.x, k.y);
+  keep_scale2(seed, idx4 + 2, thr, inv_keep, k.z, k.w);
+  return k;
 }
 
 #endif  // __HIPCC__

@@ -246,6 +246,9 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
       const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * ID / 2);
       const uint32_t stage_pair_lo = static_cast<uint32_t>(stage_pair);
       const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_pair >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
+      const uint64_t stage_quad = static_cast<uint64_t>(stage) * (R * ID / 4);
+      const uint32_t stage_quad_lo = static_cast<uint32_t>(stage_quad);
+      const uint32_t hi_term_q = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
       xbK = 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -263,11 +266,18 @@ __global__ __launch_bounds__(kRBlock, 2) void fused_linear_bwd_roles_kernel(
           float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
           if constexpr (DROP_IN) {
             // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
-            const uint32_t lo = stage_pair_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 1);
-            const uint32_t h0 = hash_mix_r((lo ^ seed_lo) * 0x9E3779B1U + hi_term);
-            const uint32_t h1 = hash_mix_r(((lo + 1u) ^ seed_lo) * 0x9E3779B1U + hi_term);
-            kp.x = (h0 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.y = (h0 >> 16) >= thr_in ? keep_in : 0.f;
-            kp.z = (h1 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.w = (h1 >> 16) >= thr_in ? keep_in : 0.f;
+            if (thr_in & kDrop8) {     // 8 bits per element: ONE hash for the lane's float4 (quad index = stage * 1024 + lane part)
+              const uint32_t lo = stage_quad_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 2);
+              const uint32_t h = hash_mix_r((lo ^ seed_lo) * 0x9E3779B1U + hi_term_q), t8 = thr_in & 0xffu;
+              kp.x = (h & 0xffu) >= t8 ? keep_in : 0.f; kp.y = ((h >> 8) & 0xffu) >= t8 ? keep_in : 0.f;
+              kp.z = ((h >> 16) & 0xffu) >= t8 ? keep_in : 0.f; kp.w = (h >> 24) >= t8 ? keep_in : 0.f;
+            } else {
+              const uint32_t lo = stage_pair_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 1);
+              const uint32_t h0 = hash_mix_r((lo ^ seed_lo) * 0x9E3779B1U + hi_term);
+              const uint32_t h1 = hash_mix_r(((lo + 1u) ^ seed_lo) * 0x9E3779B1U + hi_term);
+              kp.x = (h0 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.y = (h0 >> 16) >= thr_in ? keep_in : 0.f;
+              kp.z = (h1 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.w = (h1 >> 16) >= thr_in ? keep_in : 0.f;
+            }
           }
           kpK[j][hb] = kp;
           float4 t = xr[j][hb];

@@ -138,10 +138,18 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     };
     // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
     auto keep4 = [&](uint64_t seed, int64_t stage, int hb, uint32_t thr, float keep) -> float4 {
+      const uint32_t sl = static_cast<uint32_t>(seed);
+      if (thr & kDrop8) {     // 8 bits per element: ONE hash for the lane's float4 (quad index = stage * 1024 + lane part < 1024)
+        const uint64_t stage_quad = static_cast<uint64_t>(stage) * (R * KD / 4);
+        const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed >> 32);
+        const uint32_t lo = static_cast<uint32_t>(stage_quad) | static_cast<uint32_t>((lr * KD + 64 * hb + 4 * c) >> 2);
+        const uint32_t h = hash_mix_f((lo ^ sl) * 0x9E3779B1U + hi_term), t8 = thr & 0xffu;
+        return make_float4((h & 0xffu) >= t8 ? keep : 0.f, ((h >> 8) & 0xffu) >= t8 ? keep : 0.f,
+                           ((h >> 16) & 0xffu) >= t8 ? keep : 0.f, (h >> 24) >= t8 ? keep : 0.f);
+      }
       const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * KD / 2);
       const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_pair >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed >> 32);
       const uint32_t lo = static_cast<uint32_t>(stage_pair) | static_cast<uint32_t>((lr * KD + 64 * hb + 4 * c) >> 1);
-      const uint32_t sl = static_cast<uint32_t>(seed);
       const uint32_t h0 = hash_mix_f((lo ^ sl) * 0x9E3779B1U + hi_term);
       const uint32_t h1 = hash_mix_f(((lo + 1u) ^ sl) * 0x9E3779B1U + hi_term);
       return make_float4((h0 & 0xffffu) >= thr ? keep : 0.f, (h0 >> 16) >= thr ? keep : 0.f,

@@ -183,7 +183,9 @@ int allset_pma_bwd_src(int dtype, const int32_t* rowptrT, const int32_t* colT,
  * models.py:473-481).  fp32, row-major.  The two well-shaped GEMMs (y = x W^T, gx = gy W) stay on hipBLASLt;
  * these entry points cover what the torch ops do badly at [1M,128]: LayerNorm fwd/bwd (fused with the
  * neighbouring ReLU / dropout) and the weight-gradient GEMM.
- * Dropout: keep iff hash(seed, element index) >= p, kept values scaled by 1/(1-p); the backward regenerates the mask
+ * Dropout: keep iff hash(seed, element index) >= p, kept values scaled by 1/(1-p) (a counter hash: one 32-bit hash per four
+ * consecutive elements at 8 bits each when p * 256 is an integer -- p = 0.5, 0.25, ... exact -- otherwise per pair at 16 bits
+ * each; every entry point derives the resolution from p alone, so all sites agree); the backward regenerates the mask
  * from the same seed.  Every dropout-bearing entry point also takes `seed_base` (may be NULL): a DEVICE pointer to a
  * 64-bit counter; when given, the effective seed is counter * 0x9E3779B97F4A7C15 + seed, read when the kernel starts, so
  * a captured hipGraph draws fresh masks on every replay (the caller bumps the counter inside the graph).
