@@ -128,3 +128,42 @@ def test_oracle_training_mode_with_explicit_masks_equals_live_reference(pma, lay
             continue
         torch.testing.assert_close(sdict[kk].grad, pp.grad, rtol=1e-8, atol=1e-9 * max(1.0, float(pp.grad.abs().max())),
                                    msg=lambda m: f"{kk}: {m}")
+
+
+@pytest.mark.parametrize("name", ["rand50_ds_add", "rand50_pma_h4", "rand50_ds_mean_wnorm", "rand50_ds_add_L2_gpr"])
+def test_oracle_training_trajectory_equals_live_reference(name):
+    """Ten Adam steps of the reference's training loop body (train.py:470-476: forward, nll_loss(log_softmax) on the train split,
+    backward, step) on the LIVE reference model and on the oracle, both float64, dropouts off (eval-mode forward): the loss
+    sequence and the final parameters agree to rounding.  The GPU side of the chain is tests/test_gpu_train_trajectory.py."""
+    import torch.nn.functional as F
+    _, ref_models = ref_shim.import_reference()
+    case = cases.build_case(name)
+    args = case["args"]
+    torch.manual_seed(case["seed"])
+    norm_t = torch.from_numpy(case["norm"])
+    model = ref_models.SetGNN(args, norm=norm_t.to(torch.float32) if args.LearnMask else None)
+    model.reset_parameters()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.double().eval()
+    n = case["x"].shape[0]
+    rng = np.random.default_rng(case["seed"])
+    y = torch.from_numpy(rng.integers(0, args.num_classes, size=n))
+    train_idx = torch.from_numpy(np.sort(rng.choice(n, size=max(n // 2, 4), replace=False)))
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=0.0)
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).double(), edge_index=torch.from_numpy(case["edge_index"]).clone(),
+                           norm=norm_t.double() if norm_t.is_floating_point() else norm_t)
+    losses = []
+    for _ in range(10):
+        opt.zero_grad()
+        out = model(data)
+        loss = F.nll_loss(F.log_softmax(out, dim=1)[train_idx], y[train_idx])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_train_trajectory import trajectory_oracle
+    ref_losses, ref_params = trajectory_oracle(case, sd, y, train_idx, 10, 0.01)
+    np.testing.assert_allclose(ref_losses, losses, rtol=1e-9, atol=1e-11)
+    for k, p in model.named_parameters():
+        torch.testing.assert_close(ref_params[k].detach(), p.detach(), rtol=1e-7, atol=1e-9, msg=lambda m, k=k: f"{k}: {m}")
