@@ -149,6 +149,21 @@ def _all_to_all_single(recv: Tensor, send: Tensor, group=None) -> None:
         dist.all_to_all_single(recv, send, group=group)
 
 
+def _all_to_all_rows(send: Tensor, in_splits, out_splits, group=None) -> Tensor:
+    """All-to-all of ROW RANGES with per-peer counts: ``send`` [sum(in_splits), ...] holds the rows for peer 0, 1, ... back to
+    back; returns [sum(out_splits), ...] in peer order.  (The halo exchange of the row partition; gloo: staged through the host.)"""
+    send = send.contiguous()
+    out_shape = (int(sum(out_splits)),) + tuple(send.shape[1:])
+    if _host_staged(group, send):
+        hs = send.cpu()
+        hr = torch.empty(out_shape, dtype=hs.dtype)
+        dist.all_to_all_single(hr, hs, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group)
+        return hr.to(send.device)
+    recv = send.new_empty(out_shape)
+    dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group)
+    return recv
+
+
 def _all_gather_rows(x: Tensor, group=None) -> Tensor:
     if _skip_collective(group):
         return x
@@ -227,6 +242,103 @@ def reduce_scatter_rows(x: Tensor, group=None) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+# boundary-vertex ("halo") exchange of the row partition
+# ---------------------------------------------------------------------------------------------
+# The all-gather / reduce-scatter pair above moves the WHOLE vertex table, which is what a hypergraph without locality needs
+# (the synthetic benchmark: a rank's hyperedges touch 86 % of all vertices at P = 8).  A hypergraph WITH locality -- most members of
+# a hyperedge live in the block of vertices its rank owns -- only needs the rows of the vertices its local hyperedges actually touch:
+# the north star's "all-reduce of boundary-vertex embeddings", split into its two halves.  ``Halo`` is that exchange, built once
+# per sharded hypergraph:
+#   needed      the sorted global ids of the vertices this rank's hyperedges touch (its own block's included); the local incidence is
+#               renumbered onto 0 .. len(needed)-1, so the V->E gather reads a COMPACT table;
+#   gather      owned rows --index_select by what each peer asked for--> all-to-all (per-peer row counts) --> the compact table;
+#   scatter_add the transpose: compact partial sums --all-to-all--> rows addressed to my owned vertices --> summed per owned row
+#               in a FIXED order (a CSR over the received rows, the library's own segment-sum kernel on the device; no atomics).
+# Forward and backward of the two autograd Functions are each other.  Bytes per exchange: sum over peers of the rows asked for,
+# instead of (P-1)/P of the table.
+
+class Halo:
+    def __init__(self, local_vertex_ids: Tensor, n_v_pad: int, world: int, rank: int, group=None):
+        dev = local_vertex_ids.device
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self.block = n_v_pad // world
+        self.needed = torch.unique(local_vertex_ids)                              # sorted global ids
+        self.compact_ids = torch.searchsorted(self.needed, local_vertex_ids)      # local incidence -> rows of the compact table
+        owner = torch.div(self.needed, self.block, rounding_mode="floor")
+        need_counts = torch.bincount(owner, minlength=world)[:world]
+        ask = self.needed - owner * self.block                                     # row inside its owner's block, peer-major already
+        if world == 1 or _skip_collective(group):
+            send_counts, send_idx = need_counts.clone(), ask
+        else:
+            send_counts = _all_to_all_rows(need_counts.view(world, 1), [1] * world, [1] * world, group).view(-1)
+            send_idx = _all_to_all_rows(ask, [int(c) for c in need_counts.tolist()], [int(c) for c in send_counts.tolist()], group)
+        self.need_counts = [int(c) for c in need_counts.tolist()]                 # rows I receive from each peer (gather)
+        self.send_counts = [int(c) for c in send_counts.tolist()]                 # rows I send to each peer (gather)
+        self.send_idx = send_idx.to(dev)                                          # int64 [sum(send_counts)]: my owned rows, peer-major
+        if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.block):
+            raise ValueError("halo: a peer asked for a row outside this rank's vertex block")
+        # fixed-order sum of the rows that come back in scatter_add: CSR over my owned rows, entries = positions in the received buffer
+        order = torch.argsort(self.send_idx, stable=True)
+        counts = torch.bincount(self.send_idx, minlength=self.block)
+        self.sa_rowptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+        self.sa_col = order.to(torch.int32)
+        self.n_needed = int(self.needed.numel())
+
+    # bytes one rank receives per gather (or sends per scatter_add) for rows of ``row_bytes`` bytes -- own block excluded
+    def exchange_rows(self) -> int:
+        return sum(c for q, c in enumerate(self.need_counts) if q != self.rank)
+
+    def _gather(self, x_owned: Tensor) -> Tensor:
+        send = x_owned.index_select(0, self.send_idx)
+        if self.world == 1 or _skip_collective(self.group):
+            return send
+        return _all_to_all_rows(_narrow(send), self.send_counts, self.need_counts, self.group).to(x_owned.dtype)
+
+    def _scatter_add(self, part: Tensor) -> Tensor:
+        if self.world == 1 or _skip_collective(self.group):
+            recv = part
+        else:
+            recv = _all_to_all_rows(_narrow(part.contiguous()), self.need_counts, self.send_counts, self.group).to(part.dtype)
+        if recv.is_cuda and recv.dtype == torch.float32 and recv.shape[1] % 4 == 0:
+            from . import ops
+            return ops.segreduce(0, self.sa_rowptr, self.sa_col, None, recv.contiguous(), self.block)[0]
+        out = recv.new_zeros((self.block,) + tuple(recv.shape[1:]))
+        return out.index_add_(0, self.send_idx, recv)                             # (CPU tests / odd widths: sequential, deterministic on CPU)
+
+
+class _HaloGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_owned, halo):
+        ctx.halo = halo
+        return halo._gather(x_owned)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.halo._scatter_add(g.contiguous()), None
+
+
+class _HaloScatterAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, part, halo):
+        ctx.halo = halo
+        return halo._scatter_add(part)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.halo._gather(g.contiguous()), None
+
+
+def halo_gather(x_owned: Tensor, halo: Halo) -> Tensor:
+    """[n_v/P, d] owned rows -> [len(halo.needed), d] rows of the vertices this rank's hyperedges touch; backward = scatter_add."""
+    return _HaloGather.apply(x_owned, halo)
+
+
+def halo_scatter_add(part: Tensor, halo: Halo) -> Tensor:
+    """[len(halo.needed), d] partial sums -> [n_v/P, d] totals of the owned rows over all ranks; backward = gather."""
+    return _HaloScatterAdd.apply(part, halo)
+
+
+# ---------------------------------------------------------------------------------------------
 # the sharded layer
 # ---------------------------------------------------------------------------------------------
 
@@ -238,7 +350,10 @@ class ShardedHypergraph:
     product builds :class:`allset_amd.incidence.Incidence` objects (``build_incidences``)."""
 
     def __init__(self, local_edge_index: Tensor, n_v: int, n_e_local: int, world: int, rank: int,
-                 norm: Optional[Tensor] = None, inc_ids: Optional[Tensor] = None):
+                 norm: Optional[Tensor] = None, inc_ids: Optional[Tensor] = None, halo: bool = False, group=None):
+        """``halo=True``: exchange only the rows of the vertices the local hyperedges touch (:class:`Halo`; add / sum / mean
+        Deep Sets layers -- max / min and PMA keep the whole-table exchange) instead of all-gather / reduce-scatter of the whole
+        vertex table.  Construction then runs two small all-to-alls on ``group`` (every rank must construct at the same time)."""
         self.local_edge_index = local_edge_index
         # positions of the local incidences in the GLOBAL edge list (what a replicated per-incidence parameter such as
         # SetGNN.Importance, reference models.py:336-337, is indexed by); only LearnMask needs them
@@ -249,11 +364,21 @@ class ShardedHypergraph:
         self.v2e = None
         self.e2v = None
         self._vdeg_owned: Optional[Tensor] = None
+        self.halo: Optional[Halo] = Halo(local_edge_index[0], self.n_v_pad, self.world, self.rank, group) if halo else None
+        self.halo_v2e = None
+        self.halo_e2v = None
+
+    def halo_edge_index(self) -> Tensor:
+        """The local incidence with vertex ids renumbered onto the compact table of ``halo.needed``."""
+        return torch.stack([self.halo.compact_ids, self.local_edge_index[1]])
 
     def build_incidences(self) -> "ShardedHypergraph":
         from .incidence import Incidence
         self.v2e = Incidence.from_edge_index(self.local_edge_index, n_src=self.n_v_pad, n_dst=self.n_e_local)
         self.e2v = self.v2e.reversed(n_dst=self.n_v_pad)          # partial rows for EVERY vertex
+        if self.halo is not None:
+            self.halo_v2e = Incidence.from_edge_index(self.halo_edge_index(), n_src=self.halo.n_needed, n_dst=self.n_e_local)
+            self.halo_e2v = self.halo_v2e.reversed(n_dst=self.halo.n_needed)      # partial rows for the touched vertices only
         return self
 
     def local_vertex_has_incidence(self) -> Tensor:
@@ -265,8 +390,12 @@ class ShardedHypergraph:
     def owned_vertex_degree(self, group=None) -> Tensor:
         """Global degree of the owned vertices (for E->V 'mean'); one reduce-scatter, cached."""
         if self._vdeg_owned is None:
-            deg = torch.bincount(self.local_edge_index[0], minlength=self.n_v_pad).to(torch.float32)
-            self._vdeg_owned = _reduce_scatter_rows(deg.view(-1, 1), group).view(-1)
+            if self.halo is not None:
+                deg = torch.bincount(self.halo.compact_ids, minlength=self.halo.n_needed).to(torch.float32)
+                self._vdeg_owned = self.halo._scatter_add(deg.view(-1, 1).repeat(1, 4))[:, 0].contiguous()
+            else:
+                deg = torch.bincount(self.local_edge_index[0], minlength=self.n_v_pad).to(torch.float32)
+                self._vdeg_owned = _reduce_scatter_rows(deg.view(-1, 1), group).view(-1)
         return self._vdeg_owned
 
 
@@ -392,10 +521,14 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     p_out = dropout if dropout_out is None else dropout_out    # GPR applies the last dropout itself (models.py:466-469)
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
     # ``training`` must agree with the convs' own mode (the fused MLP kernels read conv.training)
+    use_halo = hg.halo is not None and aggr in ("add", "sum", "mean") and hg.halo_v2e is not None
     with _bn_scope(vv, group):
         h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
-    h_full = all_gather_rows(h, group)
-    e = aggregate(h_full, hg.v2e, norm, aggr)
+    if use_halo:                                               # only the rows the local hyperedges touch travel
+        e = aggregate(halo_gather(h, hg.halo), hg.halo_v2e, norm, aggr)
+    else:
+        h_full = all_gather_rows(h, group)
+        e = aggregate(h_full, hg.v2e, norm, aggr)
     with _bn_scope(e.shape[0], group):
         e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)       # conv's relu (SetGNN's outer relu is idempotent) + dropout
         # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
@@ -404,6 +537,8 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
         # local extreme over this rank's hyperedges (autograd routes to the local arg-extreme), then the key merge
         partial = aggregate(g, hg.e2v, norm, aggr)
         v = _ShardedExtremeMerge.apply(partial, hg.local_vertex_has_incidence(), hg, group, aggr == "min")
+    elif use_halo:
+        v = halo_scatter_add(aggregate(g, hg.halo_e2v, norm, "add"), hg.halo)
     else:
         partial = aggregate(g, hg.e2v, norm, "add")
         v = reduce_scatter_rows(partial, group)

@@ -52,13 +52,18 @@ def hyperedge_sizes(n_e: int, degree: float, dist: str, gen: torch.Generator, de
 
 def random_hypergraph(n_v: int, n_e: int, degree: float = 16, seed: int = 0, device="cuda", dist: str = "fixed",
                       max_degree: int = 4096, e_base: int = 0, e_offset: int = 0, sort_by_vertex: bool = True,
-                      zipf_a: float = 2.0) -> SimpleNamespace:
+                      zipf_a: float = 2.0, locality: float = 0.0, home=None) -> SimpleNamespace:
     """``n_e`` hyperedges over ``n_v`` vertices.  Returns ``SimpleNamespace(edge_index, norm, n_v, n_e,
     nnz, seed, dist)`` with ``edge_index`` int64 [2, nnz] (row 0 vertex ids, row 1 hyperedge ids
     ``e_base + e_offset + [0, n_e)``) on ``device``.
 
     ``e_offset`` lets one rank of a sharded run generate only its own block of hyperedges (their members
     still range over the global vertex set).
+
+    ``locality`` in [0, 1) with ``home = (block, n_blocks)``: each membership is re-drawn, with that probability, from the
+    home block of vertices ``[block * n_v / n_blocks, (block + 1) * n_v / n_blocks)`` -- a hypergraph whose partitions have few
+    boundary vertices (what the row partition's boundary-vertex exchange, ``allset_amd.dist.Halo``, is for).  0 = the uniform
+    hypergraph of the benchmark.  (Re-drawn members may repeat inside a hyperedge; duplicates are coalesced.)
     """
     device = torch.device(device)
     gen = torch.Generator(device=device)
@@ -73,6 +78,16 @@ def random_hypergraph(n_v: int, n_e: int, degree: float = 16, seed: int = 0, dev
         e = torch.arange(n_e, device=device, dtype=torch.int64).repeat_interleave(sizes)
         v = torch.randint(n_v, (int(e.numel()),), generator=gen, device=device, dtype=torch.int64)
         key = torch.unique(e * n_v + v)            # coalesce duplicate memberships (as the reference loaders do)
+        e, v = key // n_v, key % n_v
+    if locality > 0.0:
+        if home is None:
+            raise ValueError("locality needs home = (block, n_blocks)")
+        blk, nb = int(home[0]), int(home[1])
+        per = n_v // nb
+        local = torch.rand(v.shape, generator=gen, device=device) < float(locality)
+        redraw = blk * per + torch.randint(per, v.shape, generator=gen, device=device, dtype=torch.int64)
+        v = torch.where(local, redraw, v)
+        key = torch.unique(e * n_v + v)
         e, v = key // n_v, key % n_v
     if sort_by_vertex:
         order = torch.argsort(v, stable=True)

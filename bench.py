@@ -84,6 +84,13 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: BASELINE configs[4] regime -- bf16 tensors end to end, bf16 instantiations of the gather kernels "
                          "(fp32 accumulation / softmax statistics) and of the dense-tail kernels")
+    ap.add_argument("--locality", type=float, default=0.0,
+                    help="variant workload (not the headline): each membership of block r's hyperedges is re-drawn with this "
+                         "probability from block r's own vertices -- a hypergraph whose hyperedge partitions have few boundary "
+                         "vertices (0 = BASELINE's uniform random hypergraph)")
+    ap.add_argument("--rows-exchange", default="auto", choices=["auto", "table", "halo"],
+                    help="row partition: 'table' = all-gather / reduce-scatter of the whole vertex table, 'halo' = exchange only the "
+                         "rows of the vertices a rank's hyperedges touch (allset_amd.dist.Halo); auto = halo iff --locality > 0")
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "columns"],
                     help="N > 1: which partition is timed as `value` ('auto' = allset_amd.dist.choose_sharding)")
     ap.add_argument("--partitions", default="both", choices=["both", "primary"],
@@ -134,10 +141,17 @@ def parse_args(argv=None):
 # problem construction (pure index arithmetic + the generator: runs on any device; tests/test_bench_setup.py)
 # ---------------------------------------------------------------------------------------------------------------------
 
-def hyperedge_block(args, n_v: int, r: int, device):
+def hyperedge_block(args, n_v: int, r: int, device, world: int = 1):
     """Block r of the job's hypergraph: ``n_per_gpu`` hyperedges (local ids 0..n-1) over the GLOBAL vertex range."""
     from allset_amd.synthetic import random_hypergraph
-    return random_hypergraph(n_v, args.n_per_gpu, args.degree, seed=args.seed + 1 + r, device=device, dist=args.degree_dist)
+    loc = float(getattr(args, "locality", 0.0))
+    return random_hypergraph(n_v, args.n_per_gpu, args.degree, seed=args.seed + 1 + r, device=device, dist=args.degree_dist,
+                             locality=loc, home=(r, world) if loc > 0.0 else None)
+
+
+def rows_halo(args) -> bool:
+    mode = getattr(args, "rows_exchange", "auto")
+    return mode == "halo" or (mode == "auto" and float(getattr(args, "locality", 0.0)) > 0.0)
 
 
 def build_problem(args, mode: str, world: int, rank: int, device):
@@ -150,12 +164,12 @@ def build_problem(args, mode: str, world: int, rank: int, device):
     n_loc = args.n_per_gpu
     n_v = n_loc * world
     if mode == "columns":
-        blocks = [hyperedge_block(args, n_v, r, device) for r in range(world)]
+        blocks = [hyperedge_block(args, n_v, r, device, world) for r in range(world)]
         ei = torch.cat([torch.stack([b.edge_index[0], b.edge_index[1] + r * n_loc]) for r, b in enumerate(blocks)], dim=1)
         norm = torch.cat([b.norm for b in blocks])
         hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, rank, norm=norm, chunks=args.pipeline_chunks)
         return hg, ei.shape[1] / world, n_loc * world
-    shard = hyperedge_block(args, n_v, rank, device)
+    shard = hyperedge_block(args, n_v, rank, device, world)
     n_e_loc = n_loc
     if args.self_loops:
         if world != 1:
@@ -165,7 +179,8 @@ def build_problem(args, mode: str, world: int, rank: int, device):
         ei = ei[:, torch.argsort(ei[0], stable=True)].contiguous()
         shard.edge_index, shard.nnz, n_e_loc = ei, int(ei.shape[1]), n_loc + n_v
         shard.norm = torch.ones(shard.nnz, dtype=torch.int64, device=device)
-    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_e_loc, world, rank, norm=shard.norm)
+    halo = rows_halo(args) and world > 1 and args.model != "pma"
+    hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_e_loc, world, rank, norm=shard.norm, halo=halo)
     return hg, float(shard.nnz), n_e_loc * world
 
 
@@ -412,6 +427,9 @@ def parallelism_label(args, mode, world):
     if world == 1:
         return "single GPU"
     if mode == "rows":
+        if rows_halo(args) and args.model != "pma":
+            return (f"hyperedge-shard x{world} (boundary-vertex exchange: per direction one all-to-all of the rows of the vertices a rank's "
+                    "hyperedges touch + its transpose, allset_amd.dist.Halo)")
         return f"hyperedge-shard x{world} (all-gather + reduce-scatter of the [n_V, d] vertex table per direction)"
     how = f"in {args.pipeline_chunks} overlapped chunks" if args.pipeline_chunks > 1 else "blocking"
     return f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; all-to-all exchange {how})"
@@ -651,7 +669,8 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
          "accumulation, bf16 in / out)"),
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{cfg_index(args)}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph "
-                               f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}), "
+                               f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}"
+                               + (f", locality {args.locality:g}: VARIANT workload" if args.locality > 0 else "") + "), "
                                f"nnz={int(nnz_total)}, d={d}, " +
                                (f"AllSetTransformer layer (PMA x2, heads={args.heads}, dropout {args.dropout}), " if attn else
                                 f"AllDeepSets layer (HalfNLHconv x2, 2-layer {args.norm.upper()} MLPs, aggr=add, dropout {args.dropout}), ") +

@@ -79,16 +79,20 @@ def _tuple_incidences(hg, mode):
     n_e = hg.n_e_pad if mode == "columns" else hg.n_e_local
     hg.v2e = (ei, n_e)
     hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
+    if getattr(hg, "halo", None) is not None:                  # the row partition's boundary-vertex exchange: compact incidence
+        hloc = hg.halo_edge_index()
+        hg.halo_v2e = (hloc, n_e)
+        hg.halo_e2v = (torch.stack([hloc[1], hloc[0]]), hg.halo.n_needed)
 
 
-def _bench_worker(rank, world, port, model, q):
+def _bench_worker(rank, world, port, model, q, extra=()):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import bench
     from test_dist_cpu import TorchPmaKernels
     hooks = {"device": "cpu", "aggregate": _oracle_aggregate, "kernels": TorchPmaKernels, "incidences": _tuple_incidences}
     argv = ["--gpus", str(world), "--n-per-gpu", "120", "--degree", "4", "--feature-dim", "32", "--steps", "2", "--warmup", "1",
-            "--model", model, "--heads", "2", "--dropout", "0.0", "--chunk-entry", "2"]
+            "--model", model, "--heads", "2", "--dropout", "0.0", "--chunk-entry", "2"] + list(extra)
     import contextlib
     import io
     buf = io.StringIO()
@@ -190,3 +194,23 @@ def test_bench_hung_later_region_still_yields_the_first_regions_line(label):
     assert parts["rows"]["is_value"] and line["value"] == parts["rows"]["value"] and line["config"]["partition"] == "rows"
     assert "timeout" in (parts["columns"]["error"] if label == "columns" else line["preflight"]["error"])
     assert "value_note" in parts and "columns" in parts["value_note"] and "did not finish" in parts["value_note"]
+
+
+def test_bench_two_ranks_locality_variant_uses_the_boundary_vertex_exchange():
+    """--locality 0.9: the variant workload whose hyperedge blocks mostly stay inside their rank's vertex block; the row partition
+    then exchanges only the touched rows (dist.Halo) and says so; the line is labelled as a variant."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, "deepsets", q, ("--locality", "0.9"))) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    line = results[0][1]
+    assert "locality 0.9: VARIANT workload" in line["config"]["workload"]
+    parts = line["partitions"]
+    assert "boundary-vertex exchange" in parts["rows"]["parallelism"] and "error" not in parts["rows"] and "error" not in parts["columns"]

@@ -48,7 +48,7 @@ def _convs(d):
     return a, b
 
 
-def _worker(rank, world, port, aggr, method, q):
+def _worker(rank, world, port, aggr, method, q, halo=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -58,9 +58,14 @@ def _worker(rank, world, port, aggr, method, q):
         owner = adist.partition_hyperedges(sizes, world, method)
         loc, gids = adist.local_shard(ei, owner, rank)
         keep = owner[ei[1]] == rank
-        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=norm[keep])
+        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=norm[keep], halo=halo)
         hg.v2e = (loc, hg.n_e_local)
         hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        if halo:            # the compact incidence of the boundary-vertex exchange, in the tuple form the oracle aggregation takes
+            hloc = hg.halo_edge_index()
+            hg.halo_v2e = (hloc, hg.n_e_local)
+            hg.halo_e2v = (torch.stack([hloc[1], hloc[0]]), hg.halo.n_needed)
+            assert hg.halo.n_needed == int(torch.unique(loc[0]).numel()) and sum(hg.halo.need_counts) == hg.halo.n_needed
         a, b = _convs(d)
         xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
         Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - n_v, d)])
@@ -74,13 +79,21 @@ def _worker(rank, world, port, aggr, method, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("aggr,method,world", [("add", "contiguous", 2), ("mean", "lpt", 2), ("add", "lpt", 4), ("mean", "contiguous", 3),
+                                               ("max", "contiguous", 2)])
+def test_sharded_layer_with_boundary_vertex_exchange_equals_unsharded(aggr, method, world):
+    """The row partition with ``halo=True``: only the rows of the vertices a rank's hyperedges touch are exchanged (all-to-all with
+    per-peer counts + fixed-order sums) -- same outputs, input and parameter gradients as the unsharded layer, at 2, 3 and 4 ranks
+    (3: vertex blocks with padding); ``max`` keeps the whole-table exchange and must be unaffected by the flag."""
+    test_sharded_layer_equals_unsharded(aggr, method, world, halo=True)
+
+
 @pytest.mark.parametrize("aggr,method", [("add", "contiguous"), ("mean", "lpt"), ("max", "contiguous"), ("min", "lpt")])
-def test_sharded_layer_equals_unsharded(aggr, method):
-    world = 2
+def test_sharded_layer_equals_unsharded(aggr, method, world=2, halo=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, aggr, method, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, aggr, method, q, halo)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -109,8 +122,25 @@ def test_sharded_layer_equals_unsharded(aggr, method):
     # parameter grads through LayerNorm/bias paths multiplied by zero -> parameter grads must match
     for got, exp in zip(results[0][3], ref_pg):
         torch.testing.assert_close(got, exp, rtol=1e-4, atol=1e-5)
-    for got, got1 in zip(results[0][3], results[1][3]):
-        torch.testing.assert_close(got, got1, rtol=0, atol=0)          # all ranks hold the same summed grads
+    for r in range(1, world):
+        for got, got1 in zip(results[0][3], results[r][3]):
+            torch.testing.assert_close(got, got1, rtol=0, atol=0)      # all ranks hold the same summed grads
+
+
+def test_halo_exchange_volume_follows_locality():
+    """What the boundary-vertex exchange buys: rows received per gather on a hypergraph WITH locality (every hyperedge draws 15 of
+    its 16 members from its rank's own vertex block) against one without (members uniform over all vertices)."""
+    from allset_amd import dist as adist
+    from allset_amd.synthetic import random_hypergraph
+    world, n_loc = 4, 2000
+    for locality, lo, hi in ((0.0, 0.95, 1.0), (15 / 16, 0.0, 0.35)):
+        hg = random_hypergraph(world * n_loc, n_loc, 16, seed=3, device="cpu", locality=locality, home=(1, world))   # rank 1's block
+        ids = hg.edge_index[0]
+        halo = adist.Halo(ids, world * n_loc, 1, 0)                      # (world 1: no collective; the counts are per OWNER block below)
+        owner = torch.div(halo.needed, n_loc, rounding_mode="floor")
+        foreign = int((owner != 1).sum())
+        frac = foreign / (3 * n_loc)                                     # share of the other ranks' rows this rank would ask for
+        assert lo <= frac <= hi, (locality, frac)
 
 
 def test_partition_is_nnz_balanced_and_complete():

@@ -31,6 +31,8 @@ def _free_port():
 LAYER_CFGS = [
     ("ds", "rows", "add", "contiguous", 1, 64), ("ds", "rows", "mean", "lpt", 1, 64), ("ds", "rows", "max", "contiguous", 1, 64),
     ("ds", "rows", "min", "lpt", 1, 32),
+    # the row partition with the boundary-vertex exchange (dist.Halo): only the rows the local hyperedges touch travel
+    ("ds", "rows+halo", "add", "contiguous", 1, 64), ("ds", "rows+halo", "mean", "lpt", 1, 128), ("ds", "rows+halo", "max", "lpt", 1, 64),
     ("ds", "cols", "add", None, 1, 64), ("ds", "cols", "mean", None, 4, 64), ("ds", "cols", "max", None, 1, 128),
     ("ds", "cols", "add", None, 4, 128),
     ("pma", "rows", 4, "contiguous", 1, 64), ("pma", "rows", 1, "lpt", 1, 64),
@@ -81,7 +83,7 @@ def _shard(adist, scheme, ei, norm, world, rank, method, chunks, dev):
     loc, gids = adist.local_shard(ei, owner, rank)
     keep = owner[ei[1]] == rank
     return adist.ShardedHypergraph(loc.to(dev), N_V, gids.numel(), world, rank, norm=None if norm is None else norm[keep].to(dev),
-                                   inc_ids=keep.nonzero().reshape(-1).to(dev)).build_incidences()
+                                   inc_ids=keep.nonzero().reshape(-1).to(dev), halo=scheme == "rows+halo").build_incidences()
 
 
 def _worker(rank, world, port, q, which="two"):
@@ -163,6 +165,7 @@ LAYER_CFGS_8 = [
     ("ds", "cols", "add", None, 1, 128), ("ds", "cols", "mean", None, 2, 128), ("ds", "cols", "max", None, 1, 128),
     ("pma", "cols", 4, None, 1, 128), ("pma", "cols", 4, None, 2, 128), ("pma", "cols", 1, None, 1, 128),
     ("ds", "rows", "add", "lpt", 1, 64), ("ds", "rows", "max", "contiguous", 1, 64), ("pma", "rows", 4, "contiguous", 1, 64),
+    ("ds", "rows+halo", "add", "lpt", 1, 64), ("ds", "rows+halo", "mean", "contiguous", 1, 128),
 ]
 
 
@@ -418,3 +421,21 @@ def test_bench_eight_ranks_one_gpu_gloo(model):
     assert line["n_gpus"] == 8 and line["config"]["nnz"] == 8 * 8000 * 16 and line["config"]["n_v"] == 64000
     assert "column-shard x8" in parts["columns"]["parallelism"] and "d/8 columns" in parts["columns"]["parallelism"]
     assert len(line["preflight"]["collectives"]) >= 6
+
+
+def test_bench_two_ranks_locality_variant_with_halo_exchange():
+    """``bench.py --gpus 2 --locality 0.9`` (gloo, one device): the row partition runs the boundary-vertex exchange on the HIP path --
+    index_select of the asked-for rows, all-to-all with per-peer counts, the segment-sum kernel as the fixed-order scatter-add."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ALLSET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000",
+           "--locality", "0.9", "--chunk-entry", "0", "--no-wire-entry"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    parts = line["partitions"]
+    assert "boundary-vertex exchange" in parts["rows"]["parallelism"] and "error" not in parts["rows"] and "error" not in parts["columns"]
+    assert "VARIANT workload" in line["config"]["workload"]

@@ -22,6 +22,7 @@ DIST = os.environ.get("SIM_DIST", "fixed")          # fixed | zipf (BASELINE con
 model = sys.argv[1] if len(sys.argv) > 1 else "deepsets"
 mode = sys.argv[2] if len(sys.argv) > 2 else "rows"
 LINK = 60e9
+LOCALITY = float(os.environ.get("SIM_LOCALITY", "0"))   # rows: draw that share of every membership from the rank's own vertex block (dist.Halo exchange)
 CHUNKS = int(os.environ.get("SIM_CHUNKS", "1"))     # columns: chunks of owned rows (the overlapped exchange's machinery; its all-to-alls become local copies)
 
 
@@ -53,6 +54,10 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     adist._world = lambda group=None, w=world: w
     adist._skip_collective = lambda group=None, w=world: w == 1      # world > 1: take the real merge paths ...
     adist.dist.all_reduce = lambda *a, **k: None                      # ... with the small max-all-reduce stubbed out
+    # halo exchange (rows, SIM_LOCALITY > 0): the per-peer all-to-all returns rows of the asked-for COUNT (by symmetry of the
+    # generator every peer asks this rank for as many rows as it asks them)
+    adist._all_to_all_rows = (lambda send, ins, outs, group=None: send[:sum(outs)] if send.shape[0] >= sum(outs) else
+                              torch.cat([send, send.new_zeros((sum(outs) - send.shape[0],) + tuple(send.shape[1:]))]))
     n_v = n_loc * world
     if mode == "columns":
         blocks = [random_hypergraph(n_v, n_loc, 16, seed=5 + r, device=dev, e_offset=r * n_loc, dist=DIST) for r in range(world)]
@@ -62,8 +67,8 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
                                            norm=torch.cat([b.norm for b in blocks])).build_incidences()
         del blocks, ei
     else:
-        shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev, dist=DIST)
-        hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm).build_incidences()
+        shard = random_hypergraph(n_v, n_loc, 16, seed=5, device=dev, dist=DIST, locality=LOCALITY, home=(0, world) if LOCALITY > 0 else None)
+        hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_loc, world, 0, norm=shard.norm, halo=LOCALITY > 0 and world > 1).build_incidences()
     attn = model == "pma"
     torch.manual_seed(0)
     a = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).to(DT).train()
@@ -101,6 +106,9 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     if world == 1 or "t1" not in globals():
         t1 = ms if world == 1 else float(os.environ.get("SIM_T1_MS", "nan"))
     per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d, 2 if DT == torch.bfloat16 else 4)     # received per step (fwd + bwd)
+    if mode == "rows" and getattr(hg, "halo", None) is not None:
+        per_rank = 4 * hg.halo.exchange_rows() * d * (2 if DT == torch.bfloat16 else 4)       # four exchanges of the asked-for rows per step
+        print(f"      halo: {hg.halo.n_needed} of {n_v} vertices touched, {hg.halo.exchange_rows()} rows from peers per exchange (locality {LOCALITY:g})")
     per_link = per_rank / max(world - 1, 1)
     comm = per_link / LINK * 1e3
     print(f"{model} {mode}{f' chunks={CHUNKS}' if CHUNKS > 1 else ''} world={world}: per-rank compute {ms:7.2f} ms   exchange {per_rank/1e9:5.2f} GB per rank and step, "
