@@ -306,6 +306,36 @@ class Halo:
         return out.index_add_(0, self.send_idx, recv)                             # (CPU tests / odd widths: sequential, deterministic on CPU)
 
 
+    def _scatter_max(self, part: Tensor) -> Tensor:
+        """[len(needed), c] -> [block, c]: per owned row the maximum over what the ranks sent (rows nobody sent: 0)."""
+        if self.world == 1 or _skip_collective(self.group):
+            recv = part
+        else:
+            recv = _all_to_all_rows(part.contiguous(), self.need_counts, self.send_counts, self.group)
+        c = recv.shape[1]
+        if recv.is_cuda and recv.dtype == torch.float32:
+            from . import ops
+            pad = (-c) % 4
+            if pad:
+                recv = torch.cat([recv, recv.new_zeros(recv.shape[0], pad)], dim=1)
+            return ops.segreduce(2, self.sa_rowptr, self.sa_col, None, recv.contiguous(), self.block)[0][:, :c].contiguous()
+        out = recv.new_zeros((self.block, c))
+        idx = self.send_idx.view(-1, 1).expand_as(recv)
+        return out.scatter_reduce(0, idx, recv, "amax", include_self=False)
+
+    def gather_narrow(self, x_owned: Tensor) -> Tensor:
+        """``_gather`` for a few fp32 columns (logits, softmax statistics): rides the same all-to-all, no autograd."""
+        return self._gather(x_owned.contiguous())
+
+    def scatter_add_narrow(self, part: Tensor) -> Tensor:
+        """``_scatter_add`` for a tensor whose width is not a multiple of 4 (padded for the segment-sum kernel)."""
+        c = part.shape[1]
+        pad = (-c) % 4
+        if pad and part.is_cuda:
+            part = torch.cat([part, part.new_zeros(part.shape[0], pad)], dim=1)
+        return self._scatter_add(part)[:, :c].contiguous()
+
+
 class _HaloGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_owned, halo):
@@ -352,8 +382,8 @@ class ShardedHypergraph:
     def __init__(self, local_edge_index: Tensor, n_v: int, n_e_local: int, world: int, rank: int,
                  norm: Optional[Tensor] = None, inc_ids: Optional[Tensor] = None, halo: bool = False, group=None):
         """``halo=True``: exchange only the rows of the vertices the local hyperedges touch (:class:`Halo`; add / sum / mean
-        Deep Sets layers -- max / min and PMA keep the whole-table exchange) instead of all-gather / reduce-scatter of the whole
-        vertex table.  Construction then runs two small all-to-alls on ``group`` (every rank must construct at the same time)."""
+        Deep Sets layers and the PMA layer -- max / min keep the whole-table exchange) instead of all-gather / reduce-scatter of
+        the whole vertex table.  Construction then runs two small all-to-alls on ``group`` (every rank must construct at the same time)."""
         self.local_edge_index = local_edge_index
         # positions of the local incidences in the GLOBAL edge list (what a replicated per-incidence parameter such as
         # SetGNN.Importance, reference models.py:336-337, is indexed by); only LearnMask needs them
@@ -560,17 +590,38 @@ class _ShardedPmaE2V(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, V, alpha, hg, heads, slope, group, K):
-        inc = hg.e2v
+    def forward(ctx, V, alpha, hg, heads, slope, group, K, use_halo=False):
+        halo = hg.halo if use_halo else None
+        inc = hg.halo_e2v if halo is not None else hg.e2v
         in_dtype = V.dtype
         alpha = alpha.float()                                             # logits / softmax statistics are fp32 throughout
-        o_loc, m_loc, l_loc = K.fwd(V, alpha, inc, heads, slope)          # [n_v_pad, d], [n_v_pad, H] x2
+        o_loc, m_loc, l_loc = K.fwd(V, alpha, inc, heads, slope)          # [n_v_pad, d], [n_v_pad, H] x2 (halo: rows of the touched vertices)
         o_loc = o_loc.float()                                             # (bf16 storage: the cross-rank merge runs in fp32)
         n, d = o_loc.shape
         C = d // heads
         has = l_loc > 0
         neg_inf = torch.full_like(m_loc, float("-inf"))
         m_eff = torch.where(has, m_loc, neg_inf)
+        if halo is not None:
+            # boundary-vertex form of the same merge: every touched vertex has a local incidence (has is all true), the owners
+            # take the maximum of what their vertices' ranks report and hand it back; then the weighted sums travel to the owners
+            m_owned = halo._scatter_max(m_loc.contiguous())                            # [block, H]
+            m_gc = halo.gather_narrow(m_owned)                                         # [needed, H]
+            if hasattr(K, "merge_pack"):
+                packed = K.merge_pack(o_loc, m_loc, l_loc, m_gc, heads)
+            else:
+                w = l_loc * torch.exp(m_loc - m_gc)
+                packed = torch.cat([(o_loc.view(n, heads, C) * w.unsqueeze(-1)).view(n, d), w], dim=1)
+            red = halo.scatter_add_narrow(packed)                                      # owned rows
+            numer, l_g = red[:, :d], red[:, d:].contiguous()
+            inv = torch.where(l_g > 0, 1.0 / (l_g + 1e-16), torch.zeros_like(l_g))
+            out = (numer.reshape(-1, heads, C) * inv.unsqueeze(-1)).reshape(-1, d).contiguous()
+            m_g_owned = torch.where(l_g > 0, m_owned, torch.zeros_like(l_g)).contiguous()
+            ctx.save_for_backward(V, alpha, out, m_g_owned, l_g)
+            ctx.hg, ctx.heads, ctx.slope, ctx.group, ctx.K = hg, heads, slope, group, K
+            ctx.in_dtype, ctx.use_halo = in_dtype, True
+            return out.to(in_dtype)
+        ctx.use_halo = False
         m_g = m_eff.clone()
         if not _skip_collective(group):
             _all_reduce_(m_g, dist.ReduceOp.MAX, group)
@@ -602,11 +653,16 @@ class _ShardedPmaE2V(torch.autograd.Function):
         # the two-rank GPU test, a 1-rank group never packs)
         pad = (-(d + 2 * H)) % 4
         parts = [gout, stats.reshape(gout.shape[0], 2 * H)] + ([gout.new_zeros(gout.shape[0], pad)] if pad else [])
-        full = _all_gather_rows(torch.cat(parts, dim=1), ctx.group)
+        if ctx.use_halo:                              # the rows of the touched vertices only
+            full = hg.halo._gather(torch.cat(parts, dim=1))
+            inc = hg.halo_e2v
+        else:
+            full = _all_gather_rows(torch.cat(parts, dim=1), ctx.group)
+            inc = hg.e2v
         g_full = full[:, :d]                          # strided view: the kernels take a leading dimension, no copy
         stats_full = full[:, d:d + 2 * H].contiguous().view(-1, H, 2)
-        gV, galpha = K.bwd_src(hg.e2v, alpha, V, g_full.to(V.dtype) if g_full.dtype != V.dtype else g_full, stats_full, ctx.slope)
-        return gV, galpha.to(ctx.in_dtype) if galpha.dtype != ctx.in_dtype else galpha, None, None, None, None, None
+        gV, galpha = K.bwd_src(inc, alpha, V, g_full.to(V.dtype) if g_full.dtype != V.dtype else g_full, stats_full, ctx.slope)
+        return gV, galpha.to(ctx.in_dtype) if galpha.dtype != ctx.in_dtype else galpha, None, None, None, None, None, None
 
 
 def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph, dropout: float = 0.0,
@@ -629,11 +685,19 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
     H, C = p.heads, p.hidden
     # dense on owned vertices, then two all-gathers (no concatenate / split copies of the [n_V, d] table)
     V, alpha = p.project(x_owned)
-    V, alpha = all_gather_rows(V, group), all_gather_rows(alpha, group)
-    if K is HipPmaKernels:      # targets complete on their owner: the module's own joint pooling + ln0 node applies
-        e = p.pool_tail(V.contiguous(), alpha.contiguous(), hg.v2e, dropout if training else 0.0)[0]
+    use_halo = hg.halo is not None and hg.halo_v2e is not None and not _skip_collective(group)
+    if use_halo:                # only the rows of the vertices the local hyperedges touch travel (logits padded to 16-byte rows)
+        Hp = (-alpha.shape[1]) % 4
+        a4 = torch.cat([alpha, alpha.new_zeros(alpha.shape[0], Hp)], dim=1) if Hp else alpha
+        V, alpha = halo_gather(V, hg.halo), halo_gather(a4, hg.halo)[:, :alpha.shape[1]]
+        inc_v2e = hg.halo_v2e
     else:
-        o = K.aggregate(V.contiguous(), alpha.contiguous(), hg.v2e, H, p.negative_slope)
+        V, alpha = all_gather_rows(V, group), all_gather_rows(alpha, group)
+        inc_v2e = hg.v2e
+    if K is HipPmaKernels:      # targets complete on their owner: the module's own joint pooling + ln0 node applies
+        e = p.pool_tail(V.contiguous(), alpha.contiguous(), inc_v2e, dropout if training else 0.0)[0]
+    else:
+        o = K.aggregate(V.contiguous(), alpha.contiguous(), inc_v2e, H, p.negative_slope)
         e = p.tail(o, _post=dropout if training else 0.0)            # relu -> dropout inside ln1's pass
     # ---- E -> V
     p = e2v_conv.prop
@@ -647,7 +711,7 @@ def sharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHypergraph
         if hg.v_lo != 0 or hg.v_hi != o.shape[0]:          # (a no-op slice would still cost a zero-fill + copy backward)
             o = o[hg.v_lo:hg.v_hi]
     else:
-        o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K)
+        o = _ShardedPmaE2V.apply(V.contiguous(), alpha.contiguous(), hg, H, p.negative_slope, group, K, use_halo)
     return p.tail(o, _post=p_out if training else 0.0)
 
 

@@ -179,7 +179,7 @@ def build_problem(args, mode: str, world: int, rank: int, device):
         ei = ei[:, torch.argsort(ei[0], stable=True)].contiguous()
         shard.edge_index, shard.nnz, n_e_loc = ei, int(ei.shape[1]), n_loc + n_v
         shard.norm = torch.ones(shard.nnz, dtype=torch.int64, device=device)
-    halo = rows_halo(args) and world > 1 and args.model != "pma"
+    halo = rows_halo(args) and world > 1
     hg = adist.ShardedHypergraph(shard.edge_index, n_v, n_e_loc, world, rank, norm=shard.norm, halo=halo)
     return hg, float(shard.nnz), n_e_loc * world
 
@@ -427,7 +427,7 @@ def parallelism_label(args, mode, world):
     if world == 1:
         return "single GPU"
     if mode == "rows":
-        if rows_halo(args) and args.model != "pma":
+        if rows_halo(args):
             return (f"hyperedge-shard x{world} (boundary-vertex exchange: per direction one all-to-all of the rows of the vertices a rank's "
                     "hyperedges touch + its transpose, allset_amd.dist.Halo)")
         return f"hyperedge-shard x{world} (all-gather + reduce-scatter of the [n_V, d] vertex table per direction)"

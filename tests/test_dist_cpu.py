@@ -232,7 +232,7 @@ def _pma_convs(d, H):
     return a, b
 
 
-def _pma_worker(rank, world, port, q):
+def _pma_worker(rank, world, port, q, halo=False, H=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -240,10 +240,14 @@ def _pma_worker(rank, world, port, q):
         n_v, n_e, d, ei, _, x, G = _problem(world)
         owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "contiguous")
         loc, gids = adist.local_shard(ei, owner, rank)
-        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank)
+        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, halo=halo)
         hg.v2e = (loc, hg.n_e_local)
         hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
-        a, b = _pma_convs(d, 4)
+        if halo:
+            hloc = hg.halo_edge_index()
+            hg.halo_v2e = (hloc, hg.n_e_local)
+            hg.halo_e2v = (torch.stack([hloc[1], hloc[0]]), hg.halo.n_needed)
+        a, b = _pma_convs(d, H)
         xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
         Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - n_v, d)])
         xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
@@ -256,12 +260,19 @@ def _pma_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_pma_layer_equals_unsharded():
-    world = 2
+@pytest.mark.parametrize("world,H", [(2, 4), (3, 1), (4, 2)])
+def test_sharded_pma_layer_with_boundary_vertex_exchange_equals_unsharded(world, H):
+    """The PMA row partition with ``halo=True``: [V | logits] rows of the touched vertices only in V->E; in E->V the (m, l, o) merge
+    through the owners (per-vertex maximum of the local softmax maxima gathered back, weighted sums scattered to the owners) instead
+    of an all-reduce(max) + reduce-scatter over the whole vertex range."""
+    test_sharded_pma_layer_equals_unsharded(world, True, H)
+
+
+def test_sharded_pma_layer_equals_unsharded(world=2, halo=False, H=4):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pma_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pma_worker, args=(r, world, port, q, halo, H)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -271,7 +282,7 @@ def test_sharded_pma_layer_equals_unsharded():
 
     import torch.nn.functional as F
     n_v, n_e, d, ei, _, x, G = _problem(world)
-    a, b = _pma_convs(d, 4)
+    a, b = _pma_convs(d, H)
 
     def pma_module(p, xin, e_idx, n_dst):
         H, C = p.heads, p.hidden
