@@ -862,3 +862,103 @@ def test_bf16_wire_format_within_its_restated_tolerance(scheme, monkeypatch):
     err_o = float((out - v.detach()).abs().max()) / float(v.detach().abs().max())
     err_g = float((gx - xr.grad).abs().max()) / float(xr.grad.abs().max())
     assert 1e-6 < err_o < 2e-2 and err_g < 1e-1, (err_o, err_g)       # really rounded on the wire, and within the restated tolerance
+
+
+def test_halo_gather_and_scatter_are_transposes_single_rank():
+    """``Halo`` without a process group (world 1): gather = index_select by the touched vertices, scatter_add its transpose
+    (<gather(x), y> == <x, scatter_add(y)>), scatter_max the per-owned-row maximum; an empty incidence gives empty tables."""
+    from allset_amd import dist as adist
+    g = torch.Generator().manual_seed(0)
+    n_v, d = 29, 8
+    ids = torch.randint(0, n_v, (60,), generator=g)
+    halo = adist.Halo(ids, n_v, 1, 0)
+    assert torch.equal(halo.needed, torch.unique(ids)) and torch.equal(halo.needed[halo.compact_ids], ids)
+    x, y = torch.randn(n_v, d, generator=g), torch.randn(halo.n_needed, d, generator=g)
+    gx, sy = halo._gather(x), halo._scatter_add(y)
+    assert gx.shape == (halo.n_needed, d) and sy.shape == (n_v, d)
+    torch.testing.assert_close((gx * y).sum(), (x * sy).sum(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(gx, x[halo.needed])
+    untouched = torch.ones(n_v, dtype=torch.bool); untouched[halo.needed] = False
+    assert float(sy[untouched].abs().max()) == 0.0
+    m = halo._scatter_max(y[:, :3].contiguous())
+    assert torch.equal(m[halo.needed], y[:, :3]) and float(m[untouched].abs().max()) == 0.0
+    # autograd mirrors
+    xa = x.clone().requires_grad_(True)
+    (adist.halo_gather(xa, halo) * y).sum().backward()
+    torch.testing.assert_close(xa.grad, sy)
+    ya = y.clone().requires_grad_(True)
+    (adist.halo_scatter_add(ya, halo) * x).sum().backward()
+    torch.testing.assert_close(ya.grad, gx)
+    # a rank without any incidence
+    empty = adist.Halo(torch.zeros(0, dtype=torch.int64), n_v, 1, 0)
+    assert empty.n_needed == 0 and empty._gather(x).shape == (0, d) and float(empty._scatter_add(torch.zeros(0, d)).abs().sum()) == 0.0
+
+
+def _halo_model_worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import cases
+        from allset_amd import SetGNN, dist as adist
+        n_v, n_e, d, ei, _, x, G = _problem(world)
+        args = cases.make_args(mode, d, 32, 5, All_num_layers=2)
+        torch.manual_seed(11)
+        model = SetGNN(args).double().eval()
+        owner = adist.partition_hyperedges(torch.bincount(ei[1], minlength=n_e), world, "lpt")
+        loc, gids = adist.local_shard(ei, owner, rank)
+        keep = owner[ei[1]] == rank
+        hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=torch.ones(int(keep.sum()), dtype=torch.int64), halo=True)
+        hg.v2e = (loc, hg.n_e_local)
+        hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+        hloc = hg.halo_edge_index()
+        hg.halo_v2e = (hloc, hg.n_e_local)
+        hg.halo_e2v = (torch.stack([hloc[1], hloc[0]]), hg.halo.n_needed)
+        sharded = adist.ShardedSetGNN(model, hg, aggregate=_oracle_aggregate, kernels=TorchPmaKernels)
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)]).double()
+        out = sharded(xp[hg.v_lo:hg.v_hi])
+        live = max(0, min(hg.v_hi, n_v) - hg.v_lo)
+        cot = torch.linspace(-1.0, 1.0, n_v * out.shape[1]).view(n_v, -1)[hg.v_lo:hg.v_lo + live].double()
+        (out[:live] * cot).sum().backward()
+        sharded.allreduce_grads()
+        q.put((rank, out.detach().numpy().copy(), {k: v.numpy().copy() for k, v in model.state_dict().items()},
+               {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ds_mean", "ds_add"])       # (the PMA merge keeps its statistics in fp32 by design: layer-level tests above)
+def test_sharded_setgnn_with_halo_logits_and_gradients_equal_oracle_float64(mode):
+    """Two layers through ``ShardedSetGNN`` on the row partition with the boundary-vertex exchange, everything in float64 (so that
+    a mismatch is an algorithm error, not rounding or a relu kink): logits of the owned rows and every all-reduced parameter
+    gradient against the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cases
+    from oracle import allset_oracle as oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_model_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_v, n_e, d, ei, _, x, G = _problem(world)
+    args = cases.make_args(mode, d, 32, 5, All_num_layers=2)
+    sd = {k: torch.from_numpy(v) for k, v in results[0][2].items()}
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    ref = oracle.setgnn_forward(sd, args, x.double(), ei, torch.ones(ei.shape[1], dtype=torch.int64))
+    (ref * torch.linspace(-1.0, 1.0, n_v * ref.shape[1]).view(n_v, -1).double()).sum().backward()
+    got = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    torch.testing.assert_close(got, ref.detach(), rtol=1e-9, atol=1e-10)
+    for r in range(world):
+        for k, gnp in results[r][3].items():
+            if sd[k].grad is not None:
+                torch.testing.assert_close(torch.from_numpy(gnp), sd[k].grad, rtol=1e-7, atol=1e-9, msg=lambda m, k=k: f"{k} (rank {r}): {m}")
