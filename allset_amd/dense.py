@@ -786,6 +786,12 @@ class _FusedNormLinear(torch.autograd.Function):
     def backward(ctx, gy):
         x, stats, gamma, beta, weight, y, mask = ctx.saved_tensors
         relu_in, p_in, seed_in, p_out, has_bias, base = ctx.cfg
+        if x.shape[0] == 0:                     # no rows (a rank without hyperedges): every gradient is zero; empty tensors carry
+            z = lambda t, need: torch.zeros_like(t) if (t is not None and need) else None      # no row statistics to hand the kernels
+            return (z(x, ctx.needs_input_grad[0]), z(gamma, ctx.needs_input_grad[1]), z(beta, ctx.needs_input_grad[2]),
+                    z(weight, ctx.needs_input_grad[3]),
+                    weight.new_zeros(weight.shape[0]) if (has_bias and ctx.needs_input_grad[4]) else None,
+                    None, None, None, None, None, None, None)
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]

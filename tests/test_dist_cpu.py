@@ -23,6 +23,8 @@ def _free_port():
 def _oracle_aggregate(x, inc, norm, aggr):
     from oracle import allset_oracle as oracle
     ei, n_dst = inc
+    if ei.shape[1] == 0:                      # a rank without any incidence: zeros (kept in the graph so backward reaches x with zeros)
+        return x.new_zeros(n_dst, x.shape[1]) + 0.0 * x.sum()
     out = oracle.deepsets_aggregate(x, ei, norm, aggr)
     if out.shape[0] < n_dst:
         out = torch.cat([out, out.new_zeros(n_dst - out.shape[0], out.shape[1])])
@@ -962,3 +964,85 @@ def test_sharded_setgnn_with_halo_logits_and_gradients_equal_oracle_float64(mode
         for k, gnp in results[r][3].items():
             if sd[k].grad is not None:
                 torch.testing.assert_close(torch.from_numpy(gnp), sd[k].grad, rtol=1e-7, atol=1e-9, msg=lambda m, k=k: f"{k} (rank {r}): {m}")
+
+
+def _halo_random_worker(rank, world, port, q):
+    """Several odd-shaped problems through the row partition with the boundary-vertex exchange on one process group: fewer
+    hyperedges than ranks (a rank without any incidence), vertex counts that do not divide, untouched vertices, a hub vertex in
+    every hyperedge, weighted incidences, mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
+        res = []
+        for ci, (n_v, n_e, nnz, aggr, method, hub) in enumerate(_HALO_RANDOM):
+            rng = np.random.default_rng(100 + ci)
+            pairs = {(int(rng.integers(n_v // 2)), int(rng.integers(n_e))) for _ in range(nnz)}      # upper half of the vertices untouched
+            if hub:
+                pairs |= {(3, e) for e in range(n_e)}
+            ei = torch.tensor(sorted(pairs), dtype=torch.int64).t().contiguous()
+            norm = torch.from_numpy(rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32))
+            d = 8
+            x = torch.from_numpy(rng.standard_normal((n_v, d)).astype(np.float32))
+            sizes = torch.bincount(ei[1], minlength=n_e)
+            owner = adist.partition_hyperedges(sizes, world, method)
+            loc, gids = adist.local_shard(ei, owner, rank)
+            keep = owner[ei[1]] == rank
+            hg = adist.ShardedHypergraph(loc, n_v, gids.numel(), world, rank, norm=norm[keep], halo=True)
+            hg.v2e = (loc, hg.n_e_local)
+            hg.e2v = (torch.stack([loc[1], loc[0]]), hg.n_v_pad)
+            hloc = hg.halo_edge_index()
+            hg.halo_v2e = (hloc, hg.n_e_local)
+            hg.halo_e2v = (torch.stack([hloc[1], hloc[0]]), hg.halo.n_needed)
+            a, b = _convs(d)
+            xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+            xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
+            out = adist.sharded_deepsets_layer(a, b, xo, hg, aggr=aggr, aggregate=_oracle_aggregate)
+            cot = torch.linspace(-1, 1, hg.n_v_pad * d).view(hg.n_v_pad, d)[hg.v_lo:hg.v_hi]
+            (out * cot).sum().backward()
+            res.append((out.detach().numpy().copy(), xo.grad.numpy().copy(), hg.n_v_pad, hg.halo.n_needed))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+# n_v, n_e, nnz, aggr, partition method, hub vertex
+_HALO_RANDOM = [(23, 2, 30, "add", "contiguous", False), (41, 7, 90, "mean", "lpt", True), (64, 19, 200, "add", "lpt", True),
+                (17, 5, 25, "mean", "contiguous", False)]
+
+
+@pytest.mark.parametrize("world", [3, 5])
+def test_halo_exchange_on_odd_shaped_problems(world):
+    import torch.nn.functional as F
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_random_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for ci, (n_v, n_e, nnz, aggr, method, hub) in enumerate(_HALO_RANDOM):
+        rng = np.random.default_rng(100 + ci)
+        pairs = {(int(rng.integers(n_v // 2)), int(rng.integers(n_e))) for _ in range(nnz)}
+        if hub:
+            pairs |= {(3, e) for e in range(n_e)}
+        ei = torch.tensor(sorted(pairs), dtype=torch.int64).t().contiguous()
+        norm = torch.from_numpy(rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32))
+        d = 8
+        x = torch.from_numpy(rng.standard_normal((n_v, d)).astype(np.float32))
+        a, b = _convs(d)
+        n_pad = results[0][ci][2]
+        xr = torch.cat([x, x.new_zeros(n_pad - n_v, d)]).requires_grad_(True)     # the pad rows go through the dense tail too
+        h = F.relu(a.f_enc(xr))
+        e = F.relu(a.f_dec(_oracle_aggregate(h, (ei, n_e), norm, aggr)))
+        g = F.relu(b.f_enc(e))
+        v = F.relu(b.f_dec(_oracle_aggregate(g, (torch.stack([ei[1], ei[0]]), n_pad), norm, aggr)))
+        (v * torch.linspace(-1, 1, n_pad * d).view(n_pad, d)).sum().backward()
+        out = torch.cat([torch.from_numpy(results[r][ci][0]) for r in range(world)])
+        gx = torch.cat([torch.from_numpy(results[r][ci][1]) for r in range(world)])
+        torch.testing.assert_close(out, v.detach(), rtol=1e-5, atol=1e-5, msg=lambda m: f"config {ci}: {m}")
+        torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=1e-5, msg=lambda m: f"config {ci} grad: {m}")
+        assert any(results[r][ci][3] == 0 for r in range(world)) or n_e >= world      # (config 0: some rank has no incidence at all)

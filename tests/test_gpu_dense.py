@@ -1074,3 +1074,21 @@ def test_eval_mode_batchnorm_mlp_folds_into_the_fused_linear(layers, input_norm,
     for (k, pr), (_, pd) in zip(ref.named_parameters(), dut.named_parameters()):
         if pr.grad is not None:
             torch.testing.assert_close(pd.grad.cpu(), pr.grad, rtol=1e-3, atol=2e-4 * max(1.0, float(pr.grad.abs().max())), msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("norm", ["ln", "bn", "None"])
+def test_mlp_on_zero_rows_forward_and_backward(d, norm, device):
+    """An MLP applied to ZERO rows (a rank of a sharded job without hyperedges): empty output, zero parameter gradients, no error
+    from the fused kernels' argument checks (round 4: the backward handed an empty statistics buffer -- a null pointer -- to the
+    weight-gradient entry)."""
+    from allset_amd.layers import MLP
+    m = MLP(d, d, d, 2, 0.5, norm, True).to(device).train()
+    x = torch.zeros(0, d, device=device, requires_grad=True)
+    y = m(x, _post=0.5)
+    assert y.shape == (0, d)
+    y.sum().backward()
+    assert x.grad.shape == (0, d)
+    for p in m.parameters():
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0

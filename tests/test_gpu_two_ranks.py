@@ -443,3 +443,28 @@ def test_bench_two_ranks_locality_variant_with_halo_exchange():
     parts = line["partitions"]
     assert "boundary-vertex exchange" in parts["rows"]["parallelism"] and "error" not in parts["rows"] and "error" not in parts["columns"]
     assert "VARIANT workload" in line["config"]["workload"]
+
+
+def test_halo_layer_on_a_rank_without_incidences_single_process(device):
+    """``ShardedHypergraph(halo=True)`` whose local incidence is EMPTY (fewer hyperedges than ranks): compact table of zero rows,
+    aggregates of zero rows, the owned block's output is what the dense tail makes of zero sums -- on the HIP path, no collective
+    (world 1)."""
+    from allset_amd import dist as adist
+    a, b = _convs("ds", "add", 64)
+    a.to(device); b.to(device)
+    empty = torch.zeros(2, 0, dtype=torch.int64, device=device)
+    hg = adist.ShardedHypergraph(empty, 40, 0, 1, 0, halo=True).build_incidences()
+    assert hg.halo.n_needed == 0
+    x = torch.randn(40, 64, device=device, requires_grad=True)
+    out = adist.sharded_deepsets_layer(a, b, x, hg, aggr="add")
+    out.sum().backward()
+    ref = torch.relu(b.f_dec(torch.zeros(40, 64, device=device)))
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert float(x.grad.abs().max()) == 0.0
+    hg2 = adist.ShardedHypergraph(empty, 40, 0, 1, 0, halo=True).build_incidences()
+    c, e = _convs("pma", 4, 64)
+    c.to(device); e.to(device)
+    x2 = torch.randn(40, 64, device=device, requires_grad=True)
+    out2 = adist.sharded_pma_layer(c, e, x2, hg2)
+    out2.sum().backward()
+    assert out2.shape == (40, 64) and torch.isfinite(out2).all()
