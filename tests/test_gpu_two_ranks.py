@@ -100,7 +100,10 @@ def _worker(rank, world, port, q, which="two"):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _run_configs(rank, world, dev, q, *((LAYER_CFGS, MODEL_CFGS) if which == "two" else (LAYER_CFGS_8, [])))
+        if which == "tiny":             # 11 vertices, 5 hyperedges over 8 ranks: ranks without hyperedges, one-row vertex blocks
+            globals().update(N_V=TINY[0], N_E=TINY[1], NNZ=TINY[2])
+        _run_configs(rank, world, dev, q, *((LAYER_CFGS, MODEL_CFGS) if which == "two" else
+                                          ((LAYER_CFGS_TINY, []) if which == "tiny" else (LAYER_CFGS_8, []))))
     except BaseException:                       # report instead of leaving the parent waiting for a result that never comes
         import traceback
         q.put((rank, "ERROR\n" + traceback.format_exc()))
@@ -173,6 +176,12 @@ LAYER_CFGS_8 = [
 ]
 
 
+TINY = (11, 5, 14)
+LAYER_CFGS_TINY = [("ds", "rows", "add", "contiguous", 1, 64), ("ds", "rows+halo", "add", "contiguous", 1, 64),
+                   ("ds", "rows+halo", "mean", "lpt", 1, 64), ("ds", "cols", "add", None, 1, 128), ("ds", "cols", "max", None, 1, 128),
+                   ("pma", "rows", 4, "contiguous", 1, 64), ("pma", "rows+halo", 4, "contiguous", 1, 64), ("pma", "cols", 4, None, 1, 128)]
+
+
 def _spawn_ranks(world, which):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -199,6 +208,22 @@ def _spawn_ranks(world, which):
 @pytest.fixture(scope="module")
 def eight_ranks():
     return _spawn_ranks(8, "eight")
+
+
+@pytest.fixture(scope="module")
+def eight_ranks_tiny():
+    return _spawn_ranks(8, "tiny")
+
+
+@pytest.mark.parametrize("cfg", LAYER_CFGS_TINY, ids=lambda c: "-".join(str(t) for t in c))
+def test_eight_ranks_on_a_tiny_hypergraph(cfg, eight_ranks_tiny, device, monkeypatch):
+    """More ranks than hyperedges: 11 vertices (blocks of two rows, the last ranks' blocks all padding) and 5 hyperedges over EIGHT
+    ranks -- ranks without a single incidence, empty compact tables, zero-row MLP calls -- through both partitions and the
+    boundary-vertex exchange, against the unsharded HIP layer and the oracle."""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "N_V", TINY[0]); monkeypatch.setattr(mod, "N_E", TINY[1]); monkeypatch.setattr(mod, "NNZ", TINY[2])
+    _check_layer(cfg, eight_ranks_tiny, 8, device)
 
 
 @pytest.fixture(scope="module")
