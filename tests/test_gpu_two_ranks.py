@@ -493,3 +493,34 @@ def test_halo_layer_on_a_rank_without_incidences_single_process(device):
     out2 = adist.sharded_pma_layer(c, e, x2, hg2)
     out2.sum().backward()
     assert out2.shape == (40, 64) and torch.isfinite(out2).all()
+
+
+@pytest.mark.parametrize("method", ["AllDeepSets", "AllSetTransformer"])
+def test_sharded_training_example_reproduces_the_single_gpu_loss_curve(method):
+    """examples/sharded_train.py (the multi-GPU usage of INTEGRATION.md 3b): ten epochs of the reference's training-loop body with
+    dropouts off on ONE rank and on TWO ranks (gloo, one device) under each partition -- the loss sequence is a deterministic function
+    of the initial weights and must not depend on the number of ranks or on the partition."""
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    script = os.path.join(root, "examples", "sharded_train.py")
+    base = [script, "--method", method, "--epochs", "10", "--eval-mode", "--n-v", "1500"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+    def losses(out):
+        return [float(v) for v in re.findall(r"loss ([0-9.]+)", out)]
+
+    one = subprocess.run([sys.executable] + base + ["--partition", "rows"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    ref = losses(one.stdout)
+    assert len(ref) == 10 and ref[-1] < 0.7 * ref[0]
+    env2 = dict(env, ALLSET_DIST_BACKEND="gloo")
+    for part in ("rows", "rows+halo", "columns"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + base + ["--partition", part]
+        two = subprocess.run(cmd, cwd=root, env=env2, capture_output=True, text=True, timeout=900)
+        assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+        got = losses(two.stdout)
+        assert len(got) == 10
+        np.testing.assert_allclose(got[:4], ref[:4], rtol=2e-4, err_msg=part)         # plain parity before Adam amplifies rounding
+        np.testing.assert_allclose(got, ref, rtol=2e-2, err_msg=part)
