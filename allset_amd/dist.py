@@ -381,9 +381,8 @@ class ShardedHypergraph:
 
     def __init__(self, local_edge_index: Tensor, n_v: int, n_e_local: int, world: int, rank: int,
                  norm: Optional[Tensor] = None, inc_ids: Optional[Tensor] = None, halo: bool = False, group=None):
-        """``halo=True``: exchange only the rows of the vertices the local hyperedges touch (:class:`Halo`; add / sum / mean
-        Deep Sets layers and the PMA layer -- max / min keep the whole-table exchange) instead of all-gather / reduce-scatter of
-        the whole vertex table.  Construction then runs two small all-to-alls on ``group`` (every rank must construct at the same time)."""
+        """``halo=True``: exchange only the rows of the vertices the local hyperedges touch (:class:`Halo`; every Deep Sets
+        ``aggr`` and the PMA layer) instead of all-gather / reduce-scatter of the whole vertex table.  Construction then runs two small all-to-alls on ``group`` (every rank must construct at the same time)."""
         self.local_edge_index = local_edge_index
         # positions of the local incidences in the GLOBAL edge list (what a replicated per-incidence parameter such as
         # SetGNN.Importance, reference models.py:336-337, is indexed by); only LearnMask needs them
@@ -477,6 +476,46 @@ class _ShardedExtremeMerge(torch.autograd.Function):
         return torch.where(won, g_full, torch.zeros_like(g_full)), None, None, None, None
 
 
+class _HaloExtremeMerge(torch.autograd.Function):
+    """:class:`_ShardedExtremeMerge` through the boundary-vertex exchange: ``part`` [len(halo.needed), d] is this rank's extreme
+    for the vertices its hyperedges touch (each has a local incidence by construction).  The same keys -- (order-preserving
+    image of the value) << 8 | (255 - rank) -- travel to the vertices' owners, who keep the maximum per (vertex, feature): the
+    global extreme and a unique winner; the winning keys travel back so that every rank knows what it won; the backward gathers the
+    owners' gradient rows for the touched vertices and masks them to the elements won."""
+
+    @staticmethod
+    def forward(ctx, part, hg, is_min):
+        halo = hg.halo
+        r = halo.rank
+        v = -part if is_min else part
+        key = (_ordered_key(v) << 8) | (255 - r)
+        if halo.world == 1 or _skip_collective(halo.group):
+            recv = key
+        else:
+            recv = _all_to_all_rows(key.contiguous(), halo.need_counts, halo.send_counts, halo.group)
+        best = torch.full((halo.block, key.shape[1]), -1, dtype=torch.int64, device=key.device)
+        if recv.shape[0]:
+            best = best.scatter_reduce(0, halo.send_idx.view(-1, 1).expand_as(recv), recv, "amax", include_self=True)
+        best_c = best.index_select(0, halo.send_idx)
+        if not (halo.world == 1 or _skip_collective(halo.group)):
+            best_c = _all_to_all_rows(best_c, halo.send_counts, halo.need_counts, halo.group)
+        won = best_c == key
+        any_inc = best >= 0
+        bits = (best >> 8) & 0xFFFFFFFF
+        bits = torch.where(bits >= 0x80000000, bits - 0x80000000, 0xFFFFFFFF - bits)
+        val = torch.where(bits >= 0x80000000, bits - 0x100000000, bits).to(torch.int32).view(torch.float32)
+        out = torch.where(any_inc, -val if is_min else val, torch.zeros_like(val))
+        ctx.save_for_backward(won)
+        ctx.halo = halo
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (won,) = ctx.saved_tensors
+        g_c = ctx.halo._gather(gout.contiguous())
+        return torch.where(won, g_c, torch.zeros_like(g_c)), None, None
+
+
 def _hip_deepsets(x, inc, norm, aggr):
     from . import functional as AF
     return AF.deepsets_aggregate(x, inc, norm, aggr)
@@ -551,7 +590,7 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
     p_out = dropout if dropout_out is None else dropout_out    # GPR applies the last dropout itself (models.py:466-469)
     # ---- V -> E: dense on owned vertices, all-gather, local reduce over owned hyperedges
     # ``training`` must agree with the convs' own mode (the fused MLP kernels read conv.training)
-    use_halo = hg.halo is not None and aggr in ("add", "sum", "mean") and hg.halo_v2e is not None
+    use_halo = hg.halo is not None and hg.halo_v2e is not None
     with _bn_scope(vv, group):
         h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout)
     if use_halo:                                               # only the rows the local hyperedges touch travel
@@ -563,7 +602,9 @@ def sharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ShardedHyper
         e = v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout)       # conv's relu (SetGNN's outer relu is idempotent) + dropout
         # ---- E -> V: dense on owned hyperedges, local partial sums for all vertices, reduce-scatter
         g = e2v_conv._mlp_act(e2v_conv.f_enc, e, e2v_conv.dropout)
-    if aggr in ("max", "min"):
+    if aggr in ("max", "min") and use_halo:
+        v = _HaloExtremeMerge.apply(aggregate(g, hg.halo_e2v, norm, aggr), hg, aggr == "min")
+    elif aggr in ("max", "min"):
         # local extreme over this rank's hyperedges (autograd routes to the local arg-extreme), then the key merge
         partial = aggregate(g, hg.e2v, norm, aggr)
         v = _ShardedExtremeMerge.apply(partial, hg.local_vertex_has_incidence(), hg, group, aggr == "min")

@@ -82,11 +82,11 @@ def _worker(rank, world, port, aggr, method, q, halo=False):
 
 
 @pytest.mark.parametrize("aggr,method,world", [("add", "contiguous", 2), ("mean", "lpt", 2), ("add", "lpt", 4), ("mean", "contiguous", 3),
-                                               ("max", "contiguous", 2)])
+                                               ("max", "contiguous", 2), ("min", "lpt", 3), ("max", "lpt", 4)])
 def test_sharded_layer_with_boundary_vertex_exchange_equals_unsharded(aggr, method, world):
     """The row partition with ``halo=True``: only the rows of the vertices a rank's hyperedges touch are exchanged (all-to-all with
     per-peer counts + fixed-order sums) -- same outputs, input and parameter gradients as the unsharded layer, at 2, 3 and 4 ranks
-    (3: vertex blocks with padding); ``max`` keeps the whole-table exchange and must be unaffected by the flag."""
+    (3: vertex blocks with padding); ``max`` / ``min``: the key merge through the owners (one winner per vertex and feature)."""
     test_sharded_layer_equals_unsharded(aggr, method, world, halo=True)
 
 

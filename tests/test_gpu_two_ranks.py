@@ -33,6 +33,7 @@ LAYER_CFGS = [
     ("ds", "rows", "min", "lpt", 1, 32),
     # the row partition with the boundary-vertex exchange (dist.Halo): only the rows the local hyperedges touch travel
     ("ds", "rows+halo", "add", "contiguous", 1, 64), ("ds", "rows+halo", "mean", "lpt", 1, 128), ("ds", "rows+halo", "max", "lpt", 1, 64),
+    ("ds", "rows+halo", "min", "contiguous", 1, 32),
     ("pma", "rows+halo", 4, "contiguous", 1, 64), ("pma", "rows+halo", 1, "lpt", 1, 64),
     ("ds", "cols", "add", None, 1, 64), ("ds", "cols", "mean", None, 4, 64), ("ds", "cols", "max", None, 1, 128),
     ("ds", "cols", "add", None, 4, 128),
@@ -173,12 +174,13 @@ LAYER_CFGS_8 = [
     ("pma", "cols", 4, None, 1, 128), ("pma", "cols", 4, None, 2, 128), ("pma", "cols", 1, None, 1, 128),
     ("ds", "rows", "add", "lpt", 1, 64), ("ds", "rows", "max", "contiguous", 1, 64), ("pma", "rows", 4, "contiguous", 1, 64),
     ("ds", "rows+halo", "add", "lpt", 1, 64), ("ds", "rows+halo", "mean", "contiguous", 1, 128), ("pma", "rows+halo", 4, "lpt", 1, 64),
+    ("ds", "rows+halo", "max", "lpt", 1, 64),
 ]
 
 
 TINY = (11, 5, 14)
 LAYER_CFGS_TINY = [("ds", "rows", "add", "contiguous", 1, 64), ("ds", "rows+halo", "add", "contiguous", 1, 64),
-                   ("ds", "rows+halo", "mean", "lpt", 1, 64), ("ds", "cols", "add", None, 1, 128), ("ds", "cols", "max", None, 1, 128),
+                   ("ds", "rows+halo", "mean", "lpt", 1, 64), ("ds", "rows+halo", "max", "lpt", 1, 64), ("ds", "cols", "add", None, 1, 128), ("ds", "cols", "max", None, 1, 128),
                    ("pma", "rows", 4, "contiguous", 1, 64), ("pma", "rows+halo", 4, "contiguous", 1, 64), ("pma", "cols", 4, None, 1, 128)]
 
 
