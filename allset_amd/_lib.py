@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 F32, BF16 = 0, 1
@@ -82,6 +82,17 @@ SIGNATURES = {
     "allset_col_moments": [_P, c_int64, c_int64, c_int64, c_int, _P, _P, c_int64, _P],
     "allset_col_moments2": [_P, c_int64, c_int64, c_int64, c_int, _P, c_int64, _P],
     "allset_col_affine_add": [_P, c_int64, _P, c_int64, _P, _P, c_int, c_int64, c_int64, _P],
+    "allset_reduce_partials_batch_max": [],
+    "allset_reduce_partials_batchable": [c_int64, c_int64],
+    "allset_reduce_partials_batched": [_P, _P, _P, _P, _P, c_int64, _P],
+    "allset_linear_narrow_supported": [c_int64, c_int64],
+    "allset_linear_narrow_slices": [c_int64, POINTER(c_int64)],
+    "allset_linear_narrow_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P],
+    "allset_input_linear_k": [c_int64],
+    "allset_input_linear_supported": [c_int64],
+    "allset_xhat_rows": [_P, c_int64, c_int64, c_int64, c_float, c_float, c_uint64, _P, _P, c_int64, _P],
+    "allset_fold_ln_linear": [_P, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, _P],
+    "allset_unfold_ln_linear": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P, _P],
     "allset_fused_linear_bwd_all_aux_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, _P],
@@ -166,6 +177,7 @@ def load() -> ctypes.CDLL:
     lib.allset_fused_linear_mask_words.restype = c_int64
     lib.allset_gemm_x6_plane_bytes.restype = c_int64
     lib.allset_gemm_x6_lnb_partials.restype = c_int64
+    lib.allset_input_linear_k.restype = c_int64
     lib.allset_last_error.argtypes = []
     lib.allset_last_error.restype = c_char_p
     got = lib.allset_version()

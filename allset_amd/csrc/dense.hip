@@ -457,16 +457,17 @@ constexpr int kRedSplit = 8;                   // row groups per workgroup (256 
 constexpr int kRedRows = 64;                   // rows per slab
 
 // `slabs_here` > 1: one workgroup walks that many slabs itself (small reductions: one launch instead of two levels).
+// (`bx`, `by`: the workgroup's column-quad block and first slab -- blockIdx of the plain kernel, table-relative in the batched one.)
 template <bool OUT_BF16>
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ part, int64_t P, int64_t M,
-                                                                float* __restrict__ out, int64_t row_stride, int slabs_here) {
-  __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, int64_t P, int64_t M, float* __restrict__ out,
+                                                     int64_t row_stride, int slabs_here, int64_t bx, int64_t by,
+                                                     float4 (*red)[kBlock / kRedSplit]) {
   const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
-  const int64_t c = (static_cast<int64_t>(blockIdx.x) * (kBlock / kRedSplit) + cq) * 4;
+  const int64_t c = (bx * (kBlock / kRedSplit) + cq) * 4;
   float4 acc = make_float4(0, 0, 0, 0);
   if (c < M) {
     for (int sl = 0; sl < slabs_here; ++sl) {
-      const int64_t p0 = (static_cast<int64_t>(blockIdx.y) + sl) * kRedRows;
+      const int64_t p0 = (by + sl) * kRedRows;
       float4 v[kRedRows / kRedSplit];
 #pragma unroll
       for (int i = 0; i < kRedRows / kRedSplit; ++i) {
@@ -485,8 +486,35 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __
     if constexpr (OUT_BF16)      // single-slab launches only: `out` is a bf16 vector of M elements
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + c) = make_uint2(cvt_pk_bf16(acc.x, acc.y), cvt_pk_bf16(acc.z, acc.w));
     else
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(blockIdx.y) * M + c) = acc;
+      *reinterpret_cast<float4*>(out + by * M + c) = acc;
   }
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ part, int64_t P, int64_t M,
+                                                                float* __restrict__ out, int64_t row_stride, int slabs_here) {
+  __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
+  reduce_partials_body<OUT_BF16>(part, P, M, out, row_stride, slabs_here, blockIdx.x, blockIdx.y, red);
+}
+
+// MANY small reductions in one launch (dataset-scale training steps are chains of ~5 us kernels, a third of them these): the
+// table names up to kRedBatchMax partial buffers; every workgroup finds its buffer by a scan of the table's block offsets and then
+// does exactly what the one-launch form of the kernel above does for it -- the sums are bit-identical to separate calls.
+constexpr int kRedBatchMax = 48;
+struct RedBatchTable {
+  const float* part[kRedBatchMax];
+  float* out[kRedBatchMax];
+  int32_t P[kRedBatchMax], stride[kRedBatchMax], M[kRedBatchMax];
+  int32_t first_block[kRedBatchMax + 1];
+  int32_t count;
+};
+__global__ __launch_bounds__(kBlock) void reduce_partials_batched_kernel(RedBatchTable tb) {
+  __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
+  const int b = blockIdx.x;
+  int t = 0;
+  while (t + 1 < tb.count && tb.first_block[t + 1] <= b) ++t;
+  const int P = tb.P[t];
+  reduce_partials_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], (P + kRedRows - 1) / kRedRows, b - tb.first_block[t], 0, red);
 }
 
 static inline int ln_lpr(int64_t d) {
@@ -1708,6 +1736,11 @@ static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_
   return ALLSET_OK;
 }
 
+static inline bool reduce_one_launch(int64_t P, int64_t M) {
+  const int64_t slabs = (P + kRedRows - 1) / kRedRows;
+  return slabs == 1 || (slabs <= 8 && P * M <= (int64_t{1} << 21));
+}
+
 static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride, int64_t M, void* out, int out_bf16, float* scratch,
                                 void* stream);
 
@@ -1741,7 +1774,7 @@ static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride
   const unsigned gx = static_cast<unsigned>((quads + per_block - 1) / per_block);
   // small reductions (dataset-scale steps are launch-bound: 16 of a Cora step's 63 kernels were these): one launch, each
   // workgroup walks all slabs; large ones keep the two-level tree (1024 x 16.5k partials want every CU)
-  const bool one_launch = slabs == 1 || (slabs <= 8 && P * M <= (int64_t{1} << 21));
+  const bool one_launch = reduce_one_launch(P, M);
   if (one_launch) {
     const int sh = static_cast<int>(slabs);
     if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(part, P, M, out, row_stride, sh);
@@ -1751,6 +1784,39 @@ static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride
     if (out_bf16) reduce_partials_kernel<true><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M, 1);
     else reduce_partials_kernel<false><<<dim3(gx, 1), kBlock, 0, st>>>(scratch, slabs, M, out, M, 1);
   }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_reduce_partials_batch_max(void) { return kRedBatchMax; }
+
+// 1 when (P, M) is a reduction allset_reduce_partials finishes in ONE launch -- those are the ones the batched entry takes.
+extern "C" int allset_reduce_partials_batchable(int64_t P, int64_t M) {
+  return (P >= 1 && M >= 4 && M % 4 == 0 && M < INT32_MAX && reduce_one_launch(P, M)) ? 1 : 0;
+}
+
+extern "C" int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                              float* const* outs, int64_t count, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(count >= 0 && count <= kRedBatchMax, "reduce_partials_batched: at most %d buffers per call", kRedBatchMax);
+  if (count == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(parts && P && row_stride && M && outs, "reduce_partials_batched: null pointer");
+  RedBatchTable tb;
+  int64_t blocks = 0;
+  const int64_t per_block = kBlock / kRedSplit;
+  for (int64_t k = 0; k < count; ++k) {
+    ALLSET_REQUIRE(parts[k] && outs[k], "reduce_partials_batched: null buffer %lld", static_cast<long long>(k));
+    ALLSET_REQUIRE(allset_reduce_partials_batchable(P[k], M[k]), "reduce_partials_batched: buffer %lld is not batchable (see allset_reduce_partials_batchable)", static_cast<long long>(k));
+    ALLSET_REQUIRE(row_stride[k] >= M[k] && row_stride[k] % 4 == 0 && row_stride[k] < INT32_MAX && aligned16(parts[k]) && aligned16(outs[k]),
+                   "reduce_partials_batched: buffer %lld: row_stride >= M, a multiple of 4; 16-byte aligned pointers", static_cast<long long>(k));
+    tb.part[k] = parts[k]; tb.out[k] = outs[k];
+    tb.P[k] = static_cast<int32_t>(P[k]); tb.stride[k] = static_cast<int32_t>(row_stride[k]); tb.M[k] = static_cast<int32_t>(M[k]);
+    tb.first_block[k] = static_cast<int32_t>(blocks);
+    blocks += (M[k] / 4 + per_block - 1) / per_block;
+  }
+  tb.first_block[count] = static_cast<int32_t>(blocks);
+  tb.count = static_cast<int32_t>(count);
+  reduce_partials_batched_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, static_cast<hipStream_t>(stream)>>>(tb);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -90,6 +90,87 @@ def _check_dtype(dtype: torch.dtype, *ts: Tensor) -> None:
 
 # ---- raw wrappers --------------------------------------------------------------------------------
 
+# ---- deferred parameter gradients: ONE reduction launch per backward pass ------------------------------------------------------------
+# Every fused backward kernel leaves per-workgroup partial sums of its parameter gradients; `reduce_partials` finishes each with a
+# launch of its own -- 8 of the 41 kernels of a graphed Cora-shaped step, ~5 us each because the step is a dependent chain.
+# Inside `deferred_param_grads()` a backward node whose parameters are LEAF tensors does not reduce: it queues (partials,
+# parameter, section) and returns None for those gradients; leaving the context reduces everything queued with one batched
+# launch (`allset_reduce_partials_batched`: the same sums, bit for bit) and assigns / accumulates `.grad`.  Opt-in because the
+# gradients bypass autograd's accumulation nodes (tensor hooks on parameters do not see them): `graphs.GraphedTrainStep` uses it.
+class _Deferred:
+    active = False
+    pending: list = []          # (part [P, stride], M, [(param, offset, shape), ...])
+
+
+def _deferrable(part: Tensor, *params) -> bool:
+    if not _Deferred.active or part.dim() != 2 or part.dtype != torch.float32:
+        return False
+    P, M = part.shape
+    if not _lib.load().allset_reduce_partials_batchable(P, M):
+        return False
+    return all(p is None or (isinstance(p, torch.nn.Parameter) and p.is_leaf and p.requires_grad and p.dtype == torch.float32)
+               for p in params)
+
+
+def _defer(part: Tensor, sections) -> None:
+    _Deferred.pending.append((part, part.shape[1], [(p, off, tuple(shape)) for p, off, shape in sections if p is not None]))
+
+
+def flush_param_grads() -> None:
+    pend, _Deferred.pending = _Deferred.pending, []
+    if not pend:
+        return
+    lib = _lib.load()
+    cap = int(lib.allset_reduce_partials_batch_max())
+    dev = pend[0][0].device
+    out = torch.empty(sum(M for _, M, _ in pend), dtype=torch.float32, device=dev)
+    import ctypes
+    base, bases = 0, []
+    for part, M, _ in pend:
+        bases.append(base)
+        base += M
+    for k0 in range(0, len(pend), cap):
+        chunk = pend[k0:k0 + cap]
+        n = len(chunk)
+        parts = (ctypes.c_void_p * n)(*[part.data_ptr() for part, _, _ in chunk])
+        outs = (ctypes.c_void_p * n)(*[out.data_ptr() + 4 * b for b in bases[k0:k0 + n]])
+        Ps = (ctypes.c_int64 * n)(*[part.shape[0] for part, _, _ in chunk])
+        strides = (ctypes.c_int64 * n)(*[part.stride(0) for part, _, _ in chunk])
+        Ms = (ctypes.c_int64 * n)(*[M for _, M, _ in chunk])
+        with on_device(dev):
+            check(lib.allset_reduce_partials_batched(parts, Ps, strides, Ms, outs, n, stream_of(dev)), "allset_reduce_partials_batched")
+    with torch.no_grad():
+        for (part, M, sections), b in zip(pend, bases):
+            for p, off, shape in sections:
+                numel = 1
+                for v in shape:
+                    numel *= v
+                g = out[b + off:b + off + numel].view(shape)
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+
+
+class deferred_param_grads:
+    """Context manager around ``loss.backward()``: parameter gradients of the fused backward kernels are reduced by ONE batched
+    launch on exit (see above).  Not re-entrant."""
+
+    def __enter__(self):
+        if _Deferred.active:
+            raise _lib.AllSetHipError("deferred_param_grads is not re-entrant")
+        _Deferred.active, _Deferred.pending = True, []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _Deferred.active = False
+        if exc_type is None:
+            flush_param_grads()
+        else:
+            _Deferred.pending = []
+        return False
+
+
 def reduce_partials(part: Tensor) -> Tensor:
     """Sum a partial buffer [P, ...] over its first axis with the dedicated kernel (the torch reduction runs at
     ~1 TB/s on these shapes); returns a tensor shaped like ``part[0]``."""
@@ -524,9 +605,10 @@ def one_pass_preferred(O: int, I: int) -> bool:
 def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
                          gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
                          seed_base: Optional[Tensor] = None, acc_in: Optional[Tensor] = None, want_bias: bool = True,
-                         norm_mode: int = 0) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor, Optional[Tensor]]:
+                         norm_mode: int = 0, defer_to=None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor, Optional[Tensor]]:
     """(gx, dgamma, dbeta, gW, gb) of the fused Linear from ONE pass over gy and x (include/allset_hip.h
-    allset_fused_linear_bwd_all)."""
+    allset_fused_linear_bwd_all).  ``defer_to`` = the (gamma, beta, weight, bias) PARAMETERS: inside ``deferred_param_grads()`` their
+    gradients are queued for the batched reduction and come back as None."""
     dev = require_device(gy, mask, weight, x, stats, gamma, beta, acc_in)
     _check_f32(gy, weight, x, stats, gamma, beta, acc_in)
     gy, x = _rowmajor(gy), _rowmajor(x)
@@ -566,6 +648,11 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
             int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w), ptr(part_b if want_bias else None), P, n, O, I,
             ptr(seed_base), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0, M, stream_of(dev)), "allset_fused_linear_bwd_all")
+    if defer_to is not None and _deferrable(part, *defer_to):
+        g_p, b_p, w_p, bias_p = defer_to
+        _defer(part, [(w_p, 0, (O, I)), (bias_p if want_bias else None, O * I, (O,)),
+                      (g_p if stats is not None else None, O * I + O, (I,)), (b_p if stats is not None else None, O * I + O + I, (I,))])
+        return gx, None, None, None, None
     red = reduce_partials(part)
     gw = red[:O * I].view(O, I)
     gb = red[O * I:O * I + O] if want_bias else None
@@ -725,6 +812,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -733,9 +821,13 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = gb = None
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w and linear_narrow_supported(gy, x, weight):          # a classifier head: one kernel for all three gradients
+            defer = ctx.params if (not ctx.has_bias or need_b) else None
+            gx, gw, gb = linear_narrow_bwd(gy, x, weight, ctx.needs_input_grad[0], defer_to=defer)
+            return gx, gw, gb if need_b else None
         if ctx.needs_input_grad[0]:
             gx = gy @ weight
-        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
             if wgrad_supported(gy, x):
                 gw, gb = wgrad(gy, x, want_bias=need_b)
@@ -779,6 +871,7 @@ class _FusedNormLinear(torch.autograd.Function):
         ctx.save_for_backward(x, stats, gamma, beta, weight, y if (keep_y and mask is None) else None, mask)
         ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
         ctx.layout = (int(in_cb), int(out_cb))
+        ctx.params = (gamma, beta, weight, bias)     # (the objects themselves: deferred_param_grads assigns their .grad)
         return y
 
     @staticmethod
@@ -807,8 +900,10 @@ class _FusedNormLinear(torch.autograd.Function):
                 fused_linear_bwd_all_supported(weight.shape[0], weight.shape[1], gamma is not None, p_in > 0.0, relu_in,
                                                mask is not None)):
             # everything from one read of gy and x
+            need = ctx.needs_input_grad
+            defer = ctx.params if (_Deferred.active and (gamma is None or (need[1] and need[2])) and (not has_bias or need[4])) else None
             gx, dg, db, gw, gb = fused_linear_bwd_all(gy, mask, p_out, weight, x, stats, gamma, beta, relu_in, p_in, seed_in,
-                                                      base, want_bias=need_b)
+                                                      base, want_bias=need_b, defer_to=defer)
             return gx, dg, db, gw, gb, None, None, None, None, None, None, None
         if ctx.needs_input_grad[3] or need_b:
             gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b,
@@ -1356,6 +1451,123 @@ def relu_dropout(x: Tensor, p: float = 0.0) -> Tensor:
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     return _Linear.apply(x, weight, bias)
+
+
+def linear_narrow_supported(gy: Tensor, x: Tensor, weight: Tensor) -> bool:
+    return (gy.is_cuda and gy.dtype == x.dtype == weight.dtype == torch.float32 and gy.dim() == 2 and x.dim() == 2
+            and bool(_lib.load().allset_linear_narrow_supported(weight.shape[0], weight.shape[1]))
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def linear_narrow_bwd(gy: Tensor, x: Tensor, weight: Tensor, want_gx: bool = True, defer_to=None):
+    """``(gx, gW, gb)`` of ``y = x W^T + b`` with at most 16 outputs (a classifier head) from one kernel (csrc/narrow_linear.hip).
+    ``defer_to`` = the (weight, bias) PARAMETERS: inside ``deferred_param_grads()`` gW / gb are queued and come back as None."""
+    dev = require_device(gy, x, weight)
+    _check_f32(gy, x, weight)
+    gy, x, weight = _rowmajor(gy), _rowmajor(x), weight.contiguous()
+    n, N = gy.shape
+    K = x.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_linear_narrow_slices(n, byref(ns)), "allset_linear_narrow_slices")
+    M = (N * K + N + 3) // 4 * 4
+    part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
+    gx = torch.empty((n, K), dtype=torch.float32, device=dev) if want_gx else None
+    with on_device(dev):
+        check(lib.allset_linear_narrow_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(weight), n, N, K, ptr(gx), K, ptr(part), M, ns.value,
+                                           stream_of(dev)), "allset_linear_narrow_bwd")
+    if defer_to is not None and _deferrable(part, *defer_to):
+        _defer(part, [(defer_to[0], 0, (N, K)), (defer_to[1], N * K, (N,))])
+        return gx, None, None
+    red = reduce_partials(part)
+    return gx, red[:N * K].view(N, K), red[N * K:N * K + N]
+
+
+# ---- the FIRST Linear of a model: [dropout ->] LayerNorm(raw features) -> Linear on an input without gradient (csrc/input_linear.hip) ----
+def input_norm_linear_supported(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], weight: Tensor, bias: Optional[Tensor]) -> bool:
+    """``x`` is a device fp32 matrix that needs no gradient (raw features), the LayerNorm has both affine parameters, width
+    <= 4096.  Widths the fused kernels take (64 / 128) keep those."""
+    if gamma is None or beta is None or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    if x.requires_grad and torch.is_grad_enabled():
+        return False
+    if any(t is not None and (t.dtype != torch.float32 or not t.is_cuda) for t in (gamma, beta, weight, bias)):
+        return False
+    return bool(_lib.load().allset_input_linear_supported(x.shape[1])) and weight.shape[1] == x.shape[1]
+
+
+def xhat_rows(x: Tensor, eps: float, p_pre: float, seed: int) -> Tensor:
+    """``[LayerNorm_noaffine(dropout_p(x)) | 1 | 0...]``  [n, K], K = d + 1 rounded up to 16."""
+    require_device(x); _check_f32(x)
+    x = _rowmajor(x)
+    n, d = x.shape
+    K = int(_lib.load().allset_input_linear_k(d))
+    xh = torch.empty((n, K), dtype=torch.float32, device=x.device)
+    base = _seed_base()
+    with on_device(x.device):
+        check(_lib.load().allset_xhat_rows(ptr(x), _ld(x), n, d, float(eps), float(p_pre), seed, ptr(base) if base is not None else None,
+                                           ptr(xh), K, stream_of(x.device)), "allset_xhat_rows")
+    return xh
+
+
+def fold_ln_linear(weight: Tensor, gamma: Tensor, beta: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """``[W * gamma | b + W beta | 0...]``  [O, K]."""
+    require_device(weight); _check_f32(weight, gamma, beta, bias)
+    weight, gamma, beta = _rowmajor(weight), gamma.contiguous(), beta.contiguous()
+    O, d = weight.shape
+    K = int(_lib.load().allset_input_linear_k(d))
+    wp = torch.empty((O, K), dtype=torch.float32, device=weight.device)
+    with on_device(weight.device):
+        check(_lib.load().allset_fold_ln_linear(ptr(weight), _ld(weight), ptr(gamma), ptr(beta), ptr(bias.contiguous()) if bias is not None else None,
+                                                O, d, ptr(wp), K, stream_of(weight.device)), "allset_fold_ln_linear")
+    return wp
+
+
+def unfold_ln_linear(M: Tensor, weight: Tensor, gamma: Tensor, beta: Tensor, want_bias: bool) -> Tuple[Tensor, Optional[Tensor], Tensor, Tensor]:
+    """``M = gy^T [x_hat | 1]`` -> ``(gW, gb, ggamma, gbeta)``."""
+    require_device(M); _check_f32(M, weight, gamma, beta)
+    M, weight = _rowmajor(M), _rowmajor(weight)
+    O, d = weight.shape
+    out = torch.empty(O * d + O + 2 * d, dtype=torch.float32, device=M.device)       # one allocation: gW | gb | ggamma | gbeta
+    gw, gb = out[:O * d].view(O, d), out[O * d:O * d + O]
+    gg, gbt = out[O * d + O:O * d + O + d], out[O * d + O + d:]
+    with on_device(M.device):
+        check(_lib.load().allset_unfold_ln_linear(ptr(M), _ld(M), ptr(weight), _ld(weight), ptr(gamma.contiguous()), ptr(beta.contiguous()),
+                                                  O, d, ptr(gw), d, ptr(gb) if want_bias else None, ptr(gg), ptr(gbt),
+                                                  stream_of(M.device)), "allset_unfold_ln_linear")
+    return gw, (gb if want_bias else None), gg, gbt
+
+
+class _InputNormLinear(torch.autograd.Function):
+    """``Linear(LayerNorm(dropout_p(x)))`` for an ``x`` that needs no gradient: x_hat (LayerNorm without its affine part, a ones
+    column behind it) is written once and kept; forward = one GEMM against the folded weight ``[W * gamma | b + W beta]``; the
+    backward is ONE GEMM ``M = gy^T [x_hat | 1]`` and a [O, d]-sized kernel that unfolds it into all four parameter gradients
+    (csrc/input_linear.hip has the algebra).  Reference: models.py:473-476 + layers.py:571-573 (``x = self.normalizations[0](x)``
+    ... ``self.lins[0](x)``) -- there a dropout, a LayerNorm, a Linear and, in the backward, the [n, d] input gradient of the
+    Linear + the LayerNorm backward over it."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, bias, eps, p_pre):
+        seed = _draw_seed() if p_pre > 0.0 else 0
+        xh = xhat_rows(x, eps, p_pre, seed)
+        wp = fold_ln_linear(weight, gamma, beta, bias)
+        ctx.save_for_backward(xh, gamma, beta, weight)
+        ctx.has_bias = bias is not None
+        return xh @ wp.t()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xh, gamma, beta, weight = ctx.saved_tensors
+        M = gy.contiguous().t() @ xh
+        gw, gb, gg, gbt = unfold_ln_linear(M, weight, gamma, beta, ctx.has_bias)
+        need = ctx.needs_input_grad
+        return None, gg if need[1] else None, gbt if need[2] else None, gw if need[3] else None, gb if (ctx.has_bias and need[4]) else None, None, None
+
+
+def input_norm_linear(x: Tensor, gamma: Tensor, beta: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5,
+                      p_pre: float = 0.0) -> Tensor:
+    return _InputNormLinear.apply(x, gamma, beta, weight, bias, float(eps), float(p_pre))
 
 
 # ---- BatchNorm over a row-sharded batch (reference layers.py:499-562: MLP's default Normalization='bn') ----------------------------

@@ -116,7 +116,8 @@ class GraphedTrainStep:
             self.counter.add_(1)
             optimizer.zero_grad(set_to_none=True)
             loss = loss_fn(model(data))
-            loss.backward()
+            with dense.deferred_param_grads():       # one batched reduction of the parameter-gradient partials (dense.py)
+                loss.backward()
             optimizer.step()
             return loss
 

@@ -184,6 +184,32 @@ class MLP(nn.Module):
                 return False
         return True
 
+    def _wide_input(self, x: Tensor) -> bool:
+        """The FIRST MLP of a model at dataset scale (round 4): a LayerNorm over raw features (widths the resident-weight kernels do
+        not take) in front of its first Linear, on an input that needs no gradient -- ``dense.input_norm_linear`` (one GEMM each
+        way, no [n, d] input gradient); the remaining Linears take the fused kernels as in ``_fusable``."""
+        if not _on_hip(x) or x.dim() != 2:
+            return False
+        n0, lin0 = self.normalizations[0], self.lins[0]
+        if not (isinstance(n0, nn.LayerNorm) and n0.elementwise_affine and n0.bias is not None):
+            return False
+        if dense.fused_linear_supported(lin0.in_features, lin0.out_features):
+            return False
+        if not dense.input_norm_linear_supported(x, n0.weight, n0.bias, lin0.weight, lin0.bias):
+            return False
+        p = float(self.dropout) if self.training else 0.0
+        for nm, lin in zip(self.normalizations[1:], self.lins[1:]):
+            if lin.bias is None or not isinstance(nm, (nn.LayerNorm, nn.Identity)):
+                return False
+            if not (dense.fused_linear_supported(lin.in_features, lin.out_features) or
+                    dense.wide_linear_supported(lin.in_features, lin.out_features, isinstance(nm, nn.LayerNorm), True, p)):
+                return False
+        return True
+
+    def takes_pre_dropout(self, x: Tensor) -> bool:
+        """``forward(x, _pre=p)`` can apply the dropout in FRONT of the MLP (models.py:473) inside its first kernel."""
+        return self._wide_input(x)
+
     @staticmethod
     def _fold_bn(bn, lin) -> Tuple[Tensor, Tensor]:
         """(W', b') with ``lin(bn(x)) == x @ W'^T + b'`` for an eval-mode BatchNorm (differentiable w.r.t. W, b, gamma, beta)."""
@@ -206,12 +232,29 @@ class MLP(nn.Module):
                 all(dense.fused_linear_supported(lin.in_features, lin.out_features) for lin in self.lins) and
                 cb <= first.in_features // 2 and cb <= last.out_features // 2)
 
-    def forward(self, x, _post: Optional[float] = None, _in_cb: int = 0, _out_cb: int = 0):
+    def forward(self, x, _post: Optional[float] = None, _in_cb: int = 0, _out_cb: int = 0, _pre: float = 0.0):
         """``_post`` (internal): also apply ``dropout_p(relu(.))`` to the output -- the activation its callers
         (``HalfNLHconv``) put right after the MLP -- inside the last Linear's epilogue.  ``_in_cb`` / ``_out_cb`` (internal, only
-        after ``blockable``): the input / output is column-blocked [(C / cb) * n, cb]."""
+        after ``blockable``): the input / output is column-blocked [(C / cb) * n, cb].  ``_pre`` (internal, only after
+        ``takes_pre_dropout``): a dropout in front of the MLP, applied inside its first kernel."""
         p = float(self.dropout) if self.training else 0.0
         post_p = (float(_post) if self.training else 0.0) if _post is not None else None
+        if _pre and not self._wide_input(x):
+            raise ValueError("MLP.forward(_pre=...) needs takes_pre_dropout(x)")
+        if not (_in_cb or _out_cb) and self._wide_input(x):
+            n0, lin0 = self.normalizations[0], self.lins[0]
+            x = dense.input_norm_linear(x, n0.weight, n0.bias, lin0.weight, lin0.bias, n0.eps, float(_pre) if self.training else 0.0)
+            last = len(self.lins) - 1
+            if last == 0:
+                return x if post_p is None else relu_dropout(x, _post, self.training)
+            for i in range(1, last + 1):
+                nm, lin = self.normalizations[i], self.lins[i]
+                ln = nm if isinstance(nm, nn.LayerNorm) else None
+                ro = i == last and post_p is not None
+                x = dense.fused_norm_linear(
+                    x, ln.weight if ln is not None else None, ln.bias if ln is not None else None, lin.weight, lin.bias,
+                    ln.eps if ln is not None else 1e-5, relu_in=True, p_in=p, relu_out=ro, p_out=post_p if ro else 0.0)
+            return x
         if _in_cb or _out_cb:
             last = len(self.lins) - 1
             for i, lin in enumerate(self.lins):
@@ -449,10 +492,16 @@ class HalfNLHconv(nn.Module):
                 if not isinstance(f, nn.Identity):
                     f.reset_parameters()
 
-    def forward(self, x, edge_index: EdgeIndex, norm, aggr='add', _post_dropout: Optional[float] = None):
+    def takes_pre_dropout(self, x: Tensor) -> bool:
+        return (not self.attention) and isinstance(self.f_enc, MLP) and self.f_enc.takes_pre_dropout(x)
+
+    def forward(self, x, edge_index: EdgeIndex, norm, aggr='add', _post_dropout: Optional[float] = None, _pre_dropout: float = 0.0):
         """``_post_dropout`` (internal, used by ``SetGNN``): also apply the ``relu -> dropout(p)`` that
-        ``SetGNN.forward`` wraps around every conv (models.py:475-481) inside the conv's last fused pass."""
+        ``SetGNN.forward`` wraps around every conv (models.py:475-481) inside the conv's last fused pass.  ``_pre_dropout``
+        (internal, only after ``takes_pre_dropout``): the dropout ``SetGNN.forward`` puts in front of the first conv (models.py:473)."""
         post = _post_dropout is not None
+        if _pre_dropout and not (self.takes_pre_dropout(x) and aggr is not None):
+            raise ValueError("HalfNLHconv.forward(_pre_dropout=...) needs takes_pre_dropout(x)")
         if self.attention:
             if post and self.training:      # training: the conv's relu -> dropout rides in ln1's pass (PMA.tail)
                 return self.prop(x, edge_index, _post=float(_post_dropout))
@@ -460,15 +509,15 @@ class HalfNLHconv(nn.Module):
             return relu_dropout(x, _post_dropout, self.training) if post else x
         if aggr is None:
             raise ValueError("aggr was not passed!")
-        x = self._mlp_act(self.f_enc, x, self.dropout)
+        x = self._mlp_act(self.f_enc, x, self.dropout, pre=_pre_dropout)
         inc = _as_incidence(edge_index, x.shape[0])
         x = AF.deepsets_aggregate(x, inc, norm, aggr)
         # relu(f_dec(.)); SetGNN's outer relu is idempotent on it, so its dropout can ride in the same pass
         return self._mlp_act(self.f_dec, x, _post_dropout if post else 0.0)
 
-    def _mlp_act(self, mlp, x, p, in_cb: int = 0, out_cb: int = 0):
+    def _mlp_act(self, mlp, x, p, in_cb: int = 0, out_cb: int = 0, pre: float = 0.0):
         """``dropout_p(relu(mlp(x)))``; the activation rides in the MLP's last fused kernel when there is one.
         ``in_cb`` / ``out_cb``: column-blocked input / output (only after ``mlp.blockable``; dist.py)."""
         if isinstance(mlp, MLP):
-            return mlp(x, _post=p, _in_cb=in_cb, _out_cb=out_cb)
+            return mlp(x, _post=p, _in_cb=in_cb, _out_cb=out_cb, _pre=pre)
         return relu_dropout(mlp(x), p, self.training)

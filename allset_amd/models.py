@@ -152,9 +152,12 @@ class SetGNN(nn.Module):
             # which the library runs as a strided-batched GEMM with K = L+1 -- 19 SECONDS per step at n = 1M, d = 128
             # (tools/model_step_profile.py with MODEL_ARGS=All_num_layers=2,GPR=1); same arithmetic, same parameter.
             return self.classifier(_WeightedSum.apply(self.GPRweights.weight, *xs))
-        x = F.dropout(x, p=0.2, training=self.training)      # hard-coded input dropout (models.py:473)
+        # hard-coded input dropout (models.py:473); on raw features without gradient it rides in the first conv's first kernel
+        pre = 0.2 if (self.training and len(self.V2EConvs) and self.V2EConvs[0].takes_pre_dropout(x)) else 0.0
+        if not pre:
+            x = F.dropout(x, p=0.2, training=self.training)
         for i in range(len(self.V2EConvs)):
             # x = dropout(relu(conv(x))) (models.py:475-481); relu + dropout ride in the conv's last fused pass
-            x = self.V2EConvs[i](x, v2e, norm, self.aggr, _post_dropout=self.dropout)
+            x = self.V2EConvs[i](x, v2e, norm, self.aggr, _post_dropout=self.dropout, _pre_dropout=pre if i == 0 else 0.0)
             x = self.E2VConvs[i](x, e2v, norm, self.aggr, _post_dropout=self.dropout)
         return self.classifier(x)

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 9   /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only" */
+#define ALLSET_ABI_VERSION 10  /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batchable / _batched, allset_linear_narrow_supported / _slices / _bwd) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -299,6 +299,15 @@ int allset_reduce_partials(const float* part, int64_t P, int64_t M, float* out, 
  * (out_dtype: ALLSET_F32 -> f32[M], ALLSET_BF16 -> bf16[M], rounded once from the fp32 sum). */
 int allset_reduce_partials_ex(const float* part, int64_t P, int64_t row_stride, int64_t M, void* out, int out_dtype,
                               float* scratch, void* stream);
+/* MANY small reductions in ONE launch (ABI 10; a dataset-scale training step is a chain of ~5 us kernels, a third of them
+ * allset_reduce_partials): out[k][c] = sum_p parts[k][p * row_stride[k] + c], p < P[k], c < M[k], for k < count <=
+ * allset_reduce_partials_batch_max(); every (P[k], M[k]) must satisfy allset_reduce_partials_batchable (the reductions the single
+ * entry finishes in one launch: P <= 64, or P <= 512 with P * M <= 2^21).  The pointer / size arrays are HOST arrays (copied into
+ * the kernel's arguments).  Sums are bit-identical to count separate allset_reduce_partials calls. */
+int allset_reduce_partials_batch_max(void);
+int allset_reduce_partials_batchable(int64_t P, int64_t M);
+int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                   float* const* outs, int64_t count, void* stream);
 
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;
@@ -536,6 +545,35 @@ int allset_col_moments2(const float* x, int64_t ldx, int64_t n, int64_t d, int r
  * (s = 2 dvar / n, t = dmean / n - s * mean). */
 int allset_col_affine_add(float* gx, int64_t ldgx, const float* x, int64_t ldx, const float* s, const float* t, int relu_mask,
                           int64_t n, int64_t d, void* stream);
+/* ---- backward of a Linear with a NARROW output: the classifier head Linear(hidden -> num_classes) (reference models.py:449-456) ----
+ * ONE kernel instead of the library's three (input gradient, weight gradient on a single workgroup, bias gradient):
+ *   gx[n, K] = gy[n, N] W[N, K] (gx may be NULL);  part[slice][k * K + j] = partial sums of gW = gy^T x;  part[slice][N * K + k] of gb.
+ * N <= 16, K <= 256, K % 4 == 0 (allset_linear_narrow_supported); x / gx rows 16-byte aligned, W dense; n_slices from
+ * allset_linear_narrow_slices(n); part_stride >= N * K + N; the caller sums the slices (allset_reduce_partials / _batched).
+ * csrc/narrow_linear.hip; allset_amd/dense.py _Linear. */
+int allset_linear_narrow_supported(int64_t N, int64_t K);
+int allset_linear_narrow_slices(int64_t n, int64_t* n_slices);
+int allset_linear_narrow_bwd(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t n, int64_t N, int64_t K,
+                             float* gx, int64_t ldgx, float* part, int64_t part_stride, int64_t n_slices, void* stream);
+
+/* ---- the FIRST Linear of a model: LayerNorm(raw features) -> Linear on an input that needs no gradient (reference models.py:473-476,
+ * layers.py:571-579 with InputNorm; raw widths 1433 / 3703 fit none of the resident-weight kernels) ----
+ * y = [x_hat | 1] [W * gamma | b + W beta]^T with x_hat the LayerNorm WITHOUT its affine part, and every parameter gradient from the
+ * one product M = gy^T [x_hat | 1]: gW = gamma * M[:, :d] + beta (x) M[:, d], gb = M[:, d], ggamma_j = sum_k W[k,j] M[k,j],
+ * gbeta_j = sum_k W[k,j] M[k,d] -- the [n, d] input gradient and the LayerNorm backward over it are never formed.  The two GEMMs
+ * are the caller's (library).  csrc/input_linear.hip; allset_amd/dense.py _InputNormLinear. */
+int64_t allset_input_linear_k(int64_t d);            /* leading dimension of [x_hat | 1 | 0...]: d + 1 rounded up to 16 elements */
+int allset_input_linear_supported(int64_t d);         /* 1 <= d <= 4096 */
+/* xh[r, :d] = LayerNorm_noaffine(dropout_{p_pre}(x[r, :])), xh[r, d] = 1, xh[r, d+1 : ldxh] = 0.  The dropout (counter hash of
+ * (seed, r * d + c), as everywhere in this library) is applied BEFORE the statistics: models.py:473 `F.dropout(x, p=0.2)`. */
+int allset_xhat_rows(const float* x, int64_t ldx, int64_t n, int64_t d, float eps, float p_pre, uint64_t seed,
+                     const uint64_t* seed_base, float* xh, int64_t ldxh, void* stream);
+/* Wp[k, :d] = W[k, :d] * gamma, Wp[k, d] = b[k] + sum_j W[k,j] beta[j] (b may be NULL), Wp[k, d+1 : ldwp] = 0. */
+int allset_fold_ln_linear(const float* W, int64_t ldw, const float* gamma, const float* beta, const float* b, int64_t O, int64_t d,
+                          float* Wp, int64_t ldwp, void* stream);
+/* M [O, ldm >= d + 1] = gy^T [x_hat | 1]  ->  gW [O, d], gb [O] (may be NULL), ggamma [d], gbeta [d] (closed forms above). */
+int allset_unfold_ln_linear(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma, const float* beta,
+                            int64_t O, int64_t d, float* gW, int64_t ldgw, float* gb, float* ggamma, float* gbeta, void* stream);
 int allset_fused_linear_bwd_all(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* W, const float* x,
                                 int64_t ldx, const float* stats, const float* gamma, const float* beta, int relu_in, float p_in,
                                 uint64_t seed_in, float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b,

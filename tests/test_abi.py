@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "allset_hip.h"\nint main(void){return ALLSET_ABI_VERSION == 9 ? 0 : 1;}\n')
+    src.write_text('#include "allset_hip.h"\nint main(void){return ALLSET_ABI_VERSION == 10 ? 0 : 1;}\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
                     str(tmp_path / "t")], check=True)
     subprocess.run([str(tmp_path / "t")], check=True)
@@ -47,7 +47,7 @@ def test_header_compiles_as_plain_c(tmp_path):
 def test_version_and_error_reporting():
     from allset_amd import _lib
     lib = _lib.load()
-    assert lib.allset_version() == _lib.ABI_VERSION == 9
+    assert lib.allset_version() == _lib.ABI_VERSION == 10
     rc = lib.allset_segreduce_fwd(99, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)
     assert rc == -1 and b"bad reduce" in lib.allset_last_error()
     rc = lib.allset_segreduce_fwd(0, 7, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)      # dtype must be F32 (0) or BF16 (1)

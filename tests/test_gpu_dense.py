@@ -1092,3 +1092,89 @@ def test_mlp_on_zero_rows_forward_and_backward(d, norm, device):
     assert x.grad.shape == (0, d)
     for p in m.parameters():
         assert p.grad is None or float(p.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,width", [(2708, 64), (900, 128), (70000, 64)])
+def test_deferred_param_grads_are_bitwise_the_eager_ones(n, width, device):
+    """Inside ``dense.deferred_param_grads()`` the fused backward kernels queue their partial sums and ONE batched launch reduces
+    them on exit (csrc/dense.hip reduce_partials_batched_kernel): same bits as the per-kernel reductions; an existing ``.grad`` is
+    accumulated into; partial buffers too large for the one-launch reduction (n = 70000) are reduced eagerly as before."""
+    from allset_amd import dense
+    from allset_amd.layers import MLP
+    torch.manual_seed(3)
+    mlp = MLP(width, width, width, 3, dropout=0.0, Normalization="ln", InputNorm=True).to(device)
+    x = torch.randn(n, width, device=device, requires_grad=True)
+    G = torch.randn(n, width, device=device)
+    (mlp(x) * G).sum().backward()
+    ref = {k: p.grad.clone() for k, p in mlp.named_parameters()}
+    gx = x.grad.clone()
+    mlp.zero_grad(set_to_none=True); x.grad = None
+    calls = []
+    real = dense.reduce_partials
+    dense.reduce_partials = lambda part: calls.append(1) or real(part)
+    try:
+        with dense.deferred_param_grads():
+            (mlp(x) * G).sum().backward()
+            if n < 10000:
+                assert all(p.grad is None for p in mlp.parameters()) and not calls
+        assert not dense._Deferred.active and not dense._Deferred.pending
+    finally:
+        dense.reduce_partials = real
+    assert torch.equal(x.grad, gx)
+    for k, p in mlp.named_parameters():
+        assert torch.equal(p.grad, ref[k]), k
+    with dense.deferred_param_grads():          # a second backward accumulates
+        (mlp(x) * G).sum().backward()
+    for k, p in mlp.named_parameters():
+        assert torch.equal(p.grad, ref[k] + ref[k]), k
+    with pytest.raises(RuntimeError):
+        with dense.deferred_param_grads():
+            raise RuntimeError("boom")
+    assert not dense._Deferred.active and not dense._Deferred.pending
+
+
+@pytest.mark.parametrize("n,N,K", [(2708, 7, 64), (3312, 6, 128), (1, 1, 4), (33, 16, 256), (100000, 3, 64), (31, 10, 12), (0, 7, 64)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_narrow_linear_backward_matches_float64(n, N, K, bias, device):
+    """``dense.linear`` with at most 16 outputs (the classifier head, reference models.py:449-456): the backward is ONE kernel
+    (csrc/narrow_linear.hip) -- input, weight and bias gradients against float64."""
+    from allset_amd import dense
+    torch.manual_seed(n + N + K)
+    x = torch.randn(n, K, device=device, requires_grad=True)
+    lin = torch.nn.Linear(K, N, bias=bias).to(device)
+    calls = []
+    real = dense.linear_narrow_bwd
+    dense.linear_narrow_bwd = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        y = dense.linear(x, lin.weight, lin.bias)
+        G = torch.randn_like(y)
+        (y * G).sum().backward()
+    finally:
+        dense.linear_narrow_bwd = real
+    assert calls
+    xd = x.detach().double().requires_grad_(True)
+    wd = lin.weight.detach().double().requires_grad_(True)
+    bd = lin.bias.detach().double().requires_grad_(True) if bias else None
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    (yd * G.double()).sum().backward()
+    tol = lambda e: dict(rtol=2e-5, atol=2e-5 * max(float(e.abs().max()) if e.numel() else 0.0, 1e-6))
+    torch.testing.assert_close(x.grad.double(), xd.grad, **tol(xd.grad))
+    torch.testing.assert_close(lin.weight.grad.double(), wd.grad, **tol(wd.grad))
+    if bias:
+        torch.testing.assert_close(lin.bias.grad.double(), bd.grad, **tol(bd.grad))
+
+
+def test_narrow_linear_backward_without_input_gradient_and_deferred(device):
+    from allset_amd import dense
+    torch.manual_seed(0)
+    x = torch.randn(500, 64, device=device)
+    lin = torch.nn.Linear(64, 7).to(device)
+    G = torch.randn(500, 7, device=device)
+    (dense.linear(x, lin.weight, lin.bias) * G).sum().backward()
+    ref = (lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin.zero_grad(set_to_none=True)
+    with dense.deferred_param_grads():
+        (dense.linear(x, lin.weight, lin.bias) * G).sum().backward()
+        assert lin.weight.grad is None and lin.bias.grad is None
+    assert torch.equal(lin.weight.grad, ref[0]) and torch.equal(lin.bias.grad, ref[1])
+    torch.testing.assert_close(ref[0], G.t() @ x, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,147 @@
+"""GPU: ``dense.input_norm_linear`` (csrc/input_linear.hip) -- [dropout ->] LayerNorm -> Linear on an input without gradient, as one
+GEMM against a folded weight, and all four parameter gradients out of ONE GEMM -- against the same chain in float64 torch
+(reference models.py:473-476, layers.py:571-573)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, keep, p, gamma, beta, W, b, eps):
+    x = x.double()
+    if keep is not None:
+        x = x * keep.double() / (1.0 - p)
+    y = F.layer_norm(x, (x.shape[1],), gamma, beta, eps)
+    return F.linear(y, W, b)
+
+
+@pytest.mark.parametrize("n,d,O", [(37, 1433, 64), (300, 3703, 128), (64, 5, 7), (1, 64, 64), (129, 4096, 16), (50, 513, 64), (200, 16, 64)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("bias", [True, False])
+def test_input_norm_linear_matches_float64(n, d, O, p, bias, device, monkeypatch):
+    from allset_amd import dense
+    torch.manual_seed(n * 7 + d)
+    x = (torch.randn(n, d) * torch.rand(n, 1) * 3 + torch.randn(n, 1)).to(device)
+    if d >= 1000:                                          # bag-of-words-like rows: mostly zeros
+        x = x * (torch.rand(n, d, device=device) < 0.02)
+    gamma = (1.0 + 0.3 * torch.randn(d)).to(device).requires_grad_(True)
+    beta = (0.2 * torch.randn(d)).to(device).requires_grad_(True)
+    W = (torch.randn(O, d) / d ** 0.5).to(device).requires_grad_(True)
+    b = torch.randn(O).to(device).requires_grad_(True) if bias else None
+    assert dense.input_norm_linear_supported(x, gamma, beta, W, b)
+    seeds = []
+    real_draw = dense._draw_seed
+    monkeypatch.setattr(dense, "_draw_seed", lambda: seeds.append(real_draw()) or seeds[-1])
+    y = dense.input_norm_linear(x, gamma, beta, W, b, 1e-5, p)
+    G = torch.randn_like(y)
+    (y * G).sum().backward()
+    keep = None
+    if p > 0.0:
+        assert len(seeds) == 1
+        keep = dense.dropout_scale((n, d), p, seeds[0], device) != 0
+        assert n * d < 2000 or abs(1.0 - float(keep.float().mean()) - p) < 0.05
+    else:
+        assert not seeds
+    prm = [t.detach().double().requires_grad_(True) if t is not None else None for t in (gamma, beta, W, b)]
+    yr = _ref(x, keep, p, *prm, 1e-5)
+    (yr * G.double()).sum().backward()
+    torch.testing.assert_close(y.double(), yr, rtol=2e-5, atol=2e-5 * float(yr.abs().max()))
+    for got, exp, what in zip((gamma, beta, W, b), prm, ("ggamma", "gbeta", "gW", "gb")):
+        if got is None:
+            continue
+        torch.testing.assert_close(got.grad.double(), exp.grad, rtol=5e-5, atol=5e-5 * float(exp.grad.abs().max()), msg=lambda m: f"{what}: {m}")
+
+
+def test_input_norm_linear_is_refused_for_an_input_that_needs_gradient(device):
+    from allset_amd import dense
+    x = torch.randn(8, 100, device=device, requires_grad=True)
+    g, b = torch.ones(100, device=device), torch.zeros(100, device=device)
+    W = torch.randn(16, 100, device=device)
+    assert not dense.input_norm_linear_supported(x, g, b, W, None)
+    with torch.no_grad():
+        assert dense.input_norm_linear_supported(x, g, b, W, None)
+    assert not dense.input_norm_linear_supported(x.detach(), None, None, W, None)
+    assert not dense.input_norm_linear_supported(torch.randn(8, 5000, device=device), torch.ones(5000, device=device),
+                                                 torch.zeros(5000, device=device), torch.randn(16, 5000, device=device), None)
+
+
+@pytest.mark.parametrize("layers", [1, 2, 3])
+@pytest.mark.parametrize("hidden,p", [(64, 0.0), (128, 0.5), (64, 0.5)])
+def test_mlp_routes_raw_features_through_input_norm_linear_and_matches_torch(layers, hidden, p, device, monkeypatch):
+    """``layers.MLP`` (InputNorm, LayerNorm) on raw features: eval-mode output and training-mode (dropout 0) gradients equal the plain
+    torch module's; an input that needs gradient keeps the general path and gives the same numbers."""
+    from allset_amd import dense
+    from allset_amd.layers import MLP
+    torch.manual_seed(5)
+    mlp = MLP(1433, hidden, hidden, layers, dropout=p, Normalization="ln", InputNorm=True).to(device)
+    x = torch.randn(500, 1433, device=device) * (torch.rand(500, 1433, device=device) < 0.05)
+    calls = []
+    real = dense.input_norm_linear
+    monkeypatch.setattr(dense, "input_norm_linear", lambda *a, **k: calls.append(1) or real(*a, **k))
+    ctr = [0]
+
+    def draw():                                           # the same seed sequence for both passes (same sites, same order)
+        ctr[0] += 1
+        return 1000003 * ctr[0]
+    monkeypatch.setattr(dense, "_draw_seed", draw)
+    mlp.train()
+    y = mlp(x, _post=p)
+    assert calls
+    G = torch.randn_like(y)
+    (y * G).sum().backward()
+    got = {k: p.grad.clone() for k, p in mlp.named_parameters()}
+    mlp.zero_grad()
+    calls.clear()
+    xg = x.clone().requires_grad_(True)
+    ctr[0] = 0
+    y2 = mlp(xg, _post=p)
+    assert not calls
+    (y2 * G).sum().backward()
+    torch.testing.assert_close(y, y2, rtol=1e-4, atol=1e-4 * float(y2.abs().max()))
+    for k, p in mlp.named_parameters():
+        torch.testing.assert_close(got[k], p.grad, rtol=2e-4, atol=2e-4 * float(p.grad.abs().max()), msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("over", [{}, dict(MLP_num_layers=3, MLP_hidden=128), dict(All_num_layers=2), dict(MLP_num_layers=1)],
+                         ids=lambda o: "-".join(f"{k}{v}" for k, v in o.items()) or "stock")
+def test_leaf_feature_path_equals_the_general_path_under_the_same_masks(over, device, monkeypatch):
+    """Cora-shaped ``SetGNN`` in training mode, once with ``data.x`` a plain tensor (``dense.input_norm_linear``: hashed input
+    dropout, folded weight, one-GEMM backward) and once with ``data.x`` requiring gradient (the general path), under the SAME dropout
+    masks: a deterministic seed sequence, and the general path's torch input dropout replaced by the hash dropout of the same seed.
+    Logits and every parameter gradient agree to 1e-4 of their maximum (measured: 1e-5)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from types import SimpleNamespace
+    import cases
+    from allset_amd import SetGNN, dense, models
+    ctr = [0]
+
+    def draw():
+        ctr[0] += 1
+        return 1000003 * ctr[0]
+    monkeypatch.setattr(dense, "_draw_seed", draw)
+    fake_F = SimpleNamespace(**{k: getattr(F, k) for k in dir(F) if not k.startswith("__")})
+    fake_F.dropout = lambda x, p=0.5, training=True: x if (not training or p == 0.0) else x * dense.dropout_scale(x.shape, p, draw(), x.device)
+    monkeypatch.setattr(models, "F", fake_F)
+    case = cases.build_case("cora_ds_add")
+    args = SimpleNamespace(**{**vars(case["args"]), **over})
+    torch.manual_seed(case["seed"])
+    model = SetGNN(args)
+    model.reset_parameters()
+    model.train().to(device)
+    res = []
+    for leaf in (True, False):
+        model.zero_grad(set_to_none=True)
+        ctr[0] = 0
+        x = torch.from_numpy(case["x"]).to(device).requires_grad_(not leaf)
+        data = SimpleNamespace(x=x, edge_index=torch.from_numpy(case["edge_index"]).clone().to(device), norm=torch.from_numpy(case["norm"]).to(device))
+        out = model(data)
+        G = torch.from_numpy(cases.cotangent("cora_ds_add", out.shape)).to(device)
+        (out * G).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, ctr[0]))
+    (oa, ga, ca), (ob, gb, cb) = res
+    assert ca == cb and set(ga) == set(gb)
+    torch.testing.assert_close(oa, ob, rtol=0, atol=1e-4 * float(ob.abs().max()))
+    for k in ga:
+        torch.testing.assert_close(ga[k], gb[k], rtol=0, atol=1e-4 * float(gb[k].abs().max()) + 1e-12, msg=lambda m: f"{k}: {m}")

@@ -9,7 +9,7 @@ from types import SimpleNamespace
 import cases
 from allset_amd import SetGNN
 from allset_amd.graphs import GraphedTrainStep
-REPLAYS = 200
+REPLAYS = int(os.environ.get("REPLAYS", "200"))
 name = sys.argv[1] if len(sys.argv) > 1 else "cora_ds_add"
 dev = torch.device("cuda:0")
 case = cases.build_case(name)
