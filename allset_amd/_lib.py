@@ -85,6 +85,8 @@ SIGNATURES = {
     "allset_reduce_partials_batch_max": [],
     "allset_reduce_partials_batchable": [c_int64, c_int64],
     "allset_reduce_partials_batched": [_P, _P, _P, _P, _P, c_int64, _P],
+    "allset_reduce_partials_batched_ex": [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
+    "allset_reduce_partials_batch_max_counters": [],
     "allset_linear_narrow_supported": [c_int64, c_int64],
     "allset_linear_narrow_slices": [c_int64, POINTER(c_int64)],
     "allset_linear_narrow_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P],
@@ -136,6 +138,7 @@ SIGNATURES = {
     "allset_split_metrics": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_nll_partials": [c_int64, POINTER(c_int64)],
     "allset_nll_logsoftmax_fwd": [_P, c_int64, _P, _P, c_float, _P, c_int64, c_int64, c_int64, _P],
+    "allset_nll_logsoftmax_fwd_total": [_P, c_int64, _P, _P, c_float, _P, c_int64, _P, _P, c_int64, c_int64, _P],
     "allset_nll_logsoftmax_bwd": [_P, c_int64, _P, _P, c_float, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_linear_bf16_supported": [c_int64, c_int64],
     "allset_linear_bf16_fwd": [_P, c_int64, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],

@@ -501,16 +501,27 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __
 // table names up to kRedBatchMax partial buffers; every workgroup finds its buffer by a scan of the table's block offsets and then
 // does exactly what the one-launch form of the kernel above does for it -- the sums are bit-identical to separate calls.
 constexpr int kRedBatchMax = 48;
+constexpr int kRedBatchMaxCounters = 64;
 struct RedBatchTable {
   const float* part[kRedBatchMax];
   float* out[kRedBatchMax];
   int32_t P[kRedBatchMax], stride[kRedBatchMax], M[kRedBatchMax];
   int32_t first_block[kRedBatchMax + 1];
   int32_t count;
+  // counters advanced by one extra workgroup of the same launch (a training step's dropout-seed counter and its optimizer's step
+  // counters: each is one more ~5 us launch in the step's dependent chain otherwise)
+  int64_t* inc_i64;
+  float* inc_f32[kRedBatchMaxCounters];
+  int32_t n_inc_f32;
 };
 __global__ __launch_bounds__(kBlock) void reduce_partials_batched_kernel(RedBatchTable tb) {
   __shared__ float4 red[kRedSplit][kBlock / kRedSplit];
   const int b = blockIdx.x;
+  if (b >= tb.first_block[tb.count]) {                       // the counters' workgroup
+    if (static_cast<int>(threadIdx.x) < tb.n_inc_f32) tb.inc_f32[threadIdx.x][0] += 1.f;
+    if (threadIdx.x == 0 && tb.inc_i64 != nullptr) tb.inc_i64[0] += 1;
+    return;
+  }
   int t = 0;
   while (t + 1 < tb.count && tb.first_block[t + 1] <= b) ++t;
   const int P = tb.P[t];
@@ -1795,12 +1806,15 @@ extern "C" int allset_reduce_partials_batchable(int64_t P, int64_t M) {
   return (P >= 1 && M >= 4 && M % 4 == 0 && M < INT32_MAX && reduce_one_launch(P, M)) ? 1 : 0;
 }
 
-extern "C" int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
-                                              float* const* outs, int64_t count, void* stream) {
-  clear_error();
+static int reduce_partials_batched_impl(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                        float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32,
+                                        void* stream) {
   ALLSET_REQUIRE(count >= 0 && count <= kRedBatchMax, "reduce_partials_batched: at most %d buffers per call", kRedBatchMax);
-  if (count == 0) return ALLSET_OK;
-  ALLSET_REQUIRE(parts && P && row_stride && M && outs, "reduce_partials_batched: null pointer");
+  ALLSET_REQUIRE(n_inc_f32 >= 0 && n_inc_f32 <= kRedBatchMaxCounters && (n_inc_f32 == 0 || inc_f32 != nullptr),
+                 "reduce_partials_batched: at most %d float counters per call", kRedBatchMaxCounters);
+  const bool bump = inc_i64 != nullptr || n_inc_f32 > 0;
+  if (count == 0 && !bump) return ALLSET_OK;
+  ALLSET_REQUIRE(count == 0 || (parts && P && row_stride && M && outs), "reduce_partials_batched: null pointer");
   RedBatchTable tb;
   int64_t blocks = 0;
   const int64_t per_block = kBlock / kRedSplit;
@@ -1816,10 +1830,31 @@ extern "C" int allset_reduce_partials_batched(const float* const* parts, const i
   }
   tb.first_block[count] = static_cast<int32_t>(blocks);
   tb.count = static_cast<int32_t>(count);
-  reduce_partials_batched_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, static_cast<hipStream_t>(stream)>>>(tb);
+  tb.inc_i64 = inc_i64;
+  tb.n_inc_f32 = static_cast<int32_t>(n_inc_f32);
+  for (int64_t k = 0; k < n_inc_f32; ++k) {
+    ALLSET_REQUIRE(inc_f32[k] != nullptr, "reduce_partials_batched: null counter %lld", static_cast<long long>(k));
+    tb.inc_f32[k] = inc_f32[k];
+  }
+  reduce_partials_batched_kernel<<<static_cast<unsigned>(blocks + (bump ? 1 : 0)), kBlock, 0, static_cast<hipStream_t>(stream)>>>(tb);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
+
+extern "C" int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                              float* const* outs, int64_t count, void* stream) {
+  clear_error();
+  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, count, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int allset_reduce_partials_batched_ex(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                                 float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32,
+                                                 int64_t n_inc_f32, void* stream) {
+  clear_error();
+  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, count, inc_i64, inc_f32, n_inc_f32, stream);
+}
+
+extern "C" int allset_reduce_partials_batch_max_counters(void) { return kRedBatchMaxCounters; }
 
 extern "C" int allset_ln_res_supported(int64_t d) { return (d >= 4 && d <= 256 && d % 4 == 0) ? 1 : 0; }
 

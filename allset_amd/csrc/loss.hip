@@ -21,7 +21,8 @@ __device__ __forceinline__ float row_lse(const float* __restrict__ row, int C) {
 
 __global__ __launch_bounds__(kLossBlock) void nll_fwd_kernel(const float* __restrict__ logits, int64_t ld,
                                                             const int64_t* __restrict__ y, const float* __restrict__ w,
-                                                            float inv_count, float* __restrict__ partials, int64_t n, int C) {
+                                                            float inv_count, float* __restrict__ partials, int64_t n, int C,
+                                                            unsigned* __restrict__ ticket, float* __restrict__ total) {
   __shared__ float red[kLossBlock / kWave];
   float acc = 0.f;
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * kLossBlock + threadIdx.x; r < n; r += static_cast<int64_t>(gridDim.x) * kLossBlock) {
@@ -43,6 +44,19 @@ __global__ __launch_bounds__(kLossBlock) void nll_fwd_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < kLossBlock / kWave; ++k) s += red[k];
     partials[blockIdx.x] = s * inv_count;
+    if (ticket != nullptr) {
+      // the LAST workgroup to arrive adds the partials in index order (the same sum whichever workgroup that is) and re-arms the
+      // ticket: the loss leaves this launch as one number, not as a buffer for a reduction launch of its own
+      __threadfence();
+      const unsigned prev = atomicAdd(ticket, 1u);
+      if (prev == gridDim.x - 1) {
+        __threadfence();
+        float t = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) t += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        total[0] = t;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -132,7 +146,22 @@ extern "C" int allset_nll_logsoftmax_fwd(const float* logits, int64_t ld, const 
   ALLSET_REQUIRE(n >= 0 && C >= 1 && C < INT32_MAX && ld >= C, "nll_logsoftmax_fwd: bad size");
   ALLSET_REQUIRE(partials != nullptr && n_partials == loss_grid(n), "nll_logsoftmax_fwd: partials must hold allset_nll_partials(n) floats");
   ALLSET_REQUIRE(n == 0 || (logits && y), "nll_logsoftmax_fwd: null pointer");
-  nll_fwd_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, w, inv_count, partials, n, static_cast<int>(C));
+  nll_fwd_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, w, inv_count, partials, n, static_cast<int>(C),
+                                                                                     nullptr, nullptr);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_nll_logsoftmax_fwd_total(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
+                                               float* partials, int64_t n_partials, uint32_t* ticket, float* total, int64_t n,
+                                               int64_t C, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && C >= 1 && C < INT32_MAX && ld >= C, "nll_logsoftmax_fwd_total: bad size");
+  ALLSET_REQUIRE(partials != nullptr && n_partials == loss_grid(n), "nll_logsoftmax_fwd_total: partials must hold allset_nll_partials(n) floats");
+  ALLSET_REQUIRE(ticket != nullptr && total != nullptr, "nll_logsoftmax_fwd_total: ticket (a zeroed uint32 the launch re-arms) and total are required");
+  ALLSET_REQUIRE(n == 0 || (logits && y), "nll_logsoftmax_fwd_total: null pointer");
+  nll_fwd_kernel<<<loss_grid(n), kLossBlock, 0, static_cast<hipStream_t>(stream)>>>(logits, ld, y, w, inv_count, partials, n, static_cast<int>(C),
+                                                                                     ticket, total);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
 // stream: the rows' rowptr entries arrive in one load (lane i holds rowptr[r0+i]), the column ids of consecutive rows
 // are contiguous in the CSR and arrive LPR at a time, the gathers of a batch are in flight together regardless of row
 // boundaries, and a row is flushed (one coalesced store) whenever the stream crosses its end.  Slots never combine.
+constexpr int kFlatMinRows = 16384;   // AUTO: below this many target rows the one-group-per-row kernel (see allset_segreduce_fwd)
 constexpr int kFlatRows = 7;       // rows per slot; kFlatRows + 1 rowptr entries must fit in the smallest slot (8 lanes)
 
 template <typename T, int VEC, int LPR, bool WEIGHTED>
@@ -506,7 +507,9 @@ static int segreduce_impl(int reduce, int dtype, int variant, int64_t nnz_hint, 
   // variant: 0 = AUTO (short-row kernel when the caller's nnz says the mean degree is small), 1 = one wave per row,
   // 2 = short-row kernel.  The short-row kernel needs sum/mean, 16-byte packets and d <= 64 packets.
   const bool flat_ok = !ext && wide_ok && d <= 64 * wide;
-  const bool use_flat = flat_ok && (variant == 2 || (variant == 0 && nnz_hint >= 0 &&
+  // (AUTO at dataset scale -- every row gets its own lane group on a machine this size anyway: the one-group-per-row kernel is one
+  //  dependent round trip shorter than a slot walking seven rows as a stream, and the step there is a chain of such latencies)
+  const bool use_flat = flat_ok && (variant == 2 || (variant == 0 && nnz_hint >= 0 && n_t > kFlatMinRows &&
                                                      static_cast<double>(nnz_hint) < kFlatMaxMeanDegree * static_cast<double>(n_t)));
   if (variant == 2 && !flat_ok) {
     set_error("segreduce_fwd: the short-row variant needs sum/mean, 16-byte aligned rows and d <= %d", 64 * wide);

@@ -116,45 +116,71 @@ def _defer(part: Tensor, sections) -> None:
     _Deferred.pending.append((part, part.shape[1], [(p, off, tuple(shape)) for p, off, shape in sections if p is not None]))
 
 
-def flush_param_grads() -> None:
+def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
+    """Reduce everything queued with one batched launch and assign / accumulate the parameters' ``.grad``.  ``bump_i64`` (a
+    1-element int64 device tensor) and ``bump_f32`` (a list of 0-dim float32 device tensors, or a callable returning one -- called
+    after the gradients are in place) are advanced by one in the SAME launch: a training step's dropout-seed counter and its
+    optimizer's step counters (``graphs.GraphedTrainStep``)."""
     pend, _Deferred.pending = _Deferred.pending, []
-    if not pend:
-        return
     lib = _lib.load()
-    cap = int(lib.allset_reduce_partials_batch_max())
-    dev = pend[0][0].device
-    out = torch.empty(sum(M for _, M, _ in pend), dtype=torch.float32, device=dev)
     import ctypes
+    dev = pend[0][0].device if pend else (bump_i64.device if bump_i64 is not None else None)
+    out = None
+    later = []
     base, bases = 0, []
     for part, M, _ in pend:
         bases.append(base)
         base += M
-    for k0 in range(0, len(pend), cap):
+    if pend:
+        out = torch.empty(base, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for (part, M, sections), b in zip(pend, bases):
+                for p, off, shape in sections:
+                    numel = 1
+                    for v in shape:
+                        numel *= v
+                    g = out[b + off:b + off + numel].view(shape)
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        later.append((p, g))          # accumulate: after the launch below has produced the sum
+    counters = list(bump_f32() if callable(bump_f32) else (bump_f32 or []))
+    if dev is None and counters:
+        dev = counters[0].device
+    if dev is None:
+        return
+    cap = int(lib.allset_reduce_partials_batch_max())
+    ccap = int(lib.allset_reduce_partials_batch_max_counters())
+    if len(counters) > ccap:                  # (more optimizer counters than one launch takes: the rest the usual way)
+        torch._foreach_add_(counters[ccap:], 1.0)
+        counters = counters[:ccap]
+    first = True
+    for k0 in range(0, max(len(pend), 1), cap):
         chunk = pend[k0:k0 + cap]
         n = len(chunk)
-        parts = (ctypes.c_void_p * n)(*[part.data_ptr() for part, _, _ in chunk])
-        outs = (ctypes.c_void_p * n)(*[out.data_ptr() + 4 * b for b in bases[k0:k0 + n]])
-        Ps = (ctypes.c_int64 * n)(*[part.shape[0] for part, _, _ in chunk])
-        strides = (ctypes.c_int64 * n)(*[part.stride(0) for part, _, _ in chunk])
-        Ms = (ctypes.c_int64 * n)(*[M for _, M, _ in chunk])
+        arr = lambda vals: (ctypes.c_void_p * max(len(vals), 1))(*vals)
+        i64 = lambda vals: (ctypes.c_int64 * max(len(vals), 1))(*vals)
+        cs = counters if first else []
         with on_device(dev):
-            check(lib.allset_reduce_partials_batched(parts, Ps, strides, Ms, outs, n, stream_of(dev)), "allset_reduce_partials_batched")
+            check(lib.allset_reduce_partials_batched_ex(
+                arr([part.data_ptr() for part, _, _ in chunk]), i64([part.shape[0] for part, _, _ in chunk]),
+                i64([part.stride(0) for part, _, _ in chunk]), i64([M for _, M, _ in chunk]),
+                arr([out.data_ptr() + 4 * b for b in bases[k0:k0 + n]]) if n else arr([]), n,
+                ptr(bump_i64) if first else None, arr([c.data_ptr() for c in cs]), len(cs), stream_of(dev)),
+                "allset_reduce_partials_batched_ex")
+        first = False
     with torch.no_grad():
-        for (part, M, sections), b in zip(pend, bases):
-            for p, off, shape in sections:
-                numel = 1
-                for v in shape:
-                    numel *= v
-                g = out[b + off:b + off + numel].view(shape)
-                if p.grad is None:
-                    p.grad = g
-                else:
-                    p.grad.add_(g)
+        for p, g in later:
+            p.grad.add_(g)
 
 
 class deferred_param_grads:
     """Context manager around ``loss.backward()``: parameter gradients of the fused backward kernels are reduced by ONE batched
-    launch on exit (see above).  Not re-entrant."""
+    launch on exit (see above).  ``bump_i64`` / ``bump_f32``: counters advanced by one in that launch (:func:`flush_param_grads`).
+    Not re-entrant."""
+
+    def __init__(self, bump_i64: Optional[Tensor] = None, bump_f32=None):
+        self.bump_i64, self.bump_f32 = bump_i64, bump_f32
 
     def __enter__(self):
         if _Deferred.active:
@@ -165,7 +191,7 @@ class deferred_param_grads:
     def __exit__(self, exc_type, exc, tb):
         _Deferred.active = False
         if exc_type is None:
-            flush_param_grads()
+            flush_param_grads(self.bump_i64, self.bump_f32)
         else:
             _Deferred.pending = []
         return False

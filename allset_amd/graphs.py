@@ -8,9 +8,9 @@ same loop -- same arithmetic, one graph launch per epoch.
 What makes capture possible here:
   * every kernel of the path is stream-ordered with no host read-back once the incidence is built
     (``models.SetGNN._incidences`` caches the CSR pair on the first call, which must happen BEFORE capture);
-  * dropout masks come from a device-resident counter (``dense.device_seed_counter``): the graph bumps the counter
-    first, the kernels read it when they start, so every replay draws fresh masks although the host-side seeds were
-    frozen at capture;
+  * dropout masks come from a device-resident counter (``dense.device_seed_counter``): the kernels read it when they
+    start and the graph advances it once per step (in the launch that reduces the parameter gradients), so every replay
+    draws fresh masks although the host-side seeds were frozen at capture;
   * the optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``; add ``fused=True``: the unfused
     capturable Adam launches ~2 tiny kernels per parameter for its bias corrections, 20 % of a Cora-sized step).
 
@@ -24,6 +24,7 @@ from typing import Callable, Optional
 import torch
 
 from . import dense
+from .optim import FusedAdam
 from ._lib import AllSetHipError
 
 Tensor = torch.Tensor
@@ -112,13 +113,21 @@ class GraphedTrainStep:
         self.counter.fill_(int(torch.empty((), dtype=torch.int64).random_().item()) & 0x3FFFFFFFFFFFFFFF)
         model.train(train_mode)           # False: a dropout-free (deterministic) step, e.g. for tests / fine-tuning
 
+        one = self._one = torch.ones((), dtype=torch.float32, device=dev)     # (an attribute: the graph reads this address at every replay)
+
+        fused = isinstance(optimizer, FusedAdam)
+
         def one_step():
-            self.counter.add_(1)
             optimizer.zero_grad(set_to_none=True)
             loss = loss_fn(model(data))
-            with dense.deferred_param_grads():       # one batched reduction of the parameter-gradient partials (dense.py)
-                loss.backward()
-            optimizer.step()
+            # ONE launch reduces every parameter-gradient partial of the backward pass and advances the step's counters (the dropout
+            # seed counter; FusedAdam's step counters): dense.deferred_param_grads
+            with dense.deferred_param_grads(bump_i64=self.counter, bump_f32=optimizer.step_counters if fused else None):
+                loss.backward(one if (loss.dim() == 0 and loss.dtype == one.dtype) else None)      # (no ones_like launch per step)
+            if fused:
+                optimizer.step(counters_advanced=True)
+            else:
+                optimizer.step()
             return loss
 
         params = [p for grp in optimizer.param_groups for p in grp["params"]]

@@ -27,6 +27,18 @@ def split_mask(idx: Tensor, n: int) -> Tensor:
     return w
 
 
+_TICKETS = {}      # device index -> zeroed uint32 the forward kernel counts its workgroups on (and re-arms)
+
+
+def _ticket(dev: torch.device) -> Tensor:
+    """One per device: two loss forwards running CONCURRENTLY on different streams of one device would share it (not a pattern of
+    this package: the loss is one node of a training step's dependent chain)."""
+    t = _TICKETS.get(dev.index)
+    if t is None:
+        t = _TICKETS[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)      # (zeroed on the stream that launches next)
+    return t
+
+
 class _NllLogSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, y, w, inv_count):
@@ -35,13 +47,14 @@ class _NllLogSoftmax(torch.autograd.Function):
         lib = _lib.load()
         npart = c_int64(0)
         check(lib.allset_nll_partials(n, byref(npart)), "allset_nll_partials")
-        partials = torch.empty(npart.value, dtype=torch.float32, device=dev)
+        partials = torch.empty(npart.value + 1, dtype=torch.float32, device=dev)      # [workgroup sums | their total]
         with on_device(dev):
-            check(lib.allset_nll_logsoftmax_fwd(ptr(logits), logits.stride(0), ptr(y), ptr(w), inv_count, ptr(partials), npart.value,
-                                                n, C, stream_of(dev)), "allset_nll_logsoftmax_fwd")
+            check(lib.allset_nll_logsoftmax_fwd_total(ptr(logits), logits.stride(0), ptr(y), ptr(w), inv_count, ptr(partials), npart.value,
+                                                      ptr(_ticket(dev)), ptr(partials[npart.value:]), n, C, stream_of(dev)),
+                  "allset_nll_logsoftmax_fwd_total")
         ctx.save_for_backward(logits, y, w)
         ctx.inv_count = inv_count
-        return partials.sum() if npart.value > 1 else partials[0]
+        return partials[npart.value]
 
     @staticmethod
     @once_differentiable

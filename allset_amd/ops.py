@@ -134,6 +134,10 @@ class CSR(NamedTuple):
         profiles/r01_kernel_bench*.txt: the short-row kernels win below a mean degree of ~6 (segreduce, pma_fwd) and
         up to ~24 for pma_bwd_src, as long as no row is long enough to serialise a half-wave."""
         rows = max(int(self.n_rows if n_rows is None else n_rows), 1)
+        if kind == "segreduce" and rows <= 16384:
+            # dataset scale: every row gets its own lane group on a machine this size; the one-group-per-row kernel is one dependent
+            # round trip shorter than a slot walking seven rows as a stream (the same rule as the library's AUTO, kFlatMinRows)
+            return 1
         mean = self.col.numel() / rows
         limit = 24.0 if kind == "pma_bwd_src" else 6.0
         return 2 if (mean < limit and self.max_deg <= 512) else 1

@@ -48,8 +48,20 @@ class FusedAdam(torch.optim.Optimizer):
                 st[k] = st[k].to(p.device)
         return st
 
+    def step_counters(self):
+        """The device step counters ``step()`` will advance: one per parameter that has a gradient and takes the fused kernel.  A
+        caller that advances them itself (``graphs.GraphedTrainStep``: in the launch that reduces the gradients) then calls
+        ``step(counters_advanced=True)``."""
+        out = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if (p.grad is not None and p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and p.is_contiguous()
+                        and p.grad.is_contiguous() and p.grad.dtype == p.dtype and not p.grad.is_sparse):
+                    out.append(self._state(p)["step"])
+        return out
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, counters_advanced: bool = False):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -73,7 +85,8 @@ class FusedAdam(torch.optim.Optimizer):
             if not fast:
                 continue
             sts = [self._state(p) for p in fast]
-            torch._foreach_add_([s["step"] for s in sts], 1.0)
+            if not counters_advanced:
+                torch._foreach_add_([s["step"] for s in sts], 1.0)
             by_dev = {}
             for p, s in zip(fast, sts):
                 by_dev.setdefault((p.device, p.dtype), []).append((p, s))

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 10  /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batchable / _batched, allset_linear_narrow_supported / _slices / _bwd) */
+#define ALLSET_ABI_VERSION 10  /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -269,6 +269,12 @@ int allset_adam_step_dtype(int dtype, void* const* params, const void* const* gr
 int allset_nll_partials(int64_t n, int64_t* n_partials);
 int allset_nll_logsoftmax_fwd(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
                               float* partials, int64_t n_partials, int64_t n, int64_t C, void* stream);
+/* The same, with the sum of the partials finished inside the launch (ABI 10): the last workgroup to arrive -- counted on `ticket`, a
+ * uint32 the caller zeroes ONCE and the launch re-arms (one per stream that may run this concurrently) -- adds partials[0 ..
+ * n_partials) in index order into total[0].  Deterministic; one launch instead of kernel + reduction at dataset scale. */
+int allset_nll_logsoftmax_fwd_total(const float* logits, int64_t ld, const int64_t* y, const float* w, float inv_count,
+                                    float* partials, int64_t n_partials, uint32_t* ticket, float* total, int64_t n, int64_t C,
+                                    void* stream);
 /* PMA's folded attention logits (reference layers.py:126-131 forms K = lin_K(x) and contracts it with att_r; alpha is linear in
  * x, so the layer multiplies x by the folded weight instead):  w[h, k] = sum_c W_K[h C + c, k] att_r[h, c]  (f32 [H, K]),
  * b[h] = sum_c b_K[h C + c] att_r[h, c] (bk may be NULL: b = 0), and the backward of that fold. */
@@ -308,6 +314,13 @@ int allset_reduce_partials_batch_max(void);
 int allset_reduce_partials_batchable(int64_t P, int64_t M);
 int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
                                    float* const* outs, int64_t count, void* stream);
+/* ... and, by one more workgroup of the same launch, *inc_i64 += 1 (may be NULL) and *inc_f32[k] += 1.0f for k < n_inc_f32 <=
+ * allset_reduce_partials_batch_max_counters(): the counters a training step advances once (its dropout-seed counter -- `seed_base`
+ * of the dropout-bearing entries -- and the optimizer's step counters, allset_adam_step's `steps`).  count may be 0. */
+int allset_reduce_partials_batch_max_counters(void);
+int allset_reduce_partials_batched_ex(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                      float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32,
+                                      void* stream);
 
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;

@@ -878,6 +878,14 @@ def test_fused_adam_in_a_captured_training_step(device):
         assert torch.equal(l1, l2.detach())
     for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(a, b), k
+    # the captured step advances Adam's step counters and the dropout-seed counter in its gradient-reduction launch
+    # (dense.deferred_param_grads): four replays -> 4 (parameters that receive no gradient keep no state, as in torch)
+    steps = [float(st["step"]) for st in o1.state.values()]
+    assert steps and all(v == 4.0 for v in steps), steps
+    assert [float(st["step"]) for st in o2.state.values()] == steps
+    c0 = int(gstep.counter.item())
+    gstep()
+    assert int(gstep.counter.item()) == c0 + 1
 
 
 @pytest.mark.parametrize("n,I,O", [(20000, 64, 10), (9000, 1433, 64), (777, 1433, 7), (10000, 128, 2), (8192, 37, 128)])

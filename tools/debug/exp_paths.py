@@ -16,7 +16,7 @@ def hash_dropout(x, p=0.5, training=True):
     return x * dense.dropout_scale(x.shape, p, draw(), x.device)
 models.F = SimpleNamespace(**{k: getattr(models.F, k) for k in dir(models.F) if not k.startswith("__")})
 models.F.dropout = hash_dropout
-for over in (dict(MLP_num_layers=3, MLP_hidden=128), dict(All_num_layers=2), {}):
+for over in (dict(MLP_num_layers=3, MLP_hidden=128), dict(MLP_num_layers=3), dict(MLP_hidden=128)):
     case = cases.build_case("cora_ds_add")
     args = SimpleNamespace(**{**vars(case["args"]), **over})
     for attempt in range(3):
@@ -35,3 +35,6 @@ for over in (dict(MLP_num_layers=3, MLP_hidden=128), dict(All_num_layers=2), {})
         (oa, ga, ca), (ob, gb, cb) = res
         worst = max((float((ga[k] - gb[k]).abs().max() / gb[k].abs().max().clamp(min=1e-12)), k) for k in ga)
         print(over, attempt, "draws", ca, cb, "logits", float((oa - ob).abs().max() / ob.abs().max()), "worst grad rel-to-max", worst)
+        if worst[0] > 1e-4:
+            for k in ga:
+                print("     ", k, float((ga[k] - gb[k]).abs().max() / gb[k].abs().max().clamp(min=1e-12)))
