@@ -87,6 +87,12 @@ SIGNATURES = {
     "allset_reduce_partials_batched": [_P, _P, _P, _P, _P, c_int64, _P],
     "allset_reduce_partials_batched_ex": [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
     "allset_reduce_partials_batch_max_counters": [],
+    "allset_sparse_ln_linear_supported": [c_int64],
+    "allset_sparse_ln_linear_slices": [],
+    "allset_fold_ln_linear_t": [_P, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P],
+    "allset_sparse_ln_linear_fwd": [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_float, c_float, c_uint64, _P, _P, c_int64, _P, _P, _P],
+    "allset_sparse_ln_linear_bwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P],
+    "allset_unfold_ln_linear_ex": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, _P],
     "allset_linear_narrow_supported": [c_int64, c_int64],
     "allset_linear_narrow_slices": [c_int64, POINTER(c_int64)],
     "allset_linear_narrow_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P],

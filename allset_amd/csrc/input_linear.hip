@@ -97,19 +97,41 @@ __global__ __launch_bounds__(kBlock) void fold_ln_kernel(const float* __restrict
 __global__ __launch_bounds__(kBlock) void unfold_ln_kernel(const float* __restrict__ M, int64_t ldm, const float* __restrict__ W,
                                                            int64_t ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            int O, int d, float* __restrict__ gW, int64_t ldgw, float* __restrict__ gb,
-                                                           float* __restrict__ ggamma, float* __restrict__ gbeta) {
+                                                           float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                           const float* __restrict__ su_part, int n_slices) {
   __shared__ float red[2][3][kWave];
+  __shared__ float s_s[kBlock], u_s[kBlock];                 // su_part form (sparse_input.hip): O <= 256
   const int t = threadIdx.x, jl = t & 63, kq = t >> 6;
   const int j = blockIdx.x * kWave + jl;
-  if (gb && kq == 0 && j < O) gb[j] = M[static_cast<int64_t>(j) * ldm + d];
+  if (su_part != nullptr) {      // M holds gy^T v-hat WITHOUT the rows' shared offset: M_true = M - u, ones column = s (slice sums)
+    if (t < O) {
+      float s = 0.f, u = 0.f;
+      for (int s0 = 0; s0 < n_slices; s0 += 8) {             // eight slices' loads in flight, summed in slice order
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int sl = min(s0 + i, n_slices - 1);
+          a[i] = su_part[(2 * sl) * O + t]; b[i] = su_part[(2 * sl + 1) * O + t];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (s0 + i < n_slices) { s += a[i]; u += b[i]; }
+      }
+      s_s[t] = s; u_s[t] = u;
+    }
+    __syncthreads();
+    if (gb && kq == 0 && j < O) gb[j] = s_s[j];
+  } else if (gb && kq == 0 && j < O) {
+    gb[j] = M[static_cast<int64_t>(j) * ldm + d];
+  }
   const bool live = j < d;
   const float g = live ? gamma[j] : 0.f, bt = live ? beta[j] : 0.f;
   float gg = 0.f, gbt = 0.f;
   if (live) {
 #pragma unroll 8
     for (int k = kq; k < O; k += 4) {
-      const float m = M[static_cast<int64_t>(k) * ldm + j];
-      const float sk = M[static_cast<int64_t>(k) * ldm + d];        // (uniform across the wave)
+      const float m = M[static_cast<int64_t>(k) * ldm + j] - (su_part ? u_s[k] : 0.f);
+      const float sk = su_part ? s_s[k] : M[static_cast<int64_t>(k) * ldm + d];        // (uniform across the wave)
       const float w = W[static_cast<int64_t>(k) * ldw + j];
       gW[static_cast<int64_t>(k) * ldgw + j] = fmaf(g, m, bt * sk);
       gg = fmaf(w, m, gg);
@@ -169,16 +191,35 @@ extern "C" int allset_fold_ln_linear(const float* W, int64_t ldw, const float* g
   return ALLSET_OK;
 }
 
+static int unfold_impl(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma, const float* beta, int64_t O,
+                       int64_t d, float* gW, int64_t ldgw, float* gb, float* ggamma, float* gbeta, const float* su_part,
+                       int64_t n_slices, void* stream);
+
 extern "C" int allset_unfold_ln_linear(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma,
                                        const float* beta, int64_t O, int64_t d, float* gW, int64_t ldgw, float* gb,
                                        float* ggamma, float* gbeta, void* stream) {
   clear_error();
+  return unfold_impl(M, ldm, W, ldw, gamma, beta, O, d, gW, ldgw, gb, ggamma, gbeta, nullptr, 0, stream);
+}
+
+extern "C" int allset_unfold_ln_linear_ex(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma,
+                                          const float* beta, int64_t O, int64_t d, float* gW, int64_t ldgw, float* gb,
+                                          float* ggamma, float* gbeta, const float* su_part, int64_t n_slices, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(su_part == nullptr || (O <= kBlock && n_slices >= 1 && n_slices < 4096), "unfold_ln_linear_ex: su_part needs O <= 256 and n_slices >= 1");
+  return unfold_impl(M, ldm, W, ldw, gamma, beta, O, d, gW, ldgw, gb, ggamma, gbeta, su_part, su_part ? n_slices : 0, stream);
+}
+
+static int unfold_impl(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma, const float* beta, int64_t O,
+                       int64_t d, float* gW, int64_t ldgw, float* gb, float* ggamma, float* gbeta, const float* su_part,
+                       int64_t n_slices, void* stream) {
   ALLSET_REQUIRE(O >= 1 && O < INT32_MAX && d >= 1 && d < INT32_MAX, "unfold_ln_linear: bad size");
   ALLSET_REQUIRE(M && W && gamma && beta && gW && ggamma && gbeta, "unfold_ln_linear: null pointer");
-  ALLSET_REQUIRE(ldm >= d + 1 && ldw >= d && ldgw >= d, "unfold_ln_linear: leading dimension too small (ldm >= d + 1)");
+  ALLSET_REQUIRE(ldm >= d + (su_part ? 0 : 1) && ldw >= d && ldgw >= d, "unfold_ln_linear: leading dimension too small (ldm >= d + 1)");
   const int64_t cols = d > O ? d : O;
   unfold_ln_kernel<<<static_cast<unsigned>((cols + kWave - 1) / kWave), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      M, ldm, W, ldw, gamma, beta, static_cast<int>(O), static_cast<int>(d), gW, ldgw, gb, ggamma, gbeta);
+      M, ldm, W, ldw, gamma, beta, static_cast<int>(O), static_cast<int>(d), gW, ldgw, gb, ggamma, gbeta, su_part,
+      static_cast<int>(n_slices));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

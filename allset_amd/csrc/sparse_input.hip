@@ -1,0 +1,291 @@
+// The first Linear of a model on SPARSE raw features (bag-of-words rows: 18 of 1433 entries on Cora, 32 of 3703 on Citeseer; the
+// reference's loaders hand them over as a dense matrix, models.py:473-476 multiplies all of it).  Same layer as input_linear.hip --
+// [dropout ->] LayerNorm -> Linear on an input without gradient -- with the two GEMMs replaced by sums over the non-zeros:
+//
+//   x_hat[r, j] = rstd_r (v_rj - mean_r),  v = dropout(x)             (a row's zeros all share one value: -rstd_r mean_r)
+//   y[r, :]  = rstd_r ( sum_{j in nnz(r)} v_rj W'[:, j]  -  mean_r s ) + b'      W' = W * gamma,  s = sum_j W'[:, j],  b' = b + W beta
+//   M[:, j]  = gy^T x_hat[:, j] = sum_{r in nnz(j)} rstd_r v_rj gy[r, :]  -  u,  u = sum_r rstd_r mean_r gy[r, :]
+//
+// and M unfolds into the four parameter gradients exactly as in input_linear.hip (with s_gy = sum_r gy[r, :] for its ones column).
+// Row statistics are exact two-pass sums over the non-zeros plus the closed-form contribution of the zeros.  The dropout is the
+// library's counter hash of (seed, r * d + j): the same positions the dense kernels would drop.
+//
+//   fold_t_kernel          W'^T [d + 2, O]: rows j < d = W[:, j] * gamma_j (transposed through LDS), row d = s, row d + 1 = b'
+//   sparse_ln_fwd_kernel   one lane group per row: statistics, gather of W'^T rows, y; keeps w = rstd * v per non-zero, rstd * mean per row
+//   sparse_ln_bwd_kernel   one lane group per FEATURE (CSC): gather of gy rows -> M[:, j]; extra workgroups: partial sums of s_gy and u
+//   (unfold: allset_unfold_ln_linear_ex in input_linear.hip)
+#include "common.h"
+
+namespace allset {
+
+constexpr int kSpSlices = 16;        // row slices of the (s_gy, u) partial sums
+
+__global__ __launch_bounds__(kBlock) void fold_t_kernel(const float* __restrict__ W, int64_t ldw, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ b, int O, int d,
+                                                        float* __restrict__ WT) {
+  __shared__ float tile[64][65];
+  __shared__ float red[2][kBlock];
+  const int t = threadIdx.x;
+  const int n_tiles = (d + 63) / 64;
+  if (static_cast<int>(blockIdx.x) < n_tiles) {               // transpose 64 input columns x O outputs, 64 outputs at a time
+    const int j0 = blockIdx.x * 64, jl = t & 63, kq = t >> 6;
+    const int j = j0 + jl;
+    const float g = j < d ? gamma[j] : 0.f;
+    for (int k0 = 0; k0 < O; k0 += 64) {
+      __syncthreads();
+      for (int k = kq; k < 64; k += 4)
+        tile[jl][k] = (j < d && k0 + k < O) ? W[static_cast<int64_t>(k0 + k) * ldw + j] * g : 0.f;
+      __syncthreads();
+      for (int r = kq; r < 64; r += 4)                         // row j0 + r of W'^T, columns k0 + jl
+        if (j0 + r < d && k0 + jl < O) WT[static_cast<int64_t>(j0 + r) * O + k0 + jl] = tile[r][jl];
+    }
+    return;
+  }
+  const int k = blockIdx.x - n_tiles;                          // one workgroup per output: s[k], b'[k] (fixed-order sums)
+  const float* w = W + static_cast<int64_t>(k) * ldw;
+  float as = 0.f, ab = 0.f;
+  for (int j = t; j < d; j += kBlock) {
+    const float wv = w[j];
+    as = fmaf(wv, gamma[j], as);
+    ab = fmaf(wv, beta[j], ab);
+  }
+  red[0][t] = as; red[1][t] = ab;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    WT[static_cast<int64_t>(d) * O + k] = red[0][0];
+    WT[static_cast<int64_t>(d + 1) * O + k] = red[1][0] + (b ? b[k] : 0.f);
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ float slot_sum(float v) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// LPR lanes (O = 4 * LPR outputs) per row, 64 / LPR rows per wave.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sparse_ln_fwd_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               const float* __restrict__ val, int64_t n, int d,
+                                                               const float* __restrict__ WT, float eps, float p_pre, uint64_t seed,
+                                                               const uint64_t* __restrict__ seed_base, float* __restrict__ y,
+                                                               int64_t ldy, float* __restrict__ w_out, float* __restrict__ rm) {
+  constexpr int O = 4 * LPR, NS = kWave / LPR;
+  seed = resolve_seed(seed_base, seed);
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR, lane0 = slot * LPR;
+  const int64_t r = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const bool live = r < n;
+  const int p0 = live ? rowptr[r] : 0, p1 = live ? rowptr[r + 1] : 0;
+  const float inv_keep = p_pre > 0.f ? 1.f / (1.f - p_pre) : 1.f;
+  const uint32_t thr = drop_threshold(p_pre);
+  auto value = [&](int p, int c) -> float {
+    float v = val[p];
+    if (p_pre > 0.f) v *= keep_scale(seed, r * d + c, thr, inv_keep);
+    return v;
+  };
+  // (trip counts differ between the slots of a wave but are uniform inside a slot, and every shuffle below stays inside its slot)
+  const int len = p1 - p0;
+  float s1 = 0.f;
+  for (int b0 = 0; b0 < len; b0 += LPR) {
+    const int p = p0 + b0 + li;
+    if (b0 + li < len) s1 += value(p, col[p]);
+  }
+  const float mean = slot_sum<LPR>(s1) / static_cast<float>(d);
+  float s2 = 0.f;
+  for (int b0 = 0; b0 < len; b0 += LPR) {
+    const int p = p0 + b0 + li;
+    if (b0 + li < len) { const float c = value(p, col[p]) - mean; s2 = fmaf(c, c, s2); }
+  }
+  s2 = slot_sum<LPR>(s2) + static_cast<float>(d - len) * mean * mean;
+  const float rstd = rsqrtf(s2 / static_cast<float>(d) + eps);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = 0; b0 < len; b0 += LPR) {
+    const int p = p0 + b0 + li;
+    int c = 0;
+    float v = 0.f;
+    if (b0 + li < len) {
+      c = col[p];
+      v = value(p, c);
+      w_out[p] = rstd * v;
+    }
+    const int nb = min(LPR, len - b0);
+    for (int j = 0; j < nb; j += 8) {                     // eight gathers in flight (past the batch's end: v = 0, row 0 of W'^T)
+      float4 wv[8];
+      float vj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = lane0 + ((j + u) & (LPR - 1));
+        const int cj = (j + u < nb) ? __shfl(c, src) : 0;
+        vj[u] = (j + u < nb) ? __shfl(v, src) : 0.f;
+        wv[u] = *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(cj) * O + 4 * li);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x = fmaf(vj[u], wv[u].x, acc.x); acc.y = fmaf(vj[u], wv[u].y, acc.y);
+        acc.z = fmaf(vj[u], wv[u].z, acc.z); acc.w = fmaf(vj[u], wv[u].w, acc.w);
+      }
+    }
+  }
+  if (!live) return;
+  const float4 s = *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(d) * O + 4 * li);
+  const float4 bp = *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(d + 1) * O + 4 * li);
+  float4 o;
+  o.x = fmaf(rstd, acc.x - mean * s.x, bp.x); o.y = fmaf(rstd, acc.y - mean * s.y, bp.y);
+  o.z = fmaf(rstd, acc.z - mean * s.z, bp.z); o.w = fmaf(rstd, acc.w - mean * s.w, bp.w);
+  *reinterpret_cast<float4*>(y + r * ldy + 4 * li) = o;
+  if (li == 0) rm[r] = rstd * mean;
+}
+
+// Workgroups [0, feat_blocks): LPR lanes per feature j (CSC row), M[k, j] = sum_p w[posT[p]] gy[rowT[p], k] (k = 4 li .. 4 li + 3).
+// Workgroups [feat_blocks, feat_blocks + kSpSlices): su_part[slice][0][k] = sum_r gy[r, k], [1][k] = sum_r rm[r] gy[r, k] over the slice.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sparse_ln_bwd_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowT,
+                                                               const int32_t* __restrict__ posT, const float* __restrict__ w,
+                                                               const float* __restrict__ rm, const float* __restrict__ gy,
+                                                               int64_t ldg, int64_t n, int d, float* __restrict__ M, int64_t ldm,
+                                                               float* __restrict__ su_part, int feat_blocks) {
+  constexpr int O = 4 * LPR, NS = kWave / LPR;
+  if (static_cast<int>(blockIdx.x) >= feat_blocks) {
+    __shared__ float4 red[2][kBlock];
+    const int slice = blockIdx.x - feat_blocks;
+    const int t = threadIdx.x, q = t % LPR, g = t / LPR;
+    constexpr int G = kBlock / LPR;
+    const int64_t rows = (n + kSpSlices - 1) / kSpSlices;
+    const int64_t r0 = slice * rows, r1 = min(r0 + rows, n);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int64_t r = r0 + g; r < r1; r += G) {
+      const float4 v = *reinterpret_cast<const float4*>(gy + r * ldg + 4 * q);
+      const float m = rm[r];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      u.x = fmaf(m, v.x, u.x); u.y = fmaf(m, v.y, u.y); u.z = fmaf(m, v.z, u.z); u.w = fmaf(m, v.w, u.w);
+    }
+    red[0][t] = s; red[1][t] = u;
+    __syncthreads();
+    if (g == 0) {
+      for (int gg = 1; gg < G; ++gg) {
+        const float4 a = red[0][gg * LPR + q], c = red[1][gg * LPR + q];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        u.x += c.x; u.y += c.y; u.z += c.z; u.w += c.w;
+      }
+      float* out = su_part + static_cast<int64_t>(slice) * 2 * O;
+      *reinterpret_cast<float4*>(out + 4 * q) = s;
+      *reinterpret_cast<float4*>(out + O + 4 * q) = u;
+    }
+    return;
+  }
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR, lane0 = slot * LPR;
+  const int j = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const bool live = j < d;
+  const int p0 = live ? colptr[j] : 0, p1 = live ? colptr[j + 1] : 0;
+  const int len = p1 - p0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = 0; b0 < len; b0 += LPR) {
+    const int p = p0 + b0 + li;
+    int rr = 0;
+    float wv = 0.f;
+    if (b0 + li < len) { rr = rowT[p]; wv = w[posT[p]]; }
+    const int nb = min(LPR, len - b0);
+    for (int i = 0; i < nb; i += 8) {                     // eight gathers in flight (past the batch's end: w = 0, row 0 of gy)
+      float4 g4[8];
+      float wi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = lane0 + ((i + u) & (LPR - 1));
+        const int ri = (i + u < nb) ? __shfl(rr, src) : 0;
+        wi[u] = (i + u < nb) ? __shfl(wv, src) : 0.f;
+        g4[u] = *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(ri) * ldg + 4 * li);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x = fmaf(wi[u], g4[u].x, acc.x); acc.y = fmaf(wi[u], g4[u].y, acc.y);
+        acc.z = fmaf(wi[u], g4[u].z, acc.z); acc.w = fmaf(wi[u], g4[u].w, acc.w);
+      }
+    }
+  }
+  if (!live) return;
+  M[static_cast<int64_t>(4 * li) * ldm + j] = acc.x;
+  M[static_cast<int64_t>(4 * li + 1) * ldm + j] = acc.y;
+  M[static_cast<int64_t>(4 * li + 2) * ldm + j] = acc.z;
+  M[static_cast<int64_t>(4 * li + 3) * ldm + j] = acc.w;
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+extern "C" int allset_sparse_ln_linear_supported(int64_t O) { return (O == 64 || O == 128 || O == 256) ? 1 : 0; }
+extern "C" int allset_sparse_ln_linear_slices(void) { return kSpSlices; }
+
+extern "C" int allset_fold_ln_linear_t(const float* W, int64_t ldw, const float* gamma, const float* beta, const float* b, int64_t O,
+                                       int64_t d, float* WT, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(O >= 1 && O < (1 << 20) && d >= 1 && d < INT32_MAX - 64, "fold_ln_linear_t: bad size");
+  ALLSET_REQUIRE(W && gamma && beta && WT, "fold_ln_linear_t: null pointer");
+  ALLSET_REQUIRE(ldw >= d, "fold_ln_linear_t: leading dimension smaller than d");
+  const unsigned grid = static_cast<unsigned>((d + 63) / 64 + O);
+  fold_t_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(W, ldw, gamma, beta, b, static_cast<int>(O), static_cast<int>(d), WT);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_sparse_ln_linear_fwd(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n, int64_t d,
+                                           const float* WT, int64_t O, float eps, float p_pre, uint64_t seed, const uint64_t* seed_base,
+                                           float* y, int64_t ldy, float* w_out, float* rm, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_ln_linear_fwd: bad size");
+  ALLSET_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "sparse_ln_linear_fwd: dropout p must be in [0,1)");
+  if (!allset_sparse_ln_linear_supported(O)) {
+    set_error("sparse_ln_linear_fwd: O must be 64, 128 or 256 (got %lld)", static_cast<long long>(O));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rowptr && WT && y && rm, "sparse_ln_linear_fwd: null pointer");
+  ALLSET_REQUIRE(ldy >= O && ldy % 4 == 0 && aligned16(y) && aligned16(WT), "sparse_ln_linear_fwd: y rows / WT must be 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lpr = static_cast<int>(O / 4);
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
+  const int di = static_cast<int>(d);
+  switch (lpr) {
+    case 16: sparse_ln_fwd_kernel<16><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, eps, p_pre, seed, seed_base, y, ldy, w_out, rm); break;
+    case 32: sparse_ln_fwd_kernel<32><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, eps, p_pre, seed, seed_base, y, ldy, w_out, rm); break;
+    default: sparse_ln_fwd_kernel<64><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, eps, p_pre, seed, seed_base, y, ldy, w_out, rm); break;
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_sparse_ln_linear_bwd(const int32_t* colptr, const int32_t* rowT, const int32_t* posT, const float* w,
+                                           const float* rm, const float* gy, int64_t ldg, int64_t n, int64_t d, int64_t O, float* M,
+                                           int64_t ldm, float* su_part, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_ln_linear_bwd: bad size");
+  if (!allset_sparse_ln_linear_supported(O)) {
+    set_error("sparse_ln_linear_bwd: O must be 64, 128 or 256 (got %lld)", static_cast<long long>(O));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(colptr && M && su_part && (n == 0 || (rm && gy)), "sparse_ln_linear_bwd: null pointer");
+  ALLSET_REQUIRE(ldm >= d && (n == 0 || (ldg >= O && ldg % 4 == 0 && aligned16(gy))) && aligned16(su_part),
+                 "sparse_ln_linear_bwd: ldm >= d; gy rows and su_part 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lpr = static_cast<int>(O / 4);
+  const int64_t feats_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const int feat_blocks = static_cast<int>((d + feats_per_block - 1) / feats_per_block);
+  const unsigned grid = static_cast<unsigned>(feat_blocks + kSpSlices);
+  const int di = static_cast<int>(d);
+  switch (lpr) {
+    case 16: sparse_ln_bwd_kernel<16><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, rm, gy, ldg, n, di, M, ldm, su_part, feat_blocks); break;
+    case 32: sparse_ln_bwd_kernel<32><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, rm, gy, ldg, n, di, M, ldm, su_part, feat_blocks); break;
+    default: sparse_ln_bwd_kernel<64><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, rm, gy, ldg, n, di, M, ldm, su_part, feat_blocks); break;
+  }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}

@@ -1591,8 +1591,118 @@ class _InputNormLinear(torch.autograd.Function):
         return None, gg if need[1] else None, gbt if need[2] else None, gw if need[3] else None, gb if (ctx.has_bias and need[4]) else None, None, None
 
 
+# ---- ... and on SPARSE raw features (csrc/sparse_input.hip) -----------------------------------------------------------------------------
+class SparseRows:
+    """CSR + CSC of a constant feature matrix (bag-of-words rows), built once per tensor: ``rowptr / col / val`` in row-major order,
+    ``colptr / rowT / posT`` (row id and CSR position of each entry) in column-major order; int32 indices."""
+
+    def __init__(self, x: Tensor):
+        n, d = x.shape
+        idx = (x != 0).nonzero()                                   # row-major order; one host sync (the count)
+        rows, cols = idx[:, 0], idx[:, 1]
+        self.n, self.d, self.nnz = n, d, int(idx.shape[0])
+        self.val = x[rows, cols].contiguous()
+        self.col = cols.to(torch.int32)
+        self.rowptr = torch.zeros(n + 1, dtype=torch.int32, device=x.device)
+        self.rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0).to(torch.int32)
+        order = torch.argsort(cols, stable=True)
+        self.rowT = rows[order].to(torch.int32)
+        self.posT = order.to(torch.int32)
+        self.colptr = torch.zeros(d + 1, dtype=torch.int32, device=x.device)
+        self.colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=d), 0).to(torch.int32)
+
+
+_SPARSE_ROWS = {}           # data_ptr -> (weakref to the tensor, version, shape, SparseRows or None)
+SPARSE_MAX_DENSITY = 0.10   # above this fraction of non-zeros the GEMM path wins
+
+
+def sparse_rows(x: Tensor) -> Optional[SparseRows]:
+    """The cached :class:`SparseRows` of ``x`` when at most 10 % of it is non-zero, else None.  Built on first sight of the tensor
+    (one host read-back; keyed on identity and version, so an in-place update rebuilds it) -- never during graph capture: a tensor
+    first seen there takes the dense path."""
+    import weakref
+    key = x.data_ptr()
+    hit = _SPARSE_ROWS.get(key)
+    if hit is not None:
+        ref, ver, shape, sp = hit
+        if ref() is x and ver == x._version and shape == tuple(x.shape):
+            return sp
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    if len(_SPARSE_ROWS) > 64:
+        for k in [k for k, v in _SPARSE_ROWS.items() if v[0]() is None]:
+            del _SPARSE_ROWS[k]
+    nnz = int(torch.count_nonzero(x))
+    sp = SparseRows(x) if (x.numel() > 0 and nnz <= SPARSE_MAX_DENSITY * x.numel()) else None
+    _SPARSE_ROWS[key] = (weakref.ref(x), x._version, tuple(x.shape), sp)
+    return sp
+
+
+class _SparseInputNormLinear(torch.autograd.Function):
+    """:class:`_InputNormLinear` from the non-zeros of ``x`` (csrc/sparse_input.hip): forward = the transposed folded weight (one
+    kernel) + one gather-sum kernel; backward = one gather-sum kernel over the CSC + the unfold kernel.  No [n, d] tensor at all."""
+
+    @staticmethod
+    def forward(ctx, x, sp, gamma, beta, weight, bias, eps, p_pre):
+        lib = _lib.load()
+        dev = x.device
+        O, d = weight.shape
+        n = x.shape[0]
+        seed = _draw_seed() if p_pre > 0.0 else 0
+        base = _seed_base() if p_pre > 0.0 else None
+        weight_c, gamma_c, beta_c = _rowmajor(weight), gamma.contiguous(), beta.contiguous()
+        wt = torch.empty((d + 2, O), dtype=torch.float32, device=dev)
+        y = torch.empty((n, O), dtype=torch.float32, device=dev)
+        w = torch.empty(max(sp.nnz, 1), dtype=torch.float32, device=dev)
+        rm = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        with on_device(dev):
+            check(lib.allset_fold_ln_linear_t(ptr(weight_c), _ld(weight_c), ptr(gamma_c), ptr(beta_c), ptr(bias.contiguous()) if bias is not None else None,
+                                              O, d, ptr(wt), stream_of(dev)), "allset_fold_ln_linear_t")
+            check(lib.allset_sparse_ln_linear_fwd(ptr(sp.rowptr), ptr(sp.col), ptr(sp.val), n, d, ptr(wt), O, float(eps), float(p_pre), seed,
+                                                  ptr(base), ptr(y), O, ptr(w), ptr(rm), stream_of(dev)), "allset_sparse_ln_linear_fwd")
+        ctx.save_for_backward(w, rm, gamma, beta, weight)
+        ctx.sp = sp
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        w, rm, gamma, beta, weight = ctx.saved_tensors
+        sp = ctx.sp
+        lib = _lib.load()
+        dev = gy.device
+        gy = _rowmajor(gy.contiguous())
+        O, d = weight.shape
+        n = gy.shape[0]
+        slices = int(lib.allset_sparse_ln_linear_slices())
+        M = torch.empty((O, d), dtype=torch.float32, device=dev)
+        su = torch.empty((slices, 2, O), dtype=torch.float32, device=dev)
+        out = torch.empty(O * d + O + 2 * d, dtype=torch.float32, device=dev)       # gW | gb | ggamma | gbeta
+        gw, gb = out[:O * d].view(O, d), out[O * d:O * d + O]
+        gg, gbt = out[O * d + O:O * d + O + d], out[O * d + O + d:]
+        weight_c = _rowmajor(weight)
+        with on_device(dev):
+            check(lib.allset_sparse_ln_linear_bwd(ptr(sp.colptr), ptr(sp.rowT), ptr(sp.posT), ptr(w), ptr(rm), ptr(gy), _ld(gy), n, d, O,
+                                                  ptr(M), d, ptr(su), stream_of(dev)), "allset_sparse_ln_linear_bwd")
+            check(lib.allset_unfold_ln_linear_ex(ptr(M), d, ptr(weight_c), _ld(weight_c), ptr(gamma.contiguous()), ptr(beta.contiguous()), O, d,
+                                                 ptr(gw), d, ptr(gb) if ctx.has_bias else None, ptr(gg), ptr(gbt), ptr(su), slices,
+                                                 stream_of(dev)), "allset_unfold_ln_linear_ex")
+        need = ctx.needs_input_grad
+        return (None, None, gg if need[2] else None, gbt if need[3] else None, gw if need[4] else None,
+                gb if (ctx.has_bias and need[5]) else None, None, None)
+
+
 def input_norm_linear(x: Tensor, gamma: Tensor, beta: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5,
                       p_pre: float = 0.0) -> Tensor:
+    # (NO-GRAD forwards keep the dense kernels: graphs.GraphedForward lets its caller overwrite the features in place between
+    #  replays, a replay cannot rebuild the non-zero structure, and eager and replayed inference stay bit-identical this way; a
+    #  training step's features are constants)
+    replaceable = not torch.is_grad_enabled()
+    if x.shape[1] >= 256 and not replaceable and _lib.load().allset_sparse_ln_linear_supported(weight.shape[0]):
+        sp = sparse_rows(x)
+        if sp is not None:
+            return _SparseInputNormLinear.apply(x, sp, gamma, beta, weight, bias, float(eps), float(p_pre))
     return _InputNormLinear.apply(x, gamma, beta, weight, bias, float(eps), float(p_pre))
 
 

@@ -94,6 +94,9 @@ class GraphedTrainStep:
     ``loss_fn(logits) -> scalar`` closes over static label / index tensors, e.g.
     ``lambda out: F.nll_loss(F.log_softmax(out[train_idx], 1), y[train_idx])`` (``src/train.py:519-524``).
 
+    ``data`` (features, incidence, norm) is a CONSTANT of the captured step: kernels may read structures derived from it at
+    capture time (the CSR pair of the incidence; the non-zero structure of sparse raw features, ``dense.sparse_rows``).
+
     Capture needs a few real warm-up steps (allocator, autograd and optimizer state must exist before recording).
     With ``restore=True`` (default) parameters and optimizer state are put back afterwards -- in place, the graph holds
     their addresses -- so the first replay is step 1 of training, not step ``warmup + 1``: state the optimizer created

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 10  /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total) */
+#define ALLSET_ABI_VERSION 10  /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex) */
 
 enum allset_status {
   ALLSET_OK = 0,
@@ -558,6 +558,31 @@ int allset_col_moments2(const float* x, int64_t ldx, int64_t n, int64_t d, int r
  * (s = 2 dvar / n, t = dmean / n - s * mean). */
 int allset_col_affine_add(float* gx, int64_t ldgx, const float* x, int64_t ldx, const float* s, const float* t, int relu_mask,
                           int64_t n, int64_t d, void* stream);
+/* ---- the same first Linear on SPARSE raw features (bag-of-words rows; the loaders hand over a dense matrix, reference models.py:473-476
+ * multiplies all of it): the two GEMMs become sums over the non-zeros.  The caller holds the features' CSR (rowptr [n+1], col, val
+ * [nnz], row-major order) and CSC (colptr [d+1], rowT [nnz] = row of each entry in column-major order, posT [nnz] = its CSR position).
+ *   allset_fold_ln_linear_t   WT [d + 2, O]: rows j < d = W[:, j] * gamma_j, row d = sum_j W[:, j] gamma_j, row d + 1 = b + W beta
+ *   allset_sparse_ln_linear_fwd   y[n, O] = Linear(LayerNorm(dropout_p(x))) from the non-zeros (statistics: exact two-pass sums + the
+ *       zeros' closed form; dropout = the counter hash of (seed, r * d + j), the positions the dense kernels drop); keeps
+ *       w_out[p] = rstd_r * v_p per non-zero (CSR order) and rm[r] = rstd_r * mean_r for the backward
+ *   allset_sparse_ln_linear_bwd   M[k, j] = sum_{p in column j} w[posT[p]] gy[rowT[p], k]  ([O, ldm >= d]) and su_part
+ *       [allset_sparse_ln_linear_slices()][2][O] = per-slice sums of gy[r, :] and of rm[r] gy[r, :]
+ *   allset_unfold_ln_linear_ex    allset_unfold_ln_linear with M_true = M - u and the ones column = s taken from su_part
+ * O in {64, 128, 256} (allset_sparse_ln_linear_supported).  csrc/sparse_input.hip; allset_amd/dense.py _SparseInputNormLinear. */
+int allset_sparse_ln_linear_supported(int64_t O);
+int allset_sparse_ln_linear_slices(void);
+int allset_fold_ln_linear_t(const float* W, int64_t ldw, const float* gamma, const float* beta, const float* b, int64_t O, int64_t d,
+                            float* WT, void* stream);
+int allset_sparse_ln_linear_fwd(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n, int64_t d, const float* WT,
+                                int64_t O, float eps, float p_pre, uint64_t seed, const uint64_t* seed_base, float* y, int64_t ldy,
+                                float* w_out, float* rm, void* stream);
+int allset_sparse_ln_linear_bwd(const int32_t* colptr, const int32_t* rowT, const int32_t* posT, const float* w, const float* rm,
+                                const float* gy, int64_t ldg, int64_t n, int64_t d, int64_t O, float* M, int64_t ldm, float* su_part,
+                                void* stream);
+int allset_unfold_ln_linear_ex(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma, const float* beta,
+                               int64_t O, int64_t d, float* gW, int64_t ldgw, float* gb, float* ggamma, float* gbeta,
+                               const float* su_part, int64_t n_slices, void* stream);
+
 /* ---- backward of a Linear with a NARROW output: the classifier head Linear(hidden -> num_classes) (reference models.py:449-456) ----
  * ONE kernel instead of the library's three (input gradient, weight gradient on a single workgroup, bias gradient):
  *   gx[n, K] = gy[n, N] W[N, K] (gx may be NULL);  part[slice][k * K + j] = partial sums of gW = gy^T x;  part[slice][N * K + k] of gb.

@@ -170,3 +170,110 @@ def test_batchnorm_entries_reject_bad_arguments(device):
     _err(lib, bw(*args(None, 1)))
     _err(lib, bw(*args(P(stats), 5)))
     torch.cuda.synchronize()
+
+
+def test_dataset_scale_entries_reject_bad_arguments(device):
+    """ABI 10 additions (csrc/input_linear.hip, sparse_input.hip, narrow_linear.hip, the batched reduction, the loss total)."""
+    from allset_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    n, d, O = 50, 300, 64
+    K = lib.allset_input_linear_k(d)
+    assert K >= d + 1 and K % 16 == 0
+    x = torch.randn(n, d, device=device)
+    xh = torch.empty(n, K, device=device)
+    f = lib.allset_xhat_rows
+    assert f(P(x), d, n, d, 1e-5, 0.0, 0, None, P(xh), K, st) == 0
+    _err(lib, f(P(x), d, n, d, 1e-5, 0.0, 0, None, P(xh), d, st))               # no room for the ones column
+    _err(lib, f(P(x), d, n, 5000, 1e-5, 0.0, 0, None, P(xh), K, st))            # wider than 4096
+    _err(lib, f(P(x), d, n, d, 1e-5, 1.0, 0, None, P(xh), K, st))               # p = 1
+    _err(lib, f(None, d, n, d, 1e-5, 0.0, 0, None, P(xh), K, st))
+    W, g, b = torch.randn(O, d, device=device), torch.ones(d, device=device), torch.zeros(d, device=device)
+    Wp = torch.empty(O, K, device=device)
+    assert lib.allset_fold_ln_linear(P(W), d, P(g), P(b), None, O, d, P(Wp), K, st) == 0
+    _err(lib, lib.allset_fold_ln_linear(P(W), d, P(g), P(b), None, O, d, P(Wp), d, st))
+    _err(lib, lib.allset_fold_ln_linear(P(W), d, None, P(b), None, O, d, P(Wp), K, st))
+    M = torch.zeros(O, K, device=device)
+    gW, gg = torch.empty(O, d, device=device), torch.empty(2, d, device=device)
+    u = lib.allset_unfold_ln_linear
+    assert u(P(M), K, P(W), d, P(g), P(b), O, d, P(gW), d, None, P(gg), P(gg[1]), st) == 0
+    _err(lib, u(P(M), d, P(W), d, P(g), P(b), O, d, P(gW), d, None, P(gg), P(gg[1]), st))
+    _err(lib, u(P(M), K, P(W), d, P(g), P(b), O, d, None, d, None, P(gg), P(gg[1]), st))
+    su = torch.zeros(lib.allset_sparse_ln_linear_slices(), 2, O, device=device)
+    ux = lib.allset_unfold_ln_linear_ex
+    assert ux(P(M), K, P(W), d, P(g), P(b), O, d, P(gW), d, None, P(gg), P(gg[1]), P(su), su.shape[0], st) == 0
+    _err(lib, ux(P(M), K, P(W), d, P(g), P(b), O, d, P(gW), d, None, P(gg), P(gg[1]), P(su), 0, st))
+    # sparse first layer
+    assert lib.allset_sparse_ln_linear_supported(64) == 1 and lib.allset_sparse_ln_linear_supported(7) == 0
+    WT = torch.empty(d + 2, O, device=device)
+    assert lib.allset_fold_ln_linear_t(P(W), d, P(g), P(b), None, O, d, P(WT), st) == 0
+    _err(lib, lib.allset_fold_ln_linear_t(P(W), d - 1, P(g), P(b), None, O, d, P(WT), st))
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=device)
+    y, rm = torch.empty(n, O, device=device), torch.empty(n, device=device)
+    sf = lib.allset_sparse_ln_linear_fwd
+    assert sf(P(rowptr), None, None, n, d, P(WT), O, 1e-5, 0.0, 0, None, P(y), O, None, P(rm), st) == 0      # no non-zeros at all
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y, WT[d + 1].expand(n, O))                       # LayerNorm of a zero row is beta: y = b + W beta
+    assert _err(lib, sf(P(rowptr), None, None, n, d, P(WT), 7, 1e-5, 0.0, 0, None, P(y), O, None, P(rm), st))
+    _err(lib, sf(P(rowptr), None, None, n, d, P(WT), O, 1e-5, 0.0, 0, None, P(y), O - 4, None, P(rm), st))
+    _err(lib, sf(None, None, None, n, d, P(WT), O, 1e-5, 0.0, 0, None, P(y), O, None, P(rm), st))
+    colptr = torch.zeros(d + 1, dtype=torch.int32, device=device)
+    gy, Ms = torch.randn(n, O, device=device), torch.empty(O, d, device=device)
+    sb = lib.allset_sparse_ln_linear_bwd
+    assert sb(P(colptr), None, None, None, P(rm), P(gy), O, n, d, O, P(Ms), d, P(su), st) == 0
+    torch.cuda.synchronize()
+    assert float(Ms.abs().max()) == 0.0
+    torch.testing.assert_close(su[:, 0].sum(0), gy.sum(0), rtol=1e-5, atol=1e-5)
+    _err(lib, sb(P(colptr), None, None, None, P(rm), P(gy), O, n, d, O, P(Ms), d - 1, P(su), st))
+    _err(lib, sb(P(colptr), None, None, None, P(rm), P(gy), O, n, d, O, P(Ms), d, None, st))
+    # classifier-head backward
+    assert lib.allset_linear_narrow_supported(7, 64) == 1 and lib.allset_linear_narrow_supported(17, 64) == 0
+    assert lib.allset_linear_narrow_supported(7, 66) == 0 and lib.allset_linear_narrow_supported(7, 512) == 0
+    ns = ctypes.c_int64(0)
+    assert lib.allset_linear_narrow_slices(n, ctypes.byref(ns)) == 0 and ns.value >= 1
+    h, Wc, gl = torch.randn(n, 64, device=device), torch.randn(7, 64, device=device), torch.randn(n, 7, device=device)
+    gh, part = torch.empty(n, 64, device=device), torch.empty(ns.value, 7 * 64 + 8, device=device)
+    nb = lib.allset_linear_narrow_bwd
+    assert nb(P(gl), 7, P(h), 64, P(Wc), n, 7, 64, P(gh), 64, P(part), part.shape[1], ns.value, st) == 0
+    assert "N <=" in _err(lib, nb(P(gl), 7, P(h), 64, P(Wc), n, 17, 64, P(gh), 64, P(part), part.shape[1], ns.value, st))
+    _err(lib, nb(P(gl), 7, P(h), 64, P(Wc), n, 7, 64, P(gh), 64, P(part), part.shape[1], ns.value + 1, st))
+    _err(lib, nb(P(gl), 7, P(h), 64, P(Wc), n, 7, 64, P(gh), 64, P(part), 7 * 64, ns.value, st))
+    _err(lib, nb(P(gl), 7, P(h) + 4, 64, P(Wc), n, 7, 64, P(gh), 64, P(part), part.shape[1], ns.value, st))
+    # batched reduction
+    assert lib.allset_reduce_partials_batchable(64, 4288) == 1 and lib.allset_reduce_partials_batchable(64, 6) == 0
+    assert lib.allset_reduce_partials_batchable(4096, 4096) == 0
+    parts = [torch.randn(9, 16, device=device), torch.randn(70, 8, device=device)]
+    outs = [torch.empty(16, device=device), torch.empty(8, device=device)]
+    arr = lambda vals: (ctypes.c_void_p * len(vals))(*vals)
+    i64 = lambda vals: (ctypes.c_int64 * len(vals))(*vals)
+    rb = lib.allset_reduce_partials_batched
+    assert rb(arr([P(t) for t in parts]), i64([9, 70]), i64([16, 8]), i64([16, 8]), arr([P(t) for t in outs]), 2, st) == 0
+    torch.cuda.synchronize()
+    for t, o in zip(parts, outs):
+        torch.testing.assert_close(o, t.sum(0), rtol=1e-5, atol=1e-5)
+    _err(lib, rb(arr([P(t) for t in parts]), i64([9, 70]), i64([16, 8]), i64([16, 6]), arr([P(t) for t in outs]), 2, st))
+    _err(lib, rb(arr([P(t) for t in parts]), i64([9, 70]), i64([12, 8]), i64([16, 8]), arr([P(t) for t in outs]), 2, st))
+    _err(lib, rb(arr([P(parts[0]), 0]), i64([9, 70]), i64([16, 8]), i64([16, 8]), arr([P(t) for t in outs]), 2, st))
+    _err(lib, rb(None, None, None, None, None, lib.allset_reduce_partials_batch_max() + 1, st))
+    c64, cf = torch.zeros(1, dtype=torch.int64, device=device), [torch.zeros((), device=device) for _ in range(3)]
+    rx = lib.allset_reduce_partials_batched_ex
+    assert rx(None, None, None, None, None, 0, P(c64), arr([P(t) for t in cf]), 3, st) == 0             # counters only
+    torch.cuda.synchronize()
+    assert int(c64) == 1 and [float(t) for t in cf] == [1.0, 1.0, 1.0]
+    _err(lib, rx(None, None, None, None, None, 0, P(c64), None, 3, st))
+    _err(lib, rx(None, None, None, None, None, 0, None, arr([0]), lib.allset_reduce_partials_batch_max_counters() + 1, st))
+    # loss total
+    logits, yl = torch.randn(n, 7, device=device), torch.randint(0, 7, (n,), device=device)
+    npart = ctypes.c_int64(0)
+    lib.allset_nll_partials(n, ctypes.byref(npart))
+    partials, ticket = torch.empty(npart.value + 1, device=device), torch.zeros(1, dtype=torch.int32, device=device)
+    lt = lib.allset_nll_logsoftmax_fwd_total
+    assert lt(P(logits), 7, P(yl), None, 1.0 / n, P(partials), npart.value, P(ticket), P(partials[npart.value:]), n, 7, st) == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.nll_loss(torch.log_softmax(logits, 1), yl)
+    torch.testing.assert_close(partials[npart.value], ref, rtol=1e-5, atol=1e-6)
+    assert int(ticket) == 0                                                      # re-armed
+    _err(lib, lt(P(logits), 7, P(yl), None, 1.0 / n, P(partials), npart.value, None, P(partials[npart.value:]), n, 7, st))
+    _err(lib, lt(P(logits), 7, P(yl), None, 1.0 / n, P(partials), npart.value + 1, P(ticket), P(partials), n, 7, st))
+    torch.cuda.synchronize()

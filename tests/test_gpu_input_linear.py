@@ -163,3 +163,71 @@ def _compare_paths(case, args, device, ctr, attempt):
     torch.testing.assert_close(oa, ob, rtol=0, atol=1e-4 * float(ob.abs().max()))
     for k in ga:
         torch.testing.assert_close(ga[k], gb[k], rtol=0, atol=1e-4 * float(gb[k].abs().max()) + 1e-12, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("n,d,O,density", [(2708, 1433, 64, 0.0127), (3312, 3703, 128, 0.0086), (100, 300, 256, 0.05), (37, 257, 64, 0.0),
+                                           (513, 1000, 64, 0.09), (5, 4096, 128, 0.01)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("bias", [True, False])
+def test_sparse_input_norm_linear_matches_float64_and_the_dense_kernels(n, d, O, density, p, bias, device, monkeypatch):
+    """Bag-of-words features (csrc/sparse_input.hip): output and all four parameter gradients from the non-zeros only, against float64
+    torch and against the dense kernels of the same layer under the SAME dropout seed.  Rows without any non-zero (and, with dropout,
+    rows whose non-zeros are all dropped) are constant rows: LayerNorm gives beta, as torch does."""
+    from allset_amd import dense
+    torch.manual_seed(n + d + O)
+    x = (torch.rand(n, d) < density).float() * (1.0 + torch.rand(n, d).round())          # values 1 / 2
+    x[: min(3, n)] = 0.0                                                                     # empty rows
+    x = x.to(device)
+    gamma = (1.0 + 0.3 * torch.randn(d)).to(device).requires_grad_(True)
+    beta = (0.2 * torch.randn(d)).to(device).requires_grad_(True)
+    W = (torch.randn(O, d) / d ** 0.5).to(device).requires_grad_(True)
+    b = torch.randn(O).to(device).requires_grad_(True) if bias else None
+    sp = dense.sparse_rows(x)
+    assert sp is not None and sp.nnz == int((x != 0).sum())
+    seeds = []
+    monkeypatch.setattr(dense, "_draw_seed", lambda: seeds.append(777 + len(seeds)) or seeds[-1])
+    taken = []
+    real = dense._SparseInputNormLinear.apply
+    monkeypatch.setattr(dense._SparseInputNormLinear, "apply", staticmethod(lambda *a: taken.append(1) or real(*a)))
+    y = dense.input_norm_linear(x, gamma, beta, W, b, 1e-5, p)
+    assert taken
+    G = torch.randn_like(y)
+    (y * G).sum().backward()
+    got = [t.grad.clone() if t is not None else None for t in (gamma, beta, W, b)]
+    keep = (dense.dropout_scale((n, d), p, seeds[0], device) != 0) if p > 0.0 else None
+    prm = [t.detach().double().requires_grad_(True) if t is not None else None for t in (gamma, beta, W, b)]
+    yr = _ref(x, keep, p, *prm, 1e-5)
+    (yr * G.double()).sum().backward()
+    torch.testing.assert_close(y.double(), yr, rtol=2e-5, atol=2e-5 * float(yr.abs().max()))
+    for g, exp, what in zip(got, prm, ("ggamma", "gbeta", "gW", "gb")):
+        if g is not None:
+            torch.testing.assert_close(g.double(), exp.grad, rtol=5e-5, atol=5e-5 * float(exp.grad.abs().max()), msg=lambda m: f"{what}: {m}")
+    # the dense kernels of the same layer, same seed
+    for t in (gamma, beta, W, b):
+        if t is not None:
+            t.grad = None
+    seeds.clear()
+    y2 = dense._InputNormLinear.apply(x, gamma, beta, W, b, 1e-5, float(p))
+    (y2 * G).sum().backward()
+    torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5 * float(y2.abs().max()))
+    for g, t, what in zip(got, (gamma, beta, W, b), ("ggamma", "gbeta", "gW", "gb")):
+        if g is not None:
+            torch.testing.assert_close(g, t.grad, rtol=2e-5, atol=2e-5 * float(t.grad.abs().max()), msg=lambda m: f"dense vs sparse {what}: {m}")
+
+
+def test_sparse_rows_cache_follows_the_tensor(device):
+    from allset_amd import dense
+    x = (torch.rand(200, 500, device=device) < 0.02).float()
+    a = dense.sparse_rows(x)
+    assert a is not None and dense.sparse_rows(x) is a
+    x[0, 0] = 5.0                                           # in-place update: rebuilt
+    b = dense.sparse_rows(x)
+    assert b is not a and b.nnz == int((x != 0).sum())
+    assert dense.sparse_rows(torch.rand(50, 400, device=device)) is None           # dense features: the GEMM path
+    rp, cp = b.rowptr.cpu(), b.colptr.cpu()
+    assert int(rp[-1]) == b.nnz == int(cp[-1])
+    dense_again = torch.zeros_like(x)
+    rows = torch.repeat_interleave(torch.arange(200, device=device), (b.rowptr[1:] - b.rowptr[:-1]).long())
+    dense_again[rows, b.col.long()] = b.val
+    assert torch.equal(dense_again, x)
+    assert torch.equal(b.val[b.posT.long()], x[b.rowT.long(), torch.repeat_interleave(torch.arange(500, device=device), (b.colptr[1:] - b.colptr[:-1]).long())])
