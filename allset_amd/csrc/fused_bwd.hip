@@ -539,6 +539,16 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   int64_t ldacc, const float* aux_g, const float* aux_w, int64_t gcb, int64_t xcb, int64_t gxcb,
                                   float ln_inv);
 
+// fused_bwd6.hip: the split-role pass on two fp16 planes per operand (three MFMAs per product instead of six), eight vector
+// waves: behind a true LayerNorm prologue at O = I = 128; same grid and partial slices as the kernel above
+int fused_linear_bwd_f16x3_supported(int64_t O, int64_t I, int has_ln, int norm_mode, int has_acc, int has_aux);
+int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool drop, bool relu, bool hm, const float* gy, int64_t ldg,
+                                  const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
+                                  const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                                  float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
+                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, int64_t gcb, int64_t xcb,
+                                  int64_t gxcb);
+
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
   return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
@@ -670,6 +680,14 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
+#ifndef ALLSET_NO_F16X3
+  if (roles_kernel && fused_linear_bwd_f16x3_supported(O, I, has_ln, norm_mode, ha, 0)) {
+    launch_fused_linear_bwd_f16x3(grid, st, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in, gx,
+                                  ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, gcb, xcb, gxcb);
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
+#endif
   if (roles_kernel) {                                            // one partial per workgroup
     launch_fused_linear_bwd_roles(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in,
                                   seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, acc_in, ldacc,

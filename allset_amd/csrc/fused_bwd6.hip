@@ -1,0 +1,597 @@
+// The one-pass backward of the fused Linear behind a true LayerNorm prologue (O = I = 128), split by role like fused_bwd4.hip,
+// with the fp32 products formed from TWO fp16 planes per operand instead of three bf16 planes ("fp16x3"):
+//
+//     x s = h + l,  h = fp16(x s),  l = fp16(x s - h)         (s a power of two: the scaling is exact)
+//     (x s)(w t) = h h' + h l' + l h'  + (l l' <= 2^-22 |x w s t|, dropped)
+//
+// Three f16 MFMAs replace the six bf16 ones (and one fp32 MFMA at 1/16 the rate); the two planes carry 22+ significant bits, and
+// measured against float64 the result is as accurate as a library fp32 GEMM (rms 1.2e-8 of sum |terms|, bf16x6
+// 0.7e-8, sequential fp32 2.6e-8).  fp16 has 5 exponent bits, so every operand is brought into the window [2^-14, 2^15) by a
+// power-of-two scale that leaves the arithmetic exact:
+//   ga (masked gy)  per ROW: its largest element lands in [2^13, 2^14); the row's gu is unscaled in the LayerNorm backward;
+//   W               per matrix wave's slice (32 columns); unscaled where the wave writes its gu tile;
+//   u (the Linear's input, recomputed)  the weight gradient sums over rows, so a row scale cannot be taken out of the sum: the
+//       scales of ga and u must multiply to ONE constant.  u = (LayerNorm output) * keep is bounded by
+//       U = (sqrt(127) max|gamma| + max|beta|) * keep -- no data pass needed -- and row r of u is written as
+//       u 2^Su 2^(e_r - E), e_r = ga's row exponent, E = the largest row exponent the workgroup has seen so far: rows whose
+//       gradient is far below the largest one lose low bits of a contribution that is that much smaller.  When a stage raises E
+//       the matrix waves rescale their gW accumulators by the (exact) power of two before adding it -- the online-softmax trick.
+// An element below 2^-14 of its window is a denormal or flushed: an error <= 2^-28 of the row's (or the workgroup's) largest
+// term, below fp32 rounding of the sum.
+//
+// What the lighter matrix side buys is OCCUPANCY for the vector role: a matrix wave holds 32 registers of W fragments (the h plane;
+// the l plane, used once per k-step, is read fragment by fragment from LDS) where fused_bwd4.hip held 96, so the kernel fits 168
+// registers per wave and the CU twelve waves -- EIGHT vector waves, two per SIMD, each with one row per 16-lane group instead of
+// two -- and the vector role's dependent chains (LDS round trips, DPP row sums, the split itself) are hidden by the twin on the
+// same SIMD; fused_bwd4's single vector wave per SIMD issued one instruction per ~8 cycles.
+//
+// Stage = 32 rows, two ticks per stage, one barrier per tick (the pipeline of fused_bwd4.hip):
+//     tick 2k    vector: S0(k+1): gy -> mask -> row scale -> ga[(k+1) % 3];  S2a(k): x -> xhat, keep factors   | matrix: S1(k): gu = ga W
+//     tick 2k+1  vector: S2b(k): gu -> LayerNorm backward -> gx;  u -> u[k % 2]                                | matrix: S3(k-1): gW += ga^T u
+//   vector wave v: rows 4 v .. 4 v + 3 of the stage, one row per DPP row of 16 lanes, 8 elements per lane;
+//   matrix wave m: S1 for output columns 32 m .. 32 m + 31 (48 MFMAs 16x16x32 per stage); S3 for the 64 x 64 tile (m >> 1, m & 1)
+//     of the workgroup's ONE gW (24 MFMAs 32x32x16 per stage).
+// LDS: 3 x 16 KB ga + 2 x 16 KB u + 16.5 KB gu + 32 KB W l-plane + gamma / beta + the row-exponent slots = 130 KB.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace allset {
+
+using f16x8s = __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16;
+using f32x4s = __attribute__((ext_vector_type(4))) float;
+using f32x16s = __attribute__((ext_vector_type(16))) float;
+typedef short v4ss_t __attribute__((ext_vector_type(4)));
+union FragS { uint4 u; f16x8s v; struct { v4ss_t lo, hi; } t; };
+constexpr int kSBlock = 768;
+constexpr int kSRows = 32;                     // rows per stage
+constexpr int kSVWaves = 8;
+constexpr int kSTop = 13;                      // a scaled row's largest element lies in [2^13, 2^14)
+constexpr int kSEMin = 20;                     // floor of the biased row exponent (rows below 2^-107 are treated as that small)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_fs(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum_s(float v) {     // sum over the 16 lanes of a DPP row, result in every lane of it
+  v += dpp_fs<0xB1>(v);
+  v += dpp_fs<0x4E>(v);
+  v += dpp_fs<0x141>(v);
+  v += dpp_fs<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max_s(float v) {     // max over the 16 lanes of a DPP row (v >= 0)
+  v = fmaxf(v, dpp_fs<0xB1>(v));
+  v = fmaxf(v, dpp_fs<0x4E>(v));
+  v = fmaxf(v, dpp_fs<0x141>(v));
+  v = fmaxf(v, dpp_fs<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float amax4_s(float4 a, float m) {
+  return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), m);
+}
+// 2^(field - 127) for a biased exponent field in [0, 254] (0 -> 0.0)
+__device__ __forceinline__ float pow2_field_s(int field) { return __uint_as_float(static_cast<uint32_t>(field) << 23); }
+// x0, x1 -> packed fp16 planes {hi half: x1, lo half: x0}: h = RN16(x), l = RN16(x - h) (x - h is exact in fp32)
+__device__ __forceinline__ void split2_f16(float x0, float x1, uint32_t& ph, uint32_t& pl) {
+  float r0, r1;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(x0), "v"(x1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl) : "v"(r0), "v"(r1));
+}
+__device__ __forceinline__ f16x8s tr_frag2_s(const uint8_t* lo, const uint8_t* hi) {
+  FragS f;
+  f.t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4ss_t*)(lo));
+  f.t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4ss_t*)(hi));
+  return f.v;
+}
+// byte offset of (row, column byte) in a [rows][256 B] 16-bit plane (fused_bwd4.hip img_off_r: conflict-free for both the row-wise
+// 16-byte fragment reads and the transpose reads)
+__device__ __forceinline__ int img_off_s(int row, int colbyte) {
+  return row * 256 + ((((colbyte >> 6) ^ row) & 3) << 6) + (((((colbyte >> 4) & 3) ^ (row >> 2)) & 3) << 4) + (colbyte & 15);
+}
+__device__ __forceinline__ uint32_t hash_mix_s(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; return x; }
+#define ALLSET_S_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define ALLSET_FRESH_LANE_S(name) \
+  int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
+
+template <bool DROP_IN, bool RELU_IN, bool HAS_MASK>
+__global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
+    const float* __restrict__ gy, int64_t ldg, const uint32_t* __restrict__ mask, float p_out, const float* __restrict__ W,
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
+    float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
+    const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, int64_t gcb, int64_t xcb,
+    int64_t gxcb) {
+  // gcb / xcb / gxcb: 0 = row-major with the operand's leading dimension; cb > 0 = COLUMN-BLOCKED [128 / cb][n][cb] (ld == cb) for
+  // gy / x / gx (fused_bwd4.hip)
+  constexpr int OD = 128, ID = 128;
+  constexpr int R = kSRows;
+  constexpr int PLANE = R * 256;                 // bytes per fp16 plane of an image
+  constexpr int IMG = 2 * PLANE;                 // one image: planes h, l
+  constexpr int SPG = 132;                       // pitch (floats) of the gu tile
+  __shared__ __attribute__((aligned(16))) uint8_t sGA[3 * IMG];
+  __shared__ __attribute__((aligned(16))) uint8_t sU[2 * IMG];
+  __shared__ __attribute__((aligned(16))) float sGU[R * SPG];
+  __shared__ __attribute__((aligned(16))) float sG[ID];
+  __shared__ __attribute__((aligned(16))) float sB[ID];
+  __shared__ __attribute__((aligned(16))) uint8_t sWL[4 * 2 * 4 * 64 * 16];     // W's l plane: [matrix wave][ct][k-step][lane] fragments
+  __shared__ __attribute__((aligned(16))) int sE[4 * kSVWaves];       // [stage % 4][vector wave]: largest row exponent of its rows
+  seed_in = resolve_seed(seed_base, seed_in);
+  const int tid = threadIdx.x;
+  if (tid < ID) { sG[tid] = gamma[tid]; sB[tid] = beta[tid]; }
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n_stages = (n + R - 1) / R;
+  // this workgroup's stages: blockIdx.x + k * gridDim.x, k = 0 .. T - 1 (T >= 1: the grid never exceeds the stage count)
+  const int64_t T = (n_stages - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  auto stage_of = [&](int64_t k) -> int64_t { return blockIdx.x + k * static_cast<int64_t>(gridDim.x); };
+  auto rows_left = [&](int64_t stage) -> int {
+    const int64_t left = n - stage * R;
+    return left >= R ? R : (left > 0 ? static_cast<int>(left) : 0);
+  };
+  __syncthreads();
+  // Su: u 2^Su < 2^14 for every element of u = (xhat gamma + beta) keep, |xhat| <= sqrt(127); every wave derives it itself
+  const float keep_in_all = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
+  int Su;
+  {
+    float g = fmaxf(fabsf(sG[lane0]), fabsf(sG[lane0 + 64])), b = fmaxf(fabsf(sB[lane0]), fabsf(sB[lane0 + 64]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { g = fmaxf(g, __shfl_xor(g, off)); b = fmaxf(b, __shfl_xor(b, off)); }
+    const float U = (11.27f * g + b) * keep_in_all;
+    const int eU = static_cast<int>(__float_as_uint(U) >> 23);          // U < 2^(eU - 126)
+    Su = __builtin_amdgcn_readfirstlane(min(max(140 - eU, -40), 60));
+  }
+  // the largest biased row exponent of stages 0 .. k, from the slots the vector waves filled in S0
+  auto stage_emax = [&](int64_t k) -> int {
+    const int4 a = *reinterpret_cast<const int4*>(&sE[(k & 3) * kSVWaves]), b = *reinterpret_cast<const int4*>(&sE[(k & 3) * kSVWaves + 4]);
+    return __builtin_amdgcn_readfirstlane(max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))));
+  };
+
+  if (wave < kSVWaves) {
+    // =================================================== vector waves ===================================================
+    const float inv_i = 1.f / static_cast<float>(ID);
+    const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
+    const float keep_in = keep_in_all;
+    const uint32_t thr_in = drop_threshold(p_in);
+    const uint32_t seed_lo = static_cast<uint32_t>(seed_in);
+    const int c = lane0 & 15, rg = lane0 >> 4;
+    const int lr = 4 * wave + rg;                // this lane's row of a stage; columns 64 hb + 4 c .. + 3, hb = 0, 1
+    float4 dg[2], db[2], gbv[2];
+    const int c40 = 4 * c;
+    const uint32_t cog0 = gcb ? static_cast<uint32_t>(((c40 / gcb) * n * gcb + c40 % gcb) * 4) : 4u * c40;
+    const uint32_t cox0 = xcb ? static_cast<uint32_t>(((c40 / xcb) * n * xcb + c40 % xcb) * 4) : 4u * c40;
+    const uint32_t cogx0 = gxcb ? static_cast<uint32_t>(((c40 / gxcb) * n * gxcb + c40 % gxcb) * 4) : 4u * c40;
+    const int64_t dhg = gcb ? 256 * n : 256, dhx = xcb ? 256 * n : 256, dhgx = gxcb ? 256 * n : 256;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); gbv[hb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // Two register sets each: the operands of the next TWO stages are in flight (16 waves x 2 KB x 2 = 64 KB per CU)
+    float4 agS[2][2]; uint32_t amS[2][2];            // [set][hb]: gy row / mask words
+    float4 xrS[2][2]; float2 stS[2];                 // [set][hb]: x row; [set]: statistics
+    auto request_gy = [&](int64_t k, float4 (&ag)[2], uint32_t (&am)[2]) {
+      const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);           // past the end: re-read the last stage (never consumed)
+      const int nrc = max(rows_left(s0), 1);
+      const int lrc = min(lr, nrc - 1);
+      const char* base = reinterpret_cast<const char*>(gy + s0 * R * ldg);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        ag[hb] = *reinterpret_cast<const float4*>(base + hb * dhg + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldg) * 4u + cog0));
+        if constexpr (HAS_MASK)   // "mask layout" (include/allset_hip.h): block (row / 16, column / 64), dword (row % 16, 32-column group)
+          am[hb] = (mask + ((s0 * (R / 16) + (lrc >> 4)) * (OD / 64) + hb) * 32)[((lrc & 15) >> 2) * 8 + (lrc & 3) * 2 + (c >> 3)];
+      }
+    };
+    auto request_x = [&](int64_t k, float4 (&xr)[2], float2& st) {
+      const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);
+      const int nrc = max(rows_left(s0), 1);
+      const int lrc = min(lr, nrc - 1);
+      const char* xb = reinterpret_cast<const char*>(x + s0 * R * ldx);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+        xr[hb] = *reinterpret_cast<const float4*>(xb + hb * dhx + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + cox0));
+      st = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(stats + s0 * R * 2) + lrc * 8);
+    };
+    int eNext = kSEMin, eCur = kSEMin;            // biased row exponent of ga: stage k + 1 (written by S0), stage k (read by S2b)
+    int Erun = kSEMin;                            // max over the stages up to the one S2b is working on
+    // ---- S0(k): ga = gy under the forward's epilogue mask, scaled to the row's window, two fp16 planes into ga[k % 3]
+    auto S0 = [&](int64_t k, float4 (&ag)[2], uint32_t (&am)[2]) {
+      const int nrows = rows_left(stage_of(k));
+      const bool valid = lr < nrows;
+      uint8_t* img = sGA + (k % 3) * IMG;
+      float4 v[2];
+      float amax = 0.f;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        v[hb] = ag[hb];
+        if constexpr (HAS_MASK) {
+          const uint32_t bits = valid ? (am[hb] >> (c & 7)) : 0u;    // bit 8 q + (c % 8) for column 64 hb + 4 c + q
+          v[hb].x = (bits & 0x1u) ? v[hb].x * keep_out : 0.f; v[hb].y = (bits & 0x100u) ? v[hb].y * keep_out : 0.f;
+          v[hb].z = (bits & 0x10000u) ? v[hb].z * keep_out : 0.f; v[hb].w = (bits & 0x1000000u) ? v[hb].w * keep_out : 0.f;
+        } else {
+          v[hb].x = valid ? v[hb].x : 0.f; v[hb].y = valid ? v[hb].y : 0.f; v[hb].z = valid ? v[hb].z : 0.f; v[hb].w = valid ? v[hb].w : 0.f;
+        }
+        gbv[hb].x += v[hb].x; gbv[hb].y += v[hb].y; gbv[hb].z += v[hb].z; gbv[hb].w += v[hb].w;      // bias gradient: column sums of ga
+        amax = amax4_s(v[hb], amax);
+      }
+      amax = row16_max_s(amax);
+      const int e = min(max(static_cast<int>(__float_as_uint(amax) >> 23), kSEMin), 254);
+      eNext = e;
+      const float sa = pow2_field_s(254 + kSTop - e);        // row max -> [2^13, 2^14)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        uint32_t h0, l0, h1, l1;
+        split2_f16(v[hb].x * sa, v[hb].y * sa, h0, l0);
+        split2_f16(v[hb].z * sa, v[hb].w * sa, h1, l1);
+        const int wo = img_off_s(lr, 128 * hb + 8 * c);
+        *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(l0, l1);
+      }
+      // the wave's largest row exponent -> its slot of the stage (all lanes store the same word)
+      const int ew = max(max(__builtin_amdgcn_readlane(e, 0), __builtin_amdgcn_readlane(e, 16)),
+                         max(__builtin_amdgcn_readlane(e, 32), __builtin_amdgcn_readlane(e, 48)));
+      sE[(k & 3) * kSVWaves + wave] = ew;
+      __builtin_amdgcn_sched_barrier(0);
+      request_gy(k + 2, ag, am);                  // into the set just consumed: two stages ahead
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- S2a(k): what needs only x: xhat, the keep factors, the relu signs -- kept in registers for S2b(k)
+    float4 xhK[2];             // xhat of stage k, [hb]
+    float4 kpK[2];             // dropout-in keep factors (keep_in or 0)
+    uint32_t xbK = 0;          // "raw x > 0" flags, bit 4 hb + q
+    float rstdK = 1.f;
+    auto S2a = [&](int64_t k, float4 (&xr)[2], float2& st) {
+      const int64_t stage = stage_of(k);
+      const int nrows = rows_left(stage);
+      const bool live = lr < nrows;
+      const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * ID / 2);
+      const uint32_t stage_pair_lo = static_cast<uint32_t>(stage_pair);
+      const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_pair >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
+      const uint64_t stage_quad = static_cast<uint64_t>(stage) * (R * ID / 4);
+      const uint32_t stage_quad_lo = static_cast<uint32_t>(stage_quad);
+      const uint32_t hi_term_q = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
+      xbK = 0;
+      const float mean = st.x, rstd = st.y;
+      rstdK = rstd;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (DROP_IN) {
+          // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
+          if (thr_in & kDrop8) {     // 8 bits per element: ONE hash for the lane's float4 (quad index = stage * 1024 + lane part)
+            const uint32_t lo = stage_quad_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 2);
+            const uint32_t h = hash_mix_s((lo ^ seed_lo) * 0x9E3779B1U + hi_term_q), t8 = thr_in & 0xffu;
+            kp.x = (h & 0xffu) >= t8 ? keep_in : 0.f; kp.y = ((h >> 8) & 0xffu) >= t8 ? keep_in : 0.f;
+            kp.z = ((h >> 16) & 0xffu) >= t8 ? keep_in : 0.f; kp.w = (h >> 24) >= t8 ? keep_in : 0.f;
+          } else {
+            const uint32_t lo = stage_pair_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 1);
+            const uint32_t h0 = hash_mix_s((lo ^ seed_lo) * 0x9E3779B1U + hi_term);
+            const uint32_t h1 = hash_mix_s(((lo + 1u) ^ seed_lo) * 0x9E3779B1U + hi_term);
+            kp.x = (h0 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.y = (h0 >> 16) >= thr_in ? keep_in : 0.f;
+            kp.z = (h1 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.w = (h1 >> 16) >= thr_in ? keep_in : 0.f;
+          }
+        }
+        kpK[hb] = kp;
+        float4 t = xr[hb];
+        if (RELU_IN) {
+          xbK |= ((t.x > 0.f ? 1u : 0u) | (t.y > 0.f ? 2u : 0u) | (t.z > 0.f ? 4u : 0u) | (t.w > 0.f ? 8u : 0u)) << (4 * hb);
+          t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+        }
+        float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
+        xh.x = live ? xh.x : 0.f; xh.y = live ? xh.y : 0.f; xh.z = live ? xh.z : 0.f; xh.w = live ? xh.w : 0.f;
+        xhK[hb] = xh;
+      }
+      if constexpr (RELU_IN) __asm__ volatile("" : "+v"(xbK));     // (packed here, not at its use)
+      __builtin_amdgcn_sched_barrier(0);
+      request_x(k + 2, xr, st);                   // x is consumed: the request for two stages ahead goes out a tick earlier
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- S2b(k): gu -> LayerNorm backward -> gx; then u, scaled against the workgroup's largest row exponent, into u[k % 2]
+    auto S2b = [&](int64_t k) {
+      const int64_t stage = stage_of(k);
+      const int nrows = rows_left(stage);
+      const bool live = lr < nrows;
+      Erun = max(Erun, stage_emax(k));
+      const float inv_sa = pow2_field_s(eCur - kSTop);            // undoes the row scale of ga (the wave's W scale is undone by S1)
+      const int ffield = 127 + Su + eCur - Erun;
+      const float fu = pow2_field_s(live ? max(ffield, 0) : 0);     // (a dead row's u is 0: its xhat is, but beta is not)
+      float4 gam[2], v[2];
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
+        v[hb] = *reinterpret_cast<const float4*>(&sGU[lr * SPG + 64 * hb + 4 * c]);
+        v[hb].x *= inv_sa; v[hb].y *= inv_sa; v[hb].z *= inv_sa; v[hb].w *= inv_sa;
+        if constexpr (DROP_IN) { v[hb].x *= kpK[hb].x; v[hb].y *= kpK[hb].y; v[hb].z *= kpK[hb].z; v[hb].w *= kpK[hb].w; }
+        const float4 xh = xhK[hb];
+        dg[hb].x = fmaf(v[hb].x, xh.x, dg[hb].x); dg[hb].y = fmaf(v[hb].y, xh.y, dg[hb].y);
+        dg[hb].z = fmaf(v[hb].z, xh.z, dg[hb].z); dg[hb].w = fmaf(v[hb].w, xh.w, dg[hb].w);
+        db[hb].x += v[hb].x; db[hb].y += v[hb].y; db[hb].z += v[hb].z; db[hb].w += v[hb].w;
+        v[hb].x *= gam[hb].x; v[hb].y *= gam[hb].y; v[hb].z *= gam[hb].z; v[hb].w *= gam[hb].w;
+        a1 += (v[hb].x + v[hb].y) + (v[hb].z + v[hb].w);
+        a2 = fmaf(v[hb].x, xh.x, fmaf(v[hb].y, xh.y, fmaf(v[hb].z, xh.z, fmaf(v[hb].w, xh.w, a2))));
+      }
+      const float s1 = row16_sum_s(a1) * inv_i, s2 = row16_sum_s(a2) * inv_i;
+      const float rstd = rstdK;
+      uint8_t* img = sU + (k % 2) * IMG;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const float4 xh = xhK[hb];
+        float4 o = make_float4(rstd * (v[hb].x - s1 - xh.x * s2), rstd * (v[hb].y - s1 - xh.y * s2),
+                               rstd * (v[hb].z - s1 - xh.z * s2), rstd * (v[hb].w - s1 - xh.w * s2));
+        if (RELU_IN) {
+          const uint32_t xb = xbK >> (4 * hb);
+          o.x = (xb & 1u) ? o.x : 0.f; o.y = (xb & 2u) ? o.y : 0.f; o.z = (xb & 4u) ? o.z : 0.f; o.w = (xb & 8u) ? o.w : 0.f;
+        }
+        if (live)
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + stage * R * ldgx) +
+                                     hb * dhgx + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx0)) = o;
+        const float4 bet = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
+        float4 u = make_float4(fmaf(xh.x, gam[hb].x, bet.x), fmaf(xh.y, gam[hb].y, bet.y), fmaf(xh.z, gam[hb].z, bet.z), fmaf(xh.w, gam[hb].w, bet.w));
+        if constexpr (DROP_IN) { u.x *= kpK[hb].x; u.y *= kpK[hb].y; u.z *= kpK[hb].z; u.w *= kpK[hb].w; }
+        uint32_t h0, l0, h1, l1;
+        split2_f16(u.x * fu, u.y * fu, h0, l0);
+        split2_f16(u.z * fu, u.w * fu, h1, l1);
+        const int wo = img_off_s(lr, 128 * hb + 8 * c);
+        *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(l0, l1);
+      }
+      eCur = eNext;                               // S0(k + 1) ran in the previous tick
+    };
+
+    request_gy(0, agS[0], amS[0]);
+    request_x(0, xrS[0], stS[0]);
+    request_gy(1, agS[1], amS[1]);
+    request_x(1, xrS[1], stS[1]);
+    S0(0, agS[0], amS[0]);
+    eCur = eNext;
+    ALLSET_S_TICK();
+    // Two stages per trip: stage k lives in register set 0, stage k + 1 in set 1; no conditional half inside the trip (fused_bwd4.hip:
+    // the compiler's s_waitcnt insertion); an odd last stage is peeled off.
+    int64_t k = 0;
+    for (; k + 1 < T; k += 2) {
+      S0(k + 1, agS[1], amS[1]);
+      S2a(k, xrS[0], stS[0]);
+      ALLSET_S_TICK();
+      S2b(k);
+      ALLSET_S_TICK();
+      if (k + 2 < T) S0(k + 2, agS[0], amS[0]);
+      S2a(k + 1, xrS[1], stS[1]);
+      ALLSET_S_TICK();
+      S2b(k + 1);
+      ALLSET_S_TICK();
+    }
+    if (k < T) {                            // odd stage count: the last stage, in set 0
+      S2a(k, xrS[0], stS[0]);
+      ALLSET_S_TICK();
+      S2b(k);
+      ALLSET_S_TICK();
+    }
+    ALLSET_S_TICK();                        // (the matrix waves' last weight-gradient step)
+    // ---- column sums held by the vector waves (dgamma, dbeta, bias gradient): the four row groups of a lane column fold first,
+    // then the eight waves through LDS in a fixed order
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      float4 a = dg[hb], b = db[hb], g3 = gbv[hb];
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+        b.x += __shfl_xor(b.x, off); b.y += __shfl_xor(b.y, off); b.z += __shfl_xor(b.z, off); b.w += __shfl_xor(b.w, off);
+        g3.x += __shfl_xor(g3.x, off); g3.y += __shfl_xor(g3.y, off); g3.z += __shfl_xor(g3.z, off); g3.w += __shfl_xor(g3.w, off);
+      }
+      if (lane0 < 16) {                         // (gu is free: the last S2b read it two ticks ago)
+        *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + 64 * hb + 4 * lane0]) = a;
+        *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + ID + 64 * hb + 4 * lane0]) = b;
+        *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + 2 * ID + 64 * hb + 4 * lane0]) = g3;
+      }
+    }
+  } else {
+    // =================================================== matrix waves ===================================================
+    const int m = wave - kSVWaves;
+    const int oh = m >> 1, ih = m & 1;           // weight-gradient tile: o in [64 oh, +64), i in [64 ih, +64)
+    // ---- this wave's slice of W (32 columns 32 m + 16 ct + nn) as MFMA B fragments: column tile ct, k-step t; lane (nn = lane & 15,
+    // kg = lane >> 4) holds W[o = 32 kg + 8 t + j][column], j = 0..7, scaled so that the slice's largest element lies in
+    // [2^13, 2^14).  The h plane stays in 32 registers; the l plane is used once per k-step and lives in LDS, fragment by fragment.
+    FragS wq[2][4];
+    float inv_sw;
+    uint4* wl = reinterpret_cast<uint4*>(sWL) + m * (2 * 4 * 64) + lane0;        // [m][ct][t][lane]
+    {
+      const int nn = lane0 & 15, kg = lane0 >> 4;
+      float wv[2][4][8];                          // (read once: 64 registers that the accumulators take over afterwards)
+      float amax = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            wv[ct][t][j] = W[(32 * kg + 8 * t + j) * ID + 32 * m + 16 * ct + nn];
+            amax = fmaxf(amax, fabsf(wv[ct][t][j]));
+          }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+      const int ew = __builtin_amdgcn_readfirstlane(min(max(static_cast<int>(__float_as_uint(amax) >> 23), kSEMin), 254));
+      const float sw = pow2_field_s(254 + kSTop - ew);
+      inv_sw = pow2_field_s(ew - kSTop);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          uint32_t ph[4], pl[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) split2_f16(wv[ct][t][2 * j] * sw, wv[ct][t][2 * j + 1] * sw, ph[j], pl[j]);
+          wq[ct][t].u = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          wl[(ct * 4 + t) * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+    }
+    f32x16s gw[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gw[a][b][q] = 0.f;
+    int Erun = kSEMin;
+
+    // ---- S1(k): backward-data for this wave's 32 output columns of the stage's 32 rows: 2 row tiles x 2 column tiles = four
+    // independent accumulator chains; the A fragments of step t + 1 are requested before step t's MFMAs
+    auto S1 = [&](int64_t k) {
+      ALLSET_FRESH_LANE_S(lane);
+      const int ri = lane & 15, kg = lane >> 4;
+      const uint8_t* img = sGA + (k % 3) * IMG;
+      auto load_a = [&](FragS (&f0)[2], FragS (&f1)[2], FragS (&fl)[2], int t) {
+        const int o0 = img_off_s(ri, 64 * kg + 16 * t), o1 = img_off_s(16 + ri, 64 * kg + 16 * t);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          f0[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o0);
+          f1[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o1);
+        }
+        fl[0].u = wl[(0 * 4 + t) * 64];
+        fl[1].u = wl[(1 * 4 + t) * 64];
+      };
+      FragS fa0[2][2], fa1[2][2], fwl[2][2];
+      f32x4s acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4s{0.f, 0.f, 0.f, 0.f};
+      load_a(fa0[0], fa1[0], fwl[0], 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t + 1 < 4) load_a(fa0[(t + 1) & 1], fa1[(t + 1) & 1], fwl[(t + 1) & 1], t + 1);
+        const FragS (&a0)[2] = fa0[t & 1];
+        const FragS (&a1)[2] = fa1[t & 1];
+        const FragS (&bl)[2] = fwl[t & 1];
+        // l.h, h.l, h.h
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[1].v, wq[0][t].v, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[1].v, wq[0][t].v, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[1].v, wq[1][t].v, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[1].v, wq[1][t].v, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[0].v, bl[0].v, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[0].v, bl[0].v, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[0].v, bl[1].v, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[0].v, bl[1].v, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[0].v, wq[0][t].v, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[0].v, wq[0][t].v, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[0].v, wq[1][t].v, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[0].v, wq[1][t].v, acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // acc[rt][ct][r] = gu[row 16 rt + 4 kg + r][column 32 m + 16 ct + ri] * (row scale) * (slice scale): the slice scale goes here
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sGU[(16 * rt + 4 * kg + r) * SPG + 32 * m + 16 * ct + ri] = acc[rt][ct][r] * inv_sw;
+    };
+    // ---- S3(k): weight gradient, this wave's 64 x 64 tile of gW; K = the stage's 32 rows in two steps of 16; A = ga^T, B = u
+    auto S3 = [&](int64_t k) {
+      ALLSET_FRESH_LANE_S(lane_w);
+      const int Ek = stage_emax(k);
+      if (Ek > Erun) {                            // a larger row exponent: bring the accumulated sum to the new scale (exact)
+        const float f = pow2_field_s(max(127 - (Ek - Erun), 0));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) gw[a][b][q] *= f;
+        Erun = Ek;
+      }
+      const uint8_t* ia = sGA + (k % 3) * IMG;
+      const uint8_t* iu = sU + (k % 2) * IMG;
+      const int q4 = lane_w >> 4, tr_r = (lane_w & 15) >> 2, tr_row = 8 * (q4 >> 1) + tr_r, tr_in = 32 * (q4 & 1) + 8 * (lane_w & 3);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f16x8s wa[2][2], wb[2][2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const int a_lo = img_off_s(16 * kb + tr_row, 64 * (2 * oh + tl) + tr_in), a_hi = img_off_s(16 * kb + tr_row + 4, 64 * (2 * oh + tl) + tr_in);
+          const int b_lo = img_off_s(16 * kb + tr_row, 64 * (2 * ih + tl) + tr_in), b_hi = img_off_s(16 * kb + tr_row + 4, 64 * (2 * ih + tl) + tr_in);
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            wa[tl][pl] = tr_frag2_s(ia + pl * PLANE + a_lo, ia + pl * PLANE + a_hi);
+            wb[tl][pl] = tr_frag2_s(iu + pl * PLANE + b_lo, iu + pl * PLANE + b_hi);
+          }
+        }
+        constexpr int PA_[3] = {1, 0, 0}, PB_[3] = {0, 1, 0};     // l.h, h.l, h.h
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          gw[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][PA_[pr]], wb[0][PB_[pr]], gw[0][0], 0, 0, 0);
+          gw[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][PA_[pr]], wb[0][PB_[pr]], gw[1][0], 0, 0, 0);
+          gw[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][PA_[pr]], wb[1][PB_[pr]], gw[0][1], 0, 0, 0);
+          gw[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][PA_[pr]], wb[1][PB_[pr]], gw[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    ALLSET_S_TICK();
+    for (int64_t k = 0; k < T; ++k) {
+      S1(k);
+      ALLSET_S_TICK();
+      if (k >= 1) S3(k - 1);
+      ALLSET_S_TICK();
+    }
+    S3(T - 1);
+    ALLSET_S_TICK();
+    // ---- the workgroup's gW partial: each matrix wave its 64 x 64 tile; the accumulators hold gW 2^(kSTop + 127 + Su - Erun)
+    {
+      const int X = Erun - 127 - kSTop - Su;      // in [-180, 154]: applied as two factors
+      const int X1 = X >> 1, X2 = X - X1;
+      const float f1 = pow2_field_s(127 + X1), f2 = pow2_field_s(127 + X2);
+      float* pw = part_w + static_cast<int64_t>(blockIdx.x) * pstride_w;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int o = (2 * oh + a) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane0 >> 5);
+            pw[o * ID + (2 * ih + b) * 32 + (lane0 & 31)] = (gw[a][b][q] * f1) * f2;
+          }
+    }
+  }
+  __syncthreads();
+  if (tid < 3 * ID) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < kSVWaves; ++v) s += sGU[v * 3 * ID + tid];
+    const int64_t slice = blockIdx.x;
+    if (tid < 2 * ID) part_ln[slice * pstride_ln + tid] = s;
+    else if (part_b != nullptr) part_b[slice * pstride_b + (tid - 2 * ID)] = s;
+  }
+}
+
+}  // namespace allset
+
+using namespace allset;
+
+// 1 = the fp16x3 kernel takes this call: O = I = 128 behind a true LayerNorm prologue (row statistics on: the bound on u it scales
+// with needs them), no second gradient branch, no auxiliary columns
+int fused_linear_bwd_f16x3_supported(int64_t O, int64_t I, int has_ln, int norm_mode, int has_acc, int has_aux) {
+  return (O == 128 && I == 128 && has_ln && norm_mode == ALLSET_NORM_LAYER && !has_acc && !has_aux) ? 1 : 0;
+}
+
+// Called by allset_fused_linear_bwd_all (fused_bwd.hip) after its argument checks; ONE partial slice per workgroup, the grid of
+// fused_linear_bwd_roles_grid (one persistent workgroup per CU).
+int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool drop, bool relu, bool hm, const float* gy, int64_t ldg,
+                                  const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
+                                  const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                                  float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
+                                  const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, int64_t gcb, int64_t xcb,
+                                  int64_t gxcb) {
+#define ALLSET_S_K(DI, RI, HM)                                                                                                  \
+  fused_linear_bwd_f16x3_kernel<DI, RI, HM><<<grid, kSBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, \
+                                                                      seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base,  \
+                                                                      psw, psb, psl, gcb, xcb, gxcb)
+#define ALLSET_S_M(DI, RI) do { if (hm) ALLSET_S_K(DI, RI, true); else ALLSET_S_K(DI, RI, false); } while (0)
+  if (!relu) ALLSET_S_M(false, false);
+  else if (drop) ALLSET_S_M(true, true);
+  else ALLSET_S_M(false, true);
+#undef ALLSET_S_M
+#undef ALLSET_S_K
+  return 0;
+}

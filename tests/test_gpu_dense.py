@@ -313,6 +313,62 @@ def test_fused_linear_bf16x6_is_fp32_accurate(K, N, device, monkeypatch):
     assert errs["bf16x6"] < 2.0 * errs["f32"], errs
 
 
+@pytest.mark.parametrize("n", [1, 33, 4099, 70001])
+@pytest.mark.parametrize("kind", ["plain", "tiny", "huge", "row_scales", "late_large_row", "small_gamma", "column_scales"])
+def test_one_pass_backward_fp16x3_against_float64(n, kind, device):
+    """The LayerNorm-prologue backward at 128 x 128 runs fp32 on the f16 matrix pipe: two fp16 planes per operand, three products,
+    power-of-two operand scales (csrc/fused_bwd6.hip).  Against float64, in units of sum |terms| (the yardstick fp32 itself is held
+    to): a library fp32 GEMM's level on ordinary data whatever the overall scale of the gradient, the scale of each row (the kernel
+    scales rows), or a late row that raises the workgroup's running exponent by 40 binary orders; the one documented weakness is a
+    gradient COLUMN far below the largest element of its rows (the planes are scaled per row): its gW row then carries an absolute
+    error of 2^-38 of the row's largest gradient times |u| per term -- tested at 24 binary orders of column range."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(1000 * n + len(kind))
+    x = torch.randn(n, 128, generator=g) * 3 + 0.5
+    W = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.3 * torch.randn(128, generator=g)
+    G = torch.randn(n, 128, generator=g)
+    if kind == "tiny":
+        G = G * 1e-9
+    elif kind == "huge":
+        G = G * 1e9
+    elif kind == "row_scales":
+        G = G * torch.exp2(torch.randint(-30, 31, (n, 1), generator=g).float())
+    elif kind == "late_large_row":
+        G = G * 1e-6
+        G[-1] *= 1e12
+        G[n // 2] = 0
+    elif kind == "small_gamma":
+        gamma, beta = gamma * 1e-4, beta * 1e-4
+    elif kind == "column_scales":
+        G = G * torch.exp2(torch.randint(-12, 13, (1, 128), generator=g).float())
+    G, W, x, gamma, beta = (t.to(device) for t in (G, W, x, gamma, beta))
+    y, st = dense.fused_linear_fwd(x, W, torch.zeros(128, device=device), gamma, beta, 1e-5, False, 0.0, 0, False, 0.0, 0, None, None)
+    gx, dg, db, gw, gb = dense.fused_linear_bwd_all(G, None, 0.0, W, x, st, gamma, beta, False, 0.0, 0)
+    Gd, Wd, xd, gd, bd = G.double(), W.double(), x.double(), gamma.double(), beta.double()
+    mean = xd.mean(1, keepdim=True)
+    rstd = (((xd - mean) ** 2).mean(1, keepdim=True) + 1e-5).rsqrt()
+    xh = (xd - mean) * rstd
+    u = xh * gd + bd
+    gu = Gd @ Wd
+    v = gu * gd
+    ref_gx = rstd * (v - v.mean(1, keepdim=True) - xh * (v * xh).mean(1, keepdim=True))
+    den_w = Gd.abs().t() @ u.abs() + 1e-300
+    if kind == "column_scales":       # the per-row window: + 2^-38 max_o |gy[r, o]| |u[r, i]| per term
+        den_w = den_w + 2.0 ** -17 * (Gd.abs().max(1, keepdim=True).values.expand(-1, 128).t() @ u.abs())
+    den_gu = (Gd.abs() @ Wd.abs()).max(1, keepdim=True).values * rstd * gd.abs().max() + 1e-300
+    e_gw = float(((gw.double() - Gd.t() @ u).abs() / den_w).max())
+    e_gx = float(((gx.double() - ref_gx).abs() / den_gu).max())
+    e_gb = float(((gb.double() - Gd.sum(0)).abs() / (Gd.abs().sum(0) + 1e-300)).max())
+    gu_abs = Gd.abs() @ Wd.abs()
+    e_dg = float(((dg.double() - (gu * xh).sum(0)).abs() / ((gu_abs * xh.abs().max()).sum(0) + 1e-300)).max())
+    e_db = float(((db.double() - gu.sum(0)).abs() / (gu_abs.sum(0) + 1e-300)).max())
+    assert torch.isfinite(gw).all() and torch.isfinite(gx).all()
+    # a single product (n = 1, or one dominant row) is off by <= 2^-21 + 2^-22 from the planes + the fp32 rounding of u itself
+    lim_w = 4e-6 if (n < 64 or kind == "late_large_row") else 2e-7
+    assert e_gw < lim_w and e_gx < 1e-6 and e_gb < 3e-7 and e_dg < 3e-7 and e_db < 3e-7, (e_gw, e_gx, e_gb, e_dg, e_db)
+
+
 @pytest.mark.parametrize("N", [64, 128])
 def test_activation_mask_layout_and_use(N, device, monkeypatch):
     """The forward kernel's 1-bit mask follows the documented layout (include/allset_hip.h) and the backward kernels
