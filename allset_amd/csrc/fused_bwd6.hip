@@ -92,7 +92,11 @@ __device__ __forceinline__ int img_off_s(int row, int colbyte) {
   return row * 256 + ((((colbyte >> 6) ^ row) & 3) << 6) + (((((colbyte >> 4) & 3) ^ (row >> 2)) & 3) << 4) + (colbyte & 15);
 }
 __device__ __forceinline__ uint32_t hash_mix_s(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; return x; }
+#ifdef ALLSET_ABL6_NOBAR            // ablation builds only (tools/bwd_f16x3_ablation.py): timing without the barriers, results wrong
+#define ALLSET_S_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
 #define ALLSET_S_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 #define ALLSET_FRESH_LANE_S(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
@@ -132,6 +136,12 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     return left >= R ? R : (left > 0 ? static_cast<int>(left) : 0);
   };
   __syncthreads();
+#ifdef ALLSET_ABL6_TIMING          // diagnostic builds only: cycles per segment of waves 0 (vector) and 8 (matrix) of workgroup 0
+  uint64_t tph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define ALLSET_SMARK(k) do { const uint64_t tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define ALLSET_SMARK(k) do {} while (0)
+#endif
   // Su: u 2^Su < 2^14 for every element of u = (xhat gamma + beta) keep, |xhat| <= sqrt(127); every wave derives it itself
   const float keep_in_all = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
   int Su;
@@ -324,7 +334,11 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
           const uint32_t xb = xbK >> (4 * hb);
           o.x = (xb & 1u) ? o.x : 0.f; o.y = (xb & 2u) ? o.y : 0.f; o.z = (xb & 4u) ? o.z : 0.f; o.w = (xb & 8u) ? o.w : 0.f;
         }
+#ifdef ALLSET_ABL6_NOSTORE
+        if (live && o.x == 123.456f)
+#else
         if (live)
+#endif
           *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + stage * R * ldgx) +
                                      hb * dhgx + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx0)) = o;
         const float4 bet = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
@@ -350,17 +364,26 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     // Two stages per trip: stage k lives in register set 0, stage k + 1 in set 1; no conditional half inside the trip (fused_bwd4.hip:
     // the compiler's s_waitcnt insertion); an odd last stage is peeled off.
     int64_t k = 0;
+    ALLSET_SMARK(3);
     for (; k + 1 < T; k += 2) {
       S0(k + 1, agS[1], amS[1]);
       S2a(k, xrS[0], stS[0]);
+      ALLSET_SMARK(0);
       ALLSET_S_TICK();
+      ALLSET_SMARK(1);
       S2b(k);
+      ALLSET_SMARK(2);
       ALLSET_S_TICK();
+      ALLSET_SMARK(3);
       if (k + 2 < T) S0(k + 2, agS[0], amS[0]);
       S2a(k + 1, xrS[1], stS[1]);
+      ALLSET_SMARK(0);
       ALLSET_S_TICK();
+      ALLSET_SMARK(1);
       S2b(k + 1);
+      ALLSET_SMARK(2);
       ALLSET_S_TICK();
+      ALLSET_SMARK(3);
     }
     if (k < T) {                            // odd stage count: the last stage, in set 0
       S2a(k, xrS[0], stS[0]);
@@ -464,6 +487,9 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         const FragS (&a1)[2] = fa1[t & 1];
         const FragS (&bl)[2] = fwl[t & 1];
         // l.h, h.l, h.h
+#ifdef ALLSET_ABL6_NOMFMA
+        acc[0][0][0] += __builtin_bit_cast(float, a0[0].u.x ^ a0[1].u.y ^ bl[0].u.z ^ bl[1].u.w); acc[1][0][0] += __builtin_bit_cast(float, a1[0].u.x ^ a1[1].u.y);
+#else
         acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[1].v, wq[0][t].v, acc[0][0], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[1].v, wq[0][t].v, acc[1][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[1].v, wq[1][t].v, acc[0][1], 0, 0, 0);
@@ -476,6 +502,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[0].v, wq[0][t].v, acc[1][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[0].v, wq[1][t].v, acc[0][1], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[0].v, wq[1][t].v, acc[1][1], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // acc[rt][ct][r] = gu[row 16 rt + 4 kg + r][column 32 m + 16 ct + ri] * (row scale) * (slice scale): the slice scale goes here
@@ -516,6 +543,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
             wb[tl][pl] = tr_frag2_s(iu + pl * PLANE + b_lo, iu + pl * PLANE + b_hi);
           }
         }
+#ifdef ALLSET_ABL6_NOMFMA
+        { FragS f; f.v = wa[0][0]; FragS g2; g2.v = wb[1][1]; FragS g3; g3.v = wa[1][1]; FragS g4; g4.v = wb[0][0];
+          gw[0][0][0] += __builtin_bit_cast(float, f.u.x ^ g2.u.y ^ g3.u.z ^ g4.u.w); }
+#else
         constexpr int PA_[3] = {1, 0, 0}, PB_[3] = {0, 1, 0};     // l.h, h.l, h.h
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr) {
@@ -524,16 +555,22 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
           gw[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][PA_[pr]], wb[1][PB_[pr]], gw[0][1], 0, 0, 0);
           gw[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][PA_[pr]], wb[1][PB_[pr]], gw[1][1], 0, 0, 0);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 
     ALLSET_S_TICK();
+    ALLSET_SMARK(3);
     for (int64_t k = 0; k < T; ++k) {
       S1(k);
+      ALLSET_SMARK(0);
       ALLSET_S_TICK();
+      ALLSET_SMARK(1);
       if (k >= 1) S3(k - 1);
+      ALLSET_SMARK(2);
       ALLSET_S_TICK();
+      ALLSET_SMARK(3);
     }
     S3(T - 1);
     ALLSET_S_TICK();
@@ -555,6 +592,13 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     }
   }
   __syncthreads();
+#ifdef ALLSET_ABL6_TIMING
+  // vector wave 0: [0] S0 + S2a, [1] wait, [2] S2b, [3] wait; matrix wave 8: [4] S1, [5] wait, [6] S3, [7] wait  (cycles, all stages)
+  if (blockIdx.x == 0 && (tid == 0 || tid == 512)) {
+    float* dbg = part_w + (tid == 0 ? 0 : 4);         // over this workgroup's own gW entries (stored before the barrier above)
+    for (int q = 0; q < 4; ++q) dbg[q] = static_cast<float>(tph[q]);
+  }
+#endif
   if (tid < 3 * ID) {
     float s = 0.f;
 #pragma unroll

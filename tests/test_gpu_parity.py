@@ -52,8 +52,12 @@ def test_edge_index_is_rebased_in_place_like_the_reference(device):
     v = ei._version
     with torch.no_grad():
         again = res["model"](res["data"])
+        third = res["model"](res["data"])
     assert ei._version == v                                   # second call: untouched, cache hit
-    torch.testing.assert_close(again.cpu(), res["logits"], rtol=0, atol=0)    # deterministic kernels
+    torch.testing.assert_close(third, again, rtol=0, atol=0)  # deterministic kernels
+    # (run_product's forward differentiates with respect to x; a no-grad forward takes the raw features through
+    #  dense.input_norm_linear -- LayerNorm folded into one GEMM -- a different fp32 summation order)
+    torch.testing.assert_close(again.cpu(), res["logits"], rtol=1e-5, atol=1e-6)
 
 
 def test_learnmask_eval_follows_importance_between_no_grad_forwards(device):

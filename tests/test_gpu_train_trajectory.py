@@ -81,14 +81,24 @@ def test_training_trajectory_matches_the_oracle(name, over, device):
     # first three losses), every step on the small cases, and for the dataset-shaped ones afterwards only that the run trains like
     # the oracle's (5 % on each later loss).
     np.testing.assert_allclose(losses[:3], ref_losses[:3], rtol=2e-4, atol=2e-5)
+    # How far may a later loss sit from the float64 one?  As far as rounding alone moves THIS trajectory: the oracle evaluated in
+    # float32 (same math, torch CPU kernels) leaves its own float64 run by the amount that Adam's amplification of noise-level
+    # gradients and the relu kinks allow at that step -- three times that distance, and never less than the plain tolerance.  (A
+    # step where the float32 oracle stays on the float64 curve and the product does not is a product bug; one where both leave it --
+    # rand50_ds_add at lr = 0.01 oscillates from step nine on, 1.00 -> 1.18 -> 0.99 -- is the trajectory's conditioning.)
+    ref32, _ = trajectory_oracle(case, sd, y, train_idx, STEPS, lr, dtype=torch.float32)
+    own = np.abs(np.array(ref32) - np.array(ref_losses)) / np.abs(np.array(ref_losses))
     if case["big"]:
-        np.testing.assert_allclose(losses, ref_losses, rtol=5e-2)
+        tol = np.maximum(5e-2, 3.0 * own)
+        assert np.all(np.abs(np.array(losses) - np.array(ref_losses)) <= tol * np.abs(np.array(ref_losses))), (losses, ref_losses, ref32)
         assert losses[-1] < losses[0]
         return
     # small cases: six steps at plain parity, the rest within 2 % (one of them -- two layers + GPR at lr = 0.01 -- drives the loss
-    # from 1.9 to 0.03 in twelve steps and leaves the float64 trajectory by 0.6 % at step nine; the others hold 2e-4 throughout)
+    # from 1.9 to 0.03 in twelve steps and leaves the float64 trajectory by 0.6 % at step nine; the others hold 2e-4 while the
+    # float32 oracle does)
     np.testing.assert_allclose(losses[:6], ref_losses[:6], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(losses, ref_losses, rtol=2e-2)
+    tol = np.maximum(2e-2, 3.0 * own)
+    assert np.all(np.abs(np.array(losses) - np.array(ref_losses)) <= tol * np.abs(np.array(ref_losses))), (losses, ref_losses, ref32)
     if not np.allclose(losses, ref_losses, rtol=2e-4, atol=2e-5):
         return
     # parameters after the last step, on the scale of what the trajectory moved (STEPS * lr): at most 1 % of a tensor's entries off

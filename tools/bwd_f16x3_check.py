@@ -33,7 +33,7 @@ def reference(G, W, x, gamma, beta, eps=1e-5):
     s1 = v.mean(1, keepdim=True)
     s2 = (v * xh).mean(1, keepdim=True)
     gx = rstd * (v - s1 - xh * s2)
-    den_w = Gd.abs().t() @ u.abs()
+    den_w = Gd.abs().t() @ ((xh * gd).abs() + bd.abs())       # (the terms of u = xhat gamma + beta: fp32 rounds u itself)
     den_gu = Gd.abs() @ Wd.abs()
     return gx, gw, gb, dgam, dbet, den_w, den_gu, rstd, gd
 
