@@ -88,6 +88,7 @@ def test_training_trajectory_matches_the_oracle(name, over, device):
     # rand50_ds_add at lr = 0.01 oscillates from step nine on, 1.00 -> 1.18 -> 0.99 -- is the trajectory's conditioning.)
     ref32, _ = trajectory_oracle(case, sd, y, train_idx, STEPS, lr, dtype=torch.float32)
     own = np.abs(np.array(ref32) - np.array(ref_losses)) / np.abs(np.array(ref_losses))
+    own = np.maximum.accumulate(own)          # (a trajectory that has left the curve does not return to it: later steps are no better conditioned)
     if case["big"]:
         tol = np.maximum(5e-2, 3.0 * own)
         assert np.all(np.abs(np.array(losses) - np.array(ref_losses)) <= tol * np.abs(np.array(ref_losses))), (losses, ref_losses, ref32)
