@@ -464,7 +464,8 @@ int allset_ln_res_bwd_pma_bf16(const void* gy, int64_t ldg, const void* x, int64
  * One read + one write of the activation matrix.  Arithmetic: fp32 on the bf16 matrix pipe -- every operand is split
  * exactly into three bf16 values and six of the nine partial products are accumulated in fp32 ("bf16x6", dropped terms
  * <= 2^-23 relative: as accurate as a native fp32 MFMA, 2.7x its rate on gfx950; the only
- * kernel family since ABI 9).  stats (f32[n*2] =
+ * kernel family of the FORWARD since ABI 9; the one-pass backward behind a LayerNorm prologue at 128 x 128 uses two fp16 planes,
+ * see allset_fused_linear_bwd_all).  stats (f32[n*2] =
  * {mean, rstd}) is written when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0.
  *
  * Auxiliary output columns (optional, bf16x6 kernels): aux_out f32[n*4] = pro(x) @ aux_w^T + aux_b with aux_w f32[4*K],
@@ -515,6 +516,12 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  *   part_stride  0: part_w / part_b / part_ln are three dense arrays as sized above; > 0 (>= O*I + O + 2*I in practice): they
  *            point into ONE f32[n_slices*part_stride] buffer, slice k's sections at k*part_stride from each pointer -- one
  *            allset_reduce_partials launch then sums all of a Linear's parameter gradients.
+ * Arithmetic: bf16x6 as in the forward, except O = I = 128 behind a LayerNorm prologue (stats != NULL, ALLSET_NORM_LAYER, no
+ * acc_in): "fp16x3" (csrc/fused_bwd6.hip) -- every operand is scaled by a power of two (gy per row, W per 32-column slice, the
+ * recomputed input against the workgroup's running largest row) and split into TWO fp16 values, three of the four partial
+ * products are accumulated in fp32 on the f16 matrix pipe (half the matrix instructions of bf16x6).  Error per product <= 2^-21
+ * relative + 2^-38 of (the row's largest |gy|) x |input|: on sums, a library fp32 GEMM's level (tests/test_gpu_dense.py
+ * test_one_pass_backward_fp16x3_against_float64); a gradient column 2^17 below its rows' largest element loses low bits.
  * No atomics: bitwise reproducible run to run.  allset_fused_linear_bwd_all_supported(O, I, flags) -> 1/0: widths in
  * {64,128} and the prologue / epilogue combinations the module surface produces (dropout_in only behind relu_in, acc_in only
  * on the plain Linear).  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
