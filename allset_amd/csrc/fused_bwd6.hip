@@ -86,6 +86,22 @@ __device__ __forceinline__ f16x8s tr_frag2_s(const uint8_t* lo, const uint8_t* h
   f.t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4ss_t*)(hi));
   return f.v;
 }
+// LDS byte offsets as 32-bit integers (address space 3 kept: a round trip through a generic pointer turns the reads into flat loads)
+using lds_u8_s = __attribute__((address_space(3))) uint8_t;
+__device__ __forceinline__ uint32_t lds_off_s(const void* p) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8_s*)(p)));
+}
+typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_read16_s(uint32_t off) {
+  const u32x4_s v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_s*>(static_cast<uintptr_t>(off));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ f16x8s tr_frag2_off_s(uint32_t lo, uint32_t hi) {
+  FragS f;
+  f.t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) v4ss_t*>(static_cast<uintptr_t>(lo)));
+  f.t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) v4ss_t*>(static_cast<uintptr_t>(hi)));
+  return f.v;
+}
 // byte offset of (row, column byte) in a [rows][256 B] 16-bit plane (fused_bwd4.hip img_off_r: conflict-free for both the row-wise
 // 16-byte fragment reads and the transpose reads)
 __device__ __forceinline__ int img_off_s(int row, int colbyte) {
@@ -115,8 +131,8 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
   constexpr int PLANE = R * 256;                 // bytes per fp16 plane of an image
   constexpr int IMG = 2 * PLANE;                 // one image: planes h, l
   constexpr int SPG = 132;                       // pitch (floats) of the gu tile
-  __shared__ __attribute__((aligned(16))) uint8_t sGA[3 * IMG];
-  __shared__ __attribute__((aligned(16))) uint8_t sU[2 * IMG];
+  __shared__ __attribute__((aligned(1024))) uint8_t sGA[3 * IMG];       // (1 KB-aligned: fragment addresses are formed by XOR on the low bits)
+  __shared__ __attribute__((aligned(1024))) uint8_t sU[2 * IMG];
   __shared__ __attribute__((aligned(16))) float sGU[R * SPG];
   __shared__ __attribute__((aligned(16))) float sG[ID];
   __shared__ __attribute__((aligned(16))) float sB[ID];
@@ -459,16 +475,28 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 
     // ---- S1(k): backward-data for this wave's 32 output columns of the stage's 32 rows: 2 row tiles x 2 column tiles = four
     // independent accumulator chains; the A fragments of step t + 1 are requested before step t's MFMAs
-    auto S1 = [&](int64_t k) {
-      ALLSET_FRESH_LANE_S(lane);
-      const int ri = lane & 15, kg = lane >> 4;
-      const uint8_t* img = sGA + (k % 3) * IMG;
+    // LDS addresses: every fragment address of a stage is ONE per-lane base (kept in a register) XOR a constant in the swizzle's
+    // chunk / piece bits, plus an immediate (row tile, plane, 16-row step) and the image buffer's offset -- a handful of vector
+    // instructions per stage where the generic img_off_s arithmetic cost ~130 (the matrix waves are the critical role, and each of
+    // their vector instructions queues behind two vector waves on the same SIMD).
+    //   S1: row ri (+16), column byte 64 kg + 16 t:  base1 ^ (t << 4);   rows +16: + 4096 (same swizzle class)
+    //   S3: row 16 kb + tr_row + 4 hi, column byte 64 (2 o + tl) + tr_in:  base3 ^ (tl << 6) ^ (hi << 4), + 4096 kb + 1024 hi
+    const int base1 = img_off_s(lane0 & 15, 64 * (lane0 >> 4));
+    int base3a, base3b, base_gu;
+    {
+      const int q4 = lane0 >> 4, tr_r = (lane0 & 15) >> 2, tr_row = 8 * (q4 >> 1) + tr_r, tr_in = 32 * (q4 & 1) + 8 * (lane0 & 3);
+      base3a = img_off_s(tr_row, 64 * (2 * oh) + tr_in);
+      base3b = img_off_s(tr_row, 64 * (2 * ih) + tr_in);
+      base_gu = (4 * (lane0 >> 4) * SPG + 32 * m + (lane0 & 15)) * 4;
+    }
+    auto S1 = [&](int64_t k, int b3) {
+      const uint32_t img = lds_off_s(sGA) + static_cast<uint32_t>(b3 * IMG + base1);
       auto load_a = [&](FragS (&f0)[2], FragS (&f1)[2], FragS (&fl)[2], int t) {
-        const int o0 = img_off_s(ri, 64 * kg + 16 * t), o1 = img_off_s(16 + ri, 64 * kg + 16 * t);
+        const uint32_t pa = img ^ static_cast<uint32_t>(t << 4);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-          f0[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o0);
-          f1[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o1);
+          f0[pl].u = lds_read16_s(pa + pl * PLANE);
+          f1[pl].u = lds_read16_s(pa + pl * PLANE + 16 * 256);
         }
         fl[0].u = wl[(0 * 4 + t) * 64];
         fl[1].u = wl[(1 * 4 + t) * 64];
@@ -511,11 +539,11 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sGU[(16 * rt + 4 * kg + r) * SPG + 32 * m + 16 * ct + ri] = acc[rt][ct][r] * inv_sw;
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(sGU) + base_gu + ((16 * rt + r) * SPG + 16 * ct) * 4) = acc[rt][ct][r] * inv_sw;
     };
     // ---- S3(k): weight gradient, this wave's 64 x 64 tile of gW; K = the stage's 32 rows in two steps of 16; A = ga^T, B = u
-    auto S3 = [&](int64_t k) {
-      ALLSET_FRESH_LANE_S(lane_w);
+    auto S3 = [&](int64_t k, int b3, int b2) {
       const int Ek = stage_emax(k);
       if (Ek > Erun) {                            // a larger row exponent: bring the accumulated sum to the new scale (exact)
         const float f = pow2_field_s(max(127 - (Ek - Erun), 0));
@@ -527,20 +555,18 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
             for (int q = 0; q < 16; ++q) gw[a][b][q] *= f;
         Erun = Ek;
       }
-      const uint8_t* ia = sGA + (k % 3) * IMG;
-      const uint8_t* iu = sU + (k % 2) * IMG;
-      const int q4 = lane_w >> 4, tr_r = (lane_w & 15) >> 2, tr_row = 8 * (q4 >> 1) + tr_r, tr_in = 32 * (q4 & 1) + 8 * (lane_w & 3);
+      const uint32_t ia = lds_off_s(sGA) + static_cast<uint32_t>(b3 * IMG + base3a), iu = lds_off_s(sU) + static_cast<uint32_t>(b2 * IMG + base3b);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         f16x8s wa[2][2], wb[2][2];
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-          const int a_lo = img_off_s(16 * kb + tr_row, 64 * (2 * oh + tl) + tr_in), a_hi = img_off_s(16 * kb + tr_row + 4, 64 * (2 * oh + tl) + tr_in);
-          const int b_lo = img_off_s(16 * kb + tr_row, 64 * (2 * ih + tl) + tr_in), b_hi = img_off_s(16 * kb + tr_row + 4, 64 * (2 * ih + tl) + tr_in);
+          const uint32_t a_lo = (ia ^ static_cast<uint32_t>(tl << 6)) + kb * 4096, a_hi = (ia ^ static_cast<uint32_t>((tl << 6) | 16)) + kb * 4096 + 1024;
+          const uint32_t b_lo = (iu ^ static_cast<uint32_t>(tl << 6)) + kb * 4096, b_hi = (iu ^ static_cast<uint32_t>((tl << 6) | 16)) + kb * 4096 + 1024;
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-            wa[tl][pl] = tr_frag2_s(ia + pl * PLANE + a_lo, ia + pl * PLANE + a_hi);
-            wb[tl][pl] = tr_frag2_s(iu + pl * PLANE + b_lo, iu + pl * PLANE + b_hi);
+            wa[tl][pl] = tr_frag2_off_s(a_lo + pl * PLANE, a_hi + pl * PLANE);
+            wb[tl][pl] = tr_frag2_off_s(b_lo + pl * PLANE, b_hi + pl * PLANE);
           }
         }
 #ifdef ALLSET_ABL6_NOMFMA
@@ -562,17 +588,19 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 
     ALLSET_S_TICK();
     ALLSET_SMARK(3);
+    int c3 = 0, p3 = 2, c2 = 0;                   // k % 3, (k - 1) % 3, k % 2 without the divisions
     for (int64_t k = 0; k < T; ++k) {
-      S1(k);
+      S1(k, c3);
       ALLSET_SMARK(0);
       ALLSET_S_TICK();
       ALLSET_SMARK(1);
-      if (k >= 1) S3(k - 1);
+      if (k >= 1) S3(k - 1, p3, c2 ^ 1);
       ALLSET_SMARK(2);
       ALLSET_S_TICK();
       ALLSET_SMARK(3);
+      p3 = c3; c3 = c3 == 2 ? 0 : c3 + 1; c2 ^= 1;
     }
-    S3(T - 1);
+    S3(T - 1, p3, c2 ^ 1);
     ALLSET_S_TICK();
     // ---- the workgroup's gW partial: each matrix wave its 64 x 64 tile; the accumulators hold gW 2^(kSTop + 127 + Su - Erun)
     {

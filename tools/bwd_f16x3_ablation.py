@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 src = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bwd.hip", "fused_bwd4.hip", "fused_bwd6.hip", "abi.hip")]
+if os.environ.get("ALLSET_BWD6_SRC"):          # A/B against another version of the kernel file
+    src[2] = os.environ["ALLSET_BWD6_SRC"]
 dev = torch.device("cuda:0")
 n, d = 1_000_000, 128
 x = torch.randn(n, d, device=dev); W = torch.randn(d, d, device=dev) / d ** 0.5
