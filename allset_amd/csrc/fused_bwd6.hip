@@ -1,4 +1,4 @@
-// The one-pass backward of the fused Linear behind a true LayerNorm prologue (O = I = 128), split by role like fused_bwd4.hip,
+// The one-pass backward of the fused Linear at O = I = 128 (behind a LayerNorm prologue, or none), split by role like fused_bwd4.hip,
 // with the fp32 products formed from TWO fp16 planes per operand instead of three bf16 planes ("fp16x3"):
 //
 //     x s = h + l,  h = fp16(x s),  l = fp16(x s - h)         (s a power of two: the scaling is exact)
@@ -11,13 +11,14 @@
 //   ga (masked gy)  per ROW: its largest element lands in [2^13, 2^14); the row's gu is unscaled in the LayerNorm backward;
 //   W               per matrix wave's slice (32 columns); unscaled where the wave writes its gu tile;
 //   u (the Linear's input, recomputed)  the weight gradient sums over rows, so a row scale cannot be taken out of the sum: the
-//       scales of ga and u must multiply to ONE constant.  u = (LayerNorm output) * keep is bounded by
-//       U = (sqrt(127) max|gamma| + max|beta|) * keep -- no data pass needed -- and row r of u is written as
-//       u 2^Su 2^(e_r - E), e_r = ga's row exponent, E = the largest row exponent the workgroup has seen so far: rows whose
-//       gradient is far below the largest one lose low bits of a contribution that is that much smaller.  When a stage raises E
-//       the matrix waves rescale their gW accumulators by the (exact) power of two before adding it -- the online-softmax trick.
-// An element below 2^-14 of its window is a denormal or flushed: an error <= 2^-28 of the row's (or the workgroup's) largest
-// term, below fp32 rounding of the sum.
+//       scales of ga and u must multiply to ONE constant.  With e_r = the exponent of ga's row, eu_r = an exponent bounding u's row
+//       and q_r = e_r + eu_r, row r of u is written as u 2^(140 + e_r - Q), Q = the largest q_r the workgroup has met so far: rows
+//       whose product of magnitudes is far below the largest one lose low bits of a contribution that is that much smaller.  When a
+//       stage raises Q the matrix waves rescale their gW accumulators by the (exact) power of two before adding it -- the
+//       online-softmax trick.  Behind a LayerNorm eu_r needs no data pass: |u| <= (sqrt(127) max|gamma| + max|beta|) keep; without
+//       one it is the exponent of the row's largest |u| (a DPP row maximum of the x row already in registers).
+// An element below 2^-14 of its window is an fp16 denormal (produced by v_cvt_pk_f16_f32 and honoured by the f16 MFMA,
+// tools/micro/f16_probe.hip): an absolute error <= 2^-38 of the row's largest element, below fp32 rounding of the sum.
 //
 // What the lighter matrix side buys is OCCUPANCY for the vector role: a matrix wave holds 32 registers of W fragments (the h plane;
 // the l plane, used once per k-step, is read fragment by fragment from LDS) where fused_bwd4.hip held 96, so the kernel fits 168
@@ -26,12 +27,12 @@
 // same SIMD; fused_bwd4's single vector wave per SIMD issued one instruction per ~8 cycles.
 //
 // Stage = 32 rows, two ticks per stage, one barrier per tick (the pipeline of fused_bwd4.hip):
-//     tick 2k    vector: S0(k+1): gy -> mask -> row scale -> ga[(k+1) % 3];  S2a(k): x -> xhat, keep factors   | matrix: S1(k): gu = ga W
-//     tick 2k+1  vector: S2b(k): gu -> LayerNorm backward -> gx;  u -> u[k % 2]                                | matrix: S3(k-1): gW += ga^T u
+//     tick 2k    vector: S0(k+1): gy -> mask -> row scale -> ga[(k+1) % 3];  S2a(k): x -> xhat, keep factors, q_r   | matrix: S1(k): gu = ga W
+//     tick 2k+1  vector: S2b(k): gu -> LayerNorm backward -> gx;  u -> u[k % 2]                                     | matrix: S3(k-1): gW += ga^T u
 //   vector wave v: rows 4 v .. 4 v + 3 of the stage, one row per DPP row of 16 lanes, 8 elements per lane;
 //   matrix wave m: S1 for output columns 32 m .. 32 m + 31 (48 MFMAs 16x16x32 per stage); S3 for the 64 x 64 tile (m >> 1, m & 1)
 //     of the workgroup's ONE gW (24 MFMAs 32x32x16 per stage).
-// LDS: 3 x 16 KB ga + 2 x 16 KB u + 16.5 KB gu + 32 KB W l-plane + gamma / beta + the row-exponent slots = 130 KB.
+// LDS: 3 x 16 KB ga + 2 x 16 KB u + 16.5 KB gu + 32 KB W l-plane + gamma / beta + the q_r slots = 130 KB.
 #include <stdlib.h>
 
 #include "common.h"
@@ -116,14 +117,17 @@ __device__ __forceinline__ uint32_t hash_mix_s(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_S(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool DROP_IN, bool RELU_IN, bool HAS_MASK>
+template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC>
 __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     const float* __restrict__ gy, int64_t ldg, const uint32_t* __restrict__ mask, float p_out, const float* __restrict__ W,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, int64_t gcb, int64_t xcb,
-    int64_t gxcb) {
+    int64_t gxcb, const float* acc_in, int64_t ldacc) {
+  // HAS_LN: a true LayerNorm prologue (stats / gamma / beta); without it u = dropout(relu(x)) and the window of a row of u comes from
+  // the row's own largest element.  HAS_ACC (plain Linear only): gx = acc_in + this Linear's input gradient (may alias gx).
+  static_assert(!HAS_ACC || (!HAS_LN && !DROP_IN && !RELU_IN && !HAS_MASK), "acc_in: plain Linear only");
   // gcb / xcb / gxcb: 0 = row-major with the operand's leading dimension; cb > 0 = COLUMN-BLOCKED [128 / cb][n][cb] (ld == cb) for
   // gy / x / gx (fused_bwd4.hip)
   constexpr int OD = 128, ID = 128;
@@ -137,10 +141,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
   __shared__ __attribute__((aligned(16))) float sG[ID];
   __shared__ __attribute__((aligned(16))) float sB[ID];
   __shared__ __attribute__((aligned(16))) uint8_t sWL[4 * 2 * 4 * 64 * 16];     // W's l plane: [matrix wave][ct][k-step][lane] fragments
-  __shared__ __attribute__((aligned(16))) int sE[4 * kSVWaves];       // [stage % 4][vector wave]: largest row exponent of its rows
+  __shared__ __attribute__((aligned(16))) int sE[4 * kSVWaves];       // [stage % 4][vector wave]: largest q_r = e_r + eu_r of its rows
   seed_in = resolve_seed(seed_base, seed_in);
   const int tid = threadIdx.x;
-  if (tid < ID) { sG[tid] = gamma[tid]; sB[tid] = beta[tid]; }
+  if (tid < ID) { sG[tid] = HAS_LN ? gamma[tid] : 1.f; sB[tid] = HAS_LN ? beta[tid] : 0.f; }
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n_stages = (n + R - 1) / R;
@@ -158,18 +162,20 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #else
 #define ALLSET_SMARK(k) do {} while (0)
 #endif
-  // Su: u 2^Su < 2^14 for every element of u = (xhat gamma + beta) keep, |xhat| <= sqrt(127); every wave derives it itself
+  // The window of u.  Row r of u is written as u 2^(140 + e_r - Q): e_r = the biased exponent of ga's row, eu_r = a biased exponent
+  // with |u[r, :]| < 2^(eu_r - 126), q_r = e_r + eu_r, Q = the largest q_r the workgroup has met -- so u' < 2^14, and ga' u' = ga u
+  // 2^(kSTop + 267 - Q) whatever the row.  Behind a LayerNorm eu_r is one number for the whole launch, from
+  // |u| <= (sqrt(127) max|gamma| + max|beta|) keep -- no data pass; without one it is the exponent of the row's largest |u|.
   const float keep_in_all = DROP_IN ? 1.f / (1.f - p_in) : 1.f;
-  int Su;
-  {
+  int eUc = kSEMin;
+  if constexpr (HAS_LN) {
     float g = fmaxf(fabsf(sG[lane0]), fabsf(sG[lane0 + 64])), b = fmaxf(fabsf(sB[lane0]), fabsf(sB[lane0 + 64]));
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { g = fmaxf(g, __shfl_xor(g, off)); b = fmaxf(b, __shfl_xor(b, off)); }
     const float U = (11.27f * g + b) * keep_in_all;
-    const int eU = static_cast<int>(__float_as_uint(U) >> 23);          // U < 2^(eU - 126)
-    Su = __builtin_amdgcn_readfirstlane(min(max(140 - eU, -40), 60));
+    eUc = __builtin_amdgcn_readfirstlane(min(max(static_cast<int>(__float_as_uint(U) >> 23), kSEMin), 254));          // U < 2^(eUc - 126)
   }
-  // the largest biased row exponent of stages 0 .. k, from the slots the vector waves filled in S0
+  // the largest q_r of stage k, from the slots the vector waves filled in S2a
   auto stage_emax = [&](int64_t k) -> int {
     const int4 a = *reinterpret_cast<const int4*>(&sE[(k & 3) * kSVWaves]), b = *reinterpret_cast<const int4*>(&sE[(k & 3) * kSVWaves + 4]);
     return __builtin_amdgcn_readfirstlane(max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))));
@@ -217,10 +223,11 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb)
         xr[hb] = *reinterpret_cast<const float4*>(xb + hb * dhx + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + cox0));
-      st = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(stats + s0 * R * 2) + lrc * 8);
+      if constexpr (HAS_LN) st = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(stats + s0 * R * 2) + lrc * 8);
     };
     int eNext = kSEMin, eCur = kSEMin;            // biased row exponent of ga: stage k + 1 (written by S0), stage k (read by S2b)
-    int Erun = kSEMin;                            // max over the stages up to the one S2b is working on
+    int Erun = 2 * kSEMin;                        // the largest q_r over the stages up to the one S2b is working on
+    int quK = kSEMin;                             // eu_r of stage k (S2a -> S2b)
     // ---- S0(k): ga = gy under the forward's epilogue mask, scaled to the row's window, two fp16 planes into ga[k % 3]
     auto S0 = [&](int64_t k, float4 (&ag)[2], uint32_t (&am)[2]) {
       const int nrows = rows_left(stage_of(k));
@@ -254,10 +261,6 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(l0, l1);
       }
-      // the wave's largest row exponent -> its slot of the stage (all lanes store the same word)
-      const int ew = max(max(__builtin_amdgcn_readlane(e, 0), __builtin_amdgcn_readlane(e, 16)),
-                         max(__builtin_amdgcn_readlane(e, 32), __builtin_amdgcn_readlane(e, 48)));
-      sE[(k & 3) * kSVWaves + wave] = ew;
       __builtin_amdgcn_sched_barrier(0);
       request_gy(k + 2, ag, am);                  // into the set just consumed: two stages ahead
       __builtin_amdgcn_sched_barrier(0);
@@ -278,8 +281,9 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       const uint32_t stage_quad_lo = static_cast<uint32_t>(stage_quad);
       const uint32_t hi_term_q = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
       xbK = 0;
-      const float mean = st.x, rstd = st.y;
+      const float mean = HAS_LN ? st.x : 0.f, rstd = HAS_LN ? st.y : 1.f;
       rstdK = rstd;
+      float uamax = 0.f;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -304,11 +308,22 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
           xbK |= ((t.x > 0.f ? 1u : 0u) | (t.y > 0.f ? 2u : 0u) | (t.z > 0.f ? 4u : 0u) | (t.w > 0.f ? 8u : 0u)) << (4 * hb);
           t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
         }
-        float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
+        float4 xh = t;
+        if constexpr (HAS_LN) xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
         xh.x = live ? xh.x : 0.f; xh.y = live ? xh.y : 0.f; xh.z = live ? xh.z : 0.f; xh.w = live ? xh.w : 0.f;
         xhK[hb] = xh;
+        if constexpr (!HAS_LN) uamax = amax4_s(xh, uamax);
       }
       if constexpr (RELU_IN) __asm__ volatile("" : "+v"(xbK));     // (packed here, not at its use)
+      // eu_r, q_r = e_r + eu_r, and the wave's largest q_r -> its slot of the stage (all lanes store the same word)
+      if constexpr (HAS_LN) quK = eUc;
+      else quK = min(max(static_cast<int>(__float_as_uint(row16_max_s(uamax) * keep_in) >> 23) + 1, kSEMin), 254);     // |u| < 2^(eu - 126)
+      {
+        const int q = eCur + quK;
+        const int qw = max(max(__builtin_amdgcn_readlane(q, 0), __builtin_amdgcn_readlane(q, 16)),
+                           max(__builtin_amdgcn_readlane(q, 32), __builtin_amdgcn_readlane(q, 48)));
+        sE[(k & 3) * kSVWaves + wave] = qw;
+      }
       __builtin_amdgcn_sched_barrier(0);
       request_x(k + 2, xr, st);                   // x is consumed: the request for two stages ahead goes out a tick earlier
       __builtin_amdgcn_sched_barrier(0);
@@ -320,36 +335,52 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       const bool live = lr < nrows;
       Erun = max(Erun, stage_emax(k));
       const float inv_sa = pow2_field_s(eCur - kSTop);            // undoes the row scale of ga (the wave's W scale is undone by S1)
-      const int ffield = 127 + Su + eCur - Erun;
+      const int ffield = 267 + eCur - Erun;
       const float fu = pow2_field_s(live ? max(ffield, 0) : 0);     // (a dead row's u is 0: its xhat is, but beta is not)
       float4 gam[2], v[2];
       float a1 = 0.f, a2 = 0.f;
+      // gx = acc_in + ...: a second gradient branch of the same tensor, summed here (may alias gx: each element is read and written
+      // by the same lane).  Requested first, consumed last.
+      float4 acc[2];
+      if constexpr (HAS_ACC) {
+        const int lrc = min(lr, max(nrows, 1) - 1);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          acc[hb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(acc_in + stage * R * ldacc) +
+                                                     static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldacc) * 4u + 256 * hb + 16 * c);
+      }
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
         v[hb] = *reinterpret_cast<const float4*>(&sGU[lr * SPG + 64 * hb + 4 * c]);
         v[hb].x *= inv_sa; v[hb].y *= inv_sa; v[hb].z *= inv_sa; v[hb].w *= inv_sa;
         if constexpr (DROP_IN) { v[hb].x *= kpK[hb].x; v[hb].y *= kpK[hb].y; v[hb].z *= kpK[hb].z; v[hb].w *= kpK[hb].w; }
-        const float4 xh = xhK[hb];
-        dg[hb].x = fmaf(v[hb].x, xh.x, dg[hb].x); dg[hb].y = fmaf(v[hb].y, xh.y, dg[hb].y);
-        dg[hb].z = fmaf(v[hb].z, xh.z, dg[hb].z); dg[hb].w = fmaf(v[hb].w, xh.w, dg[hb].w);
-        db[hb].x += v[hb].x; db[hb].y += v[hb].y; db[hb].z += v[hb].z; db[hb].w += v[hb].w;
-        v[hb].x *= gam[hb].x; v[hb].y *= gam[hb].y; v[hb].z *= gam[hb].z; v[hb].w *= gam[hb].w;
-        a1 += (v[hb].x + v[hb].y) + (v[hb].z + v[hb].w);
-        a2 = fmaf(v[hb].x, xh.x, fmaf(v[hb].y, xh.y, fmaf(v[hb].z, xh.z, fmaf(v[hb].w, xh.w, a2))));
+        if constexpr (HAS_LN) {
+          const float4 xh = xhK[hb];
+          dg[hb].x = fmaf(v[hb].x, xh.x, dg[hb].x); dg[hb].y = fmaf(v[hb].y, xh.y, dg[hb].y);
+          dg[hb].z = fmaf(v[hb].z, xh.z, dg[hb].z); dg[hb].w = fmaf(v[hb].w, xh.w, dg[hb].w);
+          db[hb].x += v[hb].x; db[hb].y += v[hb].y; db[hb].z += v[hb].z; db[hb].w += v[hb].w;
+          v[hb].x *= gam[hb].x; v[hb].y *= gam[hb].y; v[hb].z *= gam[hb].z; v[hb].w *= gam[hb].w;
+          a1 += (v[hb].x + v[hb].y) + (v[hb].z + v[hb].w);
+          a2 = fmaf(v[hb].x, xh.x, fmaf(v[hb].y, xh.y, fmaf(v[hb].z, xh.z, fmaf(v[hb].w, xh.w, a2))));
+        }
       }
-      const float s1 = row16_sum_s(a1) * inv_i, s2 = row16_sum_s(a2) * inv_i;
+      float s1 = 0.f, s2 = 0.f;
+      if constexpr (HAS_LN) { s1 = row16_sum_s(a1) * inv_i; s2 = row16_sum_s(a2) * inv_i; }
       const float rstd = rstdK;
       uint8_t* img = sU + (k % 2) * IMG;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const float4 xh = xhK[hb];
-        float4 o = make_float4(rstd * (v[hb].x - s1 - xh.x * s2), rstd * (v[hb].y - s1 - xh.y * s2),
-                               rstd * (v[hb].z - s1 - xh.z * s2), rstd * (v[hb].w - s1 - xh.w * s2));
+        float4 o = v[hb];
+        if constexpr (HAS_LN)
+          o = make_float4(rstd * (v[hb].x - s1 - xh.x * s2), rstd * (v[hb].y - s1 - xh.y * s2),
+                          rstd * (v[hb].z - s1 - xh.z * s2), rstd * (v[hb].w - s1 - xh.w * s2));
         if (RELU_IN) {
           const uint32_t xb = xbK >> (4 * hb);
           o.x = (xb & 1u) ? o.x : 0.f; o.y = (xb & 2u) ? o.y : 0.f; o.z = (xb & 4u) ? o.z : 0.f; o.w = (xb & 8u) ? o.w : 0.f;
         }
+        if constexpr (HAS_ACC) { o.x += acc[hb].x; o.y += acc[hb].y; o.z += acc[hb].z; o.w += acc[hb].w; }
 #ifdef ALLSET_ABL6_NOSTORE
         if (live && o.x == 123.456f)
 #else
@@ -357,8 +388,11 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #endif
           *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + stage * R * ldgx) +
                                      hb * dhgx + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx0)) = o;
-        const float4 bet = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
-        float4 u = make_float4(fmaf(xh.x, gam[hb].x, bet.x), fmaf(xh.y, gam[hb].y, bet.y), fmaf(xh.z, gam[hb].z, bet.z), fmaf(xh.w, gam[hb].w, bet.w));
+        float4 u = xh;
+        if constexpr (HAS_LN) {
+          const float4 bet = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
+          u = make_float4(fmaf(xh.x, gam[hb].x, bet.x), fmaf(xh.y, gam[hb].y, bet.y), fmaf(xh.z, gam[hb].z, bet.z), fmaf(xh.w, gam[hb].w, bet.w));
+        }
         if constexpr (DROP_IN) { u.x *= kpK[hb].x; u.y *= kpK[hb].y; u.z *= kpK[hb].z; u.w *= kpK[hb].w; }
         uint32_t h0, l0, h1, l1;
         split2_f16(u.x * fu, u.y * fu, h0, l0);
@@ -471,7 +505,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) gw[a][b][q] = 0.f;
-    int Erun = kSEMin;
+    int Erun = 2 * kSEMin;
 
     // ---- S1(k): backward-data for this wave's 32 output columns of the stage's 32 rows: 2 row tiles x 2 column tiles = four
     // independent accumulator chains; the A fragments of step t + 1 are requested before step t's MFMAs
@@ -602,9 +636,9 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     }
     S3(T - 1, p3, c2 ^ 1);
     ALLSET_S_TICK();
-    // ---- the workgroup's gW partial: each matrix wave its 64 x 64 tile; the accumulators hold gW 2^(kSTop + 127 + Su - Erun)
+    // ---- the workgroup's gW partial: each matrix wave its 64 x 64 tile; the accumulators hold gW 2^(kSTop + 267 - Erun)
     {
-      const int X = Erun - 127 - kSTop - Su;      // in [-180, 154]: applied as two factors
+      const int X = Erun - 267 - kSTop;           // in [-240, 228]: applied as two factors
       const int X1 = X >> 1, X2 = X - X1;
       const float f1 = pow2_field_s(127 + X1), f2 = pow2_field_s(127 + X2);
       float* pw = part_w + static_cast<int64_t>(blockIdx.x) * pstride_w;
@@ -632,7 +666,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #pragma unroll
     for (int v = 0; v < kSVWaves; ++v) s += sGU[v * 3 * ID + tid];
     const int64_t slice = blockIdx.x;
-    if (tid < 2 * ID) part_ln[slice * pstride_ln + tid] = s;
+    if (tid < 2 * ID) { if constexpr (HAS_LN) part_ln[slice * pstride_ln + tid] = s; }
     else if (part_b != nullptr) part_b[slice * pstride_b + (tid - 2 * ID)] = s;
   }
 }
@@ -641,28 +675,30 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 
 using namespace allset;
 
-// 1 = the fp16x3 kernel takes this call: O = I = 128 behind a true LayerNorm prologue (row statistics on: the bound on u it scales
-// with needs them), no second gradient branch, no auxiliary columns
+// 1 = the fp16x3 kernel takes this call: O = I = 128, a LayerNorm prologue with its row statistics or no norm at all (the
+// column-affine BatchNorm prologue has neither a bound on u nor plain rows: fused_bwd4.hip), no auxiliary columns
 int fused_linear_bwd_f16x3_supported(int64_t O, int64_t I, int has_ln, int norm_mode, int has_acc, int has_aux) {
-  return (O == 128 && I == 128 && has_ln && norm_mode == ALLSET_NORM_LAYER && !has_acc && !has_aux) ? 1 : 0;
+  (void)has_acc;
+  return (O == 128 && I == 128 && (!has_ln || norm_mode == ALLSET_NORM_LAYER) && !has_aux) ? 1 : 0;
 }
 
-// Called by allset_fused_linear_bwd_all (fused_bwd.hip) after its argument checks; ONE partial slice per workgroup, the grid of
-// fused_linear_bwd_roles_grid (one persistent workgroup per CU).
-int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool drop, bool relu, bool hm, const float* gy, int64_t ldg,
+// Called by allset_fused_linear_bwd_all (fused_bwd.hip) after its argument checks (bwd_all_combo: dropout_in only behind relu_in,
+// acc_in only on the plain Linear); ONE partial slice per workgroup, the grid of fused_linear_bwd_roles_grid.
+int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy, int64_t ldg,
                                   const uint32_t* mask, float p_out, const float* W, const float* x, int64_t ldx,
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, int64_t gcb, int64_t xcb,
-                                  int64_t gxcb) {
-#define ALLSET_S_K(DI, RI, HM)                                                                                                  \
-  fused_linear_bwd_f16x3_kernel<DI, RI, HM><<<grid, kSBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, \
-                                                                      seed_in, gx, ldgx, part_ln, part_w, part_b, n, seed_base,  \
-                                                                      psw, psb, psl, gcb, xcb, gxcb)
-#define ALLSET_S_M(DI, RI) do { if (hm) ALLSET_S_K(DI, RI, true); else ALLSET_S_K(DI, RI, false); } while (0)
-  if (!relu) ALLSET_S_M(false, false);
-  else if (drop) ALLSET_S_M(true, true);
-  else ALLSET_S_M(false, true);
+                                  int64_t gxcb, const float* acc_in, int64_t ldacc) {
+#define ALLSET_S_K(LN, DI, RI, HM, HA)                                                                                            \
+  fused_linear_bwd_f16x3_kernel<LN, DI, RI, HM, HA><<<grid, kSBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta,  \
+                                                                              p_in, seed_in, gx, ldgx, part_ln, part_w, part_b, n, \
+                                                                              seed_base, psw, psb, psl, gcb, xcb, gxcb, acc_in, ldacc)
+  if (acc_in != nullptr) { ALLSET_S_K(false, false, false, false, true); return 0; }
+#define ALLSET_S_M(LN, DI, RI) do { if (hm) ALLSET_S_K(LN, DI, RI, true, false); else ALLSET_S_K(LN, DI, RI, false, false); } while (0)
+  if (!relu) { if (ln) ALLSET_S_M(true, false, false); else ALLSET_S_M(false, false, false); }
+  else if (ln) { if (drop) ALLSET_S_M(true, true, true); else ALLSET_S_M(true, false, true); }
+  else { if (drop) ALLSET_S_M(false, true, true); else ALLSET_S_M(false, false, true); }
 #undef ALLSET_S_M
 #undef ALLSET_S_K
   return 0;

@@ -516,12 +516,13 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  *   part_stride  0: part_w / part_b / part_ln are three dense arrays as sized above; > 0 (>= O*I + O + 2*I in practice): they
  *            point into ONE f32[n_slices*part_stride] buffer, slice k's sections at k*part_stride from each pointer -- one
  *            allset_reduce_partials launch then sums all of a Linear's parameter gradients.
- * Arithmetic: bf16x6 as in the forward, except O = I = 128 behind a LayerNorm prologue (stats != NULL, ALLSET_NORM_LAYER, no
- * acc_in): "fp16x3" (csrc/fused_bwd6.hip) -- every operand is scaled by a power of two (gy per row, W per 32-column slice, the
- * recomputed input against the workgroup's running largest row) and split into TWO fp16 values, three of the four partial
+ * Arithmetic: bf16x6 as in the forward, except at O = I = 128 behind a LayerNorm prologue (ALLSET_NORM_LAYER) or none at all, with
+ * or without acc_in (i.e. everything but the column-affine prologue and the auxiliary columns):
+ * "fp16x3" (csrc/fused_bwd6.hip) -- every operand is scaled by a power of two (gy per row, W per 32-column slice, the
+ * recomputed input against the workgroup's running largest row product) and split into TWO fp16 values, three of the four partial
  * products are accumulated in fp32 on the f16 matrix pipe (half the matrix instructions of bf16x6).  Error per product <= 2^-21
  * relative + 2^-38 of (the row's largest |gy|) x |input|: on sums, a library fp32 GEMM's level (tests/test_gpu_dense.py
- * test_one_pass_backward_fp16x3_against_float64); a gradient column 2^17 below its rows' largest element loses low bits.
+ * test_one_pass_backward_fp16x3_*_against_float64); a gradient column 2^17 below its rows' largest element loses low bits.
  * No atomics: bitwise reproducible run to run.  allset_fused_linear_bwd_all_supported(O, I, flags) -> 1/0: widths in
  * {64,128} and the prologue / epilogue combinations the module surface produces (dropout_in only behind relu_in, acc_in only
  * on the plain Linear).  Unsupported -> ALLSET_ERR_UNSUPPORTED; use the two-kernel pair. */
