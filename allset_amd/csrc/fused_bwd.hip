@@ -540,7 +540,7 @@ int launch_fused_linear_bwd_roles(unsigned grid, hipStream_t st, bool ln, bool d
                                   float ln_inv);
 
 // fused_bwd6.hip: the split-role pass on two fp16 planes per operand (three MFMAs per product instead of six), eight vector
-// waves: O = I = 128 behind a LayerNorm prologue or none (not the column-affine one, not with auxiliary columns); same grid and
+// waves: O = I = 128, every prologue (LayerNorm, column-affine, none) and acc_in, not the auxiliary columns; same grid and
 // partial slices as the kernel above
 int fused_linear_bwd_f16x3_supported(int64_t O, int64_t I, int has_ln, int norm_mode, int has_acc, int has_aux);
 int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool ln, bool drop, bool relu, bool hm, const float* gy, int64_t ldg,
@@ -548,7 +548,7 @@ int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, int64_t gcb, int64_t xcb,
-                                  int64_t gxcb, const float* acc_in, int64_t ldacc);
+                                  int64_t gxcb, const float* acc_in, int64_t ldacc, float ln_inv);
 
 static inline unsigned bwd_all_grid(int64_t n) {
   int64_t blocks = ((n + 15) / 16 + kMWaves - 1) / kMWaves;
@@ -684,7 +684,7 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
 #ifndef ALLSET_NO_F16X3
   if (roles_kernel && fused_linear_bwd_f16x3_supported(O, I, has_ln, norm_mode, ha, 0)) {
     launch_fused_linear_bwd_f16x3(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in,
-                                  gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, gcb, xcb, gxcb, acc_in, ldacc);
+                                  gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, gcb, xcb, gxcb, acc_in, ldacc, ln_inv);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }

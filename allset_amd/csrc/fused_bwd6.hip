@@ -124,7 +124,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, int64_t gcb, int64_t xcb,
-    int64_t gxcb, const float* acc_in, int64_t ldacc) {
+    int64_t gxcb, const float* acc_in, int64_t ldacc, float ln_inv) {
+  // ln_inv: 1 / 128 for the LayerNorm backward; 0 = the per-column affine prologue (ALLSET_NORM_COLUMN_AFFINE, fused_bwd4.hip: the
+  // forward wrote {0, 1} row statistics, gx = gu * gamma, part_ln = sum_r gu * x and sum_r gu) -- then u = x gamma + beta has no bound
+  // known in advance and its window comes from the row's own largest element, as without a norm.
   // HAS_LN: a true LayerNorm prologue (stats / gamma / beta); without it u = dropout(relu(x)) and the window of a row of u comes from
   // the row's own largest element.  HAS_ACC (plain Linear only): gx = acc_in + this Linear's input gradient (may alias gx).
   static_assert(!HAS_ACC || (!HAS_LN && !DROP_IN && !RELU_IN && !HAS_MASK), "acc_in: plain Linear only");
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 
   if (wave < kSVWaves) {
     // =================================================== vector waves ===================================================
-    const float inv_i = 1.f / static_cast<float>(ID);
+    const float inv_i = ln_inv;
+    const bool affine = HAS_LN && ln_inv == 0.f;
     const float keep_out = p_out > 0.f ? 1.f / (1.f - p_out) : 1.f;
     const float keep_in = keep_in_all;
     const uint32_t thr_in = drop_threshold(p_in);
@@ -313,10 +317,14 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         xh.x = live ? xh.x : 0.f; xh.y = live ? xh.y : 0.f; xh.z = live ? xh.z : 0.f; xh.w = live ? xh.w : 0.f;
         xhK[hb] = xh;
         if constexpr (!HAS_LN) uamax = amax4_s(xh, uamax);
+        else if (affine) {
+          const float4 gm = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]), bt = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
+          uamax = amax4_s(make_float4(fmaf(xh.x, gm.x, bt.x), fmaf(xh.y, gm.y, bt.y), fmaf(xh.z, gm.z, bt.z), fmaf(xh.w, gm.w, bt.w)), uamax);
+        }
       }
       if constexpr (RELU_IN) __asm__ volatile("" : "+v"(xbK));     // (packed here, not at its use)
       // eu_r, q_r = e_r + eu_r, and the wave's largest q_r -> its slot of the stage (all lanes store the same word)
-      if constexpr (HAS_LN) quK = eUc;
+      if (HAS_LN && !affine) quK = eUc;
       else quK = min(max(static_cast<int>(__float_as_uint(row16_max_s(uamax) * keep_in) >> 23) + 1, kSEMin), 254);     // |u| < 2^(eu - 126)
       {
         const int q = eCur + quK;
@@ -675,11 +683,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 
 using namespace allset;
 
-// 1 = the fp16x3 kernel takes this call: O = I = 128, a LayerNorm prologue with its row statistics or no norm at all (the
-// column-affine BatchNorm prologue has neither a bound on u nor plain rows: fused_bwd4.hip), no auxiliary columns
+// 1 = the fp16x3 kernel takes this call: O = I = 128 without auxiliary columns (LayerNorm, column-affine or no prologue; acc_in)
 int fused_linear_bwd_f16x3_supported(int64_t O, int64_t I, int has_ln, int norm_mode, int has_acc, int has_aux) {
-  (void)has_acc;
-  return (O == 128 && I == 128 && (!has_ln || norm_mode == ALLSET_NORM_LAYER) && !has_aux) ? 1 : 0;
+  (void)has_ln; (void)norm_mode; (void)has_acc;
+  return (O == 128 && I == 128 && !has_aux) ? 1 : 0;
 }
 
 // Called by allset_fused_linear_bwd_all (fused_bwd.hip) after its argument checks (bwd_all_combo: dropout_in only behind relu_in,
@@ -689,11 +696,11 @@ int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool ln, bool d
                                   const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                                   float* gx, int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n,
                                   const uint64_t* seed_base, int64_t psw, int64_t psb, int64_t psl, int64_t gcb, int64_t xcb,
-                                  int64_t gxcb, const float* acc_in, int64_t ldacc) {
+                                  int64_t gxcb, const float* acc_in, int64_t ldacc, float ln_inv) {
 #define ALLSET_S_K(LN, DI, RI, HM, HA)                                                                                            \
   fused_linear_bwd_f16x3_kernel<LN, DI, RI, HM, HA><<<grid, kSBlock, 0, st>>>(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta,  \
                                                                               p_in, seed_in, gx, ldgx, part_ln, part_w, part_b, n, \
-                                                                              seed_base, psw, psb, psl, gcb, xcb, gxcb, acc_in, ldacc)
+                                                                              seed_base, psw, psb, psl, gcb, xcb, gxcb, acc_in, ldacc, ln_inv)
   if (acc_in != nullptr) { ALLSET_S_K(false, false, false, false, true); return 0; }
 #define ALLSET_S_M(LN, DI, RI) do { if (hm) ALLSET_S_K(LN, DI, RI, true, false); else ALLSET_S_K(LN, DI, RI, false, false); } while (0)
   if (!relu) { if (ln) ALLSET_S_M(true, false, false); else ALLSET_S_M(false, false, false); }

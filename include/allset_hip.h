@@ -516,8 +516,8 @@ int allset_fused_linear_bwd(const float* gy, int64_t ldg, const float* y, int64_
  *   part_stride  0: part_w / part_b / part_ln are three dense arrays as sized above; > 0 (>= O*I + O + 2*I in practice): they
  *            point into ONE f32[n_slices*part_stride] buffer, slice k's sections at k*part_stride from each pointer -- one
  *            allset_reduce_partials launch then sums all of a Linear's parameter gradients.
- * Arithmetic: bf16x6 as in the forward, except at O = I = 128 behind a LayerNorm prologue (ALLSET_NORM_LAYER) or none at all, with
- * or without acc_in (i.e. everything but the column-affine prologue and the auxiliary columns):
+ * Arithmetic: bf16x6 as in the forward, except at O = I = 128, whatever the prologue, with or without acc_in (i.e. everything
+ * but allset_fused_linear_bwd_all_aux's auxiliary columns):
  * "fp16x3" (csrc/fused_bwd6.hip) -- every operand is scaled by a power of two (gy per row, W per 32-column slice, the
  * recomputed input against the workgroup's running largest row product) and split into TWO fp16 values, three of the four partial
  * products are accumulated in fp32 on the f16 matrix pipe (half the matrix instructions of bf16x6).  Error per product <= 2^-21
