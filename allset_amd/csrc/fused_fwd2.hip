@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t hash_mix_f(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_F(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool HAS_LN, bool DROP_IN, bool DROP_OUT>
+template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8>
 __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
     auto keep4 = [&](uint64_t seed, int64_t stage, int hb, uint32_t thr, float keep) -> float4 {
       const uint32_t sl = static_cast<uint32_t>(seed);
-      if (thr & kDrop8) {     // 8 bits per element: ONE hash for the lane's float4 (quad index = stage * 1024 + lane part < 1024)
+      // (D8: every active dropout of the launch has the 8-bit resolution -- known at compile time, the 16-bit path and the branch
+      //  between them drop out of the heavy variant's vector loop: -4 % on its launch time)
+      if (D8 || (thr & kDrop8)) {     // 8 bits per element: ONE hash for the lane's float4 (quad index = stage * 1024 + lane part < 1024)
         const uint64_t stage_quad = static_cast<uint64_t>(stage) * (R * KD / 4);
         const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed >> 32);
         const uint32_t lo = static_cast<uint32_t>(stage_quad) | static_cast<uint32_t>((lr * KD + 64 * hb + 4 * c) >> 2);
@@ -368,10 +370,18 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
                                   const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv) {
   const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
   const unsigned grid = static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
-#define ALLSET_F2_K(LN, DI, DO)                                                                                               \
-  fused_linear_fwd_roles_kernel<LN, DI, DO><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
-                                                                       relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
-                                                                       mask_out, xcb, ycb, ln_inv)
+  // the dropout resolution is a function of p alone (common.h drop_threshold): 8 bits per element when p * 256 is an integer
+  auto is8 = [](float p) { const float t8 = p * 256.0f; return p <= 0.f || t8 == floorf(t8); };
+#ifdef ALLSET_ABL_DROP16          // (ablation builds: the 16-bit form for every p, common.h)
+  const bool d8 = false; (void)is8;
+#else
+  const bool d8 = is8(p_in) && is8(p_out);
+#endif
+#define ALLSET_F2_KD(LN, DI, DO, E8)                                                                                              \
+  fused_linear_fwd_roles_kernel<LN, DI, DO, E8><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
+                                                                           relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
+                                                                           mask_out, xcb, ycb, ln_inv)
+#define ALLSET_F2_K(LN, DI, DO) do { if ((DI || DO) && d8) ALLSET_F2_KD(LN, DI, DO, true); else ALLSET_F2_KD(LN, DI, DO, false); } while (0)
   const int v = (gamma != nullptr ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);
   switch (v) {
     case 0: ALLSET_F2_K(false, false, false); break;
@@ -384,5 +394,6 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
     default: ALLSET_F2_K(true, true, true); break;
   }
 #undef ALLSET_F2_K
+#undef ALLSET_F2_KD
   return 0;
 }
