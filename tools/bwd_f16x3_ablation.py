@@ -11,6 +11,8 @@ import torch
 src = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bwd.hip", "fused_bwd4.hip", "fused_bwd6.hip", "abi.hip")]
 if os.environ.get("ALLSET_BWD6_SRC"):          # A/B against another version of the kernel file
     src[2] = os.environ["ALLSET_BWD6_SRC"]
+if os.environ.get("ALLSET_BWD_SRC"):           # (and the matching dispatch file, when the launch signature changed in between)
+    src[0] = os.environ["ALLSET_BWD_SRC"]
 dev = torch.device("cuda:0")
 n, d = 1_000_000, 128
 x = torch.randn(n, d, device=dev); W = torch.randn(d, d, device=dev) / d ** 0.5
