@@ -20,6 +20,11 @@
 // the outputs are bit-identical to that kernel's; the statistics themselves differ in the last bits (DPP row sums vs per-lane
 // partial sums + two shuffles).
 // LDS: 2 x 24 KB images + 2 x 16.5 KB tiles + gamma / beta / bias = 83 KB.
+//
+// Arithmetic (round 4): behind a true LayerNorm prologue the products are formed from TWO fp16 planes per operand, three f16 MFMAs each
+// (template F16, "fp16x3": fused_bwd6.hip has the scheme and its error model) -- 48 MFMAs per wave and stage, two LDS planes, W in 64
+// registers, 112 registers per wave; the matrix waves were this kernel's critical role too (ablation: 0.285 ms, 0.182 without the
+// MFMAs).  Without a norm and in the column-affine mode the operand has no bound known in advance and the kernel stays bf16x6.
 #include <stdlib.h>
 
 #include "common.h"
@@ -27,8 +32,17 @@
 namespace allset {
 
 using bf16x8f = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using f16x8f = __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16;
 using f32x4f = __attribute__((ext_vector_type(4))) float;
-union FragF { uint4 u; bf16x8f v; };
+union FragF { uint4 u; bf16x8f v; f16x8f h; };
+// fp16x3 (fused_bwd6.hip has the scheme): x0, x1 -> packed fp16 planes h = RN16(x), l = RN16(x - h)
+__device__ __forceinline__ void split2_f16_f(float x0, float x1, uint32_t& ph, uint32_t& pl) {
+  float r0, r1;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(x0), "v"(x1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl) : "v"(r0), "v"(r1));
+}
 constexpr int kF2Block = 768;
 constexpr int kF2Rows = 32;                    // rows per stage
 constexpr int kF2VWaves = 8;
@@ -58,7 +72,7 @@ __device__ __forceinline__ uint32_t hash_mix_f(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_F(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8>
+template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8, bool F16>
 __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
@@ -95,6 +109,20 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     return left >= R ? R : (left > 0 ? static_cast<int>(left) : 0);
   };
   __syncthreads();
+  // F16 (a true LayerNorm prologue only): the products are formed from two fp16 planes per operand, three MFMAs each (fused_bwd6.hip).
+  // The LayerNorm output is bounded without a data pass, |u| <= (sqrt(127) max|gamma| + max|beta|) keep, so ONE power of two 2^Su for
+  // the whole launch brings it below 2^14 -- folded into gamma and beta, it costs no instruction; W is scaled per matrix wave's
+  // slice; both are undone where the wave writes its output tile.
+  static_assert(!F16 || HAS_LN, "fp16x3 needs the LayerNorm bound on the operand");
+  int Su = 0;
+  if constexpr (F16) {
+    float g = fmaxf(fabsf(sG[lane0]), fabsf(sG[lane0 + 64])), bm = fmaxf(fabsf(sB[lane0]), fabsf(sB[lane0 + 64]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { g = fmaxf(g, __shfl_xor(g, off)); bm = fmaxf(bm, __shfl_xor(bm, off)); }
+    const float U = (11.27f * g + bm) * (DROP_IN ? 1.f / (1.f - p_in) : 1.f);
+    const int eU = static_cast<int>(__float_as_uint(U) >> 23);          // U < 2^(eU - 126)
+    Su = __builtin_amdgcn_readfirstlane(min(max(140 - eU, -60), 60));
+  }
 #ifdef ALLSET_ABL5_TIMING          // diagnostic builds only: cycles per segment of waves 0 (vector) and 8 (matrix) of workgroup 0
   uint64_t tph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #define ALLSET_FMARK(k) do { const uint64_t tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
@@ -121,6 +149,11 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
       bet[hb] = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
       bia[hb] = *reinterpret_cast<const float4*>(&sBias[64 * hb + 4 * c]);
+      if constexpr (F16) {
+        const float su = __uint_as_float(static_cast<uint32_t>(127 + Su) << 23);
+        gam[hb].x *= su; gam[hb].y *= su; gam[hb].z *= su; gam[hb].w *= su;
+        bet[hb].x *= su; bet[hb].y *= su; bet[hb].z *= su; bet[hb].w *= su;
+      }
     }
     // [set][hb]: the rows of the next kF2Sets stages.  Bytes in flight bound these kernels (~2 us of loaded latency, DESIGN.md 6a'''):
     // a vector wave's share of a stage is 2 KB, so four sets = 64 KB per CU, 16 MB chip-wide -- at 8 registers per set
@@ -192,13 +225,21 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
           const float4 kp = keep4(seed_in, stage, hb, thr_in, keep_in);
           t[hb].x *= kp.x; t[hb].y *= kp.y; t[hb].z *= kp.z; t[hb].w *= kp.w;
         }
-        uint32_t h0, m0, l0, h1, m1, l1;
-        split3_bf16(t[hb].x, t[hb].y, h0, m0, l0);
-        split3_bf16(t[hb].z, t[hb].w, h1, m1, l1);
         const int wo = img_off_f(lr, 128 * hb + 8 * c);
-        *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(img + 2 * PLANE + wo) = make_uint2(l0, l1);
+        if constexpr (F16) {
+          uint32_t h0, l0, h1, l1;
+          split2_f16_f(t[hb].x, t[hb].y, h0, l0);
+          split2_f16_f(t[hb].z, t[hb].w, h1, l1);
+          *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(l0, l1);
+        } else {
+          uint32_t h0, m0, l0, h1, m1, l1;
+          split3_bf16(t[hb].x, t[hb].y, h0, m0, l0);
+          split3_bf16(t[hb].z, t[hb].w, h1, m1, l1);
+          *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(img + 2 * PLANE + wo) = make_uint2(l0, l1);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       request_x(k + kF2Sets, xr);                // into the set just consumed: kF2Sets stages ahead
@@ -269,8 +310,42 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const int m = wave - kF2VWaves;
     // this wave's slice of W^T as MFMA B fragments: output columns 32 m + 16 ct + nn, k-step t, plane pl; lane (nn = lane & 15,
     // kg = lane >> 4) holds W[column][k = 32 kg + 8 t + j], j = 0..7 (the k-order of fused_linear_fwd_x6_kernel)
-    FragF wq[2][4][3];
-    {
+    FragF wq[2][4][F16 ? 2 : 3];
+    float inv_s = 1.f;                           // (fp16x3: undoes the slice's W scale and 2^Su on the way to the output tile)
+    if constexpr (F16) {
+      const int nn = lane0 & 15, kg = lane0 >> 4;
+      float4 wa[2][4], wb[2][4];
+      float amax = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const float4* wr = reinterpret_cast<const float4*>(W + (32 * m + 16 * ct + nn) * KD + 32 * kg + 8 * tt);
+          wa[ct][tt] = wr[0]; wb[ct][tt] = wr[1];
+          amax = fmaxf(fmaxf(fmaxf(fabsf(wa[ct][tt].x), fabsf(wa[ct][tt].y)), fmaxf(fabsf(wa[ct][tt].z), fabsf(wa[ct][tt].w))), amax);
+          amax = fmaxf(fmaxf(fmaxf(fabsf(wb[ct][tt].x), fabsf(wb[ct][tt].y)), fmaxf(fabsf(wb[ct][tt].z), fabsf(wb[ct][tt].w))), amax);
+        }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+      const int ew = __builtin_amdgcn_readfirstlane(min(max(static_cast<int>(__float_as_uint(amax) >> 23), 20), 254));
+      const float sw = __uint_as_float(static_cast<uint32_t>(254 + 13 - ew) << 23);       // slice maximum -> [2^13, 2^14)
+      // 2^(ew - 140 - Su) as two factors (each exponent field stays valid for any ew, Su)
+      const int X = ew - 140 - Su, X1 = X >> 1, X2 = X - X1;
+      inv_s = __uint_as_float(static_cast<uint32_t>(127 + X1) << 23) * __uint_as_float(static_cast<uint32_t>(127 + X2) << 23);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const float4 a = wa[ct][tt], b = wb[ct][tt];
+          uint32_t ph[4], pl[4];
+          split2_f16_f(a.x * sw, a.y * sw, ph[0], pl[0]);
+          split2_f16_f(a.z * sw, a.w * sw, ph[1], pl[1]);
+          split2_f16_f(b.x * sw, b.y * sw, ph[2], pl[2]);
+          split2_f16_f(b.z * sw, b.w * sw, ph[3], pl[3]);
+          wq[ct][tt][0].u = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          wq[ct][tt][1].u = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+    } else {
       const int nn = lane0 & 15, kg = lane0 >> 4;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -293,10 +368,11 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       const int ri = lane & 15, kg = lane >> 4;
       const uint8_t* img = sX + (k & 1) * IMG;
       float* ty = sY + (k & 1) * (R * SPY);
+      constexpr int NP = F16 ? 2 : 3;
       auto load_a = [&](FragF (&f0)[3], FragF (&f1)[3], int tt) {
         const int o0 = img_off_f(ri, 64 * kg + 16 * tt), o1 = img_off_f(16 + ri, 64 * kg + 16 * tt);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
           f0[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o0);
           f1[pl].u = *reinterpret_cast<const uint4*>(img + pl * PLANE + o1);
         }
@@ -319,13 +395,27 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
         for (int pr = 0; pr < 0; ++pr) {
 #else
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr) {
+        for (int pr = 0; pr < (F16 ? 0 : 6); ++pr) {
 #endif
-          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[PA_[pr]].v, wq[0][tt][PB_[pr]].v, acc[0][0], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[PA_[pr]].v, wq[0][tt][PB_[pr]].v, acc[1][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[PA_[pr]].v, wq[1][tt][PB_[pr]].v, acc[0][1], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[PA_[pr]].v, wq[1][tt][PB_[pr]].v, acc[1][1], 0, 0, 0);
+          if constexpr (!F16) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[PA_[pr]].v, wq[0][tt][PB_[pr]].v, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[PA_[pr]].v, wq[0][tt][PB_[pr]].v, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[PA_[pr]].v, wq[1][tt][PB_[pr]].v, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[PA_[pr]].v, wq[1][tt][PB_[pr]].v, acc[1][1], 0, 0, 0);
+          }
         }
+#ifndef ALLSET_ABL5_NOMFMA
+        if constexpr (F16) {
+          constexpr int QA_[3] = {1, 0, 0}, QB_[3] = {0, 1, 0};     // l.h, h.l, h.h
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[QA_[pr]].h, wq[0][tt][QB_[pr]].h, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[QA_[pr]].h, wq[0][tt][QB_[pr]].h, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[QA_[pr]].h, wq[1][tt][QB_[pr]].h, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[QA_[pr]].h, wq[1][tt][QB_[pr]].h, acc[1][1], 0, 0, 0);
+          }
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // acc[rt][ct][r] = y[row 16 rt + 4 kg + r][column 32 m + 16 ct + ri]
@@ -334,7 +424,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ty[(16 * rt + 4 * kg + r) * SPY + 32 * m + 16 * ct + ri] = acc[rt][ct][r];
+          for (int r = 0; r < 4; ++r) ty[(16 * rt + 4 * kg + r) * SPY + 32 * m + 16 * ct + ri] = F16 ? acc[rt][ct][r] * inv_s : acc[rt][ct][r];
     };
     ALLSET_F2_TICK();
     for (int64_t k = 0; k < T; ++k) {
@@ -377,10 +467,17 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
 #else
   const bool d8 = is8(p_in) && is8(p_out);
 #endif
-#define ALLSET_F2_KD(LN, DI, DO, E8)                                                                                              \
-  fused_linear_fwd_roles_kernel<LN, DI, DO, E8><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
-                                                                           relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
-                                                                           mask_out, xcb, ycb, ln_inv)
+  // fp16x3 arithmetic behind a true LayerNorm prologue (its bound on the operand); bf16x6 otherwise (no norm, column-affine mode)
+#ifdef ALLSET_NO_F16X3
+  const bool f16 = false;
+#else
+  const bool f16 = gamma != nullptr && ln_inv != 0.f;
+#endif
+#define ALLSET_F2_KE(LN, DI, DO, E8, H16)                                                                                              \
+  fused_linear_fwd_roles_kernel<LN, DI, DO, E8, H16><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
+                                                                                relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
+                                                                                mask_out, xcb, ycb, ln_inv)
+#define ALLSET_F2_KD(LN, DI, DO, E8) do { if (LN && f16) ALLSET_F2_KE(LN, DI, DO, E8, LN); else ALLSET_F2_KE(LN, DI, DO, E8, false); } while (0)
 #define ALLSET_F2_K(LN, DI, DO) do { if ((DI || DO) && d8) ALLSET_F2_KD(LN, DI, DO, true); else ALLSET_F2_KD(LN, DI, DO, false); } while (0)
   const int v = (gamma != nullptr ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);
   switch (v) {
@@ -395,5 +492,6 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
   }
 #undef ALLSET_F2_K
 #undef ALLSET_F2_KD
+#undef ALLSET_F2_KE
   return 0;
 }

@@ -661,10 +661,10 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "dtype_note": ("fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: fp32 products formed on the 16-bit "
-                       "matrix pipes and accumulated in fp32 -- forward (and every backward without a LayerNorm prologue): every "
-                       "operand split exactly into three bf16, six of the nine partial products (bf16x6); backward behind a LayerNorm "
-                       "prologue at 128 x 128: every operand scaled by a power of two and split into two fp16, three of the four "
-                       "partial products (fp16x3, per-product error <= 2^-21 relative) -- measured error vs float64 at the level of "
+                       "matrix pipes and accumulated in fp32 -- at 128 x 128 the forward behind a LayerNorm prologue and the one-pass "
+                       "backward: every operand scaled by a power of two and split into two fp16, three of the four partial products "
+                       "(fp16x3, per-product error <= 2^-21 relative); other shapes / prologues: every operand split exactly into "
+                       "three bf16, six of the nine partial products (bf16x6) -- measured error vs float64 at the level of "
                        "a native fp32 MFMA / library fp32 GEMM (DESIGN.md section 6.1, tests/test_gpu_dense.py)")
         if args.dtype == "f32" else
         ("bf16 tensors end to end (BASELINE configs[4] regime): bf16 instantiations of the gather kernels with fp32 "
@@ -689,8 +689,8 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         "dense_tail": {"ms_per_step": dense_ms, "note": ("HIP dense-tail kernels per step (fused norm+Linear forward; ONE backward "
                        "kernel per Linear producing input gradient, LayerNorm parameter gradients and the weight / bias "
                        "gradient from a single read of gy and x). fp32 in, fp32 out, fp32-accurate arithmetic on the 16-bit "
-                       "matrix pipes: bf16x6 (operands split exactly into 3 bf16, 6 of 9 products) in the forward, fp16x3 (2 scaled "
-                       "fp16 planes, 3 of 4 products) in the LayerNorm-prologue backward, accumulated in fp32 (error at a library "
+                       "matrix pipes: fp16x3 (2 scaled fp16 planes, 3 of 4 products) in the LayerNorm-prologue forward and the one-pass "
+                       "backward, bf16x6 (3 bf16 planes, 6 of 9 products) elsewhere, accumulated in fp32 (error at a library "
                        "fp32 GEMM's level, tests/test_gpu_dense.py); HBM-bound: gbps = algorithmic activation bytes / time")
                        if args.dtype == "f32" else
                        ("HIP dense-tail kernels per step, bf16 in / out with fp32 accumulation: Linear forward / backward-data "

@@ -464,8 +464,10 @@ int allset_ln_res_bwd_pma_bf16(const void* gy, int64_t ldg, const void* x, int64
  * One read + one write of the activation matrix.  Arithmetic: fp32 on the bf16 matrix pipe -- every operand is split
  * exactly into three bf16 values and six of the nine partial products are accumulated in fp32 ("bf16x6", dropped terms
  * <= 2^-23 relative: as accurate as a native fp32 MFMA, 2.7x its rate on gfx950; the only
- * kernel family of the FORWARD since ABI 9; the one-pass backward behind a LayerNorm prologue at 128 x 128 uses two fp16 planes,
- * see allset_fused_linear_bwd_all).  stats (f32[n*2] =
+ * kernel family since ABI 9 -- except at K = N = 128 behind a LayerNorm prologue (ALLSET_NORM_LAYER), where the forward uses the
+ * two-fp16-plane scheme of the one-pass backward, see allset_fused_linear_bwd_all: the LayerNorm output is bounded, one power of
+ * two for the launch and one per 32-column slice of W bring the operands into fp16's window; error per product <= 2^-21 relative,
+ * tests/test_gpu_dense.py test_fused_linear_forward_fp16x3_against_float64).  stats (f32[n*2] =
  * {mean, rstd}) is written when the LayerNorm prologue is on.  allset_fused_linear_supported(K, N) -> 1/0.
  *
  * Auxiliary output columns (optional, bf16x6 kernels): aux_out f32[n*4] = pro(x) @ aux_w^T + aux_b with aux_w f32[4*K],

@@ -313,6 +313,48 @@ def test_fused_linear_bf16x6_is_fp32_accurate(K, N, device, monkeypatch):
     assert errs["bf16x6"] < 2.0 * errs["f32"], errs
 
 
+@pytest.mark.parametrize("kind", ["plain", "wide_rows", "small_gamma", "large_beta", "w_column_scales"])
+@pytest.mark.parametrize("n", [1, 4099, 70001])
+def test_fused_linear_forward_fp16x3_against_float64(n, kind, device):
+    """The forward behind a LayerNorm prologue at 128 x 128 forms its products from two fp16 planes per operand too (csrc/fused_fwd2.hip
+    F16: the LayerNorm output is bounded, so one power of two for the launch -- folded into gamma / beta -- and one per 32-column
+    slice of W bring the operands into fp16's window).  Against float64 in units of sum |terms| (the terms of the LayerNorm affine
+    counted): at the level of torch's own fp32 LayerNorm + addmm on the same data."""
+    from allset_amd import dense
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(31 * n + len(kind))
+    x = torch.randn(n, 128, generator=g)
+    W = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    b = torch.randn(128, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.3 * torch.randn(128, generator=g)
+    if kind == "wide_rows":
+        x = x * torch.exp(3 * torch.randn(n, 128, generator=g)) * torch.exp2(torch.randint(-20, 21, (n, 1), generator=g).float())
+    elif kind == "small_gamma":
+        gamma, beta = gamma * 1e-6, beta * 1e-6
+    elif kind == "large_beta":
+        beta = beta * 1e4
+    elif kind == "w_column_scales":
+        W = W * torch.exp2(torch.randint(-12, 13, (1, 128), generator=g).float())
+    x, W, b, gamma, beta = (t.to(device) for t in (x, W, b, gamma, beta))
+    y, st = dense.fused_linear_fwd(x, W, b, gamma, beta, 1e-5, False, 0.0, 0, False, 0.0, 0, None, None)
+    xd = x.double()
+    mean = xd.mean(1, keepdim=True)
+    xh = (xd - mean) * (((xd - mean) ** 2).mean(1, keepdim=True) + 1e-5).rsqrt()
+    u = xh * gamma.double() + beta.double()
+    ref = u @ W.double().t() + b.double()
+    scale = ((xh * gamma.double()).abs() + beta.double().abs()) @ W.double().abs().t() + b.double().abs() + 1e-300
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        yt = torch.addmm(b, F.layer_norm(x, (128,), gamma, beta, 1e-5), W.t())
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    e_k = float(((y.double() - ref).abs() / scale).max())
+    e_t = float(((yt.double() - ref).abs() / scale).max())
+    assert torch.isfinite(y).all()
+    assert e_k < max(2e-6, 3.0 * e_t), (e_k, e_t)
+
+
 @pytest.mark.parametrize("n", [1, 33, 4099, 70001])
 @pytest.mark.parametrize("kind", ["plain", "tiny", "huge", "row_scales", "late_large_row", "small_gamma", "column_scales"])
 def test_one_pass_backward_fp16x3_against_float64(n, kind, device):
