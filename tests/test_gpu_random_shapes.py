@@ -77,9 +77,16 @@ def test_deepsets_aggregate_random(inc, d, aggr, weighted, device):
     I = Incidence.from_edge_index(ei.to(device), n_src=n_s, n_dst=n_t)
     out = deepsets_aggregate(xd, I, norm.to(device), aggr)
     (out * G.to(device)).sum().backward()
-    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    # (both sides are fp32 sums in different orders: a row of thousands of incidences -- the one_row shape -- carries 1e-7 of its sum of
+    #  |terms| as rounding, more than a flat 1e-4 when the sum itself cancels; found by a fresh-seed sweep at n_t = 1, d = 128)
+    wabs = norm.abs().double() if weighted else torch.ones(nnz, dtype=torch.float64)
+    row_abs = torch.zeros(n_t, dtype=torch.float64).index_add_(0, ei[1], x.abs().double()[ei[0]].amax(1) * wabs) if nnz else torch.zeros(1, dtype=torch.float64)
+    col_abs = torch.zeros(n_s, dtype=torch.float64).index_add_(0, ei[0], G.abs().double()[ei[1]].amax(1) * wabs) if nnz else torch.zeros(1, dtype=torch.float64)
+    atol_o = max(1e-4, 5e-7 * float(row_abs.max())) if aggr in ("add", "mean") else 1e-4
+    atol_g = max(1e-4, 5e-7 * float(col_abs.max()))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=atol_o)
     if aggr in ("add", "mean"):                               # max/min ties may pick another (equal) argument
-        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=atol_g)
     else:
         torch.testing.assert_close(xd.grad.sum(0).cpu(), xr.grad.sum(0), rtol=1e-3, atol=1e-3)
 
@@ -110,7 +117,7 @@ def test_pma_aggregate_random(inc, heads, c, device):
     # a target that holds thousands of incidences sums thousands of fp32 terms (and its logit gradient cancels almost
     # completely): the rounding scale grows with the longest row -- found by fresh-seed runs with 2000 duplicates of one pair
     longest = int(max(torch.bincount(ei[1]).max(), torch.bincount(ei[0]).max())) if ei.shape[1] else 1      # target or source row
-    slack = max(1.0, longest / 256.0)
+    slack = max(1.0, longest / 128.0)           # (a lone source under ~800 incidences: its alpha-gradient is an exact 0 reached as an fp32 sum of that many terms)
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4 * slack)
     if ei.shape[1]:
         torch.testing.assert_close(Vd.grad.cpu(), Vr.grad, rtol=1e-4, atol=1e-4 * slack)
@@ -512,4 +519,6 @@ def test_fused_loss_random(n, C, frac, sd, device):
     ref = -(F.log_softmax(b, dim=1).gather(1, yv.view(-1, 1)).squeeze(1) * w.double()).sum() / cnt
     ref.backward()
     torch.testing.assert_close(loss.double(), ref, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(a.grad.double(), b.grad, rtol=1e-5, atol=1e-7)
+    # (softmax - onehot cancels in fp32 where the label's probability is 1 - 1e-5: an absolute 3e-7 before the division by cnt; found by
+    #  a fresh-seed sweep at n = 1, C = 2)
+    torch.testing.assert_close(a.grad.double(), b.grad, rtol=1e-5, atol=max(1e-7, 5e-7 / cnt))
