@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     for (int off = 1; off < 64; off <<= 1) { g = fmaxf(g, __shfl_xor(g, off)); bm = fmaxf(bm, __shfl_xor(bm, off)); }
     const float U = (11.27f * g + bm) * (DROP_IN ? 1.f / (1.f - p_in) : 1.f);
     const int eU = static_cast<int>(__float_as_uint(U) >> 23);          // U < 2^(eU - 126)
-    Su = __builtin_amdgcn_readfirstlane(min(max(140 - eU, -60), 60));
+    Su = __builtin_amdgcn_readfirstlane(min(max(140 - eU, -100), 100));
   }
 #ifdef ALLSET_ABL5_TIMING          // diagnostic builds only: cycles per segment of waves 0 (vector) and 8 (matrix) of workgroup 0
   uint64_t tph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
