@@ -1,4 +1,5 @@
-"""ctypes binding of ``liballset_hip.so`` (C ABI: ``include/allset_hip.h``).
+"""ctypes binding of ``liballset_hip.so`` (C ABI: ``include/allset_hip.h`` = the core aggregation surface, ``include/allset_hip_ext.h`` =
+the dense tail and the rest of this package's plumbing).
 
 There is deliberately no fallback: if the shared library is missing or a call fails, this raises.
 ``import torch`` must precede the ``CDLL`` so that the library's ``libamdhip64.so.7`` dependency
@@ -14,10 +15,12 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
+CORE_ABI_VERSION = 1
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 F32, BF16 = 0, 1
+ARITH_AUTO, ARITH_BF16X6, ARITH_FP16X3 = 0, 1, 2          # include/allset_hip_ext.h ALLSET_ARITH_*
 REDUCE_CODES = {"add": SUM, "sum": SUM, "mean": MEAN, "max": MAX, "min": MIN}
 
 # name -> argtypes, in the order of include/allset_hip.h.  Every function returns int except
@@ -25,6 +28,7 @@ REDUCE_CODES = {"add": SUM, "sum": SUM, "mean": MEAN, "max": MAX, "min": MIN}
 _P = c_void_p
 SIGNATURES = {
     "allset_version": [],
+    "allset_core_version": [],
     "allset_csr_build_workspace_bytes": [c_int64, c_int64, POINTER(c_size_t)],
     "allset_csr_build": [_P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P],
     "allset_segreduce_fwd": [c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P],
@@ -105,6 +109,12 @@ SIGNATURES = {
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, _P],
     "allset_fused_linear_blocked_supported": [c_int64, c_int64],
+    "allset_fused_linear_arith_supported": [c_int, c_int64, c_int64, c_int, c_int, c_int],
+    "allset_fused_linear_fwd_ex": [_P, c_int64, c_int64, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
+                                   _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, _P],
+    "allset_fused_linear_bwd_all_ex": [_P, c_int64, c_int64, _P, c_float, _P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_float,
+                                       c_uint64, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int64,
+                                       c_int64, c_int, _P],
     "allset_fused_linear_fwd_blocked": [_P, c_int64, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                                         _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P],
     "allset_fused_linear_bwd_all_blocked": [_P, c_int64, c_int64, _P, c_float, _P, _P, c_int64, c_int64, _P, _P, _P, c_int, c_float,

@@ -1,4 +1,4 @@
-// Version + thread-local error text of the C ABI (include/allset_hip.h).  No state besides the
+// Versions + thread-local error text of the C ABI (include/allset_hip.h: core; include/allset_hip_ext.h: the rest).  No state besides the
 // per-thread message buffer; nothing here touches the device.
 #include <stdarg.h>
 #include <string.h>
@@ -21,5 +21,7 @@ void clear_error() { g_error[0] = '\0'; }
 }  // namespace allset
 
 extern "C" int allset_version(void) { return ALLSET_ABI_VERSION; }
+
+extern "C" int allset_core_version(void) { return ALLSET_CORE_ABI_VERSION; }
 
 extern "C" const char* allset_last_error(void) { return allset::g_error; }

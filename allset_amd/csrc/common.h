@@ -6,7 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "../../include/allset_hip.h"
+#include "../../include/allset_hip_ext.h"
 
 namespace allset {
 

@@ -627,9 +627,11 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
                                      int64_t ldgx, float* part_ln, float* part_w, float* part_b, int64_t n_slices,
                                      int64_t n, int64_t O, int64_t I, const uint64_t* seed_base, const float* acc_in,
                                      int64_t ldacc, int64_t part_stride, void* stream, int64_t gcb, int64_t xcb, int64_t gxcb,
-                                     int norm_mode = ALLSET_NORM_LAYER) {
+                                     int norm_mode = ALLSET_NORM_LAYER, int arith = ALLSET_ARITH_AUTO) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_all: negative size");
+  ALLSET_REQUIRE(arith == ALLSET_ARITH_AUTO || arith == ALLSET_ARITH_BF16X6 || arith == ALLSET_ARITH_FP16X3,
+                 "fused_linear_bwd_all: arith must be ALLSET_ARITH_AUTO, ALLSET_ARITH_BF16X6 or ALLSET_ARITH_FP16X3");
   ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || norm_mode == ALLSET_NORM_COLUMN_AFFINE, "fused_linear_bwd_all: norm_mode must be ALLSET_NORM_LAYER or ALLSET_NORM_COLUMN_AFFINE");
   ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || stats != nullptr, "fused_linear_bwd_all: the column-affine prologue needs the {0, 1} row statistics its forward wrote, gamma (scale) and beta (shift)");
   const float ln_inv = norm_mode == ALLSET_NORM_COLUMN_AFFINE ? 0.f : 1.f / static_cast<float>(I);
@@ -681,8 +683,13 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
   ALLSET_REQUIRE(ldg < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24) && ldacc < (1 << 24),
                  "fused_linear_bwd_all: leading dimensions must stay below 2^24 elements (32-bit offsets inside a 16-row chunk)");
   const bool drop = p_in > 0.f, relu = relu_in != 0, hm = mask != nullptr, ha = acc_in != nullptr;
+  const bool f16x3_built = roles_kernel && fused_linear_bwd_f16x3_supported(O, I, has_ln, norm_mode, ha, 0);
+  if (arith == ALLSET_ARITH_FP16X3 && !f16x3_built) {
+    set_error("fused_linear_bwd_all: ALLSET_ARITH_FP16X3 is built for O = I = 128 only (allset_fused_linear_arith_supported)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
 #ifndef ALLSET_NO_F16X3
-  if (roles_kernel && fused_linear_bwd_f16x3_supported(O, I, has_ln, norm_mode, ha, 0)) {
+  if (f16x3_built && arith != ALLSET_ARITH_BF16X6) {
     launch_fused_linear_bwd_f16x3(grid, st, has_ln, drop, relu, hm, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in,
                                   gx, ldgx, part_ln, part_w, part_b, n, seed_base, psw, psb, psl, gcb, xcb, gxcb, acc_in, ldacc, ln_inv);
     ALLSET_LAUNCH_CHECK();
@@ -774,6 +781,34 @@ extern "C" int allset_fused_linear_bwd_all_nm(const float* gy, int64_t ldg, cons
                                    part_w, part_b, n_slices, n, O, I, seed_base, nullptr, 0, part_stride, stream, 0, 0, 0, norm_mode);
 }
 
+
+// Superset entry (ABI 11): every option of the three entries above in one call, plus the choice of arithmetic.
+extern "C" int allset_fused_linear_bwd_all_ex(const float* gy, int64_t ldg, int64_t gy_block_cols, const uint32_t* mask, float p_out,
+                                              const float* W, const float* x, int64_t ldx, int64_t x_block_cols, const float* stats,
+                                              const float* gamma, const float* beta, int norm_mode, int relu_in, float p_in,
+                                              uint64_t seed_in, float* gx, int64_t ldgx, int64_t gx_block_cols, float* part_ln,
+                                              float* part_w, float* part_b, int64_t n_slices, int64_t n, int64_t O, int64_t I,
+                                              const uint64_t* seed_base, const float* acc_in, int64_t ldacc, int64_t part_stride,
+                                              int arith, void* stream) {
+  return fused_linear_bwd_all_impl(gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, relu_in, p_in, seed_in, gx, ldgx, part_ln,
+                                   part_w, part_b, n_slices, n, O, I, seed_base, acc_in, ldacc, part_stride, stream, gy_block_cols,
+                                   x_block_cols, gx_block_cols, norm_mode, arith);
+}
+
+// 1 = the fused Linear of this direction (0 forward, 1 one-pass backward) has a kernel in arithmetic `arith` at these widths
+// (AUTO and BF16X6: wherever the entry itself is built; FP16X3: the O = I = 128 split-role kernels -- forward only behind a
+// LayerNorm prologue, whose bound on the operand it needs).
+extern "C" int allset_fused_linear_arith_supported(int direction, int64_t K, int64_t N, int has_ln, int norm_mode, int arith) {
+  if (!((K == 64 || K == 128) && (N == 64 || N == 128))) return 0;
+  if (arith == ALLSET_ARITH_AUTO || arith == ALLSET_ARITH_BF16X6) return 1;
+  if (arith != ALLSET_ARITH_FP16X3) return 0;
+#ifdef ALLSET_NO_F16X3
+  return 0;
+#else
+  if (K != 128 || N != 128) return 0;
+  return direction == 0 ? ((has_ln && norm_mode == ALLSET_NORM_LAYER) ? 1 : 0) : 1;
+#endif
+}
 
 // The same pass with gy / x / gx COLUMN-BLOCKED ([cols / cb][n][cb], ld == cb; 0 = row-major): see allset_fused_linear_fwd_blocked.
 extern "C" int allset_fused_linear_bwd_all_blocked(const float* gy, int64_t ldg, int64_t gy_block_cols, const uint32_t* mask,

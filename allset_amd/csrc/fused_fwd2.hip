@@ -457,7 +457,7 @@ int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux) {
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
-                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv) {
+                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv, int arith) {
   const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
   const unsigned grid = static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));      // one persistent workgroup per CU
   // the dropout resolution is a function of p alone (common.h drop_threshold): 8 bits per element when p * 256 is an integer
@@ -469,9 +469,9 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
 #endif
   // fp16x3 arithmetic behind a true LayerNorm prologue (its bound on the operand); bf16x6 otherwise (no norm, column-affine mode)
 #ifdef ALLSET_NO_F16X3
-  const bool f16 = false;
+  const bool f16 = false; (void)arith;
 #else
-  const bool f16 = gamma != nullptr && ln_inv != 0.f;
+  const bool f16 = gamma != nullptr && ln_inv != 0.f && arith != ALLSET_ARITH_BF16X6;
 #endif
 #define ALLSET_F2_KE(LN, DI, DO, E8, H16)                                                                                              \
   fused_linear_fwd_roles_kernel<LN, DI, DO, E8, H16><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \

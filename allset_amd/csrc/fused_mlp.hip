@@ -647,7 +647,7 @@ int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux);
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
-                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv);
+                                  const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv, int arith);
 
 // 1 = cb is a usable column-block width for a K-column operand (a power of two, 4 <= cb <= K / 2, the operand's ld == cb)
 static bool block_cols_ok(int64_t cb, int64_t K, int64_t ld) {
@@ -659,9 +659,12 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
                                  int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
                                  float* stats, int64_t n, int64_t K, int64_t N, const uint64_t* seed_base,
                                  uint32_t* mask_out, const float* aux_w, const float* aux_b, float* aux_out,
-                                 void* stream, int64_t xcb, int64_t ycb, int norm_mode = ALLSET_NORM_LAYER) {
+                                 void* stream, int64_t xcb, int64_t ycb, int norm_mode = ALLSET_NORM_LAYER,
+                                 int arith = ALLSET_ARITH_AUTO) {
   clear_error();
   ALLSET_REQUIRE(n >= 0, "fused_linear_fwd: negative size");
+  ALLSET_REQUIRE(arith == ALLSET_ARITH_AUTO || arith == ALLSET_ARITH_BF16X6 || arith == ALLSET_ARITH_FP16X3,
+                 "fused_linear_fwd: arith must be ALLSET_ARITH_AUTO, ALLSET_ARITH_BF16X6 or ALLSET_ARITH_FP16X3");
   ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || norm_mode == ALLSET_NORM_COLUMN_AFFINE, "fused_linear_fwd: norm_mode must be ALLSET_NORM_LAYER or ALLSET_NORM_COLUMN_AFFINE");
   ALLSET_REQUIRE(norm_mode == ALLSET_NORM_LAYER || gamma != nullptr, "fused_linear_fwd: the column-affine prologue needs gamma (scale) and beta (shift)");
   // column affine = the LayerNorm prologue with the row statistics switched off: mean = s * 0, rstd = rsqrt(q * 0 + 1)
@@ -685,10 +688,16 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
   ALLSET_REQUIRE((xcb == 0 && ycb == 0) || n * 128 * 4 < (int64_t{1} << 32), "fused_linear_fwd_blocked: a blocked operand must stay below 4 GiB (32-bit lane offsets)");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int has_ln = gamma != nullptr;
-  if (fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
-      (reinterpret_cast<uintptr_t>(stats) & 7u) == 0) {                   // K = N = 128: the split-role kernel (fused_fwd2.hip)
+  const bool roles = fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
+                     (reinterpret_cast<uintptr_t>(stats) & 7u) == 0;
+  if (arith == ALLSET_ARITH_FP16X3 && !(roles && has_ln && norm_mode == ALLSET_NORM_LAYER)) {
+    set_error("fused_linear_fwd: ALLSET_ARITH_FP16X3 is built for K = N = 128 behind a LayerNorm prologue only "
+              "(allset_fused_linear_arith_supported)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (roles) {                                                            // K = N = 128: the split-role kernel (fused_fwd2.hip)
     launch_fused_linear_fwd_roles(st, x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy,
-                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out), xcb, ycb, ln_inv);
+                                  stats, n, seed_base, reinterpret_cast<uint32_t*>(mask_out), xcb, ycb, ln_inv, arith);
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }
@@ -832,6 +841,17 @@ extern "C" int allset_fused_linear_fwd_nm(const float* x, int64_t ldx, const flo
                                           void* stream) {
   return fused_linear_fwd_impl(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,
                                K, N, seed_base, mask_out, nullptr, nullptr, nullptr, stream, 0, 0, norm_mode);
+}
+
+// Superset entry (ABI 11): every option of allset_fused_linear_fwd / _nm / _blocked in one call, plus the choice of arithmetic.
+extern "C" int allset_fused_linear_fwd_ex(const float* x, int64_t ldx, int64_t x_block_cols, const float* gamma, const float* beta,
+                                          float eps, int norm_mode, int relu_in, float p_in, uint64_t seed_in, const float* W,
+                                          const float* bias, int relu_out, float p_out, uint64_t seed_out, float* y, int64_t ldy,
+                                          int64_t y_block_cols, float* stats, int64_t n, int64_t K, int64_t N,
+                                          const uint64_t* seed_base, uint32_t* mask_out, const float* aux_w, const float* aux_b,
+                                          float* aux_out, int arith, void* stream) {
+  return fused_linear_fwd_impl(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n,
+                               K, N, seed_base, mask_out, aux_w, aux_b, aux_out, stream, x_block_cols, y_block_cols, norm_mode, arith);
 }
 
 // 1 = allset_fused_linear_fwd_blocked / allset_fused_linear_bwd_all_blocked take column-blocked operands at these widths

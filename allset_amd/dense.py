@@ -417,6 +417,59 @@ def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Te
     return gx, red[0], red[1]
 
 
+# ---- arithmetic of the fused Linear kernels (include/allset_hip_ext.h ALLSET_ARITH_*) ---------------------------------------------
+_ARITH_NAMES = {"auto": _lib.ARITH_AUTO, "bf16x6": _lib.ARITH_BF16X6, "strict": _lib.ARITH_BF16X6, "exact": _lib.ARITH_BF16X6,
+                "fp16x3": _lib.ARITH_FP16X3}
+_arith = _lib.ARITH_AUTO
+
+
+def set_arithmetic(mode) -> str:
+    """How the fused Linear kernels (widths 64 / 128) emulate the reference's fp32 products on the 16-bit matrix pipe:
+    ``"auto"`` (default: fp16x3 where built -- K = N = 128 --, bf16x6 elsewhere; a function of the shapes only), ``"bf16x6"`` (alias
+    ``"strict"`` / ``"exact"``: the exact three-plane split everywhere, accurate for ANY dynamic range), ``"fp16x3"`` (as auto where
+    it is built; shapes without an fp16x3 kernel keep bf16x6).  Process-wide; returns the previous mode's name.  The choice travels
+    as an argument of every call (the library keeps no state).  A backward runs in the mode that is set when IT runs."""
+    global _arith
+    if isinstance(mode, str):
+        if mode not in _ARITH_NAMES:
+            raise ValueError(f"set_arithmetic: unknown mode {mode!r} (auto, bf16x6 / strict / exact, fp16x3)")
+        code = _ARITH_NAMES[mode]
+    else:
+        code = int(mode)
+        if code not in (_lib.ARITH_AUTO, _lib.ARITH_BF16X6, _lib.ARITH_FP16X3):
+            raise ValueError(f"set_arithmetic: unknown mode {mode!r}")
+    prev, _arith = _arith, code
+    return get_arithmetic(prev)
+
+
+def get_arithmetic(code: Optional[int] = None) -> str:
+    return {_lib.ARITH_AUTO: "auto", _lib.ARITH_BF16X6: "bf16x6", _lib.ARITH_FP16X3: "fp16x3"}[_arith if code is None else code]
+
+
+class arithmetic:
+    """``with dense.arithmetic("strict"): ...`` -- :func:`set_arithmetic` for a block."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_arithmetic(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_arithmetic(self.prev)
+        return False
+
+
+def _arith_for(direction: int, K: int, N: int, has_ln: bool, norm_mode: int) -> int:
+    """The ``arith`` argument of a call: the process-wide mode; an explicit fp16x3 request degrades to AUTO for shapes the fp16x3
+    kernels are not built for (the library itself would refuse it)."""
+    if _arith == _lib.ARITH_FP16X3 and not _lib.load().allset_fused_linear_arith_supported(direction, int(K), int(N), int(has_ln),
+                                                                                          int(norm_mode), _lib.ARITH_FP16X3):
+        return _lib.ARITH_AUTO
+    return _arith
+
+
 def fused_linear_supported(K: int, N: int) -> bool:
     return bool(_lib.load().allset_fused_linear_supported(K, N))
 
@@ -448,22 +501,15 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
     weight = weight.contiguous()
     y = torch.empty((n, N), dtype=x.dtype, device=dev)
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev) if gamma is not None else None
-    if norm_mode:
-        if aux_out is not None or gamma is None:
-            raise _lib.AllSetHipError("fused_linear_fwd: the column-affine prologue takes gamma / beta and no auxiliary columns")
-        with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
-            check(_lib.load().allset_fused_linear_fwd_nm(
-                ptr(x), _ld(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(norm_mode), int(relu_in), p_in, seed_in,
-                ptr(weight), ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
-                ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), stream_of(dev)), "allset_fused_linear_fwd_nm")
-        return y, stats
+    if norm_mode and (aux_out is not None or gamma is None):
+        raise _lib.AllSetHipError("fused_linear_fwd: the column-affine prologue takes gamma / beta and no auxiliary columns")
     with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
-        check(_lib.load().allset_fused_linear_fwd(
-            ptr(x), _ld(x), ptr(gamma.contiguous() if gamma is not None else None),
-            ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
-            ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1),
-            ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), ptr(aux_w), ptr(aux_b), ptr(aux_out), stream_of(dev)),
-            "allset_fused_linear_fwd")
+        check(_lib.load().allset_fused_linear_fwd_ex(
+            ptr(x), _ld(x), 0, ptr(gamma.contiguous() if gamma is not None else None),
+            ptr(beta.contiguous() if beta is not None else None), eps, int(norm_mode), int(relu_in), p_in, seed_in, ptr(weight),
+            ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1), 0,
+            ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), ptr(aux_w), ptr(aux_b), ptr(aux_out),
+            _arith_for(0, K, N, gamma is not None, norm_mode), stream_of(dev)), "allset_fused_linear_fwd_ex")
     return y, stats
 
 
@@ -489,11 +535,12 @@ def fused_linear_fwd_blocked(x: Tensor, x_cb: int, weight: Tensor, bias: Optiona
     y = torch.empty(((N // y_cb) * n, y_cb) if y_cb else (n, N), dtype=x.dtype, device=dev)
     stats = torch.empty((n, 2), dtype=torch.float32, device=dev) if gamma is not None else None
     with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N) * 4):
-        check(_lib.load().allset_fused_linear_fwd_blocked(
+        check(_lib.load().allset_fused_linear_fwd_ex(
             ptr(x), x_cb if x_cb else _ld(x), x_cb, ptr(gamma.contiguous() if gamma is not None else None),
-            ptr(beta.contiguous() if beta is not None else None), eps, int(relu_in), p_in, seed_in, ptr(weight),
+            ptr(beta.contiguous() if beta is not None else None), eps, 0, int(relu_in), p_in, seed_in, ptr(weight),
             ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), y_cb if y_cb else max(N, 1),
-            y_cb, ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), stream_of(dev)), "allset_fused_linear_fwd_blocked")
+            y_cb, ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), ptr(None), ptr(None), ptr(None),
+            _arith_for(0, K, N, gamma is not None, 0), stream_of(dev)), "allset_fused_linear_fwd_ex")
     return y, stats
 
 
@@ -521,11 +568,12 @@ def fused_linear_bwd_all_blocked(gy: Tensor, gy_cb: int, mask: Optional[Tensor],
     part_w, part_b = flat, flat[O * I:]
     part_ln = flat[O * I + O:] if stats is not None else None
     with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
-        check(lib.allset_fused_linear_bwd_all_blocked(
+        check(lib.allset_fused_linear_bwd_all_ex(
             ptr(gy), gy_cb if gy_cb else _ld(gy), gy_cb, ptr(mask), p_out, ptr(weight), ptr(x), x_cb if x_cb else _ld(x), x_cb, ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
-            int(relu_in), p_in, seed_in, ptr(gx), x_cb if x_cb else max(I, 1), x_cb, ptr(part_ln), ptr(part_w),
-            ptr(part_b if want_bias else None), P, n, O, I, ptr(seed_base), M, stream_of(dev)), "allset_fused_linear_bwd_all_blocked")
+            0, int(relu_in), p_in, seed_in, ptr(gx), x_cb if x_cb else max(I, 1), x_cb, ptr(part_ln), ptr(part_w),
+            ptr(part_b if want_bias else None), P, n, O, I, ptr(seed_base), ptr(None), 0, M,
+            _arith_for(1, I, O, stats is not None, 0), stream_of(dev)), "allset_fused_linear_bwd_all_ex")
     red = reduce_partials(part)
     gw = red[:O * I].view(O, I)
     gb = red[O * I:O * I + O] if want_bias else None
@@ -661,19 +709,21 @@ def fused_linear_bwd_all(gy: Tensor, mask: Optional[Tensor], p_out: float, weigh
         if acc_in is not None or stats is None:
             raise _lib.AllSetHipError("fused_linear_bwd_all: the column-affine prologue takes stats / gamma / beta and no acc_in")
         with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
-            check(lib.allset_fused_linear_bwd_all_nm(
-                ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()),
-                ptr(beta.contiguous()), int(norm_mode), int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w),
-                ptr(part_b if want_bias else None), P, n, O, I, ptr(seed_base), M, stream_of(dev)), "allset_fused_linear_bwd_all_nm")
+            check(lib.allset_fused_linear_bwd_all_ex(
+                ptr(gy), _ld(gy), 0, ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), 0, ptr(stats), ptr(gamma.contiguous()),
+                ptr(beta.contiguous()), int(norm_mode), int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), 0, ptr(part_ln), ptr(part_w),
+                ptr(part_b if want_bias else None), P, n, O, I, ptr(seed_base), ptr(None), 0, M,
+                _arith_for(1, I, O, True, norm_mode), stream_of(dev)), "allset_fused_linear_bwd_all_ex")
         red = reduce_partials(part)
         return (gx, red[O * I + O:O * I + O + I], red[O * I + O + I:O * I + O + 2 * I], red[:O * I].view(O, I),
                 red[O * I:O * I + O] if want_bias else None)
     with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 2 * I) * 4):
-        check(lib.allset_fused_linear_bwd_all(
-            ptr(gy), _ld(gy), ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), ptr(stats),
+        check(lib.allset_fused_linear_bwd_all_ex(
+            ptr(gy), _ld(gy), 0, ptr(mask), p_out, ptr(weight), ptr(x), _ld(x), 0, ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None),
-            int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), ptr(part_ln), ptr(part_w), ptr(part_b if want_bias else None), P, n, O, I,
-            ptr(seed_base), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0, M, stream_of(dev)), "allset_fused_linear_bwd_all")
+            0, int(relu_in), p_in, seed_in, ptr(gx), max(I, 1), 0, ptr(part_ln), ptr(part_w), ptr(part_b if want_bias else None), P, n, O, I,
+            ptr(seed_base), ptr(acc_in), _ld(acc_in) if acc_in is not None else 0, M,
+            _arith_for(1, I, O, stats is not None, 0), stream_of(dev)), "allset_fused_linear_bwd_all_ex")
     if defer_to is not None and _deferrable(part, *defer_to):
         g_p, b_p, w_p, bias_p = defer_to
         _defer(part, [(w_p, 0, (O, I)), (bias_p if want_bias else None, O * I, (O,)),

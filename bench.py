@@ -122,6 +122,12 @@ def parse_args(argv=None):
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", default="auto", choices=["auto", "strict", "bf16x6", "fp16x3"],
+                    help="arithmetic of the fused fp32 Linear kernels (allset_amd.dense.set_arithmetic; include/allset_hip_ext.h "
+                         "ALLSET_ARITH_*): auto = fp16x3 where built, strict = the exact three-bf16-plane split everywhere")
+    ap.add_argument("--no-strict-entry", dest="strict_entry", action="store_false",
+                    help="N = 1, fp32: skip the second timed region that repeats the K steps in the strict arithmetic "
+                         "(reported as `strict` / dense_tail.strict_ms_per_step, never `value`)")
     ap.add_argument("--cpu-sample-n", type=int, default=0,
                     help="|V| = |E| of the CPU-baseline sample (0 = the GPU workload itself, copied back to the host)")
     ap.add_argument("--cpu-iters", type=int, default=3, help="timed CPU iterations (median reported; BASELINE.md section 3: >= 3)")
@@ -416,11 +422,44 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
 
 
 def cfg_index(args) -> int:
-    """Which BASELINE.json configuration the flags describe: [2] AllDeepSets d = 128 fp32 (the headline), [3] AllSetTransformer
+    """Which BASELINE.json configuration the flags are closest to: [2] AllDeepSets d = 128 fp32 (the headline), [3] AllSetTransformer
     d = 128 fp32, [4] the PMA path on power-law sizes at d = 256 in bf16."""
     if args.model != "pma":
         return 2
     return 4 if (args.dtype == "bf16" and args.degree_dist == "zipf") else 3
+
+
+def workload_label(args) -> str:
+    """'BASELINE configs[i]' only when the flags ARE that configuration (per-GPU shape for the multi-GPU ones); anything else is
+    labelled a variant of the closest one, with what differs."""
+    i = cfg_index(args)
+    diffs = []
+    if args.locality > 0:
+        diffs.append(f"locality {args.locality:g}")
+    if args.self_loops:
+        diffs.append("self-loop hyperedges")
+    if args.degree != 16:
+        diffs.append(f"mean size {args.degree}")
+    if i == 2:
+        if args.d != 128: diffs.append(f"d = {args.d}")
+        if args.dtype != "f32": diffs.append(args.dtype)
+        if args.norm != "ln": diffs.append(f"normalization {args.norm}")
+        if args.degree_dist != "fixed": diffs.append(f"{args.degree_dist} sizes")
+        if args.n_per_gpu != 1_000_000: diffs.append(f"{args.n_per_gpu} rows per GPU")
+        if args.dropout != 0.5: diffs.append(f"dropout {args.dropout:g}")
+    elif i == 3:
+        if args.d != 128: diffs.append(f"d = {args.d}")
+        if args.dtype != "f32": diffs.append(args.dtype)
+        if args.heads != 4: diffs.append(f"heads {args.heads}")
+        if args.degree_dist != "fixed": diffs.append(f"{args.degree_dist} sizes")
+        if args.n_per_gpu != 1_000_000: diffs.append(f"{args.n_per_gpu} rows per GPU")
+    else:
+        if args.d != 256: diffs.append(f"d = {args.d}")
+        if args.n_per_gpu != 250_000: diffs.append(f"{args.n_per_gpu} rows per GPU")
+    shape = " per-GPU shape" if i != 2 else ""
+    if not diffs:
+        return f"BASELINE configs[{i}]{shape}"
+    return f"variant of BASELINE configs[{i}]{shape} ({', '.join(diffs)})"
 
 
 def parallelism_label(args, mode, world):
@@ -671,7 +710,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
          "accumulation and fp32 softmax statistics; dense tail: this library's bf16 kernels (fp32 arithmetic and "
          "accumulation, bf16 in / out)"),
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{cfg_index(args)}]{' per-GPU shape' if attn else ''}: synthetic random hypergraph "
+        "config": {"workload": f"{workload_label(args)}: synthetic random hypergraph "
                                f"|V|=|E|={args.n_per_gpu} per GPU, hyperedge size {args.degree} ({args.degree_dist}"
                                + (f", locality {args.locality:g}: VARIANT workload" if args.locality > 0 else "") + "), "
                                f"nnz={int(nnz_total)}, d={d}, " +
@@ -728,6 +767,22 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         line["partitions"] = parts
     if state.get("preflight") is not None or "preflight" in errors:
         line["preflight"] = state.get("preflight") or {"error": errors["preflight"]}
+    strict = state.get("strict")
+    if args.dtype == "f32":
+        from allset_amd import dense as _dense
+        line["dense_tail"]["arithmetic"] = _dense.get_arithmetic()
+    if strict is not None:
+        sks = {k: v for k, v in strict["kernels"].items() if k not in AGG_KERNELS}
+        strict_dense = sum(v["total_ms"] for v in sks.values()) / args.steps
+        line["dense_tail"]["strict_ms_per_step"] = strict_dense
+        line["strict"] = {"ms_per_step": strict["ms_per_step"], "value": strict["value"], "dense_tail_ms_per_step": strict_dense,
+                          "arithmetic": "bf16x6",
+                          "note": "the same K steps in the same run with allset_amd.dense.set_arithmetic('strict') "
+                                  "(ALLSET_ARITH_BF16X6: every fused Linear on the exact three-bf16-plane split, no dependence on the "
+                                  "data's dynamic range); `value` is the default (AUTO) arithmetic's",
+                          "kernels": {k: kernel_entry(v, args.steps, strict["rows"], d, k) for k, v in sks.items()}}
+    elif "strict" in errors:
+        line["strict"] = {"error": errors["strict"]}
     line["cpu_baseline"] = state.get("cpu_baseline")
     return line
 
@@ -829,6 +884,9 @@ def main(argv=None, hooks=None):
         if res is not None:
             state["results"][key] = res
 
+    if not cpu_mode and args.dtype == "f32":
+        from allset_amd import dense as _dense
+        _dense.set_arithmetic(args.arith)
     partition_region(order[0], order[0], first=True)
     if rank == 0:                                   # the early line: stderr only -- stdout carries exactly ONE JSON line, the final one
         early = assemble_line(args, world, primary, state, cpu_mode, final=False)
@@ -852,6 +910,20 @@ def main(argv=None, hooks=None):
             partition_region(wire_key, primary)
         finally:
             adist.set_wire_dtype(prev)
+
+    # N = 1, fp32: the same K steps once more in the STRICT arithmetic (the exact-split bf16x6 kernels everywhere) -- both numbers in
+    # one run, the default's as `value`
+    if (world == 1 and not cpu_mode and args.dtype == "f32" and args.strict_entry and args.arith == "auto" and not args.hip_graph):
+        from allset_amd import dense as _dense
+        prev_arith = _dense.set_arithmetic("strict")
+        try:
+            torch.cuda.empty_cache()
+            sres = region("strict", lambda: run_partition(args, primary, world, rank, dev, hooks))
+            if sres is not None:
+                sres.pop("edge_index_cpu", None); sres.pop("x_cpu", None)
+                state["strict"] = sres
+        finally:
+            _dense.set_arithmetic(prev_arith)
 
     line = None
     if rank == 0:

@@ -30,6 +30,7 @@ from oracle import allset_oracle as oracle  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+KINK_LEGACY = {"cora_ds_add"}     # generated before the kink guard (round 1): 1.4e-2 upstream of the first relu
 BIG_ROWS = 96           # rows of big per-row tensors kept in a fixture
 BIG_PARAM_NUMEL = 20000  # parameter grads above this size are stored as (sum, abs-sum, 64 samples)
 
@@ -73,18 +74,22 @@ def run_reference(case: dict, ref_models):
     return spec, sd_np, res, attn
 
 
-def run_oracle(case: dict, sd_np: dict):
+def run_oracle(case: dict, sd_np: dict, dtype=torch.float32):
     args = case["args"]
     sd = {k: torch.from_numpy(v).clone() for k, v in sd_np.items()}
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
-    x = torch.from_numpy(case["x"]).clone().requires_grad_(True)
+    x = torch.from_numpy(case["x"]).clone().to(dtype).requires_grad_(True)
     ei = torch.from_numpy(case["edge_index"])
     norm = torch.from_numpy(case["norm"])
+    if norm.is_floating_point():
+        norm = norm.to(dtype)
     collect = {}
     logits = oracle.setgnn_forward(sd, args, x, ei, norm, collect)
-    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape))
+    G = torch.from_numpy(cases.cotangent(case["name"], logits.shape)).to(dtype)
     (logits * G).sum().backward()
     return dict(logits=logits.detach(), v2e0=collect["v2e0"].detach(), e2v0=collect["e2v0"].detach(),
                 grad_x=x.grad.detach(),
@@ -117,8 +122,20 @@ def main() -> None:
             if k in orc["grads"]:
                 gd = max(gd, maxdiff(g, orc["grads"][k]) / (1.0 + float(g.abs().max())))
         worst = max(max(diffs[k] / (1.0 + scale[k]) for k in diffs), gd)
-        report[name] = dict(oracle_vs_reference_maxabs=diffs, param_grad_rel=gd, worst_rel=worst)
+        # kink guard: the fp32 reference against the float64 oracle.  A draw with a relu pre-activation within fp32 rounding of zero
+        # moves whole gradient tensors by percents between two correct fp32 evaluations: such a fixture would test the sign of a
+        # rounding error, not an implementation.  Refused here; give the case another offset in cases.SEED_SALT.
+        o64 = run_oracle(case, sd_np, torch.float64)
+        kink = max(maxdiff(ref[k].double(), o64[k]) / max(float(o64[k].abs().max()), 1e-30) for k in ("logits", "grad_x"))
+        gmax = max(float(g.abs().max()) for g in o64["grads"].values())
+        for k, g in ref["grads"].items():
+            if k in o64["grads"]:
+                kink = max(kink, maxdiff(g.double(), o64["grads"][k]) / max(float(o64["grads"][k].abs().max()), 1e-2 * gmax, 1e-30))
+        report[name] = dict(oracle_vs_reference_maxabs=diffs, param_grad_rel=gd, worst_rel=worst, reference_vs_float64_rel=kink)
         assert worst <= 1e-6 * (30 if case["big"] else 4), (name, diffs, gd)
+        # (fixtures older than the guard are kept as generated -- the product reproduces the fp32 reference's side of their kink --
+        #  and are listed with their value in REPORT.json)
+        assert kink <= 3e-5 or name in KINK_LEGACY, (name, "fp32 reference vs float64 oracle", kink, "relu kink: add an offset to cases.SEED_SALT")
 
         out = {
             "spec_keys": np.array([k for k, _ in spec]),

@@ -155,9 +155,16 @@ def _norm_deg_half_sym(ei: np.ndarray) -> np.ndarray:
     return (dv[v] ** -0.5 * de[e] ** -0.5).astype(np.float32)
 
 
+# Per-case seed offsets.  A case whose fp32 evaluation sits within rounding of a relu kink (one pre-activation of ~1e6 within 1e-7
+# of zero) has gradients that differ by percents between two CORRECT fp32 implementations -- and between the fp32 reference and its
+# own float64 evaluation.  oracle/gen_golden.py refuses such a draw (float64 oracle vs reference); the offset listed here is the first
+# one it accepted.
+SEED_SALT: Dict[str, int] = {"mid4k_ds_add": 3}
+
+
 def build_case(name: str) -> dict:
     """Return dict(name, args, x, edge_index, norm, seed, cotangent_seed, big)."""
-    seed = zlib.crc32(name.encode()) & 0x7FFFFFFF
+    seed = (zlib.crc32(name.encode()) + SEED_SALT.get(name, 0)) & 0x7FFFFFFF
     rng = np.random.default_rng(seed)
     big = False
     over = {}
@@ -168,7 +175,7 @@ def build_case(name: str) -> dict:
         x = rng.standard_normal((n_v, f)).astype(np.float32)
     elif name.startswith("rand50_"):
         mode = name[len("rand50_"):]
-        suffixes = {"_wnorm": ("_wnorm", True), "_L2": ("All_num_layers", 2),
+        suffixes = {"_wnorm": ("_wnorm", True), "_L2": ("All_num_layers", 2), "_d128": ("_d128", True),
                     "_bn": ("normalization", "bn"), "_mask": ("LearnMask", True), "_gpr": ("GPR", True)}
         stripped = True
         while stripped:
@@ -178,7 +185,19 @@ def build_case(name: str) -> dict:
                     mode, stripped = mode[:-len(suf)], True
                     over[key] = val
         n_v, f, d, k = 50, 16, 64, 7
+        if over.pop("_d128", False):      # the headline width: every Linear of f_enc / f_dec is 128 x 128 behind a LayerNorm
+            f, d = 128, 128               # (the split-role fp16x3 / bf16x6 kernels bench.py times)
+            over["Classifier_hidden"] = 128
         ei = random_hypergraph(rng, n_v, 20, 200, True)
+        x = rng.standard_normal((n_v, f)).astype(np.float32)
+    elif name.startswith("mid4k_"):       # >= 4099 rows at the headline width: 32-row stage tails of the persistent
+        mode, big = name[len("mid4k_"):], True    # workgroups and the multi-workgroup partial gW reduction are hit
+        if mode.endswith("_bn"):
+            mode = mode[:-3]
+            over["normalization"] = "bn"
+        n_v, f, d, k = 4611, 128, 128, 7
+        over["Classifier_hidden"] = 128
+        ei = random_hypergraph(rng, n_v, 4099, 30000, True)
         x = rng.standard_normal((n_v, f)).astype(np.float32)
     elif name.startswith("edge_"):
         mode = name[len("edge_"):]
@@ -219,10 +238,11 @@ SMALL_CASES: List[str] = (
     + [f"rand50_{m}" for m in MODES]
     + ["rand50_ds_add_wnorm", "rand50_ds_mean_wnorm", "rand50_ds_add_L2", "rand50_pma_h4_L2",
        "rand50_ds_add_bn", "rand50_ds_add_wnorm_mask", "rand50_ds_add_L2_gpr", "rand50_pma_h4_L2_gpr",
-       "rand50_ds_mean_wnorm_mask_L2"]
+       "rand50_ds_mean_wnorm_mask_L2", "rand50_ds_add_d128", "rand50_ds_mean_wnorm_d128", "rand50_ds_add_bn_d128"]
     + [f"edge_{m}" for m in MODES]
 )
-BIG_CASES: List[str] = ["cora_ds_add", "citeseer_pma_h4", "wide256_ds_add", "wide256_pma_h4"]
+BIG_CASES: List[str] = ["cora_ds_add", "citeseer_pma_h4", "wide256_ds_add", "wide256_pma_h4",
+                        "mid4k_ds_add", "mid4k_ds_add_bn", "mid4k_pma_h4"]
 ALL_CASES: List[str] = SMALL_CASES + BIG_CASES
 
 

@@ -313,9 +313,22 @@ def test_fused_linear_bf16x6_is_fp32_accurate(K, N, device, monkeypatch):
     assert errs["bf16x6"] < 2.0 * errs["f32"], errs
 
 
+@pytest.fixture
+def arith_mode(request):
+    """Run the test body under ``dense.set_arithmetic(request.param)`` ('auto' = fp16x3 at 128 x 128, 'strict' = bf16x6)."""
+    from allset_amd import dense
+    prev = dense.set_arithmetic(request.param)
+    yield request.param
+    dense.set_arithmetic(prev)
+
+
+BOTH_ARITH = pytest.mark.parametrize("arith_mode", ["auto", "strict"], indirect=True)
+
+
+@BOTH_ARITH
 @pytest.mark.parametrize("kind", ["plain", "wide_rows", "small_gamma", "large_beta", "w_column_scales"])
 @pytest.mark.parametrize("n", [1, 4099, 70001])
-def test_fused_linear_forward_fp16x3_against_float64(n, kind, device):
+def test_fused_linear_forward_fp16x3_against_float64(n, kind, arith_mode, device):
     """The forward behind a LayerNorm prologue at 128 x 128 forms its products from two fp16 planes per operand too (csrc/fused_fwd2.hip
     F16: the LayerNorm output is bounded, so one power of two for the launch -- folded into gamma / beta -- and one per 32-column
     slice of W bring the operands into fp16's window).  Against float64 in units of sum |terms| (the terms of the LayerNorm affine
@@ -355,9 +368,10 @@ def test_fused_linear_forward_fp16x3_against_float64(n, kind, device):
     assert e_k < max(2e-6, 3.0 * e_t), (e_k, e_t)
 
 
+@BOTH_ARITH
 @pytest.mark.parametrize("n", [1, 33, 4099, 70001])
 @pytest.mark.parametrize("kind", ["plain", "tiny", "huge", "row_scales", "late_large_row", "small_gamma", "column_scales"])
-def test_one_pass_backward_fp16x3_against_float64(n, kind, device):
+def test_one_pass_backward_fp16x3_against_float64(n, kind, arith_mode, device):
     """The LayerNorm-prologue backward at 128 x 128 runs fp32 on the f16 matrix pipe: two fp16 planes per operand, three products,
     power-of-two operand scales (csrc/fused_bwd6.hip).  Against float64, in units of sum |terms| (the yardstick fp32 itself is held
     to): a library fp32 GEMM's level on ordinary data whatever the overall scale of the gradient, the scale of each row (the kernel
@@ -397,8 +411,8 @@ def test_one_pass_backward_fp16x3_against_float64(n, kind, device):
     ref_gx = rstd * (v - v.mean(1, keepdim=True) - xh * (v * xh).mean(1, keepdim=True))
     ua = (xh * gd).abs() + bd.abs()       # the terms of u = xhat gamma + beta: where they cancel, fp32's own rounding of u shows
     den_w = Gd.abs().t() @ ua + 1e-300
-    if kind == "column_scales":       # the per-row window: + 2^-38 max_o |gy[r, o]| |u[r, i]| per term
-        den_w = den_w + 2.0 ** -15 * (Gd.abs().max(1, keepdim=True).values.expand(-1, 128).t() @ ua)
+    if kind == "column_scales" and arith_mode == "auto":       # fp16x3's per-row window: + 2^-38 max_o |gy[r, o]| |u[r, i]| per term
+        den_w = den_w + 2.0 ** -15 * (Gd.abs().max(1, keepdim=True).values.expand(-1, 128).t() @ ua)      # (strict: no allowance)
     den_gu = (Gd.abs() @ Wd.abs()).max(1, keepdim=True).values * rstd * gd.abs().max() + 1e-300
     e_gw = float(((gw.double() - Gd.t() @ u).abs() / den_w).max())
     e_gx = float(((gx.double() - ref_gx).abs() / den_gu).max())
@@ -412,9 +426,10 @@ def test_one_pass_backward_fp16x3_against_float64(n, kind, device):
     assert e_gw < lim_w and e_gx < 1e-6 and e_gb < 3e-7 and e_dg < 3e-7 and e_db < 3e-7, (e_gw, e_gx, e_gb, e_dg, e_db)
 
 
+@BOTH_ARITH
 @pytest.mark.parametrize("n", [1, 33, 4099, 70001])
 @pytest.mark.parametrize("kind", ["plain", "relu", "acc", "row_scales", "x_row_scales", "late_large_row"])
-def test_one_pass_backward_fp16x3_without_layernorm_against_float64(n, kind, device):
+def test_one_pass_backward_fp16x3_without_layernorm_against_float64(n, kind, arith_mode, device):
     """The same kernel on a Linear WITHOUT a LayerNorm prologue (PMA's rFF, reference layers.py:76-80, 157): the window of a row of
     the recomputed input u = relu(x) comes from the row's own largest element, and the weight-gradient accumulators follow the
     largest product of the two row exponents.  gx, gW, gb against float64 in units of sum |terms| with gradient rows AND input rows
@@ -450,6 +465,98 @@ def test_one_pass_backward_fp16x3_without_layernorm_against_float64(n, kind, dev
     assert torch.isfinite(gw).all() and torch.isfinite(gx).all()
     lim_w = 4e-6 if (n < 64 or kind == "late_large_row") else 3e-7
     assert e_gw < lim_w and e_gx < 2e-6 and e_gb < 3e-7, (e_gw, e_gx, e_gb)
+
+
+@pytest.mark.parametrize("n", [4099, 70001])
+def test_strict_arithmetic_on_hostile_dynamic_range(n, device):
+    """The caller's way out of fp16x3's window (include/allset_hip_ext.h ALLSET_ARITH_*): gradient ROWS spread over 2^40 and gradient
+    COLUMNS over 2^30 at once.  In the strict mode (exact three-bf16-plane split, no operand scaling) gW, gb, gx, dgamma, dbeta meet
+    the bounds a library fp32 GEMM is held to -- plain sum-|terms| denominators, NO allowance for any window.  The same data through
+    AUTO (fp16x3 at this shape) stays inside its DOCUMENTED bound (2^-38 of the row's largest |gy| per term) and visibly outside the
+    plain one -- which also proves that the mode switch changes the kernel."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 128, generator=g) * 3 + 0.5
+    W = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.3 * torch.randn(128, generator=g)
+    G = torch.randn(n, 128, generator=g)
+    G = G * torch.exp2(torch.randint(-20, 21, (n, 1), generator=g).float()) * torch.exp2(torch.randint(-15, 16, (1, 128), generator=g).float())
+    G, W, x, gamma, beta = (t.to(device) for t in (G, W, x, gamma, beta))
+    Gd, Wd, xd, gd, bd = G.double(), W.double(), x.double(), gamma.double(), beta.double()
+    mean = xd.mean(1, keepdim=True)
+    rstd = (((xd - mean) ** 2).mean(1, keepdim=True) + 1e-5).rsqrt()
+    xh = (xd - mean) * rstd
+    u = xh * gd + bd
+    gu = Gd @ Wd
+    v = gu * gd
+    ref_gx = rstd * (v - v.mean(1, keepdim=True) - xh * (v * xh).mean(1, keepdim=True))
+    ua = (xh * gd).abs() + bd.abs()
+    den_w = Gd.abs().t() @ ua + 1e-300
+    den_gu = (Gd.abs() @ Wd.abs()).max(1, keepdim=True).values * rstd * gd.abs().max() + 1e-300
+    gu_abs = Gd.abs() @ Wd.abs()
+    errs = {}
+    for mode in ("strict", "auto"):
+        with dense.arithmetic(mode):
+            y, st = dense.fused_linear_fwd(x, W, torch.zeros(128, device=device), gamma, beta, 1e-5, False, 0.0, 0, False, 0.0, 0, None, None)
+            gx, dg, db, gw, gb = dense.fused_linear_bwd_all(G, None, 0.0, W, x, st, gamma, beta, False, 0.0, 0)
+        assert torch.isfinite(gw).all() and torch.isfinite(gx).all()
+        errs[mode] = dict(
+            gw=float(((gw.double() - Gd.t() @ u).abs() / den_w).max()),
+            gx=float(((gx.double() - ref_gx).abs() / den_gu).max()),
+            gb=float(((gb.double() - Gd.sum(0)).abs() / (Gd.abs().sum(0) + 1e-300)).max()),
+            dg=float(((dg.double() - (gu * xh).sum(0)).abs() / ((gu_abs * xh.abs().max()).sum(0) + 1e-300)).max()),
+            db=float(((db.double() - gu.sum(0)).abs() / (gu_abs.sum(0) + 1e-300)).max()),
+            gw_windowed=float(((gw.double() - Gd.t() @ u).abs() /
+                               (den_w + 2.0 ** -15 * (Gd.abs().max(1, keepdim=True).values.expand(-1, 128).t() @ ua))).max()))
+    # torch's own fp32 chain on the same data, the same yardstick
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        ut = torch.nn.functional.layer_norm(x, (128,), gamma, beta, 1e-5)
+        e_t = float((((G.t() @ ut).double() - Gd.t() @ u).abs() / den_w).max())
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    e = errs["strict"]
+    assert e["gw"] < max(3e-7, 3.0 * e_t) and e["gx"] < 1e-6 and e["gb"] < 3e-7 and e["dg"] < 3e-7 and e["db"] < 3e-7, (errs, e_t)
+    a = errs["auto"]
+    assert a["gw_windowed"] < 2e-7 and a["gx"] < 1e-6 and a["gb"] < 3e-7, (errs, e_t)      # inside the documented window
+    assert a["gw"] > 10.0 * e["gw"], errs                                                   # and the two modes are different kernels
+
+
+def test_arithmetic_mode_api(device):
+    """set_arithmetic / get_arithmetic / the context manager; an fp16x3 request at a width without an fp16x3 kernel runs (bf16x6);
+    the C ABI refuses an unknown mode and an fp16x3 request it has no kernel for."""
+    from allset_amd import _lib, dense
+    assert dense.get_arithmetic() == "auto"
+    with dense.arithmetic("strict"):
+        assert dense.get_arithmetic() == "bf16x6"
+        with dense.arithmetic("fp16x3"):
+            assert dense.get_arithmetic() == "fp16x3"
+            x = torch.randn(100, 64, device=device)
+            W = torch.randn(64, 64, device=device)
+            y, _ = dense.fused_linear_fwd(x, W, None)                      # 64 x 64: no fp16x3 kernel -> AUTO -> bf16x6
+            torch.testing.assert_close(y, x @ W.t(), rtol=1e-4, atol=1e-4)
+        assert dense.get_arithmetic() == "bf16x6"
+    assert dense.get_arithmetic() == "auto"
+    with pytest.raises(ValueError):
+        dense.set_arithmetic("fp8")
+    lib = _lib.load()
+    assert lib.allset_fused_linear_arith_supported(0, 128, 128, 1, 0, _lib.ARITH_FP16X3) == 1
+    assert lib.allset_fused_linear_arith_supported(0, 128, 128, 0, 0, _lib.ARITH_FP16X3) == 0     # forward: LayerNorm prologue only
+    assert lib.allset_fused_linear_arith_supported(1, 128, 128, 0, 0, _lib.ARITH_FP16X3) == 1
+    assert lib.allset_fused_linear_arith_supported(1, 64, 128, 1, 0, _lib.ARITH_FP16X3) == 0
+    assert lib.allset_fused_linear_arith_supported(1, 64, 128, 1, 0, _lib.ARITH_BF16X6) == 1
+    x = torch.randn(64, 128, device=device)
+    W = torch.randn(128, 128, device=device)
+    y = torch.empty(64, 128, device=device)
+    P = lambda t: t.data_ptr()
+    args = lambda arith: (P(x), 128, 0, None, None, 1e-5, 0, 0, 0.0, 0, P(W), None, 0, 0.0, 0, P(y), 128, 0, None, 64, 128, 128, None, None,
+                          None, None, None, arith, None)
+    assert lib.allset_fused_linear_fwd_ex(*args(7)) == -1 and b"arith" in lib.allset_last_error()
+    assert lib.allset_fused_linear_fwd_ex(*args(_lib.ARITH_FP16X3)) == -3            # no LayerNorm prologue: not built
+    assert lib.allset_fused_linear_fwd_ex(*args(_lib.ARITH_BF16X6)) == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y, x @ W.t(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("N", [64, 128])

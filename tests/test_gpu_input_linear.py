@@ -127,8 +127,7 @@ def test_leaf_feature_path_equals_the_general_path_under_the_same_masks(over, de
     case = cases.build_case("cora_ds_add")
     args = SimpleNamespace(**{**vars(case["args"]), **over})
     # A relu input within rounding of zero (the two paths round the first layer differently) flips one unit: every gradient UPSTREAM
-    # of that relu then moves by ~1e-3 of its maximum while everything downstream still agrees to 1e-6 (tools/debug/exp_paths.py
-    # prints that signature; about one parameter draw in three at hidden width 128).  The comparison runs on the first of four
+    # of that relu then moves by ~1e-3 of its maximum while everything downstream still agrees to 1e-6 (measured in round 4; about one parameter draw in three at hidden width 128).  The comparison runs on the first of four
     # parameter draws that meets the tolerance; a defect of the path would fail all four.
     last = None
     for attempt in range(4):

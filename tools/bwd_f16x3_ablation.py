@@ -3,7 +3,7 @@
 timing only), without the MFMAs, without the gx stores, with per-segment cycle counters, each timed at [1M,128] x [128,128].
 Run on the GPU box: python tools/bwd_f16x3_ablation.py [--light] [--only <substring>] [-DFLAG ...]
 (the comparison arms of rounds 2-3 -- the pair / stage / three-waves kernels and their ablation scripts -- live in
-tools/micro/retired/ as they were when they lost their A/B; the library no longer builds them.)"""
+the git history before round 5, tools/micro/retired/, as they were when they lost their A/B; the library no longer builds them.)"""
 import ctypes, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

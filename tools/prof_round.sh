@@ -1,0 +1,37 @@
+# One full GPU batch for a round: usage  gpurun -- "TAG=r05 bash tools/prof_round.sh".  (The round-4 batches prof_r04*.sh were this script with the tag spelled out.)  Full GPU suite, smoke, default bench line + the same command under
+# rocprofv3 --kernel-trace --stats, refreshed HBM-traffic passes (stamped), PMC passes over the dense kernels, variant lines.
+TAG=${TAG:-r05}
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.txt 2>&1; tail -3 $OUT/${TAG}_smoke.txt
+timeout 1800 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest.txt 2>&1; grep -n "passed\|failed\|FAILED" $OUT/${TAG}_pytest.txt | tail -8
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/pmc_${TAG}_$c
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -- python tools/pmc_probe.py > $OUT/pmc_${TAG}_$c.log 2>&1
+done
+python tools/traffic_json.py c3 $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
+mkdir -p $OUT/profiles_new && cp profiles/hbm_traffic.json profiles/hbm_traffic_pma.json $OUT/profiles_new/
+timeout 900 python bench.py > $OUT/${TAG}_bench_line.json 2>$OUT/${TAG}_bench.err; tail -2 $OUT/${TAG}_bench.err
+python tools/bench_summary.py $OUT/${TAG}_bench_line.json
+rm -rf $OUT/prof_${TAG}
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG} -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_traced_bench_line.json 2>/dev/null
+S=$(find $OUT/prof_${TAG} -name '*kernel_stats.csv' | head -1); cp "$S" $OUT/${TAG}_bench_kernel_stats.csv; head -7 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-150
+find $OUT/prof_${TAG} -name '*kernel_trace.csv' -delete
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  n=$(echo $c | tr ' ' '_')
+  rm -rf $OUT/pmc_${TAG}f_$n
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}f_$n -- python tools/fused_probe.py > /dev/null 2>$OUT/pmc_${TAG}f_$n.err
+done
+python tools/pmc_sum.py fused_linear_bwd_f16x3 $OUT/pmc_${TAG}f_* > $OUT/${TAG}_pmc_dense.txt
+python tools/pmc_sum.py fused_linear_fwd_roles $OUT/pmc_${TAG}f_* >> $OUT/${TAG}_pmc_dense.txt
+cat $OUT/${TAG}_pmc_dense.txt | head -30
+find $OUT/pmc_${TAG}* -name '*kernel_trace.csv' -delete
+timeout 600 python bench.py --model pma --no-cpu-baseline --partitions primary > $OUT/${TAG}_pma_bench_line.json 2>/dev/null
+timeout 600 python bench.py --norm bn --no-cpu-baseline > $OUT/${TAG}_bn_bench_line.json 2>/dev/null
+timeout 600 python bench.py --degree-dist poisson --no-cpu-baseline > $OUT/${TAG}_poisson_bench_line.json 2>/dev/null
+timeout 600 python bench.py --dropout 0 --no-cpu-baseline > $OUT/${TAG}_bench_line_dropout0.json 2>/dev/null
+python tools/bench_summary.py $OUT/${TAG}_pma_bench_line.json $OUT/${TAG}_poisson_bench_line.json $OUT/${TAG}_bench_line_dropout0.json | grep json
+timeout 600 python tools/small_graph_step.py > $OUT/${TAG}_small_graph_step.txt 2>&1; tail -12 $OUT/${TAG}_small_graph_step.txt
+echo finished

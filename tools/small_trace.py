@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Ordered kernel timeline of the LAST graphed step in a `rocprofv3 --kernel-trace` csv (tools/prof_r04n.sh)."""
+"""Ordered kernel timeline of the LAST graphed step in a `rocprofv3 --kernel-trace` csv (tools/prof_round.sh)."""
 import csv, glob, os, sys
 path = sys.argv[1] if len(sys.argv) > 1 else max(glob.glob("gpurun_out/prof_small_trace/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
