@@ -108,7 +108,13 @@ def _deferrable(part: Tensor, *params) -> bool:
     P, M = part.shape
     if not _lib.load().allset_reduce_partials_batchable(P, M):
         return False
-    return all(p is None or (isinstance(p, torch.nn.Parameter) and p.is_leaf and p.requires_grad and p.dtype == torch.float32)
+    # ONE batched launch on ONE device: partials (and parameters) on another device than the scope's first entry reduce the usual way
+    if _Deferred.pending and part.device != _Deferred.pending[0][0].device:
+        return False
+    # a parameter with tensor hooks / post-accumulate hooks (DDP-style gradient sync) must go through autograd's accumulation node
+    return all(p is None or (isinstance(p, torch.nn.Parameter) and p.is_leaf and p.requires_grad and p.dtype == torch.float32
+                             and p.device == part.device and not getattr(p, "_backward_hooks", None)
+                             and not getattr(p, "_post_accumulate_grad_hooks", None))
                for p in params)
 
 

@@ -288,22 +288,38 @@ class Halo:
     def exchange_rows(self) -> int:
         return sum(c for q, c in enumerate(self.need_counts) if q != self.rank)
 
-    def _gather(self, x_owned: Tensor) -> Tensor:
+    def _gather(self, x_owned: Tensor, narrow: bool = True) -> Tensor:
+        """``narrow=False``: the rows travel in their own dtype whatever the wire format (softmax statistics: a few fp32 columns whose
+        rounding would not cancel between the owner's copy and the travelled one)."""
         send = x_owned.index_select(0, self.send_idx)
         if self.world == 1 or _skip_collective(self.group):
             return send
-        return _all_to_all_rows(_narrow(send), self.send_counts, self.need_counts, self.group).to(x_owned.dtype)
+        wire = _narrow(send) if narrow else send
+        return _all_to_all_rows(wire, self.send_counts, self.need_counts, self.group).to(x_owned.dtype)
 
     def _scatter_add(self, part: Tensor) -> Tensor:
+        """Fixed-order sum (no atomics) of what the ranks sent, per owned row.  On a device the sum ALWAYS runs through the library's
+        segment-sum kernel: any width (padded to a multiple of 4 here) and any floating dtype (summed in fp32, returned in the
+        input's dtype); torch's ``index_add_`` (atomics on a GPU: run-to-run nondeterministic) is the CPU path only."""
         if self.world == 1 or _skip_collective(self.group):
             recv = part
         else:
             recv = _all_to_all_rows(_narrow(part.contiguous()), self.need_counts, self.send_counts, self.group).to(part.dtype)
-        if recv.is_cuda and recv.dtype == torch.float32 and recv.shape[1] % 4 == 0:
+        if recv.is_cuda:
+            if recv.dim() != 2 or not recv.is_floating_point():
+                raise ValueError("halo scatter_add on a device takes a 2-D floating tensor (fixed-order segment sum)")
             from . import ops
-            return ops.segreduce(0, self.sa_rowptr, self.sa_col, None, recv.contiguous(), self.block)[0]
+            c = recv.shape[1]
+            r32 = recv.float()
+            pad = (-c) % 4
+            if pad:
+                r32 = torch.cat([r32, r32.new_zeros(r32.shape[0], pad)], dim=1)
+            out = ops.segreduce(0, self.sa_rowptr, self.sa_col, None, r32.contiguous(), self.block)[0]
+            if pad:
+                out = out[:, :c].contiguous()
+            return out.to(recv.dtype)
         out = recv.new_zeros((self.block,) + tuple(recv.shape[1:]))
-        return out.index_add_(0, self.send_idx, recv)                             # (CPU tests / odd widths: sequential, deterministic on CPU)
+        return out.index_add_(0, self.send_idx, recv)                             # CPU (gloo tests): sequential, deterministic
 
 
     def _scatter_max(self, part: Tensor) -> Tensor:
@@ -324,16 +340,14 @@ class Halo:
         return out.scatter_reduce(0, idx, recv, "amax", include_self=False)
 
     def gather_narrow(self, x_owned: Tensor) -> Tensor:
-        """``_gather`` for a few fp32 columns (logits, softmax statistics): rides the same all-to-all, no autograd."""
-        return self._gather(x_owned.contiguous())
+        """``_gather`` for a few fp32 columns (softmax maxima / statistics): its own all-to-all, no autograd, and NEVER the narrow
+        wire format -- the owner keeps the unrounded maximum for its backward (M = m + log l), so the copy that travels must be the
+        same number (the all-to-all is only H columns wide)."""
+        return self._gather(x_owned.contiguous(), narrow=False)
 
     def scatter_add_narrow(self, part: Tensor) -> Tensor:
-        """``_scatter_add`` for a tensor whose width is not a multiple of 4 (padded for the segment-sum kernel)."""
-        c = part.shape[1]
-        pad = (-c) % 4
-        if pad and part.is_cuda:
-            part = torch.cat([part, part.new_zeros(part.shape[0], pad)], dim=1)
-        return self._scatter_add(part)[:, :c].contiguous()
+        """``_scatter_add`` for a tensor whose width is not a multiple of 4 (kept for callers; ``_scatter_add`` pads itself now)."""
+        return self._scatter_add(part)
 
 
 class _HaloGather(torch.autograd.Function):

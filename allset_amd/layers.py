@@ -118,6 +118,7 @@ class MLP(nn.Module):
         norms = [_make_norm(Normalization if InputNorm else 'None', in_channels)]
         norms += [_make_norm(Normalization, hidden_channels) for _ in range(num_layers - 1)]
         self.normalizations = nn.ModuleList(norms)
+        self._raw_input = False          # set by the owning model on the MLP that consumes data.x (see _wide_input)
 
     def reset_parameters(self):
         for lin in self.lins:
@@ -189,6 +190,11 @@ class MLP(nn.Module):
         not take) in front of its first Linear, on an input that needs no gradient -- ``dense.input_norm_linear`` (one GEMM each
         way, no [n, d] input gradient); the remaining Linears take the fused kernels as in ``_fusable``."""
         if not _on_hip(x) or x.dim() != 2:
+            return False
+        # "needs no gradient" must mean "is the raw feature matrix": with autograd on, a tensor without requires_grad is one; under
+        # no_grad EVERY activation looks like that, so there only the MLP that a model marked as its first (``_raw_input``, set by
+        # SetGNN for the module that consumes data.x) takes this route -- every other MLP keeps the kernels its training step uses.
+        if not torch.is_grad_enabled() and not self._raw_input:
             return False
         n0, lin0 = self.normalizations[0], self.lins[0]
         if not (isinstance(n0, nn.LayerNorm) and n0.elementwise_affine and n0.bias is not None):

@@ -27,15 +27,16 @@ def split_mask(idx: Tensor, n: int) -> Tensor:
     return w
 
 
-_TICKETS = {}      # device index -> zeroed uint32 the forward kernel counts its workgroups on (and re-arms)
+_TICKETS = {}      # (device index, stream handle) -> zeroed uint32 the forward kernel counts its workgroups on (and re-arms)
 
 
 def _ticket(dev: torch.device) -> Tensor:
-    """One per device: two loss forwards running CONCURRENTLY on different streams of one device would share it (not a pattern of
-    this package: the loss is one node of a training step's dependent chain)."""
-    t = _TICKETS.get(dev.index)
+    """One per (device, stream): launches on one stream are ordered, so they may share the counter the kernel re-arms; a loss forward
+    on ANOTHER stream of the same device (an eager evaluation loss beside a captured training step on a side stream) gets its own."""
+    key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
+    t = _TICKETS.get(key)
     if t is None:
-        t = _TICKETS[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)      # (zeroed on the stream that launches next)
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=dev)      # (zeroed on the stream that launches next)
     return t
 
 
@@ -47,7 +48,13 @@ class _NllLogSoftmax(torch.autograd.Function):
         lib = _lib.load()
         npart = c_int64(0)
         check(lib.allset_nll_partials(n, byref(npart)), "allset_nll_partials")
-        partials = torch.empty(npart.value + 1, dtype=torch.float32, device=dev)      # [workgroup sums | their total]
+        # [workgroup sums | their total].  The total is written by the LAST workgroup to arrive on the ticket; outside a graph
+        # capture it starts as NaN, so a ticket wedged by an earlier aborted launch shows up as a NaN loss instead of stale memory
+        # (inside a capture the fill would be one more node of a launch-bound step; a replay that aborts takes the process with it)
+        if torch.cuda.is_current_stream_capturing():
+            partials = torch.empty(npart.value + 1, dtype=torch.float32, device=dev)
+        else:
+            partials = torch.full((npart.value + 1,), float("nan"), dtype=torch.float32, device=dev)
         with on_device(dev):
             check(lib.allset_nll_logsoftmax_fwd_total(ptr(logits), logits.stride(0), ptr(y), ptr(w), inv_count, ptr(partials), npart.value,
                                                       ptr(_ticket(dev)), ptr(partials[npart.value:]), n, C, stream_of(dev)),

@@ -95,6 +95,15 @@ class SetGNN(nn.Module):
                 self.GPRweights = Linear(self.All_num_layers + 1, 1, bias=False)
             self.classifier = head(args.MLP_hidden)
 
+        # the modules that consume data.x itself (layers.MLP._wide_input: the raw-feature route also under no_grad)
+        if self.All_num_layers == 0:
+            self.classifier._raw_input = True
+        else:
+            if isinstance(getattr(self.V2EConvs[0], "f_enc", None), MLP):
+                self.V2EConvs[0].f_enc._raw_input = True
+            if self.GPR:
+                self.MLP._raw_input = True
+
         self._inc_cache: Dict[Tuple, Tuple[weakref.ref, Tuple[Incidence, Incidence]]] = {}
 
     def reset_parameters(self):

@@ -23,7 +23,8 @@ template <typename T> static T* to_device(const std::vector<T>& h) {
 }
 
 int main() {
-  if (allset_version() != ALLSET_ABI_VERSION) { std::printf("ABI version mismatch\n"); return 1; }
+  // the core surface only (include/allset_hip.h): its own, frozen version
+  if (allset_core_version() != ALLSET_CORE_ABI_VERSION) { std::printf("core ABI version mismatch\n"); return 1; }
   const int64_t n_v = 1000, n_e = 300, nnz = 6000, d = 64, H = 4, C = d / H;
   std::srand(7);
   std::vector<int64_t> vid(nnz), eid(nnz);

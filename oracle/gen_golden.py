@@ -53,7 +53,7 @@ def run_reference(case: dict, ref_models):
     torch.manual_seed(0)
     model = ref_models.SetGNN(args, norm=norm.to(torch.float32) if args.LearnMask else None)
     spec = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
-    sd_np = cases.make_state_dict(spec, case["seed"])
+    sd_np = cases.make_state_dict(spec, case["seed"], case.get("kinkfree", False))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     model.eval()
     grabbed = {}

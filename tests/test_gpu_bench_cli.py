@@ -64,3 +64,9 @@ def test_bench_default_line_small(tmp_path):
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 8 and cb["value"] > 0 and "the GPU workload itself" in cb["sample"]
     assert abs(line["value"] - line["config"]["nnz"] * 128 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    # both arithmetics of the dense tail in the same run: the default's numbers are the line's, the strict ones beside them
+    dt, strict = line["dense_tail"], line["strict"]
+    assert dt["arithmetic"] == "auto" and strict["arithmetic"] == "bf16x6"
+    assert dt["strict_ms_per_step"] == strict["dense_tail_ms_per_step"] > 0 and strict["ms_per_step"] > 0
+    assert any(k.startswith("fused_linear") for k in strict["kernels"])
+    assert line["config"]["workload"].startswith("variant of BASELINE configs[2] (30000 rows per GPU)")

@@ -150,24 +150,25 @@ def test_fused_linear_fwd(K, N, n, device):
     b = torch.randn(N, generator=g)
     gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
     xd, Wd, bd, gd, btd = (t.to(device) for t in (x, W, b, gamma, beta))
-    for has_ln in (False, True):
+    x64, W64, b64, g64, bt64 = (t.double() for t in (xd, Wd, bd, gd, btd))         # (the float64 reference runs on the device: 8 CPU
+    for has_ln in (False, True):                                                     #  GEMMs of 70001 rows cost 5 s per case)
         for relu_in in (False, True):
             for relu_out in (False, True):
-                h = x.double()
+                h = x64
                 if relu_in:
                     h = F.relu(h)
                 if has_ln:
-                    h = F.layer_norm(h, (K,), gamma.double(), beta.double(), 1e-5)
-                ref = F.linear(h, W.double(), b.double())
+                    h = F.layer_norm(h, (K,), g64, bt64, 1e-5)
+                ref = F.linear(h, W64, b64)
                 if relu_out:
                     ref = F.relu(ref)
                 y, st = dense.fused_linear_fwd(xd, Wd, bd, gd if has_ln else None, btd if has_ln else None, 1e-5,
                                                relu_in, 0.0, 0, relu_out, 0.0, 0)
-                torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+                torch.testing.assert_close(y.double(), ref, rtol=1e-4, atol=1e-4)
                 if has_ln:
-                    hh = F.relu(x.double()) if relu_in else x.double()
-                    torch.testing.assert_close(st[:, 0].cpu().double(), hh.mean(1), rtol=1e-4, atol=1e-5)
-                    torch.testing.assert_close(st[:, 1].cpu().double(), (hh.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+                    hh = F.relu(x64) if relu_in else x64
+                    torch.testing.assert_close(st[:, 0].double(), hh.mean(1), rtol=1e-4, atol=1e-5)
+                    torch.testing.assert_close(st[:, 1].double(), (hh.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
     # dropout masks: the prologue mask equals ln_fwd's mask for the same seed; the epilogue mask equals relu_dropout's
     p = 0.3
     u, _ = dense.ln_fwd(xd, gd, btd, 1e-5, True, p, 4242)

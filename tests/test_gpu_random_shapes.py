@@ -13,7 +13,7 @@ from oracle import allset_oracle as oracle
 pytestmark = pytest.mark.gpu
 # ALLSET_HYPOTHESIS_EXAMPLES / ALLSET_HYPOTHESIS_RANDOM=1: bug-hunting runs (more examples, fresh seeds); the default is a fixed,
 # derandomized sample so that the suite is reproducible
-_N = int(os.environ.get("ALLSET_HYPOTHESIS_EXAMPLES", "40"))
+_N = int(os.environ.get("ALLSET_HYPOTHESIS_EXAMPLES", "24"))      # (40 until round 4; the sweeps: ALLSET_HYPOTHESIS_EXAMPLES=700 ALLSET_HYPOTHESIS_RANDOM=1)
 _DERAND = os.environ.get("ALLSET_HYPOTHESIS_RANDOM", "0") != "1"
 COMMON = dict(deadline=None, max_examples=_N, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.filter_too_much], derandomize=_DERAND)
 
@@ -163,7 +163,7 @@ def test_fused_norm_linear_random_rows(n, K, N, has_ln, relu_in, relu_out, sd, d
         torch.testing.assert_close(a.grad.double(), r.grad, rtol=2e-4, atol=2e-4 * scale, msg=lambda m: f"{nm}: {m}")
 
 
-@settings(deadline=None, max_examples=max(30, _N * 3 // 4), suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.filter_too_much],
+@settings(deadline=None, max_examples=max(16, _N * 3 // 4), suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.filter_too_much],
           derandomize=_DERAND)
 @given(pma=st.booleans(), layers=st.integers(1, 3), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([16, 64, 128, 256]),
        heads=st.sampled_from([1, 2, 4]), aggr=st.sampled_from(["add", "mean", "max"]), norm=st.sampled_from(["ln", "bn", "None"]),

@@ -34,7 +34,10 @@ def _case(tag, mode, heads, hidden, chid, attempt=0):
     ei = cases.random_hypergraph(rng, n_v, 90, 1100, True)           # + one self-loop hyperedge per vertex (train.py's default)
     x = rng.standard_normal((n_v, f)).astype(np.float32)
     args = cases.make_args(mode, f, hidden, k, heads=heads, Classifier_hidden=chid)
-    return dict(name=name, args=args, x=x, edge_index=ei, norm=np.ones(ei.shape[1], dtype=np.int64), seed=seed, big=False)
+    # kinkfree: cases.kinkfree_biases -- what this matrix pins is which kernel family each width / head count takes, not relu
+    # patterns (the fixtures' job); with the pre-activations away from zero the first draw is stable (the re-draw loop below used
+    # to evaluate the float64 oracle up to 90 times on the 512-wide branches: 20 s of a 1200 s budget for one test)
+    return dict(name=name, args=args, x=x, edge_index=ei, norm=np.ones(ei.shape[1], dtype=np.int64), seed=seed, big=False, kinkfree=True)
 
 
 @pytest.mark.parametrize("mode", ["pma", "ds_add"])
@@ -52,7 +55,7 @@ def test_run_script_configuration_matches_the_oracle(tag, heads, hidden, chid, m
         case = _case(tag, "pma_h1" if mode == "pma" else "ds_add", heads, hidden, chid, attempt)
         case["args"].heads = heads
         spec = [(k, tuple(v.shape)) for k, v in SetGNN(case["args"]).state_dict().items()]
-        sd = {k: torch.from_numpy(v) for k, v in cases.make_state_dict(spec, case["seed"]).items()}
+        sd = {k: torch.from_numpy(v) for k, v in cases.make_state_dict(spec, case["seed"], case.get("kinkfree", False)).items()}
         o64 = util.run_oracle(case, sd, torch.float64)
         sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
         G = torch.from_numpy(cases.cotangent(case["name"], o64["logits"].shape)).double()

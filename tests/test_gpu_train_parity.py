@@ -63,11 +63,11 @@ CASES = [("rand50_ds_add", {}), ("rand50_pma_h4", {}), ("cora_ds_add", {}), ("ci
          # 1-bit mask out (fused_fwd2.hip) and the one-pass backward with dropout on the gradient (fused_bwd6.hip).  rand50: one
          # partial 32-row stage per workgroup; mid4k (4611 vertices, 8710 hyperedges): full and tail stages, several persistent
          # workgroups whose partial gW / LayerNorm-parameter sums meet in allset_reduce_partials; _bn: the column-affine prologue.
-         ("rand50_ds_add_d128", {}), ("mid4k_ds_add", {}), ("mid4k_ds_add", dict(All_num_layers=2, MLP_num_layers=3)),
-         ("mid4k_ds_add_bn", {}), ("mid4k_pma_h4", {})]
+         ("rand50_ds_add_d128", {}), ("rand50_ds_add_d128", dict(All_num_layers=2, MLP_num_layers=3)), ("mid4k_ds_add", {}),
+         ("mid4k_ds_add_bn", {})]
 
 
-@pytest.mark.parametrize("name", ["rand50_ds_add_d128", "mid4k_ds_add", "mid4k_pma_h4"])
+@pytest.mark.parametrize("name", ["rand50_ds_add_d128", "mid4k_ds_add", "rand50_pma_h4"])
 def test_training_step_in_the_strict_arithmetic(name, device, monkeypatch):
     """The same comparison with every fused Linear on the exact-split bf16x6 kernels (``dense.set_arithmetic('strict')``): the
     dropout-bearing 128 x 128 instantiations of BOTH kernel families are pinned to the oracle."""
@@ -91,9 +91,9 @@ def test_training_step_matches_oracle_with_the_products_masks(name, over, device
     # gradients by percents (either side's value is a correct subgradient; tests/test_gpu_two_ranks.py::_model_seed has the same
     # remark).  Those configurations are evaluated on the first parameter draw whose float64 oracle gradient is stable under a
     # 2e-6 perturbation of x; the LayerNorm configurations (row-local: a kink moves one row) keep their single fixed draw.
-    # ... and so do the mid4k cases: ~3M relu inputs per evaluation put about every second draw within fp32 rounding of a kink
-    # (oracle/gen_golden.py's kink guard has the numbers), and one flipped unit moves everything upstream of it by percents.
-    bn = over.get("normalization") == "bn" or name.endswith("_bn") or name.startswith("mid4k_")
+    # (The mid4k cases -- ~3M relu inputs per evaluation, a kink within fp32 rounding on about every second draw -- avoid kinks by
+    # construction instead: cases.kinkfree_biases on the freshly initialised model.)
+    bn = (over.get("normalization") == "bn" or name.endswith("_bn")) and not name.startswith("mid4k_")
     # which instantiations ran: (K, N, LayerNorm prologue, dropout in, dropout out, 1-bit mask) of every fused forward and
     # (O, I, LayerNorm, dropout in, relu in, mask on gy) of every one-pass backward
     fwd_calls, bwd_calls = [], []
@@ -174,6 +174,8 @@ def _one_training_step(name, over, device, seeds, attempt, need_stable, leaf_x=F
     torch.manual_seed(case["seed"] + attempt)
     model = SetGNN(args)
     model.reset_parameters()
+    if case.get("kinkfree"):
+        cases.kinkfree_biases(dict(model.named_parameters()))
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.train().to(device)
 

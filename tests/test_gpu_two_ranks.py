@@ -195,7 +195,7 @@ def _spawn_ranks(world, which):
     results = {}
     try:
         for _ in range(world):
-            r, payload = q.get(timeout=600)
+            r, payload = q.get(timeout=300)
             assert not isinstance(payload, str), f"rank {r}: {payload}"
             results[r] = payload
     finally:
@@ -367,7 +367,7 @@ def test_bench_two_ranks_one_gpu_gloo():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                "--n-per-gpu", "20000", "--model", model, "--pipeline-chunks", str(chunks)]
-        res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
         lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, res.stdout[-2000:]
@@ -390,7 +390,7 @@ def test_bench_bare_command_spawns_its_own_ranks():
     env["ALLSET_DIST_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000", "--d", "128",
            "--chunk-entry", "2"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -416,8 +416,8 @@ def test_bench_hung_second_region_keeps_the_first_regions_line():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(ALLSET_DIST_BACKEND="gloo", ALLSET_BENCH_TEST_HANG="columns:1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000",
-           "--region-timeout", "20", "--preflight", "off"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+           "--region-timeout", "8", "--preflight", "off"]       # (first region: 3 x 8 s)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -440,7 +440,7 @@ def test_bench_eight_ranks_one_gpu_gloo(model):
     env["ALLSET_DIST_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n-per-gpu", "8000",
            "--model", model, "--chunk-entry", "2", "--region-timeout", "300"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -464,7 +464,7 @@ def test_bench_two_ranks_locality_variant_with_halo_exchange():
     env["ALLSET_DIST_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-per-gpu", "20000",
            "--locality", "0.9", "--chunk-entry", "0", "--no-wire-entry"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     parts = line["partitions"]
@@ -512,17 +512,28 @@ def test_sharded_training_example_reproduces_the_single_gpu_loss_curve(method):
     def losses(out):
         return [float(v) for v in re.findall(r"loss ([0-9.]+)", out)]
 
-    one = subprocess.run([sys.executable] + base + ["--partition", "rows"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run([sys.executable] + base + ["--partition", "rows"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
     ref = losses(one.stdout)
     assert len(ref) == 10 and ref[-1] < 0.7 * ref[0]
     env2 = dict(env, ALLSET_DIST_BACKEND="gloo")
+    # the three two-rank runs side by side (six processes sharing the device: each is launch-bound and small)
+    procs = {}
     for part in ("rows", "rows+halo", "columns"):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + base + ["--partition", part]
-        two = subprocess.run(cmd, cwd=root, env=env2, capture_output=True, text=True, timeout=900)
-        assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
-        got = losses(two.stdout)
+        procs[part] = subprocess.Popen(cmd, cwd=root, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    outs = {}
+    try:
+        for part, pr in procs.items():
+            outs[part] = pr.communicate(timeout=300) + (pr.returncode,)
+    finally:
+        for pr in procs.values():
+            if pr.poll() is None:
+                pr.kill()
+    for part, (so, se, rc) in outs.items():
+        assert rc == 0, part + so[-2000:] + se[-2000:]
+        got = losses(so)
         assert len(got) == 10
         np.testing.assert_allclose(got[:4], ref[:4], rtol=2e-4, err_msg=part)         # plain parity before Adam amplifies rounding
         np.testing.assert_allclose(got, ref, rtol=2e-2, err_msg=part)

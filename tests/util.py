@@ -24,7 +24,7 @@ def golden_spec(g: Dict[str, np.ndarray]):
 
 
 def state_dict_for(case: dict, g: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
-    sd_np = cases.make_state_dict(golden_spec(g), case["seed"])
+    sd_np = cases.make_state_dict(golden_spec(g), case["seed"], case.get("kinkfree", False))
     return {k: torch.from_numpy(v) for k, v in sd_np.items()}
 
 
