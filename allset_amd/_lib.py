@@ -109,6 +109,11 @@ SIGNATURES = {
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, _P],
     "allset_fused_linear_blocked_supported": [c_int64, c_int64],
+    "allset_fused_linear_tail_supported": [c_int64, c_int64],
+    "allset_fused_linear_fwd_ln_side": [_P, c_int64, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int64, _P, c_int64, _P, c_int64, c_int64,
+                                        c_int64, _P],
+    "allset_fused_linear_fwd_res_ln": [_P, c_int64, c_int, _P, _P, c_int, _P, c_int64, _P, _P, c_float, c_int, c_float, c_uint64, _P, _P,
+                                       c_int64, _P, c_int64, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_fused_linear_arith_supported": [c_int, c_int64, c_int64, c_int, c_int, c_int],
     "allset_fused_linear_fwd_ex": [_P, c_int64, c_int64, _P, _P, c_float, c_int, c_int, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                                    _P, c_int64, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_int, _P],

@@ -796,8 +796,8 @@ extern "C" int allset_fused_linear_bwd_all_ex(const float* gy, int64_t ldg, int6
 }
 
 // 1 = the fused Linear of this direction (0 forward, 1 one-pass backward) has a kernel in arithmetic `arith` at these widths
-// (AUTO and BF16X6: wherever the entry itself is built; FP16X3: the O = I = 128 split-role kernels -- forward only behind a
-// LayerNorm prologue, whose bound on the operand it needs).
+// (AUTO and BF16X6: wherever the entry itself is built; FP16X3: the O = I = 128 split-role kernels -- the forward behind a LayerNorm
+// prologue or without a norm, not in the column-affine mode, and not with auxiliary output columns).
 extern "C" int allset_fused_linear_arith_supported(int direction, int64_t K, int64_t N, int has_ln, int norm_mode, int arith) {
   if (!((K == 64 || K == 128) && (N == 64 || N == 128))) return 0;
   if (arith == ALLSET_ARITH_AUTO || arith == ALLSET_ARITH_BF16X6) return 1;
@@ -806,7 +806,7 @@ extern "C" int allset_fused_linear_arith_supported(int direction, int64_t K, int
   return 0;
 #else
   if (K != 128 || N != 128) return 0;
-  return direction == 0 ? ((has_ln && norm_mode == ALLSET_NORM_LAYER) ? 1 : 0) : 1;
+  return direction == 0 ? ((!has_ln || norm_mode == ALLSET_NORM_LAYER) ? 1 : 0) : 1;      // (forward: not in the column-affine mode)
 #endif
 }
 

@@ -72,12 +72,25 @@ __device__ __forceinline__ uint32_t hash_mix_f(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_F(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8, bool F16>
+// XM ("extra mode", round 5 -- the PMA tail of reference layers.py:153-157 folded into its two rFF Linears, fp16x3 only):
+//   1  prologue = LayerNorm(x + colb) (ln0 with the seed add riding in it), whose OUTPUT is also written to `uo` (the residual
+//      branch and the backward need it): one kernel instead of allset_ln_res_fwd + allset_fused_linear_fwd;
+//   2  no LayerNorm in front (row-scaled fp16x3, below); epilogue = z = relu?(. + bias) [1-bit mask of z], s = res + z -> `uo`,
+//      y = dropout(relu_post?(LayerNorm_{gamma,beta,eps}(s))), statistics of s -> `stats`: ln1 and the residual add inside the
+//      second rFF Linear, one kernel instead of allset_fused_linear_fwd + allset_ln_res_fwd.
+template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8, bool F16, int XM = 0>
 __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
     float p_out, uint64_t seed_out, float* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n,
-    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out, int64_t xcb, int64_t ycb, float ln_inv) {
+    const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out, int64_t xcb, int64_t ycb, float ln_inv,
+    const float* __restrict__ colb = nullptr, float* __restrict__ uo = nullptr, int64_t lduo = 0,
+    const float* __restrict__ res = nullptr, int64_t ldres = 0, int relu_post = 0) {
+  static_assert(XM == 0 || F16, "the tail modes are built on the fp16x3 arithmetic only");
+  static_assert(XM != 1 || (HAS_LN && !DROP_IN && !DROP_OUT), "mode 1: LayerNorm prologue, no dropout");
+  static_assert(XM != 2 || (!HAS_LN && !DROP_IN), "mode 2: plain operand, LayerNorm in the epilogue");
+  constexpr bool ROWSC = F16 && !HAS_LN;        // fp16x3 without a bound on the operand: one power of two per ROW, from its largest element
+  constexpr bool AFF = HAS_LN || XM == 2;       // sG / sB hold a LayerNorm's affine parameters (prologue's, or mode 2's epilogue's)
   // ln_inv: 1 / 128 for the LayerNorm prologue; 0 (with eps = 1) switches the row statistics off -- mean = 0, rstd = 1, which is
   // what gets written to `stats` -- and leaves the per-column affine map x * gamma + beta: BatchNorm with batch statistics
   // folded into (gamma, beta) by the caller (ALLSET_NORM_COLUMN_AFFINE, csrc/batchnorm.hip).
@@ -97,7 +110,9 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
   seed_in = resolve_seed(seed_base, seed_in);
   seed_out = resolve_seed(seed_base, seed_out);
   const int tid = threadIdx.x;
-  if (tid < KD) { sG[tid] = HAS_LN ? gamma[tid] : 1.f; sB[tid] = HAS_LN ? beta[tid] : 0.f; sBias[tid] = bias ? bias[tid] : 0.f; }
+  __shared__ __attribute__((aligned(16))) float sCol[XM == 1 ? KD : 4];
+  if (tid < KD) { sG[tid] = AFF ? gamma[tid] : 1.f; sB[tid] = AFF ? beta[tid] : 0.f; sBias[tid] = bias ? bias[tid] : 0.f; }
+  if constexpr (XM == 1) { if (tid < KD) sCol[tid] = colb ? colb[tid] : 0.f; }
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n_stages = (n + R - 1) / R;
@@ -113,9 +128,11 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
   // The LayerNorm output is bounded without a data pass, |u| <= (sqrt(127) max|gamma| + max|beta|) keep, so ONE power of two 2^Su for
   // the whole launch brings it below 2^14 -- folded into gamma and beta, it costs no instruction; W is scaled per matrix wave's
   // slice; both are undone where the wave writes its output tile.
-  static_assert(!F16 || HAS_LN, "fp16x3 needs the LayerNorm bound on the operand");
+  // Without a LayerNorm in front (ROWSC) the window comes from the row itself: the vector wave that stages a row takes the
+  // exponent of its largest element (a DPP row maximum of values it already holds), scales the row's planes by that power of two
+  // and undoes it in the SAME lanes' epilogue two ticks later (a lane owns the same rows in S0 and E).
   int Su = 0;
-  if constexpr (F16) {
+  if constexpr (F16 && HAS_LN) {
     float g = fmaxf(fabsf(sG[lane0]), fabsf(sG[lane0 + 64])), bm = fmaxf(fabsf(sB[lane0]), fabsf(sB[lane0 + 64]));
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { g = fmaxf(g, __shfl_xor(g, off)); bm = fmaxf(bm, __shfl_xor(bm, off)); }
@@ -149,12 +166,26 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
       bet[hb] = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
       bia[hb] = *reinterpret_cast<const float4*>(&sBias[64 * hb + 4 * c]);
-      if constexpr (F16) {
+      if constexpr (F16 && HAS_LN && XM != 1) {     // (mode 1 stores the unscaled LayerNorm output: it scales at the split instead)
         const float su = __uint_as_float(static_cast<uint32_t>(127 + Su) << 23);
         gam[hb].x *= su; gam[hb].y *= su; gam[hb].z *= su; gam[hb].w *= su;
         bet[hb].x *= su; bet[hb].y *= su; bet[hb].z *= su; bet[hb].w *= su;
       }
     }
+    const float su1 = XM == 1 ? __uint_as_float(static_cast<uint32_t>(127 + Su) << 23) : 1.f;
+    int eA = 20, eB = 20, eC = 20;               // ROWSC: biased row exponents of the last three stages staged (E(k) reads eC, the last E eB)
+    float4 resR[2];                              // mode 2: the residual rows of the next stage to leave
+    auto request_res = [&](int64_t k) {
+      if constexpr (XM == 2) {
+        const int64_t s0 = stage_of(k);
+        const int nrc = max(rows_left(s0), 1);
+        const int lrc = min(lr, nrc - 1);
+        const char* rb = reinterpret_cast<const char*>(res + s0 * R * ldres);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          resR[hb] = *reinterpret_cast<const float4*>(rb + hb * 256 + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldres) * 4u + 16u * c));
+      }
+    };
     // [set][hb]: the rows of the next kF2Sets stages.  Bytes in flight bound these kernels (~2 us of loaded latency, DESIGN.md 6a'''):
     // a vector wave's share of a stage is 2 KB, so four sets = 64 KB per CU, 16 MB chip-wide -- at 8 registers per set
     float4 xrS[kF2Sets][2];
@@ -196,6 +227,13 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       const bool live = lr < rows_left(stage);
       uint8_t* img = sX + (k & 1) * IMG;
       float4 t[2] = {xr[0], xr[1]};
+      if constexpr (XM == 1) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const float4 cb4 = *reinterpret_cast<const float4*>(&sCol[64 * hb + 4 * c]);
+          t[hb].x += cb4.x; t[hb].y += cb4.y; t[hb].z += cb4.z; t[hb].w += cb4.w;
+        }
+      }
       if (relu_in) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -219,12 +257,32 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
           t[hb].z = fmaf(t[hb].z * rstd, gam[hb].z, bet[hb].z); t[hb].w = fmaf(t[hb].w * rstd, gam[hb].w, bet[hb].w);
         }
       }
+      if constexpr (XM == 1) {                    // the LayerNorm output itself: `out` of reference layers.py:156
+        if (live) {
+          char* ub = reinterpret_cast<char*>(uo + stage * R * lduo) + static_cast<uint32_t>(lr) * static_cast<uint32_t>(lduo) * 4u + 16u * c;
+          *reinterpret_cast<float4*>(ub) = t[0];
+          *reinterpret_cast<float4*>(ub + 256) = t[1];
+        }
+      }
+      float rsc = su1;                             // the factor applied at the split: mode 1's launch-wide 2^Su, ROWSC's row scale
+      if constexpr (ROWSC) {
+        float amax = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          amax = fmaxf(fmaxf(fmaxf(fabsf(t[hb].x), fabsf(t[hb].y)), fmaxf(fabsf(t[hb].z), fabsf(t[hb].w))), amax);
+        amax = fmaxf(amax, dpp_ff<0xB1>(amax)); amax = fmaxf(amax, dpp_ff<0x4E>(amax));
+        amax = fmaxf(amax, dpp_ff<0x141>(amax)); amax = fmaxf(amax, dpp_ff<0x140>(amax));
+        const int e = min(max(static_cast<int>(__float_as_uint(amax * keep_in) >> 23), 20), 254);
+        eC = eB; eB = eA; eA = e;
+        rsc = __uint_as_float(static_cast<uint32_t>(254 + 13 - e) << 23);       // the row's largest element -> [2^13, 2^14)
+      }
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         if constexpr (DROP_IN) {
           const float4 kp = keep4(seed_in, stage, hb, thr_in, keep_in);
           t[hb].x *= kp.x; t[hb].y *= kp.y; t[hb].z *= kp.z; t[hb].w *= kp.w;
         }
+        if constexpr (ROWSC || XM == 1) { t[hb].x *= rsc; t[hb].y *= rsc; t[hb].z *= rsc; t[hb].w *= rsc; }
         const int wo = img_off_f(lr, 128 * hb + 8 * c);
         if constexpr (F16) {
           uint32_t h0, l0, h1, l1;
@@ -246,26 +304,73 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
       __builtin_amdgcn_sched_barrier(0);
     };
     // ---- E(k): the epilogue of stage k from ytile[k % 2]
-    auto E = [&](int64_t k) {
+    auto E = [&](int64_t k, int erow) {
       const int64_t stage = stage_of(k);
       const int nrows = rows_left(stage);
       const bool live = lr < nrows;
       const float* ty = sY + (k & 1) * (R * SPY);
       char* yb = reinterpret_cast<char*>(y + stage * R * ldy);
       const uint32_t yo = static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldy) * 4u + coy0;
+      const float unsc = ROWSC ? __uint_as_float(static_cast<uint32_t>(erow - 13) << 23) : 1.f;       // undoes the row's 2^(140 - e)
+      float4 vv[2];
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         float4 v = *reinterpret_cast<const float4*>(&ty[lr * SPY + 64 * hb + 4 * c]);
-        v.x += bia[hb].x; v.y += bia[hb].y; v.z += bia[hb].z; v.w += bia[hb].w;
+        if constexpr (ROWSC) {
+          v.x = fmaf(v.x, unsc, bia[hb].x); v.y = fmaf(v.y, unsc, bia[hb].y); v.z = fmaf(v.z, unsc, bia[hb].z); v.w = fmaf(v.w, unsc, bia[hb].w);
+        } else {
+          v.x += bia[hb].x; v.y += bia[hb].y; v.z += bia[hb].z; v.w += bia[hb].w;
+        }
         if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if constexpr (DROP_OUT) {
+        vv[hb] = v;
+      }
+      if constexpr (XM == 2) {
+        // s = res + z -> uo;  y = dropout(relu_post?(LayerNorm(s)));  the statistics of s -> stats
+        float4 sv[2];
+        float a1 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          sv[hb] = make_float4(resR[hb].x + vv[hb].x, resR[hb].y + vv[hb].y, resR[hb].z + vv[hb].z, resR[hb].w + vv[hb].w);
+          a1 += (sv[hb].x + sv[hb].y) + (sv[hb].z + sv[hb].w);
+        }
+        const float mean = row16_sum_f(a1) * (1.f / 128.f);
+        float q2 = 0.f;
+        float4 cv[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          cv[hb] = make_float4(sv[hb].x - mean, sv[hb].y - mean, sv[hb].z - mean, sv[hb].w - mean);
+          q2 = fmaf(cv[hb].x, cv[hb].x, fmaf(cv[hb].y, cv[hb].y, fmaf(cv[hb].z, cv[hb].z, fmaf(cv[hb].w, cv[hb].w, q2))));
+        }
+        const float rstd = rsqrtf(row16_sum_f(q2) * (1.f / 128.f) + eps);
+        if (live) {
+          if (c == 0) *reinterpret_cast<float2*>(stats + (stage * R + lr) * 2) = make_float2(mean, rstd);
+          char* ub = reinterpret_cast<char*>(uo + stage * R * lduo) + static_cast<uint32_t>(lr) * static_cast<uint32_t>(lduo) * 4u + 16u * c;
+          *reinterpret_cast<float4*>(ub) = sv[0];
+          *reinterpret_cast<float4*>(ub + 256) = sv[1];
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          float4 o = make_float4(fmaf(cv[hb].x * rstd, gam[hb].x, bet[hb].x), fmaf(cv[hb].y * rstd, gam[hb].y, bet[hb].y),
+                                 fmaf(cv[hb].z * rstd, gam[hb].z, bet[hb].z), fmaf(cv[hb].w * rstd, gam[hb].w, bet[hb].w));
+          if (relu_post) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          if constexpr (DROP_OUT) {
+            const float4 kp = keep4(seed_out, stage, hb, thr_out, keep_out);
+            o.x *= kp.x; o.y *= kp.y; o.z *= kp.z; o.w *= kp.w;
+          }
+          if (live) *reinterpret_cast<float4*>(yb + hb * dhy + yo) = o;
+        }
+      }
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        float4 v = vv[hb];
+        if constexpr (DROP_OUT && XM != 2) {
           const float4 kp = keep4(seed_out, stage, hb, thr_out, keep_out);
           v.x *= kp.x; v.y *= kp.y; v.z *= kp.z; v.w *= kp.w;
         }
 #ifdef ALLSET_ABL5_NOSTORE
         if (live && v.x == 123.456f)
 #else
-        if (live)
+        if (live && XM != 2)
 #endif
           *reinterpret_cast<float4*>(yb + hb * dhy + yo) = v;
         if (mask_out != nullptr) {
@@ -281,18 +386,24 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
             mask_out[((stage * (R / 16) + (wave >> 2)) * (ND / 64) + hb) * 32 + (wave & 3) * 8 + lane0] = word;
         }
       }
+      if constexpr (XM == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        request_res(k + 1);                       // the next stage's residual rows: a tick ahead of their use
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
 
     static_assert(kF2Sets == 4, "the trip below is written for four register sets");
 #pragma unroll
     for (int q = 0; q < kF2Sets; ++q) request_x(q, xrS[q]);
+    request_res(0);
     S0(0, xrS[0]);
     ALLSET_F2_TICK();
     S0(1, xrS[1]);                               // tick 0 (stage 1 may be a re-run of the last stage: never consumed)
     ALLSET_F2_TICK();
     // ticks 1 .. T - 1, four per trip (stage t + 1 lives in register set (t + 1) % 4); the last 1..3 ticks are peeled off: a
     // conditional part inside the trip makes hipcc wait vmcnt(0) at the loop header (DESIGN.md 6a''')
-#define ALLSET_F2_FULL_TICK(tt, set) do { ALLSET_FMARK(3); S0((tt) + 1, xrS[set]); ALLSET_FMARK(0); E((tt) - 1); ALLSET_FMARK(1); ALLSET_F2_TICK(); ALLSET_FMARK(2); } while (0)
+#define ALLSET_F2_FULL_TICK(tt, set) do { ALLSET_FMARK(3); S0((tt) + 1, xrS[set]); ALLSET_FMARK(0); E((tt) - 1, eC); ALLSET_FMARK(1); ALLSET_F2_TICK(); ALLSET_FMARK(2); } while (0)
     int64_t t = 1;
     for (; t + 3 < T; t += 4) {
       ALLSET_F2_FULL_TICK(t, 2);
@@ -304,7 +415,7 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     if (t + 1 < T) ALLSET_F2_FULL_TICK(t + 1, 3);
     if (t + 2 < T) ALLSET_F2_FULL_TICK(t + 2, 0);
 #undef ALLSET_F2_FULL_TICK
-    E(T - 1);                                    // tick T
+    E(T - 1, eB);                                // tick T (the last S0 staged stage T: a re-run of the last stage, never consumed)
   } else {
     // =================================================== matrix waves ===================================================
     const int m = wave - kF2VWaves;
@@ -467,17 +578,18 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
 #else
   const bool d8 = is8(p_in) && is8(p_out);
 #endif
-  // fp16x3 arithmetic behind a true LayerNorm prologue (its bound on the operand); bf16x6 otherwise (no norm, column-affine mode)
+  // fp16x3 arithmetic: behind a true LayerNorm prologue (its bound on the operand gives one scale per launch) and -- round 5 -- without
+  // any norm (one scale per row, from the row's largest element); bf16x6 in the column-affine mode and on request (ALLSET_ARITH_BF16X6)
 #ifdef ALLSET_NO_F16X3
   const bool f16 = false; (void)arith;
 #else
-  const bool f16 = gamma != nullptr && ln_inv != 0.f && arith != ALLSET_ARITH_BF16X6;
+  const bool f16 = arith != ALLSET_ARITH_BF16X6 && (gamma == nullptr || ln_inv != 0.f);
 #endif
 #define ALLSET_F2_KE(LN, DI, DO, E8, H16)                                                                                              \
   fused_linear_fwd_roles_kernel<LN, DI, DO, E8, H16><<<grid, kF2Block, 0, st>>>(x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, \
                                                                                 relu_out, p_out, seed_out, y, ldy, stats, n, seed_base,   \
                                                                                 mask_out, xcb, ycb, ln_inv)
-#define ALLSET_F2_KD(LN, DI, DO, E8) do { if (LN && f16) ALLSET_F2_KE(LN, DI, DO, E8, LN); else ALLSET_F2_KE(LN, DI, DO, E8, false); } while (0)
+#define ALLSET_F2_KD(LN, DI, DO, E8) do { if (f16) ALLSET_F2_KE(LN, DI, DO, E8, true); else ALLSET_F2_KE(LN, DI, DO, E8, false); } while (0)
 #define ALLSET_F2_K(LN, DI, DO) do { if ((DI || DO) && d8) ALLSET_F2_KD(LN, DI, DO, true); else ALLSET_F2_KD(LN, DI, DO, false); } while (0)
   const int v = (gamma != nullptr ? 4 : 0) | (p_in > 0.f ? 2 : 0) | (p_out > 0.f ? 1 : 0);
   switch (v) {
@@ -494,4 +606,83 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
 #undef ALLSET_F2_KD
 #undef ALLSET_F2_KE
   return 0;
+}
+
+// ---- the PMA tail (reference layers.py:153-157) folded into its two rFF Linears: modes 1 and 2 of the kernel above (fp16x3) -------
+static inline unsigned f2_grid(int64_t n) {
+  const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
+  return static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));
+}
+
+extern "C" int allset_fused_linear_tail_supported(int64_t K, int64_t N) {
+#ifdef ALLSET_NO_F16X3
+  (void)K; (void)N;
+  return 0;
+#else
+  return (K == 128 && N == 128) ? 1 : 0;
+#endif
+}
+
+// uo = LayerNorm_{gamma,beta,eps}(x + colb);  y = relu_out?(uo W^T + bias);  stats[r] = {mean, rstd} of x + colb
+extern "C" int allset_fused_linear_fwd_ln_side(const float* x, int64_t ldx, const float* colb, const float* gamma, const float* beta,
+                                               float eps, const float* W, const float* bias, int relu_out, float* y, int64_t ldy,
+                                               float* uo, int64_t lduo, float* stats, int64_t n, int64_t K, int64_t N, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "fused_linear_fwd_ln_side: negative size");
+  if (!allset_fused_linear_tail_supported(K, N)) {
+    set_error("fused_linear_fwd_ln_side: built for K = N = 128 only (allset_fused_linear_tail_supported)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && gamma && beta && W && y && uo && stats, "fused_linear_fwd_ln_side: null pointer");
+  ALLSET_REQUIRE(aligned16(x) && aligned16(y) && aligned16(uo) && aligned16(W) && (reinterpret_cast<uintptr_t>(stats) & 7u) == 0,
+                 "fused_linear_fwd_ln_side: x / y / uo / W must be 16-byte aligned, stats 8-byte aligned");
+  ALLSET_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N && ldy % 4 == 0 && lduo >= K && lduo % 4 == 0 && ldx < (1 << 24) && ldy < (1 << 24) &&
+                 lduo < (1 << 24), "fused_linear_fwd_ln_side: rows must be 16-byte aligned, leading dimensions below 2^24");
+#ifndef ALLSET_NO_F16X3
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  fused_linear_fwd_roles_kernel<true, false, false, false, true, 1><<<f2_grid(n), kF2Block, 0, st>>>(
+      x, ldx, gamma, beta, eps, 0, 0.f, 0, W, bias, relu_out, 0.f, 0, y, ldy, stats, n, nullptr, nullptr, 0, 0, 1.f / 128.f, colb, uo, lduo,
+      nullptr, 0, 0);
+  ALLSET_LAUNCH_CHECK();
+#endif
+  return ALLSET_OK;
+}
+
+// z = relu_out?(relu_in?(x) W^T + bias) [mask_out: 1 bit per element of z > 0];  s = res + z -> s_out;  stats[r] = {mean, rstd} of s;
+// y = dropout_{p_out}(relu_post?(LayerNorm_{gamma,beta,eps}(s)))
+extern "C" int allset_fused_linear_fwd_res_ln(const float* x, int64_t ldx, int relu_in, const float* W, const float* bias, int relu_out,
+                                              const float* res, int64_t ldres, const float* gamma, const float* beta, float eps,
+                                              int relu_post, float p_out, uint64_t seed_out, const uint64_t* seed_base, float* y,
+                                              int64_t ldy, float* s_out, int64_t lds, float* stats, uint32_t* mask_out, int64_t n,
+                                              int64_t K, int64_t N, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "fused_linear_fwd_res_ln: negative size");
+  ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "fused_linear_fwd_res_ln: dropout p must be in [0,1)");
+  if (!allset_fused_linear_tail_supported(K, N)) {
+    set_error("fused_linear_fwd_res_ln: built for K = N = 128 only (allset_fused_linear_tail_supported)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(x && W && res && gamma && beta && y && s_out && stats, "fused_linear_fwd_res_ln: null pointer");
+  ALLSET_REQUIRE(aligned16(x) && aligned16(y) && aligned16(s_out) && aligned16(res) && aligned16(W) &&
+                 (reinterpret_cast<uintptr_t>(stats) & 7u) == 0,
+                 "fused_linear_fwd_res_ln: x / res / y / s_out / W must be 16-byte aligned, stats 8-byte aligned");
+  ALLSET_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N && ldy % 4 == 0 && lds >= N && lds % 4 == 0 && ldres >= N && ldres % 4 == 0 &&
+                 ldx < (1 << 24) && ldy < (1 << 24) && lds < (1 << 24) && ldres < (1 << 24),
+                 "fused_linear_fwd_res_ln: rows must be 16-byte aligned, leading dimensions below 2^24");
+#ifndef ALLSET_NO_F16X3
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const float t8 = p_out * 256.0f;
+  const bool d8 = p_out <= 0.f || t8 == floorf(t8);
+#define ALLSET_F2_TB(DO, E8)                                                                                                            \
+  fused_linear_fwd_roles_kernel<false, false, DO, E8, true, 2><<<f2_grid(n), kF2Block, 0, st>>>(                                          \
+      x, ldx, gamma, beta, eps, relu_in, 0.f, 0, W, bias, relu_out, p_out, seed_out, y, ldy, stats, n, seed_base, mask_out, 0, 0, 0.f,    \
+      nullptr, s_out, lds, res, ldres, relu_post)
+  if (p_out > 0.f) { if (d8) ALLSET_F2_TB(true, true); else ALLSET_F2_TB(true, false); }
+  else ALLSET_F2_TB(false, false);
+#undef ALLSET_F2_TB
+  ALLSET_LAUNCH_CHECK();
+#endif
+  return ALLSET_OK;
 }

@@ -690,9 +690,9 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
   const int has_ln = gamma != nullptr;
   const bool roles = fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
                      (reinterpret_cast<uintptr_t>(stats) & 7u) == 0;
-  if (arith == ALLSET_ARITH_FP16X3 && !(roles && has_ln && norm_mode == ALLSET_NORM_LAYER)) {
-    set_error("fused_linear_fwd: ALLSET_ARITH_FP16X3 is built for K = N = 128 behind a LayerNorm prologue only "
-              "(allset_fused_linear_arith_supported)");
+  if (arith == ALLSET_ARITH_FP16X3 && !(roles && (!has_ln || norm_mode == ALLSET_NORM_LAYER))) {
+    set_error("fused_linear_fwd: ALLSET_ARITH_FP16X3 is built for K = N = 128 without auxiliary columns, behind a LayerNorm prologue or "
+              "none (allset_fused_linear_arith_supported)");
     return ALLSET_ERR_UNSUPPORTED;
   }
   if (roles) {                                                            // K = N = 128: the split-role kernel (fused_fwd2.hip)

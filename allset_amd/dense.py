@@ -1321,6 +1321,105 @@ def pma_residual_ff(out: Tensor, w1, b1, w2, b2, gamma, beta, eps: float = 1e-5,
     return _PmaResidualFF.apply(out, w1, b1, w2, b2, gamma, beta, float(eps), bool(relu_post), float(p))
 
 
+# ---- the PMA tail with ln0 / ln1 inside its two rFF Linears (round 5; csrc/fused_fwd2.hip modes 1 and 2) ---------------------------
+def pma_tail_supported(out_like: Tensor, d: int, w1: Tensor, w2: Tensor) -> bool:
+    """``ln1(out + relu(rFF(out)))`` with ``out = ln0(pooled + att_r)`` (reference layers.py:153-157) runs as TWO forward kernels:
+    device fp32, every width 128, the fp16x3 arithmetic not switched off."""
+    return (out_like.is_cuda and out_like.dtype == torch.float32 and d == 128 and tuple(w1.shape) == (128, 128) and tuple(w2.shape) == (128, 128)
+            and _arith != _lib.ARITH_BF16X6 and bool(_lib.load().allset_fused_linear_tail_supported(128, 128)))
+
+
+def fused_linear_fwd_ln_side(x: Tensor, colb: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float, weight: Tensor,
+                             bias: Optional[Tensor], relu_out: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """``(y, u, stats)``: ``u = LayerNorm(x + colb)``, ``y = relu_out?(u W^T + b)`` (include/allset_hip_ext.h allset_fused_linear_fwd_ln_side)."""
+    dev = require_device(x, colb, gamma, beta, weight, bias)
+    _check_f32(x, colb, gamma, beta, weight, bias)
+    x = _rowmajor(x)
+    n, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((n, N), dtype=torch.float32, device=dev)
+    u = torch.empty((n, K), dtype=torch.float32, device=dev)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + N + K) * 4):
+        check(_lib.load().allset_fused_linear_fwd_ln_side(
+            ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps,
+            ptr(weight.contiguous()), ptr(bias.contiguous() if bias is not None else None), int(relu_out), ptr(y), max(N, 1), ptr(u),
+            max(K, 1), ptr(stats), n, K, N, stream_of(dev)), "allset_fused_linear_fwd_ln_side")
+    return y, u, stats
+
+
+def fused_linear_fwd_res_ln(x: Tensor, relu_in: bool, weight: Tensor, bias: Optional[Tensor], relu_out: bool, res: Tensor, gamma: Tensor,
+                            beta: Tensor, eps: float, relu_post: bool, p: float, seed: int, seed_base: Optional[Tensor],
+                            mask_out: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """``(y, s, stats)``: ``z = relu_out?(relu_in?(x) W^T + b)``, ``s = res + z``, ``y = dropout_p(relu_post?(LayerNorm(s)))``
+    (include/allset_hip_ext.h allset_fused_linear_fwd_res_ln)."""
+    dev = require_device(x, weight, bias, res, gamma, beta)
+    _check_f32(x, weight, bias, res, gamma, beta)
+    x, res = _rowmajor(x), _rowmajor(res)
+    n, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((n, N), dtype=torch.float32, device=dev)
+    s = torch.empty((n, N), dtype=torch.float32, device=dev)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    with on_device(dev), _timed("fused_linear_fwd", dev, n * (K + 3 * N) * 4):
+        check(_lib.load().allset_fused_linear_fwd_res_ln(
+            ptr(x), _ld(x), int(relu_in), ptr(weight.contiguous()), ptr(bias.contiguous() if bias is not None else None), int(relu_out),
+            ptr(res), _ld(res), ptr(gamma.contiguous()), ptr(beta.contiguous()), eps, int(relu_post), p, seed, ptr(seed_base), ptr(y),
+            max(N, 1), ptr(s), max(N, 1), ptr(stats), ptr(mask_out), n, K, N, stream_of(dev)), "allset_fused_linear_fwd_res_ln")
+    return y, s, stats
+
+
+def pma_tail_fwd(pooled: Tensor, cb: Tensor, g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post: bool, p: float):
+    """Forward of the whole tail in two kernels.  Returns ``(y, saved)``; ``saved`` goes to :func:`pma_tail_bwd`."""
+    y1, out, stats0 = fused_linear_fwd_ln_side(pooled, cb, g0, b0, eps0, w1, b1, False)
+    words = activation_mask_words(pooled.shape[0], w2.shape[0])
+    mask = torch.empty(words, dtype=torch.int32, device=pooled.device)
+    seed = _draw_seed() if p > 0.0 else 0
+    base = _seed_base() if p > 0.0 else None
+    y, s, stats1 = fused_linear_fwd_res_ln(y1, True, w2, b2, True, out, g1, bt1, eps1, relu_post, p, seed, base, mask)
+    return y, (pooled, cb, stats0, g0, b0, out, y1, mask, s, stats1, w1, w2, g1, bt1), (bool(relu_post), float(p), seed, base,
+                                                                                       b1 is not None, b2 is not None)
+
+
+def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional[Tensor] = None):
+    """``(g_pooled, dcolb, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pma_stats or None)``: ln1's backward on the saved sum, the two
+    Linears' one-pass backward (the residual branch summed through ``acc_in``), ln0's backward -- with the pooling's backward
+    statistics written by the same pass when the softmax statistics ``(m, l)`` are given."""
+    pooled, cb, stats0, g0, b0, out, y1, mask, s, stats1, w1, w2, g1, bt1 = saved
+    relu_post, p, seed, base, has_b1, has_b2 = cfg
+    gs, dg1, db1, _ = ln_res_bwd(gy.contiguous(), s, None, None, stats1, g1, bt1, relu_post, p, seed, base)
+    gh, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
+    gout, _, _, gw1, gb1 = fused_linear_bwd_all(gh, None, 0.0, w1, out, None, None, None, False, 0.0, 0, acc_in=gs, want_bias=has_b1)
+    if m is not None:
+        g_pooled, dg0, db0, dc, pstats = ln_res_bwd_pma(gout, pooled, cb, stats0, g0, b0, m, l)
+    else:
+        g_pooled, dg0, db0, dc = ln_res_bwd(gout, pooled, cb, None, stats0, g0, b0, False, 0.0, 0, None)
+        pstats = None
+    return g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats
+
+
+class _PmaTail(torch.autograd.Function):
+    """``dropout_p(relu_post?(ln1(out + relu(rFF(out)))))`` with ``out = ln0(pooled + att_r)`` as one autograd node on two forward
+    kernels (:func:`pma_tail_fwd`)."""
+
+    @staticmethod
+    def forward(ctx, pooled, att_r, g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post, p):
+        y, saved, cfg = pma_tail_fwd(pooled, att_r.reshape(-1), g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post, p)
+        ctx.save_for_backward(*saved)
+        ctx.cfg, ctx.cshape = cfg, att_r.shape
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, _ = pma_tail_bwd(ctx.saved_tensors, ctx.cfg, gy)
+        return g_pooled, dc.reshape(ctx.cshape), dg0, db0, None, gw1, gb1, gw2, gb2, dg1, db1, None, None, None
+
+
+def pma_tail(pooled: Tensor, att_r: Tensor, g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post: bool = False, p: float = 0.0) -> Tensor:
+    return _PmaTail.apply(pooled, att_r, g0, b0, float(eps0), w1, b1, w2, b2, g1, bt1, float(eps1), bool(relu_post), float(p))
+
+
 class _PmaFold(torch.autograd.Function):
     """``(w [H, K], b [H]) = fold(W_K [H C, K], b_K [H C], att_r [.., H, C])``: the weight of PMA's folded logits as ONE kernel each
     way (as torch ops: mul, sum, mul, sum forward and six more backward -- ~80 us per replayed dataset-scale step)."""

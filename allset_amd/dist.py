@@ -916,13 +916,30 @@ class ColumnShardedHypergraph:
     vertex ids, row 1 global 0-based hyperedge ids; identical on every rank) plus the row blocks this rank owns for the
     dense work -- vertices ``v_lo:v_hi`` of the padded vertex range, hyperedges ``e_lo:e_hi`` of the padded hyperedge
     range (blocks padded to a multiple of ``chunks``, the chunk count of the overlapped exchange).  ``norm``:
-    per-incidence weights in ``edge_index`` order, or None."""
+    per-incidence weights in ``edge_index`` order, or None.
+
+    ``row_groups = R > 1`` (round 5): the HYBRID partition -- the world is R target groups x C = world / R column groups, rank
+    r = a C + b.  Rank (a, b) aggregates, for the TARGETS of group a (hyperedges ``a n_E/R .. (a+1) n_E/R`` in V->E, vertices
+    likewise in E->V), the d / C columns of slice b: it holds the incidences of those targets only (half of them at R = 2) and gathers
+    rows of d / C columns -- 128 bytes at d = 128, C = 4, where the pure column partition at 8 ranks gathers 64-byte rows at half
+    the fabric's efficiency.  Exchanges per aggregation: rows -> columns as ONE all-to-all over the whole world in
+    which every rank sends column slice b' of its rows to BOTH (all R) ranks (., b') -- every target group needs every source row,
+    and a direct send loads all world - 1 point-to-point links evenly, where an all-gather across a 2-rank group would put the
+    whole table on one xGMI link --, the local aggregation, columns -> rows inside the column group (an all-to-all over the C ranks
+    of group a: ``col_group``).  Backward: the transposes; the R copies' gradients are summed on arrival (fixed order).  Groups from
+    :func:`hybrid_groups` (every rank must create all of them, in the same order)."""
 
     def __init__(self, edge_index: Tensor, n_v: int, n_e: int, world: int, rank: int, norm: Optional[Tensor] = None,
-                 chunks: int = 1):
+                 chunks: int = 1, row_groups: int = 1, col_group=None, gather_group=None):
         self.edge_index = edge_index
         self.n_v, self.n_e, self.world, self.rank = int(n_v), int(n_e), int(world), int(rank)
-        self.chunks = max(int(chunks), 1)         # owned blocks are padded to a multiple of this (overlapped exchange)
+        self.row_groups = max(int(row_groups), 1)
+        if self.world % self.row_groups:
+            raise ValueError(f"hybrid partition: the world size ({world}) must be a multiple of row_groups ({row_groups})")
+        self.col_world = self.world // self.row_groups
+        self.group_a, self.slice_b = self.rank // self.col_world, self.rank % self.col_world
+        self.col_group, self.gather_group = col_group, gather_group
+        self.chunks = max(int(chunks), 1) if self.row_groups == 1 else 1     # owned blocks are padded to a multiple of this (overlapped exchange)
 
         def block(n):
             per = (n + world - 1) // world
@@ -933,12 +950,94 @@ class ColumnShardedHypergraph:
         self.norm = norm
         self.v2e = None
         self.e2v = None
+        self.ids_v2e = self.ids_e2v = None        # hybrid: positions (in edge_index) of the incidences each direction keeps
+
+    @property
+    def hybrid(self) -> bool:
+        return self.row_groups > 1
+
+    def target_slices(self):
+        """Hybrid: ``((ei_v2e, n_dst, ids), (ei_e2v, n_dst, ids))`` -- per direction the [2, k] (source id, LOCAL target id) list of the
+        incidences whose target lies in this rank's target group, the group's target count and the positions of those incidences in
+        ``edge_index`` (what routes ``norm`` / ``Importance``)."""
+        R, a = self.row_groups, self.group_a
+        ne, nv = self.n_e_pad // R, self.n_v_pad // R
+        v, e = self.edge_index[0], self.edge_index[1]
+        ke = torch.nonzero((e >= a * ne) & (e < (a + 1) * ne)).reshape(-1)
+        kv = torch.nonzero((v >= a * nv) & (v < (a + 1) * nv)).reshape(-1)
+        return ((torch.stack([v[ke], e[ke] - a * ne]), ne, ke), (torch.stack([e[kv], v[kv] - a * nv]), nv, kv))
+
+    def norm_of(self, norm: Optional[Tensor], direction: str) -> Optional[Tensor]:
+        """``norm`` (edge_index order) restricted to the incidences direction 'v2e' / 'e2v' keeps on this rank (hybrid); else as is."""
+        if norm is None or not self.hybrid:
+            return norm
+        ids = self.ids_v2e if direction == "v2e" else self.ids_e2v
+        return norm[ids]
 
     def build_incidences(self) -> "ColumnShardedHypergraph":
         from .incidence import Incidence
+        if self.hybrid:
+            (ei1, n1, k1), (ei2, n2, k2) = self.target_slices()
+            self.v2e = Incidence.from_edge_index(ei1.contiguous(), n_src=self.n_v_pad, n_dst=n1)
+            self.e2v = Incidence.from_edge_index(ei2.contiguous(), n_src=self.n_e_pad, n_dst=n2)
+            self.ids_v2e, self.ids_e2v = k1, k2
+            return self
         self.v2e = Incidence.from_edge_index(self.edge_index, n_src=self.n_v_pad, n_dst=self.n_e_pad)
         self.e2v = self.v2e.reversed(n_dst=self.n_v_pad)
         return self
+
+
+def hybrid_groups(world: int, row_groups: int, rank: int):
+    """``(col_group, None)`` of ``rank`` for the hybrid partition (rank = a C + b): the C ranks of target group a (the second
+    slot was the cross-group gather group of the first design; the spread is a world all-to-all now).  Collective: EVERY rank
+    creates every group, in the same order (``dist.new_group``)."""
+    R, C = int(row_groups), world // int(row_groups)
+    col = None
+    for a in range(R):
+        g = dist.new_group(ranks=[a * C + b for b in range(C)])
+        if rank // C == a:
+            col = g
+    return col, None
+
+
+class _SpreadBlocks(torch.autograd.Function):
+    """Hybrid partition, rows -> columns: ``x`` [C * r, c] = C blocks of this rank's r rows (block b' = column slice b' of them:
+    what ``_pack`` or a fused Linear with ``out_cb = c`` produces); every block goes to all R ranks (a', b') in ONE all-to-all over
+    ``group`` (the world); result [world * r, c] = column slice ``b`` of EVERY rank's rows, in rank (= global row block) order.
+    Backward: the transpose all-to-all, the R gradient copies of a block summed in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, R, group):
+        ctx.R, ctx.group, ctx.shape = R, group, x.shape
+        send = _narrow(x.contiguous()).repeat(R, 1)                  # [R][C * r, c]: destination rank a' C + b' gets block b'
+        recv = torch.empty_like(send)
+        _all_to_all_single(recv, send, group)
+        return recv.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        send = _narrow(g.contiguous())
+        recv = torch.empty_like(send)
+        _all_to_all_single(recv, send, ctx.group)                      # piece from rank (a', b') = its gradient of my rows' slice b'
+        return recv.to(g.dtype).view((ctx.R,) + tuple(ctx.shape)).sum(dim=0), None, None
+
+
+def spread_blocks(x: Tensor, row_groups: int, group=None) -> Tensor:
+    return _SpreadBlocks.apply(x, int(row_groups), group)
+
+
+class _PackCols(torch.autograd.Function):
+    """[r, C * c] -> [C * r, c] (block b' = column slice b'); backward = the inverse copy."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        ctx.C = C
+        return _pack(x, C).reshape(C * x.shape[0], x.shape[1] // C)
+
+    @staticmethod
+    def backward(ctx, g):
+        C = ctx.C
+        return _unpack(g.contiguous().view(C, g.shape[0] // C, g.shape[1])), None
 
 
 def head_slots(heads: int, world: int) -> Tuple[int, list]:
@@ -975,8 +1074,17 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
         raise ValueError(f"aggr {aggr!r}")
     norm = hg.norm if norm is None else norm
     p_out = dropout if dropout_out is None else dropout_out
-    w = 1 if _skip_collective(group) else _world(group)
-    K = _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
+    hyb = bool(getattr(hg, "hybrid", False))
+    cg = hg.col_group if hyb else group             # the ranks the columns -> rows all-to-all spans: the world, or one target group
+    norm1, norm2 = (hg.norm_of(norm, "v2e"), hg.norm_of(norm, "e2v")) if hyb else (norm, norm)
+    w = 1 if _skip_collective(cg) else _world(cg)
+    K = 1 if hyb else _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
+    if hyb:        # rows -> columns: one world all-to-all, every block to all R target groups (every group needs every source row)
+        to_cols = lambda t: spread_blocks(_PackCols.apply(t, w), hg.row_groups, group)
+        to_cols_blocked = lambda t: spread_blocks(t, hg.row_groups, group)
+    else:
+        to_cols = lambda t: rows_to_cols(t, cg)
+        to_cols_blocked = lambda t: exchange_blocks(t, cg)
     enc1 = lambda t: v2e_conv._mlp_act(v2e_conv.f_enc, t, v2e_conv.dropout)
     mid = lambda t: e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, t, dropout), e2v_conv.dropout)
     dec2 = lambda t: e2v_conv._mlp_act(e2v_conv.f_dec, t, p_out)
@@ -984,18 +1092,18 @@ def colsharded_deepsets_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnSha
     if cb:
         # repack-free: the MLPs on either side of each all-to-all write / read its buffer layout themselves
         h = v2e_conv._mlp_act(v2e_conv.f_enc, x_owned, v2e_conv.dropout, out_cb=cb)                   # [P * n_V/P, d/P] blocked
-        e = exchange_blocks(aggregate(exchange_blocks(h, group), hg.v2e, norm, aggr), group)          # [P * n_E/P, d/P] blocked
+        e = exchange_blocks(aggregate(to_cols_blocked(h), hg.v2e, norm1, aggr), cg)                   # [P * n_E/P, d/P] blocked
         g = e2v_conv._mlp_act(e2v_conv.f_enc, v2e_conv._mlp_act(v2e_conv.f_dec, e, dropout, in_cb=cb), e2v_conv.dropout, out_cb=cb)
-        v = exchange_blocks(aggregate(exchange_blocks(g, group), hg.e2v, norm, aggr), group)
+        v = exchange_blocks(aggregate(to_cols_blocked(g), hg.e2v, norm2, aggr), cg)
         return e2v_conv._mlp_act(e2v_conv.f_dec, v, p_out, in_cb=cb)
     if K == 1:
         vv, ve = _valid_rows(hg.v_lo, hg.v_hi, hg.n_v), _valid_rows(hg.e_lo, hg.e_hi, hg.n_e)     # real rows of the two owned blocks
         with _bn_scope(vv, group):
             h = enc1(x_owned)
-        e = cols_to_rows(aggregate(rows_to_cols(h, group), hg.v2e, norm, aggr), group)      # [n_E/P, d]
+        e = cols_to_rows(aggregate(to_cols(h), hg.v2e, norm1, aggr), cg)      # [n_E/P, d]
         with _bn_scope(ve, group):
             g = mid(e)
-        v = cols_to_rows(aggregate(rows_to_cols(g, group), hg.e2v, norm, aggr), group)
+        v = cols_to_rows(aggregate(to_cols(g), hg.e2v, norm2, aggr), cg)
         with _bn_scope(vv, group):
             return dec2(v)
     rc_v, rc_e = x_owned.shape[0] // K, hg.n_e_pad // w // K
@@ -1020,8 +1128,11 @@ def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedH
     """The layer of :func:`sharded_pma_layer` with column-sharded pooling: per direction one all-to-all of the values,
     one of the (few) logit columns each slice needs, the ordinary local fused pooling, one all-to-all back.
     ``chunks``: as in :func:`colsharded_deepsets_layer`."""
-    w = 1 if _skip_collective(group) else _world(group)
-    K = _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
+    hyb = bool(getattr(hg, "hybrid", False))
+    cg = hg.col_group if hyb else group
+    w = 1 if _skip_collective(cg) else _world(cg)
+    to_cols = (lambda t: spread_blocks(_PackCols.apply(t, w), hg.row_groups, group)) if hyb else (lambda t: rows_to_cols(t, cg))
+    K = 1 if hyb else _chunking(hg, x_owned, chunks, w, group, v2e_conv, e2v_conv)
     post = dropout if training else 0.0
     post_out = (dropout if dropout_out is None else dropout_out) if training else 0.0
 
@@ -1045,9 +1156,8 @@ def colsharded_pma_layer(v2e_conv, e2v_conv, x_owned: Tensor, hg: ColumnShardedH
     if K == 1:
         def pool(p, f, hl, t, inc, pp):
             V, alpha = f(t)
-            o = kernels.aggregate(rows_to_cols(V, group).contiguous(), rows_to_cols(alpha, group).contiguous(), inc, hl,
-                                  p.negative_slope)
-            return p.tail(cols_to_rows(o, group), _post=pp)
+            o = kernels.aggregate(to_cols(V).contiguous(), to_cols(alpha).contiguous(), inc, hl, p.negative_slope)
+            return p.tail(cols_to_rows(o, cg), _post=pp)
         return pool(p2, f2, hl2, pool(p1, f1, hl1, x_owned, hg.v2e, post), hg.e2v, post_out)
     rv, re = x_owned.shape[0] // K, hg.n_e_pad // w // K
     Vc, ac = _stage(torch.split(x_owned, rv), f1, rv, K, w, group)
@@ -1265,7 +1375,27 @@ def exchange_bytes_per_rank(mode: str, world: int, n_v: int, n_e: int, d: int, e
         return int(4 * f * n_v * d * elem)
     if mode == "columns":
         return int(4 * f * (n_v + n_e) / world * d * elem)
+    if mode.startswith("hybrid"):       # hybridRxC: per aggregation the spread (rows from all other ranks, d / C columns) + the return
+        R = int(mode[len("hybrid"):].split("x")[0])          # inside the column group; forward + backward, both directions
+        C = world // R
+        spread = f * (n_v + n_e) * (d / C) * elem
+        back = (C - 1) / C * (n_v + n_e) / world * d * elem
+        return int(2 * (spread + back))
     raise ValueError(mode)
+
+
+def exchange_bytes_per_link(mode: str, world: int, n_v: int, n_e: int, d: int, elem: int = 4) -> int:
+    """Bytes on the BUSIEST point-to-point link of a rank per layer (xGMI: one link per pair of GPUs): rows / columns load all
+    ``world - 1`` links evenly; the hybrid partition's spread does too, its return only the C - 1 links of the column group."""
+    if world <= 1:
+        return 0
+    if mode.startswith("hybrid"):
+        R = int(mode[len("hybrid"):].split("x")[0])
+        C = world // R
+        per_pair_spread = (n_v + n_e) / world * (d / C) * elem
+        per_pair_back = (n_v + n_e) / world * (d / C) * elem
+        return int(2 * (per_pair_spread + per_pair_back))
+    return exchange_bytes_per_rank(mode, world, n_v, n_e, d, elem) // (world - 1)
 
 
 def choose_sharding(world: int, d: int, heads: Optional[int] = None, elem: int = 4) -> str:

@@ -260,6 +260,50 @@ class _PmaPoolLn0(torch.autograd.Function):
         return gV, galpha, None, None, None, dc.reshape(ctx.cshape), dg, db, None
 
 
+class _PmaPoolTail(torch.autograd.Function):
+    """Pooling + the whole PMA tail (reference layers.py:145-157) as ONE autograd node: ``pma_fwd`` and the two tail kernels of
+    ``dense.pma_tail_fwd`` forward; backward as ``_PmaPoolLn0`` (the pooling's backward statistics come out of ln0's backward
+    pass) with ln1's backward reading the saved sum."""
+
+    @staticmethod
+    def forward(ctx, V, alpha, inc, heads, slope, att_r, g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post, p):
+        from . import dense
+        csr = inc.by_dst
+        pooled, m, l = ops.pma_fwd(csr.rowptr, csr.col, alpha, V, heads, slope, inc.n_dst,
+                                   variant=_variant(csr, "pma_fwd", inc.n_dst, V, heads), row_order=csr.row_order,
+                                   split=_split(csr, V, heads), sizes=_sizes(csr, V, heads))
+        y, saved, cfg = dense.pma_tail_fwd(pooled, att_r.reshape(-1), g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post, p)
+        ctx.inc, ctx.slope, ctx.cshape, ctx.cfg = inc, slope, att_r.shape, cfg
+        ctx.save_for_backward(V, alpha, m, l, *saved)
+        ctx.mark_non_differentiable(m, l)
+        return y, m, l
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gm, _gl):
+        from . import dense
+        V, alpha, m, l = ctx.saved_tensors[:4]
+        g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats = dense.pma_tail_bwd(ctx.saved_tensors[4:], ctx.cfg, gy, m, l)
+        T = ctx.inc.by_src
+        H = alpha.shape[1]
+        gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, g_pooled, pstats, ctx.slope,
+                                     variant=_variant(T, "pma_bwd_src", V.shape[0], V, H), row_order=T.row_order,
+                                     split=_split(T, V, H), sizes=_sizes(T, V, H))
+        return (gV, galpha, None, None, None, dc.reshape(ctx.cshape), dg0, db0, None, gw1, gb1, gw2, gb2, dg1, db1, None, None, None)
+
+
+def pma_pool_tail(V: Tensor, alpha: Tensor, inc: Incidence, heads: int, negative_slope: float, att_r: Tensor, g0, b0, eps0, w1, b1, w2, b2,
+                  g1, bt1, eps1, relu_post: bool, p: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """``(tail(pool(V, alpha)), m, l)``; see :class:`_PmaPoolTail` (callers check ``pma_pool_ln0_supported`` and
+    ``dense.pma_tail_supported``)."""
+    _lib.require_device(V, alpha)
+    _check_rows(V, inc)
+    if alpha.dtype != torch.float32:
+        alpha = alpha.float()
+    return _PmaPoolTail.apply(V, alpha, inc, int(heads), float(negative_slope), att_r, g0, b0, float(eps0), w1, b1, w2, b2, g1, bt1,
+                              float(eps1), bool(relu_post), float(p))
+
+
 def pma_pool_ln0_supported(V: Tensor, heads: int) -> bool:
     from . import dense
     d = V.shape[1]

@@ -415,6 +415,11 @@ class PMA(nn.Module):
         ``_ln0_done`` (internal): ``pooled`` already is ``ln0(pooled + att_r)`` (the joint pooling + ln0 node of ``forward``)."""
         H, C = self.heads, self.hidden
         hip = _on_hip(pooled) or (pooled.is_cuda and pooled.dtype == torch.bfloat16 and self.ln0.weight.dtype == torch.bfloat16)
+        if not _ln0_done and self._tail_fused(pooled):
+            ff = self.rFF          # round 5: ln0 / ln1 inside the two rFF Linears -- two forward kernels for the whole tail
+            return dense.pma_tail(pooled, self.att_r, self.ln0.weight, self.ln0.bias, self.ln0.eps, ff.lins[0].weight, ff.lins[0].bias,
+                                  ff.lins[1].weight, ff.lins[1].bias, self.ln1.weight, self.ln1.bias, self.ln1.eps,
+                                  _post is not None, float(_post or 0.0) if self.training else 0.0)
         if hip and dense.ln_res_supported(H * C, pooled.dtype) and self.ln0.bias is not None and self.ln1.bias is not None:
             # the seed add rides in ln0's pass, the residual add (and the conv's relu -> dropout) in ln1's
             out = pooled if _ln0_done else dense.layer_norm_res(pooled, self.att_r, None, self.ln0.weight, self.ln0.bias, self.ln0.eps)
@@ -439,11 +444,25 @@ class PMA(nn.Module):
         out = _layer_norm(self.ln1, out + self.rFF(out, _post=0.0))
         return out if _post is None else relu_dropout(out, _post, True)
 
+    def _tail_fused(self, pooled: Tensor) -> bool:
+        """The tail runs on ``dense.pma_tail`` (fp32 device tensors, every width 128, a 2-layer rFF without norms, affine LayerNorms,
+        the fp16x3 arithmetic available)."""
+        ff = self.rFF
+        return (_on_hip(pooled) and pooled.dim() == 2 and len(ff.lins) == 2 and all(isinstance(nm, nn.Identity) for nm in ff.normalizations)
+                and self.ln0.elementwise_affine and self.ln1.elementwise_affine and self.ln0.bias is not None and self.ln1.bias is not None
+                and self.att_r.dtype == torch.float32
+                and dense.pma_tail_supported(pooled, self.heads * self.hidden, ff.lins[0].weight, ff.lins[1].weight))
+
     def pool_tail(self, x_V: Tensor, alpha_r: Tensor, inc: Incidence, _post: Optional[float] = None):
         """``tail(pool(x_V, alpha_r))`` plus the softmax statistics: ``(out [n_t, H*C], m, l)`` (reference layers.py:145-157)."""
         H = self.heads
         hip = _on_hip(x_V) or (x_V.is_cuda and x_V.dtype == torch.bfloat16 and self.ln0.weight.dtype == torch.bfloat16
                                and self.att_r.dtype == torch.bfloat16)
+        if _on_hip(x_V) and AF.pma_pool_ln0_supported(x_V, H) and self._tail_fused(x_V):
+            ff = self.rFF
+            return AF.pma_pool_tail(x_V, alpha_r, inc, H, self.negative_slope, self.att_r, self.ln0.weight, self.ln0.bias, self.ln0.eps,
+                                    ff.lins[0].weight, ff.lins[0].bias, ff.lins[1].weight, ff.lins[1].bias, self.ln1.weight, self.ln1.bias,
+                                    self.ln1.eps, _post is not None, float(_post or 0.0) if self.training else 0.0)
         if (hip and self.ln0.bias is not None and self.ln1.bias is not None and self.ln0.elementwise_affine
                 and AF.pma_pool_ln0_supported(x_V, H)):
             # pooling + seed add + ln0 as one autograd node: the pooling's backward statistics come out of ln0's backward pass

@@ -29,8 +29,10 @@ N > 1 -- two partitions of the same job (allset_amd/dist.py, DESIGN.md section 7
            four all-to-alls per direction-pair, 1/N of the row scheme's bytes at N = 8, overlapped with the dense work.
 Both are timed in every N > 1 run, each in its own region of the same K steps (plus the column partition with the chunked
 overlapped exchange), and appear under ``partitions``, so a scaling record always carries the north-star partition.
-``--shard auto`` (default) reports the FASTEST of these exact (fp32-wire) executions as ``value`` / ``ms_per_step``
-(``config.partition`` / ``config.parallelism`` say which); ``--shard rows`` / ``columns`` pin it.  ``preflight`` = the layer's four
+``value`` / ``ms_per_step`` are those of ``--shard`` -- ``rows`` by default since round 5 (the north star's partition); ``columns`` /
+``hybrid`` pin another one, ``auto`` reports the FASTEST of the exact (fp32-wire) executions this run timed;
+``partitions.fastest_exact`` always names that one.  N = 2 x C >= 4 adds the hybrid partition (2 target groups x C column groups,
+``hybrid2xC``, right after ``rows``).  ``preflight`` = the layer's four
 collectives timed alone at this job's message sizes (GB/s per rank and per xGMI link).
 
 Extra objects in the JSON line:
@@ -91,7 +93,7 @@ def parse_args(argv=None):
     ap.add_argument("--rows-exchange", default="auto", choices=["auto", "table", "halo"],
                     help="row partition: 'table' = all-gather / reduce-scatter of the whole vertex table, 'halo' = exchange only the "
                          "rows of the vertices a rank's hyperedges touch (allset_amd.dist.Halo); auto = halo iff --locality > 0")
-    ap.add_argument("--shard", default="auto", choices=["auto", "rows", "columns"],
+    ap.add_argument("--shard", default="rows", choices=["auto", "rows", "columns", "hybrid"],
                     help="N > 1: which partition is timed as `value` ('auto' = allset_amd.dist.choose_sharding)")
     ap.add_argument("--partitions", default="both", choices=["both", "primary"],
                     help="N > 1: 'both' also times the other partition in a second region and reports it under `partitions`")
@@ -169,10 +171,18 @@ def build_problem(args, mode: str, world: int, rank: int, device):
     from allset_amd import dist as adist
     n_loc = args.n_per_gpu
     n_v = n_loc * world
-    if mode == "columns":
+    if mode == "columns" or mode.startswith("hybrid"):
         blocks = [hyperedge_block(args, n_v, r, device, world) for r in range(world)]
         ei = torch.cat([torch.stack([b.edge_index[0], b.edge_index[1] + r * n_loc]) for r, b in enumerate(blocks)], dim=1)
         norm = torch.cat([b.norm for b in blocks])
+        if mode.startswith("hybrid"):
+            # R target groups x C column groups (allset_amd.dist.ColumnShardedHypergraph(row_groups=R)): every rank aggregates the
+            # incidences of its target group (1 / R of them per direction) over d / C columns -- nnz / world incidence-widths, like
+            # the column partition
+            R = int(mode[len("hybrid"):].split("x")[0])
+            cg, gg = _hybrid_groups(world, R, rank)
+            hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, rank, norm=norm, row_groups=R, col_group=cg, gather_group=gg)
+            return hg, ei.shape[1] / world, n_loc * world
         hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, rank, norm=norm, chunks=args.pipeline_chunks)
         return hg, ei.shape[1] / world, n_loc * world
     shard = hyperedge_block(args, n_v, rank, device, world)
@@ -190,6 +200,32 @@ def build_problem(args, mode: str, world: int, rank: int, device):
     return hg, float(shard.nnz), n_e_loc * world
 
 
+_HYBRID_GROUPS = {}
+
+
+def _hybrid_groups(world: int, row_groups: int, rank: int):
+    """The hybrid partition's process groups, created once per process (dist.new_group is collective: every rank, same order)."""
+    from allset_amd import dist as adist
+    key = (world, row_groups)
+    if key not in _HYBRID_GROUPS:
+        _HYBRID_GROUPS[key] = adist.hybrid_groups(world, row_groups, rank) if dist.is_initialized() else (None, None)
+    return _HYBRID_GROUPS[key]
+
+
+def hybrid_mode(args, world: int):
+    """'hybridRxC' if the job has a hybrid partition worth timing (world = 2 x C >= 4, d / C columns = a whole number of heads or
+    head fractions that divide, rows of >= 128 bytes), else None."""
+    if world < 4 or world % 2 or args.dtype not in ("f32", "bf16"):
+        return None
+    C = world // 2
+    elem = 4 if args.dtype == "f32" else 2
+    if args.d % C or (args.d // C) * elem < 128:
+        return None
+    if args.model == "pma" and (args.heads % C and C % args.heads):
+        return None
+    return f"hybrid2x{C}"
+
+
 def job_value(nnz_total: float, d: int, elapsed_s: float, steps: int) -> float:
     """edges*d per second of the whole job: all ranks' incidences x width / (max-over-ranks seconds per step)."""
     return nnz_total * d / (elapsed_s / steps)
@@ -200,13 +236,13 @@ def resolve_modes(args, world: int):
     from allset_amd import dist as adist
     heads = args.heads if args.model == "pma" else None
     auto = adist.choose_sharding(world, args.d, heads)
-    primary = args.shard if args.shard != "auto" else auto
+    primary = args.shard if args.shard != "auto" else auto           # ("hybrid": main() resolves it to hybridRxC)
     forced = os.environ.get("ALLSET_FORCE_COLLECTIVES", "0") == "1"
     if world == 1 and not forced:
         return "rows", None                                    # one rank: the two layouts coincide
     other = None
     if args.partitions == "both":
-        other = "rows" if primary == "columns" else "columns"
+        other = "rows" if primary in ("columns", "hybrid") else "columns"
         if other == "columns" and (world > 1 and auto != "columns"):
             other = None                                       # the width / head count does not split over this many ranks
     return primary, other
@@ -349,7 +385,7 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
     def step():
         opt.zero_grad(set_to_none=True)
         x.grad = None
-        if mode == "columns":
+        if mode == "columns" or mode.startswith("hybrid"):
             out = (adist.colsharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True, chunks=args.pipeline_chunks, **extra)
                    if attn else
                    adist.colsharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True,
@@ -470,6 +506,12 @@ def parallelism_label(args, mode, world):
             return (f"hyperedge-shard x{world} (boundary-vertex exchange: per direction one all-to-all of the rows of the vertices a rank's "
                     "hyperedges touch + its transpose, allset_amd.dist.Halo)")
         return f"hyperedge-shard x{world} (all-gather + reduce-scatter of the [n_V, d] vertex table per direction)"
+    if mode.startswith("hybrid"):
+        R = int(mode[len("hybrid"):].split("x")[0])
+        C = world // R
+        return (f"hybrid {R} target groups x {C} column groups (rank (a, b): the targets of group a, d/{C} columns; per aggregation an "
+                f"all-to-all inside the column group, an all-gather across the {R} groups, the local aggregation over rows of d/{C} "
+                "columns, an all-to-all back; allset_amd.dist.ColumnShardedHypergraph(row_groups=...))")
     how = f"in {args.pipeline_chunks} overlapped chunks" if args.pipeline_chunks > 1 else "blocking"
     return f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; all-to-all exchange {how})"
 
@@ -649,6 +691,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
     # with the chunked overlapped exchange: same global hypergraph, same K steps each, same results up to summation order -- i.e.
     # the partition an autotuning deployment would keep.  The bf16-wire entry changes results and is never `value`.
     exact = [k for k in state["order"] if k in results and "bf16wire" not in k]
+    fastest = min(exact, key=lambda k: results[k]["ms_per_step"]) if exact else None
     if args.shard == "auto" and world > 1 and exact:
         value_key = min(exact, key=lambda k: results[k]["ms_per_step"])
     else:
@@ -760,6 +803,8 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         elif value_key != primary:
             parts["value_note"] = (f"`value` is partition {value_key!r}: the partition this run would report ({primary!r}) did not "
                                    "finish (see its entry)")
+        if fastest is not None and world > 1:
+            parts["fastest_exact"] = fastest          # (a label: `value` is --shard's partition, `rows` by default -- the north star's)
         parts["note"] = ("`rows` = hyperedge shards, the partition BASELINE.json's north star names; `columns` = column-sharded "
                          "aggregation (DESIGN.md section 7.2). Same global hypergraph, same K steps, separate timed regions (rows first: "
                          "its all-gather / reduce-scatter are the plainest collectives, so a scaling record exists before the "
@@ -833,6 +878,18 @@ def main(argv=None, hooks=None):
     order = [primary] + ([other] if other is not None else [])
     if other is not None and "rows" in order:
         order = ["rows"] + [m for m in order if m != "rows"]
+    # N = 2 x C >= 4: the hybrid partition (2 target groups x C column groups, 128-byte gather rows at d = 128, C = 4) right after
+    # `rows` -- its own `partitions` entry; `value` only under --shard auto (the fastest exact execution) or --shard hybrid
+    hyb = hybrid_mode(args, world) if (args.partitions == "both" or args.shard == "hybrid") else None
+    if args.shard == "hybrid":
+        if hyb is None:
+            raise SystemExit(f"--shard hybrid: no hybrid partition for {world} ranks at d = {args.d}")
+        primary = hyb
+        order = [hyb if m == "hybrid" else m for m in order]
+        if "rows" in order:
+            order = ["rows"] + [m for m in order if m != "rows"]
+    elif hyb is not None:
+        order = (order[:1] + [hyb] + order[1:]) if order[0] == "rows" else (order + [hyb])
     wire_key = primary + "+bf16wire"
     want_wire = world > 1 and args.dtype == "f32" and args.wire_entry and args.pipeline_chunks <= 1
     # N > 1: the column partition once more with the chunked, overlapped exchange (off by default: it has never run over xGMI;

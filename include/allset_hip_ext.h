@@ -482,6 +482,26 @@ int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, const float* W
                                     const float* aux_w, float* gx, int64_t ldgx, float* part, int64_t part_stride, int64_t n_slices,
                                     int64_t n, int64_t O, int64_t I, void* stream);
 
+/* ---- the PMA tail folded into its two rFF Linears (ABI 11; reference layers.py:153-157: out = ln0(pooled + att_r);
+ * out = ln1(out + relu(rFF(out)))), K = N = 128, fp16x3 arithmetic (allset_fused_linear_tail_supported):
+ *   _ln_side : uo = LayerNorm(x + colb) (colb f32[K] or NULL; stats[r] = {mean, rstd}), y = relu_out?(uo W^T + bias) -- ln0 as the
+ *              prologue of rFF's first Linear, its output written once as a side result (the residual branch and the backward use it);
+ *   _res_ln  : z = relu_out?(relu_in?(x) W^T + bias), mask_out = 1 bit per element "z > 0" (mask layout above; may be NULL);
+ *              s = res + z -> s_out; stats[r] = {mean, rstd} of s; y = dropout_{p_out}(relu_post?(LayerNorm(s))) -- the residual add
+ *              and ln1 (with the relu -> dropout SetGNN puts behind the conv, models.py:475-481) as the epilogue of rFF's last Linear.
+ * Backward: allset_ln_res_bwd on s_out (x = s_out, no colb / res) gives the gradient of s; the Linears' own backward is
+ * allset_fused_linear_bwd_all as before.  The operand of _res_ln has no bound known in advance: its fp16 planes are scaled per ROW
+ * (largest element to [2^13, 2^14)), undone per row in the epilogue; the plain forwards without a LayerNorm prologue use the same scheme
+ * under ALLSET_ARITH_AUTO / _FP16X3 since this version. */
+int allset_fused_linear_tail_supported(int64_t K, int64_t N);
+int allset_fused_linear_fwd_ln_side(const float* x, int64_t ldx, const float* colb, const float* gamma, const float* beta, float eps,
+                                    const float* W, const float* bias, int relu_out, float* y, int64_t ldy, float* uo, int64_t lduo,
+                                    float* stats, int64_t n, int64_t K, int64_t N, void* stream);
+int allset_fused_linear_fwd_res_ln(const float* x, int64_t ldx, int relu_in, const float* W, const float* bias, int relu_out,
+                                   const float* res, int64_t ldres, const float* gamma, const float* beta, float eps, int relu_post,
+                                   float p_out, uint64_t seed_out, const uint64_t* seed_base, float* y, int64_t ldy, float* s_out,
+                                   int64_t lds, float* stats, uint32_t* mask_out, int64_t n, int64_t K, int64_t N, void* stream);
+
 /* ---- choice of arithmetic for the fused Linear kernels (ABI 11) ------------------------------------------------------------------
  * The reference computes every Linear in IEEE fp32 (torch, layers.py:571-579).  gfx950's fp32 matrix rate is 1/16 of its bf16 / f16
  * rate, so these kernels EMULATE fp32 products on the 16-bit matrix pipe, in one of two ways:
@@ -496,8 +516,9 @@ int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, const float* W
  *                        product <= 2^-21 relative + 2^-38 x (largest |gy| of the ROW) x |u|: elements more than 2^17 below their row's
  *                        largest lose low bits.  Harmless for gx (a row sum dominated by the row's large elements) but visible in the
  *                        weight gradient when a whole COLUMN of gy sits > 2^17 below the other columns of the same rows: that column's
- *                        gW row then carries relative error 2^-(38 - k) at k binary orders below.  Built for K = N = 128 only, forward
- *                        only behind ALLSET_NORM_LAYER (allset_fused_linear_arith_supported).
+ *                        gW row then carries relative error 2^-(38 - k) at k binary orders below.  Built for K = N = 128 only; the
+ *                        forward behind ALLSET_NORM_LAYER (one scale per launch) or without a norm (one scale per row), not in the
+ *                        column-affine mode (allset_fused_linear_arith_supported).
  *   ALLSET_ARITH_AUTO    the library's choice -- a pure function of the SHAPE arguments, never of the data (no data pass, no sync):
  *                        FP16X3 wherever it is built, BF16X6 elsewhere.  AUTO therefore does NOT fall back on hostile dynamic range;
  *                        a caller whose gradient columns spread over more than 2^17 (not seen in any AllSet configuration: LayerNorm

@@ -700,6 +700,118 @@ def test_colsharded_pma_layer_equals_unsharded(H, chunks):
         torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=2e-5)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# hybrid partition (round 5): R target groups x C column groups -- gloo worlds 4 (2 x 2) and 8 (2 x 4)
+# ---------------------------------------------------------------------------------------------------------------
+
+def _hybrid_worker(rank, world, port, kind, arg, q, row_groups=2, learn_mask=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from allset_amd import dist as adist
+        n_v, n_e, d, ei, norm, x, G = _problem(world)
+        cg, gg = adist.hybrid_groups(world, row_groups, rank)
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=norm if kind == "ds" else None, row_groups=row_groups,
+                                           col_group=cg, gather_group=gg)
+        assert hg.hybrid and hg.col_world == world // row_groups and hg.rank == hg.group_a * hg.col_world + hg.slice_b
+        (ei1, n1, k1), (ei2, n2, k2) = hg.target_slices()          # the tuple form the oracle aggregation takes
+        hg.v2e, hg.e2v, hg.ids_v2e, hg.ids_e2v = (ei1, n1), (ei2, n2), k1, k2
+        # every incidence is kept by exactly one target group per direction
+        cnt = torch.tensor([k1.numel(), k2.numel()])
+        dist.all_reduce(cnt)
+        assert cnt.tolist() == [ei.shape[1] * hg.col_world, ei.shape[1] * hg.col_world]
+        xp = torch.cat([x, x.new_zeros(hg.n_v_pad - n_v, d)])
+        Gp = torch.cat([G, G.new_zeros(hg.n_v_pad - n_v, d)])
+        xo = xp[hg.v_lo:hg.v_hi].clone().requires_grad_(True)
+        imp = None
+        if kind == "ds":
+            a, b = _convs(d)
+            nrm = norm
+            if learn_mask:                                           # a replicated per-incidence parameter: gradient = sum over ranks
+                imp = torch.nn.Parameter(torch.linspace(0.5, 1.5, ei.shape[1]))
+                nrm = imp * norm
+            out = adist.colsharded_deepsets_layer(a, b, xo, hg, aggr=arg, aggregate=_oracle_aggregate, norm=nrm)
+        else:
+            a, b = _pma_convs(d, arg)
+            out = adist.colsharded_pma_layer(a, b, xo, hg, kernels=TorchPmaKernels)
+        (out * Gp[hg.v_lo:hg.v_hi]).sum().backward()
+        params = list(a.parameters()) + list(b.parameters()) + ([imp] if imp is not None else [])
+        adist.allreduce_grads(params)
+        q.put((rank, out.detach().numpy().copy(), xo.grad.numpy().copy(), [p.grad.numpy().copy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_hybrid(world, kind, arg, learn_mask=False):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, world, port, kind, arg, q, 2, learn_mask)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("world,aggr,mask", [(4, "add", False), (4, "max", False), (8, "add", True), (8, "mean", False)])
+def test_hybrid_deepsets_layer_equals_unsharded(world, aggr, mask):
+    """2 target groups x (world / 2) column groups against the unsharded layer: outputs, input gradient, parameter gradients
+    (identical on every rank after the all-reduce) and -- ``mask`` -- the gradient of a replicated per-incidence weight parameter
+    (LearnMask's Importance, reference models.py:451-452), of which every rank sees its directions' halves."""
+    import torch.nn.functional as F
+    results = _run_hybrid(world, "ds", aggr, mask)
+    n_v, n_e, d, ei, norm, x, G = _problem(world)
+    a, b = _convs(d)
+    imp = torch.nn.Parameter(torch.linspace(0.5, 1.5, ei.shape[1])) if mask else None
+    nrm = imp * norm if mask else norm
+    xr = x.clone().requires_grad_(True)
+    h = F.relu(a.f_enc(xr))
+    e = F.relu(a.f_dec(_oracle_aggregate(h, (ei, n_e), nrm, aggr)))
+    g = F.relu(b.f_enc(e))
+    v = F.relu(b.f_dec(_oracle_aggregate(g, (torch.stack([ei[1], ei[0]]), n_v), nrm, aggr)))
+    (v * G).sum().backward()
+    ref_pg = [p.grad for p in list(a.parameters()) + list(b.parameters())] + ([imp.grad] if mask else [])
+    out = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    gx = torch.cat([torch.from_numpy(r[2]) for r in results])[:n_v]
+    torch.testing.assert_close(out, v.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, xr.grad, rtol=1e-5, atol=1e-5)
+    for got, exp in zip(results[0][3], ref_pg):
+        torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=1e-5)
+    for r in results[1:]:
+        for got, got0 in zip(r[3], results[0][3]):
+            np.testing.assert_array_equal(got, got0)
+
+
+@pytest.mark.parametrize("world,H", [(4, 4), (8, 4), (8, 1)])      # 2 / 1 whole heads per column rank; one head shared by all four
+def test_hybrid_pma_layer_equals_unsharded(world, H):
+    import torch.nn.functional as F
+    results = _run_hybrid(world, "pma", H)
+    n_v, n_e, d, ei, _, x, G = _problem(world)
+    a, b = _pma_convs(d, H)
+
+    def pma_module(p, xin, e_idx, n_dst):
+        C = p.hidden
+        o = TorchPmaKernels.aggregate(p.lin_V(xin), p._logits(xin), (e_idx, n_dst), H, 0.2)
+        o = (o.view(-1, H, C) + p.att_r).view(-1, H * C)
+        o = p.ln0(o)
+        return p.ln1(o + F.relu(p.rFF(o)))
+
+    xr = x.clone().requires_grad_(True)
+    e = F.relu(pma_module(a.prop, xr, ei, n_e))
+    v = F.relu(pma_module(b.prop, e, torch.stack([ei[1], ei[0]]), n_v))
+    (v * G).sum().backward()
+    ref_pg = [p.grad for p in list(a.parameters()) + list(b.parameters())]
+    out = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    gx = torch.cat([torch.from_numpy(r[2]) for r in results])[:n_v]
+    torch.testing.assert_close(out, v.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, xr.grad, rtol=1e-4, atol=1e-5)
+    for got, exp in zip(results[0][3], ref_pg):
+        torch.testing.assert_close(torch.from_numpy(got), exp, rtol=1e-4, atol=2e-5)
+
+
 def test_head_slots_and_exchange_volume():
     from allset_amd import dist as adist
     assert adist.head_slots(4, 2) == (2, [0, 1, 2, 3])

@@ -543,7 +543,8 @@ def test_arithmetic_mode_api(device):
         dense.set_arithmetic("fp8")
     lib = _lib.load()
     assert lib.allset_fused_linear_arith_supported(0, 128, 128, 1, 0, _lib.ARITH_FP16X3) == 1
-    assert lib.allset_fused_linear_arith_supported(0, 128, 128, 0, 0, _lib.ARITH_FP16X3) == 0     # forward: LayerNorm prologue only
+    assert lib.allset_fused_linear_arith_supported(0, 128, 128, 0, 0, _lib.ARITH_FP16X3) == 1     # forward without a norm: a scale per row
+    assert lib.allset_fused_linear_arith_supported(0, 128, 128, 1, 1, _lib.ARITH_FP16X3) == 0     # forward, column-affine prologue: no bound
     assert lib.allset_fused_linear_arith_supported(1, 128, 128, 0, 0, _lib.ARITH_FP16X3) == 1
     assert lib.allset_fused_linear_arith_supported(1, 64, 128, 1, 0, _lib.ARITH_FP16X3) == 0
     assert lib.allset_fused_linear_arith_supported(1, 64, 128, 1, 0, _lib.ARITH_BF16X6) == 1
@@ -554,10 +555,109 @@ def test_arithmetic_mode_api(device):
     args = lambda arith: (P(x), 128, 0, None, None, 1e-5, 0, 0, 0.0, 0, P(W), None, 0, 0.0, 0, P(y), 128, 0, None, 64, 128, 128, None, None,
                           None, None, None, arith, None)
     assert lib.allset_fused_linear_fwd_ex(*args(7)) == -1 and b"arith" in lib.allset_last_error()
-    assert lib.allset_fused_linear_fwd_ex(*args(_lib.ARITH_FP16X3)) == -3            # no LayerNorm prologue: not built
-    assert lib.allset_fused_linear_fwd_ex(*args(_lib.ARITH_BF16X6)) == 0
-    torch.cuda.synchronize()
-    torch.testing.assert_close(y, x @ W.t(), rtol=1e-4, atol=1e-4)
+    a4 = torch.empty(64, 4, device=device)
+    w4 = torch.randn(4, 128, device=device)
+    aux = list(args(_lib.ARITH_FP16X3))
+    aux[24], aux[26] = P(w4), P(a4)                                                  # auxiliary output columns: bf16x6 kernels only
+    assert lib.allset_fused_linear_fwd_ex(*aux) == -3
+    for code in (_lib.ARITH_FP16X3, _lib.ARITH_BF16X6):
+        assert lib.allset_fused_linear_fwd_ex(*args(code)) == 0
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y, x @ W.t(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [1, 33, 4099, 70001])
+@pytest.mark.parametrize("relu_post,p", [(False, 0.0), (True, 0.0), (True, 0.5), (True, 0.3)])
+def test_pma_tail_two_kernel_forward_against_float64(n, relu_post, p, device, monkeypatch):
+    """``dense.pma_tail``: ln1(out + relu(rFF(out))), out = ln0(pooled + att_r) (reference layers.py:153-157) with ln0 as the
+    prologue of rFF's first Linear and the residual add + ln1 (+ the conv's relu -> dropout) as the epilogue of its second
+    (csrc/fused_fwd2.hip modes 1 / 2, row-scaled fp16x3 in the second).  Output and every gradient against float64 torch with the
+    kernel's own dropout mask; the same inputs through the unfused chain (ln_res kernels + plain Linears) agree too."""
+    from allset_amd import dense
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7 * n + int(relu_post))
+    mk = lambda *s, sc=1.0, off=0.0: (torch.randn(*s, generator=g) * sc + off).to(device).requires_grad_(True)
+    pooled = mk(n, 128, sc=2.0)
+    att = mk(1, 4, 32, sc=0.5)
+    g0, b0, g1, b1n = mk(128, sc=0.2, off=1.0), mk(128, sc=0.3), mk(128, sc=0.2, off=1.0), mk(128, sc=0.3)
+    w1, w2 = mk(128, 128, sc=128 ** -0.5), mk(128, 128, sc=128 ** -0.5)
+    bb1, bb2 = mk(128, sc=0.1), mk(128, sc=0.1)
+    if n > 64:       # ~10^7 relu inputs: keep them away from the kink (tests/cases.py kinkfree_biases has the reasoning)
+        sign = torch.where(torch.arange(128) % 2 == 0, 5.0, -5.0).to(device)
+        with torch.no_grad():
+            bb1 += sign; bb2 += sign; b1n += 2 * sign
+    G = torch.randn(n, 128, generator=g).to(device)
+    params = [pooled, att, g0, b0, w1, bb1, w2, bb2, g1, b1n]
+    seeds = []
+    real_draw = dense._draw_seed
+    monkeypatch.setattr(dense, "_draw_seed", lambda: seeds.append(real_draw()) or seeds[-1])
+    y = dense.pma_tail(pooled, att, g0, b0, 1e-5, w1, bb1, w2, bb2, g1, b1n, 1e-5, relu_post, p)
+    (y * G).sum().backward()
+    got = [t.grad.clone() for t in params]
+    keep = None
+    if p > 0:
+        keep = dense.dropout_scale((n, 128), p, seeds[0], device).double()          # 1 / (1 - p) or 0 per element, same hash
+    pd = [t.detach().double().requires_grad_(True) for t in params]
+    P, A, G0, B0, W1, BB1, W2, BB2, G1, B1 = pd
+    out = F.layer_norm(P + A.reshape(1, -1), (128,), G0, B0, 1e-5)
+    z = F.relu(F.linear(F.relu(F.linear(out, W1, BB1)), W2, BB2))
+    ref = F.layer_norm(out + z, (128,), G1, B1, 1e-5)
+    if relu_post:
+        ref = F.relu(ref)
+    if keep is not None:
+        ref = ref * keep
+    (ref * G.double()).sum().backward()
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    names = ["pooled", "att_r", "ln0.w", "ln0.b", "w1", "b1", "w2", "b2", "ln1.w", "ln1.b"]
+    for nm, a, b in zip(names, got, pd):
+        scale = max(float(b.grad.abs().max()), 1e-6)
+        assert float((a.double() - b.grad).abs().max()) <= (1e-4 if n > 64 else 3e-5) * scale, (nm, float((a.double() - b.grad).abs().max()), scale)
+    if p == 0.0:      # the unfused chain (strict arithmetic keeps it): same numbers up to fp32 rounding
+        for t in params:
+            t.grad = None
+        with dense.arithmetic("strict"):
+            assert not dense.pma_tail_supported(pooled, 128, w1, w2)
+            o2 = dense.layer_norm_res(pooled, att.reshape(-1), None, g0, b0, 1e-5)
+            y2 = dense.pma_residual_ff(o2, w1, bb1, w2, bb2, g1, b1n, 1e-5, relu_post, 0.0)
+        torch.testing.assert_close(y, y2, rtol=1e-4, atol=2e-5 * max(1.0, float(y2.abs().max())))
+
+
+@pytest.mark.parametrize("n", [1, 33, 4099, 70001])
+@pytest.mark.parametrize("kind", ["plain", "relu", "row_scales", "zero_rows", "w_column_scales"])
+def test_fused_linear_forward_row_scaled_fp16x3_against_float64(n, kind, device):
+    """The 128 x 128 forward WITHOUT a LayerNorm prologue on two fp16 planes (round 5): the window of a row comes from its own largest
+    element, undone per row in the epilogue.  Against float64 in units of sum |terms|, rows spread over 60 binary orders, all-zero rows,
+    W columns over 24 orders: within 3x of torch's fp32 addmm; the strict mode on the same data likewise."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(13 * n + len(kind))
+    x = torch.randn(n, 128, generator=g)
+    W = torch.randn(128, 128, generator=g) / 128 ** 0.5
+    b = torch.randn(128, generator=g)
+    relu = kind == "relu"
+    if kind == "row_scales":
+        x = x * torch.exp2(torch.randint(-30, 31, (n, 1), generator=g).float())
+        b = b * 0
+    elif kind == "zero_rows":
+        x[::3] = 0
+    elif kind == "w_column_scales":
+        W = W * torch.exp2(torch.randint(-12, 13, (1, 128), generator=g).float())
+    x, W, b = x.to(device), W.to(device), b.to(device)
+    xd = torch.relu(x.double()) if relu else x.double()
+    ref = xd @ W.double().t() + b.double()
+    den = xd.abs() @ W.double().abs().t() + b.double().abs() + 1e-300
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        yt = torch.addmm(b, torch.relu(x) if relu else x, W.t())
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    e_t = float(((yt.double() - ref).abs() / den).max())
+    for mode in ("auto", "strict"):
+        with dense.arithmetic(mode):
+            y, _ = dense.fused_linear_fwd(x, W, b, relu_in=relu)
+        assert torch.isfinite(y).all()
+        e_k = float(((y.double() - ref).abs() / den).max())
+        assert e_k < max(2e-6, 3.0 * e_t), (mode, e_k, e_t)
 
 
 @pytest.mark.parametrize("N", [64, 128])

@@ -4,7 +4,9 @@
 (all-gather -> tile the owned block N times, reduce-scatter -> keep the owned slice).  What is left out is exactly the
 xGMI time; the output bounds the scaling the driver can measure:  efficiency <= t(1) / (t_compute(N) + t_comm(N)).
 
-usage: sim_rank.py [deepsets|pma] [rows|columns]
+usage: sim_rank.py [deepsets|pma] [rows|columns|hybrid]
+``hybrid`` (round 5): the 2 x (N / 2) hybrid partition (dist.ColumnShardedHypergraph(row_groups=2)): rank 0 holds the incidences of
+target group 0 and gathers rows of d / (N / 2) columns; its world all-to-all is replaced by a stand-in of the same shapes.
 ``columns``: the column-sharded layer (full incidence on the rank, d/N columns); the all-to-alls are replaced by their
 own pack / unpack copies, which produce tensors of exactly the exchanged shapes.
 The xGMI estimate printed beside it is per LINK: every pair of GPUs is joined by one link (~77 GB/s per direction peak,
@@ -59,7 +61,25 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     adist._all_to_all_rows = (lambda send, ins, outs, group=None: send[:sum(outs)] if send.shape[0] >= sum(outs) else
                               torch.cat([send, send.new_zeros((sum(outs) - send.shape[0],) + tuple(send.shape[1:]))]))
     n_v = n_loc * world
-    if mode == "columns":
+    if mode == "hybrid":
+        if world < 4:
+            continue
+        R, C = 2, world // 2
+        adist._world = lambda group=None, w=world, C=C: C if group == "COL" else w
+        adist._skip_collective = lambda group=None: False
+
+        def _a2a_single(recv, send, group=None):       # moves nothing (timing only); the head of the buffer zeroed against stale NaNs
+            recv[:max(recv.shape[0] // 64, 1)].zero_()
+        adist._all_to_all_single = _a2a_single
+        adist._rows_to_cols = (lambda x, group=None, C=C: adist._pack(x, C).view(C * x.shape[0], x.shape[1] // C))
+        adist._cols_to_rows = (lambda x, group=None, C=C: adist._unpack(x.view(C, x.shape[0] // C, x.shape[1])))
+        blocks = [random_hypergraph(n_v, n_loc, 16, seed=5 + r, device=dev, e_offset=r * n_loc, dist=DIST) for r in range(world)]
+        ei = torch.cat([b.edge_index for b in blocks], dim=1)
+        shard = blocks[0]
+        hg = adist.ColumnShardedHypergraph(ei, n_v, n_loc * world, world, 0, norm=torch.cat([b.norm for b in blocks]), row_groups=R,
+                                           col_group="COL").build_incidences()
+        del blocks, ei
+    elif mode == "columns":
         blocks = [random_hypergraph(n_v, n_loc, 16, seed=5 + r, device=dev, e_offset=r * n_loc, dist=DIST) for r in range(world)]
         ei = torch.cat([b.edge_index for b in blocks], dim=1)
         shard = blocks[0]
@@ -79,7 +99,7 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
     G = torch.randn(n_loc, d, device=dev).to(DT)
     def step():
         opt.zero_grad(set_to_none=True); x.grad = None
-        if mode == "columns":
+        if mode in ("columns", "hybrid"):
             out = adist.colsharded_pma_layer(a, b, x, hg, dropout=0.5, training=True, chunks=CHUNKS) if attn else \
                 adist.colsharded_deepsets_layer(a, b, x, hg, aggr="add", dropout=0.5, training=True, chunks=CHUNKS)
         else:
@@ -105,11 +125,12 @@ for world in tuple(int(w) for w in os.environ.get("SIM_WORLDS", "1,2,4,8").split
             print(f"      {k:22s} {v['calls'] / 10:5.1f} calls/step  {v['avg_ms']:7.3f} ms avg  {v['total_ms'] / 10:7.3f} ms/step")
     if world == 1 or "t1" not in globals():
         t1 = ms if world == 1 else float(os.environ.get("SIM_T1_MS", "nan"))
-    per_rank = adist.exchange_bytes_per_rank(mode, world, n_v, n_loc * world, d, 2 if DT == torch.bfloat16 else 4)     # received per step (fwd + bwd)
+    mname = f"hybrid2x{world // 2}" if mode == "hybrid" else mode
+    per_rank = adist.exchange_bytes_per_rank(mname, world, n_v, n_loc * world, d, 2 if DT == torch.bfloat16 else 4)     # received per step (fwd + bwd)
     if mode == "rows" and getattr(hg, "halo", None) is not None:
         per_rank = 4 * hg.halo.exchange_rows() * d * (2 if DT == torch.bfloat16 else 4)       # four exchanges of the asked-for rows per step
         print(f"      halo: {hg.halo.n_needed} of {n_v} vertices touched, {hg.halo.exchange_rows()} rows from peers per exchange (locality {LOCALITY:g})")
-    per_link = per_rank / max(world - 1, 1)
+    per_link = adist.exchange_bytes_per_link(mname, world, n_v, n_loc * world, d, 2 if DT == torch.bfloat16 else 4) if world > 1 else 0
     comm = per_link / LINK * 1e3
     print(f"{model} {mode}{f' chunks={CHUNKS}' if CHUNKS > 1 else ''} world={world}: per-rank compute {ms:7.2f} ms   exchange {per_rank/1e9:5.2f} GB per rank and step, "
           f"{per_link/1e9:4.2f} GB per link -> {comm:5.1f} ms at 60 GB/s   speed-up if serial {world*t1/(ms+comm) if world > 1 else 1.0:4.2f}x, "
