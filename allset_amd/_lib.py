@@ -132,6 +132,12 @@ SIGNATURES = {
     "allset_gemm_x6": [_P, c_int64, _P, c_int64, c_float, c_int, _P, _P, _P, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                        _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_x6_lnb_partials": [c_int64],
+    "allset_gemm_f16x3_plane_bytes": [c_int64, c_int64],
+    "allset_gemm_f16x3_planes": [_P, c_int64, c_int, _P, c_int64, c_int64, _P],
+    "allset_gemm_f16x3": [_P, c_int64, _P, c_int64, c_float, c_int, _P, _P, _P, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
+                          _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
+    "allset_gemm_f16x3_lnb": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P,
+                              c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_x6_lnb": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P,
                            c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_block_transpose": [_P, _P, c_int64, c_int64, c_int64, c_int64, c_int, _P],
@@ -200,6 +206,7 @@ def load() -> ctypes.CDLL:
         fn.restype = c_int
     lib.allset_fused_linear_mask_words.restype = c_int64
     lib.allset_gemm_x6_plane_bytes.restype = c_int64
+    lib.allset_gemm_f16x3_plane_bytes.restype = c_int64
     lib.allset_gemm_x6_lnb_partials.restype = c_int64
     lib.allset_input_linear_k.restype = c_int64
     lib.allset_last_error.argtypes = []

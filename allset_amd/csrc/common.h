@@ -84,6 +84,17 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {   // {bf16
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+// x0, x1 -> packed fp16 planes {hi half: x1, lo half: x0}: h = RN16(x), l = RN16(x - h) (x - h is exact in fp32; fp16 denormals are
+// produced and the f16 MFMA honours them) -- "fp16x3": (x s)(w t) = h h' + h l' + l h' + (l l' <= 2^-22, dropped); the operands must have
+// been scaled into fp16's window by a power of two (csrc/fused_bwd6.hip has the scheme and its error model)
+__device__ __forceinline__ void split2_f16c(float x0, float x1, uint32_t& ph, uint32_t& pl) {
+  float r0, r1;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph) : "v"(x0), "v"(x1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl) : "v"(r0), "v"(r1));
+}
+
 __device__ __forceinline__ void split3_bf16(float x0, float x1, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
   ph = cvt_pk_bf16(x0, x1);
   const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);

@@ -30,9 +30,10 @@ union GxFrag { uint4 u; bf16x8_t v; };
 // Where dword `at` of a K step's LDS slab of B (3 planes x 256 n x 32 k bf16 = 3072 pieces of 16 bytes; thread t of the
 // 512 copies pieces t, t + 512, ..., t + 2560) sits in the global image: the six pieces of one WAVE are adjacent (6 x 1 KB),
 // so one 64-bit address per K step reaches all six through the +-4 KB immediate of global_load, each load still 1 KB contiguous.
-__device__ __forceinline__ int gx_image_at(int at) {
+template <int NPC = 6>       // pieces a thread copies per K step: 6 (three bf16 planes) or 4 (two fp16 planes)
+__host__ __device__ __forceinline__ int gx_image_at(int at) {
   const int j = at >> 2, piece = j >> 9, t = j & 511;
-  return (((t >> 6) * 6 + piece) * 64 + (t & 63)) * 4 + (at & 3);
+  return (((t >> 6) * NPC + piece) * 64 + (t & 63)) * 4 + (at & 3);
 }
 
 // ---- weight planes: [n_tile][k_step] slabs of [plane][256 n][32 k] bf16 (zero-padded in n), pieces permuted by gx_image_at ------------------------------------------
@@ -57,6 +58,48 @@ __global__ __launch_bounds__(kBlock) void gemm_x6_planes_kernel(const float* __r
     planes[image + gx_image_at(at)] = ph;
     planes[image + gx_image_at(at + kGxBN * kGxKS / 2)] = pm;
     planes[image + gx_image_at(at + 2 * (kGxBN * kGxKS / 2))] = pl;
+  }
+}
+
+// ---- the same weight in TWO fp16 planes ("fp16x3", common.h split2_f16c) -----------------------------------------------------------
+// Row n of B is scaled by 2^(140 - e_n), e_n = the biased exponent of its largest element (so that it lands in [2^13, 2^14)); the
+// inverse 2^(e_n - 140) per output column is stored behind the planes (float[n_pad]) and applied in the GEMM's epilogue.
+__global__ __launch_bounds__(kBlock) void gemm_f16_bscale_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
+                                                                 float* __restrict__ bscale, int N, int n_pad, int K) {
+  const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= n_pad) return;
+  float amax = 0.f;
+  if (n < N)
+    for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(transpose ? W[static_cast<int64_t>(k) * ldw + n] : W[static_cast<int64_t>(n) * ldw + k]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  const int e = min(max(static_cast<int>(__float_as_uint(amax) >> 23), 20), 254);
+  if (lane == 0) bscale[n] = __uint_as_float(static_cast<uint32_t>(e - 13) << 23);        // 2^(e - 140)
+}
+
+__global__ __launch_bounds__(kBlock) void gemm_f16_planes_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
+                                                                 uint32_t* __restrict__ planes, const float* __restrict__ bscale,
+                                                                 int N, int K) {
+  const int n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
+  const int64_t pairs = static_cast<int64_t>(n_pad) * (K / 2);
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < pairs;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int n = static_cast<int>(idx / (K / 2));
+    const int k = 2 * static_cast<int>(idx - static_cast<int64_t>(n) * (K / 2));
+    float w0 = 0.f, w1 = 0.f;
+    if (n < N) {
+      if (transpose) { w0 = W[static_cast<int64_t>(k) * ldw + n]; w1 = W[static_cast<int64_t>(k + 1) * ldw + n]; }
+      else { w0 = W[static_cast<int64_t>(n) * ldw + k]; w1 = W[static_cast<int64_t>(n) * ldw + k + 1]; }
+    }
+    const int e = static_cast<int>(__float_as_uint(bscale[n]) >> 23) + 13;                  // bscale[n] = 2^(e - 140)
+    const float sc = __uint_as_float(static_cast<uint32_t>(267 - e) << 23);                 // 2^(140 - e): field 13 .. 247
+    uint32_t ph, pl;
+    split2_f16c(w0 * sc, w1 * sc, ph, pl);
+    const int nt = n / kGxBN, nn = n % kGxBN, ks = k / kGxKS, kk = k % kGxKS;
+    const int64_t image = (static_cast<int64_t>(nt) * (K / kGxKS) + ks) * 2 * (kGxBN * kGxKS / 2);   // dwords
+    const int at = nn * (kGxKS / 2) + (((kk >> 3) ^ gx_swz(nn)) << 2) + ((kk & 7) >> 1);
+    planes[image + gx_image_at<4>(at)] = ph;
+    planes[image + gx_image_at<4>(at + kGxBN * kGxKS / 2)] = pl;
   }
 }
 
@@ -96,21 +139,35 @@ struct GxRow {
   const float* y;          // mask source, or NULL
   int64_t g_row;
   float mean, rstd;
-  bool ok;
+  float asc;               // fp16x3 without a LayerNorm prologue: the power of two this row's A elements are scaled by (its inverse goes
+  bool ok;                 // to sRowInv for the epilogue)
 };
+using f16x8_t = __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16;
+union GxFragH { uint4 u; f16x8_t v; };
 
-template <bool HAS_Y, bool LNB>
+// F16 (round 5, "fp16x3"): two fp16 planes per operand and three MFMAs per product instead of three bf16 planes and six -- half the
+// matrix work of a kernel whose matrix pipe is its critical resource.  fp16's five exponent bits need every operand
+// inside a window: B per output column (gemm_f16_planes_kernel; inverse scales `bscale`), A behind a LayerNorm-apply prologue by ONE
+// power of two for the launch (|u| <= (sqrt(K - 1) max|gamma| + max|beta|) keep -- folded into the LDS copy of gamma / beta, no
+// instruction), any other A per ROW: the row's largest element to [2^13, 2^14).  That row maximum needs the whole row before its
+// first K step: every thread reads, one TILE ahead, the segments it will stage for the next tile (same addresses: the second read
+// is an L2 / Infinity Cache hit, HBM traffic unchanged) and folds their maximum; the four threads of a row combine by two shuffles
+// when the tile changes.  The mask / relu of the prologue only shrink elements: the unmasked maximum is a valid bound.
+template <bool HAS_Y, bool LNB, bool F16 = false>
 __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const float* __restrict__ A, int64_t lda, GxPro pro, const uint4* __restrict__ planes, GxEpi epi,
-    float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base) {
-  // one arena: A slabs [buffer][plane][row][32 bf16 = 4 x 16 B], B slabs likewise, and -- after the K loop -- the fp32
+    float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base,
+    const float* __restrict__ bscale = nullptr) {
+  // one arena: A slabs [buffer][plane][row][32 x 16 bit = 4 x 16 B], B slabs likewise, and -- after the K loop -- the fp32
   // output tile on its way from the MFMA layout to row-major 16-byte stores
-  constexpr int kASlab = 3 * kGxBM * 4, kBSlab = 3 * kGxBN * 4, kOutPitch = kGxBN + 4;
-  __shared__ __attribute__((aligned(16))) uint4 smem[2 * kASlab + 2 * kBSlab];
+  constexpr int NP = F16 ? 2 : 3, NPC = 2 * NP;
+  constexpr int kASlab = NP * kGxBM * 4, kBSlab = NP * kGxBN * 4, kOutPitch = kGxBN + 4;
+  constexpr int kSlabs = 2 * kASlab + 2 * kBSlab, kTile16 = (kGxBM * kOutPitch * 4 + 15) / 16;
+  __shared__ __attribute__((aligned(16))) uint4 smem[kSlabs > kTile16 ? kSlabs : kTile16];
+  __shared__ float sRowInv[F16 ? kGxBM : 1];          // fp16x3: what undoes the row's (or the launch's) A scale in the epilogue
   // gamma / beta of the LayerNorm-apply prologue, once per workgroup: fetched from global memory inside the staging path
   // they would sit behind an s_waitcnt vmcnt(0) -- which also drains the prefetch of the next A / B slabs -- four times a step
   __shared__ __attribute__((aligned(16))) float sGB[2 * 512];
-  static_assert(sizeof(float) * kGxBM * kOutPitch <= sizeof(uint4) * (2 * kASlab + 2 * kBSlab), "output tile must fit the arena");
   uint4 (*sA)[kASlab] = reinterpret_cast<uint4 (*)[kASlab]>(smem);
   uint4 (*sB)[kBSlab] = reinterpret_cast<uint4 (*)[kBSlab]>(smem + 2 * kASlab);
   float* sOut = reinterpret_cast<float*>(smem);
@@ -128,7 +185,8 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   // ---- staging roles
   const int s_row = tid >> 2, s_seg = tid & 3;
   const int a_st = s_row * 4 + (s_seg ^ gx_swz(s_row));                 // swizzled 16-byte piece (gx_swz)
-  const int b_img = (tid >> 6) * 384 + (tid & 63) + 192;               // gx_image_at: this wave's six pieces, from the middle
+  const int b_img = (tid >> 6) * (64 * NPC) + (tid & 63) + 32 * NPC;   // gx_image_at: this wave's NPC pieces, from the middle
+  const bool rowsc = F16 && pro.stats == nullptr;                      // A scaled per row (no LayerNorm bound)
   auto row_ctx = [&](int64_t tile) {
     GxRow c;
     const int64_t row0 = tile / n_tiles * kGxBM;
@@ -137,15 +195,28 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const int64_t cr = c.ok ? c.g_row : rows - 1;
     c.a = A + cr * lda + s_seg * 8;
     c.y = pro.y ? pro.y + cr * pro.ldy + s_seg * 8 : nullptr;
-    c.mean = 0.f; c.rstd = 1.f;
+    c.mean = 0.f; c.rstd = 1.f; c.asc = 1.f;
     if (pro.stats) { c.mean = pro.stats[cr * 2]; c.rstd = pro.stats[cr * 2 + 1]; }
     return c;
+  };
+  // fp16x3, per-row window: the scale from the maximum of |A[row, :]| gathered by the row's four threads
+  auto row_scale = [&](float amax) -> float {
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const int e = min(max(static_cast<int>(__float_as_uint(amax * inv_mask * inv_in) >> 23), 20), 254);
+    return __uint_as_float(static_cast<uint32_t>(267 - e) << 23);      // 2^(140 - e): the largest element -> [2^13, 2^14)
+  };
+  auto amax8 = [](float4 a, float4 b, float m) -> float {
+    return fmaxf(fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                       fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))), m);
   };
 
   // One K step ahead of the MFMAs, in named registers -- not arrays: hipcc keeps indexed staging arrays in scratch, and a
   // scratch store right behind the global load is a full wait, exactly the latency the prefetch hides.
   float4 pa0, pa1, py0 = make_float4(1.f, 1.f, 1.f, 1.f), py1 = py0;
   uint4 pb0, pb1, pb2, pb3, pb4, pb5;
+  float4 la0 = make_float4(0.f, 0.f, 0.f, 0.f), la1 = la0;            // fp16x3 per-row window: the next tile's segments, one tile ahead
+  float nmax = 0.f;
 #define GX_LOAD(ctx_, img_base_, ks_)                                                           \
   do {                                                                                          \
     const int k0_ = (ks_) * kGxKS;                                                              \
@@ -156,8 +227,12 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       py1 = *reinterpret_cast<const float4*>((ctx_).y + k0_ + 4);                               \
     }                                                                                           \
     const uint4* img_ = (img_base_) + static_cast<int64_t>(ks_) * kBSlab + b_img;               \
-    pb0 = img_[-192]; pb1 = img_[-128]; pb2 = img_[-64];                                        \
-    pb3 = img_[0]; pb4 = img_[64]; pb5 = img_[128];                                             \
+    if constexpr (F16) {                                                                        \
+      pb0 = img_[-128]; pb1 = img_[-64]; pb2 = img_[0]; pb3 = img_[64];                         \
+    } else {                                                                                    \
+      pb0 = img_[-192]; pb1 = img_[-128]; pb2 = img_[-64];                                      \
+      pb3 = img_[0]; pb4 = img_[64]; pb5 = img_[128];                                           \
+    }                                                                                           \
   } while (0)
 
   auto prologue2 = [&](const GxRow& c, float a0, float a1, float y0, float y1, int kk, float& o0, float& o1) {
@@ -185,16 +260,28 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     prologue2(ctx_, pa1.x, pa1.y, py1.x, py1.y, kb_ + 4, e4, e5);                               \
     prologue2(ctx_, pa1.z, pa1.w, py1.z, py1.w, kb_ + 6, e6, e7);                               \
     uint4 h_, m_, l_;                                                                           \
-    split3_bf16(e0, e1, h_.x, m_.x, l_.x);                                                      \
-    split3_bf16(e2, e3, h_.y, m_.y, l_.y);                                                      \
-    split3_bf16(e4, e5, h_.z, m_.z, l_.z);                                                      \
-    split3_bf16(e6, e7, h_.w, m_.w, l_.w);                                                      \
-    sA[buf_][a_st] = h_;                                                                        \
-    sA[buf_][kGxBM * 4 + a_st] = m_;                                                            \
-    sA[buf_][2 * kGxBM * 4 + a_st] = l_;                                                        \
-    sB[buf_][tid] = pb0; sB[buf_][tid + kGxThreads] = pb1; sB[buf_][tid + 2 * kGxThreads] = pb2; \
-    sB[buf_][tid + 3 * kGxThreads] = pb3; sB[buf_][tid + 4 * kGxThreads] = pb4;                 \
-    sB[buf_][tid + 5 * kGxThreads] = pb5;                                                       \
+    if constexpr (F16) {                                                                        \
+      const float sc_ = (ctx_).asc;                                                             \
+      split2_f16c(e0 * sc_, e1 * sc_, h_.x, l_.x);                                              \
+      split2_f16c(e2 * sc_, e3 * sc_, h_.y, l_.y);                                              \
+      split2_f16c(e4 * sc_, e5 * sc_, h_.z, l_.z);                                              \
+      split2_f16c(e6 * sc_, e7 * sc_, h_.w, l_.w);                                              \
+      sA[buf_][a_st] = h_;                                                                      \
+      sA[buf_][kGxBM * 4 + a_st] = l_;                                                          \
+      sB[buf_][tid] = pb0; sB[buf_][tid + kGxThreads] = pb1; sB[buf_][tid + 2 * kGxThreads] = pb2; \
+      sB[buf_][tid + 3 * kGxThreads] = pb3;                                                     \
+    } else {                                                                                    \
+      split3_bf16(e0, e1, h_.x, m_.x, l_.x);                                                    \
+      split3_bf16(e2, e3, h_.y, m_.y, l_.y);                                                    \
+      split3_bf16(e4, e5, h_.z, m_.z, l_.z);                                                    \
+      split3_bf16(e6, e7, h_.w, m_.w, l_.w);                                                    \
+      sA[buf_][a_st] = h_;                                                                      \
+      sA[buf_][kGxBM * 4 + a_st] = m_;                                                          \
+      sA[buf_][2 * kGxBM * 4 + a_st] = l_;                                                      \
+      sB[buf_][tid] = pb0; sB[buf_][tid + kGxThreads] = pb1; sB[buf_][tid + 2 * kGxThreads] = pb2; \
+      sB[buf_][tid + 3 * kGxThreads] = pb3; sB[buf_][tid + 4 * kGxThreads] = pb4;               \
+      sB[buf_][tid + 5 * kGxThreads] = pb5;                                                     \
+    }                                                                                           \
   } while (0)
 
   // ---- MFMA roles: wave (wr, wc) owns rows wr*64.., columns wc*64.. of the tile as 4 x 4 tiles of 16 x 16
@@ -209,6 +296,27 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   f32x4_t acc[4][4];
 
   auto compute = [&](int buf) {
+    if constexpr (F16) {
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        GxFragH a[2][2];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) a[r2][p].u = sA[buf][p * kGxBM * 4 + a_at + (rh * 2 + r2) * 64];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          GxFragH b[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[p].u = sB[buf][p * kGxBN * 4 + b_at + ct * 64];
+#define GX_MFMAH(PA, PB)                                                                                                  \
+  acc[rh * 2][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][PA].v, b[PB].v, acc[rh * 2][ct], 0, 0, 0);                \
+  acc[rh * 2 + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][PA].v, b[PB].v, acc[rh * 2 + 1][ct], 0, 0, 0)
+          GX_MFMAH(1, 0); GX_MFMAH(0, 1); GX_MFMAH(0, 0);              // l.h, h.l, h.h
+#undef GX_MFMAH
+        }
+      }
+    } else {
 #pragma unroll
     for (int rh = 0; rh < 2; ++rh) {                                   // two row tiles at a time: 24 + 12 fragment registers
       GxFrag a[2][3];
@@ -229,6 +337,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
 #undef GX_MFMA2
       }
     }
+    }
   };
 
   const uint64_t lnb_seed = resolve_seed(seed_base, epi.lnb_seed);
@@ -241,17 +350,43 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       for (int i = threadIdx.x; i < 2 * N; i += kGxThreads) epi.lnb_part[static_cast<int64_t>(blockIdx.x) * 2 * N + i] = 0.f;
     return;
   }
+  float launch_inv = 1.f;                                              // fp16x3 behind a LayerNorm: 2^-Su, undone in the epilogue
   if (pro.stats) {
     for (int i = threadIdx.x; i < K; i += kGxThreads) { sGB[i] = pro.gamma[i]; sGB[512 + i] = pro.beta[i]; }
     __syncthreads();
+    if constexpr (F16) {
+      // |u| <= (sqrt(K - 1) max|gamma| + max|beta|) keep: one power of two 2^Su brings every A element below 2^14
+      float g = 0.f, bm = 0.f;
+      for (int i = lane; i < K; i += 64) { g = fmaxf(g, fabsf(sGB[i])); bm = fmaxf(bm, fabsf(sGB[512 + i])); }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { g = fmaxf(g, __shfl_xor(g, off)); bm = fmaxf(bm, __shfl_xor(bm, off)); }
+      const float U = (sqrtf(static_cast<float>(K)) * g + bm) * inv_in;
+      const int eU = static_cast<int>(__float_as_uint(U) >> 23);       // U < 2^(eU - 126)
+      const int Su = min(max(140 - eU, -100), 100);
+      const float su = __uint_as_float(static_cast<uint32_t>(127 + Su) << 23);
+      launch_inv = __uint_as_float(static_cast<uint32_t>(127 - Su) << 23);
+      __syncthreads();                                                 // (every wave has read the unscaled copy)
+      for (int i = threadIdx.x; i < K; i += kGxThreads) { sGB[i] *= su; sGB[512 + i] *= su; }
+      __syncthreads();
+    }
   }
   GxRow cur = row_ctx(tile);
+  if (rowsc) {                                                         // the first tile's row maxima: once per workgroup, not overlapped
+    float m = 0.f;
+    for (int ks = 0; ks < ksteps; ++ks)
+      m = amax8(*reinterpret_cast<const float4*>(cur.a + ks * kGxKS), *reinterpret_cast<const float4*>(cur.a + ks * kGxKS + 4), m);
+    cur.asc = row_scale(m);
+  }
   const uint4* img_cur = planes + static_cast<int64_t>(tile % n_tiles) * ksteps * kBSlab;
   GX_LOAD(cur, img_cur, 0);
   for (; tile < total; tile += gridDim.x) {
     const int64_t next = tile + gridDim.x;
     const bool has_next = next < total;
-    const GxRow nxt = row_ctx(has_next ? next : tile);                 // (stats of the next tile are in flight early)
+    GxRow nxt = row_ctx(has_next ? next : tile);                       // (stats of the next tile are in flight early)
+    if constexpr (F16) {                                               // what the epilogue multiplies a row of the tile by
+      if (s_seg == 0) sRowInv[s_row] = rowsc ? 1.f / cur.asc : launch_inv;
+      nmax = 0.f;
+    }
     const uint4* img_nxt = planes + static_cast<int64_t>((has_next ? next : tile) % n_tiles) * ksteps * kBSlab;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -269,12 +404,19 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   do {                                                                                          \
     const int ks_ = (KS_);                                                                      \
     const bool last_ = ks_ + 1 == ksteps;                                                       \
+    if constexpr (F16) {                                                                        \
+      if (rowsc && has_next) {        /* one tile ahead: the segments this thread will stage for the next tile */ \
+        la0 = *reinterpret_cast<const float4*>(nxt.a + ks_ * kGxKS);                            \
+        la1 = *reinterpret_cast<const float4*>(nxt.a + ks_ * kGxKS + 4);                        \
+      }                                                                                         \
+    }                                                                                           \
     if (mfma_first) compute(BUF_);                                                              \
     if (!last_) {                                                                               \
       GX_STORE(cur, ks_ + 1, (BUF_) ^ 1);                                                       \
       if (ks_ + 2 < ksteps) GX_LOAD(cur, img_cur, ks_ + 2); else if (has_next) GX_LOAD(nxt, img_nxt, 0); \
     }                                                                                           \
     if (!mfma_first) compute(BUF_);                                                             \
+    if constexpr (F16) { if (rowsc && has_next) nmax = amax8(la0, la1, nmax); }                 \
     /* LDS traffic must have landed; the global loads just issued stay in flight ACROSS the barrier (__syncthreads()   \
        would drain them: s_waitcnt vmcnt(0), one exposed memory latency per step) */                                   \
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
@@ -300,6 +442,8 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const int c4 = (tid & 63) * 4;
     const int n = static_cast<int>(tile % n_tiles) * kGxBN + c4;
     const int64_t row0 = tile / n_tiles * kGxBM;
+    float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);                      // fp16x3: the inverse scales of the lane's four B columns
+    if constexpr (F16) cs4 = *reinterpret_cast<const float4*>(bscale + n);       // (bscale has n_pad entries: always in range)
     if constexpr (LNB) {
       // one wavefront per row (64 lanes x 4 columns = the whole row, N <= 256): the two row sums of the LayerNorm
       // backward are wave reductions; dgamma / dbeta accumulate in registers over all rows this lane ever sees
@@ -313,6 +457,10 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
         float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
         if (act) {
           gv = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
+          if constexpr (F16) {
+            const float ri = sRowInv[rr];
+            gv.x *= ri * cs4.x; gv.y *= ri * cs4.y; gv.z *= ri * cs4.z; gv.w *= ri * cs4.w;
+          }
           xv = *reinterpret_cast<const float4*>(epi.lnb_x + row * epi.lnb_ldx + n);
         }
         const float mean = epi.lnb_stats[row * 2], rstd = epi.lnb_stats[row * 2 + 1];
@@ -351,7 +499,12 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
         const int64_t row = row0 + rr;
         if (row >= rows) break;
         float4 v = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if constexpr (F16) {
+          const float ri = sRowInv[rr];
+          v.x = fmaf(v.x, ri * cs4.x, bv.x); v.y = fmaf(v.y, ri * cs4.y, bv.y); v.z = fmaf(v.z, ri * cs4.z, bv.z); v.w = fmaf(v.w, ri * cs4.w, bv.w);
+        } else {
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
         if (epi.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (epi.p_out > 0.f) {
           float k0, k1, k2, k3;
@@ -363,6 +516,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       }
     }
     __syncthreads();                                                   // the arena is free again
+    if constexpr (F16) { if (rowsc && has_next) nxt.asc = row_scale(nmax); }
     cur = nxt;
     img_cur = img_nxt;
   }
@@ -462,7 +616,62 @@ extern "C" int allset_row_stats(const float* x, int64_t ldx, int relu_in, float 
 static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                         const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                         const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
-                        const uint64_t* seed_base, void* stream);
+                        const uint64_t* seed_base, void* stream, bool f16 = false);
+
+// ---- the fp16x3 family: same contracts, the weight in two fp16 planes + per-column inverse scales (allset_gemm_f16x3_planes) ----
+extern "C" int64_t allset_gemm_f16x3_plane_bytes(int64_t N, int64_t K) {
+  if (!allset_gemm_x6_supported(N, K)) return -1;
+  const int64_t n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
+  return n_pad * K * 2 * 2 + n_pad * 4;
+}
+
+extern "C" int allset_gemm_f16x3_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream) {
+  clear_error();
+  if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_f16x3_planes: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(W && planes && aligned16(planes), "gemm_f16x3_planes: null / misaligned pointer");
+  ALLSET_REQUIRE(ldw >= (transpose ? N : K), "gemm_f16x3_planes: leading dimension too small");
+  const int64_t n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
+  float* bscale = reinterpret_cast<float*>(static_cast<char*>(planes) + n_pad * K * 2 * 2);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  gemm_f16_bscale_kernel<<<static_cast<unsigned>((n_pad + kBlock / 64 - 1) / (kBlock / 64)), kBlock, 0, st>>>(
+      W, ldw, transpose, bscale, static_cast<int>(N), static_cast<int>(n_pad), static_cast<int>(K));
+  const int64_t pairs = n_pad * (K / 2);
+  const int64_t want = (pairs + kBlock - 1) / kBlock;
+  gemm_f16_planes_kernel<<<static_cast<unsigned>(want > 4096 ? 4096 : want), kBlock, 0, st>>>(
+      W, ldw, transpose, static_cast<uint32_t*>(planes), bscale, static_cast<int>(N), static_cast<int>(K));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_gemm_f16x3_lnb(const float* G, int64_t ldg, const float* mask_y, int64_t ldy, float p_mask, const void* planes,
+                                     const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p,
+                                     uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows,
+                                     int64_t N, int64_t K, const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(N >= 4 && N <= kGxBN, "gemm_f16x3_lnb: the LayerNorm row (N) must fit one 256-column tile");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "gemm_f16x3_lnb: dropout p must be in [0,1)");
+  ALLSET_REQUIRE(partials != nullptr && n_partials == allset_gemm_x6_lnb_partials(rows), "gemm_f16x3_lnb: partials must hold allset_gemm_x6_lnb_partials(rows) x 2 x N floats");
+  if (rows == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * N * sizeof(float), static_cast<hipStream_t>(stream)));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(x && stats && gamma && gx, "gemm_f16x3_lnb: null pointer");
+  ALLSET_REQUIRE(ldx >= N && ldx % 4 == 0 && aligned16(x) && aligned16(gamma), "gemm_f16x3_lnb: x rows / gamma must be 16-byte aligned");
+  GxEpi epi{nullptr, 0, 0.f, 0, x, ldx, stats, gamma, relu_in, p, seed, partials};
+  return gemm_x6_impl(G, ldg, mask_y, ldy, p_mask, 0, nullptr, nullptr, nullptr, 0.f, 0, planes, epi, gx, ldgx, rows, N, K, seed_base, stream, true);
+}
+
+extern "C" int allset_gemm_f16x3(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
+                                 const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                                 const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
+                                 float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base,
+                                 void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "gemm_f16x3: dropout p must be in [0,1)");
+  GxEpi epi{bias, relu_out, p_out, seed_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
+  ALLSET_REQUIRE(bias == nullptr || aligned16(bias), "gemm_f16x3: bias must be 16-byte aligned");
+  return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base, stream, true);
+}
 
 extern "C" int64_t allset_gemm_x6_lnb_partials(int64_t rows) {
   const int64_t tiles = (rows + kGxBM - 1) / kGxBM;
@@ -502,7 +711,7 @@ extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, 
 static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                         const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                         const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
-                        const uint64_t* seed_base, void* stream) {
+                        const uint64_t* seed_base, void* stream, bool f16) {
   if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_x6: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(rows >= 0, "gemm_x6: bad row count");
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_mask >= 0.f && p_mask < 1.f, "gemm_x6: dropout p must be in [0,1)");
@@ -515,10 +724,14 @@ static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_
   GxPro pro{mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in};
   const int64_t tiles = (rows + kGxBM - 1) / kGxBM * ((N + kGxBN - 1) / kGxBN);
   const int64_t blocks = tiles < 256 ? tiles : 256;                     // one workgroup per CU (144 KB of LDS), walking its tiles
-#define GX_LAUNCH(Y, L) gemm_x6_kernel<Y, L><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>( \
-      A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base)
-  if (epi.lnb_x != nullptr) { if (mask_y) GX_LAUNCH(true, true); else GX_LAUNCH(false, true); }
-  else { if (mask_y) GX_LAUNCH(true, false); else GX_LAUNCH(false, false); }
+  const int64_t n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
+  const float* bscale = f16 ? reinterpret_cast<const float*>(static_cast<const char*>(planes) + n_pad * K * 2 * 2) : nullptr;
+#define GX_LAUNCH(Y, L, H) gemm_x6_kernel<Y, L, H><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>( \
+      A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base, bscale)
+#define GX_LAUNCH2(Y, L) do { if (f16) GX_LAUNCH(Y, L, true); else GX_LAUNCH(Y, L, false); } while (0)
+  if (epi.lnb_x != nullptr) { if (mask_y) GX_LAUNCH2(true, true); else GX_LAUNCH2(false, true); }
+  else { if (mask_y) GX_LAUNCH2(true, false); else GX_LAUNCH2(false, false); }
+#undef GX_LAUNCH2
 #undef GX_LAUNCH
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;

@@ -349,21 +349,42 @@ def gemm_x6_supported(N: int, K: int) -> bool:
     return bool(_lib.load().allset_gemm_x6_supported(N, K))
 
 
-def gemm_x6_planes(W: Tensor, transpose: bool) -> Tensor:
-    """Pre-split bf16 planes of ``B`` for :func:`gemm_x6`: ``B = W`` ([N, K]) or, with ``transpose``, ``B = W^T``
-    (``W`` [K, N]).  Returns an opaque uint8 buffer."""
+def wide_f16(ln_forward: bool = False) -> bool:
+    """Which arithmetic a tiled wide GEMM (widths 256 / 512) runs in.  ``fp16x3`` mode: two fp16 planes everywhere; ``strict``: the
+    exact bf16x6 split everywhere; ``auto``: fp16x3 only for the FORWARD behind a LayerNorm-apply prologue (``ln_forward``), where
+    it measured 0.81 -> 0.67 ms at [1M, 256] x [256, 256]; the backward-data GEMM with the LayerNorm-backward epilogue measured
+    1.26 -> 1.30 ms (its per-row window costs a second, cache-served read of A; the kernel is bound by load latency at one
+    workgroup per CU, not by the matrix pipe: DESIGN.md 6.4) and keeps bf16x6."""
+    if _arith == _lib.ARITH_BF16X6:
+        return False
+    return True if _arith == _lib.ARITH_FP16X3 else bool(ln_forward)
+
+
+class _Planes:
+    """Opaque pre-split weight planes of :func:`gemm_x6` + which arithmetic they were split for."""
+    __slots__ = ("buf", "f16")
+
+    def __init__(self, buf: Tensor, f16: bool):
+        self.buf, self.f16 = buf, f16
+
+
+def gemm_x6_planes(W: Tensor, transpose: bool, f16: Optional[bool] = None) -> "_Planes":
+    """Pre-split planes of ``B`` for :func:`gemm_x6`: ``B = W`` ([N, K]) or, with ``transpose``, ``B = W^T`` (``W`` [K, N]) --
+    three bf16 planes (exact split), or two fp16 planes + per-column scales (``f16``; default: the process-wide arithmetic)."""
     dev = require_device(W)
     _check_f32(W)
     W = _rowmajor(W)
+    f16 = wide_f16() if f16 is None else bool(f16)            # (callers that know their prologue pass f16 themselves)
     N, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
     lib = _lib.load()
-    nbytes = int(lib.allset_gemm_x6_plane_bytes(N, K))
+    nbytes = int((lib.allset_gemm_f16x3_plane_bytes if f16 else lib.allset_gemm_x6_plane_bytes)(N, K))
     if nbytes < 0:
         raise _lib.AllSetHipError(f"gemm_x6: N={N}, K={K} not supported (K % 32 == 0, N % 4 == 0)")
     planes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with on_device(dev):
-        check(lib.allset_gemm_x6_planes(ptr(W), _ld(W), int(transpose), ptr(planes), N, K, stream_of(dev)), "allset_gemm_x6_planes")
-    return planes
+        fn, name = (lib.allset_gemm_f16x3_planes, "allset_gemm_f16x3_planes") if f16 else (lib.allset_gemm_x6_planes, "allset_gemm_x6_planes")
+        check(fn(ptr(W), _ld(W), int(transpose), ptr(planes), N, K, stream_of(dev)), name)
+    return _Planes(planes, f16)
 
 
 def row_stats(x: Tensor, relu_in: bool, eps: float) -> Tensor:
@@ -382,7 +403,9 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
             p_mask: float = 0.0, relu_in: bool = False, stats: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
             beta: Optional[Tensor] = None, p_in: float = 0.0, seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0,
             seed_out: int = 0, seed_base: Optional[Tensor] = None) -> Tensor:
-    """``out = epi(pro(A) @ B^T + bias)`` with ``B`` given as :func:`gemm_x6_planes` (include/allset_hip.h allset_gemm_x6)."""
+    """``out = epi(pro(A) @ B^T + bias)`` with ``B`` given as :func:`gemm_x6_planes` (include/allset_hip_ext.h allset_gemm_x6 /
+    allset_gemm_f16x3: the planes say which)."""
+    planes, f16 = planes.buf, planes.f16
     dev = require_device(A, planes, bias, mask_y, stats, gamma, beta)
     _check_f32(A, bias, mask_y, stats, gamma, beta)
     A = _rowmajor(A)
@@ -390,12 +413,14 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
     if mask_y is not None:
         mask_y = _rowmajor(mask_y)
     out = torch.empty((n, N), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    fn, name = (lib.allset_gemm_f16x3, "allset_gemm_f16x3") if f16 else (lib.allset_gemm_x6, "allset_gemm_x6")
     with on_device(dev), _timed("gemm_x6", dev, n * (K + N) * 4):
-        check(_lib.load().allset_gemm_x6(
+        check(fn(
             ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, int(relu_in), ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None), p_in,
             seed_in, ptr(planes), ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out,
-            ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_x6")
+            ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)), name)
     return out
 
 
@@ -404,6 +429,7 @@ def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Te
                 ) -> Tuple[Tensor, Tensor, Tensor]:
     """Backward-data of a wide Linear fused with the LayerNorm backward of its input (include/allset_hip.h
     allset_gemm_x6_lnb): returns (gx, dgamma, dbeta).  ``planes_t``: ``gemm_x6_planes(weight, True)``; N = x.shape[1] <= 256."""
+    planes_t, f16 = planes_t.buf, planes_t.f16
     dev = require_device(G, planes_t, x, stats, gamma, mask_y)
     _check_f32(G, x, stats, gamma, mask_y)
     G, x = _rowmajor(G), _rowmajor(x)
@@ -415,10 +441,11 @@ def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Te
     npart = int(lib.allset_gemm_x6_lnb_partials(n))
     partials = torch.empty((npart, 2, N), dtype=torch.float32, device=dev)
     gx = torch.empty((n, N), dtype=torch.float32, device=dev)
+    fn, name = (lib.allset_gemm_f16x3_lnb, "allset_gemm_f16x3_lnb") if f16 else (lib.allset_gemm_x6_lnb, "allset_gemm_x6_lnb")
     with on_device(dev), _timed("gemm_x6_lnb", dev, n * (K + 2 * N) * 4):
-        check(lib.allset_gemm_x6_lnb(ptr(G), _ld(G), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, ptr(planes_t),
-                                     ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
-                                     ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_x6_lnb")
+        check(fn(ptr(G), _ld(G), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, ptr(planes_t),
+                 ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
+                 ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), name)
     red = reduce_partials(partials)
     return gx, red[0], red[1]
 
@@ -1008,7 +1035,7 @@ class _WideNormLinear(torch.autograd.Function):
         seed_out = _draw_seed() if p_out > 0.0 else 0
         base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
         stats = row_stats(x, relu_in, eps) if gamma is not None else None
-        y = gemm_x6(x, gemm_x6_planes(weight, False), weight.shape[0], bias, relu_in=relu_in, stats=stats, gamma=gamma,
+        y = gemm_x6(x, gemm_x6_planes(weight, False, f16=wide_f16(gamma is not None)), weight.shape[0], bias, relu_in=relu_in, stats=stats, gamma=gamma,
                     beta=beta, p_in=p_in, seed_in=seed_in, relu_out=relu_out, p_out=p_out, seed_out=seed_out, seed_base=base)
         keep_y = relu_out or p_out > 0.0
         ctx.save_for_backward(x, stats, gamma, beta, weight, y if keep_y else None)

@@ -215,6 +215,22 @@ int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, int64_t ldy
                    const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                    const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
                    float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream);
+/* The same three entries in the fp16x3 arithmetic (ABI 11; ALLSET_ARITH_* above has the error model): the weight as TWO fp16 planes,
+ * each output column scaled into fp16's window (inverse scales stored behind the planes: allset_gemm_f16x3_plane_bytes), A behind a
+ * LayerNorm-apply prologue by one power of two for the launch (bound from gamma / beta), any other A per ROW from its largest element
+ * -- read one tile ahead inside the kernel, no extra pass.  Three MFMAs per product instead of six.  Contracts as allset_gemm_x6 /
+ * allset_gemm_x6_lnb / allset_gemm_x6_planes (`planes` from allset_gemm_f16x3_planes). */
+int64_t allset_gemm_f16x3_plane_bytes(int64_t N, int64_t K);
+int allset_gemm_f16x3_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream);
+int allset_gemm_f16x3_lnb(const float* G, int64_t ldg, const float* mask_y, int64_t ldy, float p_mask, const void* planes,
+                          const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p, uint64_t seed,
+                          float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows, int64_t N, int64_t K,
+                          const uint64_t* seed_base, void* stream);
+int allset_gemm_f16x3(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
+                      const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                      const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
+                      float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream);
+
 
 /* allset_pma_fwd_ex / allset_pma_bwd_stats / allset_pma_bwd_src_ex with explicit leading dimensions for the small per-row
  * operands the kernels GATHER next to a feature row: the logits (`lda` floats between rows, >= H) and the backward

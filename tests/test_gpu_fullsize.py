@@ -132,8 +132,12 @@ def test_wide_gemm_full_size_properties(device):
     g = torch.Generator(device=device).manual_seed(13)
     x = torch.randn(n, d, device=device, generator=g) * torch.exp(torch.randn(n, 1, device=device, generator=g))
     eye = torch.eye(d, device=device)
-    y = dense.gemm_x6(x, dense.gemm_x6_planes(eye, False), d, None)
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(eye, False, f16=False), d, None)          # the exact split (strict arithmetic)
     assert torch.equal(y, x)
+    # the default since round 5: two fp16 planes, A scaled per row from a maximum read one tile ahead -- 22 of the 24 significant
+    # bits of the row's largest element
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(eye, False, f16=True), d, None)
+    assert bool(((y - x).abs() <= 2.0 ** -21 * x.abs().max(1, keepdim=True).values).all())
     W = torch.randn(d, d, device=device, generator=g) / d ** 0.5
     b = torch.randn(d, device=device, generator=g)
     G = torch.randn(n, d, device=device, generator=g)

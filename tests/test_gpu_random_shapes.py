@@ -288,10 +288,11 @@ def test_weight_gradient_random(n, O, I, bf16, sd, device):
 @settings(**COMMON)
 @given(n=st.integers(1, 700), K=st.sampled_from([32, 96, 160, 256, 512]), N=st.sampled_from([4, 12, 100, 256, 260, 512]),
        use_mask=st.booleans(), relu_in=st.booleans(), has_ln=st.booleans(), relu_out=st.booleans(), bias=st.booleans(),
-       sd=st.integers(0, 10 ** 6))
-def test_gemm_x6_random(n, K, N, use_mask, relu_in, has_ln, relu_out, bias, sd, device):
-    """The tiled bf16x6 GEMM at random sizes (row tails of the 128-row tile, column tails of the 256-column tile, 1..16 K
-    steps) with every prologue / epilogue switch, against float64; the error is measured against sum |terms|."""
+       f16=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_gemm_x6_random(n, K, N, use_mask, relu_in, has_ln, relu_out, bias, f16, sd, device):
+    """The tiled GEMM at random sizes (row tails of the 128-row tile, column tails of the 256-column tile, 1..16 K
+    steps) with every prologue / epilogue switch, in both arithmetics (``f16``: two fp16 planes, the A window per launch behind a
+    LayerNorm, per row -- read one tile ahead -- otherwise), against float64; the error is measured against sum |terms|."""
     import torch.nn.functional as F
     from allset_amd import dense
     g = torch.Generator(device=device).manual_seed(sd)
@@ -313,7 +314,7 @@ def test_gemm_x6_random(n, K, N, use_mask, relu_in, has_ln, relu_out, bias, sd, 
         a = F.layer_norm(a, (K,), gamma.double(), beta.double(), 1e-5)
     pre = a @ W.double().t() + (b.double() if bias else 0.0)
     ref = F.relu(pre) if relu_out else pre
-    y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), N, b, mask_y=ymask, p_mask=0.25 if use_mask else 0.0, relu_in=relu_in,
+    y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False, f16=f16), N, b, mask_y=ymask, p_mask=0.25 if use_mask else 0.0, relu_in=relu_in,
                       stats=stats, gamma=gamma if has_ln else None, beta=beta if has_ln else None, relu_out=relu_out)
     scale = a.abs() @ W.double().abs().t() + (b.double().abs() if bias else 0.0) + 1e-30
     assert float(((y.double() - ref).abs() / scale).max()) < (2e-5 if has_ln else 2e-6)
@@ -435,8 +436,8 @@ def test_bf16_storage_aggregate_random(inc, d, aggr, weighted, pma_heads, device
 
 @settings(**COMMON)
 @given(n=st.integers(1, 900), K=st.sampled_from([64, 128, 256, 512]), N=st.sampled_from([4, 64, 100, 128, 256]), relu_in=st.booleans(),
-       p=st.sampled_from([0.0, 0.3]), use_mask=st.booleans(), sd=st.integers(0, 10 ** 6))
-def test_gemm_with_layer_norm_backward_epilogue_random(n, K, N, relu_in, p, use_mask, sd, device):
+       p=st.sampled_from([0.0, 0.3]), use_mask=st.booleans(), f16=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_gemm_with_layer_norm_backward_epilogue_random(n, K, N, relu_in, p, use_mask, f16, sd, device):
     """allset_gemm_x6_lnb (backward-data of a wide Linear with the LayerNorm backward as the GEMM's epilogue) against the two
     kernels it replaces, allset_gemm_x6 + allset_ln_bwd, with the same seeds: identical masks, results to rounding."""
     from allset_amd import dense
@@ -447,10 +448,11 @@ def test_gemm_with_layer_norm_backward_epilogue_random(n, K, N, relu_in, p, use_
     gamma = 1 + 0.2 * torch.randn(N, device=device, generator=g)
     ymask = torch.randn(n, K, device=device, generator=g) if use_mask else None
     stats = dense.row_stats(x, relu_in, 1e-5) if N <= 512 else None
-    planes_t = dense.gemm_x6_planes(W, True)
+    planes_t = dense.gemm_x6_planes(W, True, f16=False)
     gu = dense.gemm_x6(G, planes_t, N, None, mask_y=ymask, p_mask=0.25 if use_mask else 0.0)
     gx_ref, dg_ref, db_ref = dense.ln_bwd(gu, x, stats, gamma, relu_in, p, sd + 5)
-    gx, dg, db = dense.gemm_x6_lnb(G, planes_t, x, stats, gamma, relu_in, p, sd + 5, mask_y=ymask, p_mask=0.25 if use_mask else 0.0)
+    gx, dg, db = dense.gemm_x6_lnb(G, dense.gemm_x6_planes(W, True, f16=f16), x, stats, gamma, relu_in, p, sd + 5, mask_y=ymask,
+                                   p_mask=0.25 if use_mask else 0.0)
     sc = max(1.0, float(gx_ref.abs().max()))
     torch.testing.assert_close(gx, gx_ref, rtol=1e-4, atol=1e-4 * sc)
     torch.testing.assert_close(dg, dg_ref, rtol=1e-4, atol=1e-3 * max(1.0, float(dg_ref.abs().max())))
