@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.txt 2>&1; tail -3 $OUT/${TAG}_smoke.txt
-timeout 1800 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest.txt 2>&1; grep -n "passed\|failed\|FAILED" $OUT/${TAG}_pytest.txt | tail -8
+timeout 1800 python -m pytest tests -m gpu -q --durations=15 > $OUT/${TAG}_pytest.txt 2>&1; grep -n "passed\|failed\|FAILED" $OUT/${TAG}_pytest.txt | tail -8
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_${TAG}_$c
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -- python tools/pmc_probe.py > $OUT/pmc_${TAG}_$c.log 2>&1
@@ -33,5 +33,10 @@ timeout 600 python bench.py --norm bn --no-cpu-baseline > $OUT/${TAG}_bn_bench_l
 timeout 600 python bench.py --degree-dist poisson --no-cpu-baseline > $OUT/${TAG}_poisson_bench_line.json 2>/dev/null
 timeout 600 python bench.py --dropout 0 --no-cpu-baseline > $OUT/${TAG}_bench_line_dropout0.json 2>/dev/null
 python tools/bench_summary.py $OUT/${TAG}_pma_bench_line.json $OUT/${TAG}_poisson_bench_line.json $OUT/${TAG}_bench_line_dropout0.json | grep json
+timeout 600 python bench.py --d 256 --no-cpu-baseline > $OUT/${TAG}_d256_bench_line.json 2>/dev/null
+timeout 600 python bench.py --dtype bf16 --d 256 --model pma --degree-dist zipf --n-per-gpu 250000 --no-cpu-baseline --partitions primary > $OUT/${TAG}_c5_shape_bench_line.json 2>/dev/null
+timeout 600 python bench.py --dtype bf16 --d 256 --model pma --degree-dist zipf --n-per-gpu 250000 --no-cpu-baseline --partitions primary --hip-graph > $OUT/${TAG}_c5_shape_graph_bench_line.json 2>/dev/null
+python tools/bench_summary.py $OUT/${TAG}_d256_bench_line.json $OUT/${TAG}_c5_shape_bench_line.json $OUT/${TAG}_c5_shape_graph_bench_line.json | grep -v "^    "
+timeout 600 python tools/preprocess_bench.py > $OUT/${TAG}_preprocess_bench.txt 2>&1; tail -3 $OUT/${TAG}_preprocess_bench.txt
 timeout 600 python tools/small_graph_step.py > $OUT/${TAG}_small_graph_step.txt 2>&1; tail -12 $OUT/${TAG}_small_graph_step.txt
 echo finished
