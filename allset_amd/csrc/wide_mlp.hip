@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kBlock) void gemm_f16_planes_kernel(const float* __
 struct GxPro {
   const float* y;          // backward: A = gy * (y > 0 ? 1/(1-p_mask) : 0), y [rows, K] (the forward's output); or NULL
   int64_t ldy;
+  const uint32_t* mask;    // the same test from the forward's 1-bit activation mask ("mask layout", K % 64 == 0) instead of y; or NULL
   float p_mask;
   int relu_in;
   const float* stats;      // LayerNorm-apply: (a - mean) * rstd * gamma[k] + beta[k]; or NULL
@@ -123,6 +124,7 @@ struct GxEpi {
   // LayerNorm-backward epilogue (N <= 256: a tile holds whole rows): the GEMM's result is the gradient of
   // u = dropout_p(LN(relu_in ? relu(x) : x)); what is stored is the gradient of x, and the workgroup's sums of
   // dgamma / dbeta go to lnb_part[workgroup][0|1][N].  Active iff lnb_x != NULL (then bias / relu_out / p_out are unused).
+  uint32_t* mask_out;      // 1 bit per output element "out > 0" after the epilogue ("mask layout", N % 64 == 0); or NULL
   const float* lnb_x;
   int64_t lnb_ldx;
   const float* lnb_stats;
@@ -137,6 +139,7 @@ struct GxEpi {
 struct GxRow {
   const float* a;          // A + row * lda + seg * 8 (row clamped: loads are unconditional)
   const float* y;          // mask source, or NULL
+  const uint32_t* m;       // mask words of the row (bit-mask form), or NULL
   int64_t g_row;
   float mean, rstd;
   float asc;               // fp16x3 without a LayerNorm prologue: the power of two this row's A elements are scaled by (its inverse goes
@@ -153,7 +156,9 @@ union GxFragH { uint4 u; f16x8_t v; };
 // first K step: every thread reads, one TILE ahead, the segments it will stage for the next tile (same addresses: the second read
 // is an L2 / Infinity Cache hit, HBM traffic unchanged) and folds their maximum; the four threads of a row combine by two shuffles
 // when the tile changes.  The mask / relu of the prologue only shrink elements: the unmasked maximum is a valid bound.
-template <bool HAS_Y, bool LNB, bool F16 = false>
+// YM: where the prologue's "forward output > 0" test comes from -- 0 none, 1 the forward's fp32 output y (a second [rows, K] read),
+// 2 its 1-bit activation mask (one dword per thread and K step; round 5).
+template <int YM, bool LNB, bool F16 = false>
 __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const float* __restrict__ A, int64_t lda, GxPro pro, const uint4* __restrict__ planes, GxEpi epi,
     float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base,
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const int64_t cr = c.ok ? c.g_row : rows - 1;
     c.a = A + cr * lda + s_seg * 8;
     c.y = pro.y ? pro.y + cr * pro.ldy + s_seg * 8 : nullptr;
+    c.m = pro.mask ? pro.mask + (cr >> 4) * (K / 64) * 32 + ((cr & 15) >> 2) * 8 + (cr & 3) * 2 : nullptr;
     c.mean = 0.f; c.rstd = 1.f; c.asc = 1.f;
     if (pro.stats) { c.mean = pro.stats[cr * 2]; c.rstd = pro.stats[cr * 2 + 1]; }
     return c;
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   // scratch store right behind the global load is a full wait, exactly the latency the prefetch hides.
   float4 pa0, pa1, py0 = make_float4(1.f, 1.f, 1.f, 1.f), py1 = py0;
   uint4 pb0, pb1, pb2, pb3, pb4, pb5;
+  uint32_t pm = 0;                                                     // YM == 2: the mask dword of this thread's row and K step
   float4 la0 = make_float4(0.f, 0.f, 0.f, 0.f), la1 = la0;            // fp16x3 per-row window: the next tile's segments, one tile ahead
   float nmax = 0.f;
 #define GX_LOAD(ctx_, img_base_, ks_)                                                           \
@@ -222,10 +229,11 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     const int k0_ = (ks_) * kGxKS;                                                              \
     pa0 = *reinterpret_cast<const float4*>((ctx_).a + k0_);                                     \
     pa1 = *reinterpret_cast<const float4*>((ctx_).a + k0_ + 4);                                 \
-    if constexpr (HAS_Y) {                                                                      \
+    if constexpr (YM == 1) {                                                                    \
       py0 = *reinterpret_cast<const float4*>((ctx_).y + k0_);                                   \
       py1 = *reinterpret_cast<const float4*>((ctx_).y + k0_ + 4);                               \
     }                                                                                           \
+    if constexpr (YM == 2) pm = (ctx_).m[((ks_) >> 1) * 32 + ((ks_) & 1)];                      \
     const uint4* img_ = (img_base_) + static_cast<int64_t>(ks_) * kBSlab + b_img;               \
     if constexpr (F16) {                                                                        \
       pb0 = img_[-128]; pb1 = img_[-64]; pb2 = img_[0]; pb3 = img_[64];                         \
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   } while (0)
 
   auto prologue2 = [&](const GxRow& c, float a0, float a1, float y0, float y1, int kk, float& o0, float& o1) {
-    if constexpr (HAS_Y) { a0 = y0 > 0.f ? a0 * inv_mask : 0.f; a1 = y1 > 0.f ? a1 * inv_mask : 0.f; }
+    if constexpr (YM != 0) { a0 = y0 > 0.f ? a0 * inv_mask : 0.f; a1 = y1 > 0.f ? a1 * inv_mask : 0.f; }
     if (pro.relu_in) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
     if (pro.stats) {
       const float2 g = *reinterpret_cast<const float2*>(sGB + kk), b = *reinterpret_cast<const float2*>(sGB + 512 + kk);
@@ -254,6 +262,11 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
 #define GX_STORE(ctx_, ks_, buf_)                                                               \
   do {                                                                                          \
     const int kb_ = (ks_) * kGxKS + s_seg * 8;                                                  \
+    if constexpr (YM == 2) {   /* bits 8 q + 2 s_seg (+ 1): columns kb + q (kb + 4 + q) of the row -> the signs prologue2 tests */ \
+      const uint32_t b_ = pm >> (2 * s_seg);                                                    \
+      py0 = make_float4((b_ & 0x1u) ? 1.f : 0.f, (b_ & 0x100u) ? 1.f : 0.f, (b_ & 0x10000u) ? 1.f : 0.f, (b_ & 0x1000000u) ? 1.f : 0.f); \
+      py1 = make_float4((b_ & 0x2u) ? 1.f : 0.f, (b_ & 0x200u) ? 1.f : 0.f, (b_ & 0x20000u) ? 1.f : 0.f, (b_ & 0x2000000u) ? 1.f : 0.f); \
+    }                                                                                           \
     float e0, e1, e2, e3, e4, e5, e6, e7;                                                       \
     prologue2(ctx_, pa0.x, pa0.y, py0.x, py0.y, kb_, e0, e1);                                   \
     prologue2(ctx_, pa0.z, pa0.w, py0.z, py0.w, kb_ + 2, e2, e3);                               \
@@ -438,10 +451,30 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           sOut[(wr * 64 + rt * 16 + 4 * fg + r) * kOutPitch + wc * 64 + ct * 16 + fr] = acc[rt][ct][r];
-    __syncthreads();
     const int c4 = (tid & 63) * 4;
     const int n = static_cast<int>(tile % n_tiles) * kGxBN + c4;
     const int64_t row0 = tile / n_tiles * kGxBM;
+    // LayerNorm-backward epilogue: the x rows and row statistics of the 16 rows this wave will finish, requested NOW (the accumulators
+    // are dead, their registers hold the requests) so that their latency passes under the tile's trip through LDS instead of once
+    // per row inside the loop below (round 5: that loop's dependent loads were about half of this kernel's tile time)
+    constexpr int kLnbIter = kGxBM / (kGxThreads / 64);
+    float4 lnb_xp[LNB ? kLnbIter : 1];
+    float2 lnb_sp = make_float2(0.f, 1.f);                             // lane i < 16: the statistics of the wave's i-th row
+    if constexpr (LNB) {
+      static_assert(kLnbIter <= 64, "one lane per row of the wave");
+#pragma unroll
+      for (int i = 0; i < kLnbIter; ++i) {
+        const int64_t row = row0 + (tid >> 6) + i * (kGxThreads / 64);
+        const int64_t rc = row < rows ? row : rows - 1;
+        lnb_xp[i] = n < N ? *reinterpret_cast<const float4*>(epi.lnb_x + rc * epi.lnb_ldx + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      {
+        const int li = (tid & 63) < kLnbIter ? (tid & 63) : kLnbIter - 1;
+        const int64_t row = row0 + (tid >> 6) + li * (kGxThreads / 64);
+        lnb_sp = *reinterpret_cast<const float2*>(epi.lnb_stats + (row < rows ? row : rows - 1) * 2);
+      }
+    }
+    __syncthreads();
     float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);                      // fp16x3: the inverse scales of the lane's four B columns
     if constexpr (F16) cs4 = *reinterpret_cast<const float4*>(bscale + n);       // (bscale has n_pad entries: always in range)
     if constexpr (LNB) {
@@ -451,19 +484,21 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       const float inv_d = 1.f / static_cast<float>(N);
       float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (act) g4 = *reinterpret_cast<const float4*>(epi.lnb_gamma + n);
-      for (int rr = tid >> 6; rr < kGxBM; rr += kGxThreads / 64) {
+#pragma unroll
+      for (int it = 0; it < kLnbIter; ++it) {
+        const int rr = (tid >> 6) + it * (kGxThreads / 64);
         const int64_t row = row0 + rr;
-        if (row >= rows) break;                                        // (wave-uniform)
-        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
+        if (row >= rows) continue;                                     // (wave-uniform)
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 xv = lnb_xp[it];
         if (act) {
           gv = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
           if constexpr (F16) {
             const float ri = sRowInv[rr];
             gv.x *= ri * cs4.x; gv.y *= ri * cs4.y; gv.z *= ri * cs4.z; gv.w *= ri * cs4.w;
           }
-          xv = *reinterpret_cast<const float4*>(epi.lnb_x + row * epi.lnb_ldx + n);
         }
-        const float mean = epi.lnb_stats[row * 2], rstd = epi.lnb_stats[row * 2 + 1];
+        const float mean = __shfl(lnb_sp.x, it), rstd = __shfl(lnb_sp.y, it);
         float4 t = xv;
         if (epi.lnb_relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
         float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
@@ -513,6 +548,17 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
           v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
         }
         *reinterpret_cast<float4*>(out + row * ldo + n) = v;
+        if (epi.mask_out != nullptr) {
+          // "mask layout" (include/allset_hip_ext.h): byte q of dword j = bits 8 j .. 8 j + 7 of the ballot of component q: lane j < 8
+          // assembles the dword of columns 32 j .. 32 j + 31 of this tile's row (lanes past N are inactive: their bits are 0)
+          const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+          const int lj = tid & 63, sh = 8 * (lj & 7);
+          const uint32_t word = static_cast<uint32_t>((b0 >> sh) & 0xffu) | (static_cast<uint32_t>((b1 >> sh) & 0xffu) << 8) |
+                                (static_cast<uint32_t>((b2 >> sh) & 0xffu) << 16) | (static_cast<uint32_t>((b3 >> sh) & 0xffu) << 24);
+          const int col = static_cast<int>(tile % n_tiles) * kGxBN + 32 * lj;
+          if (lj < 8 && col < N)
+            epi.mask_out[((row >> 4) * (N / 64) + (col >> 6)) * 32 + ((row & 15) >> 2) * 8 + (row & 3) * 2 + ((col & 63) >> 5)] = word;
+        }
       }
     }
     __syncthreads();                                                   // the arena is free again
@@ -616,7 +662,7 @@ extern "C" int allset_row_stats(const float* x, int64_t ldx, int relu_in, float 
 static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                         const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                         const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
-                        const uint64_t* seed_base, void* stream, bool f16 = false);
+                        const uint64_t* seed_base, void* stream, bool f16 = false, const uint32_t* mask_bits = nullptr);
 
 // ---- the fp16x3 family: same contracts, the weight in two fp16 planes + per-column inverse scales (allset_gemm_f16x3_planes) ----
 extern "C" int64_t allset_gemm_f16x3_plane_bytes(int64_t N, int64_t K) {
@@ -657,7 +703,7 @@ extern "C" int allset_gemm_f16x3_lnb(const float* G, int64_t ldg, const float* m
   }
   ALLSET_REQUIRE(x && stats && gamma && gx, "gemm_f16x3_lnb: null pointer");
   ALLSET_REQUIRE(ldx >= N && ldx % 4 == 0 && aligned16(x) && aligned16(gamma), "gemm_f16x3_lnb: x rows / gamma must be 16-byte aligned");
-  GxEpi epi{nullptr, 0, 0.f, 0, x, ldx, stats, gamma, relu_in, p, seed, partials};
+  GxEpi epi{nullptr, 0, 0.f, 0, nullptr, x, ldx, stats, gamma, relu_in, p, seed, partials};
   return gemm_x6_impl(G, ldg, mask_y, ldy, p_mask, 0, nullptr, nullptr, nullptr, 0.f, 0, planes, epi, gx, ldgx, rows, N, K, seed_base, stream, true);
 }
 
@@ -668,7 +714,7 @@ extern "C" int allset_gemm_f16x3(const float* A, int64_t lda, const float* mask_
                                  void* stream) {
   clear_error();
   ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "gemm_f16x3: dropout p must be in [0,1)");
-  GxEpi epi{bias, relu_out, p_out, seed_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
+  GxEpi epi{bias, relu_out, p_out, seed_out, nullptr, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
   ALLSET_REQUIRE(bias == nullptr || aligned16(bias), "gemm_f16x3: bias must be 16-byte aligned");
   return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base, stream, true);
 }
@@ -692,7 +738,7 @@ extern "C" int allset_gemm_x6_lnb(const float* G, int64_t ldg, const float* mask
   }
   ALLSET_REQUIRE(x && stats && gamma && gx, "gemm_x6_lnb: null pointer");
   ALLSET_REQUIRE(ldx >= N && ldx % 4 == 0 && aligned16(x) && aligned16(gamma), "gemm_x6_lnb: x rows / gamma must be 16-byte aligned");
-  GxEpi epi{nullptr, 0, 0.f, 0, x, ldx, stats, gamma, relu_in, p, seed, partials};
+  GxEpi epi{nullptr, 0, 0.f, 0, nullptr, x, ldx, stats, gamma, relu_in, p, seed, partials};
   return gemm_x6_impl(G, ldg, mask_y, ldy, p_mask, 0, nullptr, nullptr, nullptr, 0.f, 0, planes, epi, gx, ldgx, rows, N, K, seed_base, stream);
 }
 
@@ -703,7 +749,7 @@ extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, 
                               void* stream) {
   clear_error();
   ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "gemm_x6: dropout p must be in [0,1)");
-  GxEpi epi{bias, relu_out, p_out, seed_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
+  GxEpi epi{bias, relu_out, p_out, seed_out, nullptr, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
   ALLSET_REQUIRE(bias == nullptr || aligned16(bias), "gemm_x6: bias must be 16-byte aligned");
   return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base, stream);
 }
@@ -711,7 +757,9 @@ extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, 
 static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                         const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                         const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
-                        const uint64_t* seed_base, void* stream, bool f16) {
+                        const uint64_t* seed_base, void* stream, bool f16, const uint32_t* mask_bits) {
+  ALLSET_REQUIRE(mask_bits == nullptr || (mask_y == nullptr && K % 64 == 0), "gemm_wide: the 1-bit mask needs K % 64 == 0 and replaces mask_y");
+  ALLSET_REQUIRE(epi.mask_out == nullptr || (N % 64 == 0 && epi.lnb_x == nullptr), "gemm_wide: mask_out needs N % 64 == 0 (and no LayerNorm-backward epilogue)");
   if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_x6: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(rows >= 0, "gemm_x6: bad row count");
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_mask >= 0.f && p_mask < 1.f, "gemm_x6: dropout p must be in [0,1)");
@@ -721,7 +769,7 @@ static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_
   ALLSET_REQUIRE(ldo >= N && ldo % 4 == 0 && aligned16(out), "gemm_x6: output rows must be 16-byte aligned");
   ALLSET_REQUIRE(mask_y == nullptr || (ldy >= K && ldy % 4 == 0 && aligned16(mask_y)), "gemm_x6: mask source rows must be 16-byte aligned");
   ALLSET_REQUIRE(stats == nullptr || (gamma && beta && K <= 512), "gemm_x6: LayerNorm-apply needs gamma and beta, K <= 512");
-  GxPro pro{mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in};
+  GxPro pro{mask_y, ldy, mask_bits, p_mask, relu_in, stats, gamma, beta, p_in, seed_in};
   const int64_t tiles = (rows + kGxBM - 1) / kGxBM * ((N + kGxBN - 1) / kGxBN);
   const int64_t blocks = tiles < 256 ? tiles : 256;                     // one workgroup per CU (144 KB of LDS), walking its tiles
   const int64_t n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
@@ -729,10 +777,48 @@ static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_
 #define GX_LAUNCH(Y, L, H) gemm_x6_kernel<Y, L, H><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>( \
       A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base, bscale)
 #define GX_LAUNCH2(Y, L) do { if (f16) GX_LAUNCH(Y, L, true); else GX_LAUNCH(Y, L, false); } while (0)
-  if (epi.lnb_x != nullptr) { if (mask_y) GX_LAUNCH2(true, true); else GX_LAUNCH2(false, true); }
-  else { if (mask_y) GX_LAUNCH2(true, false); else GX_LAUNCH2(false, false); }
+#define GX_LAUNCH3(L) do { if (mask_bits) GX_LAUNCH2(2, L); else if (mask_y) GX_LAUNCH2(1, L); else GX_LAUNCH2(0, L); } while (0)
+  if (epi.lnb_x != nullptr) GX_LAUNCH3(true); else GX_LAUNCH3(false);
+#undef GX_LAUNCH3
 #undef GX_LAUNCH2
 #undef GX_LAUNCH
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
+}
+
+// ---- superset entries (ABI 11): the arithmetic as an argument (1 = ALLSET_ARITH_BF16X6 planes, 2 = ALLSET_ARITH_FP16X3 planes) and the
+// forward's 1-bit activation mask -- written by the forward (mask_out; "mask layout", N % 64 == 0), read by the backward-data GEMMs
+// (mask_bits, K % 64 == 0; replaces the [rows, K] fp32 mask source mask_y: one dword per thread and K step instead of 32 bytes) ----
+extern "C" int allset_gemm_wide(int arith, const float* A, int64_t lda, const float* mask_y, int64_t ldy, const uint32_t* mask_bits,
+                                float p_mask, int relu_in, const float* stats, const float* gamma, const float* beta, float p_in,
+                                uint64_t seed_in, const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
+                                uint32_t* mask_out, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
+                                const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(arith == ALLSET_ARITH_BF16X6 || arith == ALLSET_ARITH_FP16X3, "gemm_wide: arith names the planes' format: ALLSET_ARITH_BF16X6 or ALLSET_ARITH_FP16X3");
+  ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "gemm_wide: dropout p must be in [0,1)");
+  ALLSET_REQUIRE(bias == nullptr || aligned16(bias), "gemm_wide: bias must be 16-byte aligned");
+  GxEpi epi{bias, relu_out, p_out, seed_out, mask_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
+  return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base,
+                      stream, arith == ALLSET_ARITH_FP16X3, mask_bits);
+}
+
+extern "C" int allset_gemm_wide_lnb(int arith, const float* G, int64_t ldg, const float* mask_y, int64_t ldy, const uint32_t* mask_bits,
+                                    float p_mask, const void* planes, const float* x, int64_t ldx, const float* stats,
+                                    const float* gamma, int relu_in, float p, uint64_t seed, float* gx, int64_t ldgx, float* partials,
+                                    int64_t n_partials, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(arith == ALLSET_ARITH_BF16X6 || arith == ALLSET_ARITH_FP16X3, "gemm_wide_lnb: arith names the planes' format: ALLSET_ARITH_BF16X6 or ALLSET_ARITH_FP16X3");
+  ALLSET_REQUIRE(N >= 4 && N <= kGxBN, "gemm_wide_lnb: the LayerNorm row (N) must fit one 256-column tile");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "gemm_wide_lnb: dropout p must be in [0,1)");
+  ALLSET_REQUIRE(partials != nullptr && n_partials == allset_gemm_x6_lnb_partials(rows), "gemm_wide_lnb: partials must hold allset_gemm_x6_lnb_partials(rows) x 2 x N floats");
+  if (rows == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(partials, 0, static_cast<size_t>(n_partials) * 2 * N * sizeof(float), static_cast<hipStream_t>(stream)));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(x && stats && gamma && gx, "gemm_wide_lnb: null pointer");
+  ALLSET_REQUIRE(ldx >= N && ldx % 4 == 0 && aligned16(x) && aligned16(gamma), "gemm_wide_lnb: x rows / gamma must be 16-byte aligned");
+  GxEpi epi{nullptr, 0, 0.f, 0, nullptr, x, ldx, stats, gamma, relu_in, p, seed, partials};
+  return gemm_x6_impl(G, ldg, mask_y, ldy, p_mask, 0, nullptr, nullptr, nullptr, 0.f, 0, planes, epi, gx, ldgx, rows, N, K, seed_base, stream,
+                      arith == ALLSET_ARITH_FP16X3, mask_bits);
 }

@@ -350,14 +350,11 @@ def gemm_x6_supported(N: int, K: int) -> bool:
 
 
 def wide_f16(ln_forward: bool = False) -> bool:
-    """Which arithmetic a tiled wide GEMM (widths 256 / 512) runs in.  ``fp16x3`` mode: two fp16 planes everywhere; ``strict``: the
-    exact bf16x6 split everywhere; ``auto``: fp16x3 only for the FORWARD behind a LayerNorm-apply prologue (``ln_forward``), where
-    it measured 0.81 -> 0.67 ms at [1M, 256] x [256, 256]; the backward-data GEMM with the LayerNorm-backward epilogue measured
-    1.26 -> 1.30 ms (its per-row window costs a second, cache-served read of A; the kernel is bound by load latency at one
-    workgroup per CU, not by the matrix pipe: DESIGN.md 6.4) and keeps bf16x6."""
-    if _arith == _lib.ARITH_BF16X6:
-        return False
-    return True if _arith == _lib.ARITH_FP16X3 else bool(ln_forward)
+    """Which arithmetic a tiled wide GEMM (widths 256 / 512) runs in: the exact bf16x6 split under ``set_arithmetic("strict")``, two
+    fp16 planes otherwise (auto / fp16x3).  Measured at [1M, 256] x [256, 256] (profiles/r05d_d256*_bench_line.json): forward behind a
+    LayerNorm 0.81 -> 0.67 ms, backward-data with the LayerNorm-backward epilogue 1.16 -> 1.01 ms -- modest, because these kernels are
+    bound by load latency at one workgroup per CU, not by the matrix pipe.  (``ln_forward`` kept for callers.)"""
+    return _arith != _lib.ARITH_BF16X6
 
 
 class _Planes:
@@ -402,7 +399,8 @@ def row_stats(x: Tensor, relu_in: bool, eps: float) -> Tensor:
 def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *, mask_y: Optional[Tensor] = None,
             p_mask: float = 0.0, relu_in: bool = False, stats: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
             beta: Optional[Tensor] = None, p_in: float = 0.0, seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0,
-            seed_out: int = 0, seed_base: Optional[Tensor] = None) -> Tensor:
+            seed_out: int = 0, seed_base: Optional[Tensor] = None, mask_bits: Optional[Tensor] = None,
+            mask_out: Optional[Tensor] = None) -> Tensor:
     """``out = epi(pro(A) @ B^T + bias)`` with ``B`` given as :func:`gemm_x6_planes` (include/allset_hip_ext.h allset_gemm_x6 /
     allset_gemm_f16x3: the planes say which)."""
     planes, f16 = planes.buf, planes.f16
@@ -414,19 +412,19 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
         mask_y = _rowmajor(mask_y)
     out = torch.empty((n, N), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    fn, name = (lib.allset_gemm_f16x3, "allset_gemm_f16x3") if f16 else (lib.allset_gemm_x6, "allset_gemm_x6")
-    with on_device(dev), _timed("gemm_x6", dev, n * (K + N) * 4):
-        check(fn(
-            ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, int(relu_in), ptr(stats),
+    with on_device(dev), _timed("gemm_x6", dev, n * (K * (2 if mask_y is not None else 1) + N) * 4):
+        check(lib.allset_gemm_wide(
+            _lib.ARITH_FP16X3 if f16 else _lib.ARITH_BF16X6, ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0,
+            ptr(mask_bits), p_mask, int(relu_in), ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None), p_in,
             seed_in, ptr(planes), ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out,
-            ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)), name)
+            ptr(mask_out), ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_wide")
     return out
 
 
 def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
-                mask_y: Optional[Tensor] = None, p_mask: float = 0.0, seed_base: Optional[Tensor] = None
-                ) -> Tuple[Tensor, Tensor, Tensor]:
+                mask_y: Optional[Tensor] = None, p_mask: float = 0.0, seed_base: Optional[Tensor] = None,
+                mask_bits: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Backward-data of a wide Linear fused with the LayerNorm backward of its input (include/allset_hip.h
     allset_gemm_x6_lnb): returns (gx, dgamma, dbeta).  ``planes_t``: ``gemm_x6_planes(weight, True)``; N = x.shape[1] <= 256."""
     planes_t, f16 = planes_t.buf, planes_t.f16
@@ -441,11 +439,11 @@ def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Te
     npart = int(lib.allset_gemm_x6_lnb_partials(n))
     partials = torch.empty((npart, 2, N), dtype=torch.float32, device=dev)
     gx = torch.empty((n, N), dtype=torch.float32, device=dev)
-    fn, name = (lib.allset_gemm_f16x3_lnb, "allset_gemm_f16x3_lnb") if f16 else (lib.allset_gemm_x6_lnb, "allset_gemm_x6_lnb")
-    with on_device(dev), _timed("gemm_x6_lnb", dev, n * (K + 2 * N) * 4):
-        check(fn(ptr(G), _ld(G), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0, p_mask, ptr(planes_t),
-                 ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
-                 ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), name)
+    with on_device(dev), _timed("gemm_x6_lnb", dev, n * (K * (2 if mask_y is not None else 1) + 2 * N) * 4):
+        check(lib.allset_gemm_wide_lnb(_lib.ARITH_FP16X3 if f16 else _lib.ARITH_BF16X6, ptr(G), _ld(G), ptr(mask_y),
+                                       _ld(mask_y) if mask_y is not None else 0, ptr(mask_bits), p_mask, ptr(planes_t),
+                                       ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
+                                       ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_wide_lnb")
     red = reduce_partials(partials)
     return gx, red[0], red[1]
 
@@ -1035,17 +1033,22 @@ class _WideNormLinear(torch.autograd.Function):
         seed_out = _draw_seed() if p_out > 0.0 else 0
         base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
         stats = row_stats(x, relu_in, eps) if gamma is not None else None
-        y = gemm_x6(x, gemm_x6_planes(weight, False, f16=wide_f16(gamma is not None)), weight.shape[0], bias, relu_in=relu_in, stats=stats, gamma=gamma,
-                    beta=beta, p_in=p_in, seed_in=seed_in, relu_out=relu_out, p_out=p_out, seed_out=seed_out, seed_base=base)
         keep_y = relu_out or p_out > 0.0
-        ctx.save_for_backward(x, stats, gamma, beta, weight, y if keep_y else None)
+        # the backward's "y > 0" test from a 1-bit mask the forward's epilogue writes (round 5: the backward kernels used to re-read
+        # the fp32 output twice -- 2 GB per Linear at [1M, 256]); widths that are not multiples of 64 keep y
+        words = activation_mask_words(x.shape[0], weight.shape[0]) if (keep_y and x.shape[0] > 0) else 0
+        mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
+        y = gemm_x6(x, gemm_x6_planes(weight, False, f16=wide_f16(gamma is not None)), weight.shape[0], bias, relu_in=relu_in, stats=stats, gamma=gamma,
+                    beta=beta, p_in=p_in, seed_in=seed_in, relu_out=relu_out, p_out=p_out, seed_out=seed_out, seed_base=base,
+                    mask_out=mask)
+        ctx.save_for_backward(x, stats, gamma, beta, weight, y if (keep_y and mask is None) else None, mask)
         ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, stats, gamma, beta, weight, y = ctx.saved_tensors
+        x, stats, gamma, beta, weight, y, mask = ctx.saved_tensors
         relu_in, p_in, seed_in, p_out, has_bias, base = ctx.cfg
         if x.shape[0] == 0:                     # no rows: every gradient is zero (empty tensors carry no row statistics)
             z = lambda t, need: torch.zeros_like(t) if (t is not None and need) else None
@@ -1057,16 +1060,16 @@ class _WideNormLinear(torch.autograd.Function):
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3] or need_b:
-            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b, seed_base=base)
+            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b, seed_base=base, mask=mask)
         need_x = ctx.needs_input_grad[0]
         if need_x or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
             # gradient of the Linear's input u = dropout(LN(relu(x))): (gy * epilogue mask) @ W
             if gamma is not None and weight.shape[1] <= 256:
                 # one kernel: the Linear's input gradient never leaves the chip, the LayerNorm backward is the GEMM's epilogue
                 gx, dg, db = gemm_x6_lnb(gy, gemm_x6_planes(weight, True), x, stats, gamma, relu_in, p_in, seed_in, mask_y=y,
-                                         p_mask=p_out, seed_base=base)
+                                         p_mask=p_out, seed_base=base, mask_bits=mask)
                 return gx, dg, db, gw, gb, None, None, None, None, None
-            gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out)
+            gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out, mask_bits=mask)
             if gamma is not None:
                 gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x)
             elif relu_in:                       # (p_in == 0 here, see wide_linear_supported): mask by the sign of x

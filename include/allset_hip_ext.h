@@ -230,6 +230,20 @@ int allset_gemm_f16x3(const float* A, int64_t lda, const float* mask_y, int64_t 
                       const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                       const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
                       float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream);
+/* Supersets of allset_gemm_x6 / _f16x3 and their _lnb forms (ABI 11): `arith` names the planes' format (ALLSET_ARITH_BF16X6 or
+ * ALLSET_ARITH_FP16X3, declared below), and the forward's 1-bit activation mask travels instead of its fp32 output: mask_out (forward,
+ * N % 64 == 0, may be NULL) receives "out > 0" after the epilogue in the "mask layout" of allset_fused_linear_fwd; mask_bits (backward,
+ * K % 64 == 0, may be NULL; then mask_y must be NULL) replaces mask_y -- one dword per thread and K step where mask_y costs a second
+ * [rows, K] fp32 read.  allset_wgrad_fused_ex takes the same buffer as `mask`. */
+int allset_gemm_wide(int arith, const float* A, int64_t lda, const float* mask_y, int64_t ldy, const uint32_t* mask_bits, float p_mask,
+                     int relu_in, const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
+                     const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out, uint32_t* mask_out,
+                     float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream);
+int allset_gemm_wide_lnb(int arith, const float* G, int64_t ldg, const float* mask_y, int64_t ldy, const uint32_t* mask_bits, float p_mask,
+                         const void* planes, const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p,
+                         uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows, int64_t N, int64_t K,
+                         const uint64_t* seed_base, void* stream);
+
 
 
 /* allset_pma_fwd_ex / allset_pma_bwd_stats / allset_pma_bwd_src_ex with explicit leading dimensions for the small per-row
