@@ -551,7 +551,10 @@ union WFrag { uint4 u; bf16x8_t v; };
 
 __device__ __forceinline__ int wx6_swz(int feat) { return (((feat >> 2) & 3) >> 1) * 3; }
 
-template <bool PRO>
+// MK: the source of the forward's "output > 0" test on ga (0 none, 1 its fp32 output y, 2 its 1-bit activation mask); LN: the
+// LayerNorm-apply on u.  Template parameters since round 5: as run-time flags they put a branch around every optional load of the
+// staging path, and a branch around a memory instruction makes hipcc count the loads of the longest path at every later wait.
+template <bool PRO, int MK = 0, bool LN = false>
 __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
     const float* __restrict__ ga, int64_t lda, const float* __restrict__ u, int64_t ldu,
     float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i,
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
   float keep_in = 1.f;
   uint32_t thr_in = 0;
   if constexpr (PRO) {
-    if (pro.has_ln && b_ok) {
+    if (LN && b_ok) {
       g4 = *reinterpret_cast<const float4*>(pro.gamma + i_base + s_col);
       be4 = *reinterpret_cast<const float4*>(pro.beta + i_base + s_col);
     }
@@ -582,13 +585,13 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
     thr_in = drop_threshold(pro.p_in);
     pro.seed_in = resolve_seed(pro.seed_base, pro.seed_in);
   }
-  const bool has_mask = PRO && pro.mask != nullptr;
-  const bool has_y = PRO && pro.y != nullptr && !has_mask;
+  constexpr bool has_mask = PRO && MK == 2;
+  constexpr bool has_y = PRO && MK == 1;
   // mask word of (row r, columns a_col..+3): block (r/16, a_col/64), dword (r%16/4)*8 + (r%4)*2 + ((a_col%64)/32),
   // bits 8c + ((a_col%32)/4) for column a_col + c
   const int m_col = ((a_col / 64) * 32) + ((a_col % 64) / 32);
   const int m_bit = (a_col % 32) / 4;
-  const bool has_ln = PRO && pro.has_ln;
+  constexpr bool has_ln = PRO && LN;
 
   // Two register sets: the global loads run TWO stages ahead of the MFMAs (one stage of 32-48 KiB per CU in flight is
   // latency-bound at ~3 TB/s), the LDS conversion one stage ahead.
@@ -1740,9 +1743,16 @@ static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_
   if (plain)
     wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
                                                        static_cast<int>(I), tiles_i, rows_per_slice, pro);
-  else
-    wgrad_x6_kernel<true><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O),
-                                                      static_cast<int>(I), tiles_i, rows_per_slice, pro);
+  else {
+#define ALLSET_WX6(MKV, LNV) wgrad_x6_kernel<true, MKV, LNV><<<grid, kWx6Block, 0, st>>>(gy, ldg, x, ldx, part_w, part_b, n, static_cast<int>(O), \
+                                                                                      static_cast<int>(I), tiles_i, rows_per_slice, pro)
+    const int mk = mask != nullptr ? 2 : (y != nullptr ? 1 : 0);
+    const bool ln = stats != nullptr;
+    if (mk == 2) { if (ln) ALLSET_WX6(2, true); else ALLSET_WX6(2, false); }
+    else if (mk == 1) { if (ln) ALLSET_WX6(1, true); else ALLSET_WX6(1, false); }
+    else { if (ln) ALLSET_WX6(0, true); else ALLSET_WX6(0, false); }
+#undef ALLSET_WX6
+  }
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
