@@ -159,7 +159,10 @@ def kinkfree_biases(sd, margin: float = 6.0):
     for k, v in sd.items():
         if k.endswith(".bias") and (any(t in k for t in _RELU_FED_BIAS) or k.endswith(".ln1.bias")):
             n = v.shape[0]
-            sign = np.where(np.arange(n) % 2 == 0, margin, -margin).astype(np.float32)
+            # rFF's second Linear has no normalisation in front: its input relu(. + 6) is ~6 on half of the columns, its
+            # Linear term has a standard deviation of ~4 -- the margin scales with it
+            mg = 4.0 * margin if ".rFF.lins.1." in k else margin
+            sign = np.where(np.arange(n) % 2 == 0, mg, -mg).astype(np.float32)
             if isinstance(v, np.ndarray):
                 v += sign
             else:                                   # torch tensor / Parameter (imported lazily: this module is numpy-only)

@@ -155,3 +155,61 @@ def test_wide_gemm_full_size_properties(device):
     ref = torch.relu(torch.nn.functional.layer_norm(x[rows].double(), (d,), gamma.double(), beta.double(), 1e-5)
                      @ W.double().t() + b.double())
     torch.testing.assert_close(yl[rows].double(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_pma_tail_full_size_rows_and_gradients(device):
+    """The two-kernel PMA tail (``dense.pma_tail``: ln0 / ln1 inside the rFF Linears, reference layers.py:153-157) at the bench's
+    size, n = 1M rows: everything in it is row-local for fixed parameters, so SAMPLED rows of the output and of the input gradient
+    are checked against float64 (first / last 64 rows and 4000 random ones: stage tails of the persistent workgroups included); the
+    parameter gradients -- sums over all rows -- against the unfused chain in the strict arithmetic, and with the conv's relu ->
+    dropout in the epilogue the kept share and the exact zeros are checked."""
+    import torch.nn.functional as F
+    from allset_amd import dense
+    n = 1_000_003
+    g = torch.Generator(device=device).manual_seed(21)
+    mk = lambda *s, sc=1.0, off=0.0: (torch.randn(*s, device=device, generator=g) * sc + off).requires_grad_(True)
+    pooled = mk(n, 128, sc=2.0)
+    att = mk(1, 4, 32, sc=0.5)
+    g0, b0, g1, b1 = mk(128, sc=0.2, off=1.0), mk(128, sc=0.3), mk(128, sc=0.2, off=1.0), mk(128, sc=0.3)
+    w1, w2 = mk(128, 128, sc=128 ** -0.5), mk(128, 128, sc=128 ** -0.5)
+    bb1, bb2 = mk(128, sc=0.1), mk(128, sc=0.1)
+    sign = torch.where(torch.arange(128, device=device) % 2 == 0, 5.0, -5.0)
+    with torch.no_grad():                       # ~2.6e8 relu inputs: off the kinks (tests/cases.py kinkfree_biases); the second Linear's
+        bb1 += sign; bb2 += 4 * sign            # input relu(. + 5) is not unit-scale (its Linear term has a deviation of ~3.5): +- 20
+    G = torch.randn(n, 128, device=device, generator=g)
+    params = [pooled, att, g0, b0, w1, bb1, w2, bb2, g1, b1]
+    y = dense.pma_tail(pooled, att, g0, b0, 1e-5, w1, bb1, w2, bb2, g1, b1, 1e-5, False, 0.0)
+    (y * G).sum().backward()
+    got = [t.grad.clone() for t in params]
+    rows = torch.cat([torch.arange(0, 64, device=device), torch.randint(0, n, (4000,), device=device, generator=g),
+                      torch.arange(n - 64, n, device=device)])
+    P = pooled.detach()[rows].double().requires_grad_(True)
+    pd = [t.detach().double() for t in params[1:]]
+    A, G0, B0, W1, BB1, W2, BB2, G1, B1 = pd
+    out = F.layer_norm(P + A.reshape(1, -1), (128,), G0, B0, 1e-5)
+    ref = F.layer_norm(out + F.relu(F.linear(F.relu(F.linear(out, W1, BB1)), W2, BB2)), (128,), G1, B1, 1e-5)
+    (ref * G[rows].double()).sum().backward()
+    torch.testing.assert_close(y.detach()[rows].double(), ref.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(got[0][rows].double(), P.grad, rtol=1e-4, atol=1e-4 * float(P.grad.abs().max()))
+    # parameter gradients: the unfused chain in the strict arithmetic on the same tensors
+    for t in params:
+        t.grad = None
+    with dense.arithmetic("strict"):
+        o2 = dense.layer_norm_res(pooled, att.reshape(-1), None, g0, b0, 1e-5)
+        y2 = dense.pma_residual_ff(o2, w1, bb1, w2, bb2, g1, b1, 1e-5, False, 0.0)
+        (y2 * G).sum().backward()
+    for nm, a, t in zip(["att_r", "ln0.w", "ln0.b", "w1", "b1", "w2", "b2", "ln1.w", "ln1.b"], got[1:], params[1:]):
+        # (sums of 1M signed terms in two different fp32 orders; measured against float64 both paths are within 4e-6 of the largest
+        #  element, tools/tail_diag_fullsize.py -- with the relus off their kinks: at +- 5 on the second bias a dozen of the 1.3e8
+        #  second-layer relu inputs sat within rounding of zero and these same gradients differed by 6e-4, the two paths flipping
+        #  different units)
+        scale = max(float(t.grad.abs().max()), 1e-6)
+        assert float((a - t.grad).abs().max()) <= 2e-5 * scale, (nm, float((a - t.grad).abs().max()), scale)
+    # with the conv's relu -> dropout(0.5) in the epilogue: half of the positive outputs survive, scaled by 2; nothing else changes
+    with torch.no_grad():
+        y0 = dense.pma_tail(pooled, att, g0, b0, 1e-5, w1, bb1, w2, bb2, g1, b1, 1e-5, True, 0.0)
+        yd = dense.pma_tail(pooled, att, g0, b0, 1e-5, w1, bb1, w2, bb2, g1, b1, 1e-5, True, 0.5)
+    kept = yd != 0
+    assert torch.equal(yd[kept], (2.0 * y0)[kept]) and not bool((kept & (y0 <= 0)).any())
+    share = float(kept[y0 > 0].float().mean())
+    assert abs(share - 0.5) < 2e-3, share
