@@ -454,7 +454,12 @@ def _bn_worker(rank, world, port, columns, q):
         sd0 = {k: v.clone().numpy() for k, v in model.state_dict().items()}
         adist._rank_dropout = lambda t, p, training: t            # the hard-wired input dropout (models.py:473) off
         ones = torch.ones(ei.shape[1], dtype=torch.int64)
-        if columns:
+        if columns == "hybrid":                                    # 2 target groups x world / 2 column groups (round 5)
+            cg, _ = adist.hybrid_groups(world, 2, rank)
+            hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=ones, row_groups=2, col_group=cg)
+            (e1, n1, k1), (e2, n2, k2) = hg.target_slices()
+            hg.v2e, hg.e2v, hg.ids_v2e, hg.ids_e2v = (e1, n1), (e2, n2), k1, k2
+        elif columns:
             hg = adist.ColumnShardedHypergraph(ei, n_v, n_e, world, rank, norm=ones, chunks=columns)
             hg.v2e = (ei, hg.n_e_pad)
             hg.e2v = (torch.stack([ei[1], ei[0]]), hg.n_v_pad)
@@ -478,13 +483,15 @@ def _bn_worker(rank, world, port, columns, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("columns", [0, 1])
+@pytest.mark.parametrize("columns", [0, 1, "hybrid"])
 def test_sharded_batchnorm_uses_the_statistics_of_the_whole_batch(columns):
+    """(``hybrid``: the whole two-layer model through ShardedSetGNN on four ranks = 2 target groups x 2 column groups; the batch
+    statistics run over the WORLD group, the exchanges over the world and the column groups.)"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import cases
     from oracle import allset_oracle as oracle
-    world = 2
+    world = 4 if columns == "hybrid" else 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -511,9 +518,10 @@ def test_sharded_batchnorm_uses_the_statistics_of_the_whole_batch(columns):
         for k, g in r[3].items():
             exp = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])      # (never-applied modules: zero-filled by allreduce_grads)
             torch.testing.assert_close(torch.from_numpy(g), exp, rtol=1e-3, atol=1e-4 * max(1.0, float(exp.abs().max())), msg=lambda m, k=k: f"{k}: {m}")
-    # running statistics: identical on both ranks, moved towards the whole batch's statistics exactly as torch moves them
-    for k in results[0][4]:
-        np.testing.assert_array_equal(results[0][4][k], results[1][4][k])
+    # running statistics: identical on every rank, moved towards the whole batch's statistics exactly as torch moves them
+    for r in results[1:]:
+        for k in results[0][4]:
+            np.testing.assert_array_equal(results[0][4][k], r[4][k])
     key = "V2EConvs.0.f_enc.normalizations.0"
     rm = torch.from_numpy(results[0][4][key + ".running_mean"])
     torch.testing.assert_close(rm, 0.1 * x.mean(0), rtol=1e-4, atol=1e-6)                      # InputNorm slot sees x itself
