@@ -63,6 +63,10 @@ SIGNATURES = {
     "allset_reduce_partials": [_P, c_int64, c_int64, _P, _P, _P],
     "allset_wgrad_fused_ex": [_P, c_int64, _P, c_int64, c_float, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, c_int64, c_int,
                               c_int64, c_int64, c_int64, c_int64, _P, _P, _P],
+    "allset_wgrad_f16x3_supported": [c_int64, c_int64],
+    "allset_wgrad_f16x3_slices": [c_int64, c_int64, c_int64, POINTER(c_int64)],
+    "allset_wgrad_f16x3": [_P, c_int64, _P, c_float, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, c_int64, c_int,
+                           c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_wgrad_fused": [_P, c_int64, _P, c_int64, c_float, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, _P,
                            c_int64, c_int64, c_int64, c_int64, _P, _P, _P],
     "allset_fused_linear_supported": [c_int64, c_int64],

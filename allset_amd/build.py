@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 BUILD_DIR = os.path.join(PKG_DIR, "csrc", "build")
 LIB_PATH = os.path.join(PKG_DIR, "liballset_hip.so")
 ARCH = "gfx950"
-SOURCES = ["abi.hip", "csr_build.hip", "segreduce.hip", "pma.hip", "dense.hip", "fused_mlp.hip", "fused_fwd2.hip", "fused_bwd.hip", "fused_bwd4.hip", "fused_bwd6.hip", "fused_bf16.hip", "batchnorm.hip", "input_linear.hip", "sparse_input.hip", "narrow_linear.hip", "wide_mlp.hip", "loss.hip", "optim.hip"]
+SOURCES = ["abi.hip", "csr_build.hip", "segreduce.hip", "pma.hip", "dense.hip", "fused_mlp.hip", "fused_fwd2.hip", "fused_bwd.hip", "fused_bwd4.hip", "fused_bwd6.hip", "fused_bf16.hip", "batchnorm.hip", "input_linear.hip", "sparse_input.hip", "narrow_linear.hip", "wide_mlp.hip", "wgrad_f16.hip", "loss.hip", "optim.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "allset_hip.h"), os.path.join(INCLUDE, "allset_hip_ext.h")]
 CXXFLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
             "-Wall", "-Wno-unused-function",

@@ -448,6 +448,7 @@ struct WgradPro {
   const uint64_t* seed_base;
   const uint32_t* mask; int mask_nh;        // activation mask (replaces y; bf16x6 kernels only), O / 64
   int64_t pw_stride = 0, pb_stride = 0;     // floats between consecutive slices of part_w / part_b (0: O*I and O)
+  int n_slices = 0;                         // > 0: the grid's y extent is rounded up to a multiple of 8 and remapped (wgrad_x6_kernel)
 };
 
 // out[s][c] = sum of part[p][c] over the s-th slab of kRedRows rows (p < P, c < M): one level of the tree that
@@ -560,9 +561,21 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
     float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int O, int I, int tiles_i,
     int64_t rows_per_slice, WgradPro pro) {
   __shared__ __attribute__((aligned(16))) uint32_t sP[2][2][3][kWgTile * 16];     // [buffer][A|B][plane][feature*16 + ..]
-  const int tile_o = blockIdx.x / tiles_i, tile_i = blockIdx.x % tiles_i;
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest).  With several 128 x 128 tiles per slice every
+  // half-row of ga / u is read by tiles_i (tiles_o) workgroups: in launch order those sit on DIFFERENT XCDs and each read goes to
+  // the fabric (2x the algorithmic bytes at 256 x 256, 4x at 512 x 512).  Remapped, XCD k owns ALL tiles of slices k, k + 8, ...:
+  // the co-resident tiles of a slice walk the same rows at the same time and the re-reads are hits in that XCD's L2.
+  int tile = blockIdx.x, slice = blockIdx.y;
+  if (pro.n_slices > 0) {
+    const int T = gridDim.x;
+    const int64_t L = static_cast<int64_t>(blockIdx.y) * T + blockIdx.x;
+    const int rem = static_cast<int>(L % (8 * T));
+    slice = static_cast<int>(L / (8 * T)) * 8 + (rem & 7);
+    tile = rem >> 3;
+    if (slice >= pro.n_slices) return;
+  }
+  const int tile_o = tile / tiles_i, tile_i = tile % tiles_i;
   const int o_base = tile_o * kWgTile, i_base = tile_i * kWgTile;
-  const int slice = blockIdx.y;
   const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
   const int64_t r_end = min(n, r_begin + rows_per_slice);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1638,6 +1651,13 @@ extern "C" int allset_relu_dropout_bwd(const float* gy, const float* y, float p,
   return ALLSET_OK;
 }
 
+// the launch grid of wgrad_x6_kernel: several tiles per slice -> y rounded up to a multiple of 8 and the XCD-aware remap switched on
+static inline dim3 wgrad_grid(int tiles, int64_t n_slices, WgradPro& pro) {
+  if (tiles == 1) { pro.n_slices = 0; return dim3(1u, static_cast<unsigned>(n_slices)); }
+  pro.n_slices = static_cast<int>(n_slices);
+  return dim3(static_cast<unsigned>(tiles), static_cast<unsigned>((n_slices + 7) / 8 * 8));
+}
+
 extern "C" int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices) {
   clear_error();
   ALLSET_REQUIRE(n_slices != nullptr && n >= 0 && O >= 1 && I >= 1, "wgrad_slices: bad argument");
@@ -1669,9 +1689,10 @@ extern "C" int allset_wgrad(const float* ga, int64_t lda, const float* u, int64_
   int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
   rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;
   if (rows_per_slice < kWgRows) rows_per_slice = kWgRows;
-  const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
+  WgradPro pro{};
+  const dim3 grid = wgrad_grid(tiles_o * tiles_i, n_slices, pro);
   wgrad_x6_kernel<false><<<grid, kWx6Block, 0, st>>>(ga, lda, u, ldu, part_w, part_b, n, static_cast<int>(O),
-                                                     static_cast<int>(I), tiles_i, rows_per_slice, WgradPro{});
+                                                     static_cast<int>(I), tiles_i, rows_per_slice, pro);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -1737,7 +1758,7 @@ static int wgrad_fused_impl(const float* gy, int64_t ldg, const float* y, int64_
   pro.relu_in = relu_in; pro.p_in = p_in; pro.seed_in = seed_in; pro.seed_base = seed_base;
   pro.mask = mask; pro.mask_nh = static_cast<int>(O / 64);
   pro.pw_stride = pw_stride; pro.pb_stride = pb_stride;
-  const dim3 grid(static_cast<unsigned>(tiles_o * tiles_i), static_cast<unsigned>(n_slices));
+  const dim3 grid = wgrad_grid(tiles_o * tiles_i, n_slices, pro);
   // no operand prologue at all (allset_wgrad through the one-buffer entry): the plain instantiation, 12 % faster
   const bool plain = y == nullptr && mask == nullptr && stats == nullptr && !relu_in && p_in == 0.f && p_out == 0.f;
   if (plain)

@@ -627,9 +627,19 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
     I = x.shape[1]
     lib = _lib.load()
     ns = c_int64(0)
+    M = O * I + (O if want_bias else 0)
+    if stats is not None and y is None and wide_f16() and lib.allset_wgrad_f16x3_supported(O, I):
+        # widths 256 / 512 behind a LayerNorm, auto / fp16x3 arithmetic: two fp16 planes per operand, 256 x 128 tiles (csrc/wgrad_f16.hip)
+        check(lib.allset_wgrad_f16x3_slices(n, O, I, byref(ns)), "allset_wgrad_f16x3_slices")
+        part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
+        with on_device(dev), _timed("wgrad_fused", dev, n * (O + I) * 4):
+            check(lib.allset_wgrad_f16x3(ptr(gy), _ld(gy), ptr(mask), p_out, ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()),
+                                         ptr(beta.contiguous()), int(relu_in), p_in, seed_in, ptr(part), M, int(want_bias), ns.value,
+                                         n, O, I, ptr(seed_base), stream_of(dev)), "allset_wgrad_f16x3")
+        red = reduce_partials(part)
+        return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
     check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
     # one partial buffer [slices, gW | gb] and one reduction launch (O and I are multiples of 4, checked by the kernel)
-    M = O * I + (O if want_bias else 0)
     part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
     with on_device(dev), _timed("wgrad_fused", dev, n * (O * (2 if (y is not None and mask is None) else 1) + I) * 4):
         check(lib.allset_wgrad_fused_ex(ptr(gy), _ld(gy), ptr(y), _ld(y) if y is not None else 0, p_out, ptr(x), _ld(x),

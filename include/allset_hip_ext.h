@@ -243,6 +243,18 @@ int allset_gemm_wide_lnb(int arith, const float* G, int64_t ldg, const float* ma
                          const void* planes, const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p,
                          uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows, int64_t N, int64_t K,
                          const uint64_t* seed_base, void* stream);
+/* The weight / bias gradient of a wide Linear behind a LayerNorm prologue on TWO fp16 planes per operand (csrc/wgrad_f16.hip; the
+ * ALLSET_ARITH_FP16X3 arithmetic): allset_wgrad_fused_ex's contract with `mask` the forward's 1-bit activation mask (NULL: the Linear has
+ * no relu / dropout epilogue; a fp32 mask source y is not taken) and stats / gamma / beta REQUIRED.  Built for O % 256 == 0,
+ * I % 128 == 0, I <= 512 (_supported); its own slice count (_slices).  gy is scaled per 32-row stage, u by one power of two for the
+ * launch times the stage's distance to the largest stage met so far -- the contract stated under "arithmetic" below: a gradient COLUMN
+ * more than 2^14 below the largest element of its stage loses low bits.  ALLSET_ARITH_BF16X6 callers use allset_wgrad_fused_ex. */
+int allset_wgrad_f16x3_supported(int64_t O, int64_t I);
+int allset_wgrad_f16x3_slices(int64_t n, int64_t O, int64_t I, int64_t* n_slices);
+int allset_wgrad_f16x3(const float* gy, int64_t ldg, const uint32_t* mask, float p_out, const float* x, int64_t ldx, const float* stats,
+                       const float* gamma, const float* beta, int relu_in, float p_in, uint64_t seed_in, float* part,
+                       int64_t part_stride, int want_bias, int64_t n_slices, int64_t n, int64_t O, int64_t I,
+                       const uint64_t* seed_base, void* stream);
 
 
 

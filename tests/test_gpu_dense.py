@@ -1547,3 +1547,79 @@ def test_narrow_linear_backward_without_input_gradient_and_deferred(device):
         assert lin.weight.grad is None and lin.bias.grad is None
     assert torch.equal(lin.weight.grad, ref[0]) and torch.equal(lin.bias.grad, ref[1])
     torch.testing.assert_close(ref[0], G.t() @ x, rtol=1e-4, atol=1e-4)
+
+
+def _mask_layout_words(active: np.ndarray) -> np.ndarray:
+    """[n, N] booleans -> the "mask layout" dwords of include/allset_hip_ext.h (N % 64 == 0)."""
+    n, N = active.shape
+    words = np.zeros(((n + 15) // 16) * (N // 64) * 32, dtype=np.uint32)
+    rows, cols = np.nonzero(active)
+    dword = ((rows // 16) * (N // 64) + cols // 64) * 32 + ((rows % 16) // 4) * 8 + (rows % 4) * 2 + (cols % 64) // 32
+    bit = (8 * (cols % 4) + (cols % 32) // 4).astype(np.uint32)
+    np.bitwise_or.at(words, dword, np.uint32(1) << bit)
+    return words
+
+
+@pytest.mark.parametrize("profile", ["flat", "rising", "spiky", "far"])
+@pytest.mark.parametrize("n,O,I,masked", [(1003, 256, 256, True), (40_001, 256, 256, True), (40_001, 256, 256, False),
+                                          (5000, 512, 256, True), (3000, 256, 128, True), (2500, 512, 512, True), (31, 256, 256, True)])
+def test_wgrad_f16x3_against_float64(n, O, I, masked, profile, device):
+    """csrc/wgrad_f16.hip (the 256 / 512-wide weight gradient on two fp16 planes, 256 x 128 tiles, per-stage windows with the online
+    rescale) against float64: `flat` ordinary data, `rising` gradient rows growing by 2^60 from the first row to the last (every stage
+    raises the window: the accumulators are rescaled again and again), `spiky` a few rows 2^12 above the rest (inside the window: full
+    accuracy even in the columns where the mask removes the large rows), `far` a few rows 2^40 above the rest -- OUTSIDE the window: the
+    contract (include/allset_hip_ext.h) is an absolute error below 2^-20 of (the largest |ga| met so far) x sum_r |u|, i.e. columns
+    where the mask removes the large rows lose the small rows' contribution; the strict arithmetic does not.  Error otherwise measured
+    against sum_r |ga| |u| (what a sequential fp32 sum is held to), with the strict kernel on the same inputs as the yardstick."""
+    from allset_amd import _lib, dense
+    assert _lib.load().allset_wgrad_f16x3_supported(O, I) == 1
+    g = torch.Generator().manual_seed(n + O + I)
+    x = (torch.randn(n, I, generator=g) * torch.exp(torch.randn(n, 1, generator=g))).to(device)
+    G = torch.randn(n, O, generator=g)
+    if profile == "rising":
+        G = G * torch.exp2(torch.linspace(-30, 30, n)).unsqueeze(1)
+    elif profile in ("spiky", "far"):
+        G[torch.randint(0, n, (max(n // 500, 1),), generator=g)] *= 2.0 ** (12 if profile == "spiky" else 40)
+    G = G.to(device)
+    gamma, beta = (1 + 0.2 * torch.randn(I, generator=g)).to(device), (0.3 * torch.randn(I, generator=g)).to(device)
+    p_out = 0.5 if masked else 0.0
+    active = np.random.default_rng(n).random((n, O)) > 0.45 if masked else None
+    mask = torch.from_numpy(_mask_layout_words(active).view(np.int32)).to(device) if masked else None
+    st = dense.row_stats(x, True, 1e-5)
+    with dense.arithmetic("fp16x3"):
+        gw, gb = dense.wgrad_fused(G, None, p_out, x, st, gamma, beta, True, 0.0, 0, mask=mask)
+    with dense.arithmetic("strict"):
+        gw6, gb6 = dense.wgrad_fused(G, None, p_out, x, st, gamma, beta, True, 0.0, 0, mask=mask)
+    ga = G.double()
+    if masked:
+        ga = ga * torch.from_numpy(active).to(device) / (1 - p_out)
+    u = F.layer_norm(torch.relu(x.double()), (I,), gamma.double(), beta.double(), 1e-5)
+    ref, refb = ga.t() @ u, ga.sum(0)
+    # the denominators: per element sum_r |ga| |u| -- and, for the windows' contract (a column far below its stage's largest element
+    # loses low bits), nothing is added: the three profiles scale ROWS, every column of a stage is of comparable size
+    den = ga.abs().t() @ u.abs()
+    err6 = float(((gw6.double() - ref).abs() / den).max())
+    # outside the window (`far`; `rising` when the whole 2^60 lies inside one 32-row stage): the contract's absolute bound, against the
+    # strict kernel (both evaluate u in fp32: with one row dominating a sum, float64's u differs from any fp32 u by more than that)
+    loose = profile == "far" or (profile == "rising" and n < 64)
+    bound = float(ga.abs().max()) * u.abs().sum(0, keepdim=True).expand_as(ref)
+    if loose:
+        assert float(((gw.double() - gw6.double()).abs() / bound).max()) <= 2.0 ** -20
+    else:
+        err = float(((gw.double() - ref).abs() / den).max())
+        assert err <= max(3e-7, 3.0 * err6), (err, err6)
+    denb = ga.abs().sum(0)
+    assert float(((gb.double() - refb).abs() / denb).max()) <= 3e-6
+    # with an input dropout the two arithmetics draw the same keep mask: compare them with each other
+    with dense.arithmetic("fp16x3"):
+        gwd, _ = dense.wgrad_fused(G, None, p_out, x, st, gamma, beta, True, 0.25, 77, mask=mask)
+    with dense.arithmetic("strict"):
+        gwd6, _ = dense.wgrad_fused(G, None, p_out, x, st, gamma, beta, True, 0.25, 77, mask=mask)
+    if loose:
+        assert float(((gwd.double() - gwd6.double()).abs() / (bound / 0.75)).max()) <= 2.0 ** -20
+    else:
+        assert float(((gwd.double() - gwd6.double()).abs() / (den / 0.75)).max()) <= 4e-6
+    for _ in range(2):                                                       # no atomics on the data path: bit-stable run to run
+        with dense.arithmetic("fp16x3"):
+            gw2, gb2 = dense.wgrad_fused(G, None, p_out, x, st, gamma, beta, True, 0.0, 0, mask=mask)
+        assert torch.equal(gw2, gw) and torch.equal(gb2, gb)
