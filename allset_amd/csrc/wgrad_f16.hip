@@ -286,6 +286,14 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
     b_off[t] = 2 * kWfPlaneA + fb * 16 + 4 * (fg ^ wf_swz(fb));
   }
   int Qacc = kWfEMin;                                                 // the accumulators are in units of 2^(140 + Su - Qacc)
+  // The two waves that share a SIMD (w and w + 4: waves are dealt to SIMDs cyclically) run a half trip's two phases in opposite order
+  // -- one multiplies while the other splits and stores (the phases touch different LDS buffers) -- so that the fragment reads and
+  // load waits of one are covered by the other's arithmetic instead of both stalling together (wide_mlp.hip's mfma_first).
+#ifdef ALLSET_ABL_WF_SAMEPHASE
+  const bool mfma_first = true;
+#else
+  const bool mfma_first = wave < 4;
+#endif
   auto mfma_stage = [&](int buf, int qb) {
     if (qb != Qacc) {                                                 // (uniform) the window moved up: bring the sums along
       const float s = wf_pow2(127 + Qacc - qb);
@@ -326,8 +334,10 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
   __syncthreads();
   int sl0 = 0, sl1 = 1, sl2 = 2;                                      // slots of stages k, k + 1, k + 2
   for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kWfRows) {
-    mfma_stage(0, q0);
+    const int qa = q0;
+    if (mfma_first) mfma_stage(0, qa);
     if (r0 + kWfRows < r_end) q1 = store_stage(s1, 1, sl1, r0 + kWfRows);
+    if (!mfma_first) mfma_stage(0, qa);
     load_stage(s1, r0 + 3 * kWfRows);
 #ifdef ALLSET_ABL_WF_POST          // (ablation builds: timing only, results wrong) post from the set that has had two half trips to land
     post_max(s1, sl2, r0 + 2 * kWfRows);
@@ -337,8 +347,10 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
     if (tid == 0) sMax[sl0] = 0u;
     WF_SYNC();
     if (r0 + kWfRows < r_end) {
-      mfma_stage(1, q1);
+      const int qb = q1;
+      if (mfma_first) mfma_stage(1, qb);
       if (r0 + 2 * kWfRows < r_end) q0 = store_stage(s0, 0, sl2, r0 + 2 * kWfRows);
+      if (!mfma_first) mfma_stage(1, qb);
       load_stage(s0, r0 + 4 * kWfRows);
 #ifdef ALLSET_ABL_WF_POST
       post_max(s0, sl0, r0 + 3 * kWfRows);

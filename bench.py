@@ -743,10 +743,11 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "dtype_note": ("fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: fp32 products formed on the 16-bit "
-                       "matrix pipes and accumulated in fp32 -- at 128 x 128 the forward behind a LayerNorm prologue and the one-pass "
-                       "backward: every operand scaled by a power of two and split into two fp16, three of the four partial products "
-                       "(fp16x3, per-product error <= 2^-21 relative); other shapes / prologues: every operand split exactly into "
-                       "three bf16, six of the nine partial products (bf16x6) -- measured error vs float64 at the level of "
+                       "matrix pipes and accumulated in fp32 -- at 128 x 128 (the forward and the one-pass backward) and in the tiled "
+                       "256 / 512-wide GEMMs and weight gradient: every operand scaled by a power of two and split into two fp16, three "
+                       "of the four partial products (fp16x3, per-product error <= 2^-21 relative); other shapes, and everything under "
+                       "--arith strict: every operand split exactly into three bf16, six of the nine partial products (bf16x6) -- "
+                       "measured error vs float64 at the level of "
                        "a native fp32 MFMA / library fp32 GEMM (DESIGN.md section 6.1, tests/test_gpu_dense.py)")
         if args.dtype == "f32" else
         ("bf16 tensors end to end (BASELINE configs[4] regime): bf16 instantiations of the gather kernels with fp32 "

@@ -15,7 +15,7 @@ gam = torch.ones(I, device=dev); bet = torch.zeros(I, device=dev)
 mask = torch.randint(-2**31, 2**31 - 1, ((n + 15) // 16 * (O // 64) * 32,), dtype=torch.int32, device=dev)
 P, I64, F, U64, Ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_int
 variants = [("full", []), ("no MFMA", ["-DALLSET_ABL_WF_NOMFMA"]), ("no barriers", ["-DALLSET_ABL_WF_NOBAR"]),
-            ("post from the older set", ["-DALLSET_ABL_WF_POST"]), ("no MFMA, post from the older set", ["-DALLSET_ABL_WF_NOMFMA", "-DALLSET_ABL_WF_POST"])]
+            ("both waves of a SIMD in the same phase order", ["-DALLSET_ABL_WF_SAMEPHASE"]), ("post from the older set", ["-DALLSET_ABL_WF_POST"]), ("no MFMA, post from the older set", ["-DALLSET_ABL_WF_NOMFMA", "-DALLSET_ABL_WF_POST"])]
 variants += [(a, a.split()) for a in sys.argv[1:] if a.startswith("-D")]
 if "--only" in sys.argv:
     variants = [v for v in variants if sys.argv[sys.argv.index("--only") + 1] == v[0]]
