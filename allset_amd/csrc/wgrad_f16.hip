@@ -9,7 +9,13 @@
 // operands twice and runs at a quarter of the HBM rate, the matrix pipe and the staging VALU work adding up on every SIMD
 // (DESIGN.md 6.4).  Here a workgroup owns a 256 (o) x 128 (i) tile -- ga is staged in whole rows, u once per i tile; the i tiles of a
 // slice sit on one XCD (the launch-order remap below), so the second read of ga is an L2 hit -- and a stage's 32 rows cost three
-// f16 MFMAs per 16 x 16 x 32 product instead of six bf16 ones.
+// f16 MFMAs per product instead of six bf16 ones.
+//
+// Staging is fused_bwd6.hip's: a lane owns 4 consecutive columns of ONE row in each 64-column block (16 lanes = 256 contiguous bytes of
+// a row per load instruction: 8 cache lines per wave instruction; the first version of this kernel packed ROW PAIRS per lane as
+// wgrad_x6_kernel does -- 16 rows x 64 bytes per instruction, a quarter of each line's tag lookups useful -- and its critical waves
+// spent a third of their cycles issuing loads), the two fp16 planes go to LDS ROW-major ([32 rows][256 B] images, XOR-swizzled) and
+// the reduction over rows reaches the MFMA through transposing reads (ds_read_b64_tr_b16, 32 x 32 x 16 MFMAs: fused_bwd6.hip's S3).
 //
 // fp16 has five exponent bits; every operand is brought into its window by a power of two (exact):
 //   ga   per STAGE (32 rows x 256 columns): the largest |gy| keep_out of the stage lands in [2^13, 2^14) (scale 2^(140 - e_k), e_k the
@@ -27,13 +33,15 @@
 namespace allset {
 
 using f16x8w_t = __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16;
-using f32x4w_t = __attribute__((ext_vector_type(4))) float;
-union WfFrag { uint4 u; f16x8w_t v; };
+using f32x16w_t = __attribute__((ext_vector_type(16))) float;
+typedef short wf_v4s_t __attribute__((ext_vector_type(4)));
+union WfFrag { uint4 u; f16x8w_t v; struct { wf_v4s_t lo, hi; } t; };
 constexpr int kWfBlock = 512;
-constexpr int kWfRows = 32;                          // rows per stage (the k extent of one MFMA)
+constexpr int kWfRows = 32;                          // rows per stage
 constexpr int kWfTO = 256, kWfTI = 128;              // the workgroup's tile of gW
-constexpr int kWfPlaneA = kWfTO * 16, kWfPlaneB = kWfTI * 16;       // dwords per plane: [feature][16 row pairs]
-constexpr int kWfBuf = 2 * kWfPlaneA + 2 * kWfPlaneB;               // dwords per buffer (48 KB)
+constexpr int kWfPlane = kWfRows * 256;              // bytes per fp16 plane of a 128-column image: [32 rows][256 B]
+constexpr int kWfImg = 2 * kWfPlane;                 // one image: planes h, l (16 KB)
+constexpr int kWfBuf = 3 * kWfImg;                   // a stage: ga columns 0..127, ga columns 128..255, u (48 KB)
 constexpr int kWfEMin = 20;                          // floor of a stage's biased exponent (stages below 2^-107 are treated as that small)
 
 struct WfArgs {
@@ -45,10 +53,6 @@ struct WfArgs {
   int64_t n; int O, I, tiles_i; int64_t rows_per_slice; int n_slices;
 };
 
-template <int CTRL>
-__device__ __forceinline__ float wf_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
 // max over the 16 lanes of a DPP row (v >= 0, no NaN handling wanted: one v_max_f32_dpp per step)
 __device__ __forceinline__ float wf_row16_max(float v) {
   asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -63,28 +67,40 @@ __device__ __forceinline__ float wf_amax4(float4 a, float m) {
   asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a.z), "v"(a.w));
   return m;
 }
+using wf_lds_u8 = __attribute__((address_space(3))) uint8_t;
+__device__ __forceinline__ uint32_t wf_lds_off(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((wf_lds_u8*)(p))); }
 // ds_max_u32 without the compiler's wave-reduction loop around an atomic on a uniform address (four lanes post per wave)
 __device__ __forceinline__ void wf_lds_max(uint32_t* p, uint32_t v) {
-  const uint32_t off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)(p)));
-  asm volatile("ds_max_u32 %0, %1" :: "v"(off), "v"(v) : "memory");
+  asm volatile("ds_max_u32 %0, %1" :: "v"(wf_lds_off(p)), "v"(v) : "memory");
 }
 // 2^(field - 127) for a biased exponent field; fields <= 0 give 0.0
 __device__ __forceinline__ float wf_pow2(int field) { return field > 0 ? __uint_as_float(static_cast<uint32_t>(field) << 23) : 0.f; }
-__device__ __forceinline__ int wf_swz(int feat) { return (((feat >> 2) & 3) >> 1) * 3; }      // dense.hip wx6_swz: the same LDS image
+// byte offset of (row, column byte) in a [32][256 B] 16-bit plane (fused_bwd6.hip img_off_s: conflict-free for the row-wise 8-byte
+// stores and for the transposing reads)
+__device__ __forceinline__ int wf_img_off(int row, int colbyte) {
+  return row * 256 + ((((colbyte >> 6) ^ row) & 3) << 6) + (((((colbyte >> 4) & 3) ^ (row >> 2)) & 3) << 4) + (colbyte & 15);
+}
+__device__ __forceinline__ f16x8w_t wf_tr_frag(uint32_t lo, uint32_t hi) {
+  WfFrag f;
+  f.t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) wf_v4s_t*>(static_cast<uintptr_t>(lo)));
+  f.t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) wf_v4s_t*>(static_cast<uintptr_t>(hi)));
+  return f.v;
+}
 
-// MK: the source of the forward's "output > 0" test on gy: 0 none (the Linear has no relu / dropout epilogue), 2 its 1-bit activation mask.
-// DROP: the input dropout's resolution (common.h drop_threshold): 0 none, 1 eight bits per element (one hash per four), 2 sixteen.
-// (Template parameters, not flags: a branch inside the staging path splits it into basic blocks the scheduler cannot mix, and on a
-// SIMD every vector instruction of that path is paid at the price of a quarter MFMA -- DESIGN.md 6.4.)
 #ifdef ALLSET_ABL_WF_NOBAR            // (ablation builds: timing only, results wrong)
 #define WF_SYNC() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
 #define WF_SYNC() __syncthreads()
 #endif
+// MK: the source of the forward's "output > 0" test on gy: 0 none (the Linear has no relu / dropout epilogue), 2 its 1-bit activation mask.
+// DROP: the input dropout's resolution (common.h drop_threshold): 0 none, 1 eight bits per element (one hash per four), 2 sixteen.
+// (Template parameters, not flags: a branch inside the staging path splits it into basic blocks the scheduler cannot mix, and on a
+// SIMD every vector instruction of that path is paid at the price of a quarter MFMA -- DESIGN.md 6.4.)
 template <int MK, int DROP>
 __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
-  __shared__ __attribute__((aligned(16))) uint32_t sP[2][kWfBuf];    // [buffer][A h | A l | B h | B l][feature * 16 + ..]
+  __shared__ __attribute__((aligned(1024))) uint8_t sP[2 * kWfBuf];  // (1 KB-aligned: fragment addresses are formed by XOR on the low bits)
   __shared__ __attribute__((aligned(16))) float sGB[2 * kWfTI];      // gamma | beta of this tile's input columns
+  __shared__ __attribute__((aligned(16))) float sRed[8 * kWfTO];     // the eight waves' bias column sums (epilogue)
   __shared__ uint32_t sMax[3];                                       // stage maxima (float bits), three stages in rotation
   __shared__ uint32_t sGBm[2];                                       // max |gamma|, max |beta| over the LayerNorm row
   // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest): remapped, XCD k owns ALL tiles of slices k, k + 8, ... --
@@ -102,37 +118,34 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int I = g.I;
   float* pw = g.part_w + static_cast<int64_t>(slice) * g.pw_stride;
-  // staging map: row pair rp of the 32-row stage; ga columns a_col..+3 and a_col + 128..+3, u columns u_col..+3
-  const int rp = lane & 15, cq = wave * 4 + (lane >> 4);
-  const int a_col = o_base + cq * 4, u_col = i_base + cq * 4;
-  const int w_off = cq * 64 + 4 * ((rp >> 2) ^ wf_swz(cq * 4)) + (rp & 3);          // + c * 16 for the quad's column c
+  const bool want_b = tile_i == 0 && g.part_b != nullptr;
   if (r_begin >= r_end) {                                             // an empty slice still owns a (zero) partial
     for (int e = tid; e < kWfTO * kWfTI; e += kWfBlock) pw[static_cast<int64_t>(o_base + e / kWfTI) * I + i_base + e % kWfTI] = 0.f;
-    if (tile_i == 0 && g.part_b != nullptr && tid < kWfTO) g.part_b[static_cast<int64_t>(slice) * g.pb_stride + o_base + tid] = 0.f;
+    if (want_b && tid < kWfTO) g.part_b[static_cast<int64_t>(slice) * g.pb_stride + o_base + tid] = 0.f;
     return;
   }
+  // staging map: row lr of the 32-row stage (one row per 16 lanes), columns 64 hb + 4 c .. + 3 of every 64-column block hb:
+  // four blocks of ga, two of u
+  const int c = lane & 15, lr = 4 * wave + (lane >> 4);
   const float keep_in = DROP ? 1.f / (1.f - g.p_in) : 1.f;
   const uint32_t thr_in = drop_threshold(g.p_in);
   const uint64_t seed_in = resolve_seed(g.seed_base, g.seed_in);
   const float relu_floor = g.relu_in ? 0.f : -INFINITY;               // fmaxf(t, floor): the relu without a branch
-  const int m_col = (a_col / 64) * 32 + (a_col % 64) / 32, m_bit = (a_col % 32) / 4;   // "mask layout" (include/allset_hip_ext.h)
-  float4 bsum0 = make_float4(0.f, 0.f, 0.f, 0.f), bsum1 = bsum0;
+  float4 bsum[4];
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) bsum[hb] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // Addresses = a UNIFORM base per stage (scalar registers, scalar arithmetic) + a 32-bit per-thread offset that is a constant of the
-  // thread in every full stage: the loads take the SGPR-base form and the staging path spends no vector instruction on 64-bit
-  // address arithmetic (the first version of this kernel: 100 of its 410 vector instructions per stage).  Only a slice's last,
-  // partial stage clamps its rows (a uniform branch).
+  // thread in every full stage; only a slice's last, partial stage clamps its rows (a uniform branch).
   const uint32_t ldg = static_cast<uint32_t>(g.ldg), ldx = static_cast<uint32_t>(g.ldx);
+  // "mask layout" (include/allset_hip_ext.h): block (row / 16, column / 64) of 32 dwords, dword (row % 16 / 4) * 8 + (row % 4) * 2 +
+  // (column % 64) / 32, bit 8 q + (column % 32) / 4 for column + q: this lane's dword of block hb, its bits at (c & 7) + 8 q
   auto mask_off = [&](int rl) -> uint32_t {
-    return static_cast<uint32_t>((rl >> 4) * (g.mask_nh * 32) + m_col + ((rl & 15) >> 2) * 8 + (rl & 3) * 2);
+    return static_cast<uint32_t>(((rl >> 4) * g.mask_nh + o_base / 64) * 32 + ((rl & 15) >> 2) * 8 + (rl & 3) * 2 + (c >> 3));
   };
-  uint32_t oa[2], ox[2], os[2], om[2];                               // of local rows 2 rp, 2 rp + 1
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    oa[h] = (2 * rp + h) * ldg + a_col; ox[h] = (2 * rp + h) * ldx + u_col; os[h] = (2 * rp + h) * 2; om[h] = mask_off(2 * rp + h);
-  }
+  const uint32_t oa0 = lr * ldg + o_base + 4 * c, ox0 = lr * ldx + i_base + 4 * c, os0 = lr * 2, om0 = mask_off(lr);
   const int64_t r_last = (r_end - 1) & ~static_cast<int64_t>(31);    // first row of the slice's last stage
-  struct Stage { float4 a0[2], a1[2], u[2]; float2 st[2]; uint32_t m0[2], m1[2]; };
+  struct Stage { float4 a[4], u[2]; float2 st; uint32_t m[4]; };
   auto load_stage = [&](Stage& sg, int64_t r0) {                      // issue only; stages past the end re-read the last one (never used)
     const int64_t rc = r0 < r_last ? r0 : r_last;
     const int rows_here = static_cast<int>(min(r_end - rc, static_cast<int64_t>(kWfRows)));
@@ -140,49 +153,43 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
     const float* xp = g.x + rc * g.ldx;
     const float* sp = g.stats + rc * 2;
     const uint32_t* mp = MK == 2 ? g.mask + (rc >> 4) * (g.mask_nh * 32) : nullptr;
-    uint32_t la[2] = {oa[0], oa[1]}, lx[2] = {ox[0], ox[1]}, ls[2] = {os[0], os[1]}, lm[2] = {om[0], om[1]};
+    uint32_t la = oa0, lx = ox0, ls = os0, lm = om0;
     if (rows_here < kWfRows) {                                        // (uniform) the partial stage: rows clamped to the last one
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int rl = min(2 * rp + h, rows_here - 1);
-        la[h] = rl * ldg + a_col; lx[h] = rl * ldx + u_col; ls[h] = rl * 2; lm[h] = mask_off(rl);
-      }
+      const int rl = min(lr, rows_here - 1);
+      la = rl * ldg + o_base + 4 * c; lx = rl * ldx + i_base + 4 * c; ls = rl * 2; lm = mask_off(rl);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      sg.a0[h] = *reinterpret_cast<const float4*>(gp + la[h]);
-      sg.a1[h] = *reinterpret_cast<const float4*>(gp + la[h] + 128);
-      sg.u[h] = *reinterpret_cast<const float4*>(xp + lx[h]);
-      if constexpr (MK == 2) { sg.m0[h] = mp[lm[h]]; sg.m1[h] = mp[lm[h] + 64]; }     // columns + 128: two 64-column blocks further
-      sg.st[h] = *reinterpret_cast<const float2*>(sp + ls[h]);
+    for (int hb = 0; hb < 4; ++hb) {
+      sg.a[hb] = *reinterpret_cast<const float4*>(gp + la + 64 * hb);
+      if constexpr (MK == 2) sg.m[hb] = mp[lm + 32 * hb];
     }
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) sg.u[hb] = *reinterpret_cast<const float4*>(xp + lx + 64 * hb);
+    sg.st = *reinterpret_cast<const float2*>(sp + ls);
   };
   // One stage ahead of the split: the forward's mask onto the registers (bit -> all-ones / zero -> AND with the float's bits), the
-  // stage's largest |ga| keep_out into its slot, and -- in the workgroups that own the bias partial -- the column sums of ga.
-  const bool want_b = tile_i == 0 && g.part_b != nullptr;
+  // stage's largest |ga| keep_out into its slot (the mask only removes elements: any bound of the unmasked row would do), and -- in
+  // the workgroups that own the bias partial -- the column sums of ga.
   auto post_max = [&](Stage& sg, int slot, int64_t r0) {
-    if constexpr (MK == 2) {
+    float m = 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int w0 = static_cast<int>(sg.m0[h]), w1 = static_cast<int>(sg.m1[h]);
-#define WF_MSK(v, w, sh) v = __int_as_float(__float_as_int(v) & __builtin_amdgcn_sbfe(w, m_bit + (sh), 1))
-        WF_MSK(sg.a0[h].x, w0, 0); WF_MSK(sg.a0[h].y, w0, 8); WF_MSK(sg.a0[h].z, w0, 16); WF_MSK(sg.a0[h].w, w0, 24);
-        WF_MSK(sg.a1[h].x, w1, 0); WF_MSK(sg.a1[h].y, w1, 8); WF_MSK(sg.a1[h].z, w1, 16); WF_MSK(sg.a1[h].w, w1, 24);
+    for (int hb = 0; hb < 4; ++hb) {
+      if constexpr (MK == 2) {
+        const int w = static_cast<int>(sg.m[hb]);
+#define WF_MSK(v, sh) v = __int_as_float(__float_as_int(v) & __builtin_amdgcn_sbfe(w, (c & 7) + (sh), 1))
+        WF_MSK(sg.a[hb].x, 0); WF_MSK(sg.a[hb].y, 8); WF_MSK(sg.a[hb].z, 16); WF_MSK(sg.a[hb].w, 24);
 #undef WF_MSK
       }
+      m = wf_amax4(sg.a[hb], m);
     }
-    float m = wf_amax4(sg.a0[0], 0.f);
-    m = wf_amax4(sg.a0[1], m); m = wf_amax4(sg.a1[0], m); m = wf_amax4(sg.a1[1], m);
     m = wf_row16_max(m) * g.keep_out;
-    if (rp == 0) wf_lds_max(&sMax[slot], __float_as_uint(m));
+    if (c == 0) wf_lds_max(&sMax[slot], __float_as_uint(m));
     if (want_b) {                                                     // (uniform)
-      const int rows_here = static_cast<int>(min(max(r_end - r0, static_cast<int64_t>(0)), static_cast<int64_t>(kWfRows)));
+      const float kk = lr < r_end - r0 ? g.keep_out : 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float kk = (2 * rp + h) < rows_here ? g.keep_out : 0.f;
-        const float4 a = sg.a0[h], b = sg.a1[h];
-        bsum0.x = fmaf(a.x, kk, bsum0.x); bsum0.y = fmaf(a.y, kk, bsum0.y); bsum0.z = fmaf(a.z, kk, bsum0.z); bsum0.w = fmaf(a.w, kk, bsum0.w);
-        bsum1.x = fmaf(b.x, kk, bsum1.x); bsum1.y = fmaf(b.y, kk, bsum1.y); bsum1.z = fmaf(b.z, kk, bsum1.z); bsum1.w = fmaf(b.w, kk, bsum1.w);
+      for (int hb = 0; hb < 4; ++hb) {
+        bsum[hb].x = fmaf(sg.a[hb].x, kk, bsum[hb].x); bsum[hb].y = fmaf(sg.a[hb].y, kk, bsum[hb].y);
+        bsum[hb].z = fmaf(sg.a[hb].z, kk, bsum[hb].z); bsum[hb].w = fmaf(sg.a[hb].w, kk, bsum[hb].w);
       }
     }
   };
@@ -212,35 +219,46 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
     const int eU = static_cast<int>(__float_as_uint(U) >> 23);
     S = 127 + min(max(140 - eU, -100), 100);
   }
-  const float4 g4 = *reinterpret_cast<const float4*>(sGB + cq * 4), be4 = *reinterpret_cast<const float4*>(sGB + kWfTI + cq * 4);
+  float4 g4[2], be4[2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    g4[hb] = *reinterpret_cast<const float4*>(sGB + 64 * hb + 4 * c);
+    be4[hb] = *reinterpret_cast<const float4*>(sGB + kWfTI + 64 * hb + 4 * c);
+  }
   int Q = kWfEMin;                                                    // the largest stage exponent met so far (uniform over the workgroup)
-  const uint32_t hp_lane = static_cast<uint32_t>(i_base / 4 + cq);   // dropout counter (element index / 4) = row * (I / 4) + this
+  // dropout counter (element index / 4) of (row, block hb) = row * (I / 4) + i_base / 4 + 16 hb + c
+  const uint32_t hp_lane = static_cast<uint32_t>(lr * (I / 4) + i_base / 4 + c);
+  const int wo0 = wf_img_off(lr, 8 * c), wo1 = wf_img_off(lr, 128 + 8 * c);     // column bytes 128 hb + 8 c of the lane's row
 
   auto store_stage = [&](Stage& sg, int buf, int slot, int64_t r0) -> int {   // returns the Q this stage was scaled against
     const int e = min(max(static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(sMax[slot])) >> 23), kWfEMin), 254);
     Q = max(Q, e);
     const float sa = wf_pow2(267 - e);                                // 2^(140 - e)
-    const float su = wf_pow2(S + e - Q);                              // 2^(Su + e - Q)
-    const int rows_here = static_cast<int>(min(r_end - r0, static_cast<int64_t>(kWfRows)));
-    // gamma / beta carry the launch scale, the stage's distance to the window and the dropout's 1 / keep
-    const float sk = su * keep_in;
-    const float4 gs = make_float4(g4.x * sk, g4.y * sk, g4.z * sk, g4.w * sk), bs = make_float4(be4.x * sk, be4.y * sk, be4.z * sk, be4.w * sk);
-    float4 va0[2], va1[2], vu[2];
+    const float sk = wf_pow2(S + e - Q) * keep_in;                    // 2^(Su + e - Q), and the dropout's 1 / keep
+    // rows past the slice's end were loaded from its last row: their ga is zeroed, so whatever u holds there is multiplied by zero
+    const float ks = lr < r_end - r0 ? g.keep_out * sa : 0.f;
+    uint8_t* img = sP + buf * kWfBuf;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      // rows past the slice's end were loaded from its last row: their ga is zeroed, so whatever u holds there is multiplied by zero
-      const float ks = (2 * rp + h) < rows_here ? g.keep_out * sa : 0.f;
-      const float4 a = sg.a0[h], b = sg.a1[h];
-      float4 t = sg.u[h];
-      va0[h] = make_float4(a.x * ks, a.y * ks, a.z * ks, a.w * ks);
-      va1[h] = make_float4(b.x * ks, b.y * ks, b.z * ks, b.w * ks);
+    for (int hb = 0; hb < 4; ++hb) {
+      const float4 a = sg.a[hb];
+      uint32_t h0, l0, h1, l1;
+      split2_f16c(a.x * ks, a.y * ks, h0, l0);
+      split2_f16c(a.z * ks, a.w * ks, h1, l1);
+      uint8_t* p = img + (hb >> 1) * kWfImg + ((hb & 1) ? wo1 : wo0);
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + kWfPlane) = make_uint2(l0, l1);
+    }
+    const float2 st = sg.st;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      float4 t = sg.u[hb];
+      const float4 gs = make_float4(g4[hb].x * sk, g4[hb].y * sk, g4[hb].z * sk, g4[hb].w * sk);
+      const float4 bs = make_float4(be4[hb].x * sk, be4[hb].y * sk, be4[hb].z * sk, be4[hb].w * sk);
       t.x = fmaxf(t.x, relu_floor); t.y = fmaxf(t.y, relu_floor); t.z = fmaxf(t.z, relu_floor); t.w = fmaxf(t.w, relu_floor);
-      const float2 st = sg.st[h];
       t.x = fmaf((t.x - st.x) * st.y, gs.x, bs.x); t.y = fmaf((t.y - st.x) * st.y, gs.y, bs.y);
       t.z = fmaf((t.z - st.x) * st.y, gs.z, bs.z); t.w = fmaf((t.w - st.x) * st.y, gs.w, bs.w);
       if constexpr (DROP != 0) {
-        // element index / 4 = (r0 + 2 rp + h) (I / 4) + i_base / 4 + cq: a uniform 64-bit part plus a 32-bit one
-        const int64_t quad = (r0 + h) * (I / 4) + static_cast<int64_t>(static_cast<uint32_t>(2 * rp * (I / 4)) + hp_lane);
+        const int64_t quad = r0 * (I / 4) + static_cast<int64_t>(hp_lane + 16u * hb);     // a uniform 64-bit part plus a 32-bit one
         if constexpr (DROP == 1) {
           const uint32_t hsh = pair_hash(seed_in, quad), t8 = thr_in & 0xffu;
           t.x = (hsh & 0xffu) >= t8 ? t.x : 0.f; t.y = ((hsh >> 8) & 0xffu) >= t8 ? t.y : 0.f;
@@ -250,45 +268,36 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
           t.x *= k.x; t.y *= k.y; t.z *= k.z; t.w *= k.w;
         }
       }
-      vu[h] = t;
+      uint32_t h0, l0, h1, l1;
+      split2_f16c(t.x, t.y, h0, l0);
+      split2_f16c(t.z, t.w, h1, l1);
+      uint8_t* p = img + 2 * kWfImg + (hb ? wo1 : wo0);
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + kWfPlane) = make_uint2(l0, l1);
     }
-    uint32_t* pa = &sP[buf][w_off];
-    uint32_t* pb = &sP[buf][2 * kWfPlaneA + w_off];
-    uint32_t hh, ll;
-    split2_f16c(va0[0].x, va0[1].x, hh, ll); pa[0] = hh; pa[kWfPlaneA] = ll;
-    split2_f16c(va0[0].y, va0[1].y, hh, ll); pa[16] = hh; pa[kWfPlaneA + 16] = ll;
-    split2_f16c(va0[0].z, va0[1].z, hh, ll); pa[32] = hh; pa[kWfPlaneA + 32] = ll;
-    split2_f16c(va0[0].w, va0[1].w, hh, ll); pa[48] = hh; pa[kWfPlaneA + 48] = ll;
-    split2_f16c(va1[0].x, va1[1].x, hh, ll); pa[128 * 16] = hh; pa[kWfPlaneA + 128 * 16] = ll;
-    split2_f16c(va1[0].y, va1[1].y, hh, ll); pa[128 * 16 + 16] = hh; pa[kWfPlaneA + 128 * 16 + 16] = ll;
-    split2_f16c(va1[0].z, va1[1].z, hh, ll); pa[128 * 16 + 32] = hh; pa[kWfPlaneA + 128 * 16 + 32] = ll;
-    split2_f16c(va1[0].w, va1[1].w, hh, ll); pa[128 * 16 + 48] = hh; pa[kWfPlaneA + 128 * 16 + 48] = ll;
-    split2_f16c(vu[0].x, vu[1].x, hh, ll); pb[0] = hh; pb[kWfPlaneB] = ll;
-    split2_f16c(vu[0].y, vu[1].y, hh, ll); pb[16] = hh; pb[kWfPlaneB + 16] = ll;
-    split2_f16c(vu[0].z, vu[1].z, hh, ll); pb[32] = hh; pb[kWfPlaneB + 32] = ll;
-    split2_f16c(vu[0].w, vu[1].w, hh, ll); pb[48] = hh; pb[kWfPlaneB + 48] = ll;
     return Q;
   };
 
-  // ---- MFMA side: 4 (o) x 2 (i) waves, wave tile 64 x 64 = 4 x 4 accumulators of 16 x 16; lane (fj, fg) reads piece fg of feature row fj
-  const int fj = lane & 15, fg = lane >> 4;
-  const int ob = (wave >> 1) * 64, ib = (wave & 1) * 64;
-  f32x4w_t acc[4][4];
-#pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) acc[ot][it] = f32x4w_t{0.f, 0.f, 0.f, 0.f};
-  int a_off[4], b_off[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int fa = ob + t * 16 + fj, fb = ib + t * 16 + fj;
-    a_off[t] = fa * 16 + 4 * (fg ^ wf_swz(fa));
-    b_off[t] = 2 * kWfPlaneA + fb * 16 + 4 * (fg ^ wf_swz(fb));
+  // ---- MFMA side (fused_bwd6.hip S3): 4 (o) x 2 (i) waves, wave tile 64 x 64 = 2 x 2 accumulators of 32 x 32; K = the stage's 32 rows
+  // in two steps of 16; A = ga^T, B = u, both through transposing reads of the row-major images.
+  //   row 16 kb + tr_row + 4 hi, column byte 64 (2 blk + tl) + tr_in:  base ^ (tl << 6) ^ (hi << 4), + 4096 kb + 1024 hi
+  const int oh = wave >> 1, ih = wave & 1;                            // o in [64 oh, +64) of the tile's 256, i in [64 ih, +64) of its 128
+  uint32_t base_a, base_u;
+  {
+    const int q4 = lane >> 4, tr_row = 8 * (q4 >> 1) + ((lane & 15) >> 2), tr_in = 32 * (q4 & 1) + 8 * (lane & 3);
+    base_a = wf_lds_off(sP) + static_cast<uint32_t>((oh >> 1) * kWfImg + wf_img_off(tr_row, 64 * (2 * (oh & 1)) + tr_in));
+    base_u = wf_lds_off(sP) + static_cast<uint32_t>(2 * kWfImg + wf_img_off(tr_row, 64 * (2 * ih) + tr_in));
   }
+  f32x16w_t gw[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gw[a][b][q] = 0.f;
   int Qacc = kWfEMin;                                                 // the accumulators are in units of 2^(140 + Su - Qacc)
   // The two waves that share a SIMD (w and w + 4: waves are dealt to SIMDs cyclically) run a half trip's two phases in opposite order
-  // -- one multiplies while the other splits and stores (the phases touch different LDS buffers) -- so that the fragment reads and
-  // load waits of one are covered by the other's arithmetic instead of both stalling together (wide_mlp.hip's mfma_first).
+  // -- one multiplies while the other splits and stores (the phases touch different LDS buffers).
 #ifdef ALLSET_ABL_WF_SAMEPHASE
   const bool mfma_first = true;
 #else
@@ -298,31 +307,36 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
     if (qb != Qacc) {                                                 // (uniform) the window moved up: bring the sums along
       const float s = wf_pow2(127 + Qacc - qb);
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) acc[ot][it] *= s;
+        for (int b = 0; b < 2; ++b) gw[a][b] *= s;
       Qacc = qb;
     }
 #ifdef ALLSET_ABL_WF_NOMFMA          // (ablation builds: timing only)
     return;
 #endif
-    WfFrag b[4][2];
+    const uint32_t ia = base_a + static_cast<uint32_t>(buf * kWfBuf), iu = base_u + static_cast<uint32_t>(buf * kWfBuf);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int kb = 0; kb < 2; ++kb) {
+      f16x8w_t wa[2][2], wb[2][2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) b[it][pl].u = *reinterpret_cast<const uint4*>(&sP[buf][pl * kWfPlaneB + b_off[it]]);
+      for (int tl = 0; tl < 2; ++tl) {
+        const uint32_t a_lo = (ia ^ static_cast<uint32_t>(tl << 6)) + kb * 4096, a_hi = (ia ^ static_cast<uint32_t>((tl << 6) | 16)) + kb * 4096 + 1024;
+        const uint32_t b_lo = (iu ^ static_cast<uint32_t>(tl << 6)) + kb * 4096, b_hi = (iu ^ static_cast<uint32_t>((tl << 6) | 16)) + kb * 4096 + 1024;
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) {
-      WfFrag a[2];
+        for (int pl = 0; pl < 2; ++pl) {
+          wa[tl][pl] = wf_tr_frag(a_lo + pl * kWfPlane, a_hi + pl * kWfPlane);
+          wb[tl][pl] = wf_tr_frag(b_lo + pl * kWfPlane, b_hi + pl * kWfPlane);
+        }
+      }
+      constexpr int PA_[3] = {1, 0, 0}, PB_[3] = {0, 1, 0};          // l.h, h.l, h.h
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) a[pl].u = *reinterpret_cast<const uint4*>(&sP[buf][pl * kWfPlaneA + a_off[ot]]);
-      // smallest products first; four independent accumulators between two MFMAs into the same one
-#pragma unroll
-      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1].v, b[it][0].v, acc[ot][it], 0, 0, 0);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, b[it][1].v, acc[ot][it], 0, 0, 0);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0].v, b[it][0].v, acc[ot][it], 0, 0, 0);
+      for (int pr = 0; pr < 3; ++pr) {
+        gw[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][PA_[pr]], wb[0][PB_[pr]], gw[0][0], 0, 0, 0);
+        gw[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][PA_[pr]], wb[0][PB_[pr]], gw[1][0], 0, 0, 0);
+        gw[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[0][PA_[pr]], wb[1][PB_[pr]], gw[0][1], 0, 0, 0);
+        gw[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[1][PA_[pr]], wb[1][PB_[pr]], gw[1][1], 0, 0, 0);
+      }
     }
   };
 
@@ -333,62 +347,81 @@ __global__ __launch_bounds__(kWfBlock) void wgrad_f16_kernel(WfArgs g) {
   load_stage(s0, r_begin + 2 * kWfRows);
   __syncthreads();
   int sl0 = 0, sl1 = 1, sl2 = 2;                                      // slots of stages k, k + 1, k + 2
+#ifdef ALLSET_ABL_WF_TIMING         // diagnostic builds only: cycles per segment of waves 0 and 4 of workgroup (0, 0)
+  uint64_t tph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define WF_MARK(k) do { const uint64_t tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define WF_MARK(k) do {} while (0)
+#endif
   for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kWfRows) {
     const int qa = q0;
     if (mfma_first) mfma_stage(0, qa);
+    WF_MARK(0);
     if (r0 + kWfRows < r_end) q1 = store_stage(s1, 1, sl1, r0 + kWfRows);
+    WF_MARK(1);
     if (!mfma_first) mfma_stage(0, qa);
+    WF_MARK(0);
     load_stage(s1, r0 + 3 * kWfRows);
-#ifdef ALLSET_ABL_WF_POST          // (ablation builds: timing only, results wrong) post from the set that has had two half trips to land
-    post_max(s1, sl2, r0 + 2 * kWfRows);
-#else
+    WF_MARK(2);
     post_max(s0, sl2, r0 + 2 * kWfRows);
-#endif
+    WF_MARK(3);
     if (tid == 0) sMax[sl0] = 0u;
     WF_SYNC();
+    WF_MARK(4);
     if (r0 + kWfRows < r_end) {
       const int qb = q1;
       if (mfma_first) mfma_stage(1, qb);
+      WF_MARK(0);
       if (r0 + 2 * kWfRows < r_end) q0 = store_stage(s0, 0, sl2, r0 + 2 * kWfRows);
+      WF_MARK(1);
       if (!mfma_first) mfma_stage(1, qb);
+      WF_MARK(0);
       load_stage(s0, r0 + 4 * kWfRows);
-#ifdef ALLSET_ABL_WF_POST
-      post_max(s0, sl0, r0 + 3 * kWfRows);
-#else
+      WF_MARK(2);
       post_max(s1, sl0, r0 + 3 * kWfRows);
-#endif
+      WF_MARK(3);
       if (tid == 0) sMax[sl1] = 0u;
       WF_SYNC();
+      WF_MARK(4);
     }
     const int t0 = sl0; sl0 = sl2; sl2 = sl1; sl1 = t0;               // two stages on: (k, k+1, k+2) -> (k+2, k+3, k+4) = slots (sl2, sl0, sl1)
   }
 
-  // ---- epilogue: partial tile -> part_w[slice][O][I], unscaled; acc[ot][it][r] is (o = .. + 4 fg + r, i = .. + fj)
+  // ---- epilogue: partial tile -> part_w[slice][O][I], unscaled; gw[a][b][q] is (o = 64 oh + 32 a + (q & 3) + 8 (q >> 2) + 4 (lane >> 5),
+  // i = 64 ih + 32 b + (lane & 31))
   const float f1 = wf_pow2(Qacc - 13), f2 = wf_pow2(254 - S);         // 2^(Qacc - 140) 2^(-Su)
 #pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = i_base + ib + it * 16 + fj;
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = o_base + ob + ot * 16 + 4 * fg + r;
-        pw[static_cast<int64_t>(o) * I + i] = acc[ot][it][r] * f1 * f2;
+      for (int q = 0; q < 16; ++q) {
+        const int o = o_base + 64 * oh + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        const int i = i_base + 64 * ih + 32 * b + (lane & 31);
+        pw[static_cast<int64_t>(o) * I + i] = (gw[a][b][q] * f1) * f2;
       }
-    }
-  // bias partial: the 16 row-pair lanes of a column quad fold by shuffles (only i-tile 0 writes)
-  if (tile_i == 0 && g.part_b != nullptr) {
+#ifdef ALLSET_ABL_WF_TIMING
+  // wave 0 / wave 4 of the first workgroup: [0] MFMA phase, [1] split + LDS stores, [2] load issue, [3] maximum post, [4] barrier (cycles, all stages)
+  __syncthreads();
+  if (slice == 0 && tile == 0 && (tid == 0 || tid == 256)) for (int q = 0; q < 5; ++q) pw[(tid ? 8 : 0) + q] = static_cast<float>(tph[q]);
+#endif
+  // bias partial: the four row groups of a lane column fold by shuffles, the eight waves through LDS in a fixed order (only i-tile 0)
+  if (want_b) {
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-      bsum0.x += __shfl_xor(bsum0.x, off); bsum0.y += __shfl_xor(bsum0.y, off);
-      bsum0.z += __shfl_xor(bsum0.z, off); bsum0.w += __shfl_xor(bsum0.w, off);
-      bsum1.x += __shfl_xor(bsum1.x, off); bsum1.y += __shfl_xor(bsum1.y, off);
-      bsum1.z += __shfl_xor(bsum1.z, off); bsum1.w += __shfl_xor(bsum1.w, off);
+    for (int hb = 0; hb < 4; ++hb) {
+      float4 v = bsum[hb];
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+      }
+      if (lane < 16) *reinterpret_cast<float4*>(&sRed[wave * kWfTO + 64 * hb + 4 * lane]) = v;
     }
-    if (rp == 0) {
-      float* pbv = g.part_b + static_cast<int64_t>(slice) * g.pb_stride + a_col;
-      *reinterpret_cast<float4*>(pbv) = bsum0;
-      *reinterpret_cast<float4*>(pbv + 128) = bsum1;
+    __syncthreads();
+    if (tid < kWfTO) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += sRed[w * kWfTO + tid];
+      g.part_b[static_cast<int64_t>(slice) * g.pb_stride + o_base + tid] = s;
     }
   }
 }

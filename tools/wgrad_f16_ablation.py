@@ -16,6 +16,7 @@ mask = torch.randint(-2**31, 2**31 - 1, ((n + 15) // 16 * (O // 64) * 32,), dtyp
 P, I64, F, U64, Ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_int
 variants = [("full", []), ("no MFMA", ["-DALLSET_ABL_WF_NOMFMA"]), ("no barriers", ["-DALLSET_ABL_WF_NOBAR"]),
             ("both waves of a SIMD in the same phase order", ["-DALLSET_ABL_WF_SAMEPHASE"]), ("post from the older set", ["-DALLSET_ABL_WF_POST"]), ("no MFMA, post from the older set", ["-DALLSET_ABL_WF_NOMFMA", "-DALLSET_ABL_WF_POST"])]
+variants += [("segment timing", ["-DALLSET_ABL_WF_TIMING"]), ("segment timing, no MFMA", ["-DALLSET_ABL_WF_TIMING", "-DALLSET_ABL_WF_NOMFMA"])]
 variants += [(a, a.split()) for a in sys.argv[1:] if a.startswith("-D")]
 if "--only" in sys.argv:
     variants = [v for v in variants if sys.argv[sys.argv.index("--only") + 1] == v[0]]
@@ -42,3 +43,8 @@ for name, flags in variants:
         a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = statistics.median(ts)
     print(f"{name:40s} {ms*1e3:7.0f} us  ({n * (O + I) * 4 / ms / 1e6:.0f} GB/s)  slices {ns.value}", flush=True)
+    if "-DALLSET_ABL_WF_TIMING" in flags:
+        t = part[0, :16].tolist()
+        for w, o in (("wave 0 (MFMA first)", 0), ("wave 4 (split first)", 8)):
+            tot = sum(t[o:o + 5]) or 1.0
+            print(f"    {w}: MFMA {t[o]/tot:.2f}  split+store {t[o+1]/tot:.2f}  load issue {t[o+2]/tot:.2f}  post {t[o+3]/tot:.2f}  barrier {t[o+4]/tot:.2f}   ({tot/1e6:.2f} Mcycles)", flush=True)
