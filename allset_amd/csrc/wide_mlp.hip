@@ -11,6 +11,8 @@
 // wave copies per step side by side: gx_image_at; 384 KB per 256 x 256 weight, L2-resident).  Double-buffered: 144 KB of the 160 KB LDS, one workgroup of 8 waves per CU.
 // Per step and wave: 24 ds_read_b128 feed 96 MFMAs (16 accumulator tiles x 6 plane products) -- the kernel is meant to
 // be matrix-pipe-bound: 2*rows*N*K*6 flop at the bf16 rate is ~1.6x the HBM time of its operands at K = N = 256.
+#include <type_traits>
+
 #include "common.h"
 
 namespace allset {
@@ -180,6 +182,10 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   const int64_t total = (rows + kGxBM - 1) / kGxBM * n_tiles;           // tiles; a workgroup walks tiles b, b + grid, ...
   const int ksteps = K / kGxKS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the wave's index as a SCALAR: everything the epilogues derive from "this wave's row" (64-bit row offsets, dropout counters, the
+  // mask word's address) is then scalar arithmetic -- as tid >> 6 the compiler keeps it per lane, and the forward's row pass spent as
+  // many vector instructions per tile as the whole K loop, a third of them 64-bit address arithmetic (tools/gemm_wide_ablation.py)
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint64_t seed_in = resolve_seed(seed_base, pro.seed_in), seed_out = resolve_seed(seed_base, epi.seed_out);
   const float inv_mask = pro.p_mask > 0.f ? 1.f / (1.f - pro.p_mask) : 1.f;
   const float inv_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
@@ -243,35 +249,44 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     }                                                                                           \
   } while (0)
 
-  auto prologue2 = [&](const GxRow& c, float a0, float a1, float y0, float y1, int kk, float& o0, float& o1) {
-    if constexpr (YM != 0) { a0 = y0 > 0.f ? a0 * inv_mask : 0.f; a1 = y1 > 0.f ? a1 * inv_mask : 0.f; }
-    if (pro.relu_in) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
+  // The prologue on the thread's 8 consecutive elements of a K step (columns kb .. kb + 7 of its row): ONE uniform branch per switch and
+  // step (it was one per element pair), the dropout by two quad hashes (four pair hashes), its 1 / keep folded into the LDS copy of
+  // gamma / beta, and no zeroing of rows past the end -- they re-read the last row and their output rows are never stored
+  // (tools/gemm_wide_ablation.py: prologue + split + stores were a third of the critical waves' cycles).
+  auto stage8 = [&](const GxRow& c, int kb, float (&e)[8]) {
+    e[0] = pa0.x; e[1] = pa0.y; e[2] = pa0.z; e[3] = pa0.w; e[4] = pa1.x; e[5] = pa1.y; e[6] = pa1.z; e[7] = pa1.w;
+    if constexpr (YM != 0) {
+      const float y[8] = {py0.x, py0.y, py0.z, py0.w, py1.x, py1.y, py1.z, py1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = y[i] > 0.f ? e[i] * inv_mask : 0.f;
+    }
+    if (pro.relu_in) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = fmaxf(e[i], 0.f);
+    }
     if (pro.stats) {
-      const float2 g = *reinterpret_cast<const float2*>(sGB + kk), b = *reinterpret_cast<const float2*>(sGB + 512 + kk);
-      a0 = fmaf((a0 - c.mean) * c.rstd, g.x, b.x);
-      a1 = fmaf((a1 - c.mean) * c.rstd, g.y, b.y);
+      const float4 g0 = *reinterpret_cast<const float4*>(sGB + kb), g1 = *reinterpret_cast<const float4*>(sGB + kb + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sGB + 512 + kb), b1 = *reinterpret_cast<const float4*>(sGB + 512 + kb + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = fmaf((e[i] - c.mean) * c.rstd, g[i], b[i]);
+      if (pro.p_in > 0.f) {                                            // (an input dropout comes with a LayerNorm: wide_linear_supported)
+        const float4 k0 = keep_scale4(seed_in, c.g_row * K + kb, thr_in, 1.f), k1 = keep_scale4(seed_in, c.g_row * K + kb + 4, thr_in, 1.f);
+        e[0] *= k0.x; e[1] *= k0.y; e[2] *= k0.z; e[3] *= k0.w; e[4] *= k1.x; e[5] *= k1.y; e[6] *= k1.z; e[7] *= k1.w;
+      }
     }
-    if (pro.p_in > 0.f) {
-      float k0, k1;
-      keep_scale2(seed_in, c.g_row * K + kk, thr_in, inv_in, k0, k1);
-      a0 *= k0; a1 *= k1;
-    }
-    o0 = c.ok ? a0 : 0.f;
-    o1 = c.ok ? a1 : 0.f;
   };
 #define GX_STORE(ctx_, ks_, buf_)                                                               \
   do {                                                                                          \
     const int kb_ = (ks_) * kGxKS + s_seg * 8;                                                  \
-    if constexpr (YM == 2) {   /* bits 8 q + 2 s_seg (+ 1): columns kb + q (kb + 4 + q) of the row -> the signs prologue2 tests */ \
+    if constexpr (YM == 2) {   /* bits 8 q + 2 s_seg (+ 1): columns kb + q (kb + 4 + q) of the row -> the signs stage8 tests */ \
       const uint32_t b_ = pm >> (2 * s_seg);                                                    \
       py0 = make_float4((b_ & 0x1u) ? 1.f : 0.f, (b_ & 0x100u) ? 1.f : 0.f, (b_ & 0x10000u) ? 1.f : 0.f, (b_ & 0x1000000u) ? 1.f : 0.f); \
       py1 = make_float4((b_ & 0x2u) ? 1.f : 0.f, (b_ & 0x200u) ? 1.f : 0.f, (b_ & 0x20000u) ? 1.f : 0.f, (b_ & 0x2000000u) ? 1.f : 0.f); \
     }                                                                                           \
-    float e0, e1, e2, e3, e4, e5, e6, e7;                                                       \
-    prologue2(ctx_, pa0.x, pa0.y, py0.x, py0.y, kb_, e0, e1);                                   \
-    prologue2(ctx_, pa0.z, pa0.w, py0.z, py0.w, kb_ + 2, e2, e3);                               \
-    prologue2(ctx_, pa1.x, pa1.y, py1.x, py1.y, kb_ + 4, e4, e5);                               \
-    prologue2(ctx_, pa1.z, pa1.w, py1.z, py1.w, kb_ + 6, e6, e7);                               \
+    float ee_[8];                                                                               \
+    stage8(ctx_, kb_, ee_);                                                                     \
+    const float e0 = ee_[0], e1 = ee_[1], e2 = ee_[2], e3 = ee_[3], e4 = ee_[4], e5 = ee_[5], e6 = ee_[6], e7 = ee_[7]; \
     uint4 h_, m_, l_;                                                                           \
     if constexpr (F16) {                                                                        \
       const float sc_ = (ctx_).asc;                                                             \
@@ -353,6 +368,12 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     }
   };
 
+#ifdef ALLSET_ABL_GX_TIMING         // diagnostic builds only (tools/gemm_wide_ablation.py): cycles per segment of waves 0 and 4 of workgroup 0
+  uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define GX_MARK(k) do { const uint64_t tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define GX_MARK(k) do {} while (0)
+#endif
   const uint64_t lnb_seed = resolve_seed(seed_base, epi.lnb_seed);
   const float lnb_inv = epi.lnb_p > 0.f ? 1.f / (1.f - epi.lnb_p) : 1.f;
   const uint32_t lnb_thr = drop_threshold(epi.lnb_p);
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   }
   float launch_inv = 1.f;                                              // fp16x3 behind a LayerNorm: 2^-Su, undone in the epilogue
   if (pro.stats) {
-    for (int i = threadIdx.x; i < K; i += kGxThreads) { sGB[i] = pro.gamma[i]; sGB[512 + i] = pro.beta[i]; }
+    for (int i = threadIdx.x; i < K; i += kGxThreads) { sGB[i] = pro.gamma[i] * inv_in; sGB[512 + i] = pro.beta[i] * inv_in; }     // (the dropout's 1 / keep rides along)
     __syncthreads();
     if constexpr (F16) {
       // |u| <= (sqrt(K - 1) max|gamma| + max|beta|) keep: one power of two 2^Su brings every A element below 2^14
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       for (int i = lane; i < K; i += 64) { g = fmaxf(g, fabsf(sGB[i])); bm = fmaxf(bm, fabsf(sGB[512 + i])); }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { g = fmaxf(g, __shfl_xor(g, off)); bm = fmaxf(bm, __shfl_xor(bm, off)); }
-      const float U = (sqrtf(static_cast<float>(K)) * g + bm) * inv_in;
+      const float U = sqrtf(static_cast<float>(K)) * g + bm;           // (g, bm carry 1 / keep already)
       const int eU = static_cast<int>(__float_as_uint(U) >> 23);       // U < 2^(eU - 126)
       const int Su = min(max(140 - eU, -100), 100);
       const float su = __uint_as_float(static_cast<uint32_t>(127 + Su) << 23);
@@ -405,9 +426,13 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    GX_MARK(4);
     GX_STORE(cur, 0, 0);                                               // step 0 of this tile (loaded during the previous one)
+    GX_MARK(1);
     if (ksteps > 1) GX_LOAD(cur, img_cur, 1); else if (has_next) GX_LOAD(nxt, img_nxt, 0);
+    GX_MARK(2);
     __syncthreads();
+    GX_MARK(3);
     // MFMAs out of buffer ks & 1; the registers (step ks + 1) go to the other buffer and reload with step ks + 2 -- of the
     // next tile when this one has no such step; the last step only multiplies (the arena turns into the output tile next, the
     // registers keep the next tile's step 0).  Two steps per trip so that the buffer index is a compile-time constant: every
@@ -423,16 +448,23 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
         la1 = *reinterpret_cast<const float4*>(nxt.a + ks_ * kGxKS + 4);                        \
       }                                                                                         \
     }                                                                                           \
+    GX_MARK(2);                                                                                 \
     if (mfma_first) compute(BUF_);                                                              \
+    GX_MARK(0);                                                                                 \
     if (!last_) {                                                                               \
       GX_STORE(cur, ks_ + 1, (BUF_) ^ 1);                                                       \
+      GX_MARK(1);                                                                               \
       if (ks_ + 2 < ksteps) GX_LOAD(cur, img_cur, ks_ + 2); else if (has_next) GX_LOAD(nxt, img_nxt, 0); \
+      GX_MARK(2);                                                                               \
     }                                                                                           \
     if (!mfma_first) compute(BUF_);                                                             \
+    GX_MARK(0);                                                                                 \
     if constexpr (F16) { if (rowsc && has_next) nmax = amax8(la0, la1, nmax); }                 \
+    GX_MARK(5);                                                                                 \
     /* LDS traffic must have landed; the global loads just issued stay in flight ACROSS the barrier (__syncthreads()   \
        would drain them: s_waitcnt vmcnt(0), one exposed memory latency per step) */                                   \
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
+    GX_MARK(3);                                                                                 \
   } while (0)
     for (int ks = 0; ks < ksteps; ks += 2) {
       GX_STEP(ks, 0);
@@ -464,17 +496,19 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       static_assert(kLnbIter <= 64, "one lane per row of the wave");
 #pragma unroll
       for (int i = 0; i < kLnbIter; ++i) {
-        const int64_t row = row0 + (tid >> 6) + i * (kGxThreads / 64);
+        const int64_t row = row0 + wave_u + i * (kGxThreads / 64);
         const int64_t rc = row < rows ? row : rows - 1;
         lnb_xp[i] = n < N ? *reinterpret_cast<const float4*>(epi.lnb_x + rc * epi.lnb_ldx + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       {
         const int li = (tid & 63) < kLnbIter ? (tid & 63) : kLnbIter - 1;
-        const int64_t row = row0 + (tid >> 6) + li * (kGxThreads / 64);
+        const int64_t row = row0 + wave_u + li * (kGxThreads / 64);
         lnb_sp = *reinterpret_cast<const float2*>(epi.lnb_stats + (row < rows ? row : rows - 1) * 2);
       }
     }
+    GX_MARK(6);
     __syncthreads();
+    GX_MARK(7);
     float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);                      // fp16x3: the inverse scales of the lane's four B columns
     if constexpr (F16) cs4 = *reinterpret_cast<const float4*>(bscale + n);       // (bscale has n_pad entries: always in range)
     if constexpr (LNB) {
@@ -486,7 +520,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       if (act) g4 = *reinterpret_cast<const float4*>(epi.lnb_gamma + n);
 #pragma unroll
       for (int it = 0; it < kLnbIter; ++it) {
-        const int rr = (tid >> 6) + it * (kGxThreads / 64);
+        const int rr = wave_u + it * (kGxThreads / 64);
         const int64_t row = row0 + rr;
         if (row >= rows) continue;                                     // (wave-uniform)
         float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -530,42 +564,66 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     if (!LNB && n < N) {                                               // N % 4 == 0: a packet is inside or outside
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (epi.bias) bv = *reinterpret_cast<const float4*>(epi.bias + n);
-      for (int rr = tid >> 6; rr < kGxBM; rr += kGxThreads / 64) {
-        const int64_t row = row0 + rr;
-        if (row >= rows) break;
-        float4 v = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
-        if constexpr (F16) {
-          const float ri = sRowInv[rr];
-          v.x = fmaf(v.x, ri * cs4.x, bv.x); v.y = fmaf(v.y, ri * cs4.y, bv.y); v.z = fmaf(v.z, ri * cs4.z, bv.z); v.w = fmaf(v.w, ri * cs4.w, bv.w);
-        } else {
-          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      const float out_floor = epi.relu_out ? 0.f : -INFINITY;          // fmaxf(v, floor): the relu without a branch
+      // The wave's 16 rows as straight-line code (rows past the end are computed and not stored), the dropout and the mask output
+      // as compile-time variants of the pass: as a loop with a `break` and two run-time switches inside, each row waited for its own
+      // LDS read and the pass took a quarter of the forward's cycles (tools/gemm_wide_ablation.py).
+      auto row_pass = [&](auto drop_tag, auto mask_tag) {
+        constexpr bool kDrop = decltype(drop_tag)::value, kMask = decltype(mask_tag)::value;
+        constexpr int kRowsPerWave = kGxBM / (kGxThreads / 64);
+        float4 v[kRowsPerWave];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) v[i] = *reinterpret_cast<const float4*>(sOut + (wave_u + i * (kGxThreads / 64)) * kOutPitch + c4);
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+          const int rr = wave_u + i * (kGxThreads / 64);
+          const int64_t row = row0 + rr;
+          float4 o = v[i];
+          if constexpr (F16) {
+            const float ri = sRowInv[rr];
+            o.x = fmaf(o.x, ri * cs4.x, bv.x); o.y = fmaf(o.y, ri * cs4.y, bv.y); o.z = fmaf(o.z, ri * cs4.z, bv.z); o.w = fmaf(o.w, ri * cs4.w, bv.w);
+          } else {
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+          }
+          o.x = fmaxf(o.x, out_floor); o.y = fmaxf(o.y, out_floor); o.z = fmaxf(o.z, out_floor); o.w = fmaxf(o.w, out_floor);
+          if constexpr (kDrop) {
+            const float4 k = keep_scale4(seed_out, row * N + n, thr_out, inv_out);
+            o.x *= k.x; o.y *= k.y; o.z *= k.z; o.w *= k.w;
+          }
+          if (row < rows) {                                            // (wave-uniform)
+            *reinterpret_cast<float4*>(out + row * ldo + n) = o;
+            if constexpr (kMask) {
+              // "mask layout" (include/allset_hip_ext.h): byte q of dword j = bits 8 j .. 8 j + 7 of the ballot of component q: lane j < 8
+              // assembles the dword of columns 32 j .. 32 j + 31 of this tile's row (lanes past N are inactive: their bits are 0)
+              const uint64_t b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f), b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);
+              const int lj = tid & 63, sh = 8 * (lj & 7);
+              const uint32_t word = static_cast<uint32_t>((b0 >> sh) & 0xffu) | (static_cast<uint32_t>((b1 >> sh) & 0xffu) << 8) |
+                                    (static_cast<uint32_t>((b2 >> sh) & 0xffu) << 16) | (static_cast<uint32_t>((b3 >> sh) & 0xffu) << 24);
+              const int col = static_cast<int>(tile % n_tiles) * kGxBN + 32 * lj;
+              if (lj < 8 && col < N)
+                (epi.mask_out + ((row >> 4) * (N / 64)) * 32 + ((row & 15) >> 2) * 8 + (row & 3) * 2)[(col >> 6) * 32 + ((col & 63) >> 5)] = word;
+            }
+          }
         }
-        if (epi.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (epi.p_out > 0.f) {
-          float k0, k1, k2, k3;
-          keep_scale2(seed_out, row * N + n, thr_out, inv_out, k0, k1);
-          keep_scale2(seed_out, row * N + n + 2, thr_out, inv_out, k2, k3);
-          v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
-        }
-        *reinterpret_cast<float4*>(out + row * ldo + n) = v;
-        if (epi.mask_out != nullptr) {
-          // "mask layout" (include/allset_hip_ext.h): byte q of dword j = bits 8 j .. 8 j + 7 of the ballot of component q: lane j < 8
-          // assembles the dword of columns 32 j .. 32 j + 31 of this tile's row (lanes past N are inactive: their bits are 0)
-          const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
-          const int lj = tid & 63, sh = 8 * (lj & 7);
-          const uint32_t word = static_cast<uint32_t>((b0 >> sh) & 0xffu) | (static_cast<uint32_t>((b1 >> sh) & 0xffu) << 8) |
-                                (static_cast<uint32_t>((b2 >> sh) & 0xffu) << 16) | (static_cast<uint32_t>((b3 >> sh) & 0xffu) << 24);
-          const int col = static_cast<int>(tile % n_tiles) * kGxBN + 32 * lj;
-          if (lj < 8 && col < N)
-            epi.mask_out[((row >> 4) * (N / 64) + (col >> 6)) * 32 + ((row & 15) >> 2) * 8 + (row & 3) * 2 + ((col & 63) >> 5)] = word;
-        }
-      }
+      };
+      using gx_true = std::integral_constant<bool, true>;
+      using gx_false = std::integral_constant<bool, false>;
+      if (epi.p_out > 0.f) { if (epi.mask_out != nullptr) row_pass(gx_true{}, gx_true{}); else row_pass(gx_true{}, gx_false{}); }
+      else { if (epi.mask_out != nullptr) row_pass(gx_false{}, gx_true{}); else row_pass(gx_false{}, gx_false{}); }
     }
+    GX_MARK(4);
     __syncthreads();                                                   // the arena is free again
     if constexpr (F16) { if (rowsc && has_next) nxt.asc = row_scale(nmax); }
     cur = nxt;
     img_cur = img_nxt;
+    GX_MARK(7);
   }
+#ifdef ALLSET_ABL_GX_TIMING
+  // wave 0 / wave 4 of workgroup 0: [0] MFMA phase, [1] prologue + split + LDS stores, [2] load issue, [3] K-loop barriers, [4] the epilogue's
+  // row pass (LDS reads, arithmetic, global stores), [5] row-maximum lookahead, [6] accumulators -> LDS + the epilogue's requests, [7] the
+  // epilogue's two barriers -- written over the first floats of the output (results wrong)
+  if (blockIdx.x == 0 && (tid == 0 || tid == 256)) for (int q = 0; q < 8; ++q) out[(tid ? 8 : 0) + q] = static_cast<float>(tph[q]);
+#endif
 #undef GX_LOAD
 #undef GX_STORE
   if constexpr (LNB) {
