@@ -149,6 +149,21 @@ struct GxRow {
 };
 using f16x8_t = __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16;
 union GxFragH { uint4 u; f16x8_t v; };
+// sum over the 64 lanes of a wave, the same value in every lane: DPP sums inside each row of 16 lanes, then the four row totals by
+// v_readlane (scalar registers) -- ~11 short-latency instructions where six __shfl_xor steps are six dependent ds_bpermute round trips
+template <int CTRL>
+__device__ __forceinline__ float gx_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float gx_wave_sum(float v) {
+  v += gx_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+  v += gx_dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+  v += gx_dpp<0x141>(v);         // row_half_mirror
+  v += gx_dpp<0x140>(v);         // row_mirror
+  const int b = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
 
 // F16 (round 5, "fp16x3"): two fp16 planes per operand and three MFMAs per product instead of three bf16 planes and six -- half the
 // matrix work of a kernel whose matrix pipe is its critical resource.  fp16's five exponent bits need every operand
@@ -512,52 +527,71 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);                      // fp16x3: the inverse scales of the lane's four B columns
     if constexpr (F16) cs4 = *reinterpret_cast<const float4*>(bscale + n);       // (bscale has n_pad entries: always in range)
     if constexpr (LNB) {
-      // one wavefront per row (64 lanes x 4 columns = the whole row, N <= 256): the two row sums of the LayerNorm
-      // backward are wave reductions; dgamma / dbeta accumulate in registers over all rows this lane ever sees
+      // One wavefront per row (64 lanes x 4 columns = the whole row, N <= 256): the two row sums of the LayerNorm backward are wave
+      // reductions; dgamma / dbeta accumulate in registers over all rows this lane ever sees.  The wave's 16 rows go in batches of
+      // kLnbBatch as straight-line code -- per-lane partial sums of the batch's rows, their reductions side by side (DPP row sums +
+      // four v_readlane each), then the outputs; as a loop with one row per trip (a `continue` past the end, the sums by six
+      // dependent ds_bpermute steps) every row waited out its own LDS read and two shuffle chains.
       const bool act = n < N;
       const float inv_d = 1.f / static_cast<float>(N);
       float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (act) g4 = *reinterpret_cast<const float4*>(epi.lnb_gamma + n);
+      const float relu_floor = epi.lnb_relu_in ? 0.f : -INFINITY;
+      constexpr int kLnbBatch = 4;                                     // rows per batch: 8 reductions side by side, 16 registers of gh
+      static_assert(kLnbIter % kLnbBatch == 0, "whole batches");
 #pragma unroll
-      for (int it = 0; it < kLnbIter; ++it) {
-        const int rr = wave_u + it * (kGxThreads / 64);
-        const int64_t row = row0 + rr;
-        if (row >= rows) continue;                                     // (wave-uniform)
-        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 xv = lnb_xp[it];
-        if (act) {
-          gv = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
-          if constexpr (F16) {
-            const float ri = sRowInv[rr];
-            gv.x *= ri * cs4.x; gv.y *= ri * cs4.y; gv.z *= ri * cs4.z; gv.w *= ri * cs4.w;
-          }
-        }
-        const float mean = __shfl(lnb_sp.x, it), rstd = __shfl(lnb_sp.y, it);
-        float4 t = xv;
-        if (epi.lnb_relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-        float4 xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
-        if (!act) xh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (epi.lnb_p > 0.f && act) {
-          float k0, k1, k2, k3;
-          keep_scale2(lnb_seed, row * N + n, lnb_thr, lnb_inv, k0, k1);
-          keep_scale2(lnb_seed, row * N + n + 2, lnb_thr, lnb_inv, k2, k3);
-          gv.x *= k0; gv.y *= k1; gv.z *= k2; gv.w *= k3;
-        }
-        lnb_dg.x += gv.x * xh.x; lnb_dg.y += gv.y * xh.y; lnb_dg.z += gv.z * xh.z; lnb_dg.w += gv.w * xh.w;
-        lnb_db.x += gv.x; lnb_db.y += gv.y; lnb_db.z += gv.z; lnb_db.w += gv.w;
-        const float4 gh = make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w);
-        float s1 = gh.x + gh.y + gh.z + gh.w, s2 = gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w;
+      for (int b0 = 0; b0 < kLnbIter; b0 += kLnbBatch) {
+        float4 gh[kLnbBatch];                                          // gv * gamma of the batch's rows
+        float a1[kLnbBatch], a2[kLnbBatch], rs[kLnbBatch];             // partial row sums (then the row means); rstd
+        uint32_t pos = 0u;                                             // bit 4 j + q: raw x > 0 (the relu_in mask of the output)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-        s1 *= inv_d; s2 *= inv_d;
-        if (act) {
-          float4 o = make_float4(rstd * (gh.x - s1 - xh.x * s2), rstd * (gh.y - s1 - xh.y * s2),
-                                 rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
-          if (epi.lnb_relu_in) {
-            o.x = xv.x > 0.f ? o.x : 0.f; o.y = xv.y > 0.f ? o.y : 0.f;
-            o.z = xv.z > 0.f ? o.z : 0.f; o.w = xv.w > 0.f ? o.w : 0.f;
+        for (int j = 0; j < kLnbBatch; ++j) {
+          const int it = b0 + j;
+          const int rr = wave_u + it * (kGxThreads / 64);
+          const int64_t row = row0 + rr;
+          float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (act) gv = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
+          float kz = row < rows ? 1.f : 0.f;                           // (wave-uniform) a row past the end contributes nothing
+          if constexpr (F16) kz *= sRowInv[rr];
+          gv.x *= kz * cs4.x; gv.y *= kz * cs4.y; gv.z *= kz * cs4.z; gv.w *= kz * cs4.w;
+          const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lnb_sp.x), it));
+          const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lnb_sp.y), it));
+          rs[j] = rstd;
+          const float4 xv = lnb_xp[it];
+          pos |= ((xv.x > 0.f ? 1u : 0u) | (xv.y > 0.f ? 2u : 0u) | (xv.z > 0.f ? 4u : 0u) | (xv.w > 0.f ? 8u : 0u)) << (4 * j);
+          float4 xh = make_float4((fmaxf(xv.x, relu_floor) - mu) * rstd, (fmaxf(xv.y, relu_floor) - mu) * rstd,
+                                  (fmaxf(xv.z, relu_floor) - mu) * rstd, (fmaxf(xv.w, relu_floor) - mu) * rstd);
+          if (!act) xh = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (epi.lnb_p > 0.f) {
+            const float4 k = keep_scale4(lnb_seed, row * N + n, lnb_thr, lnb_inv);
+            gv.x *= k.x; gv.y *= k.y; gv.z *= k.z; gv.w *= k.w;
           }
-          *reinterpret_cast<float4*>(out + row * ldo + n) = o;
+          lnb_dg.x = fmaf(gv.x, xh.x, lnb_dg.x); lnb_dg.y = fmaf(gv.y, xh.y, lnb_dg.y);
+          lnb_dg.z = fmaf(gv.z, xh.z, lnb_dg.z); lnb_dg.w = fmaf(gv.w, xh.w, lnb_dg.w);
+          lnb_db.x += gv.x; lnb_db.y += gv.y; lnb_db.z += gv.z; lnb_db.w += gv.w;
+          gh[j] = make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w);
+          a1[j] = (gh[j].x + gh[j].y) + (gh[j].z + gh[j].w);
+          a2[j] = fmaf(gh[j].x, xh.x, fmaf(gh[j].y, xh.y, fmaf(gh[j].z, xh.z, gh[j].w * xh.w)));
+          lnb_xp[it] = xh;                                             // (the raw row is done with: its registers carry xhat on)
+        }
+#pragma unroll
+        for (int j = 0; j < kLnbBatch; ++j) { a1[j] = gx_wave_sum(a1[j]) * inv_d; a2[j] = gx_wave_sum(a2[j]) * inv_d; }
+#pragma unroll
+        for (int j = 0; j < kLnbBatch; ++j) {
+          const int it = b0 + j;
+          const int rr = wave_u + it * (kGxThreads / 64);
+          const int64_t row = row0 + rr;
+          if (row < rows && act) {
+            const float4 xh = lnb_xp[it];
+            const float rstd = rs[j], s1 = a1[j], s2 = a2[j];
+            float4 o = make_float4(rstd * (gh[j].x - s1 - xh.x * s2), rstd * (gh[j].y - s1 - xh.y * s2),
+                                   rstd * (gh[j].z - s1 - xh.z * s2), rstd * (gh[j].w - s1 - xh.w * s2));
+            if (epi.lnb_relu_in) {
+              const uint32_t b = pos >> (4 * j);
+              o.x = (b & 1u) ? o.x : 0.f; o.y = (b & 2u) ? o.y : 0.f; o.z = (b & 4u) ? o.z : 0.f; o.w = (b & 8u) ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(out + row * ldo + n) = o;
+          }
         }
       }
     }
