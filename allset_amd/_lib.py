@@ -137,7 +137,7 @@ SIGNATURES = {
                        _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_x6_lnb_partials": [c_int64],
     "allset_gemm_wide": [c_int, _P, c_int64, _P, c_int64, _P, c_float, c_int, _P, _P, _P, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
-                         _P, _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
+                         _P, _P, c_float, c_int, _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_wide_lnb": [c_int, _P, c_int64, _P, c_int64, _P, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64,
                              _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_f16x3_plane_bytes": [c_int64, c_int64],

@@ -135,6 +135,11 @@ struct GxEpi {
   float lnb_p;
   uint64_t lnb_seed;
   float* lnb_part;
+  // the row statistics the NEXT Linear's LayerNorm prologue needs ({mean, rstd} of stats_relu ? relu(out) : out; N == 256: a wave holds
+  // whole rows), written by the row pass instead of a separate allset_row_stats pass over the output; or NULL
+  float* stats_out;
+  float stats_eps;
+  int stats_relu;
 };
 
 // Per-tile staging context of one thread: the row it stages (128 rows x 4 segments of 8 floats per K step).
@@ -602,8 +607,8 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       // The wave's 16 rows as straight-line code (rows past the end are computed and not stored), the dropout and the mask output
       // as compile-time variants of the pass: as a loop with a `break` and two run-time switches inside, each row waited for its own
       // LDS read and the pass took a quarter of the forward's cycles (tools/gemm_wide_ablation.py).
-      auto row_pass = [&](auto drop_tag, auto mask_tag) {
-        constexpr bool kDrop = decltype(drop_tag)::value, kMask = decltype(mask_tag)::value;
+      auto row_pass = [&](auto drop_tag, auto mask_tag, auto stats_tag) {
+        constexpr bool kDrop = decltype(drop_tag)::value, kMask = decltype(mask_tag)::value, kStats = decltype(stats_tag)::value;
         constexpr int kRowsPerWave = kGxBM / (kGxThreads / 64);
         float4 v[kRowsPerWave];
 #pragma unroll
@@ -624,6 +629,14 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
             const float4 k = keep_scale4(seed_out, row * N + n, thr_out, inv_out);
             o.x *= k.x; o.y *= k.y; o.z *= k.z; o.w *= k.w;
           }
+          if constexpr (kStats) {                                      // (N == 256: all 64 lanes are here, the wave holds the row)
+            const float sf = epi.stats_relu ? 0.f : -INFINITY;
+            const float4 t = make_float4(fmaxf(o.x, sf), fmaxf(o.y, sf), fmaxf(o.z, sf), fmaxf(o.w, sf));
+            const float mean = gx_wave_sum((t.x + t.y) + (t.z + t.w)) * (1.f / kGxBN);
+            const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+            const float var = gx_wave_sum(fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3)))) * (1.f / kGxBN);
+            if (row < rows && (tid & 63) == 0) *reinterpret_cast<float2*>(epi.stats_out + row * 2) = make_float2(mean, rsqrtf(var + epi.stats_eps));
+          }
           if (row < rows) {                                            // (wave-uniform)
             *reinterpret_cast<float4*>(out + row * ldo + n) = o;
             if constexpr (kMask) {
@@ -642,8 +655,11 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
       };
       using gx_true = std::integral_constant<bool, true>;
       using gx_false = std::integral_constant<bool, false>;
-      if (epi.p_out > 0.f) { if (epi.mask_out != nullptr) row_pass(gx_true{}, gx_true{}); else row_pass(gx_true{}, gx_false{}); }
-      else { if (epi.mask_out != nullptr) row_pass(gx_false{}, gx_true{}); else row_pass(gx_false{}, gx_false{}); }
+      if (epi.stats_out != nullptr) {                                  // (a Linear that feeds the next one's LayerNorm has no relu / dropout epilogue of its own)
+        if (epi.p_out > 0.f) { if (epi.mask_out != nullptr) row_pass(gx_true{}, gx_true{}, gx_true{}); else row_pass(gx_true{}, gx_false{}, gx_true{}); }
+        else { if (epi.mask_out != nullptr) row_pass(gx_false{}, gx_true{}, gx_true{}); else row_pass(gx_false{}, gx_false{}, gx_true{}); }
+      } else if (epi.p_out > 0.f) { if (epi.mask_out != nullptr) row_pass(gx_true{}, gx_true{}, gx_false{}); else row_pass(gx_true{}, gx_false{}, gx_false{}); }
+      else { if (epi.mask_out != nullptr) row_pass(gx_false{}, gx_true{}, gx_false{}); else row_pass(gx_false{}, gx_false{}, gx_false{}); }
     }
     GX_MARK(4);
     __syncthreads();                                                   // the arena is free again
@@ -884,13 +900,18 @@ static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_
 extern "C" int allset_gemm_wide(int arith, const float* A, int64_t lda, const float* mask_y, int64_t ldy, const uint32_t* mask_bits,
                                 float p_mask, int relu_in, const float* stats, const float* gamma, const float* beta, float p_in,
                                 uint64_t seed_in, const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out,
-                                uint32_t* mask_out, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
-                                const uint64_t* seed_base, void* stream) {
+                                uint32_t* mask_out, float* stats_out, float stats_eps, int stats_relu, float* out, int64_t ldo,
+                                int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream) {
   clear_error();
   ALLSET_REQUIRE(arith == ALLSET_ARITH_BF16X6 || arith == ALLSET_ARITH_FP16X3, "gemm_wide: arith names the planes' format: ALLSET_ARITH_BF16X6 or ALLSET_ARITH_FP16X3");
   ALLSET_REQUIRE(p_out >= 0.f && p_out < 1.f, "gemm_wide: dropout p must be in [0,1)");
   ALLSET_REQUIRE(bias == nullptr || aligned16(bias), "gemm_wide: bias must be 16-byte aligned");
-  GxEpi epi{bias, relu_out, p_out, seed_out, mask_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr};
+  if (stats_out != nullptr && N != kGxBN) {
+    set_error("gemm_wide: stats_out needs N == 256 (one wave holds a whole output row)");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(stats_out == nullptr || (stats_eps > 0.f && (reinterpret_cast<uintptr_t>(stats_out) & 7u) == 0), "gemm_wide: stats_out needs eps > 0 and an 8-byte aligned buffer");
+  GxEpi epi{bias, relu_out, p_out, seed_out, mask_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr, stats_out, stats_eps, stats_relu};
   return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base,
                       stream, arith == ALLSET_ARITH_FP16X3, mask_bits);
 }

@@ -400,9 +400,11 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
             p_mask: float = 0.0, relu_in: bool = False, stats: Optional[Tensor] = None, gamma: Optional[Tensor] = None,
             beta: Optional[Tensor] = None, p_in: float = 0.0, seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0,
             seed_out: int = 0, seed_base: Optional[Tensor] = None, mask_bits: Optional[Tensor] = None,
-            mask_out: Optional[Tensor] = None) -> Tensor:
+            mask_out: Optional[Tensor] = None, stats_out: Optional[Tensor] = None, stats_eps: float = 1e-5,
+            stats_relu: bool = False) -> Tensor:
     """``out = epi(pro(A) @ B^T + bias)`` with ``B`` given as :func:`gemm_x6_planes` (include/allset_hip_ext.h allset_gemm_x6 /
-    allset_gemm_f16x3: the planes say which)."""
+    allset_gemm_f16x3: the planes say which).  ``stats_out`` [n, 2] (N == 256): the row statistics of ``relu?(out)`` for the next
+    Linear's LayerNorm prologue, written by the epilogue instead of a :func:`row_stats` pass over the output."""
     planes, f16 = planes.buf, planes.f16
     dev = require_device(A, planes, bias, mask_y, stats, gamma, beta)
     _check_f32(A, bias, mask_y, stats, gamma, beta)
@@ -418,7 +420,8 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
             ptr(mask_bits), p_mask, int(relu_in), ptr(stats),
             ptr(gamma.contiguous() if gamma is not None else None), ptr(beta.contiguous() if beta is not None else None), p_in,
             seed_in, ptr(planes), ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out,
-            ptr(mask_out), ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_wide")
+            ptr(mask_out), ptr(stats_out), stats_eps, int(stats_relu), ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)),
+            "allset_gemm_wide")
     return out
 
 
@@ -1038,11 +1041,14 @@ class _WideNormLinear(torch.autograd.Function):
     incoming gradient, the LayerNorm-backward kernel, and the split-K weight gradient with both operands recomputed."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out):
+    def forward(ctx, x, gamma, beta, weight, bias, eps, relu_in, p_in, relu_out, p_out, stats_in=None, emit=None):
+        # stats_in: this input's row statistics as the PREVIOUS wide Linear's epilogue wrote them (emit = (eps, relu) of the consumer's
+        # prologue asks this one to write its output's): one allset_row_stats pass over [n, 256] less per pair of Linears
         seed_in = _draw_seed() if p_in > 0.0 else 0
         seed_out = _draw_seed() if p_out > 0.0 else 0
         base = _seed_base() if (p_in > 0.0 or p_out > 0.0) else None
-        stats = row_stats(x, relu_in, eps) if gamma is not None else None
+        stats = (stats_in if stats_in is not None else row_stats(x, relu_in, eps)) if gamma is not None else None
+        stats_y = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device) if emit is not None else None
         keep_y = relu_out or p_out > 0.0
         # the backward's "y > 0" test from a 1-bit mask the forward's epilogue writes (round 5: the backward kernels used to re-read
         # the fp32 output twice -- 2 GB per Linear at [1M, 256]); widths that are not multiples of 64 keep y
@@ -1050,14 +1056,18 @@ class _WideNormLinear(torch.autograd.Function):
         mask = torch.empty(words, dtype=torch.int32, device=x.device) if words > 0 else None
         y = gemm_x6(x, gemm_x6_planes(weight, False, f16=wide_f16(gamma is not None)), weight.shape[0], bias, relu_in=relu_in, stats=stats, gamma=gamma,
                     beta=beta, p_in=p_in, seed_in=seed_in, relu_out=relu_out, p_out=p_out, seed_out=seed_out, seed_base=base,
-                    mask_out=mask)
+                    mask_out=mask, stats_out=stats_y, stats_eps=emit[0] if emit is not None else 1e-5,
+                    stats_relu=bool(emit[1]) if emit is not None else False)
         ctx.save_for_backward(x, stats, gamma, beta, weight, y if (keep_y and mask is None) else None, mask)
         ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
-        return y
+        if emit is None:
+            return y
+        ctx.mark_non_differentiable(stats_y)
+        return y, stats_y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_stats=None):
         x, stats, gamma, beta, weight, y, mask = ctx.saved_tensors
         relu_in, p_in, seed_in, p_out, has_bias, base = ctx.cfg
         if x.shape[0] == 0:                     # no rows: every gradient is zero (empty tensors carry no row statistics)
@@ -1065,7 +1075,7 @@ class _WideNormLinear(torch.autograd.Function):
             return (z(x, ctx.needs_input_grad[0]), z(gamma, ctx.needs_input_grad[1]), z(beta, ctx.needs_input_grad[2]),
                     z(weight, ctx.needs_input_grad[3]),
                     weight.new_zeros(weight.shape[0]) if (has_bias and ctx.needs_input_grad[4]) else None,
-                    None, None, None, None, None)
+                    None, None, None, None, None, None, None)
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
@@ -1078,7 +1088,7 @@ class _WideNormLinear(torch.autograd.Function):
                 # one kernel: the Linear's input gradient never leaves the chip, the LayerNorm backward is the GEMM's epilogue
                 gx, dg, db = gemm_x6_lnb(gy, gemm_x6_planes(weight, True), x, stats, gamma, relu_in, p_in, seed_in, mask_y=y,
                                          p_mask=p_out, seed_base=base, mask_bits=mask)
-                return gx, dg, db, gw, gb, None, None, None, None, None
+                return gx, dg, db, gw, gb, None, None, None, None, None, None, None
             gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out, mask_bits=mask)
             if gamma is not None:
                 gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x)
@@ -1089,7 +1099,7 @@ class _WideNormLinear(torch.autograd.Function):
                                                               stream_of(x.device)), "allset_relu_dropout_bwd")
             else:
                 gx = gu
-        return gx, dg, db, gw, gb, None, None, None, None, None
+        return gx, dg, db, gw, gb, None, None, None, None, None, None, None
 
 
 def wide_linear_supported(K: int, N: int, has_ln: bool, relu_in: bool = False, p_in: float = 0.0) -> bool:
@@ -1103,9 +1113,18 @@ def wide_linear_supported(K: int, N: int, has_ln: bool, relu_in: bool = False, p
     return p_in == 0.0
 
 
+def wide_stats_chain_supported(K: int, N: int, has_ln: bool, relu_in: bool = False, p_in: float = 0.0) -> bool:
+    """A [N, K] Linear on the tiled wide path whose epilogue can write the next Linear's row statistics (N == 256: a wave holds a whole
+    output row) -- :func:`fused_norm_linear`'s ``emit_stats``."""
+    return N == 256 and wide_linear_supported(K, N, has_ln, relu_in, p_in)
+
+
 def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
                       eps: float = 1e-5, relu_in: bool = False, p_in: float = 0.0, relu_out: bool = False,
-                      p_out: float = 0.0, in_cb: int = 0, out_cb: int = 0) -> Tensor:
+                      p_out: float = 0.0, in_cb: int = 0, out_cb: int = 0, stats_in: Optional[Tensor] = None,
+                      emit_stats: Optional[Tuple[float, bool]] = None):
+    """``emit_stats = (eps, relu)`` (only where :func:`wide_stats_chain_supported`): returns ``(y, stats_y)``, the row statistics the
+    next Linear's LayerNorm prologue would otherwise compute with a pass of its own; ``stats_in`` hands them to that Linear."""
     if p_out > 0.0 and not relu_out:
         # the backward recovers the epilogue mask from the sign of y, which is only right behind a relu (MLP._post is
         # always relu -> dropout, reference layers.py:575-577)
@@ -1116,8 +1135,16 @@ def fused_norm_linear(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor]
             raise _lib.AllSetHipError(f"fused_norm_linear: column-blocked operands are not built for a [{N}, {K}] weight")
         return _FusedNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out),
                                       float(p_out), int(in_cb), int(out_cb))
-    fn = _FusedNormLinear if fused_linear_supported(K, N) else _WideNormLinear
-    return fn.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out), float(p_out))
+    if fused_linear_supported(K, N):
+        if stats_in is not None or emit_stats is not None:
+            raise _lib.AllSetHipError("fused_norm_linear: stats_in / emit_stats belong to the tiled wide path")
+        return _FusedNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out), float(p_out))
+    if emit_stats is not None and N != 256:
+        raise _lib.AllSetHipError("fused_norm_linear: emit_stats needs 256 output features")
+    if stats_in is None and emit_stats is None:
+        return _WideNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out), float(p_out))
+    return _WideNormLinear.apply(x, gamma, beta, weight, bias, float(eps), bool(relu_in), float(p_in), bool(relu_out), float(p_out),
+                                 stats_in, (float(emit_stats[0]), bool(emit_stats[1])) if emit_stats is not None else None)
 
 
 def ln_res_supported(d: int, dtype: torch.dtype = torch.float32) -> bool:

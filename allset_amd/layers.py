@@ -284,14 +284,27 @@ class MLP(nn.Module):
             return x
         if self._fusable(x):
             last = len(self.lins) - 1
+            stats = None
             for i, lin in enumerate(self.lins):
                 nm = self.normalizations[i]
                 ln = nm if isinstance(nm, nn.LayerNorm) else None
                 is_last = i == last
+                # two consecutive 256-wide Linears on the tiled path: the first one's epilogue writes the row statistics the second
+                # one's LayerNorm prologue needs (dense.fused_norm_linear emit_stats) -- no allset_row_stats pass in between
+                nxt = self.normalizations[i + 1] if not is_last else None
+                emit = None
+                if (isinstance(nxt, nn.LayerNorm) and not (_in_cb or _out_cb)
+                        and dense.wide_stats_chain_supported(lin.weight.shape[1], lin.weight.shape[0], ln is not None, i > 0, p if i > 0 else 0.0)
+                        and dense.wide_linear_supported(self.lins[i + 1].weight.shape[1], self.lins[i + 1].weight.shape[0], True, True, p)):
+                    emit = (nxt.eps, True)
                 x = dense.fused_norm_linear(
                     x, ln.weight if ln is not None else None, ln.bias if ln is not None else None, lin.weight, lin.bias,
                     ln.eps if ln is not None else 1e-5, relu_in=i > 0, p_in=p if i > 0 else 0.0,
-                    relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0)
+                    relu_out=is_last and post_p is not None, p_out=post_p if (is_last and post_p is not None) else 0.0,
+                    stats_in=stats if ln is not None else None, emit_stats=emit)
+                stats = None
+                if emit is not None:
+                    x, stats = x
             return x
         if self._bn_trainable(x):
             last = len(self.lins) - 1

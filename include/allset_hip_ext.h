@@ -234,11 +234,14 @@ int allset_gemm_f16x3(const float* A, int64_t lda, const float* mask_y, int64_t 
  * ALLSET_ARITH_FP16X3, declared below), and the forward's 1-bit activation mask travels instead of its fp32 output: mask_out (forward,
  * N % 64 == 0, may be NULL) receives "out > 0" after the epilogue in the "mask layout" of allset_fused_linear_fwd; mask_bits (backward,
  * K % 64 == 0, may be NULL; then mask_y must be NULL) replaces mask_y -- one dword per thread and K step where mask_y costs a second
- * [rows, K] fp32 read.  allset_wgrad_fused_ex takes the same buffer as `mask`. */
+ * [rows, K] fp32 read.  allset_wgrad_fused_ex takes the same buffer as `mask`.  stats_out (forward, N == 256, may be NULL): f32[rows][2]
+ * {mean, rstd} of (stats_relu ? relu(out) : out) with eps = stats_eps -- what allset_row_stats would compute from `out` for the NEXT
+ * Linear's LayerNorm prologue, written by the epilogue's row pass instead of by a second pass over the output. */
 int allset_gemm_wide(int arith, const float* A, int64_t lda, const float* mask_y, int64_t ldy, const uint32_t* mask_bits, float p_mask,
                      int relu_in, const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                      const void* planes, const float* bias, int relu_out, float p_out, uint64_t seed_out, uint32_t* mask_out,
-                     float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K, const uint64_t* seed_base, void* stream);
+                     float* stats_out, float stats_eps, int stats_relu, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
+                     const uint64_t* seed_base, void* stream);
 int allset_gemm_wide_lnb(int arith, const float* G, int64_t ldg, const float* mask_y, int64_t ldy, const uint32_t* mask_bits, float p_mask,
                          const void* planes, const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p,
                          uint64_t seed, float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows, int64_t N, int64_t K,

@@ -1623,3 +1623,52 @@ def test_wgrad_f16x3_against_float64(n, O, I, masked, profile, device):
         with dense.arithmetic("fp16x3"):
             gw2, gb2 = dense.wgrad_fused(G, None, p_out, x, st, gamma, beta, True, 0.0, 0, mask=mask)
         assert torch.equal(gw2, gw) and torch.equal(gb2, gb)
+
+
+@pytest.mark.parametrize("arith", ["auto", "strict"])
+@pytest.mark.parametrize("n", [1003, 40_001])
+def test_wide_forward_writes_the_next_layers_row_statistics(n, arith, device):
+    """allset_gemm_wide(stats_out): the epilogue's row pass writes {mean, rstd} of relu(out) -- what allset_row_stats computes from the
+    stored output -- and an MLP of two 256-wide Linears takes that route (no row_stats launch between them) with the same forward and
+    gradients as the route through allset_row_stats."""
+    from allset_amd import MLP, dense
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 256, generator=g).to(device)
+    W = (torch.randn(256, 256, generator=g) / 16).to(device)
+    b = torch.randn(256, generator=g).to(device)
+    gamma, beta = (1 + 0.2 * torch.randn(256, generator=g)).to(device), (0.3 * torch.randn(256, generator=g)).to(device)
+    with dense.arithmetic(arith):
+        st = dense.row_stats(x, False, 1e-5)
+        for relu in (True, False):
+            so = torch.full((n, 2), float("nan"), device=device)
+            y = dense.gemm_x6(x, dense.gemm_x6_planes(W, False), 256, b, stats=st, gamma=gamma, beta=beta, stats_out=so, stats_eps=1e-5, stats_relu=relu)
+            ref = dense.row_stats(y, relu, 1e-5)
+            torch.testing.assert_close(so, ref, rtol=2e-5, atol=2e-6)
+        # the module route: same numbers with and without the chained statistics
+        torch.manual_seed(3)
+        m = MLP(256, 256, 256, 2, dropout=0.0, Normalization="ln", InputNorm=True).to(device).train()
+        outs, launches = [], []
+        for chained in (True, False):
+            xi = x.clone().requires_grad_(True)
+            orig_chain, orig_stats, count = dense.wide_stats_chain_supported, dense.row_stats, [0]
+
+            def counted(*a, **k):
+                count[0] += 1
+                return orig_stats(*a, **k)
+            dense.row_stats = counted
+            if not chained:
+                dense.wide_stats_chain_supported = lambda *a, **k: False
+            try:
+                out = m(xi, _post=0.0)
+            finally:
+                dense.wide_stats_chain_supported, dense.row_stats = orig_chain, orig_stats
+            launches.append(count[0])
+            m.zero_grad()
+            out.square().sum().backward()
+            outs.append((out.detach(), xi.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+        assert launches == [1, 2], launches
+        (o1, g1, p1), (o0, g0, p0) = outs
+        torch.testing.assert_close(o1, o0, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-4 * float(g0.abs().max()))
+        for a, c in zip(p1, p0):
+            torch.testing.assert_close(a, c, rtol=1e-4, atol=1e-4 * float(c.abs().max()))

@@ -41,7 +41,7 @@ for name, flags in [("timed", ["-DALLSET_ABL_GX_TIMING"]), ("plain build", [])]:
     mask = torch.zeros(words, dtype=torch.int32, device=dev)
     y = torch.empty(n, N, device=dev); gx = torch.empty(n, K, device=dev)
     fw = lib.allset_gemm_wide
-    fw.argtypes = [Ci, P, I64, P, I64, P, F, Ci, P, P, P, F, U64, P, P, Ci, F, U64, P, P, I64, I64, I64, I64, P, P]
+    fw.argtypes = [Ci, P, I64, P, I64, P, F, Ci, P, P, P, F, U64, P, P, Ci, F, U64, P, P, F, Ci, P, I64, I64, I64, I64, P, P]
     bw = lib.allset_gemm_wide_lnb
     bw.argtypes = [Ci, P, I64, P, I64, P, F, P, P, I64, P, P, Ci, F, U64, P, I64, P, I64, I64, I64, I64, P, P]
     lib.allset_gemm_x6_lnb_partials.restype = I64
@@ -50,7 +50,7 @@ for name, flags in [("timed", ["-DALLSET_ABL_GX_TIMING"]), ("plain build", [])]:
     part = torch.empty(npart, 2, K, device=dev)
     def fwd():
         rc = fw(2, x.data_ptr(), K, None, 0, None, 0.0, 1, st.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0.5, 3, planes.data_ptr(), b.data_ptr(), 1, 0.5, 4,
-                mask.data_ptr(), y.data_ptr(), N, n, N, K, None, s)
+                mask.data_ptr(), None, 1e-5, 0, y.data_ptr(), N, n, N, K, None, s)
         assert rc == 0, rc
     def bwd():
         rc = bw(2, G.data_ptr(), N, None, 0, mask.data_ptr(), 0.5, planes_t.data_ptr(), x.data_ptr(), K, st.data_ptr(), gam.data_ptr(), 1, 0.5, 3,
