@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   const int a_st = s_row * 4 + (s_seg ^ gx_swz(s_row));                 // swizzled 16-byte piece (gx_swz)
   const int b_img = (tid >> 6) * (64 * NPC) + (tid & 63) + 32 * NPC;   // gx_image_at: this wave's NPC pieces, from the middle
   const bool rowsc = F16 && pro.stats == nullptr;                      // A scaled per row (no LayerNorm bound)
+  const bool mask_fold = YM == 2 && rowsc;                             // the mask's 1 / keep multiplied into the row scale (nothing non-linear in between)
   auto row_ctx = [&](int64_t tile) {
     GxRow c;
     const int64_t row0 = tile / n_tiles * kGxBM;
@@ -275,10 +276,25 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   // (tools/gemm_wide_ablation.py: prologue + split + stores were a third of the critical waves' cycles).
   auto stage8 = [&](const GxRow& c, int kb, float (&e)[8]) {
     e[0] = pa0.x; e[1] = pa0.y; e[2] = pa0.z; e[3] = pa0.w; e[4] = pa1.x; e[5] = pa1.y; e[6] = pa1.z; e[7] = pa1.w;
-    if constexpr (YM != 0) {
+    if constexpr (YM == 1) {
       const float y[8] = {py0.x, py0.y, py0.z, py0.w, py1.x, py1.y, py1.z, py1.w};
 #pragma unroll
       for (int i = 0; i < 8; ++i) e[i] = y[i] > 0.f ? e[i] * inv_mask : 0.f;
+    }
+    if constexpr (YM == 2) {
+      // bits 8 q + 2 s_seg (+ 1) of the step's mask dword: columns kb + q (kb + 4 + q) of the row.  Bit -> all-ones / zero -> AND with
+      // the float's bits: two instructions per element where a test, a select and a multiply on a float copy of the bit were six
+      // (the masked backward GEMM ran 14 % behind the unmasked one); 1 / keep rides on the row scale where that commutes (mask_fold).
+      const int w = static_cast<int>(pm);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = __int_as_float(__float_as_int(e[i]) & __builtin_amdgcn_sbfe(w, 2 * s_seg + 8 * i, 1));
+        e[4 + i] = __int_as_float(__float_as_int(e[4 + i]) & __builtin_amdgcn_sbfe(w, 2 * s_seg + 8 * i + 1, 1));
+      }
+      if (!mask_fold) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] *= inv_mask;
+      }
     }
     if (pro.relu_in) {
 #pragma unroll
@@ -299,17 +315,12 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
 #define GX_STORE(ctx_, ks_, buf_)                                                               \
   do {                                                                                          \
     const int kb_ = (ks_) * kGxKS + s_seg * 8;                                                  \
-    if constexpr (YM == 2) {   /* bits 8 q + 2 s_seg (+ 1): columns kb + q (kb + 4 + q) of the row -> the signs stage8 tests */ \
-      const uint32_t b_ = pm >> (2 * s_seg);                                                    \
-      py0 = make_float4((b_ & 0x1u) ? 1.f : 0.f, (b_ & 0x100u) ? 1.f : 0.f, (b_ & 0x10000u) ? 1.f : 0.f, (b_ & 0x1000000u) ? 1.f : 0.f); \
-      py1 = make_float4((b_ & 0x2u) ? 1.f : 0.f, (b_ & 0x200u) ? 1.f : 0.f, (b_ & 0x20000u) ? 1.f : 0.f, (b_ & 0x2000000u) ? 1.f : 0.f); \
-    }                                                                                           \
     float ee_[8];                                                                               \
     stage8(ctx_, kb_, ee_);                                                                     \
     const float e0 = ee_[0], e1 = ee_[1], e2 = ee_[2], e3 = ee_[3], e4 = ee_[4], e5 = ee_[5], e6 = ee_[6], e7 = ee_[7]; \
     uint4 h_, m_, l_;                                                                           \
     if constexpr (F16) {                                                                        \
-      const float sc_ = (ctx_).asc;                                                             \
+      const float sc_ = mask_fold ? (ctx_).asc * inv_mask : (ctx_).asc;                         \
       split2_f16c(e0 * sc_, e1 * sc_, h_.x, l_.x);                                              \
       split2_f16c(e2 * sc_, e3 * sc_, h_.y, l_.y);                                              \
       split2_f16c(e4 * sc_, e5 * sc_, h_.z, l_.z);                                              \
