@@ -243,19 +243,25 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       for (int hb = 0; hb < 2; ++hb) {
         v[hb] = ag[hb];
         if constexpr (HAS_MASK) {
-          const uint32_t bits = valid ? (am[hb] >> (c & 7)) : 0u;    // bit 8 q + (c % 8) for column 64 hb + 4 c + q
-          v[hb].x = (bits & 0x1u) ? v[hb].x * keep_out : 0.f; v[hb].y = (bits & 0x100u) ? v[hb].y * keep_out : 0.f;
-          v[hb].z = (bits & 0x10000u) ? v[hb].z * keep_out : 0.f; v[hb].w = (bits & 0x1000000u) ? v[hb].w * keep_out : 0.f;
+          // bit 8 q + (c % 8) of the word for column 64 hb + 4 c + q -> all-ones / zero -> AND with the float's bits (two instructions
+          // per element; a test, a select and a multiply were four): 1 / keep rides on the bias sums' FMA and on the row scale below
+          const int w = valid ? static_cast<int>(am[hb]) : 0;
+          v[hb].x = __int_as_float(__float_as_int(v[hb].x) & __builtin_amdgcn_sbfe(w, (c & 7), 1));
+          v[hb].y = __int_as_float(__float_as_int(v[hb].y) & __builtin_amdgcn_sbfe(w, (c & 7) + 8, 1));
+          v[hb].z = __int_as_float(__float_as_int(v[hb].z) & __builtin_amdgcn_sbfe(w, (c & 7) + 16, 1));
+          v[hb].w = __int_as_float(__float_as_int(v[hb].w) & __builtin_amdgcn_sbfe(w, (c & 7) + 24, 1));
+          gbv[hb].x = fmaf(v[hb].x, keep_out, gbv[hb].x); gbv[hb].y = fmaf(v[hb].y, keep_out, gbv[hb].y);      // bias gradient: column sums of ga
+          gbv[hb].z = fmaf(v[hb].z, keep_out, gbv[hb].z); gbv[hb].w = fmaf(v[hb].w, keep_out, gbv[hb].w);
         } else {
           v[hb].x = valid ? v[hb].x : 0.f; v[hb].y = valid ? v[hb].y : 0.f; v[hb].z = valid ? v[hb].z : 0.f; v[hb].w = valid ? v[hb].w : 0.f;
+          gbv[hb].x += v[hb].x; gbv[hb].y += v[hb].y; gbv[hb].z += v[hb].z; gbv[hb].w += v[hb].w;
         }
-        gbv[hb].x += v[hb].x; gbv[hb].y += v[hb].y; gbv[hb].z += v[hb].z; gbv[hb].w += v[hb].w;      // bias gradient: column sums of ga
         amax = amax4_s(v[hb], amax);
       }
-      amax = row16_max_s(amax);
+      amax = row16_max_s(amax) * (HAS_MASK ? keep_out : 1.f);
       const int e = min(max(static_cast<int>(__float_as_uint(amax) >> 23), kSEMin), 254);
       eNext = e;
-      const float sa = pow2_field_s(254 + kSTop - e);        // row max -> [2^13, 2^14)
+      const float sa = pow2_field_s(254 + kSTop - e) * (HAS_MASK ? keep_out : 1.f);        // row max -> [2^13, 2^14); ga = gy keep_out under the mask
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         uint32_t h0, l0, h1, l1;
@@ -271,13 +277,11 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     };
     // ---- S2a(k): what needs only x: xhat, the keep factors, the relu signs -- kept in registers for S2b(k)
     float4 xhK[2];             // xhat of stage k, [hb]
-    float4 kpK[2];             // dropout-in keep factors (keep_in or 0)
+    int4 kmK[2];               // dropout-in keep MASKS (all-ones / zero; 1 / keep rides on the scales the values meet anyway)
     uint32_t xbK = 0;          // "raw x > 0" flags, bit 4 hb + q
     float rstdK = 1.f;
     auto S2a = [&](int64_t k, float4 (&xr)[2], float2& st) {
       const int64_t stage = stage_of(k);
-      const int nrows = rows_left(stage);
-      const bool live = lr < nrows;
       const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * ID / 2);
       const uint32_t stage_pair_lo = static_cast<uint32_t>(stage_pair);
       const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_pair >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
@@ -290,23 +294,27 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       float uamax = 0.f;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
-        float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
+        int4 km = make_int4(-1, -1, -1, -1);
         if constexpr (DROP_IN) {
           // pair index of (row, column) = stage * 2048 + (lr * 128 + column) / 2: the lane's part is < 2048 -> an OR (common.h pair_hash)
           if (thr_in & kDrop8) {     // 8 bits per element: ONE hash for the lane's float4 (quad index = stage * 1024 + lane part)
             const uint32_t lo = stage_quad_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 2);
-            const uint32_t h = hash_mix_s((lo ^ seed_lo) * 0x9E3779B1U + hi_term_q), t8 = thr_in & 0xffu;
-            kp.x = (h & 0xffu) >= t8 ? keep_in : 0.f; kp.y = ((h >> 8) & 0xffu) >= t8 ? keep_in : 0.f;
-            kp.z = ((h >> 16) & 0xffu) >= t8 ? keep_in : 0.f; kp.w = (h >> 24) >= t8 ? keep_in : 0.f;
+            const int h = static_cast<int>(hash_mix_s((lo ^ seed_lo) * 0x9E3779B1U + hi_term_q));
+            const uint32_t t8 = thr_in & 0xffu;
+            if (t8 == 128u) {        // (uniform) p = 0.5, the reference's default: keep iff the byte's top bit is set -- one instruction per element
+              km = make_int4(__builtin_amdgcn_sbfe(h, 7, 1), __builtin_amdgcn_sbfe(h, 15, 1), __builtin_amdgcn_sbfe(h, 23, 1), h >> 31);
+            } else {
+              const uint32_t hu = static_cast<uint32_t>(h);
+              km = make_int4((hu & 0xffu) >= t8 ? -1 : 0, ((hu >> 8) & 0xffu) >= t8 ? -1 : 0, ((hu >> 16) & 0xffu) >= t8 ? -1 : 0, (hu >> 24) >= t8 ? -1 : 0);
+            }
           } else {
             const uint32_t lo = stage_pair_lo | static_cast<uint32_t>((lr * ID + 64 * hb + 4 * c) >> 1);
             const uint32_t h0 = hash_mix_s((lo ^ seed_lo) * 0x9E3779B1U + hi_term);
             const uint32_t h1 = hash_mix_s(((lo + 1u) ^ seed_lo) * 0x9E3779B1U + hi_term);
-            kp.x = (h0 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.y = (h0 >> 16) >= thr_in ? keep_in : 0.f;
-            kp.z = (h1 & 0xffffu) >= thr_in ? keep_in : 0.f; kp.w = (h1 >> 16) >= thr_in ? keep_in : 0.f;
+            km = make_int4((h0 & 0xffffu) >= thr_in ? -1 : 0, (h0 >> 16) >= thr_in ? -1 : 0, (h1 & 0xffffu) >= thr_in ? -1 : 0, (h1 >> 16) >= thr_in ? -1 : 0);
           }
         }
-        kpK[hb] = kp;
+        kmK[hb] = km;
         float4 t = xr[hb];
         if (RELU_IN) {
           xbK |= ((t.x > 0.f ? 1u : 0u) | (t.y > 0.f ? 2u : 0u) | (t.z > 0.f ? 4u : 0u) | (t.w > 0.f ? 8u : 0u)) << (4 * hb);
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         }
         float4 xh = t;
         if constexpr (HAS_LN) xh = make_float4((t.x - mean) * rstd, (t.y - mean) * rstd, (t.z - mean) * rstd, (t.w - mean) * rstd);
-        xh.x = live ? xh.x : 0.f; xh.y = live ? xh.y : 0.f; xh.z = live ? xh.z : 0.f; xh.w = live ? xh.w : 0.f;
+        // (a row past the end re-reads the last row: its xhat is finite and meets ga = 0, gu = 0 and fu = 0 wherever it is used)
         xhK[hb] = xh;
         if constexpr (!HAS_LN) uamax = amax4_s(xh, uamax);
         else if (affine) {
@@ -342,9 +350,9 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       const int nrows = rows_left(stage);
       const bool live = lr < nrows;
       Erun = max(Erun, stage_emax(k));
-      const float inv_sa = pow2_field_s(eCur - kSTop);            // undoes the row scale of ga (the wave's W scale is undone by S1)
+      const float inv_sa = pow2_field_s(eCur - kSTop) * keep_in;  // undoes the row scale of ga (the wave's W scale is undone by S1); x the dropout's 1 / keep
       const int ffield = 267 + eCur - Erun;
-      const float fu = pow2_field_s(live ? max(ffield, 0) : 0);     // (a dead row's u is 0: its xhat is, but beta is not)
+      const float fu = pow2_field_s(live ? max(ffield, 0) : 0) * keep_in;     // (a dead row's u is 0: its xhat is, but beta is not)
       float4 gam[2], v[2];
       float a1 = 0.f, a2 = 0.f;
       // gx = acc_in + ...: a second gradient branch of the same tensor, summed here (may alias gx: each element is read and written
@@ -361,8 +369,11 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       for (int hb = 0; hb < 2; ++hb) {
         gam[hb] = *reinterpret_cast<const float4*>(&sG[64 * hb + 4 * c]);
         v[hb] = *reinterpret_cast<const float4*>(&sGU[lr * SPG + 64 * hb + 4 * c]);
-        v[hb].x *= inv_sa; v[hb].y *= inv_sa; v[hb].z *= inv_sa; v[hb].w *= inv_sa;
-        if constexpr (DROP_IN) { v[hb].x *= kpK[hb].x; v[hb].y *= kpK[hb].y; v[hb].z *= kpK[hb].z; v[hb].w *= kpK[hb].w; }
+        v[hb].x *= inv_sa; v[hb].y *= inv_sa; v[hb].z *= inv_sa; v[hb].w *= inv_sa;          // (inv_sa carries the dropout's 1 / keep)
+        if constexpr (DROP_IN) {
+          v[hb].x = __int_as_float(__float_as_int(v[hb].x) & kmK[hb].x); v[hb].y = __int_as_float(__float_as_int(v[hb].y) & kmK[hb].y);
+          v[hb].z = __int_as_float(__float_as_int(v[hb].z) & kmK[hb].z); v[hb].w = __int_as_float(__float_as_int(v[hb].w) & kmK[hb].w);
+        }
         if constexpr (HAS_LN) {
           const float4 xh = xhK[hb];
           dg[hb].x = fmaf(v[hb].x, xh.x, dg[hb].x); dg[hb].y = fmaf(v[hb].y, xh.y, dg[hb].y);
@@ -401,7 +412,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
           const float4 bet = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
           u = make_float4(fmaf(xh.x, gam[hb].x, bet.x), fmaf(xh.y, gam[hb].y, bet.y), fmaf(xh.z, gam[hb].z, bet.z), fmaf(xh.w, gam[hb].w, bet.w));
         }
-        if constexpr (DROP_IN) { u.x *= kpK[hb].x; u.y *= kpK[hb].y; u.z *= kpK[hb].z; u.w *= kpK[hb].w; }
+        if constexpr (DROP_IN) {                    // (fu carries the dropout's 1 / keep)
+          u.x = __int_as_float(__float_as_int(u.x) & kmK[hb].x); u.y = __int_as_float(__float_as_int(u.y) & kmK[hb].y);
+          u.z = __int_as_float(__float_as_int(u.z) & kmK[hb].z); u.w = __int_as_float(__float_as_int(u.w) & kmK[hb].w);
+        }
         uint32_t h0, l0, h1, l1;
         split2_f16(u.x * fu, u.y * fu, h0, l0);
         split2_f16(u.z * fu, u.w * fu, h1, l1);
