@@ -495,11 +495,13 @@ class arithmetic:
         return False
 
 
-def _arith_for(direction: int, K: int, N: int, has_ln: bool, norm_mode: int) -> int:
+def _arith_for(direction: int, K: int, N: int, has_ln: bool, norm_mode: int, has_aux: bool = False) -> int:
     """The ``arith`` argument of a call: the process-wide mode; an explicit fp16x3 request degrades to AUTO for shapes the fp16x3
-    kernels are not built for (the library itself would refuse it)."""
-    if _arith == _lib.ARITH_FP16X3 and not _lib.load().allset_fused_linear_arith_supported(direction, int(K), int(N), int(has_ln),
-                                                                                          int(norm_mode), _lib.ARITH_FP16X3):
+    kernels are not built for (the library itself would refuse it) -- and for the forward with auxiliary output columns (PMA's value
+    projection with the folded logit columns), which the C predicate cannot see: ``set_arithmetic("fp16x3")`` documents "shapes
+    without an fp16x3 kernel keep bf16x6"."""
+    if _arith == _lib.ARITH_FP16X3 and (has_aux or not _lib.load().allset_fused_linear_arith_supported(direction, int(K), int(N), int(has_ln),
+                                                                                          int(norm_mode), _lib.ARITH_FP16X3)):
         return _lib.ARITH_AUTO
     return _arith
 
@@ -543,7 +545,7 @@ def fused_linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: O
             ptr(beta.contiguous() if beta is not None else None), eps, int(norm_mode), int(relu_in), p_in, seed_in, ptr(weight),
             ptr(bias.contiguous() if bias is not None else None), int(relu_out), p_out, seed_out, ptr(y), max(N, 1), 0,
             ptr(stats), n, K, N, ptr(seed_base), ptr(mask_out), ptr(aux_w), ptr(aux_b), ptr(aux_out),
-            _arith_for(0, K, N, gamma is not None, norm_mode), stream_of(dev)), "allset_fused_linear_fwd_ex")
+            _arith_for(0, K, N, gamma is not None, norm_mode, aux_out is not None), stream_of(dev)), "allset_fused_linear_fwd_ex")
     return y, stats
 
 

@@ -30,7 +30,6 @@ from oracle import allset_oracle as oracle  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-KINK_LEGACY = {"cora_ds_add"}     # generated before the kink guard (round 1): 1.4e-2 upstream of the first relu
 BIG_ROWS = 96           # rows of big per-row tensors kept in a fixture
 BIG_PARAM_NUMEL = 20000  # parameter grads above this size are stored as (sum, abs-sum, 64 samples)
 
@@ -133,9 +132,7 @@ def main() -> None:
                 kink = max(kink, maxdiff(g.double(), o64["grads"][k]) / max(float(o64["grads"][k].abs().max()), 1e-2 * gmax, 1e-30))
         report[name] = dict(oracle_vs_reference_maxabs=diffs, param_grad_rel=gd, worst_rel=worst, reference_vs_float64_rel=kink)
         assert worst <= 1e-6 * (30 if case["big"] else 4), (name, diffs, gd)
-        # (fixtures older than the guard are kept as generated -- the product reproduces the fp32 reference's side of their kink --
-        #  and are listed with their value in REPORT.json)
-        assert kink <= 3e-5 or name in KINK_LEGACY, (name, "fp32 reference vs float64 oracle", kink, "relu kink: add an offset to cases.SEED_SALT")
+        assert kink <= 3e-5, (name, "fp32 reference vs float64 oracle", kink, "relu kink: add an offset to cases.SEED_SALT")
 
         out = {
             "spec_keys": np.array([k for k, _ in spec]),
@@ -183,6 +180,32 @@ def main() -> None:
                        cases=report), f, indent=1, sort_keys=True)
 
 
+def find_salt(name: str, tries: int = 64) -> int:
+    """First offset for ``cases.SEED_SALT[name]`` whose draw (data AND parameters) is one on which fp32 parity is meaningful: the fp32
+    REFERENCE agrees with the float64 oracle to 3e-5 on logits, input gradient and every parameter gradient (the guard of main()),
+    and the float64 oracle's gradients are stable under a 2e-6 perturbation of x (tests/util.py::oracle_is_smooth_here: no relu input
+    within an order of fp32 rounding of zero for ANY correct fp32 implementation, not only for the reference's rounding)."""
+    import util
+    _, ref_models = ref_shim.import_reference()
+    for salt in range(tries):
+        cases.SEED_SALT[name] = salt
+        case = cases.build_case(name)
+        spec, sd_np, ref, _ = run_reference(case, ref_models)
+        o64 = run_oracle(case, sd_np, torch.float64)
+        kink = max(maxdiff(ref[k].double(), o64[k]) / max(float(o64[k].abs().max()), 1e-30) for k in ("logits", "grad_x"))
+        gmax = max(float(g.abs().max()) for g in o64["grads"].values())
+        for k, g in ref["grads"].items():
+            if k in o64["grads"]:
+                kink = max(kink, maxdiff(g.double(), o64["grads"][k]) / max(float(o64["grads"][k].abs().max()), 1e-2 * gmax, 1e-30))
+        sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+        G = torch.from_numpy(cases.cotangent(name, ref["logits"].shape))
+        smooth = kink <= 3e-5 and util.oracle_is_smooth_here(sd, case["args"], case["x"], case["edge_index"], case["norm"], G, seed=salt, eps_bow=1e-6)
+        print(f"{name}: salt {salt}: reference vs float64 {kink:.2e}, smooth under perturbation: {smooth}", flush=True)
+        if smooth:
+            return salt
+    raise SystemExit(f"{name}: no acceptable draw in {tries} offsets")
+
+
 def canon(ei: np.ndarray) -> np.ndarray:
     """Order-free form of an edge list: columns sorted lexicographically (the reference's own sorts are unstable)."""
     order = np.lexsort((ei[1], ei[0]))
@@ -219,6 +242,10 @@ def main_preprocessing() -> None:
 
 
 if __name__ == "__main__":
+    if "--find-salt" in sys.argv:                         # python oracle/gen_golden.py --find-salt case [case ...]
+        for nm in [a for a in sys.argv[1:] if not a.startswith("-")]:
+            print(f'SEED_SALT["{nm}"] = {find_salt(nm)}')
+        sys.exit(0)
     if "--preprocessing-only" not in sys.argv:
         main()
     main_preprocessing()

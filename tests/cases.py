@@ -188,8 +188,10 @@ def _norm_deg_half_sym(ei: np.ndarray) -> np.ndarray:
 # Per-case seed offsets.  A case whose fp32 evaluation sits within rounding of a relu kink (one pre-activation of ~1e6 within 1e-7
 # of zero) has gradients that differ by percents between two CORRECT fp32 implementations -- and between the fp32 reference and its
 # own float64 evaluation.  oracle/gen_golden.py refuses such a draw (float64 oracle vs reference); an offset listed here would be
-# the first one it accepted.  (Empty: the large cases avoid kinks by construction, kinkfree_biases.)
-SEED_SALT: Dict[str, int] = {}
+# the first one it accepted (python oracle/gen_golden.py --find-salt <case>: reference == float64 oracle to 3e-5 AND the float64
+# gradients stable under a perturbation of x, tests/util.py::oracle_is_smooth_here).  The >= 4099-row cases avoid kinks by
+# construction instead (kinkfree_biases).
+SEED_SALT: Dict[str, int] = {"cora_ds_add": 6}
 
 
 def build_case(name: str) -> dict:
@@ -197,7 +199,12 @@ def build_case(name: str) -> dict:
     seed = (zlib.crc32(name.encode()) + SEED_SALT.get(name, 0)) & 0x7FFFFFFF
     rng = np.random.default_rng(seed)
     big = False
-    kinkfree = name.startswith("mid4k_")          # parameters through kinkfree_biases (make_state_dict(..., kinkfree=True))
+    # parameters through kinkfree_biases (make_state_dict(..., kinkfree=True)).  A >= 4099-row case with DATA-DEPENDENT relu patterns
+    # was tried in round 6 ("mid4k_ds_add" without the biases, oracle/gen_golden.py --find-salt): of 64 draws the fp32 REFERENCE is
+    # 3e-3 .. 6e-2 off its own float64 evaluation on 50, and on none of the other 14 are the float64 gradients stable under a 5e-7
+    # perturbation of x (8 half-ulps) -- with ~3e6 relu inputs fed by sums over 7-member hyperedges there is always one within a few
+    # ulps of zero.  Row-varying masks at that size are the training-mode tests' job (per-element dropout: test_gpu_train_parity.py).
+    kinkfree = name.startswith("mid4k_")
     over = {}
     if name.startswith("doc_"):
         _, sl, mode = name.split("_", 2)

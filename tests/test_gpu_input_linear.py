@@ -127,16 +127,31 @@ def test_leaf_feature_path_equals_the_general_path_under_the_same_masks(over, de
     case = cases.build_case("cora_ds_add")
     args = SimpleNamespace(**{**vars(case["args"]), **over})
     # A relu input within rounding of zero (the two paths round the first layer differently) flips one unit: every gradient UPSTREAM
-    # of that relu then moves by ~1e-3 of its maximum while everything downstream still agrees to 1e-6 (measured in round 4; about one parameter draw in three at hidden width 128).  The comparison runs on the first of four
-    # parameter draws that meets the tolerance; a defect of the path would fail all four.
-    last = None
-    for attempt in range(4):
-        try:
-            _compare_paths(case, args, device, ctr, attempt)
-            return
-        except AssertionError as e:
-            last = e
-    raise last
+    # of that relu then moves by ~1e-3 of its maximum while everything downstream still agrees to 1e-6 (measured in round 4; about one
+    # parameter draw in three at hidden width 128).  A draw is accepted A PRIORI -- the float64 oracle under the same hash masks (seed
+    # k-th site = 1000003 * k, the sites in the reference's order) has gradients that are stable under a 2e-6 perturbation of x
+    # (tests/util.py::oracle_is_smooth_here) -- and the two paths are then compared exactly ONCE, on that draw.
+    import util
+    from oracle import allset_oracle as oracle
+    probe = util.ShapeProbe()
+    x_np, ei_np, norm_np = case["x"], case["edge_index"], case["norm"]
+    masks = None
+    for attempt in range(12):
+        torch.manual_seed(case["seed"] + attempt)
+        model = SetGNN(args)
+        model.reset_parameters()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        if masks is None:                                 # the sites in the reference's order, by a dry run of the oracle
+            oracle.setgnn_forward(sd, args, torch.from_numpy(x_np), torch.from_numpy(ei_np).clone(), torch.from_numpy(norm_np), drop=probe)
+            masks = [(dense.dropout_scale(shape, p, 1000003 * (i + 1), device) != 0).cpu() for i, (shape, p) in enumerate(probe.sites)]
+        n_out = model.classifier.lins[-1].weight.shape[0]
+        G = torch.from_numpy(cases.cotangent("cora_ds_add", (x_np.shape[0], n_out)))
+        if util.oracle_is_smooth_here(sd, args, x_np, ei_np, norm_np, G, masks=masks, seed=attempt):
+            break
+    else:
+        pytest.fail("no kink-free parameter draw in twelve attempts: the generator of this test is broken, not the product")
+    n_sites = _compare_paths(case, args, device, ctr, attempt)
+    assert n_sites == len(probe.sites), (n_sites, probe.sites)       # the masks the criterion used are the masks the product drew
 
 
 def _compare_paths(case, args, device, ctr, attempt):
@@ -159,9 +174,11 @@ def _compare_paths(case, args, device, ctr, attempt):
         res.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, ctr[0]))
     (oa, ga, ca), (ob, gb, cb) = res
     assert ca == cb and set(ga) == set(gb)
+    n_sites = ca
     torch.testing.assert_close(oa, ob, rtol=0, atol=1e-4 * float(ob.abs().max()))
     for k in ga:
         torch.testing.assert_close(ga[k], gb[k], rtol=0, atol=1e-4 * float(gb[k].abs().max()) + 1e-12, msg=lambda m: f"{k}: {m}")
+    return n_sites
 
 
 @pytest.mark.parametrize("n,d,O,density", [(2708, 1433, 64, 0.0127), (3312, 3703, 128, 0.0086), (100, 300, 256, 0.05), (37, 257, 64, 0.0),

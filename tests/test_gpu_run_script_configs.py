@@ -50,27 +50,19 @@ def test_run_script_configuration_matches_the_oracle(tag, heads, hidden, chid, m
     # Parity is only meaningful where the model is smooth: a relu input within fp32 rounding of zero (there are ~10^5 relu
     # inputs per example) makes the exact gradient itself jump -- the first data drawn for the citeseer branch has one: its
     # FLOAT64 gradient moves by 1.3 % of its scale under a 1e-7 perturbation of x, in one direction only.  Such examples are
-    # re-drawn (next seed), as tests/test_gpu_random_shapes.py rejects them.
+    # re-drawn (next seed), as tests/test_gpu_random_shapes.py rejects them -- accepted or refused by util.oracle_is_smooth_here (the
+    # float64 oracle alone, before the product has run), then compared ONCE.
     for attempt in range(30):
         case = _case(tag, "pma_h1" if mode == "pma" else "ds_add", heads, hidden, chid, attempt)
         case["args"].heads = heads
         spec = [(k, tuple(v.shape)) for k, v in SetGNN(case["args"]).state_dict().items()]
         sd = {k: torch.from_numpy(v) for k, v in cases.make_state_dict(spec, case["seed"], case.get("kinkfree", False)).items()}
         o64 = util.run_oracle(case, sd, torch.float64)
-        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        G = torch.from_numpy(cases.cotangent(case["name"], o64["logits"].shape)).double()
-        dirn = torch.from_numpy(np.random.default_rng(case["seed"]).standard_normal(case["x"].shape))
-        gs = max(1.0, float(o64["grad_x"].abs().max()))
-        stable = True
-        for sgn in (1.0, -1.0):
-            xp = (torch.from_numpy(case["x"]).double() + sgn * 2e-6 * dirn).requires_grad_(True)     # (an order above fp32 rounding of x)
-            lp = oracle.setgnn_forward(sd64, case["args"], xp, torch.from_numpy(case["edge_index"]), torch.from_numpy(case["norm"]))
-            (lp * G).sum().backward()
-            stable = stable and float((xp.grad - o64["grad_x"]).abs().max()) <= 3e-4 * gs
-        if stable:
+        G = torch.from_numpy(cases.cotangent(case["name"], o64["logits"].shape))
+        if util.oracle_is_smooth_here(sd, case["args"], case["x"], case["edge_index"], case["norm"], G, seed=case["seed"]):
             break
     else:
-        pytest.skip("no kink-free example in thirty draws")
+        pytest.fail("no kink-free example in thirty draws: the generator of this test is broken, not the product")
     res = util.run_product(case, sd, device)
     orc = util.run_oracle(case, sd)
     # Yardstick: the oracle in float64.  Allowed distance: 1e-4 of the tensor's scale, or -- where the fp32 ORACLE itself is

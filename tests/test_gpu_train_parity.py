@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 import cases
+import util
 
 pytestmark = pytest.mark.gpu
 
@@ -38,16 +39,7 @@ def _keep_mask(seed: int, shape, p: float, device) -> torch.Tensor:
     return keep.cpu()
 
 
-class _ShapeProbe:
-    """A ``drop`` callable for the oracle that only records (shape, p) of every site it meets (values pass through)."""
-
-    def __init__(self):
-        self.sites = []
-
-    def __call__(self, x, p):
-        if p > 0.0:
-            self.sites.append((tuple(x.shape), float(p)))
-        return x
+_ShapeProbe = util.ShapeProbe
 
 
 CASES = [("rand50_ds_add", {}), ("rand50_pma_h4", {}), ("cora_ds_add", {}), ("citeseer_pma_h4", {}),
@@ -73,6 +65,16 @@ def test_training_step_in_the_strict_arithmetic(name, device, monkeypatch):
     dropout-bearing 128 x 128 instantiations of BOTH kernel families are pinned to the oracle."""
     from allset_amd import dense
     with dense.arithmetic("strict"):
+        test_training_step_matches_oracle_with_the_products_masks(name, {}, device, monkeypatch)
+
+
+@pytest.mark.parametrize("name", ["citeseer_pma_h4", "mid4k_pma_h4", "rand50_pma_h4", "rand50_ds_add_d128"])
+def test_training_step_under_an_explicit_fp16x3_request(name, device, monkeypatch):
+    """``dense.set_arithmetic("fp16x3")`` (``bench.py --arith fp16x3``): shapes WITHOUT an fp16x3 kernel keep bf16x6 instead of
+    raising -- in particular PMA's value projection at 128 x 128 with H <= 4 auxiliary logit columns (the forward with ``aux_out``,
+    which ``allset_fused_linear_arith_supported`` cannot see: ADVICE r5).  Forward and backward of the whole model, against the oracle."""
+    from allset_amd import dense
+    with dense.arithmetic("fp16x3"):
         test_training_step_matches_oracle_with_the_products_masks(name, {}, device, monkeypatch)
 
 
@@ -114,7 +116,7 @@ def test_training_step_matches_oracle_with_the_products_masks(name, over, device
         if _one_training_step(name, over, device, seeds, attempt, need_stable=bn):
             break
     else:
-        pytest.skip("no kink-free parameter draw in twelve attempts")
+        pytest.fail("no kink-free parameter draw in twelve attempts: the generator of this test is broken, not the product")
     if name in ("rand50_ds_add_d128", "mid4k_ds_add"):
         # the bench's own variants were on the compared path: the "heavy" 128 x 128 forward (LayerNorm + dropout in, relu +
         # dropout + mask out) and the "heavy" one-pass backward (LayerNorm + dropout + relu in, mask on gy), plus the light ones
@@ -146,22 +148,18 @@ def test_training_step_on_features_without_gradient(name, over, device, monkeypa
     # Deeper Cora-shaped stacks: ~1M relu inputs per evaluation, and raw-feature rows whose few non-zeros become x_hat ~ 20 -- one
     # relu input within fp32 rounding of zero moves whole columns of the first weight gradient by percents of its maximum, on THIS
     # path and on the general one alike (measured in round 4: 2 of 6 draws pass there, 1-2 of 6 here; MLP_num_layers = 1 passes
-    # 6 of 6 on both).  Those configurations pass on the first parameter draw that meets the tolerance; that the two product paths
-    # agree with each other on every draw (1e-5 of the gradient's maximum, MLP_num_layers = 3 / MLP_hidden = 128 included) is
+    # 6 of 6 on both).  Those configurations are evaluated on the first parameter draw that the FLOAT64 ORACLE finds smooth (its
+    # gradients w.r.t. x and every parameter stable under a 2e-6 perturbation of x, same masks: util.oracle_is_smooth_here) and
+    # asserted exactly once there -- a draw is never accepted or refused on the outcome of the comparison; that the two product paths
+    # agree with each other (1e-5 of the gradient's maximum, MLP_num_layers = 3 / MLP_hidden = 128 included) is
     # tests/test_gpu_input_linear.py::test_leaf_feature_path_equals_the_general_path_under_the_same_masks.
     deep = bool(over) and over != dict(MLP_num_layers=1)
-    last = None
-    for attempt in range(8 if deep else 1):
+    for attempt in range(12 if deep else 1):
         seeds.clear()
-        try:
-            assert _one_training_step(name, over, device, seeds, attempt, need_stable=False, leaf_x=True)
+        if _one_training_step(name, over, device, seeds, attempt, need_stable=deep, leaf_x=True):     # (asserts once on an accepted draw)
             break
-        except AssertionError as e:
-            last = e
-            if not deep:
-                raise
     else:
-        raise last
+        pytest.fail("no kink-free parameter draw in twelve attempts: the generator of this test is broken, not the product")
     assert bool(calls) == ("_ds_" in name)                # (the PMA conv projects with lin_V / lin_K: no MLP in front)
 
 
@@ -210,18 +208,10 @@ def _one_training_step(name, over, device, seeds, attempt, need_stable, leaf_x=F
         if m.numel() >= 2000:
             assert abs(1.0 - float(m.float().mean()) - p) < 0.05, (shape, p, float(m.float().mean()))
 
-    if need_stable:                                       # float64 oracle with the same masks at x and at x +- 2e-6 * direction
-        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        dirn = torch.from_numpy(np.random.default_rng(attempt).standard_normal(x_np.shape))
-        grads = []
-        for sgn in (0.0, 1.0, -1.0):
-            xp = (torch.from_numpy(x_np).double() + sgn * 2e-6 * dirn).requires_grad_(True)
-            lp = oracle.setgnn_forward(sd64, args, xp, torch.from_numpy(ei_np), torch.from_numpy(norm_np), drop=oracle.ExplicitDropout(masks))
-            (lp * G.cpu().double()).sum().backward()
-            grads.append(xp.grad)
-        gs = max(1.0, float(grads[0].abs().max()))
-        if max(float((g - grads[0]).abs().max()) for g in grads[1:]) > 3e-4 * gs:
-            return False
+    # ---- is this parameter draw one on which fp32 parity means anything?  Decided by the float64 ORACLE alone (same masks, x and
+    # x +- 2e-6 * direction, gradient w.r.t. x and every parameter: tests/util.py), BEFORE the comparison below -- never by its outcome.
+    if need_stable and not util.oracle_is_smooth_here(sd, args, x_np, ei_np, norm_np, G, masks=masks, seed=attempt):
+        return False
 
     # ---- oracle, training mode, same masks
     sdo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
