@@ -509,9 +509,10 @@ def parallelism_label(args, mode, world):
     if mode.startswith("hybrid"):
         R = int(mode[len("hybrid"):].split("x")[0])
         C = world // R
-        return (f"hybrid {R} target groups x {C} column groups (rank (a, b): the targets of group a, d/{C} columns; per aggregation an "
-                f"all-to-all inside the column group, an all-gather across the {R} groups, the local aggregation over rows of d/{C} "
-                "columns, an all-to-all back; allset_amd.dist.ColumnShardedHypergraph(row_groups=...))")
+        return (f"hybrid {R} target groups x {C} column groups (rank (a, b): the targets of group a, d/{C} columns; per aggregation ONE "
+                f"world-wide all-to-all that sends column slice b' of a rank's rows to all {R} ranks (., b') -- the rows -> columns "
+                f"change of layout replicated to the {R} target groups, dist._SpreadBlocks --, the local aggregation over rows of "
+                f"d/{C} columns, an all-to-all back inside the column group; allset_amd.dist.ColumnShardedHypergraph(row_groups=...))")
     how = f"in {args.pipeline_chunks} overlapped chunks" if args.pipeline_chunks > 1 else "blocking"
     return f"column-shard x{world} (rows for the dense tail, d/{world} columns for the aggregation; all-to-all exchange {how})"
 

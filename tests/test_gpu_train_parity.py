@@ -145,25 +145,30 @@ def test_training_step_on_features_without_gradient(name, over, device, monkeypa
     calls = []
     real = dense.input_norm_linear
     monkeypatch.setattr(dense, "input_norm_linear", lambda *a, **k: calls.append(1) or real(*a, **k))
-    # Deeper Cora-shaped stacks: ~1M relu inputs per evaluation, and raw-feature rows whose few non-zeros become x_hat ~ 20 -- one
-    # relu input within fp32 rounding of zero moves whole columns of the first weight gradient by percents of its maximum, on THIS
-    # path and on the general one alike (measured in round 4: 2 of 6 draws pass there, 1-2 of 6 here; MLP_num_layers = 1 passes
-    # 6 of 6 on both).  Those configurations are evaluated on the first parameter draw that the FLOAT64 ORACLE finds smooth (its
-    # gradients w.r.t. x and every parameter stable under a 2e-6 perturbation of x, same masks: util.oracle_is_smooth_here) and
-    # asserted exactly once there -- a draw is never accepted or refused on the outcome of the comparison; that the two product paths
-    # agree with each other (1e-5 of the gradient's maximum, MLP_num_layers = 3 / MLP_hidden = 128 included) is
-    # tests/test_gpu_input_linear.py::test_leaf_feature_path_equals_the_general_path_under_the_same_masks.
-    deep = bool(over) and over != dict(MLP_num_layers=1)
-    for attempt in range(12 if deep else 1):
+    # Cora-shaped bag-of-words rows: the few non-zeros become x_hat ~ 20 behind the input LayerNorm, and ONE relu input within fp32
+    # rounding of zero moves whole columns of the first weight gradient by percents of its maximum -- on THIS path and on the general
+    # one alike (two correct fp32 evaluations disagree; round 4 measured 2 of 6 draws passing on either).  No draw is ever accepted or
+    # refused on the outcome of the comparison:
+    #  * the stock stack and MLP_num_layers = 1 are evaluated on the first parameter draw the FLOAT64 ORACLE finds smooth under the
+    #    product's own masks (util.oracle_is_smooth_here: gradients w.r.t. x and every parameter stable under a relative 5e-7
+    #    perturbation of x; measured acceptance with random masks: 8 of 16 draws) and asserted exactly once there;
+    #  * the deeper stacks (~1M relu inputs; measured acceptance 1 of 16 at 5e-7, 4 of 16 at 2.5e-7 -- and an accepted draw can still
+    #    sit within rounding of a kink) take their relus off the kink by construction instead (cases.kinkfree_biases on the freshly
+    #    initialised model, as the >= 4099-row fixtures do): what this test pins on them is the raw-feature path -- hashed input
+    #    dropout, folded weight, every first-layer parameter gradient out of one GEMM -- not relu patterns.
+    # That the two product paths agree with each other is tests/test_gpu_input_linear.py::test_leaf_feature_path_equals_the_general_path_under_the_same_masks.
+    bow = name == "cora_ds_add"
+    deep = bow and bool(over) and over != dict(MLP_num_layers=1)
+    for attempt in range(12 if (bow and not deep) else 1):
         seeds.clear()
-        if _one_training_step(name, over, device, seeds, attempt, need_stable=deep, leaf_x=True):     # (asserts once on an accepted draw)
+        if _one_training_step(name, over, device, seeds, attempt, need_stable=bow and not deep, leaf_x=True, kinkfree=deep):     # (asserts once on an accepted draw)
             break
     else:
         pytest.fail("no kink-free parameter draw in twelve attempts: the generator of this test is broken, not the product")
     assert bool(calls) == ("_ds_" in name)                # (the PMA conv projects with lin_V / lin_K: no MLP in front)
 
 
-def _one_training_step(name, over, device, seeds, attempt, need_stable, leaf_x=False):
+def _one_training_step(name, over, device, seeds, attempt, need_stable, leaf_x=False, kinkfree=False):
     from allset_amd import SetGNN
     from oracle import allset_oracle as oracle
     case = cases.build_case(name)
@@ -172,7 +177,7 @@ def _one_training_step(name, over, device, seeds, attempt, need_stable, leaf_x=F
     torch.manual_seed(case["seed"] + attempt)
     model = SetGNN(args)
     model.reset_parameters()
-    if case.get("kinkfree"):
+    if case.get("kinkfree") or kinkfree:
         cases.kinkfree_biases(dict(model.named_parameters()))
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.train().to(device)

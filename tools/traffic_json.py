@@ -45,7 +45,7 @@ def main():
     shape, fdir, wdir = sys.argv[1:4]
     F, W = per_dispatch(fdir, "FETCH_SIZE"), per_dispatch(wdir, "WRITE_SIZE")
     sha = bench.kernel_source_sha()
-    stamp = {"kernel_source_sha": sha, "taken": os.environ.get("ALLSET_ROUND", "round 4")}
+    stamp = {"kernel_source_sha": sha, "taken": os.environ.get("ALLSET_ROUND", "round 6")}
     avg = lambda xs: sum(xs) / len(xs)
     if shape == "c3":
         sf, sw = pick(F, "segreduce_kernel"), pick(W, "segreduce_kernel")
