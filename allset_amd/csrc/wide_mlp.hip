@@ -188,10 +188,25 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   // one arena: A slabs [buffer][plane][row][32 x 16 bit = 4 x 16 B], B slabs likewise, and -- after the K loop -- the fp32
   // output tile on its way from the MFMA layout to row-major 16-byte stores
   constexpr int NP = F16 ? 2 : 3, NPC = 2 * NP;
+  // kSwap (round 6, the forward): the MFMA operands trade places -- the weight fragment is the A operand, the activation fragment B --
+  // so a lane's four accumulator registers of a 16 x 16 tile are FOUR CONSECUTIVE OUTPUT COLUMNS of one row (lane (fr, fg): row fr,
+  // columns 4 fg .. 4 fg + 3) instead of one column of four rows: bias / relu / dropout / the 1-bit mask / the next LayerNorm's row
+  // statistics are applied where the MFMA left the numbers and the tile leaves as 16-byte stores -- no trip of the 133-KB output tile
+  // through LDS, no epilogue barriers, and the staging arena is free for the next tile's first K step while slower waves finish their
+  // epilogue.  The fragments in LDS are the same either way.  Measured (profiles/r06_wide_swap.txt): forward 0.655-0.68 -> 0.648 ms at
+  // [1M, 256] x [256, 256] -- the row pass was never the 24-29 % its cycle share suggested: a tile takes ~21 us, of which the K loop's
+  // eight ~2.3-us steps are 17-19.  The LayerNorm-BACKWARD form keeps the LDS trip: its epilogue needs the tile's 128 KB of x rows in
+  // flight at once (64 registers per lane), which only fit because the accumulators have left for LDS by then -- the register-resident
+  // form was built and measured (x rows streamed through two 16-register sets, twice: eight dependent round trips per tile): 0.94 ->
+  // 1.43 ms, reverted.
+  constexpr bool kSwap = !LNB;
   constexpr int kASlab = NP * kGxBM * 4, kBSlab = NP * kGxBN * 4, kOutPitch = kGxBN + 4;
   constexpr int kSlabs = 2 * kASlab + 2 * kBSlab, kTile16 = (kGxBM * kOutPitch * 4 + 15) / 16;
-  __shared__ __attribute__((aligned(16))) uint4 smem[kSlabs > kTile16 ? kSlabs : kTile16];
-  __shared__ float sRowInv[F16 ? kGxBM : 1];          // fp16x3: what undoes the row's (or the launch's) A scale in the epilogue
+  __shared__ __attribute__((aligned(16))) uint4 smem[(LNB && kTile16 > kSlabs) ? kTile16 : kSlabs];   // (the forward's tile never visits LDS: kSwap)
+  // fp16x3: what undoes the row's (or the launch's) A scale in the epilogue; by tile parity (kSwap: a wave may start the next tile --
+  // and write its row scales -- while another still reads this tile's in its epilogue; they meet again at the next tile's first barrier)
+  __shared__ float sRowInv[F16 ? 2 * kGxBM : 1];
+  __shared__ __attribute__((aligned(16))) float sStat[kGxBM * 4];    // kSwap + stats_out: per row, the four column quarters' partial sums
   // gamma / beta of the LayerNorm-apply prologue, once per workgroup: fetched from global memory inside the staging path
   // they would sit behind an s_waitcnt vmcnt(0) -- which also drains the prefetch of the next A / B slabs -- four times a step
   __shared__ __attribute__((aligned(16))) float sGB[2 * 512];
@@ -368,11 +383,13 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
           GxFragH b[2];
 #pragma unroll
           for (int p = 0; p < 2; ++p) b[p].u = sB[buf][p * kGxBN * 4 + b_at + ct * 64];
+#define GX_MM16(X, Y, C) (kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_f16(Y, X, C, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(X, Y, C, 0, 0, 0))
 #define GX_MFMAH(PA, PB)                                                                                                  \
-  acc[rh * 2][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][PA].v, b[PB].v, acc[rh * 2][ct], 0, 0, 0);                \
-  acc[rh * 2 + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][PA].v, b[PB].v, acc[rh * 2 + 1][ct], 0, 0, 0)
+  acc[rh * 2][ct] = GX_MM16(a[0][PA].v, b[PB].v, acc[rh * 2][ct]);                                                        \
+  acc[rh * 2 + 1][ct] = GX_MM16(a[1][PA].v, b[PB].v, acc[rh * 2 + 1][ct])
           GX_MFMAH(1, 0); GX_MFMAH(0, 1); GX_MFMAH(0, 0);              // l.h, h.l, h.h
 #undef GX_MFMAH
+#undef GX_MM16
         }
       }
     } else {
@@ -389,11 +406,13 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
 #pragma unroll
         for (int p = 0; p < 3; ++p) b[p].u = sB[buf][p * kGxBN * 4 + b_at + ct * 64];
         // smallest products first; consecutive MFMAs alternate between two accumulators
+#define GX_MMB(X, Y, C) (kSwap ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(Y, X, C, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y, C, 0, 0, 0))
 #define GX_MFMA2(PA, PB)                                                                                                  \
-  acc[rh * 2][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][PA].v, b[PB].v, acc[rh * 2][ct], 0, 0, 0);               \
-  acc[rh * 2 + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][PA].v, b[PB].v, acc[rh * 2 + 1][ct], 0, 0, 0)
+  acc[rh * 2][ct] = GX_MMB(a[0][PA].v, b[PB].v, acc[rh * 2][ct]);                                                         \
+  acc[rh * 2 + 1][ct] = GX_MMB(a[1][PA].v, b[PB].v, acc[rh * 2 + 1][ct])
         GX_MFMA2(1, 1); GX_MFMA2(2, 0); GX_MFMA2(0, 2); GX_MFMA2(1, 0); GX_MFMA2(0, 1); GX_MFMA2(0, 0);
 #undef GX_MFMA2
+#undef GX_MMB
       }
     }
     }
@@ -444,12 +463,13 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   }
   const uint4* img_cur = planes + static_cast<int64_t>(tile % n_tiles) * ksteps * kBSlab;
   GX_LOAD(cur, img_cur, 0);
-  for (; tile < total; tile += gridDim.x) {
+  int tpar = 0;                                                        // parity of the tile count (sRowInv)
+  for (; tile < total; tile += gridDim.x, tpar ^= 1) {
     const int64_t next = tile + gridDim.x;
     const bool has_next = next < total;
     GxRow nxt = row_ctx(has_next ? next : tile);                       // (stats of the next tile are in flight early)
     if constexpr (F16) {                                               // what the epilogue multiplies a row of the tile by
-      if (s_seg == 0) sRowInv[s_row] = rowsc ? 1.f / cur.asc : launch_inv;
+      if (s_seg == 0) sRowInv[tpar * kGxBM + s_row] = rowsc ? 1.f / cur.asc : launch_inv;
       nmax = 0.f;
     }
     const uint4* img_nxt = planes + static_cast<int64_t>((has_next ? next : tile) % n_tiles) * ksteps * kBSlab;
@@ -507,6 +527,103 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
     // that layout are issue-bound (~5 B/clk/CU), so the tile takes one trip through LDS (pitch 260 floats: the four row
     // groups of a wave land on disjoint banks) and leaves as whole rows of 16-byte stores -- which then drain while the
     // next tile's K loop runs; bias / relu / dropout on the row-major side.
+    if constexpr (kSwap) {
+      // ---- register epilogue.  acc[rt][ct] = out[row0 + wr*64 + rt*16 + fr][ntile*256 + wc*64 + ct*16 + 4*fg + (0..3)]
+      const int64_t row0s = tile / n_tiles * kGxBM;
+      const int ncol0 = static_cast<int>(tile % n_tiles) * kGxBN + wc * 64 + 4 * fg;      // + 16 ct
+      float4 bv[4], cs[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int n = ncol0 + 16 * ct;
+        bv[ct] = (epi.bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(epi.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (F16) cs[ct] = *reinterpret_cast<const float4*>(bscale + n);           // (bscale has n_pad entries: always in range)
+        else cs[ct] = make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+      const float out_floor = epi.relu_out ? 0.f : -INFINITY;
+      const bool has_drop = epi.p_out > 0.f, has_mask = epi.mask_out != nullptr;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int rr = wr * 64 + rt * 16 + fr;
+        const int64_t row = row0s + rr;
+        const float ri = F16 ? sRowInv[tpar * kGxBM + rr] : 1.f;
+        uint32_t mbits[2] = {0u, 0u};                                  // this lane's bits of the row's two mask dwords (32-column halves)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int n = ncol0 + 16 * ct;
+          float4 o = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
+          if constexpr (F16) {
+            o.x = fmaf(o.x, ri * cs[ct].x, bv[ct].x); o.y = fmaf(o.y, ri * cs[ct].y, bv[ct].y);
+            o.z = fmaf(o.z, ri * cs[ct].z, bv[ct].z); o.w = fmaf(o.w, ri * cs[ct].w, bv[ct].w);
+          } else {
+            o.x += bv[ct].x; o.y += bv[ct].y; o.z += bv[ct].z; o.w += bv[ct].w;
+          }
+          o.x = fmaxf(o.x, out_floor); o.y = fmaxf(o.y, out_floor); o.z = fmaxf(o.z, out_floor); o.w = fmaxf(o.w, out_floor);
+          if (has_drop) {
+            const float4 k = keep_scale4(seed_out, row * N + n, thr_out, inv_out);
+            o.x *= k.x; o.y *= k.y; o.z *= k.z; o.w *= k.w;
+          }
+          acc[rt][ct][0] = o.x; acc[rt][ct][1] = o.y; acc[rt][ct][2] = o.z; acc[rt][ct][3] = o.w;     // (stats_out reads them back)
+          if (row < rows && n < N) *reinterpret_cast<float4*>(out + row * ldo + n) = o;
+          if (has_mask) {
+            // "mask layout" (include/allset_hip_ext.h): the dword of (row, 32-column half) has bit 8 q + (c % 8) for column 4 c + q of
+            // its 64-column block; here c % 8 = 4 (ct & 1) + fg
+            const int sh = 4 * (ct & 1) + fg;
+            mbits[ct >> 1] |= ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 0x100u : 0u) | (o.z > 0.f ? 0x10000u : 0u) | (o.w > 0.f ? 0x1000000u : 0u)) << sh;
+          }
+        }
+        if (has_mask) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint32_t w = mbits[h];
+            w |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(w), 16));
+            w |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(w), 32));
+            const int col = static_cast<int>(tile % n_tiles) * kGxBN + wc * 64 + 32 * h;
+            if (fg == 0 && row < rows && col < N)
+              (epi.mask_out + ((row >> 4) * (N / 64)) * 32 + ((row & 15) >> 2) * 8 + (row & 3) * 2)[(col >> 6) * 32 + ((col & 63) >> 5)] = w;
+          }
+        }
+      }
+      if (epi.stats_out != nullptr) {
+        // {mean, rstd} of stats_relu ? relu(out) : out per row (N == 256: the row's four 64-column quarters sit in the four waves wc of a
+        // row band): per-lane partial sums over its 16 columns, the four lanes fg of a row by two shuffles, the four waves through LDS;
+        // two passes (mean, then the squared deviations) as the row pass had them
+        const float sf = epi.stats_relu ? 0.f : -INFINITY;
+        float mean4[4];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            float a = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float t = fmaxf(acc[rt][ct][q], sf);
+                if (ph == 0) a += t; else { const float dlt = t - mean4[rt]; a = fmaf(dlt, dlt, a); }
+              }
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            if (fg == 0) sStat[(wr * 64 + rt * 16 + fr) * 4 + wc] = a;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            const float4 p4 = *reinterpret_cast<const float4*>(&sStat[(wr * 64 + rt * 16 + fr) * 4]);
+            const float tot = ((p4.x + p4.y) + (p4.z + p4.w)) * (1.f / kGxBN);
+            if (ph == 0) mean4[rt] = tot;
+            else {
+              const int64_t row = row0s + wr * 64 + rt * 16 + fr;
+              if (wc == 0 && fg == 0 && row < rows) *reinterpret_cast<float2*>(epi.stats_out + row * 2) = make_float2(mean4[rt], rsqrtf(tot + epi.stats_eps));
+            }
+          }
+          __syncthreads();
+        }
+      }
+      if constexpr (F16) { if (rowsc && has_next) nxt.asc = row_scale(nmax); }
+      cur = nxt;
+      img_cur = img_nxt;
+      continue;
+    }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -568,7 +685,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
           float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
           if (act) gv = *reinterpret_cast<const float4*>(sOut + rr * kOutPitch + c4);
           float kz = row < rows ? 1.f : 0.f;                           // (wave-uniform) a row past the end contributes nothing
-          if constexpr (F16) kz *= sRowInv[rr];
+          if constexpr (F16) kz *= sRowInv[tpar * kGxBM + rr];
           gv.x *= kz * cs4.x; gv.y *= kz * cs4.y; gv.z *= kz * cs4.z; gv.w *= kz * cs4.w;
           const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lnb_sp.x), it));
           const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lnb_sp.y), it));
@@ -630,7 +747,7 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
           const int64_t row = row0 + rr;
           float4 o = v[i];
           if constexpr (F16) {
-            const float ri = sRowInv[rr];
+            const float ri = sRowInv[tpar * kGxBM + rr];
             o.x = fmaf(o.x, ri * cs4.x, bv.x); o.y = fmaf(o.y, ri * cs4.y, bv.y); o.z = fmaf(o.z, ri * cs4.z, bv.z); o.w = fmaf(o.w, ri * cs4.w, bv.w);
           } else {
             o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;

@@ -239,8 +239,10 @@ def test_setgnn_bf16_matches_the_oracle_on_bf16_rounded_inputs(name, device):
     is measured, not guessed: the YARDSTICK is the same oracle evaluated in bfloat16 on the CPU (every stored activation rounded to
     2^-9 relative, torch's bf16 kernels) -- its relative L2 distance from the fp32 evaluation is 0.4 % on logits, 2 - 10 % on
     AllSetTransformer gradients, 11 - 17 % on AllDeepSets gradients (un-normalised segment sums in front of a LayerNorm amplify the
-    rounding).  The product must be within 1.5 x the yardstick's distance (+ 5e-3) on every tensor.  A wrong weight gradient (an
-    operand transposed, a missing mask) is at relative distance ~1 and fails by an order of magnitude."""
+    rounding).  The product must be within 1.5 x the yardstick's distance (+ 5e-3 of the tensor's norm, + 3e-4 of the case's largest
+    gradient norm: a gradient tensor a hundred times smaller than its neighbours -- lin_K.bias, the signal through the attention
+    logits -- carries their absolute rounding noise) on every tensor.  A wrong weight gradient (an operand transposed, a missing
+    mask) is at relative distance ~1 and fails by an order of magnitude."""
     from types import SimpleNamespace
     from allset_amd import SetGNN
     from oracle import allset_oracle as oracle
@@ -285,9 +287,10 @@ def test_setgnn_bf16_matches_the_oracle_on_bf16_rounded_inputs(name, device):
         if k.startswith("grad ") and float(e.norm()) < 1e-3 * gnorm:
             continue                                      # analytically (near-)zero gradients: rounding noise on every side
         dp, dy = _rel_l2(got[k], e), _rel_l2(yard[k], e)
-        worst.append((dp / (1.5 * dy + 5e-3), k, dp, dy))
+        floor = 3e-4 * gnorm / max(float(e.norm()), 1e-30) if k.startswith("grad ") else 0.0
+        worst.append((dp / (1.5 * dy + 5e-3 + floor), k, dp, dy))
     bad = [w for w in worst if w[0] > 1.0]
-    assert not bad, f"{name}: product further from the fp32 oracle than 1.5 x the bf16 oracle + 5e-3 on " + \
+    assert not bad, f"{name}: product further from the fp32 oracle than 1.5 x the bf16 oracle + floors on " + \
         "; ".join(f"{k} (product {dp:.3e}, bf16 oracle {dy:.3e})" for _, k, dp, dy in sorted(bad, reverse=True))
 
 
