@@ -598,21 +598,12 @@ static void launch_bwd_all(unsigned grid, hipStream_t st, bool ln, bool drop, bo
                                                                                    gamma, beta, p_in, seed_in, gx, ldgx,      \
                                                                                    part_ln, part_w, part_b, n, seed_base,     \
                                                                                    acc_in, ldacc, psw, psb, psl, ln_inv)
-#ifdef ALLSET_ABL_SINGLE       // ablation builds: one instantiation, whatever the flags say
-#ifdef ALLSET_ABL_LIGHT
-  ALLSET_BWD_ALL_K(true, false, false, false, false);
-#else
-  ALLSET_BWD_ALL_K(true, true, true, true, false);
-#endif
-  return;
-#else
   if (ha) { ALLSET_BWD_ALL_K(false, false, false, false, true); return; }
 #define ALLSET_BWD_ALL_M(LN, DI, RI)                                                               \
   do { if (hm) ALLSET_BWD_ALL_K(LN, DI, RI, true, false); else ALLSET_BWD_ALL_K(LN, DI, RI, false, false); } while (0)
   if (!relu) { if (ln) ALLSET_BWD_ALL_M(true, false, false); else ALLSET_BWD_ALL_M(false, false, false); }
   else if (ln) { if (drop) ALLSET_BWD_ALL_M(true, true, true); else ALLSET_BWD_ALL_M(true, false, true); }
   else { if (drop) ALLSET_BWD_ALL_M(false, true, true); else ALLSET_BWD_ALL_M(false, false, true); }
-#endif
 #undef ALLSET_BWD_ALL_M
 #undef ALLSET_BWD_ALL_K
 }
@@ -705,14 +696,11 @@ static int fused_linear_bwd_all_impl(const float* gy, int64_t ldg, const uint32_
   }
 #define ALLSET_BWD_ALL_ARGS grid, st, has_ln, drop, relu, hm, ha, gy, ldg, mask, p_out, W, x, ldx, stats, gamma, beta, p_in, seed_in, \
                             gx, ldgx, part_ln, part_w, part_b, n, seed_base, acc_in, ldacc, psw, psb, psl, ln_inv
-#ifdef ALLSET_ABL_SINGLE
-  launch_bwd_all<128, 128>(ALLSET_BWD_ALL_ARGS);
-#else
-  if (O == 128 && I == 128) launch_bwd_all<128, 128>(ALLSET_BWD_ALL_ARGS);
-  else if (O == 128 && I == 64) launch_bwd_all<128, 64>(ALLSET_BWD_ALL_ARGS);
+  // (O = I = 128 never arrives here: the split-role kernels above take it in either arithmetic.  Its 13 instantiations of this kernel
+  //  were still built until round 6 -- profiles/r06_kernel_audit.md found them never launched, the dispatcher says why -- and are gone.)
+  if (O == 128 && I == 64) launch_bwd_all<128, 64>(ALLSET_BWD_ALL_ARGS);
   else if (O == 64 && I == 128) launch_bwd_all<64, 128>(ALLSET_BWD_ALL_ARGS);
   else launch_bwd_all<64, 64>(ALLSET_BWD_ALL_ARGS);
-#endif
 #undef ALLSET_BWD_ALL_ARGS
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;

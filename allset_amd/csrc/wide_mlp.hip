@@ -821,6 +821,438 @@ __global__ __launch_bounds__(kGxThreads) void gemm_x6_kernel(
   }
 }
 
+// ---- the forward on fp16 planes with the CU's waves SPLIT BY ROLE (round 6) ------------------------------------------------------------
+// gemm_x6_kernel<.., F16> has every wave do everything: per K step a wave multiplies (48 MFMAs, ~800 cycles), then runs the prologue
+// on its share of the next A slab (LayerNorm-apply, dropout hash, fp16 split: ~1300 cycles of dependent vector work and LDS stores),
+// then issues the loads of the step after -- 2750 cycles of serial work per wave and step, 3300-5500 measured with the barrier's skew
+// (profiles/r05_gemm_wide_segments.txt), a tile of 128 rows in ~21 us where its MFMAs need 5 and its bytes 6.  Same cure as at width
+// 128 (fused_fwd2.hip): 1024 threads, waves 0-7 do ALL the vector work (the staging thread map of the kernel above, unchanged: thread
+// (row = t >> 2, segment = t & 3) of 512), waves 8-15 ALL the matrix work (the 64 x 64 sub-tile map of the kernel above: wave (wr, wc));
+// every SIMD holds two vector waves, whose dependent chains hide each other's latency, and two matrix waves that issue nothing but
+// fragment reads and MFMAs.  One barrier per K step ("tick"): at tick g the vector waves stage step g into buffer g & 1 -- out of
+// registers they requested FOUR steps earlier (A: four register sets, 64 KB in flight per CU; the weight pieces, L2-resident: two)
+// -- while the matrix waves multiply step g - 1 out of the other buffer.  The stream of steps runs across tiles: the vector
+// waves stage the next tile's first steps while the matrix waves finish a tile and run its epilogue IN THEIR ACCUMULATOR REGISTERS
+// (operands swapped: a lane holds four consecutive output columns of a row -- bias / relu / dropout / 1-bit mask / the next
+// LayerNorm's row statistics -- after each wave has turned its patch row-major through a private 4-KB piece of LDS, no barrier: see
+// `epilogue`).  LDS: two 48-KB stages + gamma / beta + the patches = 138 KB.
+// Results are bit-identical to gemm_x6_kernel<.., F16>'s: the same planes, the same products in the same order.
+constexpr int kGrThreads = 1024, kGrVThreads = 512, kGrPatchPitch = 68;
+
+// ROWSC: no LayerNorm-apply prologue (pro.stats == NULL): A is scaled per row.  A template parameter, not a run-time switch: every
+// global load of the vector waves' loop is then UNCONDITIONAL -- behind a (uniform) branch hipcc's wait-count bookkeeping gives up at
+// the join and waits for vmcnt(0), i.e. for the requests issued four steps ahead: the prefetch is gone and every tick costs a memory
+// latency (measured: 4 register sets instead of 2 changed nothing until the `if (r_ti < T)` around the requests went).
+template <int YM, bool ROWSC>
+__global__ __launch_bounds__(kGrThreads) void gemm_f16_roles_kernel(
+    const float* __restrict__ A, int64_t lda, GxPro pro, const uint4* __restrict__ planes, GxEpi epi,
+    float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base,
+    const float* __restrict__ bscale) {
+  constexpr int NP = 2, NPC = 4;
+  constexpr int kASlab = NP * kGxBM * 4, kBSlab = NP * kGxBN * 4;
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * kASlab + 2 * kBSlab];
+  __shared__ float sRowInv[2 * kGxBM];                // by tile parity: what undoes the row's (or the launch's) A scale in the epilogue
+  __shared__ __attribute__((aligned(16))) float sStat[2 * kGxBM * 4];
+  __shared__ __attribute__((aligned(16))) float sGB[2 * 512];
+  // the matrix waves' private 16 x 64 patches (pitch 68 floats: the eight lanes of a 16-byte-store group land on distinct banks)
+  __shared__ __attribute__((aligned(16))) float sPatch[8 * 16 * kGrPatchPitch];
+  uint4 (*sA)[kASlab] = reinterpret_cast<uint4 (*)[kASlab]>(smem);
+  uint4 (*sB)[kBSlab] = reinterpret_cast<uint4 (*)[kBSlab]>(smem + 2 * kASlab);
+  const int n_tiles = (N + kGxBN - 1) / kGxBN;
+  const int64_t total = (rows + kGxBM - 1) / kGxBM * n_tiles;
+  const int ksteps = K / kGxKS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (static_cast<int64_t>(blockIdx.x) >= total) return;
+  const int64_t T = (total - blockIdx.x + gridDim.x - 1) / gridDim.x;          // this workgroup's tiles: blockIdx.x + i * gridDim.x
+  const int64_t total_steps = T * ksteps;
+  const uint64_t seed_in = resolve_seed(seed_base, pro.seed_in), seed_out = resolve_seed(seed_base, epi.seed_out);
+  const float inv_mask = pro.p_mask > 0.f ? 1.f / (1.f - pro.p_mask) : 1.f;
+  const float inv_in = pro.p_in > 0.f ? 1.f / (1.f - pro.p_in) : 1.f;
+  const uint32_t thr_in = drop_threshold(pro.p_in);
+  const float inv_out = epi.p_out > 0.f ? 1.f / (1.f - epi.p_out) : 1.f;
+  const uint32_t thr_out = drop_threshold(epi.p_out);
+  constexpr bool rowsc = ROWSC;                                        // A scaled per row (no LayerNorm bound)
+  float launch_inv = 1.f;                                              // behind a LayerNorm: 2^-Su, undone in the epilogue
+  if constexpr (!ROWSC) {
+    for (int i = tid; i < K; i += kGrThreads) { sGB[i] = pro.gamma[i] * inv_in; sGB[512 + i] = pro.beta[i] * inv_in; }     // (the dropout's 1 / keep rides along)
+    __syncthreads();
+    float g = 0.f, bm = 0.f;
+    for (int i = lane; i < K; i += 64) { g = fmaxf(g, fabsf(sGB[i])); bm = fmaxf(bm, fabsf(sGB[512 + i])); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { g = fmaxf(g, __shfl_xor(g, off)); bm = fmaxf(bm, __shfl_xor(bm, off)); }
+    const float U = sqrtf(static_cast<float>(K)) * g + bm;             // |u| <= (sqrt(K - 1) max|gamma| + max|beta|) keep
+    const int eU = static_cast<int>(__float_as_uint(U) >> 23);
+    const int Su = min(max(140 - eU, -100), 100);
+    const float su = __uint_as_float(static_cast<uint32_t>(127 + Su) << 23);
+    launch_inv = __uint_as_float(static_cast<uint32_t>(127 - Su) << 23);
+    __syncthreads();                                                   // (every wave has read the unscaled copy)
+    for (int i = tid; i < K; i += kGrThreads) { sGB[i] *= su; sGB[512 + i] *= su; }
+    __syncthreads();
+  }
+#ifdef ALLSET_ABL_GR_NOBAR          // ablation builds only (tools/gemm_roles_ablation.py): timing without the barriers, results wrong
+#define GR_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define GR_TICK() __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+  const bool has_stats_out = epi.stats_out != nullptr;
+#ifdef ALLSET_ABL_GR_TIMING         // diagnostic builds only (tools/gemm_roles_ablation.py): cycles per segment of waves 0 (vector) and 8 (matrix) of workgroup 0
+  uint64_t tph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define GR_MARK(k) do { const uint64_t tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define GR_MARK(k) do {} while (0)
+#endif
+
+  if (wave_u < 8) {
+    // =================================================== vector waves ===================================================
+    const int s_row = tid >> 2, s_seg = tid & 3;
+    const int a_st = s_row * 4 + (s_seg ^ gx_swz(s_row));
+    const int b_img = (tid >> 6) * (64 * NPC) + (tid & 63) + 32 * NPC;
+    const bool mask_fold = YM == 2 && rowsc;
+    auto tile_of = [&](int64_t ti) __attribute__((always_inline)) -> int64_t { return blockIdx.x + ti * static_cast<int64_t>(gridDim.x); };
+    auto crow_of = [&](int64_t ti) __attribute__((always_inline)) -> int64_t {                        // this thread's row of tile ti, clamped (loads are unconditional)
+      const int64_t g_row = tile_of(ti) / n_tiles * kGxBM + s_row;
+      return g_row < rows ? g_row : rows - 1;
+    };
+    auto row_scale = [&](float amax) __attribute__((always_inline)) -> float {
+      amax = fmaxf(amax, __shfl_xor(amax, 1));
+      amax = fmaxf(amax, __shfl_xor(amax, 2));
+      const int e = min(max(static_cast<int>(__float_as_uint(amax * inv_mask * inv_in) >> 23), 20), 254);
+      return __uint_as_float(static_cast<uint32_t>(267 - e) << 23);    // 2^(140 - e): the largest element -> [2^13, 2^14)
+    };
+    auto amax8 = [](float4 a, float4 b, float m) __attribute__((always_inline)) -> float {
+      return fmaxf(fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                         fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))), m);
+    };
+    // One step of the stream in flight per register set (named registers, two sets "0" / "1": as a struct passed by reference hipcc
+    // kept part of a set in an alloca promoted to LDS): the A segment, the mask source, the B pieces.  What depends on the TILE only --
+    // the row's address, statistics and mask words, the weight image -- is recomputed when a stream position wraps to a new tile.
+    // A segments (HBM) are requested FOUR steps ahead, the weight pieces (L2) two: bytes in flight bound this kernel -- with two sets of
+    // each, 32 KB of A per CU = 8 MB chip-wide, it read at 3.1 TB/s whatever else it did (tools/gemm_roles_ablation.py: 325 us for the
+    // K loop alone) and the reads drained while the matrix waves ran a tile's epilogue.
+    float4 a0_0, a1_0, a0_1, a1_1, a0_2, a1_2, a0_3, a1_3;
+    float4 y0_0 = make_float4(1.f, 1.f, 1.f, 1.f), y1_0 = y0_0, y0_1 = y0_0, y1_1 = y0_0, y0_2 = y0_0, y1_2 = y0_0, y0_3 = y0_0, y1_3 = y0_0;
+    uint4 b0_0, b1_0, b2_0, b3_0, b0_1, b1_1, b2_1, b3_1;
+    uint32_t pm_0 = 0, pm_1 = 0, pm_2 = 0, pm_3 = 0;
+    float2 ms_0 = make_float2(0.f, 1.f), ms_1 = ms_0, ms_2 = ms_0, ms_3 = ms_0;      // the row's LayerNorm statistics, per A set
+    // the REQUEST sides' tiles: A four steps ahead of the step being staged, the weight image two
+    int64_t r_ti = 0; int r_ks = 0;
+    const float* r_a = nullptr; const float* r_y = nullptr; const uint32_t* r_m = nullptr; const float* r_s = nullptr;
+    auto r_enter = [&](int64_t ti) __attribute__((always_inline)) {
+      const int64_t tile = tile_of(ti), rt_ = tile / n_tiles;
+      const int64_t g_row = rt_ * kGxBM + s_row, cr = g_row < rows ? g_row : rows - 1;
+      r_a = A + cr * lda + s_seg * 8;
+      if constexpr (YM == 1) r_y = pro.y + cr * pro.ldy + s_seg * 8;
+      if constexpr (YM == 2) r_m = pro.mask + (cr >> 4) * (K / 64) * 32 + ((cr & 15) >> 2) * 8 + (cr & 3) * 2;
+      if constexpr (!ROWSC) r_s = pro.stats + cr * 2;
+    };
+    int64_t q_ti = 0; int q_ks = 0;
+    const uint4* q_img = nullptr;
+    auto q_enter = [&](int64_t ti) __attribute__((always_inline)) {
+      const int64_t tile = tile_of(ti), rt_ = tile / n_tiles, nt_ = tile - rt_ * n_tiles;
+      q_img = planes + nt_ * ksteps * kBSlab + b_img;
+    };
+#define GR_REQUEST_A(X)                                                                           \
+  do {                                                                                            \
+    a0_##X = *reinterpret_cast<const float4*>(r_a + r_ks * kGxKS);                                \
+    a1_##X = *reinterpret_cast<const float4*>(r_a + r_ks * kGxKS + 4);                            \
+    if constexpr (YM == 1) {                                                                      \
+      y0_##X = *reinterpret_cast<const float4*>(r_y + r_ks * kGxKS);                              \
+      y1_##X = *reinterpret_cast<const float4*>(r_y + r_ks * kGxKS + 4);                          \
+    }                                                                                             \
+    if constexpr (YM == 2) pm_##X = r_m[(r_ks >> 1) * 32 + (r_ks & 1)];                           \
+    if constexpr (!ROWSC) ms_##X = *reinterpret_cast<const float2*>(r_s);                         \
+    if (++r_ks == ksteps) { r_ks = 0; if (r_ti + 1 < T) { ++r_ti; r_enter(r_ti); } }  /* (past the end: the last tile again, never staged) */ \
+  } while (0)
+#define GR_REQUEST_B(X)                                                                           \
+  do {                                                                                            \
+    const uint4* img_ = q_img + static_cast<int64_t>(q_ks) * kBSlab;                              \
+    b0_##X = img_[-128]; b1_##X = img_[-64]; b2_##X = img_[0]; b3_##X = img_[64];                 \
+    if (++q_ks == ksteps) { q_ks = 0; if (q_ti + 1 < T) { ++q_ti; q_enter(q_ti); } }              \
+  } while (0)
+    // the STAGING side's tile
+    int64_t s_ti = 0; int s_ks = 0;
+    int64_t s_grow = 0;                                                // this thread's row of the tile being staged (unclamped: the dropout index)
+    const float* s_next = nullptr;                                     // rowsc: this thread's segment base in the NEXT tile's row (the lookahead), or null
+    float asc = 1.f, nmax = 0.f;                                       // per-row window (rowsc): this tile's scale, the next tile's maximum so far
+    auto s_enter = [&](int64_t ti) __attribute__((always_inline)) {
+      const int64_t tile = tile_of(ti), rt_ = tile / n_tiles;
+      s_grow = rt_ * kGxBM + s_row;
+      if constexpr (ROWSC) s_next = A + crow_of(ti + 1 < T ? ti + 1 : ti) * lda + s_seg * 8;     // (the last tile looks at itself: unused)
+      if (s_seg == 0) sRowInv[(ti & 1) * kGxBM + s_row] = rowsc ? 1.f / asc : launch_inv;     // the tile's row scales for the epilogue, by tile parity
+      nmax = 0.f;
+    };
+    auto stage = [&](float4 a0, float4 a1, float4 y0, float4 y1, uint32_t pm, float2 ms, uint4 q0, uint4 q1, uint4 q2, uint4 q3, int ks, int buf) __attribute__((always_inline)) {
+      const int kb = ks * kGxKS + s_seg * 8;
+#ifdef ALLSET_ABL_GR_NOSTAGE        // ablation builds only: the loads and the LDS stores stay, the prologue's arithmetic goes
+      sA[buf][a_st] = make_uint4(__float_as_uint(a0.x), __float_as_uint(a0.y), __float_as_uint(a0.z), __float_as_uint(a0.w));
+      sA[buf][kGxBM * 4 + a_st] = make_uint4(__float_as_uint(a1.x), __float_as_uint(a1.y), __float_as_uint(a1.z), __float_as_uint(a1.w) + kb);
+      sB[buf][tid] = q0; sB[buf][tid + kGrVThreads] = q1; sB[buf][tid + 2 * kGrVThreads] = q2; sB[buf][tid + 3 * kGrVThreads] = q3;
+      return;
+#endif
+      float e[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      if constexpr (YM == 1) {
+        const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = y[i] > 0.f ? e[i] * inv_mask : 0.f;
+      }
+      if constexpr (YM == 2) {
+        const int w = static_cast<int>(pm);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[i] = __int_as_float(__float_as_int(e[i]) & __builtin_amdgcn_sbfe(w, 2 * s_seg + 8 * i, 1));
+          e[4 + i] = __int_as_float(__float_as_int(e[4 + i]) & __builtin_amdgcn_sbfe(w, 2 * s_seg + 8 * i + 1, 1));
+        }
+        if (!mask_fold) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) e[i] *= inv_mask;
+        }
+      }
+      if (pro.relu_in) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = fmaxf(e[i], 0.f);
+      }
+      if constexpr (!ROWSC) {
+        const float4 g0 = *reinterpret_cast<const float4*>(sGB + kb), g1 = *reinterpret_cast<const float4*>(sGB + kb + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(sGB + 512 + kb), c1 = *reinterpret_cast<const float4*>(sGB + 512 + kb + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = fmaf((e[i] - ms.x) * ms.y, g[i], c[i]);
+        if (pro.p_in > 0.f) {
+          const float4 k0 = keep_scale4(seed_in, s_grow * K + kb, thr_in, 1.f), k1 = keep_scale4(seed_in, s_grow * K + kb + 4, thr_in, 1.f);
+          e[0] *= k0.x; e[1] *= k0.y; e[2] *= k0.z; e[3] *= k0.w; e[4] *= k1.x; e[5] *= k1.y; e[6] *= k1.z; e[7] *= k1.w;
+        }
+      }
+      const float sc = mask_fold ? asc * inv_mask : asc;
+      uint4 h, l;
+      split2_f16c(e[0] * sc, e[1] * sc, h.x, l.x);
+      split2_f16c(e[2] * sc, e[3] * sc, h.y, l.y);
+      split2_f16c(e[4] * sc, e[5] * sc, h.z, l.z);
+      split2_f16c(e[6] * sc, e[7] * sc, h.w, l.w);
+      sA[buf][a_st] = h;
+      sA[buf][kGxBM * 4 + a_st] = l;
+      sB[buf][tid] = q0; sB[buf][tid + kGrVThreads] = q1; sB[buf][tid + 2 * kGrVThreads] = q2; sB[buf][tid + 3 * kGrVThreads] = q3;
+    };
+    if constexpr (ROWSC) {                                             // the first tile's row maxima: once per workgroup, not overlapped
+      const float* ap = A + crow_of(0) * lda + s_seg * 8;
+      float m = 0.f;
+      for (int ks = 0; ks < ksteps; ++ks) m = amax8(*reinterpret_cast<const float4*>(ap + ks * kGxKS), *reinterpret_cast<const float4*>(ap + ks * kGxKS + 4), m);
+      asc = row_scale(m);
+    }
+    r_enter(0);
+    q_enter(0);
+    GR_REQUEST_A(0); GR_REQUEST_B(0);
+    GR_REQUEST_A(1); GR_REQUEST_B(1);
+    GR_REQUEST_A(2);
+    GR_REQUEST_A(3);
+    s_enter(0);
+#define GR_ONE(X, XB, BUF)                                                                        \
+  do {                                                                                            \
+    float4 la0 = make_float4(0.f, 0.f, 0.f, 0.f), la1 = la0;                                      \
+    if constexpr (ROWSC) {          /* one tile ahead: the segment this thread will stage for the next tile */ \
+      la0 = *reinterpret_cast<const float4*>(s_next + s_ks * kGxKS);                              \
+      la1 = *reinterpret_cast<const float4*>(s_next + s_ks * kGxKS + 4);                          \
+    }                                                                                             \
+    GR_MARK(3);                                                                                   \
+    stage(a0_##X, a1_##X, y0_##X, y1_##X, pm_##X, ms_##X, b0_##XB, b1_##XB, b2_##XB, b3_##XB, s_ks, BUF); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    GR_MARK(0);                                                                                   \
+    GR_REQUEST_A(X);               /* into the sets just consumed: A four steps ahead, */         \
+    GR_REQUEST_B(XB);              /* the weight pieces two (unconditional: see ROWSC above) */   \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if constexpr (ROWSC) nmax = amax8(la0, la1, nmax);                                            \
+    const bool first_of_tile_ = s_ks == 0 && s_ti > 0;                                            \
+    if (++s_ks == ksteps) {         /* the tile is staged: the next one's row scale, statistics, lookahead base */ \
+      s_ks = 0; ++s_ti;                                                                           \
+      if constexpr (ROWSC) asc = row_scale(nmax);                                                 \
+      if (s_ti < T) s_enter(s_ti);                                                                \
+    }                                                                                             \
+    GR_MARK(1);                                                                                   \
+    GR_TICK();                                                                                    \
+    GR_MARK(2);                                                                                   \
+    if (first_of_tile_ && has_stats_out) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); } /* the matrix waves' epilogue of the previous tile */ \
+  } while (0)
+    for (int64_t g = 0; g < total_steps; g += 4) {                     // (K % 128 == 0: a multiple of four steps per tile)
+      GR_ONE(0, 0, 0);
+      GR_ONE(1, 1, 1);
+      GR_ONE(2, 0, 0);
+      GR_ONE(3, 1, 1);
+    }
+#undef GR_ONE
+#undef GR_REQUEST_A
+#undef GR_REQUEST_B
+    GR_TICK();                                                         // the matrix waves' tick after the last step
+    if (has_stats_out) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }                       // (the last tile's epilogue)
+  } else {
+    // =================================================== matrix waves ===================================================
+    const int m = wave_u - 8;
+    const int wr = m >> 2, wc = m & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sw = gx_swz(fr);
+    const int a_at = (wr * 64 + fr) * 4 + (fg ^ sw), b_at = (wc * 64 + fr) * 4 + (fg ^ sw);
+    f32x4_t acc[4][4];
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+      // 128 registers per wave (16 waves per CU): 64 accumulators + the A fragments of two row tiles (16) + the B fragments of the
+      // current and the NEXT column tile (16) -- requested one column tile ahead, explicitly: left to itself the scheduler hoists all of a
+      // step's 24 fragment reads above its MFMAs and spills (132 dwords of scratch per lane around the MFMA loop)
+      const uint4* pa = &sA[buf][a_at];
+      const uint4* pb = &sB[buf][b_at];
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        GxFragH a[2][2], b[2][2];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) a[r2][p].u = pa[p * kGxBM * 4 + (rh * 2 + r2) * 64];
+        b[0][0].u = pb[0]; b[0][1].u = pb[kGxBN * 4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if (ct + 1 < 4) { b[(ct + 1) & 1][0].u = pb[(ct + 1) * 64]; b[(ct + 1) & 1][1].u = pb[kGxBN * 4 + (ct + 1) * 64]; }
+          const GxFragH (&bc)[2] = b[ct & 1];
+          // operands swapped (the weight fragment is A): acc[rt][ct][q] = out[row fr][column 4 fg + q] of the 16 x 16 tile; l.h, h.l, h.h
+#define GR_MFMA(PA, PB)                                                                                                   \
+  acc[rh * 2][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[PB].v, a[0][PA].v, acc[rh * 2][ct], 0, 0, 0);               \
+  acc[rh * 2 + 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[PB].v, a[1][PA].v, acc[rh * 2 + 1][ct], 0, 0, 0)
+#ifdef ALLSET_ABL_GR_NOMFMA         // ablation builds only: the fragment reads stay, the MFMAs go
+          acc[rh * 2][ct][0] += __builtin_bit_cast(float, bc[0].u.x ^ bc[1].u.y ^ a[0][0].u.z ^ a[0][1].u.w);
+          acc[rh * 2 + 1][ct][0] += __builtin_bit_cast(float, bc[0].u.y ^ bc[1].u.x ^ a[1][0].u.z ^ a[1][1].u.w);
+#else
+          GR_MFMA(1, 0); GR_MFMA(0, 1); GR_MFMA(0, 0);
+#endif
+#undef GR_MFMA
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    auto epilogue = [&](int64_t ti) __attribute__((always_inline)) {
+      // The MFMAs leave a lane with four consecutive columns of ONE row per 16 x 16 tile -- 16-byte pieces whose neighbours in a row sit
+      // 16 lanes away: stored like that, a wave's store instruction is 64 separate 16-byte writes, and the tile's epilogue took 12-18
+      // us of a 28-us tile (tools/gemm_roles_ablation.py: 865 us per launch, 325 without the epilogue).  So each wave turns its 16 x 64
+      // patch of a row tile through a PRIVATE 4.3-KB LDS patch (no barrier: a wave's DS operations execute in order) into row-major
+      // lanes -- lane (r4 = lane >> 4, c = lane & 15) holds columns 4 c .. 4 c + 3 of rows r4, r4 + 4, r4 + 8, r4 + 12 -- where a store
+      // instruction writes four whole 256-byte row segments, the lane's bias / column scales are ONE float4 each, the 1-bit mask is
+      // four ballots and a row's sum over the wave's 64 columns a DPP row sum.
+      const int64_t tile = blockIdx.x + ti * static_cast<int64_t>(gridDim.x);
+      const int tpar = static_cast<int>(ti & 1);
+      const int64_t row0s = tile / n_tiles * kGxBM + wr * 64;
+      const int ntile0 = static_cast<int>(tile % n_tiles) * kGxBN;
+      const int r4 = lane >> 4, c = lane & 15;
+      const int n = ntile0 + wc * 64 + 4 * c;                          // this lane's four columns
+      const float out_floor = epi.relu_out ? 0.f : -INFINITY;
+      const bool has_drop = epi.p_out > 0.f, has_mask = epi.mask_out != nullptr;
+      const float4 bv = (epi.bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(epi.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 cs = *reinterpret_cast<const float4*>(bscale + n);    // (bscale has n_pad entries: always in range)
+      float* patch = sPatch + m * (16 * kGrPatchPitch);
+      float4 o[4][4];                                                  // [rt][j]: row wr*64 + rt*16 + r4 + 4 j
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          *reinterpret_cast<float4*>(&patch[fr * kGrPatchPitch + 16 * ct + 4 * fg]) = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[rt][j] = *reinterpret_cast<const float4*>(&patch[(r4 + 4 * j) * kGrPatchPitch + 4 * c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rr = wr * 64 + rt * 16 + r4 + 4 * j;
+          const int64_t row = row0s + rt * 16 + r4 + 4 * j;
+          const float ri = sRowInv[tpar * kGxBM + rr];
+          float4 v = o[rt][j];
+          v = make_float4(fmaf(v.x, ri * cs.x, bv.x), fmaf(v.y, ri * cs.y, bv.y), fmaf(v.z, ri * cs.z, bv.z), fmaf(v.w, ri * cs.w, bv.w));
+          v.x = fmaxf(v.x, out_floor); v.y = fmaxf(v.y, out_floor); v.z = fmaxf(v.z, out_floor); v.w = fmaxf(v.w, out_floor);
+          if (has_drop) {
+            const float4 k = keep_scale4(seed_out, row * N + n, thr_out, inv_out);
+            v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w;
+          }
+          o[rt][j] = v;
+          if (row < rows && n < N) *reinterpret_cast<float4*>(out + row * ldo + n) = v;
+          if (has_mask) {
+            // "mask layout" (include/allset_hip_ext.h): a ballot's bit 16 r4 + c is lane (c, r4): byte (2 r4 + h8) of the ballot for
+            // component q is byte q of the dword of row r4, 32-column half h8 -- lane L < 8 assembles dword (r4 = L >> 1, h8 = L & 1)
+            const bool in = n < N;
+            const uint64_t b0 = __ballot(in && v.x > 0.f), b1 = __ballot(in && v.y > 0.f), b2 = __ballot(in && v.z > 0.f), b3 = __ballot(in && v.w > 0.f);
+            const int sh = 8 * (lane & 7);
+            const uint32_t word = static_cast<uint32_t>((b0 >> sh) & 0xffu) | (static_cast<uint32_t>((b1 >> sh) & 0xffu) << 8) |
+                                  (static_cast<uint32_t>((b2 >> sh) & 0xffu) << 16) | (static_cast<uint32_t>((b3 >> sh) & 0xffu) << 24);
+            const int64_t mrow = row0s + rt * 16 + (lane >> 1) + 4 * j;                      // (lanes < 8: row r4 = lane >> 1 of this store)
+            const int col = ntile0 + wc * 64 + 32 * (lane & 1);
+            if (lane < 8 && mrow < rows && col < N)
+              (epi.mask_out + ((mrow >> 4) * (N / 64)) * 32 + ((mrow & 15) >> 2) * 8 + (mrow & 3) * 2)[(col >> 6) * 32 + ((col & 63) >> 5)] = word;
+          }
+        }
+      }
+      if (has_stats_out) {
+        // {mean, rstd} of stats_relu ? relu(out) : out per row (N == 256): the wave's 64 columns of a row by a DPP row sum, the four
+        // waves wc of a row band through LDS; two passes (mean, then the squared deviations).  The four barriers are matched by the
+        // vector waves (GR_ONE above)
+        const float sf = epi.stats_relu ? 0.f : -INFINITY;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          float* sS = sStat + ph * (kGxBM * 4);                        // the sums, then the squared deviations (the means are re-read from the first: no 16 registers of them)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int rr = wr * 64 + rt * 16 + r4 + 4 * j;
+              const float4 t = make_float4(fmaxf(o[rt][j].x, sf), fmaxf(o[rt][j].y, sf), fmaxf(o[rt][j].z, sf), fmaxf(o[rt][j].w, sf));
+              float a;
+              if (ph == 0) a = (t.x + t.y) + (t.z + t.w);
+              else {
+                const float4 p4 = *reinterpret_cast<const float4*>(&sStat[rr * 4]);
+                const float mu = ((p4.x + p4.y) + (p4.z + p4.w)) * (1.f / kGxBN);
+                const float d0 = t.x - mu, d1 = t.y - mu, d2 = t.z - mu, d3 = t.w - mu;
+                a = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3)));
+              }
+              a += gx_dpp<0xB1>(a); a += gx_dpp<0x4E>(a); a += gx_dpp<0x141>(a); a += gx_dpp<0x140>(a);
+              if (c == 0) sS[rr * 4 + wc] = a;
+            }
+          __syncthreads();
+          if (ph == 1) {
+            // rows of the band wr: 64 rows, one per lane of the wave wc == 0
+            if (wc == 0) {
+              const int rr = wr * 64 + lane;
+              const int64_t row = row0s + lane;
+              const float4 p4 = *reinterpret_cast<const float4*>(&sStat[rr * 4]), q4 = *reinterpret_cast<const float4*>(&sS[rr * 4]);
+              const float mu = ((p4.x + p4.y) + (p4.z + p4.w)) * (1.f / kGxBN), var = ((q4.x + q4.y) + (q4.z + q4.w)) * (1.f / kGxBN);
+              if (row < rows) *reinterpret_cast<float2*>(epi.stats_out + row * 2) = make_float2(mu, rsqrtf(var + epi.stats_eps));
+            }
+          }
+          __syncthreads();
+        }
+      }
+    };
+    GR_TICK();                                                         // step 0 is staged
+    for (int64_t ti = 0; ti < T; ++ti) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < ksteps; ks += 2) {                         // (ksteps is even: the buffer index is a compile-time constant --
+        GR_MARK(3);
+        compute(0);                                                    //  behind a run-time parity the accumulators became loop phis with
+        GR_MARK(0);
+        GR_TICK();                                                     //  two sources and lived in registers twice: 160 VGPRs)
+        GR_MARK(2);
+        compute(1);
+        GR_MARK(0);
+        GR_TICK();
+        GR_MARK(2);
+      }
+#ifdef ALLSET_ABL_GR_NOEPI          // ablation builds only: one store per lane instead of the epilogue
+      if (lane == 0) out[ti] = acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+#else
+      epilogue(ti);
+#endif
+      GR_MARK(1);
+    }
+  }
+#ifdef ALLSET_ABL_GR_TIMING
+  // vector wave 0: [0] staging, [1] requests + bookkeeping, [2] tick wait; matrix wave 8: [0] fragment reads + MFMAs, [1] epilogue, [2] tick wait (cycles) -> over the first floats of the output
+  if (blockIdx.x == 0 && (tid == 0 || tid == 512)) for (int q = 0; q < 4; ++q) out[(tid ? 4 : 0) + q] = static_cast<float>(tph[q]);
+#endif
+#undef GR_MARK
+#undef GR_TICK
+}
+
 // ---- row statistics for the LayerNorm-apply prologue: stats[r] = {mean, rstd} of relu_in ? relu(x[r]) : x[r] ----------------
 __global__ __launch_bounds__(kBlock) void row_stats_kernel(const float* __restrict__ x, int64_t ldx, int relu_in, float eps,
                                                            float* __restrict__ stats, int64_t rows, int d) {
@@ -1010,6 +1442,16 @@ static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_
   const int64_t blocks = tiles < 256 ? tiles : 256;                     // one workgroup per CU (144 KB of LDS), walking its tiles
   const int64_t n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
   const float* bscale = f16 ? reinterpret_cast<const float*>(static_cast<const char*>(planes) + n_pad * K * 2 * 2) : nullptr;
+  if (f16 && epi.lnb_x == nullptr && K % (4 * kGxKS) == 0) {           // the forward on fp16 planes: split-role kernel (four steps of A in flight: a multiple of four K steps)
+#define GR_LAUNCH2(Y, R) gemm_f16_roles_kernel<Y, R><<<static_cast<unsigned>(blocks), kGrThreads, 0, static_cast<hipStream_t>(stream)>>>( \
+      A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base, bscale)
+#define GR_LAUNCH(Y) do { if (stats == nullptr) GR_LAUNCH2(Y, true); else GR_LAUNCH2(Y, false); } while (0)
+    if (mask_bits) GR_LAUNCH(2); else if (mask_y) GR_LAUNCH(1); else GR_LAUNCH(0);
+#undef GR_LAUNCH2
+#undef GR_LAUNCH
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
+  }
 #define GX_LAUNCH(Y, L, H) gemm_x6_kernel<Y, L, H><<<static_cast<unsigned>(blocks), kGxThreads, 0, static_cast<hipStream_t>(stream)>>>( \
       A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base, bscale)
 #define GX_LAUNCH2(Y, L) do { if (f16) GX_LAUNCH(Y, L, true); else GX_LAUNCH(Y, L, false); } while (0)
