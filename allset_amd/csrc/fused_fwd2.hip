@@ -78,14 +78,20 @@ __device__ __forceinline__ uint32_t hash_mix_f(uint32_t x) { x ^= x >> 16; x *= 
 //   2  no LayerNorm in front (row-scaled fp16x3, below); epilogue = z = relu?(. + bias) [1-bit mask of z], s = res + z -> `uo`,
 //      y = dropout(relu_post?(LayerNorm_{gamma,beta,eps}(s))), statistics of s -> `stats`: ln1 and the residual add inside the
 //      second rFF Linear, one kernel instead of allset_fused_linear_fwd + allset_ln_res_fwd.
-template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8, bool F16, int XM = 0>
+// AUX (round 6): four auxiliary output columns aux_out[r, 0..3] = pro(x)[r, :] . aux_w[j, :] + aux_b[j] in plain fp32 FMAs of the vector
+// waves -- PMA's folded attention logits riding along with its value projection (reference layers.py:128-130: the row is in the
+// staging lane's registers anyway; a row's 128 columns sit in the 16 lanes of a DPP row).  Until round 6 an auxiliary projection took
+// the symmetric bf16x6 kernel of fused_mlp.hip (0.35 ms per [1M, 128] launch against 0.20 here).
+template <bool HAS_LN, bool DROP_IN, bool DROP_OUT, bool D8, bool F16, int XM = 0, bool AUX = false>
 __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu_in, float p_in, uint64_t seed_in, const float* __restrict__ W, const float* __restrict__ bias, int relu_out,
     float p_out, uint64_t seed_out, float* __restrict__ y, int64_t ldy, float* __restrict__ stats, int64_t n,
     const uint64_t* __restrict__ seed_base, uint32_t* __restrict__ mask_out, int64_t xcb, int64_t ycb, float ln_inv,
     const float* __restrict__ colb = nullptr, float* __restrict__ uo = nullptr, int64_t lduo = 0,
-    const float* __restrict__ res = nullptr, int64_t ldres = 0, int relu_post = 0) {
+    const float* __restrict__ res = nullptr, int64_t ldres = 0, int relu_post = 0,
+    const float* __restrict__ aux_w = nullptr, const float* __restrict__ aux_b = nullptr, float* __restrict__ aux_out = nullptr) {
+  static_assert(!AUX || (XM == 0 && !DROP_IN && !HAS_LN), "auxiliary columns: the plain prologue only (behind a LayerNorm the fp16x3 form folds 2^Su into gamma / beta)");
   static_assert(XM == 0 || F16, "the tail modes are built on the fp16x3 arithmetic only");
   static_assert(XM != 1 || (HAS_LN && !DROP_IN && !DROP_OUT), "mode 1: LayerNorm prologue, no dropout");
   static_assert(XM != 2 || (!HAS_LN && !DROP_IN), "mode 2: plain operand, LayerNorm in the epilogue");
@@ -113,6 +119,11 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
   __shared__ __attribute__((aligned(16))) float sCol[XM == 1 ? KD : 4];
   if (tid < KD) { sG[tid] = AFF ? gamma[tid] : 1.f; sB[tid] = AFF ? beta[tid] : 0.f; sBias[tid] = bias ? bias[tid] : 0.f; }
   if constexpr (XM == 1) { if (tid < KD) sCol[tid] = colb ? colb[tid] : 0.f; }
+  __shared__ __attribute__((aligned(16))) float sAuxW[AUX ? 4 * KD + 4 : 4];       // aux_w [4][KD], then aux_b [4]
+  if constexpr (AUX) {
+    if (tid < 4 * KD) sAuxW[tid] = aux_w[tid];
+    if (tid < 4) sAuxW[4 * KD + tid] = aux_b ? aux_b[tid] : 0.f;
+  }
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n_stages = (n + R - 1) / R;
@@ -263,6 +274,18 @@ __global__ __launch_bounds__(kF2Block) void fused_linear_fwd_roles_kernel(
           *reinterpret_cast<float4*>(ub) = t[0];
           *reinterpret_cast<float4*>(ub + 256) = t[1];
         }
+      }
+      if constexpr (AUX) {
+        float s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 w0 = *reinterpret_cast<const float4*>(&sAuxW[j * KD + 4 * c]), w1 = *reinterpret_cast<const float4*>(&sAuxW[j * KD + 64 + 4 * c]);
+          s4[j] = row16_sum_f(fmaf(t[0].x, w0.x, fmaf(t[0].y, w0.y, fmaf(t[0].z, w0.z, t[0].w * w0.w))) +
+                              fmaf(t[1].x, w1.x, fmaf(t[1].y, w1.y, fmaf(t[1].z, w1.z, t[1].w * w1.w))));
+        }
+        if (live && c == 0)
+          *reinterpret_cast<float4*>(aux_out + (stage * R + lr) * 4) =
+              make_float4(s4[0] + sAuxW[4 * KD], s4[1] + sAuxW[4 * KD + 1], s4[2] + sAuxW[4 * KD + 2], s4[3] + sAuxW[4 * KD + 3]);
       }
       float rsc = su1;                             // the factor applied at the split: mode 1's launch-wide 2^Su, ROWSC's row scale
       if constexpr (ROWSC) {
@@ -562,7 +585,28 @@ using namespace allset;
 
 // 1 = the split-role forward takes this call (K = N = 128, no auxiliary columns): a pure function of its arguments
 int fused_linear_fwd_roles_supported(int64_t K, int64_t N, int has_aux) {
-  return (K == 128 && N == 128 && !has_aux) ? 1 : 0;
+  (void)has_aux;                 // (round 6: the plain Linear takes its four auxiliary columns along; launch_fused_linear_fwd_roles_aux)
+  return (K == 128 && N == 128) ? 1 : 0;
+}
+
+// The plain Linear (no norm, no dropout, row-major operands) with four auxiliary output columns: y = relu_out?(relu_in?(x) W^T + b),
+// aux_out = relu_in?(x) aux_w^T + aux_b
+int launch_fused_linear_fwd_roles_aux(hipStream_t st, const float* x, int64_t ldx, int relu_in, const float* W, const float* bias,
+                                      int relu_out, float* y, int64_t ldy, int64_t n, uint32_t* mask_out, const float* aux_w,
+                                      const float* aux_b, float* aux_out, int arith) {
+  const int64_t blocks = (n + kF2Rows - 1) / kF2Rows;
+  const unsigned grid = static_cast<unsigned>(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));
+#define ALLSET_F2_AUX(H16)                                                                                                             \
+  fused_linear_fwd_roles_kernel<false, false, false, false, H16, 0, true><<<grid, kF2Block, 0, st>>>(                                   \
+      x, ldx, nullptr, nullptr, 1e-5f, relu_in, 0.f, 0, W, bias, relu_out, 0.f, 0, y, ldy, nullptr, n, nullptr, mask_out, 0, 0, 1.f / 128.f, \
+      nullptr, nullptr, 0, nullptr, 0, 0, aux_w, aux_b, aux_out)
+#ifdef ALLSET_NO_F16X3
+  (void)arith; ALLSET_F2_AUX(false);
+#else
+  if (arith != ALLSET_ARITH_BF16X6) ALLSET_F2_AUX(true); else ALLSET_F2_AUX(false);
+#endif
+#undef ALLSET_F2_AUX
+  return 0;
 }
 
 int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,

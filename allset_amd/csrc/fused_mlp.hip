@@ -648,6 +648,9 @@ int launch_fused_linear_fwd_roles(hipStream_t st, const float* x, int64_t ldx, c
                                   int relu_in, float p_in, uint64_t seed_in, const float* W, const float* bias, int relu_out,
                                   float p_out, uint64_t seed_out, float* y, int64_t ldy, float* stats, int64_t n,
                                   const uint64_t* seed_base, uint32_t* mask_out, int64_t xcb, int64_t ycb, float ln_inv, int arith);
+int launch_fused_linear_fwd_roles_aux(hipStream_t st, const float* x, int64_t ldx, int relu_in, const float* W, const float* bias,
+                                      int relu_out, float* y, int64_t ldy, int64_t n, uint32_t* mask_out, const float* aux_w,
+                                      const float* aux_b, float* aux_out, int arith);
 
 // 1 = cb is a usable column-block width for a K-column operand (a power of two, 4 <= cb <= K / 2, the operand's ld == cb)
 static bool block_cols_ok(int64_t cb, int64_t K, int64_t ld) {
@@ -688,12 +691,21 @@ static int fused_linear_fwd_impl(const float* x, int64_t ldx, const float* gamma
   ALLSET_REQUIRE((xcb == 0 && ycb == 0) || n * 128 * 4 < (int64_t{1} << 32), "fused_linear_fwd_blocked: a blocked operand must stay below 4 GiB (32-bit lane offsets)");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int has_ln = gamma != nullptr;
-  const bool roles = fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aligned16(W) && ldx < (1 << 24) && ldy < (1 << 24) &&
-                     (reinterpret_cast<uintptr_t>(stats) & 7u) == 0;
+  // (auxiliary columns ride in the split-role kernel for the plain Linear -- PMA's value projection; any other prologue / epilogue with
+  //  them keeps the symmetric kernel below)
+  const bool aux_plain = aux_out == nullptr || (!has_ln && p_in == 0.f && p_out == 0.f && xcb == 0 && ycb == 0 && aligned16(aux_w));
+  const bool roles = fused_linear_fwd_roles_supported(K, N, aux_out != nullptr) && aux_plain && aligned16(W) && ldx < (1 << 24) &&
+                     ldy < (1 << 24) && (reinterpret_cast<uintptr_t>(stats) & 7u) == 0;
   if (arith == ALLSET_ARITH_FP16X3 && !(roles && (!has_ln || norm_mode == ALLSET_NORM_LAYER))) {
-    set_error("fused_linear_fwd: ALLSET_ARITH_FP16X3 is built for K = N = 128 without auxiliary columns, behind a LayerNorm prologue or "
-              "none (allset_fused_linear_arith_supported)");
+    set_error("fused_linear_fwd: ALLSET_ARITH_FP16X3 is built for K = N = 128 behind a LayerNorm prologue or none (auxiliary columns: the "
+              "plain Linear only) (allset_fused_linear_arith_supported)");
     return ALLSET_ERR_UNSUPPORTED;
+  }
+  if (roles && aux_out != nullptr) {
+    launch_fused_linear_fwd_roles_aux(st, x, ldx, relu_in, W, bias, relu_out, y, ldy, n, reinterpret_cast<uint32_t*>(mask_out), aux_w, aux_b,
+                                      aux_out, arith);
+    ALLSET_LAUNCH_CHECK();
+    return ALLSET_OK;
   }
   if (roles) {                                                            // K = N = 128: the split-role kernel (fused_fwd2.hip)
     launch_fused_linear_fwd_roles(st, x, ldx, gamma, beta, eps, relu_in, p_in, seed_in, W, bias, relu_out, p_out, seed_out, y, ldy,

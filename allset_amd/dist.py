@@ -709,7 +709,13 @@ class _ShardedPmaE2V(torch.autograd.Function):
         pad = (-(d + 2 * H)) % 4
         parts = [gout, stats.reshape(gout.shape[0], 2 * H)] + ([gout.new_zeros(gout.shape[0], pad)] if pad else [])
         if ctx.use_halo:                              # the rows of the touched vertices only
-            full = hg.halo._gather(torch.cat(parts, dim=1))
+            if _WIRE_DTYPE is None:
+                full = hg.halo._gather(torch.cat(parts, dim=1))
+            else:
+                # narrow wire (opt-in): only the gradient rows are rounded; the softmax statistics {m + log l, delta} travel in fp32 in
+                # their own all-to-all, as the forward's maxima do (Halo.gather_narrow) -- rounded to 2^-9, exp(a - M) is off by ~1 %
+                # for |M| ~ 5 and forward and backward would use different maxima
+                full = torch.cat([hg.halo._gather(gout), hg.halo.gather_narrow(torch.cat(parts[1:], dim=1))], dim=1)
             inc = hg.halo_e2v
         else:
             full = _all_gather_rows(torch.cat(parts, dim=1), ctx.group)

@@ -743,6 +743,9 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": res["value"], "unit": "edges*d/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "arithmetic": (f"{args.arith}: `value` is measured with fp32 products formed from two scaled fp16 planes (fp16x3) wherever that kernel is "
+                       "built; the same K steps on the exact three-plane bf16 split (bf16x6) are timed in the same run: `strict`"
+                       if args.dtype == "f32" and args.arith in ("auto", "fp16x3") else args.arith),
         "dtype_note": ("fp32 tensors end to end; aggregation kernels: plain fp32 adds; dense tail: fp32 products formed on the 16-bit "
                        "matrix pipes and accumulated in fp32 -- at 128 x 128 (the forward and the one-pass backward) and in the tiled "
                        "256 / 512-wide GEMMs and weight gradient: every operand scaled by a power of two and split into two fp16, three "

@@ -986,6 +986,42 @@ def test_bf16_wire_format_within_its_restated_tolerance(scheme, monkeypatch):
     assert 1e-6 < err_o < 2e-2 and err_g < 1e-1, (err_o, err_g)       # really rounded on the wire, and within the restated tolerance
 
 
+def test_bf16_wire_with_the_boundary_vertex_exchange_keeps_the_softmax_statistics_in_fp32(monkeypatch):
+    """ALLSET_WIRE_DTYPE=bf16 + ``halo=True`` + PMA: the gathered gradient rows are rounded on the wire, the softmax statistics
+    {m + log l, delta} of the backward travel in fp32 in their own all-to-all (as the forward's maxima do) -- rounded to 2^-9 they
+    would put exp(a - M) off by ~1 % and the backward on other maxima than the forward.  The layer stays inside the bf16
+    wire's restated tolerance, and the wire really is narrow (the result differs from the exact one)."""
+    import torch.nn.functional as F
+    monkeypatch.setenv("ALLSET_WIRE_DTYPE", "bf16")            # read by allset_amd.dist at import, i.e. in the spawned ranks
+    world, H = 2, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pma_worker, args=(r, world, port, q, True, H)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_v, n_e, d, ei, _, x, G = _problem(world)
+    a, b = _pma_convs(d, H)
+
+    def pma_module(p, xin, e_idx, n_dst):
+        Hh, C = p.heads, p.hidden
+        o = TorchPmaKernels.aggregate(p.lin_V(xin), p._logits(xin), (e_idx, n_dst), Hh, 0.2)
+        o = p.ln0((o.view(-1, Hh, C) + p.att_r).view(-1, Hh * C))
+        return p.ln1(o + F.relu(p.rFF(o)))
+    xr = x.clone().requires_grad_(True)
+    v = F.relu(pma_module(b.prop, F.relu(pma_module(a.prop, xr, ei, n_e)), torch.stack([ei[1], ei[0]]), n_v))
+    (v * G).sum().backward()
+    out = torch.cat([torch.from_numpy(r[1]) for r in results])[:n_v]
+    gx = torch.cat([torch.from_numpy(r[2]) for r in results])[:n_v]
+    err_o = float((out - v.detach()).abs().max()) / float(v.detach().abs().max())
+    err_g = float((gx - xr.grad).abs().max()) / float(xr.grad.abs().max())
+    assert 1e-6 < err_o < 2e-2 and err_g < 1e-1, (err_o, err_g)
+
+
 def test_halo_gather_and_scatter_are_transposes_single_rank():
     """``Halo`` without a process group (world 1): gather = index_select by the touched vertices, scatter_add its transpose
     (<gather(x), y> == <x, scatter_add(y)>), scatter_max the per-owned-row maximum; an empty incidence gives empty tables."""

@@ -563,7 +563,16 @@ def test_arithmetic_mode_api(device):
     a4 = torch.empty(64, 4, device=device)
     w4 = torch.randn(4, 128, device=device)
     aux = list(args(_lib.ARITH_FP16X3))
-    aux[24], aux[26] = P(w4), P(a4)                                                  # auxiliary output columns: bf16x6 kernels only
+    aux[24], aux[26] = P(w4), P(a4)                                                  # auxiliary output columns of the plain Linear: both
+    for code in (_lib.ARITH_FP16X3, _lib.ARITH_BF16X6, _lib.ARITH_AUTO):                # arithmetics since round 6 (csrc/fused_fwd2.hip AUX)
+        aux[27] = code
+        assert lib.allset_fused_linear_fwd_ex(*aux) == 0
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y, x @ W.t(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(a4, x @ w4.t(), rtol=1e-5, atol=1e-5)
+    gam = torch.ones(128, device=device)
+    st2 = torch.empty(64, 2, device=device)
+    aux[3], aux[4], aux[18], aux[27] = P(gam), P(gam), P(st2), _lib.ARITH_FP16X3    # behind a LayerNorm the auxiliary columns keep bf16x6
     assert lib.allset_fused_linear_fwd_ex(*aux) == -3
     for code in (_lib.ARITH_FP16X3, _lib.ARITH_BF16X6):
         assert lib.allset_fused_linear_fwd_ex(*args(code)) == 0

@@ -1,12 +1,18 @@
 # One full GPU batch for a round: usage  gpurun -- "TAG=r05 bash tools/prof_round.sh".  (The round-4 batches prof_r04*.sh were this script with the tag spelled out.)  Full GPU suite, smoke, default bench line + the same command under
 # rocprofv3 --kernel-trace --stats, refreshed HBM-traffic passes (stamped), PMC passes over the dense kernels, variant lines.
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.txt 2>&1; tail -3 $OUT/${TAG}_smoke.txt
-timeout 1800 python -m pytest tests -m gpu -q --durations=15 > $OUT/${TAG}_pytest.txt 2>&1; grep -n "passed\|failed\|FAILED" $OUT/${TAG}_pytest.txt | tail -8
+# the whole suite under the kernel / entry-point audit (tools/kernel_audit.py): rocprofv3 --kernel-trace --stats + ALLSET_ABI_TRACE
+rm -rf $OUT/audit
+ALLSET_ABI_TRACE=$OUT/abi_trace.json timeout 2400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/audit -- python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider > $OUT/${TAG}_pytest.txt 2>&1; grep -n "passed\|failed\|FAILED" $OUT/${TAG}_pytest.txt | tail -8
+find $OUT/audit -name '*kernel_trace.csv' -delete; find $OUT/audit -name '*agent_info.csv' -delete; find $OUT/audit -name '*domain_stats.csv' -delete
+python tools/kernel_audit.py report $OUT/abi_trace.json $OUT/audit > $OUT/${TAG}_kernel_audit.md 2>&1; grep -n "never launched\.$" $OUT/${TAG}_kernel_audit.md
+# the C ABI compiled ON the box (ROCm 7.0 runtime, hipcc 7.2): a touched source sends tests/test_gpu_c_example.py down its compile path
+hipcc --version > $OUT/${TAG}_box_hipcc.txt 2>&1; touch examples/abi_example.cpp; timeout 900 python -m pytest tests/test_gpu_c_example.py -q -m gpu -p no:cacheprovider >> $OUT/${TAG}_box_hipcc.txt 2>&1; tail -2 $OUT/${TAG}_box_hipcc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_${TAG}_$c
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -- python tools/pmc_probe.py > $OUT/pmc_${TAG}_$c.log 2>&1
