@@ -15,7 +15,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 CORE_ABI_VERSION = 1
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
@@ -112,6 +112,9 @@ SIGNATURES = {
     "allset_fused_linear_bwd_all_aux_supported": [c_int64, c_int64],
     "allset_fused_linear_bwd_all_aux": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, _P],
+    "allset_fused_linear_bwd_pma_tail_supported": [c_int64, c_int64, c_int64],
+    "allset_fused_linear_bwd_pma_tail": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P,
+                                         c_int64, c_int64, c_int64, c_int64, _P],
     "allset_fused_linear_blocked_supported": [c_int64, c_int64],
     "allset_fused_linear_tail_supported": [c_int64, c_int64],
     "allset_fused_linear_fwd_ln_side": [_P, c_int64, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int64, _P, c_int64, _P, c_int64, c_int64,

@@ -117,14 +117,24 @@ __device__ __forceinline__ uint32_t hash_mix_s(uint32_t x) { x ^= x >> 16; x *= 
 #define ALLSET_FRESH_LANE_S(name) \
   int name = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); __asm__ volatile("" : "+v"(name))
 
-template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC>
+// PT (round 6, the PMA tail's first rFF Linear; reference layers.py:153-157): this Linear's input is out = ln0(pooled + att_r) and out
+// ALSO feeds the residual add in front of ln1, so the gradient of out is (this Linear's input gradient) + (the residual branch's gs).
+// With PT the kernel takes x = pooled, colb = att_r, ln0's statistics / gamma / beta and `gres` = gs: it recomputes out for the weight
+// gradient (the saved copy is not read), adds gs to gu BEFORE the LayerNorm backward, and writes what allset_ln_res_bwd_pma wrote in
+// a pass of its own -- the gradient of pooled, dcolb (its column sums), and per (row, head) the pooling's backward statistics
+// {m + log(l + 1e-16), delta = <pooled_head, gpooled_head>} for allset_pma_bwd_src.  One launch and one [n, 128] round trip less per conv.
+template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC, bool PT = false>
 __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     const float* __restrict__ gy, int64_t ldg, const uint32_t* __restrict__ mask, float p_out, const float* __restrict__ W,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float p_in, uint64_t seed_in, float* gx, int64_t ldgx,
     float* __restrict__ part_ln, float* __restrict__ part_w, float* __restrict__ part_b, int64_t n,
     const uint64_t* __restrict__ seed_base, int64_t pstride_w, int64_t pstride_b, int64_t pstride_ln, int64_t gcb, int64_t xcb,
-    int64_t gxcb, const float* acc_in, int64_t ldacc, float ln_inv) {
+    int64_t gxcb, const float* acc_in, int64_t ldacc, float ln_inv,
+    const float* __restrict__ colb = nullptr, const float* __restrict__ gres = nullptr, int64_t ldgres = 0,
+    float* __restrict__ part_c = nullptr, int64_t pstride_c = 0, const float* __restrict__ pma_m = nullptr,
+    const float* __restrict__ pma_l = nullptr, float* __restrict__ pma_stats = nullptr, int pma_heads = 1) {
+  static_assert(!PT || (HAS_LN && !DROP_IN && !RELU_IN && !HAS_MASK && !HAS_ACC), "PT: the LayerNorm prologue, nothing else");
   // ln_inv: 1 / 128 for the LayerNorm backward; 0 = the per-column affine prologue (ALLSET_NORM_COLUMN_AFFINE, fused_bwd4.hip: the
   // forward wrote {0, 1} row statistics, gx = gu * gamma, part_ln = sum_r gu * x and sum_r gu) -- then u = x gamma + beta has no bound
   // known in advance and its window comes from the row's own largest element, as without a norm.
@@ -138,6 +148,8 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
   constexpr int PLANE = R * 256;                 // bytes per fp16 plane of an image
   constexpr int IMG = 2 * PLANE;                 // one image: planes h, l
   constexpr int SPG = 132;                       // pitch (floats) of the gu tile
+  constexpr int kSCols = PT ? 4 : 3;             // column-sum arrays the vector waves hand over at the end (dgamma, dbeta, gb [, dcolb])
+  static_assert(kSVWaves * 4 * ID <= R * SPG, "the final column sums reuse the gu tile");
   __shared__ __attribute__((aligned(1024))) uint8_t sGA[3 * IMG];       // (1 KB-aligned: fragment addresses are formed by XOR on the low bits)
   __shared__ __attribute__((aligned(1024))) uint8_t sU[2 * IMG];
   __shared__ __attribute__((aligned(16))) float sGU[R * SPG];
@@ -148,6 +160,8 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
   seed_in = resolve_seed(seed_base, seed_in);
   const int tid = threadIdx.x;
   if (tid < ID) { sG[tid] = HAS_LN ? gamma[tid] : 1.f; sB[tid] = HAS_LN ? beta[tid] : 0.f; }
+  __shared__ __attribute__((aligned(16))) float sCb[PT ? ID : 4];
+  if constexpr (PT) { if (tid < ID) sCb[tid] = colb ? colb[tid] : 0.f; }
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n_stages = (n + R - 1) / R;
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     const uint32_t seed_lo = static_cast<uint32_t>(seed_in);
     const int c = lane0 & 15, rg = lane0 >> 4;
     const int lr = 4 * wave + rg;                // this lane's row of a stage; columns 64 hb + 4 c .. + 3, hb = 0, 1
-    float4 dg[2], db[2], gbv[2];
+    float4 dg[2], db[2], gbv[2], dcv[2];
     const int c40 = 4 * c;
     const uint32_t cog0 = gcb ? static_cast<uint32_t>(((c40 / gcb) * n * gcb + c40 % gcb) * 4) : 4u * c40;
     const uint32_t cox0 = xcb ? static_cast<uint32_t>(((c40 / xcb) * n * xcb + c40 % xcb) * 4) : 4u * c40;
@@ -203,7 +217,14 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       dg[hb] = make_float4(0.f, 0.f, 0.f, 0.f); db[hb] = make_float4(0.f, 0.f, 0.f, 0.f); gbv[hb] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dcv[hb] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // PT: lanes per head g (a power of two; 32: one head over both column halves), this lane's head per column half; the residual
+    // branch's rows and the pooling's softmax statistics of the lane's heads are requested in S2a for S2b of the same stage, one
+    // tick later (two register sets of them, two stages ahead like x, spilled: 58 dwords of scratch per lane)
+    const int pt_g = PT ? (ID / pma_heads) / 4 : 1;
+    const int pt_h0 = PT ? (pt_g >= 32 ? 0 : c / pt_g) : 0, pt_h1 = PT ? (pt_g >= 32 ? 0 : (16 + c) / pt_g) : 0;
+
     // Two register sets each: the operands of the next TWO stages are in flight (16 waves x 2 KB x 2 = 64 KB per CU)
     float4 agS[2][2]; uint32_t amS[2][2];            // [set][hb]: gy row / mask words
     float4 xrS[2][2]; float2 stS[2];                 // [set][hb]: x row; [set]: statistics
@@ -228,6 +249,30 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       for (int hb = 0; hb < 2; ++hb)
         xr[hb] = *reinterpret_cast<const float4*>(xb + hb * dhx + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldx) * 4u + cox0));
       if constexpr (HAS_LN) st = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(stats + s0 * R * 2) + lrc * 8);
+    };
+    // PT: the residual branch's rows / the softmax statistics of stage k, requested in S2a(k) for S2b(k), one tick ahead.  Measured
+    // on one box at [1M, 128] (tools/pma_tail_bwd_bench.py, 4 heads; the two passes this replaces: 0.76 ms): this form 0.61 ms; the
+    // requests a whole stage ahead (issued at the end of S2b(k - 1): eight more registers live through S0 / S2a) 0.66; two register
+    // sets two stages ahead, like x: 58 dwords of scratch per lane, not timed
+    auto request_gres = [&](int64_t k, float4 (&gr)[2]) {
+      if constexpr (PT) {
+        const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);
+        const int nrc = max(rows_left(s0), 1);
+        const int lrc = min(lr, nrc - 1);
+        const char* gb_ = reinterpret_cast<const char*>(gres + s0 * R * ldgres);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          gr[hb] = *reinterpret_cast<const float4*>(gb_ + hb * 256 + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(ldgres) * 4u + 16u * c));
+      }
+    };
+    auto request_ml = [&](int64_t k, float2 (&ml)[2]) {
+      if constexpr (PT) {
+        const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);
+        const int nrc = max(rows_left(s0), 1);
+        const int64_t row = s0 * R + min(lr, nrc - 1);
+        ml[0] = make_float2(pma_m[row * pma_heads + pt_h0], pma_l[row * pma_heads + pt_h0]);
+        ml[1] = make_float2(pma_m[row * pma_heads + pt_h1], pma_l[row * pma_heads + pt_h1]);
+      }
     };
     int eNext = kSEMin, eCur = kSEMin;            // biased row exponent of ga: stage k + 1 (written by S0), stage k (read by S2b)
     int Erun = 2 * kSEMin;                        // the largest q_r over the stages up to the one S2b is working on
@@ -279,8 +324,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     float4 xhK[2];             // xhat of stage k, [hb]
     int4 kmK[2];               // dropout-in keep MASKS (all-ones / zero; 1 / keep rides on the scales the values meet anyway)
     uint32_t xbK = 0;          // "raw x > 0" flags, bit 4 hb + q
-    float rstdK = 1.f;
+    float rstdK = 1.f, meanK = 0.f;
+    float4 grK[2]; float2 mlK[2];                    // PT: the residual branch's row / the softmax statistics of stage k (S2a -> S2b)
     auto S2a = [&](int64_t k, float4 (&xr)[2], float2& st) {
+      request_gres(k, grK); request_ml(k, mlK);       // (PT; no-ops otherwise)
       const int64_t stage = stage_of(k);
       const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * ID / 2);
       const uint32_t stage_pair_lo = static_cast<uint32_t>(stage_pair);
@@ -290,7 +337,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       const uint32_t hi_term_q = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed_in >> 32);
       xbK = 0;
       const float mean = HAS_LN ? st.x : 0.f, rstd = HAS_LN ? st.y : 1.f;
-      rstdK = rstd;
+      rstdK = rstd; meanK = mean;
       float uamax = 0.f;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
@@ -316,6 +363,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         }
         kmK[hb] = km;
         float4 t = xr[hb];
+        if constexpr (PT) {
+          const float4 cb4 = *reinterpret_cast<const float4*>(&sCb[64 * hb + 4 * c]);
+          t.x += cb4.x; t.y += cb4.y; t.z += cb4.z; t.w += cb4.w;
+        }
         if (RELU_IN) {
           xbK |= ((t.x > 0.f ? 1u : 0u) | (t.y > 0.f ? 2u : 0u) | (t.z > 0.f ? 4u : 0u) | (t.w > 0.f ? 8u : 0u)) << (4 * hb);
           t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
@@ -374,6 +425,10 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
           v[hb].x = __int_as_float(__float_as_int(v[hb].x) & kmK[hb].x); v[hb].y = __int_as_float(__float_as_int(v[hb].y) & kmK[hb].y);
           v[hb].z = __int_as_float(__float_as_int(v[hb].z) & kmK[hb].z); v[hb].w = __int_as_float(__float_as_int(v[hb].w) & kmK[hb].w);
         }
+        if constexpr (PT) {                         // d out = this Linear's + the residual branch's (a dead row re-read the last row: it adds nothing)
+          const float kzr = live ? 1.f : 0.f;
+          v[hb].x = fmaf(grK[hb].x, kzr, v[hb].x); v[hb].y = fmaf(grK[hb].y, kzr, v[hb].y); v[hb].z = fmaf(grK[hb].z, kzr, v[hb].z); v[hb].w = fmaf(grK[hb].w, kzr, v[hb].w);
+        }
         if constexpr (HAS_LN) {
           const float4 xh = xhK[hb];
           dg[hb].x = fmaf(v[hb].x, xh.x, dg[hb].x); dg[hb].y = fmaf(v[hb].y, xh.y, dg[hb].y);
@@ -387,6 +442,8 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       float s1 = 0.f, s2 = 0.f;
       if constexpr (HAS_LN) { s1 = row16_sum_s(a1) * inv_i; s2 = row16_sum_s(a2) * inv_i; }
       const float rstd = rstdK;
+      const float ptSd = PT ? 1.f / rstd : 0.f, ptMean = PT ? meanK : 0.f;
+      float ptDot[2] = {0.f, 0.f};
       uint8_t* img = sU + (k % 2) * IMG;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
@@ -407,6 +464,15 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #endif
           *reinterpret_cast<float4*>(reinterpret_cast<char*>(gx + stage * R * ldgx) +
                                      hb * dhgx + (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgx) * 4u + cogx0)) = o;
+        if constexpr (PT) {
+          const float kz = live ? 1.f : 0.f;
+          dcv[hb].x = fmaf(o.x, kz, dcv[hb].x); dcv[hb].y = fmaf(o.y, kz, dcv[hb].y); dcv[hb].z = fmaf(o.z, kz, dcv[hb].z); dcv[hb].w = fmaf(o.w, kz, dcv[hb].w);
+          // delta = <pooled_head, gpooled_head>: pooled = xhat / rstd + mean - colb, recomputed (eight registers of the raw row saved)
+          const float4 cb4 = *reinterpret_cast<const float4*>(&sCb[64 * hb + 4 * c]);
+          const float sd = ptSd, mu = ptMean;
+          ptDot[hb] = fmaf(fmaf(xh.x, sd, mu) - cb4.x, o.x, fmaf(fmaf(xh.y, sd, mu) - cb4.y, o.y,
+                      fmaf(fmaf(xh.z, sd, mu) - cb4.z, o.z, (fmaf(xh.w, sd, mu) - cb4.w) * o.w)));
+        }
         float4 u = xh;
         if constexpr (HAS_LN) {
           const float4 bet = *reinterpret_cast<const float4*>(&sB[64 * hb + 4 * c]);
@@ -422,6 +488,22 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
         const int wo = img_off_s(lr, 128 * hb + 8 * c);
         *reinterpret_cast<uint2*>(img + 0 * PLANE + wo) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(img + 1 * PLANE + wo) = make_uint2(l0, l1);
+      }
+      if constexpr (PT) {
+        // per head: the lanes of a head are pt_g consecutive lanes of the DPP row (both column halves together when there is one head)
+        float d0 = ptDot[0], d1 = ptDot[1];
+        if (pt_g >= 32) { d0 += d1; d1 = d0; }
+        if (pt_g >= 2) { d0 += dpp_fs<0xB1>(d0); d1 += dpp_fs<0xB1>(d1); }
+        if (pt_g >= 4) { d0 += dpp_fs<0x4E>(d0); d1 += dpp_fs<0x4E>(d1); }
+        if (pt_g >= 8) { d0 += dpp_fs<0x141>(d0); d1 += dpp_fs<0x141>(d1); }
+        if (pt_g >= 16) { d0 += dpp_fs<0x140>(d0); d1 += dpp_fs<0x140>(d1); }
+        const int64_t row = stage * R + lr;
+        const bool w0 = live && (pt_g >= 32 ? c == 0 : (c % pt_g) == 0), w1 = live && pt_g < 32 && (c % pt_g) == 0;
+        // empty target: never gathered; exp(a - FLT_MAX) = 0 (the convention of pma_bwd_stats_kernel, csrc/pma.hip)
+        if (w0) *reinterpret_cast<float2*>(pma_stats + (row * pma_heads + pt_h0) * 2) =
+            make_float2(mlK[0].y > 0.f ? mlK[0].x + __logf(mlK[0].y + 1e-16f) : 3.402823466e+38f, d0);
+        if (w1) *reinterpret_cast<float2*>(pma_stats + (row * pma_heads + pt_h1) * 2) =
+            make_float2(mlK[1].y > 0.f ? mlK[1].x + __logf(mlK[1].y + 1e-16f) : 3.402823466e+38f, d1);
       }
       eCur = eNext;                               // S0(k + 1) ran in the previous tick
     };
@@ -468,17 +550,19 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     // then the eight waves through LDS in a fixed order
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      float4 a = dg[hb], b = db[hb], g3 = gbv[hb];
+      float4 a = dg[hb], b = db[hb], g3 = gbv[hb], c4 = dcv[hb];
 #pragma unroll
       for (int off = 16; off < 64; off <<= 1) {
         a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
         b.x += __shfl_xor(b.x, off); b.y += __shfl_xor(b.y, off); b.z += __shfl_xor(b.z, off); b.w += __shfl_xor(b.w, off);
         g3.x += __shfl_xor(g3.x, off); g3.y += __shfl_xor(g3.y, off); g3.z += __shfl_xor(g3.z, off); g3.w += __shfl_xor(g3.w, off);
+        if constexpr (PT) { c4.x += __shfl_xor(c4.x, off); c4.y += __shfl_xor(c4.y, off); c4.z += __shfl_xor(c4.z, off); c4.w += __shfl_xor(c4.w, off); }
       }
       if (lane0 < 16) {                         // (gu is free: the last S2b read it two ticks ago)
-        *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + 64 * hb + 4 * lane0]) = a;
-        *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + ID + 64 * hb + 4 * lane0]) = b;
-        *reinterpret_cast<float4*>(&sGU[wave * 3 * ID + 2 * ID + 64 * hb + 4 * lane0]) = g3;
+        *reinterpret_cast<float4*>(&sGU[wave * kSCols * ID + 64 * hb + 4 * lane0]) = a;
+        *reinterpret_cast<float4*>(&sGU[wave * kSCols * ID + ID + 64 * hb + 4 * lane0]) = b;
+        *reinterpret_cast<float4*>(&sGU[wave * kSCols * ID + 2 * ID + 64 * hb + 4 * lane0]) = g3;
+        if constexpr (PT) *reinterpret_cast<float4*>(&sGU[wave * kSCols * ID + 3 * ID + 64 * hb + 4 * lane0]) = c4;
       }
     }
   } else {
@@ -683,13 +767,14 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     for (int q = 0; q < 4; ++q) dbg[q] = static_cast<float>(tph[q]);
   }
 #endif
-  if (tid < 3 * ID) {
+  if (tid < kSCols * ID) {
     float s = 0.f;
 #pragma unroll
-    for (int v = 0; v < kSVWaves; ++v) s += sGU[v * 3 * ID + tid];
+    for (int v = 0; v < kSVWaves; ++v) s += sGU[v * kSCols * ID + tid];
     const int64_t slice = blockIdx.x;
     if (tid < 2 * ID) { if constexpr (HAS_LN) part_ln[slice * pstride_ln + tid] = s; }
-    else if (part_b != nullptr) part_b[slice * pstride_b + (tid - 2 * ID)] = s;
+    else if (tid < 3 * ID) { if (part_b != nullptr) part_b[slice * pstride_b + (tid - 2 * ID)] = s; }
+    else if (part_c != nullptr) part_c[slice * pstride_c + (tid - 3 * ID)] = s;
   }
 }
 
@@ -723,4 +808,59 @@ int launch_fused_linear_bwd_f16x3(unsigned grid, hipStream_t st, bool ln, bool d
 #undef ALLSET_S_M
 #undef ALLSET_S_K
   return 0;
+}
+
+// ---- the PMA tail's first rFF Linear, backward, with ln0's backward and the pooling's backward statistics in the same pass (PT) ----
+// gu = gy W + gres;  gx = d(pooled) through ln0's backward (x = pooled, colb = att_r, stats / gamma / beta of ln0);  gW = gy^T out,
+// gb = colsum(gy) with out = ln0(pooled + att_r) recomputed;  part: [slices][stride] = gW [128*128] | gb [128] | dgamma, dbeta [256] |
+// dcolb [128];  pma_stats[r, h] = {m + log(l + 1e-16), <pooled_h, gx_h>}
+extern "C" int allset_fused_linear_bwd_pma_tail_supported(int64_t O, int64_t I, int64_t heads) {
+#ifdef ALLSET_NO_F16X3
+  (void)O; (void)I; (void)heads;
+  return 0;
+#else
+  if (O != 128 || I != 128 || heads < 1 || 128 % heads != 0 || (128 / heads) % 4 != 0) return 0;
+  const int64_t g = (128 / heads) / 4;
+  return (g & (g - 1)) == 0 ? 1 : 0;
+#endif
+}
+
+unsigned fused_linear_bwd_roles_grid(int64_t n);
+
+extern "C" int allset_fused_linear_bwd_pma_tail(const float* gy, int64_t ldg, const float* W, const float* pooled, int64_t ldx,
+                                                const float* colb, const float* stats, const float* gamma, const float* beta,
+                                                const float* gres, int64_t ldgres, float* gx, int64_t ldgx, float* part,
+                                                int64_t part_stride, int64_t n_slices, const float* pma_m, const float* pma_l,
+                                                float* pma_stats, int64_t heads, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_pma_tail: negative size");
+  if (!allset_fused_linear_bwd_pma_tail_supported(O, I, heads)) {
+    set_error("fused_linear_bwd_pma_tail: out=%lld in=%lld heads=%lld is not built (128 x 128, channels per head 4 x a power of two; "
+              "allset_fused_linear_bwd_pma_tail_supported)", static_cast<long long>(O), static_cast<long long>(I), static_cast<long long>(heads));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(part != nullptr && part_stride >= O * I + O + 3 * I, "fused_linear_bwd_pma_tail: part_stride smaller than O*I + O + 3*I");
+  const unsigned grid = fused_linear_bwd_roles_grid(n);
+  ALLSET_REQUIRE(n_slices == static_cast<int64_t>(grid), "fused_linear_bwd_pma_tail: part must hold allset_fused_linear_bwd_all_slices_for() slices");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(part, 0, static_cast<size_t>(n_slices) * part_stride * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && W && pooled && stats && gamma && beta && gres && gx && pma_m && pma_l && pma_stats, "fused_linear_bwd_pma_tail: null pointer");
+  ALLSET_REQUIRE(aligned16(gy) && aligned16(W) && aligned16(pooled) && aligned16(gres) && aligned16(gx) && (colb == nullptr || aligned16(colb)),
+                 "fused_linear_bwd_pma_tail: gy / W / pooled / gres / gx / colb must be 16-byte aligned");
+  ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && ldx >= I && ldx % 4 == 0 && ldgres >= I && ldgres % 4 == 0 && ldgx >= I && ldgx % 4 == 0 &&
+                 ldg < (1 << 24) && ldx < (1 << 24) && ldgres < (1 << 24) && ldgx < (1 << 24),
+                 "fused_linear_bwd_pma_tail: rows must be 16-byte aligned, leading dimensions below 2^24");
+  ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 7u) == 0 && (reinterpret_cast<uintptr_t>(pma_stats) & 7u) == 0,
+                 "fused_linear_bwd_pma_tail: stats / pma_stats must be 8-byte aligned");
+#ifndef ALLSET_NO_F16X3
+  fused_linear_bwd_f16x3_kernel<true, false, false, false, false, true><<<grid, kSBlock, 0, st>>>(
+      gy, ldg, nullptr, 0.f, W, pooled, ldx, stats, gamma, beta, 0.f, 0, gx, ldgx, part + O * I + O, part, part + O * I, n, nullptr, part_stride,
+      part_stride, part_stride, 0, 0, 0, nullptr, 0, 1.f / 128.f, colb, gres, ldgres, part + O * I + O + 2 * I, part_stride, pma_m, pma_l,
+      pma_stats, static_cast<int>(heads));
+  ALLSET_LAUNCH_CHECK();
+#endif
+  return ALLSET_OK;
 }

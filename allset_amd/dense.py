@@ -1450,6 +1450,40 @@ def pma_tail_fwd(pooled: Tensor, cb: Tensor, g0, b0, eps0, w1, b1, w2, b2, g1, b
                                                                                        b1 is not None, b2 is not None)
 
 
+def fused_linear_bwd_pma_tail_supported(heads: int) -> bool:
+    return _arith != _lib.ARITH_BF16X6 and bool(_lib.load().allset_fused_linear_bwd_pma_tail_supported(128, 128, int(heads)))
+
+
+def fused_linear_bwd_pma_tail(gy: Tensor, weight: Tensor, pooled: Tensor, colb: Optional[Tensor], stats: Tensor, gamma: Tensor, beta: Tensor,
+                              gres: Tensor, m: Tensor, l: Tensor, want_bias: bool = True):
+    """``(g_pooled, dgamma0, dbeta0, dcolb, gW, gb, pma_stats)``: the backward of the PMA tail's first rFF Linear with the residual
+    branch's gradient added in front of ln0's backward, ln0's backward, and the pooling's backward statistics -- ONE pass
+    (include/allset_hip_ext.h allset_fused_linear_bwd_pma_tail; until round 6: fused_linear_bwd_all(acc_in) + ln_res_bwd_pma)."""
+    dev = require_device(gy, weight, pooled, colb, stats, gamma, beta, gres, m, l)
+    _check_f32(gy, weight, pooled, colb, stats, gamma, beta, gres, m, l)
+    gy, pooled, gres = _rowmajor(gy), _rowmajor(pooled), _rowmajor(gres)
+    n, O = gy.shape
+    I = pooled.shape[1]
+    H = m.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_fused_linear_bwd_all_slices_for(n, O, I, 0, byref(ns)), "allset_fused_linear_bwd_all_slices_for")
+    P = ns.value
+    M = (O * I + O + 3 * I + 3) // 4 * 4
+    part = torch.empty((P, M), dtype=torch.float32, device=dev)
+    gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    pstats = torch.empty((n, H, 2), dtype=torch.float32, device=dev)
+    with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (O + 3 * I) * 4 + n * H * 16):
+        check(lib.allset_fused_linear_bwd_pma_tail(
+            ptr(gy), _ld(gy), ptr(weight.contiguous()), ptr(pooled), _ld(pooled), ptr(colb.contiguous() if colb is not None else None),
+            ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(gres), _ld(gres), ptr(gx), max(I, 1), ptr(part), M, P,
+            ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, n, O, I, stream_of(dev)), "allset_fused_linear_bwd_pma_tail")
+    red = reduce_partials(part)
+    o = O * I
+    return (gx, red[o + O:o + O + I], red[o + O + I:o + O + 2 * I], red[o + O + 2 * I:o + O + 3 * I], red[:o].view(O, I),
+            red[o:o + O] if want_bias else None, pstats)
+
+
 def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional[Tensor] = None):
     """``(g_pooled, dcolb, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pma_stats or None)``: ln1's backward on the saved sum, the two
     Linears' one-pass backward (the residual branch summed through ``acc_in``), ln0's backward -- with the pooling's backward
@@ -1458,6 +1492,15 @@ def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional
     relu_post, p, seed, base, has_b1, has_b2 = cfg
     gs, dg1, db1, _ = ln_res_bwd(gy.contiguous(), s, None, None, stats1, g1, bt1, relu_post, p, seed, base)
     gh, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
+    if m is None and fused_linear_bwd_pma_tail_supported(1):
+        # the tail on its own (no pooling behind it): the same pass with one dummy head, its statistics discarded
+        m1 = torch.zeros((pooled.shape[0], 1), dtype=torch.float32, device=pooled.device)
+        g_pooled, dg0, db0, dc, gw1, gb1, _ = fused_linear_bwd_pma_tail(gh, w1, pooled, cb, stats0, g0, b0, gs, m1, torch.ones_like(m1), want_bias=has_b1)
+        return g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, None
+    if m is not None and fused_linear_bwd_pma_tail_supported(m.shape[1]):
+        # the first Linear's backward, ln0's backward and the pooling's statistics in ONE pass (csrc/fused_bwd6.hip PT)
+        g_pooled, dg0, db0, dc, gw1, gb1, pstats = fused_linear_bwd_pma_tail(gh, w1, pooled, cb, stats0, g0, b0, gs, m, l, want_bias=has_b1)
+        return g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats
     gout, _, _, gw1, gb1 = fused_linear_bwd_all(gh, None, 0.0, w1, out, None, None, None, False, 0.0, 0, acc_in=gs, want_bias=has_b1)
     if m is not None:
         g_pooled, dg0, db0, dc, pstats = ln_res_bwd_pma(gout, pooled, cb, stats0, g0, b0, m, l)

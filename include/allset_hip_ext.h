@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 11  /* 2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
+#define ALLSET_ABI_VERSION 12  /* 12: additions only (allset_fused_linear_bwd_pma_tail(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now.  Earlier:  2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
 
 /* ---------------------------------------------------------------------------------------------
  * Dense tail (reference MLP.forward, layers.py:571-579: norm -> [Linear -> ReLU -> norm -> dropout]* -> Linear,
@@ -526,6 +526,22 @@ int allset_fused_linear_bwd_all_aux_supported(int64_t O, int64_t I);
 int allset_fused_linear_bwd_all_aux(const float* gy, int64_t ldg, const float* W, const float* x, int64_t ldx, const float* aux_g,
                                     const float* aux_w, float* gx, int64_t ldgx, float* part, int64_t part_stride, int64_t n_slices,
                                     int64_t n, int64_t O, int64_t I, void* stream);
+
+/* ---- the PMA tail's first rFF Linear, backward, with ln0's backward and the pooling's backward statistics in the same pass (ABI 12;
+ * reference layers.py:153-157: out = ln0(pooled + att_r) feeds rFF's first Linear AND the residual add in front of ln1).  O = I = 128,
+ * fp16x3 arithmetic, heads with 128 / heads = 4 x a power of two (allset_fused_linear_bwd_pma_tail_supported):
+ *   gu = gy W + gres            (gres [n, 128]: the residual branch's gradient of out, i.e. ln1's input gradient)
+ *   gx = the gradient of `pooled` through ln0's backward (x = pooled, colb = att_r flattened or NULL, stats / gamma / beta of ln0)
+ *   gW = gy^T out, gb = colsum(gy), with out = ln0(pooled + colb) RECOMPUTED (the forward's saved copy is not read)
+ *   part: [n_slices][part_stride] = gW [O*I] | gb [O] | dgamma [I] | dbeta [I] | dcolb [I]  (part_stride >= O*I + O + 3*I; n_slices =
+ *         allset_fused_linear_bwd_all_slices_for(n, 128, 128, 0); the caller sums over slices)
+ *   pma_stats[r, h] = {pma_m[r, h] + log(pma_l[r, h] + 1e-16)  (FLT_MAX for an empty target),  <pooled[r, h, :], gx[r, h, :]>}
+ * -- what allset_fused_linear_bwd_all (acc_in = gres) followed by allset_ln_res_bwd_pma computed in two passes. */
+int allset_fused_linear_bwd_pma_tail_supported(int64_t O, int64_t I, int64_t heads);
+int allset_fused_linear_bwd_pma_tail(const float* gy, int64_t ldg, const float* W, const float* pooled, int64_t ldx, const float* colb,
+                                     const float* stats, const float* gamma, const float* beta, const float* gres, int64_t ldgres,
+                                     float* gx, int64_t ldgx, float* part, int64_t part_stride, int64_t n_slices, const float* pma_m,
+                                     const float* pma_l, float* pma_stats, int64_t heads, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* ---- the PMA tail folded into its two rFF Linears (ABI 11; reference layers.py:153-157: out = ln0(pooled + att_r);
  * out = ln1(out + relu(rFF(out)))), K = N = 128, fp16x3 arithmetic (allset_fused_linear_tail_supported):

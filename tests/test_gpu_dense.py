@@ -636,6 +636,56 @@ def test_pma_tail_two_kernel_forward_against_float64(n, relu_post, p, device, mo
         torch.testing.assert_close(y, y2, rtol=1e-4, atol=2e-5 * max(1.0, float(y2.abs().max())))
 
 
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("n", [1, 33, 4099, 70001])
+def test_pma_tail_first_linear_backward_in_one_pass(n, H, device):
+    """``dense.fused_linear_bwd_pma_tail`` (csrc/fused_bwd6.hip PT): the backward of rFF's first Linear with the residual branch's
+    gradient added in front of ln0's backward, ln0's backward, dcolb and the pooling's backward statistics {m + log l, <pooled_h,
+    gpooled_h>} in ONE pass -- against float64, and against the two-pass pair it replaces (fused_linear_bwd_all with acc_in +
+    ln_res_bwd_pma), every head count the reference's scripts use and the extremes (one lane per head, one head over both halves)."""
+    from allset_amd import dense
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(31 * n + H)
+    mk = lambda *s, sc=1.0, off=0.0: (torch.randn(*s, generator=g) * sc + off).to(device)
+    pooled, cb = mk(n, 128, sc=2.0), mk(128, sc=0.5)
+    g0, b0 = mk(128, sc=0.2, off=1.0), mk(128, sc=0.3)
+    w1 = mk(128, 128, sc=128 ** -0.5)
+    gh, gs = mk(n, 128), mk(n, 128)
+    m = mk(n, H)
+    l = torch.rand(n, H, generator=g).to(device) * 5 + 0.1
+    if n > 1:
+        l[n // 2] = 0.0                                     # an empty target: FLT_MAX in its statistics
+    out, stats0 = dense.layer_norm_fwd(pooled + cb, g0, b0, 1e-5) if hasattr(dense, "layer_norm_fwd") else (None, None)
+    if out is None:
+        x = pooled + cb
+        mean = x.mean(1, keepdim=True); var = x.var(1, unbiased=False, keepdim=True)
+        stats0 = torch.cat([mean, torch.rsqrt(var + 1e-5)], 1).contiguous()
+        out = F.layer_norm(x, (128,), g0, b0, 1e-5)
+    got = dense.fused_linear_bwd_pma_tail(gh, w1, pooled, cb, stats0, g0, b0, gs, m, l)
+    g_pooled, dg0, db0, dc, gw1, gb1, pstats = got
+    # ---- the two-pass pair
+    gout, _, _, gw_r, gb_r = dense.fused_linear_bwd_all(gh, None, 0.0, w1, out, None, None, None, False, 0.0, 0, acc_in=gs.clone())
+    gp_r, dg_r, db_r, dc_r, ps_r = dense.ln_res_bwd_pma(gout, pooled, cb, stats0, g0, b0, m, l)
+    sc = lambda t: max(1.0, float(t.abs().max()))
+    for a, b_, what in ((g_pooled, gp_r, "g_pooled"), (dg0, dg_r, "dgamma"), (db0, db_r, "dbeta"), (dc, dc_r, "dcolb"), (gw1, gw_r, "gW"), (gb1, gb_r, "gb")):
+        torch.testing.assert_close(a, b_, rtol=2e-5, atol=2e-5 * sc(b_), msg=lambda mm: f"{what} vs the two-pass pair: {mm}")
+    torch.testing.assert_close(pstats[..., 0], ps_r[..., 0], rtol=1e-6, atol=1e-6)
+    dsc = max(1.0, float(ps_r[..., 1].abs().max()))
+    torch.testing.assert_close(pstats[..., 1], ps_r[..., 1], rtol=2e-5, atol=2e-5 * dsc)
+    # ---- float64
+    pd = pooled.double().requires_grad_(True); cbd = cb.double().requires_grad_(True)
+    g0d, b0d, w1d = g0.double().requires_grad_(True), b0.double().requires_grad_(True), w1.double().requires_grad_(True)
+    od = F.layer_norm(pd + cbd, (128,), g0d, b0d, 1e-5)
+    y1 = od @ w1d.t()
+    ((y1 * gh.double()).sum() + (od * gs.double()).sum()).backward()
+    for a, b_, what in ((g_pooled, pd.grad, "g_pooled"), (dg0, g0d.grad, "dgamma"), (db0, b0d.grad, "dbeta"), (dc, cbd.grad, "dcolb"), (gw1, w1d.grad, "gW")):
+        torch.testing.assert_close(a.double(), b_, rtol=2e-5, atol=2e-5 * sc(b_), msg=lambda mm: f"{what} vs float64: {mm}")
+    delta = (pooled.double().view(n, H, -1) * pd.grad.view(n, H, -1)).sum(-1)
+    torch.testing.assert_close(pstats[..., 1].double(), delta, rtol=2e-5, atol=2e-5 * max(1.0, float(delta.abs().max())))
+    Mexp = torch.where(l > 0, m + torch.log(l + 1e-16), torch.full_like(m, 3.402823466e+38))
+    torch.testing.assert_close(pstats[..., 0], Mexp, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("n", [1, 33, 4099, 70001])
 @pytest.mark.parametrize("kind", ["plain", "relu", "row_scales", "zero_rows", "w_column_scales"])
 def test_fused_linear_forward_row_scaled_fp16x3_against_float64(n, kind, device):
