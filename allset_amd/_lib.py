@@ -115,6 +115,9 @@ SIGNATURES = {
     "allset_fused_linear_bwd_pma_tail_supported": [c_int64, c_int64, c_int64],
     "allset_fused_linear_bwd_pma_tail": [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P,
                                          c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_fused_linear_bwd_ln_pro_supported": [c_int64, c_int64],
+    "allset_fused_linear_bwd_ln_pro": [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, c_float, c_uint64, _P, _P, _P, _P, c_int64, c_int, _P, c_int64,
+                                       _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_fused_linear_blocked_supported": [c_int64, c_int64],
     "allset_fused_linear_tail_supported": [c_int64, c_int64],
     "allset_fused_linear_fwd_ln_side": [_P, c_int64, _P, _P, _P, c_float, _P, _P, c_int, _P, c_int64, _P, c_int64, _P, c_int64, c_int64,

@@ -123,7 +123,13 @@ __device__ __forceinline__ uint32_t hash_mix_s(uint32_t x) { x ^= x >> 16; x *= 
 // gradient (the saved copy is not read), adds gs to gu BEFORE the LayerNorm backward, and writes what allset_ln_res_bwd_pma wrote in
 // a pass of its own -- the gradient of pooled, dcolb (its column sums), and per (row, head) the pooling's backward statistics
 // {m + log(l + 1e-16), delta = <pooled_head, gpooled_head>} for allset_pma_bwd_src.  One launch and one [n, 128] round trip less per conv.
-template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC, bool PT = false>
+// PT2 (round 6, the PMA tail's SECOND rFF Linear): its output z feeds s = out + relu(z), y = dropout_p(relu_post?(ln1(s))).  With PT2
+// the kernel takes the gradient of y, the saved sum s, ln1's statistics / gamma / beta and the conv's dropout (p2, seed2): stage S0
+// runs ln1's backward on the row it is about to stage -- the dropout's keep factors from the counter hash, the relu mask from the
+// recomputed LayerNorm output, two DPP row sums -- writes gs (the residual branch's gradient of out, which the first Linear's backward
+// adds in front of ln0's: PT) and stages gs under the relu mask of z as this Linear's gy.  dgamma1 / dbeta1 leave through part_ln.
+// What allset_ln_res_bwd computed in a pass of its own.
+template <bool HAS_LN, bool DROP_IN, bool RELU_IN, bool HAS_MASK, bool HAS_ACC, bool PT = false, bool PT2 = false>
 __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     const float* __restrict__ gy, int64_t ldg, const uint32_t* __restrict__ mask, float p_out, const float* __restrict__ W,
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -133,8 +139,12 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     int64_t gxcb, const float* acc_in, int64_t ldacc, float ln_inv,
     const float* __restrict__ colb = nullptr, const float* __restrict__ gres = nullptr, int64_t ldgres = 0,
     float* __restrict__ part_c = nullptr, int64_t pstride_c = 0, const float* __restrict__ pma_m = nullptr,
-    const float* __restrict__ pma_l = nullptr, float* __restrict__ pma_stats = nullptr, int pma_heads = 1) {
+    const float* __restrict__ pma_l = nullptr, float* __restrict__ pma_stats = nullptr, int pma_heads = 1,
+    const float* __restrict__ s2 = nullptr, int64_t lds2 = 0, const float* __restrict__ stats2 = nullptr,
+    const float* __restrict__ gamma2 = nullptr, const float* __restrict__ beta2 = nullptr, int relu_post = 0, float p2 = 0.f,
+    uint64_t seed2 = 0, float* __restrict__ gs_out = nullptr, int64_t ldgs = 0) {
   static_assert(!PT || (HAS_LN && !DROP_IN && !RELU_IN && !HAS_MASK && !HAS_ACC), "PT: the LayerNorm prologue, nothing else");
+  static_assert(!PT2 || (!HAS_LN && !DROP_IN && HAS_MASK && !HAS_ACC && !PT), "PT2: the masked gy of a Linear without a norm");
   // ln_inv: 1 / 128 for the LayerNorm backward; 0 = the per-column affine prologue (ALLSET_NORM_COLUMN_AFFINE, fused_bwd4.hip: the
   // forward wrote {0, 1} row statistics, gx = gu * gamma, part_ln = sum_r gu * x and sum_r gu) -- then u = x gamma + beta has no bound
   // known in advance and its window comes from the row's own largest element, as without a norm.
@@ -162,6 +172,9 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
   if (tid < ID) { sG[tid] = HAS_LN ? gamma[tid] : 1.f; sB[tid] = HAS_LN ? beta[tid] : 0.f; }
   __shared__ __attribute__((aligned(16))) float sCb[PT ? ID : 4];
   if constexpr (PT) { if (tid < ID) sCb[tid] = colb ? colb[tid] : 0.f; }
+  __shared__ __attribute__((aligned(16))) float sG2[PT2 ? 2 * OD : 4];      // PT2: ln1's gamma | beta
+  if constexpr (PT2) { if (tid < OD) { sG2[tid] = gamma2[tid]; sG2[OD + tid] = beta2[tid]; } }
+  seed2 = resolve_seed(seed_base, seed2);
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t n_stages = (n + R - 1) / R;
@@ -227,7 +240,20 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 
     // Two register sets each: the operands of the next TWO stages are in flight (16 waves x 2 KB x 2 = 64 KB per CU)
     float4 agS[2][2]; uint32_t amS[2][2];            // [set][hb]: gy row / mask words
+    float4 sgS[2][2]; float2 s2S[2];                 // PT2: [set][hb]: the saved sum's row; [set]: ln1's statistics of the row
     float4 xrS[2][2]; float2 stS[2];                 // [set][hb]: x row; [set]: statistics
+    auto request_s2 = [&](int64_t k, float4 (&sg)[2], float2& st2) {
+      if constexpr (PT2) {
+        const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);
+        const int nrc = max(rows_left(s0), 1);
+        const int lrc = min(lr, nrc - 1);
+        const char* sb = reinterpret_cast<const char*>(s2 + s0 * R * lds2);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          sg[hb] = *reinterpret_cast<const float4*>(sb + hb * 256 + (static_cast<uint32_t>(lrc) * static_cast<uint32_t>(lds2) * 4u + 16u * c));
+        st2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(stats2 + s0 * R * 2) + lrc * 8);
+      }
+    };
     auto request_gy = [&](int64_t k, float4 (&ag)[2], uint32_t (&am)[2]) {
       const int64_t s0 = k < T ? stage_of(k) : stage_of(T - 1);           // past the end: re-read the last stage (never consumed)
       const int nrc = max(rows_left(s0), 1);
@@ -278,12 +304,70 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     int Erun = 2 * kSEMin;                        // the largest q_r over the stages up to the one S2b is working on
     int quK = kSEMin;                             // eu_r of stage k (S2a -> S2b)
     // ---- S0(k): ga = gy under the forward's epilogue mask, scaled to the row's window, two fp16 planes into ga[k % 3]
-    auto S0 = [&](int64_t k, float4 (&ag)[2], uint32_t (&am)[2]) {
+    const float keep2 = (PT2 && p2 > 0.f) ? 1.f / (1.f - p2) : 1.f;
+    const uint32_t thr2 = drop_threshold(p2);
+    auto S0 = [&](int64_t k, float4 (&ag)[2], uint32_t (&am)[2], float4 (&sg)[2], float2& st2) {
       const int nrows = rows_left(stage_of(k));
       const bool valid = lr < nrows;
       uint8_t* img = sGA + (k % 3) * IMG;
       float4 v[2];
       float amax = 0.f;
+      if constexpr (PT2) {
+        // ---- ln1's backward on this row: ag = the gradient of y = dropout_p2(relu_post?(LayerNorm(s))), sg = s, st2 = {mean, rstd}
+        const int64_t stage = stage_of(k);
+        const float mean = st2.x, rstd = st2.y;
+        float4 xh[2], gh1[2];
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const float4 g4 = *reinterpret_cast<const float4*>(&sG2[64 * hb + 4 * c]), b4 = *reinterpret_cast<const float4*>(&sG2[OD + 64 * hb + 4 * c]);
+          xh[hb] = make_float4((sg[hb].x - mean) * rstd, (sg[hb].y - mean) * rstd, (sg[hb].z - mean) * rstd, (sg[hb].w - mean) * rstd);
+          float4 g = ag[hb];
+          if (p2 > 0.f) {                           // the conv's dropout on y: the forward's hash (fused_fwd2.hip keep4), element (row, column) of [n, 128]
+            float4 kp;
+            if (thr2 & kDrop8) {
+              const uint64_t stage_quad = static_cast<uint64_t>(stage) * (R * OD / 4);
+              const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_quad >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed2 >> 32);
+              const uint32_t lo = static_cast<uint32_t>(stage_quad) | static_cast<uint32_t>((lr * OD + 64 * hb + 4 * c) >> 2);
+              const uint32_t h = hash_mix_s((lo ^ static_cast<uint32_t>(seed2)) * 0x9E3779B1U + hi_term), t8 = thr2 & 0xffu;
+              kp = make_float4((h & 0xffu) >= t8 ? keep2 : 0.f, ((h >> 8) & 0xffu) >= t8 ? keep2 : 0.f,
+                               ((h >> 16) & 0xffu) >= t8 ? keep2 : 0.f, (h >> 24) >= t8 ? keep2 : 0.f);
+            } else {
+              const uint64_t stage_pair = static_cast<uint64_t>(stage) * (R * OD / 2);
+              const uint32_t hi_term = __umul24(static_cast<uint32_t>(stage_pair >> 32), 0x5EBCA7U) + static_cast<uint32_t>(seed2 >> 32);
+              const uint32_t lo = static_cast<uint32_t>(stage_pair) | static_cast<uint32_t>((lr * OD + 64 * hb + 4 * c) >> 1);
+              const uint32_t h0 = hash_mix_s((lo ^ static_cast<uint32_t>(seed2)) * 0x9E3779B1U + hi_term);
+              const uint32_t h1 = hash_mix_s(((lo + 1u) ^ static_cast<uint32_t>(seed2)) * 0x9E3779B1U + hi_term);
+              kp = make_float4((h0 & 0xffffu) >= thr2 ? keep2 : 0.f, (h0 >> 16) >= thr2 ? keep2 : 0.f,
+                               (h1 & 0xffffu) >= thr2 ? keep2 : 0.f, (h1 >> 16) >= thr2 ? keep2 : 0.f);
+            }
+            g.x *= kp.x; g.y *= kp.y; g.z *= kp.z; g.w *= kp.w;
+          }
+          if (relu_post) {                          // relu mask from the recomputed LayerNorm output (the forward's own expression)
+            if (!(fmaf(xh[hb].x, g4.x, b4.x) > 0.f)) g.x = 0.f;
+            if (!(fmaf(xh[hb].y, g4.y, b4.y) > 0.f)) g.y = 0.f;
+            if (!(fmaf(xh[hb].z, g4.z, b4.z) > 0.f)) g.z = 0.f;
+            if (!(fmaf(xh[hb].w, g4.w, b4.w) > 0.f)) g.w = 0.f;
+          }
+          if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);          // (a dead row re-read the last row: it contributes nothing)
+          dg[hb].x = fmaf(g.x, xh[hb].x, dg[hb].x); dg[hb].y = fmaf(g.y, xh[hb].y, dg[hb].y);
+          dg[hb].z = fmaf(g.z, xh[hb].z, dg[hb].z); dg[hb].w = fmaf(g.w, xh[hb].w, dg[hb].w);
+          db[hb].x += g.x; db[hb].y += g.y; db[hb].z += g.z; db[hb].w += g.w;
+          gh1[hb] = make_float4(g.x * g4.x, g.y * g4.y, g.z * g4.z, g.w * g4.w);
+          a1 += (gh1[hb].x + gh1[hb].y) + (gh1[hb].z + gh1[hb].w);
+          a2 = fmaf(gh1[hb].x, xh[hb].x, fmaf(gh1[hb].y, xh[hb].y, fmaf(gh1[hb].z, xh[hb].z, fmaf(gh1[hb].w, xh[hb].w, a2))));
+        }
+        const float s1 = row16_sum_s(a1) * (1.f / 128.f), s2r = row16_sum_s(a2) * (1.f / 128.f);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const float4 o = make_float4(rstd * (gh1[hb].x - s1 - xh[hb].x * s2r), rstd * (gh1[hb].y - s1 - xh[hb].y * s2r),
+                                       rstd * (gh1[hb].z - s1 - xh[hb].z * s2r), rstd * (gh1[hb].w - s1 - xh[hb].w * s2r));
+          if (valid)
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(gs_out + stage * R * ldgs) + hb * 256 +
+                                       (static_cast<uint32_t>(lr) * static_cast<uint32_t>(ldgs) * 4u + 16u * c)) = o;
+          ag[hb] = o;                               // this Linear's gy (under the relu mask of z, below)
+        }
+      }
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         v[hb] = ag[hb];
@@ -318,6 +402,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
       request_gy(k + 2, ag, am);                  // into the set just consumed: two stages ahead
+      request_s2(k + 2, sg, st2);
       __builtin_amdgcn_sched_barrier(0);
     };
     // ---- S2a(k): what needs only x: xhat, the keep factors, the relu signs -- kept in registers for S2b(k)
@@ -509,10 +594,12 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     };
 
     request_gy(0, agS[0], amS[0]);
+    request_s2(0, sgS[0], s2S[0]);
     request_x(0, xrS[0], stS[0]);
     request_gy(1, agS[1], amS[1]);
+    request_s2(1, sgS[1], s2S[1]);
     request_x(1, xrS[1], stS[1]);
-    S0(0, agS[0], amS[0]);
+    S0(0, agS[0], amS[0], sgS[0], s2S[0]);
     eCur = eNext;
     ALLSET_S_TICK();
     // Two stages per trip: stage k lives in register set 0, stage k + 1 in set 1; no conditional half inside the trip (fused_bwd4.hip:
@@ -520,7 +607,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
     int64_t k = 0;
     ALLSET_SMARK(3);
     for (; k + 1 < T; k += 2) {
-      S0(k + 1, agS[1], amS[1]);
+      S0(k + 1, agS[1], amS[1], sgS[1], s2S[1]);
       S2a(k, xrS[0], stS[0]);
       ALLSET_SMARK(0);
       ALLSET_S_TICK();
@@ -529,7 +616,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
       ALLSET_SMARK(2);
       ALLSET_S_TICK();
       ALLSET_SMARK(3);
-      if (k + 2 < T) S0(k + 2, agS[0], amS[0]);
+      if (k + 2 < T) S0(k + 2, agS[0], amS[0], sgS[0], s2S[0]);
       S2a(k + 1, xrS[1], stS[1]);
       ALLSET_SMARK(0);
       ALLSET_S_TICK();
@@ -772,7 +859,7 @@ __global__ __launch_bounds__(kSBlock) void fused_linear_bwd_f16x3_kernel(
 #pragma unroll
     for (int v = 0; v < kSVWaves; ++v) s += sGU[v * kSCols * ID + tid];
     const int64_t slice = blockIdx.x;
-    if (tid < 2 * ID) { if constexpr (HAS_LN) part_ln[slice * pstride_ln + tid] = s; }
+    if (tid < 2 * ID) { if constexpr (HAS_LN || PT2) part_ln[slice * pstride_ln + tid] = s; }
     else if (tid < 3 * ID) { if (part_b != nullptr) part_b[slice * pstride_b + (tid - 2 * ID)] = s; }
     else if (part_c != nullptr) part_c[slice * pstride_c + (tid - 3 * ID)] = s;
   }
@@ -860,6 +947,60 @@ extern "C" int allset_fused_linear_bwd_pma_tail(const float* gy, int64_t ldg, co
       gy, ldg, nullptr, 0.f, W, pooled, ldx, stats, gamma, beta, 0.f, 0, gx, ldgx, part + O * I + O, part, part + O * I, n, nullptr, part_stride,
       part_stride, part_stride, 0, 0, 0, nullptr, 0, 1.f / 128.f, colb, gres, ldgres, part + O * I + O + 2 * I, part_stride, pma_m, pma_l,
       pma_stats, static_cast<int>(heads));
+  ALLSET_LAUNCH_CHECK();
+#endif
+  return ALLSET_OK;
+}
+
+// ---- the PMA tail's second rFF Linear, backward, with ln1's backward as its gy prologue (PT2) ----------------------------------------
+// gs = d s through y = dropout_p(relu_post?(LayerNorm_{gamma2,beta2}(s)))  (s, stats2 saved by allset_fused_linear_fwd_res_ln; written to gs_out);
+// gx = (gs under the 1-bit mask of z > 0) W through relu_in?(x);  gW, gb as allset_fused_linear_bwd_all;
+// part: [slices][stride] = gW [128*128] | gb [128] | dgamma2 [128] | dbeta2 [128]
+extern "C" int allset_fused_linear_bwd_ln_pro_supported(int64_t O, int64_t I) {
+#ifdef ALLSET_NO_F16X3
+  (void)O; (void)I;
+  return 0;
+#else
+  return (O == 128 && I == 128) ? 1 : 0;
+#endif
+}
+
+extern "C" int allset_fused_linear_bwd_ln_pro(const float* gy, int64_t ldg, const float* s, int64_t lds, const float* stats2,
+                                              const float* gamma2, const float* beta2, int relu_post, float p, uint64_t seed,
+                                              const uint64_t* seed_base, const uint32_t* mask, const float* W, const float* x, int64_t ldx,
+                                              int relu_in, float* gs_out, int64_t ldgs, float* gx, int64_t ldgx, float* part,
+                                              int64_t part_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0, "fused_linear_bwd_ln_pro: negative size");
+  ALLSET_REQUIRE(p >= 0.f && p < 1.f, "fused_linear_bwd_ln_pro: dropout p must be in [0,1)");
+  if (!allset_fused_linear_bwd_ln_pro_supported(O, I)) {
+    set_error("fused_linear_bwd_ln_pro: out=%lld in=%lld is not built (128 x 128; allset_fused_linear_bwd_ln_pro_supported)",
+              static_cast<long long>(O), static_cast<long long>(I));
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(part != nullptr && part_stride >= O * I + 3 * O, "fused_linear_bwd_ln_pro: part_stride smaller than O*I + 3*O");
+  const unsigned grid = fused_linear_bwd_roles_grid(n);
+  ALLSET_REQUIRE(n_slices == static_cast<int64_t>(grid), "fused_linear_bwd_ln_pro: part must hold allset_fused_linear_bwd_all_slices_for() slices");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    ALLSET_HIP_CHECK(hipMemsetAsync(part, 0, static_cast<size_t>(n_slices) * part_stride * sizeof(float), st));
+    return ALLSET_OK;
+  }
+  ALLSET_REQUIRE(gy && s && stats2 && gamma2 && beta2 && mask && W && x && gs_out && gx, "fused_linear_bwd_ln_pro: null pointer");
+  ALLSET_REQUIRE(aligned16(gy) && aligned16(s) && aligned16(W) && aligned16(x) && aligned16(gs_out) && aligned16(gx) && aligned16(gamma2) && aligned16(beta2),
+                 "fused_linear_bwd_ln_pro: gy / s / W / x / gs_out / gx / gamma2 / beta2 must be 16-byte aligned");
+  ALLSET_REQUIRE(ldg >= O && ldg % 4 == 0 && lds >= O && lds % 4 == 0 && ldgs >= O && ldgs % 4 == 0 && ldx >= I && ldx % 4 == 0 && ldgx >= I &&
+                 ldgx % 4 == 0 && ldg < (1 << 24) && lds < (1 << 24) && ldgs < (1 << 24) && ldx < (1 << 24) && ldgx < (1 << 24),
+                 "fused_linear_bwd_ln_pro: rows must be 16-byte aligned, leading dimensions below 2^24");
+  ALLSET_REQUIRE((reinterpret_cast<uintptr_t>(stats2) & 7u) == 0, "fused_linear_bwd_ln_pro: stats2 must be 8-byte aligned");
+#ifndef ALLSET_NO_F16X3
+#define ALLSET_S_PT2(RI)                                                                                                              \
+  fused_linear_bwd_f16x3_kernel<false, false, RI, true, false, false, true><<<grid, kSBlock, 0, st>>>(                                 \
+      gy, ldg, mask, 0.f, W, x, ldx, nullptr, nullptr, nullptr, 0.f, 0, gx, ldgx, part + O * I + O, part, part + O * I, n, seed_base,     \
+      part_stride, part_stride, part_stride, 0, 0, 0, nullptr, 0, 1.f / 128.f, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 1, \
+      s, lds, stats2, gamma2, beta2, relu_post, p, seed, gs_out, ldgs)
+  if (relu_in) ALLSET_S_PT2(true); else ALLSET_S_PT2(false);
+#undef ALLSET_S_PT2
   ALLSET_LAUNCH_CHECK();
 #endif
   return ALLSET_OK;

@@ -1484,14 +1484,50 @@ def fused_linear_bwd_pma_tail(gy: Tensor, weight: Tensor, pooled: Tensor, colb: 
             red[o:o + O] if want_bias else None, pstats)
 
 
+def fused_linear_bwd_ln_pro_supported() -> bool:
+    return _arith != _lib.ARITH_BF16X6 and bool(_lib.load().allset_fused_linear_bwd_ln_pro_supported(128, 128))
+
+
+def fused_linear_bwd_ln_pro(gy: Tensor, s: Tensor, stats2: Tensor, gamma2: Tensor, beta2: Tensor, relu_post: bool, p: float, seed: int,
+                            seed_base: Optional[Tensor], mask: Tensor, weight: Tensor, x: Tensor, relu_in: bool, want_bias: bool = True):
+    """``(gs, dgamma2, dbeta2, gx, gW, gb)``: ln1's backward (on the saved sum ``s``) as the gy prologue of the second rFF Linear's
+    one-pass backward (include/allset_hip_ext.h allset_fused_linear_bwd_ln_pro; until round 6: ln_res_bwd + fused_linear_bwd_all)."""
+    dev = require_device(gy, s, stats2, gamma2, beta2, mask, weight, x)
+    _check_f32(gy, s, stats2, gamma2, beta2, weight, x)
+    gy, s, x = _rowmajor(gy), _rowmajor(s), _rowmajor(x)
+    n, O = gy.shape
+    I = x.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_fused_linear_bwd_all_slices_for(n, O, I, 0, byref(ns)), "allset_fused_linear_bwd_all_slices_for")
+    P = ns.value
+    M = (O * I + 3 * O + 3) // 4 * 4
+    part = torch.empty((P, M), dtype=torch.float32, device=dev)
+    gs = torch.empty((n, O), dtype=torch.float32, device=dev)
+    gx = torch.empty((n, I), dtype=torch.float32, device=dev)
+    with on_device(dev), _timed("fused_linear_bwd_all", dev, n * (3 * O + 2 * I) * 4):
+        check(lib.allset_fused_linear_bwd_ln_pro(
+            ptr(gy), _ld(gy), ptr(s), _ld(s), ptr(stats2), ptr(gamma2.contiguous()), ptr(beta2.contiguous()), int(relu_post), float(p), int(seed),
+            ptr(seed_base), ptr(mask), ptr(weight.contiguous()), ptr(x), _ld(x), int(relu_in), ptr(gs), max(O, 1), ptr(gx), max(I, 1), ptr(part), M, P,
+            n, O, I, stream_of(dev)), "allset_fused_linear_bwd_ln_pro")
+    red = reduce_partials(part)
+    o = O * I
+    return gs, red[o + O:o + 2 * O], red[o + 2 * O:o + 3 * O], gx, red[:o].view(O, I), (red[o:o + O] if want_bias else None)
+
+
 def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional[Tensor] = None):
     """``(g_pooled, dcolb, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pma_stats or None)``: ln1's backward on the saved sum, the two
     Linears' one-pass backward (the residual branch summed through ``acc_in``), ln0's backward -- with the pooling's backward
     statistics written by the same pass when the softmax statistics ``(m, l)`` are given."""
     pooled, cb, stats0, g0, b0, out, y1, mask, s, stats1, w1, w2, g1, bt1 = saved
     relu_post, p, seed, base, has_b1, has_b2 = cfg
-    gs, dg1, db1, _ = ln_res_bwd(gy.contiguous(), s, None, None, stats1, g1, bt1, relu_post, p, seed, base)
-    gh, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
+    if fused_linear_bwd_ln_pro_supported():
+        # ln1's backward inside the second Linear's one-pass backward (csrc/fused_bwd6.hip PT2): one pass instead of two
+        gs, dg1, db1, gh, gw2, gb2 = fused_linear_bwd_ln_pro(gy.contiguous(), s, stats1, g1, bt1, relu_post, p, seed, base, mask, w2, y1, True,
+                                                             want_bias=has_b2)
+    else:
+        gs, dg1, db1, _ = ln_res_bwd(gy.contiguous(), s, None, None, stats1, g1, bt1, relu_post, p, seed, base)
+        gh, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
     if m is None and fused_linear_bwd_pma_tail_supported(1):
         # the tail on its own (no pooling behind it): the same pass with one dummy head, its statistics discarded
         m1 = torch.zeros((pooled.shape[0], 1), dtype=torch.float32, device=pooled.device)

@@ -636,6 +636,32 @@ def test_pma_tail_two_kernel_forward_against_float64(n, relu_post, p, device, mo
         torch.testing.assert_close(y, y2, rtol=1e-4, atol=2e-5 * max(1.0, float(y2.abs().max())))
 
 
+@pytest.mark.parametrize("relu_post,p", [(False, 0.0), (True, 0.0), (True, 0.5), (True, 0.3), (False, 0.25)])
+@pytest.mark.parametrize("n", [1, 33, 4099, 70001])
+def test_pma_tail_second_linear_backward_with_ln1_backward_inside(n, relu_post, p, device):
+    """``dense.fused_linear_bwd_ln_pro`` (csrc/fused_bwd6.hip PT2): ln1's backward -- the conv's dropout from the counter hash (8- and
+    16-bit resolution), the relu mask from the recomputed LayerNorm output, the row sums -- as the gy prologue of the second rFF
+    Linear's one-pass backward, against the two passes it replaces (ln_res_bwd + fused_linear_bwd_all) on the forward's own saved
+    tensors.  (The pair itself is pinned to float64 by test_pma_tail_two_kernel_forward_against_float64, which now runs through
+    this kernel as well.)"""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(17 * n + int(relu_post) + int(p * 100))
+    mk = lambda *s, sc=1.0, off=0.0: (torch.randn(*s, generator=g) * sc + off).to(device)
+    y1, out = mk(n, 128), mk(n, 128)
+    w2, b2 = mk(128, 128, sc=128 ** -0.5), mk(128, sc=0.1)
+    g1, bt1 = mk(128, sc=0.2, off=1.0), mk(128, sc=0.3)
+    G = mk(n, 128)
+    mask = torch.empty(dense.activation_mask_words(n, 128), dtype=torch.int32, device=device)
+    seed = 4711
+    y, s, stats1 = dense.fused_linear_fwd_res_ln(y1, True, w2, b2, True, out, g1, bt1, 1e-5, relu_post, p, seed, None, mask)
+    gs, dg1, db1, gh, gw2, gb2 = dense.fused_linear_bwd_ln_pro(G, s, stats1, g1, bt1, relu_post, p, seed, None, mask, w2, y1, True)
+    gs_r, dg_r, db_r, _ = dense.ln_res_bwd(G, s, None, None, stats1, g1, bt1, relu_post, p, seed, None)
+    gh_r, _, _, gw_r, gb_r = dense.fused_linear_bwd_all(gs_r, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0)
+    sc = lambda t: max(1.0, float(t.abs().max()))
+    for a, b_, what in ((gs, gs_r, "gs"), (dg1, dg_r, "dgamma1"), (db1, db_r, "dbeta1"), (gh, gh_r, "gx"), (gw2, gw_r, "gW"), (gb2, gb_r, "gb")):
+        torch.testing.assert_close(a, b_, rtol=2e-5, atol=2e-5 * sc(b_), msg=lambda mm: f"{what}: {mm}")
+
+
 @pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
 @pytest.mark.parametrize("n", [1, 33, 4099, 70001])
 def test_pma_tail_first_linear_backward_in_one_pass(n, H, device):
