@@ -15,7 +15,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 CORE_ABI_VERSION = 1
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
@@ -185,6 +185,13 @@ SIGNATURES = {
     "allset_linear_bf16_fwd": [_P, c_int64, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P],
     "allset_linear_bf16_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64,
                                c_int64, _P],
+    "allset_linear_bf16_mask_pitch": [c_int64],
+    "allset_linear_bf16_fwd_mask": [_P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, _P],
+    "allset_linear_bf16_bwd_bits": [_P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_wgrad_bf16_ex2_supported": [c_int64, c_int64, c_int, c_int],
+    "allset_wgrad_bf16_ex2": [_P, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int64, c_int64, c_int64, c_int64, _P],
+    "allset_pma_fold_fwd_bf16": [_P, _P, _P, _P, _P, c_int64, c_int64, c_int64, _P],
+    "allset_pma_fold_bwd_bf16": [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, _P],
     "allset_ln_res_bwd_pma_bf16_supported": [c_int64, c_int64],
     "allset_ln_res_bwd_pma_bf16": [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P,
                                    c_int64, _P],
@@ -223,6 +230,7 @@ def load() -> ctypes.CDLL:
     lib.allset_gemm_f16x3_plane_bytes.restype = c_int64
     lib.allset_gemm_x6_lnb_partials.restype = c_int64
     lib.allset_input_linear_k.restype = c_int64
+    lib.allset_linear_bf16_mask_pitch.restype = c_int64
     lib.allset_last_error.argtypes = []
     lib.allset_last_error.restype = c_char_p
     got = lib.allset_version()

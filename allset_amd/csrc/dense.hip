@@ -1060,30 +1060,51 @@ __device__ __forceinline__ int wtr_off(int row, int cbyte) {
   return row * PITCH + ((((cbyte >> 5) ^ sw)) << 5) + (cbyte & 31);
 }
 
-template <int OTN, int ITN>       // O = 64 OTN, I = 32 ITN; wave tile (16 OTN) x (16 ITN)
+// Round 6 -- MASKED: `ga` is the gradient BEFORE the relu mask and `bits` the forward's bit mask of that relu (fused_bf16.hip:
+// bit 16 hb + j of word sq of a row is column 64 hb + 16 sq + j, N / 8 bytes per row); the mask is applied as the stage is copied
+// into LDS, so the masked gradient never exists in memory.  AUX: four more rows of the gradient -- gWa[h][i] = sum_r g4[r][h] u[r][i],
+// the weight gradient of PMA's folded logits (g4: fp32 [n, 4], rounded to bf16 here as the separate launch did) -- ride as a fifth,
+// 16-column A tile (12 columns zero) on the two waves of the first O block; the partial row becomes [gW | gb | gWa (4 x I) | gba (4)].
+template <int OTN, int ITN, bool MASKED, bool AUX>       // O = 64 OTN, I = 32 ITN; wave tile (16 OTN) x (16 ITN)
 __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
-    const uint16_t* __restrict__ ga, int64_t lda, const uint16_t* __restrict__ u, int64_t ldu,
-    float* __restrict__ part_w, float* __restrict__ part_b, int64_t n, int64_t rows_per_slice, int64_t pw_stride,
-    int64_t pb_stride) {
+    const uint16_t* __restrict__ ga, int64_t lda, const uint8_t* __restrict__ bits, const float* __restrict__ g4,
+    const uint16_t* __restrict__ u, int64_t ldu, float* __restrict__ part_w, float* __restrict__ part_b,
+    float* __restrict__ part_x, int64_t n, int64_t rows_per_slice, int64_t pw_stride, int64_t pb_stride) {
   constexpr int O = 64 * OTN, I = 32 * ITN;
   constexpr int PA = O * 2, PB = I * 2;                            // row pitches (bytes)
   constexpr int SA = 32 * PA, SB = 32 * PB;                        // bytes per stage and operand
+  constexpr int SX = AUX ? 32 * 32 : 0;                            // the auxiliary tile: 32 rows x 16 bf16
   constexpr int NPA = (32 * PA / 16 + kWx6Block - 1) / kWx6Block;  // 16-byte pieces per thread and stage
   constexpr int NPB = (32 * PB / 16 + kWx6Block - 1) / kWx6Block;
-  __shared__ __attribute__((aligned(16))) uint8_t sS[2 * (SA + SB)];
+  __shared__ __attribute__((aligned(16))) uint8_t sS[2 * (SA + SB + SX)];
   const int slice = blockIdx.x;
   const int64_t r_begin = static_cast<int64_t>(slice) * rows_per_slice;
   const int64_t r_end = min(n, r_begin + rows_per_slice);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if constexpr (AUX) {                                             // columns 4 .. 15 of the auxiliary tile stay zero
+    for (int idx = tid; idx < 2 * SX / 4; idx += kWx6Block) {
+      const int buf = idx / (SX / 4), w = idx % (SX / 4);
+      reinterpret_cast<uint32_t*>(sS + buf * (SA + SB + SX) + SA + SB)[w] = 0u;
+    }
+  }
 
-  struct Stage { uint4 a[NPA], b[NPB]; };
+  struct Stage { uint4 a[NPA], b[NPB]; uint32_t am[MASKED ? NPA : 1]; float4 x; };
   auto load_stage = [&](Stage& sg, int64_t r0) {                 // unconditional loads on clamped rows; zeroed when stored
 #pragma unroll
     for (int k = 0; k < NPA; ++k) {
       const int p = tid + k * kWx6Block, row = p / (PA / 16), c16 = p % (PA / 16);
       int64_t r = r0 + row;
       r = r < r_end ? r : r_end - 1;
-      if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16) sg.a[k] = *reinterpret_cast<const uint4*>(ga + r * lda + c16 * 8);
+      if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16) {
+        sg.a[k] = *reinterpret_cast<const uint4*>(ga + r * lda + c16 * 8);
+        if constexpr (MASKED)      // the piece's 8 columns 8 c16 ..: one byte of word sq = (c16 % 8) / 2, at bits 16 (c16 / 8) + 8 (c16 & 1)
+          sg.am[k] = bits[r * (O / 8) + ((c16 & 7) >> 1) * (O / 32) + (c16 >> 3) * 2 + (c16 & 1)];
+      }
+    }
+    if constexpr (AUX) {
+      int64_t r = r0 + (tid & 31);
+      r = r < r_end ? r : r_end - 1;
+      if (tid < 32) sg.x = *reinterpret_cast<const float4*>(g4 + r * 4);
     }
 #pragma unroll
     for (int k = 0; k < NPB; ++k) {
@@ -1094,13 +1115,29 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
     }
   };
   auto store_stage = [&](const Stage& sg, int64_t r0, int buf) {
-    uint8_t* ba = sS + buf * (SA + SB);
+    uint8_t* ba = sS + buf * (SA + SB + SX);
     uint8_t* bb = ba + SA;
 #pragma unroll
     for (int k = 0; k < NPA; ++k) {
       const int p = tid + k * kWx6Block, row = p / (PA / 16), c16 = p % (PA / 16);
-      if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16)
-        *reinterpret_cast<uint4*>(ba + wtr_off<PA>(row, c16 * 16)) = (r0 + row < r_end) ? sg.a[k] : make_uint4(0u, 0u, 0u, 0u);
+      if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16) {
+        uint4 v = sg.a[k];
+        if constexpr (MASKED) {
+          const int f = static_cast<int>(sg.am[k]);
+          auto keep = [&](int i) {
+            return (static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i, 1)) & 0x0000ffffu) |
+                   (static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i + 1, 1)) & 0xffff0000u);
+          };
+          v.x &= keep(0); v.y &= keep(1); v.z &= keep(2); v.w &= keep(3);
+        }
+        *reinterpret_cast<uint4*>(ba + wtr_off<PA>(row, c16 * 16)) = (r0 + row < r_end) ? v : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if constexpr (AUX) {
+      if (tid < 32) {
+        const bool ok = r0 + tid < r_end;
+        *reinterpret_cast<uint2*>(bb + SB + tid * 32) = ok ? make_uint2(cvt_pk_bf16(sg.x.x, sg.x.y), cvt_pk_bf16(sg.x.z, sg.x.w)) : make_uint2(0u, 0u);
+      }
     }
 #pragma unroll
     for (int k = 0; k < NPB; ++k) {
@@ -1125,6 +1162,15 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
 #pragma unroll
   for (int ot = 0; ot < OTN; ++ot) gbs[ot] = 0.f;
   const wv2bf_t ones = __builtin_bit_cast(wv2bf_t, 0x3f803f80u);
+  // the auxiliary tile's ITN column tiles of this wave's I half are shared out over the four waves of that half (wave >> 1):
+  // ITN / 4 accumulator tiles each, so that no wave carries 32 more registers
+  static_assert(!AUX || ITN % 4 == 0, "auxiliary rows: ITN must be a multiple of 4");
+  constexpr int XT = AUX ? ITN / 4 : 1;
+  const int wo = __builtin_amdgcn_readfirstlane(wave >> 1);        // wave-uniform
+  f32x4_t accx[XT];
+#pragma unroll
+  for (int it = 0; it < XT; ++it) accx[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float gbx = 0.f;
 
   auto tr_frag = [&](const uint8_t* p, int half) {
     WTrFrag f;
@@ -1133,13 +1179,26 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
     return f;
   };
   auto mfma_stage = [&](int buf) {
-    const uint8_t* ba = sS + buf * (SA + SB);
+    const uint8_t* ba = sS + buf * (SA + SB + SX);
     const uint8_t* bb = ba + SA;
     WTrFrag a[OTN];
 #pragma unroll
     for (int ot = 0; ot < OTN; ++ot) {
       const int chunk = (ob + ot * 16) / 16;
       a[ot] = tr_frag(ba + rowoff_a + (((chunk ^ sw) & (PA / 32 - 1)) << 5), 4 * PA);
+    }
+    WTrFrag ax;
+    ax.u = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (AUX) {
+      {
+        ax = tr_frag(bb + SB + (8 * fg + (fi >> 2)) * 32 + 8 * (fi & 3), 4 * 32);
+        if (wave == 0) {
+          gbx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, ax.u.x), ones, gbx, false);
+          gbx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, ax.u.y), ones, gbx, false);
+          gbx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, ax.u.z), ones, gbx, false);
+          gbx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wv2bf_t, ax.u.w), ones, gbx, false);
+        }
+      }
     }
     if ((wave & 1) == 0 && part_b != nullptr) {
 #pragma unroll
@@ -1156,6 +1215,9 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
       const WTrFrag b = tr_frag(bb + rowoff_b + (((chunk ^ sw) & (PB / 32 - 1)) << 5), 4 * PB);
 #pragma unroll
       for (int ot = 0; ot < OTN; ++ot) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ot].v, b.v, acc[ot][it], 0, 0, 0);
+      if constexpr (AUX) {
+        if (wo == it / XT) accx[it % XT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax.v, b.v, accx[it % XT], 0, 0, 0);
+      }
     }
   };
 
@@ -1195,6 +1257,23 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
       if (lane < 16) part_b[static_cast<int64_t>(slice) * pb_stride + ob + ot * 16 + fi] = v;
+    }
+  }
+  if constexpr (AUX) {
+    {                                          // accx[t][r] is (h = 4 fg + r, i = ib + 16 (wo XT + t) + fi): rows 0 .. 3 are real
+      float* px = part_x + static_cast<int64_t>(slice) * pb_stride;
+      if (fg == 0) {
+#pragma unroll
+        for (int t = 0; t < XT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) px[r * I + ib + (wo * XT + t) * 16 + fi] = accx[t][r];
+      }
+      if (wave == 0) {
+        float v = gbx;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 4) px[4 * I + lane] = v;
+      }
     }
   }
 }
@@ -2019,13 +2098,41 @@ extern "C" int allset_wgrad_bf16_slices(int64_t n, int64_t O, int64_t I, int64_t
   return ALLSET_OK;
 }
 
-static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
-                           int64_t pw_stride, int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* bits, const float* g4, const void* u, int64_t ldu, float* part_w,
+                           float* part_b, float* part_x, int64_t pw_stride, int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O,
+                           int64_t I, void* stream);
 
 extern "C" int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
                                  int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
   clear_error();
-  return wgrad_bf16_impl(ga, lda, u, ldu, part_w, part_b, O * I, O, n_slices, n, O, I, stream);
+  return wgrad_bf16_impl(ga, lda, nullptr, nullptr, u, ldu, part_w, part_b, nullptr, O * I, O, n_slices, n, O, I, stream);
+}
+
+// 1 when allset_wgrad_bf16_ex2 takes `bits` / `g4` at these widths (the full-width kernel; g4 needs O = I = 256 or 128-wide O)
+extern "C" int allset_wgrad_bf16_ex2_supported(int64_t O, int64_t I, int has_bits, int has_aux) {
+  if (!((O == 128 || O == 256) && (I == 128 || I == 256))) return 0;
+  (void)has_bits;
+  return (!has_aux || (O == 256 && I == 256)) ? 1 : 0;
+}
+
+// allset_wgrad_bf16_ex with the relu BIT mask of `ga` applied on the way (bits: allset_linear_bf16_fwd_mask's output; may be
+// NULL) and, with g4 (fp32 [n, 4], may be NULL), the weight gradient of four auxiliary output columns in the same pass: the
+// partial row is [gW (O x I) | gb (O, if want_bias) | gWa (4 x I) | gba (4)] -- the last two only with g4.
+extern "C" int allset_wgrad_bf16_ex2(const void* ga, int64_t lda, const void* bits, const float* g4, const void* u, int64_t ldu,
+                                     float* part, int64_t part_stride, int want_bias, int64_t n_slices, int64_t n, int64_t O,
+                                     int64_t I, void* stream) {
+  clear_error();
+  const int64_t need = O * I + (want_bias ? O : 0) + (g4 ? 4 * I + 4 : 0);
+  ALLSET_REQUIRE(part != nullptr && part_stride >= need && part_stride % 4 == 0 && aligned16(part),
+                 "wgrad_bf16_ex2: part must be 16-byte aligned rows of at least O*I (+O) (+4I+4) floats, stride a multiple of 4");
+  if (!allset_wgrad_bf16_ex2_supported(O, I, bits != nullptr, g4 != nullptr) || lda % 8 != 0 || ldu % 8 != 0 || !aligned16(ga) || !aligned16(u)) {
+    set_error("wgrad_bf16_ex2: O, I in {128, 256} (g4: 256 x 256), 16-byte aligned rows with leading dimensions that are multiples of 8");
+    return ALLSET_ERR_UNSUPPORTED;
+  }
+  ALLSET_REQUIRE(g4 == nullptr || aligned16(g4), "wgrad_bf16_ex2: g4 must be 16-byte aligned");
+  float* pb = want_bias ? part + O * I : nullptr;
+  float* px = g4 ? part + O * I + (want_bias ? O : 0) : nullptr;
+  return wgrad_bf16_impl(ga, lda, bits, g4, u, ldu, part, pb, px, part_stride, part_stride, n_slices, n, O, I, stream);
 }
 
 extern "C" int allset_wgrad_bf16_ex(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part, int64_t part_stride,
@@ -2033,11 +2140,12 @@ extern "C" int allset_wgrad_bf16_ex(const void* ga, int64_t lda, const void* u, 
   clear_error();
   ALLSET_REQUIRE(part != nullptr && part_stride >= O * I + (want_bias ? O : 0) && part_stride % 4 == 0 && aligned16(part),
                  "wgrad_bf16_ex: part must be 16-byte aligned rows of at least O*I (+O) floats, stride a multiple of 4");
-  return wgrad_bf16_impl(ga, lda, u, ldu, part, want_bias ? part + O * I : nullptr, part_stride, part_stride, n_slices, n, O, I, stream);
+  return wgrad_bf16_impl(ga, lda, nullptr, nullptr, u, ldu, part, want_bias ? part + O * I : nullptr, nullptr, part_stride, part_stride, n_slices, n, O, I, stream);
 }
 
-static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part_w, float* part_b,
-                           int64_t pw_stride, int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream) {
+static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* bits, const float* g4, const void* u, int64_t ldu, float* part_w,
+                           float* part_b, float* part_x, int64_t pw_stride, int64_t pb_stride, int64_t n_slices, int64_t n, int64_t O,
+                           int64_t I, void* stream) {
   ALLSET_REQUIRE(n >= 0 && O >= 1 && I >= 1 && O < INT32_MAX && I < INT32_MAX, "wgrad_bf16: bad size");
   ALLSET_REQUIRE(n_slices >= 1 && n_slices < 65536, "wgrad_bf16: bad slice count");
   ALLSET_REQUIRE(part_w != nullptr, "wgrad_bf16: null partial buffer");
@@ -2056,9 +2164,19 @@ static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t l
     const unsigned grid1 = static_cast<unsigned>(n_slices);
     const uint16_t* a16 = static_cast<const uint16_t*>(ga);
     const uint16_t* u16 = static_cast<const uint16_t*>(u);
-#define ALLSET_WGTR(OTN, ITN) wgrad_bf16_tr_kernel<OTN, ITN><<<grid1, kWx6Block, 0, st>>>(a16, lda, u16, ldu, part_w, part_b, n, rps, pw_stride, pb_stride)
+    const uint8_t* b8 = static_cast<const uint8_t*>(bits);
+#define ALLSET_WGTR_X(OTN, ITN, MK, AX) wgrad_bf16_tr_kernel<OTN, ITN, MK, AX><<<grid1, kWx6Block, 0, st>>>(a16, lda, b8, g4, u16, ldu, part_w, part_b, part_x, n, rps, pw_stride, pb_stride)
+#define ALLSET_WGTR(OTN, ITN) ALLSET_WGTR_X(OTN, ITN, false, false)
     const int otn = static_cast<int>(O / 64), itn = static_cast<int>(I / 32);
-    if (otn == 4 && itn == 8) ALLSET_WGTR(4, 8);
+    if (b8 != nullptr || g4 != nullptr) {
+      ALLSET_REQUIRE((otn == 4 || otn == 2) && (itn == 8 || itn == 4) && (g4 == nullptr || (otn == 4 && itn == 8)), "wgrad_bf16: bits / g4 at unsupported widths");
+      if (g4 != nullptr) { if (b8) ALLSET_WGTR_X(4, 8, true, true); else ALLSET_WGTR_X(4, 8, false, true); }
+      else if (otn == 4 && itn == 8) ALLSET_WGTR_X(4, 8, true, false);
+      else if (otn == 4 && itn == 4) ALLSET_WGTR_X(4, 4, true, false);
+      else if (otn == 2 && itn == 8) ALLSET_WGTR_X(2, 8, true, false);
+      else ALLSET_WGTR_X(2, 4, true, false);
+    }
+    else if (otn == 4 && itn == 8) ALLSET_WGTR(4, 8);
     else if (otn == 4 && itn == 4) ALLSET_WGTR(4, 4);
     else if (otn == 4 && itn == 2) ALLSET_WGTR(4, 2);
     else if (otn == 2 && itn == 8) ALLSET_WGTR(2, 8);
@@ -2068,9 +2186,11 @@ static int wgrad_bf16_impl(const void* ga, int64_t lda, const void* u, int64_t l
     else if (otn == 1 && itn == 4) ALLSET_WGTR(1, 4);
     else ALLSET_WGTR(1, 2);
 #undef ALLSET_WGTR
+#undef ALLSET_WGTR_X
     ALLSET_LAUNCH_CHECK();
     return ALLSET_OK;
   }
+  ALLSET_REQUIRE(bits == nullptr && g4 == nullptr, "wgrad_bf16: bits / g4 need the full-width kernel (16-byte aligned rows)");
   const int tiles_o = static_cast<int>((O + kWgTile - 1) / kWgTile), tiles_i = static_cast<int>((I + kWgTile - 1) / kWgTile);
   int64_t rows_per_slice = (n + n_slices - 1) / n_slices;
   rows_per_slice = (rows_per_slice + kWgRows - 1) / kWgRows * kWgRows;

@@ -5,6 +5,11 @@
 //                  aux[n, 4] = x aux_w^T + aux_b            PMA's folded attention logits (fp32 out), optional
 //   backward-data  gx = (gy (.) [ymask > 0]) W  [+ acc_in]  [+ galpha aux_w]                    all bf16 except galpha (fp32)
 //                  ga_out = gy (.) [ymask > 0]              the masked gradient, kept for the weight-gradient kernel
+//   round 6: the relu mask as ONE BIT per element -- the forward's epilogue writes it (`mask_out`, N / 8 bytes per row), the
+//   backward-data kernel and the weight-gradient kernel (dense.hip, wgrad_bf16_tr_kernel) both apply it to gy as they stage it:
+//   the 2-byte-per-element read of the saved activation and the write + re-read of the masked gradient are gone
+//   (640 -> 392 MB per masked backward at [250k, 256]).  Bit layout (private to these three kernels; allset_hip_ext.h):
+//   a row is four words of N / 32 bytes; bit (16 hb + j) of word sq is column 64 hb + 16 sq + j.
 //
 // The library GEMM these replace already runs near the traffic floor (62 us for [250k, 256] x [256, 256]); what a fused
 // kernel removes is the element-wise traffic AROUND it -- relu forward, relu backward, the gradient-branch sums, the skinny
@@ -51,16 +56,32 @@ __device__ __forceinline__ uint32_t keep_where_positive(uint32_t v, uint32_t y) 
   return v & (lo | hi);
 }
 
+typedef unsigned short bf_us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t nz_halves(uint32_t v) {         // per 16-bit half: 1 where the magnitude bits are set
+  const bf_us2_t one = {1, 1};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(bf_us2_t, v & 0x7fff7fffu), one));
+}
+// 16 relu outputs (+0 or positive bf16, two per dword, columns in order) -> their 16 "is positive" bits, column j at bit j
+__device__ __forceinline__ uint32_t relu_bits16(const uint4& o0, const uint4& o1) {
+  uint32_t x = nz_halves(o0.x);
+  x |= nz_halves(o0.y) << 2; x |= nz_halves(o0.z) << 4; x |= nz_halves(o0.w) << 6;
+  x |= nz_halves(o1.x) << 8; x |= nz_halves(o1.y) << 10; x |= nz_halves(o1.z) << 12; x |= nz_halves(o1.w) << 14;
+  return (x & 0xffffu) | ((x >> 16) << 1);          // low halves sit at even bits, high halves at 16 + even
+}
+
 // KD: reduction width (columns of the activation rows), ND: output width.
+// MASK: 0 none, 1 the saved bf16 activation (`ymask`), 2 the forward's bit mask (`ymask` points at the bit rows).
 // TRANS_W: W is [KD, ND] row-major (backward-data: the layer's [out, in] weight, reduced over its rows);
 //          otherwise [ND, KD] (forward).
-template <int KD, int ND, bool TRANS_W, bool HAS_MASK, bool AUX_OUT>
+template <int KD, int ND, bool TRANS_W, int MASK, bool AUX_OUT>
 __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ ymask, int64_t ldm,
     uint16_t* __restrict__ a_out, int64_t lda, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
     int relu_out, const uint16_t* __restrict__ aux_w, const uint16_t* __restrict__ aux_b, float* __restrict__ aux_out,
     const float* __restrict__ aux_in, const uint16_t* __restrict__ acc_in, int64_t ldacc, uint16_t* __restrict__ y,
-    int64_t ldy, int64_t n) {
+    int64_t ldy, uint8_t* __restrict__ mask_out, int64_t n) {
+  constexpr bool HAS_MASK = MASK == 1;             // (the bf16-activation form; MASK == 2 has its own staging below)
+  constexpr int MG = KD / 64;                      // 16-column groups per lane (bit-mask form)
   constexpr int KQ = KD / 4;                       // bf16 columns per lane
   constexpr int KQD = KQ / 2;                      // dwords per lane
   constexpr int T = KQ / 8;                        // MFMA k-steps
@@ -136,10 +157,44 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
     }
   };
 
-  auto process = [&](uint32_t (&a)[KQD], uint32_t (&m)[HAS_MASK ? KQD : 1], int64_t chunk) {
+  // bit-mask form: the lane's columns g KQ + 16 q .. + 15 are bits 16 hb .. of word sq of the row (hb = column / 64,
+  // sq = (column % 64) / 16): one 2-byte load per 16 columns, MG of them per step, one step ahead like the bf16 mask
+  constexpr int MN = MASK == 1 ? KQD : (MASK == 2 ? MG : 1);
+  uint32_t bit_off[MG];
+#pragma unroll
+  for (int q = 0; q < MG; ++q) {
+    const int col0 = g * KQ + 16 * q;
+    bit_off[q] = ((col0 & 63) >> 4) * (KD / 32) + (col0 >> 6) * 2;
+  }
+  const uint8_t* bitrows = reinterpret_cast<const uint8_t*>(ymask);
+  auto request_bits = [&](uint32_t (&m)[MN], int64_t chunk) {
+    const int64_t c = chunk < n_chunks ? chunk : n_chunks - 1;
+    const int rh = rows_here(c);
+    const uint32_t rr = ri < rh ? ri : rh - 1;
+    const uint8_t* base = bitrows + c * 16 * (KD / 8);
+#pragma unroll
+    for (int q = 0; q < MG; ++q) m[q] = *reinterpret_cast<const uint16_t*>(base + (rr * static_cast<uint32_t>(KD / 8) + bit_off[q]));
+  };
+
+  auto process = [&](uint32_t (&a)[KQD], uint32_t (&m)[MN], int64_t chunk) {
     const int rh = rows_here(chunk);
     const bool valid = ri < rh;
     const uint32_t rr = valid ? ri : rh - 1;                      // a row of this step that exists
+    if constexpr (MASK == 2) {
+#pragma unroll
+      for (int q = 0; q < MG; ++q) {
+        const int f = static_cast<int>(m[q]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i, 1));
+          const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i + 1, 1));
+          a[8 * q + i] &= (lo & 0x0000ffffu) | (hi & 0xffff0000u);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_bits(m, chunk + stride);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (HAS_MASK) {
 #pragma unroll
       for (int j = 0; j < KQD; ++j) a[j] = keep_where_positive(a[j], m[j]);
@@ -220,6 +275,7 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
 
     // ---- epilogue: 64 columns (4 tiles) per trip through the slab
     const int srow = lane >> 2, sq = lane & 3;
+    uint32_t mword[ND / 128] = {};
 #pragma unroll
     for (int hb = 0; hb < ND / 64; ++hb) {
 #pragma unroll
@@ -255,17 +311,32 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
         dst[0] = o0;
         dst[1] = o1;
       }
+      if constexpr (MASK == 0 && !TRANS_W) {
+        if (mask_out != nullptr) {                  // the relu mask of these 16 columns: bits 16 hb .. of this lane's word sq
+          const uint32_t b16 = relu_bits16(o0, o1);
+          if (hb & 1) mword[hb >> 1] |= b16 << 16;
+          else mword[hb >> 1] = b16;
+        }
+      }
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (MASK == 0 && !TRANS_W) {
+      if (mask_out != nullptr && srow < rh) {
+        uint8_t* mp = mask_out + chunk * 16 * (ND / 8) + (srow * static_cast<uint32_t>(ND / 8) + sq * (ND / 32));
+        if constexpr (ND == 256) *reinterpret_cast<uint2*>(mp) = make_uint2(mword[0], mword[1]);
+        else *reinterpret_cast<uint32_t*>(mp) = mword[0];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
 
   uint32_t a0[KQD], a1[KQD];
-  uint32_t m0[HAS_MASK ? KQD : 1];
+  uint32_t m0[MN];
   int64_t chunk = static_cast<int64_t>(blockIdx.x) * kBfWaves + wave;
   request(a0, x, ldx, chunk);
   request(a1, x, ldx, chunk + stride);
   if constexpr (HAS_MASK) request(m0, ymask, ldm, chunk);
+  if constexpr (MASK == 2) request_bits(m0, chunk);
   // (two chunks per trip, the odd last chunk peeled: a conditional second half makes the compiler wait vmcnt(0) at the loop
   // header -- see fused_mlp.hip)
   for (; chunk + stride < n_chunks; chunk += 2 * stride) {
@@ -286,20 +357,22 @@ extern "C" int allset_linear_bf16_supported(int64_t in_features, int64_t out_fea
 }
 
 template <int KD, int ND, bool TRANS_W>
-static void launch_bf16(bool has_mask, bool aux_out, unsigned grid, hipStream_t st, const uint16_t* x, int64_t ldx,
+static void launch_bf16(int mask_mode, bool aux_out, unsigned grid, hipStream_t st, const uint16_t* x, int64_t ldx,
                         const uint16_t* ymask, int64_t ldm, uint16_t* a_out, int64_t lda, const uint16_t* W,
                         const uint16_t* bias, int relu_out, const uint16_t* aux_w, const uint16_t* aux_b, float* aux_o,
-                        const float* aux_in, const uint16_t* acc_in, int64_t ldacc, uint16_t* y, int64_t ldy, int64_t n) {
+                        const float* aux_in, const uint16_t* acc_in, int64_t ldacc, uint16_t* y, int64_t ldy, uint8_t* mask_out,
+                        int64_t n) {
 #define ALLSET_BF16_GO(MASK, AUXO)                                                                                       \
   linear_bf16_kernel<KD, ND, TRANS_W, MASK, AUXO><<<grid, kBfBlock, 0, st>>>(x, ldx, ymask, ldm, a_out, lda, W, bias,   \
                                                                               relu_out, aux_w, aux_b, aux_o, aux_in,    \
-                                                                              acc_in, ldacc, y, ldy, n)
+                                                                              acc_in, ldacc, y, ldy, mask_out, n)
   if constexpr (!TRANS_W) {
-    if (aux_out) ALLSET_BF16_GO(false, true);
-    else ALLSET_BF16_GO(false, false);
+    if (aux_out) ALLSET_BF16_GO(0, true);
+    else ALLSET_BF16_GO(0, false);
   } else {
-    if (has_mask) ALLSET_BF16_GO(true, false);
-    else ALLSET_BF16_GO(false, false);
+    if (mask_mode == 2) ALLSET_BF16_GO(2, false);
+    else if (mask_mode == 1) ALLSET_BF16_GO(1, false);
+    else ALLSET_BF16_GO(0, false);
   }
 #undef ALLSET_BF16_GO
 }
@@ -314,10 +387,12 @@ static inline bool rows_ok(const void* p, int64_t ld, int64_t w) {     // 32-bit
   return p && aligned16(p) && ld >= w && ld % 8 == 0 && ld < (int64_t{1} << 26);
 }
 
-extern "C" int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void* bias, int relu_out,
-                                      const void* aux_w, const void* aux_b, float* aux_out, void* y, int64_t ldy,
-                                      int64_t n, int64_t K, int64_t N, void* stream) {
-  clear_error();
+// bytes per row of the relu bit mask of an N-wide Linear (rows are dense: pitch = this)
+extern "C" int64_t allset_linear_bf16_mask_pitch(int64_t N) { return bf16_width(N) ? N / 8 : 0; }
+
+static int linear_bf16_fwd_impl(const void* x, int64_t ldx, const void* W, const void* bias, int relu_out, const void* aux_w,
+                                const void* aux_b, float* aux_out, void* y, int64_t ldy, void* mask_out, int64_t n, int64_t K,
+                                int64_t N, void* stream) {
   ALLSET_REQUIRE(n >= 0, "linear_bf16_fwd: negative size");
   if (!allset_linear_bf16_supported(K, N)) {
     set_error("linear_bf16_fwd: K=%lld N=%lld not built (K, N in {128,256})", static_cast<long long>(K), static_cast<long long>(N));
@@ -327,13 +402,16 @@ extern "C" int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W,
   ALLSET_REQUIRE(rows_ok(x, ldx, K) && rows_ok(y, ldy, N), "linear_bf16_fwd: x and y must be 16-byte aligned rows (ld a multiple of 8)");
   ALLSET_REQUIRE(W && aligned16(W), "linear_bf16_fwd: W must be 16-byte aligned");
   ALLSET_REQUIRE(aux_out == nullptr || (aux_w != nullptr && aligned16(aux_out)), "linear_bf16_fwd: aux_out needs aux_w and 16-byte alignment");
+  ALLSET_REQUIRE(mask_out == nullptr || (relu_out && aux_out == nullptr && aligned16(mask_out)),
+                 "linear_bf16_fwd: mask_out needs relu_out, no auxiliary columns and 16-byte alignment");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned grid = bf16_grid(n);
   const uint16_t *xp = static_cast<const uint16_t*>(x), *Wp = static_cast<const uint16_t*>(W), *bp = static_cast<const uint16_t*>(bias);
   const uint16_t *awp = static_cast<const uint16_t*>(aux_w), *abp = static_cast<const uint16_t*>(aux_b);
   uint16_t* yp = static_cast<uint16_t*>(y);
+  uint8_t* mo = static_cast<uint8_t*>(mask_out);
 #define ALLSET_BF16_FWD(KD, ND) \
-  launch_bf16<KD, ND, false>(false, aux_out != nullptr, grid, st, xp, ldx, nullptr, 0, nullptr, 0, Wp, bp, relu_out, awp, abp, aux_out, nullptr, nullptr, 0, yp, ldy, n)
+  launch_bf16<KD, ND, false>(0, aux_out != nullptr, grid, st, xp, ldx, nullptr, 0, nullptr, 0, Wp, bp, relu_out, awp, abp, aux_out, nullptr, nullptr, 0, yp, ldy, mo, n)
   if (K == 256 && N == 256) ALLSET_BF16_FWD(256, 256);
   else if (K == 256 && N == 128) ALLSET_BF16_FWD(256, 128);
   else if (K == 128 && N == 256) ALLSET_BF16_FWD(128, 256);
@@ -343,11 +421,24 @@ extern "C" int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W,
   return ALLSET_OK;
 }
 
-extern "C" int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out,
-                                      int64_t lda, const void* W, const float* galpha, const void* aux_w,
-                                      const void* acc_in, int64_t ldacc, void* gx, int64_t ldgx, int64_t n, int64_t O,
-                                      int64_t I, void* stream) {
+extern "C" int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void* bias, int relu_out,
+                                      const void* aux_w, const void* aux_b, float* aux_out, void* y, int64_t ldy,
+                                      int64_t n, int64_t K, int64_t N, void* stream) {
   clear_error();
+  return linear_bf16_fwd_impl(x, ldx, W, bias, relu_out, aux_w, aux_b, aux_out, y, ldy, nullptr, n, K, N, stream);
+}
+
+// the same with the relu bit mask of y as a second output (mask_out: n rows of allset_linear_bf16_mask_pitch(N) bytes)
+extern "C" int allset_linear_bf16_fwd_mask(const void* x, int64_t ldx, const void* W, const void* bias, void* y, int64_t ldy,
+                                           void* mask_out, int64_t n, int64_t K, int64_t N, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(mask_out != nullptr, "linear_bf16_fwd_mask: null mask_out");
+  return linear_bf16_fwd_impl(x, ldx, W, bias, 1, nullptr, nullptr, nullptr, y, ldy, mask_out, n, K, N, stream);
+}
+
+static int linear_bf16_bwd_impl(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, int mask_mode, void* ga_out,
+                                int64_t lda, const void* W, const float* galpha, const void* aux_w, const void* acc_in,
+                                int64_t ldacc, void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream) {
   ALLSET_REQUIRE(n >= 0, "linear_bf16_bwd: negative size");
   if (!allset_linear_bf16_supported(I, O)) {
     set_error("linear_bf16_bwd: O=%lld I=%lld not built (O, I in {128,256})", static_cast<long long>(O), static_cast<long long>(I));
@@ -356,8 +447,9 @@ extern "C" int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* y
   if (n == 0) return ALLSET_OK;
   ALLSET_REQUIRE(rows_ok(gy, ldg, O) && rows_ok(gx, ldgx, I), "linear_bf16_bwd: gy and gx must be 16-byte aligned rows (ld a multiple of 8)");
   ALLSET_REQUIRE(W && aligned16(W), "linear_bf16_bwd: W must be 16-byte aligned");
-  ALLSET_REQUIRE(ymask == nullptr || rows_ok(ymask, ldm, O), "linear_bf16_bwd: ymask must be 16-byte aligned rows");
-  ALLSET_REQUIRE(ga_out == nullptr || (ymask != nullptr && rows_ok(ga_out, lda, O)), "linear_bf16_bwd: ga_out needs ymask and 16-byte aligned rows");
+  ALLSET_REQUIRE(mask_mode != 1 || rows_ok(ymask, ldm, O), "linear_bf16_bwd: ymask must be 16-byte aligned rows");
+  ALLSET_REQUIRE(mask_mode != 2 || (ymask != nullptr && (reinterpret_cast<uintptr_t>(ymask) & 7u) == 0), "linear_bf16_bwd_bits: the bit mask must be 8-byte aligned");
+  ALLSET_REQUIRE(ga_out == nullptr || (mask_mode == 1 && rows_ok(ga_out, lda, O)), "linear_bf16_bwd: ga_out needs ymask and 16-byte aligned rows");
   ALLSET_REQUIRE(acc_in == nullptr || (ldacc >= I && ldacc % 4 == 0 && ldacc < (int64_t{1} << 26) && (reinterpret_cast<uintptr_t>(acc_in) & 7u) == 0),
                  "linear_bf16_bwd: acc_in must be 8-byte aligned rows");
   ALLSET_REQUIRE(galpha == nullptr || (aux_w != nullptr && aligned16(galpha)), "linear_bf16_bwd: galpha needs aux_w and 16-byte alignment");
@@ -367,7 +459,7 @@ extern "C" int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* y
   const uint16_t *awp = static_cast<const uint16_t*>(aux_w), *ap = static_cast<const uint16_t*>(acc_in);
   uint16_t *gap = static_cast<uint16_t*>(ga_out), *gxp = static_cast<uint16_t*>(gx);
 #define ALLSET_BF16_BWD(KD, ND) \
-  launch_bf16<KD, ND, true>(mp != nullptr, false, grid, st, gp, ldg, mp, ldm, gap, lda, Wp, nullptr, 0, awp, nullptr, nullptr, galpha, ap, ldacc, gxp, ldgx, n)
+  launch_bf16<KD, ND, true>(mask_mode, false, grid, st, gp, ldg, mp, ldm, gap, lda, Wp, nullptr, 0, awp, nullptr, nullptr, galpha, ap, ldacc, gxp, ldgx, nullptr, n)
   if (O == 256 && I == 256) ALLSET_BF16_BWD(256, 256);
   else if (O == 256 && I == 128) ALLSET_BF16_BWD(256, 128);
   else if (O == 128 && I == 256) ALLSET_BF16_BWD(128, 256);
@@ -375,4 +467,20 @@ extern "C" int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* y
 #undef ALLSET_BF16_BWD
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
+}
+
+extern "C" int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out,
+                                      int64_t lda, const void* W, const float* galpha, const void* aux_w,
+                                      const void* acc_in, int64_t ldacc, void* gx, int64_t ldgx, int64_t n, int64_t O,
+                                      int64_t I, void* stream) {
+  clear_error();
+  return linear_bf16_bwd_impl(gy, ldg, ymask, ldm, ymask != nullptr ? 1 : 0, ga_out, lda, W, galpha, aux_w, acc_in, ldacc, gx, ldgx, n, O, I, stream);
+}
+
+// backward-data behind a relu whose mask is the forward's bit mask (allset_linear_bf16_fwd_mask): gx = (gy where bit) W [+ acc_in]
+extern "C" int allset_linear_bf16_bwd_bits(const void* gy, int64_t ldg, const void* bits, const void* W, const void* acc_in,
+                                           int64_t ldacc, void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(bits != nullptr, "linear_bf16_bwd_bits: null bit mask");
+  return linear_bf16_bwd_impl(gy, ldg, bits, 0, 2, nullptr, 0, W, nullptr, nullptr, acc_in, ldacc, gx, ldgx, n, O, I, stream);
 }

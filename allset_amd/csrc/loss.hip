@@ -194,37 +194,47 @@ extern "C" int allset_split_metrics(const float* logits, int64_t ld, const int64
 // backward are ~10 tiny launches per direction; at dataset scale that is a tenth of a replayed AllSetTransformer step.
 namespace allset {
 
-__global__ __launch_bounds__(256) void pma_fold_fwd_kernel(const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                          const float* __restrict__ att, float* __restrict__ w,
-                                                          float* __restrict__ b, int H, int C, int K) {
+// T = float, or uint16_t for bf16 parameters (configs[4] regime: fp32 arithmetic, one rounding per output -- the torch
+// expression it replaces rounded every product to bf16 first and cost ~12 launches per conv and step)
+template <typename T> __device__ __forceinline__ float fold_ld(const T* p, int64_t i);
+template <> __device__ __forceinline__ float fold_ld<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float fold_ld<uint16_t>(const uint16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+__device__ __forceinline__ void fold_st(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void fold_st(uint16_t* p, int64_t i, float v) { p[i] = static_cast<uint16_t>(cvt_pk_bf16(v, 0.f) & 0xffffu); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pma_fold_fwd_kernel(const T* __restrict__ Wk, const T* __restrict__ bk,
+                                                          const T* __restrict__ att, T* __restrict__ w,
+                                                          T* __restrict__ b, int H, int C, int K) {
   const int idx = blockIdx.x * 256 + threadIdx.x;          // (h, k) pairs, then H bias entries
   if (idx < H * K) {
     const int h = idx / K, k = idx % K;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(Wk[static_cast<int64_t>(h * C + c) * K + k], att[h * C + c], s);
-    w[idx] = s;
+    for (int c = 0; c < C; ++c) s = fmaf(fold_ld(Wk, static_cast<int64_t>(h * C + c) * K + k), fold_ld(att, h * C + c), s);
+    fold_st(w, idx, s);
   } else if (idx < H * K + H) {
     const int h = idx - H * K;
     float s = 0.f;
     if (bk != nullptr)
-      for (int c = 0; c < C; ++c) s = fmaf(bk[h * C + c], att[h * C + c], s);
-    b[h] = s;
+      for (int c = 0; c < C; ++c) s = fmaf(fold_ld(bk, h * C + c), fold_ld(att, h * C + c), s);
+    fold_st(b, h, s);
   }
 }
 
 // gWk[h C + c, k] = gw[h, k] att[h, c];  gbk[h C + c] = gb[h] att[h, c];  gatt[h, c] = sum_k gw[h, k] Wk[h C + c, k] + gb[h] bk[h C + c]
-__global__ __launch_bounds__(256) void pma_fold_bwd_kernel(const float* __restrict__ Wk, const float* __restrict__ bk,
-                                                          const float* __restrict__ att, const float* __restrict__ gw,
-                                                          const float* __restrict__ gb, float* __restrict__ gWk,
-                                                          float* __restrict__ gbk, float* __restrict__ gatt, int H, int C, int K) {
+template <typename T>
+__global__ __launch_bounds__(256) void pma_fold_bwd_kernel(const T* __restrict__ Wk, const T* __restrict__ bk,
+                                                          const T* __restrict__ att, const T* __restrict__ gw,
+                                                          const T* __restrict__ gb, T* __restrict__ gWk,
+                                                          T* __restrict__ gbk, T* __restrict__ gatt, int H, int C, int K) {
   // one workgroup per row (h, c) of W_K: writes its gWk row and reduces its gatt entry
   const int row = blockIdx.x, h = row / C;
-  const float a = att[row];
+  const float a = fold_ld(att, row);
   float s = 0.f;
   for (int k = threadIdx.x; k < K; k += 256) {
-    const float g = gw[h * K + k];
-    gWk[static_cast<int64_t>(row) * K + k] = g * a;
-    s = fmaf(g, Wk[static_cast<int64_t>(row) * K + k], s);
+    const float g = fold_ld(gw, h * K + k);
+    fold_st(gWk, static_cast<int64_t>(row) * K + k, g * a);
+    s = fmaf(g, fold_ld(Wk, static_cast<int64_t>(row) * K + k), s);
   }
   __shared__ float red[4];
 #pragma unroll
@@ -233,33 +243,60 @@ __global__ __launch_bounds__(256) void pma_fold_bwd_kernel(const float* __restri
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = red[0] + red[1] + red[2] + red[3];
-    const float g = gb ? gb[h] : 0.f;
-    if (bk != nullptr) { t = fmaf(g, bk[row], t); gbk[row] = g * a; }
-    gatt[row] = t;
+    const float g = gb ? fold_ld(gb, h) : 0.f;
+    if (bk != nullptr) { t = fmaf(g, fold_ld(bk, row), t); fold_st(gbk, row, g * a); }
+    fold_st(gatt, row, t);
   }
 }
 
 }  // namespace allset
 
-extern "C" int allset_pma_fold_fwd(const float* Wk, const float* bk, const float* att, float* w, float* b, int64_t H, int64_t C,
-                                   int64_t K, void* stream) {
-  clear_error();
+template <typename T>
+static int pma_fold_fwd_impl(const T* Wk, const T* bk, const T* att, T* w, T* b, int64_t H, int64_t C, int64_t K, void* stream) {
   ALLSET_REQUIRE(H >= 1 && C >= 1 && K >= 1 && H * K < (int64_t{1} << 30), "pma_fold_fwd: bad size");
   ALLSET_REQUIRE(Wk && att && w && b, "pma_fold_fwd: null pointer");
   const unsigned grid = static_cast<unsigned>((H * K + H + 255) / 256);
-  allset::pma_fold_fwd_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(Wk, bk, att, w, b, static_cast<int>(H), static_cast<int>(C),
-                                                                            static_cast<int>(K));
+  allset::pma_fold_fwd_kernel<T><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(Wk, bk, att, w, b, static_cast<int>(H), static_cast<int>(C),
+                                                                               static_cast<int>(K));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
+}
+
+template <typename T>
+static int pma_fold_bwd_impl(const T* Wk, const T* bk, const T* att, const T* gw, const T* gb, T* gWk, T* gbk, T* gatt, int64_t H,
+                             int64_t C, int64_t K, void* stream) {
+  ALLSET_REQUIRE(H >= 1 && C >= 1 && K >= 1 && H * C < (int64_t{1} << 30), "pma_fold_bwd: bad size");
+  ALLSET_REQUIRE(Wk && att && gw && gWk && gatt && (bk == nullptr || gbk != nullptr), "pma_fold_bwd: null pointer");
+  allset::pma_fold_bwd_kernel<T><<<static_cast<unsigned>(H * C), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      Wk, bk, att, gw, gb, gWk, gbk, gatt, static_cast<int>(H), static_cast<int>(C), static_cast<int>(K));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_pma_fold_fwd(const float* Wk, const float* bk, const float* att, float* w, float* b, int64_t H, int64_t C,
+                                   int64_t K, void* stream) {
+  clear_error();
+  return pma_fold_fwd_impl<float>(Wk, bk, att, w, b, H, C, K, stream);
 }
 
 extern "C" int allset_pma_fold_bwd(const float* Wk, const float* bk, const float* att, const float* gw, const float* gb, float* gWk,
                                    float* gbk, float* gatt, int64_t H, int64_t C, int64_t K, void* stream) {
   clear_error();
-  ALLSET_REQUIRE(H >= 1 && C >= 1 && K >= 1 && H * C < (int64_t{1} << 30), "pma_fold_bwd: bad size");
-  ALLSET_REQUIRE(Wk && att && gw && gWk && gatt && (bk == nullptr || gbk != nullptr), "pma_fold_bwd: null pointer");
-  allset::pma_fold_bwd_kernel<<<static_cast<unsigned>(H * C), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      Wk, bk, att, gw, gb, gWk, gbk, gatt, static_cast<int>(H), static_cast<int>(C), static_cast<int>(K));
-  ALLSET_LAUNCH_CHECK();
-  return ALLSET_OK;
+  return pma_fold_bwd_impl<float>(Wk, bk, att, gw, gb, gWk, gbk, gatt, H, C, K, stream);
+}
+
+// the same for bf16 parameters (every pointer bf16; fp32 arithmetic, one rounding per output element)
+extern "C" int allset_pma_fold_fwd_bf16(const void* Wk, const void* bk, const void* att, void* w, void* b, int64_t H, int64_t C,
+                                        int64_t K, void* stream) {
+  clear_error();
+  return pma_fold_fwd_impl<uint16_t>(static_cast<const uint16_t*>(Wk), static_cast<const uint16_t*>(bk), static_cast<const uint16_t*>(att),
+                                     static_cast<uint16_t*>(w), static_cast<uint16_t*>(b), H, C, K, stream);
+}
+
+extern "C" int allset_pma_fold_bwd_bf16(const void* Wk, const void* bk, const void* att, const void* gw, const void* gb, void* gWk,
+                                        void* gbk, void* gatt, int64_t H, int64_t C, int64_t K, void* stream) {
+  clear_error();
+  return pma_fold_bwd_impl<uint16_t>(static_cast<const uint16_t*>(Wk), static_cast<const uint16_t*>(bk), static_cast<const uint16_t*>(att),
+                                     static_cast<const uint16_t*>(gw), static_cast<const uint16_t*>(gb), static_cast<uint16_t*>(gWk),
+                                     static_cast<uint16_t*>(gbk), static_cast<uint16_t*>(gatt), H, C, K, stream);
 }

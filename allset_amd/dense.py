@@ -1570,7 +1570,8 @@ def pma_tail(pooled: Tensor, att_r: Tensor, g0, b0, eps0, w1, b1, w2, b2, g1, bt
 
 class _PmaFold(torch.autograd.Function):
     """``(w [H, K], b [H]) = fold(W_K [H C, K], b_K [H C], att_r [.., H, C])``: the weight of PMA's folded logits as ONE kernel each
-    way (as torch ops: mul, sum, mul, sum forward and six more backward -- ~80 us per replayed dataset-scale step)."""
+    way (as torch ops: mul, sum, mul, sum forward and six more backward -- ~80 us per replayed dataset-scale step).  fp32, or bf16
+    parameters (fp32 arithmetic, each output rounded once)."""
 
     @staticmethod
     def forward(ctx, Wk, bk, att):
@@ -1578,12 +1579,16 @@ class _PmaFold(torch.autograd.Function):
         HC, K = Wk.shape
         H = att.shape[-2]
         C = HC // H
+        dt = Wk.dtype
+        _check_dtype(dt, att, bk)
         Wk_c, att_c = Wk.contiguous(), att.contiguous()
-        w = torch.empty((H, K), dtype=torch.float32, device=dev)
-        b = torch.empty((H,), dtype=torch.float32, device=dev)
+        w = torch.empty((H, K), dtype=dt, device=dev)
+        b = torch.empty((H,), dtype=dt, device=dev)
+        lib = _lib.load()
+        fn, name = ((lib.allset_pma_fold_fwd_bf16, "allset_pma_fold_fwd_bf16") if dt == torch.bfloat16
+                    else (lib.allset_pma_fold_fwd, "allset_pma_fold_fwd"))
         with on_device(dev):
-            check(_lib.load().allset_pma_fold_fwd(ptr(Wk_c), ptr(bk.contiguous() if bk is not None else None), ptr(att_c), ptr(w), ptr(b),
-                                                  H, C, K, stream_of(dev)), "allset_pma_fold_fwd")
+            check(fn(ptr(Wk_c), ptr(bk.contiguous() if bk is not None else None), ptr(att_c), ptr(w), ptr(b), H, C, K, stream_of(dev)), name)
         ctx.save_for_backward(Wk_c, bk, att_c)
         ctx.att_shape = att.shape
         return w, b
@@ -1596,18 +1601,23 @@ class _PmaFold(torch.autograd.Function):
         HC, K = Wk.shape
         H = att.shape[-2]
         C = HC // H
+        dt = Wk.dtype
         gWk = torch.empty_like(Wk)
-        gbk = torch.empty((HC,), dtype=torch.float32, device=dev) if bk is not None else None
-        gatt = torch.empty((HC,), dtype=torch.float32, device=dev)
+        gbk = torch.empty((HC,), dtype=dt, device=dev) if bk is not None else None
+        gatt = torch.empty((HC,), dtype=dt, device=dev)
+        gw = gw.to(dt).contiguous()
+        gb = gb.to(dt).contiguous() if gb is not None else None
+        lib = _lib.load()
+        fn, name = ((lib.allset_pma_fold_bwd_bf16, "allset_pma_fold_bwd_bf16") if dt == torch.bfloat16
+                    else (lib.allset_pma_fold_bwd, "allset_pma_fold_bwd"))
         with on_device(dev):
-            check(_lib.load().allset_pma_fold_bwd(ptr(Wk), ptr(bk.contiguous() if bk is not None else None), ptr(att), ptr(gw.contiguous()),
-                                                  ptr(gb.contiguous() if gb is not None else None), ptr(gWk), ptr(gbk), ptr(gatt), H, C, K,
-                                                  stream_of(dev)), "allset_pma_fold_bwd")
+            check(fn(ptr(Wk), ptr(bk.contiguous() if bk is not None else None), ptr(att), ptr(gw), ptr(gb), ptr(gWk), ptr(gbk), ptr(gatt),
+                     H, C, K, stream_of(dev)), name)
         return gWk, gbk, gatt.view(ctx.att_shape)
 
 
 def pma_fold(Wk: Tensor, bk: Optional[Tensor], att: Tensor) -> Tuple[Tensor, Tensor]:
-    """fp32 device parameters only (callers keep the torch expression for anything else)."""
+    """fp32 or bf16 device parameters, all of one dtype (callers keep the torch expression for anything else)."""
     return _PmaFold.apply(Wk, bk, att)
 
 
@@ -1637,6 +1647,23 @@ def linear_bf16_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu_out:
     return y, aux
 
 
+def linear_bf16_fwd_mask(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """``y = relu(x W^T + b)`` (bf16) and its relu mask as one bit per element (uint8 [n, N / 8]; the private bit order of
+    ``allset_linear_bf16_fwd_mask``, consumed by :func:`linear_bf16_bwd_bits` and ``wgrad(..., bits=)``)."""
+    dev = require_device(x, weight)
+    _check_dtype(torch.bfloat16, x, weight)
+    x = _rowmajor(x)
+    n, K = x.shape
+    N = weight.shape[0]
+    lib = _lib.load()
+    y = torch.empty((n, N), dtype=torch.bfloat16, device=dev)
+    bits = torch.empty((n, int(lib.allset_linear_bf16_mask_pitch(N))), dtype=torch.uint8, device=dev)
+    with on_device(dev), _timed("linear_bf16_fwd", dev, n * (K + N) * 2 + n * N // 8):
+        check(lib.allset_linear_bf16_fwd_mask(ptr(x), _ld(x), ptr(weight.contiguous()), ptr(bias.contiguous() if bias is not None else None),
+                                              ptr(y), N, ptr(bits), n, K, N, stream_of(dev)), "allset_linear_bf16_fwd_mask")
+    return y, bits
+
+
 def linear_bf16_bwd(gy: Tensor, weight: Tensor, ymask: Optional[Tensor] = None, want_ga: bool = False,
                     acc_in: Optional[Tensor] = None, galpha: Optional[Tensor] = None, aux_w: Optional[Tensor] = None
                     ) -> Tuple[Tensor, Tensor]:
@@ -1664,15 +1691,81 @@ def linear_bf16_bwd(gy: Tensor, weight: Tensor, ymask: Optional[Tensor] = None, 
     return gx, (ga if ga is not None else gy)
 
 
+def linear_bf16_bwd_bits(gy: Tensor, weight: Tensor, bits: Tensor, acc_in: Optional[Tensor] = None) -> Tensor:
+    """``gx = (gy where bit) W [+ acc_in]`` behind a relu whose mask is :func:`linear_bf16_fwd_mask`'s bit mask.  The masked
+    gradient is not written: the weight-gradient kernel applies the same bits (``wgrad(gy, u, bits=bits)``)."""
+    dev = require_device(gy, weight, bits)
+    _check_dtype(torch.bfloat16, gy, weight)
+    gy = _rowmajor(gy)
+    n, O = gy.shape
+    I = weight.shape[1]
+    if bits.dtype != torch.uint8 or tuple(bits.shape) != (n, O // 8) or not bits.is_contiguous():
+        raise _lib.AllSetHipError("linear_bf16_bwd_bits: bits must be the contiguous uint8 [n, O / 8] mask of linear_bf16_fwd_mask")
+    gx = torch.empty((n, I), dtype=torch.bfloat16, device=dev)
+    if acc_in is not None:
+        acc_in = _rowmajor(acc_in)
+    nbytes = n * (O + I) * 2 + n * O // 8 + (n * I * 2 if acc_in is not None else 0)
+    with on_device(dev), _timed("linear_bf16_bwd", dev, nbytes):
+        check(_lib.load().allset_linear_bf16_bwd_bits(ptr(gy), _ld(gy), ptr(bits), ptr(weight.contiguous()), ptr(acc_in),
+                                                      _ld(acc_in) if acc_in is not None else 0, ptr(gx), I, n, O, I, stream_of(dev)),
+              "allset_linear_bf16_bwd_bits")
+    return gx
+
+
+def wgrad_bf16_ex2_supported(O: int, I: int, bits: bool, aux: bool) -> bool:
+    return bool(_lib.load().allset_wgrad_bf16_ex2_supported(O, I, int(bits), int(aux)))
+
+
+def wgrad_bf16_ex2(ga: Tensor, u: Tensor, bits: Optional[Tensor] = None, g4: Optional[Tensor] = None, want_bias: bool = True):
+    """``(gW, gb[, gWa [4, I], gba [4]])`` of a bf16 Linear in one pass over ``ga`` and ``u``: ``bits`` = the relu bit mask of the
+    Linear's output (``ga`` is the gradient BEFORE the mask), ``g4`` = the fp32 [n, 4] gradient of four auxiliary output columns.
+    Results bf16 (summed in fp32, rounded once by the reduction)."""
+    dev = require_device(ga, u)
+    _check_dtype(torch.bfloat16, ga, u)
+    ga, u = _rowmajor(ga), _rowmajor(u)
+    n, O = ga.shape
+    I = u.shape[1]
+    lib = _lib.load()
+    ns = c_int64(0)
+    check(lib.allset_wgrad_bf16_slices(n, O, I, byref(ns)), "allset_wgrad_bf16_slices")
+    M = O * I + (O if want_bias else 0) + (4 * I + 4 if g4 is not None else 0)
+    part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
+    if g4 is not None:
+        g4 = g4.float().contiguous()
+    nbytes = n * (O + I) * 2 + (n * O // 8 if bits is not None else 0) + (n * 16 if g4 is not None else 0)
+    with on_device(dev), _timed("wgrad", dev, nbytes):
+        check(lib.allset_wgrad_bf16_ex2(ptr(ga), _ld(ga), ptr(bits), ptr(g4), ptr(u), _ld(u), ptr(part), M, int(want_bias), ns.value,
+                                        n, O, I, stream_of(dev)), "allset_wgrad_bf16_ex2")
+    red = reduce_partials_to(part, M, torch.bfloat16)
+    gw = red[:O * I].view(O, I)
+    off = O * I
+    gb = None
+    if want_bias:
+        gb = red[off:off + O]
+        off += O
+    if g4 is None:
+        return gw, gb
+    return gw, gb, red[off:off + 4 * I].view(4, I), red[off + 4 * I:off + 4 * I + 4]
+
+
 class _LinearBf16(torch.autograd.Function):
-    """``y = act(x W^T + b)`` in the bf16 regime: one kernel forward (relu in its epilogue), one backward-data kernel (relu
-    mask from the saved output in its prologue) and the full-width bf16 weight-gradient kernel."""
+    """``y = act(x W^T + b)`` in the bf16 regime: one kernel forward (relu in its epilogue; when a gradient will be asked for, its
+    mask as one bit per element beside y), one backward-data kernel and the full-width bf16 weight-gradient kernel, both applying
+    the bit mask to gy as they stage it."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu_out):
-        y, _ = linear_bf16_fwd(x, weight, bias, relu_out)
-        ctx.save_for_backward(x, weight, y if relu_out else None)
+        O, I = weight.shape
+        need_grad = any(ctx.needs_input_grad[:3])
+        use_bits = bool(relu_out) and need_grad and wgrad_bf16_ex2_supported(O, I, True, False)
+        if use_bits:
+            y, bits = linear_bf16_fwd_mask(x, weight, bias)
+            ctx.save_for_backward(x, weight, bits)
+        else:
+            y, _ = linear_bf16_fwd(x, weight, bias, relu_out)
+            ctx.save_for_backward(x, weight, y if relu_out else None)
         ctx.has_bias = bias is not None
+        ctx.use_bits = use_bits
         return y
 
     @staticmethod
@@ -1682,6 +1775,12 @@ class _LinearBf16(torch.autograd.Function):
         gy = gy.contiguous()
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         gx = gw = gb = None
+        if ctx.use_bits:
+            if ctx.needs_input_grad[0]:
+                gx = linear_bf16_bwd_bits(gy, weight, y)
+            if need_w:
+                gw, gb = wgrad_bf16_ex2(gy, x, bits=y, want_bias=ctx.has_bias)
+            return gx, gw, gb, None
         ga = gy
         if ctx.needs_input_grad[0]:
             gx, ga = linear_bf16_bwd(gy, weight, y, want_ga=need_w)
@@ -1720,9 +1819,18 @@ class _PmaProjectBf16(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
             gx, _ = linear_bf16_bwd(g_v, w_v, galpha=g4, aux_w=w4)
-        if ctx.needs_input_grad[1] or (has_bv and ctx.needs_input_grad[2]):
+        need_v = ctx.needs_input_grad[1] or (has_bv and ctx.needs_input_grad[2])
+        need_a = ctx.needs_input_grad[3] or (has_ba and ctx.needs_input_grad[4])
+        if need_v and need_a and wgrad_bf16_ex2_supported(w_v.shape[0], w_v.shape[1], False, True) and g_v.stride(1) == 1 \
+                and g_v.stride(0) % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0:
+            # the four logit rows ride in the value projection's weight-gradient pass (one read of x instead of two)
+            g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
+            gwv, gbv, gwa4, gba4 = wgrad_bf16_ex2(g_v, x, g4=g4, want_bias=has_bv)
+            gwa, gba = gwa4[:H], (gba4[:H] if has_ba else None)
+            return gx, gwv, gbv, gwa, gba
+        if need_v:
             gwv, gbv = wgrad(g_v, x, want_bias=has_bv)
-        if ctx.needs_input_grad[3] or (has_ba and ctx.needs_input_grad[4]):
+        if need_a:
             ga16 = g_alpha.to(torch.bfloat16)
             if wgrad_supported(ga16, x):
                 gwa, gba = wgrad(ga16, x, want_bias=has_ba)
@@ -1737,26 +1845,40 @@ def pma_project_bf16(x: Tensor, w_v: Tensor, b_v: Optional[Tensor], w_a: Tensor,
 
 class _PmaResidualFFBf16(torch.autograd.Function):
     """:class:`_PmaResidualFF` in the bf16 regime: ``y = dropout_p(relu_post(LN(out + relu(W2 relu(W1 out + b1) + b2))))``;
-    both relus are Linear epilogues, their backward masks come from the saved outputs, and the two gradient branches of
-    ``out`` are summed in the last backward-data kernel."""
+    both relus are Linear epilogues that also write their masks as one bit per element; the backward-data and weight-gradient
+    kernels apply those bits to the incoming gradient as they stage it, and the two gradient branches of ``out`` are summed in
+    the last backward-data kernel."""
 
     @staticmethod
     def forward(ctx, out, w1, b1, w2, b2, gamma, beta, eps, relu_post, p):
-        h, _ = linear_bf16_fwd(out, w1, b1, True)
-        z, _ = linear_bf16_fwd(h, w2, b2, True)
+        use_bits = (any(ctx.needs_input_grad[:5]) and wgrad_bf16_ex2_supported(w1.shape[0], w1.shape[1], True, False)
+                    and wgrad_bf16_ex2_supported(w2.shape[0], w2.shape[1], True, False))
+        if use_bits:
+            h, mh = linear_bf16_fwd_mask(out, w1, b1)
+            z, mz = linear_bf16_fwd_mask(h, w2, b2)
+        else:
+            h, _ = linear_bf16_fwd(out, w1, b1, True)
+            z, _ = linear_bf16_fwd(h, w2, b2, True)
+            mh = mz = None
         seed = _draw_seed() if p > 0.0 else 0
         base = _seed_base() if p > 0.0 else None
         y, stats = ln_res_fwd(out, None, z, gamma, beta, eps, relu_post, p, seed, base)
-        ctx.save_for_backward(out, h, z, stats, w1, w2, gamma, beta)
+        ctx.save_for_backward(out, h, z, stats, w1, w2, gamma, beta, mh, mz)
         ctx.cfg = (bool(relu_post), float(p), seed, base, b1 is not None, b2 is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        out, h, z, stats, w1, w2, gamma, beta = ctx.saved_tensors
+        out, h, z, stats, w1, w2, gamma, beta, mh, mz = ctx.saved_tensors
         relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
         gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
+        if mh is not None:
+            gh = linear_bf16_bwd_bits(gs, w2, mz)
+            gw2, gb2 = wgrad_bf16_ex2(gs, h, bits=mz, want_bias=has_b2)
+            gout = linear_bf16_bwd_bits(gh, w1, mh, acc_in=gs)                  # gs + the rFF branch
+            gw1, gb1 = wgrad_bf16_ex2(gh, out, bits=mh, want_bias=has_b1)
+            return gout, gw1, gb1, gw2, gb2, dg, db, None, None, None
         gh, ga2 = linear_bf16_bwd(gs, w2, z, want_ga=True)
         gw2, gb2 = wgrad(ga2, h, want_bias=has_b2)
         gout, ga1 = linear_bf16_bwd(gh, w1, h, want_ga=True, acc_in=gs)         # gs + the rFF branch

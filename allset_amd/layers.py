@@ -387,8 +387,9 @@ class PMA(nn.Module):
         """``(w [H, in], b [H])`` with ``alpha = x w^T + b``: one kernel each way for fp32 device parameters."""
         H, C = self.heads, self.hidden
         Wk, bk = self.lin_K.weight, self.lin_K.bias
-        if Wk.is_cuda and Wk.dtype == torch.float32 and self.att_r.dtype == torch.float32 and (bk is None or bk.dtype == torch.float32):
-            return dense.pma_fold(Wk, bk, self.att_r)
+        if (Wk.is_cuda and Wk.dtype in (torch.float32, torch.bfloat16) and self.att_r.dtype == Wk.dtype
+                and (bk is None or bk.dtype == Wk.dtype)):
+            return dense.pma_fold(Wk, bk, self.att_r)       # fp32, or the bf16 regime: one kernel each way
         w = (Wk.view(H, C, -1) * self.att_r.view(H, C, 1)).sum(dim=1)     # [H, in]
         b = (bk.view(H, C) * self.att_r.view(H, C)).sum(dim=1)           # [H]
         return w, b

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 12  /* 12: additions only (allset_fused_linear_bwd_pma_tail(_supported), allset_fused_linear_bwd_ln_pro(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now.  Earlier:  2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
+#define ALLSET_ABI_VERSION 13  /* 13: additions only (bf16 regime: allset_linear_bf16_mask_pitch / _fwd_mask / _bwd_bits -- the relu mask as one bit per element --, allset_wgrad_bf16_ex2(_supported) -- that mask and PMA's four auxiliary logit rows inside the weight-gradient pass --, allset_pma_fold_fwd_bf16 / _bwd_bf16).  Earlier:  12: additions only (allset_fused_linear_bwd_pma_tail(_supported), allset_fused_linear_bwd_ln_pro(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now;   2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
 
 /* ---------------------------------------------------------------------------------------------
  * Dense tail (reference MLP.forward, layers.py:571-579: norm -> [Linear -> ReLU -> norm -> dropout]* -> Linear,
@@ -78,6 +78,14 @@ int allset_wgrad_bf16(const void* ga, int64_t lda, const void* u, int64_t ldu, f
  * and can write them as bf16.  part_stride >= O*I (+O), a multiple of 4. */
 int allset_wgrad_bf16_ex(const void* ga, int64_t lda, const void* u, int64_t ldu, float* part, int64_t part_stride,
                          int want_bias, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
+/* ABI 13.  The same with (a) `bits` (may be NULL): the relu BIT mask allset_linear_bf16_fwd_mask wrote for the Linear whose output
+ * gradient `ga` is -- applied to ga as it is staged, so the masked gradient never exists in memory -- and (b) `g4` (fp32 [n, 4], may be
+ * NULL): the gradient of four auxiliary output columns (PMA's folded logits, reference layers.py:126-131), rounded to bf16 and
+ * multiplied in the same pass.  Partial row: [gW (O*I) | gb (O, if want_bias) | gWa (4*I) | gba (4)], the last two only with g4.
+ * O, I in {128, 256} (g4: 256 x 256), see allset_wgrad_bf16_ex2_supported; n_slices from allset_wgrad_bf16_slices. */
+int allset_wgrad_bf16_ex2_supported(int64_t O, int64_t I, int has_bits, int has_aux);
+int allset_wgrad_bf16_ex2(const void* ga, int64_t lda, const void* bits, const float* g4, const void* u, int64_t ldu, float* part,
+                          int64_t part_stride, int want_bias, int64_t n_slices, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* The Linear of the bf16 regime (BASELINE configs[4]; replaces MLP.forward's Linear + ReLU, reference layers.py:571-579, and
  * PMA's value projection + folded logits, layers.py:120-145, with their autograd) -- bf16 activations and parameters, fp32
@@ -96,6 +104,16 @@ int allset_linear_bf16_fwd(const void* x, int64_t ldx, const void* W, const void
 int allset_linear_bf16_bwd(const void* gy, int64_t ldg, const void* ymask, int64_t ldm, void* ga_out, int64_t lda,
                            const void* W, const float* galpha, const void* aux_w, const void* acc_in, int64_t ldacc,
                            void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream);
+/* ABI 13.  The relu mask as ONE BIT per element: allset_linear_bf16_fwd_mask is the forward with relu_out = 1 and a second output
+ * mask_out -- n dense rows of allset_linear_bf16_mask_pitch(N) = N / 8 bytes, 16-byte aligned; bit (16 hb + j) of the row's word sq
+ * (four words of N / 32 bytes per row) is set where y[row][64 hb + 16 sq + j] > 0 -- which allset_linear_bf16_bwd_bits
+ * (gx = (gy where bit) W [+ acc_in]) and allset_wgrad_bf16_ex2 consume instead of the 2-byte-per-element activation: the masked
+ * backward reads gy + n N / 8 bytes and writes gx only (no ga_out: the weight-gradient kernel masks on its own). */
+int64_t allset_linear_bf16_mask_pitch(int64_t N);
+int allset_linear_bf16_fwd_mask(const void* x, int64_t ldx, const void* W, const void* bias, void* y, int64_t ldy, void* mask_out,
+                                int64_t n, int64_t K, int64_t N, void* stream);
+int allset_linear_bf16_bwd_bits(const void* gy, int64_t ldg, const void* bits, const void* W, const void* acc_in, int64_t ldacc,
+                                void* gx, int64_t ldgx, int64_t n, int64_t O, int64_t I, void* stream);
 
 /* torch.optim.Adam's update (reference train.py:469; non-amsgrad, L2 weight decay) for up to allset_adam_max_tensors() fp32
  * tensors in ONE launch.  params / grads / exp_avg / exp_avg_sq / numel: HOST arrays of `count` device pointers / sizes (read
@@ -131,6 +149,11 @@ int allset_pma_fold_fwd(const float* Wk, const float* bk, const float* att, floa
                         void* stream);
 int allset_pma_fold_bwd(const float* Wk, const float* bk, const float* att, const float* gw, const float* gb, float* gWk,
                         float* gbk, float* gatt, int64_t H, int64_t C, int64_t K, void* stream);
+/* ABI 13.  The same for bf16 parameters (every pointer bf16; fp32 arithmetic, each output rounded once). */
+int allset_pma_fold_fwd_bf16(const void* Wk, const void* bk, const void* att, void* w, void* b, int64_t H, int64_t C, int64_t K,
+                             void* stream);
+int allset_pma_fold_bwd_bf16(const void* Wk, const void* bk, const void* att, const void* gw, const void* gb, void* gWk, void* gbk,
+                             void* gatt, int64_t H, int64_t C, int64_t K, void* stream);
 
 /* Accuracy and loss of the reference's evaluate() (train.py:169-199) for three row sets in one pass: split[r] in {0, 1, 2} names the
  * row's set (anything else: none); partials: f32[allset_nll_partials(n)][6] = per-block sums {correct_0, correct_1, correct_2,

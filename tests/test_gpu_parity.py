@@ -307,6 +307,14 @@ def test_bf16_parity_bound_catches_a_wrong_weight_gradient(name, device, monkeyp
             gw = gw.t().contiguous()
         return gw, gb
     monkeypatch.setattr(dense, "wgrad", transposed)
+    real2 = dense.wgrad_bf16_ex2
+
+    def transposed2(ga, u, bits=None, g4=None, want_bias=True):        # (round 6: the masked / auxiliary-row form of the same kernel)
+        res = list(real2(ga, u, bits=bits, g4=g4, want_bias=want_bias))
+        if res[0].shape[0] == res[0].shape[1]:
+            res[0] = res[0].t().contiguous()
+        return tuple(res)
+    monkeypatch.setattr(dense, "wgrad_bf16_ex2", transposed2)
     with pytest.raises(AssertionError, match=r"grad .*weight"):
         test_setgnn_bf16_matches_the_oracle_on_bf16_rounded_inputs(name, device)
 
