@@ -30,12 +30,14 @@
 #include "common.h"
 
 #include <stdint.h>
+#include <type_traits>
 
 namespace allset {
 
 using bf16x8_b = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
 using f32x4_b = __attribute__((ext_vector_type(4))) float;
 union FragB { uint4 u; bf16x8_b v; };
+typedef unsigned swap2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kBfBlock = 512;
 constexpr int kBfWaves = kBfBlock / kWave;
@@ -57,9 +59,11 @@ __device__ __forceinline__ uint32_t keep_where_positive(uint32_t v, uint32_t y) 
 }
 
 typedef unsigned short bf_us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t nz_halves(uint32_t v) {         // per 16-bit half: 1 where the magnitude bits are set
+// per 16-bit half: 1 where the half is not +0.  The halves are relu outputs max(acc + bias, +0): never negative, and never -0
+// either (an fp32 sum that starts from the accumulator's +0 cannot round to -0), so "any bit set" is "> 0".
+__device__ __forceinline__ uint32_t nz_halves(uint32_t v) {
   const bf_us2_t one = {1, 1};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(bf_us2_t, v & 0x7fff7fffu), one));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(bf_us2_t, v), one));
 }
 // 16 relu outputs (+0 or positive bf16, two per dword, columns in order) -> their 16 "is positive" bits, column j at bit j
 __device__ __forceinline__ uint32_t relu_bits16(const uint4& o0, const uint4& o1) {
@@ -73,7 +77,12 @@ __device__ __forceinline__ uint32_t relu_bits16(const uint4& o0, const uint4& o1
 // MASK: 0 none, 1 the saved bf16 activation (`ymask`), 2 the forward's bit mask (`ymask` points at the bit rows).
 // TRANS_W: W is [KD, ND] row-major (backward-data: the layer's [out, in] weight, reduced over its rows);
 //          otherwise [ND, KD] (forward).
-template <int KD, int ND, bool TRANS_W, int MASK, bool AUX_OUT>
+// AUX: forward -- the four auxiliary output columns (aux_out); backward-data -- the logits' gradient term (aux_in).
+// EXTRA: forward -- the relu bit mask as a second output (mask_out); backward-data -- the other gradient branch (acc_in).
+// Compile-time on purpose (round 6): a run-time `if (acc_in != nullptr)` per tile, uniform as it is, cut the epilogue into
+// basic blocks the scheduler cannot overlap -- the per-tile switches of round 5 cost 12 us of a 69-us launch
+// (tools/linear_bf16_ablation.py).  The legacy MASK == 1 form keeps its run-time switches (one instantiation).
+template <int KD, int ND, bool TRANS_W, int MASK, bool AUX, bool EXTRA>
 __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ ymask, int64_t ldm,
     uint16_t* __restrict__ a_out, int64_t lda, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
@@ -87,13 +96,97 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
   constexpr int T = KQ / 8;                        // MFMA k-steps
   constexpr int GS = ND * KQD;
   constexpr int NTILE = ND / 16;
+  constexpr bool AUX_OUT = !TRANS_W && AUX;
+  constexpr bool RT = MASK == 1;                   // the legacy form: run-time switches
   constexpr int AUXW = AUX_OUT ? KD : ND;          // width of the 4 auxiliary weight rows this instantiation keeps
   __shared__ __attribute__((aligned(16))) uint32_t sW[4 * GS];
   __shared__ __attribute__((aligned(16))) float sBias[ND];
   __shared__ __attribute__((aligned(16))) float sAux[4 * AUXW + 4];
+#ifdef ALLSET_BF16_SLAB_EPILOGUE
   __shared__ __attribute__((aligned(16))) uint32_t sSlab[kBfWaves * 16 * kSlabPitch];
+#endif
   const int tid = threadIdx.x;
-  const bool has_aux_in = !AUX_OUT && aux_in != nullptr;
+  const bool has_aux_in = TRANS_W && (RT ? aux_in != nullptr : AUX);      // (the logits' gradient: backward-data only)
+  const bool has_acc = TRANS_W && (RT ? acc_in != nullptr : EXTRA);       // (the other gradient branch: backward-data only)
+  constexpr bool MASK_OUT = !TRANS_W && EXTRA;
+  const float relu_floor = (!TRANS_W && relu_out) ? 0.f : -__builtin_inff();   // relu as a max against a scalar: no branch per tile
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: chunk indices and row bases stay scalar
+  const int ri = lane & 15, g = lane >> 4;
+  const int64_t n_chunks = (n + 15) / 16;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBfWaves;
+#ifdef ALLSET_BF16_SLAB_EPILOGUE
+  uint32_t* slab = sSlab + wave * (16 * kSlabPitch);
+#endif
+
+  // Addresses are a scalar row base per step (64-bit, in SGPRs) plus a 32-bit lane offset: 64-bit per-lane pointers for the
+  // six row-major operands cost ~20 VGPRs, which this kernel does not have.  Loads are unconditional on a clamped row
+  // (a branch around a load costs s_waitcnt vmcnt(0) at the join, which drains the prefetch); rows past n are zeroed when
+  // consumed.  `chunk` may run past the end (prefetch): clamped to the last step.
+  auto rows_here = [&](int64_t chunk) -> int {                 // rows of this step that exist (1..16); chunk < n_chunks
+    const int64_t left = n - chunk * 16;
+    return left < 16 ? static_cast<int>(left) : 16;
+  };
+  auto request = [&](uint32_t (&a)[KQD], const uint16_t* __restrict__ src, int64_t ld, int64_t chunk) {
+    const int64_t c = chunk < n_chunks ? chunk : n_chunks - 1;
+    const int rh = rows_here(c);
+    const uint32_t rr = ri < rh ? ri : rh - 1;
+    const uint16_t* base = src + c * 16 * ld;
+    const uint4* p = reinterpret_cast<const uint4*>(base + (rr * static_cast<uint32_t>(ld) + g * KQ));
+#pragma unroll
+    for (int q = 0; q < KQD / 4; ++q) {
+#ifdef ALLSET_BF16_ABL_NOLOAD              // (tools/linear_bf16_ablation.py: the kernel without its row loads)
+      const uint4 v = make_uint4(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)) + q, 0x3f803f80u, 0u, 0x3f003f00u);
+#elif defined(ALLSET_BF16_ABL_PIECEMAP)    // (timing probe only, results wrong: the four lanes of a row read 64 contiguous bytes per instruction)
+      const uint4 v = (p - g * (KQD / 4))[4 * q + g];
+#else
+      const uint4 v = p[q];
+#endif
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+  };
+
+  // bit-mask form: the lane's columns g KQ + 16 q .. + 15 are bits 16 hb .. of word sq of the row (hb = column / 64,
+  // sq = (column % 64) / 16): one 2-byte load per 16 columns, MG of them per step, requested as soon as the previous ones are consumed
+  constexpr int MN = MASK == 1 ? KQD : (MASK == 2 ? MG : 1);
+  uint32_t bit_off[MG];
+#pragma unroll
+  for (int q = 0; q < MG; ++q) {
+    const int col0 = g * KQ + 16 * q;
+    bit_off[q] = ((col0 & 63) >> 4) * (KD / 32) + (col0 >> 6) * 2;
+  }
+  const uint8_t* bitrows = reinterpret_cast<const uint8_t*>(ymask);
+  auto request_bits = [&](uint32_t (&m)[MN], int64_t chunk) {
+    const int64_t c = chunk < n_chunks ? chunk : n_chunks - 1;
+    const int rh = rows_here(c);
+    const uint32_t rr = ri < rh ? ri : rh - 1;
+    const uint8_t* base = bitrows + c * 16 * (KD / 8);
+#pragma unroll
+    for (int q = 0; q < MG; ++q) m[q] = *reinterpret_cast<const uint16_t*>(base + (rr * static_cast<uint32_t>(KD / 8) + bit_off[q]));
+  };
+
+  // DEPTH register sets of rows in flight.  Measured (round 6, tools/linear_bf16_ablation.py): a third set in the forward
+  // (184 -> 222 registers) is SLOWER, 63 -> 70 us, and so is requesting the first rows before the weight image is staged
+  // (-DALLSET_BF16_EARLY_REQUEST: 54 -> 63 us) -- both kept as ablation arms only.
+#ifdef ALLSET_BF16_DEPTH3
+  constexpr int DEPTH = TRANS_W ? 2 : 3;
+#else
+  constexpr int DEPTH = 2;
+#endif
+  uint32_t a0[KQD], a1[KQD], a2[DEPTH == 3 ? KQD : 1];
+  uint32_t m0[MN];
+  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kBfWaves + wave;
+  auto first_requests = [&]() {
+    request(a0, x, ldx, chunk);
+    request(a1, x, ldx, chunk + stride);
+    if constexpr (DEPTH == 3) request(a2, x, ldx, chunk + 2 * stride);
+    if constexpr (HAS_MASK) request(m0, ymask, ldm, chunk);
+    if constexpr (MASK == 2) request_bits(m0, chunk);
+  };
+#ifdef ALLSET_BF16_EARLY_REQUEST
+  first_requests();
+#endif
 
   if constexpr (!TRANS_W) {
     // W[j][k]: 16-byte pieces copy straight into the image
@@ -129,57 +222,11 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
   }
   __syncthreads();
 
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: chunk indices and row bases stay scalar
-  const int ri = lane & 15, g = lane >> 4;
-  const int64_t n_chunks = (n + 15) / 16;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBfWaves;
-  uint32_t* slab = sSlab + wave * (16 * kSlabPitch);
-
-  // Addresses are a scalar row base per step (64-bit, in SGPRs) plus a 32-bit lane offset: 64-bit per-lane pointers for the
-  // six row-major operands cost ~20 VGPRs, which this kernel does not have.  Loads are unconditional on a clamped row
-  // (a branch around a load costs s_waitcnt vmcnt(0) at the join, which drains the prefetch); rows past n are zeroed when
-  // consumed.  `chunk` may run past the end (prefetch): clamped to the last step.
-  auto rows_here = [&](int64_t chunk) -> int {                 // rows of this step that exist (1..16); chunk < n_chunks
-    const int64_t left = n - chunk * 16;
-    return left < 16 ? static_cast<int>(left) : 16;
-  };
-  auto request = [&](uint32_t (&a)[KQD], const uint16_t* __restrict__ src, int64_t ld, int64_t chunk) {
-    const int64_t c = chunk < n_chunks ? chunk : n_chunks - 1;
-    const int rh = rows_here(c);
-    const uint32_t rr = ri < rh ? ri : rh - 1;
-    const uint16_t* base = src + c * 16 * ld;
-    const uint4* p = reinterpret_cast<const uint4*>(base + (rr * static_cast<uint32_t>(ld) + g * KQ));
-#pragma unroll
-    for (int q = 0; q < KQD / 4; ++q) {
-      const uint4 v = p[q];
-      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-    }
-  };
-
-  // bit-mask form: the lane's columns g KQ + 16 q .. + 15 are bits 16 hb .. of word sq of the row (hb = column / 64,
-  // sq = (column % 64) / 16): one 2-byte load per 16 columns, MG of them per step, one step ahead like the bf16 mask
-  constexpr int MN = MASK == 1 ? KQD : (MASK == 2 ? MG : 1);
-  uint32_t bit_off[MG];
-#pragma unroll
-  for (int q = 0; q < MG; ++q) {
-    const int col0 = g * KQ + 16 * q;
-    bit_off[q] = ((col0 & 63) >> 4) * (KD / 32) + (col0 >> 6) * 2;
-  }
-  const uint8_t* bitrows = reinterpret_cast<const uint8_t*>(ymask);
-  auto request_bits = [&](uint32_t (&m)[MN], int64_t chunk) {
-    const int64_t c = chunk < n_chunks ? chunk : n_chunks - 1;
-    const int rh = rows_here(c);
-    const uint32_t rr = ri < rh ? ri : rh - 1;
-    const uint8_t* base = bitrows + c * 16 * (KD / 8);
-#pragma unroll
-    for (int q = 0; q < MG; ++q) m[q] = *reinterpret_cast<const uint16_t*>(base + (rr * static_cast<uint32_t>(KD / 8) + bit_off[q]));
-  };
-
-  auto process = [&](uint32_t (&a)[KQD], uint32_t (&m)[MN], int64_t chunk) {
+  // ---- what happens to the rows of a step before the matrix phase: the relu mask (and the next mask request: `mask_next` is
+  // the step this mask buffer serves next), zeros for rows past the end, the four auxiliary output columns
+  auto prologue = [&](uint32_t (&a)[KQD], uint32_t (&m)[MN], int64_t chunk, int64_t mask_next) {
     const int rh = rows_here(chunk);
     const bool valid = ri < rh;
-    const uint32_t rr = valid ? ri : rh - 1;                      // a row of this step that exists
     if constexpr (MASK == 2) {
 #pragma unroll
       for (int q = 0; q < MG; ++q) {
@@ -192,7 +239,7 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      request_bits(m, chunk + stride);
+      request_bits(m, mask_next);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (HAS_MASK) {
@@ -205,18 +252,16 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
       }
       // ONE mask buffer: the next step's rows are requested as soon as this step's are consumed and have the whole matrix
       // phase and epilogue to arrive (the activation rows themselves are two steps ahead in two buffers)
-#ifndef ALLSET_BF16_LATE_MASK
       __builtin_amdgcn_sched_barrier(0);
-      request(m, ymask, ldm, chunk + stride);
+      request(m, ymask, ldm, mask_next);
       __builtin_amdgcn_sched_barrier(0);
-#endif
     }
     if (!valid) {
 #pragma unroll
       for (int j = 0; j < KQD; ++j) a[j] = 0u;
     }
     if constexpr (AUX_OUT) {
-      if (aux_out != nullptr) {
+      {
         // four extra output columns in plain fp32 FMAs from the rows already in registers ([n, K] x [K, 4] is all bandwidth)
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -239,17 +284,19 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
               make_float4(s0 + sAux[4 * KD], s1 + sAux[4 * KD + 1], s2 + sAux[4 * KD + 2], s3 + sAux[4 * KD + 3]);
       }
     }
-    // the gradient-branch rows and the logits' gradient of this step, requested before the matrix phase
-    uint2 accv[NTILE];
-    if (acc_in != nullptr) {
-      const uint16_t* ap = acc_in + chunk * 16 * ldacc + (rr * static_cast<uint32_t>(ldacc) + 4 * g);
-#pragma unroll
-      for (int tl = 0; tl < NTILE; ++tl) accv[tl] = *reinterpret_cast<const uint2*>(ap + tl * 16);
-    }
-    float4 ga4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_aux_in) ga4 = *reinterpret_cast<const float4*>(aux_in + chunk * 64 + rr * 4);
+  };
 
-    f32x4_b acc[NTILE];
+  // ---- matrix phase.  Swapped operands: D[i][j] = sum_k Wimg[col 16 tl + i][k] * x[row j][k]; a lane holds row (lane & 15),
+  // columns 4 g .. + 3 of every tile.  (Round 6, measured and dropped: the rows of TWO steps sharing every weight fragment --
+  // half the LDS reads -- left the matrix phase alone at 26.4 us against 28.6 and the whole launch 15 us SLOWER (the rows of the
+  // next step can only be requested once both steps' fragments are consumed): the phase is MFMA issue + the fixed weight staging,
+  // not LDS rate.  tools/linear_bf16_ablation.py, profiles/r06_bf16_linear_ablation.txt.)
+  auto matrix = [&](const uint32_t (&a)[KQD], f32x4_b (&acc)[NTILE]) {
+#ifdef ALLSET_BF16_ABL_NOMFMA               // (ablation: no matrix phase -- the accumulators take the rows' bits so that they stay live)
+#pragma unroll
+    for (int tl = 0; tl < NTILE; ++tl)
+      acc[tl] = f32x4_b{__uint_as_float(a[(2 * tl) % KQD]), __uint_as_float(a[(2 * tl + 1) % KQD]), __uint_as_float(a[(2 * tl + 7) % KQD]), 0.f};
+#else
 #pragma unroll
     for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4_b{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -261,29 +308,48 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
         FragB b0, b1;
         b0.u = *reinterpret_cast<const uint4*>(&sW[wimg_off<KQD, GS>(g, tl * 16 + ri, t)]);
         b1.u = *reinterpret_cast<const uint4*>(&sW[wimg_off<KQD, GS>(g, tl * 16 + 16 + ri, t)]);
-        // swapped operands: D[i][j] = sum_k Wimg[col 16 tl + i][k] * x[row j][k]; lane holds row (lane & 15), columns 4 g .. +3
         acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0.v, fa.v, acc[tl], 0, 0, 0);
         acc[tl + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1.v, fa.v, acc[tl + 1], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    request(a, x, ldx, chunk + 2 * stride);
-#ifdef ALLSET_BF16_LATE_MASK
-    if constexpr (HAS_MASK) request(m, ymask, ldm, chunk + stride);
 #endif
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- epilogue: 64 columns (4 tiles) per trip through the slab
-    const int srow = lane >> 2, sq = lane & 3;
+  };
+  // ---- epilogue: bias / the logits' rank-4 term / the other gradient branch / relu in fp32 on the accumulators, ONE rounding
+  // to bf16, then (round 6) the lanes of a row trade their 8-byte pieces in registers -- v_permlane16_swap pairs up the tiles of
+  // neighbouring 16-lane rows, v_permlane32_swap the pairs -- so that lane (ri, g) ends up with the 16 consecutive columns
+  // 64 hb + 16 g .. of row ri and a row leaves as whole 128-byte segments.  No LDS slab, no lgkmcnt round trips (the slab form,
+  // -DALLSET_BF16_SLAB_EPILOGUE, cost 13 us of LDS waits per launch beside the stores themselves).
+  auto epilogue = [&](auto with_acc, f32x4_b (&acc)[NTILE], int64_t chunk, const uint2 (&accv)[decltype(with_acc)::value ? NTILE : 1], const float4& ga4) {
+    constexpr bool WITH_ACC = decltype(with_acc)::value;
+    const int rh = rows_here(chunk);
+#ifdef ALLSET_BF16_ABL_NOEPI                // (ablation: no epilogue; one never-true store keeps the accumulators live)
+    {
+      float sacc = 0.f;
+#pragma unroll
+      for (int tl = 0; tl < NTILE; ++tl) sacc += acc[tl][0] + acc[tl][1] + acc[tl][2] + acc[tl][3];
+      if (sacc == 1.2345e-30f) y[chunk] = 1;
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
+#endif
     uint32_t mword[ND / 128] = {};
+#ifdef ALLSET_BF16_SLAB_EPILOGUE
+    const int srow = lane >> 2, sq = lane & 3;
+#else
+    const int srow = ri, sq = g;
+#endif
 #pragma unroll
     for (int hb = 0; hb < ND / 64; ++hb) {
+      uint2 pk[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int tl = hb * 4 + tt;
         const int c = tl * 16 + 4 * g;
-        const float4 bv = *reinterpret_cast<const float4*>(&sBias[c]);
-        float v0 = acc[tl][0] + bv.x, v1 = acc[tl][1] + bv.y, v2 = acc[tl][2] + bv.z, v3 = acc[tl][3] + bv.w;
+        float v0 = acc[tl][0], v1 = acc[tl][1], v2 = acc[tl][2], v3 = acc[tl][3];
+        if constexpr (!TRANS_W) {                  // (backward-data has no bias and no relu)
+          const float4 bv = *reinterpret_cast<const float4*>(&sBias[c]);
+          v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+        }
         if (has_aux_in) {
           const float4 w0 = *reinterpret_cast<const float4*>(&sAux[0 * AUXW + c]);
           const float4 w1 = *reinterpret_cast<const float4*>(&sAux[1 * AUXW + c]);
@@ -294,34 +360,62 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
           v2 = fmaf(ga4.x, w0.z, fmaf(ga4.y, w1.z, fmaf(ga4.z, w2.z, fmaf(ga4.w, w3.z, v2))));
           v3 = fmaf(ga4.x, w0.w, fmaf(ga4.y, w1.w, fmaf(ga4.z, w2.w, fmaf(ga4.w, w3.w, v3))));
         }
-        if (acc_in != nullptr) {
-          v0 += __uint_as_float(accv[tl].x << 16); v1 += __uint_as_float(accv[tl].x & 0xffff0000u);
-          v2 += __uint_as_float(accv[tl].y << 16); v3 += __uint_as_float(accv[tl].y & 0xffff0000u);
+        if constexpr (WITH_ACC) {
+          if (has_acc) {
+            v0 += __uint_as_float(accv[tl].x << 16); v1 += __uint_as_float(accv[tl].x & 0xffff0000u);
+            v2 += __uint_as_float(accv[tl].y << 16); v3 += __uint_as_float(accv[tl].y & 0xffff0000u);
+          }
         }
-        if (relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        *reinterpret_cast<uint2*>(&slab[ri * kSlabPitch + tt * 8 + 2 * g]) = make_uint2(cvt_pk_bf16(v0, v1), cvt_pk_bf16(v2, v3));
+        if constexpr (!TRANS_W) { v0 = fmaxf(v0, relu_floor); v1 = fmaxf(v1, relu_floor); v2 = fmaxf(v2, relu_floor); v3 = fmaxf(v3, relu_floor); }
+        pk[tt] = make_uint2(cvt_pk_bf16(v0, v1), cvt_pk_bf16(v2, v3));
       }
+      uint4 o0, o1;
+#ifdef ALLSET_BF16_SLAB_EPILOGUE
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<uint2*>(&slab[ri * kSlabPitch + tt * 8 + 2 * g]) = pk[tt];
       // one wave, in-order LDS queue: no barrier needed, but the compiler must not move the reads above the writes nor the
       // next trip's writes above these reads
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint4 o0 = *reinterpret_cast<const uint4*>(&slab[srow * kSlabPitch + sq * 8]);
-      const uint4 o1 = *reinterpret_cast<const uint4*>(&slab[srow * kSlabPitch + sq * 8 + 4]);
+      o0 = *reinterpret_cast<const uint4*>(&slab[srow * kSlabPitch + sq * 8]);
+      o1 = *reinterpret_cast<const uint4*>(&slab[srow * kSlabPitch + sq * 8 + 4]);
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+      {
+        // level 1: odd 16-lane rows of tile 0 (2) <-> even rows of tile 1 (3): lane g = 0 / 2 keeps tile 0's columns 0-7 / 8-15,
+        // lane g = 1 / 3 tile 1's (likewise tiles 2, 3)
+        const swap2_t x01 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+        const swap2_t y01 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+        const swap2_t x23 = __builtin_amdgcn_permlane16_swap(pk[2].x, pk[3].x, false, false);
+        const swap2_t y23 = __builtin_amdgcn_permlane16_swap(pk[2].y, pk[3].y, false, false);
+        // q01 = {x01[0], y01[0], x01[1], y01[1]}: 8 consecutive columns; level 2: the upper 32 lanes of (tiles 0, 1) <-> the lower
+        // 32 of (tiles 2, 3): lane g holds tile g: columns 0-7 in o0, 8-15 in o1
+        const swap2_t s0 = __builtin_amdgcn_permlane32_swap(x01[0], x23[0], false, false);
+        const swap2_t s1 = __builtin_amdgcn_permlane32_swap(y01[0], y23[0], false, false);
+        const swap2_t s2 = __builtin_amdgcn_permlane32_swap(x01[1], x23[1], false, false);
+        const swap2_t s3 = __builtin_amdgcn_permlane32_swap(y01[1], y23[1], false, false);
+        o0 = make_uint4(s0[0], s1[0], s2[0], s3[0]);
+        o1 = make_uint4(s0[1], s1[1], s2[1], s3[1]);
+      }
+#endif
+#ifdef ALLSET_BF16_ABL_NOSTORE              // (ablation: the epilogue without its global stores)
+      if (srow < rh && o0.x == 0x12345678u && o1.w == 0x9abcdef0u) y[chunk] = 1;
+#else
       if (srow < rh) {
         uint4* dst = reinterpret_cast<uint4*>(y + chunk * 16 * ldy + (srow * static_cast<uint32_t>(ldy) + sq * 16 + hb * 64));
         dst[0] = o0;
         dst[1] = o1;
       }
-      if constexpr (MASK == 0 && !TRANS_W) {
-        if (mask_out != nullptr) {                  // the relu mask of these 16 columns: bits 16 hb .. of this lane's word sq
+#endif
+      if constexpr (MASK_OUT) {
+        {                                           // the relu mask of these 16 columns: bits 16 hb .. of this lane's word sq
           const uint32_t b16 = relu_bits16(o0, o1);
           if (hb & 1) mword[hb >> 1] |= b16 << 16;
           else mword[hb >> 1] = b16;
         }
       }
-      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if constexpr (MASK == 0 && !TRANS_W) {
-      if (mask_out != nullptr && srow < rh) {
+    if constexpr (MASK_OUT) {
+      if (srow < rh) {
         uint8_t* mp = mask_out + chunk * 16 * (ND / 8) + (srow * static_cast<uint32_t>(ND / 8) + sq * (ND / 32));
         if constexpr (ND == 256) *reinterpret_cast<uint2*>(mp) = make_uint2(mword[0], mword[1]);
         else *reinterpret_cast<uint32_t*>(mp) = mword[0];
@@ -330,20 +424,55 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  uint32_t a0[KQD], a1[KQD];
-  uint32_t m0[MN];
-  int64_t chunk = static_cast<int64_t>(blockIdx.x) * kBfWaves + wave;
-  request(a0, x, ldx, chunk);
-  request(a1, x, ldx, chunk + stride);
-  if constexpr (HAS_MASK) request(m0, ymask, ldm, chunk);
-  if constexpr (MASK == 2) request_bits(m0, chunk);
-  // (two chunks per trip, the odd last chunk peeled: a conditional second half makes the compiler wait vmcnt(0) at the loop
+  auto load_ga4 = [&](int64_t chunk) -> float4 {
+    if (!has_aux_in) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int rh = rows_here(chunk);
+    const uint32_t rr = ri < rh ? ri : rh - 1;
+    return *reinterpret_cast<const float4*>(aux_in + chunk * 64 + rr * 4);
+  };
+
+  // one step: prologue, the other gradient branch's rows requested before the matrix phase, matrix phase, the rows of the step
+  // after next requested into the registers the matrix phase has just freed, epilogue
+  auto process = [&](uint32_t (&a)[KQD], uint32_t (&m)[MN], int64_t chunk, int ahead) {
+    prologue(a, m, chunk, chunk + stride);
+    uint2 accv[(TRANS_W && (RT || EXTRA)) ? NTILE : 1];
+    if constexpr (TRANS_W && (RT || EXTRA)) {   // (the other gradient branch: backward-data only)
+      if (has_acc) {
+        const int rh = rows_here(chunk);
+        const uint32_t rr = ri < rh ? ri : rh - 1;
+        const uint16_t* ap = acc_in + chunk * 16 * ldacc + (rr * static_cast<uint32_t>(ldacc) + 4 * g);
+#pragma unroll
+        for (int tl = 0; tl < NTILE; ++tl) accv[tl] = *reinterpret_cast<const uint2*>(ap + tl * 16);
+      }
+    }
+    const float4 ga4 = load_ga4(chunk);
+    f32x4_b acc[NTILE];
+    matrix(a, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    request(a, x, ldx, chunk + ahead * stride);
+    __builtin_amdgcn_sched_barrier(0);
+    epilogue(std::integral_constant<bool, TRANS_W && (RT || EXTRA)>{}, acc, chunk, accv, ga4);
+  };
+#ifndef ALLSET_BF16_EARLY_REQUEST
+  first_requests();
+#endif
+  // (DEPTH chunks per trip, the last ones peeled: a conditional second half makes the compiler wait vmcnt(0) at the loop
   // header -- see fused_mlp.hip)
-  for (; chunk + stride < n_chunks; chunk += 2 * stride) {
-    process(a0, m0, chunk);
-    process(a1, m0, chunk + stride);
+  if constexpr (DEPTH == 3) {
+    for (; chunk + 2 * stride < n_chunks; chunk += 3 * stride) {
+      process(a0, m0, chunk, DEPTH);
+      process(a1, m0, chunk + stride, DEPTH);
+      process(a2, m0, chunk + 2 * stride, DEPTH);
+    }
+    if (chunk < n_chunks) process(a0, m0, chunk, DEPTH);
+    if (chunk + stride < n_chunks) process(a1, m0, chunk + stride, DEPTH);
+  } else {
+    for (; chunk + stride < n_chunks; chunk += 2 * stride) {
+      process(a0, m0, chunk, DEPTH);
+      process(a1, m0, chunk + stride, DEPTH);
+    }
+    if (chunk < n_chunks) process(a0, m0, chunk, DEPTH);
   }
-  if (chunk < n_chunks) process(a0, m0, chunk);
 }
 
 static inline bool bf16_width(int64_t w) { return w == 128 || w == 256; }
@@ -362,17 +491,23 @@ static void launch_bf16(int mask_mode, bool aux_out, unsigned grid, hipStream_t 
                         const uint16_t* bias, int relu_out, const uint16_t* aux_w, const uint16_t* aux_b, float* aux_o,
                         const float* aux_in, const uint16_t* acc_in, int64_t ldacc, uint16_t* y, int64_t ldy, uint8_t* mask_out,
                         int64_t n) {
-#define ALLSET_BF16_GO(MASK, AUXO)                                                                                       \
-  linear_bf16_kernel<KD, ND, TRANS_W, MASK, AUXO><<<grid, kBfBlock, 0, st>>>(x, ldx, ymask, ldm, a_out, lda, W, bias,   \
-                                                                              relu_out, aux_w, aux_b, aux_o, aux_in,    \
-                                                                              acc_in, ldacc, y, ldy, mask_out, n)
+#define ALLSET_BF16_GO(MASK, AUXF, EXTRA)                                                                               \
+  linear_bf16_kernel<KD, ND, TRANS_W, MASK, AUXF, EXTRA><<<grid, kBfBlock, 0, st>>>(x, ldx, ymask, ldm, a_out, lda, W,  \
+                                                                                     bias, relu_out, aux_w, aux_b,      \
+                                                                                     aux_o, aux_in, acc_in, ldacc, y,   \
+                                                                                     ldy, mask_out, n)
   if constexpr (!TRANS_W) {
-    if (aux_out) ALLSET_BF16_GO(0, true);
-    else ALLSET_BF16_GO(0, false);
+    if (aux_out) ALLSET_BF16_GO(0, true, false);
+    else if (mask_out != nullptr) ALLSET_BF16_GO(0, false, true);
+    else ALLSET_BF16_GO(0, false, false);
   } else {
-    if (mask_mode == 2) ALLSET_BF16_GO(2, false);
-    else if (mask_mode == 1) ALLSET_BF16_GO(1, false);
-    else ALLSET_BF16_GO(0, false);
+    const bool acc = acc_in != nullptr, axi = aux_in != nullptr;
+    if (mask_mode == 2) { if (acc) ALLSET_BF16_GO(2, false, true); else ALLSET_BF16_GO(2, false, false); }
+    else if (mask_mode == 1) ALLSET_BF16_GO(1, false, false);
+    else if (acc && axi) ALLSET_BF16_GO(0, true, true);
+    else if (acc) ALLSET_BF16_GO(0, false, true);
+    else if (axi) ALLSET_BF16_GO(0, true, false);
+    else ALLSET_BF16_GO(0, false, false);
   }
 #undef ALLSET_BF16_GO
 }

@@ -202,23 +202,42 @@ template <> __device__ __forceinline__ float fold_ld<uint16_t>(const uint16_t* p
 __device__ __forceinline__ void fold_st(float* p, int64_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void fold_st(uint16_t* p, int64_t i, float v) { p[i] = static_cast<uint16_t>(cvt_pk_bf16(v, 0.f) & 0xffffu); }
 
+// One workgroup per (h, 64 columns): 64 column lanes x 4 row groups, each thread sums C / 4 rows with independent loads, the four
+// partial sums meet in LDS (round 6: the one-thread-per-output form walked C dependent loads -- 21 us at C = 64, K = 256, twice
+// per AllSetTransformer layer and step).  The last workgroup (blockIdx.x == H * ceil(K / 64)) folds the bias.
 template <typename T>
 __global__ __launch_bounds__(256) void pma_fold_fwd_kernel(const T* __restrict__ Wk, const T* __restrict__ bk,
                                                           const T* __restrict__ att, T* __restrict__ w,
                                                           T* __restrict__ b, int H, int C, int K) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // (h, k) pairs, then H bias entries
-  if (idx < H * K) {
-    const int h = idx / K, k = idx % K;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(fold_ld(Wk, static_cast<int64_t>(h * C + c) * K + k), fold_ld(att, h * C + c), s);
-    fold_st(w, idx, s);
-  } else if (idx < H * K + H) {
-    const int h = idx - H * K;
-    float s = 0.f;
-    if (bk != nullptr)
-      for (int c = 0; c < C; ++c) s = fmaf(fold_ld(bk, h * C + c), fold_ld(att, h * C + c), s);
-    fold_st(b, h, s);
+  __shared__ float red[4][64];
+  const int kb = (K + 63) / 64;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (static_cast<int>(blockIdx.x) == H * kb) {              // b[h] = sum_c bk[h C + c] att[h, c]: wave `grp` takes heads grp, grp + 4, ..
+    for (int h = grp; h < H; h += 4) {
+      float s = 0.f;
+      if (bk != nullptr)
+        for (int c = lane; c < C; c += 64) s = fmaf(fold_ld(bk, h * C + c), fold_ld(att, h * C + c), s);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) fold_st(b, h, s);
+    }
+    return;
   }
+  const int h = blockIdx.x / kb, k = (blockIdx.x % kb) * 64 + lane;
+  float s = 0.f;
+  if (k < K) {
+    int c = grp;
+    for (; c + 12 < C; c += 16) {                           // four independent loads in flight per thread
+      const float w0 = fold_ld(Wk, static_cast<int64_t>(h * C + c) * K + k), w1 = fold_ld(Wk, static_cast<int64_t>(h * C + c + 4) * K + k);
+      const float w2 = fold_ld(Wk, static_cast<int64_t>(h * C + c + 8) * K + k), w3 = fold_ld(Wk, static_cast<int64_t>(h * C + c + 12) * K + k);
+      s = fmaf(w0, fold_ld(att, h * C + c), s); s = fmaf(w1, fold_ld(att, h * C + c + 4), s);
+      s = fmaf(w2, fold_ld(att, h * C + c + 8), s); s = fmaf(w3, fold_ld(att, h * C + c + 12), s);
+    }
+    for (; c < C; c += 4) s = fmaf(fold_ld(Wk, static_cast<int64_t>(h * C + c) * K + k), fold_ld(att, h * C + c), s);
+  }
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && k < K) fold_st(w, h * K + k, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // gWk[h C + c, k] = gw[h, k] att[h, c];  gbk[h C + c] = gb[h] att[h, c];  gatt[h, c] = sum_k gw[h, k] Wk[h C + c, k] + gb[h] bk[h C + c]
@@ -255,7 +274,7 @@ template <typename T>
 static int pma_fold_fwd_impl(const T* Wk, const T* bk, const T* att, T* w, T* b, int64_t H, int64_t C, int64_t K, void* stream) {
   ALLSET_REQUIRE(H >= 1 && C >= 1 && K >= 1 && H * K < (int64_t{1} << 30), "pma_fold_fwd: bad size");
   ALLSET_REQUIRE(Wk && att && w && b, "pma_fold_fwd: null pointer");
-  const unsigned grid = static_cast<unsigned>((H * K + H + 255) / 256);
+  const unsigned grid = static_cast<unsigned>(H * ((K + 63) / 64) + 1);
   allset::pma_fold_fwd_kernel<T><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(Wk, bk, att, w, b, static_cast<int>(H), static_cast<int>(C),
                                                                                static_cast<int>(K));
   ALLSET_LAUNCH_CHECK();

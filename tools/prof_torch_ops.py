@@ -29,9 +29,9 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 30]
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.device_time_total > 2]
 rows.sort(key=lambda e: -e.device_time_total)
-for e in rows[:25]:
+for e in rows[:40]:
     print(f"{e.key:28s} n={e.count:3d} dev_us={e.device_time_total:9.0f}  shapes={str(e.input_shapes)[:110]}")
 if a.all:
     ks = [e for e in prof.key_averages() if e.device_time_total > 20 and not e.key.startswith("aten::")]
