@@ -205,11 +205,14 @@ class _PmaAggregate(torch.autograd.Function):
         ctx.inc, ctx.slope = inc, slope
         ctx.save_for_backward(V, alpha, out, m, l)
         ctx.mark_non_differentiable(m, l)
+        ctx.set_materialize_grads(False)     # (m, l never carry a gradient: no [n, H] zero-fills for them in every backward)
         return out, m, l
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout: Tensor, _gm, _gl):
+        if gout is None:
+            return None, None, None, None, None
         V, alpha, out, m, l = ctx.saved_tensors
         T = ctx.inc.by_src
         gout = gout.contiguous()
@@ -244,12 +247,15 @@ class _PmaPoolLn0(torch.autograd.Function):
         ctx.inc, ctx.slope, ctx.cshape = inc, slope, att_r.shape
         ctx.save_for_backward(V, alpha, pooled, m, l, cb, stats, gamma, beta)
         ctx.mark_non_differentiable(m, l)
+        ctx.set_materialize_grads(False)     # (m, l never carry a gradient: no [n, H] zero-fills for them in every backward)
         return y, m, l
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _gm, _gl):
         from . import dense
+        if gy is None:
+            return (None,) * 9
         V, alpha, pooled, m, l, cb, stats, gamma, beta = ctx.saved_tensors
         g_pooled, dg, db, dc, pstats = dense.ln_res_bwd_pma(gy.contiguous(), pooled, cb, stats, gamma, beta, m, l)
         T = ctx.inc.by_src
@@ -276,12 +282,15 @@ class _PmaPoolTail(torch.autograd.Function):
         ctx.inc, ctx.slope, ctx.cshape, ctx.cfg = inc, slope, att_r.shape, cfg
         ctx.save_for_backward(V, alpha, m, l, *saved)
         ctx.mark_non_differentiable(m, l)
+        ctx.set_materialize_grads(False)     # (m, l never carry a gradient: no [n, H] zero-fills for them in every backward)
         return y, m, l
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _gm, _gl):
         from . import dense
+        if gy is None:
+            return (None,) * 18
         V, alpha, m, l = ctx.saved_tensors[:4]
         g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats = dense.pma_tail_bwd(ctx.saved_tensors[4:], ctx.cfg, gy, m, l)
         T = ctx.inc.by_src
