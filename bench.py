@@ -68,6 +68,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 matrix-pipe peak (same guide; never the 2:1-sparsity headline figure)
 COPY_CEILING_GBS = 6300.0  # measured streaming-copy ceiling, same guide
 AGG_KERNELS = ("segreduce_fwd", "segmax_bwd", "sddmm_rowdot", "pma_fwd", "pma_bwd_stats", "pma_bwd_src")
 
@@ -369,8 +370,14 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
         v2e.to(tdt); e2v.to(tdt)
     params = list(v2e.parameters()) + list(e2v.parameters())
     graph_mode = bool(getattr(args, "hip_graph", False)) and on_gpu and world == 1
-    # same Adam math, one multi-tensor kernel for the 24 small parameters (capturable: its step counters live on the device)
-    opt = torch.optim.Adam(params, lr=1e-3, fused=on_gpu, capturable=graph_mode)
+    # Adam as the product's training driver runs it (allset_amd/train.py: allset_amd.optim.FusedAdam -- torch.optim.Adam's update, one
+    # launch for all 24 parameters, step counters on the device, so capturable by construction; tests/test_gpu_dense.py pins its
+    # trajectories to torch.optim.Adam's); the host-only plumbing run keeps torch.optim.Adam
+    if on_gpu:
+        from allset_amd.optim import FusedAdam
+        opt = FusedAdam(params, lr=1e-3)
+    else:
+        opt = torch.optim.Adam(params, lr=1e-3)
 
     gen = torch.Generator(device=dev).manual_seed(args.seed + 100 + rank)
     rows = hg.v_hi - hg.v_lo
@@ -529,14 +536,29 @@ def region_label(args, key, world):
     return label
 
 
-def kernel_entry(v, steps, rows=None, d=None, name=None):
+# 16-bit matrix-pipe products per fp32 product in the GEMM kernels: fp16x3 (two scaled fp16 planes, three partial products) under the
+# default arithmetic, bf16x6 (three bf16 planes, six) under --arith strict; a bf16 tensor is one product.
+GEMM_KERNELS = {"fused_linear_fwd": 1.0, "fused_linear_bwd": 1.0, "wgrad_fused": 1.0, "wgrad": 1.0, "fused_linear_bwd_all": 2.0,
+                "gemm_x6": 1.0, "gemm_x6_lnb": 1.0, "linear_bf16_fwd": 1.0, "linear_bf16_bwd": 1.0}
+
+
+def kernel_entry(v, steps, rows=None, d=None, name=None, products=None):
+    """One timed kernel: achieved algorithmic GB/s against the HBM peak and -- for the GEMM kernels -- its matrix-pipe rate against
+    the dense 16-bit MFMA peak; `bound` names the roof that is nearer for this kernel's flop / byte (at d = 512 the fp16x3 GEMMs do
+    3 x 128 flop per byte: the matrix pipe, not HBM), `roof_frac` the fraction of THAT roof."""
     gbps = (v["algo_bytes"] / (v["avg_ms"] * 1e-3) / 1e9) if v.get("algo_bytes") else None
     out = {"calls_per_step": v["calls"] / steps, "avg_ms": v["avg_ms"], "algo_bytes_per_launch": v.get("algo_bytes") or None,
            "gbps": gbps, "frac": gbps / HBM_PEAK_GBS if gbps else None,
            "frac_of_copy_ceiling": gbps / COPY_CEILING_GBS if gbps else None}
-    if rows is not None and name in ("fused_linear_fwd", "fused_linear_bwd", "wgrad_fused", "wgrad", "fused_linear_bwd_all"):
-        mult = 2.0 if name == "fused_linear_bwd_all" else 1.0
-        out["tflops"] = mult * 2.0 * rows * d * d / (v["avg_ms"] * 1e-3) / 1e12
+    if rows is not None and name in GEMM_KERNELS:
+        flops = GEMM_KERNELS[name] * 2.0 * rows * d * d                    # fp32-equivalent
+        out["tflops"] = flops / (v["avg_ms"] * 1e-3) / 1e12
+        if products and gbps:
+            out["mfma_tflops"] = products * out["tflops"]                     # what the matrix pipe actually executes
+            out["mfma_frac"] = out["mfma_tflops"] / MFMA16_PEAK_TFLOPS
+            t_hbm, t_mfma = v["algo_bytes"] / (HBM_PEAK_GBS * 1e9), products * flops / (MFMA16_PEAK_TFLOPS * 1e12)
+            out["bound"] = "mfma" if t_mfma > t_hbm else "hbm"
+            out["roof_frac"] = max(t_hbm, t_mfma) / (v["avg_ms"] * 1e-3)
     return out
 
 
@@ -701,6 +723,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
         return None
     res = results[value_key]
     d, attn = args.d, args.model == "pma"
+    products = 1.0 if args.dtype == "bf16" else (6.0 if args.arith in ("strict", "bf16x6") else 3.0)     # (GEMM_KERNELS)
     ks = res["kernels"]
     agg_ks = {k: v for k, v in ks.items() if k in AGG_KERNELS}                   # HBM-bound gather kernels
     dense_ks = {k: v for k, v in ks.items() if k not in AGG_KERNELS}             # dense tail (MFMA / streaming)
@@ -737,7 +760,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
                             "served by the 256 MiB Infinity Cache (FETCH_SIZE counts at the L2's fabric side, cache hits "
                             "included); DRAM-only bytes are not exposed by rocprofv3 on gfx950",
                     "algo_bytes_per_launch": seg["algo_bytes"], "avg_launch_ms": seg["avg_ms"], "launches": seg["calls"],
-                    "per_kernel": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in ks.items() if v.get("algo_bytes")}}
+                    "per_kernel": {k: kernel_entry(v, args.steps, res["rows"], d, k, products) for k, v in ks.items() if v.get("algo_bytes")}}
     nnz_total = res["nnz_total"]
     line = {
         "metric": "edges*d aggregated / sec (V->E->V layer fwd+bwd)", "value": res["value"], "unit": "edges*d/s",
@@ -783,7 +806,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
                        ("HIP dense-tail kernels per step, bf16 in / out with fp32 accumulation: Linear forward / backward-data "
                         "with relu, folded logits, relu mask and gradient-branch sums in the same pass (csrc/fused_bf16.hip), "
                         "full-width weight gradient, add+LayerNorm kernels; gbps = algorithmic activation bytes / time"),
-                       "kernels": {k: kernel_entry(v, args.steps, res["rows"], d, k) for k, v in dense_ks.items()}},
+                       "kernels": {k: kernel_entry(v, args.steps, res["rows"], d, k, products) for k, v in dense_ks.items()}},
     }
     if dist.is_initialized():
         line["config"]["collectives"] = ("gloo, device tensors staged through the host, ranks may share a device (test mode)"
@@ -830,7 +853,7 @@ def assemble_line(args, world, primary, state, cpu_mode=False, final=True):
                           "note": "the same K steps in the same run with allset_amd.dense.set_arithmetic('strict') "
                                   "(ALLSET_ARITH_BF16X6: every fused Linear on the exact three-bf16-plane split, no dependence on the "
                                   "data's dynamic range); `value` is the default (AUTO) arithmetic's",
-                          "kernels": {k: kernel_entry(v, args.steps, strict["rows"], d, k) for k, v in sks.items()}}
+                          "kernels": {k: kernel_entry(v, args.steps, strict["rows"], d, k, 6.0) for k, v in sks.items()}}
     elif "strict" in errors:
         line["strict"] = {"error": errors["strict"]}
     line["cpu_baseline"] = state.get("cpu_baseline")
