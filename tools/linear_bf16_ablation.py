@@ -4,7 +4,8 @@ kernel without its row loads / matrix phase / LDS weight-fragment reads / epilog
 per-GPU call ([250000, 256] x [256, 256], forward + the bit-masked backward-data).
 
   python tools/linear_bf16_ablation.py --build-only     in the build container: leaves .abl/bf16_<arm>.so (travels with gpurun)
-  python tools/linear_bf16_ablation.py [rows]           on the GPU box
+  python tools/linear_bf16_ablation.py [rows] [--warm]  on the GPU box (default: COLD operands, 1 GiB written between two launches;
+                                                        --warm: the same operands back to back, served by the Infinity Cache)
 Extra arms: ALLSET_BF16_ABL_EXTRA="name:-DFLAG -DFLAG2;name2:-DFLAG3"."""
 import ctypes, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,6 +50,7 @@ if "--build-only" in sys.argv:
 import torch
 dev = torch.device("cuda:0")
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
+WARM = "--warm" in sys.argv          # back-to-back launches on the same operands (they stay in the 256-MiB Infinity Cache)
 n = int(args[0]) if args else 250000
 K = N = 256
 g = torch.Generator().manual_seed(0)
@@ -60,7 +62,8 @@ bits = torch.randint(0, 256, (n, N // 8), dtype=torch.uint8, device=dev)
 acc = torch.randn(n, K, generator=g).to(torch.bfloat16).to(dev)
 P, I64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 flush = torch.zeros(256 * 1024 * 1024, dtype=torch.int32, device=dev)
-print(f"[{n}, {K}] x [{K}, {N}] bf16; one read + one write at 6.3 TB/s = {n * (K + N) * 2 / 6.3e12 * 1e6:.0f} us")
+print(f"[{n}, {K}] x [{K}, {N}] bf16, {'warm' if WARM else 'cold'} operands, one launch per HIP-event pair (~5 us of event overhead included); "
+      f"one read + one write at 6.3 TB/s = {n * (K + N) * 2 / 6.3e12 * 1e6:.0f} us")
 for name, _ in ARMS:
     if not os.path.exists(so_of(name)):
         print(f"{name}: not built (run with --build-only in the build container)")
@@ -94,7 +97,8 @@ for name, _ in ARMS:
         for _ in range(12):
             # COLD operands, as inside a training step: 1 GiB written between two launches empties the 256-MiB Infinity Cache
             # (back-to-back launches on the same 256 MB of operands run 10-20 us faster than the same kernel does in the step)
-            flush.add_(1)
+            if not WARM:
+                flush.add_(1)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); run(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
         out.append(statistics.median(ts) * 1e3)

@@ -43,6 +43,19 @@ timeout 600 python bench.py --d 256 --no-cpu-baseline > $OUT/${TAG}_d256_bench_l
 timeout 600 python bench.py --dtype bf16 --d 256 --model pma --degree-dist zipf --n-per-gpu 250000 --no-cpu-baseline --partitions primary > $OUT/${TAG}_c5_shape_bench_line.json 2>/dev/null
 timeout 600 python bench.py --dtype bf16 --d 256 --model pma --degree-dist zipf --n-per-gpu 250000 --no-cpu-baseline --partitions primary --hip-graph > $OUT/${TAG}_c5_shape_graph_bench_line.json 2>/dev/null
 python tools/bench_summary.py $OUT/${TAG}_d256_bench_line.json $OUT/${TAG}_c5_shape_bench_line.json $OUT/${TAG}_c5_shape_graph_bench_line.json | grep -v "^    "
+timeout 600 python bench.py --d 512 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_d512_bench_line.json 2>/dev/null
+# configs[4] per-GPU shape: the rocprofv3 summary of the same command, the gather kernels' HBM-traffic passes (stamped), the bf16 Linear's ablation arms
+rm -rf $OUT/prof_${TAG}_c5
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_c5 -- python bench.py --dtype bf16 --d 256 --model pma --degree-dist zipf --n-per-gpu 250000 --steps 20 --warmup 5 --no-cpu-baseline --partitions primary > $OUT/${TAG}_c5_traced_bench_line.json 2>/dev/null
+S=$(find $OUT/prof_${TAG}_c5 -name '*kernel_stats.csv' | head -1); cp "$S" $OUT/${TAG}_c5_kernel_stats.csv; head -14 $OUT/${TAG}_c5_kernel_stats.csv | cut -c1-150
+rm -rf $OUT/prof_${TAG}_c5
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/pmc_c5_$c
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_c5_$c -- python tools/pmc_probe_c5.py > $OUT/pmc_c5_$c.log 2>&1
+done
+python tools/traffic_json.py c5 $OUT/pmc_c5_FETCH_SIZE $OUT/pmc_c5_WRITE_SIZE; cp profiles/hbm_traffic_c5.json $OUT/profiles_new/
+find $OUT/pmc_c5_* -name '*kernel_trace.csv' -delete; find $OUT/pmc_c5_* -name '*counter_collection.csv' -delete
+(python tools/linear_bf16_ablation.py; python tools/linear_bf16_ablation.py --warm) > $OUT/${TAG}_bf16_linear_ablation.txt 2>&1; grep -c "us" $OUT/${TAG}_bf16_linear_ablation.txt
 timeout 600 python tools/preprocess_bench.py > $OUT/${TAG}_preprocess_bench.txt 2>&1; tail -3 $OUT/${TAG}_preprocess_bench.txt
 timeout 600 python tools/small_graph_step.py > $OUT/${TAG}_small_graph_step.txt 2>&1; tail -12 $OUT/${TAG}_small_graph_step.txt
 echo finished
