@@ -1123,12 +1123,14 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_bf16_tr_kernel(
       if (32 * PA / 16 % kWx6Block == 0 || p < 32 * PA / 16) {
         uint4 v = sg.a[k];
         if constexpr (MASKED) {
-          const int f = static_cast<int>(sg.am[k]);
-          auto keep = [&](int i) {
-            return (static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i, 1)) & 0x0000ffffu) |
-                   (static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i + 1, 1)) & 0xffff0000u);
+          // bit 2 i -> bit 0, bit 2 i + 1 -> bit 16 of (sp >> 2 i): the two halves' 0 / 1 factors of dword i (as in fused_bf16.hip)
+          const uint32_t sp = sg.am[k] | (sg.am[k] << 15);
+          auto keep = [&](uint32_t a, int i) {
+            uint32_t r;
+            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"((sp >> (2 * i)) & 0x00010001u));
+            return r;
           };
-          v.x &= keep(0); v.y &= keep(1); v.z &= keep(2); v.w &= keep(3);
+          v.x = keep(v.x, 0); v.y = keep(v.y, 1); v.z = keep(v.z, 2); v.w = keep(v.w, 3);
         }
         *reinterpret_cast<uint4*>(ba + wtr_off<PA>(row, c16 * 16)) = (r0 + row < r_end) ? v : make_uint4(0u, 0u, 0u, 0u);
       }

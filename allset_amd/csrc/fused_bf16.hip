@@ -62,8 +62,15 @@ typedef unsigned short bf_us2_t __attribute__((ext_vector_type(2)));
 // per 16-bit half: 1 where the half is not +0.  The halves are relu outputs max(acc + bias, +0): never negative, and never -0
 // either (an fp32 sum that starts from the accumulator's +0 cannot round to -0), so "any bit set" is "> 0".
 __device__ __forceinline__ uint32_t nz_halves(uint32_t v) {
-  const bf_us2_t one = {1, 1};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(bf_us2_t, v), one));
+  uint32_t r;                        // (as inline asm: __builtin_elementwise_min on a ushort2 compiles to two v_cmp + two v_cndmask)
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(v), "v"(0x00010001u));
+  return r;
+}
+// a (two bf16) with each half kept where the matching half of m (0 or 1) is 1: one packed multiply, exact
+__device__ __forceinline__ uint32_t keep_halves(uint32_t a, uint32_t m) {
+  uint32_t r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(m));
+  return r;
 }
 // 16 relu outputs (+0 or positive bf16, two per dword, columns in order) -> their 16 "is positive" bits, column j at bit j
 __device__ __forceinline__ uint32_t relu_bits16(const uint4& o0, const uint4& o1) {
@@ -230,13 +237,10 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
     if constexpr (MASK == 2) {
 #pragma unroll
       for (int q = 0; q < MG; ++q) {
-        const int f = static_cast<int>(m[q]);
+        // bit 2 i of the field -> bit 0, bit 2 i + 1 -> bit 16 of (sp >> 2 i): the two halves' 0 / 1 factors of dword i
+        const uint32_t sp = m[q] | (m[q] << 15);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i, 1));
-          const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_sbfe(f, 2 * i + 1, 1));
-          a[8 * q + i] &= (lo & 0x0000ffffu) | (hi & 0xffff0000u);
-        }
+        for (int i = 0; i < 8; ++i) a[8 * q + i] = keep_halves(a[8 * q + i], (sp >> (2 * i)) & 0x00010001u);
       }
       __builtin_amdgcn_sched_barrier(0);
       request_bits(m, mask_next);

@@ -64,7 +64,10 @@ P, I64, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 flush = torch.zeros(256 * 1024 * 1024, dtype=torch.int32, device=dev)
 print(f"[{n}, {K}] x [{K}, {N}] bf16, {'warm' if WARM else 'cold'} operands, one launch per HIP-event pair (~5 us of event overhead included); "
       f"one read + one write at 6.3 TB/s = {n * (K + N) * 2 / 6.3e12 * 1e6:.0f} us")
+only = os.environ.get("ALLSET_ABL_ONLY")
 for name, _ in ARMS:
+    if only and only not in name:
+        continue
     if not os.path.exists(so_of(name)):
         print(f"{name}: not built (run with --build-only in the build container)")
         continue
