@@ -1429,7 +1429,9 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_bf16_kernel(
 
 
 // ---- ln_res_* for bf16 activations: y = dropout_p(relu_out(LN(x + colb + res))), bf16 in / out, fp32 arithmetic ------------
-template <int LPR>
+// HAS_RES / DROP (and PMA in the backward) are compile-time: as run-time switches -- uniform as they are -- they put a branch around a
+// load and around the dropout hashes in every row of the loop (round 6, the lesson of fused_bf16.hip's epilogue)
+template <int LPR, bool HAS_RES, bool DROP>
 __global__ __launch_bounds__(kBlock) void ln_res_fwd_bf16_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ colb, const uint16_t* __restrict__ res,
     int64_t ldr, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta, float eps, int relu_out, float p,
@@ -1459,8 +1461,10 @@ __global__ __launch_bounds__(kBlock) void ln_res_fwd_bf16_kernel(
     int64_t row = row0 + r;
     row = row < n ? row : n - 1;
     rx[r] = *reinterpret_cast<const uint4*>(x + row * ldx + cc);
-    rr[r] = res ? *reinterpret_cast<const uint4*>(res + row * ldr + cc) : make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (HAS_RES) rr[r] = *reinterpret_cast<const uint4*>(res + row * ldr + cc);
+    else rr[r] = make_uint4(0u, 0u, 0u, 0u);
   }
+  const uint32_t relu_sel = relu_out ? 0xffffffffu : 0u;          // (bit-select instead of a branch per element; a no-relu NaN stays a NaN)
 #pragma unroll
   for (int r = 0; r < kLnRowsPerGroup; ++r) {
     const int64_t row = row0 + r;
@@ -1478,8 +1482,11 @@ __global__ __launch_bounds__(kBlock) void ln_res_fwd_bf16_kernel(
       if (active) {
         F8 o;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { o.v[k] = fmaf(t.v[k] * rstd, g8.v[k], b8.v[k]); if (relu_out) o.v[k] = fmaxf(o.v[k], 0.f); }
-        if (p > 0.f) {
+        for (int k = 0; k < 8; ++k) {
+          const float v = fmaf(t.v[k] * rstd, g8.v[k], b8.v[k]);
+          o.v[k] = __uint_as_float((__float_as_uint(fmaxf(v, 0.f)) & relu_sel) | (__float_as_uint(v) & ~relu_sel));
+        }
+        if constexpr (DROP) {
 #pragma unroll
           for (int k = 0; k < 8; k += 2) {
             float k0, k1;
@@ -1495,7 +1502,7 @@ __global__ __launch_bounds__(kBlock) void ln_res_fwd_bf16_kernel(
 }
 
 // part[blockIdx][0|1|2][c] = dgamma, dbeta, dcolb (fp32)
-template <int LPR>
+template <int LPR, bool HAS_RES, bool DROP, bool PMA>
 __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
     const uint16_t* __restrict__ gy, int64_t ldg, const uint16_t* __restrict__ x, int64_t ldx,
     const uint16_t* __restrict__ colb, const uint16_t* __restrict__ res, int64_t ldr, const float* __restrict__ stats,
@@ -1506,7 +1513,8 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
   seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
   constexpr int kGroups = kWavesPerBlock * NS;
-  const int pma_g = pma_stats ? (d / pma_heads) / 8 : 1;           // lanes per head (a power of two, checked by the host)
+  const int pma_g = PMA ? (d / pma_heads) / 8 : 1;                  // lanes per head (a power of two, checked by the host)
+  const float relu_floor = relu_out ? 0.f : -__builtin_inff();
   __shared__ float red[kGroups][3][LPR * 8];
   const int lane = lane_id();
   const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
@@ -1526,9 +1534,11 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + grp; row < n; row += rows_per_iter) {
     const F8 xv = unpack8(*reinterpret_cast<const uint4*>(x + row * ldx + cc));
     F8 gv = unpack8(*reinterpret_cast<const uint4*>(gy + row * ldg + cc));
-    const F8 rv = unpack8(res ? *reinterpret_cast<const uint4*>(res + row * ldr + cc) : make_uint4(0u, 0u, 0u, 0u));
+    uint4 rraw = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (HAS_RES) rraw = *reinterpret_cast<const uint4*>(res + row * ldr + cc);
+    const F8 rv = unpack8(rraw);
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    if (p > 0.f) {
+    if constexpr (DROP) {
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
         float k0, k1;
@@ -1542,7 +1552,7 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
     for (int k = 0; k < 8; ++k) {
       xh.v[k] = active ? (xv.v[k] + rv.v[k] + cb.v[k] - mean) * rstd : 0.f;
       if (!active) gv.v[k] = 0.f;
-      if (relu_out && !(fmaf(xh.v[k], g8.v[k], b8.v[k]) > 0.f)) gv.v[k] = 0.f;
+      if (!(fmaf(xh.v[k], g8.v[k], b8.v[k]) > relu_floor)) gv.v[k] = 0.f;     // (no relu: the floor is -inf; a NaN output drops its gradient either way)
       dg.v[k] = fmaf(gv.v[k], xh.v[k], dg.v[k]);
       db.v[k] += gv.v[k];
       gh.v[k] = gv.v[k] * g8.v[k];
@@ -1558,13 +1568,13 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_bf16_kernel(
       for (int k = 0; k < 8; ++k) { o.v[k] = rstd * (gh.v[k] - s1 - xh.v[k] * s2); dc.v[k] += o.v[k]; }
       const uint4 packed = pack8(o);
       *reinterpret_cast<uint4*>(gs + row * ldgs + c0) = packed;
-      if (pma_stats != nullptr) {                         // <x, gs> of this lane's 8 columns, on the values as stored
+      if constexpr (PMA) {                                // <x, gs> of this lane's 8 columns, on the values as stored
         const F8 r = unpack8(packed);
 #pragma unroll
         for (int k = 0; k < 8; ++k) dot = fmaf(xv.v[k], r.v[k], dot);
       }
     }
-    if (pma_stats != nullptr) {                           // (uniform branch; inactive lanes contribute 0 to the shuffles)
+    if constexpr (PMA) {                                  // (inactive lanes contribute 0 to the shuffles)
       for (int off = 1; off < pma_g; off <<= 1) dot += __shfl_xor(dot, off);
       if (active && (li % pma_g) == 0) {
         const int h = li / pma_g;
@@ -2288,9 +2298,15 @@ extern "C" int allset_ln_res_fwd_bf16(const void* x, int64_t ldx, const void* co
   const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
   const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
   typedef const uint16_t* CP;
-#define ALLSET_LNRB_FWD(L) ln_res_fwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>((CP)x, ldx, (CP)colb, (CP)res, ldr, (CP)gamma, (CP)beta, eps, relu_out, p, seed, (uint16_t*)y, ldy, stats, n, di, seed_base)
+#define ALLSET_LNRB_FWD2(L, R, D) ln_res_fwd_bf16_kernel<L, R, D><<<grid, kBlock, 0, st>>>((CP)x, ldx, (CP)colb, (CP)res, ldr, (CP)gamma, (CP)beta, eps, relu_out, p, seed, (uint16_t*)y, ldy, stats, n, di, seed_base)
+#define ALLSET_LNRB_FWD(L)                                                                        \
+  do {                                                                                            \
+    if (res != nullptr) { if (p > 0.f) ALLSET_LNRB_FWD2(L, true, true); else ALLSET_LNRB_FWD2(L, true, false); } \
+    else { if (p > 0.f) ALLSET_LNRB_FWD2(L, false, true); else ALLSET_LNRB_FWD2(L, false, false); }              \
+  } while (0)
   switch (lpr) { case 8: ALLSET_LNRB_FWD(8); break; case 16: ALLSET_LNRB_FWD(16); break; case 32: ALLSET_LNRB_FWD(32); break; default: ALLSET_LNRB_FWD(64); break; }
 #undef ALLSET_LNRB_FWD
+#undef ALLSET_LNRB_FWD2
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -2353,9 +2369,21 @@ static int ln_res_bwd_bf16_impl(const void* gy, int64_t ldg, const void* x, int6
   const int di = static_cast<int>(d);
   const unsigned grid = static_cast<unsigned>(n_partials);
   typedef const uint16_t* CP;
-#define ALLSET_LNRB_BWD(L) ln_res_bwd_bf16_kernel<L><<<grid, kBlock, 0, st>>>((CP)gy, ldg, (CP)x, ldx, (CP)colb, (CP)res, ldr, stats, (CP)gamma, (CP)beta, relu_out, p, seed, (uint16_t*)gs, ldgs, partials, n, di, seed_base, pma_m, pma_l, pma_stats, static_cast<int>(pma_heads))
+#define ALLSET_LNRB_BWD2(L, R, D, P) ln_res_bwd_bf16_kernel<L, R, D, P><<<grid, kBlock, 0, st>>>((CP)gy, ldg, (CP)x, ldx, (CP)colb, (CP)res, ldr, stats, (CP)gamma, (CP)beta, relu_out, p, seed, (uint16_t*)gs, ldgs, partials, n, di, seed_base, pma_m, pma_l, pma_stats, static_cast<int>(pma_heads))
+#define ALLSET_LNRB_BWD(L)                                                                        \
+  do {                                                                                            \
+    const bool r_ = res != nullptr, d_ = p > 0.f;                                                 \
+    if (pma_stats != nullptr) {                                                                   \
+      if (r_) { if (d_) ALLSET_LNRB_BWD2(L, true, true, true); else ALLSET_LNRB_BWD2(L, true, false, true); }    \
+      else { if (d_) ALLSET_LNRB_BWD2(L, false, true, true); else ALLSET_LNRB_BWD2(L, false, false, true); }     \
+    } else {                                                                                      \
+      if (r_) { if (d_) ALLSET_LNRB_BWD2(L, true, true, false); else ALLSET_LNRB_BWD2(L, true, false, false); }  \
+      else { if (d_) ALLSET_LNRB_BWD2(L, false, true, false); else ALLSET_LNRB_BWD2(L, false, false, false); }   \
+    }                                                                                             \
+  } while (0)
   switch (ln_bf16_lpr(d)) { case 8: ALLSET_LNRB_BWD(8); break; case 16: ALLSET_LNRB_BWD(16); break; case 32: ALLSET_LNRB_BWD(32); break; default: ALLSET_LNRB_BWD(64); break; }
 #undef ALLSET_LNRB_BWD
+#undef ALLSET_LNRB_BWD2
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

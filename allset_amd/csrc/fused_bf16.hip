@@ -116,7 +116,9 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
   const bool has_aux_in = TRANS_W && (RT ? aux_in != nullptr : AUX);      // (the logits' gradient: backward-data only)
   const bool has_acc = TRANS_W && (RT ? acc_in != nullptr : EXTRA);       // (the other gradient branch: backward-data only)
   constexpr bool MASK_OUT = !TRANS_W && EXTRA;
-  const float relu_floor = (!TRANS_W && relu_out) ? 0.f : -__builtin_inff();   // relu as a max against a scalar: no branch per tile
+  // relu without a branch per tile and without touching a no-relu output (a max against -inf would turn a NaN into -inf): the max is
+  // always computed and a bit-select on a uniform all-ones / zero mask keeps it or the input (v_bfi_b32)
+  const uint32_t relu_sel = (!TRANS_W && relu_out) ? 0xffffffffu : 0u;
 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: chunk indices and row bases stay scalar
@@ -370,7 +372,13 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
             v2 += __uint_as_float(accv[tl].y << 16); v3 += __uint_as_float(accv[tl].y & 0xffff0000u);
           }
         }
-        if constexpr (!TRANS_W) { v0 = fmaxf(v0, relu_floor); v1 = fmaxf(v1, relu_floor); v2 = fmaxf(v2, relu_floor); v3 = fmaxf(v3, relu_floor); }
+        if constexpr (!TRANS_W) {
+          auto relu_if = [&](float v) {
+            const uint32_t a = __float_as_uint(fmaxf(v, 0.f)), b = __float_as_uint(v);
+            return __uint_as_float((a & relu_sel) | (b & ~relu_sel));
+          };
+          v0 = relu_if(v0); v1 = relu_if(v1); v2 = relu_if(v2); v3 = relu_if(v3);
+        }
         pk[tt] = make_uint2(cvt_pk_bf16(v0, v1), cvt_pk_bf16(v2, v3));
       }
       uint4 o0, o1;
