@@ -11,19 +11,22 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=500_000); ap.add_argument("--d", type=int, default=128)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"]); ap.add_argument("--degree-dist", default="fixed")
 ap.add_argument("--all", action="store_true", help="every device kernel, not only aten ops")
+ap.add_argument("--model", default="pma", choices=["pma", "deepsets"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n, d = a.n, a.d
 tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 hgr = synthetic.random_hypergraph(n, n, 16, seed=1, device=dev, dist=a.degree_dist)
 hg = adist.ShardedHypergraph(hgr.edge_index, n, n, 1, 0, norm=hgr.norm).build_incidences()
-v2e = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=True).to(dev).to(tdt).train()
-e2v = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=True).to(dev).to(tdt).train()
+attn = a.model == "pma"
+v2e = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).to(tdt).train()
+e2v = HalfNLHconv(d, d, d, 2, 0.5, "ln", True, heads=4, attention=attn).to(dev).to(tdt).train()
 x = torch.randn(n, d, device=dev).to(tdt).requires_grad_(True); G = torch.randn(n, d, device=dev).to(tdt)
 def step():
     x.grad = None
     for p in list(v2e.parameters()) + list(e2v.parameters()): p.grad = None
-    out = adist.sharded_pma_layer(v2e, e2v, x, hg, dropout=0.5, training=True)
+    out = (adist.sharded_pma_layer(v2e, e2v, x, hg, dropout=0.5, training=True) if attn else
+           adist.sharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=0.5, training=True))
     out.backward(G)
 for _ in range(3): step()
 torch.cuda.synchronize()
