@@ -15,11 +15,12 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 CORE_ABI_VERSION = 1
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 F32, BF16 = 0, 1
+REDUCE_AS_TREE = 0x100
 ARITH_AUTO, ARITH_BF16X6, ARITH_FP16X3 = 0, 1, 2          # include/allset_hip_ext.h ALLSET_ARITH_*
 REDUCE_CODES = {"add": SUM, "sum": SUM, "mean": MEAN, "max": MAX, "min": MIN}
 
@@ -94,6 +95,8 @@ SIGNATURES = {
     "allset_reduce_partials_batchable": [c_int64, c_int64],
     "allset_reduce_partials_batched": [_P, _P, _P, _P, _P, c_int64, _P],
     "allset_reduce_partials_batched_ex": [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
+    "allset_reduce_partials_batched_ex2": [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
+    "allset_reduce_partials_is_tree": [c_int64, c_int64],
     "allset_reduce_partials_batch_max_counters": [],
     "allset_sparse_ln_linear_supported": [c_int64],
     "allset_sparse_ln_linear_slices": [],

@@ -491,6 +491,46 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
   }
 }
 
+// The TWO-LEVEL reduction of allset_reduce_partials (one launch that leaves a sum per 64-row slab, a second one that sums the
+// <= 8 slab sums) done by ONE workgroup per column block, with exactly the tree's association -- per slab: eight row groups of
+// eight sequential adds, the groups combined in order; then the slab sums added in order to +0 -- so the result is bit-identical
+// to the two launches (ABI 14: what lets the batched entry take the large partial buffers of the [1M, 128] / [250k, 256] steps).
+template <bool OUT_BF16>
+__device__ __forceinline__ void reduce_partials_tree_body(const float* __restrict__ part, int64_t P, int64_t M, float* __restrict__ out,
+                                                          int64_t row_stride, int slabs, int64_t bx, float4 (*red)[kBlock / kRedSplit]) {
+  const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
+  const int64_t c = (bx * (kBlock / kRedSplit) + cq) * 4;
+  float4 tot = make_float4(0, 0, 0, 0);
+  for (int sl = 0; sl < slabs; ++sl) {
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (c < M) {
+      const int64_t p0 = static_cast<int64_t>(sl) * kRedRows;
+      float4 v[kRedRows / kRedSplit];
+#pragma unroll
+      for (int i = 0; i < kRedRows / kRedSplit; ++i) {
+        const int64_t p = p0 + rg + static_cast<int64_t>(i) * kRedSplit;
+        v[i] = p < P ? *reinterpret_cast<const float4*>(part + p * row_stride + c) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < kRedRows / kRedSplit; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+    }
+    red[rg][cq] = acc;
+    __syncthreads();
+    if (rg == 0 && c < M) {
+#pragma unroll
+      for (int g = 1; g < kRedSplit; ++g) { const float4 t = red[g][cq]; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+      tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+    }
+    __syncthreads();
+  }
+  if (rg == 0 && c < M) {
+    if constexpr (OUT_BF16)
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + c) = make_uint2(cvt_pk_bf16(tot.x, tot.y), cvt_pk_bf16(tot.z, tot.w));
+    else
+      *reinterpret_cast<float4*>(out + c) = tot;
+  }
+}
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ part, int64_t P, int64_t M,
                                                                 float* __restrict__ out, int64_t row_stride, int slabs_here) {
@@ -508,6 +548,8 @@ struct RedBatchTable {
   float* out[kRedBatchMax];
   int32_t P[kRedBatchMax], stride[kRedBatchMax], M[kRedBatchMax];
   int32_t first_block[kRedBatchMax + 1];
+  uint8_t out_bf16[kRedBatchMax];            // ABI 14: the sum of buffer k leaves as bf16 (rounded once), as allset_reduce_partials_ex writes it
+  uint8_t tree[kRedBatchMax];                // ABI 14: buffer k is one the single call reduces in TWO launches (the tree body below)
   int32_t count;
   // counters advanced by one extra workgroup of the same launch (a training step's dropout-seed counter and its optimizer's step
   // counters: each is one more ~5 us launch in the step's dependent chain otherwise)
@@ -526,7 +568,15 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_batched_kernel(RedBatc
   int t = 0;
   while (t + 1 < tb.count && tb.first_block[t + 1] <= b) ++t;
   const int P = tb.P[t];
-  reduce_partials_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], (P + kRedRows - 1) / kRedRows, b - tb.first_block[t], 0, red);
+  const int slabs = (P + kRedRows - 1) / kRedRows;
+  if (tb.tree[t]) {
+    if (tb.out_bf16[t]) reduce_partials_tree_body<true>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], red);
+    else reduce_partials_tree_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], red);
+  } else if (tb.out_bf16[t]) {
+    reduce_partials_body<true>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], 0, red);
+  } else {
+    reduce_partials_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], 0, red);
+  }
 }
 
 static inline int ln_lpr(int64_t d) {
@@ -1923,14 +1973,15 @@ static int reduce_partials_impl(const float* part, int64_t P, int64_t row_stride
 
 extern "C" int allset_reduce_partials_batch_max(void) { return kRedBatchMax; }
 
-// 1 when (P, M) is a reduction allset_reduce_partials finishes in ONE launch -- those are the ones the batched entry takes.
+// 1 when the batched entry takes a (P, M) reduction: the ones allset_reduce_partials finishes in ONE launch and (ABI 14) the
+// two-launch ones of at most 8 slabs of 64 partial rows, which one workgroup per column block walks with the tree's association.
 extern "C" int allset_reduce_partials_batchable(int64_t P, int64_t M) {
-  return (P >= 1 && M >= 4 && M % 4 == 0 && M < INT32_MAX && reduce_one_launch(P, M)) ? 1 : 0;
+  return (P >= 1 && P <= 8 * kRedRows && M >= 4 && M % 4 == 0 && M < INT32_MAX && P * M < (int64_t{1} << 31)) ? 1 : 0;
 }
 
 static int reduce_partials_batched_impl(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
-                                        float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32,
-                                        void* stream) {
+                                        void* const* outs, const int32_t* out_dtypes, int64_t count, int64_t* inc_i64,
+                                        float* const* inc_f32, int64_t n_inc_f32, void* stream) {
   ALLSET_REQUIRE(count >= 0 && count <= kRedBatchMax, "reduce_partials_batched: at most %d buffers per call", kRedBatchMax);
   ALLSET_REQUIRE(n_inc_f32 >= 0 && n_inc_f32 <= kRedBatchMaxCounters && (n_inc_f32 == 0 || inc_f32 != nullptr),
                  "reduce_partials_batched: at most %d float counters per call", kRedBatchMaxCounters);
@@ -1943,9 +1994,15 @@ static int reduce_partials_batched_impl(const float* const* parts, const int64_t
   for (int64_t k = 0; k < count; ++k) {
     ALLSET_REQUIRE(parts[k] && outs[k], "reduce_partials_batched: null buffer %lld", static_cast<long long>(k));
     ALLSET_REQUIRE(allset_reduce_partials_batchable(P[k], M[k]), "reduce_partials_batched: buffer %lld is not batchable (see allset_reduce_partials_batchable)", static_cast<long long>(k));
-    ALLSET_REQUIRE(row_stride[k] >= M[k] && row_stride[k] % 4 == 0 && row_stride[k] < INT32_MAX && aligned16(parts[k]) && aligned16(outs[k]),
-                   "reduce_partials_batched: buffer %lld: row_stride >= M, a multiple of 4; 16-byte aligned pointers", static_cast<long long>(k));
-    tb.part[k] = parts[k]; tb.out[k] = outs[k];
+    const int odt = out_dtypes ? (out_dtypes[k] & 0xff) : ALLSET_F32;
+    const bool force_tree = out_dtypes != nullptr && (out_dtypes[k] & ALLSET_REDUCE_AS_TREE) != 0;
+    ALLSET_REQUIRE((out_dtypes == nullptr || (out_dtypes[k] & ~(0xff | ALLSET_REDUCE_AS_TREE)) == 0) && (odt == ALLSET_F32 || odt == ALLSET_BF16), "reduce_partials_batched: buffer %lld: out dtype must be ALLSET_F32 or ALLSET_BF16", static_cast<long long>(k));
+    ALLSET_REQUIRE(row_stride[k] >= M[k] && row_stride[k] % 4 == 0 && row_stride[k] < INT32_MAX && aligned16(parts[k]) &&
+                   (reinterpret_cast<uintptr_t>(outs[k]) & (odt == ALLSET_BF16 ? 7u : 15u)) == 0,
+                   "reduce_partials_batched: buffer %lld: row_stride >= M, a multiple of 4; 16-byte aligned pointers (8 for a bf16 output)", static_cast<long long>(k));
+    tb.part[k] = parts[k]; tb.out[k] = static_cast<float*>(outs[k]);
+    tb.out_bf16[k] = odt == ALLSET_BF16 ? 1 : 0;
+    tb.tree[k] = (force_tree || !reduce_one_launch(P[k], M[k])) ? 1 : 0;
     tb.P[k] = static_cast<int32_t>(P[k]); tb.stride[k] = static_cast<int32_t>(row_stride[k]); tb.M[k] = static_cast<int32_t>(M[k]);
     tb.first_block[k] = static_cast<int32_t>(blocks);
     blocks += (M[k] / 4 + per_block - 1) / per_block;
@@ -1966,14 +2023,26 @@ static int reduce_partials_batched_impl(const float* const* parts, const int64_t
 extern "C" int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
                                               float* const* outs, int64_t count, void* stream) {
   clear_error();
-  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, count, nullptr, nullptr, 0, stream);
+  return reduce_partials_batched_impl(parts, P, row_stride, M, reinterpret_cast<void* const*>(outs), nullptr, count, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int allset_reduce_partials_batched_ex(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
                                                  float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32,
                                                  int64_t n_inc_f32, void* stream) {
   clear_error();
-  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, count, inc_i64, inc_f32, n_inc_f32, stream);
+  return reduce_partials_batched_impl(parts, P, row_stride, M, reinterpret_cast<void* const*>(outs), nullptr, count, inc_i64, inc_f32, n_inc_f32, stream);
+}
+
+// 1 when allset_reduce_partials(_ex) sums a (P, M) buffer as the two-launch tree (whose association differs from the one-launch form's)
+extern "C" int allset_reduce_partials_is_tree(int64_t P, int64_t M) { return (P >= 1 && M >= 1 && !reduce_one_launch(P, M)) ? 1 : 0; }
+
+// ABI 14: the same with an output type per buffer (out_dtypes[k] = ALLSET_F32 or ALLSET_BF16: outs[k] is then a bf16 vector of M[k]
+// elements, each sum rounded once as allset_reduce_partials_ex rounds it; NULL = all fp32).
+extern "C" int allset_reduce_partials_batched_ex2(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                                  void* const* outs, const int32_t* out_dtypes, int64_t count, int64_t* inc_i64,
+                                                  float* const* inc_f32, int64_t n_inc_f32, void* stream) {
+  clear_error();
+  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, out_dtypes, count, inc_i64, inc_f32, n_inc_f32, stream);
 }
 
 extern "C" int allset_reduce_partials_batch_max_counters(void) { return kRedBatchMaxCounters; }

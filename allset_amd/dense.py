@@ -102,24 +102,33 @@ class _Deferred:
     pending: list = []          # (part [P, stride], M, [(param, offset, shape), ...])
 
 
-def _deferrable(part: Tensor, *params) -> bool:
+def _deferrable(part: Tensor, *params, M: Optional[int] = None) -> bool:
+    """``part`` [P, stride] fp32 partials whose first ``M`` columns (default: all) sum to the gradients of ``params`` -- all fp32, or
+    all bf16 (ABI 14: the batched launch rounds each sum once, as ``reduce_partials_to`` does)."""
     if not _Deferred.active or part.dim() != 2 or part.dtype != torch.float32:
         return False
-    P, M = part.shape
-    if not _lib.load().allset_reduce_partials_batchable(P, M):
+    P = part.shape[0]
+    M = part.shape[1] if M is None else M
+    if M % 4 != 0 or part.stride(1) != 1 or part.stride(0) % 4 != 0 or not _lib.load().allset_reduce_partials_batchable(P, M):
         return False
     # ONE batched launch on ONE device: partials (and parameters) on another device than the scope's first entry reduce the usual way
     if _Deferred.pending and part.device != _Deferred.pending[0][0].device:
         return False
+    real = [p for p in params if p is not None]
+    if not real or real[0].dtype not in (torch.float32, torch.bfloat16):
+        return False
     # a parameter with tensor hooks / post-accumulate hooks (DDP-style gradient sync) must go through autograd's accumulation node
-    return all(p is None or (isinstance(p, torch.nn.Parameter) and p.is_leaf and p.requires_grad and p.dtype == torch.float32
-                             and p.device == part.device and not getattr(p, "_backward_hooks", None)
-                             and not getattr(p, "_post_accumulate_grad_hooks", None))
-               for p in params)
+    return all(isinstance(p, torch.nn.Parameter) and p.is_leaf and p.requires_grad and p.dtype == real[0].dtype
+               and p.device == part.device and not getattr(p, "_backward_hooks", None)
+               and not getattr(p, "_post_accumulate_grad_hooks", None)
+               for p in real)
 
 
-def _defer(part: Tensor, sections) -> None:
-    _Deferred.pending.append((part, part.shape[1], [(p, off, tuple(shape)) for p, off, shape in sections if p is not None]))
+def _defer(part: Tensor, sections, M: Optional[int] = None) -> None:
+    """``sections``: (parameter or None, offset into the summed row, shape).  A parameter named twice in one scope (shared weights)
+    accumulates."""
+    secs = [(p, off, tuple(shape)) for p, off, shape in sections if p is not None]
+    _Deferred.pending.append((part, part.shape[1] if M is None else M, secs))
 
 
 def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
@@ -131,21 +140,24 @@ def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
     lib = _lib.load()
     import ctypes
     dev = pend[0][0].device if pend else (bump_i64.device if bump_i64 is not None else None)
-    out = None
     later = []
-    base, bases = 0, []
-    for part, M, _ in pend:
-        bases.append(base)
-        base += M
+    # one output buffer per gradient dtype (fp32 / bf16 parameters); an entry's row starts on a multiple of 4 elements (16 / 8 bytes)
+    tot = {torch.float32: 0, torch.bfloat16: 0}
+    bases, dts = [], []
+    for part, M, sections in pend:
+        dt = sections[0][0].dtype if sections else torch.float32
+        dts.append(dt)
+        bases.append(tot[dt])
+        tot[dt] += M
+    outs = {dt: (torch.empty(n, dtype=dt, device=dev) if n else None) for dt, n in tot.items()}
     if pend:
-        out = torch.empty(base, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for (part, M, sections), b in zip(pend, bases):
+            for (part, M, sections), b, dt in zip(pend, bases, dts):
                 for p, off, shape in sections:
                     numel = 1
                     for v in shape:
                         numel *= v
-                    g = out[b + off:b + off + numel].view(shape)
+                    g = outs[dt][b + off:b + off + numel].view(shape)
                     if p.grad is None:
                         p.grad = g
                     else:
@@ -167,13 +179,15 @@ def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
         arr = lambda vals: (ctypes.c_void_p * max(len(vals), 1))(*vals)
         i64 = lambda vals: (ctypes.c_int64 * max(len(vals), 1))(*vals)
         cs = counters if first else []
+        optrs = [outs[dt].data_ptr() + outs[dt].element_size() * b for b, dt in zip(bases[k0:k0 + n], dts[k0:k0 + n])]
+        odts = (ctypes.c_int32 * max(n, 1))(*[_lib.BF16 if dt == torch.bfloat16 else _lib.F32 for dt in dts[k0:k0 + n]])
         with on_device(dev):
-            check(lib.allset_reduce_partials_batched_ex(
+            check(lib.allset_reduce_partials_batched_ex2(
                 arr([part.data_ptr() for part, _, _ in chunk]), i64([part.shape[0] for part, _, _ in chunk]),
                 i64([part.stride(0) for part, _, _ in chunk]), i64([M for _, M, _ in chunk]),
-                arr([out.data_ptr() + 4 * b for b in bases[k0:k0 + n]]) if n else arr([]), n,
+                arr(optrs), odts, n,
                 ptr(bump_i64) if first else None, arr([c.data_ptr() for c in cs]), len(cs), stream_of(dev)),
-                "allset_reduce_partials_batched_ex")
+                "allset_reduce_partials_batched_ex2")
         first = False
     with torch.no_grad():
         for p, g in later:
@@ -221,9 +235,33 @@ def reduce_partials(part: Tensor) -> Tensor:
     return out
 
 
+def reduce_partials_slice(part: Tensor, col0: int, M: int, dtype: torch.dtype) -> Tensor:
+    """Sum columns ``[col0, col0 + M)`` of a partial buffer over its rows with the bits the reduction of the WHOLE buffer gives for
+    them (a large buffer is summed as a two-launch tree, a small one in one launch with another association): what a backward node
+    uses for the part of its partials it cannot queue in ``deferred_param_grads()``."""
+    P, width = part.shape
+    lib = _lib.load()
+    view = part[:, col0:col0 + M]
+    if not lib.allset_reduce_partials_is_tree(P, width) or lib.allset_reduce_partials_is_tree(P, M) \
+            or not lib.allset_reduce_partials_batchable(P, M):
+        return reduce_partials_to(view, M, dtype)
+    import ctypes
+    dev = part.device
+    out = torch.empty(M, dtype=dtype, device=dev)
+    flags = (ctypes.c_int32 * 1)((_lib.BF16 if dtype == torch.bfloat16 else _lib.F32) | _lib.REDUCE_AS_TREE)
+    with on_device(dev):
+        check(lib.allset_reduce_partials_batched_ex2((ctypes.c_void_p * 1)(view.data_ptr()), (ctypes.c_int64 * 1)(P),
+                                                     (ctypes.c_int64 * 1)(part.stride(0)), (ctypes.c_int64 * 1)(M),
+                                                     (ctypes.c_void_p * 1)(out.data_ptr()), flags, 1, None, None, 0, stream_of(dev)),
+              "allset_reduce_partials_batched_ex2")
+    return out
+
+
 def reduce_partials_to(part: Tensor, M: int, dtype: torch.dtype) -> Tensor:
     """Sum the first ``M`` columns of a partial buffer [P, stride] over its rows; ``dtype`` float32 or bfloat16 (rounded once)."""
-    P, stride = part.shape
+    P, stride = part.shape[0], part.stride(0)          # (a column slice of a wider partial buffer keeps the buffer's row stride)
+    if part.stride(1) != 1:
+        raise _lib.AllSetHipError("reduce_partials_to: rows must be contiguous")
     dev = part.device
     out = torch.empty(M, dtype=dtype, device=dev)
     scratch = torch.empty(((P + 63) // 64) * M, dtype=torch.float32, device=dev) if P > 64 else None
@@ -787,7 +825,7 @@ def fused_linear_bwd_all_aux_supported(O: int, I: int) -> bool:
     return bool(_lib.load().allset_fused_linear_bwd_all_aux_supported(int(O), int(I)))
 
 
-def fused_linear_bwd_all_aux(gy: Tensor, weight: Tensor, x: Tensor, aux_g: Tensor, aux_w: Tensor
+def fused_linear_bwd_all_aux(gy: Tensor, weight: Tensor, x: Tensor, aux_g: Tensor, aux_w: Tensor, defer_to=None
                              ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """(gx, gW, gb, gaux_w [4, I], gaux_b [4]) of the plain Linear with four auxiliary output columns, from ONE pass over gy and x
     (include/allset_hip.h allset_fused_linear_bwd_all_aux)."""
@@ -808,8 +846,13 @@ def fused_linear_bwd_all_aux(gy: Tensor, weight: Tensor, x: Tensor, aux_g: Tenso
         check(lib.allset_fused_linear_bwd_all_aux(ptr(gy), _ld(gy), ptr(weight), ptr(x), _ld(x), ptr(aux_g), ptr(aux_w), ptr(gx),
                                                   max(I, 1), ptr(part), M, P, n, O, I, stream_of(dev)),
               "allset_fused_linear_bwd_all_aux")
-    red = reduce_partials(part)
     o = O * I
+    if defer_to is not None and (o + O) % 4 == 0 and defer_to[1] is not None and _deferrable(part, *defer_to, M=o + O):
+        # (weight, bias) PARAMETERS: queued; the four auxiliary rows (their weight is a folded tensor, not a parameter) reduce at once
+        _defer(part, [(defer_to[0], 0, (O, I)), (defer_to[1], o, (O,))], M=o + O)
+        redx = reduce_partials_slice(part, o + O, 4 * I + 4, torch.float32)
+        return gx, None, None, redx[:4 * I].view(4, I), redx[4 * I:4 * I + 4]
+    red = reduce_partials(part)
     return gx, red[:o].view(O, I), red[o:o + O], red[o + O:o + O + 4 * I].view(4, I), red[o + O + 4 * I:o + O + 4 * I + 4]
 
 
@@ -1308,6 +1351,7 @@ class _PmaProject(torch.autograd.Function):
             alpha = torch.nn.functional.linear(x, w_a, b_a)
         ctx.save_for_backward(x, w_v, w4)
         ctx.cfg = (b_v is not None, b_a is not None, aux, H)
+        ctx.params = (w_v, b_v)
         return x_v, alpha
 
     @staticmethod
@@ -1321,7 +1365,8 @@ class _PmaProject(torch.autograd.Function):
                 and fused_linear_bwd_all_aux_supported(w_v.shape[0], w_v.shape[1])):
             # one pass: both gradient branches of x, the projection's weight / bias gradient and the logit columns' own
             g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
-            gx, gwv, gbv, gwa4, gba4 = fused_linear_bwd_all_aux(g_v, w_v, x, g4, w4)
+            defer = ctx.params if (_Deferred.active and has_bv and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
+            gx, gwv, gbv, gwa4, gba4 = fused_linear_bwd_all_aux(g_v, w_v, x, g4, w4, defer_to=defer)
             return (gx, gwv, gbv if has_bv else None, gwa4[:H] if H < 4 else gwa4,
                     (gba4[:H] if H < 4 else gba4) if has_ba else None)
         if ctx.needs_input_grad[0]:
@@ -1455,7 +1500,7 @@ def fused_linear_bwd_pma_tail_supported(heads: int) -> bool:
 
 
 def fused_linear_bwd_pma_tail(gy: Tensor, weight: Tensor, pooled: Tensor, colb: Optional[Tensor], stats: Tensor, gamma: Tensor, beta: Tensor,
-                              gres: Tensor, m: Tensor, l: Tensor, want_bias: bool = True):
+                              gres: Tensor, m: Tensor, l: Tensor, want_bias: bool = True, defer_to=None):
     """``(g_pooled, dgamma0, dbeta0, dcolb, gW, gb, pma_stats)``: the backward of the PMA tail's first rFF Linear with the residual
     branch's gradient added in front of ln0's backward, ln0's backward, and the pooling's backward statistics -- ONE pass
     (include/allset_hip_ext.h allset_fused_linear_bwd_pma_tail; until round 6: fused_linear_bwd_all(acc_in) + ln_res_bwd_pma)."""
@@ -1478,8 +1523,14 @@ def fused_linear_bwd_pma_tail(gy: Tensor, weight: Tensor, pooled: Tensor, colb: 
             ptr(gy), _ld(gy), ptr(weight.contiguous()), ptr(pooled), _ld(pooled), ptr(colb.contiguous() if colb is not None else None),
             ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(gres), _ld(gres), ptr(gx), max(I, 1), ptr(part), M, P,
             ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, n, O, I, stream_of(dev)), "allset_fused_linear_bwd_pma_tail")
-    red = reduce_partials(part)
     o = O * I
+    if defer_to is not None and colb is not None and _deferrable(part, *defer_to):
+        # (weight, bias, gamma0, beta0, att_r) PARAMETERS: queued for the batched reduction of deferred_param_grads()
+        w_p, b_p, g_p, bt_p, c_p = defer_to
+        _defer(part, [(w_p, 0, (O, I)), (b_p if want_bias else None, o, (O,)), (g_p, o + O, (I,)), (bt_p, o + O + I, (I,)),
+                      (c_p, o + O + 2 * I, tuple(c_p.shape))])
+        return gx, None, None, None, None, None, pstats
+    red = reduce_partials(part)
     return (gx, red[o + O:o + O + I], red[o + O + I:o + O + 2 * I], red[o + O + 2 * I:o + O + 3 * I], red[:o].view(O, I),
             red[o:o + O] if want_bias else None, pstats)
 
@@ -1489,7 +1540,8 @@ def fused_linear_bwd_ln_pro_supported() -> bool:
 
 
 def fused_linear_bwd_ln_pro(gy: Tensor, s: Tensor, stats2: Tensor, gamma2: Tensor, beta2: Tensor, relu_post: bool, p: float, seed: int,
-                            seed_base: Optional[Tensor], mask: Tensor, weight: Tensor, x: Tensor, relu_in: bool, want_bias: bool = True):
+                            seed_base: Optional[Tensor], mask: Tensor, weight: Tensor, x: Tensor, relu_in: bool, want_bias: bool = True,
+                            defer_to=None):
     """``(gs, dgamma2, dbeta2, gx, gW, gb)``: ln1's backward (on the saved sum ``s``) as the gy prologue of the second rFF Linear's
     one-pass backward (include/allset_hip_ext.h allset_fused_linear_bwd_ln_pro; until round 6: ln_res_bwd + fused_linear_bwd_all)."""
     dev = require_device(gy, s, stats2, gamma2, beta2, mask, weight, x)
@@ -1510,21 +1562,29 @@ def fused_linear_bwd_ln_pro(gy: Tensor, s: Tensor, stats2: Tensor, gamma2: Tenso
             ptr(gy), _ld(gy), ptr(s), _ld(s), ptr(stats2), ptr(gamma2.contiguous()), ptr(beta2.contiguous()), int(relu_post), float(p), int(seed),
             ptr(seed_base), ptr(mask), ptr(weight.contiguous()), ptr(x), _ld(x), int(relu_in), ptr(gs), max(O, 1), ptr(gx), max(I, 1), ptr(part), M, P,
             n, O, I, stream_of(dev)), "allset_fused_linear_bwd_ln_pro")
-    red = reduce_partials(part)
     o = O * I
+    if defer_to is not None and _deferrable(part, *defer_to):
+        w_p, b_p, g_p, bt_p = defer_to         # (weight, bias, gamma1, beta1) PARAMETERS
+        _defer(part, [(w_p, 0, (O, I)), (b_p if want_bias else None, o, (O,)), (g_p, o + O, (O,)), (bt_p, o + 2 * O, (O,))])
+        return gs, None, None, gx, None, None
+    red = reduce_partials(part)
     return gs, red[o + O:o + 2 * O], red[o + 2 * O:o + 3 * O], gx, red[:o].view(O, I), (red[o:o + O] if want_bias else None)
 
 
-def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional[Tensor] = None):
+def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional[Tensor] = None, params=None):
     """``(g_pooled, dcolb, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pma_stats or None)``: ln1's backward on the saved sum, the two
     Linears' one-pass backward (the residual branch summed through ``acc_in``), ln0's backward -- with the pooling's backward
     statistics written by the same pass when the softmax statistics ``(m, l)`` are given."""
     pooled, cb, stats0, g0, b0, out, y1, mask, s, stats1, w1, w2, g1, bt1 = saved
     relu_post, p, seed, base, has_b1, has_b2 = cfg
+    # ``params`` = (att_r, g0, b0, w1, b1, w2, b2, g1, bt1) as the node received them: inside deferred_param_grads() the two one-pass
+    # kernels' parameter gradients are queued for the batched reduction and come back as None
+    d1 = (params[5], params[6], params[7], params[8]) if params is not None else None
+    d0 = (params[3], params[4], params[1], params[2], params[0]) if params is not None else None
     if fused_linear_bwd_ln_pro_supported():
         # ln1's backward inside the second Linear's one-pass backward (csrc/fused_bwd6.hip PT2): one pass instead of two
         gs, dg1, db1, gh, gw2, gb2 = fused_linear_bwd_ln_pro(gy.contiguous(), s, stats1, g1, bt1, relu_post, p, seed, base, mask, w2, y1, True,
-                                                             want_bias=has_b2)
+                                                             want_bias=has_b2, defer_to=d1)
     else:
         gs, dg1, db1, _ = ln_res_bwd(gy.contiguous(), s, None, None, stats1, g1, bt1, relu_post, p, seed, base)
         gh, _, _, gw2, gb2 = fused_linear_bwd_all(gs, mask, 0.0, w2, y1, None, None, None, True, 0.0, 0, want_bias=has_b2)
@@ -1535,7 +1595,8 @@ def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional
         return g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, None
     if m is not None and fused_linear_bwd_pma_tail_supported(m.shape[1]):
         # the first Linear's backward, ln0's backward and the pooling's statistics in ONE pass (csrc/fused_bwd6.hip PT)
-        g_pooled, dg0, db0, dc, gw1, gb1, pstats = fused_linear_bwd_pma_tail(gh, w1, pooled, cb, stats0, g0, b0, gs, m, l, want_bias=has_b1)
+        g_pooled, dg0, db0, dc, gw1, gb1, pstats = fused_linear_bwd_pma_tail(gh, w1, pooled, cb, stats0, g0, b0, gs, m, l, want_bias=has_b1,
+                                                                             defer_to=d0)
         return g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats
     gout, _, _, gw1, gb1 = fused_linear_bwd_all(gh, None, 0.0, w1, out, None, None, None, False, 0.0, 0, acc_in=gs, want_bias=has_b1)
     if m is not None:
@@ -1544,6 +1605,16 @@ def pma_tail_bwd(saved, cfg, gy: Tensor, m: Optional[Tensor] = None, l: Optional
         g_pooled, dg0, db0, dc = ln_res_bwd(gout, pooled, cb, None, stats0, g0, b0, False, 0.0, 0, None)
         pstats = None
     return g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats
+
+
+def tail_defer_params(ctx, idx):
+    """``ctx.params`` (att_r, g0, b0, w1, b1, w2, b2, g1, bt1) when the node runs inside ``deferred_param_grads()`` and every one of
+    them (inputs ``idx`` of the node) wants its gradient; None otherwise."""
+    if not _Deferred.active or getattr(ctx, "params", None) is None:
+        return None
+    if not all(ctx.needs_input_grad[i] for i, q in zip(idx, ctx.params) if q is not None):
+        return None
+    return ctx.params
 
 
 class _PmaTail(torch.autograd.Function):
@@ -1555,13 +1626,15 @@ class _PmaTail(torch.autograd.Function):
         y, saved, cfg = pma_tail_fwd(pooled, att_r.reshape(-1), g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post, p)
         ctx.save_for_backward(*saved)
         ctx.cfg, ctx.cshape = cfg, att_r.shape
+        ctx.params = (att_r, g0, b0, w1, b1, w2, b2, g1, bt1)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, _ = pma_tail_bwd(ctx.saved_tensors, ctx.cfg, gy)
-        return g_pooled, dc.reshape(ctx.cshape), dg0, db0, None, gw1, gb1, gw2, gb2, dg1, db1, None, None, None
+        g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, _ = pma_tail_bwd(ctx.saved_tensors, ctx.cfg, gy,
+                                                                               params=tail_defer_params(ctx, (1, 2, 3, 5, 6, 7, 8, 9, 10)))
+        return g_pooled, (dc.reshape(ctx.cshape) if dc is not None else None), dg0, db0, None, gw1, gb1, gw2, gb2, dg1, db1, None, None, None
 
 
 def pma_tail(pooled: Tensor, att_r: Tensor, g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post: bool = False, p: float = 0.0) -> Tensor:
@@ -1716,10 +1789,13 @@ def wgrad_bf16_ex2_supported(O: int, I: int, bits: bool, aux: bool) -> bool:
     return bool(_lib.load().allset_wgrad_bf16_ex2_supported(O, I, int(bits), int(aux)))
 
 
-def wgrad_bf16_ex2(ga: Tensor, u: Tensor, bits: Optional[Tensor] = None, g4: Optional[Tensor] = None, want_bias: bool = True):
+def wgrad_bf16_ex2(ga: Tensor, u: Tensor, bits: Optional[Tensor] = None, g4: Optional[Tensor] = None, want_bias: bool = True,
+                   defer_to=None):
     """``(gW, gb[, gWa [4, I], gba [4]])`` of a bf16 Linear in one pass over ``ga`` and ``u``: ``bits`` = the relu bit mask of the
     Linear's output (``ga`` is the gradient BEFORE the mask), ``g4`` = the fp32 [n, 4] gradient of four auxiliary output columns.
-    Results bf16 (summed in fp32, rounded once by the reduction)."""
+    Results bf16 (summed in fp32, rounded once by the reduction).  ``defer_to`` = the (weight, bias) PARAMETERS: inside
+    ``deferred_param_grads()`` gW / gb are queued for the batched reduction and come back as None (the auxiliary rows, whose
+    weights are not parameters, are reduced at once)."""
     dev = require_device(ga, u)
     _check_dtype(torch.bfloat16, ga, u)
     ga, u = _rowmajor(ga), _rowmajor(u)
@@ -1736,6 +1812,13 @@ def wgrad_bf16_ex2(ga: Tensor, u: Tensor, bits: Optional[Tensor] = None, g4: Opt
     with on_device(dev), _timed("wgrad", dev, nbytes):
         check(lib.allset_wgrad_bf16_ex2(ptr(ga), _ld(ga), ptr(bits), ptr(g4), ptr(u), _ld(u), ptr(part), M, int(want_bias), ns.value,
                                         n, O, I, stream_of(dev)), "allset_wgrad_bf16_ex2")
+    M_main = O * I + (O if want_bias else 0)
+    if defer_to is not None and M_main % 4 == 0 and _deferrable(part, defer_to[0], defer_to[1] if want_bias else None, M=M_main):
+        _defer(part, [(defer_to[0], 0, (O, I)), (defer_to[1] if want_bias else None, O * I, (O,))], M=M_main)
+        if g4 is None:
+            return None, None
+        redx = reduce_partials_slice(part, M_main, 4 * I + 4, torch.bfloat16)
+        return None, None, redx[:4 * I].view(4, I), redx[4 * I:]
     red = reduce_partials_to(part, M, torch.bfloat16)
     gw = red[:O * I].view(O, I)
     off = O * I
@@ -1766,6 +1849,7 @@ class _LinearBf16(torch.autograd.Function):
             ctx.save_for_backward(x, weight, y if relu_out else None)
         ctx.has_bias = bias is not None
         ctx.use_bits = use_bits
+        ctx.params = (weight, bias)               # (the objects themselves: deferred_param_grads assigns their .grad)
         return y
 
     @staticmethod
@@ -1779,7 +1863,8 @@ class _LinearBf16(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = linear_bf16_bwd_bits(gy, weight, y)
             if need_w:
-                gw, gb = wgrad_bf16_ex2(gy, x, bits=y, want_bias=ctx.has_bias)
+                defer = ctx.params if (_Deferred.active and ctx.needs_input_grad[1] and (not ctx.has_bias or ctx.needs_input_grad[2])) else None
+                gw, gb = wgrad_bf16_ex2(gy, x, bits=y, want_bias=ctx.has_bias, defer_to=defer)
             return gx, gw, gb, None
         ga = gy
         if ctx.needs_input_grad[0]:
@@ -1807,6 +1892,7 @@ class _PmaProjectBf16(torch.autograd.Function):
         x_v, a4 = linear_bf16_fwd(x, w_v, b_v, False, w4, b4)
         ctx.save_for_backward(x, w_v, w4)
         ctx.cfg = (b_v is not None, b_a is not None, H)
+        ctx.params = (w_v, b_v)
         return x_v, (a4 if H == 4 else a4[:, :H].contiguous())
 
     @staticmethod
@@ -1825,7 +1911,8 @@ class _PmaProjectBf16(torch.autograd.Function):
                 and g_v.stride(0) % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0:
             # the four logit rows ride in the value projection's weight-gradient pass (one read of x instead of two)
             g4 = g_alpha if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(g_alpha.shape[0], 4 - H)], dim=1)
-            gwv, gbv, gwa4, gba4 = wgrad_bf16_ex2(g_v, x, g4=g4, want_bias=has_bv)
+            defer = ctx.params if (_Deferred.active and ctx.needs_input_grad[1] and (not has_bv or ctx.needs_input_grad[2])) else None
+            gwv, gbv, gwa4, gba4 = wgrad_bf16_ex2(g_v, x, g4=g4, want_bias=has_bv, defer_to=defer)
             gwa, gba = gwa4[:H], (gba4[:H] if has_ba else None)
             return gx, gwv, gbv, gwa, gba
         if need_v:
@@ -1865,6 +1952,7 @@ class _PmaResidualFFBf16(torch.autograd.Function):
         y, stats = ln_res_fwd(out, None, z, gamma, beta, eps, relu_post, p, seed, base)
         ctx.save_for_backward(out, h, z, stats, w1, w2, gamma, beta, mh, mz)
         ctx.cfg = (bool(relu_post), float(p), seed, base, b1 is not None, b2 is not None)
+        ctx.params = (w1, b1, w2, b2, gamma, beta)
         return y
 
     @staticmethod
@@ -1872,12 +1960,15 @@ class _PmaResidualFFBf16(torch.autograd.Function):
     def backward(ctx, gy):
         out, h, z, stats, w1, w2, gamma, beta, mh, mz = ctx.saved_tensors
         relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
-        gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
+        need = ctx.needs_input_grad
+        dfr = _Deferred.active and all(need[1:7][i] for i, q in enumerate(ctx.params) if q is not None)
+        p_w1, p_b1, p_w2, p_b2, p_g, p_b = ctx.params
+        gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)     # (2048 partial rows: its own reduction)
         if mh is not None:
             gh = linear_bf16_bwd_bits(gs, w2, mz)
-            gw2, gb2 = wgrad_bf16_ex2(gs, h, bits=mz, want_bias=has_b2)
+            gw2, gb2 = wgrad_bf16_ex2(gs, h, bits=mz, want_bias=has_b2, defer_to=(p_w2, p_b2) if dfr else None)
             gout = linear_bf16_bwd_bits(gh, w1, mh, acc_in=gs)                  # gs + the rFF branch
-            gw1, gb1 = wgrad_bf16_ex2(gh, out, bits=mh, want_bias=has_b1)
+            gw1, gb1 = wgrad_bf16_ex2(gh, out, bits=mh, want_bias=has_b1, defer_to=(p_w1, p_b1) if dfr else None)
             return gout, gw1, gb1, gw2, gb2, dg, db, None, None, None
         gh, ga2 = linear_bf16_bwd(gs, w2, z, want_ga=True)
         gw2, gb2 = wgrad(ga2, h, want_bias=has_b2)

@@ -280,6 +280,7 @@ class _PmaPoolTail(torch.autograd.Function):
                                    split=_split(csr, V, heads), sizes=_sizes(csr, V, heads))
         y, saved, cfg = dense.pma_tail_fwd(pooled, att_r.reshape(-1), g0, b0, eps0, w1, b1, w2, b2, g1, bt1, eps1, relu_post, p)
         ctx.inc, ctx.slope, ctx.cshape, ctx.cfg = inc, slope, att_r.shape, cfg
+        ctx.params = (att_r, g0, b0, w1, b1, w2, b2, g1, bt1)     # (the objects themselves: dense.deferred_param_grads assigns their .grad)
         ctx.save_for_backward(V, alpha, m, l, *saved)
         ctx.mark_non_differentiable(m, l)
         ctx.set_materialize_grads(False)     # (m, l never carry a gradient: no [n, H] zero-fills for them in every backward)
@@ -292,13 +293,15 @@ class _PmaPoolTail(torch.autograd.Function):
         if gy is None:
             return (None,) * 18
         V, alpha, m, l = ctx.saved_tensors[:4]
-        g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats = dense.pma_tail_bwd(ctx.saved_tensors[4:], ctx.cfg, gy, m, l)
+        g_pooled, dc, dg0, db0, gw1, gb1, gw2, gb2, dg1, db1, pstats = dense.pma_tail_bwd(
+            ctx.saved_tensors[4:], ctx.cfg, gy, m, l, params=dense.tail_defer_params(ctx, (5, 6, 7, 9, 10, 11, 12, 13, 14)))
         T = ctx.inc.by_src
         H = alpha.shape[1]
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, g_pooled, pstats, ctx.slope,
                                      variant=_variant(T, "pma_bwd_src", V.shape[0], V, H), row_order=T.row_order,
                                      split=_split(T, V, H), sizes=_sizes(T, V, H))
-        return (gV, galpha, None, None, None, dc.reshape(ctx.cshape), dg0, db0, None, gw1, gb1, gw2, gb2, dg1, db1, None, None, None)
+        return (gV, galpha, None, None, None, (dc.reshape(ctx.cshape) if dc is not None else None), dg0, db0, None, gw1, gb1, gw2, gb2,
+                dg1, db1, None, None, None)
 
 
 def pma_pool_tail(V: Tensor, alpha: Tensor, inc: Incidence, heads: int, negative_slope: float, att_r: Tensor, g0, b0, eps0, w1, b1, w2, b2,

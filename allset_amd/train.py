@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dense
 from ._lib import AllSetHipError
 from .models import SetGNN
 from .preprocessing import Add_Self_Loops, ExtractV2E, expand_edge_index, norm_contruction
@@ -543,7 +544,9 @@ def _run_loop(args, model, data, splits, device, logger, runtimes, num_params):
                 model.train()
                 optimizer.zero_grad()
                 loss = nll_log_softmax(model(data), y_all, train_mask, n_train)
-                loss.backward()
+                # every parameter-gradient partial of the backward pass reduced by ONE launch (dense.deferred_param_grads)
+                with dense.deferred_param_grads():
+                    loss.backward()
                 optimizer.step()
                 model.eval()
                 with torch.no_grad():

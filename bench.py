@@ -389,6 +389,12 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
     if "kernels" in hooks and attn:
         extra["kernels"] = hooks["kernels"]
 
+    if on_gpu:
+        from allset_amd.dense import deferred_param_grads as deferred
+    else:
+        import contextlib
+        deferred = contextlib.nullcontext
+
     def step():
         opt.zero_grad(set_to_none=True)
         x.grad = None
@@ -401,7 +407,9 @@ def run_partition(args, mode, world, rank, dev, hooks=None):
             out = adist.sharded_pma_layer(v2e, e2v, x, hg, dropout=args.dropout, training=True, **extra)
         else:
             out = adist.sharded_deepsets_layer(v2e, e2v, x, hg, aggr="add", dropout=args.dropout, training=True, **extra)
-        out.backward(G)
+        # as allset_amd/train.py runs its step: every parameter-gradient partial of the backward pass reduced by ONE launch
+        with deferred():
+            out.backward(G)
         adist.allreduce_grads(params)
         opt.step()
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 13  /* 13: additions only (bf16 regime: allset_linear_bf16_mask_pitch / _fwd_mask / _bwd_bits -- the relu mask as one bit per element --, allset_wgrad_bf16_ex2(_supported) -- that mask and PMA's four auxiliary logit rows inside the weight-gradient pass --, allset_pma_fold_fwd_bf16 / _bwd_bf16).  Earlier:  12: additions only (allset_fused_linear_bwd_pma_tail(_supported), allset_fused_linear_bwd_ln_pro(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now;   2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
+#define ALLSET_ABI_VERSION 14  /* 14: additions only (allset_reduce_partials_batched_ex2: an output type per buffer; allset_reduce_partials_batchable / _batched* now also take the reductions the single entry runs as TWO launches, at most 512 partial rows, with the same association -- a [1M, 128] or [250k, 256] step reduces every parameter gradient of its backward pass in one launch).  13: additions only (bf16 regime: allset_linear_bf16_mask_pitch / _fwd_mask / _bwd_bits -- the relu mask as one bit per element --, allset_wgrad_bf16_ex2(_supported) -- that mask and PMA's four auxiliary logit rows inside the weight-gradient pass --, allset_pma_fold_fwd_bf16 / _bwd_bf16).  Earlier:  12: additions only (allset_fused_linear_bwd_pma_tail(_supported), allset_fused_linear_bwd_ln_pro(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now;   2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
 
 /* ---------------------------------------------------------------------------------------------
  * Dense tail (reference MLP.forward, layers.py:571-579: norm -> [Linear -> ReLU -> norm -> dropout]* -> Linear,
@@ -173,9 +173,10 @@ int allset_reduce_partials_ex(const float* part, int64_t P, int64_t row_stride, 
                               float* scratch, void* stream);
 /* MANY small reductions in ONE launch (ABI 10; a dataset-scale training step is a chain of ~5 us kernels, a third of them
  * allset_reduce_partials): out[k][c] = sum_p parts[k][p * row_stride[k] + c], p < P[k], c < M[k], for k < count <=
- * allset_reduce_partials_batch_max(); every (P[k], M[k]) must satisfy allset_reduce_partials_batchable (the reductions the single
- * entry finishes in one launch: P <= 64, or P <= 512 with P * M <= 2^21).  The pointer / size arrays are HOST arrays (copied into
- * the kernel's arguments).  Sums are bit-identical to count separate allset_reduce_partials calls. */
+ * allset_reduce_partials_batch_max(); every (P[k], M[k]) must satisfy allset_reduce_partials_batchable (P <= 512, P * M < 2^31:
+ * the reductions the single entry finishes in one launch -- P <= 64, or P * M <= 2^21 -- and, since ABI 14, the ones it runs as a
+ * two-launch tree, which one workgroup per column block then walks with the tree's association).  The pointer / size arrays are
+ * HOST arrays (copied into the kernel's arguments).  Sums are bit-identical to count separate allset_reduce_partials calls. */
 int allset_reduce_partials_batch_max(void);
 int allset_reduce_partials_batchable(int64_t P, int64_t M);
 int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
@@ -187,6 +188,16 @@ int allset_reduce_partials_batch_max_counters(void);
 int allset_reduce_partials_batched_ex(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
                                       float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32,
                                       void* stream);
+/* ABI 14.  The same with an output type per buffer: out_dtypes[k] = ALLSET_F32 (outs[k]: f32[M[k]], 16-byte aligned) or ALLSET_BF16
+ * (outs[k]: bf16[M[k]], 8-byte aligned, each sum rounded once -- bit-identical to allset_reduce_partials_ex); NULL = all fp32.
+ * `| ALLSET_REDUCE_AS_TREE`: sum buffer k with the two-launch tree's association whatever its size -- for a COLUMN SLICE of a
+ * wider buffer that must come out with the bits the reduction of the whole buffer gives (allset_reduce_partials_is_tree(P, M) tells
+ * which association the single entry uses for a buffer of M columns). */
+#define ALLSET_REDUCE_AS_TREE 0x100
+int allset_reduce_partials_is_tree(int64_t P, int64_t M);
+int allset_reduce_partials_batched_ex2(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
+                                       void* const* outs, const int32_t* out_dtypes, int64_t count, int64_t* inc_i64,
+                                       float* const* inc_f32, int64_t n_inc_f32, void* stream);
 
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;
