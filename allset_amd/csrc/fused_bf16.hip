@@ -72,6 +72,12 @@ __device__ __forceinline__ uint32_t keep_halves(uint32_t a, uint32_t m) {
   asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(m));
   return r;
 }
+// 8 relu outputs (two per dword, columns in order) -> their 8 "is positive" bits, column j at bit j
+__device__ __forceinline__ uint32_t relu_bits8(const uint4& o) {
+  uint32_t x = nz_halves(o.x);
+  x |= nz_halves(o.y) << 2; x |= nz_halves(o.z) << 4; x |= nz_halves(o.w) << 6;
+  return (x & 0xffu) | ((x >> 16) << 1 & 0xffu);
+}
 // 16 relu outputs (+0 or positive bf16, two per dword, columns in order) -> their 16 "is positive" bits, column j at bit j
 __device__ __forceinline__ uint32_t relu_bits16(const uint4& o0, const uint4& o1) {
   uint32_t x = nz_halves(o0.x);
@@ -198,21 +204,45 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
 #endif
 
   if constexpr (!TRANS_W) {
-    // W[j][k]: 16-byte pieces copy straight into the image
-    for (int idx = tid; idx < ND * KD / 8; idx += kBfBlock) {
+    // W[j][k]: 16-byte pieces copy straight into the image.  ALL of a thread's pieces are requested before the first one is
+    // written (round 6, second session: as a plain loop the compiler kept ONE piece in flight -- load, s_waitcnt vmcnt(0), ds_write,
+    // branch: 16 dependent L2 round trips, most of the 8 us this copy took of a 77-us launch)
+    constexpr int NPW = ND * KD / 8 / kBfBlock;
+    static_assert(ND * KD / 8 % kBfBlock == 0, "weight image: whole pieces per thread");
+    uint4 wreg[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int idx = tid + i * kBfBlock;
       const int j = idx / (KD / 8), k0 = 8 * (idx % (KD / 8));
-      const uint4 w = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(j) * KD + k0);
-      *reinterpret_cast<uint4*>(&sW[wimg_off<KQD, GS>(k0 / KQ, j, (k0 % KQ) / 8)]) = w;
+      wreg[i] = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(j) * KD + k0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int idx = tid + i * kBfBlock;
+      const int j = idx / (KD / 8), k0 = 8 * (idx % (KD / 8));
+      *reinterpret_cast<uint4*>(&sW[wimg_off<KQD, GS>(k0 / KQ, j, (k0 % KQ) / 8)]) = wreg[i];
     }
   } else {
     // W[o][i], reduction over o: the image row of column i holds o-pairs as dwords.  A thread takes 8 columns of two
     // adjacent rows; lanes run along o, so the 64 dwords one instruction writes are 32 consecutive dwords of one image
     // row per k-quarter (two-way bank conflict at worst).
-    for (int idx = tid; idx < (KD / 2) * (ND / 8); idx += kBfBlock) {
+    // (all row pairs of a thread requested before the first is written: see the forward copy above)
+    constexpr int NPT = (KD / 2) * (ND / 8) / kBfBlock;
+    static_assert((KD / 2) * (ND / 8) % kBfBlock == 0, "transposed weight image: whole row pairs per thread");
+    uint4 wr0[NPT], wr1[NPT];
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+      const int idx = tid + it * kBfBlock;
+      const int o = 2 * (idx % (KD / 2)), i0 = 8 * (idx / (KD / 2));
+      wr0[it] = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o) * ND + i0);
+      wr1[it] = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o + 1) * ND + i0);
+    }
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+      const int idx = tid + it * kBfBlock;
       const int op = idx % (KD / 2), i0 = 8 * (idx / (KD / 2));
       const int o = 2 * op;
-      const uint4 r0 = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o) * ND + i0);
-      const uint4 r1 = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o + 1) * ND + i0);
+      const uint4 r0 = wr0[it], r1 = wr1[it];
       const uint32_t a0[4] = {r0.x, r0.y, r0.z, r0.w}, a1[4] = {r1.x, r1.y, r1.z, r1.w};
       const int g = o / KQ, e = o % KQ;
 #pragma unroll
@@ -226,7 +256,13 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
   }
   for (int idx = tid; idx < ND; idx += kBfBlock) sBias[idx] = bias ? bf16_to_f32(bias[idx]) : 0.f;
   if (AUX_OUT || has_aux_in) {
-    for (int idx = tid; idx < 4 * AUXW; idx += kBfBlock) sAux[idx] = bf16_to_f32(aux_w[idx]);
+    constexpr int NA = (4 * AUXW + kBfBlock - 1) / kBfBlock;        // (both requests before the first write, as the weight image)
+    uint16_t ar[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ar[i] = (4 * AUXW % kBfBlock == 0 || tid + i * kBfBlock < 4 * AUXW) ? aux_w[tid + i * kBfBlock] : uint16_t{0};
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (4 * AUXW % kBfBlock == 0 || tid + i * kBfBlock < 4 * AUXW) sAux[tid + i * kBfBlock] = bf16_to_f32(ar[i]);
     if (tid < 4) sAux[4 * AUXW + tid] = (AUX_OUT && aux_b) ? bf16_to_f32(aux_b[tid]) : 0.f;
   }
   __syncthreads();
@@ -338,7 +374,12 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
       return;
     }
 #endif
-    uint32_t mword[ND / 128] = {};
+    uint32_t mword[ND / 128] = {}, mword2[ND / 128] = {};
+#ifdef ALLSET_BF16_HALF_SECTOR_STORES
+    constexpr bool kFullSector = false;
+#else
+    constexpr bool kFullSector = true;
+#endif
 #ifdef ALLSET_BF16_SLAB_EPILOGUE
     const int srow = lane >> 2, sq = lane & 3;
 #else
@@ -399,26 +440,53 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
         const swap2_t y01 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
         const swap2_t x23 = __builtin_amdgcn_permlane16_swap(pk[2].x, pk[3].x, false, false);
         const swap2_t y23 = __builtin_amdgcn_permlane16_swap(pk[2].y, pk[3].y, false, false);
-        // q01 = {x01[0], y01[0], x01[1], y01[1]}: 8 consecutive columns; level 2: the upper 32 lanes of (tiles 0, 1) <-> the lower
-        // 32 of (tiles 2, 3): lane g holds tile g: columns 0-7 in o0, 8-15 in o1
-        const swap2_t s0 = __builtin_amdgcn_permlane32_swap(x01[0], x23[0], false, false);
-        const swap2_t s1 = __builtin_amdgcn_permlane32_swap(y01[0], y23[0], false, false);
-        const swap2_t s2 = __builtin_amdgcn_permlane32_swap(x01[1], x23[1], false, false);
-        const swap2_t s3 = __builtin_amdgcn_permlane32_swap(y01[1], y23[1], false, false);
-        o0 = make_uint4(s0[0], s1[0], s2[0], s3[0]);
-        o1 = make_uint4(s0[1], s1[1], s2[1], s3[1]);
+        // q01 = {x01[0], y01[0], x01[1], y01[1]}: 8 consecutive columns -- lane g holds columns 8 (g >> 1) .. + 7 of tile (g & 1) in
+        // q01 and of tile 2 + (g & 1) in q23.  Stored like that (round 6, second session), the four lanes of a row write 64 CONTIGUOUS
+        // bytes per store instruction -- whole 64-byte sectors -- where the former second level (v_permlane32_swap: lane g = tile g,
+        // 32 contiguous bytes per lane) left every sector half-written by each of the two instructions.
+        if constexpr (kFullSector) {
+          o0 = make_uint4(x01[0], y01[0], x01[1], y01[1]);
+          o1 = make_uint4(x23[0], y23[0], x23[1], y23[1]);
+        } else {
+          // level 2: the upper 32 lanes of (tiles 0, 1) <-> the lower 32 of (tiles 2, 3): lane g holds tile g: columns 0-7 in o0, 8-15 in o1
+          const swap2_t s0 = __builtin_amdgcn_permlane32_swap(x01[0], x23[0], false, false);
+          const swap2_t s1 = __builtin_amdgcn_permlane32_swap(y01[0], y23[0], false, false);
+          const swap2_t s2 = __builtin_amdgcn_permlane32_swap(x01[1], x23[1], false, false);
+          const swap2_t s3 = __builtin_amdgcn_permlane32_swap(y01[1], y23[1], false, false);
+          o0 = make_uint4(s0[0], s1[0], s2[0], s3[0]);
+          o1 = make_uint4(s0[1], s1[1], s2[1], s3[1]);
+        }
       }
 #endif
 #ifdef ALLSET_BF16_ABL_NOSTORE              // (ablation: the epilogue without its global stores)
       if (srow < rh && o0.x == 0x12345678u && o1.w == 0x9abcdef0u) y[chunk] = 1;
 #else
       if (srow < rh) {
-        uint4* dst = reinterpret_cast<uint4*>(y + chunk * 16 * ldy + (srow * static_cast<uint32_t>(ldy) + sq * 16 + hb * 64));
-        dst[0] = o0;
-        dst[1] = o1;
+#ifndef ALLSET_BF16_SLAB_EPILOGUE
+        if constexpr (kFullSector) {
+          uint4* dst = reinterpret_cast<uint4*>(y + chunk * 16 * ldy + (srow * static_cast<uint32_t>(ldy) + (sq & 1) * 16 + (sq >> 1) * 8 + hb * 64));
+          dst[0] = o0;
+          dst[4] = o1;                              // (+ 32 columns)
+        } else
+#endif
+        {
+          uint4* dst = reinterpret_cast<uint4*>(y + chunk * 16 * ldy + (srow * static_cast<uint32_t>(ldy) + sq * 16 + hb * 64));
+          dst[0] = o0;
+          dst[1] = o1;
+        }
       }
 #endif
       if constexpr (MASK_OUT) {
+#ifndef ALLSET_BF16_SLAB_EPILOGUE
+        if constexpr (kFullSector) {
+          // this lane's 8 columns of tile (sq & 1) are bits 16 hb + 8 (sq >> 1) .. of word (sq & 1), those of tile 2 + (sq & 1) the
+          // same bits of word 2 + (sq & 1); the two lanes of a word trade halves after the loop
+          const uint32_t sh = 16 * (hb & 1) + 8 * (sq >> 1);
+          const uint32_t ba = relu_bits8(o0) << sh, bb = relu_bits8(o1) << sh;
+          if (hb & 1) { mword[hb >> 1] |= ba; mword2[hb >> 1] |= bb; }
+          else { mword[hb >> 1] = ba; mword2[hb >> 1] = bb; }
+        } else
+#endif
         {                                           // the relu mask of these 16 columns: bits 16 hb .. of this lane's word sq
           const uint32_t b16 = relu_bits16(o0, o1);
           if (hb & 1) mword[hb >> 1] |= b16 << 16;
@@ -427,6 +495,17 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
       }
     }
     if constexpr (MASK_OUT) {
+#ifndef ALLSET_BF16_SLAB_EPILOGUE
+      if constexpr (kFullSector) {
+        // lanes g and g ^ 2 (32 lanes apart) hold the two halves of words (g & 1) and 2 + (g & 1): after the swap the lower 32 lanes
+        // have both halves of the first, the upper 32 both halves of the second -- lane g ends up with word g, as before
+#pragma unroll
+        for (int w = 0; w < ND / 128; ++w) {
+          const swap2_t t = __builtin_amdgcn_permlane32_swap(mword[w], mword2[w], false, false);
+          mword[w] = t[0] | t[1];
+        }
+      }
+#endif
       if (srow < rh) {
         uint8_t* mp = mask_out + chunk * 16 * (ND / 8) + (srow * static_cast<uint32_t>(ND / 8) + sq * (ND / 32));
         if constexpr (ND == 256) *reinterpret_cast<uint2*>(mp) = make_uint2(mword[0], mword[1]);

@@ -99,13 +99,30 @@ __global__ __launch_bounds__(kMBlock) void fused_linear_bwd_all_kernel(
   __shared__ __attribute__((aligned(16))) float sG[ID];
   __shared__ __attribute__((aligned(16))) float sB[ID];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < (OD / 2) * ID; idx += kMBlock) {
-    const int o = 2 * (idx / ID), i = idx % ID;                      // threads run along i: coalesced reads of W
-    uint32_t ph, pm, pl;
-    split3_bf16(W[o * ID + i], W[(o + 1) * ID + i], ph, pm, pl);
-    const int e = o % OQ;
-    const int off = mplane_off<OQD, GS>(o / OQ, i, e / 8) + (e % 8) / 2;
-    sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+  {   // all of a thread's weight pairs requested before the first is split and written (a plain loop kept ONE in flight: see fused_mlp.hip)
+    constexpr int NPW = ((OD / 2) * ID + kMBlock - 1) / kMBlock;
+    constexpr int NB = NPW > 16 ? 16 : NPW;                          // (batches of 16 pairs: 32 registers)
+    for (int b0 = 0; b0 < NPW; b0 += NB) {
+      float w0[NB], w1[NB];
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        const int idx = tid + (b0 + it) * kMBlock;
+        const int o = 2 * (idx / ID), i = idx % ID;                  // threads run along i: coalesced reads of W
+        if (idx < (OD / 2) * ID) { w0[it] = W[o * ID + i]; w1[it] = W[(o + 1) * ID + i]; }
+      }
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        const int idx = tid + (b0 + it) * kMBlock;
+        const int o = 2 * (idx / ID), i = idx % ID;
+        if (idx < (OD / 2) * ID) {
+          uint32_t ph, pm, pl;
+          split3_bf16(w0[it], w1[it], ph, pm, pl);
+          const int e = o % OQ;
+          const int off = mplane_off<OQD, GS>(o / OQ, i, e / 8) + (e % 8) / 2;
+          sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+        }
+      }
+    }
   }
   for (int idx = tid; idx < ID; idx += kMBlock) {
     sG[idx] = HAS_LN ? gamma[idx] : 1.f;

@@ -103,14 +103,30 @@ __global__ __launch_bounds__(fwd_x6_waves<HAS_LN>() * kWave) void fused_linear_f
     for (int idx = tid; idx < 4 * KD; idx += kF6Block) sAux[idx] = aux_w[idx];
     if (tid < 4) sAux[4 * KD + tid] = aux_b ? aux_b[tid] : 0.f;
   }
-  for (int idx = tid; idx < ND * KD / 2; idx += kF6Block) {
-    const int j = idx / (KD / 2), k = 2 * (idx % (KD / 2));
-    const float2 w = *reinterpret_cast<const float2*>(W + j * KD + k);
-    uint32_t ph, pm, pl;
-    split3_bf16(w.x, w.y, ph, pm, pl);
-    const int e = k % KQ;
-    const int off = plane_off<KQD, GS>(k / KQ, j, e / 8) + (e % 8) / 2;
-    sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+  // ALL of a thread's weight pairs are requested before the first is split and written (as a plain loop the compiler kept ONE in
+  // flight -- load, s_waitcnt vmcnt(0), three ds_writes, branch -- 4 to 16 dependent L2 round trips at the head of a kernel that,
+  // at dataset scale, runs for ~5 us in all; found in the ISA of csrc/fused_bf16.hip's copy, round 6)
+  {
+    constexpr int NPW = (ND * KD / 2 + kF6Block - 1) / kF6Block;
+    float2 wreg[NPW];
+#pragma unroll
+    for (int it = 0; it < NPW; ++it) {
+      const int idx = tid + it * kF6Block;
+      const int j = idx / (KD / 2), k = 2 * (idx % (KD / 2));
+      if (ND * KD / 2 % kF6Block == 0 || idx < ND * KD / 2) wreg[it] = *reinterpret_cast<const float2*>(W + j * KD + k);
+    }
+#pragma unroll
+    for (int it = 0; it < NPW; ++it) {
+      const int idx = tid + it * kF6Block;
+      const int j = idx / (KD / 2), k = 2 * (idx % (KD / 2));
+      if (ND * KD / 2 % kF6Block == 0 || idx < ND * KD / 2) {
+        uint32_t ph, pm, pl;
+        split3_bf16(wreg[it].x, wreg[it].y, ph, pm, pl);
+        const int e = k % KQ;
+        const int off = plane_off<KQD, GS>(k / KQ, j, e / 8) + (e % 8) / 2;
+        sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+      }
+    }
   }
   for (int idx = tid; idx < KD; idx += kF6Block) {
     sG[idx] = HAS_LN ? gamma[idx] : 1.f;
@@ -357,13 +373,27 @@ __global__ __launch_bounds__(kX6Block) void fused_linear_bwd_x6_kernel(
   __shared__ __attribute__((aligned(16))) float sG[ID];
   __shared__ __attribute__((aligned(16))) float sTrans[kX6Waves * 16 * 64];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < (OD / 2) * ID; idx += kX6Block) {
-    const int o = 2 * (idx / ID), i = idx % ID;                      // threads run along i: coalesced reads of W
-    uint32_t ph, pm, pl;
-    split3_bf16(W[o * ID + i], W[(o + 1) * ID + i], ph, pm, pl);
-    const int e = o % OQ;
-    const int off = plane_off<OQD, GS>(o / OQ, i, e / 8) + (e % 8) / 2;
-    sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+  {                                                                   // (all requests before the first split: see the forward kernel)
+    constexpr int NPW = ((OD / 2) * ID + kX6Block - 1) / kX6Block;
+    float w0[NPW], w1[NPW];
+#pragma unroll
+    for (int it = 0; it < NPW; ++it) {
+      const int idx = tid + it * kX6Block;
+      const int o = 2 * (idx / ID), i = idx % ID;                    // threads run along i: coalesced reads of W
+      if ((OD / 2) * ID % kX6Block == 0 || idx < (OD / 2) * ID) { w0[it] = W[o * ID + i]; w1[it] = W[(o + 1) * ID + i]; }
+    }
+#pragma unroll
+    for (int it = 0; it < NPW; ++it) {
+      const int idx = tid + it * kX6Block;
+      const int o = 2 * (idx / ID), i = idx % ID;
+      if ((OD / 2) * ID % kX6Block == 0 || idx < (OD / 2) * ID) {
+        uint32_t ph, pm, pl;
+        split3_bf16(w0[it], w1[it], ph, pm, pl);
+        const int e = o % OQ;
+        const int off = plane_off<OQD, GS>(o / OQ, i, e / 8) + (e % 8) / 2;
+        sWh[off] = ph; sWm[off] = pm; sWl[off] = pl;
+      }
+    }
   }
   for (int idx = tid; idx < ID; idx += kX6Block) sG[idx] = HAS_LN ? gamma[idx] : 1.f;
   __syncthreads();

@@ -309,8 +309,8 @@ def test_bf16_parity_bound_catches_a_wrong_weight_gradient(name, device, monkeyp
     monkeypatch.setattr(dense, "wgrad", transposed)
     real2 = dense.wgrad_bf16_ex2
 
-    def transposed2(ga, u, bits=None, g4=None, want_bias=True):        # (round 6: the masked / auxiliary-row form of the same kernel)
-        res = list(real2(ga, u, bits=bits, g4=g4, want_bias=want_bias))
+    def transposed2(ga, u, bits=None, g4=None, want_bias=True, defer_to=None):    # (round 6: the masked / auxiliary-row form of the same kernel)
+        res = list(real2(ga, u, bits=bits, g4=g4, want_bias=want_bias))            # (reduced at once: the test transposes the result)
         if res[0].shape[0] == res[0].shape[1]:
             res[0] = res[0].t().contiguous()
         return tuple(res)

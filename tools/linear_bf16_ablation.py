@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ABL = os.path.join(ROOT, ".abl")
 SRC = [os.path.join(ROOT, "allset_amd", "csrc", f) for f in ("fused_bf16.hip", "abi.hip")]
-ARMS = [("full", []), ("slab epilogue", ["-DALLSET_BF16_SLAB_EPILOGUE"]), ("three row buffers", ["-DALLSET_BF16_DEPTH3"]), ("early first request", ["-DALLSET_BF16_EARLY_REQUEST"]), ("no-load", ["-DALLSET_BF16_ABL_NOLOAD"]), ("no-store", ["-DALLSET_BF16_ABL_NOSTORE"]),
+ARMS = [("full", []), ("half-sector stores (round-6 first session)", ["-DALLSET_BF16_HALF_SECTOR_STORES"]), ("slab epilogue", ["-DALLSET_BF16_SLAB_EPILOGUE"]), ("three row buffers", ["-DALLSET_BF16_DEPTH3"]), ("early first request", ["-DALLSET_BF16_EARLY_REQUEST"]), ("no-load", ["-DALLSET_BF16_ABL_NOLOAD"]), ("no-store", ["-DALLSET_BF16_ABL_NOSTORE"]),
         ("no-epilogue", ["-DALLSET_BF16_ABL_NOEPI"]), ("no-mfma", ["-DALLSET_BF16_ABL_NOMFMA"]),
         ("no-mfma no-epilogue", ["-DALLSET_BF16_ABL_NOMFMA", "-DALLSET_BF16_ABL_NOEPI"]),
         ("no-load no-epilogue", ["-DALLSET_BF16_ABL_NOLOAD", "-DALLSET_BF16_ABL_NOEPI"]),
