@@ -223,34 +223,40 @@ __global__ __launch_bounds__(kBfBlock) void linear_bf16_kernel(
       *reinterpret_cast<uint4*>(&sW[wimg_off<KQD, GS>(k0 / KQ, j, (k0 % KQ) / 8)]) = wreg[i];
     }
   } else {
-    // W[o][i], reduction over o: the image row of column i holds o-pairs as dwords.  A thread takes 8 columns of two
-    // adjacent rows; lanes run along o, so the 64 dwords one instruction writes are 32 consecutive dwords of one image
-    // row per k-quarter (two-way bank conflict at worst).
-    // (all row pairs of a thread requested before the first is written: see the forward copy above)
-    constexpr int NPT = (KD / 2) * (ND / 8) / kBfBlock;
-    static_assert((KD / 2) * (ND / 8) % kBfBlock == 0, "transposed weight image: whole row pairs per thread");
-    uint4 wr0[NPT], wr1[NPT];
+    // W[o][i] (the layer's [out, in] weight), reduction over o: the image row of column i holds its 256 o-values, so the copy is
+    // a transpose.  A thread takes an 8 x 8 block (8 rows o, one 16-byte piece of 8 columns each), transposes it in registers
+    // (v_perm_b32: dword m of column c = {W[o0 + 2m][c], W[o0 + 2m + 1][c]}) and writes eight 16-byte pieces -- each exactly one
+    // piece (k-quarter, column, 8 k) of the image.  Round 6, second session: the former copy wrote 64 single dwords per thread
+    // behind one load at a time, 15 of the launch's ~78 us.  A wave-sized group of 64 blocks is 8 o-blocks x 8 column blocks: a
+    // load instruction reads 128 contiguous bytes of 8 rows, a write instruction spreads over 8 distinct 16-byte bank groups.
+    constexpr int NBLK = (KD / 8) * (ND / 8), NBT = (NBLK + kBfBlock - 1) / kBfBlock;
+    uint4 wreg[NBT][8];
 #pragma unroll
-    for (int it = 0; it < NPT; ++it) {
-      const int idx = tid + it * kBfBlock;
-      const int o = 2 * (idx % (KD / 2)), i0 = 8 * (idx / (KD / 2));
-      wr0[it] = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o) * ND + i0);
-      wr1[it] = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(o + 1) * ND + i0);
+    for (int sblk = 0; sblk < NBT; ++sblk) {
+      const int b = tid + sblk * kBfBlock, grp = b >> 6;
+      const int ob = (b & 7) + 8 * (grp % (KD / 64)), ib = ((b >> 3) & 7) + 8 * (grp / (KD / 64));
+      if (NBLK % kBfBlock == 0 || b < NBLK) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) wreg[sblk][r] = *reinterpret_cast<const uint4*>(W + static_cast<int64_t>(8 * ob + r) * ND + 8 * ib);
+      }
     }
 #pragma unroll
-    for (int it = 0; it < NPT; ++it) {
-      const int idx = tid + it * kBfBlock;
-      const int op = idx % (KD / 2), i0 = 8 * (idx / (KD / 2));
-      const int o = 2 * op;
-      const uint4 r0 = wr0[it], r1 = wr1[it];
-      const uint32_t a0[4] = {r0.x, r0.y, r0.z, r0.w}, a1[4] = {r1.x, r1.y, r1.z, r1.w};
-      const int g = o / KQ, e = o % KQ;
+    for (int sblk = 0; sblk < NBT; ++sblk) {
+      const int b = tid + sblk * kBfBlock, grp = b >> 6;
+      const int ob = (b & 7) + 8 * (grp % (KD / 64)), ib = ((b >> 3) & 7) + 8 * (grp / (KD / 64));
+      if (NBLK % kBfBlock == 0 || b < NBLK) {
+        const int gq = (8 * ob) / KQ, tp = ((8 * ob) % KQ) / 8;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int base0 = wimg_off<KQD, GS>(g, i0 + 2 * q, e / 8) + (e % 8) / 2;
-        const int base1 = wimg_off<KQD, GS>(g, i0 + 2 * q + 1, e / 8) + (e % 8) / 2;
-        sW[base0] = (a0[q] & 0xffffu) | (a1[q] << 16);
-        sW[base1] = (a0[q] >> 16) | (a1[q] & 0xffff0000u);
+        for (int c = 0; c < 8; ++c) {
+          uint32_t d[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const uint4 &ra = wreg[sblk][2 * m], &rb = wreg[sblk][2 * m + 1];
+            const uint32_t a = c < 2 ? ra.x : c < 4 ? ra.y : c < 6 ? ra.z : ra.w, bb = c < 2 ? rb.x : c < 4 ? rb.y : c < 6 ? rb.z : rb.w;
+            d[m] = (c & 1) ? __builtin_amdgcn_perm(bb, a, 0x07060302u) : __builtin_amdgcn_perm(bb, a, 0x05040100u);
+          }
+          *reinterpret_cast<uint4*>(&sW[wimg_off<KQD, GS>(gq, 8 * ib + c, tp)]) = make_uint4(d[0], d[1], d[2], d[3]);
+        }
       }
     }
   }
