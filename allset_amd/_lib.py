@@ -104,6 +104,11 @@ SIGNATURES = {
     "allset_sparse_ln_linear_fwd": [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_float, c_float, c_uint64, _P, _P, c_int64, _P, _P, _P],
     "allset_sparse_ln_linear_bwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P],
     "allset_unfold_ln_linear_ex": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64, _P],
+    "allset_sparse_linear_supported": [c_int64, c_int64],
+    "allset_sparse_linear_pitch": [c_int64, c_int64],
+    "allset_sparse_linear_wt": [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, _P, _P],
+    "allset_sparse_linear_fwd": [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_float, c_uint64, _P, _P, c_int64, _P, _P, _P],
+    "allset_sparse_linear_bwd": [_P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P],
     "allset_linear_narrow_supported": [c_int64, c_int64],
     "allset_linear_narrow_slices": [c_int64, POINTER(c_int64)],
     "allset_linear_narrow_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P],
@@ -234,6 +239,7 @@ def load() -> ctypes.CDLL:
     lib.allset_gemm_x6_lnb_partials.restype = c_int64
     lib.allset_input_linear_k.restype = c_int64
     lib.allset_linear_bf16_mask_pitch.restype = c_int64
+    lib.allset_sparse_linear_pitch.restype = c_int64
     lib.allset_last_error.argtypes = []
     lib.allset_last_error.restype = c_char_p
     got = lib.allset_version()

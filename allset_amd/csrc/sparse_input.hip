@@ -217,6 +217,178 @@ __global__ __launch_bounds__(kBlock) void sparse_ln_bwd_kernel(const int32_t* __
   M[static_cast<int64_t>(4 * li + 3) * ldm + j] = acc.w;
 }
 
+// ---- the same idea for a PLAIN Linear on sparse raw features: PMA's value projection and its folded logits on the first conv of an
+// AllSetTransformer (reference models.py:473 + layers.py:126-131: dropout(x) through lin_V and lin_K on Citeseer's 3703-wide rows;
+// round 6: these two Linears were 147 us of library GEMMs and 18 us of dropout in a 440-us graphed training step).
+//   [y | a][r, :] = sum_{j in nnz(r)} v_rj [W1; W2]^T[j, :] + [b1 | b2],  v = dropout(x)
+//   gW[:, j] = sum_{r in nnz(j)} v_rj [gy | ga][r, :],  gb = sum_r [gy | ga][r, :]
+// W1 [O1, d] (the projection), W2 [O2 <= 4, d] (the folded logit rows); one lane owns 4 consecutive outputs of the stacked row.
+__global__ __launch_bounds__(kBlock) void sparse_wt_kernel(const float* __restrict__ W1, int64_t ld1, int O1, const float* __restrict__ W2,
+                                                           int64_t ld2, int O2, const float* __restrict__ b1, const float* __restrict__ b2,
+                                                           int d, float* __restrict__ WT, int pitch) {
+  __shared__ float tile[64][65];
+  const int t = threadIdx.x;
+  const int n_tiles = (d + 63) / 64;
+  if (static_cast<int>(blockIdx.x) == n_tiles) {                // row d: the stacked bias
+    for (int k = t; k < pitch; k += kBlock)
+      WT[static_cast<int64_t>(d) * pitch + k] = k < O1 ? (b1 ? b1[k] : 0.f) : (k < O1 + O2 ? (b2 ? b2[k - O1] : 0.f) : 0.f);
+    return;
+  }
+  const int j0 = blockIdx.x * 64, jl = t & 63, kq = t >> 6;     // transpose 64 input columns x all outputs, 64 outputs at a time
+  const int j = j0 + jl;
+  for (int k0 = 0; k0 < pitch; k0 += 64) {
+    __syncthreads();
+    for (int k = kq; k < 64; k += 4) {
+      const int o = k0 + k;
+      float v = 0.f;
+      if (j < d) {
+        if (o < O1) v = W1[static_cast<int64_t>(o) * ld1 + j];
+        else if (o < O1 + O2) v = W2[static_cast<int64_t>(o - O1) * ld2 + j];
+      }
+      tile[jl][k] = v;
+    }
+    __syncthreads();
+    for (int r = kq; r < 64; r += 4)
+      if (j0 + r < d && k0 + jl < pitch) WT[static_cast<int64_t>(j0 + r) * pitch + k0 + jl] = tile[r][jl];
+  }
+}
+
+// LPR lanes per row (4 LPR >= pitch), 64 / LPR rows per wave; lanes past the stacked width idle.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sparse_lin_fwd_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ val, int64_t n, int d,
+                                                                const float* __restrict__ WT, int pitch, int O1, int O2, float p_pre,
+                                                                uint64_t seed, const uint64_t* __restrict__ seed_base,
+                                                                float* __restrict__ y, int64_t ldy, float* __restrict__ y2,
+                                                                float* __restrict__ w_out) {
+  constexpr int NS = kWave / LPR;
+  seed = resolve_seed(seed_base, seed);
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR, lane0 = slot * LPR;
+  const int64_t r = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const bool live = r < n;
+  const bool owns = 4 * li < pitch;
+  const int p0 = live ? rowptr[r] : 0, p1 = live ? rowptr[r + 1] : 0;
+  const float inv_keep = p_pre > 0.f ? 1.f / (1.f - p_pre) : 1.f;
+  const uint32_t thr = drop_threshold(p_pre);
+  const int len = p1 - p0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = 0; b0 < len; b0 += LPR) {
+    const int p = p0 + b0 + li;
+    int c = 0;
+    float v = 0.f;
+    if (b0 + li < len) {
+      c = col[p];
+      v = val[p];
+      if (p_pre > 0.f) v *= keep_scale(seed, r * d + c, thr, inv_keep);
+      w_out[p] = v;
+    }
+    const int nb = min(LPR, len - b0);
+    for (int j = 0; j < nb; j += 8) {                     // eight gathers in flight (past the batch's end: v = 0, row 0 of the weight)
+      float4 wv[8];
+      float vj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = lane0 + ((j + u) & (LPR - 1));
+        const int cj = (j + u < nb) ? __shfl(c, src) : 0;
+        vj[u] = (j + u < nb) ? __shfl(v, src) : 0.f;
+        wv[u] = owns ? *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(cj) * pitch + 4 * li) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x = fmaf(vj[u], wv[u].x, acc.x); acc.y = fmaf(vj[u], wv[u].y, acc.y);
+        acc.z = fmaf(vj[u], wv[u].z, acc.z); acc.w = fmaf(vj[u], wv[u].w, acc.w);
+      }
+    }
+  }
+  if (!live || !owns) return;
+  const float4 bp = *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(d) * pitch + 4 * li);
+  const float4 o = make_float4(acc.x + bp.x, acc.y + bp.y, acc.z + bp.z, acc.w + bp.w);
+  if (4 * li < O1) *reinterpret_cast<float4*>(y + r * ldy + 4 * li) = o;
+  else if (4 * li == O1 && O2 > 0) *reinterpret_cast<float4*>(y2 + r * 4) = o;           // (O1 % 4 == 0: the auxiliary columns are one lane's)
+}
+
+// Workgroups [0, feat_blocks): LPR lanes per feature j (CSC row), gW[k, j] = sum_p w[posT[p]] g[rowT[p], k] with g = [gy | g2].
+// Workgroups [feat_blocks, feat_blocks + kSpSlices): sb_part[slice][k] = sum_r g[r, k] over the slice (the stacked bias gradient).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sparse_lin_bwd_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowT,
+                                                                const int32_t* __restrict__ posT, const float* __restrict__ w,
+                                                                const float* __restrict__ gy, int64_t ldg, const float* __restrict__ g2,
+                                                                int64_t n, int d, int pitch, int O1, int O2, float* __restrict__ gW1,
+                                                                int64_t ldw1, float* __restrict__ gW2, int64_t ldw2,
+                                                                float* __restrict__ sb_part, int feat_blocks) {
+  constexpr int NS = kWave / LPR;
+  if (static_cast<int>(blockIdx.x) >= feat_blocks) {
+    __shared__ float4 red[kBlock];
+    const int slice = blockIdx.x - feat_blocks;
+    const int t = threadIdx.x, q = t % LPR, g = t / LPR;
+    constexpr int G = kBlock / LPR;
+    const int64_t rows = (n + kSpSlices - 1) / kSpSlices;
+    const int64_t r0 = slice * rows, r1 = min(r0 + rows, n);
+    const bool main_q = 4 * q < O1, aux_q = 4 * q == O1 && O2 > 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (main_q || aux_q) {
+#pragma unroll 4
+      for (int64_t r = r0 + g; r < r1; r += G) {
+        const float4 v = main_q ? *reinterpret_cast<const float4*>(gy + r * ldg + 4 * q) : *reinterpret_cast<const float4*>(g2 + r * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    red[t] = s;
+    __syncthreads();
+    if (g == 0 && 4 * q < pitch) {
+      for (int gg = 1; gg < G; ++gg) {
+        const float4 a = red[gg * LPR + q];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+      *reinterpret_cast<float4*>(sb_part + static_cast<int64_t>(slice) * pitch + 4 * q) = s;
+    }
+    return;
+  }
+  const int lane = lane_id();
+  const int slot = lane / LPR, li = lane % LPR, lane0 = slot * LPR;
+  const int j = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const bool live = j < d;
+  const bool main_l = 4 * li < O1, aux_l = 4 * li == O1 && O2 > 0;
+  const int p0 = live ? colptr[j] : 0, p1 = live ? colptr[j + 1] : 0;
+  const int len = p1 - p0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = 0; b0 < len; b0 += LPR) {
+    const int p = p0 + b0 + li;
+    int rr = 0;
+    float wv = 0.f;
+    if (b0 + li < len) { rr = rowT[p]; wv = w[posT[p]]; }
+    const int nb = min(LPR, len - b0);
+    for (int i = 0; i < nb; i += 8) {                     // eight gathers in flight (past the batch's end: w = 0, row 0)
+      float4 g4[8];
+      float wi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = lane0 + ((i + u) & (LPR - 1));
+        const int ri = (i + u < nb) ? __shfl(rr, src) : 0;
+        wi[u] = (i + u < nb) ? __shfl(wv, src) : 0.f;
+        g4[u] = main_l ? *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(ri) * ldg + 4 * li)
+                       : (aux_l ? *reinterpret_cast<const float4*>(g2 + static_cast<int64_t>(ri) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x = fmaf(wi[u], g4[u].x, acc.x); acc.y = fmaf(wi[u], g4[u].y, acc.y);
+        acc.z = fmaf(wi[u], g4[u].z, acc.z); acc.w = fmaf(wi[u], g4[u].w, acc.w);
+      }
+    }
+  }
+  if (!live) return;
+  if (main_l) {
+    gW1[static_cast<int64_t>(4 * li) * ldw1 + j] = acc.x;
+    gW1[static_cast<int64_t>(4 * li + 1) * ldw1 + j] = acc.y;
+    gW1[static_cast<int64_t>(4 * li + 2) * ldw1 + j] = acc.z;
+    gW1[static_cast<int64_t>(4 * li + 3) * ldw1 + j] = acc.w;
+  } else if (aux_l) {
+    const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+    for (int u = 0; u < O2; ++u) gW2[static_cast<int64_t>(u) * ldw2 + j] = a[u];
+  }
+}
+
 }  // namespace allset
 
 using namespace allset;
@@ -286,6 +458,72 @@ extern "C" int allset_sparse_ln_linear_bwd(const int32_t* colptr, const int32_t*
     case 32: sparse_ln_bwd_kernel<32><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, rm, gy, ldg, n, di, M, ldm, su_part, feat_blocks); break;
     default: sparse_ln_bwd_kernel<64><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, rm, gy, ldg, n, di, M, ldm, su_part, feat_blocks); break;
   }
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+// ---- ABI 14: the plain Linear (+ up to 4 auxiliary output rows) on sparse raw features -------------------------------------------------
+// Built for O1 in {64, 128} and O2 <= 4 (PMA's value projection with its folded logit rows).  pitch = allset_sparse_linear_pitch(O1, O2).
+extern "C" int allset_sparse_linear_supported(int64_t O1, int64_t O2) { return ((O1 == 64 || O1 == 128) && O2 >= 0 && O2 <= 4) ? 1 : 0; }
+extern "C" int64_t allset_sparse_linear_pitch(int64_t O1, int64_t O2) { return allset_sparse_linear_supported(O1, O2) ? O1 + (O2 > 0 ? 4 : 0) : 0; }
+
+extern "C" int allset_sparse_linear_wt(const float* W1, int64_t ld1, int64_t O1, const float* W2, int64_t ld2, int64_t O2, const float* b1,
+                                       const float* b2, int64_t d, float* WT, void* stream) {
+  clear_error();
+  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_wt: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(d >= 1 && d < INT32_MAX - 64, "sparse_linear_wt: bad size");
+  ALLSET_REQUIRE(W1 && WT && (O2 == 0 || W2) && ld1 >= d && (O2 == 0 || ld2 >= d), "sparse_linear_wt: null pointer or leading dimension smaller than d");
+  const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
+  const unsigned grid = static_cast<unsigned>((d + 63) / 64 + 1);
+  sparse_wt_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(W1, ld1, static_cast<int>(O1), W2, ld2, static_cast<int>(O2), b1, b2,
+                                                                         static_cast<int>(d), WT, pitch);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+// y [n, O1] (ldy), y2 [n, 4] (the auxiliary columns, padded to four), w_out [nnz] = the values after the dropout (kept for the backward)
+extern "C" int allset_sparse_linear_fwd(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n, int64_t d, const float* WT,
+                                        int64_t O1, int64_t O2, float p_pre, uint64_t seed, const uint64_t* seed_base, float* y, int64_t ldy,
+                                        float* y2, float* w_out, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_linear_fwd: bad size");
+  ALLSET_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "sparse_linear_fwd: dropout p must be in [0,1)");
+  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_fwd: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
+  if (n == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(rowptr && WT && y && w_out && (O2 == 0 || y2), "sparse_linear_fwd: null pointer");
+  ALLSET_REQUIRE(ldy >= O1 && ldy % 4 == 0 && aligned16(y) && aligned16(WT) && (O2 == 0 || aligned16(y2)),
+                 "sparse_linear_fwd: y rows, y2 and WT must be 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
+  const int lpr = O1 == 64 ? 32 : 64;
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
+  const int di = static_cast<int>(d), o1 = static_cast<int>(O1), o2 = static_cast<int>(O2);
+  if (lpr == 32) sparse_lin_fwd_kernel<32><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, pitch, o1, o2, p_pre, seed, seed_base, y, ldy, y2, w_out);
+  else sparse_lin_fwd_kernel<64><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, pitch, o1, o2, p_pre, seed, seed_base, y, ldy, y2, w_out);
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+// gW1 [O1, d] (ldw1), gW2 [O2, d] (ldw2), sb_part [allset_sparse_ln_linear_slices()][pitch]: the caller sums the slices into [gb1 | gb2]
+extern "C" int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* rowT, const int32_t* posT, const float* w, const float* gy,
+                                        int64_t ldg, const float* g2, int64_t n, int64_t d, int64_t O1, int64_t O2, float* gW1, int64_t ldw1,
+                                        float* gW2, int64_t ldw2, float* sb_part, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_linear_bwd: bad size");
+  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_bwd: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
+  ALLSET_REQUIRE(colptr && gW1 && sb_part && (O2 == 0 || gW2) && (n == 0 || (gy && w && (O2 == 0 || g2))), "sparse_linear_bwd: null pointer");
+  ALLSET_REQUIRE(ldw1 >= d && (O2 == 0 || ldw2 >= d) && (n == 0 || (ldg >= O1 && ldg % 4 == 0 && aligned16(gy) && (O2 == 0 || aligned16(g2)))) &&
+                 aligned16(sb_part), "sparse_linear_bwd: leading dimensions; gy rows, g2 and sb_part 16-byte aligned");
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
+  const int lpr = O1 == 64 ? 32 : 64;
+  const int64_t feats_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const int feat_blocks = static_cast<int>((d + feats_per_block - 1) / feats_per_block);
+  const unsigned grid = static_cast<unsigned>(feat_blocks + kSpSlices);
+  const int di = static_cast<int>(d), o1 = static_cast<int>(O1), o2 = static_cast<int>(O2);
+  if (lpr == 32) sparse_lin_bwd_kernel<32><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
+  else sparse_lin_bwd_kernel<64><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -2209,6 +2209,70 @@ class _SparseInputNormLinear(torch.autograd.Function):
                 gb if (ctx.has_bias and need[5]) else None, None, None)
 
 
+class _SparsePmaProject(torch.autograd.Function):
+    """``(x_V, alpha) = (dropout_p(x) W_V^T + b_V,  dropout_p(x) w_a^T + b_a)`` from the non-zeros of raw features ``x`` (no input
+    gradient): PMA's value projection and its folded logits on the first conv of an AllSetTransformer (reference models.py:473,
+    layers.py:126-131) -- three kernels forward (transposed stacked weight, gather-sum; the dropout is a hash site of the latter), one
+    gather-sum over the CSC backward + the bias sums.  csrc/sparse_input.hip ``sparse_lin_*``."""
+
+    @staticmethod
+    def forward(ctx, x, sp, w_v, b_v, w_a, b_a, p_pre):
+        lib = _lib.load()
+        dev = x.device
+        O1, d = w_v.shape
+        H = w_a.shape[0]
+        n = x.shape[0]
+        seed = _draw_seed() if p_pre > 0.0 else 0
+        base = _seed_base() if p_pre > 0.0 else None
+        w_v_c, w_a_c = _rowmajor(w_v), _rowmajor(w_a)
+        pitch = int(lib.allset_sparse_linear_pitch(O1, H))
+        wt = torch.empty((d + 1, pitch), dtype=torch.float32, device=dev)
+        y = torch.empty((n, O1), dtype=torch.float32, device=dev)
+        y2 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        w = torch.empty(max(sp.nnz, 1), dtype=torch.float32, device=dev)
+        with on_device(dev):
+            check(lib.allset_sparse_linear_wt(ptr(w_v_c), _ld(w_v_c), O1, ptr(w_a_c), _ld(w_a_c), H, ptr(b_v.contiguous()) if b_v is not None else None,
+                                              ptr(b_a.contiguous()) if b_a is not None else None, d, ptr(wt), stream_of(dev)), "allset_sparse_linear_wt")
+            check(lib.allset_sparse_linear_fwd(ptr(sp.rowptr), ptr(sp.col), ptr(sp.val), n, d, ptr(wt), O1, H, float(p_pre), seed, ptr(base),
+                                               ptr(y), O1, ptr(y2), ptr(w), stream_of(dev)), "allset_sparse_linear_fwd")
+        ctx.save_for_backward(w)
+        ctx.sp = sp
+        ctx.cfg = (O1, H, d, b_v is not None, b_a is not None)
+        return y, (y2 if H == 4 else y2[:, :H].contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_v, g_alpha):
+        (w,) = ctx.saved_tensors
+        sp = ctx.sp
+        O1, H, d, has_bv, has_ba = ctx.cfg
+        lib = _lib.load()
+        dev = g_v.device
+        g_v = _rowmajor(g_v.contiguous())
+        n = g_v.shape[0]
+        g4 = g_alpha.contiguous() if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(n, 4 - H)], dim=1)
+        pitch = int(lib.allset_sparse_linear_pitch(O1, H))
+        slices = int(lib.allset_sparse_ln_linear_slices())
+        gw = torch.empty((O1 + H, d), dtype=torch.float32, device=dev)               # gW_V | gw_a: one allocation
+        sb = torch.empty((slices, pitch), dtype=torch.float32, device=dev)
+        with on_device(dev):
+            check(lib.allset_sparse_linear_bwd(ptr(sp.colptr), ptr(sp.rowT), ptr(sp.posT), ptr(w), ptr(g_v), _ld(g_v), ptr(g4), n, d, O1, H,
+                                               ptr(gw), d, ptr(gw[O1:]), d, ptr(sb), stream_of(dev)), "allset_sparse_linear_bwd")
+        need = ctx.needs_input_grad
+        gb = reduce_partials(sb) if ((has_bv and need[3]) or (has_ba and need[5])) else None
+        return (None, None, gw[:O1] if need[2] else None, gb[:O1] if (has_bv and need[3]) else None, gw[O1:] if need[4] else None,
+                gb[O1:O1 + H] if (has_ba and need[5]) else None, None)
+
+
+def sparse_linear_supported(O1: int, H: int) -> bool:
+    return bool(_lib.load().allset_sparse_linear_supported(int(O1), int(H)))
+
+
+def sparse_pma_project(x: Tensor, sp: "SparseRows", w_v: Tensor, b_v: Optional[Tensor], w_a: Tensor, b_a: Optional[Tensor],
+                       p_pre: float = 0.0) -> Tuple[Tensor, Tensor]:
+    return _SparsePmaProject.apply(x, sp, w_v, b_v, w_a, b_a, float(p_pre))
+
+
 def input_norm_linear(x: Tensor, gamma: Tensor, beta: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5,
                       p_pre: float = 0.0) -> Tensor:
     # (NO-GRAD forwards keep the dense kernels: graphs.GraphedForward lets its caller overwrite the features in place between

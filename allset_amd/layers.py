@@ -404,9 +404,32 @@ class PMA(nn.Module):
             return dense.linear(x, w, b) if hip else F.linear(x, w, b)      # (odd H / widths: the padded weight gradient)
         return (self.lin_K(x).view(-1, H, C) * self.att_r).sum(dim=-1)
 
-    def project(self, x: Tensor) -> Tuple[Tensor, Tensor]:
-        """``(x_V, alpha_r)``: the value projection and the (folded) logits of ``x``."""
+    def _sparse_rows(self, x: Tensor):
+        """Raw bag-of-words features in a training step: the projection runs from their non-zeros (``dense.sparse_pma_project``)."""
+        if not (self.fold_alpha and _on_hip(x) and self.lin_V.weight.dtype == torch.float32 and self.att_r.dtype == torch.float32):
+            return None
+        if x.requires_grad or not torch.is_grad_enabled() or x.dim() != 2 or x.shape[1] < 256:
+            return None
+        if not dense.sparse_linear_supported(self.lin_V.out_features, self.heads):
+            return None
+        return dense.sparse_rows(x)
+
+    def takes_pre_dropout(self, x: Tensor) -> bool:
+        """``forward(x, _pre=p)`` can apply the dropout in FRONT of the conv (models.py:473) inside the projection's kernel."""
+        return self._sparse_rows(x) is not None
+
+    def project(self, x: Tensor, _pre: float = 0.0) -> Tuple[Tensor, Tensor]:
+        """``(x_V, alpha_r)``: the value projection and the (folded) logits of ``x``.  ``_pre`` (internal, only after
+        ``takes_pre_dropout``): the dropout in front of the conv."""
         H, C = self.heads, self.hidden
+        sp = self._sparse_rows(x)
+        if sp is not None:
+            # raw sparse features without gradient (Citeseer: 32 of 3703 entries per row): sums over the non-zeros, both consumers of x
+            # and the input dropout in one gather kernel each way
+            w, b = self._fold()
+            return dense.sparse_pma_project(x, sp, self.lin_V.weight, self.lin_V.bias, w, b, float(_pre) if self.training else 0.0)
+        if _pre:
+            raise ValueError("PMA.project(_pre=...) needs takes_pre_dropout(x)")
         fusable = _on_hip(x) and dense.fused_linear_supported(self.lin_V.in_features, self.lin_V.out_features)
         wide = _on_hip(x) and self.lin_V.bias is not None and dense.wide_linear_supported(
             self.lin_V.in_features, self.lin_V.out_features, False)
@@ -486,11 +509,12 @@ class PMA(nn.Module):
         out, m, l = AF.pma_aggregate(x_V, alpha_r, inc, H, self.negative_slope)
         return self.tail(out, _post), m, l
 
-    def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None, _post: Optional[float] = None):
+    def forward(self, x, edge_index: EdgeIndex, size=None, return_attention_weights=None, _post: Optional[float] = None,
+                _pre: float = 0.0):
         assert x.dim() == 2, 'Static graphs not supported in `GATConv`.'
         H = self.heads
         inc = _as_incidence(edge_index, x.shape[0])
-        x_V, alpha_r = self.project(x)                        # [n_s, H*C], [n_s, H]
+        x_V, alpha_r = self.project(x, _pre)                  # [n_s, H*C], [n_s, H]
         out, m, l = self.pool_tail(x_V, alpha_r, inc, _post)
         if isinstance(return_attention_weights, bool):
             alpha = AF.pma_attention_weights(alpha_r, m, l, inc, self.negative_slope)
@@ -532,19 +556,21 @@ class HalfNLHconv(nn.Module):
                     f.reset_parameters()
 
     def takes_pre_dropout(self, x: Tensor) -> bool:
-        return (not self.attention) and isinstance(self.f_enc, MLP) and self.f_enc.takes_pre_dropout(x)
+        if self.attention:
+            return self.prop.takes_pre_dropout(x)
+        return isinstance(self.f_enc, MLP) and self.f_enc.takes_pre_dropout(x)
 
     def forward(self, x, edge_index: EdgeIndex, norm, aggr='add', _post_dropout: Optional[float] = None, _pre_dropout: float = 0.0):
         """``_post_dropout`` (internal, used by ``SetGNN``): also apply the ``relu -> dropout(p)`` that
         ``SetGNN.forward`` wraps around every conv (models.py:475-481) inside the conv's last fused pass.  ``_pre_dropout``
         (internal, only after ``takes_pre_dropout``): the dropout ``SetGNN.forward`` puts in front of the first conv (models.py:473)."""
         post = _post_dropout is not None
-        if _pre_dropout and not (self.takes_pre_dropout(x) and aggr is not None):
+        if _pre_dropout and not (self.takes_pre_dropout(x) and (aggr is not None or self.attention)):
             raise ValueError("HalfNLHconv.forward(_pre_dropout=...) needs takes_pre_dropout(x)")
         if self.attention:
             if post and self.training:      # training: the conv's relu -> dropout rides in ln1's pass (PMA.tail)
-                return self.prop(x, edge_index, _post=float(_post_dropout))
-            x = self.prop(x, edge_index)    # eval: keep the raw PMA output observable (forward hooks), relu separately
+                return self.prop(x, edge_index, _post=float(_post_dropout), _pre=float(_pre_dropout))
+            x = self.prop(x, edge_index, _pre=float(_pre_dropout))    # eval: keep the raw PMA output observable (forward hooks), relu separately
             return relu_dropout(x, _post_dropout, self.training) if post else x
         if aggr is None:
             raise ValueError("aggr was not passed!")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALLSET_ABI_VERSION 14  /* 14: additions only (allset_reduce_partials_batched_ex2: an output type per buffer; allset_reduce_partials_batchable / _batched* now also take the reductions the single entry runs as TWO launches, at most 512 partial rows, with the same association -- a [1M, 128] or [250k, 256] step reduces every parameter gradient of its backward pass in one launch).  13: additions only (bf16 regime: allset_linear_bf16_mask_pitch / _fwd_mask / _bwd_bits -- the relu mask as one bit per element --, allset_wgrad_bf16_ex2(_supported) -- that mask and PMA's four auxiliary logit rows inside the weight-gradient pass --, allset_pma_fold_fwd_bf16 / _bwd_bf16).  Earlier:  12: additions only (allset_fused_linear_bwd_pma_tail(_supported), allset_fused_linear_bwd_ln_pro(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now;   2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
+#define ALLSET_ABI_VERSION 14  /* 14: additions only (allset_reduce_partials_batched_ex2: an output type per buffer; allset_reduce_partials_batchable / _batched* now also take the reductions the single entry runs as TWO launches, at most 512 partial rows, with the same association -- a [1M, 128] or [250k, 256] step reduces every parameter gradient of its backward pass in one launch; allset_sparse_linear_supported / _pitch / _wt / _fwd / _bwd: PMA's value projection + folded logits on sparse raw features).  13: additions only (bf16 regime: allset_linear_bf16_mask_pitch / _fwd_mask / _bwd_bits -- the relu mask as one bit per element --, allset_wgrad_bf16_ex2(_supported) -- that mask and PMA's four auxiliary logit rows inside the weight-gradient pass --, allset_pma_fold_fwd_bf16 / _bwd_bf16).  Earlier:  12: additions only (allset_fused_linear_bwd_pma_tail(_supported), allset_fused_linear_bwd_ln_pro(_supported)); the auxiliary-column forward at 128 x 128 also runs under ALLSET_ARITH_FP16X3 now;   2: dense-tail entries gained seed_base / mask / acc_in / aux parameters, new ln_res_* and pma_merge_pack; 3: additions only (bf16 ln / ln_res / wgrad, pma_*_ld, block_transpose); 4: additions only (fused_linear_bwd_all); 5: additions only (ln_res_bwd_pma, linear_bf16_*, wgrad_bf16_ex, reduce_partials_ex, nll_logsoftmax_*, split_metrics, adam_step*, pma_fold_*, wgrad_fused_ex); 6: addition only (fused_linear_bwd_all_slices_for); 7: additions only (fused_linear_bwd_all_aux, _aux_supported); 8: additions only (fused_linear_blocked_supported, fused_linear_fwd_blocked, fused_linear_bwd_all_blocked); 9: BREAKING -- the library reads no environment variable any more: which kernel an entry point launches, and the partial-slice count a caller sizes its buffers with, are pure functions of the call's arguments (the ALLSET_DENSE_MFMA=f32 comparison family and the ALLSET_BWD_ROLES / _BWD_STAGE / _BWD_PAIR / _BWD_ROLES3 / _FWD_ROLES / _LNRES_CAP / _WGRAD_BF16_TILED switches are gone with the kernels that lost their A/B); added in the same version: allset_fused_linear_fwd_nm / allset_fused_linear_bwd_all_nm (norm_mode: LayerNorm or per-column affine prologue), allset_col_moments(_slices, _supported), allset_col_moments2, allset_col_affine_add -- training-mode BatchNorm1d.  Note for ABI 4-5 callers (true since ABI 6, recorded here): allset_fused_linear_bwd_all at O = I = 128 takes the slice count of allset_fused_linear_bwd_all_slices_for, NOT that of the width-less allset_fused_linear_bwd_all_slices -- a behaviour break of ABI 6, which was wrongly listed as "addition only"; 10: additions only (dataset-scale step: allset_input_linear_*, allset_xhat_rows, allset_fold_ln_linear, allset_unfold_ln_linear, allset_reduce_partials_batch_max / _batch_max_counters / _batchable / _batched / _batched_ex, allset_linear_narrow_supported / _slices / _bwd, allset_nll_logsoftmax_fwd_total, allset_sparse_ln_linear_* / allset_fold_ln_linear_t / allset_unfold_ln_linear_ex); 11: additions only -- the header is split (the 15 aggregation entry points of SURVEY 8(b2) are allset_hip.h with their own frozen ALLSET_CORE_ABI_VERSION and allset_core_version(); this file is everything else); allset_fused_linear_fwd_ex / allset_fused_linear_bwd_all_ex / allset_fused_linear_arith_supported: the arithmetic of the fused Linear kernels (exact-split bf16x6 or fp16x3) becomes the caller's choice.  BEHAVIOUR CHANGE of ABI 11, recorded here because "additions only" undersells it: the unchanged legacy entries (allset_fused_linear_fwd / _blocked / _nm, allset_fused_linear_bwd_all / _blocked / _nm) now run ALLSET_ARITH_AUTO -- at K = N = 128 the row- / launch-scaled fp16x3 planes instead of the exact bf16x6 split (error per product <= 2^-21 relative + 2^-38 x the row's largest |gy| x |u|, relative to the ROW maximum; bf16x6 is exact to 2^-23 for any dynamic range), and the tiled 256 / 512-wide GEMMs and the weight gradient take fp16 planes under AUTO as well; a caller that needs the old numerics calls the _ex entries with ALLSET_ARITH_BF16X6 (python: dense.set_arithmetic("strict")) */
 
 /* ---------------------------------------------------------------------------------------------
  * Dense tail (reference MLP.forward, layers.py:571-579: norm -> [Linear -> ReLU -> norm -> dropout]* -> Linear,
@@ -514,6 +514,30 @@ int allset_sparse_ln_linear_bwd(const int32_t* colptr, const int32_t* rowT, cons
 int allset_unfold_ln_linear_ex(const float* M, int64_t ldm, const float* W, int64_t ldw, const float* gamma, const float* beta,
                                int64_t O, int64_t d, float* gW, int64_t ldgw, float* gb, float* ggamma, float* gbeta,
                                const float* su_part, int64_t n_slices, void* stream);
+
+/* ABI 14.  The PLAIN Linear on the same sparse rows, with up to four auxiliary output rows: PMA's value projection and its folded
+ * logits on the FIRST conv of an AllSetTransformer (reference models.py:473 -- the input dropout -- and layers.py:126-131: lin_V and
+ * lin_K applied to Citeseer's 3703-wide bag-of-words rows; as library GEMMs + a dropout pass they were 165 us of a 440-us step):
+ *   allset_sparse_linear_wt    WT[d + 1, pitch]: row j < d = column j of the stacked weight [W1 (O1 rows); W2 (O2 <= 4 rows); 0 ...],
+ *                              row d = the stacked bias (b1, b2 may be NULL); pitch = allset_sparse_linear_pitch(O1, O2) = O1 + 4 (O1 if O2 = 0)
+ *   allset_sparse_linear_fwd   y[n, O1] = dropout_p(x) W1^T + b1 and y2[n, 4] = dropout_p(x) W2^T + b2 (columns >= O2 zero) from the
+ *                              non-zeros; the dropout is the library's hash of (seed [, *seed_base], r * d + j); w_out[nnz] keeps the
+ *                              values after the dropout for the backward
+ *   allset_sparse_linear_bwd   gW1[O1, ldw1 >= d] and gW2[O2, ldw2 >= d] from gy[n, O1] and g2[n, 4] over the CSC of x; sb_part
+ *                              [allset_sparse_ln_linear_slices()][pitch] = per-slice column sums of [gy | g2] (the bias gradients:
+ *                              the caller sums the slices, allset_reduce_partials)
+ * x needs no gradient (raw features).  O1 in {64, 128}, O2 <= 4 (allset_sparse_linear_supported).  csrc/sparse_input.hip;
+ * allset_amd/dense.py _SparsePmaProject. */
+int allset_sparse_linear_supported(int64_t O1, int64_t O2);
+int64_t allset_sparse_linear_pitch(int64_t O1, int64_t O2);
+int allset_sparse_linear_wt(const float* W1, int64_t ld1, int64_t O1, const float* W2, int64_t ld2, int64_t O2, const float* b1,
+                            const float* b2, int64_t d, float* WT, void* stream);
+int allset_sparse_linear_fwd(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n, int64_t d, const float* WT,
+                             int64_t O1, int64_t O2, float p_pre, uint64_t seed, const uint64_t* seed_base, float* y, int64_t ldy,
+                             float* y2, float* w_out, void* stream);
+int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* rowT, const int32_t* posT, const float* w, const float* gy,
+                             int64_t ldg, const float* g2, int64_t n, int64_t d, int64_t O1, int64_t O2, float* gW1, int64_t ldw1,
+                             float* gW2, int64_t ldw2, float* sb_part, void* stream);
 
 /* ---- backward of a Linear with a NARROW output: the classifier head Linear(hidden -> num_classes) (reference models.py:449-456) ----
  * ONE kernel instead of the library's three (input gradient, weight gradient on a single workgroup, bias gradient):

@@ -257,3 +257,79 @@ def test_sparse_rows_cache_follows_the_tensor(device):
     dense_again[rows, b.col.long()] = b.val
     assert torch.equal(dense_again, x)
     assert torch.equal(b.val[b.posT.long()], x[b.rowT.long(), torch.repeat_interleave(torch.arange(500, device=device), (b.colptr[1:] - b.colptr[:-1]).long())])
+
+
+@pytest.mark.parametrize("n,d,O,H", [(3312, 3703, 128, 4), (300, 1433, 64, 4), (517, 3703, 128, 1), (64, 300, 64, 3), (1, 256, 128, 4)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("bias", [True, False])
+def test_sparse_pma_projection_matches_float64(n, d, O, H, p, bias, device, monkeypatch):
+    """``dense.sparse_pma_project`` (csrc/sparse_input.hip ``sparse_lin_*``): PMA's value projection and folded logits of raw sparse
+    features (reference models.py:473 + layers.py:126-131: ``dropout(x)`` through ``lin_V`` and through ``lin_K`` contracted with
+    ``att_r``) from the non-zeros, both outputs and all four parameter gradients against the dense float64 computation with the
+    kernel's own dropout mask."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(n + d + H)
+    x = (torch.rand(n, d, generator=g) * (torch.rand(n, d, generator=g) < 0.01)).float()
+    x[torch.arange(n), torch.randint(0, d, (n,), generator=g)] = 1.0
+    x = x.to(device)
+    Wv = (torch.randn(O, d, generator=g) / 8).to(device).requires_grad_(True)
+    wa = (torch.randn(H, d, generator=g) / 8).to(device).requires_grad_(True)
+    bv = torch.randn(O, generator=g).to(device).requires_grad_(True) if bias else None
+    ba = torch.randn(H, generator=g).to(device).requires_grad_(True) if bias else None
+    sp = dense.sparse_rows(x)
+    assert sp is not None and dense.sparse_linear_supported(O, H)
+    seeds = []
+    real_draw = dense._draw_seed
+    monkeypatch.setattr(dense, "_draw_seed", lambda: seeds.append(real_draw()) or seeds[-1])
+    xv, al = dense.sparse_pma_project(x, sp, Wv, bv, wa, ba, p)
+    assert tuple(xv.shape) == (n, O) and tuple(al.shape) == (n, H)
+    Gv, Ga = torch.randn(n, O, generator=g).to(device), torch.randn(n, H, generator=g).to(device)
+    ((xv * Gv).sum() + (al * Ga).sum()).backward()
+    xd = x.double().cpu()
+    if p > 0.0:
+        assert len(seeds) == 1
+        keep = (dense.dropout_scale((n, d), p, seeds[0], device) != 0).cpu()
+        xd = xd * keep.double() / (1.0 - p)
+    ps = [t.detach().double().cpu().requires_grad_(True) if t is not None else None for t in (Wv, bv, wa, ba)]
+    rv, ra = F.linear(xd, ps[0], ps[1]), F.linear(xd, ps[2], ps[3])
+    ((rv * Gv.double().cpu()).sum() + (ra * Ga.double().cpu()).sum()).backward()
+
+    def close(got, exp, what):
+        torch.testing.assert_close(got.double().cpu(), exp, rtol=2e-5, atol=2e-5 * max(float(exp.abs().max()), 1e-6), msg=lambda m: f"{what}: {m}")
+    close(xv.detach(), rv.detach(), "x_V")
+    close(al.detach(), ra.detach(), "alpha")
+    for t, r, what in zip((Wv, bv, wa, ba), ps, ("gW_V", "gb_V", "gw_a", "gb_a")):
+        if t is not None:
+            close(t.grad, r.grad, what)
+
+
+def test_first_pma_conv_takes_raw_sparse_features_from_their_nonzeros(device, monkeypatch):
+    """``SetGNN`` (AllSetTransformer) in a training step on bag-of-words features without gradient: the first conv's projection runs
+    through ``dense.sparse_pma_project`` with the input dropout as its hash site (no torch dropout launch, no library GEMM over the
+    3703-wide rows); an eval / no-grad forward keeps the dense kernels.  (Parity with the oracle under the product's masks:
+    tests/test_gpu_train_parity.py::test_training_step_on_features_without_gradient[citeseer_pma_h4].)"""
+    import cases
+    from types import SimpleNamespace
+    from allset_amd import SetGNN, dense
+    case = cases.build_case("citeseer_pma_h4")
+    torch.manual_seed(3)
+    model = SetGNN(case["args"]).to(device)
+    model.reset_parameters()
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(device), edge_index=torch.from_numpy(case["edge_index"]).clone().to(device),
+                           norm=torch.from_numpy(case["norm"]).to(device))
+    calls = []
+    real = dense.sparse_pma_project
+    monkeypatch.setattr(dense, "sparse_pma_project", lambda *a, **k: calls.append(a[-1] if not k else k.get("p_pre", a[-1])) or real(*a, **k))
+    real_drop = F.dropout
+    drops = []
+    monkeypatch.setattr(torch.nn.functional, "dropout", lambda x, p=0.5, training=True, inplace=False: drops.append(tuple(x.shape)) or real_drop(x, p, training, inplace))
+    model.train()
+    out = model(data)
+    out.sum().backward()
+    assert calls == [0.2] and not any(s == tuple(data.x.shape) for s in drops)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.V2EConvs[0].prop.lin_V.parameters())
+    assert model.V2EConvs[0].prop.lin_K.weight.grad is not None and model.V2EConvs[0].prop.att_r.grad is not None
+    model.eval()
+    with torch.no_grad():
+        model(data)
+    assert calls == [0.2]
