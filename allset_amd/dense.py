@@ -8,6 +8,7 @@ Dropout masks are a counter-based hash of (seed, element index): the seed is dra
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from ctypes import byref, c_int64
 from typing import Optional, Tuple
@@ -2273,12 +2274,32 @@ def sparse_pma_project(x: Tensor, sp: "SparseRows", w_v: Tensor, b_v: Optional[T
     return _SparsePmaProject.apply(x, sp, w_v, b_v, w_a, b_a, float(p_pre))
 
 
+class _ConstFeatures:
+    depth = 0
+
+
+@contextlib.contextmanager
+def constant_features():
+    """Inside, NO-GRAD forwards may also read raw features through their cached non-zero structure (:func:`sparse_rows`): the caller
+    promises that ``data.x`` is not overwritten in place behind a captured graph (a training loop's evaluation of the same features:
+    ``allset_amd/train.py``; ``graphs.GraphedForward(..., constant_features=True)``)."""
+    _ConstFeatures.depth += 1
+    try:
+        yield
+    finally:
+        _ConstFeatures.depth -= 1
+
+
+def constant_features_active() -> bool:
+    return _ConstFeatures.depth > 0
+
+
 def input_norm_linear(x: Tensor, gamma: Tensor, beta: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float = 1e-5,
                       p_pre: float = 0.0) -> Tensor:
     # (NO-GRAD forwards keep the dense kernels: graphs.GraphedForward lets its caller overwrite the features in place between
     #  replays, a replay cannot rebuild the non-zero structure, and eager and replayed inference stay bit-identical this way; a
-    #  training step's features are constants)
-    replaceable = not torch.is_grad_enabled()
+    #  training step's features are constants -- and so are an evaluation's inside ``constant_features()``)
+    replaceable = not torch.is_grad_enabled() and not constant_features_active()
     if x.shape[1] >= 256 and not replaceable and _lib.load().allset_sparse_ln_linear_supported(weight.shape[0]):
         sp = sparse_rows(x)
         if sp is not None:

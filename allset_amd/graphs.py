@@ -48,13 +48,17 @@ class GraphedForward:
     Parameters are read at replay time, so the graph stays valid while training updates them in place.
     """
 
-    def __init__(self, model: torch.nn.Module, data, warmup: int = 2):
+    def __init__(self, model: torch.nn.Module, data, warmup: int = 2, constant_features: bool = False):
         if not data.x.is_cuda:
             raise AllSetHipError("GraphedForward needs device tensors")
         self.model, self.data = model, data
+        self.constant_features = bool(constant_features)
         was_training = model.training
         model.eval()
-        with torch.no_grad(), torch.cuda.device(data.x.device):
+        import contextlib
+        # constant_features: the captured kernels may read data.x through its cached non-zero structure (bag-of-words rows:
+        # dense.sparse_rows) -- new features can then NOT be copied in between replays
+        with torch.no_grad(), torch.cuda.device(data.x.device), (dense.constant_features() if constant_features else contextlib.nullcontext()):
             _side_stream_warmup(lambda: model(data), max(1, warmup))
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -63,6 +67,9 @@ class GraphedForward:
 
     def __call__(self, x: Optional[Tensor] = None) -> Tensor:
         if x is not None:
+            if self.constant_features:
+                raise AllSetHipError("GraphedForward(constant_features=True): the captured kernels read the features' non-zero structure; "
+                                     "capture with constant_features=False to replace them between replays")
             self.data.x.copy_(x)
         self.graph.replay()
         return self.out

@@ -363,6 +363,7 @@ class PMA(nn.Module):
         self.dropout = 0.
         self.aggr = 'add'
         self.fold_alpha = kwargs.pop("fold_alpha", True)
+        self._raw_input = False          # set by the owning model on the conv that consumes data.x (see _sparse_rows)
         self.lin_K = nn.Linear(in_channels, self.heads * self.hidden)
         self.lin_V = nn.Linear(in_channels, self.heads * self.hidden)
         self.att_r = nn.Parameter(torch.empty(1, heads, self.hidden))
@@ -408,7 +409,15 @@ class PMA(nn.Module):
         """Raw bag-of-words features in a training step: the projection runs from their non-zeros (``dense.sparse_pma_project``)."""
         if not (self.fold_alpha and _on_hip(x) and self.lin_V.weight.dtype == torch.float32 and self.att_r.dtype == torch.float32):
             return None
-        if x.requires_grad or not torch.is_grad_enabled() or x.dim() != 2 or x.shape[1] < 256:
+        if x.dim() != 2 or x.shape[1] < 256:
+            return None
+        # "needs no gradient" must mean "is the raw feature matrix" (MLP._wide_input has the same rule): with autograd on, a tensor
+        # without requires_grad is one; a no-grad forward qualifies only on the conv the model marked as the consumer of data.x, and
+        # only where the caller declared the features constant (dense.constant_features: no in-place overwrite behind a graph)
+        if torch.is_grad_enabled():
+            if x.requires_grad:
+                return None
+        elif not (self._raw_input and dense.constant_features_active()):
             return None
         if not dense.sparse_linear_supported(self.lin_V.out_features, self.heads):
             return None

@@ -101,6 +101,8 @@ class SetGNN(nn.Module):
         else:
             if isinstance(getattr(self.V2EConvs[0], "f_enc", None), MLP):
                 self.V2EConvs[0].f_enc._raw_input = True
+            if getattr(self.V2EConvs[0], "attention", False) and not self.GPR:
+                self.V2EConvs[0].prop._raw_input = True
             if self.GPR:
                 self.MLP._raw_input = True
 

@@ -333,3 +333,45 @@ def test_first_pma_conv_takes_raw_sparse_features_from_their_nonzeros(device, mo
     with torch.no_grad():
         model(data)
     assert calls == [0.2]
+
+
+@pytest.mark.parametrize("name", ["citeseer_pma_h4", "cora_ds_add"])
+def test_no_grad_forward_reads_constant_features_from_their_nonzeros(name, device, monkeypatch):
+    """Inside ``dense.constant_features()`` an eval forward takes the raw features through their cached non-zero structure as the
+    training step does (what ``allset_amd/train.py`` runs per epoch); outside it keeps the dense kernels (``GraphedForward``'s
+    caller may overwrite the features between replays).  Same logits to fp32 rounding; a graph captured with
+    ``constant_features=True`` replays the eager result bit for bit and refuses new features."""
+    import cases
+    from types import SimpleNamespace
+    from allset_amd import SetGNN, dense
+    from allset_amd._lib import AllSetHipError
+    from allset_amd.graphs import GraphedForward
+    case = cases.build_case(name)
+    torch.manual_seed(5)
+    model = SetGNN(case["args"]).to(device)
+    model.reset_parameters()
+    model.eval()
+    data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(device), edge_index=torch.from_numpy(case["edge_index"]).clone().to(device),
+                           norm=torch.from_numpy(case["norm"]).to(device))
+    sparse_calls = []
+    for fn in ("sparse_pma_project", "_SparseInputNormLinear"):
+        real = getattr(dense, fn)
+        if fn == "sparse_pma_project":
+            monkeypatch.setattr(dense, fn, lambda *a, _r=real, **k: sparse_calls.append(1) or _r(*a, **k))
+    real_apply = dense._SparseInputNormLinear.apply
+    monkeypatch.setattr(dense._SparseInputNormLinear, "apply", staticmethod(lambda *a: sparse_calls.append(1) or real_apply(*a)))
+    with torch.no_grad():
+        dense_out = model(data)
+        assert not sparse_calls
+        with dense.constant_features():
+            sparse_out = model(data)
+        assert len(sparse_calls) == 1
+        again = model(data)
+    assert len(sparse_calls) == 1 and torch.equal(again, dense_out)
+    torch.testing.assert_close(sparse_out, dense_out, rtol=2e-5, atol=2e-5 * float(dense_out.abs().max()))
+    gf = GraphedForward(model, data, constant_features=True)
+    assert torch.equal(gf(), sparse_out)
+    with pytest.raises(AllSetHipError):
+        gf(data.x.clone())
+    gd = GraphedForward(model, data)
+    assert torch.equal(gd(), dense_out)

@@ -42,7 +42,8 @@ for name in ("cora_ds_add", "citeseer_pma_h4"):
     ones = torch.ones(n, device=dev)
     gstep = GraphedTrainStep(model, data, lambda out: nll_log_softmax(out, y, ones, n), opt_c)   # the driver's loss (allset_amd/train.py)
     gfwd = GraphedForward(model, data)
-    for fn, label in ((gstep, "train step (graph)"), (gfwd, "eval forward (graph)")):
+    gfwd_c = GraphedForward(model, data, constant_features=True)      # as allset_amd/train.py captures its per-epoch evaluation
+    for fn, label in ((gstep, "train step (graph)"), (gfwd, "eval forward (graph)"), (gfwd_c, "eval forward (graph, constant features)")):
         for _ in range(5): fn()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(200): fn()
