@@ -230,14 +230,15 @@ __global__ __launch_bounds__(kBlock) void sparse_wt_kernel(const float* __restri
   const int t = threadIdx.x;
   const int n_tiles = (d + 63) / 64;
   if (static_cast<int>(blockIdx.x) == n_tiles) {                // row d: the stacked bias
-    for (int k = t; k < pitch; k += kBlock)
-      WT[static_cast<int64_t>(d) * pitch + k] = k < O1 ? (b1 ? b1[k] : 0.f) : (k < O1 + O2 ? (b2 ? b2[k - O1] : 0.f) : 0.f);
+    if (blockIdx.y == 0)
+      for (int k = t; k < pitch; k += kBlock)
+        WT[static_cast<int64_t>(d) * pitch + k] = k < O1 ? (b1 ? b1[k] : 0.f) : (k < O1 + O2 ? (b2 ? b2[k - O1] : 0.f) : 0.f);
     return;
   }
-  const int j0 = blockIdx.x * 64, jl = t & 63, kq = t >> 6;     // transpose 64 input columns x all outputs, 64 outputs at a time
+  const int j0 = blockIdx.x * 64, jl = t & 63, kq = t >> 6;     // one 64 x 64 tile per workgroup (grid y: the 64-output blocks)
   const int j = j0 + jl;
-  for (int k0 = 0; k0 < pitch; k0 += 64) {
-    __syncthreads();
+  {
+    const int k0 = blockIdx.y * 64;
     for (int k = kq; k < 64; k += 4) {
       const int o = k0 + k;
       float v = 0.f;
@@ -309,20 +310,25 @@ __global__ __launch_bounds__(kBlock) void sparse_lin_fwd_kernel(const int32_t* _
 }
 
 // Workgroups [0, feat_blocks): LPR lanes per feature j (CSC row), gW[k, j] = sum_p w[posT[p]] g[rowT[p], k] with g = [gy | g2].
+// A workgroup of 16 waves owns 1024 / LPR CONSECUTIVE features: the sums meet in an LDS tile [output][feature] and leave as runs of
+// consecutive floats along j (a lane writing its four outputs itself puts 4 bytes into each of four rows 4 d bytes apart: one
+// partial 64-byte sector per float).
 // Workgroups [feat_blocks, feat_blocks + kSpSlices): sb_part[slice][k] = sum_r g[r, k] over the slice (the stacked bias gradient).
+constexpr int kSpBwdBlock = 1024;
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void sparse_lin_bwd_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowT,
-                                                                const int32_t* __restrict__ posT, const float* __restrict__ w,
-                                                                const float* __restrict__ gy, int64_t ldg, const float* __restrict__ g2,
-                                                                int64_t n, int d, int pitch, int O1, int O2, float* __restrict__ gW1,
-                                                                int64_t ldw1, float* __restrict__ gW2, int64_t ldw2,
-                                                                float* __restrict__ sb_part, int feat_blocks) {
-  constexpr int NS = kWave / LPR;
+__global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowT,
+                                                                     const int32_t* __restrict__ posT, const float* __restrict__ w,
+                                                                     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ g2,
+                                                                     int64_t n, int d, int pitch, int O1, int O2, float* __restrict__ gW1,
+                                                                     int64_t ldw1, float* __restrict__ gW2, int64_t ldw2,
+                                                                     float* __restrict__ sb_part, int feat_blocks) {
+  constexpr int NS = kWave / LPR, F = kSpBwdBlock / LPR;           // features per wave / per workgroup
+  __shared__ float4 lds4[kSpBwdBlock];                             // the bias partials' exchange, or the [pitch][F] tile (pitch F <= 4096 floats)
   if (static_cast<int>(blockIdx.x) >= feat_blocks) {
-    __shared__ float4 red[kBlock];
+    float4* red = lds4;
     const int slice = blockIdx.x - feat_blocks;
     const int t = threadIdx.x, q = t % LPR, g = t / LPR;
-    constexpr int G = kBlock / LPR;
+    constexpr int G = kSpBwdBlock / LPR;
     const int64_t rows = (n + kSpSlices - 1) / kSpSlices;
     const int64_t r0 = slice * rows, r1 = min(r0 + rows, n);
     const bool main_q = 4 * q < O1, aux_q = 4 * q == O1 && O2 > 0;
@@ -345,9 +351,12 @@ __global__ __launch_bounds__(kBlock) void sparse_lin_bwd_kernel(const int32_t* _
     }
     return;
   }
+  float* tile = reinterpret_cast<float*>(lds4);
   const int lane = lane_id();
   const int slot = lane / LPR, li = lane % LPR, lane0 = slot * LPR;
-  const int j = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
+  const int fl = (threadIdx.x >> 6) * NS + slot;                   // this lane group's feature inside the workgroup
+  const int j0 = blockIdx.x * F;
+  const int j = j0 + fl;
   const bool live = j < d;
   const bool main_l = 4 * li < O1, aux_l = 4 * li == O1 && O2 > 0;
   const int p0 = live ? colptr[j] : 0, p1 = live ? colptr[j + 1] : 0;
@@ -377,15 +386,19 @@ __global__ __launch_bounds__(kBlock) void sparse_lin_bwd_kernel(const int32_t* _
       }
     }
   }
-  if (!live) return;
-  if (main_l) {
-    gW1[static_cast<int64_t>(4 * li) * ldw1 + j] = acc.x;
-    gW1[static_cast<int64_t>(4 * li + 1) * ldw1 + j] = acc.y;
-    gW1[static_cast<int64_t>(4 * li + 2) * ldw1 + j] = acc.z;
-    gW1[static_cast<int64_t>(4 * li + 3) * ldw1 + j] = acc.w;
-  } else if (aux_l) {
-    const float a[4] = {acc.x, acc.y, acc.z, acc.w};
-    for (int u = 0; u < O2; ++u) gW2[static_cast<int64_t>(u) * ldw2 + j] = a[u];
+  if (main_l || aux_l) {
+    tile[(4 * li) * F + fl] = acc.x; tile[(4 * li + 1) * F + fl] = acc.y;
+    tile[(4 * li + 2) * F + fl] = acc.z; tile[(4 * li + 3) * F + fl] = acc.w;
+  }
+  __syncthreads();
+  const int rows_out = O1 + O2;
+  for (int idx = threadIdx.x; idx < rows_out * F; idx += kSpBwdBlock) {
+    const int o = idx / F, f = idx % F;
+    if (j0 + f < d) {
+      const float v = tile[o * F + f];
+      if (o < O1) gW1[static_cast<int64_t>(o) * ldw1 + j0 + f] = v;
+      else gW2[static_cast<int64_t>(o - O1) * ldw2 + j0 + f] = v;
+    }
   }
 }
 
@@ -475,8 +488,8 @@ extern "C" int allset_sparse_linear_wt(const float* W1, int64_t ld1, int64_t O1,
   ALLSET_REQUIRE(W1 && WT && (O2 == 0 || W2) && ld1 >= d && (O2 == 0 || ld2 >= d), "sparse_linear_wt: null pointer or leading dimension smaller than d");
   const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
   const unsigned grid = static_cast<unsigned>((d + 63) / 64 + 1);
-  sparse_wt_kernel<<<grid, kBlock, 0, static_cast<hipStream_t>(stream)>>>(W1, ld1, static_cast<int>(O1), W2, ld2, static_cast<int>(O2), b1, b2,
-                                                                         static_cast<int>(d), WT, pitch);
+  sparse_wt_kernel<<<dim3(grid, static_cast<unsigned>((pitch + 63) / 64)), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      W1, ld1, static_cast<int>(O1), W2, ld2, static_cast<int>(O2), b1, b2, static_cast<int>(d), WT, pitch);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -518,12 +531,12 @@ extern "C" int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* ro
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
   const int lpr = O1 == 64 ? 32 : 64;
-  const int64_t feats_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
+  const int64_t feats_per_block = kSpBwdBlock / lpr;
   const int feat_blocks = static_cast<int>((d + feats_per_block - 1) / feats_per_block);
   const unsigned grid = static_cast<unsigned>(feat_blocks + kSpSlices);
   const int di = static_cast<int>(d), o1 = static_cast<int>(O1), o2 = static_cast<int>(O2);
-  if (lpr == 32) sparse_lin_bwd_kernel<32><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
-  else sparse_lin_bwd_kernel<64><<<grid, kBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
+  if (lpr == 32) sparse_lin_bwd_kernel<32><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
+  else sparse_lin_bwd_kernel<64><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
