@@ -30,7 +30,10 @@ from ._lib import AllSetHipError
 Tensor = torch.Tensor
 
 
-def _side_stream_warmup(fn: Callable[[], None], iters: int) -> None:
+def _side_stream_warmup(fn: Callable[[], None], iters: int) -> "torch.cuda.Stream":
+    """Runs ``fn`` on a side stream and returns that stream: capturing on the SAME stream (``torch.cuda.graph(g, stream=s)``) keeps
+    per-stream state created during warm-up valid for the capture -- the loss kernel's ticket counter (losses._ticket) would
+    otherwise be allocated and zero-filled inside the capture, one more node in every replay."""
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -38,6 +41,7 @@ def _side_stream_warmup(fn: Callable[[], None], iters: int) -> None:
             fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
+    return s
 
 
 class GraphedForward:
@@ -59,9 +63,9 @@ class GraphedForward:
         # constant_features: the captured kernels may read data.x through its cached non-zero structure (bag-of-words rows:
         # dense.sparse_rows) -- new features can then NOT be copied in between replays
         with torch.no_grad(), torch.cuda.device(data.x.device), (dense.constant_features() if constant_features else contextlib.nullcontext()):
-            _side_stream_warmup(lambda: model(data), max(1, warmup))
+            st = _side_stream_warmup(lambda: model(data), max(1, warmup))
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=st):
                 self.out = model(data)
         model.train(was_training)
 
@@ -83,9 +87,9 @@ class GraphedCallable:
 
     def __init__(self, fn: Callable[[], Tensor], device, warmup: int = 2):
         with torch.no_grad(), torch.cuda.device(device):
-            _side_stream_warmup(lambda: fn(), max(1, warmup))
+            st = _side_stream_warmup(lambda: fn(), max(1, warmup))
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=st):
                 self.out = fn()
 
     def __call__(self) -> Tensor:
@@ -149,9 +153,9 @@ class GraphedTrainStep:
                 # module buffers move during warm-up too (BatchNorm running_mean / running_var / num_batches_tracked)
                 b_snap = [(b, b.detach().clone()) for b in model.buffers()]
         with torch.cuda.device(dev), dense.device_seed_counter(self.counter):
-            _side_stream_warmup(one_step, max(1, warmup))
+            st = _side_stream_warmup(one_step, max(1, warmup))
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=st):
                 self.loss = one_step()
         if restore:
             with torch.no_grad():
