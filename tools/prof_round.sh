@@ -58,4 +58,13 @@ find $OUT/pmc_c5_* -name '*kernel_trace.csv' -delete; find $OUT/pmc_c5_* -name '
 (python tools/linear_bf16_ablation.py; python tools/linear_bf16_ablation.py --warm) > $OUT/${TAG}_bf16_linear_ablation.txt 2>&1; grep -c "us" $OUT/${TAG}_bf16_linear_ablation.txt
 timeout 600 python tools/preprocess_bench.py > $OUT/${TAG}_preprocess_bench.txt 2>&1; tail -3 $OUT/${TAG}_preprocess_bench.txt
 timeout 600 python tools/small_graph_step.py > $OUT/${TAG}_small_graph_step.txt 2>&1; tail -12 $OUT/${TAG}_small_graph_step.txt
+# dataset scale: kernel inventory of the replayed training steps (launches and kernel time per step by name)
+for c in cora_ds_add citeseer_pma_h4; do
+  rm -rf $OUT/prof_sg_$c
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sg_$c -- python tools/small_graph_kernels.py $c > /dev/null 2>&1
+  S=$(find $OUT/prof_sg_$c -name '*kernel_stats.csv' | head -1); cp "$S" $OUT/${TAG}_small_graph_${c}_kernel_stats.csv; rm -rf $OUT/prof_sg_$c
+done
+timeout 600 python bench.py --hip-graph --no-cpu-baseline > $OUT/${TAG}_graph_bench_line.json 2>/dev/null
+timeout 600 python bench.py --model pma --hip-graph --no-cpu-baseline --partitions primary > $OUT/${TAG}_pma_graph_bench_line.json 2>/dev/null
+python tools/bench_summary.py $OUT/${TAG}_graph_bench_line.json $OUT/${TAG}_pma_graph_bench_line.json | grep -v "^    "
 echo finished
