@@ -128,3 +128,35 @@ def test_size_split_compacts_the_short_rows_and_lists_the_long_ones():
     assert ops.size_split(rowptr, col, 200, 32) is None                                  # nothing longer than the threshold
     many = torch.from_numpy(np.concatenate([[0], np.cumsum(np.full(16, 40))]).astype(np.int32))
     assert ops.size_split(many, torch.zeros(640, dtype=torch.int32), 16, 40) is None     # every row is long: not a skewed CSR
+
+
+def test_constant_features_scope_and_the_pre_dropout_contract_on_the_host():
+    """``dense.constant_features()`` nests and unwinds on exceptions; on host tensors no conv claims the input dropout (the sparse /
+    folded raw-feature kernels are device paths), ``SetGNN`` then applies it itself, and a conv handed ``_pre_dropout`` it did not
+    claim refuses it (reference models.py:473 stays one dropout, never two, never none)."""
+    import pytest
+    from allset_amd import SetGNN, dense
+    from allset_amd.layers import HalfNLHconv
+    assert not dense.constant_features_active()
+    with dense.constant_features():
+        with dense.constant_features():
+            assert dense.constant_features_active()
+        assert dense.constant_features_active()
+    assert not dense.constant_features_active()
+    with pytest.raises(RuntimeError):
+        with dense.constant_features():
+            raise RuntimeError("boom")
+    assert not dense.constant_features_active()
+    x = torch.zeros(10, 300)
+    x[:, 0] = 1.0
+    for attention in (True, False):
+        conv = HalfNLHconv(300, 64, 64, 2, 0.5, "ln", True, heads=4, attention=attention)
+        assert not conv.takes_pre_dropout(x)
+        ei = torch.stack([torch.arange(10), torch.arange(10) % 3])
+        with pytest.raises(ValueError):
+            conv(x, ei, torch.ones(10), "add", _pre_dropout=0.2)
+    import cases
+    model = SetGNN(cases.build_case("rand50_pma_h4")["args"])
+    assert model.V2EConvs[0].prop._raw_input and not model.E2VConvs[0].prop._raw_input      # the conv that consumes data.x, marked by the model
+    ds = SetGNN(cases.build_case("rand50_ds_add")["args"])
+    assert ds.V2EConvs[0].f_enc._raw_input and not ds.V2EConvs[0].f_dec._raw_input
