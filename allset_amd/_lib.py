@@ -95,7 +95,7 @@ SIGNATURES = {
     "allset_reduce_partials_batchable": [c_int64, c_int64],
     "allset_reduce_partials_batched": [_P, _P, _P, _P, _P, c_int64, _P],
     "allset_reduce_partials_batched_ex": [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
-    "allset_reduce_partials_batched_ex2": [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
+    "allset_reduce_partials_batched_ex2": [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P],
     "allset_reduce_partials_is_tree": [c_int64, c_int64],
     "allset_reduce_partials_batch_max_counters": [],
     "allset_sparse_ln_linear_supported": [c_int64],
@@ -108,7 +108,7 @@ SIGNATURES = {
     "allset_sparse_linear_pitch": [c_int64, c_int64],
     "allset_sparse_linear_wt": [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, c_int64, _P, _P],
     "allset_sparse_linear_fwd": [_P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_float, c_uint64, _P, _P, c_int64, _P, _P, _P],
-    "allset_sparse_linear_bwd": [_P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P],
+    "allset_sparse_linear_bwd": [_P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P],
     "allset_linear_narrow_supported": [c_int64, c_int64],
     "allset_linear_narrow_slices": [c_int64, POINTER(c_int64)],
     "allset_linear_narrow_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P],

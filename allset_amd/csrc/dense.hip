@@ -462,7 +462,7 @@ constexpr int kRedRows = 64;                   // rows per slab
 template <bool OUT_BF16>
 __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, int64_t P, int64_t M, float* __restrict__ out,
                                                      int64_t row_stride, int slabs_here, int64_t bx, int64_t by,
-                                                     float4 (*red)[kBlock / kRedSplit]) {
+                                                     float4 (*red)[kBlock / kRedSplit], const float* __restrict__ acc_in = nullptr) {
   const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
   const int64_t c = (bx * (kBlock / kRedSplit) + cq) * 4;
   float4 acc = make_float4(0, 0, 0, 0);
@@ -484,6 +484,7 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
   if (rg == 0 && c < M) {
 #pragma unroll
     for (int g = 1; g < kRedSplit; ++g) { const float4 t = red[g][cq]; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+    if (acc_in != nullptr) { const float4 a = *reinterpret_cast<const float4*>(acc_in + c); acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
     if constexpr (OUT_BF16)      // single-slab launches only: `out` is a bf16 vector of M elements
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + c) = make_uint2(cvt_pk_bf16(acc.x, acc.y), cvt_pk_bf16(acc.z, acc.w));
     else
@@ -497,7 +498,8 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
 // to the two launches (ABI 14: what lets the batched entry take the large partial buffers of the [1M, 128] / [250k, 256] steps).
 template <bool OUT_BF16>
 __device__ __forceinline__ void reduce_partials_tree_body(const float* __restrict__ part, int64_t P, int64_t M, float* __restrict__ out,
-                                                          int64_t row_stride, int slabs, int64_t bx, float4 (*red)[kBlock / kRedSplit]) {
+                                                          int64_t row_stride, int slabs, int64_t bx, float4 (*red)[kBlock / kRedSplit],
+                                                          const float* __restrict__ acc_in = nullptr) {
   const int cq = threadIdx.x % (kBlock / kRedSplit), rg = threadIdx.x / (kBlock / kRedSplit);
   const int64_t c = (bx * (kBlock / kRedSplit) + cq) * 4;
   float4 tot = make_float4(0, 0, 0, 0);
@@ -524,6 +526,7 @@ __device__ __forceinline__ void reduce_partials_tree_body(const float* __restric
     __syncthreads();
   }
   if (rg == 0 && c < M) {
+    if (acc_in != nullptr) { const float4 a = *reinterpret_cast<const float4*>(acc_in + c); tot.x += a.x; tot.y += a.y; tot.z += a.z; tot.w += a.w; }
     if constexpr (OUT_BF16)
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + c) = make_uint2(cvt_pk_bf16(tot.x, tot.y), cvt_pk_bf16(tot.z, tot.w));
     else
@@ -548,6 +551,7 @@ struct RedBatchTable {
   float* out[kRedBatchMax];
   int32_t P[kRedBatchMax], stride[kRedBatchMax], M[kRedBatchMax];
   int32_t first_block[kRedBatchMax + 1];
+  const float* acc[kRedBatchMax];            // ABI 14: added to the sum of buffer k before it is written (an existing gradient; fp32 outputs), or NULL
   uint8_t out_bf16[kRedBatchMax];            // ABI 14: the sum of buffer k leaves as bf16 (rounded once), as allset_reduce_partials_ex writes it
   uint8_t tree[kRedBatchMax];                // ABI 14: buffer k is one the single call reduces in TWO launches (the tree body below)
   int32_t count;
@@ -571,11 +575,11 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_batched_kernel(RedBatc
   const int slabs = (P + kRedRows - 1) / kRedRows;
   if (tb.tree[t]) {
     if (tb.out_bf16[t]) reduce_partials_tree_body<true>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], red);
-    else reduce_partials_tree_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], red);
+    else reduce_partials_tree_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], red, tb.acc[t]);
   } else if (tb.out_bf16[t]) {
     reduce_partials_body<true>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], 0, red);
   } else {
-    reduce_partials_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], 0, red);
+    reduce_partials_body<false>(tb.part[t], P, tb.M[t], tb.out[t], tb.stride[t], slabs, b - tb.first_block[t], 0, red, tb.acc[t]);
   }
 }
 
@@ -1980,8 +1984,8 @@ extern "C" int allset_reduce_partials_batchable(int64_t P, int64_t M) {
 }
 
 static int reduce_partials_batched_impl(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
-                                        void* const* outs, const int32_t* out_dtypes, int64_t count, int64_t* inc_i64,
-                                        float* const* inc_f32, int64_t n_inc_f32, void* stream) {
+                                        void* const* outs, const float* const* accs, const int32_t* out_dtypes, int64_t count,
+                                        int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32, void* stream) {
   ALLSET_REQUIRE(count >= 0 && count <= kRedBatchMax, "reduce_partials_batched: at most %d buffers per call", kRedBatchMax);
   ALLSET_REQUIRE(n_inc_f32 >= 0 && n_inc_f32 <= kRedBatchMaxCounters && (n_inc_f32 == 0 || inc_f32 != nullptr),
                  "reduce_partials_batched: at most %d float counters per call", kRedBatchMaxCounters);
@@ -2002,6 +2006,9 @@ static int reduce_partials_batched_impl(const float* const* parts, const int64_t
                    "reduce_partials_batched: buffer %lld: row_stride >= M, a multiple of 4; 16-byte aligned pointers (8 for a bf16 output)", static_cast<long long>(k));
     tb.part[k] = parts[k]; tb.out[k] = static_cast<float*>(outs[k]);
     tb.out_bf16[k] = odt == ALLSET_BF16 ? 1 : 0;
+    tb.acc[k] = accs ? accs[k] : nullptr;
+    ALLSET_REQUIRE(tb.acc[k] == nullptr || (odt == ALLSET_F32 && aligned16(tb.acc[k])),
+                   "reduce_partials_batched: buffer %lld: an accumulated-into gradient needs an fp32 output and 16-byte alignment", static_cast<long long>(k));
     tb.tree[k] = (force_tree || !reduce_one_launch(P[k], M[k])) ? 1 : 0;
     tb.P[k] = static_cast<int32_t>(P[k]); tb.stride[k] = static_cast<int32_t>(row_stride[k]); tb.M[k] = static_cast<int32_t>(M[k]);
     tb.first_block[k] = static_cast<int32_t>(blocks);
@@ -2023,26 +2030,27 @@ static int reduce_partials_batched_impl(const float* const* parts, const int64_t
 extern "C" int allset_reduce_partials_batched(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
                                               float* const* outs, int64_t count, void* stream) {
   clear_error();
-  return reduce_partials_batched_impl(parts, P, row_stride, M, reinterpret_cast<void* const*>(outs), nullptr, count, nullptr, nullptr, 0, stream);
+  return reduce_partials_batched_impl(parts, P, row_stride, M, reinterpret_cast<void* const*>(outs), nullptr, nullptr, count, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int allset_reduce_partials_batched_ex(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
                                                  float* const* outs, int64_t count, int64_t* inc_i64, float* const* inc_f32,
                                                  int64_t n_inc_f32, void* stream) {
   clear_error();
-  return reduce_partials_batched_impl(parts, P, row_stride, M, reinterpret_cast<void* const*>(outs), nullptr, count, inc_i64, inc_f32, n_inc_f32, stream);
+  return reduce_partials_batched_impl(parts, P, row_stride, M, reinterpret_cast<void* const*>(outs), nullptr, nullptr, count, inc_i64, inc_f32, n_inc_f32, stream);
 }
 
 // 1 when allset_reduce_partials(_ex) sums a (P, M) buffer as the two-launch tree (whose association differs from the one-launch form's)
 extern "C" int allset_reduce_partials_is_tree(int64_t P, int64_t M) { return (P >= 1 && M >= 1 && !reduce_one_launch(P, M)) ? 1 : 0; }
 
 // ABI 14: the same with an output type per buffer (out_dtypes[k] = ALLSET_F32 or ALLSET_BF16: outs[k] is then a bf16 vector of M[k]
-// elements, each sum rounded once as allset_reduce_partials_ex rounds it; NULL = all fp32).
+// elements, each sum rounded once as allset_reduce_partials_ex rounds it; NULL = all fp32) and an optional accumuland per buffer
+// (accs[k]: f32[M[k]] added to the sum before it is written -- a gradient that already exists; NULL array or NULL entry = none).
 extern "C" int allset_reduce_partials_batched_ex2(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
-                                                  void* const* outs, const int32_t* out_dtypes, int64_t count, int64_t* inc_i64,
-                                                  float* const* inc_f32, int64_t n_inc_f32, void* stream) {
+                                                  void* const* outs, const float* const* accs, const int32_t* out_dtypes, int64_t count,
+                                                  int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32, void* stream) {
   clear_error();
-  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, out_dtypes, count, inc_i64, inc_f32, n_inc_f32, stream);
+  return reduce_partials_batched_impl(parts, P, row_stride, M, outs, accs, out_dtypes, count, inc_i64, inc_f32, n_inc_f32, stream);
 }
 
 extern "C" int allset_reduce_partials_batch_max_counters(void) { return kRedBatchMaxCounters; }

@@ -19,6 +19,8 @@
 namespace allset {
 
 constexpr int kSpSlices = 16;        // row slices of the (s_gy, u) partial sums
+constexpr int kSpInFlight = 16;      // gathers a lane group keeps in flight (plain-Linear kernels; a row / feature of ~30 non-zeros is then
+                                     // two dependent round trips instead of four: these launches ARE their latency chains)
 
 __global__ __launch_bounds__(kBlock) void fold_t_kernel(const float* __restrict__ W, int64_t ldw, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ b, int O, int d,
@@ -285,18 +287,18 @@ __global__ __launch_bounds__(kBlock) void sparse_lin_fwd_kernel(const int32_t* _
       w_out[p] = v;
     }
     const int nb = min(LPR, len - b0);
-    for (int j = 0; j < nb; j += 8) {                     // eight gathers in flight (past the batch's end: v = 0, row 0 of the weight)
-      float4 wv[8];
-      float vj[8];
+    for (int j = 0; j < nb; j += kSpInFlight) {           // kSpInFlight gathers in flight (past the batch's end: v = 0, row 0 of the weight)
+      float4 wv[kSpInFlight];
+      float vj[kSpInFlight];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kSpInFlight; ++u) {
         const int src = lane0 + ((j + u) & (LPR - 1));
         const int cj = (j + u < nb) ? __shfl(c, src) : 0;
         vj[u] = (j + u < nb) ? __shfl(v, src) : 0.f;
         wv[u] = owns ? *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(cj) * pitch + 4 * li) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kSpInFlight; ++u) {
         acc.x = fmaf(vj[u], wv[u].x, acc.x); acc.y = fmaf(vj[u], wv[u].y, acc.y);
         acc.z = fmaf(vj[u], wv[u].z, acc.z); acc.w = fmaf(vj[u], wv[u].w, acc.w);
       }
@@ -321,7 +323,8 @@ __global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32
                                                                      const float* __restrict__ gy, int64_t ldg, const float* __restrict__ g2,
                                                                      int64_t n, int d, int pitch, int O1, int O2, float* __restrict__ gW1,
                                                                      int64_t ldw1, float* __restrict__ gW2, int64_t ldw2,
-                                                                     float* __restrict__ sb_part, int feat_blocks) {
+                                                                     float* __restrict__ sb_part, int feat_blocks,
+                                                                     unsigned* __restrict__ ticket, float* __restrict__ sb_total) {
   constexpr int NS = kWave / LPR, F = kSpBwdBlock / LPR;           // features per wave / per workgroup
   __shared__ float4 lds4[kSpBwdBlock];                             // the bias partials' exchange, or the [pitch][F] tile (pitch F <= 4096 floats)
   if (static_cast<int>(blockIdx.x) >= feat_blocks) {
@@ -349,6 +352,26 @@ __global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32
       }
       *reinterpret_cast<float4*>(sb_part + static_cast<int64_t>(slice) * pitch + 4 * q) = s;
     }
+    if (ticket != nullptr) {
+      // the LAST slice workgroup to arrive adds the slices in index order (the same sum whichever workgroup that is) and re-arms the
+      // ticket: the bias gradients leave this launch finished (csrc/loss.hip has the same construct)
+      __shared__ int s_last;
+      __syncthreads();
+      if (t == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == static_cast<unsigned>(kSpSlices - 1);
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();
+        for (int k = t; k < pitch; k += kSpBwdBlock) {
+          float acc = 0.f;
+          for (int sl = 0; sl < kSpSlices; ++sl) acc += __hip_atomic_load(sb_part + static_cast<int64_t>(sl) * pitch + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sb_total[k] = acc;
+        }
+        if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
   float* tile = reinterpret_cast<float*>(lds4);
@@ -368,11 +391,11 @@ __global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32
     float wv = 0.f;
     if (b0 + li < len) { rr = rowT[p]; wv = w[posT[p]]; }
     const int nb = min(LPR, len - b0);
-    for (int i = 0; i < nb; i += 8) {                     // eight gathers in flight (past the batch's end: w = 0, row 0)
-      float4 g4[8];
-      float wi[8];
+    for (int i = 0; i < nb; i += kSpInFlight) {           // kSpInFlight gathers in flight (past the batch's end: w = 0, row 0)
+      float4 g4[kSpInFlight];
+      float wi[kSpInFlight];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kSpInFlight; ++u) {
         const int src = lane0 + ((i + u) & (LPR - 1));
         const int ri = (i + u < nb) ? __shfl(rr, src) : 0;
         wi[u] = (i + u < nb) ? __shfl(wv, src) : 0.f;
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32
                        : (aux_l ? *reinterpret_cast<const float4*>(g2 + static_cast<int64_t>(ri) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kSpInFlight; ++u) {
         acc.x = fmaf(wi[u], g4[u].x, acc.x); acc.y = fmaf(wi[u], g4[u].y, acc.y);
         acc.z = fmaf(wi[u], g4[u].z, acc.z); acc.w = fmaf(wi[u], g4[u].w, acc.w);
       }
@@ -521,9 +544,10 @@ extern "C" int allset_sparse_linear_fwd(const int32_t* rowptr, const int32_t* co
 // gW1 [O1, d] (ldw1), gW2 [O2, d] (ldw2), sb_part [allset_sparse_ln_linear_slices()][pitch]: the caller sums the slices into [gb1 | gb2]
 extern "C" int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* rowT, const int32_t* posT, const float* w, const float* gy,
                                         int64_t ldg, const float* g2, int64_t n, int64_t d, int64_t O1, int64_t O2, float* gW1, int64_t ldw1,
-                                        float* gW2, int64_t ldw2, float* sb_part, void* stream) {
+                                        float* gW2, int64_t ldw2, float* sb_part, uint32_t* ticket, float* sb_total, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_linear_bwd: bad size");
+  ALLSET_REQUIRE((ticket == nullptr) == (sb_total == nullptr), "sparse_linear_bwd: ticket and sb_total go together");
   if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_bwd: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(colptr && gW1 && sb_part && (O2 == 0 || gW2) && (n == 0 || (gy && w && (O2 == 0 || g2))), "sparse_linear_bwd: null pointer");
   ALLSET_REQUIRE(ldw1 >= d && (O2 == 0 || ldw2 >= d) && (n == 0 || (ldg >= O1 && ldg % 4 == 0 && aligned16(gy) && (O2 == 0 || aligned16(g2)))) &&
@@ -535,8 +559,8 @@ extern "C" int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* ro
   const int feat_blocks = static_cast<int>((d + feats_per_block - 1) / feats_per_block);
   const unsigned grid = static_cast<unsigned>(feat_blocks + kSpSlices);
   const int di = static_cast<int>(d), o1 = static_cast<int>(O1), o2 = static_cast<int>(O2);
-  if (lpr == 32) sparse_lin_bwd_kernel<32><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
-  else sparse_lin_bwd_kernel<64><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks);
+  if (lpr == 32) sparse_lin_bwd_kernel<32><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks, ticket, sb_total);
+  else sparse_lin_bwd_kernel<64><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks, ticket, sb_total);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -136,33 +136,59 @@ def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
     """Reduce everything queued with one batched launch and assign / accumulate the parameters' ``.grad``.  ``bump_i64`` (a
     1-element int64 device tensor) and ``bump_f32`` (a list of 0-dim float32 device tensors, or a callable returning one -- called
     after the gradients are in place) are advanced by one in the SAME launch: a training step's dropout-seed counter and its
-    optimizer's step counters (``graphs.GraphedTrainStep``)."""
+    optimizer's step counters (``graphs.GraphedTrainStep``).  A parameter that already holds a gradient (autograd accumulated
+    another use of it during the backward pass -- PMA's ``att_r`` through the folded logits -- or an earlier backward) gets its
+    section as an entry of its own whose sum the kernel adds to the existing gradient: no ``add_`` launch per such parameter."""
     pend, _Deferred.pending = _Deferred.pending, []
     lib = _lib.load()
     import ctypes
     dev = pend[0][0].device if pend else (bump_i64.device if bump_i64 is not None else None)
     later = []
-    # one output buffer per gradient dtype (fp32 / bf16 parameters); an entry's row starts on a multiple of 4 elements (16 / 8 bytes)
+    # flat entry list: (partial pointer, P, row stride, M, dtype, base in that dtype's output buffer, accumuland pointer or 0)
     tot = {torch.float32: 0, torch.bfloat16: 0}
-    bases, dts = [], []
+    entries, assign = [], []
+
+    def entry(part, col0, M, dt, acc, M_whole=None):
+        base = tot[dt]
+        tot[dt] += M
+        # a column range of a buffer keeps the association the WHOLE buffer's reduction has (the bits of a per-kernel reduction)
+        tree = M_whole is not None and bool(lib.allset_reduce_partials_is_tree(part.shape[0], M_whole))
+        entries.append((part.data_ptr() + 4 * col0, part.shape[0], part.stride(0), M, dt, base, acc, tree))
+        return base
+
+    seen = set()                                  # a parameter queued twice in one scope (shared weights): the second section accumulates
     for part, M, sections in pend:
         dt = sections[0][0].dtype if sections else torch.float32
-        dts.append(dt)
-        bases.append(tot[dt])
-        tot[dt] += M
+        whole = None
+        for p, off, shape in sections:
+            numel = 1
+            for v in shape:
+                numel *= v
+            g_old = p.grad
+            if id(p) in seen:
+                if whole is None:
+                    whole = entry(part, 0, M, dt, 0)
+                later.append((p, dt, whole + off, numel, shape))
+                continue
+            seen.add(id(p))
+            if g_old is None:
+                if whole is None:
+                    whole = entry(part, 0, M, dt, 0)
+                assign.append((p, dt, whole + off, numel, shape))
+            elif (dt == torch.float32 and numel % 4 == 0 and off % 4 == 0 and g_old.dtype == torch.float32 and g_old.is_contiguous()
+                  and g_old.data_ptr() % 16 == 0 and g_old.device == part.device and tuple(g_old.shape) == tuple(shape)
+                  and lib.allset_reduce_partials_batchable(part.shape[0], numel)):
+                assign.append((p, dt, entry(part, off, numel, dt, g_old.data_ptr(), M), numel, shape))   # sum + the existing gradient
+            else:
+                if whole is None:
+                    whole = entry(part, 0, M, dt, 0)
+                later.append((p, dt, whole + off, numel, shape))
     outs = {dt: (torch.empty(n, dtype=dt, device=dev) if n else None) for dt, n in tot.items()}
-    if pend:
-        with torch.no_grad():
-            for (part, M, sections), b, dt in zip(pend, bases, dts):
-                for p, off, shape in sections:
-                    numel = 1
-                    for v in shape:
-                        numel *= v
-                    g = outs[dt][b + off:b + off + numel].view(shape)
-                    if p.grad is None:
-                        p.grad = g
-                    else:
-                        later.append((p, g))          # accumulate: after the launch below has produced the sum
+    keep = []                                     # (the accumulands stay alive until the launch has been issued)
+    with torch.no_grad():
+        for p, dt, b, numel, shape in assign:
+            keep.append(p.grad)
+            p.grad = outs[dt][b:b + numel].view(shape)
     counters = list(bump_f32() if callable(bump_f32) else (bump_f32 or []))
     if dev is None and counters:
         dev = counters[0].device
@@ -174,25 +200,25 @@ def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
         torch._foreach_add_(counters[ccap:], 1.0)
         counters = counters[:ccap]
     first = True
-    for k0 in range(0, max(len(pend), 1), cap):
-        chunk = pend[k0:k0 + cap]
+    arr = lambda vals: (ctypes.c_void_p * max(len(vals), 1))(*vals)
+    i64 = lambda vals: (ctypes.c_int64 * max(len(vals), 1))(*vals)
+    for k0 in range(0, max(len(entries), 1), cap):
+        chunk = entries[k0:k0 + cap]
         n = len(chunk)
-        arr = lambda vals: (ctypes.c_void_p * max(len(vals), 1))(*vals)
-        i64 = lambda vals: (ctypes.c_int64 * max(len(vals), 1))(*vals)
         cs = counters if first else []
-        optrs = [outs[dt].data_ptr() + outs[dt].element_size() * b for b, dt in zip(bases[k0:k0 + n], dts[k0:k0 + n])]
-        odts = (ctypes.c_int32 * max(n, 1))(*[_lib.BF16 if dt == torch.bfloat16 else _lib.F32 for dt in dts[k0:k0 + n]])
+        optrs = [outs[e[4]].data_ptr() + outs[e[4]].element_size() * e[5] for e in chunk]
+        odts = (ctypes.c_int32 * max(n, 1))(*[(_lib.BF16 if e[4] == torch.bfloat16 else _lib.F32) | (_lib.REDUCE_AS_TREE if e[7] else 0) for e in chunk])
         with on_device(dev):
             check(lib.allset_reduce_partials_batched_ex2(
-                arr([part.data_ptr() for part, _, _ in chunk]), i64([part.shape[0] for part, _, _ in chunk]),
-                i64([part.stride(0) for part, _, _ in chunk]), i64([M for _, M, _ in chunk]),
-                arr(optrs), odts, n,
+                arr([e[0] for e in chunk]), i64([e[1] for e in chunk]), i64([e[2] for e in chunk]), i64([e[3] for e in chunk]),
+                arr(optrs), arr([e[6] for e in chunk]) if any(e[6] for e in chunk) else None, odts, n,
                 ptr(bump_i64) if first else None, arr([c.data_ptr() for c in cs]), len(cs), stream_of(dev)),
                 "allset_reduce_partials_batched_ex2")
         first = False
+    del keep
     with torch.no_grad():
-        for p, g in later:
-            p.grad.add_(g)
+        for p, dt, b, numel, shape in later:
+            p.grad.add_(outs[dt][b:b + numel].view(shape))
 
 
 class deferred_param_grads:
@@ -253,7 +279,7 @@ def reduce_partials_slice(part: Tensor, col0: int, M: int, dtype: torch.dtype) -
     with on_device(dev):
         check(lib.allset_reduce_partials_batched_ex2((ctypes.c_void_p * 1)(view.data_ptr()), (ctypes.c_int64 * 1)(P),
                                                      (ctypes.c_int64 * 1)(part.stride(0)), (ctypes.c_int64 * 1)(M),
-                                                     (ctypes.c_void_p * 1)(out.data_ptr()), flags, 1, None, None, 0, stream_of(dev)),
+                                                     (ctypes.c_void_p * 1)(out.data_ptr()), None, flags, 1, None, None, 0, stream_of(dev)),
               "allset_reduce_partials_batched_ex2")
     return out
 
@@ -2210,6 +2236,17 @@ class _SparseInputNormLinear(torch.autograd.Function):
                 gb if (ctx.has_bias and need[5]) else None, None, None)
 
 
+_STREAM_TICKETS = {}      # (device index, stream handle) -> zeroed uint32 a kernel counts its workgroups on and re-arms (losses.py has the twin)
+
+
+def _stream_ticket(dev: torch.device) -> Tensor:
+    key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
+    t = _STREAM_TICKETS.get(key)
+    if t is None:
+        t = _STREAM_TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
 class _SparsePmaProject(torch.autograd.Function):
     """``(x_V, alpha) = (dropout_p(x) W_V^T + b_V,  dropout_p(x) w_a^T + b_a)`` from the non-zeros of raw features ``x`` (no input
     gradient): PMA's value projection and its folded logits on the first conv of an AllSetTransformer (reference models.py:473,
@@ -2255,12 +2292,13 @@ class _SparsePmaProject(torch.autograd.Function):
         pitch = int(lib.allset_sparse_linear_pitch(O1, H))
         slices = int(lib.allset_sparse_ln_linear_slices())
         gw = torch.empty((O1 + H, d), dtype=torch.float32, device=dev)               # gW_V | gw_a: one allocation
-        sb = torch.empty((slices, pitch), dtype=torch.float32, device=dev)
+        sb = torch.empty((slices + 1, pitch), dtype=torch.float32, device=dev)         # the slices | their total
         with on_device(dev):
             check(lib.allset_sparse_linear_bwd(ptr(sp.colptr), ptr(sp.rowT), ptr(sp.posT), ptr(w), ptr(g_v), _ld(g_v), ptr(g4), n, d, O1, H,
-                                               ptr(gw), d, ptr(gw[O1:]), d, ptr(sb), stream_of(dev)), "allset_sparse_linear_bwd")
+                                               ptr(gw), d, ptr(gw[O1:]), d, ptr(sb), ptr(_stream_ticket(dev)), ptr(sb[slices]), stream_of(dev)),
+                  "allset_sparse_linear_bwd")
         need = ctx.needs_input_grad
-        gb = reduce_partials(sb) if ((has_bv and need[3]) or (has_ba and need[5])) else None
+        gb = sb[slices]                                # (summed by the last slice workgroup of the launch itself)
         return (None, None, gw[:O1] if need[2] else None, gb[:O1] if (has_bv and need[3]) else None, gw[O1:] if need[4] else None,
                 gb[O1:O1 + H] if (has_ba and need[5]) else None, None)
 

@@ -195,9 +195,12 @@ int allset_reduce_partials_batched_ex(const float* const* parts, const int64_t* 
  * which association the single entry uses for a buffer of M columns). */
 #define ALLSET_REDUCE_AS_TREE 0x100
 int allset_reduce_partials_is_tree(int64_t P, int64_t M);
+/* accs (may be NULL; entries may be NULL): accs[k] = f32[M[k]], 16-byte aligned, ADDED to the sum of buffer k before it is written (fp32
+ * outputs only) -- the gradient a parameter already holds, so that accumulation costs no launch of its own.  parts[k] may point INTO a
+ * wider partial buffer (a column range of it, row_stride[k] = the buffer's): one section of a kernel's partial row as its own entry. */
 int allset_reduce_partials_batched_ex2(const float* const* parts, const int64_t* P, const int64_t* row_stride, const int64_t* M,
-                                       void* const* outs, const int32_t* out_dtypes, int64_t count, int64_t* inc_i64,
-                                       float* const* inc_f32, int64_t n_inc_f32, void* stream);
+                                       void* const* outs, const float* const* accs, const int32_t* out_dtypes, int64_t count,
+                                       int64_t* inc_i64, float* const* inc_f32, int64_t n_inc_f32, void* stream);
 
 /* allset_wgrad with both operands recomputed on the fly from what allset_fused_linear_fwd keeps:
  *   ga = gy * (y > 0 ? 1/(1-p_out) : 0)  if y != NULL (relu/dropout epilogue), else gy;
@@ -524,8 +527,10 @@ int allset_unfold_ln_linear_ex(const float* M, int64_t ldm, const float* W, int6
  *                              non-zeros; the dropout is the library's hash of (seed [, *seed_base], r * d + j); w_out[nnz] keeps the
  *                              values after the dropout for the backward
  *   allset_sparse_linear_bwd   gW1[O1, ldw1 >= d] and gW2[O2, ldw2 >= d] from gy[n, O1] and g2[n, 4] over the CSC of x; sb_part
- *                              [allset_sparse_ln_linear_slices()][pitch] = per-slice column sums of [gy | g2] (the bias gradients:
- *                              the caller sums the slices, allset_reduce_partials)
+ *                              [allset_sparse_ln_linear_slices()][pitch] = per-slice column sums of [gy | g2] (the bias gradients);
+ *                              with ticket (a zeroed uint32 the launch re-arms, one per stream) and sb_total[pitch] the last slice
+ *                              workgroup to finish sums the slices in index order into sb_total -- no reduction launch; both NULL:
+ *                              the caller sums the slices (allset_reduce_partials)
  * x needs no gradient (raw features).  O1 in {64, 128}, O2 <= 4 (allset_sparse_linear_supported).  csrc/sparse_input.hip;
  * allset_amd/dense.py _SparsePmaProject. */
 int allset_sparse_linear_supported(int64_t O1, int64_t O2);
@@ -537,7 +542,7 @@ int allset_sparse_linear_fwd(const int32_t* rowptr, const int32_t* col, const fl
                              float* y2, float* w_out, void* stream);
 int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* rowT, const int32_t* posT, const float* w, const float* gy,
                              int64_t ldg, const float* g2, int64_t n, int64_t d, int64_t O1, int64_t O2, float* gW1, int64_t ldw1,
-                             float* gW2, int64_t ldw2, float* sb_part, void* stream);
+                             float* gW2, int64_t ldw2, float* sb_part, uint32_t* ticket, float* sb_total, void* stream);
 
 /* ---- backward of a Linear with a NARROW output: the classifier head Linear(hidden -> num_classes) (reference models.py:449-456) ----
  * ONE kernel instead of the library's three (input gradient, weight gradient on a single workgroup, bias gradient):

@@ -34,7 +34,7 @@ def test_batched_reduction_walks_the_two_launch_tree_bit_for_bit(device):
     dts = (ctypes.c_int32 * len(shapes))(*[_lib.BF16 if b16 else _lib.F32 for *_, b16 in shapes])
     st = dense.stream_of(device)
     rc = lib.allset_reduce_partials_batched_ex2(arr([t.data_ptr() for t in parts]), i64([s[0] for s in shapes]), i64([s[1] for s in shapes]),
-                                                i64([s[2] for s in shapes]), arr([t.data_ptr() for t in outs]), dts, len(shapes), None, None, 0, st)
+                                                i64([s[2] for s in shapes]), arr([t.data_ptr() for t in outs]), None, dts, len(shapes), None, None, 0, st)
     assert rc == 0, lib.allset_last_error()
     torch.cuda.synchronize()
     for o, r, s in zip(outs, ref, shapes):
@@ -44,12 +44,22 @@ def test_batched_reduction_walks_the_two_launch_tree_bit_for_bit(device):
     assert lib.allset_reduce_partials_batched(arr([parts[0].data_ptr()]), i64([256]), i64([16768]), i64([16768]), arr([o32.data_ptr()]), 1, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(o32, ref[0])
+    # an accumuland: a COLUMN RANGE of the first buffer as an entry of its own, its sum added to an existing vector in the same launch
+    old = torch.randn(1024, device=device, generator=g)
+    o_acc = torch.empty(1024, device=device)
+    f32 = (ctypes.c_int32 * 1)(_lib.F32 | _lib.REDUCE_AS_TREE)           # (the whole buffer is a two-launch tree: keep its association)
+    assert lib.allset_reduce_partials_batched_ex2(arr([parts[0].data_ptr() + 4 * 4096]), i64([256]), i64([16768]), i64([1024]), arr([o_acc.data_ptr()]),
+                                                  arr([old.data_ptr()]), f32, 1, None, None, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_acc, ref[0][4096:5120] + old)
+    assert lib.allset_reduce_partials_batched_ex2(arr([parts[3].data_ptr()]), i64([70]), i64([8]), i64([8]), arr([outs[3].data_ptr()]),
+                                                  arr([old.data_ptr()]), (ctypes.c_int32 * 1)(_lib.BF16), 1, None, None, 0, st) != 0      # bf16 output + accumuland
     # argument checks of the new entry: an unknown output type, a bf16 output that is not 8-byte aligned
     bad = (ctypes.c_int32 * 1)(7)
-    assert lib.allset_reduce_partials_batched_ex2(arr([parts[2].data_ptr()]), i64([9]), i64([16]), i64([16]), arr([outs[2].data_ptr()]), bad, 1,
+    assert lib.allset_reduce_partials_batched_ex2(arr([parts[2].data_ptr()]), i64([9]), i64([16]), i64([16]), arr([outs[2].data_ptr()]), None, bad, 1,
                                                   None, None, 0, st) != 0
     b16 = (ctypes.c_int32 * 1)(_lib.BF16)
-    assert lib.allset_reduce_partials_batched_ex2(arr([parts[3].data_ptr()]), i64([70]), i64([8]), i64([8]), arr([outs[3].data_ptr() + 2]), b16, 1,
+    assert lib.allset_reduce_partials_batched_ex2(arr([parts[3].data_ptr()]), i64([70]), i64([8]), i64([8]), arr([outs[3].data_ptr() + 2]), None, b16, 1,
                                                   None, None, 0, st) != 0
     torch.cuda.synchronize()
 
