@@ -256,8 +256,10 @@ __global__ __launch_bounds__(kBlock) void sparse_wt_kernel(const float* __restri
   }
 }
 
-// LPR lanes per row (4 LPR >= pitch), 64 / LPR rows per wave; lanes past the stacked width idle.
-template <int LPR>
+// LPR lanes per row, 64 / LPR rows per wave; a lane owns the 16-byte chunks li + LPR v (v < VPL) of the stacked output row -- the first
+// O1 / 4 chunks are the projection's, the next ceil(O2 / 4) the auxiliary rows' (y2: [n, 4 ceil(O2 / 4)]); chunks past the row idle.
+// (LPR, VPL) = (32, 1) for O1 = 64, (64, 1) for 128, (64, 2) for 256, (64, 3) for 512.
+template <int LPR, int VPL>
 __global__ __launch_bounds__(kBlock) void sparse_lin_fwd_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                 const float* __restrict__ val, int64_t n, int d,
                                                                 const float* __restrict__ WT, int pitch, int O1, int O2, float p_pre,
@@ -265,92 +267,111 @@ __global__ __launch_bounds__(kBlock) void sparse_lin_fwd_kernel(const int32_t* _
                                                                 float* __restrict__ y, int64_t ldy, float* __restrict__ y2,
                                                                 float* __restrict__ w_out) {
   constexpr int NS = kWave / LPR;
+  constexpr int IF = VPL == 1 ? kSpInFlight : 8;                   // non-zeros in flight (x VPL gathers each)
   seed = resolve_seed(seed_base, seed);
   const int lane = lane_id();
   const int slot = lane / LPR, li = lane % LPR, lane0 = slot * LPR;
   const int64_t r = (static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6)) * NS + slot;
   const bool live = r < n;
-  const bool owns = 4 * li < pitch;
+  const int nch = pitch / 4, mch = O1 / 4, ld2 = pitch - O1;
   const int p0 = live ? rowptr[r] : 0, p1 = live ? rowptr[r + 1] : 0;
   const float inv_keep = p_pre > 0.f ? 1.f / (1.f - p_pre) : 1.f;
   const uint32_t thr = drop_threshold(p_pre);
   const int len = p1 - p0;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int b0 = 0; b0 < len; b0 += LPR) {
     const int p = p0 + b0 + li;
     int c = 0;
-    float v = 0.f;
+    float xv = 0.f;
     if (b0 + li < len) {
       c = col[p];
-      v = val[p];
-      if (p_pre > 0.f) v *= keep_scale(seed, r * d + c, thr, inv_keep);
-      w_out[p] = v;
+      xv = val[p];
+      if (p_pre > 0.f) xv *= keep_scale(seed, r * d + c, thr, inv_keep);
+      w_out[p] = xv;
     }
     const int nb = min(LPR, len - b0);
-    for (int j = 0; j < nb; j += kSpInFlight) {           // kSpInFlight gathers in flight (past the batch's end: v = 0, row 0 of the weight)
-      float4 wv[kSpInFlight];
-      float vj[kSpInFlight];
+    for (int j = 0; j < nb; j += IF) {                    // IF non-zeros in flight (past the batch's end: value 0, row 0 of the weight)
+      float4 wv[IF][VPL];
+      float vj[IF];
 #pragma unroll
-      for (int u = 0; u < kSpInFlight; ++u) {
+      for (int u = 0; u < IF; ++u) {
         const int src = lane0 + ((j + u) & (LPR - 1));
         const int cj = (j + u < nb) ? __shfl(c, src) : 0;
-        vj[u] = (j + u < nb) ? __shfl(v, src) : 0.f;
-        wv[u] = owns ? *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(cj) * pitch + 4 * li) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vj[u] = (j + u < nb) ? __shfl(xv, src) : 0.f;
+        const float* wr = WT + static_cast<int64_t>(cj) * pitch;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+          wv[u][v] = (li + LPR * v < nch) ? *reinterpret_cast<const float4*>(wr + 4 * (li + LPR * v)) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < kSpInFlight; ++u) {
-        acc.x = fmaf(vj[u], wv[u].x, acc.x); acc.y = fmaf(vj[u], wv[u].y, acc.y);
-        acc.z = fmaf(vj[u], wv[u].z, acc.z); acc.w = fmaf(vj[u], wv[u].w, acc.w);
-      }
+      for (int u = 0; u < IF; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          acc[v].x = fmaf(vj[u], wv[u][v].x, acc[v].x); acc[v].y = fmaf(vj[u], wv[u][v].y, acc[v].y);
+          acc[v].z = fmaf(vj[u], wv[u][v].z, acc[v].z); acc[v].w = fmaf(vj[u], wv[u][v].w, acc[v].w);
+        }
     }
   }
-  if (!live || !owns) return;
-  const float4 bp = *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(d) * pitch + 4 * li);
-  const float4 o = make_float4(acc.x + bp.x, acc.y + bp.y, acc.z + bp.z, acc.w + bp.w);
-  if (4 * li < O1) *reinterpret_cast<float4*>(y + r * ldy + 4 * li) = o;
-  else if (4 * li == O1 && O2 > 0) *reinterpret_cast<float4*>(y2 + r * 4) = o;           // (O1 % 4 == 0: the auxiliary columns are one lane's)
+  if (!live) return;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int ch = li + LPR * v;
+    if (ch >= nch) continue;
+    const float4 bp = *reinterpret_cast<const float4*>(WT + static_cast<int64_t>(d) * pitch + 4 * ch);
+    const float4 o = make_float4(acc[v].x + bp.x, acc[v].y + bp.y, acc[v].z + bp.z, acc[v].w + bp.w);
+    if (ch < mch) *reinterpret_cast<float4*>(y + r * ldy + 4 * ch) = o;
+    else *reinterpret_cast<float4*>(y2 + r * ld2 + 4 * (ch - mch)) = o;
+  }
 }
 
 // Workgroups [0, feat_blocks): LPR lanes per feature j (CSC row), gW[k, j] = sum_p w[posT[p]] g[rowT[p], k] with g = [gy | g2].
-// A workgroup of 16 waves owns 1024 / LPR CONSECUTIVE features: the sums meet in an LDS tile [output][feature] and leave as runs of
-// consecutive floats along j (a lane writing its four outputs itself puts 4 bytes into each of four rows 4 d bytes apart: one
-// partial 64-byte sector per float).
+// A workgroup owns BLK / LPR CONSECUTIVE features: the sums meet in an LDS tile [output][feature] and leave as runs of consecutive
+// floats along j (a lane writing its four outputs itself puts 4 bytes into each of four rows 4 d bytes apart: one partial 64-byte
+// sector per float).  BLK = 1024 threads (16 features at LPR = 64) for one chunk per lane, 512 for two or three (register budget).
 // Workgroups [feat_blocks, feat_blocks + kSpSlices): sb_part[slice][k] = sum_r g[r, k] over the slice (the stacked bias gradient).
-constexpr int kSpBwdBlock = 1024;
-template <int LPR>
-__global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowT,
-                                                                     const int32_t* __restrict__ posT, const float* __restrict__ w,
-                                                                     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ g2,
-                                                                     int64_t n, int d, int pitch, int O1, int O2, float* __restrict__ gW1,
-                                                                     int64_t ldw1, float* __restrict__ gW2, int64_t ldw2,
-                                                                     float* __restrict__ sb_part, int feat_blocks,
-                                                                     unsigned* __restrict__ ticket, float* __restrict__ sb_total) {
-  constexpr int NS = kWave / LPR, F = kSpBwdBlock / LPR;           // features per wave / per workgroup
-  __shared__ float4 lds4[kSpBwdBlock];                             // the bias partials' exchange, or the [pitch][F] tile (pitch F <= 4096 floats)
+constexpr int kSpMaxPitch = 520;
+template <int LPR, int VPL>
+__global__ __launch_bounds__(VPL == 1 ? 1024 : 512) void sparse_lin_bwd_kernel(
+    const int32_t* __restrict__ colptr, const int32_t* __restrict__ rowT, const int32_t* __restrict__ posT, const float* __restrict__ w,
+    const float* __restrict__ gy, int64_t ldg, const float* __restrict__ g2, int64_t n, int d, int pitch, int O1, int O2,
+    float* __restrict__ gW1, int64_t ldw1, float* __restrict__ gW2, int64_t ldw2, float* __restrict__ sb_part, int feat_blocks,
+    unsigned* __restrict__ ticket, float* __restrict__ sb_total) {
+  constexpr int BLK = VPL == 1 ? 1024 : 512;
+  constexpr int NS = kWave / LPR, F = BLK / LPR;                   // features per wave / per workgroup
+  constexpr int IF = VPL == 1 ? kSpInFlight : 8;
+  constexpr int TILE4 = (VPL == 1 ? 136 : kSpMaxPitch) * F / 4;    // the [pitch][F] tile, in float4s
+  __shared__ float4 lds4[TILE4 > BLK ? TILE4 : BLK];               // the bias partials' exchange, or the tile
+  const int nch = pitch / 4, mch = O1 / 4, ld2 = pitch - O1;
   if (static_cast<int>(blockIdx.x) >= feat_blocks) {
     float4* red = lds4;
     const int slice = blockIdx.x - feat_blocks;
     const int t = threadIdx.x, q = t % LPR, g = t / LPR;
-    constexpr int G = kSpBwdBlock / LPR;
+    constexpr int G = BLK / LPR;
     const int64_t rows = (n + kSpSlices - 1) / kSpSlices;
     const int64_t r0 = slice * rows, r1 = min(r0 + rows, n);
-    const bool main_q = 4 * q < O1, aux_q = 4 * q == O1 && O2 > 0;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (main_q || aux_q) {
+    for (int v = 0; v < VPL; ++v) {
+      const int ch = q + LPR * v;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ch < nch) {
 #pragma unroll 4
-      for (int64_t r = r0 + g; r < r1; r += G) {
-        const float4 v = main_q ? *reinterpret_cast<const float4*>(gy + r * ldg + 4 * q) : *reinterpret_cast<const float4*>(g2 + r * 4);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int64_t r = r0 + g; r < r1; r += G) {
+          const float4 x4 = ch < mch ? *reinterpret_cast<const float4*>(gy + r * ldg + 4 * ch)
+                                     : *reinterpret_cast<const float4*>(g2 + r * ld2 + 4 * (ch - mch));
+          s.x += x4.x; s.y += x4.y; s.z += x4.z; s.w += x4.w;
+        }
       }
-    }
-    red[t] = s;
-    __syncthreads();
-    if (g == 0 && 4 * q < pitch) {
-      for (int gg = 1; gg < G; ++gg) {
-        const float4 a = red[gg * LPR + q];
-        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      __syncthreads();
+      red[t] = s;
+      __syncthreads();
+      if (g == 0 && ch < nch) {
+        for (int gg = 1; gg < G; ++gg) {
+          const float4 a = red[gg * LPR + q];
+          s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        *reinterpret_cast<float4*>(sb_part + static_cast<int64_t>(slice) * pitch + 4 * ch) = s;
       }
-      *reinterpret_cast<float4*>(sb_part + static_cast<int64_t>(slice) * pitch + 4 * q) = s;
     }
     if (ticket != nullptr) {
       // the LAST slice workgroup to arrive adds the slices in index order (the same sum whichever workgroup that is) and re-arms the
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32
       __syncthreads();
       if (s_last) {
         __threadfence();
-        for (int k = t; k < pitch; k += kSpBwdBlock) {
+        for (int k = t; k < pitch; k += BLK) {
           float acc = 0.f;
           for (int sl = 0; sl < kSpSlices; ++sl) acc += __hip_atomic_load(sb_part + static_cast<int64_t>(sl) * pitch + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           sb_total[k] = acc;
@@ -381,46 +402,58 @@ __global__ __launch_bounds__(kSpBwdBlock) void sparse_lin_bwd_kernel(const int32
   const int j0 = blockIdx.x * F;
   const int j = j0 + fl;
   const bool live = j < d;
-  const bool main_l = 4 * li < O1, aux_l = 4 * li == O1 && O2 > 0;
   const int p0 = live ? colptr[j] : 0, p1 = live ? colptr[j + 1] : 0;
   const int len = p1 - p0;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int b0 = 0; b0 < len; b0 += LPR) {
     const int p = p0 + b0 + li;
     int rr = 0;
     float wv = 0.f;
     if (b0 + li < len) { rr = rowT[p]; wv = w[posT[p]]; }
     const int nb = min(LPR, len - b0);
-    for (int i = 0; i < nb; i += kSpInFlight) {           // kSpInFlight gathers in flight (past the batch's end: w = 0, row 0)
-      float4 g4[kSpInFlight];
-      float wi[kSpInFlight];
+    for (int i = 0; i < nb; i += IF) {                    // IF non-zeros in flight (past the batch's end: w = 0, row 0)
+      float4 g4[IF][VPL];
+      float wi[IF];
 #pragma unroll
-      for (int u = 0; u < kSpInFlight; ++u) {
+      for (int u = 0; u < IF; ++u) {
         const int src = lane0 + ((i + u) & (LPR - 1));
         const int ri = (i + u < nb) ? __shfl(rr, src) : 0;
         wi[u] = (i + u < nb) ? __shfl(wv, src) : 0.f;
-        g4[u] = main_l ? *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(ri) * ldg + 4 * li)
-                       : (aux_l ? *reinterpret_cast<const float4*>(g2 + static_cast<int64_t>(ri) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int ch = li + LPR * v;
+          g4[u][v] = ch < mch ? *reinterpret_cast<const float4*>(gy + static_cast<int64_t>(ri) * ldg + 4 * ch)
+                              : (ch < nch ? *reinterpret_cast<const float4*>(g2 + static_cast<int64_t>(ri) * ld2 + 4 * (ch - mch))
+                                          : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
       }
 #pragma unroll
-      for (int u = 0; u < kSpInFlight; ++u) {
-        acc.x = fmaf(wi[u], g4[u].x, acc.x); acc.y = fmaf(wi[u], g4[u].y, acc.y);
-        acc.z = fmaf(wi[u], g4[u].z, acc.z); acc.w = fmaf(wi[u], g4[u].w, acc.w);
-      }
+      for (int u = 0; u < IF; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          acc[v].x = fmaf(wi[u], g4[u][v].x, acc[v].x); acc[v].y = fmaf(wi[u], g4[u][v].y, acc[v].y);
+          acc[v].z = fmaf(wi[u], g4[u][v].z, acc[v].z); acc[v].w = fmaf(wi[u], g4[u][v].w, acc[v].w);
+        }
     }
   }
-  if (main_l || aux_l) {
-    tile[(4 * li) * F + fl] = acc.x; tile[(4 * li + 1) * F + fl] = acc.y;
-    tile[(4 * li + 2) * F + fl] = acc.z; tile[(4 * li + 3) * F + fl] = acc.w;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int ch = li + LPR * v;
+    if (ch < nch) {
+      tile[(4 * ch) * F + fl] = acc[v].x; tile[(4 * ch + 1) * F + fl] = acc[v].y;
+      tile[(4 * ch + 2) * F + fl] = acc[v].z; tile[(4 * ch + 3) * F + fl] = acc[v].w;
+    }
   }
   __syncthreads();
   const int rows_out = O1 + O2;
-  for (int idx = threadIdx.x; idx < rows_out * F; idx += kSpBwdBlock) {
+  for (int idx = threadIdx.x; idx < rows_out * F; idx += BLK) {
     const int o = idx / F, f = idx % F;
     if (j0 + f < d) {
-      const float v = tile[o * F + f];
-      if (o < O1) gW1[static_cast<int64_t>(o) * ldw1 + j0 + f] = v;
-      else gW2[static_cast<int64_t>(o - O1) * ldw2 + j0 + f] = v;
+      const float x1 = tile[o * F + f];
+      if (o < O1) gW1[static_cast<int64_t>(o) * ldw1 + j0 + f] = x1;
+      else gW2[static_cast<int64_t>(o - O1) * ldw2 + j0 + f] = x1;
     }
   }
 }
@@ -499,14 +532,17 @@ extern "C" int allset_sparse_ln_linear_bwd(const int32_t* colptr, const int32_t*
 }
 
 // ---- ABI 14: the plain Linear (+ up to 4 auxiliary output rows) on sparse raw features -------------------------------------------------
-// Built for O1 in {64, 128} and O2 <= 4 (PMA's value projection with its folded logit rows).  pitch = allset_sparse_linear_pitch(O1, O2).
-extern "C" int allset_sparse_linear_supported(int64_t O1, int64_t O2) { return ((O1 == 64 || O1 == 128) && O2 >= 0 && O2 <= 4) ? 1 : 0; }
-extern "C" int64_t allset_sparse_linear_pitch(int64_t O1, int64_t O2) { return allset_sparse_linear_supported(O1, O2) ? O1 + (O2 > 0 ? 4 : 0) : 0; }
+// Built for O1 in {64, 128, 256, 512} and O2 <= 8 (PMA's value projection with its folded logit rows: the tuned configurations of
+// the reference's run_AllSetTransformer.sh use MLP_hidden 64 ... 512 and 1 ... 8 heads).  pitch = allset_sparse_linear_pitch(O1, O2).
+extern "C" int allset_sparse_linear_supported(int64_t O1, int64_t O2) {
+  return ((O1 == 64 || O1 == 128 || O1 == 256 || O1 == 512) && O2 >= 0 && O2 <= 8) ? 1 : 0;
+}
+extern "C" int64_t allset_sparse_linear_pitch(int64_t O1, int64_t O2) { return allset_sparse_linear_supported(O1, O2) ? O1 + 4 * ((O2 + 3) / 4) : 0; }
 
 extern "C" int allset_sparse_linear_wt(const float* W1, int64_t ld1, int64_t O1, const float* W2, int64_t ld2, int64_t O2, const float* b1,
                                        const float* b2, int64_t d, float* WT, void* stream) {
   clear_error();
-  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_wt: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
+  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_wt: O1 must be 64, 128, 256 or 512 and O2 <= 8"); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(d >= 1 && d < INT32_MAX - 64, "sparse_linear_wt: bad size");
   ALLSET_REQUIRE(W1 && WT && (O2 == 0 || W2) && ld1 >= d && (O2 == 0 || ld2 >= d), "sparse_linear_wt: null pointer or leading dimension smaller than d");
   const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
@@ -517,14 +553,14 @@ extern "C" int allset_sparse_linear_wt(const float* W1, int64_t ld1, int64_t O1,
   return ALLSET_OK;
 }
 
-// y [n, O1] (ldy), y2 [n, 4] (the auxiliary columns, padded to four), w_out [nnz] = the values after the dropout (kept for the backward)
+// y [n, O1] (ldy), y2 [n, 4 ceil(O2 / 4)] (the auxiliary columns, padded to whole 16-byte chunks), w_out [nnz] = the values after the dropout (kept for the backward)
 extern "C" int allset_sparse_linear_fwd(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n, int64_t d, const float* WT,
                                         int64_t O1, int64_t O2, float p_pre, uint64_t seed, const uint64_t* seed_base, float* y, int64_t ldy,
                                         float* y2, float* w_out, void* stream) {
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_linear_fwd: bad size");
   ALLSET_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "sparse_linear_fwd: dropout p must be in [0,1)");
-  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_fwd: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
+  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_fwd: O1 must be 64, 128, 256 or 512 and O2 <= 8"); return ALLSET_ERR_UNSUPPORTED; }
   if (n == 0) return ALLSET_OK;
   ALLSET_REQUIRE(rowptr && WT && y && w_out && (O2 == 0 || y2), "sparse_linear_fwd: null pointer");
   ALLSET_REQUIRE(ldy >= O1 && ldy % 4 == 0 && aligned16(y) && aligned16(WT) && (O2 == 0 || aligned16(y2)),
@@ -535,8 +571,12 @@ extern "C" int allset_sparse_linear_fwd(const int32_t* rowptr, const int32_t* co
   const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr);
   const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
   const int di = static_cast<int>(d), o1 = static_cast<int>(O1), o2 = static_cast<int>(O2);
-  if (lpr == 32) sparse_lin_fwd_kernel<32><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, pitch, o1, o2, p_pre, seed, seed_base, y, ldy, y2, w_out);
-  else sparse_lin_fwd_kernel<64><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, pitch, o1, o2, p_pre, seed, seed_base, y, ldy, y2, w_out);
+#define ALLSET_SPL_FWD(L, V) sparse_lin_fwd_kernel<L, V><<<grid, kBlock, 0, st>>>(rowptr, col, val, n, di, WT, pitch, o1, o2, p_pre, seed, seed_base, y, ldy, y2, w_out)
+  if (O1 == 64) ALLSET_SPL_FWD(32, 1);
+  else if (O1 == 128) ALLSET_SPL_FWD(64, 1);
+  else if (O1 == 256) ALLSET_SPL_FWD(64, 2);
+  else ALLSET_SPL_FWD(64, 3);
+#undef ALLSET_SPL_FWD
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
@@ -548,19 +588,24 @@ extern "C" int allset_sparse_linear_bwd(const int32_t* colptr, const int32_t* ro
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1 && d < INT32_MAX, "sparse_linear_bwd: bad size");
   ALLSET_REQUIRE((ticket == nullptr) == (sb_total == nullptr), "sparse_linear_bwd: ticket and sb_total go together");
-  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_bwd: O1 must be 64 or 128 and O2 <= 4"); return ALLSET_ERR_UNSUPPORTED; }
+  if (!allset_sparse_linear_supported(O1, O2)) { set_error("sparse_linear_bwd: O1 must be 64, 128, 256 or 512 and O2 <= 8"); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(colptr && gW1 && sb_part && (O2 == 0 || gW2) && (n == 0 || (gy && w && (O2 == 0 || g2))), "sparse_linear_bwd: null pointer");
   ALLSET_REQUIRE(ldw1 >= d && (O2 == 0 || ldw2 >= d) && (n == 0 || (ldg >= O1 && ldg % 4 == 0 && aligned16(gy) && (O2 == 0 || aligned16(g2)))) &&
                  aligned16(sb_part), "sparse_linear_bwd: leading dimensions; gy rows, g2 and sb_part 16-byte aligned");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int pitch = static_cast<int>(allset_sparse_linear_pitch(O1, O2));
   const int lpr = O1 == 64 ? 32 : 64;
-  const int64_t feats_per_block = kSpBwdBlock / lpr;
+  const int blk = O1 <= 128 ? 1024 : 512;
+  const int64_t feats_per_block = blk / lpr;
   const int feat_blocks = static_cast<int>((d + feats_per_block - 1) / feats_per_block);
   const unsigned grid = static_cast<unsigned>(feat_blocks + kSpSlices);
   const int di = static_cast<int>(d), o1 = static_cast<int>(O1), o2 = static_cast<int>(O2);
-  if (lpr == 32) sparse_lin_bwd_kernel<32><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks, ticket, sb_total);
-  else sparse_lin_bwd_kernel<64><<<grid, kSpBwdBlock, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks, ticket, sb_total);
+#define ALLSET_SPL_BWD(L, V) sparse_lin_bwd_kernel<L, V><<<grid, blk, 0, st>>>(colptr, rowT, posT, w, gy, ldg, g2, n, di, pitch, o1, o2, gW1, ldw1, gW2, ldw2, sb_part, feat_blocks, ticket, sb_total)
+  if (O1 == 64) ALLSET_SPL_BWD(32, 1);
+  else if (O1 == 128) ALLSET_SPL_BWD(64, 1);
+  else if (O1 == 256) ALLSET_SPL_BWD(64, 2);
+  else ALLSET_SPL_BWD(64, 3);
+#undef ALLSET_SPL_BWD
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

@@ -2266,7 +2266,7 @@ class _SparsePmaProject(torch.autograd.Function):
         pitch = int(lib.allset_sparse_linear_pitch(O1, H))
         wt = torch.empty((d + 1, pitch), dtype=torch.float32, device=dev)
         y = torch.empty((n, O1), dtype=torch.float32, device=dev)
-        y2 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        y2 = torch.empty((n, pitch - O1), dtype=torch.float32, device=dev)            # (the auxiliary columns in whole 16-byte chunks)
         w = torch.empty(max(sp.nnz, 1), dtype=torch.float32, device=dev)
         with on_device(dev):
             check(lib.allset_sparse_linear_wt(ptr(w_v_c), _ld(w_v_c), O1, ptr(w_a_c), _ld(w_a_c), H, ptr(b_v.contiguous()) if b_v is not None else None,
@@ -2276,7 +2276,7 @@ class _SparsePmaProject(torch.autograd.Function):
         ctx.save_for_backward(w)
         ctx.sp = sp
         ctx.cfg = (O1, H, d, b_v is not None, b_a is not None)
-        return y, (y2 if H == 4 else y2[:, :H].contiguous())
+        return y, (y2 if H == y2.shape[1] else y2[:, :H].contiguous())
 
     @staticmethod
     @once_differentiable
@@ -2288,8 +2288,8 @@ class _SparsePmaProject(torch.autograd.Function):
         dev = g_v.device
         g_v = _rowmajor(g_v.contiguous())
         n = g_v.shape[0]
-        g4 = g_alpha.contiguous() if H == 4 else torch.cat([g_alpha, g_alpha.new_zeros(n, 4 - H)], dim=1)
         pitch = int(lib.allset_sparse_linear_pitch(O1, H))
+        g4 = g_alpha.contiguous() if H == pitch - O1 else torch.cat([g_alpha, g_alpha.new_zeros(n, pitch - O1 - H)], dim=1)
         slices = int(lib.allset_sparse_ln_linear_slices())
         gw = torch.empty((O1 + H, d), dtype=torch.float32, device=dev)               # gW_V | gw_a: one allocation
         sb = torch.empty((slices + 1, pitch), dtype=torch.float32, device=dev)         # the slices | their total

@@ -521,17 +521,18 @@ int allset_unfold_ln_linear_ex(const float* M, int64_t ldm, const float* W, int6
 /* ABI 14.  The PLAIN Linear on the same sparse rows, with up to four auxiliary output rows: PMA's value projection and its folded
  * logits on the FIRST conv of an AllSetTransformer (reference models.py:473 -- the input dropout -- and layers.py:126-131: lin_V and
  * lin_K applied to Citeseer's 3703-wide bag-of-words rows; as library GEMMs + a dropout pass they were 165 us of a 440-us step):
- *   allset_sparse_linear_wt    WT[d + 1, pitch]: row j < d = column j of the stacked weight [W1 (O1 rows); W2 (O2 <= 4 rows); 0 ...],
- *                              row d = the stacked bias (b1, b2 may be NULL); pitch = allset_sparse_linear_pitch(O1, O2) = O1 + 4 (O1 if O2 = 0)
- *   allset_sparse_linear_fwd   y[n, O1] = dropout_p(x) W1^T + b1 and y2[n, 4] = dropout_p(x) W2^T + b2 (columns >= O2 zero) from the
+ *   allset_sparse_linear_wt    WT[d + 1, pitch]: row j < d = column j of the stacked weight [W1 (O1 rows); W2 (O2 <= 8 rows); 0 ...],
+ *                              row d = the stacked bias (b1, b2 may be NULL); pitch = allset_sparse_linear_pitch(O1, O2) = O1 + 4 ceil(O2 / 4)
+ *   allset_sparse_linear_fwd   y[n, O1] = dropout_p(x) W1^T + b1 and y2[n, pitch - O1] = dropout_p(x) W2^T + b2 (columns >= O2 zero) from the
  *                              non-zeros; the dropout is the library's hash of (seed [, *seed_base], r * d + j); w_out[nnz] keeps the
  *                              values after the dropout for the backward
- *   allset_sparse_linear_bwd   gW1[O1, ldw1 >= d] and gW2[O2, ldw2 >= d] from gy[n, O1] and g2[n, 4] over the CSC of x; sb_part
+ *   allset_sparse_linear_bwd   gW1[O1, ldw1 >= d] and gW2[O2, ldw2 >= d] from gy[n, O1] and g2[n, pitch - O1] over the CSC of x; sb_part
  *                              [allset_sparse_ln_linear_slices()][pitch] = per-slice column sums of [gy | g2] (the bias gradients);
  *                              with ticket (a zeroed uint32 the launch re-arms, one per stream) and sb_total[pitch] the last slice
  *                              workgroup to finish sums the slices in index order into sb_total -- no reduction launch; both NULL:
  *                              the caller sums the slices (allset_reduce_partials)
- * x needs no gradient (raw features).  O1 in {64, 128}, O2 <= 4 (allset_sparse_linear_supported).  csrc/sparse_input.hip;
+ * x needs no gradient (raw features).  O1 in {64, 128, 256, 512}, O2 <= 8 (allset_sparse_linear_supported: the widths and head
+ * counts of the reference's tuned run_AllSetTransformer.sh configurations).  csrc/sparse_input.hip;
  * allset_amd/dense.py _SparsePmaProject. */
 int allset_sparse_linear_supported(int64_t O1, int64_t O2);
 int64_t allset_sparse_linear_pitch(int64_t O1, int64_t O2);

@@ -259,7 +259,9 @@ def test_sparse_rows_cache_follows_the_tensor(device):
     assert torch.equal(b.val[b.posT.long()], x[b.rowT.long(), torch.repeat_interleave(torch.arange(500, device=device), (b.colptr[1:] - b.colptr[:-1]).long())])
 
 
-@pytest.mark.parametrize("n,d,O,H", [(3312, 3703, 128, 4), (300, 1433, 64, 4), (517, 3703, 128, 1), (64, 300, 64, 3), (1, 256, 128, 4)])
+@pytest.mark.parametrize("n,d,O,H", [(3312, 3703, 128, 4), (300, 1433, 64, 4), (517, 3703, 128, 1), (64, 300, 64, 3), (1, 256, 128, 4),
+                                     (3312, 3703, 512, 8), (2708, 1433, 256, 4), (700, 1425, 256, 8), (90, 300, 64, 8), (211, 800, 128, 5),
+                                     (65, 500, 512, 1)])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 @pytest.mark.parametrize("bias", [True, False])
 def test_sparse_pma_projection_matches_float64(n, d, O, H, p, bias, device, monkeypatch):

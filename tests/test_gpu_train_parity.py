@@ -127,7 +127,10 @@ def test_training_step_matches_oracle_with_the_products_masks(name, over, device
 
 
 @pytest.mark.parametrize("name,over", [("cora_ds_add", {}), ("citeseer_pma_h4", {}), ("rand50_ds_add", {}),
-                                       ("cora_ds_add", dict(MLP_num_layers=1)), ("cora_ds_add", dict(All_num_layers=2))],
+                                       ("cora_ds_add", dict(MLP_num_layers=1)), ("cora_ds_add", dict(All_num_layers=2)),
+                                       # the reference's tuned AllSetTransformer widths / head counts (run_AllSetTransformer.sh: Cora 256 / 4,
+                                       # Citeseer 512 / 8) on bag-of-words rows: the sparse projection's wide instantiations
+                                       ("citeseer_pma_h4", dict(MLP_hidden=256, heads=8)), ("citeseer_pma_h4", dict(MLP_hidden=512, heads=8))],
                          ids=lambda v: v if isinstance(v, str) else ("-".join(f"{k}{w}" for k, w in v.items()) or "stock"))
 def test_training_step_on_features_without_gradient(name, over, device, monkeypatch):
     """The same comparison with ``data.x`` a plain tensor (what train.py feeds): raw-feature widths behind an input LayerNorm take
