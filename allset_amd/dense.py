@@ -132,6 +132,24 @@ def _defer(part: Tensor, sections, M: Optional[int] = None) -> None:
     _Deferred.pending.append((part, part.shape[1] if M is None else M, secs))
 
 
+def _defer_or_reduce(part: Tensor, sections, defer: bool):
+    """``sections``: [(parameter or None, offset, shape)] of one partial buffer [P, M].  Inside ``deferred_param_grads()`` (and with
+    ``defer``) the buffer is queued and every section comes back None; otherwise one reduction launch and the sections as views."""
+    part2 = part.reshape(part.shape[0], -1)
+    params = [p for p, _, _ in sections]
+    if defer and any(p is not None for p in params) and _deferrable(part2, *params):
+        _defer(part2, sections)
+        return [None] * len(sections)
+    red = reduce_partials(part2).reshape(-1)
+    out = []
+    for _, off, shape in sections:
+        numel = 1
+        for v in shape:
+            numel *= v
+        out.append(red[off:off + numel].view(shape))
+    return out
+
+
 def flush_param_grads(bump_i64: Optional[Tensor] = None, bump_f32=None) -> None:
     """Reduce everything queued with one batched launch and assign / accumulate the parameters' ``.grad``.  ``bump_i64`` (a
     1-element int64 device tensor) and ``bump_f32`` (a list of 0-dim float32 device tensors, or a callable returning one -- called
@@ -327,7 +345,7 @@ def ln_bf16_supported(d: int) -> bool:
 
 
 def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
-           seed_base: Optional[Tensor] = None, want_gx: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor]:
+           seed_base: Optional[Tensor] = None, want_gx: bool = True, defer_to=None) -> Tuple[Optional[Tensor], Tensor, Tensor]:
     dev = require_device(gy, x, stats, gamma)
     gy, x = _rowmajor(gy), _rowmajor(x)
     n, d = x.shape
@@ -356,8 +374,9 @@ def ln_bwd(gy: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p
                                 seed, ptr(gx), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base),
                                 stream_of(dev)),
               "allset_ln_bwd")
-    red = reduce_partials(partials)
-    return gx, red[0], red[1]
+    dg_, db_ = _defer_or_reduce(partials, [(defer_to[0] if defer_to else None, 0, (d,)), (defer_to[1] if defer_to else None, d, (d,))],
+                                defer_to is not None)
+    return gx, dg_, db_
 
 
 def wgrad(ga: Tensor, u: Tensor, want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
@@ -492,7 +511,7 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
 
 def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Tensor, relu_in: bool, p: float, seed: int,
                 mask_y: Optional[Tensor] = None, p_mask: float = 0.0, seed_base: Optional[Tensor] = None,
-                mask_bits: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                mask_bits: Optional[Tensor] = None, defer_to=None) -> Tuple[Tensor, Tensor, Tensor]:
     """Backward-data of a wide Linear fused with the LayerNorm backward of its input (include/allset_hip.h
     allset_gemm_x6_lnb): returns (gx, dgamma, dbeta).  ``planes_t``: ``gemm_x6_planes(weight, True)``; N = x.shape[1] <= 256."""
     planes_t, f16 = planes_t.buf, planes_t.f16
@@ -512,8 +531,9 @@ def gemm_x6_lnb(G: Tensor, planes_t: Tensor, x: Tensor, stats: Tensor, gamma: Te
                                        _ld(mask_y) if mask_y is not None else 0, ptr(mask_bits), p_mask, ptr(planes_t),
                                        ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()), int(relu_in), p, seed, ptr(gx), max(N, 1),
                                        ptr(partials), npart, n, N, K, ptr(seed_base), stream_of(dev)), "allset_gemm_wide_lnb")
-    red = reduce_partials(partials)
-    return gx, red[0], red[1]
+    dg_, db_ = _defer_or_reduce(partials, [(defer_to[0] if defer_to else None, 0, (N,)), (defer_to[1] if defer_to else None, N, (N,))],
+                                defer_to is not None)
+    return gx, dg_, db_
 
 
 # ---- arithmetic of the fused Linear kernels (include/allset_hip_ext.h ALLSET_ARITH_*) ---------------------------------------------
@@ -685,7 +705,7 @@ def fused_linear_bwd_all_blocked(gy: Tensor, gy_cb: int, mask: Optional[Tensor],
 
 def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats: Optional[Tensor],
                 gamma: Optional[Tensor], beta: Optional[Tensor], relu_in: bool, p_in: float, seed_in: int,
-                want_bias: bool = True, seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None
+                want_bias: bool = True, seed_base: Optional[Tensor] = None, mask: Optional[Tensor] = None, defer_to=None
                 ) -> Tuple[Tensor, Optional[Tensor]]:
     """Weight/bias gradient of the fused Linear with both operands recomputed on the fly (csrc/dense.hip).
     ``mask`` (from ``fused_linear_fwd(mask_out=...)``) replaces ``y`` as the source of the epilogue mask."""
@@ -706,8 +726,9 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
             check(lib.allset_wgrad_f16x3(ptr(gy), _ld(gy), ptr(mask), p_out, ptr(x), _ld(x), ptr(stats), ptr(gamma.contiguous()),
                                          ptr(beta.contiguous()), int(relu_in), p_in, seed_in, ptr(part), M, int(want_bias), ns.value,
                                          n, O, I, ptr(seed_base), stream_of(dev)), "allset_wgrad_f16x3")
-        red = reduce_partials(part)
-        return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
+        gw_, gb_ = _defer_or_reduce(part, [(defer_to[0] if defer_to else None, 0, (O, I)),
+                                           ((defer_to[1] if defer_to else None) if want_bias else None, O * I, (O,))], defer_to is not None)
+        return gw_, (gb_ if want_bias else None)
     check(lib.allset_wgrad_slices(n, O, I, byref(ns)), "allset_wgrad_slices")
     # one partial buffer [slices, gW | gb] and one reduction launch (O and I are multiples of 4, checked by the kernel)
     part = torch.empty((ns.value, M), dtype=torch.float32, device=dev)
@@ -717,8 +738,9 @@ def wgrad_fused(gy: Tensor, y: Optional[Tensor], p_out: float, x: Tensor, stats:
                                         ptr(beta.contiguous() if beta is not None else None), int(relu_in), p_in, seed_in,
                                         ptr(part), M, int(want_bias), ns.value, n, O, I, ptr(seed_base), ptr(mask),
                                         stream_of(dev)), "allset_wgrad_fused_ex")
-    red = reduce_partials(part)
-    return red[:O * I].view(O, I), (red[O * I:] if want_bias else None)
+    gw_, gb_ = _defer_or_reduce(part, [(defer_to[0] if defer_to else None, 0, (O, I)),
+                                       ((defer_to[1] if defer_to else None) if want_bias else None, O * I, (O,))], defer_to is not None)
+    return gw_, (gb_ if want_bias else None)
 
 
 def fused_linear_bwd(gy: Tensor, y: Optional[Tensor], p_out: float, weight: Tensor, x: Tensor, stats: Optional[Tensor],
@@ -1132,6 +1154,7 @@ class _WideNormLinear(torch.autograd.Function):
                     stats_relu=bool(emit[1]) if emit is not None else False)
         ctx.save_for_backward(x, stats, gamma, beta, weight, y if (keep_y and mask is None) else None, mask)
         ctx.cfg = (bool(relu_in), float(p_in), seed_in, float(p_out), bias is not None, base)
+        ctx.params = (gamma, beta, weight, bias)     # (the objects themselves: deferred_param_grads assigns their .grad)
         if emit is None:
             return y
         ctx.mark_non_differentiable(stats_y)
@@ -1151,19 +1174,25 @@ class _WideNormLinear(torch.autograd.Function):
         gy = gy.contiguous()
         gx = dg = db = gw = gb = None
         need_b = has_bias and ctx.needs_input_grad[4]
+        need = ctx.needs_input_grad
+        p_g, p_bt, p_w, p_b = ctx.params
+        dfr = _Deferred.active
         if ctx.needs_input_grad[3] or need_b:
-            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b, seed_base=base, mask=mask)
+            gw, gb = wgrad_fused(gy, y, p_out, x, stats, gamma, beta, relu_in, p_in, seed_in, want_bias=need_b, seed_base=base, mask=mask,
+                                 defer_to=(p_w, p_b) if (dfr and need[3] and (not has_bias or need[4])) else None)
         need_x = ctx.needs_input_grad[0]
         if need_x or (gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])):
             # gradient of the Linear's input u = dropout(LN(relu(x))): (gy * epilogue mask) @ W
             if gamma is not None and weight.shape[1] <= 256:
                 # one kernel: the Linear's input gradient never leaves the chip, the LayerNorm backward is the GEMM's epilogue
                 gx, dg, db = gemm_x6_lnb(gy, gemm_x6_planes(weight, True), x, stats, gamma, relu_in, p_in, seed_in, mask_y=y,
-                                         p_mask=p_out, seed_base=base, mask_bits=mask)
+                                         p_mask=p_out, seed_base=base, mask_bits=mask,
+                                         defer_to=(p_g, p_bt) if (dfr and need[1] and need[2]) else None)
                 return gx, dg, db, gw, gb, None, None, None, None, None, None, None
             gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out, mask_bits=mask)
             if gamma is not None:
-                gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x)
+                gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x,
+                                    defer_to=(p_g, p_bt) if (dfr and need[1] and need[2]) else None)
             elif relu_in:                       # (p_in == 0 here, see wide_linear_supported): mask by the sign of x
                 gx = torch.empty_like(x)
                 with torch.cuda.device(x.device), _timed("relu_dropout_bwd", x.device, 3 * x.numel() * 4):

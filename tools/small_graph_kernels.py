@@ -13,6 +13,10 @@ REPLAYS = int(os.environ.get("REPLAYS", "200"))
 name = sys.argv[1] if len(sys.argv) > 1 else "cora_ds_add"
 dev = torch.device("cuda:0")
 case = cases.build_case(name)
+# MODEL_ARGS="MLP_hidden=512,heads=8": the reference's tuned widths on the same stand-in data (run_AllSetTransformer.sh)
+for kv in filter(None, os.environ.get("MODEL_ARGS", "").split(",")):
+    k, v = kv.split("=")
+    setattr(case["args"], k, type(getattr(case["args"], k))(v))
 model = SetGNN(case["args"]).to(dev)
 model.reset_parameters()
 data = SimpleNamespace(x=torch.from_numpy(case["x"]).to(dev), edge_index=torch.from_numpy(case["edge_index"]).to(dev),
