@@ -66,8 +66,12 @@ __global__ __launch_bounds__(kBlock) void gemm_x6_planes_kernel(const float* __r
 // ---- the same weight in TWO fp16 planes ("fp16x3", common.h split2_f16c) -----------------------------------------------------------
 // Row n of B is scaled by 2^(140 - e_n), e_n = the biased exponent of its largest element (so that it lands in [2^13, 2^14)); the
 // inverse 2^(e_n - 140) per output column is stored behind the planes (float[n_pad]) and applied in the GEMM's epilogue.
-__global__ __launch_bounds__(kBlock) void gemm_f16_bscale_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
-                                                                 float* __restrict__ bscale, int N, int n_pad, int K) {
+// ONE launch (round 6, second session: at dataset scale a step rebuilds ten plane images -- W and W^T of five wide Linears -- and the
+// former pair of launches per image, scales then planes, was 107 us of a 1-ms step): a wave owns output row n, finds its largest
+// element, then reads the row again (out of L1 / L2) and writes the scaled planes.
+__global__ __launch_bounds__(kBlock) void gemm_f16_planes_fused_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
+                                                                       uint32_t* __restrict__ planes, float* __restrict__ bscale,
+                                                                       int N, int n_pad, int K) {
   const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= n_pad) return;
   float amax = 0.f;
@@ -77,27 +81,17 @@ __global__ __launch_bounds__(kBlock) void gemm_f16_bscale_kernel(const float* __
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   const int e = min(max(static_cast<int>(__float_as_uint(amax) >> 23), 20), 254);
   if (lane == 0) bscale[n] = __uint_as_float(static_cast<uint32_t>(e - 13) << 23);        // 2^(e - 140)
-}
-
-__global__ __launch_bounds__(kBlock) void gemm_f16_planes_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
-                                                                 uint32_t* __restrict__ planes, const float* __restrict__ bscale,
-                                                                 int N, int K) {
-  const int n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
-  const int64_t pairs = static_cast<int64_t>(n_pad) * (K / 2);
-  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < pairs;
-       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int n = static_cast<int>(idx / (K / 2));
-    const int k = 2 * static_cast<int>(idx - static_cast<int64_t>(n) * (K / 2));
+  const float sc = __uint_as_float(static_cast<uint32_t>(267 - e) << 23);                 // 2^(140 - e): field 13 .. 247
+  const int nt = n / kGxBN, nn = n % kGxBN;
+  for (int k = 2 * lane; k < K; k += 128) {
     float w0 = 0.f, w1 = 0.f;
     if (n < N) {
       if (transpose) { w0 = W[static_cast<int64_t>(k) * ldw + n]; w1 = W[static_cast<int64_t>(k + 1) * ldw + n]; }
       else { w0 = W[static_cast<int64_t>(n) * ldw + k]; w1 = W[static_cast<int64_t>(n) * ldw + k + 1]; }
     }
-    const int e = static_cast<int>(__float_as_uint(bscale[n]) >> 23) + 13;                  // bscale[n] = 2^(e - 140)
-    const float sc = __uint_as_float(static_cast<uint32_t>(267 - e) << 23);                 // 2^(140 - e): field 13 .. 247
     uint32_t ph, pl;
     split2_f16c(w0 * sc, w1 * sc, ph, pl);
-    const int nt = n / kGxBN, nn = n % kGxBN, ks = k / kGxKS, kk = k % kGxKS;
+    const int ks = k / kGxKS, kk = k % kGxKS;
     const int64_t image = (static_cast<int64_t>(nt) * (K / kGxKS) + ks) * 2 * (kGxBN * kGxKS / 2);   // dwords
     const int at = nn * (kGxKS / 2) + (((kk >> 3) ^ gx_swz(nn)) << 2) + ((kk & 7) >> 1);
     planes[image + gx_image_at<4>(at)] = ph;
@@ -172,7 +166,7 @@ __device__ __forceinline__ float gx_wave_sum(float v) {
 
 // F16 (round 5, "fp16x3"): two fp16 planes per operand and three MFMAs per product instead of three bf16 planes and six -- half the
 // matrix work of a kernel whose matrix pipe is its critical resource.  fp16's five exponent bits need every operand
-// inside a window: B per output column (gemm_f16_planes_kernel; inverse scales `bscale`), A behind a LayerNorm-apply prologue by ONE
+// inside a window: B per output column (gemm_f16_planes_fused_kernel; inverse scales `bscale`), A behind a LayerNorm-apply prologue by ONE
 // power of two for the launch (|u| <= (sqrt(K - 1) max|gamma| + max|beta|) keep -- folded into the LDS copy of gamma / beta, no
 // instruction), any other A per ROW: the row's largest element to [2^13, 2^14).  That row maximum needs the whole row before its
 // first K step: every thread reads, one TILE ahead, the segments it will stage for the next tile (same addresses: the second read
@@ -1347,12 +1341,8 @@ extern "C" int allset_gemm_f16x3_planes(const float* W, int64_t ldw, int transpo
   const int64_t n_pad = (N + kGxBN - 1) / kGxBN * kGxBN;
   float* bscale = reinterpret_cast<float*>(static_cast<char*>(planes) + n_pad * K * 2 * 2);
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  gemm_f16_bscale_kernel<<<static_cast<unsigned>((n_pad + kBlock / 64 - 1) / (kBlock / 64)), kBlock, 0, st>>>(
-      W, ldw, transpose, bscale, static_cast<int>(N), static_cast<int>(n_pad), static_cast<int>(K));
-  const int64_t pairs = n_pad * (K / 2);
-  const int64_t want = (pairs + kBlock - 1) / kBlock;
-  gemm_f16_planes_kernel<<<static_cast<unsigned>(want > 4096 ? 4096 : want), kBlock, 0, st>>>(
-      W, ldw, transpose, static_cast<uint32_t*>(planes), bscale, static_cast<int>(N), static_cast<int>(K));
+  gemm_f16_planes_fused_kernel<<<static_cast<unsigned>((n_pad + kBlock / 64 - 1) / (kBlock / 64)), kBlock, 0, st>>>(
+      W, ldw, transpose, static_cast<uint32_t*>(planes), bscale, static_cast<int>(N), static_cast<int>(n_pad), static_cast<int>(K));
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }
