@@ -824,7 +824,9 @@ __global__ __launch_bounds__(kWx6Block) void wgrad_x6_kernel(
 // SetGNN puts behind every conv, each in ONE read-write pass instead of a torch add + LayerNorm (+ relu/dropout).
 // Backward: gs = d loss / d (x + colb + res) -- the same tensor is the gradient of x and of res, its column sums the
 // gradient of colb (third partial row); the relu mask is recomputed from the statistics (no y kept).
-template <int LPR>
+// VPL = 16-byte chunks per lane: 1 for d <= 256 (LPR lanes x 4 columns cover a row), 2 for 256 < d <= 512 (LPR = 64: lane li owns
+// columns 4 li .. and 256 + 4 li ..; round 6, second session -- the reference's tuned AllSetTransformer runs use MLP_hidden 512).
+template <int LPR, int VPL = 1>
 __global__ __launch_bounds__(kBlock) void ln_res_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ colb, const float* __restrict__ res, int64_t ldr,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu_out, float p, uint64_t seed,
@@ -832,53 +834,79 @@ __global__ __launch_bounds__(kBlock) void ln_res_fwd_kernel(
     const uint64_t* __restrict__ seed_base) {
   seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
+  constexpr int RPG = VPL == 1 ? kLnRowsPerGroup : 2;              // rows in flight per lane group
   const int lane = lane_id();
   const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
   const int li = lane % LPR;
-  const int c0 = li * 4;
-  const bool active = c0 < d;
   constexpr int kGroups = kWavesPerBlock * NS;
   const float inv_d = 1.f / static_cast<float>(d);
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const uint32_t thr = drop_threshold(p);
-  float4 g4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0), cb = make_float4(0, 0, 0, 0);
-  if (active) {
-    g4 = *reinterpret_cast<const float4*>(gamma + c0);
-    b4 = *reinterpret_cast<const float4*>(beta + c0);
-    if (colb) cb = *reinterpret_cast<const float4*>(colb + c0);
-  }
-  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + grp) * kLnRowsPerGroup;
-  float4 v[kLnRowsPerGroup], w[kLnRowsPerGroup];
+  int c0[VPL];
+  bool active[VPL];
+  float4 g4[VPL], b4[VPL], cb[VPL];
 #pragma unroll
-  for (int r = 0; r < kLnRowsPerGroup; ++r) {          // unconditional loads on clamped rows
+  for (int q = 0; q < VPL; ++q) {
+    c0[q] = (li + LPR * q) * 4;
+    active[q] = c0[q] < d;
+    g4[q] = b4[q] = cb[q] = make_float4(0, 0, 0, 0);
+    if (active[q]) {
+      g4[q] = *reinterpret_cast<const float4*>(gamma + c0[q]);
+      b4[q] = *reinterpret_cast<const float4*>(beta + c0[q]);
+      if (colb) cb[q] = *reinterpret_cast<const float4*>(colb + c0[q]);
+    }
+  }
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + grp) * RPG;
+  float4 v[RPG][VPL], w[RPG][VPL];
+#pragma unroll
+  for (int r = 0; r < RPG; ++r) {                      // unconditional loads on clamped rows
     int64_t row = row0 + r;
     row = row < n ? row : n - 1;
-    const int cc = active ? c0 : 0;
-    v[r] = *reinterpret_cast<const float4*>(x + row * ldx + cc);
-    w[r] = res ? *reinterpret_cast<const float4*>(res + row * ldr + cc) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      const int cc = active[q] ? c0[q] : 0;
+      v[r][q] = *reinterpret_cast<const float4*>(x + row * ldx + cc);
+      w[r][q] = res ? *reinterpret_cast<const float4*>(res + row * ldr + cc) : make_float4(0, 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < kLnRowsPerGroup; ++r) {
+  for (int r = 0; r < RPG; ++r) {
     const int64_t row = row0 + r;
-    float4 t = make_float4(v[r].x + w[r].x + cb.x, v[r].y + w[r].y + cb.y, v[r].z + w[r].z + cb.z, v[r].w + w[r].w + cb.w);
-    if (!active) t = make_float4(0, 0, 0, 0);
-    const float mean = group_sum<LPR>(t.x + t.y + t.z + t.w) * inv_d;
-    float4 c = make_float4(t.x - mean, t.y - mean, t.z - mean, t.w - mean);
-    if (!active) c = make_float4(0, 0, 0, 0);
-    const float var = group_sum<LPR>(c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) * inv_d;
+    float4 t[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      t[q] = make_float4(v[r][q].x + w[r][q].x + cb[q].x, v[r][q].y + w[r][q].y + cb[q].y, v[r][q].z + w[r][q].z + cb[q].z,
+                         v[r][q].w + w[r][q].w + cb[q].w);
+      if (!active[q]) t[q] = make_float4(0, 0, 0, 0);
+      s += t[q].x + t[q].y + t[q].z + t[q].w;
+    }
+    const float mean = group_sum<LPR>(s) * inv_d;
+    float4 c[VPL];
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      c[q] = make_float4(t[q].x - mean, t[q].y - mean, t[q].z - mean, t[q].w - mean);
+      if (!active[q]) c[q] = make_float4(0, 0, 0, 0);
+      s2 += c[q].x * c[q].x + c[q].y * c[q].y + c[q].z * c[q].z + c[q].w * c[q].w;
+    }
+    const float var = group_sum<LPR>(s2) * inv_d;
     const float rstd = rsqrtf(var + eps);
     if (row < n) {
-      if (active) {
-        float4 o = make_float4(c.x * rstd * g4.x + b4.x, c.y * rstd * g4.y + b4.y, c.z * rstd * g4.z + b4.z,
-                               c.w * rstd * g4.w + b4.w);
-        if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        if (p > 0.f) {
-          const int64_t e = row * d + c0;
-          float k0, k1, k2, k3;
-          keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
-          o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
+#pragma unroll
+      for (int q = 0; q < VPL; ++q) {
+        if (active[q]) {
+          float4 o = make_float4(c[q].x * rstd * g4[q].x + b4[q].x, c[q].y * rstd * g4[q].y + b4[q].y, c[q].z * rstd * g4[q].z + b4[q].z,
+                                 c[q].w * rstd * g4[q].w + b4[q].w);
+          if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          if (p > 0.f) {
+            const int64_t e = row * d + c0[q];
+            float k0, k1, k2, k3;
+            keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+            o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
+          }
+          *reinterpret_cast<float4*>(y + row * ldy + c0[q]) = o;
         }
-        *reinterpret_cast<float4*>(y + row * ldy + c0) = o;
       }
       if (li == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
     }
@@ -886,7 +914,7 @@ __global__ __launch_bounds__(kBlock) void ln_res_fwd_kernel(
 }
 
 // part[blockIdx][0|1|2][c] = dgamma, dbeta, dcolb (= column sums of gs)
-template <int LPR>
+template <int LPR, int VPL = 1>
 __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
     const float* __restrict__ gy, int64_t ldg, const float* __restrict__ x, int64_t ldx, const float* __restrict__ colb,
     const float* __restrict__ res, int64_t ldr, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -896,78 +924,96 @@ __global__ __launch_bounds__(kBlock) void ln_res_bwd_kernel(
   seed = resolve_seed(seed_base, seed);
   constexpr int NS = kWave / LPR;
   constexpr int kGroups = kWavesPerBlock * NS;
-  __shared__ float red[kGroups][3][LPR * 4];
+  constexpr int W = LPR * 4 * VPL;                                  // columns covered
+  __shared__ float red[kGroups][3][W];
   // optional epilogue for the PMA tail (x = the pooled output of allset_pma_fwd, gs = its gradient): the per-(row, head)
   // backward statistics {M = m + log(l + eps), delta = <x_head, gs_head>} that allset_pma_bwd_src gathers, written here
   // where both operands are in registers instead of by a separate pass over x and gs (allset_pma_bwd_stats)
-  const int pma_g = pma_stats ? (d / pma_heads) / 4 : 1;           // lanes per head (a power of two, checked by the host)
+  const int pma_g = pma_stats ? (d / pma_heads) / 4 : 1;           // lanes per head (a power of two <= LPR, checked by the host)
   const int lane = lane_id();
   const int grp = (threadIdx.x >> 6) * NS + lane / LPR;
   const int li = lane % LPR;
-  const int c0 = li * 4;
-  const bool active = c0 < d;
-  const int cc = active ? c0 : 0;
   const float inv_d = 1.f / static_cast<float>(d);
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const uint32_t thr = drop_threshold(p);
-  float4 g4 = make_float4(0, 0, 0, 0), b4 = make_float4(0, 0, 0, 0), cb = make_float4(0, 0, 0, 0);
-  if (active) {
-    g4 = *reinterpret_cast<const float4*>(gamma + c0);
-    b4 = *reinterpret_cast<const float4*>(beta + c0);
-    if (colb) cb = *reinterpret_cast<const float4*>(colb + c0);
+  int c0[VPL], cc[VPL];
+  bool active[VPL];
+  float4 g4[VPL], b4[VPL], cb[VPL], dg[VPL], db[VPL], dc[VPL];
+#pragma unroll
+  for (int q = 0; q < VPL; ++q) {
+    c0[q] = (li + LPR * q) * 4;
+    active[q] = c0[q] < d;
+    cc[q] = active[q] ? c0[q] : 0;
+    g4[q] = b4[q] = cb[q] = dg[q] = db[q] = dc[q] = make_float4(0, 0, 0, 0);
+    if (active[q]) {
+      g4[q] = *reinterpret_cast<const float4*>(gamma + c0[q]);
+      b4[q] = *reinterpret_cast<const float4*>(beta + c0[q]);
+      if (colb) cb[q] = *reinterpret_cast<const float4*>(colb + c0[q]);
+    }
   }
-  float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0), dc = make_float4(0, 0, 0, 0);
   const int64_t rows_per_iter = static_cast<int64_t>(gridDim.x) * kGroups;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + grp; row < n; row += rows_per_iter) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + cc);
-    float4 gv = *reinterpret_cast<const float4*>(gy + row * ldg + cc);
-    const float4 rv = res ? *reinterpret_cast<const float4*>(res + row * ldr + cc) : make_float4(0, 0, 0, 0);
+    float4 xv[VPL], gv[VPL], xh[VPL], gh[VPL];
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float4 xh = make_float4((xv.x + rv.x + cb.x - mean) * rstd, (xv.y + rv.y + cb.y - mean) * rstd,
-                            (xv.z + rv.z + cb.z - mean) * rstd, (xv.w + rv.w + cb.w - mean) * rstd);
-    if (!active) { xh = make_float4(0, 0, 0, 0); gv = make_float4(0, 0, 0, 0); }
-    if (p > 0.f) {
-      const int64_t e = row * d + c0;
-      float k0, k1, k2, k3;
-      keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
-      gv.x *= k0; gv.y *= k1; gv.z *= k2; gv.w *= k3;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      xv[q] = *reinterpret_cast<const float4*>(x + row * ldx + cc[q]);
+      gv[q] = *reinterpret_cast<const float4*>(gy + row * ldg + cc[q]);
+      const float4 rv = res ? *reinterpret_cast<const float4*>(res + row * ldr + cc[q]) : make_float4(0, 0, 0, 0);
+      xh[q] = make_float4((xv[q].x + rv.x + cb[q].x - mean) * rstd, (xv[q].y + rv.y + cb[q].y - mean) * rstd,
+                          (xv[q].z + rv.z + cb[q].z - mean) * rstd, (xv[q].w + rv.w + cb[q].w - mean) * rstd);
+      if (!active[q]) { xh[q] = make_float4(0, 0, 0, 0); gv[q] = make_float4(0, 0, 0, 0); }
+      if (p > 0.f) {
+        const int64_t e = row * d + c0[q];
+        float k0, k1, k2, k3;
+        keep_scale2(seed, e, thr, inv_keep, k0, k1); keep_scale2(seed, e + 2, thr, inv_keep, k2, k3);
+        gv[q].x *= k0; gv[q].y *= k1; gv[q].z *= k2; gv[q].w *= k3;
+      }
+      if (relu_out) {                                      // relu mask from the recomputed LayerNorm output
+        if (!(fmaf(xh[q].x, g4[q].x, b4[q].x) > 0.f)) gv[q].x = 0.f;
+        if (!(fmaf(xh[q].y, g4[q].y, b4[q].y) > 0.f)) gv[q].y = 0.f;
+        if (!(fmaf(xh[q].z, g4[q].z, b4[q].z) > 0.f)) gv[q].z = 0.f;
+        if (!(fmaf(xh[q].w, g4[q].w, b4[q].w) > 0.f)) gv[q].w = 0.f;
+      }
+      dg[q].x += gv[q].x * xh[q].x; dg[q].y += gv[q].y * xh[q].y; dg[q].z += gv[q].z * xh[q].z; dg[q].w += gv[q].w * xh[q].w;
+      db[q].x += gv[q].x; db[q].y += gv[q].y; db[q].z += gv[q].z; db[q].w += gv[q].w;
+      gh[q] = make_float4(gv[q].x * g4[q].x, gv[q].y * g4[q].y, gv[q].z * g4[q].z, gv[q].w * g4[q].w);
+      t1 += gh[q].x + gh[q].y + gh[q].z + gh[q].w;
+      t2 += gh[q].x * xh[q].x + gh[q].y * xh[q].y + gh[q].z * xh[q].z + gh[q].w * xh[q].w;
     }
-    if (relu_out) {                                      // relu mask from the recomputed LayerNorm output
-      if (!(fmaf(xh.x, g4.x, b4.x) > 0.f)) gv.x = 0.f;
-      if (!(fmaf(xh.y, g4.y, b4.y) > 0.f)) gv.y = 0.f;
-      if (!(fmaf(xh.z, g4.z, b4.z) > 0.f)) gv.z = 0.f;
-      if (!(fmaf(xh.w, g4.w, b4.w) > 0.f)) gv.w = 0.f;
-    }
-    dg.x += gv.x * xh.x; dg.y += gv.y * xh.y; dg.z += gv.z * xh.z; dg.w += gv.w * xh.w;
-    db.x += gv.x; db.y += gv.y; db.z += gv.z; db.w += gv.w;
-    const float4 gh = make_float4(gv.x * g4.x, gv.y * g4.y, gv.z * g4.z, gv.w * g4.w);
-    const float s1 = group_sum<LPR>(gh.x + gh.y + gh.z + gh.w) * inv_d;
-    const float s2 = group_sum<LPR>(gh.x * xh.x + gh.y * xh.y + gh.z * xh.z + gh.w * xh.w) * inv_d;
-    if (active) {
-      const float4 o = make_float4(rstd * (gh.x - s1 - xh.x * s2), rstd * (gh.y - s1 - xh.y * s2),
-                                   rstd * (gh.z - s1 - xh.z * s2), rstd * (gh.w - s1 - xh.w * s2));
-      dc.x += o.x; dc.y += o.y; dc.z += o.z; dc.w += o.w;
-      *reinterpret_cast<float4*>(gs + row * ldgs + c0) = o;
-    }
-    if (pma_stats != nullptr) {                           // (uniform branch; inactive lanes contribute 0 to the shuffles)
-      float dot = active ? (xv.x * (rstd * (gh.x - s1 - xh.x * s2)) + xv.y * (rstd * (gh.y - s1 - xh.y * s2)) +
-                            xv.z * (rstd * (gh.z - s1 - xh.z * s2)) + xv.w * (rstd * (gh.w - s1 - xh.w * s2))) : 0.f;
-      for (int off = 1; off < pma_g; off <<= 1) dot += __shfl_xor(dot, off);
-      if (active && (li % pma_g) == 0) {
-        const int h = li / pma_g;
-        const float lv = pma_l[row * pma_heads + h];
-        // empty target: never gathered; exp(a - FLT_MAX) = 0 (same convention as pma_bwd_stats_kernel, csrc/pma.hip)
-        const float M = lv > 0.f ? pma_m[row * pma_heads + h] + __logf(lv + 1e-16f) : 3.402823466e+38f;
-        *reinterpret_cast<float2*>(pma_stats + (row * pma_heads + h) * 2) = make_float2(M, dot);
+    const float s1 = group_sum<LPR>(t1) * inv_d;
+    const float s2 = group_sum<LPR>(t2) * inv_d;
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      const float4 o = make_float4(rstd * (gh[q].x - s1 - xh[q].x * s2), rstd * (gh[q].y - s1 - xh[q].y * s2),
+                                   rstd * (gh[q].z - s1 - xh[q].z * s2), rstd * (gh[q].w - s1 - xh[q].w * s2));
+      if (active[q]) {
+        dc[q].x += o.x; dc[q].y += o.y; dc[q].z += o.z; dc[q].w += o.w;
+        *reinterpret_cast<float4*>(gs + row * ldgs + c0[q]) = o;
+      }
+      if (pma_stats != nullptr) {                           // (uniform branch; inactive lanes contribute 0 to the shuffles)
+        float dot = active[q] ? (xv[q].x * o.x + xv[q].y * o.y + xv[q].z * o.z + xv[q].w * o.w) : 0.f;
+        for (int off = 1; off < pma_g; off <<= 1) dot += __shfl_xor(dot, off);
+        if (active[q] && (li % pma_g) == 0) {
+          const int h = (li + LPR * q) / pma_g;
+          const float lv = pma_l[row * pma_heads + h];
+          // empty target: never gathered; exp(a - FLT_MAX) = 0 (same convention as pma_bwd_stats_kernel, csrc/pma.hip)
+          const float M = lv > 0.f ? pma_m[row * pma_heads + h] + __logf(lv + 1e-16f) : 3.402823466e+38f;
+          *reinterpret_cast<float2*>(pma_stats + (row * pma_heads + h) * 2) = make_float2(M, dot);
+        }
       }
     }
   }
-  *reinterpret_cast<float4*>(&red[grp][0][c0]) = dg;
-  *reinterpret_cast<float4*>(&red[grp][1][c0]) = db;
-  *reinterpret_cast<float4*>(&red[grp][2][c0]) = dc;
+#pragma unroll
+  for (int q = 0; q < VPL; ++q) {
+    *reinterpret_cast<float4*>(&red[grp][0][(li + LPR * q) * 4]) = dg[q];
+    *reinterpret_cast<float4*>(&red[grp][1][(li + LPR * q) * 4]) = db[q];
+    *reinterpret_cast<float4*>(&red[grp][2][(li + LPR * q) * 4]) = dc[q];
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * LPR * 4; i += kBlock) {
-    const int which = i / (LPR * 4), c = i % (LPR * 4);
+  for (int i = threadIdx.x; i < 3 * W; i += kBlock) {
+    const int which = i / W, c = i % W;
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) s += red[g][which][c];
@@ -2055,7 +2101,7 @@ extern "C" int allset_reduce_partials_batched_ex2(const float* const* parts, con
 
 extern "C" int allset_reduce_partials_batch_max_counters(void) { return kRedBatchMaxCounters; }
 
-extern "C" int allset_ln_res_supported(int64_t d) { return (d >= 4 && d <= 256 && d % 4 == 0) ? 1 : 0; }
+extern "C" int allset_ln_res_supported(int64_t d) { return (d >= 4 && d <= 512 && d % 4 == 0) ? 1 : 0; }
 
 extern "C" int allset_ln_res_fwd(const float* x, int64_t ldx, const float* colb, const float* res, int64_t ldr,
                                  const float* gamma, const float* beta, float eps, int relu_out, float p, uint64_t seed,
@@ -2064,7 +2110,7 @@ extern "C" int allset_ln_res_fwd(const float* x, int64_t ldx, const float* colb,
   clear_error();
   ALLSET_REQUIRE(n >= 0 && d >= 1, "ln_res_fwd: bad size");
   ALLSET_REQUIRE(p >= 0.f && p < 1.f, "ln_res_fwd: dropout p must be in [0,1)");
-  if (!allset_ln_res_supported(d)) { set_error("ln_res_fwd: width %lld not built (d %% 4 == 0, d <= 256)", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
+  if (!allset_ln_res_supported(d)) { set_error("ln_res_fwd: width %lld not built (d %% 4 == 0, d <= 512)", static_cast<long long>(d)); return ALLSET_ERR_UNSUPPORTED; }
   if (n == 0) return ALLSET_OK;
   ALLSET_REQUIRE(x && gamma && beta && y && stats, "ln_res_fwd: null pointer");
   ALLSET_REQUIRE(ldx >= d && ldy >= d && (res == nullptr || ldr >= d), "ln_res_fwd: leading dimension smaller than d");
@@ -2073,14 +2119,15 @@ extern "C" int allset_ln_res_fwd(const float* x, int64_t ldx, const float* colb,
                  "ln_res_fwd: rows and parameter vectors must be 16-byte aligned");
   const hipStream_t st = static_cast<hipStream_t>(stream);
   const int di = static_cast<int>(d), lpr = ln_lpr(d);
-  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * kLnRowsPerGroup;
+  const int64_t rows_per_block = static_cast<int64_t>(kWavesPerBlock) * (kWave / lpr) * (d > 256 ? 2 : kLnRowsPerGroup);
   const unsigned grid = static_cast<unsigned>((n + rows_per_block - 1) / rows_per_block);
-#define ALLSET_LNRES_FWD(L) ln_res_fwd_kernel<L><<<grid, kBlock, 0, st>>>(x, ldx, colb, res, ldr, gamma, beta, eps, relu_out, p, seed, y, ldy, stats, n, di, seed_base)
-  switch (lpr) {
-    case 8: ALLSET_LNRES_FWD(8); break;
-    case 16: ALLSET_LNRES_FWD(16); break;
-    case 32: ALLSET_LNRES_FWD(32); break;
-    default: ALLSET_LNRES_FWD(64); break;
+#define ALLSET_LNRES_FWD(L, V) ln_res_fwd_kernel<L, V><<<grid, kBlock, 0, st>>>(x, ldx, colb, res, ldr, gamma, beta, eps, relu_out, p, seed, y, ldy, stats, n, di, seed_base)
+  if (d > 256) ALLSET_LNRES_FWD(64, 2);             // two 16-byte chunks per lane: 256 < d <= 512
+  else switch (lpr) {
+    case 8: ALLSET_LNRES_FWD(8, 1); break;
+    case 16: ALLSET_LNRES_FWD(16, 1); break;
+    case 32: ALLSET_LNRES_FWD(32, 1); break;
+    default: ALLSET_LNRES_FWD(64, 1); break;
   }
 #undef ALLSET_LNRES_FWD
   ALLSET_LAUNCH_CHECK();
@@ -2116,8 +2163,8 @@ extern "C" int allset_ln_res_bwd(const float* gy, int64_t ldg, const float* x, i
 
 extern "C" int allset_ln_res_bwd_pma_supported(int64_t d, int64_t heads) {
   if (!allset_ln_res_supported(d) || heads < 1 || d % heads != 0 || (d / heads) % 4 != 0) return 0;
-  const int64_t g = (d / heads) / 4;
-  return (g & (g - 1)) == 0 ? 1 : 0;
+  const int64_t g = (d / heads) / 4;                  // lanes per head: a power of two, inside one 64-lane chunk row
+  return ((g & (g - 1)) == 0 && g <= 64) ? 1 : 0;
 }
 
 extern "C" int allset_ln_res_bwd_pma(const float* gy, int64_t ldg, const float* x, int64_t ldx, const float* colb,
@@ -2158,12 +2205,13 @@ static int ln_res_bwd_impl(const float* gy, int64_t ldg, const float* x, int64_t
                  (res == nullptr || (ldr % 4 == 0 && aligned16(res))), "ln_res_bwd: rows and parameter vectors must be 16-byte aligned");
   const int di = static_cast<int>(d);
   const unsigned grid = static_cast<unsigned>(n_partials);
-#define ALLSET_LNRES_BWD(L) ln_res_bwd_kernel<L><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n, di, seed_base, pma_m, pma_l, pma_stats, static_cast<int>(pma_heads))
-  switch (ln_lpr(d)) {
-    case 8: ALLSET_LNRES_BWD(8); break;
-    case 16: ALLSET_LNRES_BWD(16); break;
-    case 32: ALLSET_LNRES_BWD(32); break;
-    default: ALLSET_LNRES_BWD(64); break;
+#define ALLSET_LNRES_BWD(L, V) ln_res_bwd_kernel<L, V><<<grid, kBlock, 0, st>>>(gy, ldg, x, ldx, colb, res, ldr, stats, gamma, beta, relu_out, p, seed, gs, ldgs, partials, n, di, seed_base, pma_m, pma_l, pma_stats, static_cast<int>(pma_heads))
+  if (d > 256) ALLSET_LNRES_BWD(64, 2);
+  else switch (ln_lpr(d)) {
+    case 8: ALLSET_LNRES_BWD(8, 1); break;
+    case 16: ALLSET_LNRES_BWD(16, 1); break;
+    case 32: ALLSET_LNRES_BWD(32, 1); break;
+    default: ALLSET_LNRES_BWD(64, 1); break;
   }
 #undef ALLSET_LNRES_BWD
   ALLSET_LAUNCH_CHECK();

@@ -354,7 +354,7 @@ int allset_ln_res_bwd_bf16(const void* gy, int64_t ldg, const void* x, int64_t l
  * relu -> dropout SetGNN puts behind every conv (models.py:475-481):
  *   y = dropout_{p,seed}( relu_out ? relu(.) : . )( LayerNorm_{gamma,beta,eps}( x + colb + res ) )
  * colb f32[d] (may be NULL: e.g. PMA's seed vector att_r) and res f32[n*ldr] (may be NULL: the residual branch) are added
- * in registers; stats f32[n*2] = {mean, rstd} of the sum.  Widths: allset_ln_res_supported(d) (d % 4 == 0, d <= 256).
+ * in registers; stats f32[n*2] = {mean, rstd} of the sum.  Widths: allset_ln_res_supported(d) (d % 4 == 0, d <= 512; two 16-byte chunks per lane above 256, ABI 14).
  * Backward: gs = d loss / d (x + colb + res) -- the gradient of x AND of res; partials f32[n_partials*3*d], row k holds
  * block k's (dgamma[d], dbeta[d], dcolb[d]); the caller sums over k.  The relu mask is recomputed from the statistics. */
 int allset_ln_res_supported(int64_t d);

@@ -780,7 +780,7 @@ def test_activation_mask_layout_and_use(N, device, monkeypatch):
     assert torch.equal(gw_y, gw_m) and torch.equal(gb_y, gb_m)
 
 
-@pytest.mark.parametrize("d", [128, 64, 100, 256])
+@pytest.mark.parametrize("d", [128, 64, 100, 256, 512, 320, 260])       # (above 256: two 16-byte chunks per lane, round 6)
 @pytest.mark.parametrize("with_colb,with_res,relu_out", [(True, False, False), (False, True, True), (True, True, True),
                                                           (False, False, False)])
 def test_layer_norm_res_fwd_bwd(d, with_colb, with_res, relu_out, device):
@@ -815,10 +815,11 @@ def test_layer_norm_res_fwd_bwd(d, with_colb, with_res, relu_out, device):
         torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=2e-4, atol=1e-4 * scale, msg=lambda m: f"{nm}: {m}")
 
 
-def test_layer_norm_res_dropout_mask_consistent(device):
+@pytest.mark.parametrize("d", [128, 512])
+def test_layer_norm_res_dropout_mask_consistent(d, device):
     """relu -> dropout behind the LayerNorm: Bernoulli(1-p) mask on the positive part, backward uses the same mask."""
     from allset_amd import dense
-    n, d, p = 3000, 128, 0.4
+    n, p = 3000, 0.4
     x = torch.randn(n, d, device=device)
     res = torch.randn(n, d, device=device)
     gamma, beta = torch.ones(d, device=device), torch.full((d,), 0.2, device=device)

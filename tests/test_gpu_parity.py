@@ -585,7 +585,7 @@ def test_pma_pooling_and_ln0_as_one_node_equals_the_separate_nodes_bf16(heads, h
                                    msg=lambda m: f"{k}: {m}")
 
 
-@pytest.mark.parametrize("heads,hidden", [(4, 128), (1, 64), (8, 256)])
+@pytest.mark.parametrize("heads,hidden", [(4, 128), (1, 64), (8, 256), (8, 512), (2, 512), (16, 512)])
 def test_pma_pooling_and_ln0_as_one_node_equals_the_separate_nodes(heads, hidden, device, monkeypatch):
     """The joint pooling + ln0 node (backward statistics written by ln0's backward kernel, allset_ln_res_bwd_pma) against
     the two separate nodes (allset_pma_bwd_stats): same outputs, same gradients, targets without incidences included."""
