@@ -64,6 +64,8 @@ for c in cora_ds_add citeseer_pma_h4; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sg_$c -- python tools/small_graph_kernels.py $c > /dev/null 2>&1
   S=$(find $OUT/prof_sg_$c -name '*kernel_stats.csv' | head -1); cp "$S" $OUT/${TAG}_small_graph_${c}_kernel_stats.csv; rm -rf $OUT/prof_sg_$c
 done
+rm -rf $OUT/prof_sg_t; MODEL_ARGS="MLP_hidden=512,heads=8" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sg_t -- python tools/small_graph_kernels.py citeseer_pma_h4 > /dev/null 2>&1
+S=$(find $OUT/prof_sg_t -name '*kernel_stats.csv' | head -1); cp "$S" $OUT/${TAG}_small_graph_citeseer_512x8_kernel_stats.csv; rm -rf $OUT/prof_sg_t
 timeout 600 python tools/tuned_config_step.py > $OUT/${TAG}_tuned_config_step.txt 2>&1; grep -v amdgpu $OUT/${TAG}_tuned_config_step.txt | tail -6
 timeout 300 python tools/graph_replay_probe.py >> $OUT/${TAG}_small_graph_step.txt 2>&1
 timeout 600 python bench.py --hip-graph --no-cpu-baseline > $OUT/${TAG}_graph_bench_line.json 2>/dev/null
