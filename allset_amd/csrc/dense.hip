@@ -1853,10 +1853,13 @@ extern "C" int allset_wgrad_slices(int64_t n, int64_t O, int64_t I, int64_t* n_s
   clear_error();
   ALLSET_REQUIRE(n_slices != nullptr && n >= 0 && O >= 1 && I >= 1, "wgrad_slices: bad argument");
   const int64_t tiles = ((O + kWgTile - 1) / kWgTile) * ((I + kWgTile - 1) / kWgTile);
-  // aim at ~512 workgroups in total (two 64-KiB-LDS workgroups per CU), at least 256 rows (8 stages) per slice;
-  // fewer slices also means fewer partial tiles for the caller to sum
+  // aim at ~512 workgroups in total (two 64-KiB-LDS workgroups per CU), at least 256 rows (8 stages) per slice; fewer slices also
+  // means fewer partial tiles for the caller to sum.  Where that leaves most of the chip idle (dataset scale: 3.3k rows of a 256 x 256
+  // weight are 52 workgroups) slices go down to 128 rows (round 6: the launch is one workgroup's chain of stages; measured on the
+  // tuned-width steps, -5 % at 256 x 256 -- at 512 x 512, already 208 workgroups, twice the partial tiles cost +4 %, so not there)
   int64_t s = 512 / tiles;
-  const int64_t max_by_rows = (n + 255) / 256;
+  int64_t max_by_rows = (n + 255) / 256;
+  if ((s < max_by_rows ? s : max_by_rows) * tiles < 128) max_by_rows = (n + 127) / 128;
   if (s > max_by_rows) s = max_by_rows;
   if (s < 1) s = 1;
   *n_slices = s;
