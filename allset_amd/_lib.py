@@ -156,6 +156,8 @@ SIGNATURES = {
                              _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_f16x3_plane_bytes": [c_int64, c_int64],
     "allset_gemm_f16x3_planes": [_P, c_int64, c_int, _P, c_int64, c_int64, _P],
+    "allset_gemm_f16x3_planes_batch_max": [],
+    "allset_gemm_f16x3_planes_batched": [_P, _P, _P, _P, _P, _P, c_int64, _P],
     "allset_gemm_f16x3": [_P, c_int64, _P, c_int64, c_float, c_int, _P, _P, _P, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                           _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_f16x3_lnb": [_P, c_int64, _P, c_int64, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64, _P,

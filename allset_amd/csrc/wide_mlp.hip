@@ -69,10 +69,8 @@ __global__ __launch_bounds__(kBlock) void gemm_x6_planes_kernel(const float* __r
 // ONE launch (round 6, second session: at dataset scale a step rebuilds ten plane images -- W and W^T of five wide Linears -- and the
 // former pair of launches per image, scales then planes, was 107 us of a 1-ms step): a wave owns output row n, finds its largest
 // element, then reads the row again (out of L1 / L2) and writes the scaled planes.
-__global__ __launch_bounds__(kBlock) void gemm_f16_planes_fused_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
-                                                                       uint32_t* __restrict__ planes, float* __restrict__ bscale,
-                                                                       int N, int n_pad, int K) {
-  const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void gemm_f16_planes_row(const float* __restrict__ W, int64_t ldw, int transpose, uint32_t* __restrict__ planes,
+                                                    float* __restrict__ bscale, int N, int n_pad, int K, int n, int lane) {
   if (n >= n_pad) return;
   float amax = 0.f;
   if (n < N)
@@ -97,6 +95,32 @@ __global__ __launch_bounds__(kBlock) void gemm_f16_planes_fused_kernel(const flo
     planes[image + gx_image_at<4>(at)] = ph;
     planes[image + gx_image_at<4>(at + kGxBN * kGxKS / 2)] = pl;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void gemm_f16_planes_fused_kernel(const float* __restrict__ W, int64_t ldw, int transpose,
+                                                                       uint32_t* __restrict__ planes, float* __restrict__ bscale,
+                                                                       int N, int n_pad, int K) {
+  gemm_f16_planes_row(W, ldw, transpose, planes, bscale, N, n_pad, K, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// ... and the plane images of MANY weights in one launch (ABI 14): a dataset-scale training step at the reference's tuned widths
+// rebuilds ten of them -- W and W^T of five wide Linears -- each a ~5-us launch in front of its GEMM on the step's dependent chain; all
+// weights are known when the step starts.  Each workgroup finds its weight by a scan of the table's block offsets.
+constexpr int kPlaneBatchMax = 32;
+struct PlaneBatchTable {
+  const float* W[kPlaneBatchMax];
+  uint32_t* planes[kPlaneBatchMax];
+  int32_t ldw[kPlaneBatchMax], N[kPlaneBatchMax], n_pad[kPlaneBatchMax], K[kPlaneBatchMax], transpose[kPlaneBatchMax];
+  int32_t first_block[kPlaneBatchMax + 1];
+  int32_t count;
+};
+__global__ __launch_bounds__(kBlock) void gemm_f16_planes_batched_kernel(PlaneBatchTable tb) {
+  const int b = blockIdx.x;
+  int t = 0;
+  while (t + 1 < tb.count && tb.first_block[t + 1] <= b) ++t;
+  float* bscale = reinterpret_cast<float*>(reinterpret_cast<char*>(tb.planes[t]) + static_cast<int64_t>(tb.n_pad[t]) * tb.K[t] * 2 * 2);
+  gemm_f16_planes_row(tb.W[t], tb.ldw[t], tb.transpose[t], tb.planes[t], bscale, tb.N[t], tb.n_pad[t], tb.K[t],
+                      (b - tb.first_block[t]) * (kBlock / 64) + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 struct GxPro {
@@ -1343,6 +1367,36 @@ extern "C" int allset_gemm_f16x3_planes(const float* W, int64_t ldw, int transpo
   const hipStream_t st = static_cast<hipStream_t>(stream);
   gemm_f16_planes_fused_kernel<<<static_cast<unsigned>((n_pad + kBlock / 64 - 1) / (kBlock / 64)), kBlock, 0, st>>>(
       W, ldw, transpose, static_cast<uint32_t*>(planes), bscale, static_cast<int>(N), static_cast<int>(n_pad), static_cast<int>(K));
+  ALLSET_LAUNCH_CHECK();
+  return ALLSET_OK;
+}
+
+extern "C" int allset_gemm_f16x3_planes_batch_max(void) { return kPlaneBatchMax; }
+
+// planes[k] = allset_gemm_f16x3_planes(Ws[k], ldws[k], transposes[k], ., Ns[k], Ks[k]) for k < count <= allset_gemm_f16x3_planes_batch_max(),
+// in ONE launch (host arrays, copied into the kernel's arguments); bit-identical images.
+extern "C" int allset_gemm_f16x3_planes_batched(const float* const* Ws, const int64_t* ldws, const int32_t* transposes, void* const* planes,
+                                                const int64_t* Ns, const int64_t* Ks, int64_t count, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(count >= 0 && count <= kPlaneBatchMax, "gemm_f16x3_planes_batched: at most %d weights per call", kPlaneBatchMax);
+  if (count == 0) return ALLSET_OK;
+  ALLSET_REQUIRE(Ws && ldws && transposes && planes && Ns && Ks, "gemm_f16x3_planes_batched: null pointer");
+  PlaneBatchTable tb;
+  int64_t blocks = 0;
+  for (int64_t k = 0; k < count; ++k) {
+    if (!allset_gemm_x6_supported(Ns[k], Ks[k])) { set_error("gemm_f16x3_planes_batched: weight %lld: N=%lld K=%lld not supported", (long long)k, (long long)Ns[k], (long long)Ks[k]); return ALLSET_ERR_UNSUPPORTED; }
+    ALLSET_REQUIRE(Ws[k] && planes[k] && aligned16(planes[k]) && ldws[k] >= (transposes[k] ? Ns[k] : Ks[k]) && ldws[k] < INT32_MAX,
+                   "gemm_f16x3_planes_batched: weight %lld: null / misaligned pointer or leading dimension too small", static_cast<long long>(k));
+    const int64_t n_pad = (Ns[k] + kGxBN - 1) / kGxBN * kGxBN;
+    tb.W[k] = Ws[k]; tb.planes[k] = static_cast<uint32_t*>(planes[k]);
+    tb.ldw[k] = static_cast<int32_t>(ldws[k]); tb.N[k] = static_cast<int32_t>(Ns[k]); tb.n_pad[k] = static_cast<int32_t>(n_pad);
+    tb.K[k] = static_cast<int32_t>(Ks[k]); tb.transpose[k] = transposes[k] ? 1 : 0;
+    tb.first_block[k] = static_cast<int32_t>(blocks);
+    blocks += (n_pad + kBlock / 64 - 1) / (kBlock / 64);
+  }
+  tb.first_block[count] = static_cast<int32_t>(blocks);
+  tb.count = static_cast<int32_t>(count);
+  gemm_f16_planes_batched_kernel<<<static_cast<unsigned>(blocks), kBlock, 0, static_cast<hipStream_t>(stream)>>>(tb);
   ALLSET_LAUNCH_CHECK();
   return ALLSET_OK;
 }

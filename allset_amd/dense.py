@@ -449,6 +449,63 @@ class _Planes:
         self.buf, self.f16 = buf, f16
 
 
+# ---- the plane images of a whole step, built by ONE launch ------------------------------------------------------------------------
+# A training step at the reference's tuned widths (MLP_hidden 256 / 512) rebuilds the fp16 plane images of W (forward) and W^T
+# (backward-data) of every wide Linear -- weights change every step -- each a ~5-us launch in front of its GEMM.  All weights are known
+# when the forward starts: `prefetch_wide_planes` builds every image a model will ask for in one batched launch and
+# `gemm_x6_planes` serves them.  An entry is keyed by the weight's storage, shape, version and the weight epoch (bumped by every
+# optimizer step that writes parameters behind torch's back: allset_amd.optim.FusedAdam), consumed ONCE, and dropped by the next prefetch.
+class _PlaneStore:
+    entries: dict = {}
+    epoch = 0
+
+
+def weights_changed() -> None:
+    """Parameters were updated in place by something torch's version counters do not see (a raw-pointer optimizer kernel)."""
+    _PlaneStore.epoch += 1
+    _PlaneStore.entries = {}
+
+
+def _plane_key(W: Tensor, transpose: bool):
+    return (W.data_ptr(), tuple(W.shape), W.stride(0), W._version, _PlaneStore.epoch, bool(transpose))
+
+
+def prefetch_wide_planes(weights, with_transposed: bool) -> None:
+    """``weights``: fp32 [out, in] weight tensors of Linears on the tiled wide path; builds planes(W) -- and planes(W^T) when a backward
+    will follow -- of all of them with one launch (fp16-plane arithmetic only; anything it does not take is built on demand as before)."""
+    _PlaneStore.entries = {}
+    if not weights or not wide_f16():
+        return
+    import ctypes
+    lib = _lib.load()
+    cap = int(lib.allset_gemm_f16x3_planes_batch_max())
+    todo = []
+    for W in weights:
+        if not (W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and W.stride(1) == 1 and W.data_ptr() % 16 == 0):
+            continue
+        for tr in ((False, True) if with_transposed else (False,)):
+            N, K = (W.shape[1], W.shape[0]) if tr else (W.shape[0], W.shape[1])
+            nbytes = int(lib.allset_gemm_f16x3_plane_bytes(N, K))
+            if nbytes > 0:
+                todo.append((W, tr, N, K, nbytes))
+    if not todo:
+        return
+    dev = todo[0][0].device
+    todo = [t for t in todo if t[0].device == dev]
+    for k0 in range(0, len(todo), cap):
+        chunk = todo[k0:k0 + cap]
+        bufs = [torch.empty(t[4], dtype=torch.uint8, device=dev) for t in chunk]
+        n = len(chunk)
+        with on_device(dev):
+            check(lib.allset_gemm_f16x3_planes_batched(
+                (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in chunk]), (ctypes.c_int64 * n)(*[t[0].stride(0) for t in chunk]),
+                (ctypes.c_int32 * n)(*[int(t[1]) for t in chunk]), (ctypes.c_void_p * n)(*[b.data_ptr() for b in bufs]),
+                (ctypes.c_int64 * n)(*[t[2] for t in chunk]), (ctypes.c_int64 * n)(*[t[3] for t in chunk]), n, stream_of(dev)),
+                "allset_gemm_f16x3_planes_batched")
+        for t, b in zip(chunk, bufs):
+            _PlaneStore.entries[_plane_key(t[0], t[1])] = _Planes(b, True)
+
+
 def gemm_x6_planes(W: Tensor, transpose: bool, f16: Optional[bool] = None) -> "_Planes":
     """Pre-split planes of ``B`` for :func:`gemm_x6`: ``B = W`` ([N, K]) or, with ``transpose``, ``B = W^T`` (``W`` [K, N]) --
     three bf16 planes (exact split), or two fp16 planes + per-column scales (``f16``; default: the process-wide arithmetic)."""
@@ -456,6 +513,10 @@ def gemm_x6_planes(W: Tensor, transpose: bool, f16: Optional[bool] = None) -> "_
     _check_f32(W)
     W = _rowmajor(W)
     f16 = wide_f16() if f16 is None else bool(f16)            # (callers that know their prologue pass f16 themselves)
+    if f16 and _PlaneStore.entries:
+        hit = _PlaneStore.entries.pop(_plane_key(W, transpose), None)       # built by this step's prefetch launch; used once
+        if hit is not None:
+            return hit
     N, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
     lib = _lib.load()
     nbytes = int((lib.allset_gemm_f16x3_plane_bytes if f16 else lib.allset_gemm_x6_plane_bytes)(N, K))

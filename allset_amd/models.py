@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import Linear, Parameter
 
+from . import dense
 from .incidence import Incidence
 from .layers import MLP, HalfNLHconv, relu_dropout
 
@@ -142,6 +143,23 @@ class SetGNN(nn.Module):
         self._inc_cache[key] = (weakref.ref(edge_index), (v2e, e2v))
         return v2e, e2v
 
+    def _prefetch_planes(self, x: torch.Tensor) -> None:
+        """At dataset scale every launch is a link of the step's dependent chain: the fp16 plane images of all wide (256 / 512-wide)
+        Linears of the convs -- W for the forward, W^T too when a backward will follow -- in one launch up front (dense.prefetch_wide_planes;
+        at benchmark scale the ten 5-us launches do not matter and the images are built where they are used)."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= 65536):
+            return
+        ws = getattr(self, "_wide_weights", None)
+        if ws is None:
+            ws = []
+            for conv in list(self.V2EConvs) + list(self.E2VConvs):
+                for m in conv.modules():
+                    if isinstance(m, nn.Linear) and dense.wide_linear_supported(m.in_features, m.out_features, False):
+                        ws.append(m.weight)
+            self._wide_weights = ws
+        if ws:
+            dense.prefetch_wide_planes(ws, with_transposed=torch.is_grad_enabled() and any(w.requires_grad for w in ws))
+
     def forward(self, data):
         """``data.x`` [n_V, F] float32, ``data.edge_index`` int64 [2, nnz] (row 0 vertex ids, row 1
         hyperedge ids), ``data.norm`` [nnz] per-incidence weights.  Returns vertex logits."""
@@ -163,6 +181,7 @@ class SetGNN(nn.Module):
             # which the library runs as a strided-batched GEMM with K = L+1 -- 19 SECONDS per step at n = 1M, d = 128
             # (tools/model_step_profile.py with MODEL_ARGS=All_num_layers=2,GPR=1); same arithmetic, same parameter.
             return self.classifier(_WeightedSum.apply(self.GPRweights.weight, *xs))
+        self._prefetch_planes(x)
         # hard-coded input dropout (models.py:473); on raw features without gradient it rides in the first conv's first kernel
         pre = 0.2 if (self.training and len(self.V2EConvs) and self.V2EConvs[0].takes_pre_dropout(x)) else 0.0
         if not pre:

@@ -68,6 +68,8 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         cap = int(lib.allset_adam_max_tensors())
+        from . import dense
+        dense.weights_changed()      # (the kernel writes parameters through raw pointers: no version counter moves -- drop prebuilt plane images)
         for group in self.param_groups:
             b1, b2 = group["betas"]
             live = [p for p in group["params"] if p.grad is not None]

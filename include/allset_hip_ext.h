@@ -259,6 +259,12 @@ int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, int64_t ldy
  * allset_gemm_x6_lnb / allset_gemm_x6_planes (`planes` from allset_gemm_f16x3_planes). */
 int64_t allset_gemm_f16x3_plane_bytes(int64_t N, int64_t K);
 int allset_gemm_f16x3_planes(const float* W, int64_t ldw, int transpose, void* planes, int64_t N, int64_t K, void* stream);
+/* ABI 14.  The plane images of MANY weights in ONE launch (a dataset-scale training step at 256 / 512-wide layers rebuilds W and W^T of
+ * every wide Linear, each a ~5-us launch on the step's dependent chain): planes[k] as allset_gemm_f16x3_planes would write it, k < count <=
+ * allset_gemm_f16x3_planes_batch_max().  The arrays are HOST arrays. */
+int allset_gemm_f16x3_planes_batch_max(void);
+int allset_gemm_f16x3_planes_batched(const float* const* Ws, const int64_t* ldws, const int32_t* transposes, void* const* planes,
+                                     const int64_t* Ns, const int64_t* Ks, int64_t count, void* stream);
 int allset_gemm_f16x3_lnb(const float* G, int64_t ldg, const float* mask_y, int64_t ldy, float p_mask, const void* planes,
                           const float* x, int64_t ldx, const float* stats, const float* gamma, int relu_in, float p, uint64_t seed,
                           float* gx, int64_t ldgx, float* partials, int64_t n_partials, int64_t rows, int64_t N, int64_t K,

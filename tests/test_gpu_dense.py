@@ -1827,3 +1827,32 @@ def test_wide_forward_writes_the_next_layers_row_statistics(n, arith, device):
         torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-4 * float(g0.abs().max()))
         for a, c in zip(p1, p0):
             torch.testing.assert_close(a, c, rtol=1e-4, atol=1e-4 * float(c.abs().max()))
+
+
+def test_prefetched_plane_images_equal_the_on_demand_ones_and_are_never_stale(device):
+    """``dense.prefetch_wide_planes`` (one launch for the fp16 plane images of W and W^T of every wide Linear of a step) hands
+    ``gemm_x6_planes`` bit-identical images, each exactly once; an in-place update of a weight (torch's version counter) or
+    ``dense.weights_changed()`` (what ``FusedAdam.step`` calls: its kernel writes through raw pointers) makes the next request rebuild."""
+    from allset_amd import dense
+    g = torch.Generator().manual_seed(4)
+    ws = [torch.randn(256, 256, generator=g).to(device), torch.randn(512, 256, generator=g).to(device),
+          (torch.randn(512, 512, generator=g) * 1e-3).to(device)]
+    with dense.arithmetic("auto"):
+        ref = {(i, tr): dense.gemm_x6_planes(w, tr).buf.clone() for i, w in enumerate(ws) for tr in (False, True)}
+        dense.prefetch_wide_planes(ws, with_transposed=True)
+        assert len(dense._PlaneStore.entries) == 6
+        for i, w in enumerate(ws):
+            for tr in (False, True):
+                got = dense.gemm_x6_planes(w, tr)
+                assert got.f16 and torch.equal(got.buf, ref[(i, tr)])
+        assert not dense._PlaneStore.entries                       # consumed once
+        dense.prefetch_wide_planes(ws, with_transposed=False)
+        assert len(dense._PlaneStore.entries) == 3
+        ws[0].mul_(2.0)                                            # version bump: the prebuilt image of ws[0] must not be served
+        fresh = dense.gemm_x6_planes(ws[0], False)
+        assert not torch.equal(fresh.buf, ref[(0, False)]) and len(dense._PlaneStore.entries) == 3
+        dense.weights_changed()
+        assert not dense._PlaneStore.entries
+        with dense.arithmetic("strict"):
+            dense.prefetch_wide_planes(ws, with_transposed=True)   # the exact-split arithmetic builds its bf16 planes where they are used
+            assert not dense._PlaneStore.entries

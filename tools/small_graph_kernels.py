@@ -14,6 +14,10 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cora_ds_add"
 dev = torch.device("cuda:0")
 case = cases.build_case(name)
 # MODEL_ARGS="MLP_hidden=512,heads=8": the reference's tuned widths on the same stand-in data (run_AllSetTransformer.sh)
+if os.environ.get("MODEL_FROM"):      # MODEL_FROM=citeseer_pma_h4: that case's model arguments on THIS case's data (an AllSetTransformer on the Cora-shaped features)
+    src = cases.build_case(os.environ["MODEL_FROM"])["args"]
+    src.num_features, src.num_classes = case["args"].num_features, case["args"].num_classes
+    case["args"] = src
 for kv in filter(None, os.environ.get("MODEL_ARGS", "").split(",")):
     k, v = kv.split("=")
     setattr(case["args"], k, type(getattr(case["args"], k))(v))
