@@ -2146,7 +2146,11 @@ extern "C" int allset_ln_res_bwd_partials(int64_t n, int64_t d, int64_t* n_parti
   // persistent grid: 78 VGPRs = 6 waves per SIMD = 6 workgroups of 4 waves per CU -> 1536 resident workgroups; with 2048 the last
   // quarter runs as a second, third-full round (0.315 -> see profiles/r02_ln_res_bench.txt)
   const int64_t cap = 1536;
-  *n_partials = want < 1 ? 1 : (want > cap ? cap : want);
+  int64_t np = want < 1 ? 1 : (want > cap ? cap : want);
+  // a grid that one launch fills anyway (<= 1536 workgroups) keeps at most 512 partial rows: what the batched reduction of a
+  // backward pass takes (allset_reduce_partials_batchable) -- at dataset scale these four reductions are launches of their own otherwise
+  if (np > 512 && want <= cap) np = 512;
+  *n_partials = np;
   return ALLSET_OK;
 }
 

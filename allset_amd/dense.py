@@ -1339,10 +1339,11 @@ def ln_res_fwd(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gamma: 
 
 
 def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], stats: Tensor, gamma: Tensor,
-               beta: Tensor, relu_out: bool, p: float, seed: int, seed_base: Optional[Tensor] = None
+               beta: Tensor, relu_out: bool, p: float, seed: int, seed_base: Optional[Tensor] = None, defer_to=None
                ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """(gs, dgamma, dbeta, dcolb); gs is the gradient of x and of res.  bf16 activations: the three parameter
-    gradients are accumulated in fp32 and cast back."""
+    gradients are accumulated in fp32 and cast back.  ``defer_to`` = the (gamma, beta, colb-or-None) PARAMETERS (fp32): inside
+    ``deferred_param_grads()`` their gradients are queued and come back as None."""
     dev = require_device(gy, x, colb, res, stats, gamma, beta)
     bf16 = x.dtype == torch.bfloat16
     if bf16:
@@ -1363,6 +1364,11 @@ def ln_res_bwd(gy: Tensor, x: Tensor, colb: Optional[Tensor], res: Optional[Tens
         check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous() if colb is not None else None), ptr(res),
                  _ld(res) if res is not None else 0, ptr(stats), ptr(gamma.contiguous()), ptr(beta.contiguous()), int(relu_out), p,
                  seed, ptr(gs), max(d, 1), ptr(partials), npart.value, n, d, ptr(seed_base), stream_of(dev)), name)
+    if not bf16 and defer_to is not None:
+        dg_, db_, dc_ = _defer_or_reduce(partials, [(defer_to[0], 0, (d,)), (defer_to[1], d, (d,)),
+                                                    (defer_to[2] if colb is not None else None, 2 * d,
+                                                     tuple(defer_to[2].shape) if (colb is not None and defer_to[2] is not None) else (d,))], True)
+        return gs, dg_, db_, dc_
     if bf16 and (3 * d) % 4 == 0 and npart.value <= 4096:
         red = reduce_partials_to(partials.view(npart.value, 3 * d), 3 * d, torch.bfloat16).view(3, d)   # summed and rounded in one launch
     else:
@@ -1378,8 +1384,8 @@ def ln_res_bwd_pma_supported(d: int, heads: int, dtype: torch.dtype = torch.floa
     return dtype == torch.float32 and bool(_lib.load().allset_ln_res_bwd_pma_supported(d, heads))
 
 
-def ln_res_bwd_pma(gy: Tensor, x: Tensor, colb: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, m: Tensor, l: Tensor
-                   ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+def ln_res_bwd_pma(gy: Tensor, x: Tensor, colb: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor, m: Tensor, l: Tensor,
+                   defer_to=None) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """Backward of ``LayerNorm(x + colb)`` where ``x`` is PMA's pooled output, with the attention-backward statistics written by
     the same pass: returns (gs, dgamma, dbeta, dcolb, pma_stats [n, H, 2]) -- include/allset_hip.h allset_ln_res_bwd_pma.
     fp32, or bf16 activations and parameters (fp32 statistics)."""
@@ -1408,6 +1414,10 @@ def ln_res_bwd_pma(gy: Tensor, x: Tensor, colb: Tensor, stats: Tensor, gamma: Te
         check(fn(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(colb.contiguous()), ptr(stats), ptr(gamma.contiguous()),
                  ptr(beta.contiguous()), ptr(gs), max(d, 1), ptr(partials), npart.value, n, d,
                  ptr(m.contiguous()), ptr(l.contiguous()), ptr(pstats), H, stream_of(dev)), name)
+    if not bf16 and defer_to is not None:        # (gamma, beta, att_r) PARAMETERS: queued inside deferred_param_grads()
+        dg_, db_, dc_ = _defer_or_reduce(partials, [(defer_to[0], 0, (d,)), (defer_to[1], d, (d,)),
+                                                    (defer_to[2], 2 * d, tuple(defer_to[2].shape) if defer_to[2] is not None else (d,))], True)
+        return gs, dg_, db_, dc_, pstats
     if bf16 and (3 * d) % 4 == 0 and npart.value <= 4096:
         red = reduce_partials_to(partials.view(npart.value, 3 * d), 3 * d, torch.bfloat16).view(3, d)
     else:
@@ -1428,6 +1438,7 @@ class _LayerNormRes(torch.autograd.Function):
         y, stats = ln_res_fwd(x, cb, res, gamma, beta, eps, relu_out, p, seed, base)
         ctx.save_for_backward(x, cb, res, stats, gamma, beta)
         ctx.cfg = (bool(relu_out), float(p), seed, base, colb.shape if colb is not None else None)
+        ctx.params = (gamma, beta, colb)
         return y
 
     @staticmethod
@@ -1435,8 +1446,12 @@ class _LayerNormRes(torch.autograd.Function):
     def backward(ctx, gy):
         x, cb, res, stats, gamma, beta = ctx.saved_tensors
         relu_out, p, seed, base, cshape = ctx.cfg
-        gs, dg, db, dc = ln_res_bwd(gy.contiguous(), x, cb, res, stats, gamma, beta, relu_out, p, seed, base)
-        return gs, (dc.reshape(cshape) if cshape is not None else None), (gs if res is not None else None), dg, db, None, None, None
+        need = ctx.needs_input_grad
+        dfr = _Deferred.active and need[3] and need[4] and (cshape is None or need[1]) and x.dtype == torch.float32
+        gs, dg, db, dc = ln_res_bwd(gy.contiguous(), x, cb, res, stats, gamma, beta, relu_out, p, seed, base,
+                                    defer_to=ctx.params if dfr else None)
+        return (gs, (dc.reshape(cshape) if (cshape is not None and dc is not None) else None), (gs if res is not None else None), dg, db,
+                None, None, None)
 
 
 def layer_norm_res(x: Tensor, colb: Optional[Tensor], res: Optional[Tensor], gamma: Tensor, beta: Tensor,
@@ -1524,6 +1539,7 @@ class _PmaResidualFF(torch.autograd.Function):
         y, stats = ln_res_fwd(out, None, z, gamma, beta, eps, relu_post, p, seed, base)
         ctx.save_for_backward(out, y1, z, mask, stats, w1, w2, gamma, beta)
         ctx.cfg = (bool(relu_post), float(p), seed, base, b1 is not None, b2 is not None)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -1531,7 +1547,11 @@ class _PmaResidualFF(torch.autograd.Function):
     def backward(ctx, gy):
         out, y1, z, mask, stats, w1, w2, gamma, beta = ctx.saved_tensors
         relu_post, p, seed, base, has_b1, has_b2 = ctx.cfg
-        gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base)
+        need = ctx.needs_input_grad
+        prm = getattr(ctx, "params", None)
+        dfr = _Deferred.active and prm is not None and need[5] and need[6] and out.dtype == torch.float32
+        gs, dg, db, _ = ln_res_bwd(gy.contiguous(), out, None, z, stats, gamma, beta, relu_post, p, seed, base,
+                                   defer_to=(prm[0], prm[1], None) if dfr else None)
         zy = None if mask is not None else z
         if mask is not None and gs.shape[0] > 0 and one_pass_preferred(w2.shape[0], w2.shape[1]) and one_pass_preferred(w1.shape[0], w1.shape[1]):
             # round 3: the split-role one-pass kernel covers both Linears (relu prologue + mask; plain + acc_in): two launches

@@ -245,6 +245,7 @@ class _PmaPoolLn0(torch.autograd.Function):
         cb = att_r.reshape(-1)
         y, stats = dense.ln_res_fwd(pooled, cb, None, gamma, beta, eps, False, 0.0, 0, None)
         ctx.inc, ctx.slope, ctx.cshape = inc, slope, att_r.shape
+        ctx.params = (gamma, beta, att_r)           # (the objects themselves: dense.deferred_param_grads assigns their .grad)
         ctx.save_for_backward(V, alpha, pooled, m, l, cb, stats, gamma, beta)
         ctx.mark_non_differentiable(m, l)
         ctx.set_materialize_grads(False)     # (m, l never carry a gradient: no [n, H] zero-fills for them in every backward)
@@ -257,13 +258,16 @@ class _PmaPoolLn0(torch.autograd.Function):
         if gy is None:
             return (None,) * 9
         V, alpha, pooled, m, l, cb, stats, gamma, beta = ctx.saved_tensors
-        g_pooled, dg, db, dc, pstats = dense.ln_res_bwd_pma(gy.contiguous(), pooled, cb, stats, gamma, beta, m, l)
+        need = ctx.needs_input_grad
+        dfr = dense._Deferred.active and need[5] and need[6] and need[7] and pooled.dtype == torch.float32
+        g_pooled, dg, db, dc, pstats = dense.ln_res_bwd_pma(gy.contiguous(), pooled, cb, stats, gamma, beta, m, l,
+                                                            defer_to=ctx.params if dfr else None)
         T = ctx.inc.by_src
         H = alpha.shape[1]
         gV, galpha = ops.pma_bwd_src(T.rowptr, T.col, alpha, V, g_pooled, pstats, ctx.slope,
                                      variant=_variant(T, "pma_bwd_src", V.shape[0], V, H), row_order=T.row_order,
                                      split=_split(T, V, H), sizes=_sizes(T, V, H))
-        return gV, galpha, None, None, None, dc.reshape(ctx.cshape), dg, db, None
+        return gV, galpha, None, None, None, (dc.reshape(ctx.cshape) if dc is not None else None), dg, db, None
 
 
 class _PmaPoolTail(torch.autograd.Function):
