@@ -503,7 +503,9 @@ def prefetch_wide_planes(weights, with_transposed: bool) -> None:
                 (ctypes.c_int64 * n)(*[t[2] for t in chunk]), (ctypes.c_int64 * n)(*[t[3] for t in chunk]), n, stream_of(dev)),
                 "allset_gemm_f16x3_planes_batched")
         for t, b in zip(chunk, bufs):
-            _PlaneStore.entries[_plane_key(t[0], t[1])] = _Planes(b, True)
+            # the entry keeps the weight tensor ALIVE: while an image waits here its key (an address) cannot come to mean another tensor
+            # (a dead model's weight freed, a new model's weight of the same shape allocated in its place, version 0 again)
+            _PlaneStore.entries[_plane_key(t[0], t[1])] = (_Planes(b, True), t[0])
 
 
 def gemm_x6_planes(W: Tensor, transpose: bool, f16: Optional[bool] = None) -> "_Planes":
@@ -516,7 +518,7 @@ def gemm_x6_planes(W: Tensor, transpose: bool, f16: Optional[bool] = None) -> "_
     if f16 and _PlaneStore.entries:
         hit = _PlaneStore.entries.pop(_plane_key(W, transpose), None)       # built by this step's prefetch launch; used once
         if hit is not None:
-            return hit
+            return hit[0]
     N, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
     lib = _lib.load()
     nbytes = int((lib.allset_gemm_f16x3_plane_bytes if f16 else lib.allset_gemm_x6_plane_bytes)(N, K))

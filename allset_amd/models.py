@@ -157,8 +157,8 @@ class SetGNN(nn.Module):
                     if isinstance(m, nn.Linear) and dense.wide_linear_supported(m.in_features, m.out_features, False):
                         ws.append(m.weight)
             self._wide_weights = ws
-        if ws:
-            dense.prefetch_wide_planes(ws, with_transposed=torch.is_grad_enabled() and any(w.requires_grad for w in ws))
+        # (always: an empty list drops whatever an earlier forward left unconsumed)
+        dense.prefetch_wide_planes(ws, with_transposed=torch.is_grad_enabled() and any(w.requires_grad for w in ws))
 
     def forward(self, data):
         """``data.x`` [n_V, F] float32, ``data.edge_index`` int64 [2, nnz] (row 0 vertex ids, row 1
@@ -167,6 +167,7 @@ class SetGNN(nn.Module):
         if self.LearnMask:
             norm = self.Importance * norm
         v2e, e2v = self._incidences(edge_index, x.shape[0])
+        self._prefetch_planes(x)
         if self.GPR:
             xs = [F.relu(self.MLP(x))]
             for i in range(len(self.V2EConvs)):
@@ -181,7 +182,6 @@ class SetGNN(nn.Module):
             # which the library runs as a strided-batched GEMM with K = L+1 -- 19 SECONDS per step at n = 1M, d = 128
             # (tools/model_step_profile.py with MODEL_ARGS=All_num_layers=2,GPR=1); same arithmetic, same parameter.
             return self.classifier(_WeightedSum.apply(self.GPRweights.weight, *xs))
-        self._prefetch_planes(x)
         # hard-coded input dropout (models.py:473); on raw features without gradient it rides in the first conv's first kernel
         pre = 0.2 if (self.training and len(self.V2EConvs) and self.V2EConvs[0].takes_pre_dropout(x)) else 0.0
         if not pre:

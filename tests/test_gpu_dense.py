@@ -1853,6 +1853,17 @@ def test_prefetched_plane_images_equal_the_on_demand_ones_and_are_never_stale(de
         assert not torch.equal(fresh.buf, ref[(0, False)]) and len(dense._PlaneStore.entries) == 3
         dense.weights_changed()
         assert not dense._PlaneStore.entries
+        # an image left unconsumed must never be served for ANOTHER tensor that comes to live at the same address (a dead model's
+        # weight freed, a new model's allocated in its place: the hypothesis sweep of test_gpu_random_shapes.py found exactly that)
+        w_old = torch.randn(256, 256, generator=g).to(device)
+        dense.prefetch_wide_planes([w_old], with_transposed=False)
+        addr = w_old.data_ptr()
+        del w_old
+        w_new = torch.randn(256, 256, generator=g).to(device)             # (the store keeps w_old alive, so this is another block ...)
+        assert w_new.data_ptr() != addr
+        assert torch.equal(dense.gemm_x6_planes(w_new, False).buf, dense.gemm_x6_planes(w_new, False, f16=True).buf)
+        dense.prefetch_wide_planes([], with_transposed=False)             # (... until the next prefetch drops it)
+        assert not dense._PlaneStore.entries
         with dense.arithmetic("strict"):
             dense.prefetch_wide_planes(ws, with_transposed=True)   # the exact-split arithmetic builds its bf16 planes where they are used
             assert not dense._PlaneStore.entries
