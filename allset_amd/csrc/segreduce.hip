@@ -20,6 +20,14 @@ namespace allset {
 
 enum { kModeSum = 0, kModeExt = 1 };
 constexpr int kUnroll = 8;
+// gather batches of the one-wave-per-row kernel when a row takes the whole wave (NS = 1: d = 256 f32 / 512 bf16 and wider);
+// tools/segreduce_ablation.py rebuilds with other values
+#ifndef ALLSET_SEG_UNROLL_ONE_SLOT
+#define ALLSET_SEG_UNROLL_ONE_SLOT 8
+#endif
+#ifndef ALLSET_SEG_MAX_LPR
+#define ALLSET_SEG_MAX_LPR 64
+#endif
 constexpr int kBwdUnroll = 4;      // segmax_bwd: incidences per slot in flight (two 16-byte loads each)
 
 template <typename T, int VEC, int LPR, int MODE, bool WEIGHTED>
@@ -28,6 +36,7 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
     const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo,
     int32_t* __restrict__ argext, int n_t, int d, int mean, float sign, const int32_t* __restrict__ row_order) {
   constexpr int NS = kWave / LPR;
+  constexpr int U = NS == 1 ? ALLSET_SEG_UNROLL_ONE_SLOT : kUnroll;
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int slot_row = static_cast<int>(blk) * kWavesPerBlock + (threadIdx.x >> 6);
   if (slot_row >= n_t) return;  // whole wave exits together
@@ -54,12 +63,12 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
         my_col = col[base + lane];
         if constexpr (WEIGHTED) my_w = w[base + lane];
       }
-      for (int j = 0; j < n; j += NS * kUnroll) {
-        Raw<T, VEC> raw[kUnroll];        // kept packed while in flight (16 B per lane and load)
-        float ww[kUnroll];
-        bool ok[kUnroll];
+      for (int j = 0; j < n; j += NS * U) {
+        Raw<T, VEC> raw[U];        // kept packed while in flight (16 B per lane and load)
+        float ww[U];
+        bool ok[U];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int jj = j + u * NS + slot;
           ok[u] = (jj < n) && active;
           const int src = __shfl(my_col, jj & (kWave - 1));
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void segreduce_kernel(
           else raw[u] = zero_raw<T, VEC>();
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
           const FVec<VEC> v = unpack<T, VEC>(raw[u]);
           if constexpr (MODE == kModeSum) {
 #pragma unroll
@@ -386,10 +395,10 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowdot_vec_kernel(
 static inline unsigned row_grid(int64_t rows) { return static_cast<unsigned>((rows + kWavesPerBlock - 1) / kWavesPerBlock); }
 
 // lanes-per-row for the 16-byte path: smallest power of two >= d/vec, in [8, 64]
-static inline int pick_lpr(int64_t d, int vec = 4) {
+static inline int pick_lpr(int64_t d, int vec = 4, int max_lpr = 64) {
   const int64_t need = (d + vec - 1) / vec;
   int lpr = 8;
-  while (lpr < need && lpr < 64) lpr <<= 1;
+  while (lpr < need && lpr < max_lpr) lpr <<= 1;
   return lpr;
 }
 
@@ -435,7 +444,7 @@ static void dispatch_segreduce(bool wide_ok, int mode_ext, bool weighted, unsign
                                T* out, int64_t ldo, int32_t* argext, int n_t, int d, int mean, float sign,
                                const int32_t* row_order) {
   if (wide_ok) {
-    switch (pick_lpr(d, WIDE)) {
+    switch (pick_lpr(d, WIDE, ALLSET_SEG_MAX_LPR)) {
       case 8:  launch_segreduce<T, WIDE, 8>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
       case 16: launch_segreduce<T, WIDE, 16>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
       case 32: launch_segreduce<T, WIDE, 32>(mode_ext, weighted, grid, st, rowptr, col, w, x, ldx, out, ldo, argext, n_t, d, mean, sign, row_order); break;
