@@ -234,6 +234,100 @@ def test_setgnn_random_configurations_match_oracle(pma, layers, mlp_layers, hidd
     assert float((xd.grad.cpu().double() - x64.grad).abs().max()) <= g_tol
 
 
+@settings(deadline=None, max_examples=max(12, _N // 2), suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.filter_too_much],
+          derandomize=_DERAND)
+@given(pma=st.booleans(), layers=st.integers(1, 2), mlp_layers=st.integers(1, 3), hidden=st.sampled_from([64, 128, 256, 512]),
+       heads=st.sampled_from([1, 4, 8]), norm=st.sampled_from(["ln", "None"]), input_norm=st.booleans(), bow=st.booleans(),
+       deferred=st.booleans(), twice=st.booleans(), sd=st.integers(0, 10 ** 6))
+def test_setgnn_random_parameter_gradients_match_oracle(pma, layers, mlp_layers, hidden, heads, norm, input_norm, bow, deferred, twice, sd, device):
+    """EVERY parameter gradient of random SetGNN configurations against the float64 oracle, at the widths with their own kernel
+    families (64 / 128 one-pass, 256 / 512 tiled), up to 8 heads, over dense features (their gradient compared as well) or
+    bag-of-words rows (3 % non-zeros, 300 columns: the first conv's projection runs from the non-zeros -- ``dense.sparse_pma_project``,
+    the sparse LayerNorm + Linear of the Deep Sets encoder), eagerly or with all partial sums in one launch
+    (``dense.deferred_param_grads``), optionally twice (the second backward ACCUMULATES into ``.grad``).  Eval mode: no masks to
+    share.  A draw is accepted a priori by the oracle's own stability (``util.oracle_is_smooth_here``), never by the comparison."""
+    from types import SimpleNamespace
+    import cases
+    import util
+    from allset_amd import SetGNN, dense
+    rng = np.random.default_rng(sd)
+    n_v, n_e, k = 48, 19, 5
+    f = 300 if bow else 12
+    ei = cases.random_hypergraph(rng, n_v, n_e, 170, True)
+    if bow:
+        x = (rng.random((n_v, f)) < 0.03).astype(np.float32)
+        x[np.arange(n_v), rng.integers(0, f, n_v)] = 1.0                 # no empty row (LayerNorm of a zero row is all kink)
+    else:
+        x = rng.standard_normal((n_v, f)).astype(np.float32)
+    args = cases.make_args("pma_h1" if pma else "ds_add", f, hidden, k, All_num_layers=layers, MLP_num_layers=mlp_layers,
+                           heads=heads if pma else 1, normalization=norm, deepset_input_norm=input_norm, Classifier_num_layers=2)
+    nrm = np.ones(ei.shape[1], dtype=np.int64)
+    norm_t = torch.from_numpy(nrm)
+    torch.manual_seed(sd)
+    model = SetGNN(args)
+    model.reset_parameters()
+    # (every relu firmly on or off by column -- cases.kinkfree_biases: with ~10^5 relu inputs per evaluation at these widths one in
+    #  a few draws sits within rounding of a kink otherwise, and what this sweep is after is the gradient kernels of every shape)
+    cases.kinkfree_biases(model.state_dict())
+    model.eval()
+    sdict = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    with torch.no_grad():
+        shape = tuple(oracle.setgnn_forward(sdict, args, torch.from_numpy(x), torch.from_numpy(ei), norm_t).shape)
+    G = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    # Two a-priori criteria, both of the float64 ORACLE alone.  The perturbation probe at 1e-5 (absolute on dense features, relative on
+    # bag-of-words rows): an order above the rounding of the DEFAULT arithmetic at these widths (two fp16 planes carry 2^-22 of a row's
+    # scale per product, 512 products per sum; a fresh-seed run found a 512-wide rFF unit within 5e-6 of its relu kink -- strict
+    # arithmetic and the fp32 oracle stayed on one side, fp16 planes crossed).  And the direct one: no relu input closer to zero than
+    # 2e-5 of its row's scale -- these stacks are bias-dominated, a perturbation of x barely reaches their deep layers, and another
+    # fresh-seed run found a pre-activation 9e-8 from its kink that the probe could not move (util.oracle_relu_margin).
+    assume(util.oracle_relu_margin(sdict, args, x, ei, nrm) > 2e-5)
+    assume(util.oracle_is_smooth_here(sdict, args, x, ei, nrm, G, seed=sd, eps=1e-5, eps_bow=1e-5))
+
+    def oracle_run(dtype):
+        sdd = {kk: (v.clone().to(dtype).requires_grad_(True) if v.is_floating_point() and "running" not in kk else v.clone())
+               for kk, v in sdict.items()}
+        xo = torch.from_numpy(x).to(dtype).requires_grad_(True)
+        lo = oracle.setgnn_forward(sdd, args, xo, torch.from_numpy(ei), norm_t)
+        (lo * G.to(dtype)).sum().backward()
+        return lo.detach(), xo.grad, {kk: v.grad for kk, v in sdd.items() if v.is_floating_point() and v.requires_grad}
+    l32, gx32, g32 = oracle_run(torch.float32)
+    l64, gx64, g64 = oracle_run(torch.float64)
+
+    model.to(device)
+    xd = torch.from_numpy(x).to(device)
+    if not bow:
+        xd.requires_grad_(True)
+    data = SimpleNamespace(x=xd, edge_index=torch.from_numpy(ei).to(device), norm=norm_t.to(device))
+    for _ in range(2 if twice else 1):
+        out = model(data)
+        loss = (out * G.to(device)).sum()
+        if deferred:
+            with dense.deferred_param_grads():
+                loss.backward()
+        else:
+            loss.backward()
+    reps = 2.0 if twice else 1.0
+    scale = max(1.0, float(l64.abs().max()))
+    assert float((out.detach().cpu().double() - l64).abs().max()) <= max(2e-4 * scale, 3.0 * float((l32.double() - l64).abs().max()))
+    depth = max(1.0, layers * mlp_layers / 2.0)
+    gscale = max(float(g.abs().max()) for g in g64.values() if g is not None)
+    named = dict(model.named_parameters())
+    for kk, r in g64.items():
+        if r is None:
+            assert named[kk].grad is None or float(named[kk].grad.abs().max()) == 0.0, kk
+            continue
+        got = named[kk].grad
+        assert got is not None, kk
+        s_k = max(float(r.abs().max()), 1e-2 * gscale, 1e-30)
+        tol = max(1e-3 * s_k * depth, 3.0 * float((g32[kk].double() - r).abs().max()))
+        err = float((got.detach().cpu().double() / reps - r).abs().max())
+        assert err <= tol, f"{kk}: {err:.3e} > {tol:.3e} (scale {s_k:.3e})"
+    if not bow:
+        gs = max(1.0, float(gx64.abs().max()))
+        tol = max(1e-3 * gs * depth, 3.0 * float((gx32.double() - gx64).abs().max()))
+        assert float((xd.grad.cpu().double() / reps - gx64).abs().max()) <= tol
+
+
 @settings(**COMMON)
 @given(n=st.integers(1, 900), d=st.sampled_from([1, 3, 4, 7, 8, 32, 60, 64, 100, 128, 200, 256, 260, 512, 1000]), relu_in=st.booleans(),
        bf16=st.booleans(), sd=st.integers(0, 10 ** 6))

@@ -80,6 +80,39 @@ def oracle_is_smooth_here(sd: Dict[str, torch.Tensor], args, x_np, ei_np, norm_n
     return True
 
 
+def oracle_relu_margin(sd: Dict[str, torch.Tensor], args, x_np, ei_np, norm_np) -> float:
+    """The DIRECT form of the a-priori criterion, for evaluations whose activations hardly depend on ``x`` (bias-dominated stacks: a
+    relative 1e-5 on bag-of-words rows arrived as 6e-8 of a row's scale at the third MLP's output -- the perturbation probe of
+    ``oracle_is_smooth_here`` then cannot see a pre-activation that sits 9e-8 from its kink, and a fresh-seed run found exactly
+    that one): the smallest ``|pre-activation| / (largest entry of its row)`` over every non-zero relu input of the float64 ORACLE
+    (exact zeros are structural: relu of a relu).  A caller accepts a draw when this exceeds the arithmetic's rounding by an order
+    (fp32 sums of 512 products: 1e-6; two fp16 planes: 5e-6)."""
+    import torch.nn.functional as F
+    from oracle import allset_oracle as oracle
+    sd64 = {k: (v.detach().double() if v.is_floating_point() else v.detach()) for k, v in sd.items()}
+    norm = torch.from_numpy(norm_np)
+    real, seen = F.relu, []
+
+    def recording(t, *a, **k):
+        seen.append(t.detach())
+        return real(t, *a, **k)
+    F.relu = recording
+    try:
+        with torch.no_grad():
+            oracle.setgnn_forward(sd64, args, torch.from_numpy(x_np).double(), torch.from_numpy(ei_np).clone(),
+                                  norm.double() if norm.is_floating_point() else norm)
+    finally:
+        F.relu = real
+    best = float("inf")
+    for t in seen:
+        t2 = t.reshape(-1, t.shape[-1]).abs()
+        rel = t2 / t2.amax(dim=1, keepdim=True).clamp_min(1e-300)
+        rel = rel[t2 != 0]
+        if rel.numel():
+            best = min(best, float(rel.min()))
+    return best
+
+
 def run_oracle(case: dict, sd: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32):
     """Oracle forward + backward of loss = (logits * G).sum(); returns dict like the fixtures.  ``dtype=torch.float64``: the
     same oracle in double precision (the yardstick where fp32 rounding of the ORACLE itself exceeds the tolerance)."""
