@@ -15,7 +15,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch  # noqa: F401  (must be imported before the CDLL below)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liballset_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 CORE_ABI_VERSION = 1
 
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
@@ -152,6 +152,8 @@ SIGNATURES = {
     "allset_gemm_x6_lnb_partials": [c_int64],
     "allset_gemm_wide": [c_int, _P, c_int64, _P, c_int64, _P, c_float, c_int, _P, _P, _P, c_float, c_uint64, _P, _P, c_int, c_float, c_uint64,
                          _P, _P, c_float, c_int, _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
+    "allset_gemm_wide_sgn_supported": [c_int, c_int64, c_int64],
+    "allset_gemm_wide_sgn": [c_int, _P, c_int64, _P, c_int64, _P, c_float, _P, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_wide_lnb": [c_int, _P, c_int64, _P, c_int64, _P, c_float, _P, _P, c_int64, _P, _P, c_int, c_float, c_uint64, _P, c_int64,
                              _P, c_int64, c_int64, c_int64, c_int64, _P, _P],
     "allset_gemm_f16x3_plane_bytes": [c_int64, c_int64],

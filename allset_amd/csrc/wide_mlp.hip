@@ -158,7 +158,17 @@ struct GxEpi {
   float* stats_out;
   float stats_eps;
   int stats_relu;
+  // backward-data of a Linear whose input was relu(x) (no LayerNorm in between: PMA's rFF): the result is stored where x > 0 and zero
+  // elsewhere -- the relu's backward as the GEMM's epilogue instead of an elementwise pass over [rows, N] (ABI 15; the split-role
+  // kernel's own instantiations: allset_gemm_wide_sgn_supported); or NULL
+  const float* sgn_x;
+  int64_t sgn_ldx;
 };
+
+// out = x > 0 ? out : 0, four columns
+__device__ __forceinline__ float4 gx_sign_mask(float4 o, float4 x) {
+  return make_float4(x.x > 0.f ? o.x : 0.f, x.y > 0.f ? o.y : 0.f, x.z > 0.f ? o.z : 0.f, x.w > 0.f ? o.w : 0.f);
+}
 
 // Per-tile staging context of one thread: the row it stages (128 rows x 4 segments of 8 floats per K step).
 struct GxRow {
@@ -861,7 +871,7 @@ constexpr int kGrThreads = 1024, kGrVThreads = 512, kGrPatchPitch = 68;
 // global load of the vector waves' loop is then UNCONDITIONAL -- behind a (uniform) branch hipcc's wait-count bookkeeping gives up at
 // the join and waits for vmcnt(0), i.e. for the requests issued four steps ahead: the prefetch is gone and every tick costs a memory
 // latency (measured: 4 register sets instead of 2 changed nothing until the `if (r_ti < T)` around the requests went).
-template <int YM, bool ROWSC>
+template <int YM, bool ROWSC, bool SGN = false>
 __global__ __launch_bounds__(kGrThreads) void gemm_f16_roles_kernel(
     const float* __restrict__ A, int64_t lda, GxPro pro, const uint4* __restrict__ planes, GxEpi epi,
     float* __restrict__ out, int64_t ldo, int64_t rows, int N, int K, const uint64_t* __restrict__ seed_base,
@@ -1158,6 +1168,7 @@ __global__ __launch_bounds__(kGrThreads) void gemm_f16_roles_kernel(
       const int n = ntile0 + wc * 64 + 4 * c;                          // this lane's four columns
       const float out_floor = epi.relu_out ? 0.f : -INFINITY;
       const bool has_drop = epi.p_out > 0.f, has_mask = epi.mask_out != nullptr;
+      constexpr bool has_sgn = SGN;                                    // (its own instantiations: the forward's keep their registers)
       const float4 bv = (epi.bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(epi.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 cs = *reinterpret_cast<const float4*>(bscale + n);    // (bscale has n_pad entries: always in range)
       float* patch = sPatch + m * (16 * kGrPatchPitch);
@@ -1169,6 +1180,14 @@ __global__ __launch_bounds__(kGrThreads) void gemm_f16_roles_kernel(
           *reinterpret_cast<float4*>(&patch[fr * kGrPatchPitch + 16 * ct + 4 * fg]) = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[rt][j] = *reinterpret_cast<const float4*>(&patch[(r4 + 4 * j) * kGrPatchPitch + 4 * c]);
+        float4 sx[4];
+        if constexpr (has_sgn) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t row = row0s + rt * 16 + r4 + 4 * j;
+            sx[j] = (row < rows && n < N) ? *reinterpret_cast<const float4*>(epi.sgn_x + row * epi.sgn_ldx + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int rr = wr * 64 + rt * 16 + r4 + 4 * j;
@@ -1181,6 +1200,7 @@ __global__ __launch_bounds__(kGrThreads) void gemm_f16_roles_kernel(
             const float4 k = keep_scale4(seed_out, row * N + n, thr_out, inv_out);
             v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w;
           }
+          if constexpr (has_sgn) v = gx_sign_mask(v, sx[j]);
           o[rt][j] = v;
           if (row < rows && n < N) *reinterpret_cast<float4*>(out + row * ldo + n) = v;
           if (has_mask) {
@@ -1466,12 +1486,22 @@ extern "C" int allset_gemm_x6(const float* A, int64_t lda, const float* mask_y, 
   return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base, stream);
 }
 
+extern "C" int allset_gemm_wide_sgn_supported(int arith, int64_t N, int64_t K) {
+  return (arith == ALLSET_ARITH_FP16X3 && allset_gemm_x6_supported(N, K) && K % (4 * kGxKS) == 0) ? 1 : 0;
+}
+
 static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_t ldy, float p_mask, int relu_in,
                         const float* stats, const float* gamma, const float* beta, float p_in, uint64_t seed_in,
                         const void* planes, GxEpi epi, float* out, int64_t ldo, int64_t rows, int64_t N, int64_t K,
                         const uint64_t* seed_base, void* stream, bool f16, const uint32_t* mask_bits) {
   ALLSET_REQUIRE(mask_bits == nullptr || (mask_y == nullptr && K % 64 == 0), "gemm_wide: the 1-bit mask needs K % 64 == 0 and replaces mask_y");
   ALLSET_REQUIRE(epi.mask_out == nullptr || (N % 64 == 0 && epi.lnb_x == nullptr), "gemm_wide: mask_out needs N % 64 == 0 (and no LayerNorm-backward epilogue)");
+  ALLSET_REQUIRE(epi.sgn_x == nullptr || (epi.lnb_x == nullptr && epi.sgn_ldx >= N && epi.sgn_ldx % 4 == 0 && aligned16(epi.sgn_x)),
+                 "gemm_wide_sgn: the relu's input must have 16-byte aligned rows of at least N floats");
+  if (epi.sgn_x != nullptr && !(f16 && stats == nullptr && allset_gemm_wide_sgn_supported(ALLSET_ARITH_FP16X3, N, K))) {
+    set_error("gemm_wide_sgn: built on the split-role kernel only (fp16x3 planes, K %% 128 == 0, no LayerNorm prologue); N=%lld K=%lld", (long long)N, (long long)K);
+    return ALLSET_ERR_UNSUPPORTED;
+  }
   if (!allset_gemm_x6_supported(N, K)) { set_error("gemm_x6: N=%lld K=%lld not supported (K %% 32 == 0, N %% 4 == 0)", (long long)N, (long long)K); return ALLSET_ERR_UNSUPPORTED; }
   ALLSET_REQUIRE(rows >= 0, "gemm_x6: bad row count");
   ALLSET_REQUIRE(p_in >= 0.f && p_in < 1.f && p_mask >= 0.f && p_mask < 1.f, "gemm_x6: dropout p must be in [0,1)");
@@ -1490,7 +1520,11 @@ static int gemm_x6_impl(const float* A, int64_t lda, const float* mask_y, int64_
 #define GR_LAUNCH2(Y, R) gemm_f16_roles_kernel<Y, R><<<static_cast<unsigned>(blocks), kGrThreads, 0, static_cast<hipStream_t>(stream)>>>( \
       A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base, bscale)
 #define GR_LAUNCH(Y) do { if (stats == nullptr) GR_LAUNCH2(Y, true); else GR_LAUNCH2(Y, false); } while (0)
-    if (mask_bits) GR_LAUNCH(2); else if (mask_y) GR_LAUNCH(1); else GR_LAUNCH(0);
+#define GR_LAUNCH_SGN(Y) gemm_f16_roles_kernel<Y, true, true><<<static_cast<unsigned>(blocks), kGrThreads, 0, static_cast<hipStream_t>(stream)>>>( \
+      A, lda, pro, static_cast<const uint4*>(planes), epi, out, ldo, rows, static_cast<int>(N), static_cast<int>(K), seed_base, bscale)
+    if (epi.sgn_x != nullptr) { if (mask_bits) GR_LAUNCH_SGN(2); else if (mask_y) GR_LAUNCH_SGN(1); else GR_LAUNCH_SGN(0); }
+    else if (mask_bits) GR_LAUNCH(2); else if (mask_y) GR_LAUNCH(1); else GR_LAUNCH(0);
+#undef GR_LAUNCH_SGN
 #undef GR_LAUNCH2
 #undef GR_LAUNCH
     ALLSET_LAUNCH_CHECK();
@@ -1528,6 +1562,17 @@ extern "C" int allset_gemm_wide(int arith, const float* A, int64_t lda, const fl
   GxEpi epi{bias, relu_out, p_out, seed_out, mask_out, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr, stats_out, stats_eps, stats_relu};
   return gemm_x6_impl(A, lda, mask_y, ldy, p_mask, relu_in, stats, gamma, beta, p_in, seed_in, planes, epi, out, ldo, rows, N, K, seed_base,
                       stream, arith == ALLSET_ARITH_FP16X3, mask_bits);
+}
+
+extern "C" int allset_gemm_wide_sgn(int arith, const float* G, int64_t ldg, const float* mask_y, int64_t ldy, const uint32_t* mask_bits,
+                                    float p_mask, const void* planes, const float* x, int64_t ldx, float* gx, int64_t ldgx, int64_t rows,
+                                    int64_t N, int64_t K, const uint64_t* seed_base, void* stream) {
+  clear_error();
+  ALLSET_REQUIRE(arith == ALLSET_ARITH_BF16X6 || arith == ALLSET_ARITH_FP16X3, "gemm_wide_sgn: arith names the planes' format: ALLSET_ARITH_BF16X6 or ALLSET_ARITH_FP16X3");
+  ALLSET_REQUIRE(rows == 0 || x != nullptr, "gemm_wide_sgn: null x");
+  GxEpi epi{nullptr, 0, 0.f, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0.f, 0, nullptr, nullptr, 0.f, 0, x, ldx};
+  return gemm_x6_impl(G, ldg, mask_y, ldy, p_mask, 0, nullptr, nullptr, nullptr, 0.f, 0, planes, epi, gx, ldgx, rows, N, K, seed_base, stream,
+                      arith == ALLSET_ARITH_FP16X3, mask_bits);
 }
 
 extern "C" int allset_gemm_wide_lnb(int arith, const float* G, int64_t ldg, const float* mask_y, int64_t ldy, const uint32_t* mask_bits,

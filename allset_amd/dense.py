@@ -548,19 +548,31 @@ def gemm_x6(A: Tensor, planes: Tensor, N: int, bias: Optional[Tensor] = None, *,
             beta: Optional[Tensor] = None, p_in: float = 0.0, seed_in: int = 0, relu_out: bool = False, p_out: float = 0.0,
             seed_out: int = 0, seed_base: Optional[Tensor] = None, mask_bits: Optional[Tensor] = None,
             mask_out: Optional[Tensor] = None, stats_out: Optional[Tensor] = None, stats_eps: float = 1e-5,
-            stats_relu: bool = False) -> Tensor:
+            stats_relu: bool = False, sgn_x: Optional[Tensor] = None) -> Tensor:
     """``out = epi(pro(A) @ B^T + bias)`` with ``B`` given as :func:`gemm_x6_planes` (include/allset_hip_ext.h allset_gemm_x6 /
     allset_gemm_f16x3: the planes say which).  ``stats_out`` [n, 2] (N == 256): the row statistics of ``relu?(out)`` for the next
-    Linear's LayerNorm prologue, written by the epilogue instead of a :func:`row_stats` pass over the output."""
+    Linear's LayerNorm prologue, written by the epilogue instead of a :func:`row_stats` pass over the output.  ``sgn_x`` [n, N]
+    (backward-data of a Linear behind a bare relu: allset_gemm_wide_sgn): the result where ``sgn_x > 0``, zero elsewhere."""
     planes, f16 = planes.buf, planes.f16
-    dev = require_device(A, planes, bias, mask_y, stats, gamma, beta)
-    _check_f32(A, bias, mask_y, stats, gamma, beta)
+    dev = require_device(A, planes, bias, mask_y, stats, gamma, beta, sgn_x)
+    _check_f32(A, bias, mask_y, stats, gamma, beta, sgn_x)
     A = _rowmajor(A)
     n, K = A.shape
     if mask_y is not None:
         mask_y = _rowmajor(mask_y)
     out = torch.empty((n, N), dtype=torch.float32, device=dev)
     lib = _lib.load()
+    if sgn_x is not None:
+        if (bias is not None or relu_in or stats is not None or p_in or relu_out or p_out or mask_out is not None or stats_out is not None
+                or tuple(sgn_x.shape) != (n, N)):
+            raise _lib.AllSetHipError("gemm_x6(sgn_x=...): a backward-data GEMM takes no prologue / epilogue options besides the masks")
+        sgn_x = _rowmajor(sgn_x)
+        with on_device(dev), _timed("gemm_x6", dev, n * (K * (2 if mask_y is not None else 1) + 2 * N) * 4):
+            check(lib.allset_gemm_wide_sgn(
+                _lib.ARITH_FP16X3 if f16 else _lib.ARITH_BF16X6, ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0,
+                ptr(mask_bits), p_mask, ptr(planes), ptr(sgn_x), _ld(sgn_x), ptr(out), max(N, 1), n, N, K, ptr(seed_base), stream_of(dev)),
+                "allset_gemm_wide_sgn")
+        return out
     with on_device(dev), _timed("gemm_x6", dev, n * (K * (2 if mask_y is not None else 1) + N) * 4):
         check(lib.allset_gemm_wide(
             _lib.ARITH_FP16X3 if f16 else _lib.ARITH_BF16X6, ptr(A), _ld(A), ptr(mask_y), _ld(mask_y) if mask_y is not None else 0,
@@ -1252,11 +1264,15 @@ class _WideNormLinear(torch.autograd.Function):
                                          p_mask=p_out, seed_base=base, mask_bits=mask,
                                          defer_to=(p_g, p_bt) if (dfr and need[1] and need[2]) else None)
                 return gx, dg, db, gw, gb, None, None, None, None, None, None, None
-            gu = gemm_x6(gy, gemm_x6_planes(weight, True), weight.shape[1], None, mask_y=y, p_mask=p_out, mask_bits=mask)
+            # (behind a bare relu -- p_in == 0 there, see wide_linear_supported -- the mask by the sign of x is the GEMM's epilogue)
+            planes_t = gemm_x6_planes(weight, True)
+            sgn = x if (gamma is None and relu_in and planes_t.f16 and x.stride(-1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                        and _lib.load().allset_gemm_wide_sgn_supported(_lib.ARITH_FP16X3, weight.shape[1], weight.shape[0])) else None
+            gu = gemm_x6(gy, planes_t, weight.shape[1], None, mask_y=y, p_mask=p_out, mask_bits=mask, sgn_x=sgn)
             if gamma is not None:
                 gx, dg, db = ln_bwd(gu, x, stats, gamma, relu_in, p_in, seed_in, base, want_gx=need_x,
                                     defer_to=(p_g, p_bt) if (dfr and need[1] and need[2]) else None)
-            elif relu_in:                       # (p_in == 0 here, see wide_linear_supported): mask by the sign of x
+            elif relu_in and sgn is None:       # (rows of x that are not 16-byte aligned: the elementwise pass)
                 gx = torch.empty_like(x)
                 with torch.cuda.device(x.device), _timed("relu_dropout_bwd", x.device, 3 * x.numel() * 4):
                     check(_lib.load().allset_relu_dropout_bwd(ptr(gu), ptr(x.contiguous()), 0.0, ptr(gx), x.numel(),

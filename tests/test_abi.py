@@ -104,7 +104,7 @@ def test_library_exports_every_declared_symbol():
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
     for body in ('#include "allset_hip.h"\nint main(void){return ALLSET_CORE_ABI_VERSION == 1 ? 0 : 1;}\n',        # core alone
-                 '#include "allset_hip_ext.h"\nint main(void){return ALLSET_ABI_VERSION == 14 && ALLSET_CORE_ABI_VERSION == 1 ? 0 : 1;}\n'):
+                 '#include "allset_hip_ext.h"\nint main(void){return ALLSET_ABI_VERSION == 15 && ALLSET_CORE_ABI_VERSION == 1 ? 0 : 1;}\n'):
         src.write_text(body)
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
                         str(tmp_path / "t")], check=True)
@@ -114,7 +114,7 @@ def test_header_compiles_as_plain_c(tmp_path):
 def test_version_and_error_reporting():
     from allset_amd import _lib
     lib = _lib.load()
-    assert lib.allset_version() == _lib.ABI_VERSION == 14
+    assert lib.allset_version() == _lib.ABI_VERSION == 15
     assert lib.allset_core_version() == _lib.CORE_ABI_VERSION == 1
     rc = lib.allset_segreduce_fwd(99, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)
     assert rc == -1 and b"bad reduce" in lib.allset_last_error()

@@ -1867,3 +1867,49 @@ def test_prefetched_plane_images_equal_the_on_demand_ones_and_are_never_stale(de
         with dense.arithmetic("strict"):
             dense.prefetch_wide_planes(ws, with_transposed=True)   # the exact-split arithmetic builds its bf16 planes where they are used
             assert not dense._PlaneStore.entries
+
+
+@pytest.mark.parametrize("n,O,I", [(300, 256, 256), (4391, 512, 512), (129, 384, 256), (1, 128, 512), (3327, 512, 260)])
+@pytest.mark.parametrize("mask", ["none", "y", "bits"])
+def test_wide_backward_data_masks_by_the_sign_of_a_bare_relu_input_in_its_epilogue(n, O, I, mask, device):
+    """ABI 15, allset_gemm_wide_sgn: the backward-data GEMM of a wide Linear behind a bare relu (PMA's rFF, reference
+    layers.py:128-130 with Normalization 'None') zeroes its result where the relu's input was <= 0 -- bit-identical to the GEMM
+    followed by ``allset_relu_dropout_bwd(p = 0)``, for every form of the forward's output mask; refused (and routed to that pair by
+    the autograd node) off the split-role kernel: bf16x6 planes, K % 128 != 0."""
+    from allset_amd import dense, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + O + I)
+    W = (torch.randn(O, I, generator=g) / I ** 0.5).to(device)
+    G = torch.randn(n, O, generator=g).to(device)
+    x = torch.randn(n, I, generator=g).to(device)
+    x[::3, ::5] = 0.0                                                  # exact zeros: masked (x > 0 is the relu's own rule)
+    kw = {}
+    if mask != "none":
+        a = torch.randn(n, O, generator=g).to(device)
+        if mask == "y":
+            kw = dict(mask_y=torch.relu(a), p_mask=0.0)
+        else:
+            if O % 64:
+                pytest.skip("the 1-bit mask needs a multiple of 64 columns")
+            words = torch.zeros(int(lib.allset_fused_linear_mask_words(n, O)), dtype=torch.int32, device=device)
+            pl = dense.gemm_x6_planes(torch.eye(O, device=device), False, f16=True)
+            y = dense.gemm_x6(a, pl, O, None, relu_out=True, mask_out=words)
+            kw = dict(mask_bits=words, p_mask=0.0)
+    ok = bool(lib.allset_gemm_wide_sgn_supported(_lib.ARITH_FP16X3, I, O))
+    assert ok == (O % 128 == 0)
+    assert lib.allset_gemm_wide_sgn_supported(_lib.ARITH_BF16X6, I, O) == 0
+    planes = dense.gemm_x6_planes(W, True, f16=True)
+    ref = dense.gemm_x6(G, planes, I, None, **kw)
+    ref = torch.where(x > 0, ref, torch.zeros_like(ref))
+    if not ok:
+        with pytest.raises(_lib.AllSetHipError):
+            dense.gemm_x6(G, planes, I, None, sgn_x=x, **kw)
+        return
+    got = dense.gemm_x6(G, planes, I, None, sgn_x=x, **kw)
+    assert torch.equal(got, ref)
+    with pytest.raises(_lib.AllSetHipError):                           # strict planes: no such kernel
+        dense.gemm_x6(G, dense.gemm_x6_planes(W, True, f16=False), I, None, sgn_x=x, **kw)
+    # a row pitch of x that is not its width
+    xp = torch.zeros(n, I + 4, device=device)
+    xp[:, :I] = x
+    assert torch.equal(dense.gemm_x6(G, planes, I, None, sgn_x=xp[:, :I], **kw), ref)
