@@ -160,3 +160,43 @@ def test_constant_features_scope_and_the_pre_dropout_contract_on_the_host():
     assert model.V2EConvs[0].prop._raw_input and not model.E2VConvs[0].prop._raw_input      # the conv that consumes data.x, marked by the model
     ds = SetGNN(cases.build_case("rand50_ds_add")["args"])
     assert ds.V2EConvs[0].f_enc._raw_input and not ds.V2EConvs[0].f_dec._raw_input
+
+
+def test_oracle_relu_margin_sees_a_kink_that_the_perturbation_probe_cannot():
+    """tests/util.py::oracle_relu_margin (the direct a-priori criterion of the randomized parameter-gradient sweep): the smallest
+    |relu input| / row scale of the float64 oracle.  A bias moved so that ONE pre-activation of the classifier's hidden layer sits 1e-9
+    from zero is reported as such, whatever else the network does; kink-free biases push the conv stacks' margin up by orders."""
+    import cases
+    import util
+    from allset_amd import SetGNN
+    from oracle import allset_oracle as oracle
+    rng = np.random.default_rng(3)
+    n_v, f, k = 30, 12, 4
+    ei = cases.random_hypergraph(rng, n_v, 11, 90, True)
+    x = rng.standard_normal((n_v, f)).astype(np.float32)
+    nrm = np.ones(ei.shape[1], dtype=np.int64)
+    args = cases.make_args("ds_add", f, 64, k, Classifier_num_layers=2)
+    torch.manual_seed(3)
+    model = SetGNN(args)
+    model.reset_parameters()
+    sd = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    m0 = util.oracle_relu_margin(sd, args, x, ei, nrm)
+    assert 0.0 < m0 < 1e-2                                      # ~10^4 relu inputs: some within a percent of a row's scale of zero
+    sd_free = cases.kinkfree_biases({kk: v.clone() for kk, v in sd.items()})
+    # the classifier's hidden relu is the one site kinkfree_biases leaves alone: measure the conv stacks by moving it out of the way too
+    sd_free["classifier.lins.0.bias"] += 50.0
+    assert util.oracle_relu_margin(sd_free, args, x, ei, nrm) > 30.0 * m0
+    # one classifier pre-activation placed 1e-9 above zero
+    real, seen = torch.nn.functional.relu, []
+    torch.nn.functional.relu = lambda t, *a, **kw: (seen.append(t.detach()), real(t, *a, **kw))[1]
+    try:
+        sd64 = {kk: (v.double() if v.is_floating_point() else v) for kk, v in sd_free.items()}
+        oracle.setgnn_forward(sd64, args, torch.from_numpy(x).double(), torch.from_numpy(ei), torch.from_numpy(nrm))
+    finally:
+        torch.nn.functional.relu = real
+    pre = [t for t in seen if t.shape[-1] == args.Classifier_hidden][-1]
+    sd_kink = {kk: v.clone() for kk, v in sd_free.items()}
+    sd_kink["classifier.lins.0.bias"] = sd_kink["classifier.lins.0.bias"].double()
+    sd_kink["classifier.lins.0.bias"][5] -= pre[7, 5] - 1e-9
+    m = util.oracle_relu_margin(sd_kink, args, x, ei, nrm)
+    assert m < 1e-9
